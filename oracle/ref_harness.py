@@ -1,0 +1,146 @@
+"""Import the REAL reference (/root/reference) under documented stand-ins.
+
+TEST INFRASTRUCTURE ONLY, and only usable in the build container: the GPU box
+has no /root/reference, so nothing under ``-m gpu``, ``smoke()`` or ``bench.py``
+may call this module.  ``tests/golden/make_golden.py`` uses it to produce the
+committed fixtures; ``tests/test_oracle_vs_reference.py`` uses it (skipped when
+the reference is absent) to pin the oracle bit-for-bit.
+
+Stand-ins injected through ``sys.modules``:
+  * ``lap``  -> ``oracle.lap`` (lapx 0.9.4 is not installed; PARITY UNPINNED);
+  * ``cv2``  -> constants touched at import time + ``resize`` / ``cvtColor``
+               from ``oracle.crops`` (opencv is not installed; PARITY UNPINNED);
+  * ``gdown``, ``filterpy``, ``yacs``, ``ftfy`` -> empty modules.
+The reference tracker/Kalman/association classes themselves run unmodified.
+"""
+from __future__ import annotations
+
+import importlib.util
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+
+REFERENCE_ROOT = Path("/root/reference")
+
+
+def reference_available() -> bool:
+    return (REFERENCE_ROOT / "boxmot" / "trackers" / "bbox" / "botsort" / "botsort.py").exists()
+
+
+def _cv2_stub():
+    from oracle import crops
+
+    cv2 = types.ModuleType("cv2")
+    cv2.INTER_LINEAR = 1
+    cv2.COLOR_BGR2RGB = 4
+    cv2.COLOR_BGR2GRAY = 6
+    cv2.MOTION_TRANSLATION = 0
+    cv2.MOTION_EUCLIDEAN = 1
+    cv2.MOTION_AFFINE = 2
+    cv2.MOTION_HOMOGRAPHY = 3
+    cv2.TERM_CRITERIA_EPS = 2
+    cv2.TERM_CRITERIA_COUNT = 1
+    cv2.BORDER_CONSTANT = 0
+
+    def resize(src, dsize, interpolation=1, **_):
+        assert interpolation == cv2.INTER_LINEAR
+        return crops.cv2_resize_linear_u8(src, dsize)
+
+    def cvtColor(src, code):
+        assert code == cv2.COLOR_BGR2RGB
+        return np.ascontiguousarray(src[:, :, ::-1])
+
+    cv2.resize = resize
+    cv2.cvtColor = cvtColor
+    return cv2
+
+
+def install_standins():
+    if "lap" not in sys.modules or not hasattr(sys.modules["lap"], "_oracle_standin"):
+        from oracle import lap as oracle_lap
+
+        lap = types.ModuleType("lap")
+        lap.lapjv = oracle_lap.lapjv
+        lap._oracle_standin = True
+        sys.modules["lap"] = lap
+    if "cv2" not in sys.modules:
+        sys.modules["cv2"] = _cv2_stub()
+    for name in ("gdown", "filterpy", "yacs", "ftfy"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    if str(REFERENCE_ROOT) not in sys.path:
+        sys.path.insert(0, str(REFERENCE_ROOT))
+
+
+def load_botsort():
+    """Return the reference BotSort class (imported from /root/reference)."""
+    install_standins()
+    from boxmot.trackers.bbox.botsort.botsort import BotSort
+
+    return BotSort
+
+
+def load_osnet_module():
+    """Load boxmot/reid/backbones/osnet.py by path (``boxmot.reid`` itself cannot import)."""
+    install_standins()
+    path = REFERENCE_ROOT / "boxmot" / "reid" / "backbones" / "osnet.py"
+    spec = importlib.util.spec_from_file_location("_ref_osnet", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+class RefReID:
+    """Reference ``BaseModelBackend.get_crops/get_features`` bound to a reference OSNet.
+
+    ``boxmot.reid.backends.base_backend`` cannot be imported offline (it pulls the
+    whole ReID registry incl. CLIP/torchvision), so its two methods are executed
+    from source text against this minimal object: the crop loop and the feature
+    normalisation are the reference's own statements.
+    """
+
+    def __init__(self, model, input_shape=(256, 128)):
+        import torch
+
+        install_standins()
+        src = (REFERENCE_ROOT / "boxmot" / "reid" / "backends" / "base_backend.py").read_text()
+        import ast
+        import cv2
+
+        tree = ast.parse(src)
+        cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "BaseModelBackend")
+        keep = {"get_crops", "get_features", "_is_obb_box", "_boxes_to_xyxy", "inference_preprocess",
+                "inference_postprocess", "to_numpy"}
+        cls.body = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in keep]
+        cls.bases = []
+        module = ast.Module(body=[cls], type_ignores=[])
+        ns = {"np": np, "torch": torch, "cv2": cv2}
+        exec(compile(module, "base_backend_subset", "exec"), ns)
+        Backend = ns["BaseModelBackend"]
+        pp_path = REFERENCE_ROOT / "boxmot" / "reid" / "core" / "preprocessing.py"
+        spec = importlib.util.spec_from_file_location("_ref_reid_preprocessing", pp_path)
+        pp = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(pp)
+        get_preprocess_fn = pp.get_preprocess_fn
+
+        class _Bound(Backend):
+            def forward(self_inner, im_batch):
+                return model(im_batch)
+
+        b = _Bound.__new__(_Bound)
+        b.device = torch.device("cpu")
+        b.half = False
+        b.nhwc = False
+        b.input_shape = input_shape
+        b.preprocess_fn = get_preprocess_fn(None)
+        b.mean_array = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+        b.std_array = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+        self._b = b
+        self.model = model
+
+    def get_features(self, xyxys, img):
+        return self._b.get_features(xyxys, img)
+
+    def get_crops(self, xyxys, img):
+        return self._b.get_crops(xyxys, img)
