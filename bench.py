@@ -1,0 +1,219 @@
+#!/usr/bin/env python
+"""bench.py -- tracker frames/sec for BASELINE.json config 2:
+BoT-SORT + OSNet-x0.25 ReID inside update, 64 detections x 256 live tracks, 1080p frames.
+
+  python bench.py --gpus N --steps K --warmup W [--streams S] [--mode embs|reid] [--reid-mode 0|1]
+
+One "step" = one pass of the hot path over one batch = every one of the S streams of this GPU
+advances by one frame (ReID crop/resize/normalise + OSNet + cost matrices + assignment + Kalman +
+bookkeeping, all on the device).  Inputs (detections of every frame, one static random frame per
+stream -- the reference harness also reuses one image, tests/performance/benchmark_fps.py:186) are
+resident in HBM before the timed region.  value = total frames of all streams on all GPUs / wall
+time (max over ranks), i.e. whole-job frames/sec; scaling is weak (S streams per GPU).
+
+N > 1: launched by torch.distributed.run, one rank per GPU; streams are sharded by rank with no
+data-path collective; the per-frame result rows are gathered to rank 0 once after the timed loop
+(RCCL all_gather of a few hundred KB).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+N_DETS, N_TRACKS, WIDTH, HEIGHT, EMB_DIM = 64, 256, 1920, 1080, 512
+FLOP_PER_CROP = 2 * 82_314_880          # OSNet x0.25 forward, BASELINE.md section 2
+PEAK_TFLOPS = {0: 157.3, 1: 2500.0}     # dense MFMA peak of the dtype the ReID kernels compute in (fp32 / fp16)
+DTYPE = {0: "f32", 1: "f16"}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--streams", type=int, default=64, help="streams per GPU")
+    ap.add_argument("--mode", choices=("reid", "embs"), default="reid",
+                    help="reid: ReID inside update (headline, M2); embs: embeddings supplied (tracker math only, M1)")
+    ap.add_argument("--reid-mode", type=int, default=int(os.environ.get("BOXMOT_REID_MODE", "0")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=10)
+    return ap.parse_args()
+
+
+def cpu_baseline(sd, mode, n_frames):
+    """The oracle (a port of the reference Python path) timed on this box's host cores:
+    stream 0 of the same workload, 3 confirmation frames untimed, then n_frames timed."""
+    import torch
+
+    from boxmot_amd.scenario import Scenario
+    from boxmot_amd.tracker_zoo import BOTSORT_YAML_DEFAULTS
+    from oracle.botsort import BotSortOracle
+    from oracle.osnet import OracleReID
+
+    kw = {k: v for k, v in BOTSORT_YAML_DEFAULTS.items() if k not in ("use_cmc", "cmc_method")}
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sc = Scenario(N_DETS, N_TRACKS, WIDTH, HEIGHT, EMB_DIM, stream=0, random_image=True)
+    orc = BotSortOracle(reid=OracleReID(sd) if mode == "reid" else None, **kw)
+    rows = []
+    t_timed = 0.0
+    for t in range(3 + n_frames):
+        dets, embs = sc.frame(t)
+        t0 = time.perf_counter()
+        r = orc.update(dets, sc.image, None if mode == "reid" else embs)
+        if t >= 3:
+            t_timed += time.perf_counter() - t0
+        rows.append(r)
+    return dict(value=n_frames / t_timed, unit="frames/s", cores=cores, kind="port",
+                sample=f"oracle (NumPy/SciPy BoT-SORT + torch-CPU OSNet-x0.25, {cores} threads), stream 0, "
+                       f"{n_frames} steady-state frames after 3 confirmation frames, mode={mode}"), rows
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    import __graft_entry__ as g
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if rank == 0:
+        g.build()
+    if world > 1:
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl")
+        dist.barrier()
+    else:
+        torch.cuda.set_device(0)
+    if rank != 0:
+        g.build()
+    dev = torch.device("cuda", local if world > 1 else 0)
+
+    from boxmot_amd.reid_weights import random_osnet_state_dict
+    from boxmot_amd.scenario import Scenario
+    from boxmot_amd.streams import MultiStreamBotSort
+    from boxmot_amd.tracker_zoo import BOTSORT_YAML_DEFAULTS
+
+    S, K, W = a.streams, a.steps, a.warmup
+    T = W + K
+    kw = {k: v for k, v in BOTSORT_YAML_DEFAULTS.items() if k not in ("use_cmc", "cmc_method")}
+    sd = random_osnet_state_dict("osnet_x0_25", seed=0)
+    nd = N_TRACKS                       # the 3 confirmation frames show every object
+    ms = MultiStreamBotSort(S, max_tracks=2 * N_TRACKS, max_dets=nd, emb_dim=EMB_DIM,
+                            reid_weights=sd if a.mode == "reid" else None, **kw)
+    if a.mode == "reid":
+        ms.set_reid_mode(a.reid_mode)
+
+    # ---- synthetic inputs, resident in HBM before timing ----
+    dets_h = np.zeros((T, S, nd, 6), dtype=np.float32)
+    cnt_h = np.zeros((T, S), dtype=np.int32)
+    embs_h = np.zeros((T, S, nd, EMB_DIM), dtype=np.float32) if a.mode == "embs" else None
+    frames_h = np.zeros((S, HEIGHT, WIDTH, 3), dtype=np.uint8)
+    for s in range(S):
+        sc = Scenario(N_DETS, N_TRACKS, WIDTH, HEIGHT, EMB_DIM, stream=rank * S + s, random_image=a.mode == "reid")
+        frames_h[s] = sc.image
+        for t in range(T):
+            d, e = sc.frame(t)
+            dets_h[t, s, : len(d)] = d
+            cnt_h[t, s] = len(d)
+            if embs_h is not None:
+                embs_h[t, s, : len(d)] = e
+    d_dets = torch.from_numpy(dets_h).to(dev)
+    d_cnt = torch.from_numpy(cnt_h).to(dev)
+    d_embs = torch.from_numpy(embs_h).to(dev) if embs_h is not None else None
+    d_frames = torch.from_numpy(frames_h).to(dev)
+    d_ptrs = torch.tensor([d_frames[s].data_ptr() for s in range(S)], dtype=torch.int64, device=dev)
+    d_out = torch.zeros((T, S, nd, 8), dtype=torch.float32, device=dev)
+    d_out_n = torch.zeros((T, S), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+
+    def step(t):
+        ms.step_device(d_dets[t].data_ptr(), d_cnt[t].data_ptr(),
+                       d_embs[t].data_ptr() if d_embs is not None else None,
+                       d_ptrs.data_ptr() if a.mode == "reid" else None, HEIGHT, WIDTH,
+                       d_out[t].data_ptr(), d_out_n[t].data_ptr())
+
+    for t in range(W):
+        step(t)
+    ms.synchronize()
+    ms.reid_kernel_ms()                 # drop warm-up timings
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    ms.timer_start()
+    t0 = time.perf_counter()
+    for t in range(W, T):
+        step(t)
+    dev_ms = ms.timer_stop_ms()
+    ms.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    status = ms.status()
+    assert (status == 0).all(), f"tracker status {status}"
+    reid_ms, reid_launches = ms.reid_kernel_ms()
+
+    # ---- result gather (the only collective of the path), after the timed loop ----
+    out_h, out_n_h = d_out.cpu().numpy(), d_out_n.cpu().numpy()
+    if world > 1:
+        from boxmot_amd.streams import gather_results
+        gather_results(d_out[W:].transpose(0, 1).contiguous(), d_out_n[W:].transpose(0, 1).contiguous(), dst=0)
+
+    if rank == 0:
+        total_frames = world * S * K
+        fps = total_frames / elapsed
+        n_first = int((dets_h[W:, :, :, 4] > kw["track_high_thresh"]).sum())   # crops of this rank in the timed steps
+        res = {
+            "metric": "tracker frames/sec (64 dets x 256 tracks, 1080p)", "value": fps, "unit": "frames/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1000.0 * elapsed / K,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": DTYPE[a.reid_mode] if a.mode == "reid" else "f64", "data": "synthetic",
+            "config": {"workload": "BoT-SORT + OSNet_x0_25 ReID, 64 dets x 256 tracks, 1080p"
+                                   if a.mode == "reid" else "BoT-SORT tracker math only (embeddings supplied), 64 dets x 256 tracks",
+                       "streams_per_gpu": S, "mode": "M2 reid-in-update" if a.mode == "reid" else "M1 embs-supplied",
+                       "reid_kernels": {0: "per-layer fp32 (v1)", 1: "fused fp16 MFMA"}[a.reid_mode] if a.mode == "reid" else None,
+                       "tracker_params": "botsort.yaml defaults, use_cmc=False", "weights": "random-init OSNet-x0.25 (seed 0)",
+                       "device_ms_timed_region": dev_ms},
+        }
+        if a.mode == "reid" and reid_ms > 0:
+            tflops = n_first * FLOP_PER_CROP / (reid_ms * 1e-3) / 1e12
+            res["roofline"] = {"bound": "mfma", "achieved": tflops, "peak": PEAK_TFLOPS[a.reid_mode], "unit": "TFLOP/s",
+                               "frac": tflops / PEAK_TFLOPS[a.reid_mode], "traffic": None,
+                               "kernel": "OSNet-x0.25 forward (ReID) region, HIP events on the launch stream",
+                               "launch_ms": reid_ms / max(reid_launches, 1), "crops_per_launch": n_first / max(reid_launches, 1)}
+        else:
+            bytes_per_frame = 1.68e6     # tracker-math algorithmic bytes per frame
+            gbs = total_frames / world * bytes_per_frame / (dev_ms * 1e-3) / 1e9
+            res["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
+                               "traffic": None, "kernel": "botsort_step_kernel"}
+        if not a.no_cpu_baseline:
+            cb, rows = cpu_baseline(sd, a.mode, a.cpu_frames)
+            res["cpu_baseline"] = cb
+            # parity gate printed with the row: ids / det_ind / row order of stream 0 vs the oracle
+            ok = True
+            for t in range(min(len(rows), T)):
+                got = out_h[t, 0, : out_n_h[t, 0]]
+                ok &= got.shape == rows[t].shape and bool(np.array_equal(got[:, 4:], rows[t][:, 4:]))
+            res["config"]["parity_ids_exact_vs_oracle_stream0"] = bool(ok)
+        print(json.dumps(res))
+    ms.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,27 @@
+"""boxmot_amd -- MI355X-native BoT-SORT update path (HIP kernels behind a C ABI).
+
+Public surface (mirrors the reference's for this path):
+  BotSort, HipReID, TrackResults, create_tracker, MultiStreamBotSort.
+"""
+__version__ = "0.1.0"
+
+__all__ = ["BotSort", "HipReID", "TrackResults", "create_tracker", "MultiStreamBotSort"]
+
+
+def __getattr__(name):
+    if name == "BotSort":
+        from boxmot_amd.botsort import BotSort
+        return BotSort
+    if name == "HipReID":
+        from boxmot_amd.reid import HipReID
+        return HipReID
+    if name == "TrackResults":
+        from boxmot_amd.track_results import TrackResults
+        return TrackResults
+    if name == "create_tracker":
+        from boxmot_amd.tracker_zoo import create_tracker
+        return create_tracker
+    if name == "MultiStreamBotSort":
+        from boxmot_amd.streams import MultiStreamBotSort
+        return MultiStreamBotSort
+    raise AttributeError(name)

@@ -1,0 +1,118 @@
+"""ctypes binding of ``libboxmot_hip.so`` (include/boxmot_hip.h).
+
+Mirrors the reference's Python<->C shim for native trackers
+(boxmot/native/trackers/botsort.py:94-146 for the config struct and signatures,
+boxmot/native/trackers/_common.py:158-221 for the call convention).  The
+library is built in-tree by ``__graft_entry__.build()``; importing it when it is
+missing, or calling into it on a machine without a HIP device, fails loudly --
+there is no Python/CPU fallback for the tracker math.
+"""
+from __future__ import annotations
+
+import ctypes
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "libboxmot_hip.so"
+
+c_float_p = ctypes.POINTER(ctypes.c_float)
+c_int_p = ctypes.POINTER(ctypes.c_int)
+c_double_p = ctypes.POINTER(ctypes.c_double)
+
+
+class BotSortConfig(ctypes.Structure):
+    """``BoxMOTHipBotSortConfig`` (include/boxmot_hip.h)."""
+
+    _fields_ = [
+        ("track_high_thresh", ctypes.c_double),
+        ("track_low_thresh", ctypes.c_double),
+        ("new_track_thresh", ctypes.c_double),
+        ("track_buffer", ctypes.c_int),
+        ("match_thresh", ctypes.c_double),
+        ("proximity_thresh", ctypes.c_double),
+        ("appearance_thresh", ctypes.c_double),
+        ("cmc_method", ctypes.c_char_p),
+        ("frame_rate", ctypes.c_int),
+        ("fuse_first_associate", ctypes.c_int),
+        ("with_reid", ctypes.c_int),
+        ("max_obs", ctypes.c_int),
+        ("reid_model_path", ctypes.c_char_p),
+        ("reid_preprocess", ctypes.c_char_p),
+        ("second_match_thresh", ctypes.c_double),
+        ("unconfirmed_match_thresh", ctypes.c_double),
+        ("unconfirmed_emb_scale", ctypes.c_double),
+        ("removed_stracks_buffer", ctypes.c_int),
+        ("n_streams", ctypes.c_int),
+        ("max_tracks", ctypes.c_int),
+        ("max_dets", ctypes.c_int),
+        ("emb_dim", ctypes.c_int),
+        ("n_class_lists", ctypes.c_int),
+    ]
+
+
+# every symbol include/boxmot_hip.h declares: (name, restype, argtypes)
+_VP = ctypes.c_void_p
+_I = ctypes.c_int
+SIGNATURES = {
+    "boxmot_hip_botsort_default_config": (None, [ctypes.POINTER(BotSortConfig)]),
+    "boxmot_hip_botsort_create": (_VP, [ctypes.POINTER(BotSortConfig)]),
+    "boxmot_hip_botsort_destroy": (None, [_VP]),
+    "boxmot_hip_botsort_reset": (_I, [_VP]),
+    "boxmot_hip_botsort_update": (_I, [_VP, _VP, _I, _I, _VP, _I, _I, _VP, _I, _I, _I, _VP, _I, _I, c_int_p, c_int_p]),
+    "boxmot_hip_botsort_update_stream": (_I, [_VP, _I, _I, _I, _VP, _I, _I, _VP, _I, _I, _VP, _I, _I, _I, _VP, _I, _I,
+                                              c_int_p, c_int_p]),
+    "boxmot_hip_botsort_update_batch": (_I, [_VP, _I, _VP, _VP, _VP, _I, _VP, _I, _I, _I, _VP, _I, _VP]),
+    "boxmot_hip_botsort_step_device": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP]),
+    "boxmot_hip_botsort_synchronize": (_I, [_VP]),
+    "boxmot_hip_botsort_stream": (_VP, [_VP]),
+    "boxmot_hip_botsort_timer_start": (_I, [_VP]),
+    "boxmot_hip_botsort_timer_stop_ms": (_I, [_VP, c_double_p]),
+    "boxmot_hip_botsort_reid_kernel_ms": (_I, [_VP, c_double_p, c_int_p]),
+    "boxmot_hip_botsort_status": (_I, [_VP, _VP, _I]),
+    "boxmot_hip_botsort_set_reid_blob": (_I, [_VP, _VP, ctypes.c_long]),
+    "boxmot_hip_botsort_set_reid_mode": (_I, [_VP, _I]),
+    "boxmot_hip_botsort_last_reid_time_ms": (_I, [_VP, c_double_p]),
+    "boxmot_hip_botsort_last_reid_preprocess_time_ms": (_I, [_VP, c_double_p]),
+    "boxmot_hip_botsort_last_reid_process_time_ms": (_I, [_VP, c_double_p]),
+    "boxmot_hip_botsort_last_reid_postprocess_time_ms": (_I, [_VP, c_double_p]),
+    "boxmot_hip_botsort_last_track_time_ms": (_I, [_VP, c_double_p]),
+    "boxmot_hip_botsort_state_dump": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP, _VP, c_int_p, c_int_p, c_int_p]),
+    "boxmot_hip_reid_create": (_VP, [ctypes.c_char_p, _VP, ctypes.c_long, _I]),
+    "boxmot_hip_reid_destroy": (None, [_VP]),
+    "boxmot_hip_reid_feature_dim": (_I, [_VP]),
+    "boxmot_hip_reid_set_mode": (_I, [_VP, _I]),
+    "boxmot_hip_reid_compute_features": (_I, [_VP, _VP, _I, _I, _I, _VP, _I, _I, _VP, _I]),
+    "boxmot_hip_reid_preprocess": (_I, [_VP, _VP, _I, _I, _I, _VP, _I, _I, _VP]),
+    "boxmot_hip_last_error": (ctypes.c_char_p, []),
+    "boxmot_hip_device_count": (_I, []),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library and attach signatures; raises if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()'). boxmot_amd has no CPU fallback."
+        )
+    lib = ctypes.CDLL(str(LIB_PATH))
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    msg = load().boxmot_hip_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(ok: int) -> None:
+    if ok == 0:
+        raise RuntimeError(last_error())

@@ -1,0 +1,210 @@
+"""BoT-SORT on MI355X behind the reference plugin surface.
+
+``BotSort(...)`` takes the reference constructor's keyword arguments
+(boxmot/trackers/bbox/botsort/botsort.py:66-86; YAML keys of
+boxmot/configs/trackers/botsort.yaml) and ``update(dets, img, embs=None)``
+returns the reference's rows; every per-frame computation runs in HIP kernels
+through the C ABI (include/boxmot_hip.h).  Mirrors the shape of the reference's
+ctypes wrapper for its native backend (boxmot/native/trackers/botsort.py:94-274).
+
+Not implemented, and rejected loudly rather than approximated: camera-motion
+compensation (construct with ``use_cmc=False``), OBB detections, masks.
+"""
+from __future__ import annotations
+
+import ctypes
+from types import SimpleNamespace
+from typing import Any
+
+import numpy as np
+
+from boxmot_amd import _lib
+from boxmot_amd.basetracker import OUT_COLS, BaseTracker
+
+TRACK_STATE_NAMES = {0: "New", 1: "Tracked", 2: "Lost", 3: "LongLost", 4: "Removed"}
+
+
+class BotSort(BaseTracker):
+    supports_obb = False
+
+    def __init__(
+        self,
+        reid_model: Any | None = None,
+        track_high_thresh: float = 0.5,
+        track_low_thresh: float = 0.1,
+        new_track_thresh: float = 0.6,
+        track_buffer: int = 30,
+        match_thresh: float = 0.8,
+        proximity_thresh: float = 0.5,
+        appearance_thresh: float = 0.25,
+        use_cmc: bool = True,
+        cmc_method: str = "ecc",
+        frame_rate: int = 30,
+        fuse_first_associate: bool = False,
+        with_reid: bool = True,
+        second_match_thresh: float = 0.5,
+        unconfirmed_match_thresh: float = 0.7,
+        unconfirmed_emb_scale: float = 2.0,
+        removed_stracks_buffer: int = 100,
+        # capacity of the device-resident track table (not reference parameters)
+        max_tracks: int = 1024,
+        max_dets: int = 256,
+        emb_dim: int | None = None,
+        **kwargs: Any,
+    ):
+        super().__init__(_tracker_name="BotSort", **kwargs)
+        if use_cmc:
+            raise NotImplementedError(
+                "boxmot_amd.BotSort: camera-motion compensation is not implemented on the HIP path; "
+                "construct with use_cmc=False (the reference default is use_cmc=True, cmc_method='ecc')."
+            )
+        self.track_high_thresh = track_high_thresh
+        self.track_low_thresh = track_low_thresh
+        self.new_track_thresh = new_track_thresh
+        self.match_thresh = match_thresh
+        self.buffer_size = int(frame_rate / 30.0 * track_buffer)
+        self.max_time_lost = self.buffer_size
+        self.proximity_thresh = proximity_thresh
+        self.appearance_thresh = appearance_thresh
+        self.second_match_thresh = second_match_thresh
+        self.unconfirmed_match_thresh = unconfirmed_match_thresh
+        self.unconfirmed_emb_scale = unconfirmed_emb_scale
+        self.with_reid = with_reid
+        self.model = reid_model if with_reid else None
+        self.cmc = None
+        self.fuse_first_associate = fuse_first_associate
+        self._lib = _lib.load()
+        self._emb_dim = emb_dim or getattr(self.model, "feature_dim", None) or 512
+        self._max_dets = max_dets
+        cfg = _lib.BotSortConfig()
+        self._lib.boxmot_hip_botsort_default_config(ctypes.byref(cfg))
+        cfg.track_high_thresh = track_high_thresh
+        cfg.track_low_thresh = track_low_thresh
+        cfg.new_track_thresh = new_track_thresh
+        cfg.track_buffer = track_buffer
+        cfg.match_thresh = match_thresh
+        cfg.proximity_thresh = proximity_thresh
+        cfg.appearance_thresh = appearance_thresh
+        cfg.cmc_method = None
+        cfg.frame_rate = frame_rate
+        cfg.fuse_first_associate = int(bool(fuse_first_associate))
+        cfg.with_reid = int(bool(with_reid))
+        cfg.max_obs = self.max_obs
+        cfg.second_match_thresh = second_match_thresh
+        cfg.unconfirmed_match_thresh = unconfirmed_match_thresh
+        cfg.unconfirmed_emb_scale = unconfirmed_emb_scale
+        cfg.removed_stracks_buffer = removed_stracks_buffer
+        cfg.n_streams = 1
+        cfg.max_tracks = max_tracks
+        cfg.max_dets = max_dets
+        cfg.emb_dim = self._emb_dim
+        cfg.n_class_lists = self.nr_classes if self.per_class else 1
+        self._cfg = cfg
+        self._handle = self._lib.boxmot_hip_botsort_create(ctypes.byref(cfg))
+        if not self._handle:
+            raise RuntimeError(_lib.last_error())
+        self._max_tracks = max_tracks
+
+    # ------------------------------------------------------------------ update
+    def _update_impl(self, dets, img, embs=None, masks=None, class_list: int = 0) -> np.ndarray:
+        self.check_inputs(dets, img, embs)
+        det_arr = np.ascontiguousarray(dets, dtype=np.float32)
+        n = int(det_arr.shape[0])
+        feats = None
+        if self.with_reid:
+            if embs is not None:
+                feats = np.ascontiguousarray(embs, dtype=np.float32)
+            else:
+                # same call the reference makes (botsort.py:191-192): boxes of the high-confidence rows
+                first = det_arr[:, 4].astype(np.float64) > self.track_high_thresh
+                feats = np.zeros((n, self._emb_dim), dtype=np.float32)
+                if first.any():
+                    feats[first] = self.model.get_features(det_arr[first, :4], img)
+            if n and feats.shape[1] != self._emb_dim:
+                raise ValueError(f"embedding width {feats.shape[1]} != emb_dim {self._emb_dim}")
+        img_arr = np.ascontiguousarray(img)
+        out = np.empty((max(n, 1), 9), dtype=np.float32)
+        out_rows = ctypes.c_int(0)
+        out_is_obb = ctypes.c_int(0)
+        ok = self._lib.boxmot_hip_botsort_update_stream(
+            self._handle, 0, int(class_list), int(self.frame_count) if self.per_class else -1,
+            det_arr.ctypes.data if n else None, n, 6,
+            feats.ctypes.data if (feats is not None and n) else None, n if feats is not None else 0,
+            self._emb_dim if feats is not None else 0,
+            img_arr.ctypes.data, int(img_arr.shape[0]), int(img_arr.shape[1]),
+            int(img_arr.shape[2]) if img_arr.ndim == 3 else 1,
+            out.ctypes.data, int(out.shape[0]), 9, ctypes.byref(out_rows), ctypes.byref(out_is_obb),
+        )
+        _lib.check(ok)
+        self.frame_count += 1
+        return out[: out_rows.value, :OUT_COLS].copy()
+
+    def reset(self) -> None:
+        _lib.check(self._lib.boxmot_hip_botsort_reset(self._handle))
+        self.frame_count = 0
+        self._first_frame_processed = False
+        self._first_dets_processed = False
+
+    # ------------------------------------------------- introspection (read-only)
+    def state_dump(self, which: int = 0, class_list: int = 0) -> dict:
+        """Copy the live tracks back from the device (parity tests / debugging)."""
+        cap, dim = self._max_tracks, self._emb_dim
+        ints = np.zeros((cap, 6), dtype=np.int32)
+        kf = np.zeros((cap, 72), dtype=np.float64)
+        smooth = np.zeros((cap, dim), dtype=np.float32)
+        misc = np.zeros((cap, 3), dtype=np.float32)
+        rows, fc, ic = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(self._lib.boxmot_hip_botsort_state_dump(
+            self._handle, 0, which, class_list, ints.ctypes.data, kf.ctypes.data, smooth.ctypes.data, misc.ctypes.data,
+            ctypes.byref(rows), ctypes.byref(fc), ctypes.byref(ic)))
+        n = rows.value
+        return dict(n=n, ints=ints[:n], kf=kf[:n], smooth=smooth[:n], misc=misc[:n], frame_count=fc.value,
+                    id_count=ic.value)
+
+    def _track_views(self, which: int):
+        d = self.state_dump(which)
+        out = []
+        for r in range(d["n"]):
+            i = d["ints"][r]
+            mean = d["kf"][r, :8].copy()
+            xyxy = np.array([mean[0] - mean[2] / 2, mean[1] - mean[3] / 2, mean[0] + mean[2] / 2, mean[1] + mean[3] / 2])
+            out.append(SimpleNamespace(
+                id=int(i[0]), state=int(i[1]), is_activated=bool(i[2]), frame_id=int(i[3]), start_frame=int(i[4]),
+                tracklet_len=int(i[5]), mean=mean, covariance=d["kf"][r, 8:].reshape(8, 8).copy(), xyxy=xyxy,
+                smooth_feat=d["smooth"][r].copy(), conf=float(d["misc"][r, 0]), cls=float(d["misc"][r, 1]),
+                det_ind=float(d["misc"][r, 2])))
+        return out
+
+    @property
+    def active_tracks(self):
+        return self._track_views(0)
+
+    @property
+    def lost_stracks(self):
+        return self._track_views(1)
+
+    @property
+    def removed_stracks(self):
+        return []   # ids only live on the device; the reference keeps them for display
+
+    def get_last_reid_time_ms(self) -> float:
+        v = ctypes.c_double(0.0)
+        _lib.check(self._lib.boxmot_hip_botsort_last_reid_time_ms(self._handle, ctypes.byref(v)))
+        return float(v.value)
+
+    def get_last_track_time_ms(self) -> float:
+        v = ctypes.c_double(0.0)
+        _lib.check(self._lib.boxmot_hip_botsort_last_track_time_ms(self._handle, ctypes.byref(v)))
+        return float(v.value)
+
+    def close(self) -> None:
+        h = getattr(self, "_handle", None)
+        if h:
+            self._lib.boxmot_hip_botsort_destroy(h)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

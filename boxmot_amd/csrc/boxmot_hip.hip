@@ -1,0 +1,687 @@
+// C-ABI shared library of the MI355X BoT-SORT update path (include/boxmot_hip.h).
+// Host side: opaque handles, buffer staging, kernel sequencing on one HIP stream.
+// Device side: botsort_step.hpp (tracker), reid_kernels_v1.hpp / reid_fused.hpp (ReID).
+// There is no CPU implementation behind these entry points: without a usable
+// HIP device every call fails with an error message.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/boxmot_hip.h"
+#include "botsort_alloc.hpp"
+#include "botsort_step.hpp"
+#include "reid_engine.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+template <class F>
+int guard(F&& f) {
+    try {
+        f();
+        g_last_error.clear();
+        return 1;
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+    } catch (...) {
+        g_last_error = "unknown failure in boxmot_hip";
+    }
+    return 0;
+}
+
+constexpr int STEP_THREADS = 512;
+
+template <int NTHR>
+__global__ void __launch_bounds__(NTHR) botsort_step_kernel(bm::BotSortStepArgs args) {
+    __shared__ int s_int[bm::MAX_WAVES + 1];
+    __shared__ double s_dbl[bm::MAX_WAVES];
+    __shared__ float sA[bm::COST_TILE][bm::COST_KC + 1];
+    __shared__ float sB[bm::COST_TILE][bm::COST_KC + 1];
+    bm::botsort_step_stream<NTHR>(args, args.stream_base + blockIdx.x, s_int, s_dbl, sA, sB);
+}
+
+// Build the ReID crop list on the device: every detection with conf > track_high_thresh
+// (botsort.py:191-192, :260).  One workgroup per stream; ranges reserved with one atomic.
+__global__ void build_crop_list_kernel(const float* dets, const int* n_dets, int max_dets, double high,
+                                       int* crop_count, int* crop_stream, float* crop_boxes, int* crop_row,
+                                       int stream_base) {
+    __shared__ int s_base;
+    __shared__ int s_cnt;
+    const int s = stream_base + blockIdx.x;
+    const int n = n_dets[s];
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const float* d = dets + (long)s * max_dets * bm::DET_COLS;
+    int mine = 0;
+    for (int j = threadIdx.x; j < n; j += blockDim.x)
+        if ((double)d[j * bm::DET_COLS + 4] > high) ++mine;
+    const int local = atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = atomicAdd(crop_count, s_cnt);
+    __syncthreads();
+    int k = s_base + local;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        if ((double)d[j * bm::DET_COLS + 4] > high) {
+            crop_stream[k] = s;
+            crop_row[k] = s * max_dets + j;
+            for (int q = 0; q < 4; ++q) crop_boxes[k * 4 + q] = d[j * bm::DET_COLS + q];
+            ++k;
+        }
+    }
+}
+
+}  // namespace
+
+struct BoxMOTHipReID {
+    std::unique_ptr<bm::ReidEngine> engine;
+    std::vector<void*> owned;
+    hipStream_t stream = nullptr;
+    uint8_t* d_frame = nullptr;
+    size_t frame_bytes = 0;
+    const uint8_t** d_frames = nullptr;
+    int* d_crop_stream = nullptr;
+    float* d_boxes = nullptr;
+    float* d_feat = nullptr;
+    ~BoxMOTHipReID() {
+        engine.reset();
+        for (void* p : owned) (void)hipFree(p);
+        if (d_frame) (void)hipFree(d_frame);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+struct BoxMOTHipBotSort {
+    BoxMOTHipBotSortConfig cfg{};
+    std::string reid_path;
+    bm::BotSortStepArgs args{};
+    std::vector<void*> owned;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[2]{};
+    hipEvent_t timer_ev[2]{};
+    int S = 1, cap = 0, nd = 0, dim = 0, n_lists = 1;
+    // io staging
+    float* d_dets = nullptr;
+    int* d_ndets = nullptr;
+    float* d_embs = nullptr;
+    float* d_out = nullptr;
+    int* d_out_n = nullptr;
+    int* d_list_sel = nullptr;
+    int* d_fc_set = nullptr;
+    std::vector<float> h_dets, h_out;
+    std::vector<int> h_ndets, h_out_n, h_list_sel, h_fc_set;
+    // frames owned by the handle (host API)
+    std::vector<uint8_t*> frame_bufs;
+    size_t frame_bytes = 0;
+    int frame_rows = 0, frame_cols = 0;
+    const uint8_t** d_frames = nullptr;
+    // reid
+    std::unique_ptr<bm::ReidEngine> reid;
+    int reid_mode = 0;
+    int* d_crop_count = nullptr;
+    int* d_crop_stream = nullptr;
+    float* d_crop_boxes = nullptr;
+    int* d_crop_row = nullptr;
+    double last_track_ms = 0, last_reid_pre_ms = 0, last_reid_proc_ms = 0;
+
+    ~BoxMOTHipBotSort() {
+        reid.reset();
+        for (void* p : owned) (void)hipFree(p);
+        for (auto* p : frame_bufs) if (p) (void)hipFree(p);
+        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+        for (auto& e : timer_ev) if (e) (void)hipEventDestroy(e);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+using bm::dev_alloc;
+
+void require_device() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        throw std::runtime_error("boxmot_hip: no HIP device available (this library has no CPU fallback)");
+}
+
+template <typename T>
+T* zalloc(size_t n, std::vector<void*>& owned) {
+    T* p = dev_alloc<T>(n, owned);
+    BM_HIP(hipMemset(p, 0, (n ? n : 1) * sizeof(T)));
+    return p;
+}
+
+struct DevAlloc {
+    std::vector<void*>* owned;
+    template <typename T> T* get(size_t n) { return zalloc<T>(n, *owned); }
+};
+
+void zero_state(BoxMOTHipBotSort* h) {
+    bm::BotSortState& st = h->args.st;
+    const size_t S = h->S, cap = h->cap;
+    BM_HIP(hipMemsetAsync(st.frame_count, 0, S * 4, h->stream));
+    BM_HIP(hipMemsetAsync(st.id_count, 0, S * 4, h->stream));
+    BM_HIP(hipMemsetAsync(st.n_active, 0, S * h->n_lists * 4, h->stream));
+    BM_HIP(hipMemsetAsync(st.n_lost, 0, S * 4, h->stream));
+    BM_HIP(hipMemsetAsync(st.rm_head, 0, S * 4, h->stream));
+    BM_HIP(hipMemsetAsync(st.rm_size, 0, S * 4, h->stream));
+    BM_HIP(hipMemsetAsync(st.stamp, 0, S * 4, h->stream));
+    BM_HIP(hipMemsetAsync(st.status, 0, S * 4, h->stream));
+    BM_HIP(hipMemsetAsync(st.slot_used, 0, S * cap * 4, h->stream));
+    BM_HIP(hipMemsetAsync(st.mark, 0, S * cap * 4, h->stream));
+    BM_HIP(hipStreamSynchronize(h->stream));
+}
+
+void build(BoxMOTHipBotSort* h) {
+    const BoxMOTHipBotSortConfig& c = h->cfg;
+    if (c.cmc_method && c.cmc_method[0] && std::strcmp(c.cmc_method, "none") != 0)
+        throw std::runtime_error("boxmot_hip: camera-motion compensation is not implemented; pass cmc_method=none (use_cmc=False)");
+    if (c.reid_preprocess && c.reid_preprocess[0] && std::strcmp(c.reid_preprocess, "resize") != 0)
+        throw std::runtime_error("boxmot_hip: only the 'resize' ReID preprocess is implemented");
+    if (c.n_streams < 1 || c.max_tracks < 8 || c.max_dets < 4 || c.emb_dim < 1 || c.n_class_lists < 1)
+        throw std::runtime_error("boxmot_hip: invalid capacity configuration");
+    if (c.removed_stracks_buffer < 0) throw std::runtime_error("boxmot_hip: removed_stracks_buffer must be >= 0");
+    h->S = c.n_streams; h->cap = c.max_tracks; h->nd = c.max_dets; h->dim = c.emb_dim; h->n_lists = c.n_class_lists;
+    BM_HIP(hipStreamCreate(&h->stream));
+    BM_HIP(hipEventCreate(&h->ev[0]));
+    BM_HIP(hipEventCreate(&h->ev[1]));
+    BM_HIP(hipEventCreate(&h->timer_ev[0]));
+    BM_HIP(hipEventCreate(&h->timer_ev[1]));
+    const size_t S = h->S, cap = h->cap, nd = h->nd, dim = h->dim, nl = h->n_lists;
+    auto& o = h->owned;
+    h->args.cfg = bm::make_config_dev(c.track_high_thresh, c.track_low_thresh, c.new_track_thresh, c.match_thresh,
+                                      c.proximity_thresh, c.appearance_thresh, c.second_match_thresh,
+                                      c.unconfirmed_match_thresh, c.unconfirmed_emb_scale, c.fuse_first_associate,
+                                      c.with_reid, c.frame_rate, c.track_buffer, c.removed_stracks_buffer);
+    bm::BotSortSizes z{h->S, h->cap, h->nd, h->dim, h->n_lists, c.removed_stracks_buffer > 0 ? c.removed_stracks_buffer : 1};
+    DevAlloc dev_allocator{&o};
+    bm::botsort_allocate(h->args, z, dev_allocator);
+    // io
+    h->d_dets = zalloc<float>(S * nd * bm::DET_COLS, o);
+    h->d_ndets = zalloc<int>(S, o);
+    h->d_embs = zalloc<float>(S * nd * dim, o);
+    h->d_out = zalloc<float>(S * nd * bm::OUT_COLS, o);
+    h->d_out_n = zalloc<int>(S, o);
+    h->d_list_sel = zalloc<int>(S, o);
+    h->d_fc_set = zalloc<int>(S, o);
+    h->h_dets.assign(S * nd * bm::DET_COLS, 0.f);
+    h->h_out.assign(S * nd * bm::OUT_COLS, 0.f);
+    h->h_ndets.assign(S, 0); h->h_out_n.assign(S, 0); h->h_list_sel.assign(S, 0); h->h_fc_set.assign(S, 0);
+    h->frame_bufs.assign(S, nullptr);
+    h->d_frames = zalloc<const uint8_t*>(S, o);
+    h->d_crop_count = zalloc<int>(1, o);
+    h->d_crop_stream = zalloc<int>(S * nd, o);
+    h->d_crop_boxes = zalloc<float>(S * nd * 4, o);
+    h->d_crop_row = zalloc<int>(S * nd, o);
+    if (c.with_reid && !h->reid_path.empty()) {
+        const std::vector<float> blob = bm::read_blob_file(h->reid_path.c_str());
+        h->reid.reset(new bm::ReidEngine(blob.data(), (long)blob.size(), bm::reid_chunk_for((long)S * nd)));
+        if (h->reid->feature_dim() != h->dim) throw std::runtime_error("boxmot_hip: ReID feature dim != emb_dim");
+    }
+}
+
+void launch_step(BoxMOTHipBotSort* h, int s0, int n_streams, const float* d_dets, const int* d_ndets, const float* d_embs,
+                 const int* d_list_sel, const int* d_fc_set, float* d_out, int* d_out_n) {
+    bm::BotSortStepArgs a = h->args;
+    a.dets = d_dets; a.n_dets = d_ndets; a.embs = d_embs; a.list_sel = d_list_sel; a.frame_count_set = d_fc_set;
+    a.out = d_out; a.out_n = d_out_n; a.stream_base = s0;
+    hipLaunchKernelGGL((botsort_step_kernel<STEP_THREADS>), dim3(n_streams), dim3(STEP_THREADS), 0, h->stream, a);
+    BM_HIP(hipGetLastError());
+}
+
+// ReID for every high-confidence detection of the first n_streams streams; writes d_embs rows.
+void run_reid(BoxMOTHipBotSort* h, int s0, int n_streams, const float* d_dets, const int* d_ndets,
+              const uint8_t* const* d_frames, int rows, int cols, float* d_embs) {
+    if (!h->reid) throw std::runtime_error("boxmot_hip: with_reid=1 and no embeddings supplied, but no ReID weights are loaded");
+    BM_HIP(hipMemsetAsync(h->d_crop_count, 0, 4, h->stream));
+    hipLaunchKernelGGL(build_crop_list_kernel, dim3(n_streams), dim3(256), 0, h->stream, d_dets, d_ndets, h->nd,
+                       h->cfg.track_high_thresh, h->d_crop_count, h->d_crop_stream, h->d_crop_boxes, h->d_crop_row, s0);
+    int n_crops = 0;
+    BM_HIP(hipMemcpyAsync(&n_crops, h->d_crop_count, 4, hipMemcpyDeviceToHost, h->stream));
+    BM_HIP(hipStreamSynchronize(h->stream));
+    h->reid->run(d_frames, h->d_crop_stream, h->d_crop_boxes, 4, n_crops, cols, rows, d_embs, h->d_crop_row, h->stream);
+}
+
+void check_status(BoxMOTHipBotSort* h, int n_streams) {
+    std::vector<int> st(n_streams);
+    BM_HIP(hipMemcpy(st.data(), h->args.st.status, n_streams * 4, hipMemcpyDeviceToHost));
+    for (int s = 0; s < n_streams; ++s) {
+        if (st[s] == bm::STATUS_OK) continue;
+        const char* what = st[s] == bm::STATUS_TRACK_CAPACITY ? "track capacity (max_tracks) exceeded"
+                         : st[s] == bm::STATUS_CLASS_CAPACITY ? "more than 8 classes voted on one track"
+                         : "assignment solver did not converge (non-finite costs?)";
+        throw std::runtime_error("boxmot_hip: stream " + std::to_string(s) + ": " + what);
+    }
+}
+
+void upload_frame(BoxMOTHipBotSort* h, int s, const uint8_t* image, int rows, int cols, int channels) {
+    if (channels != 3) throw std::runtime_error("boxmot_hip: ReID needs a 3-channel uint8 BGR image");
+    const size_t bytes = (size_t)rows * cols * 3;
+    if (h->frame_bufs[s] == nullptr || bytes != h->frame_bytes) {
+        if (h->frame_bytes != 0 && bytes != h->frame_bytes)
+            throw std::runtime_error("boxmot_hip: frame size changed between updates");
+        void* p = nullptr;
+        BM_HIP(hipMalloc(&p, bytes));
+        h->frame_bufs[s] = static_cast<uint8_t*>(p);
+        h->frame_bytes = bytes; h->frame_rows = rows; h->frame_cols = cols;
+        BM_HIP(hipMemcpy(h->d_frames, h->frame_bufs.data(), h->S * sizeof(uint8_t*), hipMemcpyHostToDevice));
+    }
+    BM_HIP(hipMemcpyAsync(h->frame_bufs[s], image, bytes, hipMemcpyHostToDevice, h->stream));
+}
+
+struct StreamIn {
+    const float* dets; int det_rows;
+    const float* embs;
+    const uint8_t* image;
+};
+
+// Shared host path: stage inputs of streams [s0, s0+n), run ReID if needed, step, read back.
+void host_update(BoxMOTHipBotSort* h, int s0, int n, const StreamIn* in, int det_cols, int emb_cols,
+                 int image_rows, int image_cols, int image_channels, const int* list_sel, const int* fc_set,
+                 float* const* out, int out_capacity_rows, int* out_rows) {
+    const int nd = h->nd, dim = h->dim;
+    bool need_reid = false;
+    for (int k = 0; k < n; ++k) {
+        const int rows = in[k].det_rows;
+        if (rows < 0) throw std::runtime_error("Negative matrix dimensions are not allowed.");
+        if (rows > 0 && det_cols == 7) throw std::runtime_error("boxmot_hip: OBB detections (7 columns) are not implemented");
+        if (rows > 0 && det_cols != 6) throw std::runtime_error("boxmot_hip live tracking supports AABB detections with 6 columns.");
+        if (rows > nd) throw std::runtime_error("boxmot_hip: more detections than max_dets");
+        if (rows > 0 && in[k].dets == nullptr) throw std::runtime_error("Detection data pointer is null.");
+        if (out_capacity_rows < rows) throw std::runtime_error("boxmot_hip: output buffer is too small for the current frame.");
+        if (in[k].embs != nullptr && emb_cols != dim && rows > 0)
+            throw std::runtime_error("boxmot_hip: embedding width does not match emb_dim");
+        if (h->cfg.with_reid && in[k].embs == nullptr && rows > 0) need_reid = true;
+    }
+    if (need_reid)
+        for (int k = 0; k < n; ++k)
+            if (in[k].embs != nullptr && in[k].det_rows > 0)
+                throw std::runtime_error("boxmot_hip: either every stream of a batch supplies embeddings or none does");
+    // one staging buffer for the whole group
+    float* hd = h->h_dets.data() + (size_t)s0 * nd * bm::DET_COLS;
+    for (int k = 0; k < n; ++k) {
+        h->h_ndets[s0 + k] = in[k].det_rows;
+        if (in[k].det_rows)
+            std::memcpy(hd + (size_t)k * nd * bm::DET_COLS, in[k].dets, (size_t)in[k].det_rows * bm::DET_COLS * 4);
+        h->h_list_sel[s0 + k] = list_sel ? list_sel[k] : 0;
+        h->h_fc_set[s0 + k] = fc_set ? fc_set[k] : 0;
+    }
+    float* d_dets = h->d_dets + (size_t)s0 * nd * bm::DET_COLS;
+    BM_HIP(hipMemcpyAsync(d_dets, hd, (size_t)n * nd * bm::DET_COLS * 4, hipMemcpyHostToDevice, h->stream));
+    BM_HIP(hipMemcpyAsync(h->d_ndets + s0, h->h_ndets.data() + s0, n * 4, hipMemcpyHostToDevice, h->stream));
+    BM_HIP(hipMemcpyAsync(h->d_list_sel + s0, h->h_list_sel.data() + s0, n * 4, hipMemcpyHostToDevice, h->stream));
+    if (fc_set) BM_HIP(hipMemcpyAsync(h->d_fc_set + s0, h->h_fc_set.data() + s0, n * 4, hipMemcpyHostToDevice, h->stream));
+    float* d_embs = h->d_embs + (size_t)s0 * nd * dim;
+    for (int k = 0; k < n; ++k)
+        if (in[k].embs && in[k].det_rows)
+            BM_HIP(hipMemcpyAsync(d_embs + (size_t)k * nd * dim, in[k].embs, (size_t)in[k].det_rows * dim * 4,
+                                  hipMemcpyHostToDevice, h->stream));
+    h->last_reid_pre_ms = h->last_reid_proc_ms = 0;
+    if (need_reid) {
+        for (int k = 0; k < n; ++k) {
+            if (in[k].image) upload_frame(h, s0 + k, in[k].image, image_rows, image_cols, image_channels);
+            else if (h->frame_bufs[s0 + k] == nullptr) throw std::runtime_error("Image data pointer is null.");
+        }
+        run_reid(h, s0, n, h->d_dets, h->d_ndets, h->d_frames, h->frame_rows, h->frame_cols, h->d_embs);
+    }
+    BM_HIP(hipEventRecord(h->ev[0], h->stream));
+    launch_step(h, s0, n, h->d_dets, h->d_ndets, h->cfg.with_reid ? h->d_embs : nullptr, h->d_list_sel,
+                fc_set ? h->d_fc_set : nullptr, h->d_out, h->d_out_n);
+    BM_HIP(hipEventRecord(h->ev[1], h->stream));
+    BM_HIP(hipMemcpyAsync(h->h_out_n.data(), h->d_out_n + s0, n * 4, hipMemcpyDeviceToHost, h->stream));
+    BM_HIP(hipMemcpyAsync(h->h_out.data(), h->d_out + (size_t)s0 * nd * bm::OUT_COLS, (size_t)n * nd * bm::OUT_COLS * 4,
+                          hipMemcpyDeviceToHost, h->stream));
+    BM_HIP(hipStreamSynchronize(h->stream));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) == hipSuccess) h->last_track_ms = ms;
+    if (need_reid) h->reid->last_times(h->last_reid_pre_ms, h->last_reid_proc_ms);
+    check_status(h, h->S);
+    for (int k = 0; k < n; ++k) {
+        const int rows = h->h_out_n[k];
+        if (rows > out_capacity_rows) throw std::runtime_error("boxmot_hip: output buffer is too small for the current frame.");
+        const float* src = h->h_out.data() + (size_t)k * nd * bm::OUT_COLS;
+        for (int r = 0; r < rows; ++r) {
+            float* dst = out[k] + (size_t)r * 9;
+            for (int q = 0; q < 8; ++q) dst[q] = src[r * bm::OUT_COLS + q];
+            dst[8] = 0.0f;
+        }
+        out_rows[k] = rows;
+    }
+}
+
+// single stream at an arbitrary index: run it as a one-stream group by offsetting the args
+void host_update_one(BoxMOTHipBotSort* h, int stream, int class_list, int frame_count, const StreamIn& in,
+                     int det_cols, int emb_cols, int rows, int cols, int channels, float* out, int out_cap,
+                     int* out_rows) {
+    if (stream < 0 || stream >= h->S) throw std::runtime_error("boxmot_hip: stream index out of range");
+    if (class_list < 0 || class_list >= h->n_lists) throw std::runtime_error("boxmot_hip: class list out of range");
+    float* outs[1] = {out};
+    const int sel[1] = {class_list};
+    const int fc[1] = {frame_count};
+    host_update(h, stream, 1, &in, det_cols, emb_cols, rows, cols, channels, sel, frame_count >= 0 ? fc : nullptr, outs,
+                out_cap, out_rows);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* boxmot_hip_last_error(void) { return g_last_error.c_str(); }
+
+int boxmot_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void boxmot_hip_botsort_default_config(BoxMOTHipBotSortConfig* c) {
+    if (!c) return;
+    std::memset(c, 0, sizeof(*c));
+    c->track_high_thresh = 0.5; c->track_low_thresh = 0.1; c->new_track_thresh = 0.6; c->track_buffer = 30;
+    c->match_thresh = 0.8; c->proximity_thresh = 0.5; c->appearance_thresh = 0.25; c->cmc_method = nullptr;
+    c->frame_rate = 30; c->fuse_first_associate = 0; c->with_reid = 1; c->max_obs = 50;
+    c->reid_model_path = nullptr; c->reid_preprocess = nullptr;
+    c->second_match_thresh = 0.5; c->unconfirmed_match_thresh = 0.7; c->unconfirmed_emb_scale = 2.0;
+    c->removed_stracks_buffer = 100;
+    c->n_streams = 1; c->max_tracks = 1024; c->max_dets = 256; c->emb_dim = 512; c->n_class_lists = 1;
+}
+
+BoxMOTHipBotSort* boxmot_hip_botsort_create(const BoxMOTHipBotSortConfig* config) {
+    BoxMOTHipBotSort* h = nullptr;
+    const int ok = guard([&]() {
+        if (config == nullptr) throw std::runtime_error("boxmot_hip BoT-SORT config is required.");
+        require_device();
+        h = new BoxMOTHipBotSort();
+        h->cfg = *config;
+        if (config->reid_model_path) h->reid_path = config->reid_model_path;
+        h->cfg.reid_model_path = nullptr;
+        build(h);
+    });
+    if (!ok) { delete h; return nullptr; }
+    return h;
+}
+
+void boxmot_hip_botsort_destroy(BoxMOTHipBotSort* handle) { delete handle; }
+
+int boxmot_hip_botsort_reset(BoxMOTHipBotSort* handle) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip BoT-SORT handle is null.");
+        zero_state(handle);
+    });
+}
+
+int boxmot_hip_botsort_update(BoxMOTHipBotSort* handle, const float* dets, int det_rows, int det_cols,
+                              const float* embs, int emb_rows, int emb_cols, const uint8_t* image, int image_rows,
+                              int image_cols, int image_channels, float* out_tracks, int out_capacity_rows,
+                              int out_cols, int* out_rows, int* out_is_obb) {
+    return boxmot_hip_botsort_update_stream(handle, 0, 0, -1, dets, det_rows, det_cols, embs, emb_rows, emb_cols, image,
+                                            image_rows, image_cols, image_channels, out_tracks, out_capacity_rows,
+                                            out_cols, out_rows, out_is_obb);
+}
+
+int boxmot_hip_botsort_update_stream(BoxMOTHipBotSort* handle, int stream, int class_list, int frame_count,
+                                     const float* dets, int det_rows, int det_cols, const float* embs, int emb_rows,
+                                     int emb_cols, const uint8_t* image, int image_rows, int image_cols,
+                                     int image_channels, float* out_tracks, int out_capacity_rows, int out_cols,
+                                     int* out_rows, int* out_is_obb) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip BoT-SORT handle is not initialized.");
+        if (!out_rows || !out_is_obb) throw std::runtime_error("Output pointers are null.");
+        if (out_cols != 9) throw std::runtime_error("boxmot_hip live tracking expects an output buffer with 9 columns.");
+        if (embs != nullptr && emb_rows != det_rows) throw std::runtime_error("Detection and embedding row counts must match.");
+        if (image_rows <= 0 || image_cols <= 0) throw std::runtime_error("Image dimensions must be positive.");
+        StreamIn in{dets, det_rows, (embs && emb_cols > 0) ? embs : nullptr, image};
+        host_update_one(handle, stream, class_list, frame_count, in, det_cols, emb_cols, image_rows, image_cols,
+                        image_channels, out_tracks, out_capacity_rows, out_rows);
+        *out_is_obb = 0;
+    });
+}
+
+int boxmot_hip_botsort_update_batch(BoxMOTHipBotSort* handle, int n_streams, const float* const* dets,
+                                    const int* det_rows, const float* const* embs, int emb_cols,
+                                    const uint8_t* const* images, int image_rows, int image_cols, int image_channels,
+                                    float* const* out_tracks, int out_capacity_rows, int* out_rows) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip BoT-SORT handle is not initialized.");
+        if (n_streams < 1 || n_streams > handle->S) throw std::runtime_error("boxmot_hip: n_streams out of range");
+        if (!dets || !det_rows || !out_tracks || !out_rows) throw std::runtime_error("boxmot_hip: null batch pointers");
+        std::vector<StreamIn> in(n_streams);
+        for (int s = 0; s < n_streams; ++s)
+            in[s] = StreamIn{dets[s], det_rows[s], (embs && emb_cols > 0) ? embs[s] : nullptr, images ? images[s] : nullptr};
+        host_update(handle, 0, n_streams, in.data(), 6, emb_cols, image_rows, image_cols, image_channels, nullptr, nullptr,
+                    out_tracks, out_capacity_rows, out_rows);
+    });
+}
+
+int boxmot_hip_botsort_step_device(BoxMOTHipBotSort* handle, const float* d_dets, const int* d_det_rows,
+                                   const float* d_embs, const uint8_t* const* d_frames, int image_rows, int image_cols,
+                                   float* d_out, int* d_out_rows) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip BoT-SORT handle is not initialized.");
+        if (!d_dets || !d_det_rows || !d_out || !d_out_rows) throw std::runtime_error("boxmot_hip: null device pointers");
+        const float* embs = d_embs;
+        if (handle->cfg.with_reid && d_embs == nullptr) {
+            if (!d_frames) throw std::runtime_error("boxmot_hip: with_reid needs d_embs or d_frames");
+            run_reid(handle, 0, handle->S, d_dets, d_det_rows, d_frames, image_rows, image_cols, handle->d_embs);
+            embs = handle->d_embs;
+        }
+        launch_step(handle, 0, handle->S, d_dets, d_det_rows, handle->cfg.with_reid ? embs : nullptr, nullptr, nullptr,
+                    d_out, d_out_rows);
+    });
+}
+
+int boxmot_hip_botsort_synchronize(BoxMOTHipBotSort* handle) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip BoT-SORT handle is not initialized.");
+        BM_HIP(hipStreamSynchronize(handle->stream));
+    });
+}
+
+int boxmot_hip_botsort_timer_start(BoxMOTHipBotSort* handle) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip BoT-SORT handle is not initialized.");
+        BM_HIP(hipEventRecord(handle->timer_ev[0], handle->stream));
+    });
+}
+
+int boxmot_hip_botsort_timer_stop_ms(BoxMOTHipBotSort* handle, double* out_ms) {
+    return guard([&]() {
+        if (!handle || !out_ms) throw std::runtime_error("boxmot_hip: null argument");
+        BM_HIP(hipEventRecord(handle->timer_ev[1], handle->stream));
+        BM_HIP(hipEventSynchronize(handle->timer_ev[1]));
+        float ms = 0;
+        BM_HIP(hipEventElapsedTime(&ms, handle->timer_ev[0], handle->timer_ev[1]));
+        *out_ms = ms;
+    });
+}
+
+int boxmot_hip_botsort_reid_kernel_ms(BoxMOTHipBotSort* handle, double* out_ms, int* out_launches) {
+    return guard([&]() {
+        if (!handle || !out_ms || !out_launches) throw std::runtime_error("boxmot_hip: null argument");
+        *out_ms = 0; *out_launches = 0;
+        if (handle->reid) handle->reid->drain_kernel_timing(*out_ms, *out_launches);
+    });
+}
+
+void* boxmot_hip_botsort_stream(BoxMOTHipBotSort* handle) { return handle ? (void*)handle->stream : nullptr; }
+
+int boxmot_hip_botsort_status(BoxMOTHipBotSort* handle, int* out_status, int capacity) {
+    return guard([&]() {
+        if (!handle || !out_status) throw std::runtime_error("boxmot_hip: null argument");
+        const int n = capacity < handle->S ? capacity : handle->S;
+        BM_HIP(hipStreamSynchronize(handle->stream));
+        BM_HIP(hipMemcpy(out_status, handle->args.st.status, n * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+int boxmot_hip_botsort_set_reid_blob(BoxMOTHipBotSort* handle, const float* blob, long n_floats) {
+    return guard([&]() {
+        if (!handle || !blob) throw std::runtime_error("boxmot_hip: null argument");
+        handle->reid.reset(new bm::ReidEngine(blob, n_floats, bm::reid_chunk_for((long)handle->S * handle->nd)));
+        if (handle->reid->feature_dim() != handle->dim) {
+            handle->reid.reset();
+            throw std::runtime_error("boxmot_hip: ReID feature dim != emb_dim");
+        }
+        handle->reid->set_mode(handle->reid_mode);
+    });
+}
+
+int boxmot_hip_botsort_set_reid_mode(BoxMOTHipBotSort* handle, int mode) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip: null argument");
+        if (handle->reid) handle->reid->set_mode(mode);
+        handle->reid_mode = mode;
+    });
+}
+
+static int get_ms(BoxMOTHipBotSort* h, double* out, double BoxMOTHipBotSort::*field, bool sum_reid) {
+    return guard([&]() {
+        if (!h) throw std::runtime_error("boxmot_hip BoT-SORT handle is not initialized.");
+        if (!out) throw std::runtime_error("Output timing pointer is null.");
+        *out = sum_reid ? h->last_reid_pre_ms + h->last_reid_proc_ms : h->*field;
+    });
+}
+int boxmot_hip_botsort_last_reid_time_ms(BoxMOTHipBotSort* h, double* o) { return get_ms(h, o, &BoxMOTHipBotSort::last_reid_pre_ms, true); }
+int boxmot_hip_botsort_last_reid_preprocess_time_ms(BoxMOTHipBotSort* h, double* o) { return get_ms(h, o, &BoxMOTHipBotSort::last_reid_pre_ms, false); }
+int boxmot_hip_botsort_last_reid_process_time_ms(BoxMOTHipBotSort* h, double* o) { return get_ms(h, o, &BoxMOTHipBotSort::last_reid_proc_ms, false); }
+int boxmot_hip_botsort_last_reid_postprocess_time_ms(BoxMOTHipBotSort* h, double* o) {
+    return guard([&]() {
+        if (!h) throw std::runtime_error("boxmot_hip BoT-SORT handle is not initialized.");
+        if (!o) throw std::runtime_error("Output timing pointer is null.");
+        *o = 0.0;   // L2 normalisation is fused into the head kernel
+    });
+}
+int boxmot_hip_botsort_last_track_time_ms(BoxMOTHipBotSort* h, double* o) { return get_ms(h, o, &BoxMOTHipBotSort::last_track_ms, false); }
+
+int boxmot_hip_botsort_state_dump(BoxMOTHipBotSort* handle, int stream, int which, int class_list, int* ints,
+                                  double* kf, float* smooth, float* misc, int* out_rows, int* out_frame_count,
+                                  int* out_id_count) {
+    return guard([&]() {
+        if (!handle || !out_rows) throw std::runtime_error("boxmot_hip: null argument");
+        if (stream < 0 || stream >= handle->S) throw std::runtime_error("boxmot_hip: stream index out of range");
+        BM_HIP(hipStreamSynchronize(handle->stream));
+        const bm::BotSortState& st = handle->args.st;
+        const size_t cap = handle->cap, dim = handle->dim, s = stream;
+        int n = 0;
+        std::vector<int> list(cap);
+        if (which == 0) {
+            BM_HIP(hipMemcpy(&n, st.n_active + s * handle->n_lists + class_list, 4, hipMemcpyDeviceToHost));
+            BM_HIP(hipMemcpy(list.data(), st.active_list + (s * handle->n_lists + class_list) * cap, cap * 4, hipMemcpyDeviceToHost));
+        } else {
+            BM_HIP(hipMemcpy(&n, st.n_lost + s, 4, hipMemcpyDeviceToHost));
+            BM_HIP(hipMemcpy(list.data(), st.lost_list + s * cap, cap * 4, hipMemcpyDeviceToHost));
+        }
+        auto pull_i = [&](const int* src) { std::vector<int> v(cap); BM_HIP(hipMemcpy(v.data(), src + s * cap, cap * 4, hipMemcpyDeviceToHost)); return v; };
+        auto pull_f = [&](const float* src) { std::vector<float> v(cap); BM_HIP(hipMemcpy(v.data(), src + s * cap, cap * 4, hipMemcpyDeviceToHost)); return v; };
+        const auto id = pull_i(st.id), state = pull_i(st.state), act = pull_i(st.is_activated), fid = pull_i(st.frame_id),
+                   sf = pull_i(st.start_frame), tl = pull_i(st.tracklet_len);
+        const auto conf = pull_f(st.conf), cls = pull_f(st.cls), di = pull_f(st.det_ind);
+        std::vector<double> kfall(cap * bm::KF_STRIDE);
+        BM_HIP(hipMemcpy(kfall.data(), st.kf + s * cap * bm::KF_STRIDE, kfall.size() * 8, hipMemcpyDeviceToHost));
+        std::vector<float> sm;
+        if (smooth) { sm.resize(cap * dim); BM_HIP(hipMemcpy(sm.data(), st.smooth + s * cap * dim, sm.size() * 4, hipMemcpyDeviceToHost)); }
+        for (int r = 0; r < n; ++r) {
+            const int sl = list[r];
+            if (ints) { int* o = ints + r * 6; o[0] = id[sl]; o[1] = state[sl]; o[2] = act[sl]; o[3] = fid[sl]; o[4] = sf[sl]; o[5] = tl[sl]; }
+            if (kf) std::memcpy(kf + (size_t)r * bm::KF_STRIDE, kfall.data() + (size_t)sl * bm::KF_STRIDE, bm::KF_STRIDE * 8);
+            if (smooth) std::memcpy(smooth + (size_t)r * dim, sm.data() + (size_t)sl * dim, dim * 4);
+            if (misc) { misc[r * 3] = conf[sl]; misc[r * 3 + 1] = cls[sl]; misc[r * 3 + 2] = di[sl]; }
+        }
+        *out_rows = n;
+        if (out_frame_count) BM_HIP(hipMemcpy(out_frame_count, st.frame_count + s, 4, hipMemcpyDeviceToHost));
+        if (out_id_count) BM_HIP(hipMemcpy(out_id_count, st.id_count + s, 4, hipMemcpyDeviceToHost));
+    });
+}
+
+// ---- ReID C ABI ----
+BoxMOTHipReID* boxmot_hip_reid_create(const char* model_path, const float* blob, long n_floats, int max_crops) {
+    BoxMOTHipReID* h = nullptr;
+    const int ok = guard([&]() {
+        require_device();
+        if (max_crops < 1) throw std::runtime_error("boxmot_hip: max_crops must be >= 1");
+        h = new BoxMOTHipReID();
+        BM_HIP(hipStreamCreate(&h->stream));
+        if (blob) h->engine.reset(new bm::ReidEngine(blob, n_floats, max_crops));
+        else if (model_path) {
+            const std::vector<float> v = bm::read_blob_file(model_path);
+            h->engine.reset(new bm::ReidEngine(v.data(), (long)v.size(), max_crops));
+        } else throw std::runtime_error("boxmot_hip: ReID needs a weight blob or a model path");
+        h->d_frames = dev_alloc<const uint8_t*>(1, h->owned);
+        h->d_crop_stream = zalloc<int>(max_crops, h->owned);
+        h->d_boxes = dev_alloc<float>((size_t)max_crops * 4, h->owned);
+        h->d_feat = dev_alloc<float>((size_t)max_crops * h->engine->feature_dim(), h->owned);
+    });
+    if (!ok) { delete h; return nullptr; }
+    return h;
+}
+
+void boxmot_hip_reid_destroy(BoxMOTHipReID* handle) { delete handle; }
+
+int boxmot_hip_reid_feature_dim(BoxMOTHipReID* handle) { return handle && handle->engine ? handle->engine->feature_dim() : 0; }
+
+int boxmot_hip_reid_set_mode(BoxMOTHipReID* handle, int mode) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip: null ReID handle");
+        handle->engine->set_mode(mode);
+    });
+}
+
+static void reid_stage(BoxMOTHipReID* h, const uint8_t* image, int rows, int cols, int channels, const float* boxes,
+                       int n, int box_cols) {
+    if (!h) throw std::runtime_error("boxmot_hip: null ReID handle");
+    if (!image) throw std::runtime_error("Image data pointer is null.");
+    if (channels != 3) throw std::runtime_error("boxmot_hip: ReID needs a 3-channel uint8 BGR image");
+    if (rows <= 0 || cols <= 0) throw std::runtime_error("Image dimensions must be positive.");
+    if (n < 0 || box_cols < 4) throw std::runtime_error("boxmot_hip: boxes must have at least 4 columns");
+    if (n > h->engine->max_crops()) throw std::runtime_error("boxmot_hip: more boxes than max_crops");
+    const size_t bytes = (size_t)rows * cols * 3;
+    if (bytes > h->frame_bytes) {
+        if (h->d_frame) BM_HIP(hipFree(h->d_frame));
+        void* p = nullptr;
+        BM_HIP(hipMalloc(&p, bytes));
+        h->d_frame = static_cast<uint8_t*>(p);
+        h->frame_bytes = bytes;
+        BM_HIP(hipMemcpy(h->d_frames, &h->d_frame, sizeof(uint8_t*), hipMemcpyHostToDevice));
+    }
+    BM_HIP(hipMemcpyAsync(h->d_frame, image, bytes, hipMemcpyHostToDevice, h->stream));
+    std::vector<float> b((size_t)n * 4);
+    for (int i = 0; i < n; ++i)
+        for (int q = 0; q < 4; ++q) b[i * 4 + q] = boxes[(size_t)i * box_cols + q];
+    if (n) BM_HIP(hipMemcpyAsync(h->d_boxes, b.data(), b.size() * 4, hipMemcpyHostToDevice, h->stream));
+    BM_HIP(hipStreamSynchronize(h->stream));
+}
+
+int boxmot_hip_reid_compute_features(BoxMOTHipReID* handle, const uint8_t* image, int image_rows, int image_cols,
+                                     int image_channels, const float* boxes, int n_boxes, int box_cols,
+                                     float* out_features, int out_capacity_rows) {
+    return guard([&]() {
+        reid_stage(handle, image, image_rows, image_cols, image_channels, boxes, n_boxes, box_cols);
+        if (out_capacity_rows < n_boxes) throw std::runtime_error("boxmot_hip: feature buffer too small");
+        if (n_boxes == 0) return;
+        handle->engine->run(handle->d_frames, handle->d_crop_stream, handle->d_boxes, 4, n_boxes, image_cols, image_rows,
+                            handle->d_feat, nullptr, handle->stream);
+        BM_HIP(hipMemcpyAsync(out_features, handle->d_feat, (size_t)n_boxes * handle->engine->feature_dim() * 4,
+                              hipMemcpyDeviceToHost, handle->stream));
+        BM_HIP(hipStreamSynchronize(handle->stream));
+    });
+}
+
+int boxmot_hip_reid_preprocess(BoxMOTHipReID* handle, const uint8_t* image, int image_rows, int image_cols,
+                               int image_channels, const float* boxes, int n_boxes, int box_cols, float* out_crops) {
+    return guard([&]() {
+        reid_stage(handle, image, image_rows, image_cols, image_channels, boxes, n_boxes, box_cols);
+        if (n_boxes == 0) return;
+        handle->engine->preprocess(handle->d_frames, handle->d_crop_stream, handle->d_boxes, 4, n_boxes, image_cols,
+                                   image_rows, handle->stream);
+        BM_HIP(hipMemcpyAsync(out_crops, handle->engine->crops_buffer(),
+                              (size_t)n_boxes * bm::REID_IN_H * bm::REID_IN_W * 3 * 4, hipMemcpyDeviceToHost, handle->stream));
+        BM_HIP(hipStreamSynchronize(handle->stream));
+    });
+}
+
+}  // extern "C"

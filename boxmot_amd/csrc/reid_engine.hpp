@@ -1,0 +1,275 @@
+// Host-side ReID engine: owns the folded OSNet weights and activation buffers on
+// the device and sequences the kernels for a batch of crops.
+//   mode 0: per-layer fp32 kernels (reid_kernels_v1.hpp) -- first correct path
+//   mode 1: fused fp16 MFMA kernels (reid_fused.hpp)
+// Reference path: BaseModelBackend.get_features, base_backend.py:197-207.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "reid_layout.hpp"
+#include "reid_kernels_v1.hpp"
+
+namespace bm {
+
+inline void hip_check(hipError_t e, const char* what) {
+    if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+#define BM_HIP(x) ::bm::hip_check((x), #x)
+
+template <typename T>
+inline T* dev_alloc(size_t n, std::vector<void*>& owned) {
+    void* p = nullptr;
+    BM_HIP(hipMalloc(&p, (n ? n : 1) * sizeof(T)));
+    owned.push_back(p);
+    return static_cast<T*>(p);
+}
+
+inline std::vector<float> read_blob_file(const char* path) {
+    FILE* f = std::fopen(path, "rb");
+    if (!f) throw std::runtime_error(std::string("cannot open ReID weight blob: ") + path);
+    std::fseek(f, 0, SEEK_END);
+    const long bytes = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    std::vector<float> v((size_t)bytes / 4);
+    const size_t got = std::fread(v.data(), 4, v.size(), f);
+    std::fclose(f);
+    if (got != v.size()) throw std::runtime_error("short read on ReID weight blob");
+    return v;
+}
+
+// crops processed per pass of the engine (bounds the activation buffers)
+inline int reid_chunk_for(long max_total) { return (int)(max_total < 4096 ? max_total : 4096); }
+
+class ReidEngine {
+public:
+    ReidEngine(const float* blob, long n_floats, int max_crops) : max_crops_(max_crops) {
+        if (n_floats < REID_HEADER_INTS) throw std::runtime_error("ReID blob too small");
+        const int32_t* hdr = reinterpret_cast<const int32_t*>(blob);
+        if (hdr[0] != REID_MAGIC) throw std::runtime_error("ReID blob: bad magic (expected OSN1)");
+        const int ch[4] = {hdr[1], hdr[2], hdr[3], hdr[4]};
+        L_ = make_osnet_layout(ch, hdr[5]);
+        if (hdr[6] != (int32_t)L_.total || n_floats != REID_HEADER_INTS + L_.total)
+            throw std::runtime_error("ReID blob: size does not match the declared architecture");
+        if (ch[0] != 16 && ch[0] != 64) throw std::runtime_error("ReID: unsupported stem width");
+        d_w_ = dev_alloc<float>((size_t)L_.total, owned_);
+        BM_HIP(hipMemcpy(d_w_, blob + REID_HEADER_INTS, (size_t)L_.total * 4, hipMemcpyHostToDevice));
+        h_w_.assign(blob + REID_HEADER_INTS, blob + REID_HEADER_INTS + L_.total);
+        // (x/255 - mean)/std in fp32, exactly as base_backend.py:189-193 evaluates it
+        float lut[3 * 256];
+        const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+        for (int c = 0; c < 3; ++c)
+            for (int v = 0; v < 256; ++v) {
+                volatile float a = (float)v / 255.0f;
+                volatile float b = a - mean[c];
+                lut[c * 256 + v] = b / stdv[c];
+            }
+        d_lut_ = dev_alloc<float>(3 * 256, owned_);
+        BM_HIP(hipMemcpy(d_lut_, lut, sizeof(lut), hipMemcpyHostToDevice));
+        alloc_buffers();
+        BM_HIP(hipEventCreate(&ev_[0]));
+        BM_HIP(hipEventCreate(&ev_[1]));
+        BM_HIP(hipEventCreate(&ev_[2]));
+    }
+    ~ReidEngine() {
+        for (void* p : owned_) (void)hipFree(p);
+        for (auto& e : ev_) (void)hipEventDestroy(e);
+        for (auto& e : all_events_) (void)hipEventDestroy(e);
+    }
+    int feature_dim() const { return L_.feat; }
+    int max_crops() const { return max_crops_; }
+    void set_mode(int m) {
+        if (m != 0) throw std::runtime_error("ReID mode not available in this build");
+        mode_ = m;
+    }
+    int mode() const { return mode_; }
+    const OsnetLayout& layout() const { return L_; }
+    float* crops_buffer() { return crops_; }
+
+    // crops only (normalised NHWC fp32) for `n` boxes
+    void preprocess(const uint8_t* const* d_frames, const int* d_crop_stream, const float* d_boxes,
+                    int box_stride, int n, int W, int H, hipStream_t st) {
+        if (n > max_crops_) throw std::runtime_error("ReID: crop batch exceeds max_crops");
+        if (n == 0) return;
+        const int rows_per_block = 16;
+        hipLaunchKernelGGL(k_crop_resize<float>, dim3(n, REID_IN_H / rows_per_block), dim3(REID_IN_W), 0, st,
+                           d_frames, d_crop_stream, d_boxes, box_stride, W, H, d_lut_, crops_, rows_per_block);
+    }
+
+    // full path; out row of crop i is out_rows ? out_rows[i] : i, rows of `feat` floats.
+    // Crops are processed in chunks of max_crops_ (activation buffers are sized for one chunk).
+    void run(const uint8_t* const* d_frames, const int* d_crop_stream, const float* d_boxes, int box_stride,
+             int n, int W, int H, float* d_out, const int* d_out_rows, hipStream_t st) {
+        if (n == 0) return;
+        BM_HIP(hipEventRecord(ev_[0], st));
+        for (int i0 = 0; i0 < n; i0 += max_crops_) {
+            const int m = (n - i0) < max_crops_ ? (n - i0) : max_crops_;
+            preprocess(d_frames, d_crop_stream + i0, d_boxes + (long)i0 * box_stride, box_stride, m, W, H, st);
+            if (i0 == 0) BM_HIP(hipEventRecord(ev_[1], st));
+            hipEvent_t a = take_event(), b = take_event();
+            BM_HIP(hipEventRecord(a, st));
+            forward_v1(m, d_out_rows ? d_out : d_out + (long)i0 * L_.feat, d_out_rows ? d_out_rows + i0 : nullptr, st);
+            BM_HIP(hipEventRecord(b, st));
+            if (pending_.size() < 4096) pending_.emplace_back(a, b);
+            else { free_events_.push_back(a); free_events_.push_back(b); }
+        }
+        BM_HIP(hipEventRecord(ev_[2], st));
+        timed_ = true;
+    }
+    // Accumulated device time of the forward region (events ev_[1]..ev_[2]) over the runs since the
+    // last drain.  Every run() keeps its own event pair (ring of 64) so a timed loop needs no sync.
+    void drain_kernel_timing(double& ms, int& launches) {
+        ms = 0; launches = 0;
+        for (auto& p : pending_) {
+            float t = 0;
+            if (hipEventSynchronize(p.second) == hipSuccess && hipEventElapsedTime(&t, p.first, p.second) == hipSuccess) {
+                ms += t; ++launches;
+            }
+            free_events_.push_back(p.first); free_events_.push_back(p.second);
+        }
+        pending_.clear();
+    }
+    // (pre, process) device milliseconds of the last run(); call after a stream sync
+    void last_times(double& pre, double& proc) {
+        pre = proc = 0.0;
+        if (!timed_) return;
+        float a = 0, b = 0;
+        if (hipEventElapsedTime(&a, ev_[0], ev_[1]) == hipSuccess) pre = a;
+        if (hipEventElapsedTime(&b, ev_[1], ev_[2]) == hipSuccess) proc = b;
+    }
+
+private:
+    hipEvent_t take_event() {
+        if (!free_events_.empty()) { hipEvent_t e = free_events_.back(); free_events_.pop_back(); return e; }
+        hipEvent_t e;
+        BM_HIP(hipEventCreate(&e));
+        all_events_.push_back(e);
+        return e;
+    }
+    template <int CO_T>
+    void pointwise(const float* in, long w, long b, const float* res, float* out, long n_pix, int cin, int cout,
+                   int relu, hipStream_t st) {
+        int co_chunk = (8192 / cin) / CO_T * CO_T;          // <= 32 KB of weights per workgroup
+        if (co_chunk > cout) co_chunk = cout;
+        if (co_chunk < CO_T) co_chunk = CO_T;
+        const int n_chunks = (cout + co_chunk - 1) / co_chunk;
+        const long threads = n_pix * (co_chunk / CO_T);
+        const int bs = 256;
+        const size_t smem = ((size_t)co_chunk * cin + co_chunk) * sizeof(float);
+        hipLaunchKernelGGL((k_pointwise<float, CO_T>), dim3((unsigned)((threads + bs - 1) / bs), n_chunks), dim3(bs),
+                           smem, st, in, d_w_ + w, b >= 0 ? d_w_ + b : nullptr, res, out, n_pix, cin, cout, relu,
+                           co_chunk);
+    }
+    void pw(const float* in, long w, long b, const float* res, float* out, long n_pix, int cin, int cout, int relu,
+            hipStream_t st) {
+        if (cout % 16 == 0) pointwise<16>(in, w, b, res, out, n_pix, cin, cout, relu, st);
+        else pointwise<8>(in, w, b, res, out, n_pix, cin, cout, relu, st);
+    }
+    void osblock(const BlockW& B, const float* x, float* out, int n, int H, int W, hipStream_t st) {
+        const int P = H * W;
+        const long n_pix = (long)n * P;
+        const long n_mid = n_pix * B.mid;
+        const int bs = 256;
+        pw(x, B.conv1_w, B.conv1_b, nullptr, x1_, n_pix, B.cin, B.mid, 1, st);
+        int li = 0;
+        for (int br = 0; br < 4; ++br) {
+            const float* cur = x1_;
+            for (int k = 0; k <= br; ++k, ++li) {
+                float* dst = (k & 1) ? tb_ : ta_;
+                // 1x1 linear (no bias) then depthwise 3x3 + BN + ReLU
+                pw(cur, B.light[li].pw, -1, nullptr, tt_, n_pix, B.mid, B.mid, 0, st);
+                hipLaunchKernelGGL(k_depthwise3x3<float>, dim3((unsigned)((n_mid + bs - 1) / bs)), dim3(bs), 0, st,
+                                   tt_, d_w_ + B.light[li].dw, d_w_ + B.light[li].b, dst, H, W, B.mid, n_mid);
+                cur = dst;
+            }
+            hipLaunchKernelGGL(k_gap<float>, dim3(n), dim3(768), 0, st, cur, gap_, P, B.mid);
+            const int ppb = 64;
+            hipLaunchKernelGGL(k_gate_accumulate<float>, dim3(n, (P + ppb - 1) / ppb), dim3(256), 0, st, cur, gap_,
+                               d_w_ + B.fc1_w, d_w_ + B.fc1_b, d_w_ + B.fc2_w, d_w_ + B.fc2_b, acc_, P, B.mid, B.hid,
+                               br == 0 ? 1 : 0, ppb);
+        }
+        const float* identity = x;
+        if (B.down_w >= 0) {
+            pw(x, B.down_w, B.down_b, nullptr, idn_, n_pix, B.cin, B.cout, 0, st);
+            identity = idn_;
+        }
+        pw(acc_, B.conv3_w, B.conv3_b, identity, out, n_pix, B.mid, B.cout, 1, st);
+    }
+    void forward_v1(int n, float* d_out, const int* d_out_rows, hipStream_t st) {
+        const int bs = 256;
+        const int c0 = L_.c[0];
+        const long stem_pix = (long)n * 128 * 64;
+        if (c0 == 16)
+            hipLaunchKernelGGL((k_stem_conv<float, 16>), dim3((unsigned)((stem_pix + bs - 1) / bs)), dim3(bs), 0, st,
+                               crops_, d_w_ + L_.stem_w, d_w_ + L_.stem_b, big_a_, stem_pix);
+        else
+            hipLaunchKernelGGL((k_stem_conv<float, 64>), dim3((unsigned)((stem_pix + 63) / 64)), dim3(64), 0, st,
+                               crops_, d_w_ + L_.stem_w, d_w_ + L_.stem_b, big_a_, stem_pix);
+        long tot = (long)n * 64 * 32 * c0;
+        hipLaunchKernelGGL(k_maxpool3x3s2<float>, dim3((unsigned)((tot + bs - 1) / bs)), dim3(bs), 0, st, big_a_, big_b_,
+                           128, 64, c0, tot);
+        float* cur = big_b_;
+        float* other = big_a_;
+        int H = 64, W = 32;
+        for (int s = 0; s < 3; ++s) {
+            for (int k = 0; k < 2; ++k) {
+                osblock(L_.block[s * 2 + k], cur, other, n, H, W, st);
+                std::swap(cur, other);
+            }
+            if (s < 2) {
+                const int c = L_.c[s + 1];
+                const long n_pix = (long)n * H * W;
+                pw(cur, L_.trans_w[s], L_.trans_b[s], nullptr, other, n_pix, c, c, 1, st);
+                tot = (long)n * (H / 2) * (W / 2) * c;
+                hipLaunchKernelGGL(k_avgpool2x2<float>, dim3((unsigned)((tot + bs - 1) / bs)), dim3(bs), 0, st, other, cur,
+                                   H, W, c, tot);
+                H /= 2; W /= 2;
+            }
+        }
+        const int c3 = L_.c[3];
+        pw(cur, L_.conv5_w, L_.conv5_b, nullptr, other, (long)n * H * W, c3, c3, 1, st);
+        hipLaunchKernelGGL(k_head<float>, dim3(n), dim3(256), 0, st, other, d_w_ + L_.fc_w, d_w_ + L_.fc_b, d_out,
+                           d_out_rows, H * W, c3, L_.feat);
+    }
+    void alloc_buffers() {
+        const size_t n = (size_t)max_crops_;
+        crops_ = dev_alloc<float>(n * REID_IN_H * REID_IN_W * 3, owned_);
+        const size_t big = n * 128 * 64 * (size_t)L_.c[0];            // stem output is the largest tensor
+        const size_t s1 = n * 64 * 32 * (size_t)L_.c[1];
+        big_a_ = dev_alloc<float>(big > s1 ? big : s1, owned_);
+        big_b_ = dev_alloc<float>(big > s1 ? big : s1, owned_);
+        idn_ = dev_alloc<float>(s1, owned_);
+        const size_t mid_max = n * 64 * 32 * (size_t)(L_.c[1] / 4);   // mid tensors shrink with depth
+        const size_t m2 = n * 32 * 16 * (size_t)(L_.c[2] / 4), m3 = n * 16 * 8 * (size_t)(L_.c[3] / 4);
+        size_t mid = mid_max > m2 ? mid_max : m2;
+        mid = mid > m3 ? mid : m3;
+        x1_ = dev_alloc<float>(mid, owned_);
+        ta_ = dev_alloc<float>(mid, owned_);
+        tb_ = dev_alloc<float>(mid, owned_);
+        tt_ = dev_alloc<float>(mid, owned_);
+        acc_ = dev_alloc<float>(mid, owned_);
+        gap_ = dev_alloc<float>(n * 512, owned_);
+    }
+
+    OsnetLayout L_;
+    int max_crops_;
+    int mode_ = 0;
+    bool timed_ = false;
+    std::vector<void*> owned_;
+    std::vector<float> h_w_;
+    float* d_w_ = nullptr;
+    float* d_lut_ = nullptr;
+    float *crops_ = nullptr, *big_a_ = nullptr, *big_b_ = nullptr, *idn_ = nullptr;
+    float *x1_ = nullptr, *ta_ = nullptr, *tb_ = nullptr, *tt_ = nullptr, *acc_ = nullptr, *gap_ = nullptr;
+    hipEvent_t ev_[3];
+    std::vector<hipEvent_t> all_events_, free_events_;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_;
+};
+
+}  // namespace bm

@@ -1,0 +1,65 @@
+"""Factory slot: ``create_tracker(..., tracker_backend="hip")``.
+
+Same call shape as the reference factory (boxmot/trackers/tracker_zoo.py:33-147):
+the tracker's YAML defaults ``{param: {default: ...}}`` are flattened to keyword
+arguments, ``reid_weights`` / ``reid_model`` select the ReID backend, and the
+backend name picks the implementation -- here the closed set is {"hip"}
+(the reference's is {"python", "cpp"}, boxmot/trackers/specs.py:6).
+"""
+from __future__ import annotations
+
+from pathlib import Path
+
+import yaml
+
+from boxmot_amd.botsort import BotSort
+
+# boxmot/configs/trackers/botsort.yaml defaults (what create_tracker applies when no config is given)
+BOTSORT_YAML_DEFAULTS = dict(
+    track_high_thresh=0.6296854875023994, track_low_thresh=0.1014392537025336,
+    new_track_thresh=0.6246494191492591, track_buffer=40, match_thresh=0.7722224024589055,
+    use_cmc=True, cmc_method="sof", frame_rate=30, fuse_first_associate=True, with_reid=True,
+    proximity_thresh=0.6084297894561342, appearance_thresh=0.6188818853936099,
+    unconfirmed_emb_scale=2.5445206391993294, second_match_thresh=0.28795081514328974,
+    unconfirmed_match_thresh=0.41148010638233784, removed_stracks_buffer=329,
+)
+SUPPORTED = ("botsort",)
+
+
+def flatten_yaml_config(cfg: dict) -> dict:
+    """{param: {default, activates: {...}}} -> {param: default} (tracker_zoo.py:112-119)."""
+    out = {}
+    for key, spec in cfg.items():
+        if isinstance(spec, dict) and "default" in spec:
+            out[key] = spec["default"]
+            for sub, sub_spec in (spec.get("activates") or {}).items():
+                out[sub] = sub_spec["default"] if isinstance(sub_spec, dict) else sub_spec
+        else:
+            out[key] = spec
+    return out
+
+
+def create_tracker(tracker_type: str = "botsort", tracker_config=None, reid_weights=None, device=None, half=None,
+                   per_class: bool = False, evolve_param_dict: dict | None = None, reid_preprocess=None,
+                   reid_model=None, tracker_backend: str = "hip", **overrides):
+    if tracker_backend != "hip":
+        raise ValueError(f"tracker_backend={tracker_backend!r}: boxmot_amd provides the 'hip' backend only")
+    if tracker_type not in SUPPORTED:
+        raise NotImplementedError(f"tracker {tracker_type!r} is not implemented on the HIP backend (have: {SUPPORTED})")
+    if reid_preprocess not in (None, "resize"):
+        raise NotImplementedError("only the 'resize' ReID preprocess is implemented")
+    if evolve_param_dict is not None:
+        kwargs = dict(evolve_param_dict)
+    elif tracker_config is None:
+        kwargs = dict(BOTSORT_YAML_DEFAULTS)
+    elif isinstance(tracker_config, dict):
+        kwargs = flatten_yaml_config(tracker_config)
+    else:
+        kwargs = flatten_yaml_config(yaml.safe_load(Path(tracker_config).read_text()))
+    kwargs.update(overrides)
+    kwargs["per_class"] = per_class
+    if kwargs.get("with_reid", True) and reid_model is None and reid_weights is not None:
+        from boxmot_amd.reid import HipReID
+
+        reid_model = HipReID(reid_weights)
+    return BotSort(reid_model=reid_model, **kwargs)

@@ -1,0 +1,170 @@
+/*
+ * boxmot_hip.h -- C ABI of the MI355X (gfx950) BoT-SORT update path.
+ *
+ * Drop-in boundary: these entry points are what the reference's native FFI for
+ * this path binds (boxmot/native/cpp/trackers/botsort/include/botsort/c_api.hpp:17-61,
+ * mirrored in Python by boxmot/native/trackers/botsort.py:94-146 and called through
+ * boxmot/native/trackers/_common.py:158-221).  Conventions are the reference's:
+ *   - plain C, opaque handle, caller owns every buffer, inputs row-major
+ *     contiguous fp32 / uint8, output buffer caller-allocated (rows x 9 fp32);
+ *   - return 1 on success, 0 on failure; the message of the last failure on the
+ *     calling thread is returned by boxmot_hip_last_error();
+ *   - a handle is not thread-safe; distinct handles may be used concurrently.
+ * Differences from the precedent, all deliberate (DESIGN.md "Boundary"):
+ *   - thresholds are double: the Python tracker (the parity oracle) compares in
+ *     fp64 and its YAML defaults are not representable in fp32;
+ *   - second_match_thresh / unconfirmed_match_thresh / unconfirmed_emb_scale /
+ *     removed_stracks_buffer are configurable (the C++ reference hard-codes them,
+ *     tracker.cpp:435,465,476; the Python reference exposes them, botsort.py:81-85);
+ *   - one handle owns n_streams independent trackers advanced by one launch set
+ *     (boxmot_hip_botsort_update_batch / _step_device);
+ *   - camera-motion compensation is not implemented: cmc_method must be NULL,
+ *     "" or "none" (create fails otherwise).
+ * There is no CPU fallback: every entry point fails with an error when no HIP
+ * device is usable.
+ */
+#ifndef BOXMOT_HIP_H
+#define BOXMOT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* replaces BoxMOTBotSortConfig, c_api.hpp:17-32 */
+typedef struct BoxMOTHipBotSortConfig {
+    double track_high_thresh;
+    double track_low_thresh;
+    double new_track_thresh;
+    int track_buffer;
+    double match_thresh;
+    double proximity_thresh;
+    double appearance_thresh;
+    const char* cmc_method;          /* NULL / "" / "none" only */
+    int frame_rate;
+    int fuse_first_associate;
+    int with_reid;
+    int max_obs;                     /* accepted for signature parity; display-only state */
+    const char* reid_model_path;     /* OSN1 weight blob (boxmot_amd.reid_weights.save_blob) or NULL */
+    const char* reid_preprocess;     /* NULL or "resize" */
+    double second_match_thresh;
+    double unconfirmed_match_thresh;
+    double unconfirmed_emb_scale;
+    int removed_stracks_buffer;
+    /* capacity / batching */
+    int n_streams;                   /* >= 1 independent trackers in this handle */
+    int max_tracks;                  /* track slots per stream (live + lost) */
+    int max_dets;                    /* detections per frame per stream */
+    int emb_dim;                     /* appearance vector length (512 for OSNet) */
+    int n_class_lists;               /* 1, or nr_classes when per_class=True */
+} BoxMOTHipBotSortConfig;
+
+typedef struct BoxMOTHipBotSort BoxMOTHipBotSort;
+typedef struct BoxMOTHipReID BoxMOTHipReID;
+
+/* fills the constructor defaults of BotSort (botsort.py:66-86) */
+void boxmot_hip_botsort_default_config(BoxMOTHipBotSortConfig* config);
+
+/* boxmot_botsort_create / _destroy / _reset, c_api.hpp:36-40 */
+BoxMOTHipBotSort* boxmot_hip_botsort_create(const BoxMOTHipBotSortConfig* config);
+void boxmot_hip_botsort_destroy(BoxMOTHipBotSort* handle);
+int boxmot_hip_botsort_reset(BoxMOTHipBotSort* handle);
+
+/* boxmot_botsort_update, c_api.hpp:42-55: one frame of stream 0, synchronous. */
+int boxmot_hip_botsort_update(
+    BoxMOTHipBotSort* handle,
+    const float* dets, int det_rows, int det_cols,
+    const float* embs, int emb_rows, int emb_cols,
+    const uint8_t* image, int image_rows, int image_cols, int image_channels,
+    float* out_tracks, int out_capacity_rows, int out_cols,
+    int* out_rows, int* out_is_obb);
+
+/* Same, for stream `stream` and active-list (class) `class_list`; `frame_count`
+ * >= 0 sets the tracker's frame counter before the step (per-class fan-out,
+ * basetracker.py:223-263), -1 leaves it alone. */
+int boxmot_hip_botsort_update_stream(
+    BoxMOTHipBotSort* handle, int stream, int class_list, int frame_count,
+    const float* dets, int det_rows, int det_cols,
+    const float* embs, int emb_rows, int emb_cols,
+    const uint8_t* image, int image_rows, int image_cols, int image_channels,
+    float* out_tracks, int out_capacity_rows, int out_cols,
+    int* out_rows, int* out_is_obb);
+
+/* One frame for each of the first n_streams streams in one launch set.
+ * dets[s] -> (det_rows[s], 6) fp32; embs[s] -> (det_rows[s], emb_cols) fp32 or embs == NULL;
+ * images[s] -> (rows, cols, 3) uint8 BGR or NULL to keep the previously uploaded frame;
+ * out[s] -> (out_capacity_rows, 9) fp32. */
+int boxmot_hip_botsort_update_batch(
+    BoxMOTHipBotSort* handle, int n_streams,
+    const float* const* dets, const int* det_rows,
+    const float* const* embs, int emb_cols,
+    const uint8_t* const* images, int image_rows, int image_cols, int image_channels,
+    float* const* out_tracks, int out_capacity_rows, int* out_rows);
+
+/* Device-resident step for all streams (asynchronous on the handle's stream):
+ *   d_dets   [n_streams][max_dets][6] fp32, d_det_rows [n_streams] int32,
+ *   d_embs   [n_streams][max_dets][emb_dim] fp32 or NULL (NULL + with_reid -> ReID runs on d_frames),
+ *   d_frames device array of n_streams device pointers to (rows, cols, 3) uint8 BGR frames, or NULL,
+ *   d_out    [n_streams][max_dets][8] fp32, d_out_rows [n_streams] int32.
+ * Call boxmot_hip_botsort_synchronize() before reading the outputs. */
+int boxmot_hip_botsort_step_device(
+    BoxMOTHipBotSort* handle,
+    const float* d_dets, const int* d_det_rows, const float* d_embs,
+    const uint8_t* const* d_frames, int image_rows, int image_cols,
+    float* d_out, int* d_out_rows);
+int boxmot_hip_botsort_synchronize(BoxMOTHipBotSort* handle);
+/* the hipStream_t the handle launches on (as void*), for event timing by the caller */
+void* boxmot_hip_botsort_stream(BoxMOTHipBotSort* handle);
+/* HIP-event stopwatch on the handle's stream: start records an event, stop records a second one,
+ * synchronises on it and returns the elapsed device milliseconds in between. */
+int boxmot_hip_botsort_timer_start(BoxMOTHipBotSort* handle);
+int boxmot_hip_botsort_timer_stop_ms(BoxMOTHipBotSort* handle, double* out_ms);
+/* accumulated device milliseconds of the ReID forward kernels since the last call (and their count) */
+int boxmot_hip_botsort_reid_kernel_ms(BoxMOTHipBotSort* handle, double* out_ms, int* out_launches);
+/* per-stream status words (0 ok, 1 track capacity, 2 class capacity, 3 assignment stall) */
+int boxmot_hip_botsort_status(BoxMOTHipBotSort* handle, int* out_status, int capacity);
+
+/* ReID weights from memory (same blob format as reid_model_path). */
+int boxmot_hip_botsort_set_reid_blob(BoxMOTHipBotSort* handle, const float* blob, long n_floats);
+/* precision / kernel family of the ReID engine: 0 = per-layer fp32 kernels, 1 = fused fp16 MFMA kernels */
+int boxmot_hip_botsort_set_reid_mode(BoxMOTHipBotSort* handle, int mode);
+
+/* boxmot_botsort_last_reid_*_time_ms, c_api.hpp:57-60 (device time of the last update, HIP events) */
+int boxmot_hip_botsort_last_reid_time_ms(BoxMOTHipBotSort* handle, double* out_ms);
+int boxmot_hip_botsort_last_reid_preprocess_time_ms(BoxMOTHipBotSort* handle, double* out_ms);
+int boxmot_hip_botsort_last_reid_process_time_ms(BoxMOTHipBotSort* handle, double* out_ms);
+int boxmot_hip_botsort_last_reid_postprocess_time_ms(BoxMOTHipBotSort* handle, double* out_ms);
+int boxmot_hip_botsort_last_track_time_ms(BoxMOTHipBotSort* handle, double* out_ms);
+
+/* Parity/debug: copy the live tracks of one stream to host arrays sized for max_tracks rows.
+ * which = 0 active list `class_list`, 1 lost list.  Returns the row count in *out_rows.
+ * ints[r] = {id, state, is_activated, frame_id, start_frame, tracklet_len},
+ * kf[r] = mean[8] ++ cov[64] fp64, smooth[r] = emb_dim fp32, misc[r] = {conf, cls, det_ind}. */
+int boxmot_hip_botsort_state_dump(
+    BoxMOTHipBotSort* handle, int stream, int which, int class_list,
+    int* ints, double* kf, float* smooth, float* misc, int* out_rows,
+    int* out_frame_count, int* out_id_count);
+
+/* ReID C ABI, replaces boxmot_reid_capi_* (boxmot/native/cpp/trackers/base/include/boxmot/trackers/base/reid_capi.h:36-94) */
+BoxMOTHipReID* boxmot_hip_reid_create(const char* model_path, const float* blob, long n_floats, int max_crops);
+void boxmot_hip_reid_destroy(BoxMOTHipReID* handle);
+int boxmot_hip_reid_feature_dim(BoxMOTHipReID* handle);
+int boxmot_hip_reid_set_mode(BoxMOTHipReID* handle, int mode);
+/* boxes (n, box_cols>=4) fp32 xyxy; out (n, feature_dim) fp32, L2-normalised */
+int boxmot_hip_reid_compute_features(
+    BoxMOTHipReID* handle, const uint8_t* image, int image_rows, int image_cols, int image_channels,
+    const float* boxes, int n_boxes, int box_cols, float* out_features, int out_capacity_rows);
+/* intermediate: normalised crops (n, 256, 128, 3) fp32 NHWC, RGB */
+int boxmot_hip_reid_preprocess(
+    BoxMOTHipReID* handle, const uint8_t* image, int image_rows, int image_cols, int image_channels,
+    const float* boxes, int n_boxes, int box_cols, float* out_crops);
+
+const char* boxmot_hip_last_error(void);
+/* number of visible HIP devices (0 when none / runtime unusable) */
+int boxmot_hip_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BOXMOT_HIP_H */

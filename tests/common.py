@@ -1,0 +1,38 @@
+"""Shared helpers for the parity tests (inputs are regenerated from seeds; expected rows come
+from tests/golden, produced by the real reference -- see tests/golden/make_golden.py)."""
+from __future__ import annotations
+
+from pathlib import Path
+
+import numpy as np
+
+from boxmot_amd.scenario import Scenario, stress_frames
+from boxmot_amd.tracker_zoo import BOTSORT_YAML_DEFAULTS
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+YAML = {k: v for k, v in BOTSORT_YAML_DEFAULTS.items() if k not in ("use_cmc", "cmc_method", "with_reid")}
+
+CASES = {
+    "stress_default": (lambda: stress_frames(150, seed=7), (480, 640), {}, 32),
+    "stress_yaml": (lambda: stress_frames(150, seed=7), (480, 640), YAML, 32),
+    "stress_short_buffer": (lambda: stress_frames(150, seed=11), (480, 640), dict(track_buffer=5, removed_stracks_buffer=3), 32),
+    "c2_yaml": (lambda: Scenario(64, 256, random_image=False).frames(40), (1080, 1920), YAML, 512),
+    "c2_default": (lambda: Scenario(64, 256, random_image=False).frames(40), (1080, 1920), {}, 512),
+}
+
+
+def golden_rows(name):
+    g = np.load(GOLDEN / "botsort_golden.npz")
+    rows, counts = g[name + "_rows"], g[name + "_counts"]
+    offs = np.concatenate([[0], np.cumsum(counts)])
+    return [rows[offs[i]:offs[i + 1]] for i in range(len(counts))], g
+
+
+def assert_rows_match(got, want, frame, box_atol=1e-4):
+    got = np.asarray(got, dtype=np.float32).reshape(-1, 8)
+    want = np.asarray(want, dtype=np.float32).reshape(-1, 8)
+    assert got.shape == want.shape, f"frame {frame}: {got.shape} vs {want.shape}"
+    # ids, conf, cls, det_ind and the row order are exact; boxes come from the fp64 Kalman state
+    assert np.array_equal(got[:, 4:], want[:, 4:]), f"frame {frame}: id/conf/cls/det_ind columns differ"
+    assert np.allclose(got[:, :4], want[:, :4], rtol=0, atol=box_atol), (
+        f"frame {frame}: boxes differ by {np.abs(got[:, :4] - want[:, :4]).max()}")

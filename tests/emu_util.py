@@ -1,0 +1,70 @@
+"""TEST-ONLY ctypes driver for tests/host_emu (device kernel source run on CPU threads)."""
+from __future__ import annotations
+
+import ctypes
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent / "host_emu"
+LIB = HERE / "libemu_botsort.so"
+
+CFG_D = ("track_high_thresh", "track_low_thresh", "new_track_thresh", "match_thresh", "proximity_thresh",
+         "appearance_thresh", "second_match_thresh", "unconfirmed_match_thresh", "unconfirmed_emb_scale")
+CFG_I = ("fuse_first_associate", "with_reid", "frame_rate", "track_buffer", "removed_stracks_buffer")
+
+
+def build(sanitize: bool = False) -> Path:
+    src = HERE / "emu_botsort.cpp"
+    deps = [src, HERE / "hip_shim.hpp"] + list((HERE.parent.parent / "boxmot_amd" / "csrc").glob("botsort_*.hpp")) \
+        + [HERE.parent.parent / "boxmot_amd" / "csrc" / "block_prims.hpp"]
+    out = HERE / ("libemu_botsort_asan.so" if sanitize else "libemu_botsort.so")
+    if not out.exists() or any(d.stat().st_mtime > out.stat().st_mtime for d in deps):
+        flags = ["-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-pthread"]
+        if sanitize:
+            flags += ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"]
+        subprocess.check_call(["g++", *flags, "-o", str(out), str(src)])
+    return out
+
+
+class EmuBotSort:
+    def __init__(self, cfg: dict, cap=256, nd=64, dim=32, sanitize=False):
+        self.lib = ctypes.CDLL(str(build(sanitize)))
+        self.lib.emu_create.restype = ctypes.c_void_p
+        self.lib.emu_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        self.lib.emu_update.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                        ctypes.c_void_p, ctypes.c_void_p]
+        self.lib.emu_dump.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 5
+        self.lib.emu_destroy.argtypes = [ctypes.c_void_p]
+        cd = np.array([cfg[k] for k in CFG_D], dtype=np.float64)
+        ci = np.array([int(cfg[k]) for k in CFG_I], dtype=np.int32)
+        self.cap, self.nd, self.dim = cap, nd, dim
+        self.h = self.lib.emu_create(cd.ctypes.data, ci.ctypes.data, cap, nd, dim)
+
+    def update(self, dets, embs=None):
+        dets = np.ascontiguousarray(dets, dtype=np.float32).reshape(-1, 6)
+        n = len(dets)
+        e = None if embs is None else np.ascontiguousarray(embs, dtype=np.float32)
+        out = np.zeros((self.nd, 8), dtype=np.float32)
+        out_n = ctypes.c_int(0)
+        status = self.lib.emu_update(self.h, dets.ctypes.data, n, None if e is None else e.ctypes.data,
+                                     out.ctypes.data, ctypes.byref(out_n))
+        if status != 0:
+            raise RuntimeError(f"emulated kernel status {status}")
+        return out[: out_n.value].copy()
+
+    def dump(self, which):
+        ints = np.zeros((self.cap, 6), dtype=np.int32)
+        kf = np.zeros((self.cap, 72), dtype=np.float64)
+        sm = np.zeros((self.cap, self.dim), dtype=np.float32)
+        misc = np.zeros((self.cap, 3), dtype=np.float32)
+        cnt = np.zeros(3, dtype=np.int32)
+        n = self.lib.emu_dump(self.h, which, ints.ctypes.data, kf.ctypes.data, sm.ctypes.data, misc.ctypes.data,
+                              cnt.ctypes.data)
+        return dict(n=n, ints=ints[:n], kf=kf[:n], smooth=sm[:n], misc=misc[:n], counters=cnt)
+
+    def close(self):
+        if self.h:
+            self.lib.emu_destroy(self.h)
+            self.h = None

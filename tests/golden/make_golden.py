@@ -1,0 +1,87 @@
+"""Generate the committed golden fixtures by running the REAL reference
+(/root/reference, imported under the stand-ins documented in oracle/ref_harness.py).
+
+Run in the build container only:  python tests/golden/make_golden.py
+Outputs (small, committed):
+  tests/golden/botsort_golden.npz  per-frame output rows of the reference BotSort on seeded
+                                   scenarios (inputs are regenerated from the seed by the tests)
+  tests/golden/reid_golden.npz     a seeded OSNet-x0.25 state_dict, test boxes, and the reference
+                                   BaseModelBackend.get_features / get_crops results for them
+The lap / cv2 stand-ins make those two boundaries "parity unpinned" (see oracle/__init__.py).
+"""
+from __future__ import annotations
+
+import logging
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+
+from boxmot_amd.reid_weights import random_osnet_state_dict  # noqa: E402
+from boxmot_amd.scenario import Scenario, stress_frames  # noqa: E402
+from boxmot_amd.tracker_zoo import BOTSORT_YAML_DEFAULTS  # noqa: E402
+from oracle import ref_harness  # noqa: E402
+
+OUT = Path(__file__).resolve().parent
+YAML = {k: v for k, v in BOTSORT_YAML_DEFAULTS.items() if k not in ("use_cmc", "cmc_method", "with_reid")}
+
+CASES = {
+    # name: (frames factory, image shape, tracker kwargs)
+    "stress_default": (lambda: stress_frames(150, seed=7), (480, 640), {}),
+    "stress_yaml": (lambda: stress_frames(150, seed=7), (480, 640), YAML),
+    "stress_short_buffer": (lambda: stress_frames(150, seed=11), (480, 640), dict(track_buffer=5, removed_stracks_buffer=3)),
+    "c2_yaml": (lambda: Scenario(64, 256, random_image=False).frames(40), (1080, 1920), YAML),
+    "c2_default": (lambda: Scenario(64, 256, random_image=False).frames(40), (1080, 1920), {}),
+}
+REID_BOXES = np.array([
+    [30.2, 40.7, 90.1, 200.3], [-10.0, -5.0, 60.0, 120.0], [1800.5, 900.5, 1990.0, 1100.0],
+    [100.0, 100.0, 100.0, 150.0], [400.0, 300.0, 656.0, 812.0], [10.5, 10.5, 138.5, 266.5],
+    [700.49, 200.5, 752.51, 254.5], [5.0, 5.0, 8.0, 9.0],
+], dtype=np.float32)
+
+
+def main():
+    logging.disable(logging.CRITICAL)
+    BotSort = ref_harness.load_botsort()
+    out = {}
+    for name, (make, hw, kw) in CASES.items():
+        frames = make()
+        img = np.zeros((hw[0], hw[1], 3), dtype=np.uint8)
+        trk = BotSort(reid_model=None, with_reid=True, use_cmc=False, **kw)
+        rows, counts = [], []
+        for dets, embs in frames:
+            r = np.asarray(trk.update(dets.copy(), img, embs.copy()), dtype=np.float32).reshape(-1, 8)
+            rows.append(r)
+            counts.append(len(r))
+        out[name + "_rows"] = np.concatenate(rows, 0)
+        out[name + "_counts"] = np.array(counts, dtype=np.int32)
+        act = trk.active_tracks
+        out[name + "_final_mean"] = np.array([t.mean for t in act], dtype=np.float64).reshape(len(act), 8)
+        out[name + "_final_cov"] = np.array([t.covariance for t in act], dtype=np.float64).reshape(len(act), 8, 8)
+        out[name + "_final_ids"] = np.array([t.id for t in act], dtype=np.int64)
+        print(name, "frames", len(frames), "rows", sum(counts))
+    np.savez_compressed(OUT / "botsort_golden.npz", **out)
+
+    import torch
+
+    sd = random_osnet_state_dict("osnet_x0_25", seed=1234)
+    mod = ref_harness.load_osnet_module()
+    model = mod.osnet_x0_25(num_classes=1041, pretrained=False).eval()
+    missing = model.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys and all(k.startswith("classifier") for k in missing.missing_keys), missing
+    img = np.random.default_rng(99).integers(0, 255, (1080, 1920, 3), dtype=np.uint8)
+    ref = ref_harness.RefReID(model)
+    feats = ref.get_features(REID_BOXES, img)
+    crops = ref.get_crops(REID_BOXES, img).numpy()
+    blob = {("sd/" + k): v.numpy() for k, v in sd.items() if not k.endswith("num_batches_tracked")}
+    np.savez_compressed(OUT / "reid_golden.npz", boxes=REID_BOXES, feats=feats.astype(np.float32),
+                        crop0=crops[0], crop_sums=crops.reshape(len(crops), -1).astype(np.float64).sum(1),
+                        image_seed=np.array(99), **blob)
+    print("reid feats", feats.shape, "crop sums", crops.reshape(len(crops), -1).sum(1)[:3])
+
+
+if __name__ == "__main__":
+    main()

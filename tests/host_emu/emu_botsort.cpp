@@ -1,0 +1,127 @@
+// TEST-ONLY harness: runs bm::botsort_step_stream (the device source, unchanged)
+// on CPU threads through hip_shim.hpp.  See hip_shim.hpp for scope and limits.
+#include "hip_shim.hpp"
+
+#include <cstdlib>
+#include <vector>
+
+#include "../../boxmot_amd/csrc/botsort_alloc.hpp"
+#include "../../boxmot_amd/csrc/botsort_step.hpp"
+
+thread_local EmuDim3 threadIdx;
+thread_local EmuDim3 blockIdx;
+EmuDim3 blockDim;
+EmuBlock* g_emu_block = nullptr;
+
+namespace {
+
+constexpr int NTHR = 64;   // one emulated wavefront per workgroup keeps barrier cost low
+
+struct HostAlloc {
+    std::vector<void*> owned;
+    template <typename T> T* get(size_t n) {
+        void* p = std::calloc(n ? n : 1, sizeof(T));
+        owned.push_back(p);
+        return static_cast<T*>(p);
+    }
+};
+
+struct Emu {
+    bm::BotSortStepArgs args{};
+    HostAlloc alloc;
+    int cap, nd, dim;
+    float* dets; int* n_dets; float* embs; float* out; int* out_n;
+    EmuBlock block;
+};
+
+struct ThreadArg { Emu* e; int tid; };
+
+int* g_s_int; double* g_s_dbl;
+float (*g_sA)[bm::COST_KC + 1];
+float (*g_sB)[bm::COST_KC + 1];
+
+void* thread_main(void* p) {
+    ThreadArg* ta = static_cast<ThreadArg*>(p);
+    threadIdx.x = ta->tid;
+    blockIdx.x = 0;
+    bm::botsort_step_stream<NTHR>(ta->e->args, 0, g_s_int, g_s_dbl, g_sA, g_sB);
+    return nullptr;
+}
+
+}  // namespace
+
+extern "C" {
+
+void* emu_create(const double* cd, const int* ci, int cap, int nd, int dim) {
+    Emu* e = new Emu();
+    e->cap = cap; e->nd = nd; e->dim = dim;
+    e->args.cfg = bm::make_config_dev(cd[0], cd[1], cd[2], cd[3], cd[4], cd[5], cd[6], cd[7], cd[8], ci[0], ci[1], ci[2],
+                                      ci[3], ci[4]);
+    bm::BotSortSizes z{1, cap, nd, dim, 1, ci[4] > 0 ? ci[4] : 1};
+    bm::botsort_allocate(e->args, z, e->alloc);
+    e->dets = e->alloc.get<float>((size_t)nd * bm::DET_COLS);
+    e->n_dets = e->alloc.get<int>(1);
+    e->embs = e->alloc.get<float>((size_t)nd * dim);
+    e->out = e->alloc.get<float>((size_t)nd * bm::OUT_COLS);
+    e->out_n = e->alloc.get<int>(1);
+    e->args.dets = e->dets; e->args.n_dets = e->n_dets; e->args.embs = e->embs;
+    e->args.list_sel = nullptr; e->args.frame_count_set = nullptr;
+    e->args.out = e->out; e->args.out_n = e->out_n; e->args.stream_base = 0;
+    e->block.block_barrier.init(NTHR);
+    for (int w = 0; w < EMU_MAX_WAVES; ++w) e->block.wave_barrier[w].init(EMU_WAVE);
+    return e;
+}
+
+void emu_destroy(void* h) {
+    Emu* e = static_cast<Emu*>(h);
+    for (void* p : e->alloc.owned) std::free(p);
+    delete e;
+}
+
+// returns the status word; out rows (n_out, 8)
+int emu_update(void* h, const float* dets, int n, const float* embs, float* out, int* out_n) {
+    Emu* e = static_cast<Emu*>(h);
+    if (n > e->nd) return -1;
+    std::memcpy(e->dets, dets, (size_t)n * bm::DET_COLS * 4);
+    if (embs) std::memcpy(e->embs, embs, (size_t)n * e->dim * 4);
+    e->n_dets[0] = n;
+    static int s_int[bm::MAX_WAVES + 1];
+    static double s_dbl[bm::MAX_WAVES];
+    static float sA[bm::COST_TILE][bm::COST_KC + 1];
+    static float sB[bm::COST_TILE][bm::COST_KC + 1];
+    g_s_int = s_int; g_s_dbl = s_dbl; g_sA = sA; g_sB = sB;
+    g_emu_block = &e->block;
+    blockDim.x = NTHR;
+    std::vector<pthread_t> th(NTHR);
+    std::vector<ThreadArg> ta(NTHR);
+    pthread_attr_t attr;
+    pthread_attr_init(&attr);
+    pthread_attr_setstacksize(&attr, 1 << 20);
+    for (int t = 0; t < NTHR; ++t) { ta[t] = ThreadArg{e, t}; pthread_create(&th[t], &attr, thread_main, &ta[t]); }
+    for (int t = 0; t < NTHR; ++t) pthread_join(th[t], nullptr);
+    pthread_attr_destroy(&attr);
+    *out_n = e->out_n[0];
+    std::memcpy(out, e->out, (size_t)e->out_n[0] * bm::OUT_COLS * 4);
+    return e->args.st.status[0];
+}
+
+// which: 0 active, 1 lost.  ints (rows,6), kf (rows,72), smooth (rows,dim), misc (rows,3)
+int emu_dump(void* h, int which, int* ints, double* kf, float* smooth, float* misc, int* counters) {
+    Emu* e = static_cast<Emu*>(h);
+    const bm::BotSortState& st = e->args.st;
+    const int n = which == 0 ? st.n_active[0] : st.n_lost[0];
+    const int* list = which == 0 ? st.active_list : st.lost_list;
+    for (int r = 0; r < n; ++r) {
+        const int sl = list[r];
+        int* o = ints + r * 6;
+        o[0] = st.id[sl]; o[1] = st.state[sl]; o[2] = st.is_activated[sl]; o[3] = st.frame_id[sl];
+        o[4] = st.start_frame[sl]; o[5] = st.tracklet_len[sl];
+        std::memcpy(kf + (size_t)r * bm::KF_STRIDE, st.kf + (size_t)sl * bm::KF_STRIDE, bm::KF_STRIDE * 8);
+        std::memcpy(smooth + (size_t)r * e->dim, st.smooth + (size_t)sl * e->dim, e->dim * 4);
+        misc[r * 3] = st.conf[sl]; misc[r * 3 + 1] = st.cls[sl]; misc[r * 3 + 2] = st.det_ind[sl];
+    }
+    counters[0] = st.frame_count[0]; counters[1] = st.id_count[0]; counters[2] = st.rm_size[0];
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,87 @@
+// TEST-ONLY: minimal host emulation of the HIP constructs used by the tracker
+// kernels (boxmot_amd/csrc/botsort_step.hpp) so the *same device source* can be
+// executed by g++ on CPU threads -- one pthread per GPU thread, pthread barriers
+// for __syncthreads(), a per-wave exchange buffer for the 64-lane shuffles and
+// ballots.  It exists to run the kernel logic under ASAN/UBSAN and to debug
+// index/ordering bugs without spending GPU time.  It is NOT a product path:
+// nothing in boxmot_amd/ includes this header, and the shipped library has no
+// CPU implementation.
+#pragma once
+
+#include <pthread.h>
+#include <sched.h>
+
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+
+struct EmuDim3 { unsigned x = 0, y = 0, z = 0; };
+extern thread_local EmuDim3 threadIdx;
+extern thread_local EmuDim3 blockIdx;
+extern EmuDim3 blockDim;
+
+constexpr int EMU_WAVE = 64;
+constexpr int EMU_MAX_WAVES = 16;
+
+// sense-reversing barrier that yields instead of sleeping: with more emulated
+// threads than cores a futex barrier costs ~100 us, yielding costs ~10 us
+struct EmuBarrier {
+    std::atomic<int> count{0};
+    std::atomic<int> generation{0};
+    int parties = 1;
+    void init(int n) { parties = n; count = 0; generation = 0; }
+    void wait() {
+        const int gen = generation.load(std::memory_order_acquire);
+        if (count.fetch_add(1, std::memory_order_acq_rel) + 1 == parties) {
+            count.store(0, std::memory_order_relaxed);
+            generation.store(gen + 1, std::memory_order_release);
+        } else {
+            while (generation.load(std::memory_order_acquire) == gen) sched_yield();
+        }
+    }
+};
+
+struct EmuBlock {
+    EmuBarrier block_barrier;
+    EmuBarrier wave_barrier[EMU_MAX_WAVES];
+    uint64_t xbuf[EMU_MAX_WAVES][EMU_WAVE];
+};
+extern EmuBlock* g_emu_block;
+
+inline void __syncthreads() { g_emu_block->block_barrier.wait(); }
+
+template <class T>
+inline T emu_exchange(T v, int src_lane) {
+    static_assert(sizeof(T) <= 8, "shuffle payload");
+    const int lane = threadIdx.x % EMU_WAVE, wave = threadIdx.x / EMU_WAVE;
+    uint64_t raw = 0;
+    std::memcpy(&raw, &v, sizeof(T));
+    g_emu_block->xbuf[wave][lane] = raw;
+    g_emu_block->wave_barrier[wave].wait();
+    raw = g_emu_block->xbuf[wave][src_lane & (EMU_WAVE - 1)];
+    g_emu_block->wave_barrier[wave].wait();
+    T out;
+    std::memcpy(&out, &raw, sizeof(T));
+    return out;
+}
+
+template <class T> inline T __shfl_xor(T v, int mask, int = EMU_WAVE) { return emu_exchange(v, (int)(threadIdx.x % EMU_WAVE) ^ mask); }
+template <class T> inline T __shfl(T v, int src, int = EMU_WAVE) { return emu_exchange(v, src); }
+
+inline unsigned long long __ballot(int pred) {
+    const int wave = threadIdx.x / EMU_WAVE, lane = threadIdx.x % EMU_WAVE;
+    g_emu_block->xbuf[wave][lane] = pred ? 1 : 0;
+    g_emu_block->wave_barrier[wave].wait();
+    unsigned long long m = 0;
+    for (int l = 0; l < EMU_WAVE; ++l) m |= (unsigned long long)(g_emu_block->xbuf[wave][l] & 1) << l;
+    g_emu_block->wave_barrier[wave].wait();
+    return m;
+}
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }

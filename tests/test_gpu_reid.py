@@ -1,0 +1,123 @@
+"""GPU parity tests for the ReID path (crop -> resize -> normalise -> OSNet -> L2) through the C ABI."""
+import numpy as np
+import pytest
+
+from common import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3   # BASELINE.json north_star: embeddings within 1e-3 (fp32 reference)
+
+
+def _golden():
+    import torch
+    g = np.load(GOLDEN / "reid_golden.npz")
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd/")}
+    img = np.random.default_rng(int(g["image_seed"])).integers(0, 255, (1080, 1920, 3), dtype=np.uint8)
+    return g, sd, img
+
+
+def test_crops_bit_exact_vs_oracle_and_reference():
+    from boxmot_amd.reid import HipReID
+    from oracle.crops import get_crops
+    g, sd, img = _golden()
+    reid = HipReID(sd, max_crops=64)
+    boxes = g["boxes"]
+    got = reid.get_crops(boxes, img)
+    want = get_crops(boxes, img)
+    assert got.shape == want.shape == (len(boxes), 3, 256, 128)
+    assert np.array_equal(got, want)                     # integer resize + table lookup: bit-exact
+    assert np.array_equal(got[0], g["crop0"])            # reference get_crops (golden)
+    # ragged / degenerate boxes: outside the frame, 1-pixel, exact 2x shrink, identity size, huge
+    rng = np.random.default_rng(0)
+    extra = np.array([[-50, -50, -10, -10], [0, 0, 1, 1], [100, 100, 356, 612], [200, 50, 328, 306],
+                      [0, 0, 1920, 1080], [1919.4, 1079.4, 1925, 1085], [10.5, 20.5, 11.5, 300.5]], dtype=np.float32)
+    rand = np.stack([rng.uniform(-40, 1900, 40), rng.uniform(-40, 1000, 40), np.zeros(40), np.zeros(40)], 1)
+    rand[:, 2] = rand[:, 0] + rng.uniform(1, 300, 40)
+    rand[:, 3] = rand[:, 1] + rng.uniform(1, 500, 40)
+    allb = np.concatenate([extra, rand.astype(np.float32)])
+    assert np.array_equal(reid.get_crops(allb, img), get_crops(allb, img))
+    reid.close()
+
+
+def test_features_vs_oracle_and_reference_golden():
+    from boxmot_amd.reid import HipReID
+    from oracle.osnet import OracleReID
+    g, sd, img = _golden()
+    reid = HipReID(sd, max_crops=16)
+    got = reid.get_features(g["boxes"], img)
+    assert got.dtype == np.float32 and got.shape == (len(g["boxes"]), 512)
+    assert np.abs(got - g["feats"]).max() < TOL                       # reference (golden)
+    want = OracleReID(sd).get_features(g["boxes"], img)
+    err = np.abs(got - want).max()
+    assert err < TOL, err
+    assert np.allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-5)
+    cos = (got * want).sum(1)
+    assert cos.min() > 0.9999                                          # cf. test_reid_capi.py:158-171 (> 0.99)
+    # chunking over max_crops and the empty case
+    many = np.tile(g["boxes"], (5, 1))
+    f2 = reid.get_features(many, img)
+    assert np.array_equal(f2[:8], f2[8:16]) and np.abs(f2[:8] - got).max() == 0
+    assert reid.get_features(np.empty((0, 4), dtype=np.float32), img).shape == (0, 512)
+    reid.close()
+
+
+def test_botsort_with_reid_in_the_loop_matches_oracle_ids():
+    """embs=None: the tracker asks the ReID model itself (botsort.py:191-192)."""
+    from boxmot_amd.botsort import BotSort
+    from boxmot_amd.reid import HipReID
+    from boxmot_amd.scenario import Scenario
+    from oracle.botsort import BotSortOracle
+    from oracle.osnet import OracleReID
+    _, sd, _ = _golden()
+    sc = Scenario(16, 32, width=960, height=540, random_image=True)
+    reid = HipReID(sd, max_crops=64)
+    trk = BotSort(reid_model=reid, use_cmc=False, max_tracks=128, max_dets=64)
+    orc = BotSortOracle(reid=OracleReID(sd))
+    for t in range(10):
+        dets, _ = sc.frame(t)
+        got = np.asarray(trk.update(dets, sc.image))
+        want = orc.update(dets, sc.image)
+        assert got.shape == want.shape and np.array_equal(got[:, 4:], want[:, 4:]), t
+        assert np.allclose(got[:, :4], want[:, :4], atol=1e-3)
+    assert trk.get_last_track_time_ms() > 0
+    trk.close()
+    reid.close()
+
+
+def test_device_resident_multistream_reid_step():
+    """step_device with frames resident on the GPU: ReID crop list, OSNet and the tracker step all
+    run without host buffers; ids must equal the per-stream oracle."""
+    import torch
+
+    from boxmot_amd.scenario import Scenario
+    from boxmot_amd.streams import MultiStreamBotSort
+    from oracle.botsort import BotSortOracle
+    from oracle.osnet import OracleReID
+    _, sd, _ = _golden()
+    S, nd = 3, 32
+    scs = [Scenario(12, 24, width=640, height=480, random_image=True, stream=s) for s in range(S)]
+    ms = MultiStreamBotSort(S, max_tracks=64, max_dets=nd, emb_dim=512, reid_weights=sd)
+    orcs = [BotSortOracle(reid=OracleReID(sd)) for _ in range(S)]
+    dev = torch.device("cuda:0")
+    frames = torch.stack([torch.from_numpy(sc.image) for sc in scs]).to(dev)
+    ptrs = torch.tensor([frames[s].data_ptr() for s in range(S)], dtype=torch.int64, device=dev)
+    d_dets = torch.zeros((S, nd, 6), dtype=torch.float32, device=dev)
+    d_n = torch.zeros(S, dtype=torch.int32, device=dev)
+    d_out = torch.zeros((S, nd, 8), dtype=torch.float32, device=dev)
+    d_out_n = torch.zeros(S, dtype=torch.int32, device=dev)
+    for t in range(8):
+        per = [sc.frame(t)[0] for sc in scs]
+        for s in range(S):
+            d_dets[s, : len(per[s])] = torch.from_numpy(per[s]).to(dev)
+            d_n[s] = len(per[s])
+        torch.cuda.synchronize()
+        ms.step_device(d_dets.data_ptr(), d_n.data_ptr(), None, ptrs.data_ptr(), 480, 640, d_out.data_ptr(), d_out_n.data_ptr())
+        ms.synchronize()
+        out, cnt = d_out.cpu().numpy(), d_out_n.cpu().numpy()
+        for s in range(S):
+            want = orcs[s].update(per[s], scs[s].image)
+            got = out[s, : cnt[s]]
+            assert got.shape == want.shape and np.array_equal(got[:, 4:], want[:, 4:]), (s, t)
+    assert ms.status().tolist() == [0] * S
+    ms.close()

@@ -1,0 +1,45 @@
+"""The oracle restatement reproduces the reference's outputs bit-for-bit (fixtures made by the
+real reference classes; CPU only)."""
+import numpy as np
+import pytest
+
+from common import CASES, golden_rows
+from oracle.botsort import BotSortOracle
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_oracle_matches_reference_rows(name):
+    make, hw, kw, _ = CASES[name]
+    frames = make()
+    if name.startswith("c2"):
+        frames = frames[:12]          # keep the CPU suite short; the GPU suite runs all 40
+    want, g = golden_rows(name)
+    orc = BotSortOracle(**kw)
+    img = np.zeros((hw[0], hw[1], 3), dtype=np.uint8)
+    for t, (dets, embs) in enumerate(frames):
+        got = orc.update(dets, img, embs.copy())
+        assert got.dtype == np.float32
+        assert np.array_equal(got, want[t]), f"{name} frame {t}"
+    if len(frames) == len(want):
+        d = orc.dump()["active"]
+        assert np.array_equal(d["id"], g[name + "_final_ids"])
+        assert np.array_equal(d["mean"], g[name + "_final_mean"])      # same NumPy/SciPy calls -> bit-exact
+        assert np.array_equal(d["cov"], g[name + "_final_cov"])
+
+
+def test_oracle_reid_matches_reference_features():
+    import torch
+
+    from oracle.osnet import OracleReID
+    from common import GOLDEN
+    g = np.load(GOLDEN / "reid_golden.npz")
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd/")}
+    img = np.random.default_rng(int(g["image_seed"])).integers(0, 255, (1080, 1920, 3), dtype=np.uint8)
+    from oracle.crops import get_crops
+    crops = get_crops(g["boxes"], img)
+    assert np.array_equal(crops[0], g["crop0"])
+    assert np.allclose(crops.reshape(len(crops), -1).astype(np.float64).sum(1), g["crop_sums"], rtol=0, atol=1e-6)
+    feats = OracleReID(sd).get_features(g["boxes"], img)
+    # same torch build -> identical; allow float noise in case the CPU dispatches other conv kernels
+    assert np.abs(feats - g["feats"]).max() < 1e-5
+    assert np.allclose(np.linalg.norm(feats, axis=1), 1.0, atol=1e-5)

@@ -1,0 +1,46 @@
+"""Direct oracle-vs-reference checks; need /root/reference (build container only)."""
+import logging
+
+import numpy as np
+import pytest
+
+from oracle import ref_harness
+
+pytestmark = pytest.mark.skipif(not ref_harness.reference_available(), reason="/root/reference is not mounted")
+
+
+def test_botsort_oracle_bit_exact_incl_kalman_state():
+    from boxmot_amd.scenario import stress_frames
+    from oracle.botsort import BotSortOracle
+
+    logging.disable(logging.CRITICAL)
+    BotSort = ref_harness.load_botsort()
+    for kw in ({}, dict(track_buffer=4, removed_stracks_buffer=2, fuse_first_associate=True), dict(with_reid=False)):
+        ref = BotSort(reid_model=None, use_cmc=False, **({"with_reid": True} | kw))
+        orc = BotSortOracle(**kw)
+        img = np.zeros((480, 640, 3), np.uint8)
+        for t, (d, e) in enumerate(stress_frames(120, seed=3)):
+            r = np.asarray(ref.update(d.copy(), img, e.copy()))
+            o = orc.update(d.copy(), img, e.copy())
+            assert r.shape == o.shape and np.array_equal(r, o), (kw, t)
+        for a, b in zip(ref.active_tracks, orc.active):
+            assert a.id == b.id and np.array_equal(a.mean, b.mean) and np.array_equal(a.covariance, b.cov)
+        assert [t.id for t in ref.lost_stracks] == [t.id for t in orc.lost]
+
+
+def test_osnet_functional_equals_reference_module():
+    import torch
+
+    from boxmot_amd.reid_weights import random_osnet_state_dict
+    from oracle.osnet import osnet_forward
+
+    mod = ref_harness.load_osnet_module()
+    for arch in ("osnet_x0_25", "osnet_x1_0"):
+        sd = random_osnet_state_dict(arch, seed=5, calib_batch=2)
+        model = getattr(mod, arch)(num_classes=10, pretrained=False).eval()
+        res = model.load_state_dict(sd, strict=False)
+        assert not res.unexpected_keys
+        x = torch.randn(2, 3, 256, 128, generator=torch.Generator().manual_seed(0))
+        with torch.no_grad():
+            want = model(x)
+        assert torch.equal(osnet_forward(sd, x), want)
