@@ -67,8 +67,11 @@ class Scenario:
         rot = self.perm[self.n_persist:][g * self.n_rot:(g + 1) * self.n_rot]
         return np.concatenate([self.perm[: self.n_persist], rot])
 
-    def frame(self, t: int):
-        """Returns (dets (n,6) fp32, embs (n,D) fp32) for 0-based frame ``t`` (call in order)."""
+    def frame(self, t: int, with_embs: bool = True):
+        """Returns (dets (n,6) fp32, embs (n,D) fp32) for 0-based frame ``t`` (call in order).
+        ``with_embs=False`` skips drawing the appearance noise (embs is None); the detection
+        sequence then differs from the with_embs=True sequence (one RNG), so use one setting
+        consistently on both sides of a comparison."""
         rng = self._rng
         idx = self.visible(t)
         n = len(idx)
@@ -80,6 +83,8 @@ class Scenario:
         x2 = self.cx[idx] + self.bw[idx] / 2 + jx
         y2 = self.cy[idx] + self.bh[idx] / 2 + jy
         dets = np.stack([x1, y1, x2, y2, conf, np.zeros(n)], axis=1).astype(np.float32)
+        if not with_embs:
+            return dets, None
         embs = (self.emb[idx] + rng.normal(0.0, 0.01, (n, self.emb_dim))).astype(np.float32)
         return dets, embs
 

@@ -64,7 +64,7 @@ class MultiStreamBotSort:
         emb_ptrs = None
         embs = None
         if embs_list is not None:
-            embs = [np.ascontiguousarray(e, dtype=np.float32).reshape(len(d), -1) for e, d in zip(embs_list, dets)]
+            embs = [np.ascontiguousarray(e, dtype=np.float32).reshape(len(d), self.emb_dim) for e, d in zip(embs_list, dets)]
             emb_ptrs = (ctypes.c_void_p * S)(*[e.ctypes.data if len(e) else None for e in embs])
         img_ptrs, ir, ic = None, 1, 1
         keep = []
