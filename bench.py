@@ -43,7 +43,8 @@ def parse():
     ap.add_argument("--streams", type=int, default=64, help="streams per GPU")
     ap.add_argument("--mode", choices=("reid", "embs"), default="reid",
                     help="reid: ReID inside update (headline, M2); embs: embeddings supplied (tracker math only, M1)")
-    ap.add_argument("--reid-mode", type=int, default=int(os.environ.get("BOXMOT_REID_MODE", "0")))
+    ap.add_argument("--reid-mode", type=int, default=int(os.environ.get("BOXMOT_REID_MODE", "1")),
+                    help="0: per-layer fp32 kernels, 1: fused fp16 MFMA kernels (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=10)
     return ap.parse_args()
@@ -110,7 +111,7 @@ def main():
         g.build()
     dev = torch.device("cuda", local if world > 1 else 0)
 
-    from boxmot_amd.reid_weights import random_osnet_state_dict
+    from boxmot_amd.reid_weights import reference_init_state_dict
     from boxmot_amd.scenario import Scenario
     from boxmot_amd.streams import MultiStreamBotSort
     from boxmot_amd.tracker_zoo import BOTSORT_YAML_DEFAULTS
@@ -120,7 +121,7 @@ def main():
     log(f"rank {rank}/{world}: S={S} K={K} W={W} mode={a.mode}")
     kw = {k: v for k, v in BOTSORT_YAML_DEFAULTS.items() if k not in ("use_cmc", "cmc_method")}
     torch.set_num_threads(min(os.cpu_count() or 1, 16))
-    sd = random_osnet_state_dict("osnet_x0_25", seed=0)
+    sd = reference_init_state_dict("osnet_x0_25", seed=0)   # random init as OSNet._init_params does it
     log("weights generated")
     nd = N_TRACKS                       # the 3 confirmation frames show every object
     ms = MultiStreamBotSort(S, max_tracks=2 * N_TRACKS, max_dets=nd, emb_dim=EMB_DIM,
@@ -203,7 +204,7 @@ def main():
                                    if a.mode == "reid" else "BoT-SORT tracker math only (embeddings supplied), 64 dets x 256 tracks",
                        "streams_per_gpu": S, "mode": "M2 reid-in-update" if a.mode == "reid" else "M1 embs-supplied",
                        "reid_kernels": {0: "per-layer fp32 (v1)", 1: "fused fp16 MFMA"}[a.reid_mode] if a.mode == "reid" else None,
-                       "tracker_params": "botsort.yaml defaults, use_cmc=False", "weights": "random-init OSNet-x0.25 (seed 0)",
+                       "tracker_params": "botsort.yaml defaults, use_cmc=False", "weights": "random-init OSNet-x0.25 (reference _init_params scheme, seed 0)",
                        "device_ms_timed_region": dev_ms},
         }
         if a.mode == "reid" and reid_ms > 0:
@@ -226,6 +227,16 @@ def main():
                 got = out_h[t, 0, : out_n_h[t, 0]]
                 ok &= got.shape == rows[t].shape and bool(np.array_equal(got[:, 4:], rows[t][:, 4:]))
             res["config"]["parity_ids_exact_vs_oracle_stream0"] = bool(ok)
+            if a.mode == "reid":
+                # embeddings of the benchmark kernels vs the fp32 oracle on stream 0's steady-state crops
+                from boxmot_amd.reid import HipReID
+                from oracle.osnet import OracleReID
+                sc0 = Scenario(N_DETS, N_TRACKS, WIDTH, HEIGHT, EMB_DIM, stream=0, random_image=True)
+                boxes = sc0.frame(0, with_embs=False)[0][:32, :4]
+                hr = HipReID(sd, max_crops=32, mode=a.reid_mode)
+                err = float(np.abs(hr.get_features(boxes, sc0.image) - OracleReID(sd).get_features(boxes, sc0.image)).max())
+                hr.close()
+                res["config"]["reid_max_abs_err_vs_fp32_oracle"] = err
         print(json.dumps(res))
     ms.close()
     if world > 1:

@@ -676,8 +676,8 @@ int boxmot_hip_reid_preprocess(BoxMOTHipReID* handle, const uint8_t* image, int 
     return guard([&]() {
         reid_stage(handle, image, image_rows, image_cols, image_channels, boxes, n_boxes, box_cols);
         if (n_boxes == 0) return;
-        handle->engine->preprocess(handle->d_frames, handle->d_crop_stream, handle->d_boxes, 4, n_boxes, image_cols,
-                                   image_rows, handle->stream);
+        handle->engine->preprocess_fp32(handle->d_frames, handle->d_crop_stream, handle->d_boxes, 4, n_boxes, image_cols,
+                                        image_rows, handle->stream);
         BM_HIP(hipMemcpyAsync(out_crops, handle->engine->crops_buffer(),
                               (size_t)n_boxes * bm::REID_IN_H * bm::REID_IN_W * 3 * 4, hipMemcpyDeviceToHost, handle->stream));
         BM_HIP(hipStreamSynchronize(handle->stream));

@@ -1,0 +1,21 @@
+// Spellings of the few gfx950 constructs the kernels use through a macro so that the test harness
+// (tests/host_emu) can substitute an instrumented equivalent when it executes the same source on
+// CPU threads.  In the product build these are exactly the HIP builtins below.
+#pragma once
+
+#ifndef BM_DYNAMIC_LDS_T
+// dynamic LDS of the workgroup; keep the base 16-byte aligned (DS b64/b128 accesses)
+#define BM_DYNAMIC_LDS_T(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
+#endif
+#ifndef BM_EXPF
+#define BM_EXPF(x) __expf(x)
+#endif
+#ifndef BM_MFMA_F16_K16
+#define BM_MFMA_F16_K16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0)
+#define BM_MFMA_F16_K32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#endif
+#ifndef BM_SCHED_FENCE
+// compile-time scheduling fence: keeps the per-tile register working set from being merged
+// across tiles by the instruction scheduler (which otherwise hoists every LDS read and spills)
+#define BM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif

@@ -15,6 +15,7 @@
 
 #include "reid_layout.hpp"
 #include "reid_kernels_v1.hpp"
+#include "reid_fused.hpp"
 
 namespace bm {
 
@@ -73,6 +74,7 @@ public:
         d_lut_ = dev_alloc<float>(3 * 256, owned_);
         BM_HIP(hipMemcpy(d_lut_, lut, sizeof(lut), hipMemcpyHostToDevice));
         alloc_buffers();
+        if (ch[0] == 16 && ch[1] == 64 && ch[2] == 96 && ch[3] == 128 && L_.feat == 512) prepare_fused();
         BM_HIP(hipEventCreate(&ev_[0]));
         BM_HIP(hipEventCreate(&ev_[1]));
         BM_HIP(hipEventCreate(&ev_[2]));
@@ -85,7 +87,8 @@ public:
     int feature_dim() const { return L_.feat; }
     int max_crops() const { return max_crops_; }
     void set_mode(int m) {
-        if (m != 0) throw std::runtime_error("ReID mode not available in this build");
+        if (m != 0 && m != 1) throw std::runtime_error("ReID mode must be 0 (per-layer fp32) or 1 (fused fp16 MFMA)");
+        if (m == 1 && !fused_ready_) throw std::runtime_error("fused fp16 ReID kernels are built for OSNet-x0.25 only");
         mode_ = m;
     }
     int mode() const { return mode_; }
@@ -98,8 +101,19 @@ public:
         if (n > max_crops_) throw std::runtime_error("ReID: crop batch exceeds max_crops");
         if (n == 0) return;
         const int rows_per_block = 16;
-        hipLaunchKernelGGL(k_crop_resize<float>, dim3(n, REID_IN_H / rows_per_block), dim3(REID_IN_W), 0, st,
-                           d_frames, d_crop_stream, d_boxes, box_stride, W, H, d_lut_, crops_, rows_per_block);
+        if (mode_ == 1 && !force_fp32_crops_)
+            hipLaunchKernelGGL(k_crop_resize_rgbx, dim3(n, REID_IN_H / rows_per_block), dim3(REID_IN_W), 0, st,
+                               d_frames, d_crop_stream, d_boxes, box_stride, W, H, d_lut_, crops_h_, rows_per_block);
+        else
+            hipLaunchKernelGGL(k_crop_resize<float>, dim3(n, REID_IN_H / rows_per_block), dim3(REID_IN_W), 0, st,
+                               d_frames, d_crop_stream, d_boxes, box_stride, W, H, d_lut_, crops_, rows_per_block);
+    }
+    // the fp32 NHWC crop tensor is also the public "preprocess" result: force it regardless of the mode
+    void preprocess_fp32(const uint8_t* const* d_frames, const int* d_crop_stream, const float* d_boxes,
+                         int box_stride, int n, int W, int H, hipStream_t st) {
+        force_fp32_crops_ = true;
+        preprocess(d_frames, d_crop_stream, d_boxes, box_stride, n, W, H, st);
+        force_fp32_crops_ = false;
     }
 
     // full path; out row of crop i is out_rows ? out_rows[i] : i, rows of `feat` floats.
@@ -114,7 +128,8 @@ public:
             if (i0 == 0) BM_HIP(hipEventRecord(ev_[1], st));
             hipEvent_t a = take_event(), b = take_event();
             BM_HIP(hipEventRecord(a, st));
-            forward_v1(m, d_out_rows ? d_out : d_out + (long)i0 * L_.feat, d_out_rows ? d_out_rows + i0 : nullptr, st);
+            if (mode_ == 1) forward_fused(m, d_out_rows ? d_out : d_out + (long)i0 * L_.feat, d_out_rows ? d_out_rows + i0 : nullptr, st);
+            else forward_v1(m, d_out_rows ? d_out : d_out + (long)i0 * L_.feat, d_out_rows ? d_out_rows + i0 : nullptr, st);
             BM_HIP(hipEventRecord(b, st));
             if (pending_.size() < 4096) pending_.emplace_back(a, b);
             else { free_events_.push_back(a); free_events_.push_back(b); }
@@ -237,6 +252,57 @@ private:
         hipLaunchKernelGGL(k_head<float>, dim3(n), dim3(256), 0, st, other, d_w_ + L_.fc_w, d_w_ + L_.fc_b, d_out,
                            d_out_rows, H * W, c3, L_.feat);
     }
+    // ---- fused fp16 MFMA path (OSNet-x0.25) ----
+    unsigned char* upload(const std::vector<uint8_t>& v) {
+        unsigned char* d = dev_alloc<unsigned char>(v.size(), owned_);
+        BM_HIP(hipMemcpy(d, v.data(), v.size(), hipMemcpyHostToDevice));
+        return d;
+    }
+    template <class K>
+    static void allow_lds(K kernel, int bytes) {
+        BM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    }
+    void prepare_fused() {
+        const float* w = h_w_.data();
+        std::vector<uint8_t> buf;
+        pack_stem(w + L_.stem_w, w + L_.stem_b, buf);
+        w_stem_ = upload(buf);
+        static const int stage[6] = {0, 0, 1, 1, 2, 2}, cin[6] = {16, 64, 64, 96, 96, 128}, down[6] = {1, 0, 1, 0, 1, 0};
+        for (int b = 0; b < 6; ++b) {
+            bp_[b] = make_blk_pack(stage[b], cin[b], down[b]);
+            pack_osblock(w, L_.block[b], bp_[b], buf);
+            w_blk_[b] = upload(buf);
+        }
+        pack_pointwise(w + L_.trans_w[0], w + L_.trans_b[0], 64, 64, buf); w_tr_[0] = upload(buf);
+        pack_pointwise(w + L_.trans_w[1], w + L_.trans_b[1], 96, 96, buf); w_tr_[1] = upload(buf);
+        pack_pointwise(w + L_.conv5_w, w + L_.conv5_b, 128, 128, buf); w_c5_ = upload(buf);
+        pack_fc(w + L_.fc_w, w + L_.fc_b, 512, 128, buf); w_fc_ = upload(buf);
+        const size_t n = (size_t)max_crops_;
+        const size_t crop_halves = n * STEM_ROWS * STEM_COLS * 4;
+        crops_h_ = dev_alloc<_Float16>(crop_halves, owned_);
+        BM_HIP(hipMemset(crops_h_, 0, crop_halves * 2));          // the 3-pixel border and X channel stay zero
+        act_a_ = dev_alloc<_Float16>(n * 2048 * 64, owned_);
+        act_b_ = dev_alloc<_Float16>(n * 2048 * 64, owned_);
+        allow_lds(k_osblock<0, 16, true>, Geo<0>::LDS_BYTES);
+        allow_lds(k_osblock<0, 64, false>, Geo<0>::LDS_BYTES);
+        allow_lds(k_osblock<1, 64, true>, Geo<1>::LDS_BYTES);
+        allow_lds(k_osblock<1, 96, false>, Geo<1>::LDS_BYTES);
+        allow_lds(k_osblock<2, 96, true>, Geo<2>::LDS_BYTES);
+        allow_lds(k_osblock<2, 128, false>, Geo<2>::LDS_BYTES);
+        fused_ready_ = true;
+    }
+    void forward_fused(int n, float* d_out, const int* d_out_rows, hipStream_t st) {
+        hipLaunchKernelGGL(k_stem_fused, dim3(n), dim3(512), 0, st, crops_h_, act_a_, w_stem_);
+        hipLaunchKernelGGL((k_osblock<0, 16, true>), dim3(n), dim3(512), Geo<0>::LDS_BYTES, st, act_a_, act_b_, w_blk_[0], bp_[0]);
+        hipLaunchKernelGGL((k_osblock<0, 64, false>), dim3(n), dim3(512), Geo<0>::LDS_BYTES, st, act_b_, act_a_, w_blk_[1], bp_[1]);
+        hipLaunchKernelGGL((k_transition<64, 64, 32>), dim3((n * 32 + 3) / 4), dim3(256), 0, st, act_a_, act_b_, w_tr_[0], n);
+        hipLaunchKernelGGL((k_osblock<1, 64, true>), dim3(n), dim3(256), Geo<1>::LDS_BYTES, st, act_b_, act_a_, w_blk_[2], bp_[2]);
+        hipLaunchKernelGGL((k_osblock<1, 96, false>), dim3(n), dim3(256), Geo<1>::LDS_BYTES, st, act_a_, act_b_, w_blk_[3], bp_[3]);
+        hipLaunchKernelGGL((k_transition<96, 32, 16>), dim3((n * 16 + 3) / 4), dim3(256), 0, st, act_b_, act_a_, w_tr_[1], n);
+        hipLaunchKernelGGL((k_osblock<2, 96, true>), dim3(n), dim3(128), Geo<2>::LDS_BYTES, st, act_a_, act_b_, w_blk_[4], bp_[4]);
+        hipLaunchKernelGGL((k_osblock<2, 128, false>), dim3(n), dim3(128), Geo<2>::LDS_BYTES, st, act_b_, act_a_, w_blk_[5], bp_[5]);
+        hipLaunchKernelGGL((k_head_fused<128, 512>), dim3(n), dim3(128), 0, st, act_a_, w_c5_, w_fc_, d_out, d_out_rows);
+    }
     void alloc_buffers() {
         const size_t n = (size_t)max_crops_;
         crops_ = dev_alloc<float>(n * REID_IN_H * REID_IN_W * 3, owned_);
@@ -267,6 +333,14 @@ private:
     float* d_lut_ = nullptr;
     float *crops_ = nullptr, *big_a_ = nullptr, *big_b_ = nullptr, *idn_ = nullptr;
     float *x1_ = nullptr, *ta_ = nullptr, *tb_ = nullptr, *tt_ = nullptr, *acc_ = nullptr, *gap_ = nullptr;
+    // fused path
+    bool fused_ready_ = false, force_fp32_crops_ = false;
+    BlkPack bp_[6];
+    unsigned char* w_stem_ = nullptr;
+    unsigned char* w_blk_[6] = {};
+    unsigned char* w_tr_[2] = {};
+    unsigned char *w_c5_ = nullptr, *w_fc_ = nullptr;
+    _Float16 *crops_h_ = nullptr, *act_a_ = nullptr, *act_b_ = nullptr;
     hipEvent_t ev_[3];
     std::vector<hipEvent_t> all_events_, free_events_;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_;

@@ -1,0 +1,519 @@
+// Fused fp16 MFMA ReID kernels for OSNet-x0.25 (gfx950, wave64).
+//
+// Reference computation: OSNet.forward, boxmot/reid/backbones/osnet.py:380-405
+// (OSBlock :212-260, LightConv3x3 :127-155, ChannelGate :161-209), eval mode
+// with BatchNorm folded into the convolutions (reid_pack.hpp).
+//
+// Design (DESIGN.md "ReID kernels"):
+//  * One workgroup owns one crop for a whole OSBlock; every 1x1 convolution is
+//    an MFMA with output channels as M (weights = A operand, pre-permuted on
+//    the host) and 16 consecutive pixels as N.  The accumulator layout of one
+//    MFMA (lane = pixel + 16*channel-group) IS the B-operand layout of the
+//    next, so the conv1 -> (1x1 -> dw3x3)^k -> gate -> conv3 chain stays in
+//    registers; fp16 operands, fp32 accumulation.
+//  * The depthwise 3x3 needs spatial neighbours held by other lanes/waves: the
+//    1x1 output is written once to an LDS image of the crop (zero halo, padded
+//    pixel stride for bank spread) and read back as 9 taps of 8 bytes.
+//  * ChannelGate needs the crop-wide average of each branch: per-wave partial
+//    sums meet in LDS; the gated branches accumulate in fp32 registers and feed
+//    conv3 (+ the 1x1 downsample or the identity) straight from registers.
+//  * HBM traffic per block = block input + block output in fp16
+//    (lane-group-major NHWC, reid_pack.hpp), weights from L2.
+#pragma once
+
+#include "reid_kernels_v1.hpp"
+#include "reid_pack.hpp"
+
+namespace bm {
+
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+template <int STAGE>
+struct Geo {
+    static constexpr int H = 64 >> STAGE, W = 32 >> STAGE, P = H * W;
+    static constexpr int MID = STAGE == 0 ? 16 : (STAGE == 1 ? 24 : 32);
+    static constexpr int KT = STAGE == 0 ? 1 : 2;          // 16-channel tiles of the (padded) mid width
+    static constexpr int MIDP = 16 * KT;
+    static constexpr int HID = MID / 16;
+    static constexpr int COUT = STAGE == 0 ? 64 : (STAGE == 1 ? 96 : 128);
+    static constexpr int NCT = COUT / 16;
+    static constexpr int NWAVES = 8 >> STAGE;               // 8, 4, 2 waves per crop
+    static constexpr int NT = P / 16 / NWAVES;              // 16, 8, 4 pixel tiles per wave
+    static constexpr int PXB = KT == 1 ? 40 : 72;           // padded bytes per pixel of the LDS image
+    static constexpr int ROWB = (W + 2) * PXB;
+    static constexpr int TBUF = (H + 2) * ROWB;
+    static constexpr int LDS_BYTES = TBUF + 4 * NWAVES * MIDP * 4;
+};
+
+// (y, x) of lane l16 in pixel tile q: tiles are 16 consecutive pixels in row-major order
+template <int STAGE>
+__device__ inline int tile_lds_offset(int q, int l16) {
+    using G = Geo<STAGE>;
+    int y, x;
+    if (STAGE == 0) { y = q >> 1; x = (q & 1) * 16 + l16; }
+    else if (STAGE == 1) { y = q; x = l16; }
+    else { y = 2 * q + (l16 >> 3); x = l16 & 7; }
+    return (y + 1) * G::ROWB + (x + 1) * G::PXB;
+}
+
+__device__ inline h4 to_h4(f4 v) { return h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]}; }
+__device__ inline f4 relu4(f4 v) {
+    return f4{v[0] > 0.f ? v[0] : 0.f, v[1] > 0.f ? v[1] : 0.f, v[2] > 0.f ? v[2] : 0.f, v[3] > 0.f ? v[3] : 0.f};
+}
+__device__ inline h8 cat8(h4 a, h4 b) { return h8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
+
+// ---------------------------------------------------------------------------
+// OSBlock: in [n][P][CIN] -> out [n][P][COUT], fp16 lane-group-major NHWC
+// ---------------------------------------------------------------------------
+template <int STAGE, int CIN, bool DOWN>
+__global__ void __launch_bounds__(64 * Geo<STAGE>::NWAVES)
+k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const unsigned char* __restrict__ wts, BlkPack bp) {
+    using G = Geo<STAGE>;
+    constexpr int KT = G::KT, NT = G::NT, MIDP = G::MIDP, NCT = G::NCT, COUT = G::COUT, P = G::P;
+    constexpr int KIN = CIN == 16 ? 1 : CIN / 32;
+    BM_DYNAMIC_LDS_T(unsigned char, lds);
+    unsigned char* tbuf = lds;
+    float* gap_part = reinterpret_cast<float*>(lds + G::TBUF);      // [4 branches][NWAVES][MIDP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l16 = lane & 15;
+    const long crop = blockIdx.x;
+    const _Float16* xin = in + crop * P * CIN;
+    _Float16* yout = out + crop * P * COUT;
+
+    // zero the LDS image once: the halo ring stays zero (= the dw conv's zero padding)
+    for (int e = tid * 8; e < G::TBUF; e += 64 * G::NWAVES * 8) *reinterpret_cast<unsigned long long*>(tbuf + e) = 0ull;
+
+    // ---- conv1: 1x1 CIN -> MID, + bias, ReLU (osnet.py:248) ----
+    h4 x1[NT][KT];
+    {
+        f4 bias[KT];
+#pragma unroll
+        for (int ct = 0; ct < KT; ++ct) bias[ct] = *reinterpret_cast<const f4*>(wts + bp.conv1_b + (16 * ct + 4 * g) * 4);
+        if constexpr (CIN == 16) {
+            const h4 a = *reinterpret_cast<const h4*>(wts + bp.conv1_a + lane * 8);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int p = (wave * NT + i) * 16 + l16;
+                const h4 b = *reinterpret_cast<const h4*>(xin + (long)p * CIN + g * 4);
+                x1[i][0] = to_h4(relu4(BM_MFMA_F16_K16(a, b, bias[0])));
+            }
+        } else {
+            h8 a[KIN][KT];
+#pragma unroll
+            for (int ks = 0; ks < KIN; ++ks)
+#pragma unroll
+                for (int ct = 0; ct < KT; ++ct)
+                    a[ks][ct] = *reinterpret_cast<const h8*>(wts + bp.conv1_a + ((ks * KT + ct) * 64 + lane) * 16);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int p = (wave * NT + i) * 16 + l16;
+                f4 acc[KT];
+#pragma unroll
+                for (int ct = 0; ct < KT; ++ct) acc[ct] = bias[ct];
+#pragma unroll
+                for (int ks = 0; ks < KIN; ++ks) {
+                    const h8 b = *reinterpret_cast<const h8*>(xin + (long)p * CIN + g * (CIN / 4) + 8 * ks);
+#pragma unroll
+                    for (int ct = 0; ct < KT; ++ct) acc[ct] = BM_MFMA_F16_K32(a[ks][ct], b, acc[ct]);
+                }
+#pragma unroll
+                for (int ct = 0; ct < KT; ++ct) x1[i][ct] = to_h4(relu4(acc[ct]));
+            }
+        }
+    }
+
+    // ---- four branches of 1..4 LightConv3x3, each gated and accumulated (osnet.py:249-253) ----
+    f4 x2[NT][KT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int ct = 0; ct < KT; ++ct) x2[i][ct] = f4{0.f, 0.f, 0.f, 0.f};
+    // LDS byte offset of this lane's pixel in tile i, relative to `t00` = the (y-1, x-1) neighbour of its
+    // pixel in tile 0: every tap address is t00 + compile-time constant (DS immediate offsets)
+    const int t00 = tile_lds_offset<STAGE>(wave * NT, l16) + g * (KT * 8) - G::ROWB - G::PXB;
+    auto tile_off = [](int i) constexpr {
+        return STAGE == 0 ? (i >> 1) * G::ROWB + (i & 1) * 16 * G::PXB : (STAGE == 1 ? i * G::ROWB : 2 * i * G::ROWB);
+    };
+    __syncthreads();
+
+    int li = 0;
+#pragma unroll 1
+    for (int br = 0; br < 4; ++br) {
+        h4 cur[NT][KT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int ct = 0; ct < KT; ++ct) cur[i][ct] = x1[i][ct];
+#pragma unroll 1
+        for (int k = 0; k <= br; ++k, ++li) {
+            const unsigned char* lw = wts + bp.light0 + (long)li * bp.light_bytes;
+            // 1x1 (linear): t = W_pw . cur  -> LDS image (fp16)
+            if constexpr (KT == 1) {
+                const h4 a = *reinterpret_cast<const h4*>(lw + bp.light_pw + lane * 8);
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    const f4 t = BM_MFMA_F16_K16(a, cur[i][0], (f4{0.f, 0.f, 0.f, 0.f}));
+                    *reinterpret_cast<h4*>(tbuf + t00 + tile_off(i) + G::ROWB + G::PXB) = to_h4(t);
+                }
+            } else {
+                h8 a[KT];
+#pragma unroll
+                for (int ct = 0; ct < KT; ++ct) a[ct] = *reinterpret_cast<const h8*>(lw + bp.light_pw + (ct * 64 + lane) * 16);
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    const h8 b = cat8(cur[i][0], cur[i][1]);
+#pragma unroll
+                    for (int ct = 0; ct < KT; ++ct) {
+                        const f4 t = BM_MFMA_F16_K32(a[ct], b, (f4{0.f, 0.f, 0.f, 0.f}));
+                        *reinterpret_cast<h4*>(tbuf + t00 + tile_off(i) + G::ROWB + G::PXB + ct * 8) = to_h4(t);
+                    }
+                }
+            }
+            __syncthreads();
+            // depthwise 3x3 (pad 1) + bias + ReLU, channel tile by channel tile
+#pragma unroll
+            for (int ct = 0; ct < KT; ++ct) {
+                h4 wd[9];
+                const h4* wsrc = reinterpret_cast<const h4*>(lw + bp.light_dw) + (ct * 4 + g) * 9;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) wd[tap] = wsrc[tap];
+                const f4 bias = *reinterpret_cast<const f4*>(lw + bp.light_b + (16 * ct + 4 * g) * 4);
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    f4 o = bias;
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) {
+                        const h4 nb = *reinterpret_cast<const h4*>(tbuf + t00 + tile_off(i) + ct * 8 + (tap / 3) * G::ROWB + (tap % 3) * G::PXB);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] += (float)nb[r] * (float)wd[tap][r];
+                    }
+                    cur[i][ct] = to_h4(relu4(o));
+                    if (i & 1) BM_SCHED_FENCE();
+                }
+            }
+            __syncthreads();
+        }
+        // ChannelGate (osnet.py:194-209): crop-wide average -> fc1 -> ReLU -> fc2 -> sigmoid -> scale
+        float* part = gap_part + br * (G::NWAVES * MIDP);
+#pragma unroll
+        for (int ct = 0; ct < KT; ++ct) {
+            f4 s = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[r] += (float)cur[i][ct][r];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = s[r];
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                if (l16 == 0) part[wave * MIDP + 16 * ct + 4 * g + r] = v;
+            }
+        }
+        __syncthreads();
+        float hidv[G::HID];
+#pragma unroll
+        for (int h = 0; h < G::HID; ++h) hidv[h] = *reinterpret_cast<const float*>(wts + bp.fc1_b + 4 * h);
+        for (int c = 0; c < MIDP; ++c) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < G::NWAVES; ++w) s += part[w * MIDP + c];
+            s *= (1.0f / P);
+#pragma unroll
+            for (int h = 0; h < G::HID; ++h) hidv[h] += *reinterpret_cast<const float*>(wts + bp.fc1_w + 4 * (h * MIDP + c)) * s;
+        }
+#pragma unroll
+        for (int h = 0; h < G::HID; ++h) hidv[h] = hidv[h] > 0.f ? hidv[h] : 0.f;
+#pragma unroll
+        for (int ct = 0; ct < KT; ++ct) {
+            f4 gate;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 16 * ct + 4 * g + r;
+                float z = *reinterpret_cast<const float*>(wts + bp.fc2_b + 4 * c);
+#pragma unroll
+                for (int h = 0; h < G::HID; ++h) z += *reinterpret_cast<const float*>(wts + bp.fc2_w + 4 * (c * G::HID + h)) * hidv[h];
+                gate[r] = 1.f / (1.f + BM_EXPF(-z));
+            }
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x2[i][ct][r] += gate[r] * (float)cur[i][ct][r];
+        }
+    }
+
+    // ---- conv3 (1x1 MID -> COUT, linear) + downsample(x) or identity, ReLU (osnet.py:254-260) ----
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int p = (wave * NT + i) * 16 + l16;
+        h4 b4[KT];
+#pragma unroll
+        for (int ct = 0; ct < KT; ++ct) b4[ct] = to_h4(x2[i][ct]);
+        h8 bx[KIN];
+        h4 bx4;
+        if constexpr (DOWN) {
+            if constexpr (CIN == 16) bx4 = *reinterpret_cast<const h4*>(xin + (long)p * CIN + g * 4);
+            else {
+#pragma unroll
+                for (int ks = 0; ks < KIN; ++ks) bx[ks] = *reinterpret_cast<const h8*>(xin + (long)p * CIN + g * (CIN / 4) + 8 * ks);
+            }
+        }
+#pragma unroll
+        for (int co = 0; co < NCT; ++co) {
+            f4 acc = *reinterpret_cast<const f4*>(wts + bp.conv3_b + (16 * co + 4 * g) * 4);
+            if constexpr (KT == 1) {
+                acc = BM_MFMA_F16_K16(*reinterpret_cast<const h4*>(wts + bp.conv3_a + (co * 64 + lane) * 8), b4[0], acc);
+            } else {
+                acc = BM_MFMA_F16_K32(*reinterpret_cast<const h8*>(wts + bp.conv3_a + (co * 64 + lane) * 16), cat8(b4[0], b4[1]), acc);
+            }
+            if constexpr (DOWN) {
+                if constexpr (CIN == 16) {
+                    acc = BM_MFMA_F16_K16(*reinterpret_cast<const h4*>(wts + bp.down_a + (co * 64 + lane) * 8), bx4, acc);
+                } else {
+#pragma unroll
+                    for (int ks = 0; ks < KIN; ++ks)
+                        acc = BM_MFMA_F16_K32(*reinterpret_cast<const h8*>(wts + bp.down_a + ((co * KIN + ks) * 64 + lane) * 16), bx[ks], acc);
+                }
+            } else {
+                const h4 idn = *reinterpret_cast<const h4*>(xin + (long)p * CIN + g * (CIN / 4) + 4 * co);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] += (float)idn[r];
+            }
+            *reinterpret_cast<h4*>(yout + (long)p * COUT + g * (COUT / 4) + 4 * co) = to_h4(relu4(acc));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// transition: Conv1x1(C -> C) + BN + ReLU, then AvgPool 2x2 (osnet.py:344-350)
+// in [n][H*W][C] -> out [n][H*W/4][C].  One wave per pair of image rows.
+// wts: fragments [ct][ks] (1 KiB each) then fp32 bias[C].
+// ---------------------------------------------------------------------------
+template <int C, int H, int W>
+__global__ void __launch_bounds__(256) k_transition(const _Float16* __restrict__ in, _Float16* __restrict__ out,
+                                                    const unsigned char* __restrict__ wts, int n_crops) {
+    constexpr int NCT = C / 16, KS = C / 32, TPR = W / 16;        // tiles per image row
+    constexpr int PAIRS = H / 2;
+    const int lane = threadIdx.x & 63, g = lane >> 4, l16 = lane & 15;
+    const long unit = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // (crop, row pair)
+    if (unit >= (long)n_crops * PAIRS) return;
+    const long crop = unit / PAIRS;
+    const int yp = unit % PAIRS;
+    const _Float16* xin = in + crop * (H * W) * C;
+    _Float16* yout = out + crop * (H * W / 4) * C;
+    const unsigned char* bias = wts + NCT * KS * 1024;
+#pragma unroll 1
+    for (int half = 0; half < TPR; ++half) {
+        h8 b[2][KS];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int p = (2 * yp + rr) * W + half * 16 + l16;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) b[rr][ks] = *reinterpret_cast<const h8*>(xin + (long)p * C + g * (C / 4) + 8 * ks);
+        }
+#pragma unroll 1
+        for (int ct = 0; ct < NCT; ++ct) {
+            const f4 bv = *reinterpret_cast<const f4*>(bias + (16 * ct + 4 * g) * 4);
+            f4 acc0 = bv, acc1 = bv;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const h8 a = *reinterpret_cast<const h8*>(wts + ((ct * KS + ks) * 64 + lane) * 16);
+                acc0 = BM_MFMA_F16_K32(a, b[0][ks], acc0);
+                acc1 = BM_MFMA_F16_K32(a, b[1][ks], acc1);
+            }
+            acc0 = relu4(acc0); acc1 = relu4(acc1);
+            f4 s;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc0[r] + acc1[r];
+                v += __shfl_xor(v, 1, 64);                 // horizontal neighbour (x, x^1)
+                s[r] = v * 0.25f;
+            }
+            if ((l16 & 1) == 0) {
+                const int po = yp * (W / 2) + half * 8 + (l16 >> 1);
+                *reinterpret_cast<h4*>(yout + (long)po * C + g * (C / 4) + 4 * ct) = to_h4(s);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// head: conv5 (1x1 C->C + ReLU) -> GAP -> FC(C->F) + BN1d + ReLU -> L2 norm
+// (osnet.py:310-315, 393-396; base_backend.py:206).  in [n][128 px][C]; one
+// workgroup (2 waves) per crop.  wts5: fragments [ct][ks] + bias; wfc: fp16 [F][C] (memory order) + fp32 bias.
+// ---------------------------------------------------------------------------
+template <int C, int F>
+__global__ void __launch_bounds__(128) k_head_fused(const _Float16* __restrict__ in, const unsigned char* __restrict__ wts5,
+                                                    const unsigned char* __restrict__ wfc, float* __restrict__ out_base,
+                                                    const int* __restrict__ out_rows) {
+    constexpr int NCT = C / 16, KS = C / 32, P = 128, NT = 4;
+    __shared__ float s_gap[2][C];
+    __shared__ float s_v[C];
+    __shared__ float s_red[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l16 = lane & 15;
+    const long crop = blockIdx.x;
+    const _Float16* xin = in + crop * P * C;
+    const unsigned char* bias5 = wts5 + NCT * KS * 1024;
+    f4 sum[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) sum[ct] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int i = 0; i < NT; ++i) {
+        const int p = (wave * NT + i) * 16 + l16;
+        h8 b[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) b[ks] = *reinterpret_cast<const h8*>(xin + (long)p * C + g * (C / 4) + 8 * ks);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            f4 acc = *reinterpret_cast<const f4*>(bias5 + (16 * ct + 4 * g) * 4);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                acc = BM_MFMA_F16_K32(*reinterpret_cast<const h8*>(wts5 + ((ct * KS + ks) * 64 + lane) * 16), b[ks], acc);
+            acc = relu4(acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sum[ct][r] += acc[r];
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = sum[ct][r];
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+            if (l16 == 0) s_gap[wave][g * (C / 4) + 4 * ct + r] = v;      // memory (L-layout) channel order
+        }
+    __syncthreads();
+    for (int c = tid; c < C; c += 128) s_v[c] = (s_gap[0][c] + s_gap[1][c]) * (1.0f / P);
+    __syncthreads();
+    const float* fcb = reinterpret_cast<const float*>(wfc + (long)F * C * 2);
+    const _Float16* fcw = reinterpret_cast<const _Float16*>(wfc);
+    float* out = out_base + (out_rows ? (long)out_rows[crop] : crop) * F;
+    float vals[F / 128];
+    float sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < F / 128; ++k) {
+        const int f = tid + k * 128;
+        float a = fcb[f];
+        const h8* wr = reinterpret_cast<const h8*>(fcw + (long)f * C);
+        for (int c8 = 0; c8 < C / 8; ++c8) {
+            const h8 w8 = wr[c8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a += (float)w8[j] * s_v[c8 * 8 + j];
+        }
+        a = a > 0.f ? a : 0.f;
+        vals[k] = a;
+        sq += a * a;
+    }
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+    if (lane == 0) s_red[wave] = sq;
+    __syncthreads();
+    const float nrm = sqrtf(s_red[0] + s_red[1]);
+#pragma unroll
+    for (int k = 0; k < F / 128; ++k) out[tid + k * 128] = vals[k] / nrm;
+}
+
+// ---------------------------------------------------------------------------
+// stem: conv 7x7 stride 2 pad 3 (3 -> 16) + BN + ReLU + maxpool 3x3 stride 2 pad 1
+// (osnet.py:294-295).  Input: fp16 RGBX crops with a 3-pixel zero border,
+// [n][262][136][4]; output [n][64*32][16] lane-group-major.  One workgroup
+// (8 waves) per crop; wave w produces pooled rows 8w..8w+7.  The 7x7x3 window is
+// 7 MFMA k-steps (one per kernel row): 8 input pixels x RGBX = 32 halves = one
+// 16-byte load per lane (k-slot order fixed by pack_stem).
+// ---------------------------------------------------------------------------
+constexpr int STEM_ROWS = 262, STEM_COLS = 136;
+
+__device__ inline f4 max4(f4 a, f4 b) {
+    return f4{a[0] > b[0] ? a[0] : b[0], a[1] > b[1] ? a[1] : b[1], a[2] > b[2] ? a[2] : b[2], a[3] > b[3] ? a[3] : b[3]};
+}
+
+__global__ void __launch_bounds__(512) k_stem_fused(const _Float16* __restrict__ crops, _Float16* __restrict__ out,
+                                                    const unsigned char* __restrict__ wts) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l16 = lane & 15;
+    const long crop = blockIdx.x;
+    const _Float16* img = crops + crop * (STEM_ROWS * STEM_COLS * 4);
+    _Float16* yout = out + crop * (64 * 32) * 16;
+    h8 a[7];
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky) a[ky] = *reinterpret_cast<const h8*>(wts + (ky * 64 + lane) * 16);
+    const f4 bias = *reinterpret_cast<const f4*>(wts + 7 * 1024 + 4 * g * 4);
+
+    // conv row cy (0..127), 4 tiles of 16 conv pixels; rows outside the image contribute 0 (post-ReLU >= 0)
+    auto conv_row = [&](int cy, f4 (&row)[4]) {
+        if (cy < 0 || cy > 127) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) row[t] = f4{0.f, 0.f, 0.f, 0.f};
+            return;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f4 acc = bias;
+            const int cx = t * 16 + l16;
+#pragma unroll
+            for (int ky = 0; ky < 7; ++ky) {
+                const h8 b = *reinterpret_cast<const h8*>(img + ((long)(2 * cy + ky) * STEM_COLS + 2 * cx + 2 * g) * 4);
+                acc = BM_MFMA_F16_K32(a[ky], b, acc);
+            }
+            row[t] = relu4(acc);
+        }
+    };
+    f4 prev[4], mid[4], next[4];
+    const int oy0 = wave * 8;
+    conv_row(2 * oy0 - 1, prev);
+#pragma unroll 1
+    for (int oy = oy0; oy < oy0 + 8; ++oy) {
+        conv_row(2 * oy, mid);
+        conv_row(2 * oy + 1, next);
+        // vertical max, then horizontal max over (cx-1, cx, cx+1); pooled pixel ox = cx/2 sits on even lanes
+        f4 v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = max4(max4(prev[t], mid[t]), next[t]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f4 m = v[t];
+            const int src_r = (lane & 48) | ((l16 + 1) & 15);     // right neighbour, same tile (even lanes only need l16 <= 14)
+            const int src_l = (lane & 48) | ((l16 + 15) & 15);    // left neighbour (lane 0 wraps to lane 15: fixed below)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float right = __shfl(v[t][r], src_r, 64);
+                float left = __shfl(v[t][r], src_l, 64);
+                const float left_prev_tile = t > 0 ? __shfl(v[t > 0 ? t - 1 : 0][r], src_l, 64) : 0.f;
+                if (l16 == 0) left = left_prev_tile;
+                float mm = m[r] > right ? m[r] : right;
+                m[r] = mm > left ? mm : left;
+            }
+            if ((l16 & 1) == 0) {
+                const int p = oy * 32 + t * 8 + (l16 >> 1);
+                *reinterpret_cast<h4*>(yout + (long)p * 16 + g * 4) = to_h4(m);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) prev[t] = next[t];
+    }
+}
+
+// crop -> resize -> normalise into the stem's fp16 RGBX layout (interior only; the 3-pixel border and the
+// X channel of the buffer stay zero from allocation).  Same integer pipeline as k_crop_resize.
+__global__ void k_crop_resize_rgbx(const uint8_t* const* frames, const int* crop_stream, const float* boxes,
+                                   int box_stride, int W, int H, const float* lut, _Float16* out, int rows_per_block) {
+    const int i = blockIdx.x;
+    const int dx = threadIdx.x;
+    const uint8_t* frame = frames[crop_stream[i]];
+    const CropRect r = crop_rect(boxes + (long)i * box_stride, W, H);
+    const long row_stride = (long)W * 3;
+    const uint8_t* src = frame + (long)r.y1 * row_stride + r.x1 * 3;
+    const ResizeAxis ax = resize_axis_x(dx, REID_IN_W, r.w > 0 ? r.w : 1);
+    const int y0 = blockIdx.y * rows_per_block;
+    for (int dy = y0; dy < y0 + rows_per_block && dy < REID_IN_H; ++dy) {
+        const ResizeAxis ay = resize_axis_y(dy, REID_IN_H, r.h > 0 ? r.h : 1);
+        h4 px;
+        for (int c = 0; c < 3; ++c) {
+            const int v = resize_sample(src, row_stride, r, ax, ay, dy, dx, 2 - c, REID_IN_W, REID_IN_H);
+            px[c] = (_Float16)lut[c * 256 + v];
+        }
+        px[3] = (_Float16)0.f;
+        *reinterpret_cast<h4*>(out + (((long)i * STEM_ROWS + dy + 3) * STEM_COLS + dx + 3) * 4) = px;
+    }
+}
+
+}  // namespace bm

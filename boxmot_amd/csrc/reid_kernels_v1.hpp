@@ -7,8 +7,10 @@
 // on-device reference for the fused MFMA kernels (reid_fused.hpp).
 #pragma once
 
-#include <hip/hip_runtime.h>
 #include <cstdint>
+
+#include "kernel_macros.hpp"
+#include "reid_layout.hpp"
 
 namespace bm {
 
@@ -172,7 +174,7 @@ __global__ void k_maxpool3x3s2(const T* in, T* out, int H, int W, int C, long to
 template <typename T, int CO_T>
 __global__ void k_pointwise(const T* in, const float* w, const float* b, const T* res, T* out,
                             long n_pix, int cin, int cout, int relu, int co_chunk) {
-    extern __shared__ float s_w[];            // [co_chunk][cin] + [co_chunk]
+    BM_DYNAMIC_LDS_T(float, s_w);             // [co_chunk][cin] + [co_chunk]
     const int co0 = blockIdx.y * co_chunk;
     const int co_n = (cout - co0) < co_chunk ? (cout - co0) : co_chunk;
     for (int e = threadIdx.x; e < co_n * cin; e += blockDim.x) s_w[e] = w[(long)co0 * cin + e];

@@ -127,8 +127,65 @@ def load_weights(weights):
     return pack_osnet(weights)
 
 
+def reference_init_state_dict(arch: str = "osnet_x0_25", seed: int = 0):
+    """Random-init weights exactly as the reference architecture initialises itself
+    (OSNet._init_params, osnet.py:360-378): Kaiming-normal (fan_out, ReLU gain) convolutions,
+    identity BatchNorm (weight 1, bias 0, running mean 0 / var 1), Linear ~ N(0, 0.01), zero biases.
+    This is the "random-init weights of that architecture" the benchmark uses."""
+    import torch
+
+    ch = ARCH_CHANNELS[arch]
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def conv(name, cout, cin, k, groups=1):
+        sd[name] = torch.randn(cout, cin // groups, k, k, generator=g) * (2.0 / (cout * k * k)) ** 0.5
+
+    def bn(name, c):
+        sd[name + ".weight"] = torch.ones(c)
+        sd[name + ".bias"] = torch.zeros(c)
+        sd[name + ".running_mean"] = torch.zeros(c)
+        sd[name + ".running_var"] = torch.ones(c)
+
+    conv("conv1.conv.weight", ch[0], 3, 7)
+    bn("conv1.bn", ch[0])
+    cin = ch[0]
+    for bi, p in enumerate(BLOCKS):
+        cout = ch[bi // 2 + 1]
+        mid = cout // 4
+        conv(p + ".conv1.conv.weight", mid, cin, 1)
+        bn(p + ".conv1.bn", mid)
+        for ln in LIGHT_NAMES:
+            conv(f"{p}.{ln}.conv1.weight", mid, mid, 1)
+            conv(f"{p}.{ln}.conv2.weight", mid, mid, 3, groups=mid)
+            bn(f"{p}.{ln}.bn", mid)
+        hid = mid // 16
+        conv(p + ".gate.fc1.weight", hid, mid, 1)
+        sd[p + ".gate.fc1.bias"] = torch.zeros(hid)
+        conv(p + ".gate.fc2.weight", mid, hid, 1)
+        sd[p + ".gate.fc2.bias"] = torch.zeros(mid)
+        conv(p + ".conv3.conv.weight", cout, mid, 1)
+        bn(p + ".conv3.bn", cout)
+        if cin != cout:
+            conv(p + ".downsample.conv.weight", cout, cin, 1)
+            bn(p + ".downsample.bn", cout)
+        cin = cout
+        if bi in (1, 3):
+            t = p.rsplit(".", 1)[0] + ".2.0"
+            conv(t + ".conv.weight", cout, cout, 1)
+            bn(t + ".bn", cout)
+    conv("conv5.conv.weight", ch[3], ch[3], 1)
+    bn("conv5.bn", ch[3])
+    sd["fc.0.weight"] = torch.randn(FEATURE_DIM, ch[3], generator=g) * 0.01
+    sd["fc.0.bias"] = torch.zeros(FEATURE_DIM)
+    bn("fc.1", FEATURE_DIM)
+    return sd
+
+
 def random_osnet_state_dict(arch: str = "osnet_x0_25", seed: int = 0, num_classes: int = 0, calib_batch: int = 4):
-    """Seeded random weights with the reference's parameter names and shapes.
+    """Seeded random weights with the reference's parameter names and shapes ("calibrated" variant:
+    deliberately non-trivial BatchNorm statistics to exercise the folding; it is a noise-amplifying
+    network, used for the fp32 parity tests -- see reference_init_state_dict for the benchmark init).
 
     Convolutions: Kaiming-normal (fan_out), as osnet.py:360-378 initialises them.
     BatchNorm: gamma ~ U(0.5, 1.5), beta ~ N(0, 0.2); running statistics are set

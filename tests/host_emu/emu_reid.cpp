@@ -1,0 +1,136 @@
+// TEST-ONLY harness: runs the fused fp16 ReID kernels (boxmot_amd/csrc/reid_fused.hpp, the device
+// source unchanged) on CPU threads with an emulated MFMA.  Built with the ROCm clang in host mode
+// (needs _Float16).  Validates weight packing, fragment layouts and the data flow against the torch
+// oracle before any GPU time is spent; not a product path (see hip_shim.hpp).
+#include "hip_shim.hpp"
+
+#include <cstdlib>
+#include <functional>
+#include <vector>
+
+#include "../../boxmot_amd/csrc/reid_fused.hpp"
+
+thread_local EmuDim3 threadIdx;
+thread_local EmuDim3 blockIdx;
+EmuDim3 blockDim;
+EmuBlock* g_emu_block = nullptr;
+unsigned char* g_emu_dynamic_lds = nullptr;
+EmuMfmaBuf* g_emu_mfma = nullptr;
+
+namespace {
+
+struct TA { const std::function<void()>* fn; int tid; int bx, by; };
+
+void* tmain(void* p) {
+    TA* a = static_cast<TA*>(p);
+    threadIdx.x = a->tid; blockIdx.x = a->bx; blockIdx.y = a->by;
+    (*a->fn)();
+    return nullptr;
+}
+
+// run `fn` as a grid of gx x gy workgroups of nthr threads (workgroups sequential)
+void launch(int gx, int gy, int nthr, const std::function<void()>& fn) {
+    static EmuBlock block;
+    static EmuMfmaBuf mf;
+    static std::vector<unsigned char> lds(400000 + 64);
+    g_emu_block = &block; g_emu_mfma = &mf;
+    g_emu_dynamic_lds = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(lds.data()) + 15) & ~uintptr_t(15));
+    blockDim.x = nthr;
+    block.block_barrier.init(nthr);
+    for (int w = 0; w < EMU_MAX_WAVES; ++w) block.wave_barrier[w].init(EMU_WAVE);
+    pthread_attr_t attr;
+    pthread_attr_init(&attr);
+    pthread_attr_setstacksize(&attr, 1 << 20);
+    for (int by = 0; by < gy; ++by)
+        for (int bx = 0; bx < gx; ++bx) {
+            std::vector<pthread_t> th(nthr);
+            std::vector<TA> ta(nthr);
+            for (int t = 0; t < nthr; ++t) { ta[t] = TA{&fn, t, bx, by}; pthread_create(&th[t], &attr, tmain, &ta[t]); }
+            for (int t = 0; t < nthr; ++t) pthread_join(th[t], nullptr);
+        }
+    pthread_attr_destroy(&attr);
+}
+
+// L-layout fp16 tensor [n][P][C] -> fp32 natural NHWC
+void unpack_act(const _Float16* src, float* dst, long n_pix, int C) {
+    for (long p = 0; p < n_pix; ++p)
+        for (int c = 0; c < C; ++c) {
+            const int ct = c / 16, g = (c % 16) / 4, r = c % 4;
+            dst[p * C + c] = (float)src[p * C + g * (C / 4) + 4 * ct + r];
+        }
+}
+
+}  // namespace
+
+extern "C" {
+
+// crops: normalised fp32 NHWC (n, 256, 128, 3).  stage_out[k] (may be null) receives the fp32 NHWC
+// activation after: 0 stem+maxpool, 1..2 stage-1 blocks, 3 transition, 4..5 blocks, 6 transition,
+// 7..8 blocks.  feats: (n, 512) L2-normalised.
+int emu_reid_forward(const float* blob, long n_floats, const float* crops, int n, float* feats, float** stage_out) {
+    using namespace bm;
+    const int32_t* hdr = reinterpret_cast<const int32_t*>(blob);
+    if (hdr[0] != REID_MAGIC || hdr[1] != 16) return -1;
+    const int ch[4] = {hdr[1], hdr[2], hdr[3], hdr[4]};
+    const OsnetLayout L = make_osnet_layout(ch, hdr[5]);
+    if (n_floats != REID_HEADER_INTS + L.total) return -2;
+    const float* w = blob + REID_HEADER_INTS;
+    // inputs: fp16 RGBX with a 3-pixel zero border
+    std::vector<_Float16> cx((size_t)n * STEM_ROWS * STEM_COLS * 4, (_Float16)0.f);
+    for (int i = 0; i < n; ++i)
+        for (int y = 0; y < 256; ++y)
+            for (int x = 0; x < 128; ++x)
+                for (int c = 0; c < 3; ++c)
+                    cx[(((size_t)i * STEM_ROWS + y + 3) * STEM_COLS + x + 3) * 4 + c] =
+                        (_Float16)crops[(((size_t)i * 256 + y) * 128 + x) * 3 + c];
+    std::vector<_Float16> A((size_t)n * 2048 * 64), B((size_t)n * 2048 * 64);
+    std::vector<uint8_t> wst;
+    pack_stem(w + L.stem_w, w + L.stem_b, wst);
+    {
+        const _Float16* in = cx.data(); _Float16* out = A.data(); const unsigned char* wp = wst.data();
+        launch(n, 1, 512, [=]() { k_stem_fused(in, out, wp); });
+    }
+    if (stage_out && stage_out[0]) unpack_act(A.data(), stage_out[0], (long)n * 2048, 16);
+    _Float16* cur = A.data();
+    _Float16* nxt = B.data();
+    int dump = 1;
+    auto run_block = [&](int bi, auto kernel, int stage, int cin, int down, int nthr, int lds_bytes, int P, int cout) {
+        (void)lds_bytes;
+        const BlkPack bp = make_blk_pack(stage, cin, down);
+        std::vector<uint8_t> wb;
+        pack_osblock(w, L.block[bi], bp, wb);
+        const _Float16* in = cur; _Float16* out = nxt; const unsigned char* wp = wb.data();
+        launch(n, 1, nthr, [=]() { kernel(in, out, wp, bp); });
+        std::swap(cur, nxt);
+        if (stage_out && stage_out[dump]) unpack_act(cur, stage_out[dump], (long)n * P, cout);
+        ++dump;
+    };
+    auto run_trans = [&](int si, auto kernel, int C, int H, int W) {
+        std::vector<uint8_t> wt;
+        pack_pointwise(w + L.trans_w[si], w + L.trans_b[si], C, C, wt);
+        const _Float16* in = cur; _Float16* out = nxt; const unsigned char* wp = wt.data();
+        const int units = n * (H / 2);
+        launch((units + 3) / 4, 1, 256, [=]() { kernel(in, out, wp, n); });
+        std::swap(cur, nxt);
+        if (stage_out && stage_out[dump]) unpack_act(cur, stage_out[dump], (long)n * (H * W / 4), C);
+        ++dump;
+    };
+    run_block(0, k_osblock<0, 16, true>, 0, 16, 1, 512, Geo<0>::LDS_BYTES, 2048, 64);
+    run_block(1, k_osblock<0, 64, false>, 0, 64, 0, 512, Geo<0>::LDS_BYTES, 2048, 64);
+    run_trans(0, k_transition<64, 64, 32>, 64, 64, 32);
+    run_block(2, k_osblock<1, 64, true>, 1, 64, 1, 256, Geo<1>::LDS_BYTES, 512, 96);
+    run_block(3, k_osblock<1, 96, false>, 1, 96, 0, 256, Geo<1>::LDS_BYTES, 512, 96);
+    run_trans(1, k_transition<96, 32, 16>, 96, 32, 16);
+    run_block(4, k_osblock<2, 96, true>, 2, 96, 1, 128, Geo<2>::LDS_BYTES, 128, 128);
+    run_block(5, k_osblock<2, 128, false>, 2, 128, 0, 128, Geo<2>::LDS_BYTES, 128, 128);
+    std::vector<uint8_t> w5, wfc;
+    pack_pointwise(w + L.conv5_w, w + L.conv5_b, 128, 128, w5);
+    pack_fc(w + L.fc_w, w + L.fc_b, 512, 128, wfc);
+    {
+        const _Float16* in = cur; const unsigned char* p5 = w5.data(); const unsigned char* pf = wfc.data();
+        launch(n, 1, 128, [=]() { k_head_fused<128, 512>(in, p5, pf, feats, nullptr); });
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -85,3 +85,42 @@ inline unsigned long long __ballot(int pred) {
     return m;
 }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+
+// ---- additions for the fused ReID kernels (compiled with a host clang that knows _Float16) ----
+#define __restrict__
+#define BM_DYNAMIC_LDS_T(type, name) type* name = reinterpret_cast<type*>(g_emu_dynamic_lds)
+#define __shared__ static
+inline double __dadd_rn(double a, double b) { return a + b; }
+inline double __dmul_rn(double a, double b) { return a * b; }
+#define BM_EXPF(x) expf(x)
+#define BM_SCHED_FENCE() ((void)0)
+extern unsigned char* g_emu_dynamic_lds;
+inline float sqrtf_emu(float x) { return std::sqrt(x); }
+
+// MFMA emulation: every lane deposits its A/B fragment, then computes its 4 outputs of
+// D = A.B + C with the CDNA layouts (A: row = lane&15, k = H*(lane>>4)+j; B: col = lane&15,
+// same k; D: col = lane&15, rows 4*(lane>>4)+r).  H = 4 (16x16x16) or 8 (16x16x32).
+struct EmuMfmaBuf { float a[EMU_MAX_WAVES][EMU_WAVE][8]; float b[EMU_MAX_WAVES][EMU_WAVE][8]; };
+extern EmuMfmaBuf* g_emu_mfma;
+
+template <int H, class HA, class F>
+inline F emu_mfma(HA a, HA b, F c) {
+    const int wave = threadIdx.x / EMU_WAVE, lane = threadIdx.x % EMU_WAVE;
+    for (int j = 0; j < H; ++j) { g_emu_mfma->a[wave][lane][j] = (float)a[j]; g_emu_mfma->b[wave][lane][j] = (float)b[j]; }
+    g_emu_block->wave_barrier[wave].wait();
+    const int col = lane & 15, g = lane >> 4;
+    F d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * g + r;
+        float acc = c[r];
+        for (int k = 0; k < 4 * H; ++k) {
+            const int kg = k / H, kj = k % H;
+            acc += g_emu_mfma->a[wave][row + 16 * kg][kj] * g_emu_mfma->b[wave][col + 16 * kg][kj];
+        }
+        d[r] = acc;
+    }
+    g_emu_block->wave_barrier[wave].wait();
+    return d;
+}
+#define BM_MFMA_F16_K16(a, b, c) emu_mfma<4>(a, b, c)
+#define BM_MFMA_F16_K32(a, b, c) emu_mfma<8>(a, b, c)

@@ -121,3 +121,80 @@ def test_device_resident_multistream_reid_step():
             assert got.shape == want.shape and np.array_equal(got[:, 4:], want[:, 4:]), (s, t)
     assert ms.status().tolist() == [0] * S
     ms.close()
+
+
+def test_fused_fp16_mode_reference_init_within_tolerance():
+    """mode 1 (fused fp16 MFMA kernels) on random-init weights of the architecture (the benchmark's weights):
+    embeddings within 1e-3 of the fp32 oracle; mode 0 and mode 1 agree on the same handle."""
+    from boxmot_amd.reid import MODE_FP16_FUSED, MODE_FP32_LAYERWISE, HipReID
+    from boxmot_amd.reid_weights import reference_init_state_dict
+    from oracle.osnet import OracleReID
+    g, _, img = _golden()
+    sd = reference_init_state_dict("osnet_x0_25", seed=0)
+    rng = np.random.default_rng(1)
+    boxes = np.stack([rng.uniform(0, 1800, 48), rng.uniform(0, 900, 48), np.zeros(48), np.zeros(48)], 1).astype(np.float32)
+    boxes[:, 2] = boxes[:, 0] + rng.uniform(20, 120, 48)
+    boxes[:, 3] = boxes[:, 1] + rng.uniform(40, 180, 48)
+    boxes = np.concatenate([g["boxes"], boxes]).astype(np.float32)
+    want = OracleReID(sd).get_features(boxes, img)
+    reid = HipReID(sd, max_crops=64, mode=MODE_FP16_FUSED)
+    got16 = reid.get_features(boxes, img)
+    err16 = np.abs(got16 - want).max()
+    assert err16 < TOL, err16
+    assert (got16 * want).sum(1).min() > 0.99999
+    reid.set_mode(MODE_FP32_LAYERWISE)
+    got32 = reid.get_features(boxes, img)
+    assert np.abs(got32 - want).max() < 1e-4
+    # crops are produced by the same integer pipeline in both modes
+    assert np.array_equal(reid.get_crops(boxes[:4], img), __import__("oracle.crops", fromlist=["get_crops"]).get_crops(boxes[:4], img))
+    reid.close()
+
+
+def test_fused_fp16_mode_on_calibrated_weights_cosine():
+    """The 'calibrated' random network amplifies rounding noise (even rounding only its input image to fp16
+    moves the fp32 result by 1.2e-3); there the fused fp16 kernels are held to the reference's own
+    cross-implementation criterion instead: unit norm and per-row cosine > 0.999 (test_reid_capi.py:158-171 uses 0.99)."""
+    from boxmot_amd.reid import MODE_FP16_FUSED, HipReID
+    g, sd, img = _golden()
+    reid = HipReID(sd, max_crops=16, mode=MODE_FP16_FUSED)
+    got = reid.get_features(g["boxes"], img)
+    assert np.allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-3)
+    assert (got * g["feats"]).sum(1).min() > 0.999
+    reid.close()
+
+
+def test_botsort_multistream_fused_reid_ids_match_oracle():
+    import torch
+
+    from boxmot_amd.reid_weights import reference_init_state_dict
+    from boxmot_amd.scenario import Scenario
+    from boxmot_amd.streams import MultiStreamBotSort
+    from oracle.botsort import BotSortOracle
+    from oracle.osnet import OracleReID
+    sd = reference_init_state_dict("osnet_x0_25", seed=0)
+    S, nd = 2, 32
+    scs = [Scenario(12, 24, width=640, height=480, random_image=True, stream=s) for s in range(S)]
+    ms = MultiStreamBotSort(S, max_tracks=64, max_dets=nd, emb_dim=512, reid_weights=sd)
+    ms.set_reid_mode(1)
+    orcs = [BotSortOracle(reid=OracleReID(sd)) for _ in range(S)]
+    dev = torch.device("cuda:0")
+    frames = torch.stack([torch.from_numpy(sc.image) for sc in scs]).to(dev)
+    ptrs = torch.tensor([frames[s].data_ptr() for s in range(S)], dtype=torch.int64, device=dev)
+    d_dets = torch.zeros((S, nd, 6), dtype=torch.float32, device=dev)
+    d_n = torch.zeros(S, dtype=torch.int32, device=dev)
+    d_out = torch.zeros((S, nd, 8), dtype=torch.float32, device=dev)
+    d_out_n = torch.zeros(S, dtype=torch.int32, device=dev)
+    for t in range(8):
+        per = [sc.frame(t)[0] for sc in scs]
+        for s in range(S):
+            d_dets[s, : len(per[s])] = torch.from_numpy(per[s]).to(dev)
+            d_n[s] = len(per[s])
+        torch.cuda.synchronize()
+        ms.step_device(d_dets.data_ptr(), d_n.data_ptr(), None, ptrs.data_ptr(), 480, 640, d_out.data_ptr(), d_out_n.data_ptr())
+        ms.synchronize()
+        out, cnt = d_out.cpu().numpy(), d_out_n.cpu().numpy()
+        for s in range(S):
+            want = orcs[s].update(per[s], scs[s].image)
+            got = out[s, : cnt[s]]
+            assert got.shape == want.shape and np.array_equal(got[:, 4:], want[:, 4:]), (s, t)
+    ms.close()
