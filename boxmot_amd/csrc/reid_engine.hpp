@@ -293,14 +293,14 @@ private:
     }
     void forward_fused(int n, float* d_out, const int* d_out_rows, hipStream_t st) {
         hipLaunchKernelGGL(k_stem_fused, dim3(n), dim3(512), 0, st, crops_h_, act_a_, w_stem_);
-        hipLaunchKernelGGL((k_osblock<0, 16, true>), dim3(n), dim3(512), Geo<0>::LDS_BYTES, st, act_a_, act_b_, w_blk_[0], bp_[0]);
-        hipLaunchKernelGGL((k_osblock<0, 64, false>), dim3(n), dim3(512), Geo<0>::LDS_BYTES, st, act_b_, act_a_, w_blk_[1], bp_[1]);
+        hipLaunchKernelGGL((k_osblock<0, 16, true>), dim3(n), dim3(64 * Geo<0>::NWAVES), Geo<0>::LDS_BYTES, st, act_a_, act_b_, w_blk_[0], bp_[0]);
+        hipLaunchKernelGGL((k_osblock<0, 64, false>), dim3(n), dim3(64 * Geo<0>::NWAVES), Geo<0>::LDS_BYTES, st, act_b_, act_a_, w_blk_[1], bp_[1]);
         hipLaunchKernelGGL((k_transition<64, 64, 32>), dim3((n * 32 + 3) / 4), dim3(256), 0, st, act_a_, act_b_, w_tr_[0], n);
-        hipLaunchKernelGGL((k_osblock<1, 64, true>), dim3(n), dim3(256), Geo<1>::LDS_BYTES, st, act_b_, act_a_, w_blk_[2], bp_[2]);
-        hipLaunchKernelGGL((k_osblock<1, 96, false>), dim3(n), dim3(256), Geo<1>::LDS_BYTES, st, act_a_, act_b_, w_blk_[3], bp_[3]);
+        hipLaunchKernelGGL((k_osblock<1, 64, true>), dim3(n), dim3(64 * Geo<1>::NWAVES), Geo<1>::LDS_BYTES, st, act_b_, act_a_, w_blk_[2], bp_[2]);
+        hipLaunchKernelGGL((k_osblock<1, 96, false>), dim3(n), dim3(64 * Geo<1>::NWAVES), Geo<1>::LDS_BYTES, st, act_a_, act_b_, w_blk_[3], bp_[3]);
         hipLaunchKernelGGL((k_transition<96, 32, 16>), dim3((n * 16 + 3) / 4), dim3(256), 0, st, act_b_, act_a_, w_tr_[1], n);
-        hipLaunchKernelGGL((k_osblock<2, 96, true>), dim3(n), dim3(128), Geo<2>::LDS_BYTES, st, act_a_, act_b_, w_blk_[4], bp_[4]);
-        hipLaunchKernelGGL((k_osblock<2, 128, false>), dim3(n), dim3(128), Geo<2>::LDS_BYTES, st, act_b_, act_a_, w_blk_[5], bp_[5]);
+        hipLaunchKernelGGL((k_osblock<2, 96, true>), dim3(n), dim3(64 * Geo<2>::NWAVES), Geo<2>::LDS_BYTES, st, act_a_, act_b_, w_blk_[4], bp_[4]);
+        hipLaunchKernelGGL((k_osblock<2, 128, false>), dim3(n), dim3(64 * Geo<2>::NWAVES), Geo<2>::LDS_BYTES, st, act_b_, act_a_, w_blk_[5], bp_[5]);
         hipLaunchKernelGGL((k_head_fused<128, 512>), dim3(n), dim3(128), 0, st, act_a_, w_c5_, w_fc_, d_out, d_out_rows);
     }
     void alloc_buffers() {

@@ -115,14 +115,14 @@ int emu_reid_forward(const float* blob, long n_floats, const float* crops, int n
         if (stage_out && stage_out[dump]) unpack_act(cur, stage_out[dump], (long)n * (H * W / 4), C);
         ++dump;
     };
-    run_block(0, k_osblock<0, 16, true>, 0, 16, 1, 512, Geo<0>::LDS_BYTES, 2048, 64);
-    run_block(1, k_osblock<0, 64, false>, 0, 64, 0, 512, Geo<0>::LDS_BYTES, 2048, 64);
+    run_block(0, k_osblock<0, 16, true>, 0, 16, 1, 64 * Geo<0>::NWAVES, Geo<0>::LDS_BYTES, 2048, 64);
+    run_block(1, k_osblock<0, 64, false>, 0, 64, 0, 64 * Geo<0>::NWAVES, Geo<0>::LDS_BYTES, 2048, 64);
     run_trans(0, k_transition<64, 64, 32>, 64, 64, 32);
-    run_block(2, k_osblock<1, 64, true>, 1, 64, 1, 256, Geo<1>::LDS_BYTES, 512, 96);
-    run_block(3, k_osblock<1, 96, false>, 1, 96, 0, 256, Geo<1>::LDS_BYTES, 512, 96);
+    run_block(2, k_osblock<1, 64, true>, 1, 64, 1, 64 * Geo<1>::NWAVES, Geo<1>::LDS_BYTES, 512, 96);
+    run_block(3, k_osblock<1, 96, false>, 1, 96, 0, 64 * Geo<1>::NWAVES, Geo<1>::LDS_BYTES, 512, 96);
     run_trans(1, k_transition<96, 32, 16>, 96, 32, 16);
-    run_block(4, k_osblock<2, 96, true>, 2, 96, 1, 128, Geo<2>::LDS_BYTES, 128, 128);
-    run_block(5, k_osblock<2, 128, false>, 2, 128, 0, 128, Geo<2>::LDS_BYTES, 128, 128);
+    run_block(4, k_osblock<2, 96, true>, 2, 96, 1, 64 * Geo<2>::NWAVES, Geo<2>::LDS_BYTES, 128, 128);
+    run_block(5, k_osblock<2, 128, false>, 2, 128, 0, 64 * Geo<2>::NWAVES, Geo<2>::LDS_BYTES, 128, 128);
     std::vector<uint8_t> w5, wfc;
     pack_pointwise(w + L.conv5_w, w + L.conv5_b, 128, 128, w5);
     pack_fc(w + L.fc_w, w + L.fc_b, 512, 128, wfc);
