@@ -67,6 +67,7 @@ SIGNATURES = {
     "boxmot_hip_botsort_timer_start": (_I, [_VP]),
     "boxmot_hip_botsort_timer_stop_ms": (_I, [_VP, c_double_p]),
     "boxmot_hip_botsort_reid_kernel_ms": (_I, [_VP, c_double_p, c_int_p]),
+    "boxmot_hip_botsort_phase_clocks": (_I, [_VP, _VP]),
     "boxmot_hip_botsort_status": (_I, [_VP, _VP, _I]),
     "boxmot_hip_botsort_set_reid_blob": (_I, [_VP, _VP, ctypes.c_long]),
     "boxmot_hip_botsort_set_reid_mode": (_I, [_VP, _I]),

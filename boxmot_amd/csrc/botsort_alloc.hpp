@@ -55,6 +55,7 @@ void botsort_allocate(BotSortStepArgs& args, const BotSortSizes& z, A& a) {
     sc.lap_minv = a.template get<double>(S * cap);
     sc.lap_way = a.template get<int>(S * cap); sc.lap_used = a.template get<int>(S * cap);
     sc.box_a = a.template get<double>(S * cap * 4);
+    sc.pair_list = a.template get<int>(S * 4096);
 }
 
 inline BotSortConfigDev make_config_dev(double high, double low, double new_thresh, double match, double prox,

@@ -21,12 +21,14 @@
 
 #include "block_prims.hpp"
 #include "botsort_types.hpp"
+#include "kernel_macros.hpp"
 
 namespace bm {
 
 constexpr double LAP_INF = 1.0e300;
 constexpr int COST_TILE = 64;     // rows x cols of one cosine tile
 constexpr int COST_KC = 32;       // k-chunk staged in LDS
+constexpr int SPARSE_MAX_ALLOC = 4096;   // capacity of the per-stream ungated-pair list
 
 // Per-stream views (pointers already offset to this stream).
 struct SV {
@@ -49,7 +51,7 @@ struct SV {
     int* activated; int* refound; int* newly_lost; int* newly_removed;
     int* match_slot; int* match_det; int* match_flag; int* drop_a; int* drop_b;
     double* cost; int* lap_x; int* lap_y; double* lap_u; double* lap_v; double* lap_minv;
-    int* lap_way; int* lap_used; double* box_a;
+    int* lap_way; int* lap_used; double* box_a; int* pair_list;
     // io
     const float* dets; int n_dets; const float* embs; float* out; int* out_n;
 };
@@ -95,6 +97,7 @@ __device__ inline SV make_view(const BotSortStepArgs& a, int s, int sel) {
     v.lap_v = sc.lap_v + s * cap; v.lap_minv = sc.lap_minv + s * cap;
     v.lap_way = sc.lap_way + s * cap; v.lap_used = sc.lap_used + s * cap;
     v.box_a = sc.box_a + s * cap * 4;
+    v.pair_list = sc.pair_list + (long)s * SPARSE_MAX_ALLOC;
     v.dets = a.dets + s * nd * DET_COLS;
     v.n_dets = a.n_dets[s];
     v.embs = a.embs ? a.embs + s * nd * dim : nullptr;
@@ -246,19 +249,58 @@ __device__ inline float wave_norm_f32(const float* x, int dim, int lane) {
     return sqrtf(wave_sum(s));
 }
 
+constexpr int MAX_VEC_PER_LANE = 32;    // appearance vectors up to 64 * 32 = 2048 floats stay in registers
+
 // STrack.update_features (botsort_track.py:58-67) for a live track: the matched
-// detection's vector is normalised once more, blended, renormalised.
+// detection's vector is normalised once more, blended, renormalised.  One read of
+// each vector, one write; everything else in registers.
 __device__ inline void blend_feature_wave(float* smooth, const float* feat, int dim, int lane) {
-    const float nf = wave_norm_f32(feat, dim, lane);
+    float f[MAX_VEC_PER_LANE], sm[MAX_VEC_PER_LANE];
     float s = 0.0f;
-    for (int k = lane; k < dim; k += WAVE) {
-        const float f = feat[k] / nf;
-        const float b = 0.9f * smooth[k] + 0.1f * f;
-        smooth[k] = b;
+#pragma unroll
+    for (int q = 0; q < MAX_VEC_PER_LANE; ++q) {
+        const int k = lane + q * WAVE;
+        f[q] = k < dim ? feat[k] : 0.0f;
+        sm[q] = k < dim ? smooth[k] : 0.0f;
+        s += f[q] * f[q];
+    }
+    const float nf = sqrtf(wave_sum(s));
+    s = 0.0f;
+#pragma unroll
+    for (int q = 0; q < MAX_VEC_PER_LANE; ++q) {
+        const float b = 0.9f * sm[q] + 0.1f * (f[q] / nf);
+        sm[q] = b;
         s += b * b;
     }
     const float ns = sqrtf(wave_sum(s));
-    for (int k = lane; k < dim; k += WAVE) smooth[k] = smooth[k] / ns;
+#pragma unroll
+    for (int q = 0; q < MAX_VEC_PER_LANE; ++q) {
+        const int k = lane + q * WAVE;
+        if (k < dim) smooth[k] = sm[q] / ns;
+    }
+}
+
+// STrack constructor's update_features on a fresh detection (botsort_track.py:58-66):
+// feat /= |feat|; smooth = feat; smooth /= |smooth|  -> the vector is normalised twice.
+__device__ inline void normalize_twice_wave(const float* src, float* dst, int dim, int lane) {
+    float x[MAX_VEC_PER_LANE];
+    float s = 0.0f;
+#pragma unroll
+    for (int q = 0; q < MAX_VEC_PER_LANE; ++q) {
+        const int k = lane + q * WAVE;
+        x[q] = k < dim ? src[k] : 0.0f;
+        s += x[q] * x[q];
+    }
+    const float n1 = sqrtf(wave_sum(s));
+    s = 0.0f;
+#pragma unroll
+    for (int q = 0; q < MAX_VEC_PER_LANE; ++q) { x[q] = x[q] / n1; s += x[q] * x[q]; }
+    const float n2 = sqrtf(wave_sum(s));
+#pragma unroll
+    for (int q = 0; q < MAX_VEC_PER_LANE; ++q) {
+        const int k = lane + q * WAVE;
+        if (k < dim) dst[k] = x[q] / n2;
+    }
 }
 
 // STrack.update / re_activate (botsort_track.py:244-282) for a list of
@@ -328,70 +370,136 @@ __device__ inline double iou_dist_tt(const double* a, const double* b) {
     return 1 - o;
 }
 
-// cost[r][c] for rows (track slots) x cols (detection indices):
-//   iou_d, gate = iou_d > proximity, optional fuse_score, cosine distance
-//   (optionally / emb_scale), appearance + proximity gating, element-wise min.
+// Association cost for rows (track slots) x cols (detection indices), stored DETECTION-MAJOR
+// (cost[c * cap + r]) because the assignment solver scans one detection column over all tracks:
+//   iou_d, gate = iou_d > proximity, optional fuse_score, cosine distance (optionally / emb_scale),
+//   appearance + proximity gating, element-wise min.
 // botsort.py:306-317 (first association) and :396-413 (unconfirmed tracks).
-// The cosine term is an LDS-tiled fp32 x fp32 -> fp64 contraction: a 64x64 tile
-// of (track, detection) pairs per pass, k staged in chunks of 32 through LDS,
-// each pair accumulated in ascending k exactly like scipy's cdist loop.
+// Gated pairs get emb = 1.0 whatever their cosine is (botsort.py:314), so the cosine is evaluated
+// only for the pairs that pass the IoU gate (typically ~1 per detection): one wavefront per pair,
+// fp32 x fp32 products accumulated in fp64.  Scenes with more than SPARSE_MAX ungated pairs fall
+// back to the dense LDS-tiled contraction (64x64 pair tiles, k staged through LDS in chunks of 32,
+// every pair accumulated in ascending k like scipy's cdist loop).
+#ifndef BM_SPARSE_MAX
+#define BM_SPARSE_MAX 4096
+#endif
+constexpr int SPARSE_MAX = BM_SPARSE_MAX;     // tests build a variant with 0 to force the dense path
+
+__device__ inline double cosine_gate(double dot, double nu, double nv, double emb_scale, double app, bool gate) {
+    double cosv = dot / (nu * nv);
+    if (fabs(cosv) > 1.0) cosv = cosv > 0 ? 1.0 : -1.0;       // scipy clips rounding overshoot
+    double e = 1.0 - cosv;
+    e = e > 0.0 ? e : (e != e ? e : 0.0);                       // np.maximum(0.0, e)
+    if (emb_scale > 0.0) e = e / emb_scale;
+    if (e > app) e = 1.0;
+    if (gate) e = 1.0;
+    return e;
+}
+__device__ inline double np_minimum(double a, double b) { return (a != a || b != b) ? (a != a ? a : b) : (a < b ? a : b); }
+
 template <int NTHR>
 __device__ inline void assoc_cost(const Ctx& c, SV& v, const int* rows, int n_rows, const int* cols,
                                   int n_cols, bool use_emb, double emb_scale, bool fuse,
-                                  float (*sA)[COST_KC + 1], float (*sB)[COST_KC + 1]) {
+                                  float (*sA)[COST_KC + 1], float (*sB)[COST_KC + 1], int* s_count) {
     if (n_rows == 0 || n_cols == 0) return;
     track_boxes(c, v, rows, n_rows, v.box_a);
-    const int ld = v.nd;
-    if (use_emb) {
-        // row norms (scipy _row_norms: sqrt(sum x^2) in fp64)
-        for (int base = 0; base < n_rows + n_cols; base += c.nwaves) {
-            const int q = base + c.wave;
-            if (q < n_rows + n_cols) {
-                const float* x = (q < n_rows) ? v.smooth + (long)rows[q] * v.dim
-                                              : v.det_feat + (long)cols[q - n_rows] * v.dim;
-                double s = 0.0;
-                for (int k = c.lane; k < v.dim; k += WAVE) s += (double)x[k] * (double)x[k];
-                s = wave_sum(s);
+    const long ld = v.cap;
+    if (c.tid == 0) *s_count = 0;
+    __syncthreads();
+    // pass 1: IoU part for every pair; collect the pairs whose appearance term matters
+    for (int o = c.tid; o < n_rows * n_cols; o += c.nthr) {
+        const int cc = o / n_rows, r = o % n_rows;
+        const int d = cols[cc];
+        double iou_d = iou_dist_td(v.box_a + r * 4, v.det_xyxy + d * 4, v.det_area[d]);
+        const bool gate = iou_d > v.cfg.proximity_thresh;
+        if (fuse) {
+            const double sim = 1 - iou_d;
+            iou_d = 1 - sim * (double)v.dets[d * DET_COLS + 4];
+        }
+        double out = iou_d;
+        if (use_emb) {
+            if (gate) out = np_minimum(iou_d, 1.0);
+            else {
+                const int k = atomicAdd(s_count, 1);
+                if (k < SPARSE_MAX) v.pair_list[k] = o;
+            }
+        }
+        v.cost[cc * ld + r] = out;
+    }
+    __syncthreads();
+    if (!use_emb) return;
+    const int n_pairs = *s_count;
+    __syncthreads();
+    if (n_pairs <= SPARSE_MAX || n_pairs == 0) {
+        for (int base = 0; base < n_pairs; base += c.nwaves) {
+            const int k = base + c.wave;
+            if (k < n_pairs) {
+                const int o = v.pair_list[k];
+                const int cc = o / n_rows, r = o % n_rows;
+                const float* a = v.smooth + (long)rows[r] * v.dim;
+                const float* b = v.det_feat + (long)cols[cc] * v.dim;
+                double dot = 0.0, na = 0.0, nb = 0.0;
+                for (int q = c.lane; q < v.dim; q += WAVE) {
+                    const double x = (double)a[q], y = (double)b[q];
+                    dot += x * y; na += x * x; nb += y * y;
+                }
+                dot = wave_sum(dot); na = wave_sum(na); nb = wave_sum(nb);
                 if (c.lane == 0) {
-                    if (q < n_rows) v.trk_norm[q] = sqrt(s);
-                    else v.det_norm[q - n_rows] = sqrt(s);
+                    const double e = cosine_gate(dot, sqrt(na), sqrt(nb), emb_scale, v.cfg.appearance_thresh, false);
+                    double* dst = v.cost + cc * ld + r;
+                    *dst = np_minimum(*dst, e);
                 }
             }
         }
         __syncthreads();
+        return;
     }
+    // dense path: norms (scipy _row_norms: sqrt(sum x^2) in fp64), then the LDS-tiled contraction
+    for (int base = 0; base < n_rows + n_cols; base += c.nwaves) {
+        const int q = base + c.wave;
+        if (q < n_rows + n_cols) {
+            const float* x = (q < n_rows) ? v.smooth + (long)rows[q] * v.dim
+                                          : v.det_feat + (long)cols[q - n_rows] * v.dim;
+            double s = 0.0;
+            for (int k = c.lane; k < v.dim; k += WAVE) s += (double)x[k] * (double)x[k];
+            s = wave_sum(s);
+            if (c.lane == 0) {
+                if (q < n_rows) v.trk_norm[q] = sqrt(s);
+                else v.det_norm[q - n_rows] = sqrt(s);
+            }
+        }
+    }
+    __syncthreads();
     constexpr int per_thread = (COST_TILE * COST_TILE + NTHR - 1) / NTHR;   // fp64 accumulators per thread
     for (int r0 = 0; r0 < n_rows; r0 += COST_TILE) {
         for (int c0 = 0; c0 < n_cols; c0 += COST_TILE) {
             double acc[per_thread];
 #pragma unroll
             for (int m = 0; m < per_thread; ++m) acc[m] = 0.0;
-            if (use_emb) {
-                for (int k0 = 0; k0 < v.dim; k0 += COST_KC) {
-                    for (int e = c.tid; e < COST_TILE * COST_KC; e += c.nthr) {
-                        const int rr = e / COST_KC, kk = e % COST_KC;
-                        const int k = k0 + kk;
-                        float a = 0.0f, b = 0.0f;
-                        if (k < v.dim) {
-                            if (r0 + rr < n_rows) a = v.smooth[(long)rows[r0 + rr] * v.dim + k];
-                            if (c0 + rr < n_cols) b = v.det_feat[(long)cols[c0 + rr] * v.dim + k];
-                        }
-                        sA[rr][kk] = a;
-                        sB[rr][kk] = b;
+            for (int k0 = 0; k0 < v.dim; k0 += COST_KC) {
+                for (int e = c.tid; e < COST_TILE * COST_KC; e += c.nthr) {
+                    const int rr = e / COST_KC, kk = e % COST_KC;
+                    const int k = k0 + kk;
+                    float a = 0.0f, b = 0.0f;
+                    if (k < v.dim) {
+                        if (r0 + rr < n_rows) a = v.smooth[(long)rows[r0 + rr] * v.dim + k];
+                        if (c0 + rr < n_cols) b = v.det_feat[(long)cols[c0 + rr] * v.dim + k];
                     }
-                    __syncthreads();
-#pragma unroll
-                    for (int m = 0; m < per_thread; ++m) {
-                        const int o = c.tid + m * NTHR;
-                        if (o < COST_TILE * COST_TILE) {
-                            const int rr = o / COST_TILE, cc = o % COST_TILE;
-                            double s = acc[m];
-                            for (int kk = 0; kk < COST_KC; ++kk) s += (double)sA[rr][kk] * (double)sB[cc][kk];
-                            acc[m] = s;
-                        }
-                    }
-                    __syncthreads();
+                    sA[rr][kk] = a;
+                    sB[rr][kk] = b;
                 }
+                __syncthreads();
+#pragma unroll
+                for (int m = 0; m < per_thread; ++m) {
+                    const int o = c.tid + m * NTHR;
+                    if (o < COST_TILE * COST_TILE) {
+                        const int rr = o / COST_TILE, cc = o % COST_TILE;
+                        double s = acc[m];
+                        for (int kk = 0; kk < COST_KC; ++kk) s += (double)sA[rr][kk] * (double)sB[cc][kk];
+                        acc[m] = s;
+                    }
+                }
+                __syncthreads();
             }
 #pragma unroll
             for (int m = 0; m < per_thread; ++m) {
@@ -400,39 +508,28 @@ __device__ inline void assoc_cost(const Ctx& c, SV& v, const int* rows, int n_ro
                 const int r = r0 + o / COST_TILE, cc = c0 + o % COST_TILE;
                 if (r >= n_rows || cc >= n_cols) continue;
                 const int d = cols[cc];
-                double iou_d = iou_dist_td(v.box_a + r * 4, v.det_xyxy + d * 4, v.det_area[d]);
-                const bool gate = iou_d > v.cfg.proximity_thresh;
-                if (fuse) {
-                    const double sim = 1 - iou_d;
-                    iou_d = 1 - sim * (double)v.dets[d * DET_COLS + 4];
-                }
-                double out = iou_d;
-                if (use_emb) {
-                    double cosv = acc[m] / (v.trk_norm[r] * v.det_norm[cc]);
-                    if (fabs(cosv) > 1.0) cosv = cosv > 0 ? 1.0 : -1.0;
-                    double e = 1.0 - cosv;
-                    e = e > 0.0 ? e : (e != e ? e : 0.0);          // np.maximum(0.0, e)
-                    if (emb_scale > 0.0) e = e / emb_scale;
-                    if (e > v.cfg.appearance_thresh) e = 1.0;
-                    if (gate) e = 1.0;
-                    out = (iou_d != iou_d || e != e) ? (iou_d != iou_d ? iou_d : e) : (iou_d < e ? iou_d : e);
-                }
-                v.cost[(long)r * ld + cc] = out;
+                // the gate is re-derived from the un-fused IoU distance
+                const double raw = iou_dist_td(v.box_a + r * 4, v.det_xyxy + d * 4, v.det_area[d]);
+                const bool gate = raw > v.cfg.proximity_thresh;
+                if (gate) continue;                                   // pass 1 already stored min(iou_d, 1)
+                const double e = cosine_gate(acc[m], v.trk_norm[r], v.det_norm[cc], emb_scale, v.cfg.appearance_thresh, false);
+                double* dst = v.cost + cc * ld + r;
+                *dst = np_minimum(*dst, e);
             }
         }
     }
     __syncthreads();
 }
 
-// IoU-only cost (second association, botsort.py:356).
+// IoU-only cost (second association, botsort.py:356), detection-major.
 __device__ inline void iou_cost(const Ctx& c, SV& v, const int* rows, int n_rows, const int* cols, int n_cols) {
     if (n_rows == 0 || n_cols == 0) return;
     track_boxes(c, v, rows, n_rows, v.box_a);
-    const int ld = v.nd;
+    const long ld = v.cap;
     for (int o = c.tid; o < n_rows * n_cols; o += c.nthr) {
-        const int r = o / n_cols, cc = o % n_cols;
+        const int cc = o / n_rows, r = o % n_rows;
         const int d = cols[cc];
-        v.cost[(long)r * ld + cc] = iou_dist_td(v.box_a + r * 4, v.det_xyxy + d * 4, v.det_area[d]);
+        v.cost[cc * ld + r] = iou_dist_td(v.box_a + r * 4, v.det_xyxy + d * 4, v.det_area[d]);
     }
     __syncthreads();
 }
@@ -444,91 +541,113 @@ __device__ inline void iou_cost(const Ctx& c, SV& v, const int* rows, int n_rows
 // is solved directly on the R x C matrix: detections are inserted one by one
 // with a shortest-augmenting-path search (Dijkstra over the tracks, potentials
 // u/v), each detection also owning a private zero-cost "stay unmatched" sink.
-// One workgroup; the relaxation is parallel over tracks, the arg-min is a
+// One workgroup; solver state (potentials, distances, predecessor links,
+// matching) lives in LDS, the cost column of the detection being relaxed is one
+// coalesced read; the relaxation is parallel over tracks, the arg-min is a
 // wave-shuffle + LDS reduction.  Exact; ties broken towards the lower index.
 // ---------------------------------------------------------------------------
-__device__ inline void lap_solve(const Ctx& c, SV& v, int R, int C, double limit) {
-    const int ld = v.nd;
-    for (int t = c.tid; t < R; t += c.nthr) { v.lap_x[t] = -1; v.lap_v[t] = 0.0; }
-    for (int d = c.tid; d < C; d += c.nthr) { v.lap_y[d] = -1; v.lap_u[d] = 0.0; }
+struct LapLds {     // carved from dynamic LDS: R = cap entries for tracks, C = max_dets for detections
+    double* v; double* minv; double* u; int* x; int* way; int* used; int* y;
+};
+__device__ inline LapLds carve_lap(unsigned char* base, int cap, int nd) {
+    LapLds l;
+    l.v = reinterpret_cast<double*>(base);
+    l.minv = l.v + cap;
+    l.u = l.minv + cap;
+    l.x = reinterpret_cast<int*>(l.u + nd);
+    l.way = l.x + cap;
+    l.used = l.way + cap;
+    l.y = l.used + cap;
+    return l;
+}
+__host__ __device__ inline long lap_lds_bytes(int cap, int nd) { return (long)cap * (8 + 8 + 4 + 4 + 4) + (long)nd * (8 + 4) + 16; }
+
+__device__ inline void lap_solve(const Ctx& c, SV& v, const LapLds& L, int R, int C, double limit) {
+    const long ld = v.cap;
+    for (int t = c.tid; t < R; t += c.nthr) { L.x[t] = -1; L.v[t] = 0.0; }
+    for (int d = c.tid; d < C; d += c.nthr) { L.y[d] = -1; L.u[d] = 0.0; }
     __syncthreads();
-    if (R == 0 || C == 0) return;
-    for (int s = 0; s < C; ++s) {
-        for (int t = c.tid; t < R; t += c.nthr) { v.lap_minv[t] = LAP_INF; v.lap_used[t] = 0; v.lap_way[t] = -1; }
-        int cur = s;          // detection being relaxed
-        int via = -1;         // track through which `cur` was reached (-1 = root)
-        double sink_best = LAP_INF;
-        int sink_via = -1;
-        int end_track = -1;
-        bool end_sink = false;
-        const int max_iter = R + 2;
-        int iter = 0;
-        for (; iter < max_iter; ++iter) {
-            const double ucur = v.lap_u[cur];
-            double best = LAP_INF;
-            int best_t = -1;
-            for (int t = c.tid; t < R; t += c.nthr) {
-                if (v.lap_used[t]) continue;
-                const double cst = v.cost[(long)t * ld + cur];
-                if (cst < limit) {
-                    const double cand = (cst - limit) - ucur - v.lap_v[t];
-                    if (cand < v.lap_minv[t]) { v.lap_minv[t] = cand; v.lap_way[t] = via; }
+    bool stalled = false;
+    if (R > 0 && C > 0) {
+        for (int s = 0; s < C && !stalled; ++s) {
+            for (int t = c.tid; t < R; t += c.nthr) { L.minv[t] = LAP_INF; L.used[t] = 0; L.way[t] = -1; }
+            int cur = s;          // detection being relaxed
+            int via = -1;         // track through which `cur` was reached (-1 = root)
+            double sink_best = LAP_INF;
+            int sink_via = -1;
+            int end_track = -1;
+            bool end_sink = false;
+            const int max_iter = R + 2;
+            int iter = 0;
+            for (; iter < max_iter; ++iter) {
+                const double ucur = L.u[cur];
+                const double* col = v.cost + cur * ld;
+                double best = LAP_INF;
+                int best_t = -1;
+                for (int t = c.tid; t < R; t += c.nthr) {
+                    if (L.used[t]) continue;
+                    const double cst = col[t];
+                    double mv = L.minv[t];
+                    if (cst < limit) {
+                        const double cand = (cst - limit) - ucur - L.v[t];
+                        if (cand < mv) { mv = cand; L.minv[t] = cand; L.way[t] = via; }
+                    }
+                    if (mv < best || (mv == best && best_t < 0)) { best = mv; best_t = t; }
                 }
-                const double mv = v.lap_minv[t];
-                if (mv < best || (mv == best && best_t < 0)) { best = mv; best_t = t; }
+                if (best >= LAP_INF) best_t = -1;
+                const double sink_cand = 0.0 - ucur;
+                if (sink_cand < sink_best) { sink_best = sink_cand; sink_via = via; }
+                double gmin;
+                int gt;
+                block_argmin(c, best, best_t, gmin, gt);
+                end_sink = (gt < 0) || (sink_best <= gmin);
+                const double delta = end_sink ? sink_best : gmin;
+                // potentials
+                for (int t = c.tid; t < R; t += c.nthr) {
+                    if (L.used[t]) {
+                        L.u[L.x[t]] += delta;
+                        L.v[t] -= delta;
+                    } else if (L.minv[t] < LAP_INF) {
+                        L.minv[t] -= delta;
+                    }
+                }
+                if (c.tid == 0) L.u[s] += delta;
+                sink_best -= delta;
+                if (end_sink) break;
+                if (c.tid == (gt % c.nthr)) L.used[gt] = 1;
+                __syncthreads();
+                if (L.x[gt] < 0) { end_track = gt; break; }
+                via = gt;
+                cur = L.x[gt];
             }
-            if (best >= LAP_INF) best_t = -1;
-            const double sink_cand = 0.0 - ucur;
-            if (sink_cand < sink_best) { sink_best = sink_cand; sink_via = via; }
-            double gmin;
-            int gt;
-            block_argmin(c, best, best_t, gmin, gt);
-            end_sink = (gt < 0) || (sink_best <= gmin);
-            const double delta = end_sink ? sink_best : gmin;
-            // potentials
-            for (int t = c.tid; t < R; t += c.nthr) {
-                if (v.lap_used[t]) {
-                    v.lap_u[v.lap_x[t]] += delta;
-                    v.lap_v[t] -= delta;
-                } else if (v.lap_minv[t] < LAP_INF) {
-                    v.lap_minv[t] -= delta;
+            __syncthreads();
+            if (iter >= max_iter) { stalled = true; break; }
+            // augment along the way[] chain (short; one thread)
+            if (c.tid == 0) {
+                int t;
+                if (end_sink) {
+                    t = sink_via;            // detection reached through `t` (or the root) stays unmatched
+                    if (t >= 0) L.y[L.x[t]] = -1;
+                } else {
+                    t = end_track;
+                }
+                int guard = 0;
+                while (t >= 0 && guard++ <= R) {
+                    const int prev = L.way[t];
+                    const int det = (prev >= 0) ? L.x[prev] : s;
+                    L.x[t] = det;
+                    L.y[det] = t;
+                    t = prev;
                 }
             }
-            if (c.tid == 0) v.lap_u[s] += delta;
-            sink_best -= delta;
-            if (end_sink) break;
-            if (c.tid == (gt % c.nthr)) v.lap_used[gt] = 1;
             __syncthreads();
-            if (v.lap_x[gt] < 0) { end_track = gt; break; }
-            via = gt;
-            cur = v.lap_x[gt];
         }
-        __syncthreads();
-        if (iter >= max_iter) {
-            if (c.tid == 0) *v.status = STATUS_LAP_STALL;
-            __syncthreads();
-            return;
-        }
-        // augment along the way[] chain (short; one thread)
-        if (c.tid == 0) {
-            int t;
-            if (end_sink) {
-                t = sink_via;            // detection reached through `t` (or the root) stays unmatched
-                if (t >= 0) v.lap_y[v.lap_x[t]] = -1;
-            } else {
-                t = end_track;
-            }
-            int guard = 0;
-            while (t >= 0 && guard++ <= R) {
-                const int prev = v.lap_way[t];
-                const int det = (prev >= 0) ? v.lap_x[prev] : s;
-                v.lap_x[t] = det;
-                v.lap_y[det] = t;
-                t = prev;
-            }
-        }
-        __syncthreads();
     }
+    if (stalled && c.tid == 0) *v.status = STATUS_LAP_STALL;
+    // publish the matching for the bookkeeping phases
+    for (int t = c.tid; t < R; t += c.nthr) v.lap_x[t] = stalled ? -1 : L.x[t];
+    for (int d = c.tid; d < C; d += c.nthr) v.lap_y[d] = stalled ? -1 : L.y[d];
+    __syncthreads();
 }
 
 // ---------------------------------------------------------------------------
@@ -536,8 +655,10 @@ __device__ inline void lap_solve(const Ctx& c, SV& v, int R, int C, double limit
 // ---------------------------------------------------------------------------
 template <int NTHR>
 __device__ inline void botsort_step_stream(const BotSortStepArgs& args, int s, int* s_int, double* s_dbl,
-                                           float (*sA)[COST_KC + 1], float (*sB)[COST_KC + 1]) {
+                                           float (*sA)[COST_KC + 1], float (*sB)[COST_KC + 1], unsigned char* dyn_lds) {
     const Ctx c = make_ctx(s_int, s_dbl);
+    const LapLds lap = carve_lap(dyn_lds, args.st.cap, args.sc.max_dets);
+    int* s_count = s_int + MAX_WAVES;      // one spare LDS word (s_int has MAX_WAVES + 1 entries)
     const int sel = args.list_sel ? args.list_sel[s] : 0;
     SV v = make_view(args, s, sel);
     const BotSortConfigDev& cfg = v.cfg;
@@ -552,6 +673,10 @@ __device__ inline void botsort_step_stream(const BotSortStepArgs& args, int s, i
     __syncthreads();
     const int frame = *v.frame_count;
     const int stamp = *v.stamp;                    // marks: stamp+0..3 are fresh this step
+    long long* pclk = (args.phase_clock && s == args.stream_base && c.tid == 0) ? args.phase_clock : nullptr;
+    int pidx = 0;
+    auto tick = [&]() { if (pclk) pclk[pidx++] = BM_CLOCK(); };
+    tick();
     const int n = v.n_dets;
 
     // ---- detections: fp32 xywh / xyxy / area, confidence split (botsort.py:251-261,
@@ -574,6 +699,7 @@ __device__ inline void botsort_step_stream(const BotSortStepArgs& args, int s, i
         const double cf = conf_of(j);
         return cf > cfg.track_low_thresh && cf < cfg.track_high_thresh; }, ident, v.second_idx, 0);
 
+    tick();
     // ---- detection appearance vectors: L2-normalised twice, as the STrack
     //      constructor does (botsort_track.py:58-66: feat /= |feat|; smooth = feat; smooth /= |smooth|) ----
     if (reid) {
@@ -581,18 +707,13 @@ __device__ inline void botsort_step_stream(const BotSortStepArgs& args, int s, i
             const int k = base + c.wave;
             if (k < n_first) {
                 const int j = v.first_idx[k];
-                const float* src = v.embs + (long)j * dim;
-                float* dst = v.det_feat + (long)j * dim;
-                const float n1 = wave_norm_f32(src, dim, c.lane);
-                float s2 = 0.0f;
-                for (int q = c.lane; q < dim; q += WAVE) { const float y = src[q] / n1; dst[q] = y; s2 += y * y; }
-                const float n2 = sqrtf(wave_sum(s2));
-                for (int q = c.lane; q < dim; q += WAVE) dst[q] = dst[q] / n2;
+                normalize_twice_wave(v.embs + (long)j * dim, v.det_feat + (long)j * dim, dim, c.lane);
             }
         }
         __syncthreads();
     }
 
+    tick();
     // ---- unconfirmed / confirmed split and the association pool (botsort.py:276-283, :202) ----
     const int n_act0 = *v.n_active, n_lost0 = *v.n_lost;
     const int* al = v.active_list;
@@ -604,6 +725,7 @@ __device__ inline void botsort_step_stream(const BotSortStepArgs& args, int s, i
     n_pool = block_append_if(c, n_lost0, [&](int i) { return v.mark[v.lost_list[i]] != stamp; },
                              [&](int i) { return v.lost_list[i]; }, v.pool, n_pool);
 
+    tick();
     // ---- Kalman prediction of the pool, one wavefront per track (botsort_track.py:96-115) ----
     for (int base = 0; base < n_pool; base += c.nwaves) {
         const int k = base + c.wave;
@@ -614,9 +736,12 @@ __device__ inline void botsort_step_stream(const BotSortStepArgs& args, int s, i
     }
     __syncthreads();
 
+    tick();
     // ---- first association (botsort.py:285-333) ----
-    assoc_cost<NTHR>(c, v, v.pool, n_pool, v.first_idx, n_first, reid, 0.0, cfg.fuse_first_associate != 0, sA, sB);
-    lap_solve(c, v, n_pool, n_first, cfg.match_thresh);
+    assoc_cost<NTHR>(c, v, v.pool, n_pool, v.first_idx, n_first, reid, 0.0, cfg.fuse_first_associate != 0, sA, sB, s_count);
+    tick();
+    lap_solve(c, v, lap, n_pool, n_first, cfg.match_thresh);
+    tick();
     int n_match = block_append_if(c, n_pool, [&](int r) { return v.lap_x[r] >= 0; }, [&](int r) { return r; }, v.match_slot, 0);
     for (int k = c.tid; k < n_match; k += c.nthr) {
         const int r = v.match_slot[k];
@@ -638,10 +763,11 @@ __device__ inline void botsort_step_stream(const BotSortStepArgs& args, int s, i
     const int n_remain = block_append_if(c, n_pool, [&](int r) { return v.lap_x[r] < 0 && v.state[v.pool[r]] == ST_TRACKED; },
                                          [&](int r) { return v.pool[r]; }, v.remain, 0);
     apply_matches(c, v, n_match, frame, reid);
+    tick();
 
     // ---- second association: IoU only, low-confidence detections (botsort.py:335-378) ----
     iou_cost(c, v, v.remain, n_remain, v.second_idx, n_second);
-    lap_solve(c, v, n_remain, n_second, cfg.second_match_thresh);
+    lap_solve(c, v, lap, n_remain, n_second, cfg.second_match_thresh);
     n_match = block_append_if(c, n_remain, [&](int r) { return v.lap_x[r] >= 0; }, [&](int r) { return r; }, v.match_slot, 0);
     for (int k = c.tid; k < n_match; k += c.nthr) {
         const int r = v.match_slot[k];
@@ -657,9 +783,10 @@ __device__ inline void botsort_step_stream(const BotSortStepArgs& args, int s, i
     for (int k = c.tid; k < n_newly_lost; k += c.nthr) v.state[v.newly_lost[k]] = ST_LOST;   // mark_lost
     __syncthreads();
 
+    tick();
     // ---- unconfirmed tracks vs the left-over high-confidence detections (botsort.py:380-431) ----
-    assoc_cost<NTHR>(c, v, v.unconf, n_unconf, v.left_idx, n_left, reid, cfg.unconfirmed_emb_scale, true, sA, sB);
-    lap_solve(c, v, n_unconf, n_left, cfg.unconfirmed_match_thresh);
+    assoc_cost<NTHR>(c, v, v.unconf, n_unconf, v.left_idx, n_left, reid, cfg.unconfirmed_emb_scale, true, sA, sB, s_count);
+    lap_solve(c, v, lap, n_unconf, n_left, cfg.unconfirmed_match_thresh);
     n_match = block_append_if(c, n_unconf, [&](int r) { return v.lap_x[r] >= 0; }, [&](int r) { return r; }, v.match_slot, 0);
     for (int k = c.tid; k < n_match; k += c.nthr) {
         const int r = v.match_slot[k];
@@ -675,6 +802,7 @@ __device__ inline void botsort_step_stream(const BotSortStepArgs& args, int s, i
     for (int k = c.tid; k < n_newly_removed; k += c.nthr) v.state[v.newly_removed[k]] = ST_REMOVED;
     __syncthreads();
 
+    tick();
     // ---- births (botsort.py:433-440, botsort_track.py:232-242): unmatched left-over
     //      detections with conf >= new_track_thresh, ids in ascending detection order ----
     // list_a <- detection indices to initialise; list_b <- free slots
@@ -715,6 +843,7 @@ __device__ inline void botsort_step_stream(const BotSortStepArgs& args, int s, i
     __syncthreads();
     n_activated = block_append_if(c, n_born, [&](int) { return true; }, [&](int k) { return v.list_b[k]; }, v.activated, n_activated);
 
+    tick();
     // ---- lost tracks past max_time_lost -> Removed (botsort.py:472-476) ----
     n_newly_removed = block_append_if(c, n_lost0, [&](int i) { return frame - v.frame_id[v.lost_list[i]] > cfg.max_time_lost; },
                                       [&](int i) { return v.lost_list[i]; }, v.newly_removed, n_newly_removed);
@@ -795,6 +924,7 @@ __device__ inline void botsort_step_stream(const BotSortStepArgs& args, int s, i
     if (c.tid == 0) { *v.n_active = n_act1; *v.n_lost = n_lost1; }
     __syncthreads();
 
+    tick();
     // ---- output rows (botsort.py:494-500): activated tracks in active-list order ----
     const int n_out = block_append_if(c, n_act1, [&](int i) { return v.is_activated[v.active_list[i]] != 0; },
                                       [&](int i) { return v.active_list[i]; }, v.list_a, 0);
@@ -809,6 +939,7 @@ __device__ inline void botsort_step_stream(const BotSortStepArgs& args, int s, i
     }
     if (c.tid == 0) *v.out_n = n_out;
     __syncthreads();
+    tick();
 }
 
 }  // namespace bm

@@ -101,7 +101,7 @@ struct BotSortScratch {
     int* match_flag;     // [S][nd]
     int* drop_a;         // [S][cap]
     int* drop_b;         // [S][cap]
-    double* cost;        // [S][cap][nd]
+    double* cost;        // [S][nd][cap]  detection-major: cost[c * cap + r]
     int* lap_x;          // [S][cap]   column of row (or -1)
     int* lap_y;          // [S][nd]    row of column (or -1)
     double* lap_u;       // [S][nd]
@@ -110,6 +110,7 @@ struct BotSortScratch {
     int* lap_way;        // [S][cap]
     int* lap_used;       // [S][cap]
     double* box_a;       // [S][cap][4]  fp64 xyxy of list rows
+    int* pair_list;      // [S][4096]  (row, col) pairs that pass the IoU gate (sparse cosine evaluation)
 };
 
 struct BotSortStepArgs {
@@ -124,6 +125,7 @@ struct BotSortStepArgs {
     float* out;               // [S][max_dets][8]
     int* out_n;               // [S]
     int stream_base;          // workgroup b advances stream (stream_base + b)
+    long long* phase_clock;   // optional [16] shader-clock stamps of stream stream_base's phases (profiling), or nullptr
 };
 
 }  // namespace bm

@@ -43,7 +43,8 @@ __global__ void __launch_bounds__(NTHR) botsort_step_kernel(bm::BotSortStepArgs 
     __shared__ double s_dbl[bm::MAX_WAVES];
     __shared__ float sA[bm::COST_TILE][bm::COST_KC + 1];
     __shared__ float sB[bm::COST_TILE][bm::COST_KC + 1];
-    bm::botsort_step_stream<NTHR>(args, args.stream_base + blockIdx.x, s_int, s_dbl, sA, sB);
+    BM_DYNAMIC_LDS_T(unsigned char, dyn_lds);       // assignment-solver state, sized by lap_lds_bytes(cap, max_dets)
+    bm::botsort_step_stream<NTHR>(args, args.stream_base + blockIdx.x, s_int, s_dbl, sA, sB, dyn_lds);
 }
 
 // Build the ReID crop list on the device: every detection with conf > track_high_thresh
@@ -127,6 +128,7 @@ struct BoxMOTHipBotSort {
     int* d_crop_stream = nullptr;
     float* d_crop_boxes = nullptr;
     int* d_crop_row = nullptr;
+    long long* d_phase_clock = nullptr;
     double last_track_ms = 0, last_reid_pre_ms = 0, last_reid_proc_ms = 0;
 
     ~BoxMOTHipBotSort() {
@@ -218,9 +220,16 @@ void build(BoxMOTHipBotSort* h) {
     h->d_crop_stream = zalloc<int>(S * nd, o);
     h->d_crop_boxes = zalloc<float>(S * nd * 4, o);
     h->d_crop_row = zalloc<int>(S * nd, o);
+    h->d_phase_clock = zalloc<long long>(16, o);
+    {
+        const long lds = bm::lap_lds_bytes(h->cap, h->nd);
+        if (lds > 120 * 1024) throw std::runtime_error("boxmot_hip: max_tracks/max_dets too large for the assignment solver's LDS state");
+        BM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(botsort_step_kernel<STEP_THREADS>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     if (c.with_reid && !h->reid_path.empty()) {
         const std::vector<float> blob = bm::read_blob_file(h->reid_path.c_str());
-        h->reid.reset(new bm::ReidEngine(blob.data(), (long)blob.size(), bm::reid_chunk_for((long)S * nd)));
+        h->reid.reset(new bm::ReidEngine(blob.data(), (long)blob.size(), bm::reid_chunk_for((long)S * nd), (int)(S * nd)));
         if (h->reid->feature_dim() != h->dim) throw std::runtime_error("boxmot_hip: ReID feature dim != emb_dim");
     }
 }
@@ -229,8 +238,9 @@ void launch_step(BoxMOTHipBotSort* h, int s0, int n_streams, const float* d_dets
                  const int* d_list_sel, const int* d_fc_set, float* d_out, int* d_out_n) {
     bm::BotSortStepArgs a = h->args;
     a.dets = d_dets; a.n_dets = d_ndets; a.embs = d_embs; a.list_sel = d_list_sel; a.frame_count_set = d_fc_set;
-    a.out = d_out; a.out_n = d_out_n; a.stream_base = s0;
-    hipLaunchKernelGGL((botsort_step_kernel<STEP_THREADS>), dim3(n_streams), dim3(STEP_THREADS), 0, h->stream, a);
+    a.out = d_out; a.out_n = d_out_n; a.stream_base = s0; a.phase_clock = h->d_phase_clock;
+    hipLaunchKernelGGL((botsort_step_kernel<STEP_THREADS>), dim3(n_streams), dim3(STEP_THREADS),
+                       (size_t)bm::lap_lds_bytes(h->cap, h->nd), h->stream, a);
     BM_HIP(hipGetLastError());
 }
 
@@ -241,6 +251,12 @@ void run_reid(BoxMOTHipBotSort* h, int s0, int n_streams, const float* d_dets, c
     BM_HIP(hipMemsetAsync(h->d_crop_count, 0, 4, h->stream));
     hipLaunchKernelGGL(build_crop_list_kernel, dim3(n_streams), dim3(256), 0, h->stream, d_dets, d_ndets, h->nd,
                        h->cfg.track_high_thresh, h->d_crop_count, h->d_crop_stream, h->d_crop_boxes, h->d_crop_row, s0);
+    if (h->reid->mode() == 1) {
+        // crop count stays on the device: launches cover the capacity, surplus workgroups exit at once
+        h->reid->run_counted(d_frames, h->d_crop_stream, h->d_crop_boxes, 4, h->d_crop_count, n_streams * h->nd, cols, rows,
+                             d_embs, h->d_crop_row, h->stream);
+        return;
+    }
     int n_crops = 0;
     BM_HIP(hipMemcpyAsync(&n_crops, h->d_crop_count, 4, hipMemcpyDeviceToHost, h->stream));
     BM_HIP(hipStreamSynchronize(h->stream));
@@ -508,6 +524,14 @@ int boxmot_hip_botsort_reid_kernel_ms(BoxMOTHipBotSort* handle, double* out_ms, 
     });
 }
 
+int boxmot_hip_botsort_phase_clocks(BoxMOTHipBotSort* handle, long long* out16) {
+    return guard([&]() {
+        if (!handle || !out16) throw std::runtime_error("boxmot_hip: null argument");
+        BM_HIP(hipStreamSynchronize(handle->stream));
+        BM_HIP(hipMemcpy(out16, handle->d_phase_clock, 16 * sizeof(long long), hipMemcpyDeviceToHost));
+    });
+}
+
 void* boxmot_hip_botsort_stream(BoxMOTHipBotSort* handle) { return handle ? (void*)handle->stream : nullptr; }
 
 int boxmot_hip_botsort_status(BoxMOTHipBotSort* handle, int* out_status, int capacity) {
@@ -522,7 +546,7 @@ int boxmot_hip_botsort_status(BoxMOTHipBotSort* handle, int* out_status, int cap
 int boxmot_hip_botsort_set_reid_blob(BoxMOTHipBotSort* handle, const float* blob, long n_floats) {
     return guard([&]() {
         if (!handle || !blob) throw std::runtime_error("boxmot_hip: null argument");
-        handle->reid.reset(new bm::ReidEngine(blob, n_floats, bm::reid_chunk_for((long)handle->S * handle->nd)));
+        handle->reid.reset(new bm::ReidEngine(blob, n_floats, bm::reid_chunk_for((long)handle->S * handle->nd), handle->S * handle->nd));
         if (handle->reid->feature_dim() != handle->dim) {
             handle->reid.reset();
             throw std::runtime_error("boxmot_hip: ReID feature dim != emb_dim");

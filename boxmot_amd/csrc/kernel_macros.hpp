@@ -19,3 +19,6 @@
 // across tiles by the instruction scheduler (which otherwise hoists every LDS read and spills)
 #define BM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
+#ifndef BM_CLOCK
+#define BM_CLOCK() wall_clock64()
+#endif

@@ -50,7 +50,9 @@ inline int reid_chunk_for(long max_total) { return (int)(max_total < 4096 ? max_
 
 class ReidEngine {
 public:
-    ReidEngine(const float* blob, long n_floats, int max_crops) : max_crops_(max_crops) {
+    // max_crops: crops per pass of the per-layer path; fused_cap: crops the fused path can take in one pass
+    ReidEngine(const float* blob, long n_floats, int max_crops, int fused_cap = 0)
+        : max_crops_(max_crops), fused_cap_(fused_cap > max_crops ? fused_cap : max_crops) {
         if (n_floats < REID_HEADER_INTS) throw std::runtime_error("ReID blob too small");
         const int32_t* hdr = reinterpret_cast<const int32_t*>(blob);
         if (hdr[0] != REID_MAGIC) throw std::runtime_error("ReID blob: bad magic (expected OSN1)");
@@ -98,12 +100,13 @@ public:
     // crops only (normalised NHWC fp32) for `n` boxes
     void preprocess(const uint8_t* const* d_frames, const int* d_crop_stream, const float* d_boxes,
                     int box_stride, int n, int W, int H, hipStream_t st) {
-        if (n > max_crops_) throw std::runtime_error("ReID: crop batch exceeds max_crops");
+        const bool fused = mode_ == 1 && !force_fp32_crops_;
+        if (n > (fused ? fused_cap_ : max_crops_)) throw std::runtime_error("ReID: crop batch exceeds the engine capacity");
         if (n == 0) return;
         const int rows_per_block = 16;
-        if (mode_ == 1 && !force_fp32_crops_)
+        if (fused)
             hipLaunchKernelGGL(k_crop_resize_rgbx, dim3(n, REID_IN_H / rows_per_block), dim3(REID_IN_W), 0, st,
-                               d_frames, d_crop_stream, d_boxes, box_stride, W, H, d_lut_, crops_h_, rows_per_block);
+                               d_frames, d_crop_stream, d_boxes, box_stride, W, H, d_lut_, crops_h_, rows_per_block, d_count_);
         else
             hipLaunchKernelGGL(k_crop_resize<float>, dim3(n, REID_IN_H / rows_per_block), dim3(REID_IN_W), 0, st,
                                d_frames, d_crop_stream, d_boxes, box_stride, W, H, d_lut_, crops_, rows_per_block);
@@ -122,8 +125,9 @@ public:
              int n, int W, int H, float* d_out, const int* d_out_rows, hipStream_t st) {
         if (n == 0) return;
         BM_HIP(hipEventRecord(ev_[0], st));
-        for (int i0 = 0; i0 < n; i0 += max_crops_) {
-            const int m = (n - i0) < max_crops_ ? (n - i0) : max_crops_;
+        const int step = mode_ == 1 ? fused_cap_ : max_crops_;
+        for (int i0 = 0; i0 < n; i0 += step) {
+            const int m = (n - i0) < step ? (n - i0) : step;
             preprocess(d_frames, d_crop_stream + i0, d_boxes + (long)i0 * box_stride, box_stride, m, W, H, st);
             if (i0 == 0) BM_HIP(hipEventRecord(ev_[1], st));
             hipEvent_t a = take_event(), b = take_event();
@@ -135,6 +139,27 @@ public:
             else { free_events_.push_back(a); free_events_.push_back(b); }
         }
         BM_HIP(hipEventRecord(ev_[2], st));
+        timed_ = true;
+    }
+    // Fused path with the crop count resident on the device: launches cover n_max crops, workgroups
+    // beyond *d_count exit immediately -- no host round trip between the crop list and the ReID kernels.
+    void run_counted(const uint8_t* const* d_frames, const int* d_crop_stream, const float* d_boxes, int box_stride,
+                     const int* d_count, int n_max, int W, int H, float* d_out, const int* d_out_rows, hipStream_t st) {
+        if (mode_ != 1) throw std::runtime_error("ReID: run_counted needs the fused kernels (mode 1)");
+        if (n_max > fused_cap_) throw std::runtime_error("ReID: crop batch exceeds the engine capacity");
+        if (n_max == 0) return;
+        d_count_ = d_count;
+        BM_HIP(hipEventRecord(ev_[0], st));
+        preprocess(d_frames, d_crop_stream, d_boxes, box_stride, n_max, W, H, st);
+        BM_HIP(hipEventRecord(ev_[1], st));
+        hipEvent_t a = take_event(), b = take_event();
+        BM_HIP(hipEventRecord(a, st));
+        forward_fused(n_max, d_out, d_out_rows, st);
+        BM_HIP(hipEventRecord(b, st));
+        if (pending_.size() < 4096) pending_.emplace_back(a, b);
+        else { free_events_.push_back(a); free_events_.push_back(b); }
+        BM_HIP(hipEventRecord(ev_[2], st));
+        d_count_ = nullptr;
         timed_ = true;
     }
     // Accumulated device time of the forward region (events ev_[1]..ev_[2]) over the runs since the
@@ -277,7 +302,7 @@ private:
         pack_pointwise(w + L_.trans_w[1], w + L_.trans_b[1], 96, 96, buf); w_tr_[1] = upload(buf);
         pack_pointwise(w + L_.conv5_w, w + L_.conv5_b, 128, 128, buf); w_c5_ = upload(buf);
         pack_fc(w + L_.fc_w, w + L_.fc_b, 512, 128, buf); w_fc_ = upload(buf);
-        const size_t n = (size_t)max_crops_;
+        const size_t n = (size_t)fused_cap_;
         const size_t crop_halves = n * STEM_ROWS * STEM_COLS * 4;
         crops_h_ = dev_alloc<_Float16>(crop_halves, owned_);
         BM_HIP(hipMemset(crops_h_, 0, crop_halves * 2));          // the 3-pixel border and X channel stay zero
@@ -292,16 +317,16 @@ private:
         fused_ready_ = true;
     }
     void forward_fused(int n, float* d_out, const int* d_out_rows, hipStream_t st) {
-        hipLaunchKernelGGL(k_stem_fused, dim3(n), dim3(512), 0, st, crops_h_, act_a_, w_stem_);
-        hipLaunchKernelGGL((k_osblock<0, 16, true>), dim3(n), dim3(64 * Geo<0>::NWAVES), Geo<0>::LDS_BYTES, st, act_a_, act_b_, w_blk_[0], bp_[0]);
-        hipLaunchKernelGGL((k_osblock<0, 64, false>), dim3(n), dim3(64 * Geo<0>::NWAVES), Geo<0>::LDS_BYTES, st, act_b_, act_a_, w_blk_[1], bp_[1]);
-        hipLaunchKernelGGL((k_transition<64, 64, 32>), dim3((n * 32 + 3) / 4), dim3(256), 0, st, act_a_, act_b_, w_tr_[0], n);
-        hipLaunchKernelGGL((k_osblock<1, 64, true>), dim3(n), dim3(64 * Geo<1>::NWAVES), Geo<1>::LDS_BYTES, st, act_b_, act_a_, w_blk_[2], bp_[2]);
-        hipLaunchKernelGGL((k_osblock<1, 96, false>), dim3(n), dim3(64 * Geo<1>::NWAVES), Geo<1>::LDS_BYTES, st, act_a_, act_b_, w_blk_[3], bp_[3]);
-        hipLaunchKernelGGL((k_transition<96, 32, 16>), dim3((n * 16 + 3) / 4), dim3(256), 0, st, act_b_, act_a_, w_tr_[1], n);
-        hipLaunchKernelGGL((k_osblock<2, 96, true>), dim3(n), dim3(64 * Geo<2>::NWAVES), Geo<2>::LDS_BYTES, st, act_a_, act_b_, w_blk_[4], bp_[4]);
-        hipLaunchKernelGGL((k_osblock<2, 128, false>), dim3(n), dim3(64 * Geo<2>::NWAVES), Geo<2>::LDS_BYTES, st, act_b_, act_a_, w_blk_[5], bp_[5]);
-        hipLaunchKernelGGL((k_head_fused<128, 512>), dim3(n), dim3(128), 0, st, act_a_, w_c5_, w_fc_, d_out, d_out_rows);
+        hipLaunchKernelGGL(k_stem_fused, dim3(n), dim3(512), 0, st, crops_h_, act_a_, w_stem_, d_count_);
+        hipLaunchKernelGGL((k_osblock<0, 16, true>), dim3(n), dim3(64 * Geo<0>::NWAVES), Geo<0>::LDS_BYTES, st, act_a_, act_b_, w_blk_[0], bp_[0], d_count_);
+        hipLaunchKernelGGL((k_osblock<0, 64, false>), dim3(n), dim3(64 * Geo<0>::NWAVES), Geo<0>::LDS_BYTES, st, act_b_, act_a_, w_blk_[1], bp_[1], d_count_);
+        hipLaunchKernelGGL((k_transition<64, 64, 32>), dim3((n * 32 + 3) / 4), dim3(256), 0, st, act_a_, act_b_, w_tr_[0], n, d_count_);
+        hipLaunchKernelGGL((k_osblock<1, 64, true>), dim3(n), dim3(64 * Geo<1>::NWAVES), Geo<1>::LDS_BYTES, st, act_b_, act_a_, w_blk_[2], bp_[2], d_count_);
+        hipLaunchKernelGGL((k_osblock<1, 96, false>), dim3(n), dim3(64 * Geo<1>::NWAVES), Geo<1>::LDS_BYTES, st, act_a_, act_b_, w_blk_[3], bp_[3], d_count_);
+        hipLaunchKernelGGL((k_transition<96, 32, 16>), dim3((n * 16 + 3) / 4), dim3(256), 0, st, act_b_, act_a_, w_tr_[1], n, d_count_);
+        hipLaunchKernelGGL((k_osblock<2, 96, true>), dim3(n), dim3(64 * Geo<2>::NWAVES), Geo<2>::LDS_BYTES, st, act_a_, act_b_, w_blk_[4], bp_[4], d_count_);
+        hipLaunchKernelGGL((k_osblock<2, 128, false>), dim3(n), dim3(64 * Geo<2>::NWAVES), Geo<2>::LDS_BYTES, st, act_b_, act_a_, w_blk_[5], bp_[5], d_count_);
+        hipLaunchKernelGGL((k_head_fused<128, 512>), dim3(n), dim3(128), 0, st, act_a_, w_c5_, w_fc_, d_out, d_out_rows, d_count_);
     }
     void alloc_buffers() {
         const size_t n = (size_t)max_crops_;
@@ -325,6 +350,8 @@ private:
 
     OsnetLayout L_;
     int max_crops_;
+    int fused_cap_;
+    const int* d_count_ = nullptr;
     int mode_ = 0;
     bool timed_ = false;
     std::vector<void*> owned_;

@@ -71,8 +71,10 @@ __device__ inline h8 cat8(h4 a, h4 b) { return h8{a[0], a[1], a[2], a[3], b[0], 
 // ---------------------------------------------------------------------------
 template <int STAGE, int CIN, bool DOWN>
 __global__ void __launch_bounds__(64 * Geo<STAGE>::NWAVES)
-k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const unsigned char* __restrict__ wts, BlkPack bp) {
+k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const unsigned char* __restrict__ wts, BlkPack bp,
+          const int* __restrict__ count) {
     using G = Geo<STAGE>;
+    if (count && (int)blockIdx.x >= *count) return;     // device-side crop count (no host round trip)
     constexpr int KT = G::KT, NT = G::NT, MIDP = G::MIDP, NCT = G::NCT, COUT = G::COUT, P = G::P;
     constexpr int KIN = CIN == 16 ? 1 : CIN / 32;
     BM_DYNAMIC_LDS_T(unsigned char, lds);
@@ -297,7 +299,8 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
 // ---------------------------------------------------------------------------
 template <int C, int H, int W>
 __global__ void __launch_bounds__(256) k_transition(const _Float16* __restrict__ in, _Float16* __restrict__ out,
-                                                    const unsigned char* __restrict__ wts, int n_crops) {
+                                                    const unsigned char* __restrict__ wts, int n_crops, const int* __restrict__ count) {
+    if (count) n_crops = *count < n_crops ? *count : n_crops;
     constexpr int NCT = C / 16, KS = C / 32, TPR = W / 16;        // tiles per image row
     constexpr int PAIRS = H / 2;
     const int lane = threadIdx.x & 63, g = lane >> 4, l16 = lane & 15;
@@ -351,7 +354,8 @@ __global__ void __launch_bounds__(256) k_transition(const _Float16* __restrict__
 template <int C, int F>
 __global__ void __launch_bounds__(128) k_head_fused(const _Float16* __restrict__ in, const unsigned char* __restrict__ wts5,
                                                     const unsigned char* __restrict__ wfc, float* __restrict__ out_base,
-                                                    const int* __restrict__ out_rows) {
+                                                    const int* __restrict__ out_rows, const int* __restrict__ count) {
+    if (count && (int)blockIdx.x >= *count) return;
     constexpr int NCT = C / 16, KS = C / 32, P = 128, NT = 4;
     __shared__ float s_gap[2][C];
     __shared__ float s_v[C];
@@ -433,7 +437,8 @@ __device__ inline f4 max4(f4 a, f4 b) {
 }
 
 __global__ void __launch_bounds__(512) k_stem_fused(const _Float16* __restrict__ crops, _Float16* __restrict__ out,
-                                                    const unsigned char* __restrict__ wts) {
+                                                    const unsigned char* __restrict__ wts, const int* __restrict__ count) {
+    if (count && (int)blockIdx.x >= *count) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l16 = lane & 15;
     const long crop = blockIdx.x;
     const _Float16* img = crops + crop * (STEM_ROWS * STEM_COLS * 4);
@@ -500,7 +505,9 @@ __global__ void __launch_bounds__(512) k_stem_fused(const _Float16* __restrict__
 // crop -> resize -> normalise into the stem's fp16 RGBX layout (interior only; the 3-pixel border and the
 // X channel of the buffer stay zero from allocation).  Same integer pipeline as k_crop_resize.
 __global__ void k_crop_resize_rgbx(const uint8_t* const* frames, const int* crop_stream, const float* boxes,
-                                   int box_stride, int W, int H, const float* lut, _Float16* out, int rows_per_block) {
+                                   int box_stride, int W, int H, const float* lut, _Float16* out, int rows_per_block,
+                                   const int* count) {
+    if (count && (int)blockIdx.x >= *count) return;
     const int i = blockIdx.x;
     const int dx = threadIdx.x;
     const uint8_t* frame = frames[crop_stream[i]];

@@ -122,6 +122,10 @@ int boxmot_hip_botsort_timer_start(BoxMOTHipBotSort* handle);
 int boxmot_hip_botsort_timer_stop_ms(BoxMOTHipBotSort* handle, double* out_ms);
 /* accumulated device milliseconds of the ReID forward kernels since the last call (and their count) */
 int boxmot_hip_botsort_reid_kernel_ms(BoxMOTHipBotSort* handle, double* out_ms, int* out_launches);
+/* profiling aid: shader-clock (100 MHz wall clock) stamps of the phases of the last step of the first
+ * stream of the launch: start, det prep, det features, pool lists, predict, cost, assignment, updates,
+ * second association, unconfirmed, births, bookkeeping, end */
+int boxmot_hip_botsort_phase_clocks(BoxMOTHipBotSort* handle, long long* out16);
 /* per-stream status words (0 ok, 1 track capacity, 2 class capacity, 3 assignment stall) */
 int boxmot_hip_botsort_status(BoxMOTHipBotSort* handle, int* out_status, int capacity);
 

@@ -36,7 +36,7 @@ struct Emu {
 
 struct ThreadArg { Emu* e; int tid; };
 
-int* g_s_int; double* g_s_dbl;
+int* g_s_int; double* g_s_dbl; unsigned char* g_dyn;
 float (*g_sA)[bm::COST_KC + 1];
 float (*g_sB)[bm::COST_KC + 1];
 
@@ -44,7 +44,7 @@ void* thread_main(void* p) {
     ThreadArg* ta = static_cast<ThreadArg*>(p);
     threadIdx.x = ta->tid;
     blockIdx.x = 0;
-    bm::botsort_step_stream<NTHR>(ta->e->args, 0, g_s_int, g_s_dbl, g_sA, g_sB);
+    bm::botsort_step_stream<NTHR>(ta->e->args, 0, g_s_int, g_s_dbl, g_sA, g_sB, g_dyn);
     return nullptr;
 }
 
@@ -66,7 +66,7 @@ void* emu_create(const double* cd, const int* ci, int cap, int nd, int dim) {
     e->out_n = e->alloc.get<int>(1);
     e->args.dets = e->dets; e->args.n_dets = e->n_dets; e->args.embs = e->embs;
     e->args.list_sel = nullptr; e->args.frame_count_set = nullptr;
-    e->args.out = e->out; e->args.out_n = e->out_n; e->args.stream_base = 0;
+    e->args.out = e->out; e->args.out_n = e->out_n; e->args.stream_base = 0; e->args.phase_clock = nullptr;
     e->block.block_barrier.init(NTHR);
     for (int w = 0; w < EMU_MAX_WAVES; ++w) e->block.wave_barrier[w].init(EMU_WAVE);
     return e;
@@ -89,7 +89,9 @@ int emu_update(void* h, const float* dets, int n, const float* embs, float* out,
     static double s_dbl[bm::MAX_WAVES];
     static float sA[bm::COST_TILE][bm::COST_KC + 1];
     static float sB[bm::COST_TILE][bm::COST_KC + 1];
-    g_s_int = s_int; g_s_dbl = s_dbl; g_sA = sA; g_sB = sB;
+    static std::vector<double> dyn;
+    dyn.assign((size_t)bm::lap_lds_bytes(e->cap, e->nd) / 8 + 2, 0.0);
+    g_s_int = s_int; g_s_dbl = s_dbl; g_sA = sA; g_sB = sB; g_dyn = reinterpret_cast<unsigned char*>(dyn.data());
     g_emu_block = &e->block;
     blockDim.x = NTHR;
     std::vector<pthread_t> th(NTHR);

@@ -88,7 +88,7 @@ int emu_reid_forward(const float* blob, long n_floats, const float* crops, int n
     pack_stem(w + L.stem_w, w + L.stem_b, wst);
     {
         const _Float16* in = cx.data(); _Float16* out = A.data(); const unsigned char* wp = wst.data();
-        launch(n, 1, 512, [=]() { k_stem_fused(in, out, wp); });
+        launch(n, 1, 512, [=]() { k_stem_fused(in, out, wp, nullptr); });
     }
     if (stage_out && stage_out[0]) unpack_act(A.data(), stage_out[0], (long)n * 2048, 16);
     _Float16* cur = A.data();
@@ -100,7 +100,7 @@ int emu_reid_forward(const float* blob, long n_floats, const float* crops, int n
         std::vector<uint8_t> wb;
         pack_osblock(w, L.block[bi], bp, wb);
         const _Float16* in = cur; _Float16* out = nxt; const unsigned char* wp = wb.data();
-        launch(n, 1, nthr, [=]() { kernel(in, out, wp, bp); });
+        launch(n, 1, nthr, [=]() { kernel(in, out, wp, bp, nullptr); });
         std::swap(cur, nxt);
         if (stage_out && stage_out[dump]) unpack_act(cur, stage_out[dump], (long)n * P, cout);
         ++dump;
@@ -110,7 +110,7 @@ int emu_reid_forward(const float* blob, long n_floats, const float* crops, int n
         pack_pointwise(w + L.trans_w[si], w + L.trans_b[si], C, C, wt);
         const _Float16* in = cur; _Float16* out = nxt; const unsigned char* wp = wt.data();
         const int units = n * (H / 2);
-        launch((units + 3) / 4, 1, 256, [=]() { kernel(in, out, wp, n); });
+        launch((units + 3) / 4, 1, 256, [=]() { kernel(in, out, wp, n, nullptr); });
         std::swap(cur, nxt);
         if (stage_out && stage_out[dump]) unpack_act(cur, stage_out[dump], (long)n * (H * W / 4), C);
         ++dump;
@@ -128,7 +128,7 @@ int emu_reid_forward(const float* blob, long n_floats, const float* crops, int n
     pack_fc(w + L.fc_w, w + L.fc_b, 512, 128, wfc);
     {
         const _Float16* in = cur; const unsigned char* p5 = w5.data(); const unsigned char* pf = wfc.data();
-        launch(n, 1, 128, [=]() { k_head_fused<128, 512>(in, p5, pf, feats, nullptr); });
+        launch(n, 1, 128, [=]() { k_head_fused<128, 512>(in, p5, pf, feats, nullptr, nullptr); });
     }
     return 0;
 }

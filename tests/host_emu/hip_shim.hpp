@@ -27,6 +27,7 @@ extern thread_local EmuDim3 threadIdx;
 extern thread_local EmuDim3 blockIdx;
 extern EmuDim3 blockDim;
 
+#define BM_CLOCK() 0LL
 constexpr int EMU_WAVE = 64;
 constexpr int EMU_MAX_WAVES = 16;
 
@@ -85,6 +86,7 @@ inline unsigned long long __ballot(int pred) {
     return m;
 }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 
 // ---- additions for the fused ReID kernels (compiled with a host clang that knows _Float16) ----
 #define __restrict__

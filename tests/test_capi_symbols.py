@@ -59,4 +59,6 @@ def test_product_does_not_import_oracle():
         src = py.read_text()
         assert "import oracle" not in src and "from oracle" not in src, py
     for c in (ROOT / "boxmot_amd" / "csrc").iterdir():
+        if c.suffix not in (".hpp", ".hip", ".h"):
+            continue
         assert "oracle" not in c.read_text().replace("the oracle's", "").replace("oracle's", ""), c

@@ -10,10 +10,10 @@ from emu_util import EmuBotSort
 from oracle.botsort import DEFAULTS, BotSortOracle
 
 
-def _run(frames, dim, cap, nd, sanitize=False, **kw):
+def _run(frames, dim, cap, nd, sanitize=False, dense=False, **kw):
     cfg = dict(DEFAULTS)
     cfg.update(kw)
-    orc, emu = BotSortOracle(**kw), EmuBotSort(cfg, cap=cap, nd=nd, dim=dim, sanitize=sanitize)
+    orc, emu = BotSortOracle(**kw), EmuBotSort(cfg, cap=cap, nd=nd, dim=dim, sanitize=sanitize, dense=dense)
     try:
         for t, (d, e) in enumerate(frames):
             want = orc.update(d.copy(), None, e.copy())
@@ -39,6 +39,12 @@ def _run(frames, dim, cap, nd, sanitize=False, **kw):
                                 dict(with_reid=False)])
 def test_emulated_kernel_matches_oracle_stress(kw):
     _run(stress_frames(80, seed=7), 32, 128, 64, **kw)
+
+
+def test_emulated_kernel_dense_cosine_path():
+    """Same kernel built with the sparse-pair limit at 0: every frame takes the LDS-tiled dense contraction."""
+    _run(stress_frames(60, seed=7), 32, 128, 64, dense=True)
+    _run(stress_frames(40, seed=9), 32, 128, 64, dense=True, fuse_first_associate=True)
 
 
 def test_emulated_kernel_matches_oracle_c2_shape():
