@@ -94,6 +94,7 @@ public:
         mode_ = m;
     }
     int mode() const { return mode_; }
+    void set_fuse_stem(bool on) { fuse_stem_ = on; }     // A/B switch: fused crop+stem kernel vs resize kernel + stem kernel
     const OsnetLayout& layout() const { return L_; }
     float* crops_buffer() { return crops_; }
 
@@ -128,12 +129,17 @@ public:
         const int step = mode_ == 1 ? fused_cap_ : max_crops_;
         for (int i0 = 0; i0 < n; i0 += step) {
             const int m = (n - i0) < step ? (n - i0) : step;
-            preprocess(d_frames, d_crop_stream + i0, d_boxes + (long)i0 * box_stride, box_stride, m, W, H, st);
+            const bool fuse_stem = mode_ == 1 && fuse_stem_;
+            if (!fuse_stem) preprocess(d_frames, d_crop_stream + i0, d_boxes + (long)i0 * box_stride, box_stride, m, W, H, st);
             if (i0 == 0) BM_HIP(hipEventRecord(ev_[1], st));
             hipEvent_t a = take_event(), b = take_event();
             BM_HIP(hipEventRecord(a, st));
-            if (mode_ == 1) forward_fused(m, d_out_rows ? d_out : d_out + (long)i0 * L_.feat, d_out_rows ? d_out_rows + i0 : nullptr, st);
-            else forward_v1(m, d_out_rows ? d_out : d_out + (long)i0 * L_.feat, d_out_rows ? d_out_rows + i0 : nullptr, st);
+            float* o = d_out_rows ? d_out : d_out + (long)i0 * L_.feat;
+            const int* orow = d_out_rows ? d_out_rows + i0 : nullptr;
+            if (mode_ == 1) {
+                const FrameArgs fa{d_frames, d_crop_stream + i0, d_boxes + (long)i0 * box_stride, box_stride, W, H};
+                forward_fused(m, fuse_stem ? &fa : nullptr, o, orow, st);
+            } else forward_v1(m, o, orow, st);
             BM_HIP(hipEventRecord(b, st));
             if (pending_.size() < 4096) pending_.emplace_back(a, b);
             else { free_events_.push_back(a); free_events_.push_back(b); }
@@ -150,11 +156,12 @@ public:
         if (n_max == 0) return;
         d_count_ = d_count;
         BM_HIP(hipEventRecord(ev_[0], st));
-        preprocess(d_frames, d_crop_stream, d_boxes, box_stride, n_max, W, H, st);
+        if (!fuse_stem_) preprocess(d_frames, d_crop_stream, d_boxes, box_stride, n_max, W, H, st);
         BM_HIP(hipEventRecord(ev_[1], st));
         hipEvent_t a = take_event(), b = take_event();
         BM_HIP(hipEventRecord(a, st));
-        forward_fused(n_max, d_out, d_out_rows, st);
+        const FrameArgs fa{d_frames, d_crop_stream, d_boxes, box_stride, W, H};
+        forward_fused(n_max, fuse_stem_ ? &fa : nullptr, d_out, d_out_rows, st);
         BM_HIP(hipEventRecord(b, st));
         if (pending_.size() < 4096) pending_.emplace_back(a, b);
         else { free_events_.push_back(a); free_events_.push_back(b); }
@@ -308,6 +315,7 @@ private:
         BM_HIP(hipMemset(crops_h_, 0, crop_halves * 2));          // the 3-pixel border and X channel stay zero
         act_a_ = dev_alloc<_Float16>(n * 2048 * 64, owned_);
         act_b_ = dev_alloc<_Float16>(n * 2048 * 64, owned_);
+        allow_lds(k_stem_resize_fused, STEM2_LDS);
         allow_lds(k_osblock<0, 16, true>, Geo<0>::LDS_BYTES);
         allow_lds(k_osblock<0, 64, false>, Geo<0>::LDS_BYTES);
         allow_lds(k_osblock<1, 64, true>, Geo<1>::LDS_BYTES);
@@ -316,8 +324,13 @@ private:
         allow_lds(k_osblock<2, 128, false>, Geo<2>::LDS_BYTES);
         fused_ready_ = true;
     }
-    void forward_fused(int n, float* d_out, const int* d_out_rows, hipStream_t st) {
-        hipLaunchKernelGGL(k_stem_fused, dim3(n), dim3(512), 0, st, crops_h_, act_a_, w_stem_, d_count_);
+    struct FrameArgs { const uint8_t* const* frames; const int* crop_stream; const float* boxes; int box_stride, W, H; };
+    void forward_fused(int n, const FrameArgs* fa, float* d_out, const int* d_out_rows, hipStream_t st) {
+        if (fa)     // crop + resize + normalise fused into the stem (the resized crop never reaches HBM)
+            hipLaunchKernelGGL(k_stem_resize_fused, dim3(n), dim3(512), STEM2_LDS, st, fa->frames, fa->crop_stream, fa->boxes,
+                               fa->box_stride, fa->W, fa->H, d_lut_, act_a_, w_stem_, d_count_);
+        else
+            hipLaunchKernelGGL(k_stem_fused, dim3(n), dim3(512), 0, st, crops_h_, act_a_, w_stem_, d_count_);
         hipLaunchKernelGGL((k_osblock<0, 16, true>), dim3(n), dim3(64 * Geo<0>::NWAVES), Geo<0>::LDS_BYTES, st, act_a_, act_b_, w_blk_[0], bp_[0], d_count_);
         hipLaunchKernelGGL((k_osblock<0, 64, false>), dim3(n), dim3(64 * Geo<0>::NWAVES), Geo<0>::LDS_BYTES, st, act_b_, act_a_, w_blk_[1], bp_[1], d_count_);
         hipLaunchKernelGGL((k_transition<64, 64, 32>), dim3((n * 32 + 3) / 4), dim3(256), 0, st, act_a_, act_b_, w_tr_[0], n, d_count_);
@@ -361,7 +374,7 @@ private:
     float *crops_ = nullptr, *big_a_ = nullptr, *big_b_ = nullptr, *idn_ = nullptr;
     float *x1_ = nullptr, *ta_ = nullptr, *tb_ = nullptr, *tt_ = nullptr, *acc_ = nullptr, *gap_ = nullptr;
     // fused path
-    bool fused_ready_ = false, force_fp32_crops_ = false;
+    bool fused_ready_ = false, force_fp32_crops_ = false, fuse_stem_ = true;
     BlkPack bp_[6];
     unsigned char* w_stem_ = nullptr;
     unsigned char* w_blk_[6] = {};

@@ -502,6 +502,164 @@ __global__ void __launch_bounds__(512) k_stem_fused(const _Float16* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------
+// Fused crop -> resize -> normalise -> stem conv 7x7/2 -> maxpool 3x3/2: the resized crop never
+// exists in HBM.  One workgroup (8 waves) per crop walks the crop in 8 bands of 8 pooled rows:
+//   1. the source rows the band needs are staged from the frame into LDS with coalesced dword loads
+//      (crop pixels are read from HBM exactly once; boxes too large for the staging area take direct loads),
+//   2. cv2.resize's fixed-point bilinear + the normalisation table produce 32 new fp16 RGBX input rows
+//      into a 40-row LDS ring (rows are reused by the next band),
+//   3. wave w computes pooled row 8*band + w: three conv rows as MFMA k-steps over LDS B fragments
+//      (one ds_read_b128 per MFMA), vertical + horizontal max, store.
+// Same arithmetic (and bit-identical fp16 output) as k_crop_resize_rgbx + k_stem_fused.
+// ---------------------------------------------------------------------------
+constexpr int RING_ROWS = 40;
+constexpr int RING_ROW_BYTES = STEM_COLS * 8;                    // 136 px * RGBX fp16
+constexpr int SRC_STAGE_BYTES = 20 * 1024;
+constexpr int STEM2_LDS = RING_ROWS * RING_ROW_BYTES + SRC_STAGE_BYTES + 768 * 2;
+
+__global__ void __launch_bounds__(512) k_stem_resize_fused(const uint8_t* const* frames, const int* crop_stream,
+                                                           const float* boxes, int box_stride, int W, int H,
+                                                           const float* lut, _Float16* __restrict__ out,
+                                                           const unsigned char* __restrict__ wts,
+                                                           const int* __restrict__ count) {
+    if (count && (int)blockIdx.x >= *count) return;
+    BM_DYNAMIC_LDS_T(unsigned char, lds);
+    unsigned char* ring = lds;
+    unsigned char* stage = lds + RING_ROWS * RING_ROW_BYTES;
+    _Float16* lut_h = reinterpret_cast<_Float16*>(stage + SRC_STAGE_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l16 = lane & 15;
+    const long crop = blockIdx.x;
+    const uint8_t* frame = frames[crop_stream[crop]];
+    const CropRect r = crop_rect(boxes + crop * box_stride, W, H);
+    const long row_stride = (long)W * 3;
+    _Float16* yout = out + crop * (64 * 32) * 16;
+    for (int e = tid; e < 768; e += 512) lut_h[e] = (_Float16)lut[e];
+    for (int e = tid * 8; e < RING_ROWS * RING_ROW_BYTES; e += 512 * 8) *reinterpret_cast<unsigned long long*>(ring + e) = 0ull;
+    h8 a[7];
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky) a[ky] = *reinterpret_cast<const h8*>(wts + (ky * 64 + lane) * 16);
+    const f4 bias = *reinterpret_cast<const f4*>(wts + 7 * 1024 + 4 * g * 4);
+    // resampling role of this thread: output column dx, row phase rp (4 threads per column)
+    const int dx = tid & 127, rp = tid >> 7;
+    const ResizeAxis ax = resize_axis_x(dx, REID_IN_W, r.w > 0 ? r.w : 1);
+    const bool identity = r.w == REID_IN_W && r.h == REID_IN_H;
+    const bool area2 = r.w == 2 * REID_IN_W && r.h == 2 * REID_IN_H;
+    __syncthreads();
+
+#pragma unroll 1
+    for (int band = 0; band < 8; ++band) {
+        // padded input rows [pr0, pr1) are new in this band (padded row = resized row + 3)
+        const int pr0 = band == 0 ? 0 : 32 * band + 5, pr1 = 32 * band + 37 < STEM_ROWS ? 32 * band + 37 : STEM_ROWS;
+        const int dy0 = pr0 - 3 > 0 ? pr0 - 3 : 0, dy1 = pr1 - 3 < REID_IN_H ? pr1 - 3 : REID_IN_H;   // resized rows [dy0, dy1)
+        // ---- 1. stage the source rows of the band ----
+        int sy_lo = 0, sy_hi = -1, pitch = 0;
+        bool staged = false;
+        if (r.w > 0 && dy1 > dy0) {
+            if (identity) { sy_lo = dy0; sy_hi = dy1 - 1; }
+            else if (area2) { sy_lo = 2 * dy0; sy_hi = 2 * dy1 - 1; }
+            else { sy_lo = resize_axis_y(dy0, REID_IN_H, r.h).s0; sy_hi = resize_axis_y(dy1 - 1, REID_IN_H, r.h).s1; }
+            const long byte0 = (long)r.x1 * 3;
+            pitch = ((3 + r.w * 3 + 3) / 4) * 4;          // room for the per-row alignment offset (0..3)
+            staged = (long)(sy_hi - sy_lo + 1) * pitch <= SRC_STAGE_BYTES;
+            if (staged) {
+                const int ndw = pitch / 4, total = (sy_hi - sy_lo + 1) * ndw;
+                const uint8_t* frame_end = frame + (long)H * row_stride;
+                for (int e = tid; e < total; e += 512) {
+                    const int rr = e / ndw, cw = e % ndw;
+                    const uint8_t* rowp = frame + (long)(r.y1 + sy_lo + rr) * row_stride + byte0;
+                    const uint8_t* src = rowp - (reinterpret_cast<uintptr_t>(rowp) & 3) + 4L * cw;   // aligned dwords
+                    unsigned v;
+                    if (src + 4 <= frame_end) v = *reinterpret_cast<const unsigned*>(src);
+                    else {                                  // tail of the frame: stay inside the allocation
+                        v = 0;
+                        for (int q = 0; q < 4 && src + q < frame_end; ++q) v |= (unsigned)src[q] << (8 * q);
+                    }
+                    *reinterpret_cast<unsigned*>(stage + rr * pitch + 4 * cw) = v;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- 2. resample the new rows into the ring ----
+        for (int pr = pr0 + rp; pr < pr1; pr += 4) {
+            const int dy = pr - 3;
+            h4 px = h4{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+            if (dy >= 0 && dy < REID_IN_H) {
+                const ResizeAxis ay = resize_axis_y(dy, REID_IN_H, r.h > 0 ? r.h : 1);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    int v;
+                    if (r.w == 0) v = 0;
+                    else if (staged) {
+                        // staged row sy starts at the byte offset its frame address has inside a dword
+                        auto row_ptr = [&](int sy) {
+                            const uintptr_t addr = reinterpret_cast<uintptr_t>(frame + (long)(r.y1 + sy) * row_stride + (long)r.x1 * 3);
+                            return stage + (sy - sy_lo) * pitch + (int)(addr & 3) + (2 - c);
+                        };
+                        if (identity) v = row_ptr(dy)[dx * 3];
+                        else if (area2) {
+                            const unsigned char* p0 = row_ptr(2 * dy) + 6 * dx;
+                            const unsigned char* p1 = row_ptr(2 * dy + 1) + 6 * dx;
+                            v = (p0[0] + p0[3] + p1[0] + p1[3] + 2) >> 2;
+                        } else {
+                            const unsigned char* r0 = row_ptr(ay.s0);
+                            const unsigned char* r1 = row_ptr(ay.s1);
+                            const int S0 = r0[ax.s0 * 3] * ax.a0 + r0[ax.s1 * 3] * ax.a1;
+                            const int S1 = r1[ax.s0 * 3] * ax.a0 + r1[ax.s1 * 3] * ax.a1;
+                            v = (((ay.a0 * (S0 >> 4)) >> 16) + ((ay.a1 * (S1 >> 4)) >> 16) + 2) >> 2;
+                        }
+                    } else {
+                        v = resize_sample(frame + (long)r.y1 * row_stride + r.x1 * 3, row_stride, r, ax, ay, dy, dx, 2 - c,
+                                          REID_IN_W, REID_IN_H);
+                    }
+                    px[c] = lut_h[c * 256 + v];
+                }
+            }
+            *reinterpret_cast<h4*>(ring + (pr % RING_ROWS) * RING_ROW_BYTES + (dx + 3) * 8) = px;
+        }
+        __syncthreads();
+        // ---- 3. conv rows + pooling for pooled row oy ----
+        const int oy = 8 * band + wave;
+        f4 vprev = f4{0.f, 0.f, 0.f, 0.f};       // vertical max of the previous tile (for the left neighbour of lane 0)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f4 vm = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dc = -1; dc <= 1; ++dc) {
+                const int cy = 2 * oy + dc;
+                if (cy < 0 || cy > 127) continue;          // wave-uniform
+                f4 acc = bias;
+                const int cx = t * 16 + l16;
+#pragma unroll
+                for (int ky = 0; ky < 7; ++ky) {
+                    const int slot = (2 * cy + ky) % RING_ROWS;
+                    const h8 b = *reinterpret_cast<const h8*>(ring + slot * RING_ROW_BYTES + (2 * cx + 2 * g) * 8);
+                    acc = BM_MFMA_F16_K32(a[ky], b, acc);
+                }
+                vm = max4(vm, relu4(acc));
+            }
+            f4 m = vm;
+            const int src_r = (lane & 48) | ((l16 + 1) & 15);
+            const int src_l = (lane & 48) | ((l16 + 15) & 15);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const float right = __shfl(vm[rr], src_r, 64);
+                float left = __shfl(vm[rr], src_l, 64);
+                const float left_prev = __shfl(vprev[rr], src_l, 64);
+                if (l16 == 0) left = t > 0 ? left_prev : 0.f;
+                const float mm = m[rr] > right ? m[rr] : right;
+                m[rr] = mm > left ? mm : left;
+            }
+            if ((l16 & 1) == 0) {
+                const int p = oy * 32 + t * 8 + (l16 >> 1);
+                *reinterpret_cast<h4*>(yout + (long)p * 16 + g * 4) = to_h4(m);
+            }
+            vprev = vm;
+        }
+        __syncthreads();
+    }
+}
+
 // crop -> resize -> normalise into the stem's fp16 RGBX layout (interior only; the 3-pixel border and the
 // X channel of the buffer stay zero from allocation).  Same integer pipeline as k_crop_resize.
 __global__ void k_crop_resize_rgbx(const uint8_t* const* frames, const int* crop_stream, const float* boxes,

@@ -67,6 +67,38 @@ extern "C" {
 // crops: normalised fp32 NHWC (n, 256, 128, 3).  stage_out[k] (may be null) receives the fp32 NHWC
 // activation after: 0 stem+maxpool, 1..2 stage-1 blocks, 3 transition, 4..5 blocks, 6 transition,
 // 7..8 blocks.  feats: (n, 512) L2-normalised.
+// Fused crop+resize+stem kernel alone: frame (H, W, 3) uint8 BGR + boxes (n, 4) -> stem output fp32 NHWC (n, 2048, 16)
+int emu_stem_from_frame(const float* blob, long n_floats, const uint8_t* frame, int W, int H, const float* boxes, int n,
+                        float* stage0) {
+    using namespace bm;
+    const int32_t* hdr = reinterpret_cast<const int32_t*>(blob);
+    if (hdr[0] != REID_MAGIC || hdr[1] != 16) return -1;
+    const int ch[4] = {hdr[1], hdr[2], hdr[3], hdr[4]};
+    const OsnetLayout L = make_osnet_layout(ch, hdr[5]);
+    if (n_floats != REID_HEADER_INTS + L.total) return -2;
+    const float* w = blob + REID_HEADER_INTS;
+    std::vector<uint8_t> wst;
+    pack_stem(w + L.stem_w, w + L.stem_b, wst);
+    float lut[768];
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    for (int c = 0; c < 3; ++c)
+        for (int v = 0; v < 256; ++v) {
+            volatile float a = (float)v / 255.0f;
+            volatile float b = a - mean[c];
+            lut[c * 256 + v] = b / stdv[c];
+        }
+    std::vector<_Float16> A((size_t)n * 2048 * 16);
+    std::vector<int> streams(n, 0);
+    const uint8_t* frames[1] = {frame};
+    {
+        const uint8_t* const* fr = frames; const int* cs = streams.data(); _Float16* out = A.data();
+        const unsigned char* wp = wst.data(); const float* lp = lut;
+        launch(n, 1, 512, [=]() { k_stem_resize_fused(fr, cs, boxes, 4, W, H, lp, out, wp, nullptr); });
+    }
+    unpack_act(A.data(), stage0, (long)n * 2048, 16);
+    return 0;
+}
+
 int emu_reid_forward(const float* blob, long n_floats, const float* crops, int n, float* feats, float** stage_out) {
     using namespace bm;
     const int32_t* hdr = reinterpret_cast<const int32_t*>(blob);

@@ -53,3 +53,40 @@ def test_fused_reid_kernels_emulated_vs_oracle():
     w = w / np.linalg.norm(w, axis=1, keepdims=True)
     assert np.abs(feats - w).max() < 1e-3
     assert (feats * w).sum(1).min() > 0.99999
+
+
+@pytest.mark.skipif(CLANG is None, reason="needs a host clang with _Float16")
+def test_fused_crop_stem_kernel_equals_separate_kernels_emulated():
+    """k_stem_resize_fused (crop + cv2-style resize + normalise + conv7x7 + maxpool in one kernel, LDS row ring)
+    must reproduce the resize-kernel + stem-kernel pair bit for bit; odd frame width exercises the
+    per-row dword alignment of the staged source rows, the box list the special cases."""
+    import torch
+
+    from boxmot_amd.reid_weights import pack_osnet, reference_init_state_dict
+    from oracle.crops import get_crops
+    from oracle.osnet import osnet_forward
+
+    lib = ctypes.CDLL(str(_build()))
+    lib.emu_reid_forward.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    lib.emu_stem_from_frame.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    sd = reference_init_state_dict("osnet_x0_25", seed=0)
+    blob = pack_osnet(sd)
+    wd, hd = 641, 480
+    img = np.random.default_rng(5).integers(0, 255, (hd, wd, 3), dtype=np.uint8)
+    boxes = np.array([[30.2, 40.7, 90.1, 200.3], [-20, -10, 40, 60], [100, 100, 100, 150], [10, 10, 138, 266],
+                      [0, 0, 641, 480], [600.4, 430.2, 700, 500]], dtype=np.float32)
+    n = len(boxes)
+    crops = get_crops(boxes, img)
+    nhwc = np.ascontiguousarray(np.transpose(crops, (0, 2, 3, 1)))
+    feats = np.zeros((n, 512), np.float32)
+    st_sep = np.zeros((n, 2048, 16), np.float32)
+    ptrs = (ctypes.c_void_p * 9)(st_sep.ctypes.data, *[None] * 8)
+    assert lib.emu_reid_forward(blob.ctypes.data, blob.size, nhwc.ctypes.data, n, feats.ctypes.data, ptrs) == 0
+    st_fused = np.zeros((n, 2048, 16), np.float32)
+    assert lib.emu_stem_from_frame(blob.ctypes.data, blob.size, img.ctypes.data, wd, hd, boxes.ctypes.data, n,
+                                   st_fused.ctypes.data) == 0
+    assert np.array_equal(st_fused, st_sep)
+    _, st = osnet_forward(sd, torch.from_numpy(crops), return_stages=True)
+    ref = st["maxpool"].numpy().transpose(0, 2, 3, 1).reshape(n, 2048, 16)
+    assert np.abs(st_fused - ref).max() < 1e-3 * np.abs(ref).max()
