@@ -31,6 +31,8 @@ sys.path.insert(0, str(ROOT))
 
 N_DETS, N_TRACKS, WIDTH, HEIGHT, EMB_DIM = 64, 256, 1920, 1080, 512
 FLOP_PER_CROP = 2 * 82_314_880          # OSNet x0.25 forward, BASELINE.md section 2
+# HBM bytes per crop of the ReID launch set, from rocprofv3 FETCH_SIZE/WRITE_SIZE passes (profiles/r1_final_pmc_traffic.txt)
+TRAFFIC_BYTES_PER_CROP = {0: None, 1: 2.83e6}
 PEAK_TFLOPS = {0: 157.3, 1: 2500.0}     # dense MFMA peak of the dtype the ReID kernels compute in (fp32 / fp16)
 DTYPE = {0: "f32", 1: "f16"}
 
@@ -210,7 +212,9 @@ def main():
         if a.mode == "reid" and reid_ms > 0:
             tflops = n_first * FLOP_PER_CROP / (reid_ms * 1e-3) / 1e12
             res["roofline"] = {"bound": "mfma", "achieved": tflops, "peak": PEAK_TFLOPS[a.reid_mode], "unit": "TFLOP/s",
-                               "frac": tflops / PEAK_TFLOPS[a.reid_mode], "traffic": None,
+                               "frac": tflops / PEAK_TFLOPS[a.reid_mode],
+                               "traffic": (TRAFFIC_BYTES_PER_CROP[a.reid_mode] * n_first / max(reid_launches, 1)
+                                           if TRAFFIC_BYTES_PER_CROP[a.reid_mode] else None),
                                "kernel": "OSNet-x0.25 forward (ReID) region, HIP events on the launch stream",
                                "launch_ms": reid_ms / max(reid_launches, 1), "crops_per_launch": n_first / max(reid_launches, 1)}
         else:
