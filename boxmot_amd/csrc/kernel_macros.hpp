@@ -19,6 +19,10 @@
 // across tiles by the instruction scheduler (which otherwise hoists every LDS read and spills)
 #define BM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
+#ifndef BM_OPAQUE_U32
+// makes a value opaque to the optimiser (defeats loop-invariant hoisting of the loads that depend on it)
+#define BM_OPAQUE_U32(x) asm volatile("" : "+v"(x))
+#endif
 #ifndef BM_CLOCK
 #define BM_CLOCK() wall_clock64()
 #endif

@@ -39,12 +39,18 @@ struct Geo {
     static constexpr int HID = MID / 16;
     static constexpr int COUT = STAGE == 0 ? 64 : (STAGE == 1 ? 96 : 128);
     static constexpr int NCT = COUT / 16;
-    static constexpr int NWAVES = 16 >> STAGE;              // 16, 8, 4 waves per crop (4 waves/SIMD budget: <= 128 VGPRs)
-    static constexpr int NT = P / 16 / NWAVES;              // 8, 4, 2 pixel tiles per wave
-    static constexpr int PXB = KT == 1 ? 40 : 72;           // padded bytes per pixel of the LDS image
+    // Stage 0 runs TWO workgroups (different crops) per CU so that one crop's LDS/barrier phases overlap the
+    // other's VALU/MFMA phases: 8 waves x 16 tiles, <= 128 VGPRs (conv1 is recomputed per branch instead of
+    // being held), and an unpadded 72 KB LDS image whose bank spread comes from an XOR swizzle.
+    static constexpr int NWAVES = STAGE == 0 ? 8 : (16 >> STAGE);   // 8, 8, 4 waves per crop
+    static constexpr int NT = P / 16 / NWAVES;              // 16, 4, 2 pixel tiles per wave
+    static constexpr bool SWZ = STAGE == 0;
+    static constexpr bool RECOMP = STAGE == 0;
+    static constexpr int WG_PER_CU_WAVES = STAGE == 2 ? 1 : 4;     // __launch_bounds__ 2nd argument (waves per SIMD)
+    static constexpr int PXB = SWZ ? 32 : (KT == 1 ? 40 : 72);      // bytes per pixel of the LDS image
     static constexpr int ROWB = (W + 2) * PXB;
     static constexpr int TBUF = (H + 2) * ROWB;
-    static constexpr int LDS_BYTES = TBUF + 4 * NWAVES * MIDP * 4;
+    static constexpr int LDS_BYTES = TBUF + 4 * NWAVES * HID * 4;          // image + per-branch gate partials
 };
 
 // (y, x) of lane l16 in pixel tile q: tiles are 16 consecutive pixels in row-major order
@@ -58,6 +64,23 @@ __device__ inline int tile_lds_offset(int q, int l16) {
     return (y + 1) * G::ROWB + (x + 1) * G::PXB;
 }
 
+// Optional in-kernel phase clocks for tools/osblock_prof.hip (never defined in the product build)
+#ifdef BM_OSBLOCK_PROF
+__device__ unsigned long long g_osblock_prof[8];
+#define BM_PROF_DECL() unsigned long long prof_t = clock64(), prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define BM_PROF(k) do { unsigned long long t_ = clock64(); prof_acc[k] += t_ - prof_t; prof_t = t_; } while (0)
+#define BM_PROF_FLUSH() do { if ((threadIdx.x & 63) == 0) for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&g_osblock_prof[k_], prof_acc[k_]); } while (0)
+#else
+#define BM_PROF_DECL() ((void)0)
+#define BM_PROF(k) ((void)0)
+#define BM_PROF_FLUSH() ((void)0)
+#endif
+
+#ifndef BM_ABLATE
+#define BM_ABLATE 0
+#endif
+#define BM_ABL(n) (BM_ABLATE == (n))
+
 __device__ inline h4 to_h4(f4 v) { return h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]}; }
 __device__ inline f4 relu4(f4 v) {
     return f4{v[0] > 0.f ? v[0] : 0.f, v[1] > 0.f ? v[1] : 0.f, v[2] > 0.f ? v[2] : 0.f, v[3] > 0.f ? v[3] : 0.f};
@@ -70,7 +93,7 @@ __device__ inline h8 cat8(h4 a, h4 b) { return h8{a[0], a[1], a[2], a[3], b[0], 
 // OSBlock: in [n][P][CIN] -> out [n][P][COUT], fp16 lane-group-major NHWC
 // ---------------------------------------------------------------------------
 template <int STAGE, int CIN, bool DOWN>
-__global__ void __launch_bounds__(64 * Geo<STAGE>::NWAVES)
+__global__ void __launch_bounds__(64 * Geo<STAGE>::NWAVES, Geo<STAGE>::WG_PER_CU_WAVES)
 k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const unsigned char* __restrict__ wts, BlkPack bp,
           const int* __restrict__ count) {
     using G = Geo<STAGE>;
@@ -79,19 +102,21 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
     constexpr int KIN = CIN == 16 ? 1 : CIN / 32;
     BM_DYNAMIC_LDS_T(unsigned char, lds);
     unsigned char* tbuf = lds;
-    float* gap_part = reinterpret_cast<float*>(lds + G::TBUF);      // [4 branches][NWAVES][MIDP]
+    float* gap_part = reinterpret_cast<float*>(lds + G::TBUF);      // [4 branches][NWAVES][HID]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l16 = lane & 15;
     const long crop = blockIdx.x;
     const _Float16* xin = in + crop * P * CIN;
     _Float16* yout = out + crop * P * COUT;
+    BM_PROF_DECL();
 
     // zero the LDS image once: the halo ring stays zero (= the dw conv's zero padding)
     for (int e = tid * 8; e < G::TBUF; e += 64 * G::NWAVES * 8) *reinterpret_cast<unsigned long long*>(tbuf + e) = 0ull;
 
     // ---- conv1: 1x1 CIN -> MID, + bias, ReLU (osnet.py:248) ----
-    h4 x1[NT][KT];
-    {
+    auto conv1_into = [&](h4 (&x1)[NT][KT]) {
+        unsigned xo = 0;            // opaque zero: the recomputing stage must re-read its input per branch,
+        if constexpr (G::RECOMP) BM_OPAQUE_U32(xo);   // not hoist 128 registers of it out of the branch loop
         f4 bias[KT];
 #pragma unroll
         for (int ct = 0; ct < KT; ++ct) bias[ct] = *reinterpret_cast<const f4*>(wts + bp.conv1_b + (16 * ct + 4 * g) * 4);
@@ -100,7 +125,7 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const int p = (wave * NT + i) * 16 + l16;
-                const h4 b = *reinterpret_cast<const h4*>(xin + (long)p * CIN + g * 4);
+                const h4 b = BM_ABL(4) ? (h4)(_Float16)(0.01f * lane) : *reinterpret_cast<const h4*>(xin + (xo + (unsigned)(p * CIN + g * 4)));
                 x1[i][0] = to_h4(relu4(BM_MFMA_F16_K16(a, b, bias[0])));
                 if ((i & 3) == 3) BM_SCHED_FENCE();
             }
@@ -119,7 +144,7 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
                 for (int ct = 0; ct < KT; ++ct) acc[ct] = bias[ct];
 #pragma unroll
                 for (int ks = 0; ks < KIN; ++ks) {
-                    const h8 b = *reinterpret_cast<const h8*>(xin + (long)p * CIN + g * (CIN / 4) + 8 * ks);
+                    const h8 b = BM_ABL(4) ? (h8)(_Float16)(0.01f * lane) : *reinterpret_cast<const h8*>(xin + (xo + (unsigned)(p * CIN + g * (CIN / 4) + 8 * ks)));
 #pragma unroll
                     for (int ct = 0; ct < KT; ++ct) acc[ct] = BM_MFMA_F16_K32(a[ks][ct], b, acc[ct]);
                 }
@@ -128,7 +153,9 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
                 if (i & 1) BM_SCHED_FENCE();
             }
         }
-    }
+    };
+    h4 x1[NT][KT];
+    if constexpr (!G::RECOMP) conv1_into(x1);
 
     // ---- four branches of 1..4 LightConv3x3, each gated and accumulated (osnet.py:249-253) ----
     h4 x2[NT][KT];          // gated sum of the four branches (packed fp16 accumulate: 4 terms)
@@ -136,22 +163,38 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int ct = 0; ct < KT; ++ct) x2[i][ct] = (h4)(_Float16)0.f;
-    // LDS byte offset of this lane's pixel in tile i, relative to `t00` = the (y-1, x-1) neighbour of its
-    // pixel in tile 0: every tap address is t00 + compile-time constant (DS immediate offsets)
-    const int t00 = tile_lds_offset<STAGE>(wave * NT, l16) + g * (KT * 8) - G::ROWB - G::PXB;
+    // LDS addressing: `tap_base[d]` = byte address of the (y-1, x-1+d) neighbour of this lane's pixel in tile 0,
+    // channel group included; every tap is tap_base[dx+1] + compile-time constant (DS immediate offsets).
+    // Swizzled stage: the 8-byte channel-group slot is g ^ 2*bit3(column), which spreads the 16 pixels of a
+    // row tile over all 64 banks without padding (a +16 column step of the second tile leaves bit 3 alone).
+    int tap_base[3];
+    {
+        const int base00 = tile_lds_offset<STAGE>(wave * NT, l16) - G::ROWB - G::PXB;
+        const int col0 = (STAGE == 0 ? l16 : (STAGE == 1 ? l16 : (l16 & 7)));     // column of this lane (+1 halo, -1 tap)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int gslot = G::SWZ ? (g ^ ((((col0 + d) >> 3) & 1) << 1)) * 8 : g * (KT * 8);
+            tap_base[d] = base00 + d * G::PXB + gslot;
+        }
+    }
     auto tile_off = [](int i) constexpr {
         return STAGE == 0 ? (i >> 1) * G::ROWB + (i & 1) * 16 * G::PXB : (STAGE == 1 ? i * G::ROWB : 2 * i * G::ROWB);
     };
     __syncthreads();
+    BM_PROF(0);
 
     int li = 0;
 #pragma unroll 1
     for (int br = 0; br < 4; ++br) {
         h4 cur[NT][KT];
+        if constexpr (G::RECOMP) conv1_into(cur);
+        else {
 #pragma unroll
-        for (int i = 0; i < NT; ++i)
+            for (int i = 0; i < NT; ++i)
 #pragma unroll
-            for (int ct = 0; ct < KT; ++ct) cur[i][ct] = x1[i][ct];
+                for (int ct = 0; ct < KT; ++ct) cur[i][ct] = x1[i][ct];
+        }
+        BM_PROF(1);
 #pragma unroll 1
         for (int k = 0; k <= br; ++k, ++li) {
             const unsigned char* lw = wts + bp.light0 + (long)li * bp.light_bytes;
@@ -161,7 +204,8 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
 #pragma unroll
                 for (int i = 0; i < NT; ++i) {
                     const f4 t = BM_MFMA_F16_K16(a, cur[i][0], (f4{0.f, 0.f, 0.f, 0.f}));
-                    *reinterpret_cast<h4*>(tbuf + t00 + tile_off(i) + G::ROWB + G::PXB) = to_h4(t);
+                    if (BM_ABL(5)) { cur[i][0] = to_h4(t); continue; }
+                    *reinterpret_cast<h4*>(tbuf + tap_base[1] + tile_off(i) + G::ROWB) = to_h4(t);
                 }
             } else {
                 h8 a[KT];
@@ -173,12 +217,17 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
 #pragma unroll
                     for (int ct = 0; ct < KT; ++ct) {
                         const f4 t = BM_MFMA_F16_K32(a[ct], b, (f4{0.f, 0.f, 0.f, 0.f}));
-                        *reinterpret_cast<h4*>(tbuf + t00 + tile_off(i) + G::ROWB + G::PXB + ct * 8) = to_h4(t);
+                        *reinterpret_cast<h4*>(tbuf + tap_base[1] + tile_off(i) + G::ROWB + ct * 8) = to_h4(t);
                     }
                 }
             }
-            __syncthreads();
-            // depthwise 3x3 (pad 1) + bias + ReLU, channel tile by channel tile
+            BM_PROF(2);
+            if (!BM_ABL(6)) __syncthreads();
+            BM_PROF(3);
+            // depthwise 3x3 (pad 1) + bias + ReLU, channel tile by channel tile.  A wave's tiles form NSEQ column
+            // strips of consecutive image rows, so the 3x3 window slides down a strip: only the RS new rows are
+            // read from LDS per tile (3 reads instead of 9 for stages 0/1) -- the dw phase is LDS-bandwidth bound.
+            constexpr int NSEQ = STAGE == 0 ? 2 : 1, SEQ_LEN = NT / NSEQ, RS = STAGE == 2 ? 2 : 1;
 #pragma unroll
             for (int ct = 0; ct < KT; ++ct) {
                 h4 wd[9];
@@ -187,58 +236,91 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
                 for (int tap = 0; tap < 9; ++tap) wd[tap] = wsrc[tap];
                 const h4 bias = to_h4(*reinterpret_cast<const f4*>(lw + bp.light_b + (16 * ct + 4 * g) * 4));
 #pragma unroll
-                for (int i = 0; i < NT; ++i) {
-                    // 9 taps x 4 channels as packed fp16 FMAs (v_pk_fma_f16); the 9-term fp16 accumulation
-                    // is inside the error budget (tests/test_reid_emu.py, test_gpu_reid.py)
-                    h4 o = bias;
+                for (int sq = 0; sq < NSEQ; ++sq) {
+                    h4 win[3][3];
 #pragma unroll
-                    for (int tap = 0; tap < 9; ++tap) {
-                        const h4 nb = *reinterpret_cast<const h4*>(tbuf + t00 + tile_off(i) + ct * 8 + (tap / 3) * G::ROWB + (tap % 3) * G::PXB);
-                        o = fma_h4(nb, wd[tap], o);
+                    for (int j = 0; j < SEQ_LEN; ++j) {
+                        const int i = STAGE == 0 ? 2 * j + sq : j;
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy) {
+                            if (j > 0 && dy + RS < 3) {
+#pragma unroll
+                                for (int dx = 0; dx < 3; ++dx) win[dy][dx] = win[dy + RS][dx];
+                            } else {
+#pragma unroll
+                                for (int dx = 0; dx < 3; ++dx)
+                                    win[dy][dx] = *reinterpret_cast<const h4*>(tbuf + tap_base[dx] + tile_off(i) + ct * 8 + dy * G::ROWB);
+                            }
+                        }
+                        // 9 taps x 4 channels as packed fp16 FMAs (v_pk_fma_f16); the 9-term fp16 accumulation
+                        // is inside the error budget (tests/test_reid_emu.py, test_gpu_reid.py)
+                        h4 o = bias;
+#pragma unroll
+                        for (int tap = 0; tap < 9; ++tap) o = fma_h4(win[tap / 3][tap % 3], wd[tap], o);
+                        cur[i][ct] = relu_h4(o);
+                        if (j & 1) BM_SCHED_FENCE();
                     }
-                    cur[i][ct] = relu_h4(o);
-                    if (i & 1) BM_SCHED_FENCE();
                 }
             }
-            __syncthreads();
+            BM_PROF(4);
+            if (!BM_ABL(6)) __syncthreads();
+            BM_PROF(5);
         }
         // ChannelGate (osnet.py:194-209): crop-wide average -> fc1 -> ReLU -> fc2 -> sigmoid -> scale
-        float* part = gap_part + br * (G::NWAVES * MIDP);
+        if (BM_ABL(2)) {
 #pragma unroll
-        for (int ct = 0; ct < KT; ++ct) {
-            f4 s = f4{0.f, 0.f, 0.f, 0.f};
+            for (int ct = 0; ct < KT; ++ct)
 #pragma unroll
-            for (int i = 0; i < NT; ++i)
+                for (int i = 0; i < NT; ++i) x2[i][ct] = fma_h4((h4)(_Float16)0.5f, cur[i][ct], x2[i][ct]);
+            continue;
+        }
+        // fc1 is linear in the pooled vector, so every wave reduces its own share of sum_c W1[h][c] * sum_p x[c][p]
+        // to HID scalars (one 64-lane butterfly each); the waves' partials meet in LDS.
+        float* part = gap_part + br * (G::NWAVES * G::HID);
+        {
+            float ph[G::HID];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s[r] += (float)cur[i][ct][r];
+            for (int h = 0; h < G::HID; ++h) ph[h] = 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = s[r];
+            for (int ct = 0; ct < KT; ++ct) {
+                f4 s = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[r] += (float)cur[i][ct][r];
+#pragma unroll
+                for (int h = 0; h < G::HID; ++h) {
+                    const f4 w1 = *reinterpret_cast<const f4*>(wts + bp.fc1_w + 4 * (h * MIDP + 16 * ct + 4 * g));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ph[h] += w1[r] * s[r];
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < G::HID; ++h) {
+                float v = ph[h];
                 v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-                if (l16 == 0) part[wave * MIDP + 16 * ct + 4 * g + r] = v;
+                v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+                if (lane == 0) part[wave * G::HID + h] = v;
             }
         }
         __syncthreads();
         float hidv[G::HID];
 #pragma unroll
-        for (int h = 0; h < G::HID; ++h) hidv[h] = *reinterpret_cast<const float*>(wts + bp.fc1_b + 4 * h);
-        for (int c = 0; c < MIDP; ++c) {
-            float s = 0.f;
+        for (int h = 0; h < G::HID; ++h) {
+            float sum = 0.f;
 #pragma unroll
-            for (int w = 0; w < G::NWAVES; ++w) s += part[w * MIDP + c];
-            s *= (1.0f / P);
-#pragma unroll
-            for (int h = 0; h < G::HID; ++h) hidv[h] += *reinterpret_cast<const float*>(wts + bp.fc1_w + 4 * (h * MIDP + c)) * s;
+            for (int w = 0; w < G::NWAVES; ++w) sum += part[w * G::HID + h];
+            const float z = *reinterpret_cast<const float*>(wts + bp.fc1_b + 4 * h) + sum * (1.0f / P);
+            hidv[h] = z > 0.f ? z : 0.f;
         }
 #pragma unroll
-        for (int h = 0; h < G::HID; ++h) hidv[h] = hidv[h] > 0.f ? hidv[h] : 0.f;
-#pragma unroll
         for (int ct = 0; ct < KT; ++ct) {
+            const f4 zb = *reinterpret_cast<const f4*>(wts + bp.fc2_b + 4 * (16 * ct + 4 * g));
             f4 gate;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int c = 16 * ct + 4 * g + r;
-                float z = *reinterpret_cast<const float*>(wts + bp.fc2_b + 4 * c);
+                float z = zb[r];
 #pragma unroll
                 for (int h = 0; h < G::HID; ++h) z += *reinterpret_cast<const float*>(wts + bp.fc2_w + 4 * (c * G::HID + h)) * hidv[h];
                 gate[r] = 1.f / (1.f + BM_EXPF(-z));
@@ -247,6 +329,7 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
 #pragma unroll
             for (int i = 0; i < NT; ++i) x2[i][ct] = fma_h4(gate_h, cur[i][ct], x2[i][ct]);
         }
+        BM_PROF(6);
     }
 
     // ---- conv3 (1x1 MID -> COUT, linear) + downsample(x) or identity, ReLU (osnet.py:254-260) ----
@@ -259,10 +342,10 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
         h8 bx[KIN];
         h4 bx4;
         if constexpr (DOWN) {
-            if constexpr (CIN == 16) bx4 = *reinterpret_cast<const h4*>(xin + (long)p * CIN + g * 4);
+            if constexpr (CIN == 16) bx4 = *reinterpret_cast<const h4*>(xin + (unsigned)(p * CIN + g * 4));
             else {
 #pragma unroll
-                for (int ks = 0; ks < KIN; ++ks) bx[ks] = *reinterpret_cast<const h8*>(xin + (long)p * CIN + g * (CIN / 4) + 8 * ks);
+                for (int ks = 0; ks < KIN; ++ks) bx[ks] = *reinterpret_cast<const h8*>(xin + (unsigned)(p * CIN + g * (CIN / 4) + 8 * ks));
             }
         }
 #pragma unroll
@@ -282,14 +365,17 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
                         acc = BM_MFMA_F16_K32(*reinterpret_cast<const h8*>(wts + bp.down_a + ((co * KIN + ks) * 64 + lane) * 16), bx[ks], acc);
                 }
             } else {
-                const h4 idn = *reinterpret_cast<const h4*>(xin + (long)p * CIN + g * (CIN / 4) + 4 * co);
+                const h4 idn = *reinterpret_cast<const h4*>(xin + (unsigned)(p * CIN + g * (CIN / 4) + 4 * co));
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[r] += (float)idn[r];
             }
-            *reinterpret_cast<h4*>(yout + (long)p * COUT + g * (COUT / 4) + 4 * co) = to_h4(relu4(acc));
+            if (BM_ABL(3) && acc[0] != 12345.f) continue;
+            *reinterpret_cast<h4*>(yout + (unsigned)(p * COUT + g * (COUT / 4) + 4 * co)) = to_h4(relu4(acc));
         }
         BM_SCHED_FENCE();
     }
+    BM_PROF(7);
+    BM_PROF_FLUSH();
 }
 
 // ---------------------------------------------------------------------------

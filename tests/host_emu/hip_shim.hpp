@@ -96,6 +96,7 @@ inline double __dadd_rn(double a, double b) { return a + b; }
 inline double __dmul_rn(double a, double b) { return a * b; }
 #define BM_EXPF(x) expf(x)
 #define BM_SCHED_FENCE() ((void)0)
+#define BM_OPAQUE_U32(x) ((void)0)
 extern unsigned char* g_emu_dynamic_lds;
 inline float sqrtf_emu(float x) { return std::sqrt(x); }
 

@@ -1,0 +1,75 @@
+// Standalone phase profiler for the fused OSBlock kernel (development tool, not part of the library).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DBM_OSBLOCK_PROF -I boxmot_amd/csrc \
+//         tools/osblock_prof.hip -o gpurun_out/osblock_prof && gpurun_out/osblock_prof [n_crops] [iters]
+// Prints the launch time (HIP events) and the shader-clock cycles each phase of k_osblock took, averaged per wave.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "kernel_macros.hpp"
+#include "reid_fused.hpp"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+template <int STAGE, int CIN, bool DOWN>
+static void run(const char* name, int n, int iters) {
+    using G = bm::Geo<STAGE>;
+    bm::BlkPack bp = bm::make_blk_pack(STAGE, CIN, DOWN);
+    std::vector<unsigned short> w(bp.total / 2);
+    unsigned s = 12345u;
+    for (auto& v : w) { s = s * 1664525u + 1013904223u; v = bm::f32_to_f16_bits(((s >> 8) & 0xffff) / 65536.0f * 0.2f - 0.1f); }
+    // fp32 regions (biases, gate fc) get small fp32 values
+    auto fill_f32 = [&](long off, long cnt) { float* f = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(w.data()) + off); for (long i = 0; i < cnt; ++i) f[i] = 0.01f * (i % 7); };
+    fill_f32(bp.conv1_b, bp.midp); fill_f32(bp.fc1_w, bp.hid * bp.midp); fill_f32(bp.fc1_b, bp.hid);
+    fill_f32(bp.fc2_w, bp.midp * bp.hid); fill_f32(bp.fc2_b, bp.midp); fill_f32(bp.conv3_b, bp.cout);
+    for (int li = 0; li < 10; ++li) fill_f32(bp.light0 + li * bp.light_bytes + bp.light_b, bp.midp);
+    const size_t in_elems = (size_t)n * G::P * CIN, out_elems = (size_t)n * G::P * G::COUT;
+    std::vector<unsigned short> x(in_elems);
+    for (auto& v : x) { s = s * 1664525u + 1013904223u; v = bm::f32_to_f16_bits(((s >> 8) & 0xffff) / 65536.0f); }
+    unsigned char* d_w; _Float16 *d_in, *d_out;
+    CK(hipMalloc(&d_w, bp.total)); CK(hipMalloc(&d_in, in_elems * 2)); CK(hipMalloc(&d_out, out_elems * 2));
+    CK(hipMemcpy(d_w, w.data(), bp.total, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_in, x.data(), in_elems * 2, hipMemcpyHostToDevice));
+    auto kern = bm::k_osblock<STAGE, CIN, DOWN>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    unsigned long long zero[8] = {};
+    float best = 1e9f;
+    for (int it = 0; it < iters; ++it) {
+#ifdef BM_OSBLOCK_PROF
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(bm::g_osblock_prof), zero, sizeof(zero)));
+#endif
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(kern, dim3(n), dim3(64 * G::NWAVES), G::LDS_BYTES, 0, d_in, d_out, d_w, bp, (const int*)nullptr);
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    unsigned long long acc[8] = {};
+#ifdef BM_OSBLOCK_PROF
+    CK(hipMemcpyFromSymbol(acc, HIP_SYMBOL(bm::g_osblock_prof), sizeof(acc)));
+#else
+    printf("[abl %d] %s: n=%d best %.3f ms\n", BM_ABLATE, name, n, best); (void)zero;
+    CK(hipFree(d_w)); CK(hipFree(d_in)); CK(hipFree(d_out));
+    return;
+#endif
+    const double waves = (double)n * G::NWAVES;
+    static const char* PH[8] = {"init", "conv1", "pw+write", "barrier1", "dw3x3", "barrier2", "gate", "conv3"};
+    double tot = 0; for (int k = 0; k < 8; ++k) tot += acc[k] / waves;
+    printf("%s: n=%d best %.3f ms, waves/crop %d, lds %d B; cycles per wave: total %.0f\n", name, n, best, G::NWAVES, G::LDS_BYTES, tot);
+    for (int k = 0; k < 8; ++k) printf("    %-9s %9.0f  %5.1f%%\n", PH[k], acc[k] / waves, 100.0 * acc[k] / waves / tot);
+    CK(hipFree(d_w)); CK(hipFree(d_in)); CK(hipFree(d_out));
+}
+
+int main(int argc, char** argv) {
+    const int n = argc > 1 ? atoi(argv[1]) : 4096, iters = argc > 2 ? atoi(argv[2]) : 5;
+    run<0, 16, true>("osblock<0,16,down>", n, iters);
+    run<0, 64, false>("osblock<0,64>", n, iters);
+    run<1, 64, true>("osblock<1,64,down>", n, iters);
+    run<1, 96, false>("osblock<1,96>", n, iters);
+    run<2, 96, true>("osblock<2,96,down>", n, iters);
+    run<2, 128, false>("osblock<2,128>", n, iters);
+    return 0;
+}
