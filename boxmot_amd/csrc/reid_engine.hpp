@@ -315,13 +315,14 @@ private:
         BM_HIP(hipMemset(crops_h_, 0, crop_halves * 2));          // the 3-pixel border and X channel stay zero
         act_a_ = dev_alloc<_Float16>(n * 2048 * 64, owned_);
         act_b_ = dev_alloc<_Float16>(n * 2048 * 64, owned_);
+        x1s_ = dev_alloc<_Float16>(n * 2048 * 16, owned_);      // conv1 output of the second stage-0 block (k_osblock STASH)
         allow_lds(k_stem_resize_fused, STEM2_LDS);
-        allow_lds(k_osblock<0, 16, true>, Geo<0>::LDS_BYTES);
-        allow_lds(k_osblock<0, 64, false>, Geo<0>::LDS_BYTES);
-        allow_lds(k_osblock<1, 64, true>, Geo<1>::LDS_BYTES);
-        allow_lds(k_osblock<1, 96, false>, Geo<1>::LDS_BYTES);
-        allow_lds(k_osblock<2, 96, true>, Geo<2>::LDS_BYTES);
-        allow_lds(k_osblock<2, 128, false>, Geo<2>::LDS_BYTES);
+        allow_lds(k_osblock<0, 16, true, false>, Geo<0>::LDS_BYTES);
+        allow_lds(k_osblock<0, 64, false, true>, Geo<0>::LDS_BYTES);
+        allow_lds(k_osblock<1, 64, true, false>, Geo<1>::LDS_BYTES);
+        allow_lds(k_osblock<1, 96, false, true>, Geo<1>::LDS_BYTES);
+        allow_lds(k_osblock<2, 96, true, false>, Geo<2>::LDS_BYTES);
+        allow_lds(k_osblock<2, 128, false, false>, Geo<2>::LDS_BYTES);
         fused_ready_ = true;
     }
     struct FrameArgs { const uint8_t* const* frames; const int* crop_stream; const float* boxes; int box_stride, W, H; };
@@ -331,14 +332,16 @@ private:
                                fa->box_stride, fa->W, fa->H, d_lut_, act_a_, w_stem_, d_count_);
         else
             hipLaunchKernelGGL(k_stem_fused, dim3(n), dim3(512), 0, st, crops_h_, act_a_, w_stem_, d_count_);
-        hipLaunchKernelGGL((k_osblock<0, 16, true>), dim3(n), dim3(64 * Geo<0>::NWAVES), Geo<0>::LDS_BYTES, st, act_a_, act_b_, w_blk_[0], bp_[0], d_count_);
-        hipLaunchKernelGGL((k_osblock<0, 64, false>), dim3(n), dim3(64 * Geo<0>::NWAVES), Geo<0>::LDS_BYTES, st, act_b_, act_a_, w_blk_[1], bp_[1], d_count_);
-        hipLaunchKernelGGL((k_transition<64, 64, 32>), dim3((n * 32 + 3) / 4), dim3(256), 0, st, act_a_, act_b_, w_tr_[0], n, d_count_);
-        hipLaunchKernelGGL((k_osblock<1, 64, true>), dim3(n), dim3(64 * Geo<1>::NWAVES), Geo<1>::LDS_BYTES, st, act_b_, act_a_, w_blk_[2], bp_[2], d_count_);
-        hipLaunchKernelGGL((k_osblock<1, 96, false>), dim3(n), dim3(64 * Geo<1>::NWAVES), Geo<1>::LDS_BYTES, st, act_a_, act_b_, w_blk_[3], bp_[3], d_count_);
-        hipLaunchKernelGGL((k_transition<96, 32, 16>), dim3((n * 16 + 3) / 4), dim3(256), 0, st, act_b_, act_a_, w_tr_[1], n, d_count_);
-        hipLaunchKernelGGL((k_osblock<2, 96, true>), dim3(n), dim3(64 * Geo<2>::NWAVES), Geo<2>::LDS_BYTES, st, act_a_, act_b_, w_blk_[4], bp_[4], d_count_);
-        hipLaunchKernelGGL((k_osblock<2, 128, false>), dim3(n), dim3(64 * Geo<2>::NWAVES), Geo<2>::LDS_BYTES, st, act_b_, act_a_, w_blk_[5], bp_[5], d_count_);
+        // activations ping-pong between act_a_ and act_b_; the transitions are fused into the second block of a stage
+        auto blk = [&](auto kernel, int nw, int lds, const _Float16* in, _Float16* out, int b, const unsigned char* wtr) {
+            hipLaunchKernelGGL(kernel, dim3(n), dim3(64 * nw), lds, st, in, out, w_blk_[b], bp_[b], d_count_, x1s_, wtr);
+        };
+        blk(k_osblock<0, 16, true, false>, Geo<0>::NWAVES, Geo<0>::LDS_BYTES, act_a_, act_b_, 0, nullptr);
+        blk(k_osblock<0, 64, false, true>, Geo<0>::NWAVES, Geo<0>::LDS_BYTES, act_b_, act_a_, 1, w_tr_[0]);
+        blk(k_osblock<1, 64, true, false>, Geo<1>::NWAVES, Geo<1>::LDS_BYTES, act_a_, act_b_, 2, nullptr);
+        blk(k_osblock<1, 96, false, true>, Geo<1>::NWAVES, Geo<1>::LDS_BYTES, act_b_, act_a_, 3, w_tr_[1]);
+        blk(k_osblock<2, 96, true, false>, Geo<2>::NWAVES, Geo<2>::LDS_BYTES, act_a_, act_b_, 4, nullptr);
+        blk(k_osblock<2, 128, false, false>, Geo<2>::NWAVES, Geo<2>::LDS_BYTES, act_b_, act_a_, 5, nullptr);
         hipLaunchKernelGGL((k_head_fused<128, 512>), dim3(n), dim3(128), 0, st, act_a_, w_c5_, w_fc_, d_out, d_out_rows, d_count_);
     }
     void alloc_buffers() {
@@ -380,7 +383,7 @@ private:
     unsigned char* w_blk_[6] = {};
     unsigned char* w_tr_[2] = {};
     unsigned char *w_c5_ = nullptr, *w_fc_ = nullptr;
-    _Float16 *crops_h_ = nullptr, *act_a_ = nullptr, *act_b_ = nullptr;
+    _Float16 *crops_h_ = nullptr, *act_a_ = nullptr, *act_b_ = nullptr, *x1s_ = nullptr;
     hipEvent_t ev_[3];
     std::vector<hipEvent_t> all_events_, free_events_;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_;

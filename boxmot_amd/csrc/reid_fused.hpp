@@ -76,11 +76,6 @@ __device__ unsigned long long g_osblock_prof[8];
 #define BM_PROF_FLUSH() ((void)0)
 #endif
 
-#ifndef BM_ABLATE
-#define BM_ABLATE 0
-#endif
-#define BM_ABL(n) (BM_ABLATE == (n))
-
 __device__ inline h4 to_h4(f4 v) { return h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]}; }
 __device__ inline f4 relu4(f4 v) {
     return f4{v[0] > 0.f ? v[0] : 0.f, v[1] > 0.f ? v[1] : 0.f, v[2] > 0.f ? v[2] : 0.f, v[3] > 0.f ? v[3] : 0.f};
@@ -92,14 +87,21 @@ __device__ inline h8 cat8(h4 a, h4 b) { return h8{a[0], a[1], a[2], a[3], b[0], 
 // ---------------------------------------------------------------------------
 // OSBlock: in [n][P][CIN] -> out [n][P][COUT], fp16 lane-group-major NHWC
 // ---------------------------------------------------------------------------
-template <int STAGE, int CIN, bool DOWN>
+//
+// TRANS fuses the stage's transition (Conv1x1 C->C + BN + ReLU + AvgPool 2x2, osnet.py:344-350) into the
+// epilogue: the block output is consumed from registers and only the pooled [P/4][COUT] tensor is written
+// (`wtr`: fragments [ct][ks] (1 KiB each) then fp32 bias[COUT], reid_pack.hpp pack_pointwise).
+// `x1s` ([n][P][MIDP] halves) is where a recomputing stage with a wide input parks conv1's output instead of
+// re-reading CIN channels per branch.
+template <int STAGE, int CIN, bool DOWN, bool TRANS>
 __global__ void __launch_bounds__(64 * Geo<STAGE>::NWAVES, Geo<STAGE>::WG_PER_CU_WAVES)
 k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const unsigned char* __restrict__ wts, BlkPack bp,
-          const int* __restrict__ count) {
+          const int* __restrict__ count, _Float16* __restrict__ x1s, const unsigned char* __restrict__ wtr) {
     using G = Geo<STAGE>;
     if (count && (int)blockIdx.x >= *count) return;     // device-side crop count (no host round trip)
     constexpr int KT = G::KT, NT = G::NT, MIDP = G::MIDP, NCT = G::NCT, COUT = G::COUT, P = G::P;
     constexpr int KIN = CIN == 16 ? 1 : CIN / 32;
+    constexpr bool STASH = G::RECOMP && CIN != 16;      // conv1 output parked in global scratch (L2-resident re-reads)
     BM_DYNAMIC_LDS_T(unsigned char, lds);
     unsigned char* tbuf = lds;
     float* gap_part = reinterpret_cast<float*>(lds + G::TBUF);      // [4 branches][NWAVES][HID]
@@ -107,7 +109,7 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l16 = lane & 15;
     const long crop = blockIdx.x;
     const _Float16* xin = in + crop * P * CIN;
-    _Float16* yout = out + crop * P * COUT;
+    _Float16* yout = out + crop * (TRANS ? P / 4 : P) * COUT;
     BM_PROF_DECL();
 
     // zero the LDS image once: the halo ring stays zero (= the dw conv's zero padding)
@@ -125,7 +127,7 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const int p = (wave * NT + i) * 16 + l16;
-                const h4 b = BM_ABL(4) ? (h4)(_Float16)(0.01f * lane) : *reinterpret_cast<const h4*>(xin + (xo + (unsigned)(p * CIN + g * 4)));
+                const h4 b = *reinterpret_cast<const h4*>(xin + (xo + (unsigned)(p * CIN + g * 4)));
                 x1[i][0] = to_h4(relu4(BM_MFMA_F16_K16(a, b, bias[0])));
                 if ((i & 3) == 3) BM_SCHED_FENCE();
             }
@@ -144,7 +146,7 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
                 for (int ct = 0; ct < KT; ++ct) acc[ct] = bias[ct];
 #pragma unroll
                 for (int ks = 0; ks < KIN; ++ks) {
-                    const h8 b = BM_ABL(4) ? (h8)(_Float16)(0.01f * lane) : *reinterpret_cast<const h8*>(xin + (xo + (unsigned)(p * CIN + g * (CIN / 4) + 8 * ks)));
+                    const h8 b = *reinterpret_cast<const h8*>(xin + (xo + (unsigned)(p * CIN + g * (CIN / 4) + 8 * ks)));
 #pragma unroll
                     for (int ct = 0; ct < KT; ++ct) acc[ct] = BM_MFMA_F16_K32(a[ks][ct], b, acc[ct]);
                 }
@@ -156,6 +158,8 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
     };
     h4 x1[NT][KT];
     if constexpr (!G::RECOMP) conv1_into(x1);
+    _Float16* x1w = nullptr;        // this lane's slots in the scratch: [(tile, ct)][lane] h4 = 512 B per wave access
+    if constexpr (STASH) x1w = x1s + crop * (P * MIDP) + (long)(wave * NT * KT * 64 + lane) * 4;
 
     // ---- four branches of 1..4 LightConv3x3, each gated and accumulated (osnet.py:249-253) ----
     h4 x2[NT][KT];          // gated sum of the four branches (packed fp16 accumulate: 4 terms)
@@ -187,7 +191,20 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
 #pragma unroll 1
     for (int br = 0; br < 4; ++br) {
         h4 cur[NT][KT];
-        if constexpr (G::RECOMP) conv1_into(cur);
+        if constexpr (STASH) {
+            if (br == 0) {
+                conv1_into(cur);
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int ct = 0; ct < KT; ++ct) *reinterpret_cast<h4*>(x1w + (i * KT + ct) * 256) = cur[i][ct];
+            } else {
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int ct = 0; ct < KT; ++ct) cur[i][ct] = *reinterpret_cast<const h4*>(x1w + (i * KT + ct) * 256);
+            }
+        } else if constexpr (G::RECOMP) conv1_into(cur);
         else {
 #pragma unroll
             for (int i = 0; i < NT; ++i)
@@ -204,7 +221,6 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
 #pragma unroll
                 for (int i = 0; i < NT; ++i) {
                     const f4 t = BM_MFMA_F16_K16(a, cur[i][0], (f4{0.f, 0.f, 0.f, 0.f}));
-                    if (BM_ABL(5)) { cur[i][0] = to_h4(t); continue; }
                     *reinterpret_cast<h4*>(tbuf + tap_base[1] + tile_off(i) + G::ROWB) = to_h4(t);
                 }
             } else {
@@ -222,7 +238,7 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
                 }
             }
             BM_PROF(2);
-            if (!BM_ABL(6)) __syncthreads();
+            __syncthreads();
             BM_PROF(3);
             // depthwise 3x3 (pad 1) + bias + ReLU, channel tile by channel tile.  A wave's tiles form NSEQ column
             // strips of consecutive image rows, so the 3x3 window slides down a strip: only the RS new rows are
@@ -263,17 +279,10 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
                 }
             }
             BM_PROF(4);
-            if (!BM_ABL(6)) __syncthreads();
+            __syncthreads();
             BM_PROF(5);
         }
         // ChannelGate (osnet.py:194-209): crop-wide average -> fc1 -> ReLU -> fc2 -> sigmoid -> scale
-        if (BM_ABL(2)) {
-#pragma unroll
-            for (int ct = 0; ct < KT; ++ct)
-#pragma unroll
-                for (int i = 0; i < NT; ++i) x2[i][ct] = fma_h4((h4)(_Float16)0.5f, cur[i][ct], x2[i][ct]);
-            continue;
-        }
         // fc1 is linear in the pooled vector, so every wave reduces its own share of sum_c W1[h][c] * sum_p x[c][p]
         // to HID scalars (one 64-lane butterfly each); the waves' partials meet in LDS.
         float* part = gap_part + br * (G::NWAVES * G::HID);
@@ -333,12 +342,9 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
     }
 
     // ---- conv3 (1x1 MID -> COUT, linear) + downsample(x) or identity, ReLU (osnet.py:254-260) ----
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        const int p = (wave * NT + i) * 16 + l16;
-        h4 b4[KT];
-#pragma unroll
-        for (int ct = 0; ct < KT; ++ct) b4[ct] = x2[i][ct];
+    auto conv3_tile = [&](int i, h4 (&y)[NCT]) {
+        unsigned p = (wave * NT + i) * 16 + l16;
+        if constexpr (STASH) BM_OPAQUE_U32(p);           // addresses are formed at the use, not precomputed and spilled
         h8 bx[KIN];
         h4 bx4;
         if constexpr (DOWN) {
@@ -352,9 +358,9 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
         for (int co = 0; co < NCT; ++co) {
             f4 acc = *reinterpret_cast<const f4*>(wts + bp.conv3_b + (16 * co + 4 * g) * 4);
             if constexpr (KT == 1) {
-                acc = BM_MFMA_F16_K16(*reinterpret_cast<const h4*>(wts + bp.conv3_a + (co * 64 + lane) * 8), b4[0], acc);
+                acc = BM_MFMA_F16_K16(*reinterpret_cast<const h4*>(wts + bp.conv3_a + (co * 64 + lane) * 8), x2[i][0], acc);
             } else {
-                acc = BM_MFMA_F16_K32(*reinterpret_cast<const h8*>(wts + bp.conv3_a + (co * 64 + lane) * 16), cat8(b4[0], b4[1]), acc);
+                acc = BM_MFMA_F16_K32(*reinterpret_cast<const h8*>(wts + bp.conv3_a + (co * 64 + lane) * 16), cat8(x2[i][0], x2[i][1]), acc);
             }
             if constexpr (DOWN) {
                 if constexpr (CIN == 16) {
@@ -369,67 +375,60 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[r] += (float)idn[r];
             }
-            if (BM_ABL(3) && acc[0] != 12345.f) continue;
-            *reinterpret_cast<h4*>(yout + (unsigned)(p * COUT + g * (COUT / 4) + 4 * co)) = to_h4(relu4(acc));
+            y[co] = to_h4(relu4(acc));
         }
-        BM_SCHED_FENCE();
+    };
+    if constexpr (!TRANS) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int p = (wave * NT + i) * 16 + l16;
+            h4 y[NCT];
+            conv3_tile(i, y);
+#pragma unroll
+            for (int co = 0; co < NCT; ++co) *reinterpret_cast<h4*>(yout + (unsigned)(p * COUT + g * (COUT / 4) + 4 * co)) = y[co];
+            BM_SCHED_FENCE();
+        }
+    } else {
+        // two vertically adjacent tiles at a time: transition conv on the in-register block output (its MFMA
+        // accumulator layout is the K32 B operand: k-slot j <-> channel tile 2ks + (j >> 2)), ReLU, 2x2 average
+        // (vertical = the two tiles, horizontal = lane ^ 1), even lanes store the pooled pixel.
+        static_assert(!TRANS || (STAGE < 2 && COUT % 32 == 0), "fused transition: stages 0 and 1");
+        constexpr int KS3 = COUT / 32, WP = G::W / 2;
+        const unsigned char* tbias = wtr + NCT * KS3 * 1024;
+#pragma unroll
+        for (int pr = 0; pr < NT / 2; ++pr) {
+            const int i0 = STAGE == 0 ? (pr >> 1) * 4 + (pr & 1) : 2 * pr;
+            const int i1 = STAGE == 0 ? i0 + 2 : i0 + 1;
+            h4 y0[NCT], y1[NCT];
+            conv3_tile(i0, y0);
+            conv3_tile(i1, y1);
+            const int row = STAGE == 0 ? wave * (NT / 2) + (i0 >> 1) : wave * NT + i0;     // even image row of tile i0
+            const int po = (row >> 1) * WP + (STAGE == 0 ? (i0 & 1) * 8 : 0) + (l16 >> 1);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const f4 bv = *reinterpret_cast<const f4*>(tbias + (16 * ct + 4 * g) * 4);
+                f4 a0 = bv, a1 = bv;
+#pragma unroll
+                for (int ks = 0; ks < KS3; ++ks) {
+                    const h8 a = *reinterpret_cast<const h8*>(wtr + ((ct * KS3 + ks) * 64 + lane) * 16);
+                    a0 = BM_MFMA_F16_K32(a, cat8(y0[2 * ks], y0[2 * ks + 1]), a0);
+                    a1 = BM_MFMA_F16_K32(a, cat8(y1[2 * ks], y1[2 * ks + 1]), a1);
+                }
+                a0 = relu4(a0); a1 = relu4(a1);
+                f4 sp;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = a0[r] + a1[r];
+                    v += __shfl_xor(v, 1, 64);
+                    sp[r] = v * 0.25f;
+                }
+                if ((l16 & 1) == 0) *reinterpret_cast<h4*>(yout + (unsigned)(po * COUT + g * (COUT / 4) + 4 * ct)) = to_h4(sp);
+            }
+            BM_SCHED_FENCE();
+        }
     }
     BM_PROF(7);
     BM_PROF_FLUSH();
-}
-
-// ---------------------------------------------------------------------------
-// transition: Conv1x1(C -> C) + BN + ReLU, then AvgPool 2x2 (osnet.py:344-350)
-// in [n][H*W][C] -> out [n][H*W/4][C].  One wave per pair of image rows.
-// wts: fragments [ct][ks] (1 KiB each) then fp32 bias[C].
-// ---------------------------------------------------------------------------
-template <int C, int H, int W>
-__global__ void __launch_bounds__(256) k_transition(const _Float16* __restrict__ in, _Float16* __restrict__ out,
-                                                    const unsigned char* __restrict__ wts, int n_crops, const int* __restrict__ count) {
-    if (count) n_crops = *count < n_crops ? *count : n_crops;
-    constexpr int NCT = C / 16, KS = C / 32, TPR = W / 16;        // tiles per image row
-    constexpr int PAIRS = H / 2;
-    const int lane = threadIdx.x & 63, g = lane >> 4, l16 = lane & 15;
-    const long unit = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // (crop, row pair)
-    if (unit >= (long)n_crops * PAIRS) return;
-    const long crop = unit / PAIRS;
-    const int yp = unit % PAIRS;
-    const _Float16* xin = in + crop * (H * W) * C;
-    _Float16* yout = out + crop * (H * W / 4) * C;
-    const unsigned char* bias = wts + NCT * KS * 1024;
-#pragma unroll 1
-    for (int half = 0; half < TPR; ++half) {
-        h8 b[2][KS];
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int p = (2 * yp + rr) * W + half * 16 + l16;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) b[rr][ks] = *reinterpret_cast<const h8*>(xin + (long)p * C + g * (C / 4) + 8 * ks);
-        }
-#pragma unroll 1
-        for (int ct = 0; ct < NCT; ++ct) {
-            const f4 bv = *reinterpret_cast<const f4*>(bias + (16 * ct + 4 * g) * 4);
-            f4 acc0 = bv, acc1 = bv;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const h8 a = *reinterpret_cast<const h8*>(wts + ((ct * KS + ks) * 64 + lane) * 16);
-                acc0 = BM_MFMA_F16_K32(a, b[0][ks], acc0);
-                acc1 = BM_MFMA_F16_K32(a, b[1][ks], acc1);
-            }
-            acc0 = relu4(acc0); acc1 = relu4(acc1);
-            f4 s;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = acc0[r] + acc1[r];
-                v += __shfl_xor(v, 1, 64);                 // horizontal neighbour (x, x^1)
-                s[r] = v * 0.25f;
-            }
-            if ((l16 & 1) == 0) {
-                const int po = yp * (W / 2) + half * 8 + (l16 >> 1);
-                *reinterpret_cast<h4*>(yout + (long)po * C + g * (C / 4) + 4 * ct) = to_h4(s);
-            }
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------

@@ -126,35 +126,29 @@ int emu_reid_forward(const float* blob, long n_floats, const float* crops, int n
     _Float16* cur = A.data();
     _Float16* nxt = B.data();
     int dump = 1;
-    auto run_block = [&](int bi, auto kernel, int stage, int cin, int down, int nthr, int lds_bytes, int P, int cout) {
-        (void)lds_bytes;
+    std::vector<_Float16> x1s((size_t)n * 2048 * 16);
+    _Float16* x1p = x1s.data();
+    // `trans` >= 0: the stage's transition is fused into the block (the product configuration); the block's own
+    // output then never exists in memory and its dump slot is skipped.
+    auto run_block = [&](int bi, auto kernel, int stage, int cin, int down, int nthr, int P, int cout, int trans) {
         const BlkPack bp = make_blk_pack(stage, cin, down);
-        std::vector<uint8_t> wb;
+        std::vector<uint8_t> wb, wt;
         pack_osblock(w, L.block[bi], bp, wb);
+        if (trans >= 0) pack_pointwise(w + L.trans_w[trans], w + L.trans_b[trans], cout, cout, wt);
         const _Float16* in = cur; _Float16* out = nxt; const unsigned char* wp = wb.data();
-        launch(n, 1, nthr, [=]() { kernel(in, out, wp, bp, nullptr); });
+        const unsigned char* wtp = trans >= 0 ? wt.data() : nullptr;
+        launch(n, 1, nthr, [=]() { kernel(in, out, wp, bp, nullptr, x1p, wtp); });
         std::swap(cur, nxt);
+        if (trans >= 0) { ++dump; P /= 4; }
         if (stage_out && stage_out[dump]) unpack_act(cur, stage_out[dump], (long)n * P, cout);
         ++dump;
     };
-    auto run_trans = [&](int si, auto kernel, int C, int H, int W) {
-        std::vector<uint8_t> wt;
-        pack_pointwise(w + L.trans_w[si], w + L.trans_b[si], C, C, wt);
-        const _Float16* in = cur; _Float16* out = nxt; const unsigned char* wp = wt.data();
-        const int units = n * (H / 2);
-        launch((units + 3) / 4, 1, 256, [=]() { kernel(in, out, wp, n, nullptr); });
-        std::swap(cur, nxt);
-        if (stage_out && stage_out[dump]) unpack_act(cur, stage_out[dump], (long)n * (H * W / 4), C);
-        ++dump;
-    };
-    run_block(0, k_osblock<0, 16, true>, 0, 16, 1, 64 * Geo<0>::NWAVES, Geo<0>::LDS_BYTES, 2048, 64);
-    run_block(1, k_osblock<0, 64, false>, 0, 64, 0, 64 * Geo<0>::NWAVES, Geo<0>::LDS_BYTES, 2048, 64);
-    run_trans(0, k_transition<64, 64, 32>, 64, 64, 32);
-    run_block(2, k_osblock<1, 64, true>, 1, 64, 1, 64 * Geo<1>::NWAVES, Geo<1>::LDS_BYTES, 512, 96);
-    run_block(3, k_osblock<1, 96, false>, 1, 96, 0, 64 * Geo<1>::NWAVES, Geo<1>::LDS_BYTES, 512, 96);
-    run_trans(1, k_transition<96, 32, 16>, 96, 32, 16);
-    run_block(4, k_osblock<2, 96, true>, 2, 96, 1, 64 * Geo<2>::NWAVES, Geo<2>::LDS_BYTES, 128, 128);
-    run_block(5, k_osblock<2, 128, false>, 2, 128, 0, 64 * Geo<2>::NWAVES, Geo<2>::LDS_BYTES, 128, 128);
+    run_block(0, k_osblock<0, 16, true, false>, 0, 16, 1, 64 * Geo<0>::NWAVES, 2048, 64, -1);
+    run_block(1, k_osblock<0, 64, false, true>, 0, 64, 0, 64 * Geo<0>::NWAVES, 2048, 64, 0);
+    run_block(2, k_osblock<1, 64, true, false>, 1, 64, 1, 64 * Geo<1>::NWAVES, 512, 96, -1);
+    run_block(3, k_osblock<1, 96, false, true>, 1, 96, 0, 64 * Geo<1>::NWAVES, 512, 96, 1);
+    run_block(4, k_osblock<2, 96, true, false>, 2, 96, 1, 64 * Geo<2>::NWAVES, 128, 128, -1);
+    run_block(5, k_osblock<2, 128, false, false>, 2, 128, 0, 64 * Geo<2>::NWAVES, 128, 128, -1);
     std::vector<uint8_t> w5, wfc;
     pack_pointwise(w + L.conv5_w, w + L.conv5_b, 128, 128, w5);
     pack_fc(w + L.fc_w, w + L.fc_b, 512, 128, wfc);

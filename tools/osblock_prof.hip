@@ -13,7 +13,7 @@
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-template <int STAGE, int CIN, bool DOWN>
+template <int STAGE, int CIN, bool DOWN, bool TRANS>
 static void run(const char* name, int n, int iters) {
     using G = bm::Geo<STAGE>;
     bm::BlkPack bp = bm::make_blk_pack(STAGE, CIN, DOWN);
@@ -28,11 +28,17 @@ static void run(const char* name, int n, int iters) {
     const size_t in_elems = (size_t)n * G::P * CIN, out_elems = (size_t)n * G::P * G::COUT;
     std::vector<unsigned short> x(in_elems);
     for (auto& v : x) { s = s * 1664525u + 1013904223u; v = bm::f32_to_f16_bits(((s >> 8) & 0xffff) / 65536.0f); }
-    unsigned char* d_w; _Float16 *d_in, *d_out;
+    unsigned char *d_w, *d_wt; _Float16 *d_in, *d_out, *d_x1;
     CK(hipMalloc(&d_w, bp.total)); CK(hipMalloc(&d_in, in_elems * 2)); CK(hipMalloc(&d_out, out_elems * 2));
+    CK(hipMalloc(&d_x1, (size_t)n * G::P * G::MIDP * 2));
+    const size_t wt_bytes = (size_t)(G::COUT / 16) * (G::COUT / 32) * 1024 + G::COUT * 4;     // transition fragments + bias
+    std::vector<unsigned short> wt(wt_bytes / 2);
+    for (auto& v : wt) { s = s * 1664525u + 1013904223u; v = bm::f32_to_f16_bits(((s >> 8) & 0xffff) / 65536.0f * 0.2f - 0.1f); }
+    for (int i = 0; i < G::COUT; ++i) reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(wt.data()) + wt_bytes - G::COUT * 4)[i] = 0.01f;
+    CK(hipMalloc(&d_wt, wt_bytes)); CK(hipMemcpy(d_wt, wt.data(), wt_bytes, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_w, w.data(), bp.total, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_in, x.data(), in_elems * 2, hipMemcpyHostToDevice));
-    auto kern = bm::k_osblock<STAGE, CIN, DOWN>;
+    auto kern = bm::k_osblock<STAGE, CIN, DOWN, TRANS>;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     unsigned long long zero[8] = {};
@@ -42,7 +48,7 @@ static void run(const char* name, int n, int iters) {
         CK(hipMemcpyToSymbol(HIP_SYMBOL(bm::g_osblock_prof), zero, sizeof(zero)));
 #endif
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(kern, dim3(n), dim3(64 * G::NWAVES), G::LDS_BYTES, 0, d_in, d_out, d_w, bp, (const int*)nullptr);
+        hipLaunchKernelGGL(kern, dim3(n), dim3(64 * G::NWAVES), G::LDS_BYTES, 0, d_in, d_out, d_w, bp, (const int*)nullptr, d_x1, (const unsigned char*)d_wt);
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         if (ms < best) best = ms;
@@ -51,8 +57,8 @@ static void run(const char* name, int n, int iters) {
 #ifdef BM_OSBLOCK_PROF
     CK(hipMemcpyFromSymbol(acc, HIP_SYMBOL(bm::g_osblock_prof), sizeof(acc)));
 #else
-    printf("[abl %d] %s: n=%d best %.3f ms\n", BM_ABLATE, name, n, best); (void)zero;
-    CK(hipFree(d_w)); CK(hipFree(d_in)); CK(hipFree(d_out));
+    printf("%s: n=%d best %.3f ms\n", name, n, best); (void)zero;
+    CK(hipFree(d_w)); CK(hipFree(d_in)); CK(hipFree(d_out)); CK(hipFree(d_x1)); CK(hipFree(d_wt));
     return;
 #endif
     const double waves = (double)n * G::NWAVES;
@@ -60,16 +66,16 @@ static void run(const char* name, int n, int iters) {
     double tot = 0; for (int k = 0; k < 8; ++k) tot += acc[k] / waves;
     printf("%s: n=%d best %.3f ms, waves/crop %d, lds %d B; cycles per wave: total %.0f\n", name, n, best, G::NWAVES, G::LDS_BYTES, tot);
     for (int k = 0; k < 8; ++k) printf("    %-9s %9.0f  %5.1f%%\n", PH[k], acc[k] / waves, 100.0 * acc[k] / waves / tot);
-    CK(hipFree(d_w)); CK(hipFree(d_in)); CK(hipFree(d_out));
+    CK(hipFree(d_w)); CK(hipFree(d_in)); CK(hipFree(d_out)); CK(hipFree(d_x1)); CK(hipFree(d_wt));
 }
 
 int main(int argc, char** argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 4096, iters = argc > 2 ? atoi(argv[2]) : 5;
-    run<0, 16, true>("osblock<0,16,down>", n, iters);
-    run<0, 64, false>("osblock<0,64>", n, iters);
-    run<1, 64, true>("osblock<1,64,down>", n, iters);
-    run<1, 96, false>("osblock<1,96>", n, iters);
-    run<2, 96, true>("osblock<2,96,down>", n, iters);
-    run<2, 128, false>("osblock<2,128>", n, iters);
+    run<0, 16, true, false>("osblock<0,16,down>", n, iters);
+    run<0, 64, false, true>("osblock<0,64,trans>", n, iters);
+    run<1, 64, true, false>("osblock<1,64,down>", n, iters);
+    run<1, 96, false, true>("osblock<1,96,trans>", n, iters);
+    run<2, 96, true, false>("osblock<2,96,down>", n, iters);
+    run<2, 128, false, false>("osblock<2,128>", n, iters);
     return 0;
 }
