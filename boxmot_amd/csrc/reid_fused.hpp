@@ -601,7 +601,7 @@ __global__ void __launch_bounds__(512) k_stem_fused(const _Float16* __restrict__
 constexpr int RING_ROWS = 40;
 constexpr int RING_ROW_BYTES = STEM_COLS * 8;                    // 136 px * RGBX fp16
 constexpr int SRC_STAGE_BYTES = 20 * 1024;
-constexpr int STEM2_LDS = RING_ROWS * RING_ROW_BYTES + SRC_STAGE_BYTES + 768 * 2;
+constexpr int STEM2_LDS = RING_ROWS * RING_ROW_BYTES + SRC_STAGE_BYTES + 768 * 2 + 256 * 8;   // ring, staging, LUT, y table
 
 __global__ void __launch_bounds__(512) k_stem_resize_fused(const uint8_t* const* frames, const int* crop_stream,
                                                            const float* boxes, int box_stride, int W, int H,
@@ -613,6 +613,7 @@ __global__ void __launch_bounds__(512) k_stem_resize_fused(const uint8_t* const*
     unsigned char* ring = lds;
     unsigned char* stage = lds + RING_ROWS * RING_ROW_BYTES;
     _Float16* lut_h = reinterpret_cast<_Float16*>(stage + SRC_STAGE_BYTES);
+    unsigned* ytab = reinterpret_cast<unsigned*>(stage + SRC_STAGE_BYTES + 768 * 2);   // [256]{s0 | s1 << 16, a0 | a1 << 16}
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l16 = lane & 15;
     const long crop = blockIdx.x;
     const uint8_t* frame = frames[crop_stream[crop]];
@@ -620,6 +621,11 @@ __global__ void __launch_bounds__(512) k_stem_resize_fused(const uint8_t* const*
     const long row_stride = (long)W * 3;
     _Float16* yout = out + crop * (64 * 32) * 16;
     for (int e = tid; e < 768; e += 512) lut_h[e] = (_Float16)lut[e];
+    if (tid < REID_IN_H) {      // vertical taps of every resized row, once per crop
+        const ResizeAxis ay = resize_axis_y(tid, REID_IN_H, r.h > 0 ? r.h : 1);
+        ytab[2 * tid] = (unsigned)ay.s0 | ((unsigned)ay.s1 << 16);
+        ytab[2 * tid + 1] = (unsigned)ay.a0 | ((unsigned)ay.a1 << 16);
+    }
     for (int e = tid * 8; e < RING_ROWS * RING_ROW_BYTES; e += 512 * 8) *reinterpret_cast<unsigned long long*>(ring + e) = 0ull;
     h8 a[7];
 #pragma unroll
@@ -666,6 +672,61 @@ __global__ void __launch_bounds__(512) k_stem_resize_fused(const uint8_t* const*
         }
         __syncthreads();
         // ---- 2. resample the new rows into the ring ----
+        if (staged && !identity && !area2) {
+            // Bilinear fast path.  A thread owns one output column and a run of consecutive rows: the horizontal
+            // interpolations S0/S1 of the two source rows are kept while the vertical tap pair is unchanged (an
+            // upscaled crop repeats it for several rows) and S1 becomes S0 when the pair advances by one row.
+            // A pixel's three bytes come from one 8-byte LDS read + funnel shift at any byte alignment.
+            const int nrows = pr1 - pr0, run = (nrows + 3) >> 2;
+            const unsigned abase = (unsigned)reinterpret_cast<uintptr_t>(frame + (long)r.y1 * row_stride + (long)r.x1 * 3);
+            const unsigned rs = (unsigned)row_stride;
+            const int xs0 = ax.s0 * 3, xs1 = ax.s1 * 3;
+            auto hrow = [&](int sy, int (&S)[3]) {
+                const int o = (sy - sy_lo) * pitch + (int)((abase + (unsigned)sy * rs) & 3u);
+                unsigned w[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int A = o + (k ? xs1 : xs0);
+                    const unsigned* q = reinterpret_cast<const unsigned*>(stage + (A & ~3));
+                    const unsigned long long two = ((unsigned long long)q[1] << 32) | q[0];
+                    w[k] = (unsigned)(two >> (8 * (A & 3)));
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c)         // output channel c (RGB) = source byte 2 - c (BGR)
+                    S[c] = (int)((w[0] >> (8 * (2 - c))) & 255u) * ax.a0 + (int)((w[1] >> (8 * (2 - c))) & 255u) * ax.a1;
+            };
+            int S0[3] = {0, 0, 0}, S1[3] = {0, 0, 0}, have0 = -1, have1 = -1;
+            for (int k = 0; k < run; ++k) {
+                const int pr = pr0 + rp * run + k;
+                if (pr >= pr1) break;
+                const int dy = pr - 3;
+                h4 px = h4{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+                if (dy >= 0 && dy < REID_IN_H) {
+                    const unsigned ys = ytab[2 * dy], ya = ytab[2 * dy + 1];
+                    const int s0 = (int)(ys & 0xffffu), s1 = (int)(ys >> 16), a0 = (int)(ya & 0xffffu), a1 = (int)(ya >> 16);
+                    if (s0 != have0) {
+                        if (s0 == have1) {
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) S0[c] = S1[c];
+                        } else hrow(s0, S0);
+                        have0 = s0;
+                    }
+                    if (s1 != have1) {
+                        if (s1 == s0) {
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) S1[c] = S0[c];
+                        } else hrow(s1, S1);
+                        have1 = s1;
+                    }
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const int v = (((a0 * (S0[c] >> 4)) >> 16) + ((a1 * (S1[c] >> 4)) >> 16) + 2) >> 2;
+                        px[c] = lut_h[c * 256 + v];
+                    }
+                }
+                *reinterpret_cast<h4*>(ring + (pr % RING_ROWS) * RING_ROW_BYTES + (dx + 3) * 8) = px;
+            }
+        } else
         for (int pr = pr0 + rp; pr < pr1; pr += 4) {
             const int dy = pr - 3;
             h4 px = h4{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
@@ -682,16 +743,10 @@ __global__ void __launch_bounds__(512) k_stem_resize_fused(const uint8_t* const*
                             return stage + (sy - sy_lo) * pitch + (int)(addr & 3) + (2 - c);
                         };
                         if (identity) v = row_ptr(dy)[dx * 3];
-                        else if (area2) {
+                        else {                      // area2: exact 2x shrink -> box filter
                             const unsigned char* p0 = row_ptr(2 * dy) + 6 * dx;
                             const unsigned char* p1 = row_ptr(2 * dy + 1) + 6 * dx;
                             v = (p0[0] + p0[3] + p1[0] + p1[3] + 2) >> 2;
-                        } else {
-                            const unsigned char* r0 = row_ptr(ay.s0);
-                            const unsigned char* r1 = row_ptr(ay.s1);
-                            const int S0 = r0[ax.s0 * 3] * ax.a0 + r0[ax.s1 * 3] * ax.a1;
-                            const int S1 = r1[ax.s0 * 3] * ax.a0 + r1[ax.s1 * 3] * ax.a1;
-                            v = (((ay.a0 * (S0 >> 4)) >> 16) + ((ay.a1 * (S1 >> 4)) >> 16) + 2) >> 2;
                         }
                     } else {
                         v = resize_sample(frame + (long)r.y1 * row_stride + r.x1 * 3, row_stride, r, ax, ay, dy, dx, 2 - c,

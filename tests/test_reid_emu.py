@@ -78,7 +78,7 @@ def test_fused_crop_stem_kernel_equals_separate_kernels_emulated():
     wd, hd = 641, 480
     img = np.random.default_rng(5).integers(0, 255, (hd, wd, 3), dtype=np.uint8)
     boxes = np.array([[30.2, 40.7, 90.1, 200.3], [-20, -10, 40, 60], [100, 100, 100, 150], [10, 10, 138, 266],
-                      [0, 0, 641, 480], [600.4, 430.2, 700, 500]], dtype=np.float32)
+                      [0, 0, 641, 480], [600.4, 430.2, 700, 500], [50, 20, 200, 330], [300, 5, 420, 300]], dtype=np.float32)
     n = len(boxes)
     crops = get_crops(boxes, img)
     nhwc = np.ascontiguousarray(np.transpose(crops, (0, 2, 3, 1)))
