@@ -23,6 +23,14 @@
 // makes a value opaque to the optimiser (defeats loop-invariant hoisting of the loads that depend on it)
 #define BM_OPAQUE_U32(x) asm volatile("" : "+v"(x))
 #endif
+#ifndef BM_ROW_SHL1_F32
+// neighbour exchange inside each row of 16 lanes as DPP modifiers (no LDS crossbar traffic): the value of
+// lane+1 / lane-1 (0 where the row has no such lane) / lane-1 with wrap-around
+#define BM_DPP_F32(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (float)(v)), ctrl, 0xf, 0xf, true))
+#define BM_ROW_SHL1_F32(v) BM_DPP_F32(v, 0x101)
+#define BM_ROW_SHR1_F32(v) BM_DPP_F32(v, 0x111)
+#define BM_ROW_ROR1_F32(v) BM_DPP_F32(v, 0x121)
+#endif
 #ifndef BM_CLOCK
 #define BM_CLOCK() wall_clock64()
 #endif

@@ -566,14 +566,12 @@ __global__ void __launch_bounds__(512) k_stem_fused(const _Float16* __restrict__
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             f4 m = v[t];
-            const int src_r = (lane & 48) | ((l16 + 1) & 15);     // right neighbour, same tile (even lanes only need l16 <= 14)
-            const int src_l = (lane & 48) | ((l16 + 15) & 15);    // left neighbour (lane 0 wraps to lane 15: fixed below)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float right = __shfl(v[t][r], src_r, 64);
-                float left = __shfl(v[t][r], src_l, 64);
-                const float left_prev_tile = t > 0 ? __shfl(v[t > 0 ? t - 1 : 0][r], src_l, 64) : 0.f;
-                if (l16 == 0) left = left_prev_tile;
+            for (int r = 0; r < 4; ++r) {      // all values are >= 0 (post-ReLU), so a missing neighbour reads as 0
+                const float right = BM_ROW_SHL1_F32(v[t][r]);
+                float left = BM_ROW_SHR1_F32(v[t][r]);
+                const float left_prev_tile = BM_ROW_ROR1_F32(v[t > 0 ? t - 1 : 0][r]);
+                if (l16 == 0) left = t > 0 ? left_prev_tile : 0.f;
                 float mm = m[r] > right ? m[r] : right;
                 m[r] = mm > left ? mm : left;
             }
@@ -779,13 +777,11 @@ __global__ void __launch_bounds__(512) k_stem_resize_fused(const uint8_t* const*
                 vm = max4(vm, relu4(acc));
             }
             f4 m = vm;
-            const int src_r = (lane & 48) | ((l16 + 1) & 15);
-            const int src_l = (lane & 48) | ((l16 + 15) & 15);
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const float right = __shfl(vm[rr], src_r, 64);
-                float left = __shfl(vm[rr], src_l, 64);
-                const float left_prev = __shfl(vprev[rr], src_l, 64);
+            for (int rr = 0; rr < 4; ++rr) {   // all values are >= 0 (post-ReLU), so a missing neighbour reads as 0
+                const float right = BM_ROW_SHL1_F32(vm[rr]);
+                float left = BM_ROW_SHR1_F32(vm[rr]);
+                const float left_prev = BM_ROW_ROR1_F32(vprev[rr]);
                 if (l16 == 0) left = t > 0 ? left_prev : 0.f;
                 const float mm = m[rr] > right ? m[rr] : right;
                 m[rr] = mm > left ? mm : left;

@@ -97,6 +97,14 @@ inline double __dmul_rn(double a, double b) { return a * b; }
 #define BM_EXPF(x) expf(x)
 #define BM_SCHED_FENCE() ((void)0)
 #define BM_OPAQUE_U32(x) ((void)0)
+inline float emu_row_shift(float v, int d, bool rotate) {
+    const int lane = threadIdx.x % EMU_WAVE, src16 = (lane & 15) + d;
+    const float r = emu_exchange(v, (lane & 48) | (src16 & 15));
+    return (rotate || (src16 >= 0 && src16 < 16)) ? r : 0.f;
+}
+#define BM_ROW_SHL1_F32(v) emu_row_shift(v, 1, false)
+#define BM_ROW_SHR1_F32(v) emu_row_shift(v, -1, false)
+#define BM_ROW_ROR1_F32(v) emu_row_shift(v, -1, true)
 extern unsigned char* g_emu_dynamic_lds;
 inline float sqrtf_emu(float x) { return std::sqrt(x); }
 

@@ -69,8 +69,49 @@ static void run(const char* name, int n, int iters) {
     CK(hipFree(d_w)); CK(hipFree(d_in)); CK(hipFree(d_out)); CK(hipFree(d_x1)); CK(hipFree(d_wt));
 }
 
+// stem: one 1080p frame of noise, boxes of the bench scenario's size (35-70 px wide and tall)
+static void run_stem(int n, int iters) {
+    const int W = 1920, H = 1080;
+    std::vector<unsigned char> frame((size_t)W * H * 3);
+    unsigned s = 777u;
+    for (auto& v : frame) { s = s * 1664525u + 1013904223u; v = (unsigned char)(s >> 24); }
+    std::vector<float> boxes((size_t)n * 4), lut(768);
+    for (int i = 0; i < n; ++i) {
+        s = s * 1664525u + 1013904223u; const float x = 10.f + (s >> 8) % 1800;
+        s = s * 1664525u + 1013904223u; const float y = 10.f + (s >> 8) % 980;
+        s = s * 1664525u + 1013904223u; const float w = 35.f + (s >> 8) % 36;
+        s = s * 1664525u + 1013904223u; const float h = 36.f + (s >> 8) % 37;
+        boxes[4 * i] = x + 0.3f; boxes[4 * i + 1] = y + 0.6f; boxes[4 * i + 2] = x + w; boxes[4 * i + 3] = y + h;
+    }
+    for (int i = 0; i < 768; ++i) lut[i] = ((i & 255) / 255.f - 0.45f) / 0.225f;
+    std::vector<unsigned short> w(7 * 512 + 32);
+    for (auto& v : w) { s = s * 1664525u + 1013904223u; v = bm::f32_to_f16_bits(((s >> 8) & 0xffff) / 65536.0f * 0.2f - 0.1f); }
+    unsigned char *d_frame, *d_w; const unsigned char** d_frames; int* d_cs; float *d_boxes, *d_lut; _Float16* d_out;
+    CK(hipMalloc(&d_frame, frame.size())); CK(hipMemcpy(d_frame, frame.data(), frame.size(), hipMemcpyHostToDevice));
+    CK(hipMalloc(&d_frames, sizeof(void*))); CK(hipMemcpy(d_frames, &d_frame, sizeof(void*), hipMemcpyHostToDevice));
+    CK(hipMalloc(&d_cs, n * 4)); CK(hipMemset(d_cs, 0, n * 4));
+    CK(hipMalloc(&d_boxes, boxes.size() * 4)); CK(hipMemcpy(d_boxes, boxes.data(), boxes.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&d_lut, 768 * 4)); CK(hipMemcpy(d_lut, lut.data(), 768 * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&d_w, w.size() * 2)); CK(hipMemcpy(d_w, w.data(), w.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMalloc(&d_out, (size_t)n * 2048 * 16 * 2));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(bm::k_stem_resize_fused), hipFuncAttributeMaxDynamicSharedMemorySize, bm::STEM2_LDS));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float best = 1e9f;
+    for (int it = 0; it < iters; ++it) {
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(bm::k_stem_resize_fused, dim3(n), dim3(512), bm::STEM2_LDS, 0, (const uint8_t* const*)d_frames, (const int*)d_cs,
+                           (const float*)d_boxes, 4, W, H, (const float*)d_lut, d_out, (const unsigned char*)d_w, (const int*)nullptr);
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    printf("stem_resize_fused: n=%d best %.3f ms\n", n, best);
+}
+
 int main(int argc, char** argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 4096, iters = argc > 2 ? atoi(argv[2]) : 5;
+    run_stem(n, iters);
+    if (argc > 3) return 0;
     run<0, 16, true, false>("osblock<0,16,down>", n, iters);
     run<0, 64, false, true>("osblock<0,64,trans>", n, iters);
     run<1, 64, true, false>("osblock<1,64,down>", n, iters);
