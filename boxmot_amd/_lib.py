@@ -62,6 +62,7 @@ SIGNATURES = {
                                               c_int_p, c_int_p]),
     "boxmot_hip_botsort_update_batch": (_I, [_VP, _I, _VP, _VP, _VP, _I, _VP, _I, _I, _I, _VP, _I, _VP]),
     "boxmot_hip_botsort_step_device": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP]),
+    "boxmot_hip_botsort_set_warp": (_I, [_VP, _I, _VP]),
     "boxmot_hip_botsort_synchronize": (_I, [_VP]),
     "boxmot_hip_botsort_stream": (_VP, [_VP]),
     "boxmot_hip_botsort_timer_start": (_I, [_VP]),

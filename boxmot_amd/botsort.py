@@ -7,8 +7,11 @@ returns the reference's rows; every per-frame computation runs in HIP kernels
 through the C ABI (include/boxmot_hip.h).  Mirrors the shape of the reference's
 ctypes wrapper for its native backend (boxmot/native/trackers/botsort.py:94-274).
 
-Not implemented, and rejected loudly rather than approximated: camera-motion
-compensation (construct with ``use_cmc=False``), OBB detections, masks.
+Camera-motion compensation: applying a warp to the track state runs on the device
+(STrack.multi_gmc); *estimating* it from images (the reference's ECC / SOF objects,
+boxmot/motion/cmc) is not implemented here, so ``use_cmc=True`` needs a ``cmc=`` object
+exposing the reference's ``apply(img, dets) -> 2x3 warp`` (e.g. the reference's own).
+Not implemented, and rejected loudly rather than approximated: OBB detections, masks.
 """
 from __future__ import annotations
 
@@ -50,13 +53,15 @@ class BotSort(BaseTracker):
         max_tracks: int = 1024,
         max_dets: int = 256,
         emb_dim: int | None = None,
+        cmc: Any | None = None,
         **kwargs: Any,
     ):
         super().__init__(_tracker_name="BotSort", **kwargs)
-        if use_cmc:
+        if use_cmc and cmc is None:
             raise NotImplementedError(
-                "boxmot_amd.BotSort: camera-motion compensation is not implemented on the HIP path; "
-                "construct with use_cmc=False (the reference default is use_cmc=True, cmc_method='ecc')."
+                "boxmot_amd.BotSort: camera-motion estimation (cmc_method=%r) is not implemented on the HIP path; "
+                "construct with use_cmc=False, or pass cmc=<object with apply(img, dets) -> 2x3 warp> "
+                "(the reference default is use_cmc=True, cmc_method='ecc')." % (cmc_method,)
             )
         self.track_high_thresh = track_high_thresh
         self.track_low_thresh = track_low_thresh
@@ -71,7 +76,7 @@ class BotSort(BaseTracker):
         self.unconfirmed_emb_scale = unconfirmed_emb_scale
         self.with_reid = with_reid
         self.model = reid_model if with_reid else None
-        self.cmc = None
+        self.cmc = cmc if use_cmc else None
         self.fuse_first_associate = fuse_first_associate
         self._lib = _lib.load()
         self._emb_dim = emb_dim or getattr(self.model, "feature_dim", None) or 512
@@ -123,6 +128,14 @@ class BotSort(BaseTracker):
             if n and feats.shape[1] != self._emb_dim:
                 raise ValueError(f"embedding width {feats.shape[1]} != emb_dim {self._emb_dim}")
         img_arr = np.ascontiguousarray(img)
+        if self.cmc is not None:
+            # botsort.py:142: the estimator sees the detection table incl. the index column; the warp is applied
+            # on the device after the Kalman prediction (boxmot_hip_botsort_set_warp)
+            table = np.hstack([det_arr, np.arange(n, dtype=np.int32).reshape(-1, 1)]) if n else np.empty((0, 7), det_arr.dtype)
+            warp = np.ascontiguousarray(np.asarray(self.cmc.apply(img, table), dtype=np.float64)[:2, :3])
+            if warp.shape != (2, 3):
+                raise ValueError(f"cmc.apply returned shape {warp.shape}, expected (2, 3)")
+            _lib.check(self._lib.boxmot_hip_botsort_set_warp(self._handle, 0, warp.ctypes.data))
         out = np.empty((max(n, 1), 9), dtype=np.float32)
         out_rows = ctypes.c_int(0)
         out_is_obb = ctypes.c_int(0)

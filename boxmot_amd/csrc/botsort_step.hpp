@@ -141,6 +141,30 @@ __device__ inline void kf_predict_wave(double* kf, bool zero_size_vel, int lane)
     if (i == 0) kf[j] = mnew;
 }
 
+// STrack.multi_gmc for one track (botsort_track.py:117-132): mean <- kron(I4, R) mean (+ t on x, y),
+// cov <- R8 cov R8^T with R8 = kron(I4, R); W = [r00 r01 tx; r10 r11 ty].  Every element is a sum of two
+// products; numpy evaluates the matrix-vector product as mul, mul, add and the two 8x8 matrix products as
+// fma(b_hi, a_hi, b_lo * a_lo) (k ascending, OpenBLAS dgemm micro-kernel) -- reproduced here so the fp64 state
+// follows the NumPy reference to the last bit on such hosts (the tests accept 1e-9 relative).
+__device__ inline void kf_warp_wave(double* kf, const double* W, int lane) {
+    const int i = lane >> 3, j = lane & 7;
+    const double m = kf[j];
+    const double p = kf[KF_DIM + lane];
+    const double mp = __shfl(m, (lane & ~7) | (j ^ 1), WAVE);
+    const double m0 = (j & 1) ? mp : m, m1 = (j & 1) ? m : mp;
+    double mn = W[(j & 1) * 3 + 0] * m0 + W[(j & 1) * 3 + 1] * m1;
+    if (j < 2) mn = mn + W[j * 3 + 2];
+    const double pp = __shfl(p, lane ^ 8, WAVE);                      // P[i ^ 1][j]
+    const double p0 = (i & 1) ? pp : p, p1 = (i & 1) ? p : pp;
+    const double a = fma(W[(i & 1) * 3 + 1], p1, W[(i & 1) * 3 + 0] * p0);   // (R8 P)[i][j]
+    const double ap = __shfl(a, lane ^ 1, WAVE);                      // (R8 P)[i][j ^ 1]
+    const double a0 = (j & 1) ? ap : a, a1 = (j & 1) ? a : ap;
+    const double cnew = fma(a1, W[(j & 1) * 3 + 1], a0 * W[(j & 1) * 3 + 0]);
+    const double cn = __shfl(cnew, lane, WAVE);                       // wave-wide dependency: all loads precede the stores
+    kf[KF_DIM + lane] = cn;
+    if (i == 0) kf[j] = mn;
+}
+
 // KalmanFilterXYWH.update for one track with measurement z (fp32 xywh);
 // base.py:286-355 (confidence = 0: BoT-SORT never passes it, botsort_track.py:269-271).
 __device__ inline void kf_update_wave(double* kf, const float* z, int lane) {
@@ -735,6 +759,18 @@ __device__ inline void botsort_step_stream(const BotSortStepArgs& args, int s, i
         }
     }
     __syncthreads();
+    // ---- camera-motion warp of the pool and the unconfirmed tracks (botsort.py:134-145, :300-303) ----
+    if (args.warp_flag && args.warp_flag[s]) {
+        const double* W = args.warp + (long)s * 6;
+        for (int base = 0; base < n_pool + n_unconf; base += c.nwaves) {
+            const int k = base + c.wave;
+            if (k < n_pool + n_unconf) {
+                const int slot = k < n_pool ? v.pool[k] : v.unconf[k - n_pool];
+                kf_warp_wave(v.kf + (long)slot * KF_STRIDE, W, c.lane);
+            }
+        }
+        __syncthreads();
+    }
 
     tick();
     // ---- first association (botsort.py:285-333) ----

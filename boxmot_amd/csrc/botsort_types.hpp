@@ -124,6 +124,8 @@ struct BotSortStepArgs {
     const int* frame_count_set;  // [S] value to set before the step (per_class), or nullptr
     float* out;               // [S][max_dets][8]
     int* out_n;               // [S]
+    const double* warp;       // [S][6] camera-motion warp (2x3 row-major) applied after prediction, or nullptr
+    const int* warp_flag;     // [S] non-zero: apply warp[s] in this step
     int stream_base;          // workgroup b advances stream (stream_base + b)
     long long* phase_clock;   // optional [16] shader-clock stamps of stream stream_base's phases (profiling), or nullptr
 };

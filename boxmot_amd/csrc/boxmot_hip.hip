@@ -114,8 +114,11 @@ struct BoxMOTHipBotSort {
     int* d_out_n = nullptr;
     int* d_list_sel = nullptr;
     int* d_fc_set = nullptr;
+    double* d_warp = nullptr;      // [S][6] camera-motion warps for the next update of each stream
+    int* d_warp_flag = nullptr;
     std::vector<float> h_dets, h_out;
-    std::vector<int> h_ndets, h_out_n, h_list_sel, h_fc_set;
+    std::vector<int> h_ndets, h_out_n, h_list_sel, h_fc_set, h_warp_flag;
+    std::vector<double> h_warp;
     // frames owned by the handle (host API)
     std::vector<uint8_t*> frame_bufs;
     size_t frame_bytes = 0;
@@ -182,7 +185,8 @@ void zero_state(BoxMOTHipBotSort* h) {
 void build(BoxMOTHipBotSort* h) {
     const BoxMOTHipBotSortConfig& c = h->cfg;
     if (c.cmc_method && c.cmc_method[0] && std::strcmp(c.cmc_method, "none") != 0)
-        throw std::runtime_error("boxmot_hip: camera-motion compensation is not implemented; pass cmc_method=none (use_cmc=False)");
+        throw std::runtime_error("boxmot_hip: camera-motion estimation (ecc/sof/...) is not implemented; pass cmc_method=none "
+                                 "and supply the warp per frame with boxmot_hip_botsort_set_warp");
     if (c.reid_preprocess && c.reid_preprocess[0] && std::strcmp(c.reid_preprocess, "resize") != 0)
         throw std::runtime_error("boxmot_hip: only the 'resize' ReID preprocess is implemented");
     if (c.n_streams < 1 || c.max_tracks < 8 || c.max_dets < 4 || c.emb_dim < 1 || c.n_class_lists < 1)
@@ -211,6 +215,9 @@ void build(BoxMOTHipBotSort* h) {
     h->d_out_n = zalloc<int>(S, o);
     h->d_list_sel = zalloc<int>(S, o);
     h->d_fc_set = zalloc<int>(S, o);
+    h->d_warp = zalloc<double>(S * 6, o);
+    h->d_warp_flag = zalloc<int>(S, o);
+    h->h_warp.assign(S * 6, 0.0); h->h_warp_flag.assign(S, 0);
     h->h_dets.assign(S * nd * bm::DET_COLS, 0.f);
     h->h_out.assign(S * nd * bm::OUT_COLS, 0.f);
     h->h_ndets.assign(S, 0); h->h_out_n.assign(S, 0); h->h_list_sel.assign(S, 0); h->h_fc_set.assign(S, 0);
@@ -235,9 +242,10 @@ void build(BoxMOTHipBotSort* h) {
 }
 
 void launch_step(BoxMOTHipBotSort* h, int s0, int n_streams, const float* d_dets, const int* d_ndets, const float* d_embs,
-                 const int* d_list_sel, const int* d_fc_set, float* d_out, int* d_out_n) {
+                 const int* d_list_sel, const int* d_fc_set, float* d_out, int* d_out_n, bool with_warp = false) {
     bm::BotSortStepArgs a = h->args;
     a.dets = d_dets; a.n_dets = d_ndets; a.embs = d_embs; a.list_sel = d_list_sel; a.frame_count_set = d_fc_set;
+    a.warp = with_warp ? h->d_warp : nullptr; a.warp_flag = with_warp ? h->d_warp_flag : nullptr;
     a.out = d_out; a.out_n = d_out_n; a.stream_base = s0; a.phase_clock = h->d_phase_clock;
     hipLaunchKernelGGL((botsort_step_kernel<STEP_THREADS>), dim3(n_streams), dim3(STEP_THREADS),
                        (size_t)bm::lap_lds_bytes(h->cap, h->nd), h->stream, a);
@@ -332,6 +340,12 @@ void host_update(BoxMOTHipBotSort* h, int s0, int n, const StreamIn* in, int det
     BM_HIP(hipMemcpyAsync(h->d_ndets + s0, h->h_ndets.data() + s0, n * 4, hipMemcpyHostToDevice, h->stream));
     BM_HIP(hipMemcpyAsync(h->d_list_sel + s0, h->h_list_sel.data() + s0, n * 4, hipMemcpyHostToDevice, h->stream));
     if (fc_set) BM_HIP(hipMemcpyAsync(h->d_fc_set + s0, h->h_fc_set.data() + s0, n * 4, hipMemcpyHostToDevice, h->stream));
+    bool any_warp = false;
+    for (int k = 0; k < n; ++k) any_warp = any_warp || h->h_warp_flag[s0 + k] != 0;
+    if (any_warp) {     // warps set with boxmot_hip_botsort_set_warp are consumed by this update
+        BM_HIP(hipMemcpyAsync(h->d_warp + (size_t)s0 * 6, h->h_warp.data() + (size_t)s0 * 6, (size_t)n * 6 * 8, hipMemcpyHostToDevice, h->stream));
+        BM_HIP(hipMemcpyAsync(h->d_warp_flag + s0, h->h_warp_flag.data() + s0, n * 4, hipMemcpyHostToDevice, h->stream));
+    }
     float* d_embs = h->d_embs + (size_t)s0 * nd * dim;
     for (int k = 0; k < n; ++k)
         if (in[k].embs && in[k].det_rows)
@@ -347,12 +361,13 @@ void host_update(BoxMOTHipBotSort* h, int s0, int n, const StreamIn* in, int det
     }
     BM_HIP(hipEventRecord(h->ev[0], h->stream));
     launch_step(h, s0, n, h->d_dets, h->d_ndets, h->cfg.with_reid ? h->d_embs : nullptr, h->d_list_sel,
-                fc_set ? h->d_fc_set : nullptr, h->d_out, h->d_out_n);
+                fc_set ? h->d_fc_set : nullptr, h->d_out, h->d_out_n, any_warp);
     BM_HIP(hipEventRecord(h->ev[1], h->stream));
     BM_HIP(hipMemcpyAsync(h->h_out_n.data(), h->d_out_n + s0, n * 4, hipMemcpyDeviceToHost, h->stream));
     BM_HIP(hipMemcpyAsync(h->h_out.data(), h->d_out + (size_t)s0 * nd * bm::OUT_COLS, (size_t)n * nd * bm::OUT_COLS * 4,
                           hipMemcpyDeviceToHost, h->stream));
     BM_HIP(hipStreamSynchronize(h->stream));
+    for (int k = 0; k < n; ++k) h->h_warp_flag[s0 + k] = 0;
     float ms = 0;
     if (hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) == hipSuccess) h->last_track_ms = ms;
     if (need_reid) h->reid->last_times(h->last_reid_pre_ms, h->last_reid_proc_ms);
@@ -488,6 +503,19 @@ int boxmot_hip_botsort_step_device(BoxMOTHipBotSort* handle, const float* d_dets
         }
         launch_step(handle, 0, handle->S, d_dets, d_det_rows, handle->cfg.with_reid ? embs : nullptr, nullptr, nullptr,
                     d_out, d_out_rows);
+    });
+}
+
+int boxmot_hip_botsort_set_warp(BoxMOTHipBotSort* handle, int stream, const double* warp_2x3) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip BoT-SORT handle is null.");
+        if (stream < 0 || stream >= handle->S) throw std::runtime_error("boxmot_hip: stream index out of range");
+        if (warp_2x3 == nullptr) { handle->h_warp_flag[stream] = 0; return; }
+        for (int k = 0; k < 6; ++k) {
+            if (!std::isfinite(warp_2x3[k])) throw std::runtime_error("boxmot_hip: camera-motion warp has non-finite entries");
+            handle->h_warp[(size_t)stream * 6 + k] = warp_2x3[k];
+        }
+        handle->h_warp_flag[stream] = 1;
     });
 }
 

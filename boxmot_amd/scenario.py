@@ -135,3 +135,20 @@ def stress_frames(n_frames: int, seed: int = 7, width: int = 640, height: int = 
         order = rng.permutation(len(idx))
         out.append((dets[order].astype(np.float32), e[order].astype(np.float32)))
     return out
+
+
+def camera_warps(n_frames: int, seed: int = 5, every: int = 1):
+    """A seeded schedule of small 2x3 fp32 camera-motion warps (rotation/scale jitter ~1e-2, translation
+    ~3 px), the kind ``cmc.apply`` returns in the reference (motion/cmc/ecc.py:45-96).  Frames where
+    ``t % every != 0`` get the identity."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for t in range(n_frames):
+        H = np.eye(2, 3, dtype=np.float32)
+        a = rng.normal(0.0, 0.01, (2, 2)).astype(np.float32)
+        tr = rng.normal(0.0, 3.0, 2).astype(np.float32)
+        if t % every == 0:
+            H[:, :2] += a
+            H[:, 2] = tr
+        out.append(H)
+    return out

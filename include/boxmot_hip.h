@@ -91,6 +91,13 @@ int boxmot_hip_botsort_update_stream(
     float* out_tracks, int out_capacity_rows, int out_cols,
     int* out_rows, int* out_is_obb);
 
+/* Camera-motion compensation, application half (STrack.multi_gmc, botsort_track.py:117-132; called from
+ * BotSort._apply_aabb_camera_motion_compensation, botsort.py:134-145).  `warp_2x3` = the row-major 2x3 matrix
+ * the reference's cmc.apply(img, dets) returns ([r00 r01 tx; r10 r11 ty]); it is applied to the predicted pool and
+ * to the unconfirmed tracks in the NEXT update / update_stream / update_batch of `stream` and then dropped.
+ * NULL clears a pending warp.  Estimating the warp from images (ECC / SOF) is not part of this library. */
+int boxmot_hip_botsort_set_warp(BoxMOTHipBotSort* handle, int stream, const double* warp_2x3);
+
 /* One frame for each of the first n_streams streams in one launch set.
  * dets[s] -> (det_rows[s], 6) fp32; embs[s] -> (det_rows[s], emb_cols) fp32 or embs == NULL;
  * images[s] -> (rows, cols, 3) uint8 BGR or NULL to keep the previously uploaded frame;

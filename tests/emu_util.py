@@ -45,7 +45,11 @@ class EmuBotSort:
         self.cap, self.nd, self.dim = cap, nd, dim
         self.h = self.lib.emu_create(cd.ctypes.data, ci.ctypes.data, cap, nd, dim)
 
-    def update(self, dets, embs=None):
+    def update(self, dets, embs=None, warp=None):
+        if warp is not None:
+            w = np.ascontiguousarray(warp, dtype=np.float64).reshape(6)
+            self.lib.emu_set_warp.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+            self.lib.emu_set_warp(self.h, w.ctypes.data)
         dets = np.ascontiguousarray(dets, dtype=np.float32).reshape(-1, 6)
         n = len(dets)
         e = None if embs is None else np.ascontiguousarray(embs, dtype=np.float32)

@@ -21,7 +21,7 @@ ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
 
 from boxmot_amd.reid_weights import random_osnet_state_dict  # noqa: E402
-from boxmot_amd.scenario import Scenario, stress_frames  # noqa: E402
+from boxmot_amd.scenario import Scenario, camera_warps, stress_frames  # noqa: E402
 from boxmot_amd.tracker_zoo import BOTSORT_YAML_DEFAULTS  # noqa: E402
 from oracle import ref_harness  # noqa: E402
 
@@ -41,6 +41,42 @@ REID_BOXES = np.array([
     [100.0, 100.0, 100.0, 150.0], [400.0, 300.0, 656.0, 812.0], [10.5, 10.5, 138.5, 266.5],
     [700.49, 200.5, 752.51, 254.5], [5.0, 5.0, 8.0, 9.0],
 ], dtype=np.float32)
+
+
+class ScheduledCMC:
+    """Stands where the reference's ECC/SOF object stands (botsort.py:116-117): returns a scheduled warp."""
+
+    def __init__(self, warps):
+        self.warps, self.k = warps, 0
+
+    def apply(self, img, dets):
+        self.k += 1
+        return self.warps[self.k - 1]
+
+
+def warp_golden():
+    """botsort_warp_golden.npz: the reference BotSort driven with a scheduled camera-motion warp."""
+    logging.disable(logging.CRITICAL)
+    BotSort = ref_harness.load_botsort()
+    out = {}
+    for name, seed, kw in (("warp_default", 7, {}), ("warp_yaml", 11, YAML)):
+        frames = stress_frames(120, seed=seed)
+        img = np.zeros((480, 640, 3), dtype=np.uint8)
+        trk = BotSort(reid_model=None, with_reid=True, use_cmc=False, **kw)
+        trk.cmc = ScheduledCMC(camera_warps(len(frames), seed=seed))
+        rows, counts = [], []
+        for dets, embs in frames:
+            r = np.asarray(trk.update(dets.copy(), img, embs.copy()), dtype=np.float32).reshape(-1, 8)
+            rows.append(r)
+            counts.append(len(r))
+        out[name + "_rows"] = np.concatenate(rows, 0)
+        out[name + "_counts"] = np.array(counts, dtype=np.int32)
+        act = trk.active_tracks
+        out[name + "_final_mean"] = np.array([t.mean for t in act], dtype=np.float64).reshape(len(act), 8)
+        out[name + "_final_cov"] = np.array([t.covariance for t in act], dtype=np.float64).reshape(len(act), 8, 8)
+        out[name + "_final_ids"] = np.array([t.id for t in act], dtype=np.int64)
+        print(name, "rows", sum(counts))
+    np.savez_compressed(OUT / "botsort_warp_golden.npz", **out)
 
 
 def main():
@@ -84,4 +120,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "warp":
+        warp_golden()
+    else:
+        main()
+        warp_golden()

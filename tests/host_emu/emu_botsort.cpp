@@ -31,6 +31,7 @@ struct Emu {
     HostAlloc alloc;
     int cap, nd, dim;
     float* dets; int* n_dets; float* embs; float* out; int* out_n;
+    double* warp; int* warp_flag;
     EmuBlock block;
 };
 
@@ -67,6 +68,9 @@ void* emu_create(const double* cd, const int* ci, int cap, int nd, int dim) {
     e->args.dets = e->dets; e->args.n_dets = e->n_dets; e->args.embs = e->embs;
     e->args.list_sel = nullptr; e->args.frame_count_set = nullptr;
     e->args.out = e->out; e->args.out_n = e->out_n; e->args.stream_base = 0; e->args.phase_clock = nullptr;
+    e->warp = e->alloc.get<double>(6);
+    e->warp_flag = e->alloc.get<int>(1);
+    e->args.warp = e->warp; e->args.warp_flag = e->warp_flag;
     e->block.block_barrier.init(NTHR);
     for (int w = 0; w < EMU_MAX_WAVES; ++w) e->block.wave_barrier[w].init(EMU_WAVE);
     return e;
@@ -76,6 +80,13 @@ void emu_destroy(void* h) {
     Emu* e = static_cast<Emu*>(h);
     for (void* p : e->alloc.owned) std::free(p);
     delete e;
+}
+
+// warp (6 doubles, 2x3 row-major) applied by the next emu_update only
+void emu_set_warp(void* h, const double* w) {
+    Emu* e = static_cast<Emu*>(h);
+    for (int k = 0; k < 6; ++k) e->warp[k] = w[k];
+    e->warp_flag[0] = 1;
 }
 
 // returns the status word; out rows (n_out, 8)
@@ -102,6 +113,7 @@ int emu_update(void* h, const float* dets, int n, const float* embs, float* out,
     for (int t = 0; t < NTHR; ++t) { ta[t] = ThreadArg{e, t}; pthread_create(&th[t], &attr, thread_main, &ta[t]); }
     for (int t = 0; t < NTHR; ++t) pthread_join(th[t], nullptr);
     pthread_attr_destroy(&attr);
+    e->warp_flag[0] = 0;
     *out_n = e->out_n[0];
     std::memcpy(out, e->out, (size_t)e->out_n[0] * bm::OUT_COLS * 4);
     return e->args.st.status[0];

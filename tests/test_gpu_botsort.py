@@ -51,6 +51,46 @@ def test_hip_matches_reference_golden_and_oracle(name):
     trk.close()
 
 
+@pytest.mark.parametrize("name,seed", [("warp_default", 7), ("warp_yaml", 11)])
+def test_camera_warp_application_matches_reference(name, seed):
+    """use_cmc=True with a warp provider: STrack.multi_gmc runs on the device (botsort_track.py:117-132);
+    golden rows come from the reference driven with the same scheduled warps."""
+    from boxmot_amd.botsort import BotSort
+    from boxmot_amd.scenario import camera_warps, stress_frames
+    from common import GOLDEN, YAML
+    from oracle.botsort import BotSortOracle
+
+    class Scheduled:
+        def __init__(self, warps):
+            self.warps, self.k = warps, 0
+
+        def apply(self, img, dets):
+            assert dets.ndim == 2 and dets.shape[1] == 7
+            self.k += 1
+            return self.warps[self.k - 1]
+
+    g = np.load(GOLDEN / "botsort_warp_golden.npz")
+    rows, counts = g[name + "_rows"], g[name + "_counts"]
+    offs = np.concatenate([[0], np.cumsum(counts)])
+    kw = YAML if name == "warp_yaml" else {}
+    frames = stress_frames(120, seed=seed)
+    warps = camera_warps(len(frames), seed=seed)
+    img = np.zeros((480, 640, 3), dtype=np.uint8)
+    trk = BotSort(use_cmc=True, cmc=Scheduled(warps), emb_dim=32, max_tracks=256, max_dets=64, **kw)
+    orc = BotSortOracle(**kw)
+    for t, (dets, embs) in enumerate(frames):
+        got = trk.update(dets, img, embs)
+        assert_rows_match(got, rows[offs[t]:offs[t + 1]], t)
+        assert_rows_match(got, orc.update(dets, img, embs.copy(), warp=warps[t]), t)
+    od = orc.dump()
+    for which, key in ((0, "active"), (1, "lost")):
+        d = trk.state_dump(which)
+        assert np.array_equal(d["ints"][:, 0], od[key]["id"])
+        assert _kf_report(d, od[key]) < 1e-9
+    assert np.array_equal(trk.state_dump(0)["ints"][:, 0], g[name + "_final_ids"])
+    trk.close()
+
+
 def test_without_reid_and_mixed_options():
     from boxmot_amd.scenario import stress_frames
     from oracle.botsort import BotSortOracle

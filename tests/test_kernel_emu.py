@@ -10,14 +10,15 @@ from emu_util import EmuBotSort
 from oracle.botsort import DEFAULTS, BotSortOracle
 
 
-def _run(frames, dim, cap, nd, sanitize=False, dense=False, **kw):
+def _run(frames, dim, cap, nd, sanitize=False, dense=False, warps=None, **kw):
     cfg = dict(DEFAULTS)
     cfg.update(kw)
     orc, emu = BotSortOracle(**kw), EmuBotSort(cfg, cap=cap, nd=nd, dim=dim, sanitize=sanitize, dense=dense)
     try:
         for t, (d, e) in enumerate(frames):
-            want = orc.update(d.copy(), None, e.copy())
-            got = emu.update(d, e)
+            w = None if warps is None else warps[t]
+            want = orc.update(d.copy(), None, e.copy(), warp=w)
+            got = emu.update(d, e, warp=w)
             assert got.shape == want.shape, t
             assert np.array_equal(got[:, 4:], want[:, 4:]), t
             assert np.allclose(got[:, :4], want[:, :4], rtol=0, atol=1e-4), t
@@ -39,6 +40,13 @@ def _run(frames, dim, cap, nd, sanitize=False, dense=False, **kw):
                                 dict(with_reid=False)])
 def test_emulated_kernel_matches_oracle_stress(kw):
     _run(stress_frames(80, seed=7), 32, 128, 64, **kw)
+
+
+def test_emulated_kernel_applies_camera_warp():
+    """STrack.multi_gmc on the device state (botsort_track.py:117-132), warp every frame and every third frame."""
+    from boxmot_amd.scenario import camera_warps
+    _run(stress_frames(60, seed=7), 32, 128, 64, warps=camera_warps(60, seed=7))
+    _run(stress_frames(60, seed=11), 32, 128, 64, warps=camera_warps(60, seed=3, every=3), fuse_first_associate=True)
 
 
 def test_emulated_kernel_dense_cosine_path():

@@ -27,6 +27,27 @@ def test_oracle_matches_reference_rows(name):
         assert np.array_equal(d["cov"], g[name + "_final_cov"])
 
 
+@pytest.mark.parametrize("name,seed", [("warp_default", 7), ("warp_yaml", 11)])
+def test_oracle_warp_application_matches_reference(name, seed):
+    """Camera-motion warp supplied per frame (the reference ran with a scheduled stand-in for its ECC object,
+    tests/golden/make_golden.py ScheduledCMC): STrack.multi_gmc on the pool and the unconfirmed tracks."""
+    from boxmot_amd.scenario import camera_warps, stress_frames
+    from common import GOLDEN, YAML
+    g = np.load(GOLDEN / "botsort_warp_golden.npz")
+    rows, counts = g[name + "_rows"], g[name + "_counts"]
+    offs = np.concatenate([[0], np.cumsum(counts)])
+    frames = stress_frames(120, seed=seed)
+    warps = camera_warps(len(frames), seed=seed)
+    orc = BotSortOracle(**(YAML if name == "warp_yaml" else {}))
+    for t, (dets, embs) in enumerate(frames):
+        got = orc.update(dets, None, embs.copy(), warp=warps[t])
+        assert np.array_equal(got, rows[offs[t]:offs[t + 1]]), f"{name} frame {t}"
+    d = orc.dump()["active"]
+    assert np.array_equal(d["id"], g[name + "_final_ids"])
+    assert np.array_equal(d["mean"], g[name + "_final_mean"])
+    assert np.array_equal(d["cov"], g[name + "_final_cov"])
+
+
 def test_oracle_reid_matches_reference_features():
     import torch
 
