@@ -81,6 +81,14 @@ def load_botsort():
     return BotSort
 
 
+def load_deepocsort():
+    """Return the reference DeepOcSort class (imported from /root/reference)."""
+    install_standins()
+    from boxmot.trackers.bbox.deepocsort.deepocsort import DeepOcSort
+
+    return DeepOcSort
+
+
 def load_osnet_module():
     """Load boxmot/reid/backbones/osnet.py by path (``boxmot.reid`` itself cannot import)."""
     install_standins()

@@ -36,3 +36,20 @@ def assert_rows_match(got, want, frame, box_atol=1e-4):
     assert np.array_equal(got[:, 4:], want[:, 4:]), f"frame {frame}: id/conf/cls/det_ind columns differ"
     assert np.allclose(got[:, :4], want[:, :4], rtol=0, atol=box_atol), (
         f"frame {frame}: boxes differ by {np.abs(got[:, :4] - want[:, :4]).max()}")
+
+
+DEEPOCSORT_CASES = {
+    # name: (frames factory, image shape, tracker kwargs, emb dim)  -- keep in step with tests/golden/make_golden.py
+    "docs_stress_default": (lambda: stress_frames(150, seed=7), (480, 640), {}, 32),
+    "docs_stress_short": (lambda: stress_frames(150, seed=11), (480, 640), dict(max_age=5, min_hits=1), 32),
+    "docs_stress_awoff": (lambda: stress_frames(120, seed=3), (480, 640), dict(aw_off=True, inertia=0.4, w_association_emb=0.75), 32),
+    "docs_stress_noemb": (lambda: stress_frames(120, seed=5), (480, 640), dict(embedding_off=True), 32),
+    "docs_c2": (lambda: Scenario(64, 256, emb_dim=128, random_image=False).frames(30), (1080, 1920), {}, 128),
+}
+
+
+def deepocsort_golden_rows(name):
+    g = np.load(GOLDEN / "deepocsort_golden.npz")
+    rows, counts = g[name + "_rows"], g[name + "_counts"]
+    offs = np.concatenate([[0], np.cumsum(counts)])
+    return [rows[offs[i]:offs[i + 1]] for i in range(len(counts))], g

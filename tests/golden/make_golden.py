@@ -5,6 +5,8 @@ Run in the build container only:  python tests/golden/make_golden.py
 Outputs (small, committed):
   tests/golden/botsort_golden.npz  per-frame output rows of the reference BotSort on seeded
                                    scenarios (inputs are regenerated from the seed by the tests)
+  tests/golden/botsort_warp_golden.npz   the same with a scheduled camera-motion warp (STrack.multi_gmc)
+  tests/golden/deepocsort_golden.npz     per-frame rows + final Kalman state of the reference DeepOcSort
   tests/golden/reid_golden.npz     a seeded OSNet-x0.25 state_dict, test boxes, and the reference
                                    BaseModelBackend.get_features / get_crops results for them
 The lap / cv2 stand-ins make those two boundaries "parity unpinned" (see oracle/__init__.py).
@@ -79,6 +81,40 @@ def warp_golden():
     np.savez_compressed(OUT / "botsort_warp_golden.npz", **out)
 
 
+DEEPOCSORT_CASES = {
+    # name: (frames factory, image shape, tracker kwargs)
+    "docs_stress_default": (lambda: stress_frames(150, seed=7), (480, 640), {}),
+    "docs_stress_short": (lambda: stress_frames(150, seed=11), (480, 640), dict(max_age=5, min_hits=1)),
+    "docs_stress_awoff": (lambda: stress_frames(120, seed=3), (480, 640), dict(aw_off=True, inertia=0.4, w_association_emb=0.75)),
+    "docs_stress_noemb": (lambda: stress_frames(120, seed=5), (480, 640), dict(embedding_off=True)),
+    "docs_c2": (lambda: Scenario(64, 256, emb_dim=128, random_image=False).frames(30), (1080, 1920), {}),
+}
+
+
+def deepocsort_golden():
+    """deepocsort_golden.npz: the reference DeepOcSort (cmc_off=True, embeddings supplied) on seeded scenarios."""
+    logging.disable(logging.CRITICAL)
+    DeepOcSort = ref_harness.load_deepocsort()
+    out = {}
+    for name, (make, hw, kw) in DEEPOCSORT_CASES.items():
+        frames = make()
+        img = np.zeros((hw[0], hw[1], 3), dtype=np.uint8)
+        trk = DeepOcSort(reid_model=None, cmc_off=True, **kw)
+        rows, counts = [], []
+        for dets, embs in frames:
+            r = np.asarray(trk.update(dets.copy(), img, embs.copy()), dtype=np.float32).reshape(-1, 8)
+            rows.append(r)
+            counts.append(len(r))
+        out[name + "_rows"] = np.concatenate(rows, 0)
+        out[name + "_counts"] = np.array(counts, dtype=np.int32)
+        act = trk.active_tracks
+        out[name + "_final_x"] = np.array([t.kf.x[:, 0] for t in act], dtype=np.float64).reshape(len(act), 7)
+        out[name + "_final_P"] = np.array([t.kf.P for t in act], dtype=np.float64).reshape(len(act), 7, 7)
+        out[name + "_final_ids"] = np.array([t.id for t in act], dtype=np.int64)
+        print(name, "frames", len(frames), "rows", sum(counts), "tracks", len(act))
+    np.savez_compressed(OUT / "deepocsort_golden.npz", **out)
+
+
 def main():
     logging.disable(logging.CRITICAL)
     BotSort = ref_harness.load_botsort()
@@ -122,6 +158,9 @@ def main():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "warp":
         warp_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "deepocsort":
+        deepocsort_golden()
     else:
         main()
         warp_golden()
+        deepocsort_golden()

@@ -48,6 +48,27 @@ def test_oracle_warp_application_matches_reference(name, seed):
     assert np.array_equal(d["cov"], g[name + "_final_cov"])
 
 
+@pytest.mark.parametrize("name", ["docs_stress_default", "docs_stress_short", "docs_stress_awoff", "docs_stress_noemb", "docs_c2"])
+def test_deepocsort_oracle_matches_reference_rows(name):
+    from common import DEEPOCSORT_CASES, deepocsort_golden_rows
+    from oracle.deepocsort import DeepOcSortOracle
+    make, hw, kw, _ = DEEPOCSORT_CASES[name]
+    frames = make()
+    want, g = deepocsort_golden_rows(name)
+    if name == "docs_c2":
+        frames = frames[:10]
+    orc = DeepOcSortOracle(**kw)
+    for t, (dets, embs) in enumerate(frames):
+        got = orc.update(dets, None, embs.copy())
+        assert got.dtype == np.float32
+        assert np.array_equal(got.reshape(-1, 8), want[t]), f"{name} frame {t}"
+    if len(frames) == len(want):
+        d = orc.dump()
+        assert np.array_equal(d["id"], g[name + "_final_ids"])
+        assert np.array_equal(d["x"], g[name + "_final_x"])           # same NumPy/SciPy calls -> bit-exact
+        assert np.array_equal(d["P"], g[name + "_final_P"])
+
+
 def test_oracle_reid_matches_reference_features():
     import torch
 

@@ -28,6 +28,25 @@ def test_botsort_oracle_bit_exact_incl_kalman_state():
         assert [t.id for t in ref.lost_stracks] == [t.id for t in orc.lost]
 
 
+def test_deepocsort_oracle_bit_exact_incl_kalman_state():
+    from boxmot_amd.scenario import stress_frames
+    from oracle.deepocsort import DeepOcSortOracle
+
+    logging.disable(logging.CRITICAL)
+    DeepOcSort = ref_harness.load_deepocsort()
+    img = np.zeros((480, 640, 3), np.uint8)
+    for kw in ({}, dict(max_age=5, min_hits=1), dict(aw_off=True, inertia=0.4), dict(embedding_off=True)):
+        ref, orc = DeepOcSort(reid_model=None, cmc_off=True, **kw), DeepOcSortOracle(**kw)
+        for t, (d, e) in enumerate(stress_frames(100, seed=3)):
+            r = np.asarray(ref.update(d.copy(), img, e.copy()))
+            o = orc.update(d.copy(), img, e.copy())
+            assert r.shape == o.shape and np.array_equal(r, o), (kw, t)
+        dd = orc.dump()
+        assert [k.id for k in ref.active_tracks] == list(dd["id"])
+        for k, x, P in zip(ref.active_tracks, dd["x"], dd["P"]):
+            assert np.array_equal(k.kf.x[:, 0], x) and np.array_equal(k.kf.P, P)
+
+
 def test_osnet_functional_equals_reference_module():
     import torch
 
