@@ -1,17 +1,20 @@
-"""boxmot_amd -- MI355X-native BoT-SORT update path (HIP kernels behind a C ABI).
+"""boxmot_amd -- MI355X-native tracker update path (BoT-SORT, DeepOCSORT; HIP kernels behind a C ABI).
 
 Public surface (mirrors the reference's for this path):
-  BotSort, HipReID, TrackResults, create_tracker, MultiStreamBotSort.
+  BotSort, DeepOcSort, HipReID, TrackResults, create_tracker, MultiStreamBotSort.
 """
 __version__ = "0.1.0"
 
-__all__ = ["BotSort", "HipReID", "TrackResults", "create_tracker", "MultiStreamBotSort"]
+__all__ = ["BotSort", "DeepOcSort", "HipReID", "TrackResults", "create_tracker", "MultiStreamBotSort"]
 
 
 def __getattr__(name):
     if name == "BotSort":
         from boxmot_amd.botsort import BotSort
         return BotSort
+    if name == "DeepOcSort":
+        from boxmot_amd.deepocsort import DeepOcSort
+        return DeepOcSort
     if name == "HipReID":
         from boxmot_amd.reid import HipReID
         return HipReID

@@ -49,6 +49,33 @@ class BotSortConfig(ctypes.Structure):
     ]
 
 
+class DeepOcSortConfig(ctypes.Structure):
+    """``BoxMOTHipDeepOcSortConfig`` (include/boxmot_hip.h)."""
+
+    _fields_ = [
+        ("det_thresh", ctypes.c_double),
+        ("max_age", ctypes.c_int),
+        ("max_obs", ctypes.c_int),
+        ("min_hits", ctypes.c_int),
+        ("iou_threshold", ctypes.c_double),
+        ("delta_t", ctypes.c_int),
+        ("inertia", ctypes.c_double),
+        ("w_association_emb", ctypes.c_double),
+        ("alpha_fixed_emb", ctypes.c_double),
+        ("aw_param", ctypes.c_double),
+        ("embedding_off", ctypes.c_int),
+        ("cmc_off", ctypes.c_int),
+        ("aw_off", ctypes.c_int),
+        ("Q_xy_scaling", ctypes.c_double),
+        ("Q_s_scaling", ctypes.c_double),
+        ("reid_model_path", ctypes.c_char_p),
+        ("n_streams", ctypes.c_int),
+        ("max_tracks", ctypes.c_int),
+        ("max_dets", ctypes.c_int),
+        ("emb_dim", ctypes.c_int),
+    ]
+
+
 # every symbol include/boxmot_hip.h declares: (name, restype, argtypes)
 _VP = ctypes.c_void_p
 _I = ctypes.c_int
@@ -78,6 +105,13 @@ SIGNATURES = {
     "boxmot_hip_botsort_last_reid_postprocess_time_ms": (_I, [_VP, c_double_p]),
     "boxmot_hip_botsort_last_track_time_ms": (_I, [_VP, c_double_p]),
     "boxmot_hip_botsort_state_dump": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP, _VP, c_int_p, c_int_p, c_int_p]),
+    "boxmot_hip_deepocsort_default_config": (None, [ctypes.POINTER(DeepOcSortConfig)]),
+    "boxmot_hip_deepocsort_create": (_VP, [ctypes.POINTER(DeepOcSortConfig)]),
+    "boxmot_hip_deepocsort_destroy": (None, [_VP]),
+    "boxmot_hip_deepocsort_reset": (_I, [_VP]),
+    "boxmot_hip_deepocsort_update": (_I, [_VP, _VP, _I, _I, _VP, _I, _I, _VP, _I, _I, _I, _VP, _I, _I, c_int_p, c_int_p]),
+    "boxmot_hip_deepocsort_update_batch": (_I, [_VP, _I, _VP, _VP, _VP, _I, _VP, _I, _I, _I, _VP, _I, _VP]),
+    "boxmot_hip_deepocsort_state_dump": (_I, [_VP, _I, _VP, _VP, _VP, c_int_p, c_int_p, c_int_p]),
     "boxmot_hip_reid_create": (_VP, [ctypes.c_char_p, _VP, ctypes.c_long, _I]),
     "boxmot_hip_reid_destroy": (None, [_VP]),
     "boxmot_hip_reid_feature_dim": (_I, [_VP]),

@@ -15,6 +15,7 @@
 #include "../../include/boxmot_hip.h"
 #include "botsort_alloc.hpp"
 #include "botsort_step.hpp"
+#include "deepocsort_step.hpp"
 #include "reid_engine.hpp"
 
 namespace {
@@ -45,6 +46,14 @@ __global__ void __launch_bounds__(NTHR) botsort_step_kernel(bm::BotSortStepArgs 
     __shared__ float sB[bm::COST_TILE][bm::COST_KC + 1];
     BM_DYNAMIC_LDS_T(unsigned char, dyn_lds);       // assignment-solver state, sized by lap_lds_bytes(cap, max_dets)
     bm::botsort_step_stream<NTHR>(args, args.stream_base + blockIdx.x, s_int, s_dbl, sA, sB, dyn_lds);
+}
+
+template <int NTHR>
+__global__ void __launch_bounds__(NTHR) deepocsort_step_kernel(bm::DocsStepArgs args) {
+    __shared__ int s_int[bm::MAX_WAVES + 1];
+    __shared__ double s_dbl[bm::MAX_WAVES];
+    BM_DYNAMIC_LDS_T(unsigned char, dyn_lds);       // assignment-solver state, docs_lap_lds_bytes(cap, max_dets)
+    bm::docs_step_stream<NTHR>(args, args.stream_base + blockIdx.x, s_int, s_dbl, dyn_lds);
 }
 
 // Build the ReID crop list on the device: every detection with conf > track_high_thresh
@@ -140,6 +149,30 @@ struct BoxMOTHipBotSort {
         for (auto* p : frame_bufs) if (p) (void)hipFree(p);
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
         for (auto& e : timer_ev) if (e) (void)hipEventDestroy(e);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+struct BoxMOTHipDeepOcSort {
+    BoxMOTHipDeepOcSortConfig cfg{};
+    std::string reid_path;
+    bm::DocsStepArgs args{};
+    std::vector<void*> owned;
+    hipStream_t stream = nullptr;
+    int S = 1, cap = 0, nd = 0, dim = 0;
+    float* d_dets = nullptr; int* d_ndets = nullptr; float* d_embs = nullptr; float* d_out = nullptr; int* d_out_n = nullptr;
+    std::vector<float> h_dets, h_out;
+    std::vector<int> h_ndets, h_out_n;
+    std::vector<uint8_t*> frame_bufs;
+    size_t frame_bytes = 0;
+    int frame_rows = 0, frame_cols = 0;
+    const uint8_t** d_frames = nullptr;
+    std::unique_ptr<bm::ReidEngine> reid;
+    int* d_crop_count = nullptr; int* d_crop_stream = nullptr; float* d_crop_boxes = nullptr; int* d_crop_row = nullptr;
+    ~BoxMOTHipDeepOcSort() {
+        reid.reset();
+        for (void* p : owned) (void)hipFree(p);
+        for (auto* p : frame_bufs) if (p) (void)hipFree(p);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -396,6 +429,160 @@ void host_update_one(BoxMOTHipBotSort* h, int stream, int class_list, int frame_
     const int fc[1] = {frame_count};
     host_update(h, stream, 1, &in, det_cols, emb_cols, rows, cols, channels, sel, frame_count >= 0 ? fc : nullptr, outs,
                 out_cap, out_rows);
+}
+
+
+// ---------------------------------------------------------------------------
+// DeepOCSORT host path
+// ---------------------------------------------------------------------------
+void docs_zero_state(BoxMOTHipDeepOcSort* h) {
+    bm::DocsState& st = h->args.st;
+    const size_t S = h->S, cap = h->cap;
+    BM_HIP(hipMemsetAsync(st.frame_count, 0, S * 4, h->stream));
+    BM_HIP(hipMemsetAsync(st.id_count, 0, S * 4, h->stream));
+    BM_HIP(hipMemsetAsync(st.n_tracks, 0, S * 4, h->stream));
+    BM_HIP(hipMemsetAsync(st.status, 0, S * 4, h->stream));
+    BM_HIP(hipMemsetAsync(st.slot_used, 0, S * cap * 4, h->stream));
+    BM_HIP(hipStreamSynchronize(h->stream));
+}
+
+void docs_build(BoxMOTHipDeepOcSort* h) {
+    const BoxMOTHipDeepOcSortConfig& c = h->cfg;
+    if (!c.cmc_off) throw std::runtime_error("boxmot_hip: DeepOCSORT camera-motion compensation is not implemented; pass cmc_off=1");
+    if (c.n_streams < 1 || c.max_tracks < 8 || c.max_dets < 4 || c.emb_dim < 1)
+        throw std::runtime_error("boxmot_hip: invalid capacity configuration");
+    if (c.max_age < 0 || c.max_age > 45)
+        throw std::runtime_error("boxmot_hip: DeepOCSORT max_age must be in [0, 45] (the reference's 50-entry observation history, xysr.py:18)");
+    if (c.delta_t < 1 || c.delta_t > 3) throw std::runtime_error("boxmot_hip: DeepOCSORT delta_t must be 1..3");
+    if (!(c.aw_param < 1.0)) throw std::runtime_error("boxmot_hip: aw_param must be < 1");
+    h->S = c.n_streams; h->cap = c.max_tracks; h->nd = c.max_dets; h->dim = c.embedding_off ? 1 : c.emb_dim;
+    BM_HIP(hipStreamCreate(&h->stream));
+    bm::DocsConfigDev& d = h->args.cfg;
+    d.det_thresh = c.det_thresh; d.det_thresh_f32 = (float)c.det_thresh; d.max_age = c.max_age; d.min_hits = c.min_hits;
+    d.delta_t = c.delta_t; d.iou_threshold = c.iou_threshold; d.inertia = c.inertia; d.w_emb = c.w_association_emb;
+    d.alpha_fixed = c.alpha_fixed_emb; d.aw_param = c.aw_param; d.q_xy = c.Q_xy_scaling; d.q_s = c.Q_s_scaling;
+    d.embedding_off = c.embedding_off; d.aw_off = c.aw_off;
+    auto& o = h->owned;
+    DevAlloc dev_allocator{&o};
+    bm::DocsSizes z{h->S, h->cap, h->nd, h->dim};
+    bm::docs_allocate(h->args, z, dev_allocator);
+    const size_t S = h->S, cap = h->cap, nd = h->nd, dim = h->dim;
+    h->d_dets = zalloc<float>(S * nd * bm::DET_COLS, o);
+    h->d_ndets = zalloc<int>(S, o);
+    h->d_embs = zalloc<float>(S * nd * dim, o);
+    h->d_out = zalloc<float>(S * cap * bm::OUT_COLS, o);
+    h->d_out_n = zalloc<int>(S, o);
+    h->h_dets.assign(S * nd * bm::DET_COLS, 0.f);
+    h->h_out.assign(S * cap * bm::OUT_COLS, 0.f);
+    h->h_ndets.assign(S, 0); h->h_out_n.assign(S, 0);
+    h->frame_bufs.assign(S, nullptr);
+    h->d_frames = zalloc<const uint8_t*>(S, o);
+    h->d_crop_count = zalloc<int>(1, o);
+    h->d_crop_stream = zalloc<int>(S * nd, o);
+    h->d_crop_boxes = zalloc<float>(S * nd * 4, o);
+    h->d_crop_row = zalloc<int>(S * nd, o);
+    const long lds = bm::docs_lap_lds_bytes(h->cap, h->nd);
+    if (lds > 120 * 1024) throw std::runtime_error("boxmot_hip: max_tracks/max_dets too large for the assignment solver's LDS state");
+    BM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deepocsort_step_kernel<STEP_THREADS>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (!c.embedding_off && !h->reid_path.empty()) {
+        const std::vector<float> blob = bm::read_blob_file(h->reid_path.c_str());
+        h->reid.reset(new bm::ReidEngine(blob.data(), (long)blob.size(), bm::reid_chunk_for((long)S * nd), (int)(S * nd)));
+        if (h->reid->feature_dim() != h->dim) throw std::runtime_error("boxmot_hip: ReID feature dim != emb_dim");
+    }
+}
+
+// Stage inputs of the first n streams, run ReID on the kept detections if embeddings are not supplied, step, read back.
+void docs_host_update(BoxMOTHipDeepOcSort* h, int n, const StreamIn* in, int det_cols, int emb_cols, int image_rows,
+                      int image_cols, int image_channels, float* const* out, int out_capacity_rows, int* out_rows) {
+    const int nd = h->nd, dim = h->dim, cap = h->cap;
+    const bool want_emb = !h->cfg.embedding_off;
+    bool need_reid = false;
+    for (int k = 0; k < n; ++k) {
+        const int rows = in[k].det_rows;
+        if (rows < 0) throw std::runtime_error("Negative matrix dimensions are not allowed.");
+        if (rows > 0 && det_cols != 6) throw std::runtime_error("boxmot_hip live tracking supports AABB detections with 6 columns.");
+        if (rows > nd) throw std::runtime_error("boxmot_hip: more detections than max_dets");
+        if (rows > 0 && in[k].dets == nullptr) throw std::runtime_error("Detection data pointer is null.");
+        if (out_capacity_rows < rows) throw std::runtime_error("boxmot_hip: output buffer is too small for the current frame.");
+        if (want_emb && in[k].embs != nullptr && emb_cols != dim && rows > 0)
+            throw std::runtime_error("boxmot_hip: embedding width does not match emb_dim");
+        if (want_emb && in[k].embs == nullptr && rows > 0) need_reid = true;
+    }
+    if (need_reid)
+        for (int k = 0; k < n; ++k)
+            if (in[k].embs != nullptr && in[k].det_rows > 0)
+                throw std::runtime_error("boxmot_hip: either every stream of a batch supplies embeddings or none does");
+    for (int k = 0; k < n; ++k) {
+        h->h_ndets[k] = in[k].det_rows;
+        if (in[k].det_rows)
+            std::memcpy(h->h_dets.data() + (size_t)k * nd * bm::DET_COLS, in[k].dets, (size_t)in[k].det_rows * bm::DET_COLS * 4);
+    }
+    BM_HIP(hipMemcpyAsync(h->d_dets, h->h_dets.data(), (size_t)n * nd * bm::DET_COLS * 4, hipMemcpyHostToDevice, h->stream));
+    BM_HIP(hipMemcpyAsync(h->d_ndets, h->h_ndets.data(), n * 4, hipMemcpyHostToDevice, h->stream));
+    if (want_emb)
+        for (int k = 0; k < n; ++k)
+            if (in[k].embs && in[k].det_rows)
+                BM_HIP(hipMemcpyAsync(h->d_embs + (size_t)k * nd * dim, in[k].embs, (size_t)in[k].det_rows * dim * 4,
+                                      hipMemcpyHostToDevice, h->stream));
+    if (need_reid) {
+        if (!h->reid) throw std::runtime_error("boxmot_hip: embeddings are needed and none were supplied, but no ReID weights are loaded");
+        if (image_channels != 3) throw std::runtime_error("boxmot_hip: ReID needs a 3-channel uint8 BGR image");
+        const size_t bytes = (size_t)image_rows * image_cols * 3;
+        for (int k = 0; k < n; ++k) {
+            if (!in[k].image) { if (!h->frame_bufs[k]) throw std::runtime_error("Image data pointer is null."); continue; }
+            if (h->frame_bufs[k] == nullptr || bytes != h->frame_bytes) {
+                if (h->frame_bytes != 0 && bytes != h->frame_bytes) throw std::runtime_error("boxmot_hip: frame size changed between updates");
+                void* p = nullptr;
+                BM_HIP(hipMalloc(&p, bytes));
+                h->frame_bufs[k] = static_cast<uint8_t*>(p);
+                h->frame_bytes = bytes; h->frame_rows = image_rows; h->frame_cols = image_cols;
+                BM_HIP(hipMemcpy(h->d_frames, h->frame_bufs.data(), h->S * sizeof(uint8_t*), hipMemcpyHostToDevice));
+            }
+            BM_HIP(hipMemcpyAsync(h->frame_bufs[k], in[k].image, bytes, hipMemcpyHostToDevice, h->stream));
+        }
+        // every detection above det_thresh gets an embedding (deepocsort.py:337-345)
+        BM_HIP(hipMemsetAsync(h->d_crop_count, 0, 4, h->stream));
+        hipLaunchKernelGGL(build_crop_list_kernel, dim3(n), dim3(256), 0, h->stream, h->d_dets, h->d_ndets, nd,
+                           (double)(float)h->cfg.det_thresh, h->d_crop_count, h->d_crop_stream, h->d_crop_boxes, h->d_crop_row, 0);
+        if (h->reid->mode() == 1) {
+            h->reid->run_counted(h->d_frames, h->d_crop_stream, h->d_crop_boxes, 4, h->d_crop_count, n * nd, h->frame_cols,
+                                 h->frame_rows, h->d_embs, h->d_crop_row, h->stream);
+        } else {
+            int n_crops = 0;
+            BM_HIP(hipMemcpyAsync(&n_crops, h->d_crop_count, 4, hipMemcpyDeviceToHost, h->stream));
+            BM_HIP(hipStreamSynchronize(h->stream));
+            h->reid->run(h->d_frames, h->d_crop_stream, h->d_crop_boxes, 4, n_crops, h->frame_cols, h->frame_rows, h->d_embs,
+                         h->d_crop_row, h->stream);
+        }
+    }
+    bm::DocsStepArgs a = h->args;
+    a.dets = h->d_dets; a.n_dets = h->d_ndets; a.embs = want_emb ? h->d_embs : nullptr;
+    a.out = h->d_out; a.out_n = h->d_out_n; a.stream_base = 0;
+    hipLaunchKernelGGL((deepocsort_step_kernel<STEP_THREADS>), dim3(n), dim3(STEP_THREADS),
+                       (size_t)bm::docs_lap_lds_bytes(h->cap, h->nd), h->stream, a);
+    BM_HIP(hipGetLastError());
+    BM_HIP(hipMemcpyAsync(h->h_out_n.data(), h->d_out_n, n * 4, hipMemcpyDeviceToHost, h->stream));
+    BM_HIP(hipStreamSynchronize(h->stream));
+    std::vector<int> st(n);
+    BM_HIP(hipMemcpy(st.data(), h->args.st.status, n * 4, hipMemcpyDeviceToHost));
+    for (int k = 0; k < n; ++k)
+        if (st[k] != bm::STATUS_OK)
+            throw std::runtime_error("boxmot_hip: DeepOCSORT stream " + std::to_string(k) + ": " +
+                                     (st[k] == bm::STATUS_TRACK_CAPACITY ? "track capacity (max_tracks) exceeded"
+                                      : st[k] == bm::STATUS_LAP_STALL ? "assignment solver did not converge (non-finite costs?)"
+                                                                      : "innovation covariance is not positive definite"));
+    for (int k = 0; k < n; ++k) {
+        const int rows = h->h_out_n[k];
+        if (rows > out_capacity_rows) throw std::runtime_error("boxmot_hip: output buffer is too small for the current frame.");
+        if (rows) BM_HIP(hipMemcpy(h->h_out.data(), h->d_out + (size_t)k * cap * bm::OUT_COLS, (size_t)rows * bm::OUT_COLS * 4, hipMemcpyDeviceToHost));
+        for (int r = 0; r < rows; ++r) {
+            float* dst = out[k] + (size_t)r * 9;
+            for (int q = 0; q < 8; ++q) dst[q] = h->h_out[(size_t)r * bm::OUT_COLS + q];
+            dst[8] = 0.0f;
+        }
+        out_rows[k] = rows;
+    }
 }
 
 }  // namespace
@@ -736,4 +923,104 @@ int boxmot_hip_reid_preprocess(BoxMOTHipReID* handle, const uint8_t* image, int 
     });
 }
 
+// ---- DeepOCSORT ----
+void boxmot_hip_deepocsort_default_config(BoxMOTHipDeepOcSortConfig* c) {
+    if (!c) return;
+    std::memset(c, 0, sizeof(*c));
+    c->det_thresh = 0.3; c->max_age = 30; c->max_obs = 50; c->min_hits = 3; c->iou_threshold = 0.3;
+    c->delta_t = 3; c->inertia = 0.2; c->w_association_emb = 0.5; c->alpha_fixed_emb = 0.95; c->aw_param = 0.5;
+    c->embedding_off = 0; c->cmc_off = 0; c->aw_off = 0; c->Q_xy_scaling = 0.01; c->Q_s_scaling = 0.0001;
+    c->reid_model_path = nullptr;
+    c->n_streams = 1; c->max_tracks = 1024; c->max_dets = 256; c->emb_dim = 512;
+}
+
+BoxMOTHipDeepOcSort* boxmot_hip_deepocsort_create(const BoxMOTHipDeepOcSortConfig* config) {
+    BoxMOTHipDeepOcSort* h = nullptr;
+    const int ok = guard([&]() {
+        if (config == nullptr) throw std::runtime_error("boxmot_hip DeepOCSORT config is required.");
+        require_device();
+        h = new BoxMOTHipDeepOcSort();
+        h->cfg = *config;
+        if (config->reid_model_path) h->reid_path = config->reid_model_path;
+        h->cfg.reid_model_path = nullptr;
+        docs_build(h);
+    });
+    if (!ok) { delete h; return nullptr; }
+    return h;
+}
+
+void boxmot_hip_deepocsort_destroy(BoxMOTHipDeepOcSort* handle) { delete handle; }
+
+int boxmot_hip_deepocsort_reset(BoxMOTHipDeepOcSort* handle) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip DeepOCSORT handle is null.");
+        docs_zero_state(handle);
+    });
+}
+
+int boxmot_hip_deepocsort_update_batch(BoxMOTHipDeepOcSort* handle, int n_streams, const float* const* dets,
+                                       const int* det_rows, const float* const* embs, int emb_cols,
+                                       const uint8_t* const* images, int image_rows, int image_cols, int image_channels,
+                                       float* const* out_tracks, int out_capacity_rows, int* out_rows) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip DeepOCSORT handle is not initialized.");
+        if (n_streams < 1 || n_streams > handle->S) throw std::runtime_error("boxmot_hip: n_streams out of range");
+        if (!dets || !det_rows || !out_tracks || !out_rows) throw std::runtime_error("boxmot_hip: null batch pointers");
+        std::vector<StreamIn> in(n_streams);
+        for (int s = 0; s < n_streams; ++s)
+            in[s] = StreamIn{dets[s], det_rows[s], (embs && emb_cols > 0) ? embs[s] : nullptr, images ? images[s] : nullptr};
+        docs_host_update(handle, n_streams, in.data(), 6, emb_cols, image_rows, image_cols, image_channels, out_tracks,
+                         out_capacity_rows, out_rows);
+    });
+}
+
+int boxmot_hip_deepocsort_update(BoxMOTHipDeepOcSort* handle, const float* dets, int det_rows, int det_cols,
+                                 const float* embs, int emb_rows, int emb_cols, const uint8_t* image, int image_rows,
+                                 int image_cols, int image_channels, float* out_tracks, int out_capacity_rows,
+                                 int out_cols, int* out_rows, int* out_is_obb) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip DeepOCSORT handle is not initialized.");
+        if (!out_rows || !out_is_obb) throw std::runtime_error("Output pointers are null.");
+        if (out_cols != 9) throw std::runtime_error("boxmot_hip live tracking expects an output buffer with 9 columns.");
+        if (embs != nullptr && emb_rows != det_rows) throw std::runtime_error("Detection and embedding row counts must match.");
+        if (image_rows <= 0 || image_cols <= 0) throw std::runtime_error("Image dimensions must be positive.");
+        StreamIn in{dets, det_rows, (embs && emb_cols > 0) ? embs : nullptr, image};
+        float* outs[1] = {out_tracks};
+        docs_host_update(handle, 1, &in, det_cols, emb_cols, image_rows, image_cols, image_channels, outs, out_capacity_rows, out_rows);
+        *out_is_obb = 0;
+    });
+}
+
+int boxmot_hip_deepocsort_state_dump(BoxMOTHipDeepOcSort* handle, int stream, int* ints5, double* kf72, double* emb,
+                                     int* out_rows, int* out_frame_count, int* out_id_count) {
+    return guard([&]() {
+        if (!handle || !out_rows) throw std::runtime_error("boxmot_hip: null argument");
+        if (stream < 0 || stream >= handle->S) throw std::runtime_error("boxmot_hip: stream index out of range");
+        BM_HIP(hipStreamSynchronize(handle->stream));
+        const bm::DocsState& st = handle->args.st;
+        const size_t cap = handle->cap, dim = handle->dim, off = (size_t)stream * cap;
+        int n = 0, fc = 0, ic = 0;
+        BM_HIP(hipMemcpy(&n, st.n_tracks + stream, 4, hipMemcpyDeviceToHost));
+        BM_HIP(hipMemcpy(&fc, st.frame_count + stream, 4, hipMemcpyDeviceToHost));
+        BM_HIP(hipMemcpy(&ic, st.id_count + stream, 4, hipMemcpyDeviceToHost));
+        std::vector<int> list(cap), id(cap), age(cap), tsu(cap), hs(cap), obs(cap);
+        BM_HIP(hipMemcpy(list.data(), st.list + off, cap * 4, hipMemcpyDeviceToHost));
+        BM_HIP(hipMemcpy(id.data(), st.id + off, cap * 4, hipMemcpyDeviceToHost));
+        BM_HIP(hipMemcpy(age.data(), st.age + off, cap * 4, hipMemcpyDeviceToHost));
+        BM_HIP(hipMemcpy(tsu.data(), st.tsu + off, cap * 4, hipMemcpyDeviceToHost));
+        BM_HIP(hipMemcpy(hs.data(), st.hit_streak + off, cap * 4, hipMemcpyDeviceToHost));
+        BM_HIP(hipMemcpy(obs.data(), st.observed + off, cap * 4, hipMemcpyDeviceToHost));
+        for (int r = 0; r < n; ++r) {
+            const int sl = list[r];
+            if (ints5) { int* o = ints5 + r * 5; o[0] = id[sl]; o[1] = age[sl]; o[2] = tsu[sl]; o[3] = hs[sl]; o[4] = obs[sl]; }
+            if (kf72) BM_HIP(hipMemcpy(kf72 + (size_t)r * bm::KF_STRIDE, st.kf + (off + sl) * bm::KF_STRIDE, bm::KF_STRIDE * 8, hipMemcpyDeviceToHost));
+            if (emb) BM_HIP(hipMemcpy(emb + (size_t)r * dim, st.emb + (off + sl) * dim, dim * 8, hipMemcpyDeviceToHost));
+        }
+        *out_rows = n;
+        if (out_frame_count) *out_frame_count = fc;
+        if (out_id_count) *out_id_count = ic;
+    });
+}
+
 }  // extern "C"
+

@@ -1,0 +1,139 @@
+"""DeepOCSORT on MI355X behind the reference plugin surface.
+
+``DeepOcSort(...)`` takes the reference constructor's keyword arguments
+(boxmot/trackers/bbox/deepocsort/deepocsort.py:263-281 plus the BaseTracker ones,
+basetracker.py:19-31) and ``update(dets, img, embs=None)`` returns the reference's rows
+(deepocsort.py:302-492); the per-frame computation -- per-track 7-state Kalman filters with the
+observation-centric re-update, IoU / velocity-direction / adaptive-weighted appearance costs, assignment,
+recovery round, bookkeeping -- runs in one HIP kernel through the C ABI (include/boxmot_hip.h).
+
+Rejected loudly rather than approximated: camera-motion compensation (construct with ``cmc_off=True``;
+the reference default estimates a warp with OpenCV's sparse optical flow), ``per_class=True``, OBB
+detections, ``max_age > 45``.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Any
+
+import numpy as np
+
+from boxmot_amd import _lib
+from boxmot_amd.basetracker import OUT_COLS, BaseTracker
+
+
+class DeepOcSort(BaseTracker):
+    supports_obb = False
+
+    def __init__(
+        self,
+        reid_model: Any | None = None,
+        delta_t: int = 3,
+        inertia: float = 0.2,
+        w_association_emb: float = 0.5,
+        alpha_fixed_emb: float = 0.95,
+        aw_param: float = 0.5,
+        embedding_off: bool = False,
+        cmc_off: bool = False,
+        aw_off: bool = False,
+        Q_xy_scaling: float = 0.01,
+        Q_s_scaling: float = 0.0001,
+        # capacity of the device-resident track table (not reference parameters)
+        max_tracks: int = 1024,
+        max_dets: int = 256,
+        emb_dim: int | None = None,
+        **kwargs: Any,
+    ):
+        super().__init__(_tracker_name="DeepOcSort", **kwargs)
+        if not cmc_off:
+            raise NotImplementedError(
+                "boxmot_amd.DeepOcSort: camera-motion compensation is not implemented on the HIP path; construct with "
+                "cmc_off=True (the reference default is cmc_off=False with the 'sof' estimator)."
+            )
+        if self.per_class:
+            raise NotImplementedError("boxmot_amd.DeepOcSort: per_class=True is not implemented")
+        self.delta_t, self.inertia = delta_t, inertia
+        self.w_association_emb, self.alpha_fixed_emb, self.aw_param = w_association_emb, alpha_fixed_emb, aw_param
+        self.Q_xy_scaling, self.Q_s_scaling = Q_xy_scaling, Q_s_scaling
+        self.model = reid_model
+        self.cmc = None
+        self.embedding_off, self.cmc_off, self.aw_off = embedding_off, cmc_off, aw_off
+        self._lib = _lib.load()
+        self._emb_dim = 1 if embedding_off else (emb_dim or getattr(self.model, "feature_dim", None) or 512)
+        cfg = _lib.DeepOcSortConfig()
+        self._lib.boxmot_hip_deepocsort_default_config(ctypes.byref(cfg))
+        cfg.det_thresh, cfg.max_age, cfg.max_obs = self.det_thresh, self.max_age, self.max_obs
+        cfg.min_hits, cfg.iou_threshold = self.min_hits, self.iou_threshold
+        cfg.delta_t, cfg.inertia, cfg.w_association_emb = delta_t, inertia, w_association_emb
+        cfg.alpha_fixed_emb, cfg.aw_param = alpha_fixed_emb, aw_param
+        cfg.embedding_off, cfg.cmc_off, cfg.aw_off = int(bool(embedding_off)), 1, int(bool(aw_off))
+        cfg.Q_xy_scaling, cfg.Q_s_scaling = Q_xy_scaling, Q_s_scaling
+        cfg.n_streams, cfg.max_tracks, cfg.max_dets, cfg.emb_dim = 1, max_tracks, max_dets, self._emb_dim
+        self._cfg = cfg
+        self._max_tracks = max_tracks
+        self._handle = self._lib.boxmot_hip_deepocsort_create(ctypes.byref(cfg))
+        if not self._handle:
+            raise RuntimeError(_lib.last_error())
+
+    def _update_impl(self, dets, img, embs=None, masks=None, class_list: int = 0) -> np.ndarray:
+        self.check_inputs(dets, img, embs)
+        det_arr = np.ascontiguousarray(dets, dtype=np.float32)
+        n = int(det_arr.shape[0])
+        feats = None
+        if not self.embedding_off and n:
+            keep = det_arr[:, 4] > np.float32(self.det_thresh)          # deepocsort.py:334 (fp32 compare)
+            if embs is not None:
+                feats = np.ascontiguousarray(embs, dtype=np.float32)
+            elif keep.any():
+                # same call the reference makes (deepocsort.py:345): every detection above det_thresh
+                feats = np.zeros((n, self._emb_dim), dtype=np.float32)
+                feats[keep] = self.model.get_features(det_arr[keep, :4], img)
+            else:
+                feats = np.zeros((n, self._emb_dim), dtype=np.float32)
+            if feats.shape[1] != self._emb_dim:
+                raise ValueError(f"embedding width {feats.shape[1]} != emb_dim {self._emb_dim}")
+        img_arr = np.ascontiguousarray(img)
+        out = np.empty((max(n, 1), 9), dtype=np.float32)
+        out_rows, out_is_obb = ctypes.c_int(0), ctypes.c_int(0)
+        ok = self._lib.boxmot_hip_deepocsort_update(
+            self._handle, det_arr.ctypes.data if n else None, n, 6,
+            feats.ctypes.data if feats is not None else None, n if feats is not None else 0,
+            self._emb_dim if feats is not None else 0,
+            img_arr.ctypes.data, int(img_arr.shape[0]), int(img_arr.shape[1]),
+            int(img_arr.shape[2]) if img_arr.ndim == 3 else 1,
+            out.ctypes.data, int(out.shape[0]), 9, ctypes.byref(out_rows), ctypes.byref(out_is_obb))
+        _lib.check(ok)
+        self.frame_count += 1
+        if out_rows.value == 0:
+            return np.array([])                      # deepocsort.py:490-492 -> TrackResults of shape (0, 0)
+        return out[: out_rows.value, :OUT_COLS].copy()
+
+    def reset(self) -> None:
+        _lib.check(self._lib.boxmot_hip_deepocsort_reset(self._handle))
+        self.frame_count = 0
+        self._first_frame_processed = False
+        self._first_dets_processed = False
+
+    def state_dump(self) -> dict:
+        """Copy the live tracks back from the device in list order (parity tests / debugging)."""
+        cap, dim = self._max_tracks, self._emb_dim
+        ints = np.zeros((cap, 5), dtype=np.int32)
+        kf = np.zeros((cap, 72), dtype=np.float64)
+        emb = np.zeros((cap, dim), dtype=np.float64)
+        rows, fc, ic = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(self._lib.boxmot_hip_deepocsort_state_dump(
+            self._handle, 0, ints.ctypes.data, kf.ctypes.data, emb.ctypes.data, ctypes.byref(rows), ctypes.byref(fc),
+            ctypes.byref(ic)))
+        n = rows.value
+        return dict(n=n, ints=ints[:n], kf=kf[:n], emb=emb[:n], frame_count=fc.value, id_count=ic.value)
+
+    def close(self) -> None:
+        if getattr(self, "_handle", None):
+            self._lib.boxmot_hip_deepocsort_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

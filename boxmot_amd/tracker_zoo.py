@@ -23,7 +23,15 @@ BOTSORT_YAML_DEFAULTS = dict(
     unconfirmed_emb_scale=2.5445206391993294, second_match_thresh=0.28795081514328974,
     unconfirmed_match_thresh=0.41148010638233784, removed_stracks_buffer=329,
 )
-SUPPORTED = ("botsort",)
+# boxmot/configs/trackers/deepocsort.yaml defaults.  The YAML key `iou_thresh` is not a constructor argument
+# (`iou_threshold` is): the reference swallows it in BaseTracker(**kwargs) and the 0.3 default applies
+#  -- reproduced by passing it through unchanged.
+DEEPOCSORT_YAML_DEFAULTS = dict(
+    det_thresh=0.5, max_age=30, min_hits=3, iou_thresh=0.3, delta_t=3, asso_func="iou", inertia=0.2,
+    w_association_emb=0.75, alpha_fixed_emb=0.95, aw_param=0.5, embedding_off=False, cmc_off=False, aw_off=False,
+    Q_xy_scaling=0.01, Q_s_scaling=0.0001,
+)
+SUPPORTED = ("botsort", "deepocsort")
 
 
 def flatten_yaml_config(cfg: dict) -> dict:
@@ -51,13 +59,21 @@ def create_tracker(tracker_type: str = "botsort", tracker_config=None, reid_weig
     if evolve_param_dict is not None:
         kwargs = dict(evolve_param_dict)
     elif tracker_config is None:
-        kwargs = dict(BOTSORT_YAML_DEFAULTS)
+        kwargs = dict(BOTSORT_YAML_DEFAULTS if tracker_type == "botsort" else DEEPOCSORT_YAML_DEFAULTS)
     elif isinstance(tracker_config, dict):
         kwargs = flatten_yaml_config(tracker_config)
     else:
         kwargs = flatten_yaml_config(yaml.safe_load(Path(tracker_config).read_text()))
     kwargs.update(overrides)
     kwargs["per_class"] = per_class
+    if tracker_type == "deepocsort":
+        from boxmot_amd.deepocsort import DeepOcSort
+
+        if not kwargs.get("embedding_off", False) and reid_model is None and reid_weights is not None:
+            from boxmot_amd.reid import HipReID
+
+            reid_model = HipReID(reid_weights)
+        return DeepOcSort(reid_model=reid_model, **kwargs)
     if kwargs.get("with_reid", True) and reid_model is None and reid_weights is not None:
         from boxmot_amd.reid import HipReID
 

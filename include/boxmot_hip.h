@@ -175,6 +175,63 @@ const char* boxmot_hip_last_error(void);
 /* number of visible HIP devices (0 when none / runtime unusable) */
 int boxmot_hip_device_count(void);
 
+/* ------------------------------------------------------------------------------------------------
+ * DeepOCSORT (boxmot/trackers/bbox/deepocsort/deepocsort.py:235-492).  The reference has no native backend
+ * for this tracker; the entry points follow the BoT-SORT ones above (same buffer, error and ownership
+ * conventions, c_api.hpp:36-61).  Fields = the constructor arguments of DeepOcSort (deepocsort.py:263-281) and
+ * of BaseTracker (basetracker.py:19-31).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct BoxMOTHipDeepOcSortConfig {
+    double det_thresh;
+    int max_age;                     /* <= 45: the reference's filter keeps a 50-entry observation history (xysr.py:18) */
+    int max_obs;
+    int min_hits;
+    double iou_threshold;
+    int delta_t;                     /* 1..3 */
+    double inertia;
+    double w_association_emb;
+    double alpha_fixed_emb;
+    double aw_param;
+    int embedding_off;
+    int cmc_off;                     /* must be 1: camera-motion compensation is not implemented for this tracker */
+    int aw_off;
+    double Q_xy_scaling;
+    double Q_s_scaling;
+    const char* reid_model_path;     /* OSN1 blob (boxmot_amd.reid_weights.save_blob) or NULL when embeddings are supplied */
+    int n_streams;
+    int max_tracks;
+    int max_dets;
+    int emb_dim;
+} BoxMOTHipDeepOcSortConfig;
+
+typedef struct BoxMOTHipDeepOcSort BoxMOTHipDeepOcSort;
+
+/* fills the constructor defaults (deepocsort.py:263-281, basetracker.py:19-31); note cmc_off defaults to 0 there */
+void boxmot_hip_deepocsort_default_config(BoxMOTHipDeepOcSortConfig* config);
+BoxMOTHipDeepOcSort* boxmot_hip_deepocsort_create(const BoxMOTHipDeepOcSortConfig* config);
+void boxmot_hip_deepocsort_destroy(BoxMOTHipDeepOcSort* handle);
+int boxmot_hip_deepocsort_reset(BoxMOTHipDeepOcSort* handle);
+/* DeepOcSort.update for stream 0 (deepocsort.py:302-492): arguments as boxmot_hip_botsort_update; embs == NULL runs the
+ * ReID engine on every detection with conf > det_thresh.  Rows [x1,y1,x2,y2,id,conf,cls,det_ind,0]. */
+int boxmot_hip_deepocsort_update(
+    BoxMOTHipDeepOcSort* handle,
+    const float* dets, int det_rows, int det_cols,
+    const float* embs, int emb_rows, int emb_cols,
+    const uint8_t* image, int image_rows, int image_cols, int image_channels,
+    float* out_tracks, int out_capacity_rows, int out_cols,
+    int* out_rows, int* out_is_obb);
+/* one frame for each of the first n_streams streams in one launch set (arguments as boxmot_hip_botsort_update_batch) */
+int boxmot_hip_deepocsort_update_batch(
+    BoxMOTHipDeepOcSort* handle, int n_streams,
+    const float* const* dets, const int* det_rows,
+    const float* const* embs, int emb_cols,
+    const uint8_t* const* images, int image_rows, int image_cols, int image_channels,
+    float* const* out_tracks, int out_capacity_rows, int* out_rows);
+/* parity debugging: live tracks of `stream` in list order -- ints5 (rows,5) = id, age, time_since_update, hit_streak,
+ * observed; kf72 (rows,72) = x[8] ++ P[8][8] fp64 (index 7 unused); emb (rows, emb_dim) fp64.  NULL skips an output. */
+int boxmot_hip_deepocsort_state_dump(BoxMOTHipDeepOcSort* handle, int stream, int* ints5, double* kf72, double* emb,
+                                     int* out_rows, int* out_frame_count, int* out_id_count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -75,3 +75,63 @@ class EmuBotSort:
         if self.h:
             self.lib.emu_destroy(self.h)
             self.h = None
+
+
+DOCS_D = ("det_thresh", "iou_threshold", "inertia", "w_association_emb", "alpha_fixed_emb", "aw_param", "Q_xy_scaling", "Q_s_scaling")
+DOCS_I = ("max_age", "min_hits", "delta_t", "embedding_off", "aw_off")
+
+
+def build_docs(sanitize: bool = False) -> Path:
+    src = HERE / "emu_docs.cpp"
+    csrc = HERE.parent.parent / "boxmot_amd" / "csrc"
+    deps = [src, HERE / "hip_shim.hpp", csrc / "deepocsort_step.hpp", csrc / "block_prims.hpp", csrc / "kernel_macros.hpp",
+            csrc / "botsort_types.hpp"]
+    out = HERE / ("libemu_docs_asan.so" if sanitize else "libemu_docs.so")
+    if not out.exists() or any(d.stat().st_mtime > out.stat().st_mtime for d in deps):
+        flags = ["-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-pthread"]
+        if sanitize:
+            flags += ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"]
+        subprocess.check_call(["g++", *flags, "-o", str(out), str(src)])
+    return out
+
+
+class EmuDeepOcSort:
+    """The DeepOCSORT device step (deepocsort_step.hpp) executed on CPU threads."""
+
+    def __init__(self, cfg: dict, cap=256, nd=64, dim=32, sanitize=False):
+        self.lib = ctypes.CDLL(str(build_docs(sanitize)))
+        self.lib.emu_docs_create.restype = ctypes.c_void_p
+        self.lib.emu_docs_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        self.lib.emu_docs_update.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                             ctypes.c_void_p, ctypes.c_void_p]
+        self.lib.emu_docs_dump.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 4
+        self.lib.emu_docs_destroy.argtypes = [ctypes.c_void_p]
+        cd = np.array([cfg[k] for k in DOCS_D], dtype=np.float64)
+        ci = np.array([int(cfg[k]) for k in DOCS_I], dtype=np.int32)
+        self.cap, self.nd, self.dim = cap, nd, dim
+        self.h = self.lib.emu_docs_create(cd.ctypes.data, ci.ctypes.data, cap, nd, dim)
+
+    def update(self, dets, embs=None):
+        dets = np.ascontiguousarray(dets, dtype=np.float32).reshape(-1, 6)
+        n = len(dets)
+        e = None if embs is None else np.ascontiguousarray(embs, dtype=np.float32)
+        out = np.zeros((self.cap, 8), dtype=np.float32)
+        out_n = ctypes.c_int(0)
+        status = self.lib.emu_docs_update(self.h, dets.ctypes.data, n, None if e is None else e.ctypes.data,
+                                          out.ctypes.data, ctypes.byref(out_n))
+        if status != 0:
+            raise RuntimeError(f"emulated kernel status {status}")
+        return out[: out_n.value].copy()
+
+    def dump(self):
+        ints = np.zeros((self.cap, 5), dtype=np.int32)
+        kf = np.zeros((self.cap, 72), dtype=np.float64)
+        emb = np.zeros((self.cap, self.dim), dtype=np.float64)
+        cnt = np.zeros(2, dtype=np.int32)
+        n = self.lib.emu_docs_dump(self.h, ints.ctypes.data, kf.ctypes.data, emb.ctypes.data, cnt.ctypes.data)
+        return dict(n=n, ints=ints[:n], kf=kf[:n], emb=emb[:n], counters=cnt)
+
+    def close(self):
+        if self.h:
+            self.lib.emu_docs_destroy(self.h)
+            self.h = None

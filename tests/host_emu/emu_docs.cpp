@@ -1,0 +1,121 @@
+// TEST-ONLY harness: runs bm::docs_step_stream (the DeepOCSORT device source, unchanged) on CPU threads through
+// hip_shim.hpp.  See hip_shim.hpp for scope and limits.
+#include "hip_shim.hpp"
+
+#include <cstdlib>
+#include <vector>
+
+#include "../../boxmot_amd/csrc/deepocsort_step.hpp"
+
+thread_local EmuDim3 threadIdx;
+thread_local EmuDim3 blockIdx;
+EmuDim3 blockDim;
+EmuBlock* g_emu_block = nullptr;
+
+namespace {
+
+constexpr int NTHR = 64;
+
+struct HostAlloc {
+    std::vector<void*> owned;
+    template <typename T> T* get(size_t n) {
+        void* p = std::calloc(n ? n : 1, sizeof(T));
+        owned.push_back(p);
+        return static_cast<T*>(p);
+    }
+};
+
+struct Emu {
+    bm::DocsStepArgs args{};
+    HostAlloc alloc;
+    int cap, nd, dim;
+    float* dets; int* n_dets; float* embs; float* out; int* out_n;
+    EmuBlock block;
+};
+
+struct ThreadArg { Emu* e; int tid; };
+int* g_s_int; double* g_s_dbl; unsigned char* g_dyn;
+
+void* thread_main(void* p) {
+    ThreadArg* ta = static_cast<ThreadArg*>(p);
+    threadIdx.x = ta->tid;
+    blockIdx.x = 0;
+    bm::docs_step_stream<NTHR>(ta->e->args, 0, g_s_int, g_s_dbl, g_dyn);
+    return nullptr;
+}
+
+}  // namespace
+
+extern "C" {
+
+// cd: det_thresh, iou_threshold, inertia, w_emb, alpha_fixed, aw_param, q_xy, q_s; ci: max_age, min_hits, delta_t, embedding_off, aw_off
+void* emu_docs_create(const double* cd, const int* ci, int cap, int nd, int dim) {
+    Emu* e = new Emu();
+    e->cap = cap; e->nd = nd; e->dim = dim;
+    bm::DocsConfigDev& c = e->args.cfg;
+    c.det_thresh = cd[0]; c.det_thresh_f32 = (float)cd[0]; c.iou_threshold = cd[1]; c.inertia = cd[2]; c.w_emb = cd[3];
+    c.alpha_fixed = cd[4]; c.aw_param = cd[5]; c.q_xy = cd[6]; c.q_s = cd[7];
+    c.max_age = ci[0]; c.min_hits = ci[1]; c.delta_t = ci[2]; c.embedding_off = ci[3]; c.aw_off = ci[4];
+    bm::DocsSizes z{1, cap, nd, dim};
+    bm::docs_allocate(e->args, z, e->alloc);
+    e->dets = e->alloc.get<float>((size_t)nd * bm::DET_COLS);
+    e->n_dets = e->alloc.get<int>(1);
+    e->embs = e->alloc.get<float>((size_t)nd * dim);
+    e->out = e->alloc.get<float>((size_t)cap * bm::OUT_COLS);
+    e->out_n = e->alloc.get<int>(1);
+    e->args.dets = e->dets; e->args.n_dets = e->n_dets; e->args.embs = e->embs;
+    e->args.out = e->out; e->args.out_n = e->out_n; e->args.stream_base = 0;
+    e->block.block_barrier.init(NTHR);
+    for (int w = 0; w < EMU_MAX_WAVES; ++w) e->block.wave_barrier[w].init(EMU_WAVE);
+    return e;
+}
+
+void emu_docs_destroy(void* h) {
+    Emu* e = static_cast<Emu*>(h);
+    for (void* p : e->alloc.owned) std::free(p);
+    delete e;
+}
+
+int emu_docs_update(void* h, const float* dets, int n, const float* embs, float* out, int* out_n) {
+    Emu* e = static_cast<Emu*>(h);
+    if (n > e->nd) return -1;
+    std::memcpy(e->dets, dets, (size_t)n * bm::DET_COLS * 4);
+    if (embs) std::memcpy(e->embs, embs, (size_t)n * e->dim * 4);
+    e->n_dets[0] = n;
+    static int s_int[bm::MAX_WAVES + 1];
+    static double s_dbl[bm::MAX_WAVES];
+    static std::vector<double> dyn;
+    dyn.assign((size_t)bm::docs_lap_lds_bytes(e->cap, e->nd) / 8 + 2, 0.0);
+    g_s_int = s_int; g_s_dbl = s_dbl; g_dyn = reinterpret_cast<unsigned char*>(dyn.data());
+    g_emu_block = &e->block;
+    blockDim.x = NTHR;
+    std::vector<pthread_t> th(NTHR);
+    std::vector<ThreadArg> ta(NTHR);
+    pthread_attr_t attr;
+    pthread_attr_init(&attr);
+    pthread_attr_setstacksize(&attr, 1 << 20);
+    for (int t = 0; t < NTHR; ++t) { ta[t] = ThreadArg{e, t}; pthread_create(&th[t], &attr, thread_main, &ta[t]); }
+    for (int t = 0; t < NTHR; ++t) pthread_join(th[t], nullptr);
+    pthread_attr_destroy(&attr);
+    *out_n = e->out_n[0];
+    std::memcpy(out, e->out, (size_t)e->out_n[0] * bm::OUT_COLS * 4);
+    return e->args.st.status[0];
+}
+
+// tracks in list order: ints (rows,5) = id, age, time_since_update, hit_streak, observed; kf (rows,72); emb (rows,dim)
+int emu_docs_dump(void* h, int* ints, double* kf, double* emb, int* counters) {
+    Emu* e = static_cast<Emu*>(h);
+    const bm::DocsState& st = e->args.st;
+    const int n = st.n_tracks[0];
+    for (int r = 0; r < n; ++r) {
+        const int sl = st.list[r];
+        int* o = ints + r * 5;
+        o[0] = st.id[sl]; o[1] = st.age[sl]; o[2] = st.tsu[sl]; o[3] = st.hit_streak[sl]; o[4] = st.observed[sl];
+        std::memcpy(kf + (size_t)r * bm::KF_STRIDE, st.kf + (size_t)sl * bm::KF_STRIDE, bm::KF_STRIDE * 8);
+        std::memcpy(emb + (size_t)r * e->dim, st.emb + (size_t)sl * e->dim, (size_t)e->dim * 8);
+    }
+    counters[0] = st.frame_count[0]; counters[1] = st.id_count[0];
+    return n;
+}
+
+}  // extern "C"

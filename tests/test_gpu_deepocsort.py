@@ -1,0 +1,87 @@
+"""GPU parity tests for DeepOCSORT: the HIP step, called through the C ABI, against the committed golden rows
+of the real reference and against the oracle on the same seeded inputs."""
+import numpy as np
+import pytest
+
+from common import DEEPOCSORT_CASES, assert_rows_match, deepocsort_golden_rows
+
+pytestmark = pytest.mark.gpu
+
+
+def _tracker(**kw):
+    from boxmot_amd.deepocsort import DeepOcSort
+    return DeepOcSort(cmc_off=True, **kw)
+
+
+def _check_state(trk, orc, embedding_off=False):
+    od, d = orc.dump(), trk.state_dump()
+    assert np.array_equal(d["ints"][:, 0], od["id"])
+    assert np.array_equal(d["ints"][:, 1], od["age"])
+    assert np.array_equal(d["ints"][:, 2], od["time_since_update"])
+    assert np.array_equal(d["ints"][:, 3], od["hit_streak"])
+    if d["n"]:
+        x = d["kf"][:, :7]
+        P = d["kf"][:, 8:].reshape(-1, 8, 8)[:, :7, :7]
+        assert np.allclose(x, od["x"], rtol=1e-9, atol=1e-9)
+        assert np.allclose(P, od["P"], rtol=1e-8, atol=1e-9)
+        if not embedding_off:
+            for r, emb in enumerate(od["emb"]):
+                assert np.abs(d["emb"][r] - emb).max() < 1e-6
+    assert d["id_count"] + 1 == od["count"]
+
+
+@pytest.mark.parametrize("name", list(DEEPOCSORT_CASES))
+def test_hip_deepocsort_matches_reference_golden_and_oracle(name):
+    from oracle.deepocsort import DeepOcSortOracle
+    make, hw, kw, dim = DEEPOCSORT_CASES[name]
+    frames = make()
+    want, g = deepocsort_golden_rows(name)
+    img = np.zeros((hw[0], hw[1], 3), dtype=np.uint8)
+    trk = _tracker(emb_dim=dim, max_tracks=512 if name == "docs_c2" else 256, max_dets=256, **kw)
+    orc = DeepOcSortOracle(**kw)
+    for t, (dets, embs) in enumerate(frames):
+        got = np.asarray(trk.update(dets, img, embs)).reshape(-1, 8)
+        assert_rows_match(got, want[t], t)                                            # reference (golden)
+        assert_rows_match(got, orc.update(dets, img, embs.copy()).reshape(-1, 8), t)   # oracle, same inputs
+    _check_state(trk, orc, embedding_off=kw.get("embedding_off", False))
+    assert np.array_equal(trk.state_dump()["ints"][:, 0], g[name + "_final_ids"])
+    trk.close()
+
+
+@pytest.mark.parametrize("seed", [22, 24, 28])
+def test_hip_deepocsort_tie_prone_scenes(seed):
+    """More detections than tracks with several optimal assignments: the oracle runs with the device solver's tie
+    rule (the reference's comes from lapx, which is unpinned), everything else is compared exactly."""
+    from boxmot_amd.scenario import stress_frames
+    from oracle.deepocsort import DeepOcSortOracle
+    img = np.zeros((480, 640, 3), dtype=np.uint8)
+    for kw in ({}, dict(max_age=8, min_hits=2, iou_threshold=0.2)):
+        trk, orc = _tracker(emb_dim=32, max_tracks=128, max_dets=64, **kw), DeepOcSortOracle(lap_rule="lowest_index", **kw)
+        for t, (dets, embs) in enumerate(stress_frames(120, seed=seed, max_objects=30)):
+            got = np.asarray(trk.update(dets, img, embs)).reshape(-1, 8)
+            assert_rows_match(got, orc.update(dets, img, embs.copy()).reshape(-1, 8), t)
+        _check_state(trk, orc)
+        trk.close()
+
+
+def test_deepocsort_surface_and_edge_inputs():
+    from boxmot_amd import create_tracker
+    from boxmot_amd.deepocsort import DeepOcSort
+    from boxmot_amd.track_results import TrackResults
+    with pytest.raises(NotImplementedError):
+        DeepOcSort()                                   # reference default cmc_off=False
+    trk = create_tracker("deepocsort", cmc_off=True, embedding_off=True, max_tracks=64, max_dets=32)
+    img = np.zeros((240, 320, 3), dtype=np.uint8)
+    out = trk.update(np.empty((0, 6), dtype=np.float32), img)
+    assert isinstance(out, TrackResults) and out.shape == (0, 0)          # deepocsort.py:490-492
+    out = trk.update(None, img)
+    assert out.shape == (0, 0)
+    d = np.array([[10, 10, 60, 110, 0.9, 0], [100, 50, 150, 160, 0.2, 1]], dtype=np.float32)
+    out = trk.update(d, img)
+    assert out.shape == (1, 8) and out[0, 4] == 1 and out[0, 7] == 0       # below det_thresh is dropped; ids start at 1
+    with pytest.raises(AssertionError):
+        trk.update(np.zeros((2, 5), dtype=np.float32), img)
+    trk.reset()
+    out = trk.update(d, img)
+    assert out[0, 4] == 1
+    trk.close()
