@@ -89,6 +89,25 @@ def load_deepocsort():
     return DeepOcSort
 
 
+def load_strongsort():
+    """Return the reference StrongSort class.  Tracks start Confirmed when GITHUB_ACTIONS == "true"
+    (sort/track.py:91-98), so that variable is cleared first."""
+    import os
+
+    os.environ.pop("GITHUB_ACTIONS", None)
+    install_standins()
+    from boxmot.trackers.bbox.strongsort.strongsort import StrongSort
+
+    return StrongSort
+
+
+class IdentityCMC:
+    """Stands where StrongSort's unconditional ECC object stands (strongsort.py:67): no camera motion."""
+
+    def apply(self, img, dets):
+        return np.eye(2, 3)
+
+
 def load_osnet_module():
     """Load boxmot/reid/backbones/osnet.py by path (``boxmot.reid`` itself cannot import)."""
     install_standins()

@@ -1,0 +1,319 @@
+"""CPU restatement of the reference StrongSORT update path -- TEST INFRASTRUCTURE ONLY.
+
+Follows (statement order and NumPy / SciPy / torch calls kept, so results are bit-identical on one host):
+  * boxmot/trackers/bbox/strongsort/strongsort.py:69-123 (StrongSort._update_impl);
+  * strongsort/sort/tracker.py:63-169 (Tracker.predict / update / _match / _initiate_track);
+  * strongsort/sort/track.py:25-208 (Track: camera_update, predict, update, mark_missed, EMA feature);
+  * strongsort/sort/linear_assignment.py:14-79 (min_cost_matching, SciPy LSA), :82-142 (matching_cascade),
+    :145-198 (gate_cost_matrix), :201-284 (_cosine_distance, _nn_cosine_distance), :286-353
+    (NearestNeighborDistanceMetric, per-target sample bank with budget);
+  * strongsort/sort/iou_matching.py:10-87 (iou, iou_cost); sort/detection.py (to_xyah);
+  * motion/kalman_filters/xyah.py:8-172 over base.py:234-355, :523-551 (initiate / predict / project with the
+    NSA confidence scaling / update / gating_distance).
+Pinned against the reference classes themselves (tests/test_oracle_vs_reference.py, tests/golden/strongsort_golden.npz);
+the assignment is the real ``scipy.optimize.linear_sum_assignment`` here, so this oracle has no unpinned part.
+The reference applies its ECC camera-motion object unconditionally; the oracle takes the 2x3 warp as an argument
+(identity by default), which is what the reference computes with an identity estimator injected.
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.linalg
+import torch
+from scipy.optimize import linear_sum_assignment
+
+DEFAULTS = dict(
+    max_age=30,                                                               # basetracker.py:19-31
+    min_conf=0.1, max_cos_dist=0.2, max_iou_dist=0.7, n_init=3, nn_budget=100, mc_lambda=0.98, ema_alpha=0.9,
+)
+INFTY_COST = 1e5
+CHI2_4 = 9.4877
+TENTATIVE, CONFIRMED, DELETED = 1, 2, 3
+STD_POS, STD_VEL = 1.0 / 20, 1.0 / 160
+
+_F = np.eye(8)
+for _i in range(4):
+    _F[_i, 4 + _i] = 1.0
+_H = np.eye(4, 8)
+
+
+# ---- KalmanFilterXYAH (stateless use) ----
+def kf_initiate(z):
+    z = np.asarray(z, dtype=float).copy()
+    mean = np.r_[z, np.zeros_like(z)]
+    std = [2 * STD_POS * z[3], 2 * STD_POS * z[3], 1e-2, 2 * STD_POS * z[3],
+           10 * STD_VEL * z[3], 10 * STD_VEL * z[3], 1e-5, 10 * STD_VEL * z[3]]
+    cov = np.diag(np.square(std))
+    mean[2] = max(float(mean[2]), 1e-4)
+    mean[3] = max(float(mean[3]), 1e-4)
+    return mean, cov
+
+
+def kf_predict(mean, cov):
+    std_pos = [STD_POS * mean[3], STD_POS * mean[3], 1e-2, STD_POS * mean[3]]
+    std_vel = [STD_VEL * mean[3], STD_VEL * mean[3], 1e-5, STD_VEL * mean[3]]
+    motion_cov = np.diag(np.square(np.r_[std_pos, std_vel]))
+    mean = np.dot(mean, _F.T)
+    cov = np.linalg.multi_dot((_F, cov, _F.T)) + motion_cov
+    mean[2] = max(float(mean[2]), 1e-4)
+    mean[3] = max(float(mean[3]), 1e-4)
+    return mean, cov
+
+
+def kf_project(mean, cov, confidence=0.0):
+    std = [STD_POS * mean[3], STD_POS * mean[3], 1e-1, STD_POS * mean[3]]
+    std = [(1 - confidence) * x for x in std]
+    innovation_cov = np.diag(np.square(std))
+    return np.dot(_H, mean), np.linalg.multi_dot((_H, cov, _H.T)) + innovation_cov
+
+
+def kf_update(mean, cov, z, confidence):
+    pm, pc = kf_project(mean, cov, confidence)
+    cf, lower = scipy.linalg.cho_factor(pc, lower=True, check_finite=False)
+    K = scipy.linalg.cho_solve((cf, lower), np.dot(cov, _H.T).T, check_finite=False).T
+    new_mean = mean + np.dot(z - pm, K.T)
+    new_cov = cov - np.linalg.multi_dot((K, pc, K.T))
+    new_mean[2] = max(float(new_mean[2]), 1e-4)
+    new_mean[3] = max(float(new_mean[3]), 1e-4)
+    return new_mean, new_cov
+
+
+def kf_gating_distance(mean, cov, measurements):
+    pm, pc = kf_project(mean, cov)
+    d = measurements - pm
+    L = np.linalg.cholesky(pc)
+    z = scipy.linalg.solve_triangular(L, d.T, lower=True, check_finite=False, overwrite_b=True)
+    return np.sum(z * z, axis=0)
+
+
+class _Det:
+    def __init__(self, tlwh, conf, cls, det_ind, feat):
+        self.tlwh, self.conf, self.cls, self.det_ind, self.feat = tlwh, conf, cls, det_ind, feat
+
+    def to_xyah(self):
+        ret = self.tlwh.copy()
+        ret[:2] += ret[2:] / 2
+        ret[2] /= ret[3]
+        return ret
+
+
+class _Track:
+    def __init__(self, det, tid, n_init, max_age, ema_alpha):
+        self.id = tid
+        self.conf, self.cls, self.det_ind = det.conf, det.cls, det.det_ind
+        self.hits = self.age = 1
+        self.time_since_update = 0
+        self.ema_alpha = ema_alpha
+        self.state = TENTATIVE                      # GITHUB_ACTIONS unset (track.py:91-98)
+        self.features = []
+        if det.feat is not None:
+            det.feat /= np.linalg.norm(det.feat)
+            self.features.append(det.feat)
+        self.n_init, self.max_age = n_init, max_age
+        self.mean, self.cov = kf_initiate(det.to_xyah())
+
+    def to_tlwh(self):
+        ret = self.mean[:4].copy()
+        ret[2] *= ret[3]
+        ret[:2] -= ret[2:] / 2
+        return ret
+
+    def to_tlbr(self):
+        ret = self.to_tlwh()
+        ret[2:] = ret[:2] + ret[2:]
+        return ret
+
+    def camera_update(self, warp):                  # track.py:139-148
+        a, b = warp
+        m = np.array([a, b, [0, 0, 1]]).tolist()
+        x1, y1, x2, y2 = self.to_tlbr()
+        x1_, y1_, _ = m @ np.array([x1, y1, 1]).T
+        x2_, y2_, _ = m @ np.array([x2, y2, 1]).T
+        w, h = x2_ - x1_, y2_ - y1_
+        cx, cy = x1_ + w / 2, y1_ + h / 2
+        self.mean[:4] = [cx, cy, w / h, h]
+
+    def predict(self):
+        self.mean, self.cov = kf_predict(self.mean, self.cov)
+        self.age += 1
+        self.time_since_update += 1
+
+    def update(self, det):
+        self.conf, self.cls, self.det_ind = det.conf, det.cls, det.det_ind
+        self.mean, self.cov = kf_update(self.mean, self.cov, det.to_xyah(), self.conf)
+        feature = det.feat / np.linalg.norm(det.feat)
+        smooth = self.ema_alpha * self.features[-1] + (1 - self.ema_alpha) * feature
+        smooth /= np.linalg.norm(smooth)
+        self.features = [smooth]
+        self.hits += 1
+        self.time_since_update = 0
+        if self.state == TENTATIVE and self.hits >= self.n_init:
+            self.state = CONFIRMED
+
+    def mark_missed(self):
+        if self.state == TENTATIVE:
+            self.state = DELETED
+        elif self.time_since_update > self.max_age:
+            self.state = DELETED
+
+
+def _cosine_distance(a, b):                         # linear_assignment.py:201-220 (data_is_normalized=False)
+    a = np.asarray(a) / np.linalg.norm(a, axis=1, keepdims=True)
+    b = np.asarray(b) / np.linalg.norm(b, axis=1, keepdims=True)
+    return 1.0 - np.dot(a, b.T)
+
+
+def _nn_cosine_distance(x, y):                      # :266-284
+    x_ = torch.from_numpy(np.asarray(x))
+    y_ = torch.from_numpy(np.asarray(y))
+    return _cosine_distance(x_, y_).min(axis=0)
+
+
+def iou_tlwh(bbox, candidates):                     # iou_matching.py:10-46
+    bbox_tl, bbox_br = bbox[:2], bbox[:2] + bbox[2:]
+    c_tl, c_br = candidates[:, :2], candidates[:, :2] + candidates[:, 2:]
+    tl = np.c_[np.maximum(bbox_tl[0], c_tl[:, 0])[:, np.newaxis], np.maximum(bbox_tl[1], c_tl[:, 1])[:, np.newaxis]]
+    br = np.c_[np.minimum(bbox_br[0], c_br[:, 0])[:, np.newaxis], np.minimum(bbox_br[1], c_br[:, 1])[:, np.newaxis]]
+    wh = np.maximum(0.0, br - tl)
+    inter = wh.prod(axis=1)
+    return inter / (bbox[2:].prod() + candidates[:, 2:].prod(axis=1) - inter)
+
+
+class StrongSortOracle:
+    def __init__(self, reid=None, **kw):
+        cfg = dict(DEFAULTS)
+        unknown = set(kw) - set(cfg)
+        if unknown:
+            raise TypeError(f"unknown StrongSORT options: {sorted(unknown)}")
+        cfg.update(kw)
+        self.cfg = cfg
+        self.reid = reid
+        self.tracks = []
+        self.next_id = 1
+        self.samples = {}
+        self.frame_count = 0
+
+    # ---- association ----
+    def _min_cost_matching(self, metric, max_distance, tracks, dets, track_idx, det_idx):   # :14-79
+        if len(det_idx) == 0 or len(track_idx) == 0:
+            return [], track_idx, det_idx
+        cost = metric(tracks, dets, track_idx, det_idx)
+        cost[cost > max_distance] = max_distance + 1e-5
+        rows, cols = linear_sum_assignment(cost)
+        matches, un_t, un_d = [], [], []
+        for col, d in enumerate(det_idx):
+            if col not in cols:
+                un_d.append(d)
+        for row, t in enumerate(track_idx):
+            if row not in rows:
+                un_t.append(t)
+        for row, col in zip(rows, cols):
+            t, d = track_idx[row], det_idx[col]
+            if cost[row, col] > max_distance:
+                un_t.append(t)
+                un_d.append(d)
+            else:
+                matches.append((t, d))
+        self.last_cost = cost
+        return matches, un_t, un_d
+
+    def _gated_metric(self, tracks, dets, track_idx, det_idx):       # tracker.py:110-125, linear_assignment.py:145-198
+        feats = np.array([dets[i].feat for i in det_idx])
+        cost = np.zeros((len(track_idx), len(feats)))
+        for i, t in enumerate(track_idx):
+            cost[i, :] = _nn_cosine_distance(self.samples[tracks[t].id], feats)
+        meas = np.asarray([dets[i].to_xyah() for i in det_idx])
+        for row, t in enumerate(track_idx):
+            gd = kf_gating_distance(tracks[t].mean, tracks[t].cov, meas)
+            cost[row, gd > CHI2_4] = INFTY_COST
+            cost[row] = self.cfg["mc_lambda"] * cost[row] + (1 - self.cfg["mc_lambda"]) * gd
+        return cost
+
+    @staticmethod
+    def _iou_cost(tracks, dets, track_idx, det_idx):                  # iou_matching.py:49-87
+        cost = np.zeros((len(track_idx), len(det_idx)))
+        for row, t in enumerate(track_idx):
+            if tracks[t].time_since_update > 1:
+                cost[row, :] = INFTY_COST
+                continue
+            cand = np.asarray([dets[i].tlwh for i in det_idx])
+            cost[row, :] = 1.0 - iou_tlwh(tracks[t].to_tlwh(), cand)
+        return cost
+
+    def update(self, dets, img=None, embs=None, warp=None):
+        """dets (N,6) [x1,y1,x2,y2,conf,cls] -> (M,8) fp32 rows (what ``StrongSort.update`` hands back)."""
+        c = self.cfg
+        self.frame_count += 1
+        dets = np.asarray(dets)
+        if dets.size == 0:
+            dets = np.empty((0, 7), dtype=np.float32)
+        else:
+            dets = np.hstack([dets, np.arange(len(dets), dtype=np.int32).reshape(-1, 1)])
+        keep = dets[:, 4] >= c["min_conf"]
+        dets = dets[keep]
+        xyxy, confs, clss, det_ind = dets[:, :4], dets[:, 4], dets[:, 5], dets[:, 6]
+        if len(self.tracks) >= 1:
+            w = np.eye(2, 3) if warp is None else warp
+            for t in self.tracks:
+                t.camera_update(w)
+        feats = embs[keep] if embs is not None else self.reid.get_features(xyxy, img)
+        tlwh = np.copy(xyxy)
+        tlwh[..., 2] = xyxy[..., 2] - xyxy[..., 0]
+        tlwh[..., 3] = xyxy[..., 3] - xyxy[..., 1]
+        D = [_Det(b, cf, cl, di, f) for b, cf, cl, di, f in zip(tlwh, confs, clss, det_ind, feats)]
+
+        for t in self.tracks:
+            t.predict()
+        # ---- Tracker.update ----
+        tracks = self.tracks
+        confirmed = [i for i, t in enumerate(tracks) if t.state == CONFIRMED]
+        unconfirmed = [i for i, t in enumerate(tracks) if t.state != CONFIRMED]
+        matches_a, _, un_d = self._min_cost_matching(self._gated_metric, c["max_cos_dist"], tracks, D, list(confirmed),
+                                                     list(range(len(D))))
+        un_t_a = list(set(confirmed) - set(k for k, _ in matches_a))
+        iou_cand = unconfirmed + [k for k in un_t_a if tracks[k].time_since_update == 1]
+        un_t_a = [k for k in un_t_a if tracks[k].time_since_update != 1]
+        matches_b, un_t_b, un_d = self._min_cost_matching(self._iou_cost, c["max_iou_dist"], tracks, D, iou_cand, un_d)
+        matches = matches_a + matches_b
+        un_t = list(set(un_t_a + un_t_b))
+        for ti, di in matches:
+            tracks[ti].update(D[di])
+        for ti in un_t:
+            tracks[ti].mark_missed()
+        for di in un_d:
+            tracks.append(_Track(D[di], self.next_id, c["n_init"], c["max_age"], c["ema_alpha"]))
+            self.next_id += 1
+        self.tracks = tracks = [t for t in tracks if t.state != DELETED]
+        active = [t.id for t in tracks if t.state == CONFIRMED]
+        for t in tracks:
+            if t.state != CONFIRMED:
+                continue
+            for f in t.features:
+                self.samples.setdefault(t.id, []).append(f)
+                if c["nn_budget"] is not None:
+                    self.samples[t.id] = self.samples[t.id][-c["nn_budget"]:]
+        self.samples = {k: self.samples[k] for k in active}
+
+        out = []
+        for t in tracks:
+            if t.state != CONFIRMED or t.time_since_update >= 1:
+                continue
+            x1, y1, x2, y2 = t.to_tlbr()
+            out.append(np.concatenate(([x1, y1, x2, y2], [t.id], [t.conf], [t.cls], [t.det_ind])).reshape(1, -1))
+        raw = np.concatenate(out) if out else np.empty((0, 8), dtype=float)
+        return np.asarray(raw, dtype=np.float32)
+
+    def dump(self):
+        t = self.tracks
+        return {
+            "id": np.array([k.id for k in t], dtype=np.int64),
+            "state": np.array([k.state for k in t], dtype=np.int64),
+            "hits": np.array([k.hits for k in t], dtype=np.int64),
+            "age": np.array([k.age for k in t], dtype=np.int64),
+            "time_since_update": np.array([k.time_since_update for k in t], dtype=np.int64),
+            "mean": np.array([k.mean for k in t], dtype=np.float64).reshape(len(t), 8),
+            "cov": np.array([k.cov for k in t], dtype=np.float64).reshape(len(t), 8, 8),
+            "feat": [np.asarray(k.features[-1]) for k in t],
+            "bank": {k: len(v) for k, v in self.samples.items()},
+            "next_id": self.next_id,
+        }

@@ -53,3 +53,20 @@ def deepocsort_golden_rows(name):
     rows, counts = g[name + "_rows"], g[name + "_counts"]
     offs = np.concatenate([[0], np.cumsum(counts)])
     return [rows[offs[i]:offs[i + 1]] for i in range(len(counts))], g
+
+
+STRONGSORT_CASES = {
+    # keep in step with tests/golden/make_golden.py
+    "ss_stress_default": (lambda: stress_frames(150, seed=7), (480, 640), {}, 32),
+    "ss_stress_short": (lambda: stress_frames(150, seed=11), (480, 640), dict(max_age=5, n_init=1, nn_budget=3), 32),
+    "ss_stress_loose": (lambda: stress_frames(120, seed=3), (480, 640),
+                        dict(max_cos_dist=0.4, max_iou_dist=0.9, mc_lambda=0.9, ema_alpha=0.8, min_conf=0.3), 32),
+    "ss_c2": (lambda: Scenario(64, 256, emb_dim=128, random_image=False).frames(30), (1080, 1920), {}, 128),
+}
+
+
+def strongsort_golden_rows(name):
+    g = np.load(GOLDEN / "strongsort_golden.npz")
+    rows, counts = g[name + "_rows"], g[name + "_counts"]
+    offs = np.concatenate([[0], np.cumsum(counts)])
+    return [rows[offs[i]:offs[i + 1]] for i in range(len(counts))], g

@@ -7,6 +7,7 @@ Outputs (small, committed):
                                    scenarios (inputs are regenerated from the seed by the tests)
   tests/golden/botsort_warp_golden.npz   the same with a scheduled camera-motion warp (STrack.multi_gmc)
   tests/golden/deepocsort_golden.npz     per-frame rows + final Kalman state of the reference DeepOcSort
+  tests/golden/strongsort_golden.npz     the same for the reference StrongSort (identity camera motion)
   tests/golden/reid_golden.npz     a seeded OSNet-x0.25 state_dict, test boxes, and the reference
                                    BaseModelBackend.get_features / get_crops results for them
 The lap / cv2 stand-ins make those two boundaries "parity unpinned" (see oracle/__init__.py).
@@ -115,6 +116,41 @@ def deepocsort_golden():
     np.savez_compressed(OUT / "deepocsort_golden.npz", **out)
 
 
+STRONGSORT_CASES = {
+    "ss_stress_default": (lambda: stress_frames(150, seed=7), (480, 640), {}),
+    "ss_stress_short": (lambda: stress_frames(150, seed=11), (480, 640), dict(max_age=5, n_init=1, nn_budget=3)),
+    "ss_stress_loose": (lambda: stress_frames(120, seed=3), (480, 640),
+                        dict(max_cos_dist=0.4, max_iou_dist=0.9, mc_lambda=0.9, ema_alpha=0.8, min_conf=0.3)),
+    "ss_c2": (lambda: Scenario(64, 256, emb_dim=128, random_image=False).frames(30), (1080, 1920), {}),
+}
+
+
+def strongsort_golden():
+    """strongsort_golden.npz: the reference StrongSort with an identity camera-motion object (its ECC estimator is
+    unconditional, strongsort.py:67,83-86), embeddings supplied, on seeded scenarios."""
+    logging.disable(logging.CRITICAL)
+    StrongSort = ref_harness.load_strongsort()
+    out = {}
+    for name, (make, hw, kw) in STRONGSORT_CASES.items():
+        frames = make()
+        img = np.zeros((hw[0], hw[1], 3), dtype=np.uint8)
+        trk = StrongSort(reid_model=None, **kw)
+        trk.cmc = ref_harness.IdentityCMC()
+        rows, counts = [], []
+        for dets, embs in frames:
+            r = np.asarray(trk.update(dets.copy(), img, embs.copy()), dtype=np.float32).reshape(-1, 8)
+            rows.append(r)
+            counts.append(len(r))
+        out[name + "_rows"] = np.concatenate(rows, 0)
+        out[name + "_counts"] = np.array(counts, dtype=np.int32)
+        act = trk.tracker.tracks
+        out[name + "_final_mean"] = np.array([t.mean for t in act], dtype=np.float64).reshape(len(act), 8)
+        out[name + "_final_cov"] = np.array([t.covariance for t in act], dtype=np.float64).reshape(len(act), 8, 8)
+        out[name + "_final_ids"] = np.array([t.id for t in act], dtype=np.int64)
+        print(name, "frames", len(frames), "rows", sum(counts), "tracks", len(act))
+    np.savez_compressed(OUT / "strongsort_golden.npz", **out)
+
+
 def main():
     logging.disable(logging.CRITICAL)
     BotSort = ref_harness.load_botsort()
@@ -160,7 +196,10 @@ if __name__ == "__main__":
         warp_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "deepocsort":
         deepocsort_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "strongsort":
+        strongsort_golden()
     else:
         main()
         warp_golden()
         deepocsort_golden()
+        strongsort_golden()

@@ -69,6 +69,27 @@ def test_deepocsort_oracle_matches_reference_rows(name):
         assert np.array_equal(d["P"], g[name + "_final_P"])
 
 
+@pytest.mark.parametrize("name", ["ss_stress_default", "ss_stress_short", "ss_stress_loose", "ss_c2"])
+def test_strongsort_oracle_matches_reference_rows(name):
+    from common import STRONGSORT_CASES, strongsort_golden_rows
+    from oracle.strongsort import StrongSortOracle
+    make, hw, kw, _ = STRONGSORT_CASES[name]
+    frames = make()
+    want, g = strongsort_golden_rows(name)
+    if name == "ss_c2":
+        frames = frames[:8]
+    orc = StrongSortOracle(**kw)
+    for t, (dets, embs) in enumerate(frames):
+        got = orc.update(dets, None, embs.copy())
+        assert got.dtype == np.float32
+        assert np.array_equal(got.reshape(-1, 8), want[t]), f"{name} frame {t}"
+    if len(frames) == len(want):
+        d = orc.dump()
+        assert np.array_equal(d["id"], g[name + "_final_ids"])
+        assert np.array_equal(d["mean"], g[name + "_final_mean"])
+        assert np.array_equal(d["cov"], g[name + "_final_cov"])
+
+
 def test_oracle_reid_matches_reference_features():
     import torch
 

@@ -47,6 +47,26 @@ def test_deepocsort_oracle_bit_exact_incl_kalman_state():
             assert np.array_equal(k.kf.x[:, 0], x) and np.array_equal(k.kf.P, P)
 
 
+def test_strongsort_oracle_bit_exact_incl_kalman_state():
+    from boxmot_amd.scenario import stress_frames
+    from oracle.strongsort import StrongSortOracle
+
+    logging.disable(logging.CRITICAL)
+    StrongSort = ref_harness.load_strongsort()
+    img = np.zeros((480, 640, 3), np.uint8)
+    for kw in ({}, dict(max_age=5, n_init=1, nn_budget=3), dict(max_cos_dist=0.4, max_iou_dist=0.9, mc_lambda=0.9, ema_alpha=0.8)):
+        ref, orc = StrongSort(reid_model=None, **kw), StrongSortOracle(**kw)
+        ref.cmc = ref_harness.IdentityCMC()
+        for t, (d, e) in enumerate(stress_frames(100, seed=3)):
+            r = np.asarray(ref.update(d.copy(), img, e.copy()))
+            o = orc.update(d.copy(), img, e.copy())
+            assert r.shape == o.shape and np.array_equal(r, o), (kw, t)
+        dd = orc.dump()
+        assert [k.id for k in ref.tracker.tracks] == list(dd["id"])
+        for k, m, P in zip(ref.tracker.tracks, dd["mean"], dd["cov"]):
+            assert np.array_equal(k.mean, m) and np.array_equal(k.covariance, P)
+
+
 def test_osnet_functional_equals_reference_module():
     import torch
 
