@@ -76,6 +76,26 @@ class DeepOcSortConfig(ctypes.Structure):
     ]
 
 
+class StrongSortConfig(ctypes.Structure):
+    """``BoxMOTHipStrongSortConfig`` (include/boxmot_hip.h)."""
+
+    _fields_ = [
+        ("max_age", ctypes.c_int),
+        ("min_conf", ctypes.c_double),
+        ("max_cos_dist", ctypes.c_double),
+        ("max_iou_dist", ctypes.c_double),
+        ("n_init", ctypes.c_int),
+        ("nn_budget", ctypes.c_int),
+        ("mc_lambda", ctypes.c_double),
+        ("ema_alpha", ctypes.c_double),
+        ("reid_model_path", ctypes.c_char_p),
+        ("n_streams", ctypes.c_int),
+        ("max_tracks", ctypes.c_int),
+        ("max_dets", ctypes.c_int),
+        ("emb_dim", ctypes.c_int),
+    ]
+
+
 # every symbol include/boxmot_hip.h declares: (name, restype, argtypes)
 _VP = ctypes.c_void_p
 _I = ctypes.c_int
@@ -112,6 +132,14 @@ SIGNATURES = {
     "boxmot_hip_deepocsort_update": (_I, [_VP, _VP, _I, _I, _VP, _I, _I, _VP, _I, _I, _I, _VP, _I, _I, c_int_p, c_int_p]),
     "boxmot_hip_deepocsort_update_batch": (_I, [_VP, _I, _VP, _VP, _VP, _I, _VP, _I, _I, _I, _VP, _I, _VP]),
     "boxmot_hip_deepocsort_state_dump": (_I, [_VP, _I, _VP, _VP, _VP, c_int_p, c_int_p, c_int_p]),
+    "boxmot_hip_strongsort_default_config": (None, [ctypes.POINTER(StrongSortConfig)]),
+    "boxmot_hip_strongsort_create": (_VP, [ctypes.POINTER(StrongSortConfig)]),
+    "boxmot_hip_strongsort_destroy": (None, [_VP]),
+    "boxmot_hip_strongsort_reset": (_I, [_VP]),
+    "boxmot_hip_strongsort_set_warp": (_I, [_VP, _I, _VP]),
+    "boxmot_hip_strongsort_update": (_I, [_VP, _VP, _I, _I, _VP, _I, _I, _VP, _I, _I, _I, _VP, _I, _I, c_int_p, c_int_p]),
+    "boxmot_hip_strongsort_update_batch": (_I, [_VP, _I, _VP, _VP, _VP, _I, _VP, _I, _I, _I, _VP, _I, _VP]),
+    "boxmot_hip_strongsort_state_dump": (_I, [_VP, _I, _VP, _VP, _VP, c_int_p, c_int_p, c_int_p]),
     "boxmot_hip_reid_create": (_VP, [ctypes.c_char_p, _VP, ctypes.c_long, _I]),
     "boxmot_hip_reid_destroy": (None, [_VP]),
     "boxmot_hip_reid_feature_dim": (_I, [_VP]),

@@ -16,6 +16,7 @@
 #include "botsort_alloc.hpp"
 #include "botsort_step.hpp"
 #include "deepocsort_step.hpp"
+#include "strongsort_step.hpp"
 #include "reid_engine.hpp"
 
 namespace {
@@ -56,11 +57,26 @@ __global__ void __launch_bounds__(NTHR) deepocsort_step_kernel(bm::DocsStepArgs 
     bm::docs_step_stream<NTHR>(args, args.stream_base + blockIdx.x, s_int, s_dbl, dyn_lds);
 }
 
+template <int NTHR>
+__global__ void __launch_bounds__(NTHR) strongsort_bank_kernel(bm::SsStepArgs args) {
+    __shared__ float s_vec[2048];
+    __shared__ float s_red[bm::MAX_WAVES];
+    bm::ss_bank_distance_block<NTHR>(args, args.stream_base + blockIdx.y, blockIdx.x, s_vec, s_red);
+}
+
+template <int NTHR>
+__global__ void __launch_bounds__(NTHR) strongsort_step_kernel(bm::SsStepArgs args) {
+    __shared__ int s_int[bm::MAX_WAVES + 1];
+    __shared__ double s_dbl[bm::MAX_WAVES];
+    BM_DYNAMIC_LDS_T(unsigned char, dyn_lds);       // assignment-solver state, ss_lsa_lds_bytes(max(cap, max_dets))
+    bm::ss_step_stream<NTHR>(args, args.stream_base + blockIdx.x, s_int, s_dbl, dyn_lds);
+}
+
 // Build the ReID crop list on the device: every detection with conf > track_high_thresh
 // (botsort.py:191-192, :260).  One workgroup per stream; ranges reserved with one atomic.
 __global__ void build_crop_list_kernel(const float* dets, const int* n_dets, int max_dets, double high,
                                        int* crop_count, int* crop_stream, float* crop_boxes, int* crop_row,
-                                       int stream_base) {
+                                       int stream_base, int inclusive = 0) {
     __shared__ int s_base;
     __shared__ int s_cnt;
     const int s = stream_base + blockIdx.x;
@@ -69,15 +85,16 @@ __global__ void build_crop_list_kernel(const float* dets, const int* n_dets, int
     __syncthreads();
     const float* d = dets + (long)s * max_dets * bm::DET_COLS;
     int mine = 0;
+    auto pass = [&](int j) { const double cf = (double)d[j * bm::DET_COLS + 4]; return inclusive ? cf >= high : cf > high; };
     for (int j = threadIdx.x; j < n; j += blockDim.x)
-        if ((double)d[j * bm::DET_COLS + 4] > high) ++mine;
+        if (pass(j)) ++mine;
     const int local = atomicAdd(&s_cnt, mine);
     __syncthreads();
     if (threadIdx.x == 0) s_base = atomicAdd(crop_count, s_cnt);
     __syncthreads();
     int k = s_base + local;
     for (int j = threadIdx.x; j < n; j += blockDim.x) {
-        if ((double)d[j * bm::DET_COLS + 4] > high) {
+        if (pass(j)) {
             crop_stream[k] = s;
             crop_row[k] = s * max_dets + j;
             for (int q = 0; q < 4; ++q) crop_boxes[k * 4 + q] = d[j * bm::DET_COLS + q];
@@ -170,6 +187,32 @@ struct BoxMOTHipDeepOcSort {
     std::unique_ptr<bm::ReidEngine> reid;
     int* d_crop_count = nullptr; int* d_crop_stream = nullptr; float* d_crop_boxes = nullptr; int* d_crop_row = nullptr;
     ~BoxMOTHipDeepOcSort() {
+        reid.reset();
+        for (void* p : owned) (void)hipFree(p);
+        for (auto* p : frame_bufs) if (p) (void)hipFree(p);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+struct BoxMOTHipStrongSort {
+    BoxMOTHipStrongSortConfig cfg{};
+    std::string reid_path;
+    bm::SsStepArgs args{};
+    std::vector<void*> owned;
+    hipStream_t stream = nullptr;
+    int S = 1, cap = 0, nd = 0, dim = 0;
+    float* d_dets = nullptr; int* d_ndets = nullptr; float* d_embs = nullptr; float* d_out = nullptr; int* d_out_n = nullptr;
+    double* d_warp = nullptr;
+    std::vector<float> h_dets, h_out;
+    std::vector<int> h_ndets, h_out_n, h_warp_flag;
+    std::vector<double> h_warp;
+    std::vector<uint8_t*> frame_bufs;
+    size_t frame_bytes = 0;
+    int frame_rows = 0, frame_cols = 0;
+    const uint8_t** d_frames = nullptr;
+    std::unique_ptr<bm::ReidEngine> reid;
+    int* d_crop_count = nullptr; int* d_crop_stream = nullptr; float* d_crop_boxes = nullptr; int* d_crop_row = nullptr;
+    ~BoxMOTHipStrongSort() {
         reid.reset();
         for (void* p : owned) (void)hipFree(p);
         for (auto* p : frame_bufs) if (p) (void)hipFree(p);
@@ -571,6 +614,163 @@ void docs_host_update(BoxMOTHipDeepOcSort* h, int n, const StreamIn* in, int det
             throw std::runtime_error("boxmot_hip: DeepOCSORT stream " + std::to_string(k) + ": " +
                                      (st[k] == bm::STATUS_TRACK_CAPACITY ? "track capacity (max_tracks) exceeded"
                                       : st[k] == bm::STATUS_LAP_STALL ? "assignment solver did not converge (non-finite costs?)"
+                                                                      : "innovation covariance is not positive definite"));
+    for (int k = 0; k < n; ++k) {
+        const int rows = h->h_out_n[k];
+        if (rows > out_capacity_rows) throw std::runtime_error("boxmot_hip: output buffer is too small for the current frame.");
+        if (rows) BM_HIP(hipMemcpy(h->h_out.data(), h->d_out + (size_t)k * cap * bm::OUT_COLS, (size_t)rows * bm::OUT_COLS * 4, hipMemcpyDeviceToHost));
+        for (int r = 0; r < rows; ++r) {
+            float* dst = out[k] + (size_t)r * 9;
+            for (int q = 0; q < 8; ++q) dst[q] = h->h_out[(size_t)r * bm::OUT_COLS + q];
+            dst[8] = 0.0f;
+        }
+        out_rows[k] = rows;
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// StrongSORT host path
+// ---------------------------------------------------------------------------
+constexpr int SS_BANK_THREADS = 256;
+
+void ss_zero_state(BoxMOTHipStrongSort* h) {
+    bm::SsState& st = h->args.st;
+    const size_t S = h->S, cap = h->cap;
+    std::vector<int> ones(S, 1);
+    BM_HIP(hipMemsetAsync(st.frame_count, 0, S * 4, h->stream));
+    BM_HIP(hipMemcpyAsync(st.next_id, ones.data(), S * 4, hipMemcpyHostToDevice, h->stream));     // Tracker._next_id = 1, tracker.py:59
+    BM_HIP(hipMemsetAsync(st.n_tracks, 0, S * 4, h->stream));
+    BM_HIP(hipMemsetAsync(st.status, 0, S * 4, h->stream));
+    BM_HIP(hipMemsetAsync(st.slot_used, 0, S * cap * 4, h->stream));
+    BM_HIP(hipStreamSynchronize(h->stream));
+}
+
+void ss_build(BoxMOTHipStrongSort* h) {
+    const BoxMOTHipStrongSortConfig& c = h->cfg;
+    if (c.n_streams < 1 || c.max_tracks < 8 || c.max_dets < 4 || c.emb_dim < 1 || c.emb_dim > 2048)
+        throw std::runtime_error("boxmot_hip: invalid capacity configuration");
+    if (c.max_dets > 4 * SS_BANK_THREADS) throw std::runtime_error("boxmot_hip: StrongSORT max_dets must be <= 1024");
+    if (c.nn_budget < 1 || c.nn_budget > 1024) throw std::runtime_error("boxmot_hip: StrongSORT nn_budget must be in [1, 1024] (None is not supported)");
+    if (c.n_init < 1 || c.max_age < 0) throw std::runtime_error("boxmot_hip: invalid n_init / max_age");
+    h->S = c.n_streams; h->cap = c.max_tracks; h->nd = c.max_dets; h->dim = c.emb_dim;
+    BM_HIP(hipStreamCreate(&h->stream));
+    bm::SsConfigDev& d = h->args.cfg;
+    d.min_conf = c.min_conf; d.max_cos_dist = c.max_cos_dist; d.max_iou_dist = c.max_iou_dist; d.mc_lambda = c.mc_lambda;
+    d.ema_alpha_f32 = (float)c.ema_alpha; d.one_minus_alpha_f32 = (float)(1 - c.ema_alpha);
+    d.max_age = c.max_age; d.n_init = c.n_init; d.budget = c.nn_budget;
+    auto& o = h->owned;
+    DevAlloc dev_allocator{&o};
+    bm::SsSizes z{h->S, h->cap, h->nd, h->dim, c.nn_budget};
+    bm::ss_allocate(h->args, z, dev_allocator);
+    const size_t S = h->S, cap = h->cap, nd = h->nd, dim = h->dim;
+    h->d_dets = zalloc<float>(S * nd * bm::DET_COLS, o);
+    h->d_ndets = zalloc<int>(S, o);
+    h->d_embs = zalloc<float>(S * nd * dim, o);
+    h->d_out = zalloc<float>(S * cap * bm::OUT_COLS, o);
+    h->d_out_n = zalloc<int>(S, o);
+    h->d_warp = zalloc<double>(S * 6, o);
+    h->h_dets.assign(S * nd * bm::DET_COLS, 0.f);
+    h->h_out.assign(S * cap * bm::OUT_COLS, 0.f);
+    h->h_ndets.assign(S, 0); h->h_out_n.assign(S, 0);
+    h->h_warp.assign(S * 6, 0.0); h->h_warp_flag.assign(S, 0);
+    h->frame_bufs.assign(S, nullptr);
+    h->d_frames = zalloc<const uint8_t*>(S, o);
+    h->d_crop_count = zalloc<int>(1, o);
+    h->d_crop_stream = zalloc<int>(S * nd, o);
+    h->d_crop_boxes = zalloc<float>(S * nd * 4, o);
+    h->d_crop_row = zalloc<int>(S * nd, o);
+    const long lds = bm::ss_lsa_lds_bytes(h->cap > h->nd ? h->cap : h->nd);
+    if (lds > 120 * 1024) throw std::runtime_error("boxmot_hip: max_tracks/max_dets too large for the assignment solver's LDS state");
+    BM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(strongsort_step_kernel<STEP_THREADS>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (!h->reid_path.empty()) {
+        const std::vector<float> blob = bm::read_blob_file(h->reid_path.c_str());
+        h->reid.reset(new bm::ReidEngine(blob.data(), (long)blob.size(), bm::reid_chunk_for((long)S * nd), (int)(S * nd)));
+        if (h->reid->feature_dim() != h->dim) throw std::runtime_error("boxmot_hip: ReID feature dim != emb_dim");
+    }
+    ss_zero_state(h);
+}
+
+void ss_host_update(BoxMOTHipStrongSort* h, int n, const StreamIn* in, int det_cols, int emb_cols, int image_rows,
+                    int image_cols, int image_channels, float* const* out, int out_capacity_rows, int* out_rows) {
+    const int nd = h->nd, dim = h->dim, cap = h->cap;
+    bool need_reid = false;
+    for (int k = 0; k < n; ++k) {
+        const int rows = in[k].det_rows;
+        if (rows < 0) throw std::runtime_error("Negative matrix dimensions are not allowed.");
+        if (rows > 0 && det_cols != 6) throw std::runtime_error("boxmot_hip live tracking supports AABB detections with 6 columns.");
+        if (rows > nd) throw std::runtime_error("boxmot_hip: more detections than max_dets");
+        if (rows > 0 && in[k].dets == nullptr) throw std::runtime_error("Detection data pointer is null.");
+        if (out_capacity_rows < rows) throw std::runtime_error("boxmot_hip: output buffer is too small for the current frame.");
+        if (in[k].embs != nullptr && emb_cols != dim && rows > 0) throw std::runtime_error("boxmot_hip: embedding width does not match emb_dim");
+        if (in[k].embs == nullptr && rows > 0) need_reid = true;
+    }
+    if (need_reid)
+        for (int k = 0; k < n; ++k)
+            if (in[k].embs != nullptr && in[k].det_rows > 0)
+                throw std::runtime_error("boxmot_hip: either every stream of a batch supplies embeddings or none does");
+    for (int k = 0; k < n; ++k) {
+        h->h_ndets[k] = in[k].det_rows;
+        if (in[k].det_rows)
+            std::memcpy(h->h_dets.data() + (size_t)k * nd * bm::DET_COLS, in[k].dets, (size_t)in[k].det_rows * bm::DET_COLS * 4);
+        if (!h->h_warp_flag[k]) { double* w = h->h_warp.data() + (size_t)k * 6; w[0] = 1; w[1] = 0; w[2] = 0; w[3] = 0; w[4] = 1; w[5] = 0; }
+    }
+    BM_HIP(hipMemcpyAsync(h->d_dets, h->h_dets.data(), (size_t)n * nd * bm::DET_COLS * 4, hipMemcpyHostToDevice, h->stream));
+    BM_HIP(hipMemcpyAsync(h->d_ndets, h->h_ndets.data(), n * 4, hipMemcpyHostToDevice, h->stream));
+    BM_HIP(hipMemcpyAsync(h->d_warp, h->h_warp.data(), (size_t)n * 6 * 8, hipMemcpyHostToDevice, h->stream));
+    for (int k = 0; k < n; ++k)
+        if (in[k].embs && in[k].det_rows)
+            BM_HIP(hipMemcpyAsync(h->d_embs + (size_t)k * nd * dim, in[k].embs, (size_t)in[k].det_rows * dim * 4, hipMemcpyHostToDevice, h->stream));
+    if (need_reid) {
+        if (!h->reid) throw std::runtime_error("boxmot_hip: embeddings are needed and none were supplied, but no ReID weights are loaded");
+        if (image_channels != 3) throw std::runtime_error("boxmot_hip: ReID needs a 3-channel uint8 BGR image");
+        const size_t bytes = (size_t)image_rows * image_cols * 3;
+        for (int k = 0; k < n; ++k) {
+            if (!in[k].image) { if (!h->frame_bufs[k]) throw std::runtime_error("Image data pointer is null."); continue; }
+            if (h->frame_bufs[k] == nullptr || bytes != h->frame_bytes) {
+                if (h->frame_bytes != 0 && bytes != h->frame_bytes) throw std::runtime_error("boxmot_hip: frame size changed between updates");
+                void* p = nullptr;
+                BM_HIP(hipMalloc(&p, bytes));
+                h->frame_bufs[k] = static_cast<uint8_t*>(p);
+                h->frame_bytes = bytes; h->frame_rows = image_rows; h->frame_cols = image_cols;
+                BM_HIP(hipMemcpy(h->d_frames, h->frame_bufs.data(), h->S * sizeof(uint8_t*), hipMemcpyHostToDevice));
+            }
+            BM_HIP(hipMemcpyAsync(h->frame_bufs[k], in[k].image, bytes, hipMemcpyHostToDevice, h->stream));
+        }
+        // every detection with conf >= min_conf gets an embedding (strongsort.py:74-91)
+        BM_HIP(hipMemsetAsync(h->d_crop_count, 0, 4, h->stream));
+        hipLaunchKernelGGL(build_crop_list_kernel, dim3(n), dim3(256), 0, h->stream, h->d_dets, h->d_ndets, nd, h->cfg.min_conf,
+                           h->d_crop_count, h->d_crop_stream, h->d_crop_boxes, h->d_crop_row, 0, 1);
+        if (h->reid->mode() == 1) {
+            h->reid->run_counted(h->d_frames, h->d_crop_stream, h->d_crop_boxes, 4, h->d_crop_count, n * nd, h->frame_cols,
+                                 h->frame_rows, h->d_embs, h->d_crop_row, h->stream);
+        } else {
+            int n_crops = 0;
+            BM_HIP(hipMemcpyAsync(&n_crops, h->d_crop_count, 4, hipMemcpyDeviceToHost, h->stream));
+            BM_HIP(hipStreamSynchronize(h->stream));
+            h->reid->run(h->d_frames, h->d_crop_stream, h->d_crop_boxes, 4, n_crops, h->frame_cols, h->frame_rows, h->d_embs,
+                         h->d_crop_row, h->stream);
+        }
+    }
+    bm::SsStepArgs a = h->args;
+    a.dets = h->d_dets; a.n_dets = h->d_ndets; a.embs = h->d_embs; a.warp = h->d_warp;
+    a.out = h->d_out; a.out_n = h->d_out_n; a.stream_base = 0;
+    // appearance distances of every confirmed track to every detection (uses the state BEFORE this frame's step)
+    hipLaunchKernelGGL((strongsort_bank_kernel<SS_BANK_THREADS>), dim3(cap, n), dim3(SS_BANK_THREADS), 0, h->stream, a);
+    hipLaunchKernelGGL((strongsort_step_kernel<STEP_THREADS>), dim3(n), dim3(STEP_THREADS),
+                       (size_t)bm::ss_lsa_lds_bytes(cap > nd ? cap : nd), h->stream, a);
+    BM_HIP(hipGetLastError());
+    BM_HIP(hipMemcpyAsync(h->h_out_n.data(), h->d_out_n, n * 4, hipMemcpyDeviceToHost, h->stream));
+    BM_HIP(hipStreamSynchronize(h->stream));
+    for (int k = 0; k < n; ++k) h->h_warp_flag[k] = 0;
+    std::vector<int> st(n);
+    BM_HIP(hipMemcpy(st.data(), h->args.st.status, n * 4, hipMemcpyDeviceToHost));
+    for (int k = 0; k < n; ++k)
+        if (st[k] != bm::STATUS_OK)
+            throw std::runtime_error("boxmot_hip: StrongSORT stream " + std::to_string(k) + ": " +
+                                     (st[k] == bm::STATUS_TRACK_CAPACITY ? "track capacity (max_tracks) exceeded"
+                                      : st[k] == bm::STATUS_LAP_STALL ? "assignment solver found the cost matrix infeasible (non-finite costs?)"
                                                                       : "innovation covariance is not positive definite"));
     for (int k = 0; k < n; ++k) {
         const int rows = h->h_out_n[k];
@@ -1022,5 +1222,121 @@ int boxmot_hip_deepocsort_state_dump(BoxMOTHipDeepOcSort* handle, int stream, in
     });
 }
 
+// ---- StrongSORT ----
+void boxmot_hip_strongsort_default_config(BoxMOTHipStrongSortConfig* c) {
+    if (!c) return;
+    std::memset(c, 0, sizeof(*c));
+    c->max_age = 30; c->min_conf = 0.1; c->max_cos_dist = 0.2; c->max_iou_dist = 0.7; c->n_init = 3; c->nn_budget = 100;
+    c->mc_lambda = 0.98; c->ema_alpha = 0.9; c->reid_model_path = nullptr;
+    c->n_streams = 1; c->max_tracks = 1024; c->max_dets = 256; c->emb_dim = 512;
+}
+
+BoxMOTHipStrongSort* boxmot_hip_strongsort_create(const BoxMOTHipStrongSortConfig* config) {
+    BoxMOTHipStrongSort* h = nullptr;
+    const int ok = guard([&]() {
+        if (config == nullptr) throw std::runtime_error("boxmot_hip StrongSORT config is required.");
+        require_device();
+        h = new BoxMOTHipStrongSort();
+        h->cfg = *config;
+        if (config->reid_model_path) h->reid_path = config->reid_model_path;
+        h->cfg.reid_model_path = nullptr;
+        ss_build(h);
+    });
+    if (!ok) { delete h; return nullptr; }
+    return h;
+}
+
+void boxmot_hip_strongsort_destroy(BoxMOTHipStrongSort* handle) { delete handle; }
+
+int boxmot_hip_strongsort_reset(BoxMOTHipStrongSort* handle) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip StrongSORT handle is null.");
+        ss_zero_state(handle);
+    });
+}
+
+int boxmot_hip_strongsort_set_warp(BoxMOTHipStrongSort* handle, int stream, const double* warp_2x3) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip StrongSORT handle is null.");
+        if (stream < 0 || stream >= handle->S) throw std::runtime_error("boxmot_hip: stream index out of range");
+        if (warp_2x3 == nullptr) { handle->h_warp_flag[stream] = 0; return; }
+        for (int k = 0; k < 6; ++k) {
+            if (!std::isfinite(warp_2x3[k])) throw std::runtime_error("boxmot_hip: camera-motion warp has non-finite entries");
+            handle->h_warp[(size_t)stream * 6 + k] = warp_2x3[k];
+        }
+        handle->h_warp_flag[stream] = 1;
+    });
+}
+
+int boxmot_hip_strongsort_update_batch(BoxMOTHipStrongSort* handle, int n_streams, const float* const* dets,
+                                       const int* det_rows, const float* const* embs, int emb_cols,
+                                       const uint8_t* const* images, int image_rows, int image_cols, int image_channels,
+                                       float* const* out_tracks, int out_capacity_rows, int* out_rows) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip StrongSORT handle is not initialized.");
+        if (n_streams < 1 || n_streams > handle->S) throw std::runtime_error("boxmot_hip: n_streams out of range");
+        if (!dets || !det_rows || !out_tracks || !out_rows) throw std::runtime_error("boxmot_hip: null batch pointers");
+        std::vector<StreamIn> in(n_streams);
+        for (int s = 0; s < n_streams; ++s)
+            in[s] = StreamIn{dets[s], det_rows[s], (embs && emb_cols > 0) ? embs[s] : nullptr, images ? images[s] : nullptr};
+        ss_host_update(handle, n_streams, in.data(), 6, emb_cols, image_rows, image_cols, image_channels, out_tracks,
+                       out_capacity_rows, out_rows);
+    });
+}
+
+int boxmot_hip_strongsort_update(BoxMOTHipStrongSort* handle, const float* dets, int det_rows, int det_cols,
+                                 const float* embs, int emb_rows, int emb_cols, const uint8_t* image, int image_rows,
+                                 int image_cols, int image_channels, float* out_tracks, int out_capacity_rows,
+                                 int out_cols, int* out_rows, int* out_is_obb) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip StrongSORT handle is not initialized.");
+        if (!out_rows || !out_is_obb) throw std::runtime_error("Output pointers are null.");
+        if (out_cols != 9) throw std::runtime_error("boxmot_hip live tracking expects an output buffer with 9 columns.");
+        if (embs != nullptr && emb_rows != det_rows) throw std::runtime_error("Detection and embedding row counts must match.");
+        if (image_rows <= 0 || image_cols <= 0) throw std::runtime_error("Image dimensions must be positive.");
+        StreamIn in{dets, det_rows, (embs && emb_cols > 0) ? embs : nullptr, image};
+        float* outs[1] = {out_tracks};
+        ss_host_update(handle, 1, &in, det_cols, emb_cols, image_rows, image_cols, image_channels, outs, out_capacity_rows, out_rows);
+        *out_is_obb = 0;
+    });
+}
+
+int boxmot_hip_strongsort_state_dump(BoxMOTHipStrongSort* handle, int stream, int* ints6, double* kf72, float* feat,
+                                     int* out_rows, int* out_frame_count, int* out_next_id) {
+    return guard([&]() {
+        if (!handle || !out_rows) throw std::runtime_error("boxmot_hip: null argument");
+        if (stream < 0 || stream >= handle->S) throw std::runtime_error("boxmot_hip: stream index out of range");
+        BM_HIP(hipStreamSynchronize(handle->stream));
+        const bm::SsState& st = handle->args.st;
+        const size_t cap = handle->cap, dim = handle->dim, off = (size_t)stream * cap;
+        int n = 0, fc = 0, ni = 0;
+        BM_HIP(hipMemcpy(&n, st.n_tracks + stream, 4, hipMemcpyDeviceToHost));
+        BM_HIP(hipMemcpy(&fc, st.frame_count + stream, 4, hipMemcpyDeviceToHost));
+        BM_HIP(hipMemcpy(&ni, st.next_id + stream, 4, hipMemcpyDeviceToHost));
+        std::vector<int> list(cap), id(cap), state(cap), hits(cap), age(cap), tsu(cap), bank(cap);
+        BM_HIP(hipMemcpy(list.data(), st.list + off, cap * 4, hipMemcpyDeviceToHost));
+        BM_HIP(hipMemcpy(id.data(), st.id + off, cap * 4, hipMemcpyDeviceToHost));
+        BM_HIP(hipMemcpy(state.data(), st.state + off, cap * 4, hipMemcpyDeviceToHost));
+        BM_HIP(hipMemcpy(hits.data(), st.hits + off, cap * 4, hipMemcpyDeviceToHost));
+        BM_HIP(hipMemcpy(age.data(), st.age + off, cap * 4, hipMemcpyDeviceToHost));
+        BM_HIP(hipMemcpy(tsu.data(), st.tsu + off, cap * 4, hipMemcpyDeviceToHost));
+        BM_HIP(hipMemcpy(bank.data(), st.bank_n + off, cap * 4, hipMemcpyDeviceToHost));
+        for (int r = 0; r < n; ++r) {
+            const int sl = list[r];
+            if (ints6) {
+                int* o = ints6 + r * 6;
+                o[0] = id[sl]; o[1] = state[sl]; o[2] = hits[sl]; o[3] = age[sl]; o[4] = tsu[sl];
+                o[5] = bank[sl] < st.budget ? bank[sl] : st.budget;
+            }
+            if (kf72) BM_HIP(hipMemcpy(kf72 + (size_t)r * bm::KF_STRIDE, st.kf + (off + sl) * bm::KF_STRIDE, bm::KF_STRIDE * 8, hipMemcpyDeviceToHost));
+            if (feat) BM_HIP(hipMemcpy(feat + (size_t)r * dim, st.feat + (off + sl) * dim, dim * 4, hipMemcpyDeviceToHost));
+        }
+        *out_rows = n;
+        if (out_frame_count) *out_frame_count = fc;
+        if (out_next_id) *out_next_id = ni;
+    });
+}
+
 }  // extern "C"
+
 

@@ -1,0 +1,127 @@
+"""StrongSORT on MI355X behind the reference plugin surface.
+
+``StrongSort(...)`` takes the reference constructor's keyword arguments
+(boxmot/trackers/bbox/strongsort/strongsort.py:41-52 plus the BaseTracker ones) and
+``update(dets, img, embs=None)`` returns the reference's rows (strongsort.py:69-123).  Per frame two HIP kernels run
+through the C ABI (include/boxmot_hip.h): the nearest-neighbour appearance distances of every confirmed track's
+sample bank to every detection, and the frame step (camera update, 8-state XYAH Kalman filters with the NSA
+confidence scaling, gated appearance stage, IoU stage -- both assigned with a restatement of SciPy's
+``linear_sum_assignment`` -- track management, sample banks).
+
+Camera motion: the reference applies an ECC estimate unconditionally; estimation is not implemented here, so the
+tracker applies the identity (static camera) unless a ``cmc=`` object exposing the reference's
+``apply(img, boxes) -> 2x3 warp`` is given.  Rejected loudly: ``per_class=True``, OBB detections, ``nn_budget=None``.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Any
+
+import numpy as np
+
+from boxmot_amd import _lib
+from boxmot_amd.basetracker import OUT_COLS, BaseTracker
+
+
+class StrongSort(BaseTracker):
+    supports_obb = False
+
+    def __init__(
+        self,
+        reid_model: Any | None = None,
+        min_conf: float = 0.1,
+        max_cos_dist: float = 0.2,
+        max_iou_dist: float = 0.7,
+        n_init: int = 3,
+        nn_budget: int = 100,
+        mc_lambda: float = 0.98,
+        ema_alpha: float = 0.9,
+        # not reference parameters: camera-motion provider and capacity of the device-resident track table
+        cmc: Any | None = None,
+        max_tracks: int = 1024,
+        max_dets: int = 256,
+        emb_dim: int | None = None,
+        **kwargs: Any,
+    ):
+        super().__init__(_tracker_name="StrongSort", **kwargs)
+        if self.per_class:
+            raise NotImplementedError("boxmot_amd.StrongSort: per_class=True is not implemented")
+        if nn_budget is None:
+            raise NotImplementedError("boxmot_amd.StrongSort: nn_budget=None (unbounded sample bank) is not supported")
+        self.min_conf = min_conf
+        self.model = reid_model
+        self.cmc = cmc
+        self._lib = _lib.load()
+        self._emb_dim = emb_dim or getattr(self.model, "feature_dim", None) or 512
+        cfg = _lib.StrongSortConfig()
+        self._lib.boxmot_hip_strongsort_default_config(ctypes.byref(cfg))
+        cfg.max_age, cfg.min_conf, cfg.max_cos_dist, cfg.max_iou_dist = self.max_age, min_conf, max_cos_dist, max_iou_dist
+        cfg.n_init, cfg.nn_budget, cfg.mc_lambda, cfg.ema_alpha = n_init, nn_budget, mc_lambda, ema_alpha
+        cfg.n_streams, cfg.max_tracks, cfg.max_dets, cfg.emb_dim = 1, max_tracks, max_dets, self._emb_dim
+        self._cfg = cfg
+        self._max_tracks = max_tracks
+        self._handle = self._lib.boxmot_hip_strongsort_create(ctypes.byref(cfg))
+        if not self._handle:
+            raise RuntimeError(_lib.last_error())
+
+    def _update_impl(self, dets, img, embs=None, masks=None, class_list: int = 0) -> np.ndarray:
+        self.check_inputs(dets, img, embs)
+        det_arr = np.ascontiguousarray(dets, dtype=np.float32)
+        n = int(det_arr.shape[0])
+        keep = det_arr[:, 4].astype(np.float64) >= self.min_conf if n else np.zeros(0, bool)      # strongsort.py:75
+        if self.cmc is not None:
+            warp = np.ascontiguousarray(np.asarray(self.cmc.apply(img, det_arr[keep, :4].astype(np.float64)), dtype=np.float64)[:2, :3])
+            _lib.check(self._lib.boxmot_hip_strongsort_set_warp(self._handle, 0, warp.ctypes.data))
+        feats = None
+        if n:
+            if embs is not None:
+                feats = np.ascontiguousarray(embs, dtype=np.float32)
+            else:
+                feats = np.zeros((n, self._emb_dim), dtype=np.float32)
+                if keep.any():
+                    feats[keep] = self.model.get_features(det_arr[keep, :4], img)       # strongsort.py:91
+            if feats.shape[1] != self._emb_dim:
+                raise ValueError(f"embedding width {feats.shape[1]} != emb_dim {self._emb_dim}")
+        img_arr = np.ascontiguousarray(img)
+        out = np.empty((max(n, 1), 9), dtype=np.float32)
+        out_rows, out_is_obb = ctypes.c_int(0), ctypes.c_int(0)
+        ok = self._lib.boxmot_hip_strongsort_update(
+            self._handle, det_arr.ctypes.data if n else None, n, 6,
+            feats.ctypes.data if feats is not None else None, n if feats is not None else 0,
+            self._emb_dim if feats is not None else 0,
+            img_arr.ctypes.data, int(img_arr.shape[0]), int(img_arr.shape[1]),
+            int(img_arr.shape[2]) if img_arr.ndim == 3 else 1,
+            out.ctypes.data, int(out.shape[0]), 9, ctypes.byref(out_rows), ctypes.byref(out_is_obb))
+        _lib.check(ok)
+        self.frame_count += 1
+        return out[: out_rows.value, :OUT_COLS].copy()
+
+    def reset(self) -> None:
+        # the reference's StrongSort.reset is a no-op (strongsort.py:125-126); the HIP handle does reset its tracks
+        _lib.check(self._lib.boxmot_hip_strongsort_reset(self._handle))
+        self.frame_count = 0
+        self._first_frame_processed = False
+        self._first_dets_processed = False
+
+    def state_dump(self) -> dict:
+        cap, dim = self._max_tracks, self._emb_dim
+        ints = np.zeros((cap, 6), dtype=np.int32)
+        kf = np.zeros((cap, 72), dtype=np.float64)
+        feat = np.zeros((cap, dim), dtype=np.float32)
+        rows, fc, ni = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(self._lib.boxmot_hip_strongsort_state_dump(
+            self._handle, 0, ints.ctypes.data, kf.ctypes.data, feat.ctypes.data, ctypes.byref(rows), ctypes.byref(fc),
+            ctypes.byref(ni)))
+        n = rows.value
+        return dict(n=n, ints=ints[:n], kf=kf[:n], feat=feat[:n], frame_count=fc.value, next_id=ni.value)
+
+    def close(self) -> None:
+        if getattr(self, "_handle", None):
+            self._lib.boxmot_hip_strongsort_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

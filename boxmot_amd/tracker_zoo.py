@@ -31,7 +31,10 @@ DEEPOCSORT_YAML_DEFAULTS = dict(
     w_association_emb=0.75, alpha_fixed_emb=0.95, aw_param=0.5, embedding_off=False, cmc_off=False, aw_off=False,
     Q_xy_scaling=0.01, Q_s_scaling=0.0001,
 )
-SUPPORTED = ("botsort", "deepocsort")
+# boxmot/configs/trackers/strongsort.yaml defaults
+STRONGSORT_YAML_DEFAULTS = dict(min_conf=0.6, max_cos_dist=0.4, max_iou_dist=0.7, max_age=30, n_init=3, nn_budget=100,
+                                mc_lambda=0.98, ema_alpha=0.9)
+SUPPORTED = ("botsort", "deepocsort", "strongsort")
 
 
 def flatten_yaml_config(cfg: dict) -> dict:
@@ -59,13 +62,22 @@ def create_tracker(tracker_type: str = "botsort", tracker_config=None, reid_weig
     if evolve_param_dict is not None:
         kwargs = dict(evolve_param_dict)
     elif tracker_config is None:
-        kwargs = dict(BOTSORT_YAML_DEFAULTS if tracker_type == "botsort" else DEEPOCSORT_YAML_DEFAULTS)
+        kwargs = dict({"botsort": BOTSORT_YAML_DEFAULTS, "deepocsort": DEEPOCSORT_YAML_DEFAULTS,
+                       "strongsort": STRONGSORT_YAML_DEFAULTS}[tracker_type])
     elif isinstance(tracker_config, dict):
         kwargs = flatten_yaml_config(tracker_config)
     else:
         kwargs = flatten_yaml_config(yaml.safe_load(Path(tracker_config).read_text()))
     kwargs.update(overrides)
     kwargs["per_class"] = per_class
+    if tracker_type == "strongsort":
+        from boxmot_amd.strongsort import StrongSort
+
+        if reid_model is None and reid_weights is not None:
+            from boxmot_amd.reid import HipReID
+
+            reid_model = HipReID(reid_weights)
+        return StrongSort(reid_model=reid_model, **kwargs)
     if tracker_type == "deepocsort":
         from boxmot_amd.deepocsort import DeepOcSort
 

@@ -232,6 +232,57 @@ int boxmot_hip_deepocsort_update_batch(
 int boxmot_hip_deepocsort_state_dump(BoxMOTHipDeepOcSort* handle, int stream, int* ints5, double* kf72, double* emb,
                                      int* out_rows, int* out_frame_count, int* out_id_count);
 
+/* ------------------------------------------------------------------------------------------------
+ * StrongSORT (boxmot/trackers/bbox/strongsort/strongsort.py:16-126, sort/tracker.py, sort/track.py,
+ * sort/linear_assignment.py).  No native backend exists in the reference; conventions as above.
+ * Fields = the constructor arguments of StrongSort (strongsort.py:41-52) + BaseTracker.max_age.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct BoxMOTHipStrongSortConfig {
+    int max_age;
+    double min_conf;
+    double max_cos_dist;
+    double max_iou_dist;
+    int n_init;
+    int nn_budget;                   /* 1..1024 samples per track (None is not supported) */
+    double mc_lambda;
+    double ema_alpha;
+    const char* reid_model_path;     /* OSN1 blob or NULL when embeddings are supplied */
+    int n_streams;
+    int max_tracks;
+    int max_dets;                    /* <= 1024 */
+    int emb_dim;                     /* <= 2048 */
+} BoxMOTHipStrongSortConfig;
+
+typedef struct BoxMOTHipStrongSort BoxMOTHipStrongSort;
+
+void boxmot_hip_strongsort_default_config(BoxMOTHipStrongSortConfig* config);
+BoxMOTHipStrongSort* boxmot_hip_strongsort_create(const BoxMOTHipStrongSortConfig* config);
+void boxmot_hip_strongsort_destroy(BoxMOTHipStrongSort* handle);
+int boxmot_hip_strongsort_reset(BoxMOTHipStrongSort* handle);
+/* Track.camera_update (sort/track.py:139-148): the 2x3 warp the reference's cmc.apply returned, applied to every track in
+ * the NEXT update of `stream` (the reference applies its ECC estimate unconditionally, strongsort.py:83-86); without a
+ * pending warp the identity is applied, which is what the reference computes for a static camera. */
+int boxmot_hip_strongsort_set_warp(BoxMOTHipStrongSort* handle, int stream, const double* warp_2x3);
+/* StrongSort.update for stream 0 (strongsort.py:69-123); embs == NULL runs the ReID engine on every detection with
+ * conf >= min_conf.  Rows [x1,y1,x2,y2,id,conf,cls,det_ind,0]. */
+int boxmot_hip_strongsort_update(
+    BoxMOTHipStrongSort* handle,
+    const float* dets, int det_rows, int det_cols,
+    const float* embs, int emb_rows, int emb_cols,
+    const uint8_t* image, int image_rows, int image_cols, int image_channels,
+    float* out_tracks, int out_capacity_rows, int out_cols,
+    int* out_rows, int* out_is_obb);
+int boxmot_hip_strongsort_update_batch(
+    BoxMOTHipStrongSort* handle, int n_streams,
+    const float* const* dets, const int* det_rows,
+    const float* const* embs, int emb_cols,
+    const uint8_t* const* images, int image_rows, int image_cols, int image_channels,
+    float* const* out_tracks, int out_capacity_rows, int* out_rows);
+/* parity debugging: tracks of `stream` in list order -- ints6 (rows,6) = id, state (1 tentative / 2 confirmed), hits, age,
+ * time_since_update, sample-bank size; kf72 (rows,72) = mean[8] ++ cov[8][8]; feat (rows, emb_dim) fp32. */
+int boxmot_hip_strongsort_state_dump(BoxMOTHipStrongSort* handle, int stream, int* ints6, double* kf72, float* feat,
+                                     int* out_rows, int* out_frame_count, int* out_next_id);
+
 #ifdef __cplusplus
 }
 #endif

@@ -135,3 +135,64 @@ class EmuDeepOcSort:
         if self.h:
             self.lib.emu_docs_destroy(self.h)
             self.h = None
+
+
+SS_D = ("min_conf", "max_cos_dist", "max_iou_dist", "mc_lambda", "ema_alpha")
+SS_I = ("max_age", "n_init", "nn_budget")
+
+
+def build_ss(sanitize: bool = False) -> Path:
+    src = HERE / "emu_ssort.cpp"
+    csrc = HERE.parent.parent / "boxmot_amd" / "csrc"
+    deps = [src, HERE / "hip_shim.hpp", csrc / "strongsort_step.hpp", csrc / "block_prims.hpp", csrc / "kernel_macros.hpp",
+            csrc / "botsort_types.hpp"]
+    out = HERE / ("libemu_ssort_asan.so" if sanitize else "libemu_ssort.so")
+    if not out.exists() or any(d.stat().st_mtime > out.stat().st_mtime for d in deps):
+        flags = ["-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-pthread"]
+        if sanitize:
+            flags += ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"]
+        subprocess.check_call(["g++", *flags, "-o", str(out), str(src)])
+    return out
+
+
+class EmuStrongSort:
+    """The StrongSORT device kernels (strongsort_step.hpp) executed on CPU threads."""
+
+    def __init__(self, cfg: dict, cap=256, nd=64, dim=32, sanitize=False):
+        self.lib = ctypes.CDLL(str(build_ss(sanitize)))
+        self.lib.emu_ss_create.restype = ctypes.c_void_p
+        self.lib.emu_ss_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        self.lib.emu_ss_update.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_void_p]
+        self.lib.emu_ss_dump.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 4
+        self.lib.emu_ss_destroy.argtypes = [ctypes.c_void_p]
+        cd = np.array([cfg[k] for k in SS_D], dtype=np.float64)
+        ci = np.array([int(cfg[k]) for k in SS_I], dtype=np.int32)
+        self.cap, self.nd, self.dim = cap, nd, dim
+        self.h = self.lib.emu_ss_create(cd.ctypes.data, ci.ctypes.data, cap, nd, dim)
+
+    def update(self, dets, embs, warp=None):
+        dets = np.ascontiguousarray(dets, dtype=np.float32).reshape(-1, 6)
+        n = len(dets)
+        e = np.ascontiguousarray(embs, dtype=np.float32)
+        w = None if warp is None else np.ascontiguousarray(warp, dtype=np.float64).reshape(6)
+        out = np.zeros((self.cap, 8), dtype=np.float32)
+        out_n = ctypes.c_int(0)
+        status = self.lib.emu_ss_update(self.h, dets.ctypes.data, n, e.ctypes.data, None if w is None else w.ctypes.data,
+                                        out.ctypes.data, ctypes.byref(out_n))
+        if status != 0:
+            raise RuntimeError(f"emulated kernel status {status}")
+        return out[: out_n.value].copy()
+
+    def dump(self):
+        ints = np.zeros((self.cap, 6), dtype=np.int32)
+        kf = np.zeros((self.cap, 72), dtype=np.float64)
+        feat = np.zeros((self.cap, self.dim), dtype=np.float32)
+        cnt = np.zeros(2, dtype=np.int32)
+        n = self.lib.emu_ss_dump(self.h, ints.ctypes.data, kf.ctypes.data, feat.ctypes.data, cnt.ctypes.data)
+        return dict(n=n, ints=ints[:n], kf=kf[:n], feat=feat[:n], counters=cnt)
+
+    def close(self):
+        if self.h:
+            self.lib.emu_ss_destroy(self.h)
+            self.h = None

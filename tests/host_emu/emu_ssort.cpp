@@ -1,0 +1,183 @@
+// TEST-ONLY harness: runs the StrongSORT device source (bm::ss_bank_distance_block + bm::ss_step_stream, unchanged)
+// on CPU threads through hip_shim.hpp.  See hip_shim.hpp for scope and limits.
+#include "hip_shim.hpp"
+
+#include <cstdlib>
+#include <vector>
+
+#include "../../boxmot_amd/csrc/strongsort_step.hpp"
+
+thread_local EmuDim3 threadIdx;
+thread_local EmuDim3 blockIdx;
+EmuDim3 blockDim;
+EmuBlock* g_emu_block = nullptr;
+
+namespace {
+
+constexpr int NTHR = 64;
+
+struct HostAlloc {
+    std::vector<void*> owned;
+    template <typename T> T* get(size_t n) {
+        void* p = std::calloc(n ? n : 1, sizeof(T));
+        owned.push_back(p);
+        return static_cast<T*>(p);
+    }
+};
+
+struct Emu {
+    bm::SsStepArgs args{};
+    HostAlloc alloc;
+    int cap, nd, dim;
+    float* dets; int* n_dets; float* embs; float* out; int* out_n; double* warp;
+    EmuBlock block;
+};
+
+struct ThreadArg { Emu* e; int tid; int mode; int t; };
+int* g_s_int; double* g_s_dbl; unsigned char* g_dyn; float* g_vec; float* g_red;
+
+const double* g_lsa_cost; int g_lsa_nr, g_lsa_nc; int* g_lsa_out;
+
+void* thread_main(void* p) {
+    ThreadArg* ta = static_cast<ThreadArg*>(p);
+    threadIdx.x = ta->tid;
+    blockIdx.x = 0;
+    if (ta->mode == 2) {
+        const bm::Ctx c = bm::make_ctx(g_s_int, g_s_dbl);
+        const int n = g_lsa_nr > g_lsa_nc ? g_lsa_nr : g_lsa_nc;
+        const bm::LsaLds l = bm::ss_carve_lsa(g_dyn, n);
+        const double* cm = g_lsa_cost; const int nc = g_lsa_nc;
+        bm::lsa_scipy(c, l, g_lsa_nr, g_lsa_nc, [&](int r, int q) { return cm[r * nc + q]; }, g_lsa_out);
+        return nullptr;
+    }
+    if (ta->mode == 0) bm::ss_bank_distance_block<NTHR>(ta->e->args, 0, ta->t, g_vec, g_red);
+    else bm::ss_step_stream<NTHR>(ta->e->args, 0, g_s_int, g_s_dbl, g_dyn);
+    return nullptr;
+}
+
+void run_block(Emu* e, int mode, int t) {
+    std::vector<pthread_t> th(NTHR);
+    std::vector<ThreadArg> ta(NTHR);
+    pthread_attr_t attr;
+    pthread_attr_init(&attr);
+    pthread_attr_setstacksize(&attr, 1 << 20);
+    for (int k = 0; k < NTHR; ++k) { ta[k] = ThreadArg{e, k, mode, t}; pthread_create(&th[k], &attr, thread_main, &ta[k]); }
+    for (int k = 0; k < NTHR; ++k) pthread_join(th[k], nullptr);
+    pthread_attr_destroy(&attr);
+}
+
+}  // namespace
+
+extern "C" {
+
+// cd: min_conf, max_cos_dist, max_iou_dist, mc_lambda, ema_alpha; ci: max_age, n_init, budget
+void* emu_ss_create(const double* cd, const int* ci, int cap, int nd, int dim) {
+    Emu* e = new Emu();
+    e->cap = cap; e->nd = nd; e->dim = dim;
+    bm::SsConfigDev& c = e->args.cfg;
+    c.min_conf = cd[0]; c.max_cos_dist = cd[1]; c.max_iou_dist = cd[2]; c.mc_lambda = cd[3];
+    c.ema_alpha_f32 = (float)cd[4]; c.one_minus_alpha_f32 = (float)(1 - cd[4]);
+    c.max_age = ci[0]; c.n_init = ci[1]; c.budget = ci[2];
+    bm::SsSizes z{1, cap, nd, dim, ci[2]};
+    bm::ss_allocate(e->args, z, e->alloc);
+    e->args.st.next_id[0] = 1;
+    e->dets = e->alloc.get<float>((size_t)nd * bm::DET_COLS);
+    e->n_dets = e->alloc.get<int>(1);
+    e->embs = e->alloc.get<float>((size_t)nd * dim);
+    e->out = e->alloc.get<float>((size_t)cap * bm::OUT_COLS);
+    e->out_n = e->alloc.get<int>(1);
+    e->warp = e->alloc.get<double>(6);
+    e->args.dets = e->dets; e->args.n_dets = e->n_dets; e->args.embs = e->embs; e->args.warp = nullptr;
+    e->args.out = e->out; e->args.out_n = e->out_n; e->args.stream_base = 0;
+    e->block.block_barrier.init(NTHR);
+    for (int w = 0; w < EMU_MAX_WAVES; ++w) e->block.wave_barrier[w].init(EMU_WAVE);
+    return e;
+}
+
+void emu_ss_destroy(void* h) {
+    Emu* e = static_cast<Emu*>(h);
+    for (void* p : e->alloc.owned) std::free(p);
+    delete e;
+}
+
+int emu_ss_update(void* h, const float* dets, int n, const float* embs, const double* warp, float* out, int* out_n) {
+    Emu* e = static_cast<Emu*>(h);
+    if (n > e->nd) return -1;
+    std::memcpy(e->dets, dets, (size_t)n * bm::DET_COLS * 4);
+    if (embs) std::memcpy(e->embs, embs, (size_t)n * e->dim * 4);
+    e->n_dets[0] = n;
+    if (warp) { std::memcpy(e->warp, warp, 48); e->args.warp = e->warp; } else e->args.warp = nullptr;
+    static int s_int[bm::MAX_WAVES + 1];
+    static double s_dbl[bm::MAX_WAVES];
+    static std::vector<double> dyn;
+    static std::vector<float> vec, red;
+    const int big = e->cap > e->nd ? e->cap : e->nd;
+    dyn.assign((size_t)bm::ss_lsa_lds_bytes(big) / 8 + 2, 0.0);
+    vec.assign(e->dim, 0.f); red.assign(bm::MAX_WAVES, 0.f);
+    g_s_int = s_int; g_s_dbl = s_dbl; g_dyn = reinterpret_cast<unsigned char*>(dyn.data());
+    g_vec = vec.data(); g_red = red.data();
+    g_emu_block = &e->block;
+    blockDim.x = NTHR;
+    const int nt = e->args.st.n_tracks[0];
+    for (int t = 0; t < nt; ++t)
+        if (e->args.st.state[e->args.st.list[t]] == bm::SS_CONFIRMED) run_block(e, 0, t);
+    run_block(e, 1, 0);
+    *out_n = e->out_n[0];
+    std::memcpy(out, e->out, (size_t)e->out_n[0] * bm::OUT_COLS * 4);
+    return e->args.st.status[0];
+}
+
+// debugging aid: scratch lists of the last step
+void emu_ss_debug(void* h, int* rows_b, int* cols_b, int* m_trk, int* m_det, int* un_d, double* cost, int n) {
+    Emu* e = static_cast<Emu*>(h);
+    const bm::SsScratch& sc = e->args.sc;
+    for (int k = 0; k < n; ++k) { rows_b[k] = sc.rows_b[k]; cols_b[k] = sc.cols_b[k]; m_trk[k] = sc.m_trk[k]; m_det[k] = sc.m_det[k]; un_d[k] = sc.un_d[k]; }
+    const int big = e->cap > e->nd ? e->cap : e->nd;
+    for (int r = 0; r < n; ++r) for (int q = 0; q < n; ++q) cost[r * n + q] = sc.cost[(size_t)r * big + q];
+}
+
+void emu_ss_app(void* h, float* app, int rows, int cols) {
+    Emu* e = static_cast<Emu*>(h);
+    for (int r = 0; r < rows; ++r) for (int q = 0; q < cols; ++q) app[r * cols + q] = e->args.sc.app[(size_t)r * e->nd + q];
+}
+
+void emu_ss_bank(void* h, int pos, int k, float* out) {
+    Emu* e = static_cast<Emu*>(h);
+    const int sl = e->args.st.list[pos];
+    std::memcpy(out, e->args.st.bank + ((size_t)sl * e->args.st.budget + k) * e->dim, (size_t)e->dim * 4);
+}
+
+// the device assignment solver alone (nr <= nc), for comparison with scipy.optimize.linear_sum_assignment
+void emu_lsa(const double* cost, int nr, int nc, int* col_of) {
+    static Emu e;
+    static int s_int[bm::MAX_WAVES + 1];
+    static double s_dbl[bm::MAX_WAVES];
+    static std::vector<double> dyn;
+    dyn.assign((size_t)bm::ss_lsa_lds_bytes(nr > nc ? nr : nc) / 8 + 2, 0.0);
+    g_s_int = s_int; g_s_dbl = s_dbl; g_dyn = reinterpret_cast<unsigned char*>(dyn.data());
+    g_lsa_cost = cost; g_lsa_nr = nr; g_lsa_nc = nc; g_lsa_out = col_of;
+    e.block.block_barrier.init(NTHR);
+    for (int w = 0; w < EMU_MAX_WAVES; ++w) e.block.wave_barrier[w].init(EMU_WAVE);
+    g_emu_block = &e.block;
+    blockDim.x = NTHR;
+    run_block(&e, 2, 0);
+}
+
+// tracks in list order: ints (rows,6) = id, state, hits, age, time_since_update, bank size; kf (rows,72); feat (rows,dim)
+int emu_ss_dump(void* h, int* ints, double* kf, float* feat, int* counters) {
+    Emu* e = static_cast<Emu*>(h);
+    const bm::SsState& st = e->args.st;
+    const int n = st.n_tracks[0];
+    for (int r = 0; r < n; ++r) {
+        const int sl = st.list[r];
+        int* o = ints + r * 6;
+        o[0] = st.id[sl]; o[1] = st.state[sl]; o[2] = st.hits[sl]; o[3] = st.age[sl]; o[4] = st.tsu[sl];
+        o[5] = st.bank_n[sl] < st.budget ? st.bank_n[sl] : st.budget;
+        std::memcpy(kf + (size_t)r * bm::KF_STRIDE, st.kf + (size_t)sl * bm::KF_STRIDE, bm::KF_STRIDE * 8);
+        std::memcpy(feat + (size_t)r * e->dim, st.feat + (size_t)sl * e->dim, (size_t)e->dim * 4);
+    }
+    counters[0] = st.frame_count[0]; counters[1] = st.next_id[0];
+    return n;
+}
+
+}  // extern "C"

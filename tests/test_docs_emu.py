@@ -41,16 +41,16 @@ def _run(frames, dim, cap, nd, sanitize=False, lap_rule="jv", **kw):
 @pytest.mark.parametrize("kw,seed", [({}, 7), (dict(max_age=5, min_hits=1), 11), (dict(aw_off=True, inertia=0.4, w_association_emb=0.75), 3),
                                      (dict(embedding_off=True), 5)])
 def test_emulated_deepocsort_matches_oracle_stress(kw, seed):
-    _run(stress_frames(90, seed=seed), 32, 128, 64, **kw)
+    _run(stress_frames(60, seed=seed), 32, 128, 64, **kw)
 
 
-@pytest.mark.parametrize("seed", [22, 24, 28, 31])
+@pytest.mark.parametrize("seed", [22, 24, 28])
 def test_emulated_deepocsort_tie_prone_scenes(seed):
     """Crowded births with more detections than tracks: the assignment has several optima (zero-cost pairs), and
     which detections end up "never assigned" decides the id order of the new tracks.  The reference's choice comes
     from lapx (unavailable, parity unpinned); here the oracle is run with the device solver's tie rule so that
     everything else -- costs, filters, recovery round, bookkeeping -- is still compared exactly."""
-    frames = stress_frames(120, seed=seed, max_objects=30)
+    frames = stress_frames(80, seed=seed, max_objects=30)
     _run(frames, 32, 128, 64, lap_rule="lowest_index")
     _run(frames, 32, 128, 64, lap_rule="lowest_index", max_age=8, min_hits=2, iou_threshold=0.2)
 
