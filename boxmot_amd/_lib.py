@@ -131,6 +131,8 @@ SIGNATURES = {
     "boxmot_hip_deepocsort_reset": (_I, [_VP]),
     "boxmot_hip_deepocsort_update": (_I, [_VP, _VP, _I, _I, _VP, _I, _I, _VP, _I, _I, _I, _VP, _I, _I, c_int_p, c_int_p]),
     "boxmot_hip_deepocsort_update_batch": (_I, [_VP, _I, _VP, _VP, _VP, _I, _VP, _I, _I, _I, _VP, _I, _VP]),
+    "boxmot_hip_deepocsort_step_device": (_I, [_VP, _VP, _VP, _VP, _VP, _VP]),
+    "boxmot_hip_deepocsort_synchronize": (_I, [_VP]),
     "boxmot_hip_deepocsort_state_dump": (_I, [_VP, _I, _VP, _VP, _VP, c_int_p, c_int_p, c_int_p]),
     "boxmot_hip_strongsort_default_config": (None, [ctypes.POINTER(StrongSortConfig)]),
     "boxmot_hip_strongsort_create": (_VP, [ctypes.POINTER(StrongSortConfig)]),
@@ -139,6 +141,8 @@ SIGNATURES = {
     "boxmot_hip_strongsort_set_warp": (_I, [_VP, _I, _VP]),
     "boxmot_hip_strongsort_update": (_I, [_VP, _VP, _I, _I, _VP, _I, _I, _VP, _I, _I, _I, _VP, _I, _I, c_int_p, c_int_p]),
     "boxmot_hip_strongsort_update_batch": (_I, [_VP, _I, _VP, _VP, _VP, _I, _VP, _I, _I, _I, _VP, _I, _VP]),
+    "boxmot_hip_strongsort_step_device": (_I, [_VP, _VP, _VP, _VP, _VP, _VP]),
+    "boxmot_hip_strongsort_synchronize": (_I, [_VP]),
     "boxmot_hip_strongsort_state_dump": (_I, [_VP, _I, _VP, _VP, _VP, c_int_p, c_int_p, c_int_p]),
     "boxmot_hip_reid_create": (_VP, [ctypes.c_char_p, _VP, ctypes.c_long, _I]),
     "boxmot_hip_reid_destroy": (None, [_VP]),

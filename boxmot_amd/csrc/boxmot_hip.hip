@@ -58,10 +58,16 @@ __global__ void __launch_bounds__(NTHR) deepocsort_step_kernel(bm::DocsStepArgs 
 }
 
 template <int NTHR>
+__global__ void __launch_bounds__(NTHR) strongsort_detnorm_kernel(bm::SsStepArgs args) {
+    bm::ss_det_norm_block<NTHR>(args, args.stream_base + blockIdx.x);
+}
+
+template <int NTHR>
 __global__ void __launch_bounds__(NTHR) strongsort_bank_kernel(bm::SsStepArgs args) {
-    __shared__ float s_vec[2048];
-    __shared__ float s_red[bm::MAX_WAVES];
-    bm::ss_bank_distance_block<NTHR>(args, args.stream_base + blockIdx.y, blockIdx.x, s_vec, s_red);
+    __shared__ float sA[bm::SS_KC][bm::SS_TILE + 1];
+    __shared__ float sB[bm::SS_KC][bm::SS_TILE + 1];
+    __shared__ float sMin[16][bm::SS_TILE];
+    bm::ss_bank_distance_block<NTHR>(args, args.stream_base + blockIdx.y, blockIdx.x, sA, sB, sMin);
 }
 
 template <int NTHR>
@@ -648,9 +654,8 @@ void ss_zero_state(BoxMOTHipStrongSort* h) {
 
 void ss_build(BoxMOTHipStrongSort* h) {
     const BoxMOTHipStrongSortConfig& c = h->cfg;
-    if (c.n_streams < 1 || c.max_tracks < 8 || c.max_dets < 4 || c.emb_dim < 1 || c.emb_dim > 2048)
+    if (c.n_streams < 1 || c.max_tracks < 8 || c.max_dets < 4 || c.emb_dim < 1)
         throw std::runtime_error("boxmot_hip: invalid capacity configuration");
-    if (c.max_dets > 4 * SS_BANK_THREADS) throw std::runtime_error("boxmot_hip: StrongSORT max_dets must be <= 1024");
     if (c.nn_budget < 1 || c.nn_budget > 1024) throw std::runtime_error("boxmot_hip: StrongSORT nn_budget must be in [1, 1024] (None is not supported)");
     if (c.n_init < 1 || c.max_age < 0) throw std::runtime_error("boxmot_hip: invalid n_init / max_age");
     h->S = c.n_streams; h->cap = c.max_tracks; h->nd = c.max_dets; h->dim = c.emb_dim;
@@ -757,6 +762,7 @@ void ss_host_update(BoxMOTHipStrongSort* h, int n, const StreamIn* in, int det_c
     a.dets = h->d_dets; a.n_dets = h->d_ndets; a.embs = h->d_embs; a.warp = h->d_warp;
     a.out = h->d_out; a.out_n = h->d_out_n; a.stream_base = 0;
     // appearance distances of every confirmed track to every detection (uses the state BEFORE this frame's step)
+    hipLaunchKernelGGL((strongsort_detnorm_kernel<SS_BANK_THREADS>), dim3(n), dim3(SS_BANK_THREADS), 0, h->stream, a);
     hipLaunchKernelGGL((strongsort_bank_kernel<SS_BANK_THREADS>), dim3(cap, n), dim3(SS_BANK_THREADS), 0, h->stream, a);
     hipLaunchKernelGGL((strongsort_step_kernel<STEP_THREADS>), dim3(n), dim3(STEP_THREADS),
                        (size_t)bm::ss_lsa_lds_bytes(cap > nd ? cap : nd), h->stream, a);
@@ -1191,6 +1197,28 @@ int boxmot_hip_deepocsort_update(BoxMOTHipDeepOcSort* handle, const float* dets,
     });
 }
 
+int boxmot_hip_deepocsort_step_device(BoxMOTHipDeepOcSort* handle, const float* d_dets, const int* d_det_rows,
+                                       const float* d_embs, float* d_out, int* d_out_rows) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip DeepOCSORT handle is not initialized.");
+        if (!d_dets || !d_det_rows || !d_out || !d_out_rows) throw std::runtime_error("boxmot_hip: null device pointers");
+        if (!handle->cfg.embedding_off && !d_embs) throw std::runtime_error("boxmot_hip: step_device needs d_embs unless embedding_off");
+        bm::DocsStepArgs a = handle->args;
+        a.dets = d_dets; a.n_dets = d_det_rows; a.embs = handle->cfg.embedding_off ? nullptr : d_embs;
+        a.out = d_out; a.out_n = d_out_rows; a.stream_base = 0;
+        hipLaunchKernelGGL((deepocsort_step_kernel<STEP_THREADS>), dim3(handle->S), dim3(STEP_THREADS),
+                           (size_t)bm::docs_lap_lds_bytes(handle->cap, handle->nd), handle->stream, a);
+        BM_HIP(hipGetLastError());
+    });
+}
+
+int boxmot_hip_deepocsort_synchronize(BoxMOTHipDeepOcSort* handle) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip DeepOCSORT handle is not initialized.");
+        BM_HIP(hipStreamSynchronize(handle->stream));
+    });
+}
+
 int boxmot_hip_deepocsort_state_dump(BoxMOTHipDeepOcSort* handle, int stream, int* ints5, double* kf72, double* emb,
                                      int* out_rows, int* out_frame_count, int* out_id_count) {
     return guard([&]() {
@@ -1298,6 +1326,29 @@ int boxmot_hip_strongsort_update(BoxMOTHipStrongSort* handle, const float* dets,
         float* outs[1] = {out_tracks};
         ss_host_update(handle, 1, &in, det_cols, emb_cols, image_rows, image_cols, image_channels, outs, out_capacity_rows, out_rows);
         *out_is_obb = 0;
+    });
+}
+
+int boxmot_hip_strongsort_step_device(BoxMOTHipStrongSort* handle, const float* d_dets, const int* d_det_rows,
+                                       const float* d_embs, float* d_out, int* d_out_rows) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip StrongSORT handle is not initialized.");
+        if (!d_dets || !d_det_rows || !d_embs || !d_out || !d_out_rows) throw std::runtime_error("boxmot_hip: null device pointers");
+        bm::SsStepArgs a = handle->args;
+        a.dets = d_dets; a.n_dets = d_det_rows; a.embs = d_embs; a.warp = nullptr;
+        a.out = d_out; a.out_n = d_out_rows; a.stream_base = 0;
+        hipLaunchKernelGGL((strongsort_detnorm_kernel<SS_BANK_THREADS>), dim3(handle->S), dim3(SS_BANK_THREADS), 0, handle->stream, a);
+        hipLaunchKernelGGL((strongsort_bank_kernel<SS_BANK_THREADS>), dim3(handle->cap, handle->S), dim3(SS_BANK_THREADS), 0, handle->stream, a);
+        hipLaunchKernelGGL((strongsort_step_kernel<STEP_THREADS>), dim3(handle->S), dim3(STEP_THREADS),
+                           (size_t)bm::ss_lsa_lds_bytes(handle->cap > handle->nd ? handle->cap : handle->nd), handle->stream, a);
+        BM_HIP(hipGetLastError());
+    });
+}
+
+int boxmot_hip_strongsort_synchronize(BoxMOTHipStrongSort* handle) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip StrongSORT handle is not initialized.");
+        BM_HIP(hipStreamSynchronize(handle->stream));
     });
 }
 

@@ -44,6 +44,7 @@ struct SsState {
     double* kf;           // [S][cap][72]
     float* feat;          // [S][cap][dim]      features[-1]
     float* bank;          // [S][cap][budget][dim]
+    float* bank_norm;     // [S][cap][budget]  |sample|, computed when the sample is appended
     int* bank_n;          // [S][cap]   samples ever appended (ring position = bank_n % budget)
     int* id; int* state; int* hits; int* age; int* tsu;
     float* conf; float* cls; float* det_ind;
@@ -52,6 +53,7 @@ struct SsState {
 struct SsScratch {
     int max_dets;
     float* app;           // [S][cap][nd]  min cosine distance (list position, detection), from ss_bank_distance
+    float* det_norm;      // [S][nd]
     int* keep;            // [S][nd]
     double* det_tlwh;     // [S][nd][4]   per kept detection
     double* det_xyah;     // [S][nd][4]
@@ -197,6 +199,7 @@ void ss_allocate(SsStepArgs& args, const SsSizes& z, A& a) {
     st.kf = a.template get<double>(S * cap * KF_STRIDE);
     st.feat = a.template get<float>(S * cap * dim);
     st.bank = a.template get<float>(S * cap * (size_t)z.budget * dim);
+    st.bank_norm = a.template get<float>(S * cap * (size_t)z.budget);
     st.bank_n = a.template get<int>(S * cap);
     st.id = a.template get<int>(S * cap); st.state = a.template get<int>(S * cap); st.hits = a.template get<int>(S * cap);
     st.age = a.template get<int>(S * cap); st.tsu = a.template get<int>(S * cap);
@@ -204,6 +207,7 @@ void ss_allocate(SsStepArgs& args, const SsSizes& z, A& a) {
     SsScratch& sc = args.sc;
     sc.max_dets = z.nd;
     sc.app = a.template get<float>(S * cap * nd);
+    sc.det_norm = a.template get<float>(S * nd);
     sc.keep = a.template get<int>(S * nd);
     sc.det_tlwh = a.template get<double>(S * nd * 4); sc.det_xyah = a.template get<double>(S * nd * 4);
     sc.cost = a.template get<double>(S * big * big);
@@ -217,53 +221,88 @@ void ss_allocate(SsStepArgs& args, const SsSizes& z, A& a) {
 
 // ---------------------------------------------------------------------------
 // NearestNeighborDistanceMetric.distance (linear_assignment.py:336-353, _nn_cosine_distance :266-284):
-// app[t][j] = min over the bank of track t of 1 - <a/|a|, b/|b|>, all fp32.  One workgroup per (track position,
-// stream); confirmed tracks only.  Thread j owns detection j; the normalised bank vector sits in LDS.
+// app[t][j] = min over the bank of track t of 1 - <a/|a|, b/|b|>, all fp32 -- the reference's float32 matrix
+// product followed by a min.  A batched GEMM: one workgroup per (track position, stream), confirmed tracks only,
+// C[m][n] = <bank row m, detection n> over 64x64 tiles staged through LDS in k-chunks of 16, TMR x TNR outputs per
+// thread in registers; the norms (bank rows: stored when the sample is appended; detections: ss_det_norm_block) scale
+// the product afterwards.  fp32 FMAs: the fp32 matrix pipe has the same peak as the vector pipe on gfx950.
 // ---------------------------------------------------------------------------
+constexpr int SS_TILE = 64, SS_KC = 16;
+
+// |b| of every detection of stream s: one wavefront per detection
 template <int NTHR>
-__device__ inline void ss_bank_distance_block(const SsStepArgs& a, int s, int t, float* s_vec, float* s_red) {
+__device__ inline void ss_det_norm_block(const SsStepArgs& a, int s) {
+    const long dim = a.st.dim, nd = a.sc.max_dets;
+    const int n_d = a.n_dets[s], lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    const float* embs = a.embs + (long)s * nd * dim;
+    for (int j = wave; j < n_d; j += NTHR / WAVE) {
+        float ss = 0.f;
+        for (int k = lane; k < dim; k += WAVE) ss = fmaf(embs[j * dim + k], embs[j * dim + k], ss);
+        ss = wave_sum(ss);
+        if (lane == 0) a.sc.det_norm[s * nd + j] = sqrtf(ss);
+    }
+}
+
+template <int NTHR>
+__device__ inline void ss_bank_distance_block(const SsStepArgs& a, int s, int t, float (*sA)[SS_TILE + 1], float (*sB)[SS_TILE + 1],
+                                              float (*sMin)[SS_TILE]) {
+    constexpr int TX = NTHR == 256 ? 16 : 8, TY = NTHR / TX, TMR = SS_TILE / TY, TNR = SS_TILE / TX;
     const SsState& st = a.st;
     const long cap = st.cap, dim = st.dim, nd = a.sc.max_dets;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, tx = tid % TX, ty = tid / TX;
     if (t >= st.n_tracks[s]) return;
     const int slot = st.list[s * cap + t];
     if (st.state[s * cap + slot] != SS_CONFIRMED) return;
     const int n_d = a.n_dets[s];
     const float* embs = a.embs + (long)s * nd * dim;
-    const int n_bank = st.bank_n[s * cap + slot] < st.budget ? st.bank_n[s * cap + slot] : st.budget;
+    const int M = st.bank_n[s * cap + slot] < st.budget ? st.bank_n[s * cap + slot] : st.budget;
     const float* bank = st.bank + ((long)(s * cap + slot)) * st.budget * dim;
-    // detection norms: thread j
-    float best[4], dn[4];
-    for (int q = 0; q < 4; ++q) { best[q] = 3.0e38f; dn[q] = 1.f; }
-    for (int q = 0, j = tid; j < n_d && q < 4; j += NTHR, ++q) {
-        float ss = 0.f;
-        const float* e = embs + (long)j * dim;
-        for (int k = 0; k < dim; ++k) ss = fmaf(e[k], e[k], ss);
-        dn[q] = sqrtf(ss);
-    }
-    for (int b = 0; b < n_bank; ++b) {
-        const float* v = bank + (long)b * dim;
-        float part = 0.f;
-        for (int k = tid; k < dim; k += NTHR) part = fmaf(v[k], v[k], part);
-        part = wave_sum(part);
-        if ((tid & (WAVE - 1)) == 0) s_red[tid / WAVE] = part;
+    const float* bnorm = st.bank_norm + (long)(s * cap + slot) * st.budget;
+    const float* dnorm = a.sc.det_norm + s * nd;
+    float* out = a.sc.app + ((long)s * cap + t) * nd;
+    for (int n0 = 0; n0 < n_d; n0 += SS_TILE) {
+        float best[TNR];
+        for (int q = 0; q < TNR; ++q) best[q] = 3.0e38f;
+        for (int m0 = 0; m0 < M; m0 += SS_TILE) {
+            float acc[TMR][TNR];
+            for (int p = 0; p < TMR; ++p) for (int q = 0; q < TNR; ++q) acc[p][q] = 0.f;
+            for (int k0 = 0; k0 < dim; k0 += SS_KC) {
+                // stage A[m][k] and B[n][k] as [k][m], [k][n]: consecutive threads read consecutive k (coalesced 64-byte rows)
+                for (int e = tid; e < SS_TILE * SS_KC; e += NTHR) {
+                    const int r = e / SS_KC, k = e % SS_KC;
+                    sA[k][r] = (m0 + r < M && k0 + k < dim) ? bank[(long)(m0 + r) * dim + k0 + k] : 0.f;
+                    sB[k][r] = (n0 + r < n_d && k0 + k < dim) ? embs[(long)(n0 + r) * dim + k0 + k] : 0.f;
+                }
+                __syncthreads();
+                for (int k = 0; k < SS_KC; ++k) {
+                    float av[TMR], bv[TNR];
+                    for (int p = 0; p < TMR; ++p) av[p] = sA[k][ty * TMR + p];
+                    for (int q = 0; q < TNR; ++q) bv[q] = sB[k][tx * TNR + q];
+                    for (int p = 0; p < TMR; ++p) for (int q = 0; q < TNR; ++q) acc[p][q] = fmaf(av[p], bv[q], acc[p][q]);
+                }
+                __syncthreads();
+            }
+            for (int p = 0; p < TMR; ++p) {
+                const int m = m0 + ty * TMR + p;
+                if (m >= M) continue;
+                const float an = bnorm[m];
+                for (int q = 0; q < TNR; ++q) {
+                    const int n = n0 + tx * TNR + q;
+                    if (n >= n_d) continue;
+                    const float dist = 1.0f - acc[p][q] / (an * dnorm[n]);
+                    best[q] = dist < best[q] ? dist : best[q];
+                }
+            }
+        }
+        for (int q = 0; q < TNR; ++q) sMin[ty][tx * TNR + q] = best[q];
         __syncthreads();
-        float tot = 0.f;
-        for (int w = 0; w < NTHR / WAVE; ++w) tot += s_red[w];
-        const float nrm = sqrtf(tot);
-        for (int k = tid; k < dim; k += NTHR) s_vec[k] = v[k] / nrm;
-        __syncthreads();
-        for (int q = 0, j = tid; j < n_d && q < 4; j += NTHR, ++q) {
-            const float* e = embs + (long)j * dim;
-            float acc = 0.f;
-            for (int k = 0; k < dim; ++k) acc = fmaf(s_vec[k], e[k] / dn[q], acc);
-            const float dist = 1.0f - acc;
-            best[q] = dist < best[q] ? dist : best[q];
+        for (int n = tid; n < SS_TILE && n0 + n < n_d; n += NTHR) {
+            float m = sMin[0][n];
+            for (int y = 1; y < TY; ++y) m = sMin[y][n] < m ? sMin[y][n] : m;
+            out[n0 + n] = m;
         }
         __syncthreads();
     }
-    float* out = a.sc.app + ((long)s * cap + t) * nd;
-    for (int q = 0, j = tid; j < n_d && q < 4; j += NTHR, ++q) out[j] = best[q];
 }
 
 // ---------------------------------------------------------------------------
@@ -492,7 +531,7 @@ struct SSV {
     SsConfigDev cfg;
     int cap, dim, nd, budget;
     int* frame_count; int* next_id; int* n_tracks; int* status; int* list; int* slot_used;
-    double* kf; float* feat; float* bank; int* bank_n; int* id; int* state; int* hits; int* age; int* tsu;
+    double* kf; float* feat; float* bank; float* bank_norm; int* bank_n; int* id; int* state; int* hits; int* age; int* tsu;
     float* conf; float* cls; float* det_ind;
     float* app; int* keep; double* det_tlwh; double* det_xyah; double* cost;
     int* rows_a; int* rows_b; int* cols_b; int* un_d; int* tmp_a; int* tmp_b; int* m_trk; int* m_det; int* row_of; int* col_of; int* flag_t; int* pyset;
@@ -507,7 +546,7 @@ __device__ inline SSV ss_view(const SsStepArgs& a, int s) {
     v.frame_count = st.frame_count + s; v.next_id = st.next_id + s; v.n_tracks = st.n_tracks + s; v.status = st.status + s;
     v.list = st.list + s * cap; v.slot_used = st.slot_used + s * cap;
     v.kf = st.kf + s * cap * KF_STRIDE; v.feat = st.feat + s * cap * dim;
-    v.bank = st.bank + s * cap * (long)st.budget * dim; v.bank_n = st.bank_n + s * cap;
+    v.bank = st.bank + s * cap * (long)st.budget * dim; v.bank_norm = st.bank_norm + s * cap * (long)st.budget; v.bank_n = st.bank_n + s * cap;
     v.id = st.id + s * cap; v.state = st.state + s * cap; v.hits = st.hits + s * cap; v.age = st.age + s * cap; v.tsu = st.tsu + s * cap;
     v.conf = st.conf + s * cap; v.cls = st.cls + s * cap; v.det_ind = st.det_ind + s * cap;
     v.app = sc.app + s * cap * nd; v.keep = sc.keep + s * nd; v.det_tlwh = sc.det_tlwh + s * nd * 4; v.det_xyah = sc.det_xyah + s * nd * 4;
@@ -794,8 +833,10 @@ __device__ inline void ss_step_stream(const SsStepArgs& args, int s, int* s_int,
             if (v.state[slot] == SS_CONFIRMED) {
                 const int bn = __shfl(v.bank_n[slot], 0, WAVE);       // every lane has read the count before lane 0 bumps it
                 float* dst = v.bank + ((long)slot * v.budget + bn % v.budget) * dim;
-                for (int e = c.lane; e < dim; e += WAVE) dst[e] = v.feat[(long)slot * dim + e];
-                if (c.lane == 0) v.bank_n[slot] = bn + 1;
+                float ss = 0.f;
+                for (int e = c.lane; e < dim; e += WAVE) { const float f = v.feat[(long)slot * dim + e]; dst[e] = f; ss = fmaf(f, f, ss); }
+                ss = wave_sum(ss);
+                if (c.lane == 0) { v.bank_norm[(long)slot * v.budget + bn % v.budget] = sqrtf(ss); v.bank_n[slot] = bn + 1; }
             }
         }
     }

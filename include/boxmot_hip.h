@@ -227,6 +227,11 @@ int boxmot_hip_deepocsort_update_batch(
     const float* const* embs, int emb_cols,
     const uint8_t* const* images, int image_rows, int image_cols, int image_channels,
     float* const* out_tracks, int out_capacity_rows, int* out_rows);
+/* Device-resident step for all n_streams streams (asynchronous on the handle's stream; embeddings supplied):
+ * d_dets [S][max_dets][6], d_det_rows [S], d_embs [S][max_dets][emb_dim], d_out [S][max_tracks][8], d_out_rows [S]. */
+int boxmot_hip_deepocsort_step_device(BoxMOTHipDeepOcSort* handle, const float* d_dets, const int* d_det_rows,
+                                       const float* d_embs, float* d_out, int* d_out_rows);
+int boxmot_hip_deepocsort_synchronize(BoxMOTHipDeepOcSort* handle);
 /* parity debugging: live tracks of `stream` in list order -- ints5 (rows,5) = id, age, time_since_update, hit_streak,
  * observed; kf72 (rows,72) = x[8] ++ P[8][8] fp64 (index 7 unused); emb (rows, emb_dim) fp64.  NULL skips an output. */
 int boxmot_hip_deepocsort_state_dump(BoxMOTHipDeepOcSort* handle, int stream, int* ints5, double* kf72, double* emb,
@@ -249,8 +254,8 @@ typedef struct BoxMOTHipStrongSortConfig {
     const char* reid_model_path;     /* OSN1 blob or NULL when embeddings are supplied */
     int n_streams;
     int max_tracks;
-    int max_dets;                    /* <= 1024 */
-    int emb_dim;                     /* <= 2048 */
+    int max_dets;
+    int emb_dim;
 } BoxMOTHipStrongSortConfig;
 
 typedef struct BoxMOTHipStrongSort BoxMOTHipStrongSort;
@@ -278,6 +283,11 @@ int boxmot_hip_strongsort_update_batch(
     const float* const* embs, int emb_cols,
     const uint8_t* const* images, int image_rows, int image_cols, int image_channels,
     float* const* out_tracks, int out_capacity_rows, int* out_rows);
+/* Device-resident step for all n_streams streams (asynchronous; embeddings supplied, identity camera motion):
+ * d_dets [S][max_dets][6], d_det_rows [S], d_embs [S][max_dets][emb_dim], d_out [S][max_tracks][8], d_out_rows [S]. */
+int boxmot_hip_strongsort_step_device(BoxMOTHipStrongSort* handle, const float* d_dets, const int* d_det_rows,
+                                       const float* d_embs, float* d_out, int* d_out_rows);
+int boxmot_hip_strongsort_synchronize(BoxMOTHipStrongSort* handle);
 /* parity debugging: tracks of `stream` in list order -- ints6 (rows,6) = id, state (1 tentative / 2 confirmed), hits, age,
  * time_since_update, sample-bank size; kf72 (rows,72) = mean[8] ++ cov[8][8]; feat (rows, emb_dim) fp32. */
 int boxmot_hip_strongsort_state_dump(BoxMOTHipStrongSort* handle, int stream, int* ints6, double* kf72, float* feat,

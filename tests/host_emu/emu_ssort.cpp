@@ -34,7 +34,8 @@ struct Emu {
 };
 
 struct ThreadArg { Emu* e; int tid; int mode; int t; };
-int* g_s_int; double* g_s_dbl; unsigned char* g_dyn; float* g_vec; float* g_red;
+int* g_s_int; double* g_s_dbl; unsigned char* g_dyn;
+float (*g_sA)[bm::SS_TILE + 1]; float (*g_sB)[bm::SS_TILE + 1]; float (*g_sMin)[bm::SS_TILE];
 
 const double* g_lsa_cost; int g_lsa_nr, g_lsa_nc; int* g_lsa_out;
 
@@ -50,7 +51,8 @@ void* thread_main(void* p) {
         bm::lsa_scipy(c, l, g_lsa_nr, g_lsa_nc, [&](int r, int q) { return cm[r * nc + q]; }, g_lsa_out);
         return nullptr;
     }
-    if (ta->mode == 0) bm::ss_bank_distance_block<NTHR>(ta->e->args, 0, ta->t, g_vec, g_red);
+    if (ta->mode == 3) { bm::ss_det_norm_block<NTHR>(ta->e->args, 0); return nullptr; }
+    if (ta->mode == 0) bm::ss_bank_distance_block<NTHR>(ta->e->args, 0, ta->t, g_sA, g_sB, g_sMin);
     else bm::ss_step_stream<NTHR>(ta->e->args, 0, g_s_int, g_s_dbl, g_dyn);
     return nullptr;
 }
@@ -110,15 +112,15 @@ int emu_ss_update(void* h, const float* dets, int n, const float* embs, const do
     static int s_int[bm::MAX_WAVES + 1];
     static double s_dbl[bm::MAX_WAVES];
     static std::vector<double> dyn;
-    static std::vector<float> vec, red;
+    static float sA[bm::SS_KC][bm::SS_TILE + 1], sB[bm::SS_KC][bm::SS_TILE + 1], sMin[16][bm::SS_TILE];
     const int big = e->cap > e->nd ? e->cap : e->nd;
     dyn.assign((size_t)bm::ss_lsa_lds_bytes(big) / 8 + 2, 0.0);
-    vec.assign(e->dim, 0.f); red.assign(bm::MAX_WAVES, 0.f);
     g_s_int = s_int; g_s_dbl = s_dbl; g_dyn = reinterpret_cast<unsigned char*>(dyn.data());
-    g_vec = vec.data(); g_red = red.data();
+    g_sA = sA; g_sB = sB; g_sMin = sMin;
     g_emu_block = &e->block;
     blockDim.x = NTHR;
     const int nt = e->args.st.n_tracks[0];
+    run_block(e, 3, 0);
     for (int t = 0; t < nt; ++t)
         if (e->args.st.state[e->args.st.list[t]] == bm::SS_CONFIRMED) run_block(e, 0, t);
     run_block(e, 1, 0);
