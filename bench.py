@@ -2,14 +2,16 @@
 """bench.py -- tracker frames/sec for BASELINE.json config 2:
 BoT-SORT + OSNet-x0.25 ReID inside update, 64 detections x 256 live tracks, 1080p frames.
 
-  python bench.py --gpus N --steps K --warmup W [--streams S] [--mode embs|reid] [--reid-mode 0|1]
+  python bench.py --gpus N --steps K --warmup W [--streams S] [--groups G] [--mode embs|reid] [--reid-mode 0|1]
 
 One "step" = one pass of the hot path over one batch = every one of the S streams of this GPU
 advances by one frame (ReID crop/resize/normalise + OSNet + cost matrices + assignment + Kalman +
 bookkeeping, all on the device).  Inputs (detections of every frame, one static random frame per
 stream -- the reference harness also reuses one image, tests/performance/benchmark_fps.py:186) are
 resident in HBM before the timed region.  value = total frames of all streams on all GPUs / wall
-time (max over ranks), i.e. whole-job frames/sec; scaling is weak (S streams per GPU).
+time (max over ranks), i.e. whole-job frames/sec; scaling is weak (S streams per GPU).  The S streams
+are split into G groups, each with its own handle and HIP stream, so that one group's tracker step
+(one workgroup per stream: latency-bound, few CUs) overlaps the other group's ReID kernels.
 
 N > 1: launched by torch.distributed.run, one rank per GPU; streams are sharded by rank with no
 data-path collective; the per-frame result rows are gathered to rank 0 once after the timed loop
@@ -40,9 +42,12 @@ DTYPE = {0: "f32", 1: "f16"}
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--groups", type=int, default=2,
+                    help="stream groups per GPU, each with its own handle and HIP stream (one group's tracker step overlaps "
+                         "the other's ReID kernels)")
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--streams", type=int, default=64, help="streams per GPU")
+    ap.add_argument("--streams", type=int, default=128, help="streams per GPU")
     ap.add_argument("--mode", choices=("reid", "embs"), default="reid",
                     help="reid: ReID inside update (headline, M2); embs: embeddings supplied (tracker math only, M1)")
     ap.add_argument("--reid-mode", type=int, default=int(os.environ.get("BOXMOT_REID_MODE", "1")),
@@ -126,10 +131,16 @@ def main():
     sd = reference_init_state_dict("osnet_x0_25", seed=0)   # random init as OSNet._init_params does it
     log("weights generated")
     nd = N_TRACKS                       # the 3 confirmation frames show every object
-    ms = MultiStreamBotSort(S, max_tracks=2 * N_TRACKS, max_dets=nd, emb_dim=EMB_DIM,
-                            reid_weights=sd if a.mode == "reid" else None, **kw)
+    G = max(1, min(a.groups, S))
+    while S % G:
+        G -= 1
+    Sg = S // G
+    groups = [MultiStreamBotSort(Sg, max_tracks=2 * N_TRACKS, max_dets=nd, emb_dim=EMB_DIM,
+                                 reid_weights=sd if a.mode == "reid" else None, **kw) for _ in range(G)]
+    ms = groups[0]
     if a.mode == "reid":
-        ms.set_reid_mode(a.reid_mode)
+        for m in groups:
+            m.set_reid_mode(a.reid_mode)
 
     # ---- synthetic inputs, resident in HBM before timing ----
     dets_h = np.zeros((T, S, nd, 6), dtype=np.float32)
@@ -156,16 +167,20 @@ def main():
     log("inputs resident on the device")
 
     def step(t):
-        ms.step_device(d_dets[t].data_ptr(), d_cnt[t].data_ptr(),
-                       d_embs[t].data_ptr() if d_embs is not None else None,
-                       d_ptrs.data_ptr() if a.mode == "reid" else None, HEIGHT, WIDTH,
-                       d_out[t].data_ptr(), d_out_n[t].data_ptr())
+        for gi, m in enumerate(groups):          # asynchronous launches, one HIP stream per group
+            lo = gi * Sg
+            m.step_device(d_dets[t, lo:lo + Sg].data_ptr(), d_cnt[t, lo:lo + Sg].data_ptr(),
+                          d_embs[t, lo:lo + Sg].data_ptr() if d_embs is not None else None,
+                          d_ptrs[lo:lo + Sg].data_ptr() if a.mode == "reid" else None, HEIGHT, WIDTH,
+                          d_out[t, lo:lo + Sg].data_ptr(), d_out_n[t, lo:lo + Sg].data_ptr())
 
     for t in range(W):
         step(t)
-    ms.synchronize()
+    for m in groups:
+        m.synchronize()
     log("warm-up done")
-    ms.reid_kernel_ms()                 # drop warm-up timings
+    for m in groups:
+        m.reid_kernel_ms()              # drop warm-up timings
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -174,7 +189,8 @@ def main():
     for t in range(W, T):
         step(t)
     dev_ms = ms.timer_stop_ms()
-    ms.synchronize()
+    for m in groups:
+        m.synchronize()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -183,9 +199,14 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     log(f"timed loop done: {elapsed:.3f}s")
-    status = ms.status()
-    assert (status == 0).all(), f"tracker status {status}"
-    reid_ms, reid_launches = ms.reid_kernel_ms()
+    for m in groups:
+        status = m.status()
+        assert (status == 0).all(), f"tracker status {status}"
+    reid_ms, reid_launches = 0.0, 0
+    for m in groups:
+        r_ms, r_n = m.reid_kernel_ms()
+        reid_ms += r_ms
+        reid_launches += r_n
 
     # ---- result gather (the only collective of the path), after the timed loop ----
     out_h, out_n_h = d_out.cpu().numpy(), d_out_n.cpu().numpy()
@@ -204,7 +225,7 @@ def main():
             "dtype": DTYPE[a.reid_mode] if a.mode == "reid" else "f64", "data": "synthetic",
             "config": {"workload": "BoT-SORT + OSNet_x0_25 ReID, 64 dets x 256 tracks, 1080p"
                                    if a.mode == "reid" else "BoT-SORT tracker math only (embeddings supplied), 64 dets x 256 tracks",
-                       "streams_per_gpu": S, "mode": "M2 reid-in-update" if a.mode == "reid" else "M1 embs-supplied",
+                       "streams_per_gpu": S, "stream_groups": G, "mode": "M2 reid-in-update" if a.mode == "reid" else "M1 embs-supplied",
                        "reid_kernels": {0: "per-layer fp32 (v1)", 1: "fused fp16 MFMA"}[a.reid_mode] if a.mode == "reid" else None,
                        "tracker_params": "botsort.yaml defaults, use_cmc=False", "weights": "random-init OSNet-x0.25 (reference _init_params scheme, seed 0)",
                        "device_ms_timed_region": dev_ms},
