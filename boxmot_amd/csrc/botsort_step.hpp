@@ -680,6 +680,10 @@ __device__ inline void lap_solve(const Ctx& c, SV& v, const LapLds& L, int R, in
 template <int NTHR>
 __device__ inline void botsort_step_stream(const BotSortStepArgs& args, int s, int* s_int, double* s_dbl,
                                            float (*sA)[COST_KC + 1], float (*sB)[COST_KC + 1], unsigned char* dyn_lds) {
+    if (args.n_dets[s] < 0) {                 // "no update for this stream in this call" (frames without detections are
+        if (threadIdx.x == 0) args.out_n[s] = 0;      // not passed to the tracker by the reference's replay loop, replay.py:318-341)
+        return;
+    }
     const Ctx c = make_ctx(s_int, s_dbl);
     const LapLds lap = carve_lap(dyn_lds, args.st.cap, args.sc.max_dets);
     int* s_count = s_int + MAX_WAVES;      // one spare LDS word (s_int has MAX_WAVES + 1 entries)

@@ -394,7 +394,7 @@ void host_update(BoxMOTHipBotSort* h, int s0, int n, const StreamIn* in, int det
     bool need_reid = false;
     for (int k = 0; k < n; ++k) {
         const int rows = in[k].det_rows;
-        if (rows < 0) throw std::runtime_error("Negative matrix dimensions are not allowed.");
+        if (rows < -1) throw std::runtime_error("Negative matrix dimensions are not allowed.");
         if (rows > 0 && det_cols == 7) throw std::runtime_error("boxmot_hip: OBB detections (7 columns) are not implemented");
         if (rows > 0 && det_cols != 6) throw std::runtime_error("boxmot_hip live tracking supports AABB detections with 6 columns.");
         if (rows > nd) throw std::runtime_error("boxmot_hip: more detections than max_dets");
@@ -412,7 +412,7 @@ void host_update(BoxMOTHipBotSort* h, int s0, int n, const StreamIn* in, int det
     float* hd = h->h_dets.data() + (size_t)s0 * nd * bm::DET_COLS;
     for (int k = 0; k < n; ++k) {
         h->h_ndets[s0 + k] = in[k].det_rows;
-        if (in[k].det_rows)
+        if (in[k].det_rows > 0)
             std::memcpy(hd + (size_t)k * nd * bm::DET_COLS, in[k].dets, (size_t)in[k].det_rows * bm::DET_COLS * 4);
         h->h_list_sel[s0 + k] = list_sel ? list_sel[k] : 0;
         h->h_fc_set[s0 + k] = fc_set ? fc_set[k] : 0;
@@ -430,7 +430,7 @@ void host_update(BoxMOTHipBotSort* h, int s0, int n, const StreamIn* in, int det
     }
     float* d_embs = h->d_embs + (size_t)s0 * nd * dim;
     for (int k = 0; k < n; ++k)
-        if (in[k].embs && in[k].det_rows)
+        if (in[k].embs && in[k].det_rows > 0)
             BM_HIP(hipMemcpyAsync(d_embs + (size_t)k * nd * dim, in[k].embs, (size_t)in[k].det_rows * dim * 4,
                                   hipMemcpyHostToDevice, h->stream));
     h->last_reid_pre_ms = h->last_reid_proc_ms = 0;
@@ -549,7 +549,7 @@ void docs_host_update(BoxMOTHipDeepOcSort* h, int n, const StreamIn* in, int det
     bool need_reid = false;
     for (int k = 0; k < n; ++k) {
         const int rows = in[k].det_rows;
-        if (rows < 0) throw std::runtime_error("Negative matrix dimensions are not allowed.");
+        if (rows < -1) throw std::runtime_error("Negative matrix dimensions are not allowed.");
         if (rows > 0 && det_cols != 6) throw std::runtime_error("boxmot_hip live tracking supports AABB detections with 6 columns.");
         if (rows > nd) throw std::runtime_error("boxmot_hip: more detections than max_dets");
         if (rows > 0 && in[k].dets == nullptr) throw std::runtime_error("Detection data pointer is null.");
@@ -564,14 +564,14 @@ void docs_host_update(BoxMOTHipDeepOcSort* h, int n, const StreamIn* in, int det
                 throw std::runtime_error("boxmot_hip: either every stream of a batch supplies embeddings or none does");
     for (int k = 0; k < n; ++k) {
         h->h_ndets[k] = in[k].det_rows;
-        if (in[k].det_rows)
+        if (in[k].det_rows > 0)
             std::memcpy(h->h_dets.data() + (size_t)k * nd * bm::DET_COLS, in[k].dets, (size_t)in[k].det_rows * bm::DET_COLS * 4);
     }
     BM_HIP(hipMemcpyAsync(h->d_dets, h->h_dets.data(), (size_t)n * nd * bm::DET_COLS * 4, hipMemcpyHostToDevice, h->stream));
     BM_HIP(hipMemcpyAsync(h->d_ndets, h->h_ndets.data(), n * 4, hipMemcpyHostToDevice, h->stream));
     if (want_emb)
         for (int k = 0; k < n; ++k)
-            if (in[k].embs && in[k].det_rows)
+            if (in[k].embs && in[k].det_rows > 0)
                 BM_HIP(hipMemcpyAsync(h->d_embs + (size_t)k * nd * dim, in[k].embs, (size_t)in[k].det_rows * dim * 4,
                                       hipMemcpyHostToDevice, h->stream));
     if (need_reid) {
@@ -703,7 +703,7 @@ void ss_host_update(BoxMOTHipStrongSort* h, int n, const StreamIn* in, int det_c
     bool need_reid = false;
     for (int k = 0; k < n; ++k) {
         const int rows = in[k].det_rows;
-        if (rows < 0) throw std::runtime_error("Negative matrix dimensions are not allowed.");
+        if (rows < -1) throw std::runtime_error("Negative matrix dimensions are not allowed.");
         if (rows > 0 && det_cols != 6) throw std::runtime_error("boxmot_hip live tracking supports AABB detections with 6 columns.");
         if (rows > nd) throw std::runtime_error("boxmot_hip: more detections than max_dets");
         if (rows > 0 && in[k].dets == nullptr) throw std::runtime_error("Detection data pointer is null.");
@@ -717,7 +717,7 @@ void ss_host_update(BoxMOTHipStrongSort* h, int n, const StreamIn* in, int det_c
                 throw std::runtime_error("boxmot_hip: either every stream of a batch supplies embeddings or none does");
     for (int k = 0; k < n; ++k) {
         h->h_ndets[k] = in[k].det_rows;
-        if (in[k].det_rows)
+        if (in[k].det_rows > 0)
             std::memcpy(h->h_dets.data() + (size_t)k * nd * bm::DET_COLS, in[k].dets, (size_t)in[k].det_rows * bm::DET_COLS * 4);
         if (!h->h_warp_flag[k]) { double* w = h->h_warp.data() + (size_t)k * 6; w[0] = 1; w[1] = 0; w[2] = 0; w[3] = 0; w[4] = 1; w[5] = 0; }
     }
@@ -725,7 +725,7 @@ void ss_host_update(BoxMOTHipStrongSort* h, int n, const StreamIn* in, int det_c
     BM_HIP(hipMemcpyAsync(h->d_ndets, h->h_ndets.data(), n * 4, hipMemcpyHostToDevice, h->stream));
     BM_HIP(hipMemcpyAsync(h->d_warp, h->h_warp.data(), (size_t)n * 6 * 8, hipMemcpyHostToDevice, h->stream));
     for (int k = 0; k < n; ++k)
-        if (in[k].embs && in[k].det_rows)
+        if (in[k].embs && in[k].det_rows > 0)
             BM_HIP(hipMemcpyAsync(h->d_embs + (size_t)k * nd * dim, in[k].embs, (size_t)in[k].det_rows * dim * 4, hipMemcpyHostToDevice, h->stream));
     if (need_reid) {
         if (!h->reid) throw std::runtime_error("boxmot_hip: embeddings are needed and none were supplied, but no ReID weights are loaded");

@@ -474,6 +474,10 @@ __device__ inline void docs_apply_match(DV& v, int slot, int kd, int lane) {
 // ---------------------------------------------------------------------------
 template <int NTHR>
 __device__ inline void docs_step_stream(const DocsStepArgs& args, int s, int* s_int, double* s_dbl, unsigned char* dyn_lds) {
+    if (args.n_dets[s] < 0) {                 // stream not stepped in this call
+        if (threadIdx.x == 0) args.out_n[s] = 0;
+        return;
+    }
     const Ctx c = make_ctx(s_int, s_dbl);
     DV v = docs_view(args, s);
     const DocsConfigDev& cfg = v.cfg;

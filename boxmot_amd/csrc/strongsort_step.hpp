@@ -250,7 +250,7 @@ __device__ inline void ss_bank_distance_block(const SsStepArgs& a, int s, int t,
     const SsState& st = a.st;
     const long cap = st.cap, dim = st.dim, nd = a.sc.max_dets;
     const int tid = threadIdx.x, tx = tid % TX, ty = tid / TX;
-    if (t >= st.n_tracks[s]) return;
+    if (a.n_dets[s] < 0 || t >= st.n_tracks[s]) return;
     const int slot = st.list[s * cap + t];
     if (st.state[s * cap + slot] != SS_CONFIRMED) return;
     const int n_d = a.n_dets[s];
@@ -617,6 +617,10 @@ __device__ inline MatchOut ss_min_cost_matching(const Ctx& c, SSV& v, const LsaL
 
 template <int NTHR>
 __device__ inline void ss_step_stream(const SsStepArgs& args, int s, int* s_int, double* s_dbl, unsigned char* dyn_lds) {
+    if (args.n_dets[s] < 0) {                 // stream not stepped in this call
+        if (threadIdx.x == 0) args.out_n[s] = 0;
+        return;
+    }
     const Ctx c = make_ctx(s_int, s_dbl);
     SSV v = ss_view(args, s);
     const SsConfigDev& cfg = v.cfg;

@@ -98,7 +98,8 @@ int boxmot_hip_botsort_update_stream(
  * NULL clears a pending warp.  Estimating the warp from images (ECC / SOF) is not part of this library. */
 int boxmot_hip_botsort_set_warp(BoxMOTHipBotSort* handle, int stream, const double* warp_2x3);
 
-/* One frame for each of the first n_streams streams in one launch set.
+/* One frame for each of the first n_streams streams in one launch set.  det_rows[s] == -1 leaves stream s untouched
+ * in this call (the reference's replay loop does not pass frames without detections to the tracker, replay.py:318-341).
  * dets[s] -> (det_rows[s], 6) fp32; embs[s] -> (det_rows[s], emb_cols) fp32 or embs == NULL;
  * images[s] -> (rows, cols, 3) uint8 BGR or NULL to keep the previously uploaded frame;
  * out[s] -> (out_capacity_rows, 9) fp32. */
