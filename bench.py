@@ -10,8 +10,10 @@ bookkeeping, all on the device).  Inputs (detections of every frame, one static 
 stream -- the reference harness also reuses one image, tests/performance/benchmark_fps.py:186) are
 resident in HBM before the timed region.  value = total frames of all streams on all GPUs / wall
 time (max over ranks), i.e. whole-job frames/sec; scaling is weak (S streams per GPU).  The S streams
-are split into G groups, each with its own handle and HIP stream, so that one group's tracker step
-(one workgroup per stream: latency-bound, few CUs) overlaps the other group's ReID kernels.
+can be split into G groups (--groups, default 1), each with its own handle and HIP stream, so that one
+group's tracker step (one workgroup per stream: latency-bound, few CUs) overlaps the other group's ReID
+kernels (+4 % at G = 2); the default keeps one group so that the HIP-event launch durations behind
+`roofline` are those of kernels running alone and agree with the rocprofv3 per-kernel averages.
 
 N > 1: launched by torch.distributed.run, one rank per GPU; streams are sharded by rank with no
 data-path collective; the per-frame result rows are gathered to rank 0 once after the timed loop
@@ -42,7 +44,7 @@ DTYPE = {0: "f32", 1: "f16"}
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--groups", type=int, default=2,
+    ap.add_argument("--groups", type=int, default=1,
                     help="stream groups per GPU, each with its own handle and HIP stream (one group's tracker step overlaps "
                          "the other's ReID kernels)")
     ap.add_argument("--steps", type=int, default=40)
