@@ -58,3 +58,23 @@ def test_emulated_deepocsort_tie_prone_scenes(seed):
 def test_emulated_deepocsort_c2_shape():
     sc = Scenario(64, 256, emb_dim=64, random_image=False)
     _run(sc.frames(8), 64, 512, 256)
+
+
+def test_emulated_kernels_clean_under_asan():
+    """Same device source under AddressSanitizer / UBSan (index lists, LDS carving, scratch sizing)."""
+    import ctypes.util
+    import glob
+    import os
+    import subprocess
+    import sys
+    libasan = sorted(glob.glob("/usr/lib/gcc/x86_64-linux-gnu/*/libasan.so"))
+    if not libasan:
+        pytest.skip("libasan.so not found")
+    code = ("import sys; sys.path[:0]=['.', 'tests']\n"
+            "from test_docs_emu import _run\n"
+            "from boxmot_amd.scenario import stress_frames\n"
+            "_run(stress_frames(14, seed=7), 32, 64, 32, sanitize=True)\nprint('ASAN-OK')\n")
+    env = dict(os.environ, LD_PRELOAD=libasan[-1], ASAN_OPTIONS="detect_leaks=0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900)
+    assert "ASAN-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]

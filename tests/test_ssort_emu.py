@@ -12,10 +12,10 @@ from emu_util import EmuStrongSort, build_ss
 from oracle.strongsort import DEFAULTS, StrongSortOracle
 
 
-def _run(frames, dim, cap, nd, warps=None, **kw):
+def _run(frames, dim, cap, nd, warps=None, sanitize=False, **kw):
     cfg = dict(DEFAULTS)
     cfg.update(kw)
-    orc, emu = StrongSortOracle(**kw), EmuStrongSort(cfg, cap=cap, nd=nd, dim=dim)
+    orc, emu = StrongSortOracle(**kw), EmuStrongSort(cfg, cap=cap, nd=nd, dim=dim, sanitize=sanitize)
     try:
         for t, (d, e) in enumerate(frames):
             w = None if warps is None else warps[t]
@@ -77,3 +77,23 @@ def test_device_assignment_solver_equals_scipy_incl_ties():
         out = np.zeros(nr, np.int32)
         lib.emu_lsa(c.ctypes.data, nr, nc, out.ctypes.data)
         assert np.array_equal(linear_sum_assignment(c)[1], out), (it, c)
+
+
+def test_emulated_kernels_clean_under_asan():
+    """Same device source under AddressSanitizer / UBSan (index lists, LDS carving, scratch sizing)."""
+    import ctypes.util
+    import glob
+    import os
+    import subprocess
+    import sys
+    libasan = sorted(glob.glob("/usr/lib/gcc/x86_64-linux-gnu/*/libasan.so"))
+    if not libasan:
+        pytest.skip("libasan.so not found")
+    code = ("import sys; sys.path[:0]=['.', 'tests']\n"
+            "from test_ssort_emu import _run\n"
+            "from boxmot_amd.scenario import stress_frames\n"
+            "_run(stress_frames(14, seed=7), 32, 64, 32, sanitize=True)\nprint('ASAN-OK')\n")
+    env = dict(os.environ, LD_PRELOAD=libasan[-1], ASAN_OPTIONS="detect_leaks=0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900)
+    assert "ASAN-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
