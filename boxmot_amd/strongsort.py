@@ -10,7 +10,7 @@ confidence scaling, gated appearance stage, IoU stage -- both assigned with a re
 
 Camera motion: the reference applies an ECC estimate unconditionally; estimation is not implemented here, so the
 tracker applies the identity (static camera) unless a ``cmc=`` object exposing the reference's
-``apply(img, boxes) -> 2x3 warp`` is given.  Rejected loudly: ``per_class=True``, OBB detections, ``nn_budget=None``.
+``apply(img, boxes) -> 2x3 warp`` is given.  Rejected loudly: OBB detections, ``nn_budget=None``.
 """
 from __future__ import annotations
 
@@ -44,8 +44,9 @@ class StrongSort(BaseTracker):
         **kwargs: Any,
     ):
         super().__init__(_tracker_name="StrongSort", **kwargs)
-        if self.per_class:
-            raise NotImplementedError("boxmot_amd.StrongSort: per_class=True is not implemented")
+        # per_class=True needs nothing here: StrongSort keeps its tracks in ``self.tracker.tracks``, which the reference's
+        # per-class fan-out (basetracker.py:223-263, it swaps ``self.active_tracks``) never partitions -- the effect is
+        # one ``_update_impl`` call per class on the same tracker, which is what BaseTracker._do_update does here too.
         if nn_budget is None:
             raise NotImplementedError("boxmot_amd.StrongSort: nn_budget=None (unbounded sample bank) is not supported")
         self.min_conf = min_conf

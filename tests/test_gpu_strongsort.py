@@ -83,3 +83,26 @@ def test_strongsort_surface_and_edge_inputs():
     with pytest.raises(AssertionError):
         trk.update(np.zeros((2, 5), dtype=np.float32), img, e)
     trk.close()
+
+
+def test_strongsort_per_class_is_one_update_per_class_like_the_reference():
+    """basetracker.py:223-263 swaps ``active_tracks`` per class, which StrongSort does not use (its tracks live in
+    ``tracker.tracks``): per_class=True therefore means nr_classes consecutive updates of the same tracker."""
+    from boxmot_amd.scenario import stress_frames
+    from boxmot_amd.strongsort import StrongSort
+    from oracle.strongsort import StrongSortOracle
+    img = np.zeros((480, 640, 3), dtype=np.uint8)
+    nc = 3
+    trk = StrongSort(emb_dim=32, max_tracks=128, max_dets=64, per_class=True, nr_classes=nc, n_init=1, max_age=60)
+    orc = StrongSortOracle(n_init=1, max_age=60)
+    for t, (dets, embs) in enumerate(stress_frames(40, seed=4)):
+        got = np.asarray(trk.update(dets, img, embs)).reshape(-1, 8)
+        want = []
+        for c in range(nc):
+            idx = np.where(dets[:, 5] == c)[0]
+            rows = orc.update(dets[idx], img, embs[idx].copy()).reshape(-1, 8)
+            if rows.size:
+                want.append(rows)
+        want = np.vstack(want) if want else np.empty((0, 8), np.float32)
+        assert_rows_match(got, want, t)
+    trk.close()
