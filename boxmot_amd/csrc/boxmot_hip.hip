@@ -184,8 +184,10 @@ struct BoxMOTHipDeepOcSort {
     hipStream_t stream = nullptr;
     int S = 1, cap = 0, nd = 0, dim = 0;
     float* d_dets = nullptr; int* d_ndets = nullptr; float* d_embs = nullptr; float* d_out = nullptr; int* d_out_n = nullptr;
+    double* d_warp = nullptr; int* d_warp_flag = nullptr;
     std::vector<float> h_dets, h_out;
-    std::vector<int> h_ndets, h_out_n;
+    std::vector<int> h_ndets, h_out_n, h_warp_flag;
+    std::vector<double> h_warp;
     std::vector<uint8_t*> frame_bufs;
     size_t frame_bytes = 0;
     int frame_rows = 0, frame_cols = 0;
@@ -497,7 +499,6 @@ void docs_zero_state(BoxMOTHipDeepOcSort* h) {
 
 void docs_build(BoxMOTHipDeepOcSort* h) {
     const BoxMOTHipDeepOcSortConfig& c = h->cfg;
-    if (!c.cmc_off) throw std::runtime_error("boxmot_hip: DeepOCSORT camera-motion compensation is not implemented; pass cmc_off=1");
     if (c.n_streams < 1 || c.max_tracks < 8 || c.max_dets < 4 || c.emb_dim < 1)
         throw std::runtime_error("boxmot_hip: invalid capacity configuration");
     if (c.max_age < 0 || c.max_age > 45)
@@ -521,6 +522,9 @@ void docs_build(BoxMOTHipDeepOcSort* h) {
     h->d_embs = zalloc<float>(S * nd * dim, o);
     h->d_out = zalloc<float>(S * cap * bm::OUT_COLS, o);
     h->d_out_n = zalloc<int>(S, o);
+    h->d_warp = zalloc<double>(S * 6, o);
+    h->d_warp_flag = zalloc<int>(S, o);
+    h->h_warp.assign(S * 6, 0.0); h->h_warp_flag.assign(S, 0);
     h->h_dets.assign(S * nd * bm::DET_COLS, 0.f);
     h->h_out.assign(S * cap * bm::OUT_COLS, 0.f);
     h->h_ndets.assign(S, 0); h->h_out_n.assign(S, 0);
@@ -605,14 +609,22 @@ void docs_host_update(BoxMOTHipDeepOcSort* h, int n, const StreamIn* in, int det
                          h->d_crop_row, h->stream);
         }
     }
+    bool any_warp = false;
+    for (int k = 0; k < n; ++k) any_warp = any_warp || h->h_warp_flag[k] != 0;
+    if (any_warp) {      // warps set with boxmot_hip_deepocsort_set_warp are consumed by this update
+        BM_HIP(hipMemcpyAsync(h->d_warp, h->h_warp.data(), (size_t)n * 6 * 8, hipMemcpyHostToDevice, h->stream));
+        BM_HIP(hipMemcpyAsync(h->d_warp_flag, h->h_warp_flag.data(), n * 4, hipMemcpyHostToDevice, h->stream));
+    }
     bm::DocsStepArgs a = h->args;
     a.dets = h->d_dets; a.n_dets = h->d_ndets; a.embs = want_emb ? h->d_embs : nullptr;
+    a.warp = any_warp ? h->d_warp : nullptr; a.warp_flag = any_warp ? h->d_warp_flag : nullptr;
     a.out = h->d_out; a.out_n = h->d_out_n; a.stream_base = 0;
     hipLaunchKernelGGL((deepocsort_step_kernel<STEP_THREADS>), dim3(n), dim3(STEP_THREADS),
                        (size_t)bm::docs_lap_lds_bytes(h->cap, h->nd), h->stream, a);
     BM_HIP(hipGetLastError());
     BM_HIP(hipMemcpyAsync(h->h_out_n.data(), h->d_out_n, n * 4, hipMemcpyDeviceToHost, h->stream));
     BM_HIP(hipStreamSynchronize(h->stream));
+    for (int k = 0; k < n; ++k) h->h_warp_flag[k] = 0;
     std::vector<int> st(n);
     BM_HIP(hipMemcpy(st.data(), h->args.st.status, n * 4, hipMemcpyDeviceToHost));
     for (int k = 0; k < n; ++k)
@@ -1164,6 +1176,19 @@ int boxmot_hip_deepocsort_reset(BoxMOTHipDeepOcSort* handle) {
     });
 }
 
+int boxmot_hip_deepocsort_set_warp(BoxMOTHipDeepOcSort* handle, int stream, const double* warp_2x3) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip DeepOCSORT handle is null.");
+        if (stream < 0 || stream >= handle->S) throw std::runtime_error("boxmot_hip: stream index out of range");
+        if (warp_2x3 == nullptr) { handle->h_warp_flag[stream] = 0; return; }
+        for (int k = 0; k < 6; ++k) {
+            if (!std::isfinite(warp_2x3[k])) throw std::runtime_error("boxmot_hip: camera-motion warp has non-finite entries");
+            handle->h_warp[(size_t)stream * 6 + k] = warp_2x3[k];
+        }
+        handle->h_warp_flag[stream] = 1;
+    });
+}
+
 int boxmot_hip_deepocsort_update_batch(BoxMOTHipDeepOcSort* handle, int n_streams, const float* const* dets,
                                        const int* det_rows, const float* const* embs, int emb_cols,
                                        const uint8_t* const* images, int image_rows, int image_cols, int image_channels,
@@ -1205,6 +1230,7 @@ int boxmot_hip_deepocsort_step_device(BoxMOTHipDeepOcSort* handle, const float* 
         if (!handle->cfg.embedding_off && !d_embs) throw std::runtime_error("boxmot_hip: step_device needs d_embs unless embedding_off");
         bm::DocsStepArgs a = handle->args;
         a.dets = d_dets; a.n_dets = d_det_rows; a.embs = handle->cfg.embedding_off ? nullptr : d_embs;
+        a.warp = nullptr; a.warp_flag = nullptr;
         a.out = d_out; a.out_n = d_out_rows; a.stream_base = 0;
         hipLaunchKernelGGL((deepocsort_step_kernel<STEP_THREADS>), dim3(handle->S), dim3(STEP_THREADS),
                            (size_t)bm::docs_lap_lds_bytes(handle->cap, handle->nd), handle->stream, a);

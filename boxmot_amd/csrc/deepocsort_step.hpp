@@ -40,6 +40,7 @@ struct DocsState {
     double* kf;           // [S][cap][72]   x[8] ++ P[8][8]
     double* kf_saved;     // [S][cap][72]   filter state at freeze() (first missed frame)
     double* last_obs;     // [S][cap][5]    last_observation (placeholder -1 x5)
+    double* last_z;       // [S][cap][4]    the last measurement as the filter stored it (history_obs; never warped)
     double* obs_box;      // [S][cap][3][5] the three most recent observations, oldest first
     int* obs_age;         // [S][cap][3]
     int* n_obs;           // [S][cap]
@@ -77,6 +78,8 @@ struct DocsStepArgs {
     const float* dets;        // [S][nd][6]
     const int* n_dets;        // [S]
     const float* embs;        // [S][nd][dim] or nullptr
+    const double* warp;       // [S][6] camera-motion warp (2x3 row-major) applied before the prediction, or nullptr
+    const int* warp_flag;     // [S] non-zero: apply warp[s] in this step
     float* out;               // [S][cap][8]  (a frame can output more rows than detections: new + matched)
     int* out_n;               // [S]
     int stream_base;
@@ -93,7 +96,7 @@ void docs_allocate(DocsStepArgs& args, const DocsSizes& z, A& a) {
     st.n_tracks = a.template get<int>(S); st.status = a.template get<int>(S);
     st.list = a.template get<int>(S * cap); st.slot_used = a.template get<int>(S * cap);
     st.kf = a.template get<double>(S * cap * KF_STRIDE); st.kf_saved = a.template get<double>(S * cap * KF_STRIDE);
-    st.last_obs = a.template get<double>(S * cap * 5); st.obs_box = a.template get<double>(S * cap * 15);
+    st.last_obs = a.template get<double>(S * cap * 5); st.last_z = a.template get<double>(S * cap * 4); st.obs_box = a.template get<double>(S * cap * 15);
     st.obs_age = a.template get<int>(S * cap * 3); st.n_obs = a.template get<int>(S * cap);
     st.velocity = a.template get<double>(S * cap * 2); st.has_vel = a.template get<int>(S * cap);
     st.emb = a.template get<double>(S * cap * dim);
@@ -242,6 +245,61 @@ __device__ inline bool kf7_update(Kf7& k, const double* m, int lane) {
     return true;
 }
 
+// KalmanFilterXYSR.apply_affine_correction, axis-aligned branch (xysr.py:311-366): x[:2] <- m x[:2] + t, x[4:6] <- m x[4:6],
+// P[:2,:2] <- m P[:2,:2] m^T, P[4:6,4:6] <- m P[4:6,4:6] m^T (diagonal blocks only), then the constraints.
+// W = [m00 m01 tx; m10 m11 ty].
+__device__ inline void kf7_affine(Kf7& k, const double* W, int lane) {
+    const int i = lane >> 3, j = lane & 7;
+    // state: lanes j in {0,1,4,5}
+    const int jb = j & ~1;                                   // 0 or 4 for the affected pairs
+    const double xa = __shfl(k.xv, (lane & ~7) | jb, WAVE), xb = __shfl(k.xv, (lane & ~7) | (jb + 1), WAVE);
+    if (j < 2 || (j >= 4 && j < 6)) {
+        double nv = W[(j & 1) * 3 + 0] * xa + W[(j & 1) * 3 + 1] * xb;
+        if (j < 2) nv = nv + W[(j & 1) * 3 + 2];
+        k.xv = nv;
+    }
+    // covariance blocks (rows/cols {0,1} and {4,5})
+    const int r0 = i & ~1;
+    const bool in_block = (r0 == 0 || r0 == 4) && (j & ~1) == r0;
+    const double p0 = __shfl(k.p, r0 * 8 + j, WAVE), p1 = __shfl(k.p, (r0 + 1) * 8 + j, WAVE);
+    const double a_ij = fma(W[(i & 1) * 3 + 1], p1, W[(i & 1) * 3 + 0] * p0);          // (m P)[i][j]
+    const double a0 = __shfl(a_ij, i * 8 + (j & ~1), WAVE), a1 = __shfl(a_ij, i * 8 + (j & ~1) + 1, WAVE);
+    const double c_ij = fma(a1, W[(j & 1) * 3 + 1], a0 * W[(j & 1) * 3 + 0]);           // ((m P) m^T)[i][j]
+    if (in_block) k.p = c_ij;
+    kf7_constrain(k, lane);
+}
+
+// KalmanBoxTracker.apply_affine_correction (deepocsort.py:190-209) for one track: the observation boxes, the filter and --
+// for an unobserved track -- its frozen copy.  `last_observation` and the newest entry of `observations` are ONE array in
+// the reference (deepocsort.py:168-170), so that box is transformed twice when it is recent enough; reproduced.
+__device__ inline void docs_affine_wave(double* kf, double* kf_saved, bool fix_saved, double* last_obs, double* obs_box, const int* obs_age,
+                                        int n_obs, int age, int delta_t, const double* W, int lane) {
+    if (lane == 0) {
+        auto T = [&](double* b) {
+            const double x1 = fma(W[1], b[1], W[0] * b[0]) + W[2], y1 = fma(W[4], b[1], W[3] * b[0]) + W[5];
+            const double x2 = fma(W[1], b[3], W[0] * b[2]) + W[2], y2 = fma(W[4], b[3], W[3] * b[2]) + W[5];
+            b[0] = x1; b[1] = y1; b[2] = x2; b[3] = y2;
+        };
+        if (last_obs[0] + last_obs[1] + last_obs[2] + last_obs[3] + last_obs[4] > 0) T(last_obs);
+        const int n_have = n_obs < 3 ? n_obs : 3;
+        for (int q = 3 - n_have; q < 3; ++q) {
+            const int a = obs_age[q];
+            if (a < age - delta_t || a > age) continue;
+            if (q == 2) T(last_obs);                       // shared storage with last_observation
+            else T(obs_box + q * 5);
+        }
+        if (n_have > 0) for (int e = 0; e < 4; ++e) obs_box[2 * 5 + e] = last_obs[e];
+    }
+    Kf7 k = kf7_load(kf, lane);
+    kf7_affine(k, W, lane);
+    kf7_store(kf, k, lane);
+    if (fix_saved) {
+        Kf7 ks = kf7_load(kf_saved, lane);
+        kf7_affine(ks, W, lane);
+        kf7_store(kf_saved, ks, lane);
+    }
+}
+
 // xyxy2xysr + _prepare_measurement (geometry.py:103-124, xysr.py:139-152)
 __device__ inline void box_to_z(const double* b, double* z) {
     const double w = b[2] - b[0], h = b[3] - b[1];
@@ -266,7 +324,7 @@ struct DV {
     int cap, dim, nd;
     int* frame_count; int* id_count; int* n_tracks; int* status;
     int* list; int* slot_used;
-    double* kf; double* kf_saved; double* last_obs; double* obs_box; int* obs_age; int* n_obs;
+    double* kf; double* kf_saved; double* last_obs; double* last_z; double* obs_box; int* obs_age; int* n_obs;
     double* velocity; int* has_vel; double* emb;
     int* id; int* age; int* tsu; int* hits; int* hit_streak; int* observed; int* has_saved; int* n_miss;
     float* conf; float* cls; float* det_ind;
@@ -284,7 +342,7 @@ __device__ inline DV docs_view(const DocsStepArgs& a, int s) {
     v.frame_count = st.frame_count + s; v.id_count = st.id_count + s; v.n_tracks = st.n_tracks + s; v.status = st.status + s;
     v.list = st.list + s * cap; v.slot_used = st.slot_used + s * cap;
     v.kf = st.kf + s * cap * KF_STRIDE; v.kf_saved = st.kf_saved + s * cap * KF_STRIDE;
-    v.last_obs = st.last_obs + s * cap * 5; v.obs_box = st.obs_box + s * cap * 15; v.obs_age = st.obs_age + s * cap * 3;
+    v.last_obs = st.last_obs + s * cap * 5; v.last_z = st.last_z + s * cap * 4; v.obs_box = st.obs_box + s * cap * 15; v.obs_age = st.obs_age + s * cap * 3;
     v.n_obs = st.n_obs + s * cap; v.velocity = st.velocity + s * cap * 2; v.has_vel = st.has_vel + s * cap;
     v.emb = st.emb + s * cap * dim;
     v.id = st.id + s * cap; v.age = st.age + s * cap; v.tsu = st.tsu + s * cap; v.hits = st.hits + s * cap;
@@ -421,7 +479,7 @@ __device__ inline void docs_apply_match(DV& v, int slot, int kd, int lane) {
     if (!v.observed[slot] && v.has_saved[slot]) {
         k = kf7_load(v.kf_saved + (long)slot * KF_STRIDE, lane);
         double zl[4];
-        box_to_z(lo, zl);                                  // last observed measurement (history_obs[index1])
+        for (int q = 0; q < 4; ++q) zl[q] = v.last_z[slot * 4 + q];      // last observed measurement (history_obs[index1])
         const int gap = v.n_miss[slot] + 1;
         const double w1 = sqrt(zl[2] * zl[3]), h1 = sqrt(zl[2] / zl[3]);
         const double w2 = sqrt(z[2] * z[3]), h2 = sqrt(z[2] / z[3]);
@@ -440,6 +498,7 @@ __device__ inline void docs_apply_match(DV& v, int slot, int kd, int lane) {
     if (lane == 0) {
         if (!ok) *v.status = STATUS_LAP_STALL + 1;
         for (int q = 0; q < 5; ++q) lo[q] = box[q];
+        for (int q = 0; q < 4; ++q) v.last_z[slot * 4 + q] = z[q];
         // observations[age] = box (keep the three most recent)
         for (int q = 0; q < 2; ++q) {
             v.obs_age[slot * 3 + q] = v.obs_age[slot * 3 + q + 1];
@@ -499,8 +558,22 @@ __device__ inline void docs_step_stream(const DocsStepArgs& args, int s, int* s_
         v.alpha[k] = cfg.alpha_fixed + (1 - cfg.alpha_fixed) * (1 - trust);
     }
 
-    // ---- predict every track (deepocsort.py:358-368, :211-225), wave per track ----
     int nt = *v.n_tracks;
+    // ---- camera-motion correction of every track (deepocsort.py:347-351), wave per track ----
+    if (args.warp_flag && args.warp_flag[s]) {
+        const double* W = args.warp + (long)s * 6;
+        for (int base = 0; base < nt; base += c.nwaves) {
+            const int t = base + c.wave;
+            if (t < nt) {
+                const int slot = v.list[t];
+                docs_affine_wave(v.kf + (long)slot * KF_STRIDE, v.kf_saved + (long)slot * KF_STRIDE, !v.observed[slot] && v.has_saved[slot],
+                                 v.last_obs + slot * 5, v.obs_box + slot * 15, v.obs_age + slot * 3, v.n_obs[slot], v.age[slot],
+                                 cfg.delta_t, W, c.lane);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- predict every track (deepocsort.py:358-368, :211-225), wave per track ----
     for (int base = 0; base < nt; base += c.nwaves) {
         const int t = base + c.wave;
         if (t < nt) {

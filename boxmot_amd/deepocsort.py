@@ -7,9 +7,10 @@ basetracker.py:19-31) and ``update(dets, img, embs=None)`` returns the reference
 observation-centric re-update, IoU / velocity-direction / adaptive-weighted appearance costs, assignment,
 recovery round, bookkeeping -- runs in one HIP kernel through the C ABI (include/boxmot_hip.h).
 
-Rejected loudly rather than approximated: camera-motion compensation (construct with ``cmc_off=True``;
-the reference default estimates a warp with OpenCV's sparse optical flow), ``per_class=True``, OBB
-detections, ``max_age > 45``.
+Camera motion: applying a warp to the tracks runs on the device (``apply_affine_correction``); estimating it from
+images (the reference's sparse-optical-flow object) is not implemented, so ``cmc_off=False`` needs a ``cmc=`` object
+exposing the reference's ``apply(img, boxes) -> 2x3 warp``.  Rejected loudly: ``per_class=True``, OBB detections,
+``max_age > 45``.
 """
 from __future__ import annotations
 
@@ -42,13 +43,15 @@ class DeepOcSort(BaseTracker):
         max_tracks: int = 1024,
         max_dets: int = 256,
         emb_dim: int | None = None,
+        cmc: Any | None = None,
         **kwargs: Any,
     ):
         super().__init__(_tracker_name="DeepOcSort", **kwargs)
-        if not cmc_off:
+        if not cmc_off and cmc is None:
             raise NotImplementedError(
-                "boxmot_amd.DeepOcSort: camera-motion compensation is not implemented on the HIP path; construct with "
-                "cmc_off=True (the reference default is cmc_off=False with the 'sof' estimator)."
+                "boxmot_amd.DeepOcSort: camera-motion estimation is not implemented on the HIP path; construct with "
+                "cmc_off=True, or pass cmc=<object with apply(img, boxes) -> 2x3 warp> (the reference default is "
+                "cmc_off=False with the 'sof' estimator)."
             )
         if self.per_class:
             raise NotImplementedError("boxmot_amd.DeepOcSort: per_class=True is not implemented")
@@ -56,7 +59,7 @@ class DeepOcSort(BaseTracker):
         self.w_association_emb, self.alpha_fixed_emb, self.aw_param = w_association_emb, alpha_fixed_emb, aw_param
         self.Q_xy_scaling, self.Q_s_scaling = Q_xy_scaling, Q_s_scaling
         self.model = reid_model
-        self.cmc = None
+        self.cmc = None if cmc_off else cmc
         self.embedding_off, self.cmc_off, self.aw_off = embedding_off, cmc_off, aw_off
         self._lib = _lib.load()
         self._emb_dim = 1 if embedding_off else (emb_dim or getattr(self.model, "feature_dim", None) or 512)
@@ -66,7 +69,7 @@ class DeepOcSort(BaseTracker):
         cfg.min_hits, cfg.iou_threshold = self.min_hits, self.iou_threshold
         cfg.delta_t, cfg.inertia, cfg.w_association_emb = delta_t, inertia, w_association_emb
         cfg.alpha_fixed_emb, cfg.aw_param = alpha_fixed_emb, aw_param
-        cfg.embedding_off, cfg.cmc_off, cfg.aw_off = int(bool(embedding_off)), 1, int(bool(aw_off))
+        cfg.embedding_off, cfg.cmc_off, cfg.aw_off = int(bool(embedding_off)), int(bool(cmc_off)), int(bool(aw_off))
         cfg.Q_xy_scaling, cfg.Q_s_scaling = Q_xy_scaling, Q_s_scaling
         cfg.n_streams, cfg.max_tracks, cfg.max_dets, cfg.emb_dim = 1, max_tracks, max_dets, self._emb_dim
         self._cfg = cfg
@@ -93,6 +96,10 @@ class DeepOcSort(BaseTracker):
             if feats.shape[1] != self._emb_dim:
                 raise ValueError(f"embedding width {feats.shape[1]} != emb_dim {self._emb_dim}")
         img_arr = np.ascontiguousarray(img)
+        if self.cmc is not None:
+            kept = det_arr[det_arr[:, 4] > np.float32(self.det_thresh), :4].astype(np.float64) if n else np.empty((0, 4))
+            warp = np.ascontiguousarray(np.asarray(self.cmc.apply(img, kept), dtype=np.float64)[:2, :3])     # deepocsort.py:348-349
+            _lib.check(self._lib.boxmot_hip_deepocsort_set_warp(self._handle, 0, warp.ctypes.data))
         out = np.empty((max(n, 1), 9), dtype=np.float32)
         out_rows, out_is_obb = ctypes.c_int(0), ctypes.c_int(0)
         ok = self._lib.boxmot_hip_deepocsort_update(

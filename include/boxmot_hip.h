@@ -194,7 +194,7 @@ typedef struct BoxMOTHipDeepOcSortConfig {
     double alpha_fixed_emb;
     double aw_param;
     int embedding_off;
-    int cmc_off;                     /* must be 1: camera-motion compensation is not implemented for this tracker */
+    int cmc_off;                     /* informational: a warp is applied only when one was supplied (boxmot_hip_deepocsort_set_warp) */
     int aw_off;
     double Q_xy_scaling;
     double Q_s_scaling;
@@ -212,6 +212,9 @@ void boxmot_hip_deepocsort_default_config(BoxMOTHipDeepOcSortConfig* config);
 BoxMOTHipDeepOcSort* boxmot_hip_deepocsort_create(const BoxMOTHipDeepOcSortConfig* config);
 void boxmot_hip_deepocsort_destroy(BoxMOTHipDeepOcSort* handle);
 int boxmot_hip_deepocsort_reset(BoxMOTHipDeepOcSort* handle);
+/* KalmanBoxTracker.apply_affine_correction (deepocsort.py:190-209, xysr.py:311-366): the 2x3 warp cmc.apply returned,
+ * applied to every track of `stream` at the start of its NEXT update (deepocsort.py:347-351) and then dropped. */
+int boxmot_hip_deepocsort_set_warp(BoxMOTHipDeepOcSort* handle, int stream, const double* warp_2x3);
 /* DeepOcSort.update for stream 0 (deepocsort.py:302-492): arguments as boxmot_hip_botsort_update; embs == NULL runs the
  * ReID engine on every detection with conf > det_thresh.  Rows [x1,y1,x2,y2,id,conf,cls,det_ind,0]. */
 int boxmot_hip_deepocsort_update(

@@ -139,6 +139,20 @@ class _FilterXYSR:
         self.P = np.linalg.multi_dot((ikh, self.P, ikh.T)) + np.linalg.multi_dot((K, self.R, K.T))
         self.P = 0.5 * (self.P + self.P.T)
 
+    def apply_affine(self, m, t):                  # xysr.py:311-366 (axis-aligned branch)
+        m = np.asarray(m, dtype=float).reshape((2, 2))
+        t = np.asarray(t, dtype=float).reshape((2, 1))
+        self.x[:2] = m @ self.x[:2] + t
+        self.x[4:6] = m @ self.x[4:6]
+        self.P[:2, :2] = m @ self.P[:2, :2] @ m.T
+        self.P[4:6, 4:6] = m @ self.P[4:6, 4:6] @ m.T
+        if not self.observed and self.saved is not None:
+            self.saved["x"][:2] = m @ self.saved["x"][:2] + t
+            self.saved["x"][4:6] = m @ self.saved["x"][4:6]
+            self.saved["P"][:2, :2] = m @ self.saved["P"][:2, :2] @ m.T
+            self.saved["P"][4:6, 4:6] = m @ self.saved["P"][4:6, 4:6] @ m.T
+        self._constrain()
+
     def _unfreeze(self):                           # xysr.py:383-440 (observation-centric re-update)
         if self.saved is None:
             return
@@ -186,6 +200,20 @@ class _Track:
         self.velocity = None
         self.delta_t = delta_t
         self.emb = emb
+
+    def apply_affine_correction(self, affine):      # :190-209 (last_observation and observations[age] share storage)
+        m = affine[:, :2]
+        t = affine[:, 2].reshape(2, 1)
+        if self.last_observation.sum() > 0:
+            ps = self.last_observation[:4].reshape(2, 2).T
+            ps = m @ ps + t
+            self.last_observation[:4] = ps.T.reshape(-1)
+        for dt in range(self.delta_t, -1, -1):
+            if self.age - dt in self.observations:
+                ps = self.observations[self.age - dt][:4].reshape(2, 2).T
+                ps = m @ ps + t
+                self.observations[self.age - dt][:4] = ps.T.reshape(-1)
+        self.kf.apply_affine(m, t)
 
     def predict(self):                              # :211-225
         if (self.kf.x[6] + self.kf.x[2]) <= 0:
@@ -349,9 +377,10 @@ class DeepOcSortOracle:
         self.count = 1                              # KalmanBoxTracker.count = 1 (deepocsort.py:293)
         self.tracks = []
 
-    def update(self, dets, img=None, embs=None):
+    def update(self, dets, img=None, embs=None, warp=None):
         """dets (N,6) [x1,y1,x2,y2,conf,cls] -> what ``DeepOcSort.update`` hands back: rows cast to fp32 by
-        ``TrackResults`` (track_results.py:22-31), shape (M,8), or (0,0) when nothing is output."""
+        ``TrackResults`` (track_results.py:22-31), shape (M,8), or (0,0) when nothing is output.  ``warp``: the 2x3
+        matrix ``cmc.apply`` returned (cmc_off=False, deepocsort.py:347-351), applied before the prediction."""
         global _lap_rule
         _lap_rule = self.lap_rule
         c = self.cfg
@@ -369,6 +398,9 @@ class DeepOcSortOracle:
             dets_embs = embs[keep]
         else:
             dets_embs = self.reid.get_features(dets[:, 0:4], img)
+        if warp is not None:
+            for trk in self.tracks:
+                trk.apply_affine_correction(warp)
         trust = (dets[:, 4] - c["det_thresh"]) / (1 - c["det_thresh"])
         af = c["alpha_fixed_emb"]
         dets_alpha = af + (1 - af) * (1 - trust)

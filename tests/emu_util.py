@@ -102,7 +102,7 @@ class EmuDeepOcSort:
         self.lib = ctypes.CDLL(str(build_docs(sanitize)))
         self.lib.emu_docs_create.restype = ctypes.c_void_p
         self.lib.emu_docs_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
-        self.lib.emu_docs_update.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+        self.lib.emu_docs_update.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                              ctypes.c_void_p, ctypes.c_void_p]
         self.lib.emu_docs_dump.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 4
         self.lib.emu_docs_destroy.argtypes = [ctypes.c_void_p]
@@ -111,14 +111,15 @@ class EmuDeepOcSort:
         self.cap, self.nd, self.dim = cap, nd, dim
         self.h = self.lib.emu_docs_create(cd.ctypes.data, ci.ctypes.data, cap, nd, dim)
 
-    def update(self, dets, embs=None):
+    def update(self, dets, embs=None, warp=None):
         dets = np.ascontiguousarray(dets, dtype=np.float32).reshape(-1, 6)
         n = len(dets)
         e = None if embs is None else np.ascontiguousarray(embs, dtype=np.float32)
+        w = None if warp is None else np.ascontiguousarray(warp, dtype=np.float64).reshape(6)
         out = np.zeros((self.cap, 8), dtype=np.float32)
         out_n = ctypes.c_int(0)
         status = self.lib.emu_docs_update(self.h, dets.ctypes.data, n, None if e is None else e.ctypes.data,
-                                          out.ctypes.data, ctypes.byref(out_n))
+                                          None if w is None else w.ctypes.data, out.ctypes.data, ctypes.byref(out_n))
         if status != 0:
             raise RuntimeError(f"emulated kernel status {status}")
         return out[: out_n.value].copy()

@@ -113,6 +113,21 @@ def deepocsort_golden():
         out[name + "_final_P"] = np.array([t.kf.P for t in act], dtype=np.float64).reshape(len(act), 7, 7)
         out[name + "_final_ids"] = np.array([t.id for t in act], dtype=np.int64)
         print(name, "frames", len(frames), "rows", sum(counts), "tracks", len(act))
+    # camera-motion correction: cmc_off=False with a scheduled stand-in for the reference's SOF object (deepocsort.py:296)
+    for name, seed, kw in (("docs_warp_default", 7, {}), ("docs_warp_short", 11, dict(max_age=6, min_hits=1))):
+        frames = stress_frames(120, seed=seed)
+        img = np.zeros((480, 640, 3), dtype=np.uint8)
+        trk = DeepOcSort(reid_model=None, cmc_off=False, **kw)
+        trk.cmc = ScheduledCMC(camera_warps(len(frames), seed=seed))
+        rows, counts = [], []
+        for dets, embs in frames:
+            r = np.asarray(trk.update(dets.copy(), img, embs.copy()), dtype=np.float32).reshape(-1, 8)
+            rows.append(r)
+            counts.append(len(r))
+        out[name + "_rows"] = np.concatenate(rows, 0)
+        out[name + "_counts"] = np.array(counts, dtype=np.int32)
+        out[name + "_final_ids"] = np.array([t.id for t in trk.active_tracks], dtype=np.int64)
+        print(name, "rows", sum(counts))
     np.savez_compressed(OUT / "deepocsort_golden.npz", **out)
 
 

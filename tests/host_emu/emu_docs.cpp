@@ -29,7 +29,7 @@ struct Emu {
     bm::DocsStepArgs args{};
     HostAlloc alloc;
     int cap, nd, dim;
-    float* dets; int* n_dets; float* embs; float* out; int* out_n;
+    float* dets; int* n_dets; float* embs; float* out; int* out_n; double* warp; int* warp_flag;
     EmuBlock block;
 };
 
@@ -64,6 +64,8 @@ void* emu_docs_create(const double* cd, const int* ci, int cap, int nd, int dim)
     e->out = e->alloc.get<float>((size_t)cap * bm::OUT_COLS);
     e->out_n = e->alloc.get<int>(1);
     e->args.dets = e->dets; e->args.n_dets = e->n_dets; e->args.embs = e->embs;
+    e->warp = e->alloc.get<double>(6); e->warp_flag = e->alloc.get<int>(1);
+    e->args.warp = e->warp; e->args.warp_flag = e->warp_flag;
     e->args.out = e->out; e->args.out_n = e->out_n; e->args.stream_base = 0;
     e->block.block_barrier.init(NTHR);
     for (int w = 0; w < EMU_MAX_WAVES; ++w) e->block.wave_barrier[w].init(EMU_WAVE);
@@ -76,8 +78,10 @@ void emu_docs_destroy(void* h) {
     delete e;
 }
 
-int emu_docs_update(void* h, const float* dets, int n, const float* embs, float* out, int* out_n) {
+int emu_docs_update(void* h, const float* dets, int n, const float* embs, const double* warp, float* out, int* out_n) {
     Emu* e = static_cast<Emu*>(h);
+    e->warp_flag[0] = warp != nullptr;
+    if (warp) std::memcpy(e->warp, warp, 48);
     if (n > e->nd) return -1;
     std::memcpy(e->dets, dets, (size_t)n * bm::DET_COLS * 4);
     if (embs) std::memcpy(e->embs, embs, (size_t)n * e->dim * 4);

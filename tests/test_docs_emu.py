@@ -9,14 +9,15 @@ from emu_util import EmuDeepOcSort
 from oracle.deepocsort import DEFAULTS, DeepOcSortOracle
 
 
-def _run(frames, dim, cap, nd, sanitize=False, lap_rule="jv", **kw):
+def _run(frames, dim, cap, nd, sanitize=False, lap_rule="jv", warps=None, **kw):
     cfg = dict(DEFAULTS)
     cfg.update(kw)
     orc, emu = DeepOcSortOracle(lap_rule=lap_rule, **kw), EmuDeepOcSort(cfg, cap=cap, nd=nd, dim=dim, sanitize=sanitize)
     try:
         for t, (d, e) in enumerate(frames):
-            want = orc.update(d.copy(), None, e.copy()).reshape(-1, 8)
-            got = emu.update(d, e)
+            w = None if warps is None else warps[t]
+            want = orc.update(d.copy(), None, e.copy(), warp=w).reshape(-1, 8)
+            got = emu.update(d, e, warp=w)
             assert got.shape == want.shape, t
             assert np.array_equal(got[:, 4:], want[:, 4:]), t
             assert np.allclose(got[:, :4], want[:, :4], rtol=0, atol=1e-4), t
@@ -53,6 +54,14 @@ def test_emulated_deepocsort_tie_prone_scenes(seed):
     frames = stress_frames(80, seed=seed, max_objects=30)
     _run(frames, 32, 128, 64, lap_rule="lowest_index")
     _run(frames, 32, 128, 64, lap_rule="lowest_index", max_age=8, min_hits=2, iou_threshold=0.2)
+
+
+def test_emulated_deepocsort_camera_motion_correction():
+    """apply_affine_correction (deepocsort.py:190-209, xysr.py:311-366) incl. the doubly-transformed newest observation
+    and the frozen filter copy of unobserved tracks."""
+    from boxmot_amd.scenario import camera_warps
+    _run(stress_frames(70, seed=7), 32, 128, 64, warps=camera_warps(70, seed=7))
+    _run(stress_frames(60, seed=11), 32, 128, 64, warps=camera_warps(60, seed=3, every=2), max_age=6, min_hits=1)
 
 
 def test_emulated_deepocsort_c2_shape():

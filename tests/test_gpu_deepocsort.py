@@ -64,6 +64,40 @@ def test_hip_deepocsort_tie_prone_scenes(seed):
         trk.close()
 
 
+@pytest.mark.parametrize("name,seed,kw", [("docs_warp_default", 7, {}), ("docs_warp_short", 11, dict(max_age=6, min_hits=1))])
+def test_hip_deepocsort_camera_motion_correction(name, seed, kw):
+    """cmc_off=False with a warp provider: apply_affine_correction on the device; golden rows from the reference driven
+    with the same scheduled warps."""
+    from boxmot_amd.deepocsort import DeepOcSort
+    from boxmot_amd.scenario import camera_warps, stress_frames
+    from common import GOLDEN
+    from oracle.deepocsort import DeepOcSortOracle
+
+    class Scheduled:
+        def __init__(self, warps):
+            self.warps, self.k = warps, 0
+
+        def apply(self, img, boxes):
+            self.k += 1
+            return self.warps[self.k - 1]
+
+    g = np.load(GOLDEN / "deepocsort_golden.npz")
+    rows, counts = g[name + "_rows"], g[name + "_counts"]
+    offs = np.concatenate([[0], np.cumsum(counts)])
+    frames = stress_frames(120, seed=seed)
+    warps = camera_warps(len(frames), seed=seed)
+    img = np.zeros((480, 640, 3), dtype=np.uint8)
+    trk = DeepOcSort(cmc_off=False, cmc=Scheduled(warps), emb_dim=32, max_tracks=256, max_dets=64, **kw)
+    orc = DeepOcSortOracle(**kw)
+    for t, (dets, embs) in enumerate(frames):
+        got = np.asarray(trk.update(dets, img, embs)).reshape(-1, 8)
+        assert_rows_match(got, rows[offs[t]:offs[t + 1]], t)
+        assert_rows_match(got, orc.update(dets, img, embs.copy(), warp=warps[t]).reshape(-1, 8), t)
+    _check_state(trk, orc)
+    assert np.array_equal(trk.state_dump()["ints"][:, 0], g[name + "_final_ids"])
+    trk.close()
+
+
 def test_deepocsort_surface_and_edge_inputs():
     from boxmot_amd import create_tracker
     from boxmot_amd.deepocsort import DeepOcSort

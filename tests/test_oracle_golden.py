@@ -90,6 +90,23 @@ def test_strongsort_oracle_matches_reference_rows(name):
         assert np.array_equal(d["cov"], g[name + "_final_cov"])
 
 
+@pytest.mark.parametrize("name,seed,kw", [("docs_warp_default", 7, {}), ("docs_warp_short", 11, dict(max_age=6, min_hits=1))])
+def test_deepocsort_oracle_camera_motion_correction_matches_reference(name, seed, kw):
+    from boxmot_amd.scenario import camera_warps, stress_frames
+    from common import GOLDEN
+    from oracle.deepocsort import DeepOcSortOracle
+    g = np.load(GOLDEN / "deepocsort_golden.npz")
+    rows, counts = g[name + "_rows"], g[name + "_counts"]
+    offs = np.concatenate([[0], np.cumsum(counts)])
+    frames = stress_frames(120, seed=seed)
+    warps = camera_warps(len(frames), seed=seed)
+    orc = DeepOcSortOracle(**kw)
+    for t, (dets, embs) in enumerate(frames):
+        got = orc.update(dets, None, embs.copy(), warp=warps[t]).reshape(-1, 8)
+        assert np.array_equal(got, rows[offs[t]:offs[t + 1]]), f"{name} frame {t}"
+    assert np.array_equal(orc.dump()["id"], g[name + "_final_ids"])
+
+
 def test_oracle_reid_matches_reference_features():
     import torch
 
