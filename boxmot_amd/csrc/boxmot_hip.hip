@@ -158,7 +158,7 @@ struct BoxMOTHipBotSort {
     const uint8_t** d_frames = nullptr;
     // reid
     std::unique_ptr<bm::ReidEngine> reid;
-    int reid_mode = 0;
+    int reid_mode = 0, reid_pad = 0;
     int* d_crop_count = nullptr;
     int* d_crop_stream = nullptr;
     float* d_crop_boxes = nullptr;
@@ -271,8 +271,13 @@ void build(BoxMOTHipBotSort* h) {
     if (c.cmc_method && c.cmc_method[0] && std::strcmp(c.cmc_method, "none") != 0)
         throw std::runtime_error("boxmot_hip: camera-motion estimation (ecc/sof/...) is not implemented; pass cmc_method=none "
                                  "and supply the warp per frame with boxmot_hip_botsort_set_warp");
-    if (c.reid_preprocess && c.reid_preprocess[0] && std::strcmp(c.reid_preprocess, "resize") != 0)
-        throw std::runtime_error("boxmot_hip: only the 'resize' ReID preprocess is implemented");
+    h->reid_pad = 0;
+    if (c.reid_preprocess && c.reid_preprocess[0]) {
+        if (std::strcmp(c.reid_preprocess, "resize_pad") == 0) h->reid_pad = 1;
+        else if (std::strcmp(c.reid_preprocess, "resize") != 0)
+            throw std::runtime_error("boxmot_hip: unknown ReID preprocess (have: resize, resize_pad)");
+    }
+    h->cfg.reid_preprocess = nullptr;
     if (c.n_streams < 1 || c.max_tracks < 8 || c.max_dets < 4 || c.emb_dim < 1 || c.n_class_lists < 1)
         throw std::runtime_error("boxmot_hip: invalid capacity configuration");
     if (c.removed_stracks_buffer < 0) throw std::runtime_error("boxmot_hip: removed_stracks_buffer must be >= 0");
@@ -322,6 +327,7 @@ void build(BoxMOTHipBotSort* h) {
         const std::vector<float> blob = bm::read_blob_file(h->reid_path.c_str());
         h->reid.reset(new bm::ReidEngine(blob.data(), (long)blob.size(), bm::reid_chunk_for((long)S * nd), (int)(S * nd)));
         if (h->reid->feature_dim() != h->dim) throw std::runtime_error("boxmot_hip: ReID feature dim != emb_dim");
+        h->reid->set_preprocess(h->reid_pad);
     }
 }
 
@@ -985,6 +991,7 @@ int boxmot_hip_botsort_set_reid_blob(BoxMOTHipBotSort* handle, const float* blob
             throw std::runtime_error("boxmot_hip: ReID feature dim != emb_dim");
         }
         handle->reid->set_mode(handle->reid_mode);
+        handle->reid->set_preprocess(handle->reid_pad);
     });
 }
 
@@ -1080,6 +1087,15 @@ BoxMOTHipReID* boxmot_hip_reid_create(const char* model_path, const float* blob,
 void boxmot_hip_reid_destroy(BoxMOTHipReID* handle) { delete handle; }
 
 int boxmot_hip_reid_feature_dim(BoxMOTHipReID* handle) { return handle && handle->engine ? handle->engine->feature_dim() : 0; }
+
+int boxmot_hip_reid_set_preprocess(BoxMOTHipReID* handle, const char* name) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip: null ReID handle");
+        if (name == nullptr || std::strcmp(name, "resize") == 0) handle->engine->set_preprocess(0);
+        else if (std::strcmp(name, "resize_pad") == 0) handle->engine->set_preprocess(1);
+        else throw std::runtime_error("boxmot_hip: unknown ReID preprocess (have: resize, resize_pad)");
+    });
+}
 
 int boxmot_hip_reid_set_mode(BoxMOTHipReID* handle, int mode) {
     return guard([&]() {

@@ -95,6 +95,9 @@ public:
     }
     int mode() const { return mode_; }
     void set_fuse_stem(bool on) { fuse_stem_ = on; }     // A/B switch: fused crop+stem kernel vs resize kernel + stem kernel
+    // 0 = "resize" (default), 1 = "resize_pad" (reid/core/preprocessing.py:12-45); resize_pad runs the separate crop kernel
+    void set_preprocess(int pad) { pad_ = pad; }
+    int preprocess_mode() const { return pad_; }
     const OsnetLayout& layout() const { return L_; }
     float* crops_buffer() { return crops_; }
 
@@ -107,10 +110,10 @@ public:
         const int rows_per_block = 16;
         if (fused)
             hipLaunchKernelGGL(k_crop_resize_rgbx, dim3(n, REID_IN_H / rows_per_block), dim3(REID_IN_W), 0, st,
-                               d_frames, d_crop_stream, d_boxes, box_stride, W, H, d_lut_, crops_h_, rows_per_block, d_count_);
+                               d_frames, d_crop_stream, d_boxes, box_stride, W, H, d_lut_, crops_h_, rows_per_block, d_count_, pad_);
         else
             hipLaunchKernelGGL(k_crop_resize<float>, dim3(n, REID_IN_H / rows_per_block), dim3(REID_IN_W), 0, st,
-                               d_frames, d_crop_stream, d_boxes, box_stride, W, H, d_lut_, crops_, rows_per_block);
+                               d_frames, d_crop_stream, d_boxes, box_stride, W, H, d_lut_, crops_, rows_per_block, pad_);
     }
     // the fp32 NHWC crop tensor is also the public "preprocess" result: force it regardless of the mode
     void preprocess_fp32(const uint8_t* const* d_frames, const int* d_crop_stream, const float* d_boxes,
@@ -129,7 +132,7 @@ public:
         const int step = mode_ == 1 ? fused_cap_ : max_crops_;
         for (int i0 = 0; i0 < n; i0 += step) {
             const int m = (n - i0) < step ? (n - i0) : step;
-            const bool fuse_stem = mode_ == 1 && fuse_stem_;
+            const bool fuse_stem = mode_ == 1 && fuse_stem_ && !pad_;
             if (!fuse_stem) preprocess(d_frames, d_crop_stream + i0, d_boxes + (long)i0 * box_stride, box_stride, m, W, H, st);
             if (i0 == 0) BM_HIP(hipEventRecord(ev_[1], st));
             hipEvent_t a = take_event(), b = take_event();
@@ -156,12 +159,13 @@ public:
         if (n_max == 0) return;
         d_count_ = d_count;
         BM_HIP(hipEventRecord(ev_[0], st));
-        if (!fuse_stem_) preprocess(d_frames, d_crop_stream, d_boxes, box_stride, n_max, W, H, st);
+        const bool fuse_stem = fuse_stem_ && !pad_;
+        if (!fuse_stem) preprocess(d_frames, d_crop_stream, d_boxes, box_stride, n_max, W, H, st);
         BM_HIP(hipEventRecord(ev_[1], st));
         hipEvent_t a = take_event(), b = take_event();
         BM_HIP(hipEventRecord(a, st));
         const FrameArgs fa{d_frames, d_crop_stream, d_boxes, box_stride, W, H};
-        forward_fused(n_max, fuse_stem_ ? &fa : nullptr, d_out, d_out_rows, st);
+        forward_fused(n_max, fuse_stem ? &fa : nullptr, d_out, d_out_rows, st);
         BM_HIP(hipEventRecord(b, st));
         if (pending_.size() < 4096) pending_.emplace_back(a, b);
         else { free_events_.push_back(a); free_events_.push_back(b); }
@@ -378,6 +382,7 @@ private:
     float *x1_ = nullptr, *ta_ = nullptr, *tb_ = nullptr, *tt_ = nullptr, *acc_ = nullptr, *gap_ = nullptr;
     // fused path
     bool fused_ready_ = false, force_fp32_crops_ = false, fuse_stem_ = true;
+    int pad_ = 0;
     BlkPack bp_[6];
     unsigned char* w_stem_ = nullptr;
     unsigned char* w_blk_[6] = {};

@@ -800,7 +800,7 @@ __global__ void __launch_bounds__(512) k_stem_resize_fused(const uint8_t* const*
 // X channel of the buffer stay zero from allocation).  Same integer pipeline as k_crop_resize.
 __global__ void k_crop_resize_rgbx(const uint8_t* const* frames, const int* crop_stream, const float* boxes,
                                    int box_stride, int W, int H, const float* lut, _Float16* out, int rows_per_block,
-                                   const int* count) {
+                                   const int* count, int pad) {
     if (count && (int)blockIdx.x >= *count) return;
     const int i = blockIdx.x;
     const int dx = threadIdx.x;
@@ -809,12 +809,12 @@ __global__ void k_crop_resize_rgbx(const uint8_t* const* frames, const int* crop
     const long row_stride = (long)W * 3;
     const uint8_t* src = frame + (long)r.y1 * row_stride + r.x1 * 3;
     const ResizeAxis ax = resize_axis_x(dx, REID_IN_W, r.w > 0 ? r.w : 1);
+    const PadGeom g = pad_geom(r, REID_IN_W, REID_IN_H);
     const int y0 = blockIdx.y * rows_per_block;
     for (int dy = y0; dy < y0 + rows_per_block && dy < REID_IN_H; ++dy) {
-        const ResizeAxis ay = resize_axis_y(dy, REID_IN_H, r.h > 0 ? r.h : 1);
         h4 px;
         for (int c = 0; c < 3; ++c) {
-            const int v = resize_sample(src, row_stride, r, ax, ay, dy, dx, 2 - c, REID_IN_W, REID_IN_H);
+            const int v = preprocess_sample(src, row_stride, r, g, pad, ax, dy, dx, 2 - c, REID_IN_W, REID_IN_H);
             px[c] = (_Float16)lut[c * 256 + v];
         }
         px[3] = (_Float16)0.f;

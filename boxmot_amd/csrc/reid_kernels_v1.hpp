@@ -83,9 +83,37 @@ __device__ inline int resize_sample(const uint8_t* src, long row_stride, const C
     return (((ay.a0 * (S0 >> 4)) >> 16) + ((ay.a1 * (S1 >> 4)) >> 16) + 2) >> 2;
 }
 
+// resize_pad (reid/core/preprocessing.py:21-45): aspect-preserving resize to (new_w, new_h) = int(dim * scale) with
+// scale = min(tw / w, th / h), centred, constant ImageNet-mean border (BGR 104, 116, 124).
+struct PadGeom { int new_w, new_h, top, left; };
+__device__ inline PadGeom pad_geom(const CropRect& r, int out_w, int out_h) {
+    const int w = r.w > 0 ? r.w : out_w, h = r.w > 0 ? r.h : out_h;      // an empty box is a blank out_h x out_w crop
+    const double sx = (double)out_w / (double)w, sy = (double)out_h / (double)h;
+    const double scale = sx < sy ? sx : sy;
+    PadGeom g;
+    g.new_w = (int)((double)w * scale);
+    g.new_h = (int)((double)h * scale);
+    g.top = (out_h - g.new_h) / 2;
+    g.left = (out_w - g.new_w) / 2;
+    return g;
+}
+// One uint8 sample (BGR source channel c) of the preprocessed crop at (dy, dx); pad == 0: plain resize.
+__device__ inline int preprocess_sample(const uint8_t* src, long row_stride, const CropRect& r, const PadGeom& g, int pad,
+                                        const ResizeAxis& ax_plain, int dy, int dx, int c, int out_w, int out_h) {
+    if (!pad) {
+        const ResizeAxis ay = resize_axis_y(dy, out_h, r.h > 0 ? r.h : 1);
+        return resize_sample(src, row_stride, r, ax_plain, ay, dy, dx, c, out_w, out_h);
+    }
+    if (r.w == 0) return 0;
+    const int yy = dy - g.top, xx = dx - g.left;
+    if (yy < 0 || yy >= g.new_h || xx < 0 || xx >= g.new_w) return c == 0 ? 104 : (c == 1 ? 116 : 124);
+    const ResizeAxis ax = resize_axis_x(xx, g.new_w, r.w), ay = resize_axis_y(yy, g.new_h, r.h);
+    return resize_sample(src, row_stride, r, ax, ay, yy, xx, c, g.new_w, g.new_h);
+}
+
 template <typename T>
 __global__ void k_crop_resize(const uint8_t* const* frames, const int* crop_stream, const float* boxes,
-                              int box_stride, int W, int H, const float* lut, T* out, int rows_per_block) {
+                              int box_stride, int W, int H, const float* lut, T* out, int rows_per_block, int pad) {
     const int i = blockIdx.x;
     const int dx = threadIdx.x;               // 0..127
     const uint8_t* frame = frames[crop_stream[i]];
@@ -93,12 +121,12 @@ __global__ void k_crop_resize(const uint8_t* const* frames, const int* crop_stre
     const long row_stride = (long)W * 3;
     const uint8_t* src = frame + (long)r.y1 * row_stride + r.x1 * 3;
     ResizeAxis ax = resize_axis_x(dx, REID_IN_W, r.w > 0 ? r.w : 1);
+    const PadGeom g = pad_geom(r, REID_IN_W, REID_IN_H);
     const int y0 = blockIdx.y * rows_per_block;
     for (int dy = y0; dy < y0 + rows_per_block && dy < REID_IN_H; ++dy) {
-        const ResizeAxis ay = resize_axis_y(dy, REID_IN_H, r.h > 0 ? r.h : 1);
         T* o = out + (((long)i * REID_IN_H + dy) * REID_IN_W + dx) * 3;
         for (int c = 0; c < 3; ++c) {         // c = RGB output channel; source is BGR
-            const int v = resize_sample(src, row_stride, r, ax, ay, dy, dx, 2 - c, REID_IN_W, REID_IN_H);
+            const int v = preprocess_sample(src, row_stride, r, g, pad, ax, dy, dx, 2 - c, REID_IN_W, REID_IN_H);
             o[c] = (T)lut[c * 256 + v];
         }
     }

@@ -25,8 +25,9 @@ MODE_FP16_FUSED = 1
 class HipReID:
     input_shape = (256, 128)
 
-    def __init__(self, weights, max_crops: int = 1024, mode: int = MODE_FP32_LAYERWISE):
-        """``weights``: state_dict, ``.pt`` checkpoint path, OSN1 blob path or blob array."""
+    def __init__(self, weights, max_crops: int = 1024, mode: int = MODE_FP32_LAYERWISE, preprocess: str | None = None):
+        """``weights``: state_dict, ``.pt`` checkpoint path, OSN1 blob path or blob array.  ``preprocess``: "resize"
+        (default) or "resize_pad" (reid/core/preprocessing.py:48-65)."""
         self._lib = _lib.load()
         self.blob = load_weights(weights)
         self.max_crops = max_crops
@@ -36,6 +37,8 @@ class HipReID:
         self.feature_dim = int(self._lib.boxmot_hip_reid_feature_dim(self._handle))
         if mode != MODE_FP32_LAYERWISE:
             self.set_mode(mode)
+        if preprocess is not None:
+            _lib.check(self._lib.boxmot_hip_reid_set_preprocess(self._handle, preprocess.encode()))
 
     def set_mode(self, mode: int) -> None:
         _lib.check(self._lib.boxmot_hip_reid_set_mode(self._handle, int(mode)))

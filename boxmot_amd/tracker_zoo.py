@@ -57,8 +57,8 @@ def create_tracker(tracker_type: str = "botsort", tracker_config=None, reid_weig
         raise ValueError(f"tracker_backend={tracker_backend!r}: boxmot_amd provides the 'hip' backend only")
     if tracker_type not in SUPPORTED:
         raise NotImplementedError(f"tracker {tracker_type!r} is not implemented on the HIP backend (have: {SUPPORTED})")
-    if reid_preprocess not in (None, "resize"):
-        raise NotImplementedError("only the 'resize' ReID preprocess is implemented")
+    if reid_preprocess not in (None, "resize", "resize_pad"):
+        raise ValueError(f"Unknown preprocess '{reid_preprocess}'. Available: ['resize', 'resize_pad']")   # preprocessing.py:60-64
     if evolve_param_dict is not None:
         kwargs = dict(evolve_param_dict)
     elif tracker_config is None:
@@ -76,7 +76,7 @@ def create_tracker(tracker_type: str = "botsort", tracker_config=None, reid_weig
         if reid_model is None and reid_weights is not None:
             from boxmot_amd.reid import HipReID
 
-            reid_model = HipReID(reid_weights)
+            reid_model = HipReID(reid_weights, preprocess=reid_preprocess)
         return StrongSort(reid_model=reid_model, **kwargs)
     if tracker_type == "deepocsort":
         from boxmot_amd.deepocsort import DeepOcSort
@@ -84,10 +84,10 @@ def create_tracker(tracker_type: str = "botsort", tracker_config=None, reid_weig
         if not kwargs.get("embedding_off", False) and reid_model is None and reid_weights is not None:
             from boxmot_amd.reid import HipReID
 
-            reid_model = HipReID(reid_weights)
+            reid_model = HipReID(reid_weights, preprocess=reid_preprocess)
         return DeepOcSort(reid_model=reid_model, **kwargs)
     if kwargs.get("with_reid", True) and reid_model is None and reid_weights is not None:
         from boxmot_amd.reid import HipReID
 
-        reid_model = HipReID(reid_weights)
+        reid_model = HipReID(reid_weights, preprocess=reid_preprocess)
     return BotSort(reid_model=reid_model, **kwargs)

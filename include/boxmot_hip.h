@@ -162,6 +162,8 @@ int boxmot_hip_botsort_state_dump(
 BoxMOTHipReID* boxmot_hip_reid_create(const char* model_path, const float* blob, long n_floats, int max_crops);
 void boxmot_hip_reid_destroy(BoxMOTHipReID* handle);
 int boxmot_hip_reid_feature_dim(BoxMOTHipReID* handle);
+/* "resize" (default) or "resize_pad" (reid/core/preprocessing.py:12-45; get_preprocess_fn :56-65) */
+int boxmot_hip_reid_set_preprocess(BoxMOTHipReID* handle, const char* name);
 int boxmot_hip_reid_set_mode(BoxMOTHipReID* handle, int mode);
 /* boxes (n, box_cols>=4) fp32 xyxy; out (n, feature_dim) fp32, L2-normalised */
 int boxmot_hip_reid_compute_features(

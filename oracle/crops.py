@@ -104,8 +104,26 @@ def crop_boxes_int(xyxys: np.ndarray, w: int, h: int) -> np.ndarray:
     return out
 
 
-def get_crops_u8(xyxys: np.ndarray, img: np.ndarray, input_shape=(256, 128)) -> np.ndarray:
-    """uint8 RGB crops (N, H, W, 3): slice -> resize -> BGR2RGB (blank if empty)."""
+IMAGENET_MEAN_BGR = (104, 116, 124)          # reid/core/preprocessing.py:8-9
+
+
+def resize_pad_u8(crop: np.ndarray, target_shape) -> np.ndarray:
+    """reid/core/preprocessing.py:21-45: aspect-preserving resize, constant ImageNet-mean (BGR) border."""
+    th, tw = target_shape
+    h, w = crop.shape[:2]
+    scale = min(tw / w, th / h)
+    new_w, new_h = int(w * scale), int(h * scale)
+    resized = cv2_resize_linear_u8(crop, (new_w, new_h))
+    top = (th - new_h) // 2
+    left = (tw - new_w) // 2
+    out = np.empty((th, tw, 3), dtype=np.uint8)
+    out[:] = np.array(IMAGENET_MEAN_BGR, dtype=np.uint8)
+    out[top:top + new_h, left:left + new_w] = resized
+    return out
+
+
+def get_crops_u8(xyxys: np.ndarray, img: np.ndarray, input_shape=(256, 128), preprocess: str = "resize") -> np.ndarray:
+    """uint8 RGB crops (N, H, W, 3): slice -> resize (or resize_pad) -> BGR2RGB (blank if empty)."""
     h, w = img.shape[:2]
     xyxys = np.asarray(xyxys, dtype=np.float32)
     if xyxys.size == 0:
@@ -117,7 +135,10 @@ def get_crops_u8(xyxys: np.ndarray, img: np.ndarray, input_shape=(256, 128)) -> 
             crop = img[y1:y2, x1:x2]
         else:
             crop = np.zeros((input_shape[0], input_shape[1], 3), dtype=np.uint8)
-        crop = cv2_resize_linear_u8(crop, (input_shape[1], input_shape[0]))
+        if preprocess == "resize_pad":
+            crop = resize_pad_u8(crop, input_shape)
+        else:
+            crop = cv2_resize_linear_u8(crop, (input_shape[1], input_shape[0]))
         out[i] = crop[:, :, ::-1]
     return out
 
@@ -136,5 +157,5 @@ def normalization_lut() -> np.ndarray:
     return ((v[None, :] - MEAN_RGB[:, None]) / STD_RGB[:, None]).astype(np.float32)
 
 
-def get_crops(xyxys: np.ndarray, img: np.ndarray, input_shape=(256, 128)) -> np.ndarray:
-    return normalize_crops(get_crops_u8(xyxys, img, input_shape))
+def get_crops(xyxys: np.ndarray, img: np.ndarray, input_shape=(256, 128), preprocess: str = "resize") -> np.ndarray:
+    return normalize_crops(get_crops_u8(xyxys, img, input_shape, preprocess))

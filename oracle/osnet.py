@@ -105,9 +105,10 @@ def osnet_forward(sd, x: torch.Tensor, return_stages: bool = False):
 class OracleReID:
     """Oracle of ``BaseModelBackend.get_features`` (base_backend.py:197-207)."""
 
-    def __init__(self, state_dict, input_shape=(256, 128), threads: int | None = None):
+    def __init__(self, state_dict, input_shape=(256, 128), threads: int | None = None, preprocess: str = "resize"):
         self.sd = {k: v.detach().to(torch.float32) for k, v in state_dict.items()}
         self.input_shape = input_shape
+        self.preprocess = preprocess
         if threads:
             torch.set_num_threads(threads)
 
@@ -118,7 +119,7 @@ class OracleReID:
 
         xyxys = np.asarray(xyxys)
         if xyxys.size != 0:
-            crops = get_crops(xyxys, img, self.input_shape)
+            crops = get_crops(xyxys, img, self.input_shape, self.preprocess)
             feats = osnet_forward(self.sd, torch.from_numpy(crops)).numpy()
         else:
             feats = np.array([])

@@ -52,8 +52,17 @@ def _cv2_stub():
         assert code == cv2.COLOR_BGR2RGB
         return np.ascontiguousarray(src[:, :, ::-1])
 
+    def copyMakeBorder(src, top, bottom, left, right, borderType, value=0):
+        assert borderType == cv2.BORDER_CONSTANT
+        h, w = src.shape[:2]
+        out = np.empty((h + top + bottom, w + left + right, src.shape[2]), dtype=src.dtype)
+        out[:] = np.asarray(value, dtype=src.dtype)
+        out[top:top + h, left:left + w] = src
+        return out
+
     cv2.resize = resize
     cv2.cvtColor = cvtColor
+    cv2.copyMakeBorder = copyMakeBorder
     return cv2
 
 
@@ -127,7 +136,7 @@ class RefReID:
     normalisation are the reference's own statements.
     """
 
-    def __init__(self, model, input_shape=(256, 128)):
+    def __init__(self, model, input_shape=(256, 128), preprocess=None):
         import torch
 
         install_standins()
@@ -160,7 +169,7 @@ class RefReID:
         b.half = False
         b.nhwc = False
         b.input_shape = input_shape
-        b.preprocess_fn = get_preprocess_fn(None)
+        b.preprocess_fn = get_preprocess_fn(preprocess)
         b.mean_array = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
         b.std_array = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
         self._b = b

@@ -99,6 +99,25 @@ int emu_stem_from_frame(const float* blob, long n_floats, const uint8_t* frame, 
     return 0;
 }
 
+// The standalone crop kernel (k_crop_resize<float>): frame (H, W, 3) uint8 BGR + boxes (n, 4) -> normalised fp32 NHWC
+// crops (n, 256, 128, 3); pad = 0 "resize", 1 "resize_pad".
+int emu_crop_resize(const uint8_t* frame, int W, int H, const float* boxes, int n, int pad, float* out) {
+    using namespace bm;
+    float lut[768];
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    for (int c = 0; c < 3; ++c)
+        for (int v = 0; v < 256; ++v) {
+            volatile float a = (float)v / 255.0f;
+            volatile float b = a - mean[c];
+            lut[c * 256 + v] = b / stdv[c];
+        }
+    std::vector<int> streams(n, 0);
+    const uint8_t* frames[1] = {frame};
+    const uint8_t* const* fr = frames; const int* cs = streams.data(); const float* lp = lut;
+    launch(n, REID_IN_H / 16, REID_IN_W, [=]() { k_crop_resize<float>(fr, cs, boxes, 4, W, H, lp, out, 16, pad); });
+    return 0;
+}
+
 int emu_reid_forward(const float* blob, long n_floats, const float* crops, int n, float* feats, float** stage_out) {
     using namespace bm;
     const int32_t* hdr = reinterpret_cast<const int32_t*>(blob);

@@ -198,3 +198,26 @@ def test_botsort_multistream_fused_reid_ids_match_oracle():
             got = out[s, : cnt[s]]
             assert got.shape == want.shape and np.array_equal(got[:, 4:], want[:, 4:]), (s, t)
     ms.close()
+
+
+def test_resize_pad_preprocess_matches_oracle_in_both_modes():
+    """reid_preprocess="resize_pad" (reid/core/preprocessing.py:21-45): crops bit-exact, features within tolerance."""
+    import torch
+
+    from boxmot_amd.reid import MODE_FP16_FUSED, MODE_FP32_LAYERWISE, HipReID
+    from boxmot_amd.reid_weights import reference_init_state_dict
+    from oracle.crops import get_crops
+    from oracle.osnet import OracleReID
+    sd = reference_init_state_dict("osnet_x0_25", seed=0)
+    img = np.random.default_rng(11).integers(0, 255, (480, 641, 3), dtype=np.uint8)
+    boxes = np.array([[30.2, 40.7, 90.1, 200.3], [-20, -10, 40, 60], [100, 100, 100, 150], [10, 10, 138, 266], [0, 0, 641, 480],
+                      [600.4, 430.2, 700, 500], [50, 20, 200, 330], [5, 5, 300, 40], [7, 3, 9, 400]], dtype=np.float32)
+    want = OracleReID(sd, preprocess="resize_pad").get_features(boxes, img)
+    for mode, tol in ((MODE_FP32_LAYERWISE, 2e-5), (MODE_FP16_FUSED, 1e-3)):
+        r = HipReID(sd, mode=mode, preprocess="resize_pad")
+        if mode == MODE_FP32_LAYERWISE:
+            crops = r.get_crops(boxes, img)
+            assert np.array_equal(np.asarray(crops), get_crops(boxes, img, preprocess="resize_pad"))
+        assert np.abs(r.get_features(boxes, img) - want).max() < tol
+    with pytest.raises(RuntimeError):
+        HipReID(sd, preprocess="letterbox")

@@ -93,3 +93,22 @@ def test_fused_crop_stem_kernel_equals_separate_kernels_emulated():
     _, st = osnet_forward(sd, torch.from_numpy(crops), return_stages=True)
     ref = st["maxpool"].numpy().transpose(0, 2, 3, 1).reshape(n, 2048, 16)
     assert np.abs(st_fused - ref).max() < 1e-3 * np.abs(ref).max()
+
+
+@pytest.mark.skipif(CLANG is None, reason="needs a host clang with _Float16")
+@pytest.mark.parametrize("pad", [0, 1])
+def test_crop_kernel_resize_and_resize_pad_equal_the_oracle_emulated(pad):
+    """k_crop_resize (device source on CPU threads) vs oracle.crops for both preprocess modes: "resize" and the
+    aspect-preserving "resize_pad" with the ImageNet-mean border (reid/core/preprocessing.py:12-45) -- bit for bit."""
+    from oracle.crops import get_crops
+
+    lib = ctypes.CDLL(str(_build()))
+    lib.emu_crop_resize.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    wd, hd = 641, 480
+    img = np.random.default_rng(5).integers(0, 255, (hd, wd, 3), dtype=np.uint8)
+    boxes = np.array([[30.2, 40.7, 90.1, 200.3], [-20, -10, 40, 60], [100, 100, 100, 150], [10, 10, 138, 266],
+                      [0, 0, 641, 480], [600.4, 430.2, 700, 500], [50, 20, 200, 330], [5, 5, 300, 40], [7, 3, 9, 400]], dtype=np.float32)
+    out = np.zeros((len(boxes), 256, 128, 3), np.float32)
+    assert lib.emu_crop_resize(img.ctypes.data, wd, hd, boxes.ctypes.data, len(boxes), pad, out.ctypes.data) == 0
+    want = get_crops(boxes, img, preprocess="resize_pad" if pad else "resize").transpose(0, 2, 3, 1)
+    assert np.array_equal(out, want)
