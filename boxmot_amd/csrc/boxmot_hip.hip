@@ -176,10 +176,10 @@ struct BoxMOTHipBotSort {
     }
 };
 
-struct BoxMOTHipDeepOcSort {
-    BoxMOTHipDeepOcSortConfig cfg{};
+// Host-side plumbing shared by the DeepOCSORT and StrongSORT handles: pinned-down staging of the per-stream inputs,
+// the frames and ReID engine for "embeddings not supplied", pending camera-motion warps, result read-back.
+struct StreamIo {
     std::string reid_path;
-    bm::DocsStepArgs args{};
     std::vector<void*> owned;
     hipStream_t stream = nullptr;
     int S = 1, cap = 0, nd = 0, dim = 0;
@@ -194,7 +194,7 @@ struct BoxMOTHipDeepOcSort {
     const uint8_t** d_frames = nullptr;
     std::unique_ptr<bm::ReidEngine> reid;
     int* d_crop_count = nullptr; int* d_crop_stream = nullptr; float* d_crop_boxes = nullptr; int* d_crop_row = nullptr;
-    ~BoxMOTHipDeepOcSort() {
+    ~StreamIo() {
         reid.reset();
         for (void* p : owned) (void)hipFree(p);
         for (auto* p : frame_bufs) if (p) (void)hipFree(p);
@@ -202,30 +202,14 @@ struct BoxMOTHipDeepOcSort {
     }
 };
 
-struct BoxMOTHipStrongSort {
+struct BoxMOTHipDeepOcSort : StreamIo {
+    BoxMOTHipDeepOcSortConfig cfg{};
+    bm::DocsStepArgs args{};
+};
+
+struct BoxMOTHipStrongSort : StreamIo {
     BoxMOTHipStrongSortConfig cfg{};
-    std::string reid_path;
     bm::SsStepArgs args{};
-    std::vector<void*> owned;
-    hipStream_t stream = nullptr;
-    int S = 1, cap = 0, nd = 0, dim = 0;
-    float* d_dets = nullptr; int* d_ndets = nullptr; float* d_embs = nullptr; float* d_out = nullptr; int* d_out_n = nullptr;
-    double* d_warp = nullptr;
-    std::vector<float> h_dets, h_out;
-    std::vector<int> h_ndets, h_out_n, h_warp_flag;
-    std::vector<double> h_warp;
-    std::vector<uint8_t*> frame_bufs;
-    size_t frame_bytes = 0;
-    int frame_rows = 0, frame_cols = 0;
-    const uint8_t** d_frames = nullptr;
-    std::unique_ptr<bm::ReidEngine> reid;
-    int* d_crop_count = nullptr; int* d_crop_stream = nullptr; float* d_crop_boxes = nullptr; int* d_crop_row = nullptr;
-    ~BoxMOTHipStrongSort() {
-        reid.reset();
-        for (void* p : owned) (void)hipFree(p);
-        for (auto* p : frame_bufs) if (p) (void)hipFree(p);
-        if (stream) (void)hipStreamDestroy(stream);
-    }
 };
 
 namespace {
@@ -490,6 +474,146 @@ void host_update_one(BoxMOTHipBotSort* h, int stream, int class_list, int frame_
 
 
 // ---------------------------------------------------------------------------
+// StreamIo: shared host plumbing of the DeepOCSORT / StrongSORT handles
+// ---------------------------------------------------------------------------
+void io_allocate(StreamIo* h, int S, int cap, int nd, int dim, bool with_reid) {
+    h->S = S; h->cap = cap; h->nd = nd; h->dim = dim;
+    BM_HIP(hipStreamCreate(&h->stream));
+    auto& o = h->owned;
+    const size_t s = S, c = cap, n = nd, d = dim;
+    h->d_dets = zalloc<float>(s * n * bm::DET_COLS, o);
+    h->d_ndets = zalloc<int>(s, o);
+    h->d_embs = zalloc<float>(s * n * d, o);
+    h->d_out = zalloc<float>(s * c * bm::OUT_COLS, o);
+    h->d_out_n = zalloc<int>(s, o);
+    h->d_warp = zalloc<double>(s * 6, o);
+    h->d_warp_flag = zalloc<int>(s, o);
+    h->h_dets.assign(s * n * bm::DET_COLS, 0.f);
+    h->h_out.assign(c * bm::OUT_COLS, 0.f);
+    h->h_ndets.assign(s, 0); h->h_out_n.assign(s, 0);
+    h->h_warp.assign(s * 6, 0.0); h->h_warp_flag.assign(s, 0);
+    h->frame_bufs.assign(s, nullptr);
+    h->d_frames = zalloc<const uint8_t*>(s, o);
+    h->d_crop_count = zalloc<int>(1, o);
+    h->d_crop_stream = zalloc<int>(s * n, o);
+    h->d_crop_boxes = zalloc<float>(s * n * 4, o);
+    h->d_crop_row = zalloc<int>(s * n, o);
+    if (with_reid && !h->reid_path.empty()) {
+        const std::vector<float> blob = bm::read_blob_file(h->reid_path.c_str());
+        h->reid.reset(new bm::ReidEngine(blob.data(), (long)blob.size(), bm::reid_chunk_for((long)S * nd), (int)(S * nd)));
+        if (h->reid->feature_dim() != h->dim) throw std::runtime_error("boxmot_hip: ReID feature dim != emb_dim");
+    }
+}
+
+void io_set_warp(StreamIo* h, int stream, const double* warp_2x3) {
+    if (stream < 0 || stream >= h->S) throw std::runtime_error("boxmot_hip: stream index out of range");
+    if (warp_2x3 == nullptr) { h->h_warp_flag[stream] = 0; return; }
+    for (int k = 0; k < 6; ++k) {
+        if (!std::isfinite(warp_2x3[k])) throw std::runtime_error("boxmot_hip: camera-motion warp has non-finite entries");
+        h->h_warp[(size_t)stream * 6 + k] = warp_2x3[k];
+    }
+    h->h_warp_flag[stream] = 1;
+}
+
+// Validate and upload the inputs of the first n streams; run the ReID engine on every detection passing the confidence
+// test (`conf > thresh`, or `>=` when inclusive) when embeddings are wanted and not supplied.  Streams without a pending
+// warp get the identity.  Returns whether any stream has a pending warp.
+bool io_stage(StreamIo* h, int n, const StreamIn* in, int det_cols, int emb_cols, bool want_emb, int image_rows, int image_cols,
+              int image_channels, int out_capacity_rows, double reid_thresh, int inclusive) {
+    const int nd = h->nd, dim = h->dim;
+    bool need_reid = false;
+    for (int k = 0; k < n; ++k) {
+        const int rows = in[k].det_rows;
+        if (rows < -1) throw std::runtime_error("Negative matrix dimensions are not allowed.");
+        if (rows > 0 && det_cols != 6) throw std::runtime_error("boxmot_hip live tracking supports AABB detections with 6 columns.");
+        if (rows > nd) throw std::runtime_error("boxmot_hip: more detections than max_dets");
+        if (rows > 0 && in[k].dets == nullptr) throw std::runtime_error("Detection data pointer is null.");
+        if (out_capacity_rows < rows) throw std::runtime_error("boxmot_hip: output buffer is too small for the current frame.");
+        if (want_emb && in[k].embs != nullptr && emb_cols != dim && rows > 0)
+            throw std::runtime_error("boxmot_hip: embedding width does not match emb_dim");
+        if (want_emb && in[k].embs == nullptr && rows > 0) need_reid = true;
+    }
+    if (need_reid)
+        for (int k = 0; k < n; ++k)
+            if (in[k].embs != nullptr && in[k].det_rows > 0)
+                throw std::runtime_error("boxmot_hip: either every stream of a batch supplies embeddings or none does");
+    bool any_warp = false;
+    for (int k = 0; k < n; ++k) {
+        h->h_ndets[k] = in[k].det_rows;
+        if (in[k].det_rows > 0)
+            std::memcpy(h->h_dets.data() + (size_t)k * nd * bm::DET_COLS, in[k].dets, (size_t)in[k].det_rows * bm::DET_COLS * 4);
+        if (h->h_warp_flag[k]) any_warp = true;
+        else { double* w = h->h_warp.data() + (size_t)k * 6; w[0] = 1; w[1] = 0; w[2] = 0; w[3] = 0; w[4] = 1; w[5] = 0; }
+    }
+    BM_HIP(hipMemcpyAsync(h->d_dets, h->h_dets.data(), (size_t)n * nd * bm::DET_COLS * 4, hipMemcpyHostToDevice, h->stream));
+    BM_HIP(hipMemcpyAsync(h->d_ndets, h->h_ndets.data(), n * 4, hipMemcpyHostToDevice, h->stream));
+    BM_HIP(hipMemcpyAsync(h->d_warp, h->h_warp.data(), (size_t)n * 6 * 8, hipMemcpyHostToDevice, h->stream));
+    BM_HIP(hipMemcpyAsync(h->d_warp_flag, h->h_warp_flag.data(), n * 4, hipMemcpyHostToDevice, h->stream));
+    if (want_emb)
+        for (int k = 0; k < n; ++k)
+            if (in[k].embs && in[k].det_rows > 0)
+                BM_HIP(hipMemcpyAsync(h->d_embs + (size_t)k * nd * dim, in[k].embs, (size_t)in[k].det_rows * dim * 4,
+                                      hipMemcpyHostToDevice, h->stream));
+    if (!need_reid) return any_warp;
+    if (!h->reid) throw std::runtime_error("boxmot_hip: embeddings are needed and none were supplied, but no ReID weights are loaded");
+    if (image_channels != 3) throw std::runtime_error("boxmot_hip: ReID needs a 3-channel uint8 BGR image");
+    const size_t bytes = (size_t)image_rows * image_cols * 3;
+    for (int k = 0; k < n; ++k) {
+        if (!in[k].image) { if (!h->frame_bufs[k]) throw std::runtime_error("Image data pointer is null."); continue; }
+        if (h->frame_bufs[k] == nullptr || bytes != h->frame_bytes) {
+            if (h->frame_bytes != 0 && bytes != h->frame_bytes) throw std::runtime_error("boxmot_hip: frame size changed between updates");
+            void* p = nullptr;
+            BM_HIP(hipMalloc(&p, bytes));
+            h->frame_bufs[k] = static_cast<uint8_t*>(p);
+            h->frame_bytes = bytes; h->frame_rows = image_rows; h->frame_cols = image_cols;
+            BM_HIP(hipMemcpy(h->d_frames, h->frame_bufs.data(), h->S * sizeof(uint8_t*), hipMemcpyHostToDevice));
+        }
+        BM_HIP(hipMemcpyAsync(h->frame_bufs[k], in[k].image, bytes, hipMemcpyHostToDevice, h->stream));
+    }
+    BM_HIP(hipMemsetAsync(h->d_crop_count, 0, 4, h->stream));
+    hipLaunchKernelGGL(build_crop_list_kernel, dim3(n), dim3(256), 0, h->stream, h->d_dets, h->d_ndets, nd, reid_thresh,
+                       h->d_crop_count, h->d_crop_stream, h->d_crop_boxes, h->d_crop_row, 0, inclusive);
+    if (h->reid->mode() == 1) {
+        h->reid->run_counted(h->d_frames, h->d_crop_stream, h->d_crop_boxes, 4, h->d_crop_count, n * nd, h->frame_cols,
+                             h->frame_rows, h->d_embs, h->d_crop_row, h->stream);
+    } else {
+        int n_crops = 0;
+        BM_HIP(hipMemcpyAsync(&n_crops, h->d_crop_count, 4, hipMemcpyDeviceToHost, h->stream));
+        BM_HIP(hipStreamSynchronize(h->stream));
+        h->reid->run(h->d_frames, h->d_crop_stream, h->d_crop_boxes, 4, n_crops, h->frame_cols, h->frame_rows, h->d_embs,
+                     h->d_crop_row, h->stream);
+    }
+    return any_warp;
+}
+
+// After the step kernel: wait, clear the consumed warps, turn a non-zero status word into an exception, copy the rows out.
+void io_read_back(StreamIo* h, int n, const int* d_status, const char* tracker, float* const* out, int out_capacity_rows, int* out_rows) {
+    BM_HIP(hipGetLastError());
+    BM_HIP(hipMemcpyAsync(h->h_out_n.data(), h->d_out_n, n * 4, hipMemcpyDeviceToHost, h->stream));
+    BM_HIP(hipStreamSynchronize(h->stream));
+    for (int k = 0; k < n; ++k) h->h_warp_flag[k] = 0;
+    std::vector<int> st(n);
+    BM_HIP(hipMemcpy(st.data(), d_status, n * 4, hipMemcpyDeviceToHost));
+    for (int k = 0; k < n; ++k)
+        if (st[k] != bm::STATUS_OK)
+            throw std::runtime_error(std::string("boxmot_hip: ") + tracker + " stream " + std::to_string(k) + ": " +
+                                     (st[k] == bm::STATUS_TRACK_CAPACITY ? "track capacity (max_tracks) exceeded"
+                                      : st[k] == bm::STATUS_LAP_STALL ? "assignment solver did not converge (non-finite costs?)"
+                                                                      : "innovation covariance is not positive definite"));
+    for (int k = 0; k < n; ++k) {
+        const int rows = h->h_out_n[k];
+        if (rows > out_capacity_rows) throw std::runtime_error("boxmot_hip: output buffer is too small for the current frame.");
+        if (rows) BM_HIP(hipMemcpy(h->h_out.data(), h->d_out + (size_t)k * h->cap * bm::OUT_COLS, (size_t)rows * bm::OUT_COLS * 4, hipMemcpyDeviceToHost));
+        for (int r = 0; r < rows; ++r) {
+            float* dst = out[k] + (size_t)r * 9;
+            for (int q = 0; q < 8; ++q) dst[q] = h->h_out[(size_t)r * bm::OUT_COLS + q];
+            dst[8] = 0.0f;
+        }
+        out_rows[k] = rows;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // DeepOCSORT host path
 // ---------------------------------------------------------------------------
 void docs_zero_state(BoxMOTHipDeepOcSort* h) {
@@ -511,147 +635,36 @@ void docs_build(BoxMOTHipDeepOcSort* h) {
         throw std::runtime_error("boxmot_hip: DeepOCSORT max_age must be in [0, 45] (the reference's 50-entry observation history, xysr.py:18)");
     if (c.delta_t < 1 || c.delta_t > 3) throw std::runtime_error("boxmot_hip: DeepOCSORT delta_t must be 1..3");
     if (!(c.aw_param < 1.0)) throw std::runtime_error("boxmot_hip: aw_param must be < 1");
-    h->S = c.n_streams; h->cap = c.max_tracks; h->nd = c.max_dets; h->dim = c.embedding_off ? 1 : c.emb_dim;
-    BM_HIP(hipStreamCreate(&h->stream));
+    io_allocate(h, c.n_streams, c.max_tracks, c.max_dets, c.embedding_off ? 1 : c.emb_dim, !c.embedding_off);
     bm::DocsConfigDev& d = h->args.cfg;
     d.det_thresh = c.det_thresh; d.det_thresh_f32 = (float)c.det_thresh; d.max_age = c.max_age; d.min_hits = c.min_hits;
     d.delta_t = c.delta_t; d.iou_threshold = c.iou_threshold; d.inertia = c.inertia; d.w_emb = c.w_association_emb;
     d.alpha_fixed = c.alpha_fixed_emb; d.aw_param = c.aw_param; d.q_xy = c.Q_xy_scaling; d.q_s = c.Q_s_scaling;
     d.embedding_off = c.embedding_off; d.aw_off = c.aw_off;
-    auto& o = h->owned;
-    DevAlloc dev_allocator{&o};
+    DevAlloc dev_allocator{&h->owned};
     bm::DocsSizes z{h->S, h->cap, h->nd, h->dim};
     bm::docs_allocate(h->args, z, dev_allocator);
-    const size_t S = h->S, cap = h->cap, nd = h->nd, dim = h->dim;
-    h->d_dets = zalloc<float>(S * nd * bm::DET_COLS, o);
-    h->d_ndets = zalloc<int>(S, o);
-    h->d_embs = zalloc<float>(S * nd * dim, o);
-    h->d_out = zalloc<float>(S * cap * bm::OUT_COLS, o);
-    h->d_out_n = zalloc<int>(S, o);
-    h->d_warp = zalloc<double>(S * 6, o);
-    h->d_warp_flag = zalloc<int>(S, o);
-    h->h_warp.assign(S * 6, 0.0); h->h_warp_flag.assign(S, 0);
-    h->h_dets.assign(S * nd * bm::DET_COLS, 0.f);
-    h->h_out.assign(S * cap * bm::OUT_COLS, 0.f);
-    h->h_ndets.assign(S, 0); h->h_out_n.assign(S, 0);
-    h->frame_bufs.assign(S, nullptr);
-    h->d_frames = zalloc<const uint8_t*>(S, o);
-    h->d_crop_count = zalloc<int>(1, o);
-    h->d_crop_stream = zalloc<int>(S * nd, o);
-    h->d_crop_boxes = zalloc<float>(S * nd * 4, o);
-    h->d_crop_row = zalloc<int>(S * nd, o);
     const long lds = bm::docs_lap_lds_bytes(h->cap, h->nd);
     if (lds > 120 * 1024) throw std::runtime_error("boxmot_hip: max_tracks/max_dets too large for the assignment solver's LDS state");
     BM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deepocsort_step_kernel<STEP_THREADS>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (!c.embedding_off && !h->reid_path.empty()) {
-        const std::vector<float> blob = bm::read_blob_file(h->reid_path.c_str());
-        h->reid.reset(new bm::ReidEngine(blob.data(), (long)blob.size(), bm::reid_chunk_for((long)S * nd), (int)(S * nd)));
-        if (h->reid->feature_dim() != h->dim) throw std::runtime_error("boxmot_hip: ReID feature dim != emb_dim");
-    }
 }
 
-// Stage inputs of the first n streams, run ReID on the kept detections if embeddings are not supplied, step, read back.
+// Stage the inputs of the first n streams (ReID on every detection above det_thresh when embeddings are not supplied,
+// deepocsort.py:337-345), step, read back.
 void docs_host_update(BoxMOTHipDeepOcSort* h, int n, const StreamIn* in, int det_cols, int emb_cols, int image_rows,
                       int image_cols, int image_channels, float* const* out, int out_capacity_rows, int* out_rows) {
-    const int nd = h->nd, dim = h->dim, cap = h->cap;
     const bool want_emb = !h->cfg.embedding_off;
-    bool need_reid = false;
-    for (int k = 0; k < n; ++k) {
-        const int rows = in[k].det_rows;
-        if (rows < -1) throw std::runtime_error("Negative matrix dimensions are not allowed.");
-        if (rows > 0 && det_cols != 6) throw std::runtime_error("boxmot_hip live tracking supports AABB detections with 6 columns.");
-        if (rows > nd) throw std::runtime_error("boxmot_hip: more detections than max_dets");
-        if (rows > 0 && in[k].dets == nullptr) throw std::runtime_error("Detection data pointer is null.");
-        if (out_capacity_rows < rows) throw std::runtime_error("boxmot_hip: output buffer is too small for the current frame.");
-        if (want_emb && in[k].embs != nullptr && emb_cols != dim && rows > 0)
-            throw std::runtime_error("boxmot_hip: embedding width does not match emb_dim");
-        if (want_emb && in[k].embs == nullptr && rows > 0) need_reid = true;
-    }
-    if (need_reid)
-        for (int k = 0; k < n; ++k)
-            if (in[k].embs != nullptr && in[k].det_rows > 0)
-                throw std::runtime_error("boxmot_hip: either every stream of a batch supplies embeddings or none does");
-    for (int k = 0; k < n; ++k) {
-        h->h_ndets[k] = in[k].det_rows;
-        if (in[k].det_rows > 0)
-            std::memcpy(h->h_dets.data() + (size_t)k * nd * bm::DET_COLS, in[k].dets, (size_t)in[k].det_rows * bm::DET_COLS * 4);
-    }
-    BM_HIP(hipMemcpyAsync(h->d_dets, h->h_dets.data(), (size_t)n * nd * bm::DET_COLS * 4, hipMemcpyHostToDevice, h->stream));
-    BM_HIP(hipMemcpyAsync(h->d_ndets, h->h_ndets.data(), n * 4, hipMemcpyHostToDevice, h->stream));
-    if (want_emb)
-        for (int k = 0; k < n; ++k)
-            if (in[k].embs && in[k].det_rows > 0)
-                BM_HIP(hipMemcpyAsync(h->d_embs + (size_t)k * nd * dim, in[k].embs, (size_t)in[k].det_rows * dim * 4,
-                                      hipMemcpyHostToDevice, h->stream));
-    if (need_reid) {
-        if (!h->reid) throw std::runtime_error("boxmot_hip: embeddings are needed and none were supplied, but no ReID weights are loaded");
-        if (image_channels != 3) throw std::runtime_error("boxmot_hip: ReID needs a 3-channel uint8 BGR image");
-        const size_t bytes = (size_t)image_rows * image_cols * 3;
-        for (int k = 0; k < n; ++k) {
-            if (!in[k].image) { if (!h->frame_bufs[k]) throw std::runtime_error("Image data pointer is null."); continue; }
-            if (h->frame_bufs[k] == nullptr || bytes != h->frame_bytes) {
-                if (h->frame_bytes != 0 && bytes != h->frame_bytes) throw std::runtime_error("boxmot_hip: frame size changed between updates");
-                void* p = nullptr;
-                BM_HIP(hipMalloc(&p, bytes));
-                h->frame_bufs[k] = static_cast<uint8_t*>(p);
-                h->frame_bytes = bytes; h->frame_rows = image_rows; h->frame_cols = image_cols;
-                BM_HIP(hipMemcpy(h->d_frames, h->frame_bufs.data(), h->S * sizeof(uint8_t*), hipMemcpyHostToDevice));
-            }
-            BM_HIP(hipMemcpyAsync(h->frame_bufs[k], in[k].image, bytes, hipMemcpyHostToDevice, h->stream));
-        }
-        // every detection above det_thresh gets an embedding (deepocsort.py:337-345)
-        BM_HIP(hipMemsetAsync(h->d_crop_count, 0, 4, h->stream));
-        hipLaunchKernelGGL(build_crop_list_kernel, dim3(n), dim3(256), 0, h->stream, h->d_dets, h->d_ndets, nd,
-                           (double)(float)h->cfg.det_thresh, h->d_crop_count, h->d_crop_stream, h->d_crop_boxes, h->d_crop_row, 0);
-        if (h->reid->mode() == 1) {
-            h->reid->run_counted(h->d_frames, h->d_crop_stream, h->d_crop_boxes, 4, h->d_crop_count, n * nd, h->frame_cols,
-                                 h->frame_rows, h->d_embs, h->d_crop_row, h->stream);
-        } else {
-            int n_crops = 0;
-            BM_HIP(hipMemcpyAsync(&n_crops, h->d_crop_count, 4, hipMemcpyDeviceToHost, h->stream));
-            BM_HIP(hipStreamSynchronize(h->stream));
-            h->reid->run(h->d_frames, h->d_crop_stream, h->d_crop_boxes, 4, n_crops, h->frame_cols, h->frame_rows, h->d_embs,
-                         h->d_crop_row, h->stream);
-        }
-    }
-    bool any_warp = false;
-    for (int k = 0; k < n; ++k) any_warp = any_warp || h->h_warp_flag[k] != 0;
-    if (any_warp) {      // warps set with boxmot_hip_deepocsort_set_warp are consumed by this update
-        BM_HIP(hipMemcpyAsync(h->d_warp, h->h_warp.data(), (size_t)n * 6 * 8, hipMemcpyHostToDevice, h->stream));
-        BM_HIP(hipMemcpyAsync(h->d_warp_flag, h->h_warp_flag.data(), n * 4, hipMemcpyHostToDevice, h->stream));
-    }
+    const bool any_warp = io_stage(h, n, in, det_cols, emb_cols, want_emb, image_rows, image_cols, image_channels, out_capacity_rows,
+                                   (double)(float)h->cfg.det_thresh, 0);
     bm::DocsStepArgs a = h->args;
     a.dets = h->d_dets; a.n_dets = h->d_ndets; a.embs = want_emb ? h->d_embs : nullptr;
     a.warp = any_warp ? h->d_warp : nullptr; a.warp_flag = any_warp ? h->d_warp_flag : nullptr;
     a.out = h->d_out; a.out_n = h->d_out_n; a.stream_base = 0;
     hipLaunchKernelGGL((deepocsort_step_kernel<STEP_THREADS>), dim3(n), dim3(STEP_THREADS),
                        (size_t)bm::docs_lap_lds_bytes(h->cap, h->nd), h->stream, a);
-    BM_HIP(hipGetLastError());
-    BM_HIP(hipMemcpyAsync(h->h_out_n.data(), h->d_out_n, n * 4, hipMemcpyDeviceToHost, h->stream));
-    BM_HIP(hipStreamSynchronize(h->stream));
-    for (int k = 0; k < n; ++k) h->h_warp_flag[k] = 0;
-    std::vector<int> st(n);
-    BM_HIP(hipMemcpy(st.data(), h->args.st.status, n * 4, hipMemcpyDeviceToHost));
-    for (int k = 0; k < n; ++k)
-        if (st[k] != bm::STATUS_OK)
-            throw std::runtime_error("boxmot_hip: DeepOCSORT stream " + std::to_string(k) + ": " +
-                                     (st[k] == bm::STATUS_TRACK_CAPACITY ? "track capacity (max_tracks) exceeded"
-                                      : st[k] == bm::STATUS_LAP_STALL ? "assignment solver did not converge (non-finite costs?)"
-                                                                      : "innovation covariance is not positive definite"));
-    for (int k = 0; k < n; ++k) {
-        const int rows = h->h_out_n[k];
-        if (rows > out_capacity_rows) throw std::runtime_error("boxmot_hip: output buffer is too small for the current frame.");
-        if (rows) BM_HIP(hipMemcpy(h->h_out.data(), h->d_out + (size_t)k * cap * bm::OUT_COLS, (size_t)rows * bm::OUT_COLS * 4, hipMemcpyDeviceToHost));
-        for (int r = 0; r < rows; ++r) {
-            float* dst = out[k] + (size_t)r * 9;
-            for (int q = 0; q < 8; ++q) dst[q] = h->h_out[(size_t)r * bm::OUT_COLS + q];
-            dst[8] = 0.0f;
-        }
-        out_rows[k] = rows;
-    }
+    io_read_back(h, n, h->args.st.status, "DeepOCSORT", out, out_capacity_rows, out_rows);
 }
-
 
 // ---------------------------------------------------------------------------
 // StrongSORT host path
@@ -676,137 +689,39 @@ void ss_build(BoxMOTHipStrongSort* h) {
         throw std::runtime_error("boxmot_hip: invalid capacity configuration");
     if (c.nn_budget < 1 || c.nn_budget > 1024) throw std::runtime_error("boxmot_hip: StrongSORT nn_budget must be in [1, 1024] (None is not supported)");
     if (c.n_init < 1 || c.max_age < 0) throw std::runtime_error("boxmot_hip: invalid n_init / max_age");
-    h->S = c.n_streams; h->cap = c.max_tracks; h->nd = c.max_dets; h->dim = c.emb_dim;
-    BM_HIP(hipStreamCreate(&h->stream));
+    io_allocate(h, c.n_streams, c.max_tracks, c.max_dets, c.emb_dim, true);
     bm::SsConfigDev& d = h->args.cfg;
     d.min_conf = c.min_conf; d.max_cos_dist = c.max_cos_dist; d.max_iou_dist = c.max_iou_dist; d.mc_lambda = c.mc_lambda;
     d.ema_alpha_f32 = (float)c.ema_alpha; d.one_minus_alpha_f32 = (float)(1 - c.ema_alpha);
     d.max_age = c.max_age; d.n_init = c.n_init; d.budget = c.nn_budget;
-    auto& o = h->owned;
-    DevAlloc dev_allocator{&o};
+    DevAlloc dev_allocator{&h->owned};
     bm::SsSizes z{h->S, h->cap, h->nd, h->dim, c.nn_budget};
     bm::ss_allocate(h->args, z, dev_allocator);
-    const size_t S = h->S, cap = h->cap, nd = h->nd, dim = h->dim;
-    h->d_dets = zalloc<float>(S * nd * bm::DET_COLS, o);
-    h->d_ndets = zalloc<int>(S, o);
-    h->d_embs = zalloc<float>(S * nd * dim, o);
-    h->d_out = zalloc<float>(S * cap * bm::OUT_COLS, o);
-    h->d_out_n = zalloc<int>(S, o);
-    h->d_warp = zalloc<double>(S * 6, o);
-    h->h_dets.assign(S * nd * bm::DET_COLS, 0.f);
-    h->h_out.assign(S * cap * bm::OUT_COLS, 0.f);
-    h->h_ndets.assign(S, 0); h->h_out_n.assign(S, 0);
-    h->h_warp.assign(S * 6, 0.0); h->h_warp_flag.assign(S, 0);
-    h->frame_bufs.assign(S, nullptr);
-    h->d_frames = zalloc<const uint8_t*>(S, o);
-    h->d_crop_count = zalloc<int>(1, o);
-    h->d_crop_stream = zalloc<int>(S * nd, o);
-    h->d_crop_boxes = zalloc<float>(S * nd * 4, o);
-    h->d_crop_row = zalloc<int>(S * nd, o);
     const long lds = bm::ss_lsa_lds_bytes(h->cap > h->nd ? h->cap : h->nd);
     if (lds > 120 * 1024) throw std::runtime_error("boxmot_hip: max_tracks/max_dets too large for the assignment solver's LDS state");
     BM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(strongsort_step_kernel<STEP_THREADS>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (!h->reid_path.empty()) {
-        const std::vector<float> blob = bm::read_blob_file(h->reid_path.c_str());
-        h->reid.reset(new bm::ReidEngine(blob.data(), (long)blob.size(), bm::reid_chunk_for((long)S * nd), (int)(S * nd)));
-        if (h->reid->feature_dim() != h->dim) throw std::runtime_error("boxmot_hip: ReID feature dim != emb_dim");
-    }
     ss_zero_state(h);
 }
 
+// detection norms -> sample-bank distances of every confirmed track (state BEFORE this frame's step) -> frame step
+void ss_launch(BoxMOTHipStrongSort* h, const bm::SsStepArgs& a, int n) {
+    hipLaunchKernelGGL((strongsort_detnorm_kernel<SS_BANK_THREADS>), dim3(n), dim3(SS_BANK_THREADS), 0, h->stream, a);
+    hipLaunchKernelGGL((strongsort_bank_kernel<SS_BANK_THREADS>), dim3(h->cap, n), dim3(SS_BANK_THREADS), 0, h->stream, a);
+    hipLaunchKernelGGL((strongsort_step_kernel<STEP_THREADS>), dim3(n), dim3(STEP_THREADS),
+                       (size_t)bm::ss_lsa_lds_bytes(h->cap > h->nd ? h->cap : h->nd), h->stream, a);
+}
+
+// Stage the inputs of the first n streams (ReID on every detection with conf >= min_conf when embeddings are not supplied,
+// strongsort.py:74-91), step, read back.
 void ss_host_update(BoxMOTHipStrongSort* h, int n, const StreamIn* in, int det_cols, int emb_cols, int image_rows,
                     int image_cols, int image_channels, float* const* out, int out_capacity_rows, int* out_rows) {
-    const int nd = h->nd, dim = h->dim, cap = h->cap;
-    bool need_reid = false;
-    for (int k = 0; k < n; ++k) {
-        const int rows = in[k].det_rows;
-        if (rows < -1) throw std::runtime_error("Negative matrix dimensions are not allowed.");
-        if (rows > 0 && det_cols != 6) throw std::runtime_error("boxmot_hip live tracking supports AABB detections with 6 columns.");
-        if (rows > nd) throw std::runtime_error("boxmot_hip: more detections than max_dets");
-        if (rows > 0 && in[k].dets == nullptr) throw std::runtime_error("Detection data pointer is null.");
-        if (out_capacity_rows < rows) throw std::runtime_error("boxmot_hip: output buffer is too small for the current frame.");
-        if (in[k].embs != nullptr && emb_cols != dim && rows > 0) throw std::runtime_error("boxmot_hip: embedding width does not match emb_dim");
-        if (in[k].embs == nullptr && rows > 0) need_reid = true;
-    }
-    if (need_reid)
-        for (int k = 0; k < n; ++k)
-            if (in[k].embs != nullptr && in[k].det_rows > 0)
-                throw std::runtime_error("boxmot_hip: either every stream of a batch supplies embeddings or none does");
-    for (int k = 0; k < n; ++k) {
-        h->h_ndets[k] = in[k].det_rows;
-        if (in[k].det_rows > 0)
-            std::memcpy(h->h_dets.data() + (size_t)k * nd * bm::DET_COLS, in[k].dets, (size_t)in[k].det_rows * bm::DET_COLS * 4);
-        if (!h->h_warp_flag[k]) { double* w = h->h_warp.data() + (size_t)k * 6; w[0] = 1; w[1] = 0; w[2] = 0; w[3] = 0; w[4] = 1; w[5] = 0; }
-    }
-    BM_HIP(hipMemcpyAsync(h->d_dets, h->h_dets.data(), (size_t)n * nd * bm::DET_COLS * 4, hipMemcpyHostToDevice, h->stream));
-    BM_HIP(hipMemcpyAsync(h->d_ndets, h->h_ndets.data(), n * 4, hipMemcpyHostToDevice, h->stream));
-    BM_HIP(hipMemcpyAsync(h->d_warp, h->h_warp.data(), (size_t)n * 6 * 8, hipMemcpyHostToDevice, h->stream));
-    for (int k = 0; k < n; ++k)
-        if (in[k].embs && in[k].det_rows > 0)
-            BM_HIP(hipMemcpyAsync(h->d_embs + (size_t)k * nd * dim, in[k].embs, (size_t)in[k].det_rows * dim * 4, hipMemcpyHostToDevice, h->stream));
-    if (need_reid) {
-        if (!h->reid) throw std::runtime_error("boxmot_hip: embeddings are needed and none were supplied, but no ReID weights are loaded");
-        if (image_channels != 3) throw std::runtime_error("boxmot_hip: ReID needs a 3-channel uint8 BGR image");
-        const size_t bytes = (size_t)image_rows * image_cols * 3;
-        for (int k = 0; k < n; ++k) {
-            if (!in[k].image) { if (!h->frame_bufs[k]) throw std::runtime_error("Image data pointer is null."); continue; }
-            if (h->frame_bufs[k] == nullptr || bytes != h->frame_bytes) {
-                if (h->frame_bytes != 0 && bytes != h->frame_bytes) throw std::runtime_error("boxmot_hip: frame size changed between updates");
-                void* p = nullptr;
-                BM_HIP(hipMalloc(&p, bytes));
-                h->frame_bufs[k] = static_cast<uint8_t*>(p);
-                h->frame_bytes = bytes; h->frame_rows = image_rows; h->frame_cols = image_cols;
-                BM_HIP(hipMemcpy(h->d_frames, h->frame_bufs.data(), h->S * sizeof(uint8_t*), hipMemcpyHostToDevice));
-            }
-            BM_HIP(hipMemcpyAsync(h->frame_bufs[k], in[k].image, bytes, hipMemcpyHostToDevice, h->stream));
-        }
-        // every detection with conf >= min_conf gets an embedding (strongsort.py:74-91)
-        BM_HIP(hipMemsetAsync(h->d_crop_count, 0, 4, h->stream));
-        hipLaunchKernelGGL(build_crop_list_kernel, dim3(n), dim3(256), 0, h->stream, h->d_dets, h->d_ndets, nd, h->cfg.min_conf,
-                           h->d_crop_count, h->d_crop_stream, h->d_crop_boxes, h->d_crop_row, 0, 1);
-        if (h->reid->mode() == 1) {
-            h->reid->run_counted(h->d_frames, h->d_crop_stream, h->d_crop_boxes, 4, h->d_crop_count, n * nd, h->frame_cols,
-                                 h->frame_rows, h->d_embs, h->d_crop_row, h->stream);
-        } else {
-            int n_crops = 0;
-            BM_HIP(hipMemcpyAsync(&n_crops, h->d_crop_count, 4, hipMemcpyDeviceToHost, h->stream));
-            BM_HIP(hipStreamSynchronize(h->stream));
-            h->reid->run(h->d_frames, h->d_crop_stream, h->d_crop_boxes, 4, n_crops, h->frame_cols, h->frame_rows, h->d_embs,
-                         h->d_crop_row, h->stream);
-        }
-    }
+    io_stage(h, n, in, det_cols, emb_cols, true, image_rows, image_cols, image_channels, out_capacity_rows, h->cfg.min_conf, 1);
     bm::SsStepArgs a = h->args;
-    a.dets = h->d_dets; a.n_dets = h->d_ndets; a.embs = h->d_embs; a.warp = h->d_warp;
+    a.dets = h->d_dets; a.n_dets = h->d_ndets; a.embs = h->d_embs; a.warp = h->d_warp;     // identity where no warp is pending
     a.out = h->d_out; a.out_n = h->d_out_n; a.stream_base = 0;
-    // appearance distances of every confirmed track to every detection (uses the state BEFORE this frame's step)
-    hipLaunchKernelGGL((strongsort_detnorm_kernel<SS_BANK_THREADS>), dim3(n), dim3(SS_BANK_THREADS), 0, h->stream, a);
-    hipLaunchKernelGGL((strongsort_bank_kernel<SS_BANK_THREADS>), dim3(cap, n), dim3(SS_BANK_THREADS), 0, h->stream, a);
-    hipLaunchKernelGGL((strongsort_step_kernel<STEP_THREADS>), dim3(n), dim3(STEP_THREADS),
-                       (size_t)bm::ss_lsa_lds_bytes(cap > nd ? cap : nd), h->stream, a);
-    BM_HIP(hipGetLastError());
-    BM_HIP(hipMemcpyAsync(h->h_out_n.data(), h->d_out_n, n * 4, hipMemcpyDeviceToHost, h->stream));
-    BM_HIP(hipStreamSynchronize(h->stream));
-    for (int k = 0; k < n; ++k) h->h_warp_flag[k] = 0;
-    std::vector<int> st(n);
-    BM_HIP(hipMemcpy(st.data(), h->args.st.status, n * 4, hipMemcpyDeviceToHost));
-    for (int k = 0; k < n; ++k)
-        if (st[k] != bm::STATUS_OK)
-            throw std::runtime_error("boxmot_hip: StrongSORT stream " + std::to_string(k) + ": " +
-                                     (st[k] == bm::STATUS_TRACK_CAPACITY ? "track capacity (max_tracks) exceeded"
-                                      : st[k] == bm::STATUS_LAP_STALL ? "assignment solver found the cost matrix infeasible (non-finite costs?)"
-                                                                      : "innovation covariance is not positive definite"));
-    for (int k = 0; k < n; ++k) {
-        const int rows = h->h_out_n[k];
-        if (rows > out_capacity_rows) throw std::runtime_error("boxmot_hip: output buffer is too small for the current frame.");
-        if (rows) BM_HIP(hipMemcpy(h->h_out.data(), h->d_out + (size_t)k * cap * bm::OUT_COLS, (size_t)rows * bm::OUT_COLS * 4, hipMemcpyDeviceToHost));
-        for (int r = 0; r < rows; ++r) {
-            float* dst = out[k] + (size_t)r * 9;
-            for (int q = 0; q < 8; ++q) dst[q] = h->h_out[(size_t)r * bm::OUT_COLS + q];
-            dst[8] = 0.0f;
-        }
-        out_rows[k] = rows;
-    }
+    ss_launch(h, a, n);
+    io_read_back(h, n, h->args.st.status, "StrongSORT", out, out_capacity_rows, out_rows);
 }
 
 }  // namespace
@@ -1195,13 +1110,7 @@ int boxmot_hip_deepocsort_reset(BoxMOTHipDeepOcSort* handle) {
 int boxmot_hip_deepocsort_set_warp(BoxMOTHipDeepOcSort* handle, int stream, const double* warp_2x3) {
     return guard([&]() {
         if (!handle) throw std::runtime_error("boxmot_hip DeepOCSORT handle is null.");
-        if (stream < 0 || stream >= handle->S) throw std::runtime_error("boxmot_hip: stream index out of range");
-        if (warp_2x3 == nullptr) { handle->h_warp_flag[stream] = 0; return; }
-        for (int k = 0; k < 6; ++k) {
-            if (!std::isfinite(warp_2x3[k])) throw std::runtime_error("boxmot_hip: camera-motion warp has non-finite entries");
-            handle->h_warp[(size_t)stream * 6 + k] = warp_2x3[k];
-        }
-        handle->h_warp_flag[stream] = 1;
+        io_set_warp(handle, stream, warp_2x3);
     });
 }
 
@@ -1328,13 +1237,7 @@ int boxmot_hip_strongsort_reset(BoxMOTHipStrongSort* handle) {
 int boxmot_hip_strongsort_set_warp(BoxMOTHipStrongSort* handle, int stream, const double* warp_2x3) {
     return guard([&]() {
         if (!handle) throw std::runtime_error("boxmot_hip StrongSORT handle is null.");
-        if (stream < 0 || stream >= handle->S) throw std::runtime_error("boxmot_hip: stream index out of range");
-        if (warp_2x3 == nullptr) { handle->h_warp_flag[stream] = 0; return; }
-        for (int k = 0; k < 6; ++k) {
-            if (!std::isfinite(warp_2x3[k])) throw std::runtime_error("boxmot_hip: camera-motion warp has non-finite entries");
-            handle->h_warp[(size_t)stream * 6 + k] = warp_2x3[k];
-        }
-        handle->h_warp_flag[stream] = 1;
+        io_set_warp(handle, stream, warp_2x3);
     });
 }
 
@@ -1379,10 +1282,7 @@ int boxmot_hip_strongsort_step_device(BoxMOTHipStrongSort* handle, const float* 
         bm::SsStepArgs a = handle->args;
         a.dets = d_dets; a.n_dets = d_det_rows; a.embs = d_embs; a.warp = nullptr;
         a.out = d_out; a.out_n = d_out_rows; a.stream_base = 0;
-        hipLaunchKernelGGL((strongsort_detnorm_kernel<SS_BANK_THREADS>), dim3(handle->S), dim3(SS_BANK_THREADS), 0, handle->stream, a);
-        hipLaunchKernelGGL((strongsort_bank_kernel<SS_BANK_THREADS>), dim3(handle->cap, handle->S), dim3(SS_BANK_THREADS), 0, handle->stream, a);
-        hipLaunchKernelGGL((strongsort_step_kernel<STEP_THREADS>), dim3(handle->S), dim3(STEP_THREADS),
-                           (size_t)bm::ss_lsa_lds_bytes(handle->cap > handle->nd ? handle->cap : handle->nd), handle->stream, a);
+        ss_launch(handle, a, handle->S);
         BM_HIP(hipGetLastError());
     });
 }
