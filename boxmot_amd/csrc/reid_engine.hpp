@@ -4,6 +4,7 @@
 //   mode 1: fused fp16 MFMA kernels (reid_fused.hpp)
 // Reference path: BaseModelBackend.get_features, base_backend.py:197-207.
 #pragma once
+#include <cstdlib>
 
 #include <hip/hip_runtime.h>
 
