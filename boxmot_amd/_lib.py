@@ -131,6 +131,8 @@ SIGNATURES = {
     "boxmot_hip_deepocsort_reset": (_I, [_VP]),
     "boxmot_hip_deepocsort_set_warp": (_I, [_VP, _I, _VP]),
     "boxmot_hip_deepocsort_update": (_I, [_VP, _VP, _I, _I, _VP, _I, _I, _VP, _I, _I, _I, _VP, _I, _I, c_int_p, c_int_p]),
+    "boxmot_hip_deepocsort_update_stream": (_I, [_VP, _I, _I, c_int_p, _VP, _I, _I, _VP, _I, _I, _VP, _I, _I, _I, _VP, _I, _I,
+                                                 c_int_p, c_int_p]),
     "boxmot_hip_deepocsort_update_batch": (_I, [_VP, _I, _VP, _VP, _VP, _I, _VP, _I, _I, _I, _VP, _I, _VP]),
     "boxmot_hip_deepocsort_step_device": (_I, [_VP, _VP, _VP, _VP, _VP, _VP]),
     "boxmot_hip_deepocsort_synchronize": (_I, [_VP]),

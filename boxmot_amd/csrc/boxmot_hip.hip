@@ -519,8 +519,9 @@ void io_set_warp(StreamIo* h, int stream, const double* warp_2x3) {
 // test (`conf > thresh`, or `>=` when inclusive) when embeddings are wanted and not supplied.  Streams without a pending
 // warp get the identity.  Returns whether any stream has a pending warp.
 bool io_stage(StreamIo* h, int n, const StreamIn* in, int det_cols, int emb_cols, bool want_emb, int image_rows, int image_cols,
-              int image_channels, int out_capacity_rows, double reid_thresh, int inclusive) {
+              int image_channels, int out_capacity_rows, double reid_thresh, int inclusive, int s0 = 0) {
     const int nd = h->nd, dim = h->dim;
+    if (s0 < 0 || n < 1 || s0 + n > h->S) throw std::runtime_error("boxmot_hip: stream index out of range");
     bool need_reid = false;
     for (int k = 0; k < n; ++k) {
         const int rows = in[k].det_rows;
@@ -539,40 +540,44 @@ bool io_stage(StreamIo* h, int n, const StreamIn* in, int det_cols, int emb_cols
                 throw std::runtime_error("boxmot_hip: either every stream of a batch supplies embeddings or none does");
     bool any_warp = false;
     for (int k = 0; k < n; ++k) {
-        h->h_ndets[k] = in[k].det_rows;
+        const size_t sk = (size_t)(s0 + k);
+        h->h_ndets[sk] = in[k].det_rows;
         if (in[k].det_rows > 0)
-            std::memcpy(h->h_dets.data() + (size_t)k * nd * bm::DET_COLS, in[k].dets, (size_t)in[k].det_rows * bm::DET_COLS * 4);
-        if (h->h_warp_flag[k]) any_warp = true;
-        else { double* w = h->h_warp.data() + (size_t)k * 6; w[0] = 1; w[1] = 0; w[2] = 0; w[3] = 0; w[4] = 1; w[5] = 0; }
+            std::memcpy(h->h_dets.data() + sk * nd * bm::DET_COLS, in[k].dets, (size_t)in[k].det_rows * bm::DET_COLS * 4);
+        if (h->h_warp_flag[sk]) any_warp = true;
+        else { double* w = h->h_warp.data() + sk * 6; w[0] = 1; w[1] = 0; w[2] = 0; w[3] = 0; w[4] = 1; w[5] = 0; }
     }
-    BM_HIP(hipMemcpyAsync(h->d_dets, h->h_dets.data(), (size_t)n * nd * bm::DET_COLS * 4, hipMemcpyHostToDevice, h->stream));
-    BM_HIP(hipMemcpyAsync(h->d_ndets, h->h_ndets.data(), n * 4, hipMemcpyHostToDevice, h->stream));
-    BM_HIP(hipMemcpyAsync(h->d_warp, h->h_warp.data(), (size_t)n * 6 * 8, hipMemcpyHostToDevice, h->stream));
-    BM_HIP(hipMemcpyAsync(h->d_warp_flag, h->h_warp_flag.data(), n * 4, hipMemcpyHostToDevice, h->stream));
+    const size_t o = (size_t)s0;
+    BM_HIP(hipMemcpyAsync(h->d_dets + o * nd * bm::DET_COLS, h->h_dets.data() + o * nd * bm::DET_COLS, (size_t)n * nd * bm::DET_COLS * 4,
+                          hipMemcpyHostToDevice, h->stream));
+    BM_HIP(hipMemcpyAsync(h->d_ndets + o, h->h_ndets.data() + o, n * 4, hipMemcpyHostToDevice, h->stream));
+    BM_HIP(hipMemcpyAsync(h->d_warp + o * 6, h->h_warp.data() + o * 6, (size_t)n * 6 * 8, hipMemcpyHostToDevice, h->stream));
+    BM_HIP(hipMemcpyAsync(h->d_warp_flag + o, h->h_warp_flag.data() + o, n * 4, hipMemcpyHostToDevice, h->stream));
     if (want_emb)
         for (int k = 0; k < n; ++k)
             if (in[k].embs && in[k].det_rows > 0)
-                BM_HIP(hipMemcpyAsync(h->d_embs + (size_t)k * nd * dim, in[k].embs, (size_t)in[k].det_rows * dim * 4,
+                BM_HIP(hipMemcpyAsync(h->d_embs + (size_t)(s0 + k) * nd * dim, in[k].embs, (size_t)in[k].det_rows * dim * 4,
                                       hipMemcpyHostToDevice, h->stream));
     if (!need_reid) return any_warp;
     if (!h->reid) throw std::runtime_error("boxmot_hip: embeddings are needed and none were supplied, but no ReID weights are loaded");
     if (image_channels != 3) throw std::runtime_error("boxmot_hip: ReID needs a 3-channel uint8 BGR image");
     const size_t bytes = (size_t)image_rows * image_cols * 3;
     for (int k = 0; k < n; ++k) {
-        if (!in[k].image) { if (!h->frame_bufs[k]) throw std::runtime_error("Image data pointer is null."); continue; }
-        if (h->frame_bufs[k] == nullptr || bytes != h->frame_bytes) {
+        const int sk = s0 + k;
+        if (!in[k].image) { if (!h->frame_bufs[sk]) throw std::runtime_error("Image data pointer is null."); continue; }
+        if (h->frame_bufs[sk] == nullptr || bytes != h->frame_bytes) {
             if (h->frame_bytes != 0 && bytes != h->frame_bytes) throw std::runtime_error("boxmot_hip: frame size changed between updates");
             void* p = nullptr;
             BM_HIP(hipMalloc(&p, bytes));
-            h->frame_bufs[k] = static_cast<uint8_t*>(p);
+            h->frame_bufs[sk] = static_cast<uint8_t*>(p);
             h->frame_bytes = bytes; h->frame_rows = image_rows; h->frame_cols = image_cols;
             BM_HIP(hipMemcpy(h->d_frames, h->frame_bufs.data(), h->S * sizeof(uint8_t*), hipMemcpyHostToDevice));
         }
-        BM_HIP(hipMemcpyAsync(h->frame_bufs[k], in[k].image, bytes, hipMemcpyHostToDevice, h->stream));
+        BM_HIP(hipMemcpyAsync(h->frame_bufs[sk], in[k].image, bytes, hipMemcpyHostToDevice, h->stream));
     }
     BM_HIP(hipMemsetAsync(h->d_crop_count, 0, 4, h->stream));
     hipLaunchKernelGGL(build_crop_list_kernel, dim3(n), dim3(256), 0, h->stream, h->d_dets, h->d_ndets, nd, reid_thresh,
-                       h->d_crop_count, h->d_crop_stream, h->d_crop_boxes, h->d_crop_row, 0, inclusive);
+                       h->d_crop_count, h->d_crop_stream, h->d_crop_boxes, h->d_crop_row, s0, inclusive);
     if (h->reid->mode() == 1) {
         h->reid->run_counted(h->d_frames, h->d_crop_stream, h->d_crop_boxes, 4, h->d_crop_count, n * nd, h->frame_cols,
                              h->frame_rows, h->d_embs, h->d_crop_row, h->stream);
@@ -587,23 +592,24 @@ bool io_stage(StreamIo* h, int n, const StreamIn* in, int det_cols, int emb_cols
 }
 
 // After the step kernel: wait, clear the consumed warps, turn a non-zero status word into an exception, copy the rows out.
-void io_read_back(StreamIo* h, int n, const int* d_status, const char* tracker, float* const* out, int out_capacity_rows, int* out_rows) {
+void io_read_back(StreamIo* h, int n, const int* d_status, const char* tracker, float* const* out, int out_capacity_rows, int* out_rows,
+                  int s0 = 0) {
     BM_HIP(hipGetLastError());
-    BM_HIP(hipMemcpyAsync(h->h_out_n.data(), h->d_out_n, n * 4, hipMemcpyDeviceToHost, h->stream));
+    BM_HIP(hipMemcpyAsync(h->h_out_n.data(), h->d_out_n + s0, n * 4, hipMemcpyDeviceToHost, h->stream));
     BM_HIP(hipStreamSynchronize(h->stream));
-    for (int k = 0; k < n; ++k) h->h_warp_flag[k] = 0;
+    for (int k = 0; k < n; ++k) h->h_warp_flag[s0 + k] = 0;
     std::vector<int> st(n);
-    BM_HIP(hipMemcpy(st.data(), d_status, n * 4, hipMemcpyDeviceToHost));
+    BM_HIP(hipMemcpy(st.data(), d_status + s0, n * 4, hipMemcpyDeviceToHost));
     for (int k = 0; k < n; ++k)
         if (st[k] != bm::STATUS_OK)
-            throw std::runtime_error(std::string("boxmot_hip: ") + tracker + " stream " + std::to_string(k) + ": " +
+            throw std::runtime_error(std::string("boxmot_hip: ") + tracker + " stream " + std::to_string(s0 + k) + ": " +
                                      (st[k] == bm::STATUS_TRACK_CAPACITY ? "track capacity (max_tracks) exceeded"
                                       : st[k] == bm::STATUS_LAP_STALL ? "assignment solver did not converge (non-finite costs?)"
                                                                       : "innovation covariance is not positive definite"));
     for (int k = 0; k < n; ++k) {
         const int rows = h->h_out_n[k];
         if (rows > out_capacity_rows) throw std::runtime_error("boxmot_hip: output buffer is too small for the current frame.");
-        if (rows) BM_HIP(hipMemcpy(h->h_out.data(), h->d_out + (size_t)k * h->cap * bm::OUT_COLS, (size_t)rows * bm::OUT_COLS * 4, hipMemcpyDeviceToHost));
+        if (rows) BM_HIP(hipMemcpy(h->h_out.data(), h->d_out + (size_t)(s0 + k) * h->cap * bm::OUT_COLS, (size_t)rows * bm::OUT_COLS * 4, hipMemcpyDeviceToHost));
         for (int r = 0; r < rows; ++r) {
             float* dst = out[k] + (size_t)r * 9;
             for (int q = 0; q < 8; ++q) dst[q] = h->h_out[(size_t)r * bm::OUT_COLS + q];
@@ -653,17 +659,23 @@ void docs_build(BoxMOTHipDeepOcSort* h) {
 // Stage the inputs of the first n streams (ReID on every detection above det_thresh when embeddings are not supplied,
 // deepocsort.py:337-345), step, read back.
 void docs_host_update(BoxMOTHipDeepOcSort* h, int n, const StreamIn* in, int det_cols, int emb_cols, int image_rows,
-                      int image_cols, int image_channels, float* const* out, int out_capacity_rows, int* out_rows) {
+                      int image_cols, int image_channels, float* const* out, int out_capacity_rows, int* out_rows, int s0 = 0,
+                      int frame_count = -1, int* id_count_inout = nullptr) {
     const bool want_emb = !h->cfg.embedding_off;
     const bool any_warp = io_stage(h, n, in, det_cols, emb_cols, want_emb, image_rows, image_cols, image_channels, out_capacity_rows,
-                                   (double)(float)h->cfg.det_thresh, 0);
+                                   (double)(float)h->cfg.det_thresh, 0, s0);
+    // per-class fan-out (basetracker.py:223-263): the frame counter is rewound for every class and the id counter
+    // (KalmanBoxTracker.count, deepocsort.py:57,117-118) is shared by all of them
+    if (frame_count >= 0) BM_HIP(hipMemcpyAsync(h->args.st.frame_count + s0, &frame_count, 4, hipMemcpyHostToDevice, h->stream));
+    if (id_count_inout) BM_HIP(hipMemcpyAsync(h->args.st.id_count + s0, id_count_inout, 4, hipMemcpyHostToDevice, h->stream));
     bm::DocsStepArgs a = h->args;
     a.dets = h->d_dets; a.n_dets = h->d_ndets; a.embs = want_emb ? h->d_embs : nullptr;
     a.warp = any_warp ? h->d_warp : nullptr; a.warp_flag = any_warp ? h->d_warp_flag : nullptr;
-    a.out = h->d_out; a.out_n = h->d_out_n; a.stream_base = 0;
+    a.out = h->d_out; a.out_n = h->d_out_n; a.stream_base = s0;
     hipLaunchKernelGGL((deepocsort_step_kernel<STEP_THREADS>), dim3(n), dim3(STEP_THREADS),
                        (size_t)bm::docs_lap_lds_bytes(h->cap, h->nd), h->stream, a);
-    io_read_back(h, n, h->args.st.status, "DeepOCSORT", out, out_capacity_rows, out_rows);
+    io_read_back(h, n, h->args.st.status, "DeepOCSORT", out, out_capacity_rows, out_rows, s0);
+    if (id_count_inout) BM_HIP(hipMemcpy(id_count_inout, h->args.st.id_count + s0, 4, hipMemcpyDeviceToHost));
 }
 
 // ---------------------------------------------------------------------------
@@ -1143,6 +1155,24 @@ int boxmot_hip_deepocsort_update(BoxMOTHipDeepOcSort* handle, const float* dets,
         StreamIn in{dets, det_rows, (embs && emb_cols > 0) ? embs : nullptr, image};
         float* outs[1] = {out_tracks};
         docs_host_update(handle, 1, &in, det_cols, emb_cols, image_rows, image_cols, image_channels, outs, out_capacity_rows, out_rows);
+        *out_is_obb = 0;
+    });
+}
+
+int boxmot_hip_deepocsort_update_stream(BoxMOTHipDeepOcSort* handle, int stream, int frame_count, int* id_count_inout,
+                                        const float* dets, int det_rows, int det_cols, const float* embs, int emb_rows,
+                                        int emb_cols, const uint8_t* image, int image_rows, int image_cols, int image_channels,
+                                        float* out_tracks, int out_capacity_rows, int out_cols, int* out_rows, int* out_is_obb) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip DeepOCSORT handle is not initialized.");
+        if (!out_rows || !out_is_obb) throw std::runtime_error("Output pointers are null.");
+        if (out_cols != 9) throw std::runtime_error("boxmot_hip live tracking expects an output buffer with 9 columns.");
+        if (embs != nullptr && emb_rows != det_rows) throw std::runtime_error("Detection and embedding row counts must match.");
+        if (image_rows <= 0 || image_cols <= 0) throw std::runtime_error("Image dimensions must be positive.");
+        StreamIn in{dets, det_rows, (embs && emb_cols > 0) ? embs : nullptr, image};
+        float* outs[1] = {out_tracks};
+        docs_host_update(handle, 1, &in, det_cols, emb_cols, image_rows, image_cols, image_channels, outs, out_capacity_rows, out_rows,
+                         stream, frame_count, id_count_inout);
         *out_is_obb = 0;
     });
 }

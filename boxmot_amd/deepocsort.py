@@ -9,8 +9,9 @@ recovery round, bookkeeping -- runs in one HIP kernel through the C ABI (include
 
 Camera motion: applying a warp to the tracks runs on the device (``apply_affine_correction``); estimating it from
 images (the reference's sparse-optical-flow object) is not implemented, so ``cmc_off=False`` needs a ``cmc=`` object
-exposing the reference's ``apply(img, boxes) -> 2x3 warp``.  Rejected loudly: ``per_class=True``, OBB detections,
-``max_age > 45``.
+exposing the reference's ``apply(img, boxes) -> 2x3 warp``.  ``per_class=True`` keeps one track list per class on the
+device (one stream per class) with the shared id counter and rewound frame counter of the reference's fan-out.
+Rejected loudly: OBB detections, ``max_age > 45``.
 """
 from __future__ import annotations
 
@@ -53,8 +54,6 @@ class DeepOcSort(BaseTracker):
                 "cmc_off=True, or pass cmc=<object with apply(img, boxes) -> 2x3 warp> (the reference default is "
                 "cmc_off=False with the 'sof' estimator)."
             )
-        if self.per_class:
-            raise NotImplementedError("boxmot_amd.DeepOcSort: per_class=True is not implemented")
         self.delta_t, self.inertia = delta_t, inertia
         self.w_association_emb, self.alpha_fixed_emb, self.aw_param = w_association_emb, alpha_fixed_emb, aw_param
         self.Q_xy_scaling, self.Q_s_scaling = Q_xy_scaling, Q_s_scaling
@@ -71,7 +70,9 @@ class DeepOcSort(BaseTracker):
         cfg.alpha_fixed_emb, cfg.aw_param = alpha_fixed_emb, aw_param
         cfg.embedding_off, cfg.cmc_off, cfg.aw_off = int(bool(embedding_off)), int(bool(cmc_off)), int(bool(aw_off))
         cfg.Q_xy_scaling, cfg.Q_s_scaling = Q_xy_scaling, Q_s_scaling
-        cfg.n_streams, cfg.max_tracks, cfg.max_dets, cfg.emb_dim = 1, max_tracks, max_dets, self._emb_dim
+        cfg.n_streams = self.nr_classes if self.per_class else 1
+        cfg.max_tracks, cfg.max_dets, cfg.emb_dim = max_tracks, max_dets, self._emb_dim
+        self._ids_issued = ctypes.c_int(0)           # KalmanBoxTracker.count - 1, shared by the per-class lists
         self._cfg = cfg
         self._max_tracks = max_tracks
         self._handle = self._lib.boxmot_hip_deepocsort_create(ctypes.byref(cfg))
@@ -96,14 +97,17 @@ class DeepOcSort(BaseTracker):
             if feats.shape[1] != self._emb_dim:
                 raise ValueError(f"embedding width {feats.shape[1]} != emb_dim {self._emb_dim}")
         img_arr = np.ascontiguousarray(img)
+        stream = int(class_list) if self.per_class else 0
         if self.cmc is not None:
             kept = det_arr[det_arr[:, 4] > np.float32(self.det_thresh), :4].astype(np.float64) if n else np.empty((0, 4))
             warp = np.ascontiguousarray(np.asarray(self.cmc.apply(img, kept), dtype=np.float64)[:2, :3])     # deepocsort.py:348-349
-            _lib.check(self._lib.boxmot_hip_deepocsort_set_warp(self._handle, 0, warp.ctypes.data))
+            _lib.check(self._lib.boxmot_hip_deepocsort_set_warp(self._handle, stream, warp.ctypes.data))
         out = np.empty((max(n, 1), 9), dtype=np.float32)
         out_rows, out_is_obb = ctypes.c_int(0), ctypes.c_int(0)
-        ok = self._lib.boxmot_hip_deepocsort_update(
-            self._handle, det_arr.ctypes.data if n else None, n, 6,
+        ok = self._lib.boxmot_hip_deepocsort_update_stream(
+            self._handle, stream, int(self.frame_count) if self.per_class else -1,
+            ctypes.byref(self._ids_issued) if self.per_class else None,
+            det_arr.ctypes.data if n else None, n, 6,
             feats.ctypes.data if feats is not None else None, n if feats is not None else 0,
             self._emb_dim if feats is not None else 0,
             img_arr.ctypes.data, int(img_arr.shape[0]), int(img_arr.shape[1]),
@@ -117,6 +121,7 @@ class DeepOcSort(BaseTracker):
 
     def reset(self) -> None:
         _lib.check(self._lib.boxmot_hip_deepocsort_reset(self._handle))
+        self._ids_issued = ctypes.c_int(0)
         self.frame_count = 0
         self._first_frame_processed = False
         self._first_dets_processed = False

@@ -226,6 +226,16 @@ int boxmot_hip_deepocsort_update(
     const uint8_t* image, int image_rows, int image_cols, int image_channels,
     float* out_tracks, int out_capacity_rows, int out_cols,
     int* out_rows, int* out_is_obb);
+/* Same for stream `stream`.  frame_count >= 0 sets the tracker's frame counter before the step and *id_count_inout
+ * (ids issued so far) is loaded before and stored after it: the per-class fan-out of the reference rewinds the frame
+ * counter for every class and shares one id counter (basetracker.py:223-263; deepocsort.py:57,117-118). */
+int boxmot_hip_deepocsort_update_stream(
+    BoxMOTHipDeepOcSort* handle, int stream, int frame_count, int* id_count_inout,
+    const float* dets, int det_rows, int det_cols,
+    const float* embs, int emb_rows, int emb_cols,
+    const uint8_t* image, int image_rows, int image_cols, int image_channels,
+    float* out_tracks, int out_capacity_rows, int out_cols,
+    int* out_rows, int* out_is_obb);
 /* one frame for each of the first n_streams streams in one launch set (arguments as boxmot_hip_botsort_update_batch) */
 int boxmot_hip_deepocsort_update_batch(
     BoxMOTHipDeepOcSort* handle, int n_streams,

@@ -481,3 +481,26 @@ class DeepOcSortOracle:
             "emb": [np.asarray(k.emb, dtype=np.float64) for k in t],
             "count": self.count,
         }
+
+
+class PerClassDeepOcSortOracle:
+    """The reference's per-class fan-out around DeepOcSort (basetracker.py:223-263): one track list per class, the
+    frame counter rewound for every class, one shared id counter (KalmanBoxTracker.count)."""
+
+    def __init__(self, nr_classes, **kw):
+        self.per_class = [DeepOcSortOracle(**kw) for _ in range(nr_classes)]
+        self.frame_count = 0
+        self.count = 1
+
+    def update(self, dets, img=None, embs=None):
+        dets = np.asarray(dets)
+        rows = []
+        for c, orc in enumerate(self.per_class):
+            idx = np.where(dets[:, 5] == c)[0] if dets.size else np.zeros(0, int)
+            orc.frame_count, orc.count = self.frame_count, self.count
+            out = orc.update(dets[idx] if dets.size else dets, img, None if embs is None else embs[idx])
+            self.count = orc.count
+            if out.size > 0:
+                rows.append(out)
+        self.frame_count += 1
+        return np.vstack(rows) if rows else np.empty((0, 8), dtype=np.float32)

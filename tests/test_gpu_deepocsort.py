@@ -98,6 +98,24 @@ def test_hip_deepocsort_camera_motion_correction(name, seed, kw):
     trk.close()
 
 
+def test_hip_deepocsort_per_class_matches_the_reference_fan_out():
+    """per_class=True: one track list per class, rewound frame counter, shared id counter (basetracker.py:223-263)."""
+    from boxmot_amd.scenario import stress_frames
+    from oracle.deepocsort import PerClassDeepOcSortOracle
+    img = np.zeros((480, 640, 3), dtype=np.uint8)
+    trk = _tracker(emb_dim=32, max_tracks=128, max_dets=64, per_class=True, nr_classes=3, min_hits=1)
+    orc = PerClassDeepOcSortOracle(3, min_hits=1)
+    for t, (dets, embs) in enumerate(stress_frames(80, seed=4)):
+        got = np.asarray(trk.update(dets, img, embs)).reshape(-1, 8)
+        assert_rows_match(got, np.asarray(orc.update(dets, img, embs.copy()), dtype=np.float32).reshape(-1, 8), t)
+    # reference test_per_class_isolation (tests/unit/test_trackers.py:537-557): overlapping boxes of two classes -> two ids
+    trk2 = _tracker(emb_dim=8, max_tracks=64, max_dets=16, per_class=True, nr_classes=3)
+    det = np.array([[100, 100, 150, 150, 0.9, 1], [102, 102, 152, 152, 0.9, 2]])
+    out = trk2.update(det, np.zeros((640, 640, 3), np.uint8), np.random.rand(2, 8))
+    assert len(set(out[:, 4].tolist())) == 2
+    trk.close(); trk2.close()
+
+
 def test_deepocsort_surface_and_edge_inputs():
     from boxmot_amd import create_tracker
     from boxmot_amd.deepocsort import DeepOcSort

@@ -47,6 +47,21 @@ def test_deepocsort_oracle_bit_exact_incl_kalman_state():
             assert np.array_equal(k.kf.x[:, 0], x) and np.array_equal(k.kf.P, P)
 
 
+def test_deepocsort_per_class_oracle_matches_reference():
+    from boxmot_amd.scenario import stress_frames
+    from oracle.deepocsort import PerClassDeepOcSortOracle
+
+    logging.disable(logging.CRITICAL)
+    DeepOcSort = ref_harness.load_deepocsort()
+    img = np.zeros((480, 640, 3), np.uint8)
+    ref = DeepOcSort(reid_model=None, cmc_off=True, per_class=True, nr_classes=3, min_hits=1)
+    orc = PerClassDeepOcSortOracle(3, min_hits=1)
+    for t, (d, e) in enumerate(stress_frames(80, seed=4)):
+        r = np.asarray(ref.update(d.copy(), img, e.copy())).reshape(-1, 8)
+        o = np.asarray(orc.update(d.copy(), img, e.copy()), dtype=np.float32).reshape(-1, 8)
+        assert r.shape == o.shape and np.array_equal(r, o), t
+
+
 def test_strongsort_oracle_bit_exact_incl_kalman_state():
     from boxmot_amd.scenario import stress_frames
     from oracle.strongsort import StrongSortOracle
