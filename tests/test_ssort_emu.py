@@ -77,6 +77,17 @@ def test_device_assignment_solver_equals_scipy_incl_ties():
         out = np.zeros(nr, np.int32)
         lib.emu_lsa(c.ctypes.data, nr, nc, out.ctypes.data)
         assert np.array_equal(linear_sum_assignment(c)[1], out), (it, c)
+    # stage-A shape of a crowded frame (parity soak seed 159): 21 confirmed tracks x 9 detections, every gated entry
+    # clamped to the same 0.20001 -- SciPy solves the transpose, so the device does too
+    c = np.full((21, 9), 0.20001)
+    for r, q, val in [(1, 3, 0.06822), (7, 1, 0.03715), (7, 2, 0.06602), (11, 6, 0.0644), (13, 7, 0.09929), (14, 4, 0.06037),
+                      (16, 8, 0.0711), (20, 0, 0.04554)]:
+        c[r, q] = val
+    ct = np.ascontiguousarray(c.T)
+    out = np.zeros(9, np.int32)
+    lib.emu_lsa(ct.ctypes.data, 9, 21, out.ctypes.data)
+    rows, cols = linear_sum_assignment(c)
+    assert sorted(zip(out.tolist(), range(9))) == list(zip(rows.tolist(), cols.tolist()))
 
 
 def test_emulated_kernels_clean_under_asan():
