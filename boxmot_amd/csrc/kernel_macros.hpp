@@ -31,6 +31,15 @@
 #define BM_ROW_SHR1_F32(v) BM_DPP_F32(v, 0x111)
 #define BM_ROW_ROR1_F32(v) BM_DPP_F32(v, 0x121)
 #endif
+#ifndef BM_RELU_F32
+// max(v, 0) as one integer max on the bit pattern (negative floats are negative ints); a float max costs a second,
+// canonicalising v_max under IEEE mode
+#define BM_RELU_F32(v) __builtin_bit_cast(float, __builtin_elementwise_max(__builtin_bit_cast(int, (float)(v)), 0))
+#endif
+#ifndef BM_QUAD_SWAP1_F32
+// value of the horizontally adjacent lane (lane ^ 1) as a DPP quad permute [1,0,3,2]
+#define BM_QUAD_SWAP1_F32(v) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (float)(v)), 0xB1, 0xf, 0xf, true))
+#endif
 #ifndef BM_CLOCK
 #define BM_CLOCK() wall_clock64()
 #endif

@@ -310,8 +310,8 @@ private:
             pack_osblock(w, L_.block[b], bp_[b], buf);
             w_blk_[b] = upload(buf);
         }
-        pack_pointwise(w + L_.trans_w[0], w + L_.trans_b[0], 64, 64, buf); w_tr_[0] = upload(buf);
-        pack_pointwise(w + L_.trans_w[1], w + L_.trans_b[1], 96, 96, buf); w_tr_[1] = upload(buf);
+        pack_pointwise(w + L_.trans_w[0], w + L_.trans_b[0], 64, 64, buf, 0.25f); w_tr_[0] = upload(buf);
+        pack_pointwise(w + L_.trans_w[1], w + L_.trans_b[1], 96, 96, buf, 0.25f); w_tr_[1] = upload(buf);
         pack_pointwise(w + L_.conv5_w, w + L_.conv5_b, 128, 128, buf); w_c5_ = upload(buf);
         pack_fc(w + L_.fc_w, w + L_.fc_b, 512, 128, buf); w_fc_ = upload(buf);
         const size_t n = (size_t)fused_cap_;

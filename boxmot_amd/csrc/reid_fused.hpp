@@ -77,9 +77,7 @@ __device__ unsigned long long g_osblock_prof[8];
 #endif
 
 __device__ inline h4 to_h4(f4 v) { return h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]}; }
-__device__ inline f4 relu4(f4 v) {
-    return f4{v[0] > 0.f ? v[0] : 0.f, v[1] > 0.f ? v[1] : 0.f, v[2] > 0.f ? v[2] : 0.f, v[3] > 0.f ? v[3] : 0.f};
-}
+__device__ inline f4 relu4(f4 v) { return f4{BM_RELU_F32(v[0]), BM_RELU_F32(v[1]), BM_RELU_F32(v[2]), BM_RELU_F32(v[3])}; }
 __device__ inline h4 relu_h4(h4 v) { return __builtin_elementwise_max(v, (h4)(_Float16)0.f); }
 __device__ inline h4 fma_h4(h4 a, h4 b, h4 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ inline h8 cat8(h4 a, h4 b) { return h8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
@@ -128,7 +126,7 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
             for (int i = 0; i < NT; ++i) {
                 const int p = (wave * NT + i) * 16 + l16;
                 const h4 b = *reinterpret_cast<const h4*>(xin + (xo + (unsigned)(p * CIN + g * 4)));
-                x1[i][0] = to_h4(relu4(BM_MFMA_F16_K16(a, b, bias[0])));
+                x1[i][0] = relu_h4(to_h4(BM_MFMA_F16_K16(a, b, bias[0])));
                 if ((i & 3) == 3) BM_SCHED_FENCE();
             }
         } else {
@@ -151,7 +149,7 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
                     for (int ct = 0; ct < KT; ++ct) acc[ct] = BM_MFMA_F16_K32(a[ks][ct], b, acc[ct]);
                 }
 #pragma unroll
-                for (int ct = 0; ct < KT; ++ct) x1[i][ct] = to_h4(relu4(acc[ct]));
+                for (int ct = 0; ct < KT; ++ct) x1[i][ct] = relu_h4(to_h4(acc[ct]));
                 if (i & 1) BM_SCHED_FENCE();
             }
         }
@@ -286,7 +284,25 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
         // fc1 is linear in the pooled vector, so every wave reduces its own share of sum_c W1[h][c] * sum_p x[c][p]
         // to HID scalars (one 64-lane butterfly each); the waves' partials meet in LDS.
         float* part = gap_part + br * (G::NWAVES * G::HID);
-        {
+        if constexpr (G::HID == 1 && KT == 1) {
+            // one hidden unit, one channel tile: the pooled fc1 product is row 0 of W1 . cur summed over the wave's
+            // pixels -- accumulate it on the matrix pipe (W1 as fp16 hi + lo parts: fp32-grade weights), then add up
+            // the 16 pixel columns of row 0 (lanes 0..15; rows 4, 8, 12 of the other lane groups are zero)
+            const f4 w1 = *reinterpret_cast<const f4*>(wts + bp.fc1_w + 4 * (4 * g));
+            const h4 w1h = to_h4(w1);
+            const f4 w1r = f4{w1[0] - (float)w1h[0], w1[1] - (float)w1h[1], w1[2] - (float)w1h[2], w1[3] - (float)w1h[3]};
+            const h4 zero4 = (h4)(_Float16)0.f;
+            const h4 a_hi = l16 == 0 ? w1h : zero4, a_lo = l16 == 0 ? to_h4(w1r) : zero4;
+            f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                acc = BM_MFMA_F16_K16(a_hi, cur[i][0], acc);
+                acc = BM_MFMA_F16_K16(a_lo, cur[i][0], acc);
+            }
+            float v = acc[0];
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+            if (lane == 0) part[wave] = v;
+        } else {
             float ph[G::HID];
 #pragma unroll
             for (int h = 0; h < G::HID; ++h) ph[h] = 0.f;
@@ -342,6 +358,22 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
     }
 
     // ---- conv3 (1x1 MID -> COUT, linear) + downsample(x) or identity, ReLU (osnet.py:254-260) ----
+    // stage 0 keeps the epilogue's operands in the registers the branch loop has released (16 tiles re-use them);
+    // the wider stages have too many fragments for that and re-read them per tile from L1
+    h4 eye;                 // A fragment of the 16x16 identity: row l16, k-slots 4g..4g+3
+#pragma unroll
+    for (int j = 0; j < 4; ++j) eye[j] = (_Float16)(l16 == 4 * g + j ? 1.f : 0.f);
+    constexpr bool W3REG = STAGE == 0;
+    h4 w3r[NCT], wdr[NCT];
+    f4 b3r[NCT];
+    if constexpr (W3REG) {
+#pragma unroll
+        for (int co = 0; co < NCT; ++co) {
+            w3r[co] = *reinterpret_cast<const h4*>(wts + bp.conv3_a + (co * 64 + lane) * 8);
+            b3r[co] = *reinterpret_cast<const f4*>(wts + bp.conv3_b + (16 * co + 4 * g) * 4);
+            if constexpr (DOWN && CIN == 16) wdr[co] = *reinterpret_cast<const h4*>(wts + bp.down_a + (co * 64 + lane) * 8);
+        }
+    }
     auto conv3_tile = [&](int i, h4 (&y)[NCT]) {
         unsigned p = (wave * NT + i) * 16 + l16;
         if constexpr (STASH) BM_OPAQUE_U32(p);           // addresses are formed at the use, not precomputed and spilled
@@ -356,14 +388,20 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
         }
 #pragma unroll
         for (int co = 0; co < NCT; ++co) {
-            f4 acc = *reinterpret_cast<const f4*>(wts + bp.conv3_b + (16 * co + 4 * g) * 4);
-            if constexpr (KT == 1) {
+            f4 acc;
+            if constexpr (W3REG) acc = b3r[co];
+            else acc = *reinterpret_cast<const f4*>(wts + bp.conv3_b + (16 * co + 4 * g) * 4);
+            if constexpr (W3REG) {
+                acc = BM_MFMA_F16_K16(w3r[co], x2[i][0], acc);
+            } else if constexpr (KT == 1) {
                 acc = BM_MFMA_F16_K16(*reinterpret_cast<const h4*>(wts + bp.conv3_a + (co * 64 + lane) * 8), x2[i][0], acc);
             } else {
                 acc = BM_MFMA_F16_K32(*reinterpret_cast<const h8*>(wts + bp.conv3_a + (co * 64 + lane) * 16), cat8(x2[i][0], x2[i][1]), acc);
             }
             if constexpr (DOWN) {
-                if constexpr (CIN == 16) {
+                if constexpr (CIN == 16 && W3REG) {
+                    acc = BM_MFMA_F16_K16(wdr[co], bx4, acc);
+                } else if constexpr (CIN == 16) {
                     acc = BM_MFMA_F16_K16(*reinterpret_cast<const h4*>(wts + bp.down_a + (co * 64 + lane) * 8), bx4, acc);
                 } else {
 #pragma unroll
@@ -371,11 +409,18 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
                         acc = BM_MFMA_F16_K32(*reinterpret_cast<const h8*>(wts + bp.down_a + ((co * KIN + ks) * 64 + lane) * 16), bx[ks], acc);
                 }
             } else {
+                // identity shortcut: the 4 input channels this lane holds are a K=16 B fragment, so adding them is one
+                // MFMA with the 16x16 identity (exact: products by 1, fp32 accumulate) instead of 4 converts + 4 adds;
+                // only where conv3 is itself a K=16 MFMA: a dependent chain that mixes the 16x16x16 and 16x16x32 shapes
+                // on one accumulator returns wrong sums on gfx950 / ROCm 7.2 (tools/mfma_chain_test.hip)
                 const h4 idn = *reinterpret_cast<const h4*>(xin + (unsigned)(p * CIN + g * (CIN / 4) + 4 * co));
+                if constexpr (KT == 1) acc = BM_MFMA_F16_K16(eye, idn, acc);       // same shape as conv3's own MFMA
+                else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[r] += (float)idn[r];
+                    for (int r = 0; r < 4; ++r) acc[r] += (float)idn[r];
+                }
             }
-            y[co] = to_h4(relu4(acc));
+            y[co] = relu_h4(to_h4(acc));
         }
     };
     if constexpr (!TRANS) {
@@ -418,9 +463,8 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
                 f4 sp;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float v = a0[r] + a1[r];
-                    v += __shfl_xor(v, 1, 64);
-                    sp[r] = v * 0.25f;
+                    const float v = a0[r] + a1[r];
+                    sp[r] = v + BM_QUAD_SWAP1_F32(v);       // the average's 1/4 is folded into `wtr` (reid_pack.hpp)
                 }
                 if ((l16 & 1) == 0) *reinterpret_cast<h4*>(yout + (unsigned)(po * COUT + g * (COUT / 4) + 4 * ct)) = to_h4(sp);
             }

@@ -161,14 +161,19 @@ inline void pack_osblock(const float* w, const BlockW& B, const BlkPack& P, std:
 }
 
 // 1x1 conv C -> M over an L-layout tensor: fragments [ct][ks] (x32) + fp32 bias[M]
-inline void pack_pointwise(const float* W, const float* bias, int M, int C, std::vector<uint8_t>& out) {
+// `scale` (a power of two) multiplies weights and bias: the stage transitions fold their 2x2 average's 1/4 into the
+// conv (ReLU is positively homogeneous), which is exact in fp16/fp32
+inline void pack_pointwise(const float* W, const float* bias, int M, int C, std::vector<uint8_t>& out, float scale = 1.0f) {
     const int nct = M / 16, ks_n = C / 32;
     out.assign((size_t)nct * ks_n * 1024 + (size_t)M * 4, 0);
+    std::vector<float> ws(W, W + (size_t)M * C), bs(bias, bias + M);
+    for (auto& v : ws) v *= scale;
+    for (auto& v : bs) v *= scale;
     for (int ct = 0; ct < nct; ++ct)
         for (int ks = 0; ks < ks_n; ++ks)
-            pack_a_frag(reinterpret_cast<uint16_t*>(out.data() + ((long)ct * ks_n + ks) * 1024), W, M, C, C, ct, 8,
+            pack_a_frag(reinterpret_cast<uint16_t*>(out.data() + ((long)ct * ks_n + ks) * 1024), ws.data(), M, C, C, ct, 8,
                         [&](int g, int j) { return chan_mem_slot(C, ks, g, j); });
-    std::memcpy(out.data() + (size_t)nct * ks_n * 1024, bias, (size_t)M * 4);
+    std::memcpy(out.data() + (size_t)nct * ks_n * 1024, bs.data(), (size_t)M * 4);
 }
 
 // stem 7x7/2: seven fragments (one per ky), k-slot j of group g = input pixel 2*cx + 2g + (j>>2)

@@ -43,6 +43,9 @@ void launch(int gx, int gy, int nthr, const std::function<void()>& fn) {
     pthread_attr_setstacksize(&attr, 1 << 20);
     for (int by = 0; by < gy; ++by)
         for (int bx = 0; bx < gx; ++bx) {
+            // LDS is NOT zero on the device when a workgroup starts: poison it (fp16/fp32 NaN patterns) so that a
+            // kernel relying on stale or zero LDS fails here too
+            std::memset(lds.data(), 0xFF, lds.size());
             std::vector<pthread_t> th(nthr);
             std::vector<TA> ta(nthr);
             for (int t = 0; t < nthr; ++t) { ta[t] = TA{&fn, t, bx, by}; pthread_create(&th[t], &attr, tmain, &ta[t]); }
@@ -153,7 +156,7 @@ int emu_reid_forward(const float* blob, long n_floats, const float* crops, int n
         const BlkPack bp = make_blk_pack(stage, cin, down);
         std::vector<uint8_t> wb, wt;
         pack_osblock(w, L.block[bi], bp, wb);
-        if (trans >= 0) pack_pointwise(w + L.trans_w[trans], w + L.trans_b[trans], cout, cout, wt);
+        if (trans >= 0) pack_pointwise(w + L.trans_w[trans], w + L.trans_b[trans], cout, cout, wt, 0.25f);
         const _Float16* in = cur; _Float16* out = nxt; const unsigned char* wp = wb.data();
         const unsigned char* wtp = trans >= 0 ? wt.data() : nullptr;
         launch(n, 1, nthr, [=]() { kernel(in, out, wp, bp, nullptr, x1p, wtp); });

@@ -102,6 +102,15 @@ inline float emu_row_shift(float v, int d, bool rotate) {
     const float r = emu_exchange(v, (lane & 48) | (src16 & 15));
     return (rotate || (src16 >= 0 && src16 < 16)) ? r : 0.f;
 }
+// DPP row modes used by the kernels: 0x10n row_shl:n (lane+n), 0x11n row_shr:n (lane-n), 0x12n row_ror:n
+inline unsigned emu_dpp_u32(unsigned old, unsigned v, int ctrl, bool zero_fill) {
+    const int lane = threadIdx.x % EMU_WAVE, l16 = lane & 15, n = ctrl & 15, mode = ctrl & 0x1f0;
+    const int src16 = mode == 0x100 ? l16 + n : (mode == 0x110 ? l16 - n : ((l16 - n) & 15));
+    const unsigned r = emu_exchange(v, (lane & 48) | (src16 & 15));
+    return (src16 >= 0 && src16 < 16) ? r : (zero_fill ? 0u : old);
+}
+#define BM_DPP_U32(old, v, ctrl, zero_fill) emu_dpp_u32(old, v, ctrl, zero_fill)
+#define BM_QUAD_SWAP1_F32(v) __shfl_xor((float)(v), 1, 64)
 #define BM_ROW_SHL1_F32(v) emu_row_shift(v, 1, false)
 #define BM_ROW_SHR1_F32(v) emu_row_shift(v, -1, false)
 #define BM_ROW_ROR1_F32(v) emu_row_shift(v, -1, true)

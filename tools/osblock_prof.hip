@@ -6,6 +6,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "kernel_macros.hpp"
@@ -52,6 +53,18 @@ static void run(const char* name, int n, int iters) {
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         if (ms < best) best = ms;
+    }
+    {   // output statistics: the same inputs through a differently built kernel must give (nearly) the same numbers
+        const size_t oe = (size_t)n * (TRANS ? G::P / 4 : G::P) * G::COUT;
+        std::vector<unsigned short> y(oe);
+        CK(hipMemcpy(y.data(), d_out, oe * 2, hipMemcpyDeviceToHost));
+        double sum = 0, sabs = 0; size_t bad = 0;
+        for (size_t i = 0; i < oe; ++i) {
+            _Float16 hv; memcpy(&hv, &y[i], 2); const float f = (float)hv;
+            if (!(f == f) || f > 60000.f || f < -60000.f) { ++bad; continue; }
+            sum += f * (double)((i % 97) + 1); sabs += f < 0 ? -f : f;
+        }
+        printf("%s: output weighted sum %.6e, mean |y| %.6e, non-finite %zu\n", name, sum, sabs / oe, bad);
     }
     unsigned long long acc[8] = {};
 #ifdef BM_OSBLOCK_PROF
