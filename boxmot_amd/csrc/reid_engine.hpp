@@ -318,12 +318,14 @@ private:
         const size_t crop_halves = n * STEM_ROWS * STEM_COLS * 4;
         crops_h_ = dev_alloc<_Float16>(crop_halves, owned_);
         BM_HIP(hipMemset(crops_h_, 0, crop_halves * 2));          // the 3-pixel border and X channel stay zero
-        act_a_ = dev_alloc<_Float16>(n * 2048 * 64, owned_);
-        act_b_ = dev_alloc<_Float16>(n * 2048 * 64, owned_);
-        x1s_ = dev_alloc<_Float16>(n * 2048 * 16, owned_);      // conv1 output of the second stage-0 block (k_osblock STASH)
+        // largest activation that reaches memory: stage-1 block output, 512 px x 96 channels (the 2048 x 64 tensor of stage 0 never does)
+        act_a_ = dev_alloc<_Float16>(n * 2048 * 32, owned_);
+        act_b_ = dev_alloc<_Float16>(n * 2048 * 32, owned_);
+        x1s_ = dev_alloc<_Float16>(n * 2048 * 16, owned_);      // conv1 output of the second stage-0 block (k_osblock EMIT -> RECON)
+        x2s_ = dev_alloc<_Float16>(n * 2048 * 16, owned_);      // branch sum of the first stage-0 block
         allow_lds(k_stem_resize_fused, STEM2_LDS);
-        allow_lds(k_osblock<0, 16, true, false>, Geo<0>::LDS_BYTES);
-        allow_lds(k_osblock<0, 64, false, true>, Geo<0>::LDS_BYTES);
+        allow_lds(k_osblock<0, 16, true, false, true, false>, Geo<0>::LDS_BYTES);
+        allow_lds(k_osblock<0, 64, false, true, false, true>, Geo<0>::LDS_BYTES);
         allow_lds(k_osblock<1, 64, true, false>, Geo<1>::LDS_BYTES);
         allow_lds(k_osblock<1, 96, false, true>, Geo<1>::LDS_BYTES);
         allow_lds(k_osblock<2, 96, true, false>, Geo<2>::LDS_BYTES);
@@ -338,16 +340,20 @@ private:
         else
             hipLaunchKernelGGL(k_stem_fused, dim3(n), dim3(512), 0, st, crops_h_, act_a_, w_stem_, d_count_);
         // activations ping-pong between act_a_ and act_b_; the transitions are fused into the second block of a stage
-        auto blk = [&](auto kernel, int nw, int lds, const _Float16* in, _Float16* out, int b, const unsigned char* wtr) {
-            hipLaunchKernelGGL(kernel, dim3(n), dim3(64 * nw), lds, st, in, out, w_blk_[b], bp_[b], d_count_, x1s_, wtr);
+        auto blk = [&](auto kernel, int nw, int lds, const _Float16* in, _Float16* out, int b, const unsigned char* wtr, BlkLink link) {
+            hipLaunchKernelGGL(kernel, dim3(n), dim3(64 * nw), lds, st, in, out, w_blk_[b], bp_[b], d_count_, x1s_, wtr, link);
         };
-        blk(k_osblock<0, 16, true, false>, Geo<0>::NWAVES, Geo<0>::LDS_BYTES, act_a_, act_b_, 0, nullptr);
-        blk(k_osblock<0, 64, false, true>, Geo<0>::NWAVES, Geo<0>::LDS_BYTES, act_b_, act_a_, 1, w_tr_[0]);
-        blk(k_osblock<1, 64, true, false>, Geo<1>::NWAVES, Geo<1>::LDS_BYTES, act_a_, act_b_, 2, nullptr);
-        blk(k_osblock<1, 96, false, true>, Geo<1>::NWAVES, Geo<1>::LDS_BYTES, act_b_, act_a_, 3, w_tr_[1]);
-        blk(k_osblock<2, 96, true, false>, Geo<2>::NWAVES, Geo<2>::LDS_BYTES, act_a_, act_b_, 4, nullptr);
-        blk(k_osblock<2, 128, false, false>, Geo<2>::NWAVES, Geo<2>::LDS_BYTES, act_b_, act_a_, 5, nullptr);
-        hipLaunchKernelGGL((k_head_fused<128, 512>), dim3(n), dim3(128), 0, st, act_a_, w_c5_, w_fc_, d_out, d_out_rows, d_count_);
+        // stage 0: block 1 hands block 2 its conv1 result and its branch sum (2 x 16 channels) instead of its 64-channel
+        // output; block 2 rebuilds that output per tile for the shortcut (k_osblock EMIT / RECON)
+        blk(k_osblock<0, 16, true, false, true, false>, Geo<0>::NWAVES, Geo<0>::LDS_BYTES, act_a_, nullptr, 0, nullptr,
+            BlkLink{w_blk_[1], bp_[1].conv1_a, bp_[1].conv1_b, 0, x2s_});
+        blk(k_osblock<0, 64, false, true, false, true>, Geo<0>::NWAVES, Geo<0>::LDS_BYTES, act_a_, act_b_, 1, w_tr_[0],
+            BlkLink{w_blk_[0], bp_[0].conv3_a, bp_[0].conv3_b, bp_[0].down_a, x2s_});
+        blk(k_osblock<1, 64, true, false>, Geo<1>::NWAVES, Geo<1>::LDS_BYTES, act_b_, act_a_, 2, nullptr, BlkLink{});
+        blk(k_osblock<1, 96, false, true>, Geo<1>::NWAVES, Geo<1>::LDS_BYTES, act_a_, act_b_, 3, w_tr_[1], BlkLink{});
+        blk(k_osblock<2, 96, true, false>, Geo<2>::NWAVES, Geo<2>::LDS_BYTES, act_b_, act_a_, 4, nullptr, BlkLink{});
+        blk(k_osblock<2, 128, false, false>, Geo<2>::NWAVES, Geo<2>::LDS_BYTES, act_a_, act_b_, 5, nullptr, BlkLink{});
+        hipLaunchKernelGGL((k_head_fused<128, 512>), dim3(n), dim3(128), 0, st, act_b_, w_c5_, w_fc_, d_out, d_out_rows, d_count_);
     }
     void alloc_buffers() {
         const size_t n = (size_t)max_crops_;
@@ -389,7 +395,7 @@ private:
     unsigned char* w_blk_[6] = {};
     unsigned char* w_tr_[2] = {};
     unsigned char *w_c5_ = nullptr, *w_fc_ = nullptr;
-    _Float16 *crops_h_ = nullptr, *act_a_ = nullptr, *act_b_ = nullptr, *x1s_ = nullptr;
+    _Float16 *crops_h_ = nullptr, *act_a_ = nullptr, *act_b_ = nullptr, *x1s_ = nullptr, *x2s_ = nullptr;
     hipEvent_t ev_[3];
     std::vector<hipEvent_t> all_events_, free_events_;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_;

@@ -91,22 +91,40 @@ __device__ inline h8 cat8(h4 a, h4 b) { return h8{a[0], a[1], a[2], a[3], b[0], 
 // (`wtr`: fragments [ct][ks] (1 KiB each) then fp32 bias[COUT], reid_pack.hpp pack_pointwise).
 // `x1s` ([n][P][MIDP] halves) is where a recomputing stage with a wide input parks conv1's output instead of
 // re-reading CIN channels per branch.
-template <int STAGE, int CIN, bool DOWN, bool TRANS>
+//
+// EMIT / RECON split the first stage's block pair so that the 64-channel output of block 1 (256 KiB per crop, the
+// largest tensor of the network) never exists in memory:
+//   * EMIT (block 1): per tile, the block output stays in registers and feeds the NEXT block's conv1 (weights `link.w`
+//     at link.a0 / bias link.a1); what is stored is that conv1's 16-channel result (`x1s`) and this block's 16-channel
+//     gated branch sum (`link.x2s`) -- 2 x 64 KiB instead of 256 KiB.
+//   * RECON (block 2): takes conv1 from `x1s` for every branch and, where the identity shortcut needs the block input,
+//     recomputes it per tile from the PREVIOUS block's branch sum and input (`in` is the previous block's input;
+//     conv3 / bias / downsample fragments of the previous block at link.a0 / a1 / a2 of `link.w`).  Same operations
+//     in the same order on the same fp16 values: bit-identical to storing and re-reading the tensor.
+struct BlkLink {
+    const unsigned char* w = nullptr;
+    long a0 = 0, a1 = 0, a2 = 0;
+    _Float16* x2s = nullptr;
+};
+
+template <int STAGE, int CIN, bool DOWN, bool TRANS, bool EMIT = false, bool RECON = false>
 __global__ void __launch_bounds__(64 * Geo<STAGE>::NWAVES, Geo<STAGE>::WG_PER_CU_WAVES)
 k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const unsigned char* __restrict__ wts, BlkPack bp,
-          const int* __restrict__ count, _Float16* __restrict__ x1s, const unsigned char* __restrict__ wtr) {
+          const int* __restrict__ count, _Float16* __restrict__ x1s, const unsigned char* __restrict__ wtr, BlkLink link) {
+    static_assert(!EMIT || (STAGE == 0 && CIN == 16 && DOWN && !TRANS), "EMIT: first block of stage 0");
+    static_assert(!RECON || (STAGE == 0 && CIN == 64 && !DOWN && TRANS), "RECON: second block of stage 0");
     using G = Geo<STAGE>;
     if (count && (int)blockIdx.x >= *count) return;     // device-side crop count (no host round trip)
     constexpr int KT = G::KT, NT = G::NT, MIDP = G::MIDP, NCT = G::NCT, COUT = G::COUT, P = G::P;
     constexpr int KIN = CIN == 16 ? 1 : CIN / 32;
-    constexpr bool STASH = G::RECOMP && CIN != 16;      // conv1 output parked in global scratch (L2-resident re-reads)
+    constexpr bool STASH = G::RECOMP && CIN != 16 && !RECON;      // conv1 output parked in global scratch (L2-resident re-reads)
     BM_DYNAMIC_LDS_T(unsigned char, lds);
     unsigned char* tbuf = lds;
     float* gap_part = reinterpret_cast<float*>(lds + G::TBUF);      // [4 branches][NWAVES][HID]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l16 = lane & 15;
     const long crop = blockIdx.x;
-    const _Float16* xin = in + crop * P * CIN;
+    const _Float16* xin = in + crop * P * (RECON ? 16 : CIN);      // RECON: the previous block's 16-channel input
     _Float16* yout = out + crop * (TRANS ? P / 4 : P) * COUT;
     BM_PROF_DECL();
 
@@ -157,7 +175,9 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
     h4 x1[NT][KT];
     if constexpr (!G::RECOMP) conv1_into(x1);
     _Float16* x1w = nullptr;        // this lane's slots in the scratch: [(tile, ct)][lane] h4 = 512 B per wave access
-    if constexpr (STASH) x1w = x1s + crop * (P * MIDP) + (long)(wave * NT * KT * 64 + lane) * 4;
+    if constexpr (STASH || EMIT || RECON) x1w = x1s + crop * (P * MIDP) + (long)(wave * NT * KT * 64 + lane) * 4;
+    _Float16* x2w = nullptr;        // same slot layout for the branch sum handed from EMIT to RECON
+    if constexpr (EMIT || RECON) x2w = link.x2s + crop * (P * MIDP) + (long)(wave * NT * KT * 64 + lane) * 4;
 
     // ---- four branches of 1..4 LightConv3x3, each gated and accumulated (osnet.py:249-253) ----
     h4 x2[NT][KT];          // gated sum of the four branches (packed fp16 accumulate: 4 terms)
@@ -189,7 +209,12 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
 #pragma unroll 1
     for (int br = 0; br < 4; ++br) {
         h4 cur[NT][KT];
-        if constexpr (STASH) {
+        if constexpr (RECON) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int ct = 0; ct < KT; ++ct) cur[i][ct] = *reinterpret_cast<const h4*>(x1w + (i * KT + ct) * 256);
+        } else if constexpr (STASH) {
             if (br == 0) {
                 conv1_into(cur);
 #pragma unroll
@@ -376,9 +401,14 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
     }
     auto conv3_tile = [&](int i, h4 (&y)[NCT]) {
         unsigned p = (wave * NT + i) * 16 + l16;
-        if constexpr (STASH) BM_OPAQUE_U32(p);           // addresses are formed at the use, not precomputed and spilled
+        if constexpr (STASH || RECON) BM_OPAQUE_U32(p);  // addresses are formed at the use, not precomputed and spilled
         h8 bx[KIN];
         h4 bx4;
+        h4 x2p, xp;             // RECON: previous block's branch sum and input at this tile
+        if constexpr (RECON) {
+            x2p = *reinterpret_cast<const h4*>(x2w + i * 256);
+            xp = *reinterpret_cast<const h4*>(xin + (unsigned)(p * 16 + g * 4));
+        }
         if constexpr (DOWN) {
             if constexpr (CIN == 16) bx4 = *reinterpret_cast<const h4*>(xin + (unsigned)(p * CIN + g * 4));
             else {
@@ -413,7 +443,15 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
                 // MFMA with the 16x16 identity (exact: products by 1, fp32 accumulate) instead of 4 converts + 4 adds;
                 // only where conv3 is itself a K=16 MFMA: a dependent chain that mixes the 16x16x16 and 16x16x32 shapes
                 // on one accumulator returns wrong sums on gfx950 / ROCm 7.2 (tools/mfma_chain_test.hip)
-                const h4 idn = *reinterpret_cast<const h4*>(xin + (unsigned)(p * CIN + g * (CIN / 4) + 4 * co));
+                h4 idn;
+                if constexpr (RECON) {      // block input = ReLU(conv3_prev . x2_prev + down_prev . x_prev + bias), as EMIT computed it
+                    f4 ap = *reinterpret_cast<const f4*>(link.w + link.a1 + (16 * co + 4 * g) * 4);
+                    ap = BM_MFMA_F16_K16(*reinterpret_cast<const h4*>(link.w + link.a0 + (co * 64 + lane) * 8), x2p, ap);
+                    ap = BM_MFMA_F16_K16(*reinterpret_cast<const h4*>(link.w + link.a2 + (co * 64 + lane) * 8), xp, ap);
+                    idn = relu_h4(to_h4(ap));
+                } else {
+                    idn = *reinterpret_cast<const h4*>(xin + (unsigned)(p * CIN + g * (CIN / 4) + 4 * co));
+                }
                 if constexpr (KT == 1) acc = BM_MFMA_F16_K16(eye, idn, acc);       // same shape as conv3's own MFMA
                 else {
 #pragma unroll
@@ -423,7 +461,26 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
             y[co] = relu_h4(to_h4(acc));
         }
     };
-    if constexpr (!TRANS) {
+    if constexpr (EMIT) {
+        // next block's conv1 (COUT -> 16, + bias, ReLU) on the in-register block output: its accumulator layout is the
+        // K=32 B operand (k-slot j <-> channel tile 2ks + (j >> 2)), exactly as the fused transition consumes it
+        constexpr int KSN = COUT / 32;
+        h8 wn[KSN];
+#pragma unroll
+        for (int ks = 0; ks < KSN; ++ks) wn[ks] = *reinterpret_cast<const h8*>(link.w + link.a0 + (ks * 64 + lane) * 16);
+        const f4 bn = *reinterpret_cast<const f4*>(link.w + link.a1 + 4 * g * 4);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            h4 y[NCT];
+            conv3_tile(i, y);
+            f4 an = bn;
+#pragma unroll
+            for (int ks = 0; ks < KSN; ++ks) an = BM_MFMA_F16_K32(wn[ks], cat8(y[2 * ks], y[2 * ks + 1]), an);
+            *reinterpret_cast<h4*>(x1w + i * 256) = relu_h4(to_h4(an));
+            *reinterpret_cast<h4*>(x2w + i * 256) = x2[i][0];
+            BM_SCHED_FENCE();
+        }
+    } else if constexpr (!TRANS) {
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
             const int p = (wave * NT + i) * 16 + l16;

@@ -148,8 +148,9 @@ int emu_reid_forward(const float* blob, long n_floats, const float* crops, int n
     _Float16* cur = A.data();
     _Float16* nxt = B.data();
     int dump = 1;
-    std::vector<_Float16> x1s((size_t)n * 2048 * 16);
+    std::vector<_Float16> x1s((size_t)n * 2048 * 16), x2s((size_t)n * 2048 * 16);
     _Float16* x1p = x1s.data();
+    _Float16* x2p = x2s.data();
     // `trans` >= 0: the stage's transition is fused into the block (the product configuration); the block's own
     // output then never exists in memory and its dump slot is skipped.
     auto run_block = [&](int bi, auto kernel, int stage, int cin, int down, int nthr, int P, int cout, int trans) {
@@ -159,14 +160,28 @@ int emu_reid_forward(const float* blob, long n_floats, const float* crops, int n
         if (trans >= 0) pack_pointwise(w + L.trans_w[trans], w + L.trans_b[trans], cout, cout, wt, 0.25f);
         const _Float16* in = cur; _Float16* out = nxt; const unsigned char* wp = wb.data();
         const unsigned char* wtp = trans >= 0 ? wt.data() : nullptr;
-        launch(n, 1, nthr, [=]() { kernel(in, out, wp, bp, nullptr, x1p, wtp); });
+        launch(n, 1, nthr, [=]() { kernel(in, out, wp, bp, nullptr, x1p, wtp, BlkLink{}); });
         std::swap(cur, nxt);
         if (trans >= 0) { ++dump; P /= 4; }
         if (stage_out && stage_out[dump]) unpack_act(cur, stage_out[dump], (long)n * P, cout);
         ++dump;
     };
-    run_block(0, k_osblock<0, 16, true, false>, 0, 16, 1, 64 * Geo<0>::NWAVES, 2048, 64, -1);
-    run_block(1, k_osblock<0, 64, false, true>, 0, 64, 0, 64 * Geo<0>::NWAVES, 2048, 64, 0);
+    {   // stage 0 as the engine runs it: EMIT (block 1) -> RECON (block 2); block 1's 64-channel output is never stored
+        const BlkPack bp0 = make_blk_pack(0, 16, 1), bp1 = make_blk_pack(0, 64, 0);
+        std::vector<uint8_t> wb0, wb1, wt;
+        pack_osblock(w, L.block[0], bp0, wb0);
+        pack_osblock(w, L.block[1], bp1, wb1);
+        pack_pointwise(w + L.trans_w[0], w + L.trans_b[0], 64, 64, wt, 0.25f);
+        const _Float16* in = cur; _Float16* out = nxt;
+        const unsigned char *w0 = wb0.data(), *w1 = wb1.data(), *wtp = wt.data();
+        const BlkLink emit{w1, bp1.conv1_a, bp1.conv1_b, 0, x2p}, recon{w0, bp0.conv3_a, bp0.conv3_b, bp0.down_a, x2p};
+        launch(n, 1, 64 * Geo<0>::NWAVES, [=]() { k_osblock<0, 16, true, false, true, false>(in, nullptr, w0, bp0, nullptr, x1p, nullptr, emit); });
+        launch(n, 1, 64 * Geo<0>::NWAVES, [=]() { k_osblock<0, 64, false, true, false, true>(in, out, w1, bp1, nullptr, x1p, wtp, recon); });
+        std::swap(cur, nxt);
+        dump = 3;
+        if (stage_out && stage_out[dump]) unpack_act(cur, stage_out[dump], (long)n * 512, 64);
+        ++dump;
+    }
     run_block(2, k_osblock<1, 64, true, false>, 1, 64, 1, 64 * Geo<1>::NWAVES, 512, 96, -1);
     run_block(3, k_osblock<1, 96, false, true>, 1, 96, 0, 64 * Geo<1>::NWAVES, 512, 96, 1);
     run_block(4, k_osblock<2, 96, true, false>, 2, 96, 1, 64 * Geo<2>::NWAVES, 128, 128, -1);

@@ -14,7 +14,7 @@
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-template <int STAGE, int CIN, bool DOWN, bool TRANS>
+template <int STAGE, int CIN, bool DOWN, bool TRANS, bool EMIT = false, bool RECON = false>
 static void run(const char* name, int n, int iters) {
     using G = bm::Geo<STAGE>;
     bm::BlkPack bp = bm::make_blk_pack(STAGE, CIN, DOWN);
@@ -26,7 +26,7 @@ static void run(const char* name, int n, int iters) {
     fill_f32(bp.conv1_b, bp.midp); fill_f32(bp.fc1_w, bp.hid * bp.midp); fill_f32(bp.fc1_b, bp.hid);
     fill_f32(bp.fc2_w, bp.midp * bp.hid); fill_f32(bp.fc2_b, bp.midp); fill_f32(bp.conv3_b, bp.cout);
     for (int li = 0; li < 10; ++li) fill_f32(bp.light0 + li * bp.light_bytes + bp.light_b, bp.midp);
-    const size_t in_elems = (size_t)n * G::P * CIN, out_elems = (size_t)n * G::P * G::COUT;
+    const size_t in_elems = (size_t)n * G::P * (RECON ? 16 : CIN), out_elems = (size_t)n * G::P * G::COUT;
     std::vector<unsigned short> x(in_elems);
     for (auto& v : x) { s = s * 1664525u + 1013904223u; v = bm::f32_to_f16_bits(((s >> 8) & 0xffff) / 65536.0f); }
     unsigned char *d_w, *d_wt; _Float16 *d_in, *d_out, *d_x1;
@@ -39,7 +39,14 @@ static void run(const char* name, int n, int iters) {
     CK(hipMalloc(&d_wt, wt_bytes)); CK(hipMemcpy(d_wt, wt.data(), wt_bytes, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_w, w.data(), bp.total, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_in, x.data(), in_elems * 2, hipMemcpyHostToDevice));
-    auto kern = bm::k_osblock<STAGE, CIN, DOWN, TRANS>;
+    auto kern = bm::k_osblock<STAGE, CIN, DOWN, TRANS, EMIT, RECON>;
+    // EMIT / RECON: the neighbouring block's weights are the same random blob (only the access pattern matters here)
+    _Float16* d_x2; CK(hipMalloc(&d_x2, (size_t)n * G::P * G::MIDP * 2)); CK(hipMemset(d_x2, 0, (size_t)n * G::P * G::MIDP * 2)); CK(hipMemset(d_x1, 0, (size_t)n * G::P * G::MIDP * 2));
+    const bm::BlkPack bq = bm::make_blk_pack(0, EMIT ? 64 : 16, EMIT ? 0 : 1);
+    std::vector<unsigned short> wq(bq.total / 2);
+    for (auto& v : wq) { s = s * 1664525u + 1013904223u; v = bm::f32_to_f16_bits(((s >> 8) & 0xffff) / 65536.0f * 0.2f - 0.1f); }
+    unsigned char* d_wq; CK(hipMalloc(&d_wq, bq.total)); CK(hipMemcpy(d_wq, wq.data(), bq.total, hipMemcpyHostToDevice));
+    const bm::BlkLink link = EMIT ? bm::BlkLink{d_wq, bq.conv1_a, bq.conv1_b, 0, d_x2} : (RECON ? bm::BlkLink{d_wq, bq.conv3_a, bq.conv3_b, bq.down_a, d_x2} : bm::BlkLink{});
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     unsigned long long zero[8] = {};
@@ -49,7 +56,7 @@ static void run(const char* name, int n, int iters) {
         CK(hipMemcpyToSymbol(HIP_SYMBOL(bm::g_osblock_prof), zero, sizeof(zero)));
 #endif
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(kern, dim3(n), dim3(64 * G::NWAVES), G::LDS_BYTES, 0, d_in, d_out, d_w, bp, (const int*)nullptr, d_x1, (const unsigned char*)d_wt);
+        hipLaunchKernelGGL(kern, dim3(n), dim3(64 * G::NWAVES), G::LDS_BYTES, 0, d_in, d_out, d_w, bp, (const int*)nullptr, d_x1, (const unsigned char*)d_wt, link);
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         if (ms < best) best = ms;
@@ -127,6 +134,8 @@ int main(int argc, char** argv) {
     if (argc > 3) return 0;
     run<0, 16, true, false>("osblock<0,16,down>", n, iters);
     run<0, 64, false, true>("osblock<0,64,trans>", n, iters);
+    run<0, 16, true, false, true, false>("osblock<0,16,down,EMIT>", n, iters);
+    run<0, 64, false, true, false, true>("osblock<0,64,trans,RECON>", n, iters);
     run<1, 64, true, false>("osblock<1,64,down>", n, iters);
     run<1, 96, false, true>("osblock<1,96,trans>", n, iters);
     run<2, 96, true, false>("osblock<2,96,down>", n, iters);
