@@ -70,3 +70,18 @@ def strongsort_golden_rows(name):
     rows, counts = g[name + "_rows"], g[name + "_counts"]
     offs = np.concatenate([[0], np.cumsum(counts)])
     return [rows[offs[i]:offs[i + 1]] for i in range(len(counts))], g
+
+
+MOT17_DIM = 16
+
+
+def mot17_embeddings(rows: np.ndarray) -> np.ndarray:
+    """Deterministic appearance vectors for the MOT17-mini golden (tests/golden/make_golden.py mot17): sines/cosines of the
+    box centre at four spatial frequencies plus seeded noise -- a function of the committed detection rows only."""
+    cx, cy = (rows[:, 1] + rows[:, 3]) / 2, (rows[:, 2] + rows[:, 4]) / 2
+    feats = []
+    for k in range(MOT17_DIM // 4):
+        f = np.float32(2 * np.pi * (k + 1) / 1920.0 * 3)
+        feats += [np.sin(f * cx), np.cos(f * cx), np.sin(f * cy), np.cos(f * cy)]
+    emb = np.stack(feats, 1).astype(np.float64) + np.random.default_rng(17).normal(0, 0.05, (len(rows), MOT17_DIM))
+    return emb.astype(np.float32)

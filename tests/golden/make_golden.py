@@ -8,6 +8,7 @@ Outputs (small, committed):
   tests/golden/botsort_warp_golden.npz   the same with a scheduled camera-motion warp (STrack.multi_gmc)
   tests/golden/deepocsort_golden.npz     per-frame rows + final Kalman state of the reference DeepOcSort
   tests/golden/strongsort_golden.npz     the same for the reference StrongSort (identity camera motion)
+  tests/golden/mot17_golden.npz          the four reference trackers replayed over the reference's MOT17-mini det.txt files
   tests/golden/reid_golden.npz     a seeded OSNet-x0.25 state_dict, test boxes, and the reference
                                    BaseModelBackend.get_features / get_crops results for them
 The lap / cv2 stand-ins make those two boundaries "parity unpinned" (see oracle/__init__.py).
@@ -27,6 +28,7 @@ from boxmot_amd.reid_weights import random_osnet_state_dict  # noqa: E402
 from boxmot_amd.scenario import Scenario, camera_warps, stress_frames  # noqa: E402
 from boxmot_amd.tracker_zoo import BOTSORT_YAML_DEFAULTS  # noqa: E402
 from oracle import ref_harness  # noqa: E402
+from tests.common import mot17_embeddings  # noqa: E402
 
 OUT = Path(__file__).resolve().parent
 YAML = {k: v for k, v in BOTSORT_YAML_DEFAULTS.items() if k not in ("use_cmc", "cmc_method", "with_reid")}
@@ -166,6 +168,65 @@ def strongsort_golden():
     np.savez_compressed(OUT / "strongsort_golden.npz", **out)
 
 
+MOT17_FRAMES = 200
+
+
+def mot17_inputs(seq: str):
+    """First MOT17_FRAMES frames of the reference's own detection fixture (assets/MOT17-mini/train/<seq>/det/det.txt, public
+    FRCNN detections with their real confidences 0.05..1) as dets_n_embs rows [frame, x1, y1, x2, y2, conf, cls], plus a
+    deterministic appearance vector per detection: sines/cosines of the box centre at four spatial frequencies (neighbouring
+    people look alike, as real embeddings of a crowd do) with a little seeded noise."""
+    path = Path("/root/reference/assets/MOT17-mini/train") / seq / "det" / "det.txt"
+    d = np.loadtxt(path, delimiter=",")
+    d = d[d[:, 0] <= MOT17_FRAMES]
+    d = d[np.argsort(d[:, 0], kind="stable")]
+    rows = np.zeros((len(d), 7), dtype=np.float32)
+    rows[:, 0] = d[:, 0]
+    rows[:, 1:3] = d[:, 2:4]
+    rows[:, 3:5] = d[:, 2:4] + d[:, 4:6]
+    rows[:, 5] = d[:, 6]
+    return rows, mot17_embeddings(rows)
+
+
+def mot17_golden():
+    """mot17_golden.npz: the reference BotSort (with and without appearance), DeepOcSort and StrongSort replayed over the
+    reference's MOT17-mini detection files the way process_sequence does (frames without detections are skipped)."""
+    logging.disable(logging.CRITICAL)
+    BotSort, DeepOcSort, StrongSort = ref_harness.load_botsort(), ref_harness.load_deepocsort(), ref_harness.load_strongsort()
+    img = np.zeros((1080, 1920, 3), dtype=np.uint8)
+    out = {}
+
+    def strong():
+        t = StrongSort(reid_model=None)
+        t.cmc = ref_harness.IdentityCMC()
+        return t
+
+    makers = {
+        "botsort": lambda: BotSort(reid_model=None, with_reid=True, use_cmc=False, **YAML),
+        "botsort_noreid": lambda: BotSort(reid_model=None, with_reid=False, use_cmc=False, **YAML),
+        "deepocsort": lambda: DeepOcSort(reid_model=None, cmc_off=True),
+        "strongsort": strong,
+    }
+    for seq in ("MOT17-02-FRCNN", "MOT17-04-FRCNN"):
+        rows, emb = mot17_inputs(seq)
+        out[seq + "_dets"] = rows           # the embeddings are a function of these rows (tests/common.py mot17_embeddings)
+        for name, mk in makers.items():
+            trk = mk()
+            res, counts = [], []
+            for fid in range(1, MOT17_FRAMES + 1):
+                m = rows[:, 0] == fid
+                if not m.any():
+                    counts.append(-1)
+                    continue
+                r = np.asarray(trk.update(rows[m, 1:].copy(), img, emb[m].copy()), dtype=np.float32).reshape(-1, 8)
+                res.append(r)
+                counts.append(len(r))
+            out[f"{seq}_{name}_rows"] = np.concatenate(res, 0)
+            out[f"{seq}_{name}_counts"] = np.array(counts, dtype=np.int32)
+            print(seq, name, "dets", len(rows), "rows", len(out[f"{seq}_{name}_rows"]), "max id", int(out[f"{seq}_{name}_rows"][:, 4].max()))
+    np.savez_compressed(OUT / "mot17_golden.npz", **out)
+
+
 def main():
     logging.disable(logging.CRITICAL)
     BotSort = ref_harness.load_botsort()
@@ -213,8 +274,12 @@ if __name__ == "__main__":
         deepocsort_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "strongsort":
         strongsort_golden()
+        mot17_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "mot17":
+        mot17_golden()
     else:
         main()
         warp_golden()
         deepocsort_golden()
         strongsort_golden()
+        mot17_golden()
