@@ -1,11 +1,11 @@
-"""boxmot_amd -- MI355X-native tracker update path (BoT-SORT, DeepOCSORT, StrongSORT; HIP kernels behind a C ABI).
+"""boxmot_amd -- MI355X-native tracker update path (BoT-SORT, DeepOCSORT, OC-SORT, StrongSORT; HIP kernels behind a C ABI).
 
 Public surface (mirrors the reference's for this path):
-  BotSort, DeepOcSort, StrongSort, HipReID, TrackResults, create_tracker, MultiStreamBotSort.
+  BotSort, DeepOcSort, OcSort, StrongSort, HipReID, TrackResults, create_tracker, MultiStreamBotSort.
 """
 __version__ = "0.1.0"
 
-__all__ = ["BotSort", "DeepOcSort", "StrongSort", "HipReID", "TrackResults", "create_tracker", "MultiStreamBotSort"]
+__all__ = ["BotSort", "DeepOcSort", "OcSort", "StrongSort", "HipReID", "TrackResults", "create_tracker", "MultiStreamBotSort"]
 
 
 def __getattr__(name):
@@ -15,6 +15,9 @@ def __getattr__(name):
     if name == "DeepOcSort":
         from boxmot_amd.deepocsort import DeepOcSort
         return DeepOcSort
+    if name == "OcSort":
+        from boxmot_amd.deepocsort import OcSort
+        return OcSort
     if name == "StrongSort":
         from boxmot_amd.strongsort import StrongSort
         return StrongSort

@@ -149,3 +149,32 @@ class DeepOcSort(BaseTracker):
             self.close()
         except Exception:
             pass
+
+
+class OcSort(DeepOcSort):
+    """OC-SORT behind the reference plugin surface (boxmot/trackers/bbox/ocsort/ocsort.py:334-555).
+
+    The reference's ``OcSort`` (``use_byte=False``) and its ``DeepOcSort`` with the appearance and camera-motion terms
+    switched off run the same arithmetic -- same ``KalmanBoxTracker`` / ``KalmanFilterXYSR``, ``associate`` with the
+    velocity-direction term, observation-centric recovery round and re-update, same output rule (ocsort.py:398-555 vs
+    deepocsort.py:302-492); pinned bit-for-bit on the reference classes (tests/golden/mot17_golden.npz,
+    tests/test_oracle_vs_reference.py).  So OC-SORT runs on the DeepOCSORT step kernel with those two terms off.
+    ``use_byte=True`` (a second association over low-confidence detections, ocsort.py:456-485) is not implemented and is
+    rejected loudly; ``min_conf`` only matters for that branch."""
+
+    def __init__(self, min_conf: float = 0.1, delta_t: int = 3, inertia: float = 0.2, use_byte: bool = False,
+                 Q_xy_scaling: float = 0.01, Q_s_scaling: float = 0.0001, max_tracks: int = 1024, max_dets: int = 256,
+                 **kwargs: Any):
+        if use_byte:
+            raise NotImplementedError("boxmot_amd.OcSort: use_byte=True (BYTE association of low-confidence detections) "
+                                      "is not implemented on the HIP path")
+        for k in ("reid_model", "embedding_off", "cmc_off", "cmc", "emb_dim"):
+            if k in kwargs:
+                raise TypeError(f"OcSort() got an unexpected keyword argument {k!r}")
+        super().__init__(reid_model=None, delta_t=delta_t, inertia=inertia, embedding_off=True, cmc_off=True,
+                         Q_xy_scaling=Q_xy_scaling, Q_s_scaling=Q_s_scaling, max_tracks=max_tracks, max_dets=max_dets, **kwargs)
+        self.min_conf, self.use_byte = min_conf, use_byte
+        self.asso_threshold = self.iou_threshold
+
+    def _update_impl(self, dets, img, embs=None, masks=None, class_list: int = 0) -> np.ndarray:
+        return super()._update_impl(dets, img, None, masks, class_list)      # appearance is never used (ocsort.py:361-365)

@@ -504,3 +504,18 @@ class PerClassDeepOcSortOracle:
                 rows.append(out)
         self.frame_count += 1
         return np.vstack(rows) if rows else np.empty((0, 8), dtype=np.float32)
+
+
+class OcSortOracle(DeepOcSortOracle):
+    """OC-SORT (boxmot/trackers/bbox/ocsort/ocsort.py:334-555, ``use_byte=False``): the reference's ``OcSort`` and its
+    ``DeepOcSort`` with ``embedding_off=True, cmc_off=True`` produce identical rows (pinned on the reference classes:
+    tests/test_oracle_vs_reference.py, tests/golden/mot17_golden.npz), so the restatement is the DeepOCSORT one with
+    those terms off.  ``min_conf`` / ``use_byte`` are accepted for signature parity; ``use_byte=True`` is not restated."""
+
+    def __init__(self, min_conf=0.1, use_byte=False, **kw):
+        if use_byte:
+            raise NotImplementedError("OcSortOracle: use_byte=True is not restated")
+        super().__init__(embedding_off=True, **kw)
+
+    def update(self, dets, img=None, embs=None, warp=None):
+        return super().update(dets, img, None)

@@ -98,6 +98,14 @@ def load_deepocsort():
     return DeepOcSort
 
 
+def load_ocsort():
+    """Return the reference OcSort class (imported from /root/reference)."""
+    install_standins()
+    from boxmot.trackers.bbox.ocsort.ocsort import OcSort
+
+    return OcSort
+
+
 def load_strongsort():
     """Return the reference StrongSort class.  Tracks start Confirmed when GITHUB_ACTIONS == "true"
     (sort/track.py:91-98), so that variable is cleared first."""

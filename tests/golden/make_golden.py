@@ -8,7 +8,7 @@ Outputs (small, committed):
   tests/golden/botsort_warp_golden.npz   the same with a scheduled camera-motion warp (STrack.multi_gmc)
   tests/golden/deepocsort_golden.npz     per-frame rows + final Kalman state of the reference DeepOcSort
   tests/golden/strongsort_golden.npz     the same for the reference StrongSort (identity camera motion)
-  tests/golden/mot17_golden.npz          the four reference trackers replayed over the reference's MOT17-mini det.txt files
+  tests/golden/mot17_golden.npz          the reference BotSort / DeepOcSort / OcSort / StrongSort replayed over the reference's MOT17-mini det.txt files
   tests/golden/reid_golden.npz     a seeded OSNet-x0.25 state_dict, test boxes, and the reference
                                    BaseModelBackend.get_features / get_crops results for them
 The lap / cv2 stand-ins make those two boundaries "parity unpinned" (see oracle/__init__.py).
@@ -193,6 +193,7 @@ def mot17_golden():
     reference's MOT17-mini detection files the way process_sequence does (frames without detections are skipped)."""
     logging.disable(logging.CRITICAL)
     BotSort, DeepOcSort, StrongSort = ref_harness.load_botsort(), ref_harness.load_deepocsort(), ref_harness.load_strongsort()
+    OcSort = ref_harness.load_ocsort()
     img = np.zeros((1080, 1920, 3), dtype=np.uint8)
     out = {}
 
@@ -206,6 +207,8 @@ def mot17_golden():
         "botsort_noreid": lambda: BotSort(reid_model=None, with_reid=False, use_cmc=False, **YAML),
         "deepocsort": lambda: DeepOcSort(reid_model=None, cmc_off=True),
         "strongsort": strong,
+        "ocsort": lambda: OcSort(),
+        "ocsort_yaml": lambda: OcSort(det_thresh=0.6, inertia=0.1),       # configs/trackers/ocsort.yaml defaults
     }
     for seq in ("MOT17-02-FRCNN", "MOT17-04-FRCNN"):
         rows, emb = mot17_inputs(seq)

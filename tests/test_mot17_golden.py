@@ -1,6 +1,6 @@
 """The reference's own detection fixture (assets/MOT17-mini/train/*/det/det.txt: public FRCNN detections with real
 confidences, so the low-confidence second association, the confidence filters and crowded frames are all exercised)
-replayed through the four reference tracker configurations by tests/golden/make_golden.py, frozen in
+replayed through the reference BotSort (with / without appearance), DeepOcSort, StrongSort and OcSort by tests/golden/make_golden.py, frozen in
 tests/golden/mot17_golden.npz.  CPU: the oracles reproduce the reference rows bit for bit.  GPU: the HIP trackers,
 driven through boxmot_amd.replay like the reference's process_sequence drives a tracker, reproduce them too."""
 from pathlib import Path
@@ -12,7 +12,7 @@ from common import BOTSORT_YAML_DEFAULTS, mot17_embeddings
 
 GOLD = Path(__file__).resolve().parent / "golden" / "mot17_golden.npz"
 SEQS = ("MOT17-02-FRCNN", "MOT17-04-FRCNN")
-KINDS = ("botsort", "botsort_noreid", "deepocsort", "strongsort")
+KINDS = ("botsort", "botsort_noreid", "deepocsort", "strongsort", "ocsort", "ocsort_yaml")
 YAML = {k: v for k, v in BOTSORT_YAML_DEFAULTS.items() if k not in ("use_cmc", "cmc_method", "with_reid")}
 
 
@@ -37,8 +37,12 @@ def _golden_rows(g, seq, kind):
 
 def _oracle(kind, **kw):
     from oracle.botsort import BotSortOracle
-    from oracle.deepocsort import DeepOcSortOracle
+    from oracle.deepocsort import DeepOcSortOracle, OcSortOracle
     from oracle.strongsort import StrongSortOracle
+    if kind == "ocsort":
+        return OcSortOracle(**kw)
+    if kind == "ocsort_yaml":
+        return OcSortOracle(det_thresh=0.6, inertia=0.1, **kw)
     if kind == "botsort":
         return BotSortOracle(**YAML)
     if kind == "botsort_noreid":
@@ -75,10 +79,12 @@ def test_hip_replay_reproduces_reference_on_mot17_detections(kind):
     kw = dict(YAML) if kind.startswith("botsort") else {}
     if kind == "botsort_noreid":
         kw["with_reid"] = False
+    if kind == "ocsort_yaml":
+        kw.update(det_thresh=0.6, inertia=0.1)
     got = replay(seqs, tracker_type=kind.split("_")[0], max_tracks=512, max_dets=64, **kw)
     for seq in SEQS:
         want = _golden_rows(g, seq, kind)
-        if kind == "deepocsort":
+        if kind in ("deepocsort", "ocsort", "ocsort_yaml"):
             # the device assignment breaks exact cost ties towards the lowest index, the reference's (stand-in) solver
             # otherwise; the oracle with the device's rule must still equal the reference here (no decisive tie)
             orc, w2 = _oracle(kind, lap_rule="lowest_index"), {}

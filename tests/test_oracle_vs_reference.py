@@ -47,6 +47,27 @@ def test_deepocsort_oracle_bit_exact_incl_kalman_state():
             assert np.array_equal(k.kf.x[:, 0], x) and np.array_equal(k.kf.P, P)
 
 
+def test_ocsort_oracle_bit_exact_incl_kalman_state():
+    """The reference OcSort class itself (ocsort.py) against the OC-SORT oracle = DeepOCSORT restatement with the
+    appearance and camera terms off: rows and fp64 filter state identical."""
+    from boxmot_amd.scenario import stress_frames
+    from oracle.deepocsort import OcSortOracle
+
+    logging.disable(logging.CRITICAL)
+    OcSort = ref_harness.load_ocsort()
+    img = np.zeros((480, 640, 3), np.uint8)
+    for kw in ({}, dict(max_age=5, min_hits=1, delta_t=2), dict(det_thresh=0.6, inertia=0.1, iou_threshold=0.2)):
+        ref, orc = OcSort(**kw), OcSortOracle(**kw)
+        for t, (d, e) in enumerate(stress_frames(100, seed=3)):
+            r = np.asarray(ref.update(d.copy(), img))
+            o = orc.update(d.copy(), img)
+            assert r.shape == o.shape and np.array_equal(r, o), (kw, t)
+        dd = orc.dump()
+        assert [k.id + 1 for k in ref.active_tracks] == list(dd["id"])      # OcSort counts from 0 and emits id + 1 (ocsort.py:541)
+        for k, x, P in zip(ref.active_tracks, dd["x"], dd["P"]):
+            assert np.array_equal(k.kf.x[:, 0], x) and np.array_equal(k.kf.P, P)
+
+
 def test_deepocsort_per_class_oracle_matches_reference():
     from boxmot_amd.scenario import stress_frames
     from oracle.deepocsort import PerClassDeepOcSortOracle
