@@ -1,17 +1,20 @@
-"""boxmot_amd -- MI355X-native tracker update path (BoT-SORT, DeepOCSORT, OC-SORT, StrongSORT; HIP kernels behind a C ABI).
+"""boxmot_amd -- MI355X-native tracker update path (BoT-SORT, ByteTrack, DeepOCSORT, OC-SORT, StrongSORT; HIP kernels behind a C ABI).
 
 Public surface (mirrors the reference's for this path):
-  BotSort, DeepOcSort, OcSort, StrongSort, HipReID, TrackResults, create_tracker, MultiStreamBotSort.
+  BotSort, ByteTrack, DeepOcSort, OcSort, StrongSort, HipReID, TrackResults, create_tracker, MultiStreamBotSort.
 """
 __version__ = "0.1.0"
 
-__all__ = ["BotSort", "DeepOcSort", "OcSort", "StrongSort", "HipReID", "TrackResults", "create_tracker", "MultiStreamBotSort"]
+__all__ = ["BotSort", "ByteTrack", "DeepOcSort", "OcSort", "StrongSort", "HipReID", "TrackResults", "create_tracker", "MultiStreamBotSort"]
 
 
 def __getattr__(name):
     if name == "BotSort":
         from boxmot_amd.botsort import BotSort
         return BotSort
+    if name == "ByteTrack":
+        from boxmot_amd.bytetrack import ByteTrack
+        return ByteTrack
     if name == "DeepOcSort":
         from boxmot_amd.deepocsort import DeepOcSort
         return DeepOcSort

@@ -46,6 +46,7 @@ class BotSortConfig(ctypes.Structure):
         ("max_dets", ctypes.c_int),
         ("emb_dim", ctypes.c_int),
         ("n_class_lists", ctypes.c_int),
+        ("tracker_kind", ctypes.c_int),
     ]
 
 
@@ -101,6 +102,7 @@ _VP = ctypes.c_void_p
 _I = ctypes.c_int
 SIGNATURES = {
     "boxmot_hip_botsort_default_config": (None, [ctypes.POINTER(BotSortConfig)]),
+    "boxmot_hip_bytetrack_default_config": (None, [ctypes.POINTER(BotSortConfig)]),
     "boxmot_hip_botsort_create": (_VP, [ctypes.POINTER(BotSortConfig)]),
     "boxmot_hip_botsort_destroy": (None, [_VP]),
     "boxmot_hip_botsort_reset": (_I, [_VP]),

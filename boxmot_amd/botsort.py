@@ -54,9 +54,11 @@ class BotSort(BaseTracker):
         max_dets: int = 256,
         emb_dim: int | None = None,
         cmc: Any | None = None,
+        _tracker_kind: int = 0,
+        _tracker_name: str = "BotSort",
         **kwargs: Any,
     ):
-        super().__init__(_tracker_name="BotSort", **kwargs)
+        super().__init__(_tracker_name=_tracker_name, **kwargs)
         if use_cmc and cmc is None:
             raise NotImplementedError(
                 "boxmot_amd.BotSort: camera-motion estimation (cmc_method=%r) is not implemented on the HIP path; "
@@ -104,6 +106,7 @@ class BotSort(BaseTracker):
         cfg.max_dets = max_dets
         cfg.emb_dim = self._emb_dim
         cfg.n_class_lists = self.nr_classes if self.per_class else 1
+        cfg.tracker_kind = int(_tracker_kind)
         self._cfg = cfg
         self._handle = self._lib.boxmot_hip_botsort_create(ctypes.byref(cfg))
         if not self._handle:

@@ -60,7 +60,7 @@ void botsort_allocate(BotSortStepArgs& args, const BotSortSizes& z, A& a) {
 
 inline BotSortConfigDev make_config_dev(double high, double low, double new_thresh, double match, double prox,
                                         double app, double second, double unc, double unc_scale, int fuse,
-                                        int with_reid, int frame_rate, int track_buffer, int removed_cap) {
+                                        int with_reid, int frame_rate, int track_buffer, int removed_cap, int kind = 0) {
     BotSortConfigDev d;
     d.track_high_thresh = high; d.track_low_thresh = low; d.new_track_thresh = new_thresh;
     d.match_thresh = match; d.proximity_thresh = prox; d.appearance_thresh = app;
@@ -69,6 +69,7 @@ inline BotSortConfigDev make_config_dev(double high, double low, double new_thre
     d.fuse_first_associate = fuse; d.with_reid = with_reid;
     d.max_time_lost = (int)(frame_rate / 30.0 * track_buffer);   // botsort.py:103-104
     d.removed_cap = removed_cap;
+    d.kind = kind;
     return d;
 }
 

@@ -115,10 +115,12 @@ constexpr double MIN_SIZE = 1e-4;
 
 // multi_predict for one track (base.py:311-327, xywh.py:149-160) incl. the
 // "zero (vw, vh) unless Tracked" rule of STrack.multi_predict (botsort_track.py:104-109).
-__device__ inline void kf_predict_wave(double* kf, bool zero_size_vel, int lane) {
+// `xyah`: KalmanFilterXYAH noise model (xyah.py:70-89: every std from the height, constants for the aspect ratio)
+// and ByteTrack's rule "zero vh unless Tracked" (bytetrack.py:63-74).
+__device__ inline void kf_predict_wave(double* kf, bool zero_size_vel, int lane, bool xyah = false) {
     const int i = lane >> 3, j = lane & 7;
     double mj = kf[j];                       // mean[j]
-    if (zero_size_vel && j >= 6) mj = 0.0;
+    if (zero_size_vel && (xyah ? j == 7 : j >= 6)) mj = 0.0;
     const double w = __shfl(mj, 2, WAVE), h = __shfl(mj, 3, WAVE);   // pre-motion w, h
     const double p = kf[KF_DIM + lane];
     // mean' = mean . F^T  (one rounding: m_k + m_{k+4})
@@ -131,8 +133,10 @@ __device__ inline void kf_predict_wave(double* kf, bool zero_size_vel, int lane)
     const double fp_rt = __shfl(fp, (lane + 4) & 63, WAVE);       // (FP)[i][j+4]
     double c = (j < 4) ? (fp + fp_rt) : fp;
     if (i == j) {
-        const double dim_v = (i & 1) ? h : w;
-        const double sd = ((i < 4) ? STD_POS : STD_VEL) * dim_v;
+        const double dim_v = xyah ? h : ((i & 1) ? h : w);
+        double sd = ((i < 4) ? STD_POS : STD_VEL) * dim_v;
+        if (xyah && i == 2) sd = 1e-2;
+        if (xyah && i == 6) sd = 1e-5;
         c = c + sd * sd;
     } else {
         c = c + 0.0;
@@ -167,7 +171,8 @@ __device__ inline void kf_warp_wave(double* kf, const double* W, int lane) {
 
 // KalmanFilterXYWH.update for one track with measurement z (fp32 xywh);
 // base.py:286-355 (confidence = 0: BoT-SORT never passes it, botsort_track.py:269-271).
-__device__ inline void kf_update_wave(double* kf, const float* z, int lane) {
+// `xyah`: z is (x, y, aspect, height) and the measurement noise follows xyah.py:57-68.
+__device__ inline void kf_update_wave(double* kf, const float* z, int lane, bool xyah = false) {
     const int i = lane >> 3, j = lane & 7;
     double m[8];
     for (int k = 0; k < 8; ++k) m[k] = kf[k];
@@ -177,7 +182,8 @@ __device__ inline void kf_update_wave(double* kf, const float* z, int lane) {
     for (int a = 0; a < 4; ++a)
         for (int b = 0; b < 4; ++b) S[a][b] = P[a * 8 + b];
     for (int a = 0; a < 4; ++a) {
-        const double sd = STD_POS * m[2 + (a & 1)];
+        double sd = STD_POS * (xyah ? m[3] : m[2 + (a & 1)]);
+        if (xyah && a == 2) sd = 1e-1;
         S[a][a] = S[a][a] + sd * sd;
     }
     // lower Cholesky factor (dpotrf, lower triangle of S only)
@@ -231,13 +237,16 @@ __device__ inline void kf_update_wave(double* kf, const float* z, int lane) {
 }
 
 // KalmanFilterXYWH.initiate (xywh.py:136-142, base.py:234-244, std xywh.py:22-36)
-__device__ inline void kf_initiate_wave(double* kf, const float* z, int lane) {
+// `xyah`: xyah.py:22-37, 99-105.
+__device__ inline void kf_initiate_wave(double* kf, const float* z, int lane, bool xyah = false) {
     const int i = lane >> 3, j = lane & 7;
     const double w = (double)z[2], h = (double)z[3];
     double c = 0.0;
     if (i == j) {
-        const double dim_v = (i & 1) ? h : w;
-        const double sd = (i < 4) ? (2 * STD_POS) * dim_v : (10 * STD_VEL) * dim_v;
+        const double dim_v = xyah ? h : ((i & 1) ? h : w);
+        double sd = (i < 4) ? (2 * STD_POS) * dim_v : (10 * STD_VEL) * dim_v;
+        if (xyah && i == 2) sd = 1e-2;
+        if (xyah && i == 6) sd = 1e-5;
         c = sd * sd;
     }
     kf[KF_DIM + lane] = c;
@@ -335,7 +344,7 @@ __device__ inline void apply_matches(const Ctx& c, SV& v, int n_match, int frame
         if (k < n_match) {
             const int slot = v.match_slot[k], d = v.match_det[k];
             const bool was_tracked = v.match_flag[k] != 0;
-            kf_update_wave(v.kf + (long)slot * KF_STRIDE, v.det_xywh + d * 4, c.lane);
+            kf_update_wave(v.kf + (long)slot * KF_STRIDE, v.det_xywh + d * 4, c.lane, v.cfg.kind == 1);
             if (with_feat) blend_feature_wave(v.smooth + (long)slot * v.dim, v.det_feat + (long)d * v.dim, v.dim, c.lane);
             if (c.lane == 0) {
                 v.tracklet_len[slot] = was_tracked ? v.tracklet_len[slot] + 1 : 0;
@@ -346,7 +355,7 @@ __device__ inline void apply_matches(const Ctx& c, SV& v, int n_match, int frame
                 v.conf[slot] = conf;
                 v.cls[slot] = cls;
                 v.det_ind[slot] = (float)d;
-                vote_cls(v, slot, cls, conf);
+                if (v.cfg.kind == 0) vote_cls(v, slot, cls, conf);      // ByteTrack takes the detection's class (bytetrack.py:139)
             }
         }
     }
@@ -360,7 +369,7 @@ __device__ inline void apply_matches(const Ctx& c, SV& v, int n_match, int frame
 __device__ inline void track_boxes(const Ctx& c, const SV& v, const int* rows, int n, double* box) {
     for (int r = c.tid; r < n; r += c.nthr) {
         const double* m = v.kf + (long)rows[r] * KF_STRIDE;
-        const double hw = m[2] / 2, hh = m[3] / 2;
+        const double hw = (v.cfg.kind == 1 ? m[2] * m[3] : m[2]) / 2, hh = m[3] / 2;     // xyah: w = a * h (bytetrack.py:185-186)
         box[r * 4 + 0] = m[0] - hw;
         box[r * 4 + 1] = m[1] - hh;
         box[r * 4 + 2] = m[0] + hw;
@@ -715,6 +724,10 @@ __device__ inline void botsort_step_stream(const BotSortStepArgs& args, int s, i
         const float w = d[2] - d[0], h = d[3] - d[1];
         float* q = v.det_xywh + j * 4;
         q[0] = cx; q[1] = cy; q[2] = w; q[3] = h;
+        if (cfg.kind == 1) {        // the filter's measurement is tlwh2xyah(xywh2tlwh(xywh)) in fp32 (bytetrack.py:33-35, geometry.py:56-99)
+            const float tl = cx - w / 2.0f, tt = cy - h / 2.0f;
+            q[0] = tl + (w / 2); q[1] = tt + (h / 2); q[2] = w / h;
+        }
         float* b = v.det_xyxy + j * 4;
         b[0] = cx - w * 0.5f; b[1] = cy - h * 0.5f; b[2] = cx + w * 0.5f; b[3] = cy + h * 0.5f;
         v.det_area[j] = (b[2] - b[0]) * (b[3] - b[1]);
@@ -759,7 +772,7 @@ __device__ inline void botsort_step_stream(const BotSortStepArgs& args, int s, i
         const int k = base + c.wave;
         if (k < n_pool) {
             const int slot = v.pool[k];
-            kf_predict_wave(v.kf + (long)slot * KF_STRIDE, v.state[slot] != ST_TRACKED, c.lane);
+            kf_predict_wave(v.kf + (long)slot * KF_STRIDE, v.state[slot] != ST_TRACKED, c.lane, cfg.kind == 1);
         }
     }
     __syncthreads();
@@ -861,7 +874,7 @@ __device__ inline void botsort_step_stream(const BotSortStepArgs& args, int s, i
         const int k = base + c.wave;
         if (k < n_born) {
             const int d = v.list_a[k], slot = v.list_b[k];
-            kf_initiate_wave(v.kf + (long)slot * KF_STRIDE, v.det_xywh + d * 4, c.lane);
+            kf_initiate_wave(v.kf + (long)slot * KF_STRIDE, v.det_xywh + d * 4, c.lane, cfg.kind == 1);
             if (reid) for (int q = c.lane; q < dim; q += WAVE) v.smooth[(long)slot * dim + q] = v.det_feat[(long)d * dim + q];
             if (c.lane == 0) {
                 const float conf = v.dets[d * DET_COLS + 4], cls = v.dets[d * DET_COLS + 5];
@@ -873,7 +886,7 @@ __device__ inline void botsort_step_stream(const BotSortStepArgs& args, int s, i
                 v.start_frame[slot] = frame;
                 v.tracklet_len[slot] = 0;
                 v.conf[slot] = conf; v.cls[slot] = cls; v.det_ind[slot] = (float)d;
-                v.hist_n[slot] = 1;
+                v.hist_n[slot] = cfg.kind == 1 ? 0 : 1;     // ByteTrack: "has been marked removed" flag, see below
                 v.hist_cls[slot * KCLS] = cls;
                 v.hist_w[slot * KCLS] = conf;
             }
@@ -908,6 +921,9 @@ __device__ inline void botsort_step_stream(const BotSortStepArgs& args, int s, i
     // L = ((lost \ A) + newly_lost) \ removed_ids
     const int rm_size = *v.rm_size, rm_head = *v.rm_head, rm_cap = cfg.removed_cap;
     auto in_removed = [&](int slot) {
+        // ByteTrack's removed list is unbounded (bytetrack.py:393): a track keeps its slot while it is in either list,
+        // so "its id is in the list" is a per-slot flag, set below once this frame's subtraction is done
+        if (cfg.kind == 1) return v.hist_n[slot] != 0;
         const int tid_ = v.id[slot];
         for (int q = 0; q < rm_size; ++q)
             if (v.removed_ring[(rm_head + q) % v.removed_alloc] == tid_) return true;
@@ -929,6 +945,8 @@ __device__ inline void botsort_step_stream(const BotSortStepArgs& args, int s, i
         *v.rm_head = head;
         *v.rm_size = size;
     }
+    __syncthreads();
+    if (cfg.kind == 1) for (int k = c.tid; k < n_newly_removed; k += c.nthr) v.hist_n[v.newly_removed[k]] = 1;
     // remove_duplicate_stracks (botsort_utils.py:55-82)
     for (int i = c.tid; i < n_a; i += c.nthr) v.drop_a[i] = 0;
     for (int i = c.tid; i < n_l; i += c.nthr) v.drop_b[i] = 0;
@@ -971,7 +989,7 @@ __device__ inline void botsort_step_stream(const BotSortStepArgs& args, int s, i
     for (int k = c.tid; k < n_out; k += c.nthr) {
         const int sl = v.list_a[k];
         const double* m = v.kf + (long)sl * KF_STRIDE;
-        const double hw = m[2] / 2, hh = m[3] / 2;
+        const double hw = (cfg.kind == 1 ? m[2] * m[3] : m[2]) / 2, hh = m[3] / 2;
         float* o = v.out + k * OUT_COLS;
         o[0] = (float)(m[0] - hw); o[1] = (float)(m[1] - hh);
         o[2] = (float)(m[0] + hw); o[3] = (float)(m[1] + hh);

@@ -41,6 +41,10 @@ struct BotSortConfigDev {
     int fuse_first_associate, with_reid;
     int max_time_lost;            // int(frame_rate / 30.0 * track_buffer), botsort.py:103-104
     int removed_cap;              // removed_stracks_buffer (deque maxlen)
+    // 0 = BoT-SORT; 1 = ByteTrack (bytetrack.py:258-408): the same stages with an (x, y, aspect, height) filter state
+    // (kalman_filters/xyah.py), only vh zeroed for non-tracked tracks, score fusion in the first and the unconfirmed
+    // association, no class vote, an unbounded removed list (a per-slot flag, kept in `hist_n`)
+    int kind;
 };
 
 // Persistent tracker state, all pointers device memory, indexed [stream][...].

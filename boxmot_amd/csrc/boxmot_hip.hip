@@ -265,6 +265,8 @@ void build(BoxMOTHipBotSort* h) {
     if (c.n_streams < 1 || c.max_tracks < 8 || c.max_dets < 4 || c.emb_dim < 1 || c.n_class_lists < 1)
         throw std::runtime_error("boxmot_hip: invalid capacity configuration");
     if (c.removed_stracks_buffer < 0) throw std::runtime_error("boxmot_hip: removed_stracks_buffer must be >= 0");
+    if (c.tracker_kind != 0 && c.tracker_kind != 1) throw std::runtime_error("boxmot_hip: tracker_kind must be 0 (BoT-SORT) or 1 (ByteTrack)");
+    if (c.tracker_kind == 1) { h->cfg.with_reid = 0; h->cfg.fuse_first_associate = 1; }
     h->S = c.n_streams; h->cap = c.max_tracks; h->nd = c.max_dets; h->dim = c.emb_dim; h->n_lists = c.n_class_lists;
     BM_HIP(hipStreamCreate(&h->stream));
     BM_HIP(hipEventCreate(&h->ev[0]));
@@ -276,7 +278,8 @@ void build(BoxMOTHipBotSort* h) {
     h->args.cfg = bm::make_config_dev(c.track_high_thresh, c.track_low_thresh, c.new_track_thresh, c.match_thresh,
                                       c.proximity_thresh, c.appearance_thresh, c.second_match_thresh,
                                       c.unconfirmed_match_thresh, c.unconfirmed_emb_scale, c.fuse_first_associate,
-                                      c.with_reid, c.frame_rate, c.track_buffer, c.removed_stracks_buffer);
+                                      c.tracker_kind == 1 ? 0 : c.with_reid, c.frame_rate, c.track_buffer, c.removed_stracks_buffer,
+                                      c.tracker_kind);
     bm::BotSortSizes z{h->S, h->cap, h->nd, h->dim, h->n_lists, c.removed_stracks_buffer > 0 ? c.removed_stracks_buffer : 1};
     DevAlloc dev_allocator{&o};
     bm::botsort_allocate(h->args, z, dev_allocator);
@@ -758,6 +761,16 @@ void boxmot_hip_botsort_default_config(BoxMOTHipBotSortConfig* c) {
     c->second_match_thresh = 0.5; c->unconfirmed_match_thresh = 0.7; c->unconfirmed_emb_scale = 2.0;
     c->removed_stracks_buffer = 100;
     c->n_streams = 1; c->max_tracks = 1024; c->max_dets = 256; c->emb_dim = 512; c->n_class_lists = 1;
+}
+
+void boxmot_hip_bytetrack_default_config(BoxMOTHipBotSortConfig* c) {
+    if (!c) return;
+    boxmot_hip_botsort_default_config(c);
+    c->tracker_kind = 1;
+    c->track_low_thresh = 0.1; c->track_high_thresh = 0.45; c->new_track_thresh = 0.45;     // min_conf, track_thresh, det_thresh
+    c->match_thresh = 0.8; c->track_buffer = 25; c->frame_rate = 30;
+    c->second_match_thresh = 0.5; c->unconfirmed_match_thresh = 0.7;                          // bytetrack.py:338, 358
+    c->with_reid = 0; c->fuse_first_associate = 1; c->emb_dim = 1;
 }
 
 BoxMOTHipBotSort* boxmot_hip_botsort_create(const BoxMOTHipBotSortConfig* config) {

@@ -21,7 +21,7 @@ import numpy as np
 
 from boxmot_amd import _lib
 
-TRACKERS = ("botsort", "deepocsort", "ocsort", "strongsort")
+TRACKERS = ("botsort", "bytetrack", "deepocsort", "ocsort", "strongsort")
 
 
 @dataclass
@@ -96,14 +96,20 @@ class MultiStreamTracker:
             raise NotImplementedError(f"tracker {tracker_type!r} is not implemented on the HIP backend (have: {TRACKERS})")
         self._lib = _lib.load()
         self.kind, self.n_streams, self.emb_dim, self.max_tracks = tracker_type, n_streams, emb_dim, max_tracks
-        native = "deepocsort" if tracker_type == "ocsort" else tracker_type      # OC-SORT = the DeepOCSORT step without its
+        native = {"ocsort": "deepocsort", "bytetrack": "botsort"}.get(tracker_type, tracker_type)   # OC-SORT = the DeepOCSORT step without its
         prefix = f"boxmot_hip_{native}_"                                          # appearance / camera terms (deepocsort.py OcSort)
         cfg = {"botsort": _lib.BotSortConfig, "deepocsort": _lib.DeepOcSortConfig, "strongsort": _lib.StrongSortConfig}[native]()
-        getattr(self._lib, prefix + "default_config")(ctypes.byref(cfg))
+        getattr(self._lib, f"boxmot_hip_{'bytetrack' if tracker_type == 'bytetrack' else native}_default_config")(ctypes.byref(cfg))
         fields = {f[0] for f in cfg._fields_}
         if tracker_type == "botsort":
             kw = {k: v for k, v in kw.items() if k not in ("use_cmc", "cmc_method")}
             cfg.n_class_lists = 1
+        if tracker_type == "bytetrack":           # constructor names -> the shared step configuration (bytetrack.py:225-250)
+            cfg.n_class_lists = 1
+            if "min_conf" in kw:
+                cfg.track_low_thresh = kw.pop("min_conf")
+            if "track_thresh" in kw:
+                cfg.track_high_thresh = cfg.new_track_thresh = kw.pop("track_thresh")
         if tracker_type == "ocsort":
             if kw.pop("use_byte", False):
                 raise NotImplementedError("OC-SORT use_byte=True is not implemented on the HIP backend")
@@ -134,8 +140,8 @@ class MultiStreamTracker:
         dets = [None if d is None else np.ascontiguousarray(d, dtype=np.float32).reshape(-1, 6) for d in dets_list]
         rows = np.array([-1 if d is None else len(d) for d in dets], dtype=np.int32)
         det_ptrs = (ctypes.c_void_p * S)(*[None if d is None or not len(d) else d.ctypes.data for d in dets])
-        if self.kind == "ocsort":
-            embs_list = [None] * S                  # appearance is not an input of OC-SORT
+        if self.kind in ("ocsort", "bytetrack"):
+            embs_list = [None] * S                  # appearance is not an input of OC-SORT / ByteTrack
         embs = [None if (d is None or e is None) else np.ascontiguousarray(e, dtype=np.float32).reshape(len(d), self.emb_dim)
                 for d, e in zip(dets, embs_list)]
         emb_ptrs = (ctypes.c_void_p * S)(*[None if e is None or not len(e) else e.ctypes.data for e in embs])
@@ -168,9 +174,9 @@ def replay(sequences, tracker_type: str = "botsort", conf_threshold: float = 0.0
     seqs = list(sequences)
     if not seqs:
         return {}
-    if any(s.embs is None for s in seqs) and tracker_type not in ("botsort", "ocsort"):
+    if any(s.embs is None for s in seqs) and tracker_type not in ("botsort", "ocsort", "bytetrack"):
         raise ValueError("cached embeddings are required (live ReID over cached frames is not part of the replay path)")
-    dim = 1 if tracker_type == "ocsort" else next((s.embs.shape[1] for s in seqs if s.embs is not None), 1)
+    dim = 1 if tracker_type in ("ocsort", "bytetrack") else next((s.embs.shape[1] for s in seqs if s.embs is not None), 1)
     if max_dets is None:
         max_dets = 4
         for s in seqs:

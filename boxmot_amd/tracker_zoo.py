@@ -37,7 +37,9 @@ STRONGSORT_YAML_DEFAULTS = dict(min_conf=0.6, max_cos_dist=0.4, max_iou_dist=0.7
 # boxmot/configs/trackers/ocsort.yaml defaults
 OCSORT_YAML_DEFAULTS = dict(min_conf=0.1, det_thresh=0.6, max_age=30, min_hits=3, delta_t=3, asso_func="iou", use_byte=False,
                             inertia=0.1, Q_xy_scaling=0.01, Q_s_scaling=0.0001)
-SUPPORTED = ("botsort", "deepocsort", "ocsort", "strongsort")
+# boxmot/configs/trackers/bytetrack.yaml defaults
+BYTETRACK_YAML_DEFAULTS = dict(min_conf=0.1, track_thresh=0.6, match_thresh=0.9, track_buffer=30, frame_rate=30)
+SUPPORTED = ("botsort", "bytetrack", "deepocsort", "ocsort", "strongsort")
 
 
 def flatten_yaml_config(cfg: dict) -> dict:
@@ -66,7 +68,7 @@ def create_tracker(tracker_type: str = "botsort", tracker_config=None, reid_weig
         kwargs = dict(evolve_param_dict)
     elif tracker_config is None:
         kwargs = dict({"botsort": BOTSORT_YAML_DEFAULTS, "deepocsort": DEEPOCSORT_YAML_DEFAULTS,
-                       "ocsort": OCSORT_YAML_DEFAULTS, "strongsort": STRONGSORT_YAML_DEFAULTS}[tracker_type])
+                       "ocsort": OCSORT_YAML_DEFAULTS, "bytetrack": BYTETRACK_YAML_DEFAULTS, "strongsort": STRONGSORT_YAML_DEFAULTS}[tracker_type])
     elif isinstance(tracker_config, dict):
         kwargs = flatten_yaml_config(tracker_config)
     else:
@@ -81,6 +83,10 @@ def create_tracker(tracker_type: str = "botsort", tracker_config=None, reid_weig
 
             reid_model = HipReID(reid_weights, preprocess=reid_preprocess)
         return StrongSort(reid_model=reid_model, **kwargs)
+    if tracker_type == "bytetrack":
+        from boxmot_amd.bytetrack import ByteTrack
+
+        return ByteTrack(**kwargs)
     if tracker_type == "ocsort":
         from boxmot_amd.deepocsort import OcSort
 

@@ -58,6 +58,7 @@ typedef struct BoxMOTHipBotSortConfig {
     int max_dets;                    /* detections per frame per stream */
     int emb_dim;                     /* appearance vector length (512 for OSNet) */
     int n_class_lists;               /* 1, or nr_classes when per_class=True */
+    int tracker_kind;                /* 0 = BoT-SORT; 1 = ByteTrack (set by boxmot_hip_bytetrack_default_config) */
 } BoxMOTHipBotSortConfig;
 
 typedef struct BoxMOTHipBotSort BoxMOTHipBotSort;
@@ -65,6 +66,15 @@ typedef struct BoxMOTHipReID BoxMOTHipReID;
 
 /* fills the constructor defaults of BotSort (botsort.py:66-86) */
 void boxmot_hip_botsort_default_config(BoxMOTHipBotSortConfig* config);
+
+/* ByteTrack (boxmot/trackers/bbox/bytetrack/bytetrack.py:201-408; the reference's native twin:
+ * boxmot/native/cpp/trackers/bytetrack) runs on the same handle type and entry points: BoT-SORT grew out of it, so the
+ * frame step is the same sequence of stages with an (x, y, aspect, height) Kalman state, score fusion in the first and the
+ * unconfirmed association, fixed 0.5 / 0.7 thresholds for the second / unconfirmed association, no appearance, no class
+ * vote and an unbounded removed list.  This fills ByteTrack's constructor defaults (bytetrack.py:225-233: min_conf 0.1 ->
+ * track_low_thresh, track_thresh 0.45 -> track_high_thresh and new_track_thresh, match_thresh 0.8, track_buffer 25,
+ * frame_rate 30) and tracker_kind = 1; create / update / ... are the boxmot_hip_botsort_* functions. */
+void boxmot_hip_bytetrack_default_config(BoxMOTHipBotSortConfig* config);
 
 /* boxmot_botsort_create / _destroy / _reset, c_api.hpp:36-40 */
 BoxMOTHipBotSort* boxmot_hip_botsort_create(const BoxMOTHipBotSortConfig* config);

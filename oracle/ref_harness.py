@@ -106,6 +106,16 @@ def load_ocsort():
     return OcSort
 
 
+def load_bytetrack():
+    """Return the reference ByteTrack class with its process-global id counter rewound (bytetrack/basetrack.py:16)."""
+    install_standins()
+    from boxmot.trackers.bbox.bytetrack.basetrack import BaseTrack
+    from boxmot.trackers.bbox.bytetrack.bytetrack import ByteTrack
+
+    BaseTrack._count = 0
+    return ByteTrack
+
+
 def load_strongsort():
     """Return the reference StrongSort class.  Tracks start Confirmed when GITHUB_ACTIONS == "true"
     (sort/track.py:91-98), so that variable is cleared first."""

@@ -85,3 +85,14 @@ def mot17_embeddings(rows: np.ndarray) -> np.ndarray:
         feats += [np.sin(f * cx), np.cos(f * cx), np.sin(f * cy), np.cos(f * cy)]
     emb = np.stack(feats, 1).astype(np.float64) + np.random.default_rng(17).normal(0, 0.05, (len(rows), MOT17_DIM))
     return emb.astype(np.float32)
+
+
+def bytetrack_device_config(**kw) -> dict:
+    """ByteTrack constructor arguments (bytetrack.py:225-233) -> the BoT-SORT step kernel's configuration in its ByteTrack
+    mode (what boxmot_hip_bytetrack_default_config / boxmot_amd.ByteTrack set)."""
+    c = dict(min_conf=0.1, track_thresh=0.45, match_thresh=0.8, track_buffer=25, frame_rate=30)
+    c.update(kw)
+    return dict(track_high_thresh=c["track_thresh"], track_low_thresh=c["min_conf"], new_track_thresh=c["track_thresh"],
+                match_thresh=c["match_thresh"], proximity_thresh=0.5, appearance_thresh=0.25, second_match_thresh=0.5,
+                unconfirmed_match_thresh=0.7, unconfirmed_emb_scale=2.0, fuse_first_associate=1, with_reid=0,
+                frame_rate=c["frame_rate"], track_buffer=c["track_buffer"], removed_stracks_buffer=100, kind=1)

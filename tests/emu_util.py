@@ -12,7 +12,7 @@ LIB = HERE / "libemu_botsort.so"
 
 CFG_D = ("track_high_thresh", "track_low_thresh", "new_track_thresh", "match_thresh", "proximity_thresh",
          "appearance_thresh", "second_match_thresh", "unconfirmed_match_thresh", "unconfirmed_emb_scale")
-CFG_I = ("fuse_first_associate", "with_reid", "frame_rate", "track_buffer", "removed_stracks_buffer")
+CFG_I = ("fuse_first_associate", "with_reid", "frame_rate", "track_buffer", "removed_stracks_buffer", "kind")
 
 
 def build(sanitize: bool = False, dense: bool = False) -> Path:
@@ -41,7 +41,7 @@ class EmuBotSort:
         self.lib.emu_dump.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 5
         self.lib.emu_destroy.argtypes = [ctypes.c_void_p]
         cd = np.array([cfg[k] for k in CFG_D], dtype=np.float64)
-        ci = np.array([int(cfg[k]) for k in CFG_I], dtype=np.int32)
+        ci = np.array([int(cfg.get(k, 0)) for k in CFG_I], dtype=np.int32)
         self.cap, self.nd, self.dim = cap, nd, dim
         self.h = self.lib.emu_create(cd.ctypes.data, ci.ctypes.data, cap, nd, dim)
 

@@ -8,7 +8,7 @@ Outputs (small, committed):
   tests/golden/botsort_warp_golden.npz   the same with a scheduled camera-motion warp (STrack.multi_gmc)
   tests/golden/deepocsort_golden.npz     per-frame rows + final Kalman state of the reference DeepOcSort
   tests/golden/strongsort_golden.npz     the same for the reference StrongSort (identity camera motion)
-  tests/golden/mot17_golden.npz          the reference BotSort / DeepOcSort / OcSort / StrongSort replayed over the reference's MOT17-mini det.txt files
+  tests/golden/mot17_golden.npz          the reference BotSort / ByteTrack / DeepOcSort / OcSort / StrongSort replayed over the reference's MOT17-mini det.txt files
   tests/golden/reid_golden.npz     a seeded OSNet-x0.25 state_dict, test boxes, and the reference
                                    BaseModelBackend.get_features / get_crops results for them
 The lap / cv2 stand-ins make those two boundaries "parity unpinned" (see oracle/__init__.py).
@@ -195,6 +195,10 @@ def mot17_golden():
     BotSort, DeepOcSort, StrongSort = ref_harness.load_botsort(), ref_harness.load_deepocsort(), ref_harness.load_strongsort()
     OcSort = ref_harness.load_ocsort()
     img = np.zeros((1080, 1920, 3), dtype=np.uint8)
+
+    def byte():
+        return ref_harness.load_bytetrack()()            # rewinds the process-global id counter first
+
     out = {}
 
     def strong():
@@ -209,6 +213,7 @@ def mot17_golden():
         "strongsort": strong,
         "ocsort": lambda: OcSort(),
         "ocsort_yaml": lambda: OcSort(det_thresh=0.6, inertia=0.1),       # configs/trackers/ocsort.yaml defaults
+        "bytetrack": byte,
     }
     for seq in ("MOT17-02-FRCNN", "MOT17-04-FRCNN"):
         rows, emb = mot17_inputs(seq)

@@ -57,7 +57,7 @@ void* emu_create(const double* cd, const int* ci, int cap, int nd, int dim) {
     Emu* e = new Emu();
     e->cap = cap; e->nd = nd; e->dim = dim;
     e->args.cfg = bm::make_config_dev(cd[0], cd[1], cd[2], cd[3], cd[4], cd[5], cd[6], cd[7], cd[8], ci[0], ci[1], ci[2],
-                                      ci[3], ci[4]);
+                                      ci[3], ci[4], ci[5]);
     bm::BotSortSizes z{1, cap, nd, dim, 1, ci[4] > 0 ? ci[4] : 1};
     bm::botsort_allocate(e->args, z, e->alloc);
     e->dets = e->alloc.get<float>((size_t)nd * bm::DET_COLS);

@@ -1,0 +1,78 @@
+"""GPU parity tests for ByteTrack (the BoT-SORT step kernel in its ByteTrack mode, through the C ABI) against the oracle,
+which is pinned bit-for-bit on the reference class (tests/test_oracle_vs_reference.py, tests/golden/mot17_golden.npz).
+Includes BASELINE.json's configuration 0 shape: 32 synthetic detections per frame on 640x640 frames."""
+import numpy as np
+import pytest
+
+from common import assert_rows_match
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_state(trk, orc):
+    od = orc.dump()
+    for which, key in ((0, "active"), (1, "lost")):
+        d = trk.state_dump(which)
+        assert np.array_equal(d["ints"][:, 0], od[key]["id"])
+        assert np.array_equal(d["ints"][:, 1], od[key]["state"])
+        assert np.array_equal(d["ints"][:, 3], od[key]["frame_id"])
+        if d["n"]:
+            ref = np.concatenate([od[key]["mean"], od[key]["cov"].reshape(-1, 64)], 1)
+            assert np.allclose(d["kf"], ref, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("kw", [{}, dict(track_thresh=0.6, match_thresh=0.7, track_buffer=5),
+                                dict(min_conf=0.3, track_buffer=40, frame_rate=25)])
+def test_hip_bytetrack_matches_oracle_on_stress_scenes(kw):
+    from boxmot_amd import ByteTrack
+    from boxmot_amd.scenario import stress_frames
+    from oracle.bytetrack import ByteTrackOracle
+    img = np.zeros((480, 640, 3), dtype=np.uint8)
+    for seed in (3, 7):
+        trk, orc = ByteTrack(max_tracks=256, max_dets=64, **kw), ByteTrackOracle(**kw)
+        for t, (dets, embs) in enumerate(stress_frames(150, seed=seed)):
+            got = np.asarray(trk.update(dets, img, embs)).reshape(-1, 8)          # embeddings are accepted and ignored
+            assert_rows_match(got, orc.update(dets.copy(), img), t)
+        _check_state(trk, orc)
+        trk.close()
+
+
+def test_config0_bytetrack_32_dets_640x640():
+    from boxmot_amd import ByteTrack
+    from boxmot_amd.scenario import Scenario
+    from oracle.bytetrack import ByteTrackOracle
+    sc = Scenario(32, 128, width=640, height=640, emb_dim=8, random_image=False)
+    img = np.zeros((640, 640, 3), dtype=np.uint8)
+    trk, orc = ByteTrack(max_tracks=512, max_dets=128), ByteTrackOracle()
+    rows = 0
+    for t in range(60):
+        d, _ = sc.frame(t)
+        got = np.asarray(trk.update(d, img)).reshape(-1, 8)
+        assert_rows_match(got, orc.update(d.copy(), img), t)
+        rows += len(got)
+    assert rows >= 128 + 50 * 24
+    _check_state(trk, orc)
+    trk.close()
+
+
+def test_bytetrack_surface():
+    from boxmot_amd import ByteTrack, create_tracker
+    from boxmot_amd.track_results import TrackResults
+    with pytest.raises(NotImplementedError):
+        ByteTrack(per_class=True)
+    with pytest.raises(TypeError):
+        ByteTrack(with_reid=True)
+    trk = create_tracker("bytetrack", max_tracks=64, max_dets=32)                  # bytetrack.yaml: track_thresh 0.6, match 0.9
+    assert trk.track_thresh == 0.6 and trk.max_time_lost == 30
+    img = np.zeros((240, 320, 3), dtype=np.uint8)
+    out = trk.update(np.empty((0, 6), dtype=np.float32), img)
+    assert isinstance(out, TrackResults) and len(out) == 0
+    d = np.array([[10, 10, 60, 110, 0.9, 0], [100, 50, 150, 160, 0.5, 1]], dtype=np.float32)
+    out = trk.update(d, img)          # frame 2: a new track is not yet activated -> no rows; frame-1 rule tested via reset
+    assert len(out) == 0
+    trk.reset()
+    out = trk.update(d, img)
+    assert out.shape == (1, 8) and out[0, 4] == 1 and out[0, 7] == 0               # first frame activates immediately; 0.5 < track_thresh
+    with pytest.raises(AssertionError):
+        trk.update(np.zeros((2, 5), dtype=np.float32), img)
+    trk.close()

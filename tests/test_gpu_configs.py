@@ -1,0 +1,51 @@
+"""Parity at the sizes of BASELINE.json's other configurations (parity-test cases, not bench lines):
+config 3 = DeepOCSORT, 128 dets x 512 tracks, 512-d embeddings (OSNet-x1.0 width);
+config 5 = StrongSORT, 256 dets x 1024 tracks, 1280-d embeddings (CLIP-ReID width).
+Embeddings are supplied (the ReID backbones of those configs are covered by tests/test_gpu_reid.py for OSNet widths;
+CLIP-ReID is out of scope).  Scenario of SURVEY.md section 8(d): three confirmation frames with every object, then the
+mixed persistent / rotating schedule."""
+import numpy as np
+import pytest
+
+from common import assert_rows_match
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config3_deepocsort_128_dets_512_tracks():
+    from boxmot_amd import DeepOcSort
+    from boxmot_amd.scenario import Scenario
+    from oracle.deepocsort import DeepOcSortOracle
+    sc = Scenario(128, 512, emb_dim=512, random_image=False)
+    img = np.zeros((1080, 1920, 3), dtype=np.uint8)
+    trk = DeepOcSort(cmc_off=True, emb_dim=512, max_tracks=1024, max_dets=512)
+    orc = DeepOcSortOracle(lap_rule="lowest_index")
+    rows = 0
+    for t in range(9):
+        d, e = sc.frame(t)
+        got = np.asarray(trk.update(d, img, e)).reshape(-1, 8)
+        assert_rows_match(got, np.asarray(orc.update(d, img, e.copy()), dtype=np.float32).reshape(-1, 8), t, box_atol=1e-3)
+        rows += len(got)
+    assert rows >= 512 + 5 * 96                       # every object confirmed, then the persistent ones every frame
+    st, od = trk.state_dump(), orc.dump()
+    assert np.array_equal(st["ints"][:, 0], od["id"])
+    assert np.allclose(st["kf"][:, :7], od["x"], rtol=1e-9, atol=1e-9)
+    trk.close()
+
+
+def test_config5_strongsort_256_dets_1024_tracks_1280d():
+    from boxmot_amd import StrongSort
+    from boxmot_amd.scenario import Scenario
+    from oracle.strongsort import StrongSortOracle
+    sc = Scenario(256, 1024, emb_dim=1280, random_image=False)
+    img = np.zeros((2160, 3840, 3), dtype=np.uint8)
+    trk = StrongSort(emb_dim=1280, max_tracks=2048, max_dets=1024)
+    orc = StrongSortOracle()
+    rows = 0
+    for t in range(6):
+        d, e = sc.frame(t)
+        got = np.asarray(trk.update(d, img, e)).reshape(-1, 8)
+        assert_rows_match(got, np.asarray(orc.update(d, img, e.copy()), dtype=np.float32).reshape(-1, 8), t, box_atol=1e-3)
+        rows += len(got)
+    assert rows >= 1024 + 3 * 192
+    trk.close()

@@ -1,6 +1,6 @@
 """The reference's own detection fixture (assets/MOT17-mini/train/*/det/det.txt: public FRCNN detections with real
 confidences, so the low-confidence second association, the confidence filters and crowded frames are all exercised)
-replayed through the reference BotSort (with / without appearance), DeepOcSort, StrongSort and OcSort by tests/golden/make_golden.py, frozen in
+replayed through the reference BotSort (with / without appearance), ByteTrack, DeepOcSort, StrongSort and OcSort by tests/golden/make_golden.py, frozen in
 tests/golden/mot17_golden.npz.  CPU: the oracles reproduce the reference rows bit for bit.  GPU: the HIP trackers,
 driven through boxmot_amd.replay like the reference's process_sequence drives a tracker, reproduce them too."""
 from pathlib import Path
@@ -12,7 +12,7 @@ from common import BOTSORT_YAML_DEFAULTS, mot17_embeddings
 
 GOLD = Path(__file__).resolve().parent / "golden" / "mot17_golden.npz"
 SEQS = ("MOT17-02-FRCNN", "MOT17-04-FRCNN")
-KINDS = ("botsort", "botsort_noreid", "deepocsort", "strongsort", "ocsort", "ocsort_yaml")
+KINDS = ("botsort", "botsort_noreid", "deepocsort", "strongsort", "ocsort", "ocsort_yaml", "bytetrack")
 YAML = {k: v for k, v in BOTSORT_YAML_DEFAULTS.items() if k not in ("use_cmc", "cmc_method", "with_reid")}
 
 
@@ -39,6 +39,9 @@ def _oracle(kind, **kw):
     from oracle.botsort import BotSortOracle
     from oracle.deepocsort import DeepOcSortOracle, OcSortOracle
     from oracle.strongsort import StrongSortOracle
+    if kind == "bytetrack":
+        from oracle.bytetrack import ByteTrackOracle
+        return ByteTrackOracle()
     if kind == "ocsort":
         return OcSortOracle(**kw)
     if kind == "ocsort_yaml":
@@ -99,7 +102,7 @@ def test_hip_replay_reproduces_reference_on_mot17_detections(kind):
         assert np.abs(out[:, 2:6] - ref[:, 2:6]).max() <= 1 and np.allclose(out[:, 6], ref[:, 6])
 
 
-@pytest.mark.parametrize("kind", ["botsort", "deepocsort", "strongsort"])
+@pytest.mark.parametrize("kind", ["botsort", "deepocsort", "strongsort", "bytetrack"])
 def test_device_kernels_emulated_reproduce_reference_on_mot17_detections(kind):
     """The same device sources on CPU threads (tests/host_emu), first sequence: rows equal to the REFERENCE's."""
     import oracle.deepocsort as od
@@ -110,6 +113,9 @@ def test_device_kernels_emulated_reproduce_reference_on_mot17_detections(kind):
     seq = SEQS[0]
     if kind == "botsort":
         emu = EmuBotSort({**BOTSORT_DEFAULTS, **YAML}, cap=256, nd=64, dim=16)
+    elif kind == "bytetrack":
+        from common import bytetrack_device_config
+        emu = EmuBotSort(bytetrack_device_config(), cap=256, nd=64, dim=1)
     elif kind == "deepocsort":
         emu = EmuDeepOcSort(dict(od.DEFAULTS), cap=256, nd=64, dim=16)
     else:

@@ -68,6 +68,25 @@ def test_ocsort_oracle_bit_exact_incl_kalman_state():
             assert np.array_equal(k.kf.x[:, 0], x) and np.array_equal(k.kf.P, P)
 
 
+def test_bytetrack_oracle_bit_exact_incl_kalman_state():
+    from boxmot_amd.scenario import stress_frames
+    from oracle.bytetrack import ByteTrackOracle
+
+    logging.disable(logging.CRITICAL)
+    img = np.zeros((480, 640, 3), np.uint8)
+    for kw in ({}, dict(track_thresh=0.6, match_thresh=0.7, track_buffer=5), dict(min_conf=0.3, track_buffer=40, frame_rate=25)):
+        ref, orc = ref_harness.load_bytetrack()(**kw), ByteTrackOracle(**kw)
+        for t, (d, e) in enumerate(stress_frames(150, seed=7)):
+            r = np.asarray(ref.update(d.copy(), img)).reshape(-1, 8)
+            o = orc.update(d.copy(), img)
+            assert r.shape == o.shape and np.array_equal(r, o), (kw, t)
+        od = orc.dump()
+        for recs, key in ((ref.active_tracks, "active"), (ref.lost_stracks, "lost")):
+            assert [k.id for k in recs] == list(od[key]["id"])
+            for k, m, P in zip(recs, od[key]["mean"], od[key]["cov"]):
+                assert np.array_equal(k.mean, m) and np.array_equal(k.covariance, P)
+
+
 def test_deepocsort_per_class_oracle_matches_reference():
     from boxmot_amd.scenario import stress_frames
     from oracle.deepocsort import PerClassDeepOcSortOracle
