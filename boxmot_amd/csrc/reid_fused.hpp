@@ -385,6 +385,34 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
     // ---- conv3 (1x1 MID -> COUT, linear) + downsample(x) or identity, ReLU (osnet.py:254-260) ----
     // stage 0 keeps the epilogue's operands in the registers the branch loop has released (16 tiles re-use them);
     // the wider stages have too many fragments for that and re-read them per tile from L1
+    // Epilogue operands that do not fit in registers are staged ONCE per workgroup into LDS (the image is dead after the
+    // last layer): 16 waves re-reading 10-30 KB of fragments per tile pair from the vector L1 (64 B/clk) was a sizeable
+    // share of the block time; LDS delivers 128 B/clk and leaves the L1 to the activations.
+    //   [0, EPI_A)      this block's conv3 fragments, bias, downsample fragments (contiguous in the packed blob)
+    //   [EPI_A, +EPI_T) fused transition: fragments + bias        [.., +EPI_P) RECON: previous block's conv3/bias/down
+    constexpr bool EPI = STAGE <= 1;
+    constexpr int KS3E = COUT / 32;
+    constexpr int EPI_T = TRANS ? NCT * KS3E * 1024 + COUT * 4 : 0;
+    const int epi_a = (EPI && STAGE == 1) ? (int)(bp.total - bp.conv3_a) : 0;
+    const unsigned char* ew = wts + bp.conv3_a;          // conv3_a-relative base of this block's epilogue operands
+    const unsigned char* etr = wtr;
+    const unsigned char* epv = RECON ? link.w + link.a0 : nullptr;      // a0-relative base of the previous block's operands
+    if constexpr (EPI) {
+        auto stage_in = [&](const unsigned char* src, int bytes, int off) {
+            for (int e = tid * 16; e < bytes; e += 64 * G::NWAVES * 16)
+                *reinterpret_cast<f4*>(tbuf + off + e) = *reinterpret_cast<const f4*>(src + e);
+        };
+        if (epi_a) { stage_in(ew, epi_a, 0); ew = tbuf; }
+        if constexpr (TRANS) { stage_in(wtr, EPI_T, epi_a); etr = tbuf + epi_a; }
+        if constexpr (RECON) {
+            const int bytes = (int)(link.a2 - link.a0) + NCT * 512;      // conv3_a .. end of down_a (K=16 fragments)
+            stage_in(epv, bytes, epi_a + EPI_T);
+            epv = tbuf + epi_a + EPI_T;
+        }
+        __syncthreads();
+    }
+    const long o3a = 0, o3b = bp.conv3_b - bp.conv3_a, oda = bp.down_a - bp.conv3_a;      // offsets from `ew`
+    const long p3b = link.a1 - link.a0, pda = link.a2 - link.a0;                            // offsets from `epv`
     h4 eye;                 // A fragment of the 16x16 identity: row l16, k-slots 4g..4g+3
 #pragma unroll
     for (int j = 0; j < 4; ++j) eye[j] = (_Float16)(l16 == 4 * g + j ? 1.f : 0.f);
@@ -394,9 +422,9 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
     if constexpr (W3REG) {
 #pragma unroll
         for (int co = 0; co < NCT; ++co) {
-            w3r[co] = *reinterpret_cast<const h4*>(wts + bp.conv3_a + (co * 64 + lane) * 8);
-            b3r[co] = *reinterpret_cast<const f4*>(wts + bp.conv3_b + (16 * co + 4 * g) * 4);
-            if constexpr (DOWN && CIN == 16) wdr[co] = *reinterpret_cast<const h4*>(wts + bp.down_a + (co * 64 + lane) * 8);
+            w3r[co] = *reinterpret_cast<const h4*>(ew + o3a + (co * 64 + lane) * 8);
+            b3r[co] = *reinterpret_cast<const f4*>(ew + o3b + (16 * co + 4 * g) * 4);
+            if constexpr (DOWN && CIN == 16) wdr[co] = *reinterpret_cast<const h4*>(ew + oda + (co * 64 + lane) * 8);
         }
     }
     auto conv3_tile = [&](int i, h4 (&y)[NCT]) {
@@ -420,23 +448,23 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
         for (int co = 0; co < NCT; ++co) {
             f4 acc;
             if constexpr (W3REG) acc = b3r[co];
-            else acc = *reinterpret_cast<const f4*>(wts + bp.conv3_b + (16 * co + 4 * g) * 4);
+            else acc = *reinterpret_cast<const f4*>(ew + o3b + (16 * co + 4 * g) * 4);
             if constexpr (W3REG) {
                 acc = BM_MFMA_F16_K16(w3r[co], x2[i][0], acc);
             } else if constexpr (KT == 1) {
-                acc = BM_MFMA_F16_K16(*reinterpret_cast<const h4*>(wts + bp.conv3_a + (co * 64 + lane) * 8), x2[i][0], acc);
+                acc = BM_MFMA_F16_K16(*reinterpret_cast<const h4*>(ew + o3a + (co * 64 + lane) * 8), x2[i][0], acc);
             } else {
-                acc = BM_MFMA_F16_K32(*reinterpret_cast<const h8*>(wts + bp.conv3_a + (co * 64 + lane) * 16), cat8(x2[i][0], x2[i][1]), acc);
+                acc = BM_MFMA_F16_K32(*reinterpret_cast<const h8*>(ew + o3a + (co * 64 + lane) * 16), cat8(x2[i][0], x2[i][1]), acc);
             }
             if constexpr (DOWN) {
                 if constexpr (CIN == 16 && W3REG) {
                     acc = BM_MFMA_F16_K16(wdr[co], bx4, acc);
                 } else if constexpr (CIN == 16) {
-                    acc = BM_MFMA_F16_K16(*reinterpret_cast<const h4*>(wts + bp.down_a + (co * 64 + lane) * 8), bx4, acc);
+                    acc = BM_MFMA_F16_K16(*reinterpret_cast<const h4*>(ew + oda + (co * 64 + lane) * 8), bx4, acc);
                 } else {
 #pragma unroll
                     for (int ks = 0; ks < KIN; ++ks)
-                        acc = BM_MFMA_F16_K32(*reinterpret_cast<const h8*>(wts + bp.down_a + ((co * KIN + ks) * 64 + lane) * 16), bx[ks], acc);
+                        acc = BM_MFMA_F16_K32(*reinterpret_cast<const h8*>(ew + oda + ((co * KIN + ks) * 64 + lane) * 16), bx[ks], acc);
                 }
             } else {
                 // identity shortcut: the 4 input channels this lane holds are a K=16 B fragment, so adding them is one
@@ -445,9 +473,9 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
                 // on one accumulator returns wrong sums on gfx950 / ROCm 7.2 (tools/mfma_chain_test.hip)
                 h4 idn;
                 if constexpr (RECON) {      // block input = ReLU(conv3_prev . x2_prev + down_prev . x_prev + bias), as EMIT computed it
-                    f4 ap = *reinterpret_cast<const f4*>(link.w + link.a1 + (16 * co + 4 * g) * 4);
-                    ap = BM_MFMA_F16_K16(*reinterpret_cast<const h4*>(link.w + link.a0 + (co * 64 + lane) * 8), x2p, ap);
-                    ap = BM_MFMA_F16_K16(*reinterpret_cast<const h4*>(link.w + link.a2 + (co * 64 + lane) * 8), xp, ap);
+                    f4 ap = *reinterpret_cast<const f4*>(epv + p3b + (16 * co + 4 * g) * 4);
+                    ap = BM_MFMA_F16_K16(*reinterpret_cast<const h4*>(epv + (co * 64 + lane) * 8), x2p, ap);
+                    ap = BM_MFMA_F16_K16(*reinterpret_cast<const h4*>(epv + pda + (co * 64 + lane) * 8), xp, ap);
                     idn = relu_h4(to_h4(ap));
                 } else {
                     idn = *reinterpret_cast<const h4*>(xin + (unsigned)(p * CIN + g * (CIN / 4) + 4 * co));
@@ -496,7 +524,7 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
         // (vertical = the two tiles, horizontal = lane ^ 1), even lanes store the pooled pixel.
         static_assert(!TRANS || (STAGE < 2 && COUT % 32 == 0), "fused transition: stages 0 and 1");
         constexpr int KS3 = COUT / 32, WP = G::W / 2;
-        const unsigned char* tbias = wtr + NCT * KS3 * 1024;
+        const unsigned char* tbias = etr + NCT * KS3 * 1024;
 #pragma unroll
         for (int pr = 0; pr < NT / 2; ++pr) {
             const int i0 = STAGE == 0 ? (pr >> 1) * 4 + (pr & 1) : 2 * pr;
@@ -512,7 +540,7 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
                 f4 a0 = bv, a1 = bv;
 #pragma unroll
                 for (int ks = 0; ks < KS3; ++ks) {
-                    const h8 a = *reinterpret_cast<const h8*>(wtr + ((ct * KS3 + ks) * 64 + lane) * 16);
+                    const h8 a = *reinterpret_cast<const h8*>(etr + ((ct * KS3 + ks) * 64 + lane) * 16);
                     a0 = BM_MFMA_F16_K32(a, cat8(y0[2 * ks], y0[2 * ks + 1]), a0);
                     a1 = BM_MFMA_F16_K32(a, cat8(y1[2 * ks], y1[2 * ks + 1]), a1);
                 }
