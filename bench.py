@@ -35,8 +35,8 @@ sys.path.insert(0, str(ROOT))
 
 N_DETS, N_TRACKS, WIDTH, HEIGHT, EMB_DIM = 64, 256, 1920, 1080, 512
 FLOP_PER_CROP = 2 * 82_314_880          # OSNet x0.25 forward, BASELINE.md section 2
-# HBM bytes per crop of the ReID launch set, from rocprofv3 FETCH_SIZE/WRITE_SIZE passes (profiles/r1f_pmc_traffic.txt: 1719 KiB)
-TRAFFIC_BYTES_PER_CROP = {0: None, 1: 1.76e6}
+# HBM bytes per crop of the ReID launch set, from rocprofv3 FETCH_SIZE/WRITE_SIZE passes (profiles/r1g_pmc_traffic.txt: 1614 KiB)
+TRAFFIC_BYTES_PER_CROP = {0: None, 1: 1.65e6}
 PEAK_TFLOPS = {0: 157.3, 1: 2500.0}     # dense MFMA peak of the dtype the ReID kernels compute in (fp32 / fp16)
 DTYPE = {0: "f32", 1: "f16"}
 
@@ -49,7 +49,7 @@ def parse():
                          "the other's ReID kernels)")
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--streams", type=int, default=128, help="streams per GPU")
+    ap.add_argument("--streams", type=int, default=256, help="streams per GPU")
     ap.add_argument("--mode", choices=("reid", "embs"), default="reid",
                     help="reid: ReID inside update (headline, M2); embs: embeddings supplied (tracker math only, M1)")
     ap.add_argument("--reid-mode", type=int, default=int(os.environ.get("BOXMOT_REID_MODE", "1")),

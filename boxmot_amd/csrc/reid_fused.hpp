@@ -210,10 +210,12 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
     for (int br = 0; br < 4; ++br) {
         h4 cur[NT][KT];
         if constexpr (RECON) {
+            unsigned xo = 0;            // opaque zero: form the 16 addresses here, per branch, instead of keeping (and
+            BM_OPAQUE_U32(xo);          // spilling) 16 loop-invariant 64-bit pointers across the branch loop
 #pragma unroll
             for (int i = 0; i < NT; ++i)
 #pragma unroll
-                for (int ct = 0; ct < KT; ++ct) cur[i][ct] = *reinterpret_cast<const h4*>(x1w + (i * KT + ct) * 256);
+                for (int ct = 0; ct < KT; ++ct) cur[i][ct] = *reinterpret_cast<const h4*>(x1w + (xo + (unsigned)((i * KT + ct) * 256)));
         } else if constexpr (STASH) {
             if (br == 0) {
                 conv1_into(cur);
