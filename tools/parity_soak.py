@@ -1,5 +1,5 @@
 """Long parity soak (development tool): many seeds x long stress sequences, HIP trackers vs oracles, ids/rows exact.
-    python tools/parity_soak.py [n_seeds] [n_frames]"""
+    python tools/parity_soak.py [n_seeds] [n_frames] [tracker,tracker,...]"""
 import sys
 import time
 from pathlib import Path
@@ -13,11 +13,14 @@ sys.path[:0] = [str(ROOT), str(ROOT / "tests")]
 def main():
     n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 6
     n_frames = int(sys.argv[2]) if len(sys.argv) > 2 else 300
-    from boxmot_amd import BotSort, DeepOcSort, StrongSort
+    only = set(sys.argv[3].split(",")) if len(sys.argv) > 3 else None
+    from boxmot_amd import BotSort, ByteTrack, DeepOcSort, OcSort, StrongSort
     from boxmot_amd.scenario import camera_warps, stress_frames
     from oracle.botsort import BotSortOracle
     from oracle.deepocsort import DeepOcSortOracle
     from oracle.strongsort import StrongSortOracle
+    from oracle.bytetrack import ByteTrackOracle
+    from oracle.deepocsort import OcSortOracle
 
     class Sched:
         def __init__(self, w):
@@ -39,13 +42,19 @@ def main():
             ("deepocsort", lambda c: DeepOcSort(cmc_off=not use_w, cmc=c, emb_dim=32, max_tracks=1024, max_dets=64),
              lambda: DeepOcSortOracle(lap_rule="lowest_index")),
             ("strongsort", lambda c: StrongSort(cmc=c if use_w else None, emb_dim=32, max_tracks=1024, max_dets=64), lambda: StrongSortOracle()),
+            ("bytetrack", lambda c: ByteTrack(max_tracks=1024, max_dets=64), lambda: ByteTrackOracle()),
+            ("ocsort", lambda c: OcSort(max_tracks=1024, max_dets=64), lambda: OcSortOracle(lap_rule="lowest_index")),
         ]
+        if only:
+            cases = [c for c in cases if c[0] in only]
         for name, mk, mko in cases:
-            trk, orc = mk(Sched(warps) if use_w else None), mko()
+            warped = use_w and name not in ("bytetrack", "ocsort")          # no camera-motion input in those two
+            trk, orc = mk(Sched(warps) if warped else None), mko()
             ok = True
             for t, (d, e) in enumerate(frames):
                 got = np.asarray(trk.update(d, img, e)).reshape(-1, 8)
-                want = np.asarray(orc.update(d, img, e.copy(), warp=warps[t] if use_w else None)).reshape(-1, 8)
+                want = (np.asarray(orc.update(d, img, e.copy(), warp=warps[t] if use_w else None)) if name not in ("bytetrack", "ocsort")
+                        else np.asarray(orc.update(d, img))).reshape(-1, 8)
                 if got.shape != want.shape or not np.array_equal(got[:, 4:], want[:, 4:]) or not np.allclose(got[:, :4], want[:, :4], atol=1e-3):
                     # same boxes under a permutation of ids = an assignment tie resolved the other way (StrongSORT: the
                     # clamped costs tie exactly and the reference's fp32 BLAS rounding of the other entries decides)
