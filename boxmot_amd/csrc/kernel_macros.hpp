@@ -40,6 +40,11 @@
 // value of the horizontally adjacent lane (lane ^ 1) as a DPP quad permute [1,0,3,2]
 #define BM_QUAD_SWAP1_F32(v) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (float)(v)), 0xB1, 0xf, 0xf, true))
 #endif
+#ifndef BM_UNIFORM_I32
+// a value that is the same in every lane of the wavefront (e.g. the wave index), moved to a scalar register so that
+// everything derived from it (ring-buffer modulo, row offsets, base pointers) is computed once on the scalar unit
+#define BM_UNIFORM_I32(x) __builtin_amdgcn_readfirstlane((int)(x))
+#endif
 #ifndef BM_CLOCK
 #define BM_CLOCK() wall_clock64()
 #endif

@@ -743,7 +743,7 @@ __global__ void __launch_bounds__(512) k_stem_resize_fused(const uint8_t* const*
     unsigned char* stage = lds + RING_ROWS * RING_ROW_BYTES;
     _Float16* lut_h = reinterpret_cast<_Float16*>(stage + SRC_STAGE_BYTES);
     unsigned* ytab = reinterpret_cast<unsigned*>(stage + SRC_STAGE_BYTES + 768 * 2);   // [256]{s0 | s1 << 16, a0 | a1 << 16}
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l16 = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, wave = BM_UNIFORM_I32(tid >> 6), g = lane >> 4, l16 = lane & 15;
     const long crop = blockIdx.x;
     const uint8_t* frame = frames[crop_stream[crop]];
     const CropRect r = crop_rect(boxes + crop * box_stride, W, H);
