@@ -125,6 +125,8 @@ def test_device_kernels_emulated_reproduce_reference_on_mot17_detections(kind):
         for fid, d, e in _frames(g, seq):
             if not len(d):
                 continue
+            if fid > 120:                # the emulation runs one OS thread per GPU thread; the GPU test covers all 200 frames
+                break
             got = np.asarray(emu.update(d, e)).reshape(-1, 8)
             assert got.shape == want[fid].shape and np.array_equal(got[:, 4:], want[fid][:, 4:]), (kind, fid)
             assert np.allclose(got[:, :4], want[fid][:, :4], rtol=0, atol=1e-3), (kind, fid)

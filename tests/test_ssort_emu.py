@@ -45,7 +45,7 @@ def _run(frames, dim, cap, nd, warps=None, sanitize=False, **kw):
 @pytest.mark.parametrize("kw,seed", [({}, 7), (dict(max_age=5, n_init=1, nn_budget=3), 11),
                                      (dict(max_cos_dist=0.4, max_iou_dist=0.9, mc_lambda=0.9, ema_alpha=0.8, min_conf=0.3), 3)])
 def test_emulated_strongsort_matches_oracle_stress(kw, seed):
-    _run(stress_frames(60, seed=seed), 32, 128, 64, **kw)
+    _run(stress_frames(45, seed=seed), 32, 128, 64, **kw)
 
 
 def test_emulated_strongsort_camera_update_and_set_order():
