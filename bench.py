@@ -35,7 +35,7 @@ sys.path.insert(0, str(ROOT))
 
 N_DETS, N_TRACKS, WIDTH, HEIGHT, EMB_DIM = 64, 256, 1920, 1080, 512
 FLOP_PER_CROP = 2 * 82_314_880          # OSNet x0.25 forward, BASELINE.md section 2
-# HBM bytes per crop of the ReID launch set, from rocprofv3 FETCH_SIZE/WRITE_SIZE passes (profiles/r1g_pmc_traffic.txt: 1614 KiB)
+# HBM bytes per crop of the ReID launch set, from rocprofv3 FETCH_SIZE/WRITE_SIZE passes (profiles/r1h_pmc_traffic.txt: 1614 KiB)
 TRAFFIC_BYTES_PER_CROP = {0: None, 1: 1.65e6}
 PEAK_TFLOPS = {0: 157.3, 1: 2500.0}     # dense MFMA peak of the dtype the ReID kernels compute in (fp32 / fp16)
 DTYPE = {0: "f32", 1: "f16"}
