@@ -111,6 +111,8 @@ template <int STAGE, int CIN, bool DOWN, bool TRANS, bool EMIT = false, bool REC
 __global__ void __launch_bounds__(64 * Geo<STAGE>::NWAVES, Geo<STAGE>::WG_PER_CU_WAVES)
 k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const unsigned char* __restrict__ wts, BlkPack bp,
           const int* __restrict__ count, _Float16* __restrict__ x1s, const unsigned char* __restrict__ wtr, BlkLink link) {
+    static_assert(!(Geo<STAGE>::KT == 1 && DOWN && CIN != 16),
+                  "conv3 (K=16 MFMA) and a K=32 downsample would share an accumulator: mixed-shape chains are wrong on gfx950");
     static_assert(!EMIT || (STAGE == 0 && CIN == 16 && DOWN && !TRANS), "EMIT: first block of stage 0");
     static_assert(!RECON || (STAGE == 0 && CIN == 64 && !DOWN && TRANS), "RECON: second block of stage 0");
     using G = Geo<STAGE>;
