@@ -113,3 +113,34 @@ def test_update_time_with_embeddings_supplied(kind, reid):       # test_tracking
     per_iter = (time.perf_counter() - t0) / 100
     assert per_iter < 0.005, f"{kind}: {per_iter * 1e3:.2f} ms per update"
     trk.close()
+
+
+@pytest.mark.parametrize("kind", ["botsort", "bytetrack", "deepocsort", "ocsort", "strongsort"])
+def test_capacity_limits_fail_loudly(kind):
+    """Maximum sizes: one detection more than max_dets, or more simultaneous tracks than max_tracks, is an error with a
+    message -- never a silent truncation (the reference has no such limits; the device tables are sized at construction)."""
+    from boxmot_amd import BotSort, ByteTrack, DeepOcSort, OcSort, StrongSort
+    mk = {"botsort": lambda **kw: BotSort(use_cmc=False, with_reid=False, **kw), "bytetrack": ByteTrack,
+          "deepocsort": lambda **kw: DeepOcSort(cmc_off=True, embedding_off=True, **kw), "ocsort": OcSort,
+          "strongsort": lambda **kw: StrongSort(emb_dim=8, **kw)}[kind]
+    img = np.zeros((480, 640, 3), dtype=np.uint8)
+    rng = np.random.default_rng(0)
+
+    def dets(n, x0=0.0):
+        x = x0 + 40.0 * (np.arange(n) % 14)
+        y = 60.0 * (np.arange(n) // 14)
+        return np.stack([x, y, x + 30, y + 50, np.full(n, 0.9), np.zeros(n)], 1).astype(np.float32)
+
+    trk = mk(max_tracks=64, max_dets=16)
+    embs = lambda n: rng.standard_normal((n, 8)).astype(np.float32)
+    assert len(trk.update(dets(16), img, embs(16))) >= 0                 # exactly max_dets is fine
+    with pytest.raises(RuntimeError, match="max_dets"):
+        trk.update(dets(17), img, embs(17))
+    trk.close()
+    trk = mk(max_tracks=16, max_dets=16)
+    for t in range(3):                                                    # 16 tracks, confirmed by every tracker's rule
+        trk.update(dets(16), img, embs(16))
+    with pytest.raises(RuntimeError, match="capacity"):
+        for t in range(1, 5):                                             # 16 new objects elsewhere per frame: no free slot
+            trk.update(dets(16) + np.array([3.0, 700.0 * t, 3.0, 700.0 * t, 0, 0], np.float32), img, embs(16))
+    trk.close()
