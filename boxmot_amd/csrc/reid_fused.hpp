@@ -124,6 +124,7 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
     unsigned char* tbuf = lds;
     float* gap_part = reinterpret_cast<float*>(lds + G::TBUF);      // [4 branches][NWAVES][HID]
 
+    // (a scalar wave index, as in the stem, was measured here and is 5-15 % slower: more scalar traffic, no VALU saved)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l16 = lane & 15;
     const long crop = blockIdx.x;
     const _Float16* xin = in + crop * P * (RECON ? 16 : CIN);      // RECON: the previous block's 16-channel input
@@ -578,6 +579,7 @@ __global__ void __launch_bounds__(128) k_head_fused(const _Float16* __restrict__
     __shared__ float s_gap[2][C];
     __shared__ float s_v[C];
     __shared__ float s_red[2];
+    // (a scalar wave index, as in the stem, was measured here and is 5-15 % slower: more scalar traffic, no VALU saved)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l16 = lane & 15;
     const long crop = blockIdx.x;
     const _Float16* xin = in + crop * P * C;
