@@ -74,6 +74,8 @@ class DeepOcSortConfig(ctypes.Structure):
         ("max_tracks", ctypes.c_int),
         ("max_dets", ctypes.c_int),
         ("emb_dim", ctypes.c_int),
+        ("use_byte", ctypes.c_int),
+        ("min_conf", ctypes.c_double),
     ]
 
 

@@ -650,6 +650,8 @@ void docs_build(BoxMOTHipDeepOcSort* h) {
     d.delta_t = c.delta_t; d.iou_threshold = c.iou_threshold; d.inertia = c.inertia; d.w_emb = c.w_association_emb;
     d.alpha_fixed = c.alpha_fixed_emb; d.aw_param = c.aw_param; d.q_xy = c.Q_xy_scaling; d.q_s = c.Q_s_scaling;
     d.embedding_off = c.embedding_off; d.aw_off = c.aw_off;
+    if (c.use_byte && !c.embedding_off) throw std::runtime_error("boxmot_hip: use_byte is OC-SORT's option and needs embedding_off = 1");
+    d.use_byte = c.use_byte ? 1 : 0; d.min_conf_f32 = (float)c.min_conf;
     DevAlloc dev_allocator{&h->owned};
     bm::DocsSizes z{h->S, h->cap, h->nd, h->dim};
     bm::docs_allocate(h->args, z, dev_allocator);
@@ -1106,6 +1108,7 @@ void boxmot_hip_deepocsort_default_config(BoxMOTHipDeepOcSortConfig* c) {
     c->embedding_off = 0; c->cmc_off = 0; c->aw_off = 0; c->Q_xy_scaling = 0.01; c->Q_s_scaling = 0.0001;
     c->reid_model_path = nullptr;
     c->n_streams = 1; c->max_tracks = 1024; c->max_dets = 256; c->emb_dim = 512;
+    c->use_byte = 0; c->min_conf = 0.1;
 }
 
 BoxMOTHipDeepOcSort* boxmot_hip_deepocsort_create(const BoxMOTHipDeepOcSortConfig* config) {

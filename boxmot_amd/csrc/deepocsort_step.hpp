@@ -30,6 +30,10 @@ struct DocsConfigDev {
     int max_age, min_hits, delta_t;
     double iou_threshold, inertia, w_emb, alpha_fixed, aw_param, q_xy, q_s;
     int embedding_off, aw_off;
+    // OC-SORT's BYTE branch (ocsort.py:393-399, 456-485): detections with min_conf < score < det_thresh are associated,
+    // after the first round, with the predicted boxes of the still unmatched tracks
+    int use_byte;
+    float min_conf_f32;
 };
 
 struct DocsState {
@@ -552,6 +556,12 @@ __device__ inline void docs_step_stream(const DocsStepArgs& args, int s, int* s_
 
     // ---- detections above det_thresh, in order (deepocsort.py:331-335); trust -> dets_alpha (:353-356) ----
     const int nk = block_append_if(c, v.n_dets, [&](int j) { return v.dets[j * DET_COLS + 4] > cfg.det_thresh_f32; }, ident, v.keep, 0);
+    // BYTE candidates are appended behind the kept detections: keep[nk .. nk + n_byte)
+    int n_byte = 0;
+    if (cfg.use_byte)
+        n_byte = block_append_if(c, v.n_dets, [&](int j) {
+            const float s = v.dets[j * DET_COLS + 4];
+            return s > cfg.min_conf_f32 && s < cfg.det_thresh_f32; }, ident, v.keep, nk) - nk;
     for (int k = c.tid; k < nk; k += c.nthr) {
         const double conf = (double)v.dets[v.keep[k] * DET_COLS + 4];
         const double trust = (conf - cfg.det_thresh) / (1 - cfg.det_thresh);
@@ -777,6 +787,51 @@ __device__ inline void docs_step_stream(const DocsStepArgs& args, int s, int* s_
             if (q < n_match) docs_apply_match(v, v.list[v.m_trk[q]], v.m_det[q], c.lane);
         }
         __syncthreads();
+    }
+
+    // ---- OC-SORT only: BYTE association of the low-score detections with the predicted boxes of the unmatched tracks
+    //      (ocsort.py:456-485); matched tracks take the detection, the rest stay unmatched (np.setdiff1d: ascending) ----
+    if (cfg.use_byte && n_byte > 0 && n_ut > 0) {
+        const long total = (long)n_byte * n_ut;
+        double mxi = -DOCS_INF;
+        for (long e = c.tid; e < total; e += c.nthr) {
+            const int a = (int)(e / n_ut), b = (int)(e % n_ut);
+            const float* df = v.dets + v.keep[nk + a] * DET_COLS;
+            const double db[4] = {(double)df[0], (double)df[1], (double)df[2], (double)df[3]};
+            const double io = iou_pair(db, v.trk_box + v.un_t[b] * 4);
+            v.iou[a * ld + b] = io;
+            v.cost[a * ld + b] = -io;
+            mxi = io > mxi ? io : mxi;
+        }
+        {
+            for (int off = WAVE / 2; off > 0; off >>= 1) { const double o = __shfl_xor(mxi, off, WAVE); mxi = o > mxi ? o : mxi; }
+            if (c.lane == 0) c.s_dbl[c.wave] = mxi;
+            __syncthreads();
+            double g = -DOCS_INF;
+            for (int w = 0; w < c.nwaves; ++w) g = c.s_dbl[w] > g ? c.s_dbl[w] : g;
+            __syncthreads();
+            mxi = g;
+        }
+        if (mxi > cfg.iou_threshold) {
+            const double* cm = v.cost;
+            if (!lap_full(c, lap, n_ut, n_byte, [&](int d, int t) { return cm[d * ld + t]; }, v.lap_x, v.lap_y) && c.tid == 0)
+                *v.status = STATUS_LAP_STALL;
+            auto good_b = [&](int a) { return v.lap_y[a] >= 0 && !(v.iou[a * ld + v.lap_y[a]] < cfg.iou_threshold); };
+            const int nb = block_append_if(c, n_byte, good_b, ident, v.tmp_a, 0);
+            for (int q = c.tid; q < nb; q += c.nthr) { const int a = v.tmp_a[q]; v.m_det[q] = nk + a; v.m_trk[q] = v.un_t[v.lap_y[a]]; }
+            __syncthreads();
+            for (int base = 0; base < nb; base += c.nwaves) {
+                const int q = base + c.wave;
+                if (q < nb) docs_apply_match(v, v.list[v.m_trk[q]], v.m_det[q], c.lane);
+            }
+            for (int t = c.tid; t < nt; t += c.nthr) v.flag_t[t] = 0;
+            __syncthreads();
+            for (int b = c.tid; b < n_ut; b += c.nthr) v.flag_t[v.un_t[b]] = 1;
+            __syncthreads();
+            for (int q = c.tid; q < nb; q += c.nthr) v.flag_t[v.m_trk[q]] = 0;
+            __syncthreads();
+            n_ut = block_append_if(c, nt, [&](int t) { return v.flag_t[t] != 0; }, ident, v.un_t, 0);
+        }
     }
 
     // ---- second round: observation-centric recovery against the last observations (deepocsort.py:411-450) ----

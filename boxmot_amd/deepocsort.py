@@ -70,6 +70,7 @@ class DeepOcSort(BaseTracker):
         cfg.alpha_fixed_emb, cfg.aw_param = alpha_fixed_emb, aw_param
         cfg.embedding_off, cfg.cmc_off, cfg.aw_off = int(bool(embedding_off)), int(bool(cmc_off)), int(bool(aw_off))
         cfg.Q_xy_scaling, cfg.Q_s_scaling = Q_xy_scaling, Q_s_scaling
+        cfg.use_byte, cfg.min_conf = (int(self._byte[0]), self._byte[1]) if hasattr(self, "_byte") else (0, 0.1)   # OcSort only
         cfg.n_streams = self.nr_classes if self.per_class else 1
         cfg.max_tracks, cfg.max_dets, cfg.emb_dim = max_tracks, max_dets, self._emb_dim
         self._ids_issued = ctypes.c_int(0)           # KalmanBoxTracker.count - 1, shared by the per-class lists
@@ -154,23 +155,20 @@ class DeepOcSort(BaseTracker):
 class OcSort(DeepOcSort):
     """OC-SORT behind the reference plugin surface (boxmot/trackers/bbox/ocsort/ocsort.py:334-555).
 
-    The reference's ``OcSort`` (``use_byte=False``) and its ``DeepOcSort`` with the appearance and camera-motion terms
-    switched off run the same arithmetic -- same ``KalmanBoxTracker`` / ``KalmanFilterXYSR``, ``associate`` with the
-    velocity-direction term, observation-centric recovery round and re-update, same output rule (ocsort.py:398-555 vs
-    deepocsort.py:302-492); pinned bit-for-bit on the reference classes (tests/golden/mot17_golden.npz,
-    tests/test_oracle_vs_reference.py).  So OC-SORT runs on the DeepOCSORT step kernel with those two terms off.
-    ``use_byte=True`` (a second association over low-confidence detections, ocsort.py:456-485) is not implemented and is
-    rejected loudly; ``min_conf`` only matters for that branch."""
+    The reference's ``OcSort`` and its ``DeepOcSort`` with the appearance and camera-motion terms switched off run the
+    same arithmetic -- same ``KalmanBoxTracker`` / ``KalmanFilterXYSR``, ``associate`` with the velocity-direction term,
+    observation-centric recovery round and re-update, same output rule (ocsort.py:398-555 vs deepocsort.py:302-492);
+    pinned bit-for-bit on the reference classes (tests/golden/mot17_golden.npz, tests/test_oracle_vs_reference.py).  So
+    OC-SORT runs on the DeepOCSORT step kernel with those two terms off, plus its own optional BYTE association of the
+    detections with ``min_conf < score < det_thresh`` (``use_byte=True``, ocsort.py:393-399, 456-485)."""
 
     def __init__(self, min_conf: float = 0.1, delta_t: int = 3, inertia: float = 0.2, use_byte: bool = False,
                  Q_xy_scaling: float = 0.01, Q_s_scaling: float = 0.0001, max_tracks: int = 1024, max_dets: int = 256,
                  **kwargs: Any):
-        if use_byte:
-            raise NotImplementedError("boxmot_amd.OcSort: use_byte=True (BYTE association of low-confidence detections) "
-                                      "is not implemented on the HIP path")
         for k in ("reid_model", "embedding_off", "cmc_off", "cmc", "emb_dim"):
             if k in kwargs:
                 raise TypeError(f"OcSort() got an unexpected keyword argument {k!r}")
+        self._byte = (bool(use_byte), float(min_conf))
         super().__init__(reid_model=None, delta_t=delta_t, inertia=inertia, embedding_off=True, cmc_off=True,
                          Q_xy_scaling=Q_xy_scaling, Q_s_scaling=Q_s_scaling, max_tracks=max_tracks, max_dets=max_dets, **kwargs)
         self.min_conf, self.use_byte = min_conf, use_byte

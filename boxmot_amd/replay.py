@@ -111,10 +111,7 @@ class MultiStreamTracker:
             if "track_thresh" in kw:
                 cfg.track_high_thresh = cfg.new_track_thresh = kw.pop("track_thresh")
         if tracker_type == "ocsort":
-            if kw.pop("use_byte", False):
-                raise NotImplementedError("OC-SORT use_byte=True is not implemented on the HIP backend")
-            kw.pop("min_conf", None)                # only read by the use_byte branch (ocsort.py:456)
-            kw.pop("asso_func", None)
+            kw.pop("asso_func", None)               # use_byte / min_conf are fields of the shared configuration
             cfg.embedding_off, cfg.cmc_off = 1, 1
         if tracker_type == "deepocsort":
             if not kw.pop("cmc_off", True):

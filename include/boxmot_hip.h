@@ -215,6 +215,10 @@ typedef struct BoxMOTHipDeepOcSortConfig {
     int max_tracks;
     int max_dets;
     int emb_dim;
+    /* OC-SORT (trackers/bbox/ocsort/ocsort.py:334-349) = this step with embedding_off = cmc_off = 1, plus its optional BYTE
+     * association of detections with min_conf < score < det_thresh (ocsort.py:393-399, 456-485); use_byte needs embedding_off */
+    int use_byte;
+    double min_conf;
 } BoxMOTHipDeepOcSortConfig;
 
 typedef struct BoxMOTHipDeepOcSort BoxMOTHipDeepOcSort;

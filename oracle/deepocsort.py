@@ -360,6 +360,8 @@ def associate(dets, trks, iou_threshold, velocities, previous_obs, vdc_weight, e
 
 
 class DeepOcSortOracle:
+    use_byte, min_conf = False, 0.1        # OC-SORT's BYTE branch; only OcSortOracle switches it on
+
     def __init__(self, reid=None, lap_rule="jv", **kw):
         """``lap_rule``: which exact solver stands in for ``lap.lapjv`` -- "jv" (oracle/lapjv.c, the default, used for
         the golden fixtures) or "lowest_index" (same optimum, the device solver's choice among tied optima)."""
@@ -391,6 +393,8 @@ class DeepOcSortOracle:
         scores = dets[:, 4]
         dets = np.hstack([dets, np.arange(len(dets)).reshape(-1, 1)])
         keep = scores > c["det_thresh"]
+        # OC-SORT's BYTE branch (ocsort.py:393-399): det_thresh > score > min_conf go to a second association
+        dets_second = dets[np.logical_and(scores > self.min_conf, scores < c["det_thresh"])] if self.use_byte else dets[:0]
         dets = dets[keep]
         if c["embedding_off"] or dets.shape[0] == 0:
             dets_embs = np.ones((dets.shape[0], 1))
@@ -432,6 +436,20 @@ class DeepOcSortOracle:
         for m in matched:
             self.tracks[m[1]].update(dets[m[0], :])
             self.tracks[m[1]].update_emb(dets_embs[m[0]], alpha=dets_alpha[m[0]])
+
+        # OC-SORT only: BYTE association of the low-score detections with the predicted boxes of the unmatched tracks
+        # (ocsort.py:456-485)
+        if self.use_byte and len(dets_second) > 0 and un_t.shape[0] > 0:
+            iou_left = np.array(iou_batch(dets_second, trks[un_t]))
+            if iou_left.max() > c["iou_threshold"]:
+                rem_t = []
+                for m in _assign(-iou_left):
+                    di, ti = m[0], un_t[m[1]]
+                    if iou_left[m[0], m[1]] < c["iou_threshold"]:
+                        continue
+                    self.tracks[ti].update(dets_second[di, :])
+                    rem_t.append(ti)
+                un_t = np.setdiff1d(un_t, np.array(rem_t))
 
         # second round: observation-centric recovery on the last observations (deepocsort.py:411-450)
         if un_d.shape[0] > 0 and un_t.shape[0] > 0:
@@ -507,15 +525,14 @@ class PerClassDeepOcSortOracle:
 
 
 class OcSortOracle(DeepOcSortOracle):
-    """OC-SORT (boxmot/trackers/bbox/ocsort/ocsort.py:334-555, ``use_byte=False``): the reference's ``OcSort`` and its
-    ``DeepOcSort`` with ``embedding_off=True, cmc_off=True`` produce identical rows (pinned on the reference classes:
+    """OC-SORT (boxmot/trackers/bbox/ocsort/ocsort.py:334-555): the reference's ``OcSort`` and its ``DeepOcSort`` with
+    ``embedding_off=True, cmc_off=True`` produce identical rows (pinned on the reference classes:
     tests/test_oracle_vs_reference.py, tests/golden/mot17_golden.npz), so the restatement is the DeepOCSORT one with
-    those terms off.  ``min_conf`` / ``use_byte`` are accepted for signature parity; ``use_byte=True`` is not restated."""
+    those terms off, plus OC-SORT's optional BYTE association (``use_byte=True``, ocsort.py:393-399, 456-485)."""
 
     def __init__(self, min_conf=0.1, use_byte=False, **kw):
-        if use_byte:
-            raise NotImplementedError("OcSortOracle: use_byte=True is not restated")
         super().__init__(embedding_off=True, **kw)
+        self.min_conf, self.use_byte = min_conf, bool(use_byte)
 
     def update(self, dets, img=None, embs=None, warp=None):
         return super().update(dets, img, None)

@@ -77,8 +77,9 @@ class EmuBotSort:
             self.h = None
 
 
-DOCS_D = ("det_thresh", "iou_threshold", "inertia", "w_association_emb", "alpha_fixed_emb", "aw_param", "Q_xy_scaling", "Q_s_scaling")
-DOCS_I = ("max_age", "min_hits", "delta_t", "embedding_off", "aw_off")
+DOCS_D = ("det_thresh", "iou_threshold", "inertia", "w_association_emb", "alpha_fixed_emb", "aw_param", "Q_xy_scaling", "Q_s_scaling",
+          "min_conf")
+DOCS_I = ("max_age", "min_hits", "delta_t", "embedding_off", "aw_off", "use_byte")
 
 
 def build_docs(sanitize: bool = False) -> Path:
@@ -106,6 +107,7 @@ class EmuDeepOcSort:
                                              ctypes.c_void_p, ctypes.c_void_p]
         self.lib.emu_docs_dump.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 4
         self.lib.emu_docs_destroy.argtypes = [ctypes.c_void_p]
+        cfg = {"min_conf": 0.1, "use_byte": 0, **cfg}
         cd = np.array([cfg[k] for k in DOCS_D], dtype=np.float64)
         ci = np.array([int(cfg[k]) for k in DOCS_I], dtype=np.int32)
         self.cap, self.nd, self.dim = cap, nd, dim

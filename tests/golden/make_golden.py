@@ -214,6 +214,7 @@ def mot17_golden():
         "ocsort": lambda: OcSort(),
         "ocsort_yaml": lambda: OcSort(det_thresh=0.6, inertia=0.1),       # configs/trackers/ocsort.yaml defaults
         "bytetrack": byte,
+        "ocsort_byte": lambda: OcSort(use_byte=True),
     }
     for seq in ("MOT17-02-FRCNN", "MOT17-04-FRCNN"):
         rows, emb = mot17_inputs(seq)

@@ -48,7 +48,7 @@ void* thread_main(void* p) {
 
 extern "C" {
 
-// cd: det_thresh, iou_threshold, inertia, w_emb, alpha_fixed, aw_param, q_xy, q_s; ci: max_age, min_hits, delta_t, embedding_off, aw_off
+// cd: det_thresh, iou_threshold, inertia, w_emb, alpha_fixed, aw_param, q_xy, q_s, min_conf; ci: max_age, min_hits, delta_t, embedding_off, aw_off, use_byte
 void* emu_docs_create(const double* cd, const int* ci, int cap, int nd, int dim) {
     Emu* e = new Emu();
     e->cap = cap; e->nd = nd; e->dim = dim;
@@ -56,6 +56,7 @@ void* emu_docs_create(const double* cd, const int* ci, int cap, int nd, int dim)
     c.det_thresh = cd[0]; c.det_thresh_f32 = (float)cd[0]; c.iou_threshold = cd[1]; c.inertia = cd[2]; c.w_emb = cd[3];
     c.alpha_fixed = cd[4]; c.aw_param = cd[5]; c.q_xy = cd[6]; c.q_s = cd[7];
     c.max_age = ci[0]; c.min_hits = ci[1]; c.delta_t = ci[2]; c.embedding_off = ci[3]; c.aw_off = ci[4];
+    c.use_byte = ci[5]; c.min_conf_f32 = (float)cd[8];
     bm::DocsSizes z{1, cap, nd, dim};
     bm::docs_allocate(e->args, z, e->alloc);
     e->dets = e->alloc.get<float>((size_t)nd * bm::DET_COLS);

@@ -87,3 +87,24 @@ def test_emulated_kernels_clean_under_asan():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900)
     assert "ASAN-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("kw,seed", [(dict(), 7), (dict(min_conf=0.2, det_thresh=0.6, inertia=0.1), 3)])
+def test_emulated_ocsort_byte_association_matches_oracle(kw, seed):
+    """OC-SORT's BYTE round (ocsort.py:456-485) in the device step vs the oracle pinned on the reference OcSort(use_byte=True):
+    rows and the fp64 filter state of every track."""
+    from oracle.deepocsort import OcSortOracle
+    cfg = {**DEFAULTS, **{k: v for k, v in kw.items() if k in DEFAULTS}, "embedding_off": 1, "use_byte": 1, "min_conf": kw.get("min_conf", 0.1)}
+    orc, emu = OcSortOracle(lap_rule="lowest_index", use_byte=True, **kw), EmuDeepOcSort(cfg, cap=128, nd=64, dim=1)
+    try:
+        for t, (d, _) in enumerate(stress_frames(70, seed=seed)):
+            want = np.asarray(orc.update(d.copy()), dtype=np.float32).reshape(-1, 8)
+            got = emu.update(d, None)
+            assert got.shape == want.shape and np.array_equal(got[:, 4:], want[:, 4:]), t
+            assert np.allclose(got[:, :4], want[:, :4], rtol=0, atol=1e-4), t
+        od, dd = orc.dump(), emu.dump()
+        assert np.array_equal(dd["ints"][:, 0], od["id"]) and np.array_equal(dd["ints"][:, 3], od["hit_streak"])
+        if dd["n"]:
+            assert np.allclose(dd["kf"][:, :7], od["x"], rtol=1e-9, atol=1e-9)
+    finally:
+        emu.close()

@@ -146,14 +146,13 @@ def test_hip_ocsort_matches_oracle_and_surface():
     from boxmot_amd.scenario import stress_frames
     from oracle.deepocsort import OcSortOracle
     img = np.zeros((480, 640, 3), dtype=np.uint8)
-    for kw in ({}, dict(max_age=5, min_hits=1, delta_t=2), dict(det_thresh=0.6, inertia=0.1, iou_threshold=0.2)):
+    for kw in ({}, dict(max_age=5, min_hits=1, delta_t=2), dict(det_thresh=0.6, inertia=0.1, iou_threshold=0.2), dict(use_byte=True),
+               dict(use_byte=True, min_conf=0.2, det_thresh=0.6, inertia=0.1)):
         trk, orc = OcSort(max_tracks=128, max_dets=64, **kw), OcSortOracle(lap_rule="lowest_index", **kw)
         for t, (dets, embs) in enumerate(stress_frames(100, seed=3)):
             got = np.asarray(trk.update(dets, img, embs)).reshape(-1, 8)          # embeddings are accepted and ignored
             assert_rows_match(got, np.asarray(orc.update(dets, img), dtype=np.float32).reshape(-1, 8), t)
         trk.close()
-    with pytest.raises(NotImplementedError):
-        OcSort(use_byte=True)
     with pytest.raises(TypeError):
         OcSort(embedding_off=False)
     trk = create_tracker("ocsort", max_tracks=64, max_dets=32)                    # ocsort.yaml defaults: det_thresh 0.6

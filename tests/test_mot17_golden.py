@@ -12,7 +12,7 @@ from common import BOTSORT_YAML_DEFAULTS, mot17_embeddings
 
 GOLD = Path(__file__).resolve().parent / "golden" / "mot17_golden.npz"
 SEQS = ("MOT17-02-FRCNN", "MOT17-04-FRCNN")
-KINDS = ("botsort", "botsort_noreid", "deepocsort", "strongsort", "ocsort", "ocsort_yaml", "bytetrack")
+KINDS = ("botsort", "botsort_noreid", "deepocsort", "strongsort", "ocsort", "ocsort_yaml", "bytetrack", "ocsort_byte")
 YAML = {k: v for k, v in BOTSORT_YAML_DEFAULTS.items() if k not in ("use_cmc", "cmc_method", "with_reid")}
 
 
@@ -46,6 +46,8 @@ def _oracle(kind, **kw):
         return OcSortOracle(**kw)
     if kind == "ocsort_yaml":
         return OcSortOracle(det_thresh=0.6, inertia=0.1, **kw)
+    if kind == "ocsort_byte":
+        return OcSortOracle(use_byte=True, **kw)
     if kind == "botsort":
         return BotSortOracle(**YAML)
     if kind == "botsort_noreid":
@@ -84,10 +86,12 @@ def test_hip_replay_reproduces_reference_on_mot17_detections(kind):
         kw["with_reid"] = False
     if kind == "ocsort_yaml":
         kw.update(det_thresh=0.6, inertia=0.1)
+    if kind == "ocsort_byte":
+        kw.update(use_byte=1)
     got = replay(seqs, tracker_type=kind.split("_")[0], max_tracks=512, max_dets=64, **kw)
     for seq in SEQS:
         want = _golden_rows(g, seq, kind)
-        if kind in ("deepocsort", "ocsort", "ocsort_yaml"):
+        if kind in ("deepocsort", "ocsort", "ocsort_yaml", "ocsort_byte"):
             # the device assignment breaks exact cost ties towards the lowest index, the reference's (stand-in) solver
             # otherwise; the oracle with the device's rule must still equal the reference here (no decisive tie)
             orc, w2 = _oracle(kind, lap_rule="lowest_index"), {}

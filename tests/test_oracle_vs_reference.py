@@ -56,7 +56,8 @@ def test_ocsort_oracle_bit_exact_incl_kalman_state():
     logging.disable(logging.CRITICAL)
     OcSort = ref_harness.load_ocsort()
     img = np.zeros((480, 640, 3), np.uint8)
-    for kw in ({}, dict(max_age=5, min_hits=1, delta_t=2), dict(det_thresh=0.6, inertia=0.1, iou_threshold=0.2)):
+    for kw in ({}, dict(max_age=5, min_hits=1, delta_t=2), dict(det_thresh=0.6, inertia=0.1, iou_threshold=0.2), dict(use_byte=True),
+               dict(use_byte=True, min_conf=0.2, det_thresh=0.6, inertia=0.1)):
         ref, orc = OcSort(**kw), OcSortOracle(**kw)
         for t, (d, e) in enumerate(stress_frames(100, seed=3)):
             r = np.asarray(ref.update(d.copy(), img))
