@@ -70,7 +70,17 @@ def test_emulated_kernel_clean_under_asan():
     code = ("import sys; sys.path[:0]=['.', 'tests']\n"
             "from test_kernel_emu import _run\n"
             "from boxmot_amd.scenario import stress_frames\n"
-            "_run(stress_frames(25, seed=7), 32, 64, 32, sanitize=True)\nprint('ASAN-OK')\n")
+            "_run(stress_frames(25, seed=7), 32, 64, 32, sanitize=True)\n"
+            # the ByteTrack mode of the same kernel (XYAH filter, per-slot removed flag)
+            "import numpy as np\n"
+            "from common import bytetrack_device_config\n"
+            "from emu_util import EmuBotSort\n"
+            "from oracle.bytetrack import ByteTrackOracle\n"
+            "emu, orc = EmuBotSort(bytetrack_device_config(), cap=64, nd=32, dim=1, sanitize=True), ByteTrackOracle()\n"
+            "for d, _ in stress_frames(20, seed=7):\n"
+            "    g, w = emu.update(d[:32], None), orc.update(d[:32].copy())\n"
+            "    assert g.shape == w.shape and np.array_equal(g[:, 4:], w[:, 4:])\n"
+            "emu.close()\nprint('ASAN-OK')\n")
     import glob
     libasan = sorted(glob.glob("/usr/lib/gcc/x86_64-linux-gnu/*/libasan.so"))
     if not libasan:
