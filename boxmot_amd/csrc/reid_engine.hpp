@@ -18,6 +18,10 @@
 #include "reid_kernels_v1.hpp"
 #include "reid_fused.hpp"
 
+#ifndef BM_STAGE1_HANDOVER
+#define BM_STAGE1_HANDOVER 0
+#endif
+
 namespace bm {
 
 inline void hip_check(hipError_t e, const char* what) {
@@ -326,6 +330,10 @@ private:
         allow_lds(k_stem_resize_fused, STEM2_LDS);
         allow_lds(k_osblock<0, 16, true, false, true, false>, Geo<0>::LDS_BYTES);
         allow_lds(k_osblock<0, 64, false, true, false, true>, Geo<0>::LDS_BYTES);
+#if BM_STAGE1_HANDOVER
+        allow_lds(k_osblock<1, 64, true, false, true, false>, Geo<1>::LDS_BYTES);
+        allow_lds(k_osblock<1, 96, false, true, false, true>, Geo<1>::LDS_BYTES);
+#endif
         allow_lds(k_osblock<1, 64, true, false>, Geo<1>::LDS_BYTES);
         allow_lds(k_osblock<1, 96, false, true>, Geo<1>::LDS_BYTES);
         allow_lds(k_osblock<2, 96, true, false>, Geo<2>::LDS_BYTES);
@@ -349,11 +357,22 @@ private:
             BlkLink{w_blk_[1], bp_[1].conv1_a, bp_[1].conv1_b, 0, x2s_});
         blk(k_osblock<0, 64, false, true, false, true>, Geo<0>::NWAVES, Geo<0>::LDS_BYTES, act_a_, act_b_, 1, w_tr_[0],
             BlkLink{w_blk_[0], bp_[0].conv3_a, bp_[0].conv3_b, bp_[0].down_a, x2s_});
+#if BM_STAGE1_HANDOVER
+        // the same hand-over for stage 1 (its 512 x 96 block output is otherwise written once and read twice); validated in
+        // emulation (tests/test_reid_emu.py), not yet measured on the device -- off by default
+        blk(k_osblock<1, 64, true, false, true, false>, Geo<1>::NWAVES, Geo<1>::LDS_BYTES, act_b_, nullptr, 2, nullptr,
+            BlkLink{w_blk_[3], bp_[3].conv1_a, bp_[3].conv1_b, 0, x2s_});
+        blk(k_osblock<1, 96, false, true, false, true>, Geo<1>::NWAVES, Geo<1>::LDS_BYTES, act_b_, act_a_, 3, w_tr_[1],
+            BlkLink{w_blk_[2], bp_[2].conv3_a, bp_[2].conv3_b, bp_[2].down_a, x2s_});
+        _Float16 *s2_in = act_a_, *s2_mid = act_b_;
+#else
         blk(k_osblock<1, 64, true, false>, Geo<1>::NWAVES, Geo<1>::LDS_BYTES, act_b_, act_a_, 2, nullptr, BlkLink{});
         blk(k_osblock<1, 96, false, true>, Geo<1>::NWAVES, Geo<1>::LDS_BYTES, act_a_, act_b_, 3, w_tr_[1], BlkLink{});
-        blk(k_osblock<2, 96, true, false>, Geo<2>::NWAVES, Geo<2>::LDS_BYTES, act_b_, act_a_, 4, nullptr, BlkLink{});
-        blk(k_osblock<2, 128, false, false>, Geo<2>::NWAVES, Geo<2>::LDS_BYTES, act_a_, act_b_, 5, nullptr, BlkLink{});
-        hipLaunchKernelGGL((k_head_fused<128, 512>), dim3(n), dim3(128), 0, st, act_b_, w_c5_, w_fc_, d_out, d_out_rows, d_count_);
+        _Float16 *s2_in = act_b_, *s2_mid = act_a_;
+#endif
+        blk(k_osblock<2, 96, true, false>, Geo<2>::NWAVES, Geo<2>::LDS_BYTES, s2_in, s2_mid, 4, nullptr, BlkLink{});
+        blk(k_osblock<2, 128, false, false>, Geo<2>::NWAVES, Geo<2>::LDS_BYTES, s2_mid, s2_in, 5, nullptr, BlkLink{});
+        hipLaunchKernelGGL((k_head_fused<128, 512>), dim3(n), dim3(128), 0, st, s2_in, w_c5_, w_fc_, d_out, d_out_rows, d_count_);
     }
     void alloc_buffers() {
         const size_t n = (size_t)max_crops_;

@@ -92,8 +92,8 @@ __device__ inline h8 cat8(h4 a, h4 b) { return h8{a[0], a[1], a[2], a[3], b[0], 
 // `x1s` ([n][P][MIDP] halves) is where a recomputing stage with a wide input parks conv1's output instead of
 // re-reading CIN channels per branch.
 //
-// EMIT / RECON split the first stage's block pair so that the 64-channel output of block 1 (256 KiB per crop, the
-// largest tensor of the network) never exists in memory:
+// EMIT / RECON split a stage's block pair (stage 0; stage 1 behind BM_STAGE1_HANDOVER, reid_engine.hpp) so that the
+// output of block 1 (stage 0: 64 channels x 2048 px = 256 KiB per crop, the largest tensor of the network) never exists in memory:
 //   * EMIT (block 1): per tile, the block output stays in registers and feeds the NEXT block's conv1 (weights `link.w`
 //     at link.a0 / bias link.a1); what is stored is that conv1's 16-channel result (`x1s`) and this block's 16-channel
 //     gated branch sum (`link.x2s`) -- 2 x 64 KiB instead of 256 KiB.
@@ -113,8 +113,10 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
           const int* __restrict__ count, _Float16* __restrict__ x1s, const unsigned char* __restrict__ wtr, BlkLink link) {
     static_assert(!(Geo<STAGE>::KT == 1 && DOWN && CIN != 16),
                   "conv3 (K=16 MFMA) and a K=32 downsample would share an accumulator: mixed-shape chains are wrong on gfx950");
-    static_assert(!EMIT || (STAGE == 0 && CIN == 16 && DOWN && !TRANS), "EMIT: first block of stage 0");
-    static_assert(!RECON || (STAGE == 0 && CIN == 64 && !DOWN && TRANS), "RECON: second block of stage 0");
+    static_assert(!EMIT || (STAGE <= 1 && CIN == (STAGE == 0 ? 16 : 64) && DOWN && !TRANS), "EMIT: first block of stage 0 or 1");
+    static_assert(!RECON || (STAGE <= 1 && CIN == Geo<STAGE>::COUT && !DOWN && TRANS), "RECON: second block of stage 0 or 1");
+    constexpr int PREV_CIN = STAGE == 0 ? 16 : 64;       // RECON: input width of the previous block (= the stage input)
+    constexpr int KINP = PREV_CIN == 16 ? 1 : PREV_CIN / 32;
     using G = Geo<STAGE>;
     if (count && (int)blockIdx.x >= *count) return;     // device-side crop count (no host round trip)
     constexpr int KT = G::KT, NT = G::NT, MIDP = G::MIDP, NCT = G::NCT, COUT = G::COUT, P = G::P;
@@ -127,7 +129,7 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
     // (a scalar wave index, as in the stem, was measured here and is 5-15 % slower: more scalar traffic, no VALU saved)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l16 = lane & 15;
     const long crop = blockIdx.x;
-    const _Float16* xin = in + crop * P * (RECON ? 16 : CIN);      // RECON: the previous block's 16-channel input
+    const _Float16* xin = in + crop * P * (RECON ? PREV_CIN : CIN);      // RECON: the previous block's input
     _Float16* yout = out + crop * (TRANS ? P / 4 : P) * COUT;
     BM_PROF_DECL();
 
@@ -398,7 +400,7 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
     constexpr bool EPI = STAGE <= 1;
     constexpr int KS3E = COUT / 32;
     constexpr int EPI_T = TRANS ? NCT * KS3E * 1024 + COUT * 4 : 0;
-    const int epi_a = (EPI && STAGE == 1) ? (int)(bp.total - bp.conv3_a) : 0;
+    const int epi_a = (EPI && STAGE == 1 && !RECON) ? (int)(bp.total - bp.conv3_a) : 0;     // (stage-1 RECON: no room left)
     const unsigned char* ew = wts + bp.conv3_a;          // conv3_a-relative base of this block's epilogue operands
     const unsigned char* etr = wtr;
     const unsigned char* epv = RECON ? link.w + link.a0 : nullptr;      // a0-relative base of the previous block's operands
@@ -410,7 +412,7 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
         if (epi_a) { stage_in(ew, epi_a, 0); ew = tbuf; }
         if constexpr (TRANS) { stage_in(wtr, EPI_T, epi_a); etr = tbuf + epi_a; }
         if constexpr (RECON) {
-            const int bytes = (int)(link.a2 - link.a0) + NCT * 512;      // conv3_a .. end of down_a (K=16 fragments)
+            const int bytes = (int)(link.a2 - link.a0) + NCT * (PREV_CIN == 16 ? 512 : KINP * 1024);   // conv3_a .. end of down_a
             stage_in(epv, bytes, epi_a + EPI_T);
             epv = tbuf + epi_a + EPI_T;
         }
@@ -437,10 +439,17 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
         if constexpr (STASH || RECON) BM_OPAQUE_U32(p);  // addresses are formed at the use, not precomputed and spilled
         h8 bx[KIN];
         h4 bx4;
-        h4 x2p, xp;             // RECON: previous block's branch sum and input at this tile
+        h4 x2p[KT], xp;         // RECON: previous block's branch sum and input at this tile
+        h8 xp8[KINP];
         if constexpr (RECON) {
-            x2p = *reinterpret_cast<const h4*>(x2w + i * 256);
-            xp = *reinterpret_cast<const h4*>(xin + (unsigned)(p * 16 + g * 4));
+#pragma unroll
+            for (int ct = 0; ct < KT; ++ct) x2p[ct] = *reinterpret_cast<const h4*>(x2w + (i * KT + ct) * 256);
+            if constexpr (PREV_CIN == 16) xp = *reinterpret_cast<const h4*>(xin + (unsigned)(p * 16 + g * 4));
+            else {
+#pragma unroll
+                for (int ks = 0; ks < KINP; ++ks)
+                    xp8[ks] = *reinterpret_cast<const h8*>(xin + (unsigned)(p * PREV_CIN + g * (PREV_CIN / 4) + 8 * ks));
+            }
         }
         if constexpr (DOWN) {
             if constexpr (CIN == 16) bx4 = *reinterpret_cast<const h4*>(xin + (unsigned)(p * CIN + g * 4));
@@ -479,8 +488,15 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
                 h4 idn;
                 if constexpr (RECON) {      // block input = ReLU(conv3_prev . x2_prev + down_prev . x_prev + bias), as EMIT computed it
                     f4 ap = *reinterpret_cast<const f4*>(epv + p3b + (16 * co + 4 * g) * 4);
-                    ap = BM_MFMA_F16_K16(*reinterpret_cast<const h4*>(epv + (co * 64 + lane) * 8), x2p, ap);
-                    ap = BM_MFMA_F16_K16(*reinterpret_cast<const h4*>(epv + pda + (co * 64 + lane) * 8), xp, ap);
+                    if constexpr (KT == 1) {        // one MFMA shape per accumulator: K=16 in stage 0, K=32 in stage 1
+                        ap = BM_MFMA_F16_K16(*reinterpret_cast<const h4*>(epv + (co * 64 + lane) * 8), x2p[0], ap);
+                        ap = BM_MFMA_F16_K16(*reinterpret_cast<const h4*>(epv + pda + (co * 64 + lane) * 8), xp, ap);
+                    } else {
+                        ap = BM_MFMA_F16_K32(*reinterpret_cast<const h8*>(epv + (co * 64 + lane) * 16), cat8(x2p[0], x2p[1]), ap);
+#pragma unroll
+                        for (int ks = 0; ks < KINP; ++ks)
+                            ap = BM_MFMA_F16_K32(*reinterpret_cast<const h8*>(epv + pda + ((co * KINP + ks) * 64 + lane) * 16), xp8[ks], ap);
+                    }
                     idn = relu_h4(to_h4(ap));
                 } else {
                     idn = *reinterpret_cast<const h4*>(xin + (unsigned)(p * CIN + g * (CIN / 4) + 4 * co));
@@ -498,19 +514,26 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
         // next block's conv1 (COUT -> 16, + bias, ReLU) on the in-register block output: its accumulator layout is the
         // K=32 B operand (k-slot j <-> channel tile 2ks + (j >> 2)), exactly as the fused transition consumes it
         constexpr int KSN = COUT / 32;
-        h8 wn[KSN];
+        h8 wn[KSN][KT];
+        f4 bn[KT];
 #pragma unroll
-        for (int ks = 0; ks < KSN; ++ks) wn[ks] = *reinterpret_cast<const h8*>(link.w + link.a0 + (ks * 64 + lane) * 16);
-        const f4 bn = *reinterpret_cast<const f4*>(link.w + link.a1 + 4 * g * 4);
+        for (int ct = 0; ct < KT; ++ct) {
+#pragma unroll
+            for (int ks = 0; ks < KSN; ++ks) wn[ks][ct] = *reinterpret_cast<const h8*>(link.w + link.a0 + ((ks * KT + ct) * 64 + lane) * 16);
+            bn[ct] = *reinterpret_cast<const f4*>(link.w + link.a1 + (16 * ct + 4 * g) * 4);
+        }
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
             h4 y[NCT];
             conv3_tile(i, y);
-            f4 an = bn;
 #pragma unroll
-            for (int ks = 0; ks < KSN; ++ks) an = BM_MFMA_F16_K32(wn[ks], cat8(y[2 * ks], y[2 * ks + 1]), an);
-            *reinterpret_cast<h4*>(x1w + i * 256) = relu_h4(to_h4(an));
-            *reinterpret_cast<h4*>(x2w + i * 256) = x2[i][0];
+            for (int ct = 0; ct < KT; ++ct) {
+                f4 an = bn[ct];
+#pragma unroll
+                for (int ks = 0; ks < KSN; ++ks) an = BM_MFMA_F16_K32(wn[ks][ct], cat8(y[2 * ks], y[2 * ks + 1]), an);
+                *reinterpret_cast<h4*>(x1w + (i * KT + ct) * 256) = relu_h4(to_h4(an));
+                *reinterpret_cast<h4*>(x2w + (i * KT + ct) * 256) = x2[i][ct];
+            }
             BM_SCHED_FENCE();
         }
     } else if constexpr (!TRANS) {

@@ -15,6 +15,7 @@ thread_local EmuDim3 blockIdx;
 EmuDim3 blockDim;
 EmuBlock* g_emu_block = nullptr;
 unsigned char* g_emu_dynamic_lds = nullptr;
+static int g_stage1_handover = 0;
 EmuMfmaBuf* g_emu_mfma = nullptr;
 
 namespace {
@@ -66,6 +67,8 @@ void unpack_act(const _Float16* src, float* dst, long n_pix, int C) {
 }  // namespace
 
 extern "C" {
+
+void emu_reid_set_stage1_handover(int on) { g_stage1_handover = on; }
 
 // crops: normalised fp32 NHWC (n, 256, 128, 3).  stage_out[k] (may be null) receives the fp32 NHWC
 // activation after: 0 stem+maxpool, 1..2 stage-1 blocks, 3 transition, 4..5 blocks, 6 transition,
@@ -182,8 +185,25 @@ int emu_reid_forward(const float* blob, long n_floats, const float* crops, int n
         if (stage_out && stage_out[dump]) unpack_act(cur, stage_out[dump], (long)n * 512, 64);
         ++dump;
     }
-    run_block(2, k_osblock<1, 64, true, false>, 1, 64, 1, 64 * Geo<1>::NWAVES, 512, 96, -1);
-    run_block(3, k_osblock<1, 96, false, true>, 1, 96, 0, 64 * Geo<1>::NWAVES, 512, 96, 1);
+    if (g_stage1_handover) {   // stage 1 the same way (engine: BM_STAGE1_HANDOVER)
+        const BlkPack bp0 = make_blk_pack(1, 64, 1), bp1 = make_blk_pack(1, 96, 0);
+        std::vector<uint8_t> wb0, wb1, wt;
+        pack_osblock(w, L.block[2], bp0, wb0);
+        pack_osblock(w, L.block[3], bp1, wb1);
+        pack_pointwise(w + L.trans_w[1], w + L.trans_b[1], 96, 96, wt, 0.25f);
+        const _Float16* in = cur; _Float16* out = nxt;
+        const unsigned char *w0 = wb0.data(), *w1 = wb1.data(), *wtp = wt.data();
+        const BlkLink emit{w1, bp1.conv1_a, bp1.conv1_b, 0, x2p}, recon{w0, bp0.conv3_a, bp0.conv3_b, bp0.down_a, x2p};
+        launch(n, 1, 64 * Geo<1>::NWAVES, [=]() { k_osblock<1, 64, true, false, true, false>(in, nullptr, w0, bp0, nullptr, x1p, nullptr, emit); });
+        launch(n, 1, 64 * Geo<1>::NWAVES, [=]() { k_osblock<1, 96, false, true, false, true>(in, out, w1, bp1, nullptr, x1p, wtp, recon); });
+        std::swap(cur, nxt);
+        dump = 6;
+        if (stage_out && stage_out[dump]) unpack_act(cur, stage_out[dump], (long)n * 128, 96);
+        ++dump;
+    } else {
+        run_block(2, k_osblock<1, 64, true, false>, 1, 64, 1, 64 * Geo<1>::NWAVES, 512, 96, -1);
+        run_block(3, k_osblock<1, 96, false, true>, 1, 96, 0, 64 * Geo<1>::NWAVES, 512, 96, 1);
+    }
     run_block(4, k_osblock<2, 96, true, false>, 2, 96, 1, 64 * Geo<2>::NWAVES, 128, 128, -1);
     run_block(5, k_osblock<2, 128, false, false>, 2, 128, 0, 64 * Geo<2>::NWAVES, 128, 128, -1);
     std::vector<uint8_t> w5, wfc;

@@ -22,8 +22,11 @@ def _build():
     return out
 
 
+@pytest.mark.parametrize("stage1_handover", [0, 1])
 @pytest.mark.skipif(CLANG is None, reason="needs a host clang with _Float16")
-def test_fused_reid_kernels_emulated_vs_oracle():
+def test_fused_reid_kernels_emulated_vs_oracle(stage1_handover):
+    """stage1_handover = 1: stage 1 also runs as an EMIT / RECON pair (engine build flag BM_STAGE1_HANDOVER, off by default
+    until it has been measured on the device)."""
     import torch
 
     from boxmot_amd.reid_weights import pack_osnet, reference_init_state_dict
@@ -43,11 +46,16 @@ def test_fused_reid_kernels_emulated_vs_oracle():
     shapes = [(2048, 16), (2048, 64), (2048, 64), (512, 64), (512, 96), (512, 96), (128, 96), (128, 128), (128, 128)]
     bufs = [np.zeros((n,) + s, np.float32) for s in shapes]
     ptrs = (ctypes.c_void_p * 9)(*[b.ctypes.data for b in bufs])
-    assert lib.emu_reid_forward(blob.ctypes.data, blob.size, nhwc.ctypes.data, n, feats.ctypes.data, ptrs) == 0
+    lib.emu_reid_set_stage1_handover(stage1_handover)
+    try:
+        assert lib.emu_reid_forward(blob.ctypes.data, blob.size, nhwc.ctypes.data, n, feats.ctypes.data, ptrs) == 0
+    finally:
+        lib.emu_reid_set_stage1_handover(0)
     want, st = osnet_forward(sd, torch.from_numpy(crops), return_stages=True)
     names = ["maxpool", "conv2.0", "conv2.1", "conv2.2", "conv3.0", "conv3.1", "conv3.2", "conv4.0", "conv4.1"]
     for nm, buf in zip(names, bufs):
-        if nm in ("conv2.0", "conv2.1", "conv3.1"):   # consumed in registers (EMIT/RECON hand-over, fused transitions), never stored
+        if nm in ("conv2.0", "conv2.1", "conv3.1") or (stage1_handover and nm == "conv3.0"):
+            # consumed in registers (EMIT/RECON hand-over, fused transitions), never stored
             assert not buf.any()
             continue
         ref = st[nm].numpy().transpose(0, 2, 3, 1).reshape(buf.shape)
