@@ -30,6 +30,15 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
+// Unmeasured variants for the next round (validated in emulation, off by default): epilogue operands of the stage-2
+// blocks through LDS as in stages 0-1, and a <= 128-VGPR build of them (4 instead of 3 workgroups per CU).
+#ifndef BM_STAGE2_EPI_LDS
+#define BM_STAGE2_EPI_LDS 0
+#endif
+#ifndef BM_STAGE2_OCC4
+#define BM_STAGE2_OCC4 0
+#endif
+
 template <int STAGE>
 struct Geo {
     static constexpr int H = 64 >> STAGE, W = 32 >> STAGE, P = H * W;
@@ -46,10 +55,12 @@ struct Geo {
     static constexpr int NT = P / 16 / NWAVES;              // 16, 4, 2 pixel tiles per wave
     static constexpr bool SWZ = STAGE == 0;
     static constexpr bool RECOMP = STAGE == 0;
-    static constexpr int WG_PER_CU_WAVES = STAGE == 2 ? 1 : 4;     // __launch_bounds__ 2nd argument (waves per SIMD)
+    static constexpr int WG_PER_CU_WAVES = (STAGE == 2 && !BM_STAGE2_OCC4) ? 1 : 4;     // __launch_bounds__ 2nd argument (waves per SIMD)
     static constexpr int PXB = SWZ ? 32 : (KT == 1 ? 40 : 72);      // bytes per pixel of the LDS image
     static constexpr int ROWB = (W + 2) * PXB;
-    static constexpr int TBUF = (H + 2) * ROWB;
+    static constexpr int IMG = (H + 2) * ROWB;
+    // stage 2 with LDS-staged epilogue operands: conv3 (8 KiB) + bias + downsample 96 -> 128 (24 KiB) outgrow the image
+    static constexpr int TBUF = (STAGE == 2 && BM_STAGE2_EPI_LDS && IMG < 33280) ? 33280 : IMG;
     static constexpr int LDS_BYTES = TBUF + 4 * NWAVES * HID * 4;          // image + per-branch gate partials
 };
 
@@ -134,7 +145,7 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
     BM_PROF_DECL();
 
     // zero the LDS image once: the halo ring stays zero (= the dw conv's zero padding)
-    for (int e = tid * 8; e < G::TBUF; e += 64 * G::NWAVES * 8) *reinterpret_cast<unsigned long long*>(tbuf + e) = 0ull;
+    for (int e = tid * 8; e < G::IMG; e += 64 * G::NWAVES * 8) *reinterpret_cast<unsigned long long*>(tbuf + e) = 0ull;
 
     // ---- conv1: 1x1 CIN -> MID, + bias, ReLU (osnet.py:248) ----
     auto conv1_into = [&](h4 (&x1)[NT][KT]) {
@@ -397,10 +408,10 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
     // share of the block time; LDS delivers 128 B/clk and leaves the L1 to the activations.
     //   [0, EPI_A)      this block's conv3 fragments, bias, downsample fragments (contiguous in the packed blob)
     //   [EPI_A, +EPI_T) fused transition: fragments + bias        [.., +EPI_P) RECON: previous block's conv3/bias/down
-    constexpr bool EPI = STAGE <= 1;
+    constexpr bool EPI = STAGE <= 1 || BM_STAGE2_EPI_LDS;
     constexpr int KS3E = COUT / 32;
     constexpr int EPI_T = TRANS ? NCT * KS3E * 1024 + COUT * 4 : 0;
-    const int epi_a = (EPI && STAGE == 1 && !RECON) ? (int)(bp.total - bp.conv3_a) : 0;     // (stage-1 RECON: no room left)
+    const int epi_a = (EPI && STAGE >= 1 && !RECON) ? (int)(bp.total - bp.conv3_a) : 0;     // (stage-1 RECON: no room left)
     const unsigned char* ew = wts + bp.conv3_a;          // conv3_a-relative base of this block's epilogue operands
     const unsigned char* etr = wtr;
     const unsigned char* epv = RECON ? link.w + link.a0 : nullptr;      // a0-relative base of the previous block's operands
