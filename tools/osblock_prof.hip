@@ -26,7 +26,7 @@ static void run(const char* name, int n, int iters) {
     fill_f32(bp.conv1_b, bp.midp); fill_f32(bp.fc1_w, bp.hid * bp.midp); fill_f32(bp.fc1_b, bp.hid);
     fill_f32(bp.fc2_w, bp.midp * bp.hid); fill_f32(bp.fc2_b, bp.midp); fill_f32(bp.conv3_b, bp.cout);
     for (int li = 0; li < 10; ++li) fill_f32(bp.light0 + li * bp.light_bytes + bp.light_b, bp.midp);
-    const size_t in_elems = (size_t)n * G::P * (RECON ? 16 : CIN), out_elems = (size_t)n * G::P * G::COUT;
+    const size_t in_elems = (size_t)n * G::P * (RECON ? (STAGE == 0 ? 16 : 64) : CIN), out_elems = (size_t)n * G::P * G::COUT;
     std::vector<unsigned short> x(in_elems);
     for (auto& v : x) { s = s * 1664525u + 1013904223u; v = bm::f32_to_f16_bits(((s >> 8) & 0xffff) / 65536.0f); }
     unsigned char *d_w, *d_wt; _Float16 *d_in, *d_out, *d_x1;
@@ -42,7 +42,7 @@ static void run(const char* name, int n, int iters) {
     auto kern = bm::k_osblock<STAGE, CIN, DOWN, TRANS, EMIT, RECON>;
     // EMIT / RECON: the neighbouring block's weights are the same random blob (only the access pattern matters here)
     _Float16* d_x2; CK(hipMalloc(&d_x2, (size_t)n * G::P * G::MIDP * 2)); CK(hipMemset(d_x2, 0, (size_t)n * G::P * G::MIDP * 2)); CK(hipMemset(d_x1, 0, (size_t)n * G::P * G::MIDP * 2));
-    const bm::BlkPack bq = bm::make_blk_pack(0, EMIT ? 64 : 16, EMIT ? 0 : 1);
+    const bm::BlkPack bq = bm::make_blk_pack(STAGE, EMIT ? G::COUT : (STAGE == 0 ? 16 : 64), EMIT ? 0 : 1);
     std::vector<unsigned short> wq(bq.total / 2);
     for (auto& v : wq) { s = s * 1664525u + 1013904223u; v = bm::f32_to_f16_bits(((s >> 8) & 0xffff) / 65536.0f * 0.2f - 0.1f); }
     unsigned char* d_wq; CK(hipMalloc(&d_wq, bq.total)); CK(hipMemcpy(d_wq, wq.data(), bq.total, hipMemcpyHostToDevice));
@@ -138,6 +138,8 @@ int main(int argc, char** argv) {
     run<0, 64, false, true, false, true>("osblock<0,64,trans,RECON>", n, iters);
     run<1, 64, true, false>("osblock<1,64,down>", n, iters);
     run<1, 96, false, true>("osblock<1,96,trans>", n, iters);
+    run<1, 64, true, false, true, false>("osblock<1,64,down,EMIT>", n, iters);          // BM_STAGE1_HANDOVER pair
+    run<1, 96, false, true, false, true>("osblock<1,96,trans,RECON>", n, iters);
     run<2, 96, true, false>("osblock<2,96,down>", n, iters);
     run<2, 128, false, false>("osblock<2,128>", n, iters);
     return 0;
