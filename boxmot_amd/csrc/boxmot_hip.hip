@@ -266,7 +266,10 @@ void build(BoxMOTHipBotSort* h) {
         throw std::runtime_error("boxmot_hip: invalid capacity configuration");
     if (c.removed_stracks_buffer < 0) throw std::runtime_error("boxmot_hip: removed_stracks_buffer must be >= 0");
     if (c.tracker_kind != 0 && c.tracker_kind != 1) throw std::runtime_error("boxmot_hip: tracker_kind must be 0 (BoT-SORT) or 1 (ByteTrack)");
-    if (c.tracker_kind == 1) { h->cfg.with_reid = 0; h->cfg.fuse_first_associate = 1; }
+    if (c.tracker_kind == 1) {
+        if (c.n_class_lists != 1) throw std::runtime_error("boxmot_hip: ByteTrack with per-class track lists is not implemented");
+        h->cfg.with_reid = 0; h->cfg.fuse_first_associate = 1;
+    }
     h->S = c.n_streams; h->cap = c.max_tracks; h->nd = c.max_dets; h->dim = c.emb_dim; h->n_lists = c.n_class_lists;
     BM_HIP(hipStreamCreate(&h->stream));
     BM_HIP(hipEventCreate(&h->ev[0]));
