@@ -10,6 +10,7 @@ there is no Python/CPU fallback for the tracker math.
 from __future__ import annotations
 
 import ctypes
+import os
 from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "libboxmot_hip.so"
@@ -170,12 +171,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not LIB_PATH.exists():
+    path = Path(os.environ.get("BOXMOT_HIP_LIB") or LIB_PATH)       # a differently built library (tools/ab_variants.py)
+    if not path.exists():
         raise ImportError(
-            f"{LIB_PATH} is missing: build the HIP extension first "
+            f"{path} is missing: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()'). boxmot_amd has no CPU fallback."
         )
-    lib = ctypes.CDLL(str(LIB_PATH))
+    lib = ctypes.CDLL(str(path))
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = restype

@@ -1,0 +1,59 @@
+"""A/B of compile-time kernel variants on the device (development tool).
+
+Builds `libboxmot_hip` once per variant into tools/_build/ (run this part in the build container -- hipcc cross-compiles),
+then, on the GPU box, runs the ReID parity tests and `bench.py --no-cpu-baseline` against each and prints one line per
+variant.  The variants are the off-by-default flags of reid_engine.hpp / reid_fused.hpp:
+
+    python tools/ab_variants.py build                      # here
+    gpurun -- 'python tools/ab_variants.py run'            # there
+"""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+OUT = ROOT / "tools" / "_build"
+VARIANTS = {
+    "base": [],
+    "s1_handover": ["-DBM_STAGE1_HANDOVER=1"],
+    "s2_epi_lds": ["-DBM_STAGE2_EPI_LDS=1"],
+    "s2_occ4": ["-DBM_STAGE2_OCC4=1"],
+    "s2_both": ["-DBM_STAGE2_EPI_LDS=1", "-DBM_STAGE2_OCC4=1"],
+    "all": ["-DBM_STAGE1_HANDOVER=1", "-DBM_STAGE2_EPI_LDS=1", "-DBM_STAGE2_OCC4=1"],
+}
+
+
+def build():
+    sys.path.insert(0, str(ROOT))
+    import __graft_entry__ as g
+    OUT.mkdir(parents=True, exist_ok=True)
+    for name, flags in VARIANTS.items():
+        lib = OUT / f"libboxmot_hip_{name}.so"
+        cmd = [os.environ.get("HIPCC", "hipcc"), *g.HIPCC_FLAGS, *flags, "-o", str(lib), str(g.CSRC / "boxmot_hip.hip")]
+        print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+
+def run():
+    for name in VARIANTS:
+        lib = OUT / f"libboxmot_hip_{name}.so"
+        if not lib.exists():
+            print(f"{name}: not built")
+            continue
+        env = dict(os.environ, BOXMOT_HIP_LIB=str(lib))
+        t = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_reid.py", "-x", "-q"], cwd=ROOT, env=env,
+                           capture_output=True, text=True)
+        ok = t.returncode == 0
+        b = subprocess.run([sys.executable, "bench.py", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True)
+        line = b.stdout.strip().splitlines()[-1] if b.stdout.strip() else "{}"
+        try:
+            d = json.loads(line)
+            print(f"{name:12s} parity={'ok' if ok else 'FAIL'} frames/s={d['value']:.0f} reid_launch_ms={d['roofline']['launch_ms']:.3f}", flush=True)
+        except Exception:
+            print(f"{name:12s} parity={'ok' if ok else 'FAIL'} bench failed: {b.stderr[-300:]}", flush=True)
+
+
+if __name__ == "__main__":
+    {"build": build, "run": run}[sys.argv[1] if len(sys.argv) > 1 else "run"]()
