@@ -26,6 +26,12 @@ __global__ void k(const _Float16* a8p, const _Float16* b8p, const _Float16* a4p,
     if (MODE == 8) { f4 acc2 = acc; for (int q = 0; q < 6; ++q) { acc = BM_MFMA_F16_K32(a8, b8, acc); acc2 = BM_MFMA_F16_K32(b8, a8, acc2); } acc = acc + acc2 * 0.f; }
     if (MODE == 9) { acc = BM_MFMA_F16_K32(a8, b8, acc); acc = BM_MFMA_F16_K16(a4, b4, acc); acc = BM_MFMA_F16_K32(a8, b8, acc); }
     if (MODE == 10) { acc = BM_MFMA_F16_K16(a4, b4, acc); acc = BM_MFMA_F16_K32(a8, b8, acc); acc = BM_MFMA_F16_K16(a4, b4, acc); }
+    // modes 11-13: the failing chain of mode 4 with explicit wait states between the links (2, 8, 16): if one of them is
+    // exact, the mixed-shape dense 3x3 of DESIGN.md section 8 becomes usable with hand-placed s_nops
+#define BM_GAP(n) asm volatile("s_nop " #n : "+v"(acc))      /* tied to the accumulator so it stays between the two MFMAs */
+    if (MODE == 11) for (int q = 0; q < 3; ++q) { acc = BM_MFMA_F16_K32(a8, b8, acc); BM_GAP(1); acc = BM_MFMA_F16_K16(a4, b4, acc); BM_GAP(1); }
+    if (MODE == 12) for (int q = 0; q < 3; ++q) { acc = BM_MFMA_F16_K32(a8, b8, acc); BM_GAP(7); acc = BM_MFMA_F16_K16(a4, b4, acc); BM_GAP(7); }
+    if (MODE == 13) for (int q = 0; q < 3; ++q) { acc = BM_MFMA_F16_K32(a8, b8, acc); BM_GAP(15); acc = BM_MFMA_F16_K16(a4, b4, acc); BM_GAP(15); }
     *reinterpret_cast<f4*>(out + lane * 4) = acc;
 }
 static float A8[16][32], B8[32][16], A4[16][16], B4[16][16], C[16][16];
@@ -43,7 +49,7 @@ int main() {
     (void)hipMalloc(&da8, 1024); (void)hipMalloc(&db8, 1024); (void)hipMalloc(&da4, 512); (void)hipMalloc(&db4, 512); (void)hipMalloc(&dc, 1024); (void)hipMalloc(&dout, 1024);
     (void)hipMemcpy(da8, ha8, 1024, hipMemcpyHostToDevice); (void)hipMemcpy(db8, hb8, 1024, hipMemcpyHostToDevice);
     (void)hipMemcpy(da4, ha4, 512, hipMemcpyHostToDevice); (void)hipMemcpy(db4, hb4, 512, hipMemcpyHostToDevice); (void)hipMemcpy(dc, hc, 1024, hipMemcpyHostToDevice);
-    for (int mode = 0; mode < 11; ++mode) {
+    for (int mode = 0; mode < 14; ++mode) {
         if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(1), dim3(64), 0, 0, da8, db8, da4, db4, dc, dout);
         if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(1), dim3(64), 0, 0, da8, db8, da4, db4, dc, dout);
         if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(1), dim3(64), 0, 0, da8, db8, da4, db4, dc, dout);
@@ -54,9 +60,12 @@ int main() {
         if (mode == 8) hipLaunchKernelGGL(k<8>, dim3(1), dim3(64), 0, 0, da8, db8, da4, db4, dc, dout);
         if (mode == 9) hipLaunchKernelGGL(k<9>, dim3(1), dim3(64), 0, 0, da8, db8, da4, db4, dc, dout);
         if (mode == 10) hipLaunchKernelGGL(k<10>, dim3(1), dim3(64), 0, 0, da8, db8, da4, db4, dc, dout);
+        if (mode == 11) hipLaunchKernelGGL(k<11>, dim3(1), dim3(64), 0, 0, da8, db8, da4, db4, dc, dout);
+        if (mode == 12) hipLaunchKernelGGL(k<12>, dim3(1), dim3(64), 0, 0, da8, db8, da4, db4, dc, dout);
+        if (mode == 13) hipLaunchKernelGGL(k<13>, dim3(1), dim3(64), 0, 0, da8, db8, da4, db4, dc, dout);
         if (mode == 4) hipLaunchKernelGGL(k<4>, dim3(1), dim3(64), 0, 0, da8, db8, da4, db4, dc, dout);
         (void)hipMemcpy(ho, dout, 1024, hipMemcpyDeviceToHost);
-        static const int N32[11] = {1, 1, 2, 0, 3, 6, 0, 0, 6, 2, 1}, N16[11] = {1, 1, 0, 2, 3, 0, 32, 9, 0, 1, 2};
+        static const int N32[14] = {1, 1, 2, 0, 3, 6, 0, 0, 6, 2, 1, 3, 3, 3}, N16[14] = {1, 1, 0, 2, 3, 0, 32, 9, 0, 1, 2, 3, 3, 3};
         const int n32 = N32[mode], n16 = N16[mode];
         int bad = 0;
         for (int lane = 0; lane < 64; ++lane) for (int r = 0; r < 4; ++r) {
