@@ -151,6 +151,7 @@ SIGNATURES = {
     "boxmot_hip_strongsort_update_batch": (_I, [_VP, _I, _VP, _VP, _VP, _I, _VP, _I, _I, _I, _VP, _I, _VP]),
     "boxmot_hip_strongsort_step_device": (_I, [_VP, _VP, _VP, _VP, _VP, _VP]),
     "boxmot_hip_strongsort_synchronize": (_I, [_VP]),
+    "boxmot_hip_strongsort_track_count": (_I, [_VP, _I, c_int_p]),
     "boxmot_hip_strongsort_state_dump": (_I, [_VP, _I, _VP, _VP, _VP, c_int_p, c_int_p, c_int_p]),
     "boxmot_hip_reid_create": (_VP, [ctypes.c_char_p, _VP, ctypes.c_long, _I]),
     "boxmot_hip_reid_destroy": (None, [_VP]),
@@ -161,6 +162,70 @@ SIGNATURES = {
     "boxmot_hip_reid_preprocess": (_I, [_VP, _VP, _I, _I, _I, _VP, _I, _I, _VP]),
     "boxmot_hip_last_error": (ctypes.c_char_p, []),
     "boxmot_hip_device_count": (_I, []),
+}
+
+
+class RefBotSortConfig(ctypes.Structure):
+    """``BoxMOTBotSortConfig`` exactly as the reference declares it (c_api.hpp:17-32; its ctypes twin is
+    ``_BotSortCConfig``, boxmot/native/trackers/botsort.py:94-110)."""
+
+    _fields_ = [
+        ("track_high_thresh", ctypes.c_float), ("track_low_thresh", ctypes.c_float), ("new_track_thresh", ctypes.c_float),
+        ("track_buffer", ctypes.c_int),
+        ("match_thresh", ctypes.c_float), ("proximity_thresh", ctypes.c_float), ("appearance_thresh", ctypes.c_float),
+        ("cmc_method", ctypes.c_char_p),
+        ("frame_rate", ctypes.c_int), ("fuse_first_associate", ctypes.c_int), ("with_reid", ctypes.c_int), ("max_obs", ctypes.c_int),
+        ("reid_model_path", ctypes.c_char_p), ("reid_preprocess", ctypes.c_char_p),
+    ]
+
+
+class RefByteTrackConfig(ctypes.Structure):
+    """``BoxMOTByteTrackConfig`` (bytetrack/c_api.hpp:16-23)."""
+
+    _fields_ = [("min_conf", ctypes.c_float), ("track_thresh", ctypes.c_float), ("match_thresh", ctypes.c_float),
+                ("track_buffer", ctypes.c_int), ("frame_rate", ctypes.c_int), ("max_obs", ctypes.c_int)]
+
+
+class RefOcSortConfig(ctypes.Structure):
+    """``BoxMOTOCSORTConfig`` (ocsort/c_api.hpp:16-28)."""
+
+    _fields_ = [("min_conf", ctypes.c_float), ("det_thresh", ctypes.c_float), ("iou_threshold", ctypes.c_float),
+                ("max_age", ctypes.c_int), ("min_hits", ctypes.c_int), ("delta_t", ctypes.c_int), ("use_byte", ctypes.c_int),
+                ("inertia", ctypes.c_float), ("q_xy_scaling", ctypes.c_float), ("q_s_scaling", ctypes.c_float),
+                ("max_obs", ctypes.c_int)]
+
+
+# every symbol include/boxmot_compat.h declares (the reference's own FFI names)
+_UPD_EMBS = [_VP, _VP, _I, _I, _VP, _I, _I, _VP, _I, _I, _I, _VP, _I, _I, c_int_p, c_int_p]
+_UPD = [_VP, _VP, _I, _I, _VP, _I, _I, _I, _VP, _I, _I, c_int_p, c_int_p]
+COMPAT_SIGNATURES = {
+    "boxmot_botsort_create": (_VP, [ctypes.POINTER(RefBotSortConfig)]),
+    "boxmot_botsort_destroy": (None, [_VP]),
+    "boxmot_botsort_reset": (_I, [_VP]),
+    "boxmot_botsort_update": (_I, _UPD_EMBS),
+    "boxmot_botsort_last_reid_time_ms": (_I, [_VP, c_double_p]),
+    "boxmot_botsort_last_reid_preprocess_time_ms": (_I, [_VP, c_double_p]),
+    "boxmot_botsort_last_reid_process_time_ms": (_I, [_VP, c_double_p]),
+    "boxmot_botsort_last_reid_postprocess_time_ms": (_I, [_VP, c_double_p]),
+    "boxmot_botsort_last_error": (ctypes.c_char_p, []),
+    "boxmot_bytetrack_create": (_VP, [ctypes.POINTER(RefByteTrackConfig)]),
+    "boxmot_bytetrack_destroy": (None, [_VP]),
+    "boxmot_bytetrack_reset": (_I, [_VP]),
+    "boxmot_bytetrack_update": (_I, _UPD),
+    "boxmot_bytetrack_last_error": (ctypes.c_char_p, []),
+    "boxmot_ocsort_create": (_VP, [ctypes.POINTER(RefOcSortConfig)]),
+    "boxmot_ocsort_destroy": (None, [_VP]),
+    "boxmot_ocsort_reset": (_I, [_VP]),
+    "boxmot_ocsort_update": (_I, _UPD),
+    "boxmot_ocsort_last_error": (ctypes.c_char_p, []),
+    "boxmot_reid_capi_create": (_I, [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(_VP)]),
+    "boxmot_reid_capi_destroy": (None, [_VP]),
+    "boxmot_reid_capi_feature_dim": (_I, [_VP, c_int_p]),
+    "boxmot_reid_capi_compute_features": (_I, [_VP, _VP, _I, _VP, _I, _I, _I, _VP, _I]),
+    "boxmot_reid_capi_preprocess": (_I, [_VP, _VP, _I, _VP, _I, _I, _I]),
+    "boxmot_reid_capi_process": (_I, [_VP]),
+    "boxmot_reid_capi_postprocess": (_I, [_VP, _VP, _I]),
+    "boxmot_reid_capi_last_error": (ctypes.c_char_p, []),
 }
 
 _lib = None
@@ -178,7 +243,7 @@ def load():
             "(python -c 'import __graft_entry__ as g; g.build()'). boxmot_amd has no CPU fallback."
         )
     lib = ctypes.CDLL(str(path))
-    for name, (restype, argtypes) in SIGNATURES.items():
+    for name, (restype, argtypes) in list(SIGNATURES.items()) + list(COMPAT_SIGNATURES.items()):
         fn = getattr(lib, name)
         fn.restype = restype
         fn.argtypes = argtypes
@@ -194,3 +259,13 @@ def last_error() -> str:
 def check(ok: int) -> None:
     if ok == 0:
         raise RuntimeError(last_error())
+
+
+_STATUS_MSG = __import__("re").compile(r"boxmot_hip: [\w-]+ stream \d+: ")
+
+
+def step_ran(ok: int) -> bool:
+    """True when the frame step of an update call ran on the device: the call succeeded, or it failed with a per-stream
+    status report (capacity overflow, solver stall).  Those are raised after the step -- the device's frame counter has
+    advanced and the rows of the frame were returned -- so the caller's frame counter must advance too."""
+    return ok != 0 or bool(_STATUS_MSG.match(last_error()))

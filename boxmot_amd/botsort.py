@@ -151,8 +151,9 @@ class BotSort(BaseTracker):
             int(img_arr.shape[2]) if img_arr.ndim == 3 else 1,
             out.ctypes.data, int(out.shape[0]), 9, ctypes.byref(out_rows), ctypes.byref(out_is_obb),
         )
+        if _lib.step_ran(ok):       # a per-stream status report (capacity, solver) is raised after the step has run
+            self.frame_count += 1
         _lib.check(ok)
-        self.frame_count += 1
         return out[: out_rows.value, :OUT_COLS].copy()
 
     def reset(self) -> None:

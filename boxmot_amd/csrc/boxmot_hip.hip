@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/boxmot_hip.h"
+#include "../../include/boxmot_compat.h"
 #include "botsort_alloc.hpp"
 #include "botsort_step.hpp"
 #include "deepocsort_step.hpp"
@@ -121,6 +122,8 @@ struct BoxMOTHipReID {
     int* d_crop_stream = nullptr;
     float* d_boxes = nullptr;
     float* d_feat = nullptr;
+    int staged_n = -1, staged_rows = 0, staged_cols = 0;      // boxmot_reid_capi_preprocess -> process -> postprocess
+    bool staged_done = false;
     ~BoxMOTHipReID() {
         engine.reset();
         for (void* p : owned) (void)hipFree(p);
@@ -351,16 +354,29 @@ void run_reid(BoxMOTHipBotSort* h, int s0, int n_streams, const float* d_dets, c
     h->reid->run(d_frames, h->d_crop_stream, h->d_crop_boxes, 4, n_crops, cols, rows, d_embs, h->d_crop_row, h->stream);
 }
 
-void check_status(BoxMOTHipBotSort* h, int n_streams) {
-    std::vector<int> st(n_streams);
-    BM_HIP(hipMemcpy(st.data(), h->args.st.status, n_streams * 4, hipMemcpyDeviceToHost));
-    for (int s = 0; s < n_streams; ++s) {
-        if (st[s] == bm::STATUS_OK) continue;
-        const char* what = st[s] == bm::STATUS_TRACK_CAPACITY ? "track capacity (max_tracks) exceeded"
-                         : st[s] == bm::STATUS_CLASS_CAPACITY ? "more than 8 classes voted on one track"
-                         : "assignment solver did not converge (non-finite costs?)";
-        throw std::runtime_error("boxmot_hip: stream " + std::to_string(s) + ": " + what);
+// Status words of streams [s0, s0 + n): a non-zero word is reported once and cleared, so that one overflow neither poisons the
+// later updates of this stream nor the updates of the handle's other streams (the step has already run: the caller still
+// receives the rows of this frame, see host_update).  Returns the message of the first failing stream ("" when all are ok).
+std::string take_status(hipStream_t stream, int* d_status, int s0, int n, const char* tracker) {
+    std::vector<int> st(n);
+    BM_HIP(hipMemcpy(st.data(), d_status + s0, n * 4, hipMemcpyDeviceToHost));
+    std::string msg;
+    bool any = false;
+    for (int k = 0; k < n; ++k) {
+        if (st[k] == bm::STATUS_OK) continue;
+        any = true;
+        if (!msg.empty()) continue;
+        const char* what = st[k] == bm::STATUS_TRACK_CAPACITY ? "track capacity (max_tracks) exceeded: the births of this frame were clamped"
+                         : st[k] == bm::STATUS_CLASS_CAPACITY ? "more than 8 classes voted on one track"
+                         : st[k] == bm::STATUS_LAP_STALL ? "assignment solver did not converge (non-finite costs?)"
+                                                         : "innovation covariance is not positive definite";
+        msg = std::string("boxmot_hip: ") + tracker + " stream " + std::to_string(s0 + k) + ": " + what;
     }
+    if (any) {
+        BM_HIP(hipMemsetAsync(d_status + s0, 0, n * 4, stream));
+        BM_HIP(hipStreamSynchronize(stream));
+    }
+    return msg;
 }
 
 void upload_frame(BoxMOTHipBotSort* h, int s, const uint8_t* image, int rows, int cols, int channels) {
@@ -451,7 +467,7 @@ void host_update(BoxMOTHipBotSort* h, int s0, int n, const StreamIn* in, int det
     float ms = 0;
     if (hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) == hipSuccess) h->last_track_ms = ms;
     if (need_reid) h->reid->last_times(h->last_reid_pre_ms, h->last_reid_proc_ms);
-    check_status(h, h->S);
+    const std::string status_msg = take_status(h->stream, h->args.st.status, s0, n, h->cfg.tracker_kind == 1 ? "ByteTrack" : "BoT-SORT");
     for (int k = 0; k < n; ++k) {
         const int rows = h->h_out_n[k];
         if (rows > out_capacity_rows) throw std::runtime_error("boxmot_hip: output buffer is too small for the current frame.");
@@ -463,6 +479,7 @@ void host_update(BoxMOTHipBotSort* h, int s0, int n, const StreamIn* in, int det
         }
         out_rows[k] = rows;
     }
+    if (!status_msg.empty()) throw std::runtime_error(status_msg);      // rows of this frame are in `out` all the same
 }
 
 // single stream at an arbitrary index: run it as a one-stream group by offsetting the args
@@ -604,14 +621,7 @@ void io_read_back(StreamIo* h, int n, const int* d_status, const char* tracker, 
     BM_HIP(hipMemcpyAsync(h->h_out_n.data(), h->d_out_n + s0, n * 4, hipMemcpyDeviceToHost, h->stream));
     BM_HIP(hipStreamSynchronize(h->stream));
     for (int k = 0; k < n; ++k) h->h_warp_flag[s0 + k] = 0;
-    std::vector<int> st(n);
-    BM_HIP(hipMemcpy(st.data(), d_status + s0, n * 4, hipMemcpyDeviceToHost));
-    for (int k = 0; k < n; ++k)
-        if (st[k] != bm::STATUS_OK)
-            throw std::runtime_error(std::string("boxmot_hip: ") + tracker + " stream " + std::to_string(s0 + k) + ": " +
-                                     (st[k] == bm::STATUS_TRACK_CAPACITY ? "track capacity (max_tracks) exceeded"
-                                      : st[k] == bm::STATUS_LAP_STALL ? "assignment solver did not converge (non-finite costs?)"
-                                                                      : "innovation covariance is not positive definite"));
+    const std::string status_msg = take_status(h->stream, const_cast<int*>(d_status), s0, n, tracker);
     for (int k = 0; k < n; ++k) {
         const int rows = h->h_out_n[k];
         if (rows > out_capacity_rows) throw std::runtime_error("boxmot_hip: output buffer is too small for the current frame.");
@@ -623,6 +633,7 @@ void io_read_back(StreamIo* h, int n, const int* d_status, const char* tracker, 
         }
         out_rows[k] = rows;
     }
+    if (!status_msg.empty()) throw std::runtime_error(status_msg);      // rows of this frame are in `out` all the same
 }
 
 // ---------------------------------------------------------------------------
@@ -857,8 +868,18 @@ int boxmot_hip_botsort_step_device(BoxMOTHipBotSort* handle, const float* d_dets
             run_reid(handle, 0, handle->S, d_dets, d_det_rows, d_frames, image_rows, image_cols, handle->d_embs);
             embs = handle->d_embs;
         }
+        // warps set with boxmot_hip_botsort_set_warp since the last step are consumed by this one
+        bool any_warp = false;
+        for (int s = 0; s < handle->S; ++s) any_warp = any_warp || handle->h_warp_flag[s] != 0;
+        if (any_warp) {
+            BM_HIP(hipMemcpyAsync(handle->d_warp, handle->h_warp.data(), (size_t)handle->S * 6 * 8, hipMemcpyHostToDevice, handle->stream));
+            BM_HIP(hipMemcpyAsync(handle->d_warp_flag, handle->h_warp_flag.data(), handle->S * 4, hipMemcpyHostToDevice, handle->stream));
+            // the staging vectors are reused by the next set_warp: the copies must have left the host before returning
+            BM_HIP(hipStreamSynchronize(handle->stream));
+        }
         launch_step(handle, 0, handle->S, d_dets, d_det_rows, handle->cfg.with_reid ? embs : nullptr, nullptr, nullptr,
-                    d_out, d_out_rows);
+                    d_out, d_out_rows, any_warp);
+        for (int s = 0; s < handle->S; ++s) handle->h_warp_flag[s] = 0;
     });
 }
 
@@ -1336,6 +1357,16 @@ int boxmot_hip_strongsort_step_device(BoxMOTHipStrongSort* handle, const float* 
     });
 }
 
+int boxmot_hip_strongsort_track_count(BoxMOTHipStrongSort* handle, int stream, int* out_tracks) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip StrongSORT handle is null.");
+        if (stream < 0 || stream >= handle->S) throw std::runtime_error("boxmot_hip: stream index out of range");
+        if (!out_tracks) throw std::runtime_error("Output pointers are null.");
+        BM_HIP(hipStreamSynchronize(handle->stream));
+        BM_HIP(hipMemcpy(out_tracks, handle->args.st.n_tracks + stream, 4, hipMemcpyDeviceToHost));
+    });
+}
+
 int boxmot_hip_strongsort_synchronize(BoxMOTHipStrongSort* handle) {
     return guard([&]() {
         if (!handle) throw std::runtime_error("boxmot_hip StrongSORT handle is not initialized.");
@@ -1378,6 +1409,283 @@ int boxmot_hip_strongsort_state_dump(BoxMOTHipStrongSort* handle, int stream, in
         if (out_next_id) *out_next_id = ni;
     });
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Reference-named exports (include/boxmot_compat.h): the exact symbol names, struct layouts and signatures of the
+// reference's native FFI, so that its own ctypes bindings load this library unchanged:
+//   boxmot_botsort_*    boxmot/native/cpp/trackers/botsort/include/botsort/c_api.hpp:17-61   (native/trackers/botsort.py:94-146)
+//   boxmot_bytetrack_*  boxmot/native/cpp/trackers/bytetrack/include/bytetrack/c_api.hpp:16-46
+//   boxmot_ocsort_*     boxmot/native/cpp/trackers/ocsort/include/ocsort/c_api.hpp:16-52
+//   boxmot_reid_capi_*  boxmot/native/cpp/trackers/base/include/boxmot/trackers/base/reid_capi.h:36-94
+// They are thin adapters over the boxmot_hip_* entry points above (float thresholds widened to double; the knobs the C++
+// reference hard-codes -- second/unconfirmed thresholds 0.5 / 0.7, embedding scale 2.0, tracker.cpp:435,465,476 -- at
+// those values; capacities from BOXMOT_HIP_MAX_TRACKS / BOXMOT_HIP_MAX_DETS, default 1024 / 512).
+// ---------------------------------------------------------------------------------------------------------------------
+// The embedding width is a create-time capacity of the device state; the reference learns it from the first embeddings it
+// sees.  The adapter therefore builds the inner handle at create when the width is known (ReID weights given: their feature
+// width; with_reid = 0: none needed) and otherwise at the first update that brings embeddings.
+struct BoxMOTBotSortHandle {
+    BoxMOTHipBotSortConfig cfg{};
+    std::string reid_path, reid_pre, cmc;
+    int empty_frames = 0;           // updates seen before the inner handle exists (they advance the frame counter, botsort.py:183)
+    BoxMOTHipBotSort* inner = nullptr;
+    ~BoxMOTBotSortHandle() { delete inner; }
+};
+struct BoxMOTByteTrackHandle { BoxMOTHipBotSort* inner = nullptr; ~BoxMOTByteTrackHandle() { delete inner; } };
+struct BoxMOTOCSORTHandle { BoxMOTHipDeepOcSort* inner = nullptr; ~BoxMOTOCSORTHandle() { delete inner; } };
+
+namespace {
+int env_int(const char* name, int dflt) {
+    const char* v = std::getenv(name);
+    if (!v || !*v) return dflt;
+    const int x = std::atoi(v);
+    return x > 0 ? x : dflt;
+}
+void compat_build_inner(BoxMOTBotSortHandle* h, int emb_dim) {
+    h->cfg.emb_dim = emb_dim;
+    h->cfg.reid_model_path = h->reid_path.empty() ? nullptr : h->reid_path.c_str();
+    h->cfg.reid_preprocess = h->reid_pre.empty() ? nullptr : h->reid_pre.c_str();
+    h->cfg.cmc_method = h->cmc.empty() ? nullptr : h->cmc.c_str();
+    BoxMOTHipBotSort* inner = boxmot_hip_botsort_create(&h->cfg);
+    if (!inner) throw std::runtime_error(g_last_error);
+    h->inner = inner;
+}
+// feature width declared in the header of an OSN1 weight blob (reid_layout.hpp)
+int blob_feature_dim(const std::string& path) {
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("cannot open ReID weight blob: " + path);
+    int32_t hdr[bm::REID_HEADER_INTS] = {0};
+    const size_t got = std::fread(hdr, 4, bm::REID_HEADER_INTS, f);
+    std::fclose(f);
+    if (got != (size_t)bm::REID_HEADER_INTS || hdr[0] != bm::REID_MAGIC)
+        throw std::runtime_error("ReID weights must be an OSN1 blob (boxmot_amd.reid_weights.save_blob): " + path);
+    return hdr[5];
+}
+}  // namespace
+
+BoxMOTBotSortHandle* boxmot_botsort_create(const BoxMOTBotSortConfig* c) {
+    BoxMOTBotSortHandle* h = nullptr;
+    const int ok = guard([&]() {
+        if (c == nullptr) throw std::runtime_error("BoTSORT config is required.");
+        require_device();
+        h = new BoxMOTBotSortHandle();
+        BoxMOTHipBotSortConfig& k = h->cfg;
+        boxmot_hip_botsort_default_config(&k);          // second 0.5, unconfirmed 0.7, scale 2.0, removed buffer 100
+        k.track_high_thresh = (double)c->track_high_thresh; k.track_low_thresh = (double)c->track_low_thresh;
+        k.new_track_thresh = (double)c->new_track_thresh; k.track_buffer = c->track_buffer;
+        k.match_thresh = (double)c->match_thresh; k.proximity_thresh = (double)c->proximity_thresh;
+        k.appearance_thresh = (double)c->appearance_thresh;
+        k.frame_rate = c->frame_rate; k.fuse_first_associate = c->fuse_first_associate; k.with_reid = c->with_reid ? 1 : 0;
+        k.max_obs = c->max_obs;
+        if (c->cmc_method) h->cmc = c->cmc_method;
+        if (c->reid_model_path) h->reid_path = c->reid_model_path;
+        if (c->reid_preprocess) h->reid_pre = c->reid_preprocess;
+        k.n_streams = 1; k.n_class_lists = 1; k.tracker_kind = 0;
+        k.max_tracks = env_int("BOXMOT_HIP_MAX_TRACKS", 1024);
+        k.max_dets = env_int("BOXMOT_HIP_MAX_DETS", 512);
+        if (!k.with_reid) compat_build_inner(h, 1);
+        else if (!h->reid_path.empty()) compat_build_inner(h, blob_feature_dim(h->reid_path));
+        // else: embeddings will be supplied by the caller; their width is known at the first update
+    });
+    if (!ok) { delete h; return nullptr; }
+    return h;
+}
+void boxmot_botsort_destroy(BoxMOTBotSortHandle* h) { delete h; }
+int boxmot_botsort_reset(BoxMOTBotSortHandle* h) {
+    if (h && !h->inner) { h->empty_frames = 0; return guard([]() {}); }
+    return boxmot_hip_botsort_reset(h ? h->inner : nullptr);
+}
+int boxmot_botsort_update(BoxMOTBotSortHandle* h, const float* dets, int det_rows, int det_cols, const float* embs,
+                          int emb_rows, int emb_cols, const uint8_t* image, int image_rows, int image_cols,
+                          int image_channels, float* out_tracks, int out_capacity_rows, int out_cols, int* out_rows,
+                          int* out_is_obb) {
+    if (h && !h->inner) {
+        const int ok = guard([&]() {
+            if (embs == nullptr || emb_cols <= 0) {
+                if (det_rows > 0) throw std::runtime_error("BoTSORT: with_reid is set, no ReID weights were given and no embeddings were supplied.");
+                return;
+            }
+            compat_build_inner(h, emb_cols);
+        });
+        if (!ok) return 0;
+        if (!h->inner) {        // nothing to track yet and no width known: an empty frame
+            h->empty_frames += 1;
+            if (out_rows) *out_rows = 0;
+            if (out_is_obb) *out_is_obb = 0;
+            return 1;
+        }
+        if (h->empty_frames > 0) {      // the frames that went by count (a first detection on frame > 1 is not activated at once)
+            const int fc = h->empty_frames;
+            h->empty_frames = 0;
+            return boxmot_hip_botsort_update_stream(h->inner, 0, 0, fc, dets, det_rows, det_cols, embs, emb_rows, emb_cols, image,
+                                                    image_rows, image_cols, image_channels, out_tracks, out_capacity_rows, out_cols,
+                                                    out_rows, out_is_obb);
+        }
+    }
+    return boxmot_hip_botsort_update(h ? h->inner : nullptr, dets, det_rows, det_cols, embs, emb_rows, emb_cols, image,
+                                     image_rows, image_cols, image_channels, out_tracks, out_capacity_rows, out_cols,
+                                     out_rows, out_is_obb);
+}
+#define BM_COMPAT_TIME(name, fn)                                                         \
+    int name(BoxMOTBotSortHandle* h, double* out) {                                      \
+        if (h && !h->inner) { if (out) *out = 0.0; return 1; }                           \
+        return fn(h ? h->inner : nullptr, out);                                          \
+    }
+BM_COMPAT_TIME(boxmot_botsort_last_reid_time_ms, boxmot_hip_botsort_last_reid_time_ms)
+BM_COMPAT_TIME(boxmot_botsort_last_reid_preprocess_time_ms, boxmot_hip_botsort_last_reid_preprocess_time_ms)
+BM_COMPAT_TIME(boxmot_botsort_last_reid_process_time_ms, boxmot_hip_botsort_last_reid_process_time_ms)
+BM_COMPAT_TIME(boxmot_botsort_last_reid_postprocess_time_ms, boxmot_hip_botsort_last_reid_postprocess_time_ms)
+#undef BM_COMPAT_TIME
+const char* boxmot_botsort_last_error() { return g_last_error.c_str(); }
+
+BoxMOTByteTrackHandle* boxmot_bytetrack_create(const BoxMOTByteTrackConfig* c) {
+    BoxMOTByteTrackHandle* h = nullptr;
+    const int ok = guard([&]() {
+        if (c == nullptr) throw std::runtime_error("ByteTrack config is required.");
+        BoxMOTHipBotSortConfig k;
+        boxmot_hip_bytetrack_default_config(&k);
+        k.track_low_thresh = (double)c->min_conf; k.track_high_thresh = (double)c->track_thresh;
+        k.new_track_thresh = (double)c->track_thresh;       // det_thresh = track_thresh, bytetrack.py:250
+        k.match_thresh = (double)c->match_thresh; k.track_buffer = c->track_buffer; k.frame_rate = c->frame_rate;
+        k.max_obs = c->max_obs;
+        k.max_tracks = env_int("BOXMOT_HIP_MAX_TRACKS", 1024);
+        k.max_dets = env_int("BOXMOT_HIP_MAX_DETS", 512);
+        h = new BoxMOTByteTrackHandle();
+        h->inner = boxmot_hip_botsort_create(&k);
+        if (!h->inner) throw std::runtime_error(g_last_error);
+    });
+    if (!ok) { delete h; return nullptr; }
+    return h;
+}
+void boxmot_bytetrack_destroy(BoxMOTByteTrackHandle* h) { delete h; }
+int boxmot_bytetrack_reset(BoxMOTByteTrackHandle* h) { return boxmot_hip_botsort_reset(h ? h->inner : nullptr); }
+int boxmot_bytetrack_update(BoxMOTByteTrackHandle* h, const float* dets, int det_rows, int det_cols, const uint8_t* image,
+                            int image_rows, int image_cols, int image_channels, float* out_tracks, int out_capacity_rows,
+                            int out_cols, int* out_rows, int* out_is_obb) {
+    return boxmot_hip_botsort_update(h ? h->inner : nullptr, dets, det_rows, det_cols, nullptr, 0, 0, image, image_rows,
+                                     image_cols, image_channels, out_tracks, out_capacity_rows, out_cols, out_rows, out_is_obb);
+}
+const char* boxmot_bytetrack_last_error() { return g_last_error.c_str(); }
+
+BoxMOTOCSORTHandle* boxmot_ocsort_create(const BoxMOTOCSORTConfig* c) {
+    BoxMOTOCSORTHandle* h = nullptr;
+    const int ok = guard([&]() {
+        if (c == nullptr) throw std::runtime_error("OCSORT config is required.");
+        BoxMOTHipDeepOcSortConfig k;
+        boxmot_hip_deepocsort_default_config(&k);
+        k.embedding_off = 1; k.cmc_off = 1; k.aw_off = 1;          // OC-SORT = this step without appearance / camera terms
+        k.min_conf = (double)c->min_conf; k.det_thresh = (double)c->det_thresh; k.iou_threshold = (double)c->iou_threshold;
+        k.max_age = c->max_age; k.min_hits = c->min_hits; k.delta_t = c->delta_t; k.use_byte = c->use_byte ? 1 : 0;
+        k.inertia = (double)c->inertia; k.Q_xy_scaling = (double)c->q_xy_scaling; k.Q_s_scaling = (double)c->q_s_scaling;
+        k.max_obs = c->max_obs;
+        k.max_tracks = env_int("BOXMOT_HIP_MAX_TRACKS", 1024);
+        k.max_dets = env_int("BOXMOT_HIP_MAX_DETS", 512);
+        h = new BoxMOTOCSORTHandle();
+        h->inner = boxmot_hip_deepocsort_create(&k);
+        if (!h->inner) throw std::runtime_error(g_last_error);
+    });
+    if (!ok) { delete h; return nullptr; }
+    return h;
+}
+void boxmot_ocsort_destroy(BoxMOTOCSORTHandle* h) { delete h; }
+int boxmot_ocsort_reset(BoxMOTOCSORTHandle* h) { return boxmot_hip_deepocsort_reset(h ? h->inner : nullptr); }
+int boxmot_ocsort_update(BoxMOTOCSORTHandle* h, const float* dets, int det_rows, int det_cols, const uint8_t* image,
+                         int image_rows, int image_cols, int image_channels, float* out_tracks, int out_capacity_rows,
+                         int out_cols, int* out_rows, int* out_is_obb) {
+    return boxmot_hip_deepocsort_update(h ? h->inner : nullptr, dets, det_rows, det_cols, nullptr, 0, 0, image, image_rows,
+                                        image_cols, image_channels, out_tracks, out_capacity_rows, out_cols, out_rows, out_is_obb);
+}
+const char* boxmot_ocsort_last_error() { return g_last_error.c_str(); }
+
+// ---- boxmot_reid_capi_* (reid_capi.h:36-94) ----
+// model_path: an OSN1 weight blob (the reference takes an ONNX file; this library reads the folded OSNet weights written by
+// boxmot_amd.reid_weights.save_blob).  preprocess NULL -> "resize_pad", the reference's default (reid_capi.h:33-34).
+// BOXMOT_HIP_REID_MODE selects the kernel family (0 per-layer fp32 = default, 1 fused fp16 MFMA), BOXMOT_HIP_REID_MAX_CROPS
+// the per-call capacity (default 1024).
+int boxmot_reid_capi_create(const char* model_path, const char* preprocess, void** out_handle) {
+    return guard([&]() {
+        if (out_handle == nullptr) throw std::runtime_error("out_handle is null.");
+        *out_handle = nullptr;
+        if (model_path == nullptr || !*model_path) throw std::runtime_error("ReID model path is required.");
+        BoxMOTHipReID* h = boxmot_hip_reid_create(model_path, nullptr, 0, env_int("BOXMOT_HIP_REID_MAX_CROPS", 1024));
+        if (!h) throw std::runtime_error(g_last_error);
+        const std::string err_keep;
+        if (!boxmot_hip_reid_set_preprocess(h, preprocess ? preprocess : "resize_pad")) {
+            const std::string e = g_last_error; delete h; throw std::runtime_error(e);
+        }
+        const char* m = std::getenv("BOXMOT_HIP_REID_MODE");
+        if (m && *m && !boxmot_hip_reid_set_mode(h, std::atoi(m))) { const std::string e = g_last_error; delete h; throw std::runtime_error(e); }
+        *out_handle = h;
+    });
+}
+void boxmot_reid_capi_destroy(void* handle) { delete static_cast<BoxMOTHipReID*>(handle); }
+int boxmot_reid_capi_feature_dim(void* handle, int* out_feature_dim) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("ReID handle is null.");
+        if (!out_feature_dim) throw std::runtime_error("out_feature_dim is null.");
+        *out_feature_dim = boxmot_hip_reid_feature_dim(static_cast<BoxMOTHipReID*>(handle));
+    });
+}
+int boxmot_reid_capi_compute_features(void* handle, const float* boxes_xyxy, int n_boxes, const uint8_t* image_data,
+                                      int image_rows, int image_cols, int image_channels, float* out_features,
+                                      int out_capacity_floats) {
+    BoxMOTHipReID* h = static_cast<BoxMOTHipReID*>(handle);
+    const int ok = guard([&]() {
+        if (!h) throw std::runtime_error("ReID handle is null.");
+        if (n_boxes > 0 && (long)out_capacity_floats < (long)n_boxes * h->engine->feature_dim())
+            throw std::runtime_error("Output feature buffer is too small.");
+    });
+    if (!ok) return 0;
+    // the reference takes any number of boxes per call: walk them in chunks of the engine's capacity
+    const int step = h->engine->max_crops(), dim = h->engine->feature_dim();
+    int i0 = 0;
+    do {
+        const int m = n_boxes - i0 < step ? n_boxes - i0 : step;
+        if (!boxmot_hip_reid_compute_features(h, image_data, image_rows, image_cols, image_channels, boxes_xyxy + (size_t)i0 * 4, m, 4,
+                                              out_features + (size_t)i0 * dim, m)) return 0;
+        i0 += m;
+    } while (i0 < n_boxes);
+    return 1;
+}
+// Staged calls: preprocess stages frame + boxes on the device and (per-layer path) writes the normalised crop blob into the
+// engine; process runs the forward pass into the handle's feature buffer (the head kernel already L2-normalises -- the
+// norm is idempotent); postprocess copies the rows out.  preprocess -> process -> postprocess == compute_features, bit for bit.
+int boxmot_reid_capi_preprocess(void* handle, const float* boxes_xyxy, int n_boxes, const uint8_t* image_data, int image_rows,
+                                int image_cols, int image_channels) {
+    BoxMOTHipReID* h = static_cast<BoxMOTHipReID*>(handle);
+    return guard([&]() {
+        if (!h) throw std::runtime_error("ReID handle is null.");
+        h->staged_n = -1;
+        reid_stage(h, image_data, image_rows, image_cols, image_channels, boxes_xyxy, n_boxes, 4);
+        h->staged_n = n_boxes; h->staged_rows = image_rows; h->staged_cols = image_cols; h->staged_done = false;
+    });
+}
+int boxmot_reid_capi_process(void* handle) {
+    BoxMOTHipReID* h = static_cast<BoxMOTHipReID*>(handle);
+    return guard([&]() {
+        if (!h) throw std::runtime_error("ReID handle is null.");
+        if (h->staged_n < 0) throw std::runtime_error("boxmot_reid_capi_process called before boxmot_reid_capi_preprocess.");
+        if (h->staged_n > 0) {
+            h->engine->run(h->d_frames, h->d_crop_stream, h->d_boxes, 4, h->staged_n, h->staged_cols, h->staged_rows, h->d_feat,
+                           nullptr, h->stream);
+            BM_HIP(hipStreamSynchronize(h->stream));
+        }
+        h->staged_done = true;
+    });
+}
+int boxmot_reid_capi_postprocess(void* handle, float* out_features, int out_capacity_floats) {
+    BoxMOTHipReID* h = static_cast<BoxMOTHipReID*>(handle);
+    return guard([&]() {
+        if (!h) throw std::runtime_error("ReID handle is null.");
+        if (h->staged_n < 0 || !h->staged_done) throw std::runtime_error("boxmot_reid_capi_postprocess called before boxmot_reid_capi_process.");
+        const long need = (long)h->staged_n * h->engine->feature_dim();
+        if ((long)out_capacity_floats < need) throw std::runtime_error("Output feature buffer is too small.");
+        if (need) BM_HIP(hipMemcpy(out_features, h->d_feat, (size_t)need * 4, hipMemcpyDeviceToHost));
+        h->staged_n = -1; h->staged_done = false;
+    });
+}
+const char* boxmot_reid_capi_last_error(void) { return g_last_error.c_str(); }
 
 }  // extern "C"
 

@@ -114,8 +114,9 @@ class DeepOcSort(BaseTracker):
             img_arr.ctypes.data, int(img_arr.shape[0]), int(img_arr.shape[1]),
             int(img_arr.shape[2]) if img_arr.ndim == 3 else 1,
             out.ctypes.data, int(out.shape[0]), 9, ctypes.byref(out_rows), ctypes.byref(out_is_obb))
+        if _lib.step_ran(ok):       # a per-stream status report (capacity, solver) is raised after the step has run
+            self.frame_count += 1
         _lib.check(ok)
-        self.frame_count += 1
         if out_rows.value == 0:
             return np.array([])                      # deepocsort.py:490-492 -> TrackResults of shape (0, 0)
         return out[: out_rows.value, :OUT_COLS].copy()

@@ -34,8 +34,9 @@ def shard_streams(n_streams_total: int, rank: int, world: int) -> list[int]:
 class MultiStreamBotSort:
     def __init__(self, n_streams: int, max_tracks: int = 1024, max_dets: int = 256, emb_dim: int = 512,
                  reid_weights=None, use_cmc: bool = False, **botsort_kwargs):
-        if use_cmc:
-            raise NotImplementedError("camera-motion compensation is not implemented on the HIP path")
+        # camera-motion compensation: the warp of a stream is supplied per frame with set_warp() (estimating it from the
+        # images is the caller's, as for BotSort(cmc=...)); use_cmc only documents the intent
+        self.use_cmc = bool(use_cmc)
         unknown = set(botsort_kwargs) - set(BOTSORT_KEYS)
         if unknown:
             raise TypeError(f"unknown BoT-SORT options: {sorted(unknown)}")
@@ -70,9 +71,10 @@ class MultiStreamBotSort:
         keep = []
         if imgs is not None:
             keep = [None if im is None else np.ascontiguousarray(im) for im in imgs]
-            first = next(im for im in keep if im is not None)
-            ir, ic = first.shape[0], first.shape[1]
-            img_ptrs = (ctypes.c_void_p * S)(*[None if im is None else im.ctypes.data for im in keep])
+            first = next((im for im in keep if im is not None), None)
+            if first is not None:       # every entry None: all streams keep their previously uploaded frame
+                ir, ic = first.shape[0], first.shape[1]
+                img_ptrs = (ctypes.c_void_p * S)(*[None if im is None else im.ctypes.data for im in keep])
         cap = max(int(rows.max()) if S else 0, 1)
         outs = [np.empty((cap, 9), dtype=np.float32) for _ in range(S)]
         out_ptrs = (ctypes.c_void_p * S)(*[o.ctypes.data for o in outs])
@@ -87,6 +89,17 @@ class MultiStreamBotSort:
                     d_out: int, d_out_rows: int) -> None:
         _lib.check(self._lib.boxmot_hip_botsort_step_device(
             self._handle, d_dets, d_det_rows, d_embs, d_frames, rows, cols, d_out, d_out_rows))
+
+    def set_warp(self, stream: int, warp_2x3) -> None:
+        """2x3 camera-motion warp (what the reference's ``cmc.apply(img, dets)`` returns) for the NEXT update_batch /
+        step_device of ``stream`` (STrack.multi_gmc, botsort_track.py:117-132); ``None`` clears a pending warp."""
+        if warp_2x3 is None:
+            _lib.check(self._lib.boxmot_hip_botsort_set_warp(self._handle, int(stream), None))
+            return
+        w = np.ascontiguousarray(np.asarray(warp_2x3, dtype=np.float64)[:2, :3])
+        if w.shape != (2, 3):
+            raise ValueError(f"warp shape {w.shape}, expected (2, 3)")
+        _lib.check(self._lib.boxmot_hip_botsort_set_warp(self._handle, int(stream), w.ctypes.data))
 
     def synchronize(self) -> None:
         _lib.check(self._lib.boxmot_hip_botsort_synchronize(self._handle))

@@ -61,6 +61,7 @@ class StrongSort(BaseTracker):
         cfg.n_streams, cfg.max_tracks, cfg.max_dets, cfg.emb_dim = 1, max_tracks, max_dets, self._emb_dim
         self._cfg = cfg
         self._max_tracks = max_tracks
+        self._n_tracks = 0          # len(self.tracker.tracks) after the last update (gates the camera-motion estimator)
         self._handle = self._lib.boxmot_hip_strongsort_create(ctypes.byref(cfg))
         if not self._handle:
             raise RuntimeError(_lib.last_error())
@@ -70,7 +71,9 @@ class StrongSort(BaseTracker):
         det_arr = np.ascontiguousarray(dets, dtype=np.float32)
         n = int(det_arr.shape[0])
         keep = det_arr[:, 4].astype(np.float64) >= self.min_conf if n else np.zeros(0, bool)      # strongsort.py:75
-        if self.cmc is not None:
+        if self.cmc is not None and self._n_tracks >= 1:
+            # strongsort.py:83-86: the estimator is asked only while tracks exist (it is stateful: its first call just
+            # stores the frame and returns the identity, ecc.py:45-96 -- calling it on other frames changes later warps)
             warp = np.ascontiguousarray(np.asarray(self.cmc.apply(img, det_arr[keep, :4].astype(np.float64)), dtype=np.float64)[:2, :3])
             _lib.check(self._lib.boxmot_hip_strongsort_set_warp(self._handle, 0, warp.ctypes.data))
         feats = None
@@ -93,14 +96,22 @@ class StrongSort(BaseTracker):
             img_arr.ctypes.data, int(img_arr.shape[0]), int(img_arr.shape[1]),
             int(img_arr.shape[2]) if img_arr.ndim == 3 else 1,
             out.ctypes.data, int(out.shape[0]), 9, ctypes.byref(out_rows), ctypes.byref(out_is_obb))
-        _lib.check(ok)
-        self.frame_count += 1
+        err = None if ok else _lib.last_error()
+        if _lib.step_ran(ok):       # a per-stream status report (capacity, solver) is raised after the step has run
+            self.frame_count += 1
+            if self.cmc is not None:
+                cnt = ctypes.c_int(0)
+                _lib.check(self._lib.boxmot_hip_strongsort_track_count(self._handle, 0, ctypes.byref(cnt)))
+                self._n_tracks = cnt.value
+        if err is not None:
+            raise RuntimeError(err)
         return out[: out_rows.value, :OUT_COLS].copy()
 
     def reset(self) -> None:
         # the reference's StrongSort.reset is a no-op (strongsort.py:125-126); the HIP handle does reset its tracks
         _lib.check(self._lib.boxmot_hip_strongsort_reset(self._handle))
         self.frame_count = 0
+        self._n_tracks = 0
         self._first_frame_processed = False
         self._first_dets_processed = False
 

@@ -58,6 +58,11 @@ def flatten_yaml_config(cfg: dict) -> dict:
 def create_tracker(tracker_type: str = "botsort", tracker_config=None, reid_weights=None, device=None, half=None,
                    per_class: bool = False, evolve_param_dict: dict | None = None, reid_preprocess=None,
                    reid_model=None, tracker_backend: str = "hip", **overrides):
+    """``overrides`` are constructor arguments laid over the YAML defaults.  Camera-motion compensation: the HIP trackers
+    apply a warp on the device but do not estimate it, so the reference's YAML defaults (BoT-SORT ``use_cmc=True``,
+    DeepOCSORT ``cmc_off=False``, StrongSORT's built-in ECC) need either ``cmc=<object with apply(img, dets) -> 2x3 warp>``
+    or ``use_cmc=False`` / ``cmc_off=True`` among the overrides; BoT-SORT / DeepOCSORT raise NotImplementedError otherwise
+    and StrongSORT warns that it runs with the identity warp (= the reference on a static camera)."""
     if tracker_backend != "hip":
         raise ValueError(f"tracker_backend={tracker_backend!r}: boxmot_amd provides the 'hip' backend only")
     if tracker_type not in SUPPORTED:
@@ -82,6 +87,12 @@ def create_tracker(tracker_type: str = "botsort", tracker_config=None, reid_weig
             from boxmot_amd.reid import HipReID
 
             reid_model = HipReID(reid_weights, preprocess=reid_preprocess)
+        if kwargs.get("cmc") is None:
+            import warnings
+
+            warnings.warn("boxmot_amd StrongSort: no cmc= estimator supplied; tracks get the identity camera warp (the reference "
+                          "always runs ECC, strongsort.py:67,83-86). Pass cmc=<object with apply(img, dets)> for moving cameras.",
+                          RuntimeWarning, stacklevel=2)
         return StrongSort(reid_model=reid_model, **kwargs)
     if tracker_type == "bytetrack":
         from boxmot_amd.bytetrack import ByteTrack

@@ -18,8 +18,10 @@
  *     tracker.cpp:435,465,476; the Python reference exposes them, botsort.py:81-85);
  *   - one handle owns n_streams independent trackers advanced by one launch set
  *     (boxmot_hip_botsort_update_batch / _step_device);
- *   - camera-motion compensation is not implemented: cmc_method must be NULL,
- *     "" or "none" (create fails otherwise).
+ *   - camera-motion compensation: the warp is APPLIED on the device (boxmot_hip_*_set_warp supplies the 2x3 matrix
+ *     the reference's cmc.apply() returns); estimating it from images is the caller's: cmc_method must be NULL,
+ *     "" or "none" (create fails otherwise);
+ *   - the reference's own symbol names and struct layouts are exported next to these (boxmot_compat.h).
  * There is no CPU fallback: every entry point fails with an error when no HIP
  * device is usable.
  */
@@ -41,7 +43,7 @@ typedef struct BoxMOTHipBotSortConfig {
     double match_thresh;
     double proximity_thresh;
     double appearance_thresh;
-    const char* cmc_method;          /* NULL / "" / "none" only */
+    const char* cmc_method;          /* NULL / "" / "none" only (the warp itself: boxmot_hip_botsort_set_warp) */
     int frame_rate;
     int fuse_first_associate;
     int with_reid;
@@ -144,7 +146,9 @@ int boxmot_hip_botsort_reid_kernel_ms(BoxMOTHipBotSort* handle, double* out_ms, 
  * stream of the launch: start, det prep, det features, pool lists, predict, cost, assignment, updates,
  * second association, unconfirmed, births, bookkeeping, end */
 int boxmot_hip_botsort_phase_clocks(BoxMOTHipBotSort* handle, long long* out16);
-/* per-stream status words (0 ok, 1 track capacity, 2 class capacity, 3 assignment stall) */
+/* per-stream status words (0 ok, 1 track capacity, 2 class capacity, 3 assignment stall).  The host-API updates report a
+ * non-zero word of their streams as an error once and clear it; the device-resident step leaves the words set until
+ * boxmot_hip_botsort_reset -- poll them here. */
 int boxmot_hip_botsort_status(BoxMOTHipBotSort* handle, int* out_status, int capacity);
 
 /* ReID weights from memory (same blob format as reid_model_path). */
@@ -318,6 +322,9 @@ int boxmot_hip_strongsort_update_batch(
 int boxmot_hip_strongsort_step_device(BoxMOTHipStrongSort* handle, const float* d_dets, const int* d_det_rows,
                                        const float* d_embs, float* d_out, int* d_out_rows);
 int boxmot_hip_strongsort_synchronize(BoxMOTHipStrongSort* handle);
+/* len(self.tracker.tracks) of `stream` (tentative + confirmed): the reference asks its camera-motion estimator for a warp only
+ * when this is >= 1 (strongsort.py:83-86), and that estimator is stateful -- a caller that owns one needs the same gate. */
+int boxmot_hip_strongsort_track_count(BoxMOTHipStrongSort* handle, int stream, int* out_tracks);
 /* parity debugging: tracks of `stream` in list order -- ints6 (rows,6) = id, state (1 tentative / 2 confirmed), hits, age,
  * time_since_update, sample-bank size; kf72 (rows,72) = mean[8] ++ cov[8][8]; feat (rows, emb_dim) fp32. */
 int boxmot_hip_strongsort_state_dump(BoxMOTHipStrongSort* handle, int stream, int* ints6, double* kf72, float* feat,

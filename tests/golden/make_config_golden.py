@@ -1,0 +1,106 @@
+"""Golden rows at the sizes of BASELINE.json's large configurations, from the REAL reference classes
+(/root/reference imported under the stand-ins of oracle/ref_harness.py).  Build container only:
+
+    python tests/golden/make_config_golden.py c5 [frames]     # StrongSORT, 256 dets x 1024 tracks x 1280-d, ~17 s per frame
+    python tests/golden/make_config_golden.py c2 [frames]     # BoT-SORT, 64 dets x 256 tracks, YAML defaults, embeddings supplied
+    python tests/golden/make_config_golden.py c2reid init|calib [frames]
+                                                              # the same with ReID INSIDE update: the reference BotSort asks the
+                                                              # reference OSNet-x0.25 (random-init / BN-calibrated weights) per frame
+
+The CPU reference needs about a quarter of a minute per frame at config 5 (a Python loop per track), far too slow to run beside
+the GPU test, so its per-frame output rows are committed instead (tests/golden/config5_strongsort_golden.npz: ids / det
+indices as int32, boxes and confidences as fp32; the inputs are regenerated from the seed by the test).  StrongSORT's
+assignment is SciPy's own (no stand-in on its path), so these rows are reference-exact.
+"""
+from __future__ import annotations
+
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+
+from boxmot_amd.scenario import Scenario  # noqa: E402
+from boxmot_amd.tracker_zoo import BOTSORT_YAML_DEFAULTS  # noqa: E402
+from oracle import ref_harness  # noqa: E402
+
+OUT = Path(__file__).resolve().parent
+
+
+def _save(name, rows_per_frame, extra):
+    counts = np.array([len(r) for r in rows_per_frame], dtype=np.int32)
+    rows = np.concatenate([np.asarray(r, dtype=np.float64).reshape(-1, 8) for r in rows_per_frame]) if counts.sum() else np.zeros((0, 8))
+    np.savez_compressed(OUT / name, counts=counts, boxes=rows[:, :4].astype(np.float32), ids=rows[:, 4].astype(np.int32),
+                        conf=rows[:, 5].astype(np.float32), cls=rows[:, 6].astype(np.int32), det_ind=rows[:, 7].astype(np.int32),
+                        **extra)
+
+
+def config5(frames: int):
+    StrongSort = ref_harness.load_strongsort()
+    sc = Scenario(256, 1024, emb_dim=1280, random_image=False)
+    img = np.zeros((2160, 3840, 3), dtype=np.uint8)
+    trk = StrongSort(reid_model=None)                 # constructor defaults: n_init 3, nn_budget 100, max_age 30
+    trk.cmc = ref_harness.IdentityCMC()               # stands where its unconditional ECC object stands (strongsort.py:67)
+    out = []
+    t0 = time.time()
+    for t in range(frames):
+        d, e = sc.frame(t)
+        r = np.asarray(trk.update(d, img, e.copy()), dtype=np.float64).reshape(-1, 8)
+        out.append(r)
+        if t % 10 == 0:
+            print(f"c5 frame {t}: {len(r)} rows, {time.time() - t0:.0f} s", flush=True)
+            _save("config5_strongsort_golden.npz", out, dict(frames=np.int32(len(out))))
+    _save("config5_strongsort_golden.npz", out, dict(frames=np.int32(len(out))))
+
+
+def config2(frames: int):
+    BotSort = ref_harness.load_botsort()
+    kw = {k: v for k, v in BOTSORT_YAML_DEFAULTS.items() if k not in ("use_cmc", "cmc_method")}
+    sc = Scenario(64, 256, emb_dim=512, random_image=False)
+    img = np.zeros((1080, 1920, 3), dtype=np.uint8)
+    trk = BotSort(reid_model=None, use_cmc=False, **kw)
+    out = []
+    for t in range(frames):
+        d, e = sc.frame(t)
+        out.append(np.asarray(trk.update(d, img, e.copy()), dtype=np.float64).reshape(-1, 8))
+    _save("config2_botsort_golden.npz", out, dict(frames=np.int32(frames)))
+
+
+def config2_reid(weights: str, frames: int):
+    """BASELINE.json config 2 exactly as bench.py runs it (64 dets x 256 tracks, 1080p random frame of stream 0, YAML
+    defaults, use_cmc=False, embs=None -> ReID inside update), on the reference classes: BotSort + BaseModelBackend
+    get_features + OSNet-x0.25 (cv2 / lap stand-ins as documented in oracle/ref_harness.py)."""
+    import torch
+
+    from boxmot_amd.reid_weights import random_osnet_state_dict, reference_init_state_dict
+
+    torch.set_num_threads(8)
+    sd = reference_init_state_dict("osnet_x0_25", seed=0) if weights == "init" else random_osnet_state_dict("osnet_x0_25", seed=0)
+    mod = ref_harness.load_osnet_module()
+    model = mod.osnet_x0_25(num_classes=1041, pretrained=False).eval()
+    missing = model.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys and all(k.startswith("classifier") for k in missing.missing_keys), missing
+    BotSort = ref_harness.load_botsort()
+    kw = {k: v for k, v in BOTSORT_YAML_DEFAULTS.items() if k not in ("use_cmc", "cmc_method")}
+    sc = Scenario(64, 256, emb_dim=512, stream=0, random_image=True)
+    trk = BotSort(reid_model=ref_harness.RefReID(model), use_cmc=False, **kw)
+    out = []
+    t0 = time.time()
+    for t in range(frames):
+        d, _ = sc.frame(t, with_embs=False)
+        out.append(np.asarray(trk.update(d, sc.image), dtype=np.float64).reshape(-1, 8))
+        if t % 20 == 0:
+            print(f"c2reid[{weights}] frame {t}: {len(out[-1])} rows, {time.time() - t0:.0f} s", flush=True)
+    _save(f"config2_reid_{weights}_golden.npz", out, dict(frames=np.int32(frames)))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1]
+    if which == "c2reid":
+        config2_reid(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 240)
+    else:
+        n = int(sys.argv[2]) if len(sys.argv) > 2 else 240
+        {"c5": config5, "c2": config2}[which](n)
