@@ -35,8 +35,23 @@ sys.path.insert(0, str(ROOT))
 
 N_DETS, N_TRACKS, WIDTH, HEIGHT, EMB_DIM = 64, 256, 1920, 1080, 512
 FLOP_PER_CROP = 2 * 82_314_880          # OSNet x0.25 forward, BASELINE.md section 2
-# HBM bytes per crop of the ReID launch set, from rocprofv3 FETCH_SIZE/WRITE_SIZE passes (profiles/r1h_pmc_traffic.txt: 1614 KiB)
-TRAFFIC_BYTES_PER_CROP = {0: None, 1: 1.65e6}
+# HBM bytes per crop of the fused ReID launch set: read from the committed rocprofv3 FETCH_SIZE / WRITE_SIZE summary named
+# here (separate --pmc passes, gfx950 FETCH correction applied by profiles/summarize_pmc.py) -- counters cannot be collected
+# inside a timed run, so the line carries the profile's figure and says which file it came from
+TRAFFIC_PROFILES = ("profiles/r2_pmc_traffic.txt", "profiles/r1h_pmc_traffic.txt")
+
+
+def profile_traffic_bytes_per_crop():
+    import re
+    for rel in TRAFFIC_PROFILES:
+        f = ROOT / rel
+        if f.exists():
+            m = re.search(r"->\s*([0-9.]+)\s*KB per crop", f.read_text())
+            if m:
+                return float(m.group(1)) * 1024.0, rel
+    return None, None
+
+
 PEAK_TFLOPS = {0: 157.3, 1: 2500.0}     # dense MFMA peak of the dtype the ReID kernels compute in (fp32 / fp16)
 DTYPE = {0: "f32", 1: "f16"}
 
@@ -47,14 +62,15 @@ def parse():
     ap.add_argument("--groups", type=int, default=1,
                     help="stream groups per GPU, each with its own handle and HIP stream (one group's tracker step overlaps "
                          "the other's ReID kernels)")
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=200)       # warm-up 40 frames, measure >= 200
+    ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--streams", type=int, default=256, help="streams per GPU")
     ap.add_argument("--mode", choices=("reid", "embs"), default="reid",
                     help="reid: ReID inside update (headline, M2); embs: embeddings supplied (tracker math only, M1)")
     ap.add_argument("--reid-mode", type=int, default=int(os.environ.get("BOXMOT_REID_MODE", "1")),
                     help="0: per-layer fp32 kernels, 1: fused fp16 MFMA kernels (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-m1", action="store_true", help="skip the tracker-math-only (embeddings supplied) side measurement")
     ap.add_argument("--cpu-frames", type=int, default=10)
     return ap.parse_args()
 
@@ -74,8 +90,17 @@ def cpu_baseline(sd, mode, n_frames):
     from oracle.osnet import OracleReID
 
     kw = {k: v for k, v in BOTSORT_YAML_DEFAULTS.items() if k not in ("use_cmc", "cmc_method")}
-    cores = min(os.cpu_count() or 1, 32)      # OSNet-x0.25 at batch 64 does not scale past ~32 threads
+    total_cores = os.cpu_count() or 1
+    cores = min(total_cores, 32)      # OSNet-x0.25 at batch 64 does not scale past ~32 threads
     torch.set_num_threads(cores)
+    cpu_model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     sc = Scenario(N_DETS, N_TRACKS, WIDTH, HEIGHT, EMB_DIM, stream=0, random_image=True)
     orc = BotSortOracle(reid=OracleReID(sd) if mode == "reid" else None, **kw)
     rows = []
@@ -95,8 +120,50 @@ def cpu_baseline(sd, mode, n_frames):
             break
     n_frames = max(done, 1)
     return dict(value=n_frames / max(t_timed, 1e-9), unit="frames/s", cores=cores, kind="port",
-                sample=f"oracle (NumPy/SciPy BoT-SORT + torch-CPU OSNet-x0.25, {cores} threads), stream 0, "
-                       f"{n_frames} steady-state frames after 3 confirmation frames, mode={mode}"), rows
+                cpu_model=cpu_model, host_cores_total=total_cores,
+                sample=f"oracle (NumPy/SciPy BoT-SORT, one Python thread + torch-CPU OSNet-x0.25 on {cores} threads), stream 0, "
+                       f"{n_frames} steady-state frames after 3 confirmation frames, mode={mode}; host = {cpu_model}, "
+                       f"{total_cores} logical cores"), rows
+
+
+def m1_tracker_only(kw, dev, rank):
+    """Side measurement (M1): tracker math only -- embeddings supplied, no ReID -- on 32 streams,
+    6 warm-up + 30 timed steps, inputs resident in HBM; reported with the HBM fraction of its algorithmic 1.68 MB per frame."""
+    import torch
+
+    from boxmot_amd.scenario import Scenario
+    from boxmot_amd.streams import MultiStreamBotSort
+    S1, W1, K1, nd = 32, 6, 30, N_TRACKS
+    T1 = W1 + K1
+    ms = MultiStreamBotSort(S1, max_tracks=2 * N_TRACKS, max_dets=nd, emb_dim=EMB_DIM, **kw)
+    dets_h = np.zeros((T1, S1, nd, 6), dtype=np.float32)
+    cnt_h = np.zeros((T1, S1), dtype=np.int32)
+    embs_h = np.zeros((T1, S1, nd, EMB_DIM), dtype=np.float32)
+    for s in range(S1):
+        sc = Scenario(N_DETS, N_TRACKS, WIDTH, HEIGHT, EMB_DIM, stream=rank * S1 + s, random_image=False)
+        for t in range(T1):
+            d, e = sc.frame(t)
+            dets_h[t, s, : len(d)] = d
+            cnt_h[t, s] = len(d)
+            embs_h[t, s, : len(d)] = e
+    d_dets, d_cnt, d_embs = (torch.from_numpy(x).to(dev) for x in (dets_h, cnt_h, embs_h))
+    d_out = torch.zeros((S1, nd, 8), dtype=torch.float32, device=dev)
+    d_out_n = torch.zeros(S1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    for t in range(W1):
+        ms.step_device(d_dets[t].data_ptr(), d_cnt[t].data_ptr(), d_embs[t].data_ptr(), None, HEIGHT, WIDTH, d_out.data_ptr(), d_out_n.data_ptr())
+    ms.synchronize()
+    ms.timer_start()
+    for t in range(W1, T1):
+        ms.step_device(d_dets[t].data_ptr(), d_cnt[t].data_ptr(), d_embs[t].data_ptr(), None, HEIGHT, WIDTH, d_out.data_ptr(), d_out_n.data_ptr())
+    dev_ms = ms.timer_stop_ms()
+    ms.synchronize()
+    assert (ms.status() == 0).all()
+    ms.close()
+    fps = S1 * K1 / (dev_ms * 1e-3)
+    gbs = fps * 1.68e6 / 1e9
+    return {"mode": "M1 embs-supplied (tracker math only)", "frames_per_s": fps, "streams": S1, "steps": K1, "ms_per_step": dev_ms / K1,
+            "kernel": "botsort_step_kernel", "algorithmic_bytes_per_frame": 1.68e6, "hbm_GBps": gbs, "hbm_frac_of_8TBps": gbs / 8000.0}
 
 
 def main():
@@ -234,10 +301,11 @@ def main():
         }
         if a.mode == "reid" and reid_ms > 0:
             tflops = n_first * FLOP_PER_CROP / (reid_ms * 1e-3) / 1e12
+            per_crop, traffic_src = profile_traffic_bytes_per_crop() if a.reid_mode == 1 else (None, None)
             res["roofline"] = {"bound": "mfma", "achieved": tflops, "peak": PEAK_TFLOPS[a.reid_mode], "unit": "TFLOP/s",
                                "frac": tflops / PEAK_TFLOPS[a.reid_mode],
-                               "traffic": (TRAFFIC_BYTES_PER_CROP[a.reid_mode] * n_first / max(reid_launches, 1)
-                                           if TRAFFIC_BYTES_PER_CROP[a.reid_mode] else None),
+                               "traffic": per_crop * n_first / max(reid_launches, 1) if per_crop else None,
+                               "traffic_source": traffic_src,
                                "kernel": "OSNet-x0.25 forward (ReID) region, HIP events on the launch stream",
                                "launch_ms": reid_ms / max(reid_launches, 1), "crops_per_launch": n_first / max(reid_launches, 1)}
         else:
@@ -245,7 +313,12 @@ def main():
             gbs = total_frames / world * bytes_per_frame / (dev_ms * 1e-3) / 1e9
             res["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
                                "traffic": None, "kernel": "botsort_step_kernel"}
-        if not a.no_cpu_baseline:
+        if world == 1 and a.mode == "reid" and not a.no_m1:
+            for m in groups:
+                m.close()
+            groups = []
+            res["tracker_math_m1"] = m1_tracker_only(kw, dev, rank)
+        if not a.no_cpu_baseline and world == 1:
             cb, rows = cpu_baseline(sd, a.mode, a.cpu_frames)
             res["cpu_baseline"] = cb
             # parity gate printed with the row: ids / det_ind / row order of stream 0 vs the oracle
@@ -265,7 +338,8 @@ def main():
                 hr.close()
                 res["config"]["reid_max_abs_err_vs_fp32_oracle"] = err
         print(json.dumps(res))
-    ms.close()
+    for m in groups:
+        m.close()
     if world > 1:
         dist.destroy_process_group()
 

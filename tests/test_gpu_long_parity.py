@@ -1,0 +1,249 @@
+"""Long parity runs at BASELINE.json's configuration sizes (>= 240 frames, SURVEY.md section 8(d): "run >= 240 frames so
+errors can compound"), and the ReID-inside-update paths of the three trackers.
+
+* config 2 exactly as bench.py runs it (BoT-SORT + OSNet-x0.25, 64 dets x 256 tracks, 1080p, YAML defaults, ReID inside
+  update through the device-resident step): ids / det indices / classes / confidences of 240 frames equal the rows the REAL
+  reference produced (tests/golden/config2_reid_*_golden.npz, made by tests/golden/make_config_golden.py from the reference
+  BotSort + reference OSNet); both ReID kernel families, random-init and BN-calibrated weights.
+* config 3 (DeepOCSORT, 128 x 512, 512-d) for 240 frames against the oracle, live.
+* config 5 (StrongSORT, 256 x 1024, 1280-d, sample banks filling to their budget of 100) for 240 frames against rows of
+  the real reference class (tests/golden/config5_strongsort_golden.npz; the CPU reference is too slow to run beside the test).
+* OSNet-x1.0 (config 3's backbone) on the device: embeddings vs the torch oracle, and DeepOCSORT / StrongSORT id parity
+  with the ReID engine inside update.
+"""
+import numpy as np
+import pytest
+
+from common import GOLDEN, assert_rows_match
+
+pytestmark = pytest.mark.gpu
+
+
+def _golden_frames(name):
+    g = np.load(GOLDEN / name)
+    offs = np.concatenate([[0], np.cumsum(g["counts"])])
+    rows = np.concatenate([g["boxes"], g["ids"][:, None].astype(np.float32), g["conf"][:, None], g["cls"][:, None].astype(np.float32),
+                           g["det_ind"][:, None].astype(np.float32)], axis=1).astype(np.float32)
+    return [rows[offs[i]:offs[i + 1]] for i in range(len(g["counts"]))]
+
+
+@pytest.mark.parametrize("weights,mode", [("init", 1), ("calib", 0), ("calib", 1), ("init", 0)])
+def test_long_config2_reid_inside_update_240_frames_vs_reference_rows(weights, mode):
+    """The benchmarked configuration, as benchmarked (device-resident frame, crop list built on the device, fused or per-layer
+    ReID kernels, one tracker step per frame), for 240 frames.  `calib` + mode 1 runs the fp16 kernels on the noise-amplifying
+    BN-calibrated network (embeddings within ~5e-3 of fp32 there): ids are still the reference's."""
+    import torch
+
+    from boxmot_amd.reid_weights import random_osnet_state_dict, reference_init_state_dict
+    from boxmot_amd.scenario import Scenario
+    from boxmot_amd.streams import MultiStreamBotSort
+    from boxmot_amd.tracker_zoo import BOTSORT_YAML_DEFAULTS
+    want = _golden_frames(f"config2_reid_{weights}_golden.npz")
+    assert len(want) >= 240
+    sd = reference_init_state_dict("osnet_x0_25", seed=0) if weights == "init" else random_osnet_state_dict("osnet_x0_25", seed=0)
+    kw = {k: v for k, v in BOTSORT_YAML_DEFAULTS.items() if k not in ("use_cmc", "cmc_method")}
+    nd = 256
+    sc = Scenario(64, 256, emb_dim=512, stream=0, random_image=True)
+    ms = MultiStreamBotSort(1, max_tracks=512, max_dets=nd, emb_dim=512, reid_weights=sd, **kw)
+    ms.set_reid_mode(mode)
+    dev = torch.device("cuda:0")
+    frame = torch.from_numpy(sc.image).to(dev)
+    ptrs = torch.tensor([frame.data_ptr()], dtype=torch.int64, device=dev)
+    d_dets = torch.zeros((1, nd, 6), dtype=torch.float32, device=dev)
+    d_n = torch.zeros(1, dtype=torch.int32, device=dev)
+    d_out = torch.zeros((1, nd, 8), dtype=torch.float32, device=dev)
+    d_out_n = torch.zeros(1, dtype=torch.int32, device=dev)
+    for t in range(240):
+        dets, _ = sc.frame(t, with_embs=False)
+        d_dets[0, : len(dets)] = torch.from_numpy(dets).to(dev)
+        d_n[0] = len(dets)
+        torch.cuda.synchronize()
+        ms.step_device(d_dets.data_ptr(), d_n.data_ptr(), None, ptrs.data_ptr(), sc.height, sc.width, d_out.data_ptr(), d_out_n.data_ptr())
+        ms.synchronize()
+        got = d_out[0, : int(d_out_n[0])].cpu().numpy()
+        assert_rows_match(got, want[t], t, box_atol=2e-3)
+    assert ms.status().tolist() == [0]
+    st = ms.state_dump(0, 0)
+    assert st["id_count"] == 256 and st["frame_count"] == 240
+    ms.close()
+
+
+def test_long_config3_deepocsort_128x512_240_frames():
+    from boxmot_amd import DeepOcSort
+    from boxmot_amd.scenario import Scenario
+    from oracle.deepocsort import DeepOcSortOracle
+    sc = Scenario(128, 512, emb_dim=512, random_image=False)
+    img = np.zeros((1080, 1920, 3), dtype=np.uint8)
+    trk = DeepOcSort(cmc_off=True, emb_dim=512, max_tracks=1024, max_dets=512)
+    orc = DeepOcSortOracle(lap_rule="lowest_index")       # the device's choice among exactly tied optima
+    rows = 0
+    for t in range(240):
+        d, e = sc.frame(t)
+        got = np.asarray(trk.update(d, img, e)).reshape(-1, 8)
+        assert_rows_match(got, np.asarray(orc.update(d, img, e.copy()), dtype=np.float32).reshape(-1, 8), t, box_atol=1e-3)
+        rows += len(got)
+    assert rows >= 512 + 230 * 96
+    st, od = trk.state_dump(), orc.dump()
+    assert np.array_equal(st["ints"][:, 0], od["id"])
+    assert np.allclose(st["kf"][:, :7], od["x"], rtol=1e-8, atol=1e-8)
+    trk.close()
+
+
+def test_long_config5_strongsort_256x1024_1280d_240_frames_vs_reference_rows():
+    """Persistent objects (192 of the 256 detections of a frame) reach their sample-bank budget of 100 after 103 frames: the
+    last 137 frames run the bank distance with full banks."""
+    from boxmot_amd import StrongSort
+    from boxmot_amd.scenario import Scenario
+    want = _golden_frames("config5_strongsort_golden.npz")
+    assert len(want) >= 240
+    sc = Scenario(256, 1024, emb_dim=1280, random_image=False)
+    img = np.zeros((2160, 3840, 3), dtype=np.uint8)
+    trk = StrongSort(emb_dim=1280, max_tracks=2048, max_dets=1024)
+    for t in range(240):
+        d, e = sc.frame(t)
+        got = np.asarray(trk.update(d, img, e)).reshape(-1, 8)
+        assert_rows_match(got, want[t], t, box_atol=2e-3)
+    st = trk.state_dump()
+    assert st["ints"][:, 5].max() == 100                  # sample banks at their budget
+    trk.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# OSNet-x1.0 (BASELINE.json config 3's backbone) and ReID inside DeepOCSORT / StrongSORT updates
+# ---------------------------------------------------------------------------------------------------------------------
+def _boxes(rng, n, w, h):
+    b = np.stack([rng.uniform(0, w - 130, n), rng.uniform(0, h - 190, n), np.zeros(n), np.zeros(n)], 1).astype(np.float32)
+    b[:, 2] = b[:, 0] + rng.uniform(20, 120, n)
+    b[:, 3] = b[:, 1] + rng.uniform(40, 180, n)
+    return b
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_osnet_x1_0_features_on_device_vs_oracle(seed):
+    """x1.0 widths (64/256/384/512) through the per-layer fp32 kernels, BN-calibrated weights: <= 1e-3 (measured ~1e-5)."""
+    from boxmot_amd.reid import HipReID
+    from boxmot_amd.reid_weights import random_osnet_state_dict
+    from oracle.osnet import OracleReID
+    sd = random_osnet_state_dict("osnet_x1_0", seed=seed)
+    img = np.random.default_rng(17).integers(0, 255, (720, 1280, 3), dtype=np.uint8)
+    boxes = np.concatenate([_boxes(np.random.default_rng(seed), 10, 1280, 720),
+                            np.array([[-10, -5, 60, 120], [1200, 650, 1300, 740], [100, 100, 100, 150]], dtype=np.float32)])
+    reid = HipReID(sd, max_crops=8)                       # 13 boxes -> two chunks
+    assert reid.feature_dim == 512
+    got = reid.get_features(boxes, img)
+    want = OracleReID(sd).get_features(boxes, img)
+    err = float(np.abs(got - want).max())
+    print(f"osnet_x1_0 seed {seed}: max|diff| = {err:.2e}")
+    assert err < 1e-3
+    assert np.allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-5)
+    with pytest.raises(RuntimeError, match="x0.25"):
+        reid.set_mode(1)                                  # the fused fp16 kernels exist for x0.25 only: loud, not silent
+    reid.close()
+
+
+def test_deepocsort_with_osnet_x1_0_inside_update_matches_oracle_ids():
+    """embs=None: DeepOcSort asks its ReID model for every detection above det_thresh (deepocsort.py:337-345)."""
+    from boxmot_amd import DeepOcSort
+    from boxmot_amd.reid import HipReID
+    from boxmot_amd.reid_weights import random_osnet_state_dict
+    from boxmot_amd.scenario import Scenario
+    from oracle.deepocsort import DeepOcSortOracle
+    from oracle.osnet import OracleReID
+    sd = random_osnet_state_dict("osnet_x1_0", seed=0)
+    sc = Scenario(12, 24, width=960, height=540, random_image=True)
+    reid = HipReID(sd, max_crops=32)
+    trk = DeepOcSort(reid_model=reid, cmc_off=True, max_tracks=128, max_dets=64)
+    orc = DeepOcSortOracle(reid=OracleReID(sd), lap_rule="lowest_index")
+    for t in range(14):
+        dets, _ = sc.frame(t, with_embs=False)
+        got = np.asarray(trk.update(dets, sc.image)).reshape(-1, 8)
+        want = np.asarray(orc.update(dets, sc.image), dtype=np.float32).reshape(-1, 8)
+        assert_rows_match(got, want, t, box_atol=1e-3)
+    st, od = trk.state_dump(), orc.dump()
+    assert np.array_equal(st["ints"][:, 0], od["id"])
+    trk.close()
+    reid.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_strongsort_with_reid_inside_update_matches_oracle_ids(mode):
+    """embs=None: StrongSort asks its ReID model for every detection with conf >= min_conf (strongsort.py:88-91)."""
+    from boxmot_amd import StrongSort
+    from boxmot_amd.reid import HipReID
+    from boxmot_amd.reid_weights import random_osnet_state_dict, reference_init_state_dict
+    from boxmot_amd.scenario import Scenario
+    from oracle.osnet import OracleReID
+    from oracle.strongsort import StrongSortOracle
+    sd = random_osnet_state_dict("osnet_x0_25", seed=0) if mode == 0 else reference_init_state_dict("osnet_x0_25", seed=0)
+    sc = Scenario(12, 24, width=960, height=540, random_image=True)
+    reid = HipReID(sd, max_crops=32, mode=mode)
+    trk = StrongSort(reid_model=reid, max_tracks=128, max_dets=64)
+    orc = StrongSortOracle(reid=OracleReID(sd))
+    for t in range(16):
+        dets, _ = sc.frame(t, with_embs=False)
+        got = np.asarray(trk.update(dets, sc.image)).reshape(-1, 8)
+        want = np.asarray(orc.update(dets, sc.image), dtype=np.float32).reshape(-1, 8)
+        assert_rows_match(got, want, t, box_atol=1e-3)
+    trk.close()
+    reid.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_deepocsort_with_reid_inside_update_both_kernel_families(mode):
+    from boxmot_amd import DeepOcSort
+    from boxmot_amd.reid import HipReID
+    from boxmot_amd.reid_weights import random_osnet_state_dict, reference_init_state_dict
+    from boxmot_amd.scenario import Scenario
+    from oracle.deepocsort import DeepOcSortOracle
+    from oracle.osnet import OracleReID
+    sd = random_osnet_state_dict("osnet_x0_25", seed=0) if mode == 0 else reference_init_state_dict("osnet_x0_25", seed=0)
+    sc = Scenario(12, 24, width=960, height=540, random_image=True)
+    reid = HipReID(sd, max_crops=32, mode=mode)
+    trk = DeepOcSort(reid_model=reid, cmc_off=True, max_tracks=128, max_dets=64)
+    orc = DeepOcSortOracle(reid=OracleReID(sd), lap_rule="lowest_index")
+    for t in range(16):
+        dets, _ = sc.frame(t, with_embs=False)
+        got = np.asarray(trk.update(dets, sc.image)).reshape(-1, 8)
+        want = np.asarray(orc.update(dets, sc.image), dtype=np.float32).reshape(-1, 8)
+        assert_rows_match(got, want, t, box_atol=1e-3)
+    trk.close()
+    reid.close()
+
+
+def test_stateful_cmc_is_asked_only_while_tracks_exist():
+    """strongsort.py:83-86: `if len(self.tracker.tracks) >= 1: warp = self.cmc.apply(...)`.  The reference's ECC object is
+    stateful (first call stores the frame and returns the identity), so WHICH frames it sees decides later warps: a stub
+    that counts its calls and returns a call-dependent warp must be driven identically by the HIP tracker and the oracle."""
+    from boxmot_amd import StrongSort
+    from boxmot_amd.scenario import stress_frames
+    from oracle.strongsort import StrongSortOracle
+
+    class StatefulCMC:
+        def __init__(self):
+            self.calls = []
+            self.prev = None
+
+        def apply(self, img, dets):
+            self.calls.append(len(dets))
+            if self.prev is None:                # like ECC.apply: the first call only stores the frame
+                self.prev = True
+                return np.eye(2, 3)
+            k = len(self.calls)
+            return np.array([[1.0, 0.001 * (k % 3), 0.7 * ((k % 5) - 2)], [-0.001 * (k % 3), 1.0, 0.4 * ((k % 4) - 1.5)]])
+
+    img = np.zeros((480, 640, 3), dtype=np.uint8)
+    frames = stress_frames(60, seed=21)
+    # leading empty frames and a gap: no tracks exist there, the estimator must not be called
+    empty = (np.empty((0, 6), dtype=np.float32), np.empty((0, 32), dtype=np.float32))
+    frames = [empty, empty] + frames[:20] + [empty] * 40 + frames[20:]
+    cmc_hip, cmc_orc = StatefulCMC(), StatefulCMC()
+    trk = StrongSort(cmc=cmc_hip, emb_dim=32, max_tracks=128, max_dets=64)
+    orc = StrongSortOracle()
+    for t, (d, e) in enumerate(frames):
+        got = np.asarray(trk.update(d, img, e)).reshape(-1, 8)
+        keep = d[:, 4].astype(np.float64) >= 0.1 if len(d) else np.zeros(0, bool)      # min_conf default (strongsort.py:75)
+        warp = cmc_orc.apply(img, d[keep, :4]) if len(orc.tracks) >= 1 else None
+        want = np.asarray(orc.update(d, img, e.copy(), warp=warp), dtype=np.float32).reshape(-1, 8)
+        assert_rows_match(got, want, t, box_atol=1e-3)
+    assert cmc_hip.calls == cmc_orc.calls and 0 < len(cmc_hip.calls) < len(frames)
+    trk.close()

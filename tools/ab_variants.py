@@ -36,24 +36,38 @@ def build():
         subprocess.check_call(cmd)
 
 
-def run():
-    for name in VARIANTS:
-        lib = OUT / f"libboxmot_hip_{name}.so"
-        if not lib.exists():
-            print(f"{name}: not built")
+def run(with_tests: bool = False, rounds: int = 1, only=None):
+    """Interleaved rounds (variant order repeated) so that clock / thermal drift does not read as a kernel property."""
+    results = {name: [] for name in VARIANTS}
+    parity = {}
+    for r in range(rounds):
+        for name in VARIANTS:
+            lib = OUT / f"libboxmot_hip_{name}.so"
+            if not lib.exists() or (only and name not in only):
+                continue
+            env = dict(os.environ, BOXMOT_HIP_LIB=str(lib))
+            if with_tests and r == 0:
+                t = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_reid.py", "-x", "-q"], cwd=ROOT, env=env,
+                                   capture_output=True, text=True)
+                parity[name] = t.returncode == 0
+            b = subprocess.run([sys.executable, "bench.py", "--no-cpu-baseline", "--steps", "30", "--warmup", "8"], cwd=ROOT, env=env,
+                               capture_output=True, text=True)
+            line = b.stdout.strip().splitlines()[-1] if b.stdout.strip() else "{}"
+            try:
+                d = json.loads(line)
+                results[name].append((d["value"], d["roofline"]["launch_ms"], d.get("parity_ids_exact_vs_oracle_stream0"),
+                                      d.get("reid_max_abs_err_vs_fp32_oracle")))
+            except Exception:
+                print(f"{name:12s} bench failed: {b.stderr[-300:]}", flush=True)
+    for name, rs in results.items():
+        if not rs:
+            print(f"{name}: not built / no result")
             continue
-        env = dict(os.environ, BOXMOT_HIP_LIB=str(lib))
-        t = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_reid.py", "-x", "-q"], cwd=ROOT, env=env,
-                           capture_output=True, text=True)
-        ok = t.returncode == 0
-        b = subprocess.run([sys.executable, "bench.py", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True)
-        line = b.stdout.strip().splitlines()[-1] if b.stdout.strip() else "{}"
-        try:
-            d = json.loads(line)
-            print(f"{name:12s} parity={'ok' if ok else 'FAIL'} frames/s={d['value']:.0f} reid_launch_ms={d['roofline']['launch_ms']:.3f}", flush=True)
-        except Exception:
-            print(f"{name:12s} parity={'ok' if ok else 'FAIL'} bench failed: {b.stderr[-300:]}", flush=True)
+        fps = " ".join(f"{v:.0f}" for v, _, _, _ in rs)
+        ms = " ".join(f"{m:.3f}" for _, m, _, _ in rs)
+        print(f"{name:12s} frames/s [{fps}]  reid_launch_ms [{ms}]  ids_exact={rs[0][2]} emb_err={rs[0][3]}"
+              + (f" reid_tests={'ok' if parity.get(name) else 'FAIL'}" if name in parity else ""), flush=True)
 
 
 if __name__ == "__main__":
-    {"build": build, "run": run}[sys.argv[1] if len(sys.argv) > 1 else "run"]()
+    {"build": build, "run": lambda: run(only=sys.argv[2:] or None), "run_tests": lambda: run(True)}[sys.argv[1] if len(sys.argv) > 1 else "run"]()
