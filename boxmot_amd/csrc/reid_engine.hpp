@@ -21,6 +21,9 @@
 #ifndef BM_STAGE1_HANDOVER
 #define BM_STAGE1_HANDOVER 0
 #endif
+#ifndef BM_HEAD_PER_CROP
+#define BM_HEAD_PER_CROP 0          // 1: the round-1 head (one workgroup of two waves per crop) instead of k_head_batched
+#endif
 
 namespace bm {
 
@@ -338,6 +341,7 @@ private:
         allow_lds(k_osblock<1, 96, false, true>, Geo<1>::LDS_BYTES);
         allow_lds(k_osblock<2, 96, true, false>, Geo<2>::LDS_BYTES);
         allow_lds(k_osblock<2, 128, false, false>, Geo<2>::LDS_BYTES);
+        allow_lds(k_head_batched<128, 512>, HeadGeo<128>::LDS_BYTES);
         fused_ready_ = true;
     }
     struct FrameArgs { const uint8_t* const* frames; const int* crop_stream; const float* boxes; int box_stride, W, H; };
@@ -372,7 +376,12 @@ private:
 #endif
         blk(k_osblock<2, 96, true, false>, Geo<2>::NWAVES, Geo<2>::LDS_BYTES, s2_in, s2_mid, 4, nullptr, BlkLink{});
         blk(k_osblock<2, 128, false, false>, Geo<2>::NWAVES, Geo<2>::LDS_BYTES, s2_mid, s2_in, 5, nullptr, BlkLink{});
+#if BM_HEAD_PER_CROP
         hipLaunchKernelGGL((k_head_fused<128, 512>), dim3(n), dim3(128), 0, st, s2_in, w_c5_, w_fc_, d_out, d_out_rows, d_count_);
+#else
+        hipLaunchKernelGGL((k_head_batched<128, 512>), dim3((n + HEAD_NB - 1) / HEAD_NB), dim3(256), HeadGeo<128>::LDS_BYTES, st, s2_in,
+                           w_c5_, w_fc_, d_out, d_out_rows, d_count_, n);
+#endif
     }
     void alloc_buffers() {
         const size_t n = (size_t)max_crops_;

@@ -677,6 +677,154 @@ __global__ void __launch_bounds__(128) k_head_fused(const _Float16* __restrict__
 }
 
 // ---------------------------------------------------------------------------
+// Batched head (the shipped one): the same computation as k_head_fused for NB = 16 crops per workgroup of 4 waves.
+//   * conv5: wave w owns output-channel tiles 2w, 2w+1 for every pixel tile and keeps their 8 A fragments in registers for
+//     all 16 crops; a crop's input (32 KiB) is staged once into LDS (16-byte slots XOR-swizzled by the pixel so that the
+//     16 pixels of a B-fragment read spread over the banks) while the previous crop computes (loads issued before, LDS
+//     writes after the MFMAs); bias + ReLU + global average in fp32 registers.
+//   * FC 128 -> 512 for the 16 crops at once on the matrix pipe: M = feature, N = crop, K = channel; the pooled vector
+//     enters as an fp16 hi + lo pair (two MFMAs per k-step: fp32-grade operand, the weights are the fp16 ones of
+//     k_head_fused), + bias, ReLU, L2 normalisation over the 512 features (per crop = per accumulator column).
+// k_head_fused keeps 2 waves per crop at 256 + 110 registers (one wave per SIMD, 0.64 ms per 16384 crops); this one runs
+// two workgroups per CU with the FC as a real 16-column MFMA tile.
+// ---------------------------------------------------------------------------
+constexpr int HEAD_NB = 16;
+template <int C>
+struct HeadGeo {
+    static constexpr int CROP_BYTES = 128 * C * 2;
+    static constexpr int VSTRIDE = C + 4;                       // floats per pooled vector in LDS (+4: bank spread, 16-byte rows)
+    static constexpr int LDS_BYTES = 2 * CROP_BYTES + HEAD_NB * VSTRIDE * 4 + 4 * HEAD_NB * 4;
+};
+
+template <int C, int F>
+__global__ void __launch_bounds__(256, 2) k_head_batched(const _Float16* __restrict__ in, const unsigned char* __restrict__ wts5,
+                                                         const unsigned char* __restrict__ wfc, float* __restrict__ out_base,
+                                                         const int* __restrict__ out_rows, const int* __restrict__ count, int n_total) {
+    static_assert(C == 128 && F % 64 == 0, "head: 128 channels in, a multiple of 64 features out");
+    constexpr int NCT = C / 16, KS = C / 32, P = 128, NB = HEAD_NB, CROP_BYTES = HeadGeo<C>::CROP_BYTES, VS = HeadGeo<C>::VSTRIDE;
+    constexpr int FT_PER_WAVE = F / 16 / 4;
+    BM_DYNAMIC_LDS_T(unsigned char, lds);
+    float* vbuf = reinterpret_cast<float*>(lds + 2 * CROP_BYTES);          // [NB][VS] pooled vectors (L-layout channel order)
+    float* red = vbuf + NB * VS;                                            // [4 waves][NB]
+    int n_eff = n_total;
+    if (count) { const int c = *count; n_eff = c < n_total ? c : n_total; }
+    const long crop0 = (long)blockIdx.x * NB;
+    if (crop0 >= n_eff) return;
+    const int nb = n_eff - crop0 < NB ? (int)(n_eff - crop0) : NB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l16 = lane & 15;
+    const unsigned char* bias5 = wts5 + NCT * KS * 1024;
+    h8 a[2][KS];
+    f4 bias[2];
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2) {
+        const int ct = 2 * wave + c2;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) a[c2][ks] = *reinterpret_cast<const h8*>(wts5 + ((ct * KS + ks) * 64 + lane) * 16);
+        bias[c2] = *reinterpret_cast<const f4*>(bias5 + (16 * ct + 4 * g) * 4);
+    }
+    for (int e = tid; e < NB * VS; e += 256) vbuf[e] = 0.f;                 // rows of absent crops stay zero
+    // staging: thread t moves the 16-byte slots t, t + 256, ... of a crop; slot q = (pixel q >> 4, slot q & 15)
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    u4 st[CROP_BYTES / 16 / 256];
+    auto stage_load = [&](int k) {
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(in + (crop0 + k) * (long)(P * C));
+#pragma unroll
+        for (int j = 0; j < CROP_BYTES / 16 / 256; ++j) st[j] = *reinterpret_cast<const u4*>(src + (size_t)(tid + 256 * j) * 16);
+    };
+    auto stage_store = [&](int b) {
+#pragma unroll
+        for (int j = 0; j < CROP_BYTES / 16 / 256; ++j) {
+            const int q = tid + 256 * j, p = q >> 4, slot = q & 15;
+            *reinterpret_cast<u4*>(lds + b * CROP_BYTES + p * (C * 2) + ((slot ^ (p & 15)) << 4)) = st[j];
+        }
+    };
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+#pragma unroll 1
+    for (int k = 0; k < nb; ++k) {
+        if (k + 1 < nb) stage_load(k + 1);
+        const unsigned char* buf = lds + (k & 1) * CROP_BYTES;
+        f4 sum[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int i = 0; i < P / 16; ++i) {
+            const int p = i * 16 + l16;
+            h8 b[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) b[ks] = *reinterpret_cast<const h8*>(buf + p * (C * 2) + (((g * KS + ks) ^ (p & 15)) << 4));
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                f4 acc = bias[c2];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) acc = BM_MFMA_F16_K32(a[c2][ks], b[ks], acc);
+                acc = relu4(acc);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sum[c2][r] += acc[r];
+            }
+        }
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = sum[c2][r];
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                if (l16 == 0) vbuf[k * VS + g * (C / 4) + 4 * (2 * wave + c2) + r] = v * (1.0f / P);
+            }
+        if (k + 1 < nb) stage_store((k + 1) & 1);
+        __syncthreads();
+    }
+    // ---- FC + BN1d (folded) + ReLU for the NB crops: D[f][crop] = sum_c W[f][c] * v[crop][c] ----
+    const float* fcb = reinterpret_cast<const float*>(wfc + (long)F * C * 2);
+    const _Float16* fcw = reinterpret_cast<const _Float16*>(wfc);
+    h8 vh[KS], vl[KS];          // this lane's k-slots of crop l16: channels 32 ks + 8 g + j (memory order), hi + lo parts
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const f4 v0 = *reinterpret_cast<const f4*>(vbuf + l16 * VS + 32 * ks + 8 * g);
+        const f4 v1 = *reinterpret_cast<const f4*>(vbuf + l16 * VS + 32 * ks + 8 * g + 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = j < 4 ? v0[j & 3] : v1[j & 3];
+            const _Float16 hi = (_Float16)v;
+            vh[ks][j] = hi;
+            vl[ks][j] = (_Float16)(v - (float)hi);
+        }
+    }
+    f4 vals[FT_PER_WAVE];
+    float sq = 0.f;
+#pragma unroll
+    for (int fi = 0; fi < FT_PER_WAVE; ++fi) {
+        const int ft = wave * FT_PER_WAVE + fi;
+        f4 acc = *reinterpret_cast<const f4*>(fcb + 16 * ft + 4 * g);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const h8 w = *reinterpret_cast<const h8*>(fcw + (long)(16 * ft + l16) * C + 32 * ks + 8 * g);
+            acc = BM_MFMA_F16_K32(w, vh[ks], acc);
+            acc = BM_MFMA_F16_K32(w, vl[ks], acc);
+        }
+        acc = relu4(acc);
+        vals[fi] = acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sq += acc[r] * acc[r];
+    }
+    sq += __shfl_xor(sq, 16, 64);
+    sq += __shfl_xor(sq, 32, 64);
+    if (lane < 16) red[wave * NB + l16] = sq;
+    __syncthreads();
+    const float nrm = sqrtf(red[l16] + red[NB + l16] + red[2 * NB + l16] + red[3 * NB + l16]);
+    if (l16 < nb) {
+        float* out = out_base + (out_rows ? (long)out_rows[crop0 + l16] : crop0 + l16) * F;
+#pragma unroll
+        for (int fi = 0; fi < FT_PER_WAVE; ++fi) {
+            const int ft = wave * FT_PER_WAVE + fi;
+            f4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = vals[fi][r] / nrm;
+            *reinterpret_cast<f4*>(out + 16 * ft + 4 * g) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // stem: conv 7x7 stride 2 pad 3 (3 -> 16) + BN + ReLU + maxpool 3x3 stride 2 pad 1
 // (osnet.py:294-295).  Input: fp16 RGBX crops with a 3-pixel zero border,
 // [n][262][136][4]; output [n][64*32][16] lane-group-major.  One workgroup

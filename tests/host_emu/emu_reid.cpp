@@ -16,6 +16,7 @@ EmuDim3 blockDim;
 EmuBlock* g_emu_block = nullptr;
 unsigned char* g_emu_dynamic_lds = nullptr;
 static int g_stage1_handover = 0;
+static int g_head_per_crop = 0;
 EmuMfmaBuf* g_emu_mfma = nullptr;
 
 namespace {
@@ -69,6 +70,7 @@ void unpack_act(const _Float16* src, float* dst, long n_pix, int C) {
 extern "C" {
 
 void emu_reid_set_stage1_handover(int on) { g_stage1_handover = on; }
+void emu_reid_set_head_per_crop(int on) { g_head_per_crop = on; }
 
 // crops: normalised fp32 NHWC (n, 256, 128, 3).  stage_out[k] (may be null) receives the fp32 NHWC
 // activation after: 0 stem+maxpool, 1..2 stage-1 blocks, 3 transition, 4..5 blocks, 6 transition,
@@ -121,6 +123,33 @@ int emu_crop_resize(const uint8_t* frame, int W, int H, const float* boxes, int 
     const uint8_t* frames[1] = {frame};
     const uint8_t* const* fr = frames; const int* cs = streams.data(); const float* lp = lut;
     launch(n, REID_IN_H / 16, REID_IN_W, [=]() { k_crop_resize<float>(fr, cs, boxes, 4, W, H, lp, out, 16, pad); });
+    return 0;
+}
+
+// Head kernels alone on given stage-2 activations (fp32 natural NHWC, (n, 128, 128)): the batched head (16 crops per
+// workgroup, FC on the matrix pipe) and the per-crop head of round 1, with an optional output-row map and device-style count.
+int emu_head_pair(const float* blob, long n_floats, const float* act, int n, int count, const int* rows, float* feats_batched,
+                  float* feats_per_crop) {
+    using namespace bm;
+    const int32_t* hdr = reinterpret_cast<const int32_t*>(blob);
+    if (hdr[0] != REID_MAGIC || hdr[1] != 16) return -1;
+    const int ch[4] = {hdr[1], hdr[2], hdr[3], hdr[4]};
+    const OsnetLayout L = make_osnet_layout(ch, hdr[5]);
+    if (n_floats != REID_HEADER_INTS + L.total) return -2;
+    const float* w = blob + REID_HEADER_INTS;
+    std::vector<_Float16> A((size_t)n * 128 * 128);
+    for (long p = 0; p < (long)n * 128; ++p)
+        for (int c = 0; c < 128; ++c) {
+            const int ct = c / 16, g = (c % 16) / 4, r = c % 4;
+            A[p * 128 + g * 32 + 4 * ct + r] = (_Float16)act[p * 128 + c];
+        }
+    std::vector<uint8_t> w5, wfc;
+    pack_pointwise(w + L.conv5_w, w + L.conv5_b, 128, 128, w5);
+    pack_fc(w + L.fc_w, w + L.fc_b, 512, 128, wfc);
+    const _Float16* in = A.data(); const unsigned char* p5 = w5.data(); const unsigned char* pf = wfc.data();
+    const int* cnt = count >= 0 ? &count : nullptr;
+    launch(n, 1, 128, [=]() { k_head_fused<128, 512>(in, p5, pf, feats_per_crop, rows, cnt); });
+    launch((n + HEAD_NB - 1) / HEAD_NB, 1, 256, [=]() { k_head_batched<128, 512>(in, p5, pf, feats_batched, rows, cnt, n); });
     return 0;
 }
 
@@ -211,7 +240,8 @@ int emu_reid_forward(const float* blob, long n_floats, const float* crops, int n
     pack_fc(w + L.fc_w, w + L.fc_b, 512, 128, wfc);
     {
         const _Float16* in = cur; const unsigned char* p5 = w5.data(); const unsigned char* pf = wfc.data();
-        launch(n, 1, 128, [=]() { k_head_fused<128, 512>(in, p5, pf, feats, nullptr, nullptr); });
+        if (g_head_per_crop) launch(n, 1, 128, [=]() { k_head_fused<128, 512>(in, p5, pf, feats, nullptr, nullptr); });
+        else launch((n + HEAD_NB - 1) / HEAD_NB, 1, 256, [=]() { k_head_batched<128, 512>(in, p5, pf, feats, nullptr, nullptr, n); });
     }
     return 0;
 }

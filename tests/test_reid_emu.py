@@ -120,3 +120,41 @@ def test_crop_kernel_resize_and_resize_pad_equal_the_oracle_emulated(pad):
     assert lib.emu_crop_resize(img.ctypes.data, wd, hd, boxes.ctypes.data, len(boxes), pad, out.ctypes.data) == 0
     want = get_crops(boxes, img, preprocess="resize_pad" if pad else "resize").transpose(0, 2, 3, 1)
     assert np.array_equal(out, want)
+
+
+@pytest.mark.skipif(CLANG is None, reason="needs a host clang with _Float16")
+def test_batched_head_equals_per_crop_head_and_oracle_emulated():
+    """k_head_batched (16 crops per workgroup, conv5 from an LDS-staged swizzled crop, FC as hi + lo MFMAs) against the
+    per-crop head and against torch on random stage-2 activations: 37 crops = two full batches + a ragged one, an output
+    row map, and a device-side crop count that cuts the last batch short."""
+    import torch
+    import torch.nn.functional as F
+
+    from boxmot_amd.reid_weights import pack_osnet, random_osnet_state_dict
+
+    lib = ctypes.CDLL(str(_build()))
+    lib.emu_head_pair.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                  ctypes.c_void_p, ctypes.c_void_p]
+    sd = random_osnet_state_dict("osnet_x0_25", seed=3)
+    blob = pack_osnet(sd)
+    n, count = 37, 35
+    rng = np.random.default_rng(0)
+    act = np.maximum(rng.normal(0.3, 1.0, (n, 128, 128)), 0).astype(np.float16).astype(np.float32)     # post-ReLU, fp16-exact
+    rows = rng.permutation(n).astype(np.int32)
+    fb = np.full((n, 512), np.nan, np.float32)
+    fp = np.full((n, 512), np.nan, np.float32)
+    assert lib.emu_head_pair(blob.ctypes.data, blob.size, act.ctypes.data, n, count, rows.ctypes.data, fb.ctypes.data, fp.ctypes.data) == 0
+    live = rows[:count]
+    dead = rows[count:]
+    assert np.isnan(fb[dead]).all() and np.isnan(fp[dead]).all()            # crops beyond the device-side count are not touched
+    assert np.isfinite(fb[live]).all()
+    assert np.abs(fb[live] - fp[live]).max() < 2e-6                           # same fp16 operands; only the fp32 summation order differs
+    with torch.no_grad():
+        x = torch.from_numpy(act).permute(0, 2, 1).reshape(n, 128, 16, 8)     # (n, C, H, W)
+        sdf = {k: v.float() for k, v in sd.items()}
+        y = F.relu(F.batch_norm(F.conv2d(x, sdf["conv5.conv.weight"]), sdf["conv5.bn.running_mean"], sdf["conv5.bn.running_var"],
+                                sdf["conv5.bn.weight"], sdf["conv5.bn.bias"], False, 0.0, 1e-5))
+        v = F.linear(y.mean((2, 3)), sdf["fc.0.weight"], sdf["fc.0.bias"])
+        v = F.relu(F.batch_norm(v, sdf["fc.1.running_mean"], sdf["fc.1.running_var"], sdf["fc.1.weight"], sdf["fc.1.bias"], False, 0.0, 1e-5))
+        want = (v / v.norm(dim=1, keepdim=True)).numpy()
+    assert np.abs(fb[rows[:count]] - want[:count]).max() < 1e-3

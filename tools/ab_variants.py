@@ -17,6 +17,7 @@ ROOT = Path(__file__).resolve().parents[1]
 OUT = ROOT / "tools" / "_build"
 VARIANTS = {
     "base": [],
+    "head_per_crop": ["-DBM_HEAD_PER_CROP=1"],        # the round-1 head instead of k_head_batched
     "s1_handover": ["-DBM_STAGE1_HANDOVER=1"],
     "s2_epi_lds": ["-DBM_STAGE2_EPI_LDS=1"],
     "s2_occ4": ["-DBM_STAGE2_OCC4=1"],
