@@ -242,6 +242,14 @@ def load():
             f"{path} is missing: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()'). boxmot_amd has no CPU fallback."
         )
+    # PyTorch-ROCm wheels bundle their own HIP runtime.  When this library (linked against the system libamdhip64) is loaded
+    # BEFORE torch in a process, torch's runtime later reports "No HIP GPUs are available" (seen on the MI355X box, ROCm 7.2
+    # + torch 2.10-rocm7.0); loaded after torch, both coexist.  Everything in this package that touches torch device memory
+    # needs that order, so torch -- when installed -- is imported first.  Pure ctypes users without torch are unaffected.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(str(path))
     for name, (restype, argtypes) in list(SIGNATURES.items()) + list(COMPAT_SIGNATURES.items()):
         fn = getattr(lib, name)

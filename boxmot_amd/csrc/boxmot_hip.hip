@@ -1479,6 +1479,9 @@ BoxMOTBotSortHandle* boxmot_botsort_create(const BoxMOTBotSortConfig* c) {
         k.frame_rate = c->frame_rate; k.fuse_first_associate = c->fuse_first_associate; k.with_reid = c->with_reid ? 1 : 0;
         k.max_obs = c->max_obs;
         if (c->cmc_method) h->cmc = c->cmc_method;
+        if (!h->cmc.empty() && h->cmc != "none")        // checked here: the inner handle may only be built at the first update
+            throw std::runtime_error("boxmot_hip: camera-motion estimation (ecc/sof/...) is not implemented; pass cmc_method=none "
+                                     "and supply the warp per frame with boxmot_hip_botsort_set_warp");
         if (c->reid_model_path) h->reid_path = c->reid_model_path;
         if (c->reid_preprocess) h->reid_pre = c->reid_preprocess;
         k.n_streams = 1; k.n_class_lists = 1; k.tracker_kind = 0;

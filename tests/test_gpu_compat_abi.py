@@ -58,6 +58,8 @@ LIVE_UPDATE_ARGTYPES = [ctypes.c_void_p, _F, _I, _I, _U8, _I, _I, _I, _F, _I, _I
 
 @pytest.fixture(scope="module")
 def lib():
+    import torch  # noqa: F401  -- the reference imports torch long before it binds a native tracker; the bundled HIP runtime of
+    # the torch wheel must be in the process before a library linked against the system runtime (boxmot_amd/_lib.py)
     import __graft_entry__ as g
     g.build()
     L = ctypes.CDLL(str(ROOT / "boxmot_amd" / "libboxmot_hip.so"))
