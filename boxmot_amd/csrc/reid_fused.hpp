@@ -38,6 +38,18 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #ifndef BM_STAGE2_OCC4
 #define BM_STAGE2_OCC4 0
 #endif
+// Memory-latency hiding in the OSBlock kernels (bit-identical results): conv1 issues all of its input loads before its first
+// MFMA, and the epilogue loads the operands of tile i + 1 (block input for the shortcut / downsample, the hand-over tensors)
+// before it computes tile i.  0 = the round-1 order (loads at their use), kept for A/B timing (tools/osblock_prof.hip).
+#ifndef BM_PREFETCH
+#define BM_PREFETCH 1
+#endif
+#ifndef BM_PREFETCH_CONV1
+#define BM_PREFETCH_CONV1 BM_PREFETCH
+#endif
+#ifndef BM_PREFETCH_EPI
+#define BM_PREFETCH_EPI BM_PREFETCH
+#endif
 
 template <int STAGE>
 struct Geo {
@@ -156,6 +168,18 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
         for (int ct = 0; ct < KT; ++ct) bias[ct] = *reinterpret_cast<const f4*>(wts + bp.conv1_b + (16 * ct + 4 * g) * 4);
         if constexpr (CIN == 16) {
             const h4 a = *reinterpret_cast<const h4*>(wts + bp.conv1_a + lane * 8);
+#if BM_PREFETCH_CONV1
+            // all input loads first, into the registers the results will live in: one memory round trip per call instead
+            // of one per group of four tiles (the phase is latency-bound: 16 waves per CU, 8-byte loads)
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int p = (wave * NT + i) * 16 + l16;
+                x1[i][0] = *reinterpret_cast<const h4*>(xin + (xo + (unsigned)(p * CIN + g * 4)));
+            }
+            BM_SCHED_FENCE();
+#pragma unroll
+            for (int i = 0; i < NT; ++i) x1[i][0] = relu_h4(to_h4(BM_MFMA_F16_K16(a, x1[i][0], bias[0])));
+#else
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const int p = (wave * NT + i) * 16 + l16;
@@ -163,6 +187,7 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
                 x1[i][0] = relu_h4(to_h4(BM_MFMA_F16_K16(a, b, bias[0])));
                 if ((i & 3) == 3) BM_SCHED_FENCE();
             }
+#endif
         } else {
             h8 a[KIN][KT];
 #pragma unroll
@@ -170,6 +195,34 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
 #pragma unroll
                 for (int ct = 0; ct < KT; ++ct)
                     a[ks][ct] = *reinterpret_cast<const h8*>(wts + bp.conv1_a + ((ks * KT + ct) * 64 + lane) * 16);
+#if BM_PREFETCH_CONV1
+            constexpr int GRP = NT * KIN <= 12 ? NT : 4;        // tiles whose loads are in flight together (<= 48 registers)
+#pragma unroll
+            for (int i0 = 0; i0 < NT; i0 += GRP) {
+                h8 braw[GRP][KIN];
+#pragma unroll
+                for (int i = 0; i < GRP; ++i) {
+                    const int p = (wave * NT + i0 + i) * 16 + l16;
+#pragma unroll
+                    for (int ks = 0; ks < KIN; ++ks)
+                        braw[i][ks] = *reinterpret_cast<const h8*>(xin + (xo + (unsigned)(p * CIN + g * (CIN / 4) + 8 * ks)));
+                }
+                BM_SCHED_FENCE();
+#pragma unroll
+                for (int i = 0; i < GRP; ++i) {
+                    f4 acc[KT];
+#pragma unroll
+                    for (int ct = 0; ct < KT; ++ct) acc[ct] = bias[ct];
+#pragma unroll
+                    for (int ks = 0; ks < KIN; ++ks)
+#pragma unroll
+                        for (int ct = 0; ct < KT; ++ct) acc[ct] = BM_MFMA_F16_K32(a[ks][ct], braw[i][ks], acc[ct]);
+#pragma unroll
+                    for (int ct = 0; ct < KT; ++ct) x1[i0 + i][ct] = relu_h4(to_h4(acc[ct]));
+                }
+                BM_SCHED_FENCE();
+            }
+#else
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const int p = (wave * NT + i) * 16 + l16;
@@ -186,6 +239,7 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
                 for (int ct = 0; ct < KT; ++ct) x1[i][ct] = relu_h4(to_h4(acc[ct]));
                 if (i & 1) BM_SCHED_FENCE();
             }
+#endif
         }
     };
     h4 x1[NT][KT];
@@ -445,30 +499,40 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
             if constexpr (DOWN && CIN == 16) wdr[co] = *reinterpret_cast<const h4*>(ew + oda + (co * 64 + lane) * 8);
         }
     }
-    auto conv3_tile = [&](int i, h4 (&y)[NCT]) {
+    // Operands a tile's epilogue takes from memory: loaded one tile ahead of their use (BM_PREFETCH) -- with two workgroups
+    // per CU the round trip of these loads (L2 or further) was exposed once per tile.
+    struct TileIn {
+        h8 bx[KIN];             // DOWN, wide input: the block input (downsample operand)
+        h4 bx4;                 // DOWN, 16-channel input
+        h4 x2p[KT], xp;         // RECON: previous block's branch sum and (16-channel) input
+        h8 xp8[KINP];           // RECON: previous block's wide input
+        h4 idn[NCT];            // identity shortcut read from memory (neither DOWN nor RECON)
+    };
+    auto tile_loads = [&](int i, TileIn& t) {
         unsigned p = (wave * NT + i) * 16 + l16;
         if constexpr (STASH || RECON) BM_OPAQUE_U32(p);  // addresses are formed at the use, not precomputed and spilled
-        h8 bx[KIN];
-        h4 bx4;
-        h4 x2p[KT], xp;         // RECON: previous block's branch sum and input at this tile
-        h8 xp8[KINP];
         if constexpr (RECON) {
 #pragma unroll
-            for (int ct = 0; ct < KT; ++ct) x2p[ct] = *reinterpret_cast<const h4*>(x2w + (i * KT + ct) * 256);
-            if constexpr (PREV_CIN == 16) xp = *reinterpret_cast<const h4*>(xin + (unsigned)(p * 16 + g * 4));
+            for (int ct = 0; ct < KT; ++ct) t.x2p[ct] = *reinterpret_cast<const h4*>(x2w + (i * KT + ct) * 256);
+            if constexpr (PREV_CIN == 16) t.xp = *reinterpret_cast<const h4*>(xin + (unsigned)(p * 16 + g * 4));
             else {
 #pragma unroll
                 for (int ks = 0; ks < KINP; ++ks)
-                    xp8[ks] = *reinterpret_cast<const h8*>(xin + (unsigned)(p * PREV_CIN + g * (PREV_CIN / 4) + 8 * ks));
+                    t.xp8[ks] = *reinterpret_cast<const h8*>(xin + (unsigned)(p * PREV_CIN + g * (PREV_CIN / 4) + 8 * ks));
             }
         }
         if constexpr (DOWN) {
-            if constexpr (CIN == 16) bx4 = *reinterpret_cast<const h4*>(xin + (unsigned)(p * CIN + g * 4));
+            if constexpr (CIN == 16) t.bx4 = *reinterpret_cast<const h4*>(xin + (unsigned)(p * CIN + g * 4));
             else {
 #pragma unroll
-                for (int ks = 0; ks < KIN; ++ks) bx[ks] = *reinterpret_cast<const h8*>(xin + (unsigned)(p * CIN + g * (CIN / 4) + 8 * ks));
+                for (int ks = 0; ks < KIN; ++ks) t.bx[ks] = *reinterpret_cast<const h8*>(xin + (unsigned)(p * CIN + g * (CIN / 4) + 8 * ks));
             }
+        } else if constexpr (!RECON) {
+#pragma unroll
+            for (int co = 0; co < NCT; ++co) t.idn[co] = *reinterpret_cast<const h4*>(xin + (unsigned)(p * CIN + g * (CIN / 4) + 4 * co));
         }
+    };
+    auto conv3_compute = [&](int i, const TileIn& t, h4 (&y)[NCT]) {
 #pragma unroll
         for (int co = 0; co < NCT; ++co) {
             f4 acc;
@@ -483,34 +547,35 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
             }
             if constexpr (DOWN) {
                 if constexpr (CIN == 16 && W3REG) {
-                    acc = BM_MFMA_F16_K16(wdr[co], bx4, acc);
+                    acc = BM_MFMA_F16_K16(wdr[co], t.bx4, acc);
                 } else if constexpr (CIN == 16) {
-                    acc = BM_MFMA_F16_K16(*reinterpret_cast<const h4*>(ew + oda + (co * 64 + lane) * 8), bx4, acc);
+                    acc = BM_MFMA_F16_K16(*reinterpret_cast<const h4*>(ew + oda + (co * 64 + lane) * 8), t.bx4, acc);
                 } else {
 #pragma unroll
                     for (int ks = 0; ks < KIN; ++ks)
-                        acc = BM_MFMA_F16_K32(*reinterpret_cast<const h8*>(ew + oda + ((co * KIN + ks) * 64 + lane) * 16), bx[ks], acc);
+                        acc = BM_MFMA_F16_K32(*reinterpret_cast<const h8*>(ew + oda + ((co * KIN + ks) * 64 + lane) * 16), t.bx[ks], acc);
                 }
             } else {
                 // identity shortcut: the 4 input channels this lane holds are a K=16 B fragment, so adding them is one
                 // MFMA with the 16x16 identity (exact: products by 1, fp32 accumulate) instead of 4 converts + 4 adds;
                 // only where conv3 is itself a K=16 MFMA: a dependent chain that mixes the 16x16x16 and 16x16x32 shapes
-                // on one accumulator returns wrong sums on gfx950 / ROCm 7.2 (tools/mfma_chain_test.hip)
+                // on one accumulator returns wrong sums on gfx950 / ROCm 7.2 unless >= 8 wait states separate the links
+                // (tools/mfma_chain_test.hip modes 11-13)
                 h4 idn;
                 if constexpr (RECON) {      // block input = ReLU(conv3_prev . x2_prev + down_prev . x_prev + bias), as EMIT computed it
                     f4 ap = *reinterpret_cast<const f4*>(epv + p3b + (16 * co + 4 * g) * 4);
                     if constexpr (KT == 1) {        // one MFMA shape per accumulator: K=16 in stage 0, K=32 in stage 1
-                        ap = BM_MFMA_F16_K16(*reinterpret_cast<const h4*>(epv + (co * 64 + lane) * 8), x2p[0], ap);
-                        ap = BM_MFMA_F16_K16(*reinterpret_cast<const h4*>(epv + pda + (co * 64 + lane) * 8), xp, ap);
+                        ap = BM_MFMA_F16_K16(*reinterpret_cast<const h4*>(epv + (co * 64 + lane) * 8), t.x2p[0], ap);
+                        ap = BM_MFMA_F16_K16(*reinterpret_cast<const h4*>(epv + pda + (co * 64 + lane) * 8), t.xp, ap);
                     } else {
-                        ap = BM_MFMA_F16_K32(*reinterpret_cast<const h8*>(epv + (co * 64 + lane) * 16), cat8(x2p[0], x2p[1]), ap);
+                        ap = BM_MFMA_F16_K32(*reinterpret_cast<const h8*>(epv + (co * 64 + lane) * 16), cat8(t.x2p[0], t.x2p[1]), ap);
 #pragma unroll
                         for (int ks = 0; ks < KINP; ++ks)
-                            ap = BM_MFMA_F16_K32(*reinterpret_cast<const h8*>(epv + pda + ((co * KINP + ks) * 64 + lane) * 16), xp8[ks], ap);
+                            ap = BM_MFMA_F16_K32(*reinterpret_cast<const h8*>(epv + pda + ((co * KINP + ks) * 64 + lane) * 16), t.xp8[ks], ap);
                     }
                     idn = relu_h4(to_h4(ap));
                 } else {
-                    idn = *reinterpret_cast<const h4*>(xin + (unsigned)(p * CIN + g * (CIN / 4) + 4 * co));
+                    idn = t.idn[co];
                 }
                 if constexpr (KT == 1) acc = BM_MFMA_F16_K16(eye, idn, acc);       // same shape as conv3's own MFMA
                 else {
@@ -520,6 +585,14 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
             }
             y[co] = relu_h4(to_h4(acc));
         }
+    };
+    // tile i's operands are in tin[i & 1]: loaded while tile i - 1 computes (BM_PREFETCH) or right before the use
+    TileIn tin[2];
+    auto epi_begin = [&](int i_first) { if constexpr (BM_PREFETCH_EPI) tile_loads(i_first, tin[i_first & 1]); };
+    auto epi_tile = [&](int i, int i_next, h4 (&y)[NCT]) {          // i_next < 0: no further tile
+        if constexpr (BM_PREFETCH_EPI) { if (i_next >= 0) tile_loads(i_next, tin[i_next & 1]); }
+        else tile_loads(i, tin[i & 1]);
+        conv3_compute(i, tin[i & 1], y);
     };
     if constexpr (EMIT) {
         // next block's conv1 (COUT -> 16, + bias, ReLU) on the in-register block output: its accumulator layout is the
@@ -533,10 +606,11 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
             for (int ks = 0; ks < KSN; ++ks) wn[ks][ct] = *reinterpret_cast<const h8*>(link.w + link.a0 + ((ks * KT + ct) * 64 + lane) * 16);
             bn[ct] = *reinterpret_cast<const f4*>(link.w + link.a1 + (16 * ct + 4 * g) * 4);
         }
+        epi_begin(0);
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
             h4 y[NCT];
-            conv3_tile(i, y);
+            epi_tile(i, i + 1 < NT ? i + 1 : -1, y);
 #pragma unroll
             for (int ct = 0; ct < KT; ++ct) {
                 f4 an = bn[ct];
@@ -548,11 +622,12 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
             BM_SCHED_FENCE();
         }
     } else if constexpr (!TRANS) {
+        epi_begin(0);
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
             const int p = (wave * NT + i) * 16 + l16;
             h4 y[NCT];
-            conv3_tile(i, y);
+            epi_tile(i, i + 1 < NT ? i + 1 : -1, y);
 #pragma unroll
             for (int co = 0; co < NCT; ++co) *reinterpret_cast<h4*>(yout + (unsigned)(p * COUT + g * (COUT / 4) + 4 * co)) = y[co];
             BM_SCHED_FENCE();
@@ -564,13 +639,19 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
         static_assert(!TRANS || (STAGE < 2 && COUT % 32 == 0), "fused transition: stages 0 and 1");
         constexpr int KS3 = COUT / 32, WP = G::W / 2;
         const unsigned char* tbias = etr + NCT * KS3 * 1024;
+        auto pair_i0 = [](int pr) constexpr { return STAGE == 0 ? (pr >> 1) * 4 + (pr & 1) : 2 * pr; };
+        auto pair_i1 = [](int pr) constexpr { return (STAGE == 0 ? (pr >> 1) * 4 + (pr & 1) : 2 * pr) + (STAGE == 0 ? 2 : 1); };
+        TileIn tp[2][2];        // [pair parity][tile of the pair]: the operands of pair pr + 1 load while pair pr computes
+        if constexpr (BM_PREFETCH_EPI) { tile_loads(pair_i0(0), tp[0][0]); tile_loads(pair_i1(0), tp[0][1]); }
 #pragma unroll
         for (int pr = 0; pr < NT / 2; ++pr) {
-            const int i0 = STAGE == 0 ? (pr >> 1) * 4 + (pr & 1) : 2 * pr;
-            const int i1 = STAGE == 0 ? i0 + 2 : i0 + 1;
+            const int i0 = pair_i0(pr), i1 = pair_i1(pr);
             h4 y0[NCT], y1[NCT];
-            conv3_tile(i0, y0);
-            conv3_tile(i1, y1);
+            if constexpr (BM_PREFETCH_EPI) {
+                if (pr + 1 < NT / 2) { tile_loads(pair_i0(pr + 1), tp[(pr + 1) & 1][0]); tile_loads(pair_i1(pr + 1), tp[(pr + 1) & 1][1]); }
+            } else { tile_loads(i0, tp[pr & 1][0]); tile_loads(i1, tp[pr & 1][1]); }
+            conv3_compute(i0, tp[pr & 1][0], y0);
+            conv3_compute(i1, tp[pr & 1][1], y1);
             const int row = STAGE == 0 ? wave * (NT / 2) + (i0 >> 1) : wave * NT + i0;     // even image row of tile i0
             const int po = (row >> 1) * WP + (STAGE == 0 ? (i0 & 1) * 8 : 0) + (l16 >> 1);
 #pragma unroll
