@@ -72,6 +72,12 @@ __global__ void __launch_bounds__(NTHR) strongsort_bank_kernel(bm::SsStepArgs ar
 }
 
 template <int NTHR>
+__global__ void __launch_bounds__(NTHR) strongsort_bank_mfma_kernel(bm::SsStepArgs args) {
+    __shared__ __attribute__((aligned(16))) float lds[bm::SS_MFMA_LDS_FLOATS(NTHR)];
+    bm::ss_bank_distance_block_mfma<NTHR>(args, args.stream_base + blockIdx.y, blockIdx.x, lds);
+}
+
+template <int NTHR>
 __global__ void __launch_bounds__(NTHR) strongsort_step_kernel(bm::SsStepArgs args) {
     __shared__ int s_int[bm::MAX_WAVES + 1];
     __shared__ double s_dbl[bm::MAX_WAVES];
@@ -213,6 +219,7 @@ struct BoxMOTHipDeepOcSort : StreamIo {
 struct BoxMOTHipStrongSort : StreamIo {
     BoxMOTHipStrongSortConfig cfg{};
     bm::SsStepArgs args{};
+    bool bank_valu = false;         // BOXMOT_HIP_SS_BANK=valu: the scalar-FMA bank-distance kernel (A/B timing, cross-check)
 };
 
 namespace {
@@ -720,6 +727,7 @@ void ss_build(BoxMOTHipStrongSort* h) {
         throw std::runtime_error("boxmot_hip: invalid capacity configuration");
     if (c.nn_budget < 1 || c.nn_budget > 1024) throw std::runtime_error("boxmot_hip: StrongSORT nn_budget must be in [1, 1024] (None is not supported)");
     if (c.n_init < 1 || c.max_age < 0) throw std::runtime_error("boxmot_hip: invalid n_init / max_age");
+    { const char* v = std::getenv("BOXMOT_HIP_SS_BANK"); h->bank_valu = v && std::strcmp(v, "valu") == 0; }
     io_allocate(h, c.n_streams, c.max_tracks, c.max_dets, c.emb_dim, true);
     bm::SsConfigDev& d = h->args.cfg;
     d.min_conf = c.min_conf; d.max_cos_dist = c.max_cos_dist; d.max_iou_dist = c.max_iou_dist; d.mc_lambda = c.mc_lambda;
@@ -738,7 +746,11 @@ void ss_build(BoxMOTHipStrongSort* h) {
 // detection norms -> sample-bank distances of every confirmed track (state BEFORE this frame's step) -> frame step
 void ss_launch(BoxMOTHipStrongSort* h, const bm::SsStepArgs& a, int n) {
     hipLaunchKernelGGL((strongsort_detnorm_kernel<SS_BANK_THREADS>), dim3(n), dim3(SS_BANK_THREADS), 0, h->stream, a);
-    hipLaunchKernelGGL((strongsort_bank_kernel<SS_BANK_THREADS>), dim3(h->cap, n), dim3(SS_BANK_THREADS), 0, h->stream, a);
+    // sample-bank distances: fp32 matrix pipe (budgets up to 112 samples; bit-identical sums), else / on request the scalar-FMA kernel
+    if (h->cfg.nn_budget <= bm::SS_MT * 16 && !h->bank_valu)
+        hipLaunchKernelGGL((strongsort_bank_mfma_kernel<SS_BANK_THREADS>), dim3(h->cap, n), dim3(SS_BANK_THREADS), 0, h->stream, a);
+    else
+        hipLaunchKernelGGL((strongsort_bank_kernel<SS_BANK_THREADS>), dim3(h->cap, n), dim3(SS_BANK_THREADS), 0, h->stream, a);
     hipLaunchKernelGGL((strongsort_step_kernel<STEP_THREADS>), dim3(n), dim3(STEP_THREADS),
                        (size_t)bm::ss_lsa_lds_bytes(h->cap > h->nd ? h->cap : h->nd), h->stream, a);
 }

@@ -48,3 +48,15 @@
 #ifndef BM_CLOCK
 #define BM_CLOCK() wall_clock64()
 #endif
+
+// fp32 matrix pipe: D = A.B + C on 16x16x4 tiles (v_mfma_f32_16x16x4_f32; A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15],
+// D: column lane & 15, rows 4 (lane >> 4) + r).  Exact fp32: bit-for-bit the k-ordered fmaf chain, so a kernel written on it
+// returns what the same sums written as scalar fmaf loops return (the test harness substitutes exactly that).
+#if defined(__clang__)
+typedef float bm_f4 __attribute__((ext_vector_type(4)));
+#else
+typedef float bm_f4 __attribute__((vector_size(16)));
+#endif
+#ifndef BM_MFMA_F32_K4
+#define BM_MFMA_F32_K4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
+#endif

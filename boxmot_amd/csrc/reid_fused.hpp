@@ -38,17 +38,18 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #ifndef BM_STAGE2_OCC4
 #define BM_STAGE2_OCC4 0
 #endif
-// Memory-latency hiding in the OSBlock kernels (bit-identical results): conv1 issues all of its input loads before its first
-// MFMA, and the epilogue loads the operands of tile i + 1 (block input for the shortcut / downsample, the hand-over tensors)
-// before it computes tile i.  0 = the round-1 order (loads at their use), kept for A/B timing (tools/osblock_prof.hip).
-#ifndef BM_PREFETCH
-#define BM_PREFETCH 1
-#endif
+// Memory-latency hiding in the OSBlock kernels (bit-identical results), measured per kernel at 4096 crops
+// (tools/osblock_prof.hip, profiles/r2_osblock_variants.txt):
+//   BM_PREFETCH_CONV1: conv1 issues all of its input loads before its first MFMA             -> -1.7 % over the six kernels
+//   BM_PREFETCH_EPI:   the epilogue loads tile i + 1's operands (block input for the shortcut / downsample, the hand-over
+//                      tensors) while tile i computes: -6 % on the stage-1 second block, but +3 % / +7 % on the stage-0 RECON
+//                      and stage-2 first blocks (they are at the 128-register budget: the second operand set spills), so it
+//                      is compiled in for that one kernel only (value 2 = "where it pays"; 0 / 1 = off / everywhere for A/B).
 #ifndef BM_PREFETCH_CONV1
-#define BM_PREFETCH_CONV1 BM_PREFETCH
+#define BM_PREFETCH_CONV1 1
 #endif
 #ifndef BM_PREFETCH_EPI
-#define BM_PREFETCH_EPI BM_PREFETCH
+#define BM_PREFETCH_EPI 2
 #endif
 
 template <int STAGE>
@@ -501,6 +502,7 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
     }
     // Operands a tile's epilogue takes from memory: loaded one tile ahead of their use (BM_PREFETCH) -- with two workgroups
     // per CU the round trip of these loads (L2 or further) was exposed once per tile.
+    constexpr bool EPI_PF = BM_PREFETCH_EPI == 1 || (BM_PREFETCH_EPI == 2 && STAGE == 1 && TRANS && !RECON);
     struct TileIn {
         h8 bx[KIN];             // DOWN, wide input: the block input (downsample operand)
         h4 bx4;                 // DOWN, 16-channel input
@@ -588,9 +590,9 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
     };
     // tile i's operands are in tin[i & 1]: loaded while tile i - 1 computes (BM_PREFETCH) or right before the use
     TileIn tin[2];
-    auto epi_begin = [&](int i_first) { if constexpr (BM_PREFETCH_EPI) tile_loads(i_first, tin[i_first & 1]); };
+    auto epi_begin = [&](int i_first) { if constexpr (EPI_PF) tile_loads(i_first, tin[i_first & 1]); };
     auto epi_tile = [&](int i, int i_next, h4 (&y)[NCT]) {          // i_next < 0: no further tile
-        if constexpr (BM_PREFETCH_EPI) { if (i_next >= 0) tile_loads(i_next, tin[i_next & 1]); }
+        if constexpr (EPI_PF) { if (i_next >= 0) tile_loads(i_next, tin[i_next & 1]); }
         else tile_loads(i, tin[i & 1]);
         conv3_compute(i, tin[i & 1], y);
     };
@@ -642,12 +644,12 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
         auto pair_i0 = [](int pr) constexpr { return STAGE == 0 ? (pr >> 1) * 4 + (pr & 1) : 2 * pr; };
         auto pair_i1 = [](int pr) constexpr { return (STAGE == 0 ? (pr >> 1) * 4 + (pr & 1) : 2 * pr) + (STAGE == 0 ? 2 : 1); };
         TileIn tp[2][2];        // [pair parity][tile of the pair]: the operands of pair pr + 1 load while pair pr computes
-        if constexpr (BM_PREFETCH_EPI) { tile_loads(pair_i0(0), tp[0][0]); tile_loads(pair_i1(0), tp[0][1]); }
+        if constexpr (EPI_PF) { tile_loads(pair_i0(0), tp[0][0]); tile_loads(pair_i1(0), tp[0][1]); }
 #pragma unroll
         for (int pr = 0; pr < NT / 2; ++pr) {
             const int i0 = pair_i0(pr), i1 = pair_i1(pr);
             h4 y0[NCT], y1[NCT];
-            if constexpr (BM_PREFETCH_EPI) {
+            if constexpr (EPI_PF) {
                 if (pr + 1 < NT / 2) { tile_loads(pair_i0(pr + 1), tp[(pr + 1) & 1][0]); tile_loads(pair_i1(pr + 1), tp[(pr + 1) & 1][1]); }
             } else { tile_loads(i0, tp[pr & 1][0]); tile_loads(i1, tp[pr & 1][1]); }
             conv3_compute(i0, tp[pr & 1][0], y0);

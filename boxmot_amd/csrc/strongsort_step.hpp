@@ -305,6 +305,118 @@ __device__ inline void ss_bank_distance_block(const SsStepArgs& a, int s, int t,
     }
 }
 
+// The same distances on the fp32 matrix pipe (the shipped kernel; the scalar-FMA version above is kept as its
+// on-device cross-check).  One workgroup of NTHR / 64 waves per (track position, stream):
+//   C[m][n] = <bank row m, detection n>,  m < M <= budget (up to SS_MT = 7 row tiles of 16: budgets <= 112),
+//   n in passes of 16 * (NTHR / 64) detections: wave w owns one 16-detection column tile and all row tiles (7 accumulators).
+// K runs in chunks of SS_MKC = 32 through LDS (row stride 36 floats: 16-byte rows for the staging writes, 2-way at most for
+// the one-dword fragment reads); the next chunk's global loads are issued before the current chunk's MFMAs and written to
+// LDS after them, so the only exposed round trip is the first.  v_mfma_f32_16x16x4_f32 is the exact k-ordered fmaf chain:
+// the sums are bit-identical to the scalar version's (k ascending, one fmaf per k) -- same distances, same argmin.
+// Rate: 64 FLOP/clk/SIMD like the vector pipe, but issued as 1 instruction per 2 KiFLOP with the operands read once per
+// 16x16 tile, and with the vector ALUs free for the staging (MI355X_MICROARCH.md: 122 TF untuned vs 52 TF for a VALU GEMM).
+// ---------------------------------------------------------------------------
+constexpr int SS_MT = 7, SS_MKC = 32, SS_MLD = 36;
+constexpr int SS_MFMA_LDS_FLOATS(int nthr) { return (SS_MT * 16 + 16 * (nthr / 64)) * SS_MLD; }
+
+template <int NTHR>
+__device__ inline void ss_bank_distance_block_mfma(const SsStepArgs& a, int s, int t, float* lds) {
+    constexpr int NW = NTHR / WAVE, NB = 16 * NW, ROWS_A = SS_MT * 16;
+    constexpr int QA = (ROWS_A * SS_MKC / 4 + NTHR - 1) / NTHR, QB = (NB * SS_MKC / 4 + NTHR - 1) / NTHR;     // float4 slots per thread
+    const SsState& st = a.st;
+    const long cap = st.cap, dim = st.dim, nd = a.sc.max_dets;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE, g = lane >> 4, l16 = lane & 15;
+    if (a.n_dets[s] < 0 || t >= st.n_tracks[s]) return;
+    const int slot = st.list[s * cap + t];
+    if (st.state[s * cap + slot] != SS_CONFIRMED) return;
+    const int n_d = a.n_dets[s];
+    const float* embs = a.embs + (long)s * nd * dim;
+    const int M = st.bank_n[s * cap + slot] < st.budget ? st.bank_n[s * cap + slot] : st.budget;
+    const float* bank = st.bank + ((long)(s * cap + slot)) * st.budget * dim;
+    const float* bnorm = st.bank_norm + (long)(s * cap + slot) * st.budget;
+    const float* dnorm = a.sc.det_norm + s * nd;
+    float* out = a.sc.app + ((long)s * cap + t) * nd;
+    float* sA = lds;                        // [ROWS_A][SS_MLD]
+    float* sB = lds + ROWS_A * SS_MLD;      // [NB][SS_MLD]
+    const int mt_used = (M + 15) / 16;      // row tiles that hold samples (wave-uniform)
+    for (int n0 = 0; n0 < n_d; n0 += NB) {
+        bm_f4 acc[SS_MT];
+#pragma unroll
+        for (int mt = 0; mt < SS_MT; ++mt) acc[mt] = bm_f4{0.f, 0.f, 0.f, 0.f};
+        bm_f4 ra[QA], rb[QB];
+        // chunk loader: slot e of the A part = (row e / 8, four consecutive k's e % 8); rows / k's beyond the data read as 0
+        auto load_chunk = [&](int k0) {
+#pragma unroll
+            for (int q = 0; q < QA; ++q) {
+                const int e = tid + q * NTHR, r = e / (SS_MKC / 4), c4 = (e % (SS_MKC / 4)) * 4;
+                bm_f4 v = bm_f4{0.f, 0.f, 0.f, 0.f};
+                if (e < ROWS_A * SS_MKC / 4 && r < M) {
+                    const float* src = bank + (long)r * dim + k0 + c4;
+                    if (k0 + c4 + 3 < dim) v = *reinterpret_cast<const bm_f4*>(src);
+                    else for (int j = 0; j < 4; ++j) if (k0 + c4 + j < dim) v[j] = src[j];
+                }
+                ra[q] = v;
+            }
+#pragma unroll
+            for (int q = 0; q < QB; ++q) {
+                const int e = tid + q * NTHR, r = e / (SS_MKC / 4), c4 = (e % (SS_MKC / 4)) * 4;
+                bm_f4 v = bm_f4{0.f, 0.f, 0.f, 0.f};
+                if (e < NB * SS_MKC / 4 && n0 + r < n_d) {
+                    const float* src = embs + (long)(n0 + r) * dim + k0 + c4;
+                    if (k0 + c4 + 3 < dim) v = *reinterpret_cast<const bm_f4*>(src);
+                    else for (int j = 0; j < 4; ++j) if (k0 + c4 + j < dim) v[j] = src[j];
+                }
+                rb[q] = v;
+            }
+        };
+        auto store_chunk = [&]() {
+#pragma unroll
+            for (int q = 0; q < QA; ++q) {
+                const int e = tid + q * NTHR, r = e / (SS_MKC / 4), c4 = (e % (SS_MKC / 4)) * 4;
+                if (e < ROWS_A * SS_MKC / 4) *reinterpret_cast<bm_f4*>(sA + r * SS_MLD + c4) = ra[q];
+            }
+#pragma unroll
+            for (int q = 0; q < QB; ++q) {
+                const int e = tid + q * NTHR, r = e / (SS_MKC / 4), c4 = (e % (SS_MKC / 4)) * 4;
+                if (e < NB * SS_MKC / 4) *reinterpret_cast<bm_f4*>(sB + r * SS_MLD + c4) = rb[q];
+            }
+        };
+        load_chunk(0);
+        for (int k0 = 0; k0 < dim; k0 += SS_MKC) {
+            __syncthreads();                // every wave is done reading the previous chunk
+            store_chunk();
+            __syncthreads();
+            if (k0 + SS_MKC < dim) load_chunk(k0 + SS_MKC);          // in flight while this chunk multiplies
+#pragma unroll
+            for (int kk = 0; kk < SS_MKC / 4; ++kk) {
+                const float b = sB[(wave * 16 + l16) * SS_MLD + 4 * kk + g];
+#pragma unroll
+                for (int mt = 0; mt < SS_MT; ++mt)
+                    if (mt < mt_used) acc[mt] = BM_MFMA_F32_K4(sA[(mt * 16 + l16) * SS_MLD + 4 * kk + g], b, acc[mt]);
+            }
+        }
+        // D layout: column (detection) l16, rows (samples) 16 mt + 4 g + r: distance, minimum over the lane's samples, then over g
+        const int n = n0 + wave * 16 + l16;
+        const float dn = n < n_d ? dnorm[n] : 1.f;
+        float best = 3.0e38f;
+#pragma unroll
+        for (int mt = 0; mt < SS_MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = mt * 16 + 4 * g + r;
+                if (m < M) {
+                    const float dist = 1.0f - acc[mt][r] / (bnorm[m] * dn);
+                    best = dist < best ? dist : best;
+                }
+            }
+        const float o1 = __shfl_xor(best, 16, WAVE);
+        best = o1 < best ? o1 : best;
+        const float o2 = __shfl_xor(best, 32, WAVE);
+        best = o2 < best ? o2 : best;
+        if (g == 0 && n < n_d) out[n] = best;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // KalmanFilterXYAH, one wavefront per track (lane l <-> cov element (l>>3, l&7))
 // ---------------------------------------------------------------------------

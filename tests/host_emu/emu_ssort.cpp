@@ -11,6 +11,7 @@ thread_local EmuDim3 threadIdx;
 thread_local EmuDim3 blockIdx;
 EmuDim3 blockDim;
 EmuBlock* g_emu_block = nullptr;
+EmuMfmaBuf* g_emu_mfma = nullptr;
 
 namespace {
 
@@ -36,6 +37,7 @@ struct Emu {
 struct ThreadArg { Emu* e; int tid; int mode; int t; };
 int* g_s_int; double* g_s_dbl; unsigned char* g_dyn;
 float (*g_sA)[bm::SS_TILE + 1]; float (*g_sB)[bm::SS_TILE + 1]; float (*g_sMin)[bm::SS_TILE];
+float* g_mfma_lds;
 
 const double* g_lsa_cost; int g_lsa_nr, g_lsa_nc; int* g_lsa_out;
 
@@ -52,6 +54,7 @@ void* thread_main(void* p) {
         return nullptr;
     }
     if (ta->mode == 3) { bm::ss_det_norm_block<NTHR>(ta->e->args, 0); return nullptr; }
+    if (ta->mode == 4) { bm::ss_bank_distance_block_mfma<NTHR>(ta->e->args, 0, ta->t, g_mfma_lds); return nullptr; }
     if (ta->mode == 0) bm::ss_bank_distance_block<NTHR>(ta->e->args, 0, ta->t, g_sA, g_sB, g_sMin);
     else bm::ss_step_stream<NTHR>(ta->e->args, 0, g_s_int, g_s_dbl, g_dyn);
     return nullptr;
@@ -121,8 +124,24 @@ int emu_ss_update(void* h, const float* dets, int n, const float* embs, const do
     blockDim.x = NTHR;
     const int nt = e->args.st.n_tracks[0];
     run_block(e, 3, 0);
+    // both bank-distance kernels on every confirmed track: the fp32-MFMA one (the shipped kernel; here the k-ordered fmaf
+    // chain the instruction is) must reproduce the scalar-FMA one bit for bit
+    static EmuMfmaBuf mf;
+    static std::vector<float> mlds;
+    mlds.assign((size_t)bm::SS_MFMA_LDS_FLOATS(NTHR) + 4, -12345.f);
+    g_emu_mfma = &mf; g_mfma_lds = mlds.data();
+    std::vector<float> row(e->nd);
     for (int t = 0; t < nt; ++t)
-        if (e->args.st.state[e->args.st.list[t]] == bm::SS_CONFIRMED) run_block(e, 0, t);
+        if (e->args.st.state[e->args.st.list[t]] == bm::SS_CONFIRMED) {
+            float* app = e->args.sc.app + (size_t)t * e->nd;
+            run_block(e, 0, t);
+            std::memcpy(row.data(), app, (size_t)n * 4);
+            if (e->args.cfg.budget <= bm::SS_MT * 16) {
+                for (int q = 0; q < n; ++q) app[q] = -7.f;
+                run_block(e, 4, t);
+                if (std::memcmp(row.data(), app, (size_t)n * 4) != 0) return -77;
+            }
+        }
     run_block(e, 1, 0);
     *out_n = e->out_n[0];
     std::memcpy(out, e->out, (size_t)e->out_n[0] * bm::OUT_COLS * 4);

@@ -145,3 +145,25 @@ inline F emu_mfma(HA a, HA b, F c) {
 }
 #define BM_MFMA_F16_K16(a, b, c) emu_mfma<4>(a, b, c)
 #define BM_MFMA_F16_K32(a, b, c) emu_mfma<8>(a, b, c)
+
+// fp32 16x16x4 MFMA: the k-ordered fmaf chain the hardware computes (one rounding per product-accumulate)
+#if defined(__clang__)
+typedef float emu_f4 __attribute__((ext_vector_type(4)));
+#else
+typedef float emu_f4 __attribute__((vector_size(16)));
+#endif
+inline emu_f4 emu_mfma_f32_k4(float a, float b, emu_f4 c) {
+    const int wave = threadIdx.x / EMU_WAVE, lane = threadIdx.x % EMU_WAVE;
+    g_emu_mfma->a[wave][lane][0] = a; g_emu_mfma->b[wave][lane][0] = b;
+    g_emu_block->wave_barrier[wave].wait();
+    const int col = lane & 15, g = lane >> 4;
+    emu_f4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) acc = fmaf(g_emu_mfma->a[wave][4 * g + r + 16 * k][0], g_emu_mfma->b[wave][col + 16 * k][0], acc);
+        d[r] = acc;
+    }
+    g_emu_block->wave_barrier[wave].wait();
+    return d;
+}
+#define BM_MFMA_F32_K4(a, b, c) emu_mfma_f32_k4(a, b, c)

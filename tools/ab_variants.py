@@ -18,9 +18,8 @@ OUT = ROOT / "tools" / "_build"
 VARIANTS = {
     "base": [],
     "head_per_crop": ["-DBM_HEAD_PER_CROP=1"],        # the round-1 head instead of k_head_batched
-    "no_prefetch": ["-DBM_PREFETCH=0"],               # round-1 load order in conv1 / epilogue
-    "pf_conv1_only": ["-DBM_PREFETCH_EPI=0"],
-    "pf_epi_only": ["-DBM_PREFETCH_CONV1=0"],
+    "no_prefetch": ["-DBM_PREFETCH_CONV1=0", "-DBM_PREFETCH_EPI=0"],     # round-1 load order in conv1 / epilogue
+    "pf_epi_all": ["-DBM_PREFETCH_EPI=1"],
     "s1_handover": ["-DBM_STAGE1_HANDOVER=1"],
     "s2_epi_lds": ["-DBM_STAGE2_EPI_LDS=1"],
     "s2_occ4": ["-DBM_STAGE2_OCC4=1"],

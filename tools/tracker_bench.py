@@ -113,10 +113,22 @@ def main():
             want = np.asarray(orc.update(dets_h[t, 0, :n], None, embs_h[t, 0, :n].copy())).reshape(-1, 8)
             got = out_h[t, 0, : out_n[t, 0]]
             ok = ok and got.shape == want.shape and np.array_equal(got[:, 4:], want[:, 4:]) and np.allclose(got[:, :4], want[:, :4], atol=1e-3)
+        extra = {}
+        if name == "strongsort":
+            # work of the sample-bank distance kernel in the last step: sum over the confirmed tracks of stream 0 of
+            # (samples in the bank) x (detections) x dim x 2 FLOP, times the streams (same schedule in every stream)
+            ints = np.zeros((cap, 6), np.int32)
+            rows, fc, ni = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+            _lib.check(lib.boxmot_hip_strongsort_state_dump(h, 0, ints.ctypes.data, None, None, ctypes.byref(rows), ctypes.byref(fc), ctypes.byref(ni)))
+            conf = ints[: rows.value][ints[: rows.value, 1] == 2]
+            samples = int(conf[:, 5].sum())
+            extra = {"confirmed_tracks": int(len(conf)), "bank_samples_stream0": samples, "banks_full": int((conf[:, 5] >= 100).sum()),
+                     "bank_kernel_gflop_per_step": S * samples * int(cnt_h[-1, 0]) * dim * 2 / 1e9,
+                     "bank_bytes_per_step_GB": S * samples * dim * 4 / 1e9}
         destroy(h)
-        print(json.dumps({"tracker": name, "config": a.config, "streams": S, "steps": a.steps, "frames_per_s": S * a.steps / dt,
+        print(json.dumps({"tracker": name, "config": a.config, "streams": S, "steps": a.steps, "warmup": a.warmup, "frames_per_s": S * a.steps / dt,
                           "ms_per_step": 1e3 * dt / a.steps, "rows_stream0_last": int(out_n[-1, 0]),
-                          "parity_first_frames_vs_oracle": bool(ok)}), flush=True)
+                          "parity_first_frames_vs_oracle": bool(ok), **extra}), flush=True)
 
 
 if __name__ == "__main__":
