@@ -97,9 +97,20 @@ def config2_reid(weights: str, frames: int):
     _save(f"config2_reid_{weights}_golden.npz", out, dict(frames=np.int32(frames)))
 
 
+def mot17_mini_gt():
+    """tests/golden/mot17_mini_gt.npz: the ground-truth rows of the reference's MOT17-mini fixture (assets/MOT17-mini/train/
+    <seq>/gt/gt.txt -- 4 and 8 annotated frames) for the metric tests (boxmot_amd.metrics)."""
+    out = {}
+    for seq in ("MOT17-02-FRCNN", "MOT17-04-FRCNN"):
+        out[seq] = np.loadtxt(ref_harness.REFERENCE_ROOT / "assets" / "MOT17-mini" / "train" / seq / "gt" / "gt.txt", delimiter=",").astype(np.float32)
+    np.savez_compressed(OUT / "mot17_mini_gt.npz", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1]
-    if which == "c2reid":
+    if which == "gt":
+        mot17_mini_gt()
+    elif which == "c2reid":
         config2_reid(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 240)
     else:
         n = int(sys.argv[2]) if len(sys.argv) > 2 else 240

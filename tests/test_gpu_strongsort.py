@@ -61,9 +61,12 @@ def test_hip_strongsort_camera_update_and_seed_sweep():
         frames = stress_frames(100, seed=seed, max_objects=30)
         warps = camera_warps(len(frames), seed=seed)
         trk, orc = StrongSort(emb_dim=32, max_tracks=128, max_dets=64, cmc=Scheduled(warps), **kw), StrongSortOracle(**kw)
+        sched = Scheduled(warps)        # the estimator is asked only while tracks exist (strongsort.py:83-86): same gate on both sides
         for t, (dets, embs) in enumerate(frames):
             got = np.asarray(trk.update(dets, img, embs)).reshape(-1, 8)
-            assert_rows_match(got, orc.update(dets, img, embs.copy(), warp=warps[t]).reshape(-1, 8), t)
+            warp = sched.apply(img, None) if len(orc.tracks) >= 1 else None
+            assert_rows_match(got, orc.update(dets, img, embs.copy(), warp=warp).reshape(-1, 8), t)
+        assert trk.cmc.k == sched.k > 0
         _check_state(trk, orc)
         trk.close()
 
