@@ -31,6 +31,10 @@
 #define BM_ROW_SHR1_F32(v) BM_DPP_F32(v, 0x111)
 #define BM_ROW_ROR1_F32(v) BM_DPP_F32(v, 0x121)
 #endif
+#ifndef BM_DPP_U32
+// raw DPP move: lanes whose source lane does not exist take 0 (zero_fill) or keep `old`
+#define BM_DPP_U32(old, v, ctrl, zero_fill) ((unsigned)__builtin_amdgcn_update_dpp((int)(old), (int)(v), ctrl, 0xf, 0xf, zero_fill))
+#endif
 #ifndef BM_RELU_F32
 // max(v, 0) as one integer max on the bit pattern (negative floats are negative ints); a float max costs a second,
 // canonicalising v_max under IEEE mode

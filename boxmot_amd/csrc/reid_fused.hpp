@@ -52,6 +52,14 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #define BM_PREFETCH_EPI 2
 #endif
 
+// Stage-0 LightConv3x3 as ONE dense 3x3 on the matrix pipe (reid_pack.hpp pack_light_dense): no LDS image, no depthwise
+// VALU loop -- per 16-pixel tile 3 K=32 + 3 K=16 MFMAs on pixel-shifted copies of the rows (DPP row shifts inside a tile, the
+// neighbour tile's edge pixel by a row rotate), rows of other waves through a 2 x 16 KiB LDS halo exchange (one barrier per
+// layer).  0 = the round-1 layer (1x1 MFMA -> LDS image -> sliding-window depthwise on packed-fp16 FMAs).
+#ifndef BM_DENSE_LIGHT
+#define BM_DENSE_LIGHT 0
+#endif
+
 template <int STAGE>
 struct Geo {
     static constexpr int H = 64 >> STAGE, W = 32 >> STAGE, P = H * W;
@@ -73,7 +81,9 @@ struct Geo {
     static constexpr int ROWB = (W + 2) * PXB;
     static constexpr int IMG = (H + 2) * ROWB;
     // stage 2 with LDS-staged epilogue operands: conv3 (8 KiB) + bias + downsample 96 -> 128 (24 KiB) outgrow the image
-    static constexpr int TBUF = (STAGE == 2 && BM_STAGE2_EPI_LDS && IMG < 33280) ? 33280 : IMG;
+    static constexpr bool DENSE = BM_DENSE_LIGHT && STAGE == 0;
+    static constexpr int HALO = 2 * NWAVES * 2 * 2 * 64 * 8;       // [layer parity][wave][first / last row][half][lane] h4
+    static constexpr int TBUF = DENSE ? HALO : ((STAGE == 2 && BM_STAGE2_EPI_LDS && IMG < 33280) ? 33280 : IMG);
     static constexpr int LDS_BYTES = TBUF + 4 * NWAVES * HID * 4;          // image + per-branch gate partials
 };
 
@@ -125,6 +135,33 @@ __device__ inline h8 cat8(h4 a, h4 b) { return h8{a[0], a[1], a[2], a[3], b[0], 
 //     recomputes it per tile from the PREVIOUS block's branch sum and input (`in` is the previous block's input;
 //     conv3 / bias / downsample fragments of the previous block at link.a0 / a1 / a2 of `link.w`).  Same operations
 //     in the same order on the same fp16 values: bit-identical to storing and re-reading the tensor.
+typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+// Value of the pixel to the left (x - 1) / right (x + 1) of every lane's pixel in a 16-pixel row tile, as DPP moves inside the
+// rows of 16 lanes (lane = pixel + 16 * channel group: a row of lanes is one channel group of the tile's 16 pixels).  The
+// tile's outer lane takes the facing edge pixel of the neighbour tile `edge` (row rotate), or zero at the image border.
+template <bool HAS_EDGE>
+__device__ inline h4 pixel_left(h4 c, h4 edge) {
+    const u2v u = __builtin_bit_cast(u2v, c), e = __builtin_bit_cast(u2v, edge);
+    u2v r;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        if constexpr (HAS_EDGE) r[d] = BM_DPP_U32(BM_DPP_U32(0u, e[d], 0x121, true), u[d], 0x111, false);      // row_ror:1, then row_shr:1 keeping lane 0
+        else r[d] = BM_DPP_U32(0u, u[d], 0x111, true);
+    }
+    return __builtin_bit_cast(h4, r);
+}
+template <bool HAS_EDGE>
+__device__ inline h4 pixel_right(h4 c, h4 edge) {
+    const u2v u = __builtin_bit_cast(u2v, c), e = __builtin_bit_cast(u2v, edge);
+    u2v r;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        if constexpr (HAS_EDGE) r[d] = BM_DPP_U32(BM_DPP_U32(0u, e[d], 0x12F, true), u[d], 0x101, false);      // row_ror:15, then row_shl:1 keeping lane 15
+        else r[d] = BM_DPP_U32(0u, u[d], 0x101, true);
+    }
+    return __builtin_bit_cast(h4, r);
+}
+
 struct BlkLink {
     const unsigned char* w = nullptr;
     long a0 = 0, a1 = 0, a2 = 0;
@@ -158,7 +195,8 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
     BM_PROF_DECL();
 
     // zero the LDS image once: the halo ring stays zero (= the dw conv's zero padding)
-    for (int e = tid * 8; e < G::IMG; e += 64 * G::NWAVES * 8) *reinterpret_cast<unsigned long long*>(tbuf + e) = 0ull;
+    if constexpr (!G::DENSE)
+        for (int e = tid * 8; e < G::IMG; e += 64 * G::NWAVES * 8) *reinterpret_cast<unsigned long long*>(tbuf + e) = 0ull;
 
     // ---- conv1: 1x1 CIN -> MID, + bias, ReLU (osnet.py:248) ----
     auto conv1_into = [&](h4 (&x1)[NT][KT]) {
@@ -311,6 +349,65 @@ k_osblock(const _Float16* __restrict__ in, _Float16* __restrict__ out, const uns
 #pragma unroll 1
         for (int k = 0; k <= br; ++k, ++li) {
             const unsigned char* lw = wts + bp.light0 + (long)li * bp.light_bytes;
+            if constexpr (G::DENSE) {
+                // ---- LightConv3x3 as a dense 3x3 on the matrix pipe (pack_light_dense) ----
+                static_assert(!G::DENSE || (STAGE == 0 && KT == 1 && NT == 16), "dense LightConv: stage 0 geometry");
+                const unsigned char* ld = wts + bp.dense0 + (long)li * bp.dense_bytes;
+                h8 aP[3];
+                h4 aR[3];
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    aP[dy] = *reinterpret_cast<const h8*>(ld + dy * 1024 + lane * 16);
+                    aR[dy] = *reinterpret_cast<const h4*>(ld + 3072 + dy * 512 + lane * 8);
+                }
+                const f4 lbias = *reinterpret_cast<const f4*>(lw + bp.light_b + (4 * g) * 4);
+                // rows of the neighbouring waves: every wave publishes its first and last row, one barrier, then reads the row
+                // above its strip (last row of wave - 1) and below it (first row of wave + 1); the two buffers alternate by
+                // layer, so a wave that is one layer ahead never overwrites rows a slower wave still has to read
+                unsigned char* hb = tbuf + (li & 1) * (G::HALO / 2);
+                auto hslot = [&](int w, int which, int hf) { return hb + (((w * 2 + which) * 2 + hf) * 64 + lane) * 8; };
+                *reinterpret_cast<h4*>(hslot(wave, 0, 0)) = cur[0][0];
+                *reinterpret_cast<h4*>(hslot(wave, 0, 1)) = cur[1][0];
+                *reinterpret_cast<h4*>(hslot(wave, 1, 0)) = cur[NT - 2][0];
+                *reinterpret_cast<h4*>(hslot(wave, 1, 1)) = cur[NT - 1][0];
+                BM_PROF(2);
+                __syncthreads();
+                BM_PROF(3);
+                const h4 zero4 = (h4)(_Float16)0.f;
+                h4 up[2] = {zero4, zero4}, dn[2] = {zero4, zero4};
+                if (wave > 0) { up[0] = *reinterpret_cast<const h4*>(hslot(wave - 1, 1, 0)); up[1] = *reinterpret_cast<const h4*>(hslot(wave - 1, 1, 1)); }
+                if (wave < G::NWAVES - 1) { dn[0] = *reinterpret_cast<const h4*>(hslot(wave + 1, 0, 0)); dn[1] = *reinterpret_cast<const h4*>(hslot(wave + 1, 0, 1)); }
+                struct RowOps { h8 P[2]; h4 R[2]; };
+                auto build = [&](h4 c0, h4 c1) {
+                    RowOps o;
+                    o.P[0] = cat8(pixel_left<false>(c0, c0), c0);
+                    o.P[1] = cat8(pixel_left<true>(c1, c0), c1);
+                    o.R[0] = pixel_right<true>(c0, c1);
+                    o.R[1] = pixel_right<false>(c1, c1);
+                    return o;
+                };
+                RowOps w0 = build(up[0], up[1]), w1 = build(cur[0][0], cur[1][0]);
+#pragma unroll
+                for (int r = 0; r < NT / 2; ++r) {
+                    const RowOps w2 = r + 1 < NT / 2 ? build(cur[2 * r + 2][0], cur[2 * r + 3][0]) : build(dn[0], dn[1]);
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        f4 accP = lbias, accR = f4{0.f, 0.f, 0.f, 0.f};      // one MFMA shape per accumulator
+                        accP = BM_MFMA_F16_K32(aP[0], w0.P[hf], accP);
+                        accR = BM_MFMA_F16_K16(aR[0], w0.R[hf], accR);
+                        accP = BM_MFMA_F16_K32(aP[1], w1.P[hf], accP);
+                        accR = BM_MFMA_F16_K16(aR[1], w1.R[hf], accR);
+                        accP = BM_MFMA_F16_K32(aP[2], w2.P[hf], accP);
+                        accR = BM_MFMA_F16_K16(aR[2], w2.R[hf], accR);
+                        cur[2 * r + hf][0] = relu_h4(to_h4(f4{accP[0] + accR[0], accP[1] + accR[1], accP[2] + accR[2], accP[3] + accR[3]}));
+                    }
+                    w0 = w1; w1 = w2;
+                    BM_SCHED_FENCE();
+                }
+                BM_PROF(4);
+                BM_PROF(5);
+                continue;
+            }
             // 1x1 (linear): t = W_pw . cur  -> LDS image (fp16)
             if constexpr (KT == 1) {
                 const h4 a = *reinterpret_cast<const h4*>(lw + bp.light_pw + lane * 8);

@@ -56,8 +56,10 @@ struct BlkPack {
     long fc1_w, fc1_b, fc2_w, fc2_b;
     long conv3_a, conv3_b;       // [nct] fragments, fp32 bias[cout] (conv3 + downsample biases)
     long down_a;                 // [nct][ks] fragments
+    long dense0, dense_bytes;    // stage 0 only: per light, the 1x1 and the depthwise 3x3 composed into one dense 3x3 (pack_light_dense)
     long total;
 };
+constexpr long DENSE_LIGHT_BYTES = 3 * 1024 + 3 * 512;
 
 inline BlkPack make_blk_pack(int stage, int cin, int down) {
     static const int MID[3] = {16, 24, 32}, COUT[3] = {64, 96, 128};
@@ -83,6 +85,8 @@ inline BlkPack make_blk_pack(int stage, int cin, int down) {
     b.conv3_a = take(b.nct * frag_mid);
     b.conv3_b = take(b.cout * 4);
     b.down_a = take(down ? b.nct * b.kin_steps * frag_in : 0);
+    b.dense_bytes = DENSE_LIGHT_BYTES;
+    b.dense0 = stage == 0 ? take(10 * DENSE_LIGHT_BYTES) : 0;
     b.total = off;
     return b;
 }
@@ -110,6 +114,27 @@ inline void put_f32(std::vector<uint8_t>& buf, long off, const float* src, int n
     for (int i = 0; i < n_padded; ++i) {
         const float v = i < n_real ? src[i] : 0.f;
         std::memcpy(buf.data() + off + 4L * i, &v, 4);
+    }
+}
+
+// LightConv3x3 = 1x1 (linear, mid -> mid) then depthwise 3x3 (+ folded BN): out[co][p] = sum_tap wd[co][tap] * sum_ci W1[co][ci] *
+// x[ci][p + tap], i.e. ONE dense 3x3 convolution with weights wd[co][tap] * W1[co][ci].  For a 16-channel mid width its
+// K = 9 x 16 runs on the matrix pipe as, per image row dy of the window, one K=32 fragment "P" over the taps (x - 1, x) and one
+// K=16 fragment "R" over the tap x + 1 (the kernel keeps the pixel-shifted copies of a row as [left | centre] and [right]):
+//   P_dy: lane (co = lane & 15, g), k-slot j -> tap dx = j >> 2, input channel 4 g + (j & 3)
+//   R_dy: lane (co, g), k-slot j -> tap dx = 2, input channel 4 g + j
+// The products are formed in fp32 and rounded to fp16 once.
+inline void pack_light_dense(const float* w1 /*[16][16]*/, const float* wd /*[16][9]*/, uint8_t* dst) {
+    for (int dy = 0; dy < 3; ++dy) {
+        uint16_t* P = reinterpret_cast<uint16_t*>(dst + dy * 1024);
+        uint16_t* R = reinterpret_cast<uint16_t*>(dst + 3 * 1024 + dy * 512);
+        for (int lane = 0; lane < 64; ++lane) {
+            const int co = lane & 15, g = lane >> 4;
+            for (int j = 0; j < 8; ++j)
+                P[lane * 8 + j] = f32_to_f16_bits(wd[co * 9 + dy * 3 + (j >> 2)] * w1[co * 16 + 4 * g + (j & 3)]);
+            for (int j = 0; j < 4; ++j)
+                R[lane * 4 + j] = f32_to_f16_bits(wd[co * 9 + dy * 3 + 2] * w1[co * 16 + 4 * g + j]);
+        }
     }
 }
 
@@ -143,6 +168,7 @@ inline void pack_osblock(const float* w, const BlockW& B, const BlkPack& P, std:
                         }
         }
         put_f32(out, base + P.light_b, w + B.light[l].b, P.mid, P.midp);
+        if (P.stage == 0) pack_light_dense(w + B.light[l].pw, w + B.light[l].dw, out.data() + P.dense0 + l * P.dense_bytes);
     }
     // gate: fc1 [hid][midp] (padded columns zero), fc2 [midp][hid]
     for (int h = 0; h < P.hid; ++h) put_f32(out, P.fc1_w + 4L * h * P.midp, w + B.fc1_w + (long)h * P.mid, P.mid, P.midp);

@@ -17,6 +17,7 @@ ROOT = Path(__file__).resolve().parents[1]
 OUT = ROOT / "tools" / "_build"
 VARIANTS = {
     "base": [],
+    "dense": ["-DBM_DENSE_LIGHT=1"],                  # stage-0 LightConv as a dense 3x3 on the matrix pipe
     "head_per_crop": ["-DBM_HEAD_PER_CROP=1"],        # the round-1 head instead of k_head_batched
     "no_prefetch": ["-DBM_PREFETCH_CONV1=0", "-DBM_PREFETCH_EPI=0"],     # round-1 load order in conv1 / epilogue
     "pf_epi_all": ["-DBM_PREFETCH_EPI=1"],
