@@ -160,6 +160,7 @@ SIGNATURES = {
     "boxmot_hip_reid_set_preprocess": (_I, [_VP, ctypes.c_char_p]),
     "boxmot_hip_reid_compute_features": (_I, [_VP, _VP, _I, _I, _I, _VP, _I, _I, _VP, _I]),
     "boxmot_hip_reid_preprocess": (_I, [_VP, _VP, _I, _I, _I, _VP, _I, _I, _VP]),
+    "boxmot_hip_reid_last_time_ms": (_I, [_VP, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "boxmot_hip_last_error": (ctypes.c_char_p, []),
     "boxmot_hip_device_count": (_I, []),
 }

@@ -1122,6 +1122,16 @@ int boxmot_hip_reid_compute_features(BoxMOTHipReID* handle, const uint8_t* image
     });
 }
 
+int boxmot_hip_reid_last_time_ms(BoxMOTHipReID* handle, double* out_preprocess_ms, double* out_process_ms) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip: null ReID handle");
+        double pre = 0, proc = 0;
+        handle->engine->last_times(pre, proc);
+        if (out_preprocess_ms) *out_preprocess_ms = pre;
+        if (out_process_ms) *out_process_ms = proc;
+    });
+}
+
 int boxmot_hip_reid_preprocess(BoxMOTHipReID* handle, const uint8_t* image, int image_rows, int image_cols,
                                int image_channels, const float* boxes, int n_boxes, int box_cols, float* out_crops) {
     return guard([&]() {
@@ -1470,8 +1480,9 @@ int blob_feature_dim(const std::string& path) {
     int32_t hdr[bm::REID_HEADER_INTS] = {0};
     const size_t got = std::fread(hdr, 4, bm::REID_HEADER_INTS, f);
     std::fclose(f);
+    if (got == (size_t)bm::REID_HEADER_INTS && hdr[0] == bm::CLIP_MAGIC) return hdr[1] + hdr[7];       // CLIP-ReID: width + projection
     if (got != (size_t)bm::REID_HEADER_INTS || hdr[0] != bm::REID_MAGIC)
-        throw std::runtime_error("ReID weights must be an OSN1 blob (boxmot_amd.reid_weights.save_blob): " + path);
+        throw std::runtime_error("ReID weights must be an OSN1 (OSNet) or CLP1 (CLIP-ReID) blob (boxmot_amd.reid_weights / clip_weights): " + path);
     return hdr[5];
 }
 }  // namespace

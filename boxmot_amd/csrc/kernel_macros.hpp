@@ -35,6 +35,11 @@
 // raw DPP move: lanes whose source lane does not exist take 0 (zero_fill) or keep `old`
 #define BM_DPP_U32(old, v, ctrl, zero_fill) ((unsigned)__builtin_amdgcn_update_dpp((int)(old), (int)(v), ctrl, 0xf, 0xf, zero_fill))
 #endif
+#ifndef BM_WAVE_LDS_SYNC
+// LDS written by some lanes of a wavefront and read by others of the SAME wavefront: the DS operations of one wave execute in
+// order, so only the compiler has to be kept from reordering them (no workgroup barrier)
+#define BM_WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#endif
 #ifndef BM_RELU_F32
 // max(v, 0) as one integer max on the bit pattern (negative floats are negative ints); a float max costs a second,
 // canonicalising v_max under IEEE mode

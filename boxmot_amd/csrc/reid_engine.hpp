@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -17,6 +18,7 @@
 #include "reid_layout.hpp"
 #include "reid_kernels_v1.hpp"
 #include "reid_fused.hpp"
+#include "clip_engine.hpp"
 
 #ifndef BM_STAGE1_HANDOVER
 #define BM_STAGE1_HANDOVER 0
@@ -63,28 +65,40 @@ public:
         : max_crops_(max_crops), fused_cap_(fused_cap > max_crops ? fused_cap : max_crops) {
         if (n_floats < REID_HEADER_INTS) throw std::runtime_error("ReID blob too small");
         const int32_t* hdr = reinterpret_cast<const int32_t*>(blob);
-        if (hdr[0] != REID_MAGIC) throw std::runtime_error("ReID blob: bad magic (expected OSN1)");
-        const int ch[4] = {hdr[1], hdr[2], hdr[3], hdr[4]};
-        L_ = make_osnet_layout(ch, hdr[5]);
-        if (hdr[6] != (int32_t)L_.total || n_floats != REID_HEADER_INTS + L_.total)
-            throw std::runtime_error("ReID blob: size does not match the declared architecture");
-        if (ch[0] != 16 && ch[0] != 64) throw std::runtime_error("ReID: unsupported stem width");
-        d_w_ = dev_alloc<float>((size_t)L_.total, owned_);
-        BM_HIP(hipMemcpy(d_w_, blob + REID_HEADER_INTS, (size_t)L_.total * 4, hipMemcpyHostToDevice));
-        h_w_.assign(blob + REID_HEADER_INTS, blob + REID_HEADER_INTS + L_.total);
-        // (x/255 - mean)/std in fp32, exactly as base_backend.py:189-193 evaluates it
+        // normalisation table (x/255 - mean)/std in fp32, exactly as base_backend.py:189-193 evaluates it; "clip" models use
+        // mean = std = 0.5 (base_backend.py:50-54)
+        const bool is_clip = hdr[0] == CLIP_MAGIC;
         float lut[3 * 256];
-        const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+        const float mean_i[3] = {0.485f, 0.456f, 0.406f}, std_i[3] = {0.229f, 0.224f, 0.225f};
         for (int c = 0; c < 3; ++c)
             for (int v = 0; v < 256; ++v) {
                 volatile float a = (float)v / 255.0f;
-                volatile float b = a - mean[c];
-                lut[c * 256 + v] = b / stdv[c];
+                volatile float b = a - (is_clip ? 0.5f : mean_i[c]);
+                lut[c * 256 + v] = b / (is_clip ? 0.5f : std_i[c]);
             }
         d_lut_ = dev_alloc<float>(3 * 256, owned_);
         BM_HIP(hipMemcpy(d_lut_, lut, sizeof(lut), hipMemcpyHostToDevice));
-        alloc_buffers();
-        if (ch[0] == 16 && ch[1] == 64 && ch[2] == 96 && ch[3] == 128 && L_.feat == 512) prepare_fused();
+        if (is_clip) {
+            // CLIP-ReID (ViT-B/16): one kernel family (fp16 GEMM operands, fp32 residual stream); crops through the standalone
+            // crop kernel, then clip_engine.hpp
+            clip_.reset(new ClipNet(blob, n_floats, max_crops, owned_));
+            if (clip_->in_h != REID_IN_H || clip_->in_w != REID_IN_W)
+                throw std::runtime_error("CLIP-ReID: the crop kernels produce 256 x 128 inputs only");
+            crops_ = dev_alloc<float>((size_t)max_crops * REID_IN_H * REID_IN_W * 3, owned_);
+            L_.feat = clip_->feature_dim();
+        } else {
+            if (hdr[0] != REID_MAGIC) throw std::runtime_error("ReID blob: bad magic (expected OSN1 or CLP1)");
+            const int ch[4] = {hdr[1], hdr[2], hdr[3], hdr[4]};
+            L_ = make_osnet_layout(ch, hdr[5]);
+            if (hdr[6] != (int32_t)L_.total || n_floats != REID_HEADER_INTS + L_.total)
+                throw std::runtime_error("ReID blob: size does not match the declared architecture");
+            if (ch[0] != 16 && ch[0] != 64) throw std::runtime_error("ReID: unsupported stem width");
+            d_w_ = dev_alloc<float>((size_t)L_.total, owned_);
+            BM_HIP(hipMemcpy(d_w_, blob + REID_HEADER_INTS, (size_t)L_.total * 4, hipMemcpyHostToDevice));
+            h_w_.assign(blob + REID_HEADER_INTS, blob + REID_HEADER_INTS + L_.total);
+            alloc_buffers();
+            if (ch[0] == 16 && ch[1] == 64 && ch[2] == 96 && ch[3] == 128 && L_.feat == 512) prepare_fused();
+        }
         BM_HIP(hipEventCreate(&ev_[0]));
         BM_HIP(hipEventCreate(&ev_[1]));
         BM_HIP(hipEventCreate(&ev_[2]));
@@ -98,6 +112,7 @@ public:
     int max_crops() const { return max_crops_; }
     void set_mode(int m) {
         if (m != 0 && m != 1) throw std::runtime_error("ReID mode must be 0 (per-layer fp32) or 1 (fused fp16 MFMA)");
+        if (clip_) return;                  // CLIP-ReID has one kernel family; the mode switch is OSNet's
         if (m == 1 && !fused_ready_) throw std::runtime_error("fused fp16 ReID kernels are built for OSNet-x0.25 only");
         mode_ = m;
     }
@@ -147,7 +162,8 @@ public:
             BM_HIP(hipEventRecord(a, st));
             float* o = d_out_rows ? d_out : d_out + (long)i0 * L_.feat;
             const int* orow = d_out_rows ? d_out_rows + i0 : nullptr;
-            if (mode_ == 1) {
+            if (clip_) clip_->forward(crops_, m, o, orow, st);
+            else if (mode_ == 1) {
                 const FrameArgs fa{d_frames, d_crop_stream + i0, d_boxes + (long)i0 * box_stride, box_stride, W, H};
                 forward_fused(m, fuse_stem ? &fa : nullptr, o, orow, st);
             } else forward_v1(m, o, orow, st);
@@ -416,6 +432,7 @@ private:
     float *crops_ = nullptr, *big_a_ = nullptr, *big_b_ = nullptr, *idn_ = nullptr;
     float *x1_ = nullptr, *ta_ = nullptr, *tb_ = nullptr, *tt_ = nullptr, *acc_ = nullptr, *gap_ = nullptr;
     // fused path
+    std::unique_ptr<ClipNet> clip_;         // non-null: the weights are a CLP1 blob (CLIP-ReID ViT-B/16)
     bool fused_ready_ = false, force_fp32_crops_ = false, fuse_stem_ = true;
     int pad_ = 0;
     BlkPack bp_[6];

@@ -4,7 +4,9 @@
 ``BaseModelBackend.get_features`` (boxmot/reid/backends/base_backend.py:197-217):
 boxes ``(N, >=4)`` xyxy + a BGR uint8 frame in, ``(N, 512)`` float32
 L2-normalised embeddings out (``np.array([])``-like empty result for no boxes);
-``warmup()`` exists.  Crop / resize / normalise / OSNet / L2 all run in HIP
+``warmup()`` exists.  Two backbones, chosen by the checkpoint's parameter names: OSNet (512-d; x0.25 has the fused fp16
+MFMA kernel family) and CLIP-ReID ViT-B/16 (1280-d, make_model.py:95-139; crops normalised with mean = std = 0.5 as
+base_backend.py:50-54 does for "clip" models).  Crop / resize / normalise / backbone / L2 all run in HIP
 kernels through the ReID C ABI (include/boxmot_hip.h, replacing
 boxmot/native/cpp/trackers/base/include/boxmot/trackers/base/reid_capi.h:36-94).
 PyTorch is only the container the weights are read from.
@@ -26,7 +28,7 @@ class HipReID:
     input_shape = (256, 128)
 
     def __init__(self, weights, max_crops: int = 1024, mode: int = MODE_FP32_LAYERWISE, preprocess: str | None = None):
-        """``weights``: state_dict, ``.pt`` checkpoint path, OSN1 blob path or blob array.  ``preprocess``: "resize"
+        """``weights``: state_dict, ``.pt`` checkpoint path, OSN1 / CLP1 blob path or blob array.  ``preprocess``: "resize"
         (default) or "resize_pad" (reid/core/preprocessing.py:48-65)."""
         self._lib = _lib.load()
         self.blob = load_weights(weights)
@@ -89,6 +91,12 @@ class HipReID:
             _lib.check(self._lib.boxmot_hip_reid_preprocess(
                 self._handle, a.ctypes.data, a.shape[0], a.shape[1], 3, boxes.ctypes.data, n, 4, out.ctypes.data))
         return np.ascontiguousarray(np.transpose(out, (0, 3, 1, 2)))
+
+    def last_time_ms(self):
+        """(preprocess, backbone) device milliseconds of the last ``get_features`` chunk (HIP events)."""
+        pre, proc = ctypes.c_double(0), ctypes.c_double(0)
+        _lib.check(self._lib.boxmot_hip_reid_last_time_ms(self._handle, ctypes.byref(pre), ctypes.byref(proc)))
+        return pre.value, proc.value
 
     def warmup(self, imgsz=((256, 128, 3),)):
         im = np.random.randint(0, 255, imgsz[0], dtype=np.uint8)

@@ -113,8 +113,19 @@ def save_blob(blob: np.ndarray, path) -> Path:
     return path
 
 
+def _pack_state_dict(sd):
+    """OSNet or CLIP-ReID by the parameter names of the checkpoint (the reference picks the architecture from the file name,
+    reid/core/registry.py; the names are what the file actually holds)."""
+    inner = sd.get("state_dict", sd) if isinstance(sd, dict) and "state_dict" in sd else sd
+    if any(k.replace("module.", "", 1).startswith("image_encoder.") for k in inner):
+        from boxmot_amd.clip_weights import pack_clipreid
+
+        return pack_clipreid(sd)
+    return pack_osnet(sd)
+
+
 def load_weights(weights):
-    """Accepts a state_dict, a ``.pt`` checkpoint path, an OSN1 blob path or a blob array."""
+    """Accepts a state_dict, a ``.pt`` checkpoint path, an OSN1 / CLP1 blob path or a blob array."""
     if isinstance(weights, np.ndarray):
         return np.ascontiguousarray(weights, dtype=np.float32)
     if isinstance(weights, (str, Path)):
@@ -122,9 +133,9 @@ def load_weights(weights):
         if path.suffix == ".pt" or path.suffix == ".pth":
             import torch
 
-            return pack_osnet(torch.load(path, map_location="cpu", weights_only=False))
+            return _pack_state_dict(torch.load(path, map_location="cpu", weights_only=False))
         return np.fromfile(path, dtype=np.float32)
-    return pack_osnet(weights)
+    return _pack_state_dict(weights)
 
 
 def reference_init_state_dict(arch: str = "osnet_x0_25", seed: int = 0):

@@ -38,6 +38,7 @@ class StrongSort(BaseTracker):
         ema_alpha: float = 0.9,
         # not reference parameters: camera-motion provider and capacity of the device-resident track table
         cmc: Any | None = None,
+        reid_weights: Any | None = None,
         max_tracks: int = 1024,
         max_dets: int = 256,
         emb_dim: int | None = None,
@@ -56,6 +57,23 @@ class StrongSort(BaseTracker):
         self._emb_dim = emb_dim or getattr(self.model, "feature_dim", None) or 512
         cfg = _lib.StrongSortConfig()
         self._lib.boxmot_hip_strongsort_default_config(ctypes.byref(cfg))
+        # reid_weights (state_dict / checkpoint / OSN1 or CLP1 blob): the handle runs crops -> backbone on the device inside
+        # update (the C ABI's reid_model_path) instead of asking a Python-side model -- no embedding round trip over PCIe
+        self._device_reid = reid_weights is not None
+        self._blob_file = None
+        if self._device_reid:
+            import os
+            import tempfile
+
+            from boxmot_amd.reid_weights import load_weights, save_blob
+            if isinstance(reid_weights, (str, os.PathLike)) and not str(reid_weights).endswith((".pt", ".pth")):
+                path = str(reid_weights)
+            else:
+                fd, path = tempfile.mkstemp(suffix=".reidblob")
+                os.close(fd)
+                save_blob(load_weights(reid_weights), path)
+                self._blob_file = path
+            cfg.reid_model_path = path.encode()
         cfg.max_age, cfg.min_conf, cfg.max_cos_dist, cfg.max_iou_dist = self.max_age, min_conf, max_cos_dist, max_iou_dist
         cfg.n_init, cfg.nn_budget, cfg.mc_lambda, cfg.ema_alpha = n_init, nn_budget, mc_lambda, ema_alpha
         cfg.n_streams, cfg.max_tracks, cfg.max_dets, cfg.emb_dim = 1, max_tracks, max_dets, self._emb_dim
@@ -63,6 +81,9 @@ class StrongSort(BaseTracker):
         self._max_tracks = max_tracks
         self._n_tracks = 0          # len(self.tracker.tracks) after the last update (gates the camera-motion estimator)
         self._handle = self._lib.boxmot_hip_strongsort_create(ctypes.byref(cfg))
+        if self._blob_file:
+            import os
+            os.unlink(self._blob_file)       # read at create
         if not self._handle:
             raise RuntimeError(_lib.last_error())
 
@@ -80,11 +101,13 @@ class StrongSort(BaseTracker):
         if n:
             if embs is not None:
                 feats = np.ascontiguousarray(embs, dtype=np.float32)
+            elif self._device_reid:
+                feats = None            # the handle crops and embeds the detections with conf >= min_conf itself
             else:
                 feats = np.zeros((n, self._emb_dim), dtype=np.float32)
                 if keep.any():
                     feats[keep] = self.model.get_features(det_arr[keep, :4], img)       # strongsort.py:91
-            if feats.shape[1] != self._emb_dim:
+            if feats is not None and feats.shape[1] != self._emb_dim:
                 raise ValueError(f"embedding width {feats.shape[1]} != emb_dim {self._emb_dim}")
         img_arr = np.ascontiguousarray(img)
         out = np.empty((max(n, 1), 9), dtype=np.float32)

@@ -48,7 +48,7 @@ typedef struct BoxMOTHipBotSortConfig {
     int fuse_first_associate;
     int with_reid;
     int max_obs;                     /* accepted for signature parity; display-only state */
-    const char* reid_model_path;     /* OSN1 weight blob (boxmot_amd.reid_weights.save_blob) or NULL */
+    const char* reid_model_path;     /* OSN1 (OSNet) or CLP1 (CLIP-ReID ViT-B/16) weight blob (boxmot_amd.reid_weights / clip_weights) or NULL */
     const char* reid_preprocess;     /* NULL or "resize" */
     double second_match_thresh;
     double unconfirmed_match_thresh;
@@ -188,6 +188,10 @@ int boxmot_hip_reid_preprocess(
     BoxMOTHipReID* handle, const uint8_t* image, int image_rows, int image_cols, int image_channels,
     const float* boxes, int n_boxes, int box_cols, float* out_crops);
 
+/* device milliseconds (HIP events on the handle's stream) of the last compute_features: crop / resize / normalise, and the
+ * backbone forward (cf. boxmot_botsort_last_reid_{preprocess,process}_time_ms, c_api.hpp:58-59) */
+int boxmot_hip_reid_last_time_ms(BoxMOTHipReID* handle, double* out_preprocess_ms, double* out_process_ms);
+
 const char* boxmot_hip_last_error(void);
 /* number of visible HIP devices (0 when none / runtime unusable) */
 int boxmot_hip_device_count(void);
@@ -214,7 +218,7 @@ typedef struct BoxMOTHipDeepOcSortConfig {
     int aw_off;
     double Q_xy_scaling;
     double Q_s_scaling;
-    const char* reid_model_path;     /* OSN1 blob (boxmot_amd.reid_weights.save_blob) or NULL when embeddings are supplied */
+    const char* reid_model_path;     /* OSN1 / CLP1 blob or NULL when embeddings are supplied */
     int n_streams;
     int max_tracks;
     int max_dets;
@@ -285,7 +289,7 @@ typedef struct BoxMOTHipStrongSortConfig {
     int nn_budget;                   /* 1..1024 samples per track (None is not supported) */
     double mc_lambda;
     double ema_alpha;
-    const char* reid_model_path;     /* OSN1 blob or NULL when embeddings are supplied */
+    const char* reid_model_path;     /* OSN1 / CLP1 blob or NULL when embeddings are supplied */
     int n_streams;
     int max_tracks;
     int max_dets;

@@ -143,11 +143,14 @@ def get_crops_u8(xyxys: np.ndarray, img: np.ndarray, input_shape=(256, 128), pre
     return out
 
 
-def normalize_crops(crops_u8: np.ndarray) -> np.ndarray:
-    """base_backend.py:183-193: NCHW fp32, ``/255.0`` then ``(x - mean) / std``."""
+def normalize_crops(crops_u8: np.ndarray, mean=None, std=None) -> np.ndarray:
+    """base_backend.py:183-193: NCHW fp32, ``/255.0`` then ``(x - mean) / std``; mean / std default to the ImageNet values,
+    "clip" models use 0.5 / 0.5 (base_backend.py:50-54)."""
+    m = MEAN_RGB if mean is None else np.asarray(mean, dtype=np.float32)
+    s = STD_RGB if std is None else np.asarray(std, dtype=np.float32)
     x = np.ascontiguousarray(np.transpose(crops_u8, (0, 3, 1, 2))).astype(np.float32)
     x = x / np.float32(255.0)
-    x = (x - MEAN_RGB.reshape(1, 3, 1, 1)) / STD_RGB.reshape(1, 3, 1, 1)
+    x = (x - m.reshape(1, 3, 1, 1)) / s.reshape(1, 3, 1, 1)
     return np.ascontiguousarray(x, dtype=np.float32)
 
 
@@ -157,5 +160,5 @@ def normalization_lut() -> np.ndarray:
     return ((v[None, :] - MEAN_RGB[:, None]) / STD_RGB[:, None]).astype(np.float32)
 
 
-def get_crops(xyxys: np.ndarray, img: np.ndarray, input_shape=(256, 128), preprocess: str = "resize") -> np.ndarray:
-    return normalize_crops(get_crops_u8(xyxys, img, input_shape, preprocess))
+def get_crops(xyxys: np.ndarray, img: np.ndarray, input_shape=(256, 128), preprocess: str = "resize", mean=None, std=None) -> np.ndarray:
+    return normalize_crops(get_crops_u8(xyxys, img, input_shape, preprocess), mean, std)

@@ -26,6 +26,7 @@ struct EmuDim3 { unsigned x = 0, y = 0, z = 0; };
 extern thread_local EmuDim3 threadIdx;
 extern thread_local EmuDim3 blockIdx;
 extern EmuDim3 blockDim;
+extern EmuDim3 gridDim;
 
 #define BM_CLOCK() 0LL
 constexpr int EMU_WAVE = 64;
@@ -167,3 +168,4 @@ inline emu_f4 emu_mfma_f32_k4(float a, float b, emu_f4 c) {
     return d;
 }
 #define BM_MFMA_F32_K4(a, b, c) emu_mfma_f32_k4(a, b, c)
+#define BM_WAVE_LDS_SYNC() g_emu_block->wave_barrier[threadIdx.x / EMU_WAVE].wait()
