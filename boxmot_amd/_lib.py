@@ -140,6 +140,9 @@ SIGNATURES = {
                                                  c_int_p, c_int_p]),
     "boxmot_hip_deepocsort_update_batch": (_I, [_VP, _I, _VP, _VP, _VP, _I, _VP, _I, _I, _I, _VP, _I, _VP]),
     "boxmot_hip_deepocsort_step_device": (_I, [_VP, _VP, _VP, _VP, _VP, _VP]),
+    "boxmot_hip_deepocsort_step_device_frames": (_I, [_VP, _VP, _VP, _VP, _I, _I, _VP, _VP]),
+    "boxmot_hip_deepocsort_reid_kernel_ms": (_I, [_VP, ctypes.POINTER(ctypes.c_double), c_int_p]),
+    "boxmot_hip_deepocsort_set_reid_mode": (_I, [_VP, _I]),
     "boxmot_hip_deepocsort_synchronize": (_I, [_VP]),
     "boxmot_hip_deepocsort_state_dump": (_I, [_VP, _I, _VP, _VP, _VP, c_int_p, c_int_p, c_int_p]),
     "boxmot_hip_strongsort_default_config": (None, [ctypes.POINTER(StrongSortConfig)]),
@@ -150,6 +153,9 @@ SIGNATURES = {
     "boxmot_hip_strongsort_update": (_I, [_VP, _VP, _I, _I, _VP, _I, _I, _VP, _I, _I, _I, _VP, _I, _I, c_int_p, c_int_p]),
     "boxmot_hip_strongsort_update_batch": (_I, [_VP, _I, _VP, _VP, _VP, _I, _VP, _I, _I, _I, _VP, _I, _VP]),
     "boxmot_hip_strongsort_step_device": (_I, [_VP, _VP, _VP, _VP, _VP, _VP]),
+    "boxmot_hip_strongsort_step_device_frames": (_I, [_VP, _VP, _VP, _VP, _I, _I, _VP, _VP]),
+    "boxmot_hip_strongsort_reid_kernel_ms": (_I, [_VP, ctypes.POINTER(ctypes.c_double), c_int_p]),
+    "boxmot_hip_strongsort_set_reid_mode": (_I, [_VP, _I]),
     "boxmot_hip_strongsort_synchronize": (_I, [_VP]),
     "boxmot_hip_strongsort_track_count": (_I, [_VP, _I, c_int_p]),
     "boxmot_hip_strongsort_state_dump": (_I, [_VP, _I, _VP, _VP, _VP, c_int_p, c_int_p, c_int_p]),

@@ -349,7 +349,7 @@ void run_reid(BoxMOTHipBotSort* h, int s0, int n_streams, const float* d_dets, c
     BM_HIP(hipMemsetAsync(h->d_crop_count, 0, 4, h->stream));
     hipLaunchKernelGGL(build_crop_list_kernel, dim3(n_streams), dim3(256), 0, h->stream, d_dets, d_ndets, h->nd,
                        h->cfg.track_high_thresh, h->d_crop_count, h->d_crop_stream, h->d_crop_boxes, h->d_crop_row, s0);
-    if (h->reid->mode() == 1) {
+    if (h->reid->counted_ok()) {
         // crop count stays on the device: launches cover the capacity, surplus workgroups exit at once
         h->reid->run_counted(d_frames, h->d_crop_stream, h->d_crop_boxes, 4, h->d_crop_count, n_streams * h->nd, cols, rows,
                              d_embs, h->d_crop_row, h->stream);
@@ -608,7 +608,7 @@ bool io_stage(StreamIo* h, int n, const StreamIn* in, int det_cols, int emb_cols
     BM_HIP(hipMemsetAsync(h->d_crop_count, 0, 4, h->stream));
     hipLaunchKernelGGL(build_crop_list_kernel, dim3(n), dim3(256), 0, h->stream, h->d_dets, h->d_ndets, nd, reid_thresh,
                        h->d_crop_count, h->d_crop_stream, h->d_crop_boxes, h->d_crop_row, s0, inclusive);
-    if (h->reid->mode() == 1) {
+    if (h->reid->counted_ok()) {
         h->reid->run_counted(h->d_frames, h->d_crop_stream, h->d_crop_boxes, 4, h->d_crop_count, n * nd, h->frame_cols,
                              h->frame_rows, h->d_embs, h->d_crop_row, h->stream);
     } else {
@@ -619,6 +619,27 @@ bool io_stage(StreamIo* h, int n, const StreamIn* in, int det_cols, int emb_cols
                      h->d_crop_row, h->stream);
     }
     return any_warp;
+}
+
+// Device-resident ReID for the DeepOCSORT / StrongSORT step_device_frames entry points: crop list from the caller's device
+// detections, backbone over the caller's device frames, embeddings into h->d_embs (rows of skipped detections keep stale
+// values; the step kernels never read them).
+void io_device_reid(StreamIo* h, const float* d_dets, const int* d_ndets, const uint8_t* const* d_frames, int image_rows,
+                    int image_cols, double reid_thresh, int inclusive) {
+    if (!h->reid) throw std::runtime_error("boxmot_hip: embeddings are needed and none were supplied, but no ReID weights are loaded");
+    if (!d_frames || image_rows <= 0 || image_cols <= 0) throw std::runtime_error("boxmot_hip: step_device_frames needs device frames");
+    BM_HIP(hipMemsetAsync(h->d_crop_count, 0, 4, h->stream));
+    hipLaunchKernelGGL(build_crop_list_kernel, dim3(h->S), dim3(256), 0, h->stream, d_dets, d_ndets, h->nd, reid_thresh,
+                       h->d_crop_count, h->d_crop_stream, h->d_crop_boxes, h->d_crop_row, 0, inclusive);
+    if (h->reid->counted_ok()) {
+        h->reid->run_counted(d_frames, h->d_crop_stream, h->d_crop_boxes, 4, h->d_crop_count, h->S * h->nd, image_cols, image_rows,
+                             h->d_embs, h->d_crop_row, h->stream);
+    } else {
+        int n_crops = 0;
+        BM_HIP(hipMemcpyAsync(&n_crops, h->d_crop_count, 4, hipMemcpyDeviceToHost, h->stream));
+        BM_HIP(hipStreamSynchronize(h->stream));
+        h->reid->run(d_frames, h->d_crop_stream, h->d_crop_boxes, 4, n_crops, image_cols, image_rows, h->d_embs, h->d_crop_row, h->stream);
+    }
 }
 
 // After the step kernel: wait, clear the consumed warps, turn a non-zero status word into an exception, copy the rows out.
@@ -1255,6 +1276,39 @@ int boxmot_hip_deepocsort_step_device(BoxMOTHipDeepOcSort* handle, const float* 
     });
 }
 
+int boxmot_hip_deepocsort_step_device_frames(BoxMOTHipDeepOcSort* handle, const float* d_dets, const int* d_det_rows,
+                                              const uint8_t* const* d_frames, int image_rows, int image_cols, float* d_out,
+                                              int* d_out_rows) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip DeepOCSORT handle is not initialized.");
+        if (!d_dets || !d_det_rows || !d_out || !d_out_rows) throw std::runtime_error("boxmot_hip: null device pointers");
+        if (!handle->cfg.embedding_off)      // deepocsort.py:337-345: every detection above det_thresh is embedded
+            io_device_reid(handle, d_dets, d_det_rows, d_frames, image_rows, image_cols, (double)(float)handle->cfg.det_thresh, 0);
+        bm::DocsStepArgs a = handle->args;
+        a.dets = d_dets; a.n_dets = d_det_rows; a.embs = handle->cfg.embedding_off ? nullptr : handle->d_embs;
+        a.warp = nullptr; a.warp_flag = nullptr;
+        a.out = d_out; a.out_n = d_out_rows; a.stream_base = 0;
+        hipLaunchKernelGGL((deepocsort_step_kernel<STEP_THREADS>), dim3(handle->S), dim3(STEP_THREADS),
+                           (size_t)bm::docs_lap_lds_bytes(handle->cap, handle->nd), handle->stream, a);
+        BM_HIP(hipGetLastError());
+    });
+}
+
+int boxmot_hip_deepocsort_set_reid_mode(BoxMOTHipDeepOcSort* handle, int mode) {
+    return guard([&]() {
+        if (!handle || !handle->reid) throw std::runtime_error("boxmot_hip: no ReID weights are loaded in this handle");
+        handle->reid->set_mode(mode);
+    });
+}
+
+int boxmot_hip_deepocsort_reid_kernel_ms(BoxMOTHipDeepOcSort* handle, double* out_ms, int* out_launches) {
+    return guard([&]() {
+        if (!handle || !out_ms || !out_launches) throw std::runtime_error("boxmot_hip: null argument");
+        *out_ms = 0; *out_launches = 0;
+        if (handle->reid) handle->reid->drain_kernel_timing(*out_ms, *out_launches);
+    });
+}
+
 int boxmot_hip_deepocsort_synchronize(BoxMOTHipDeepOcSort* handle) {
     return guard([&]() {
         if (!handle) throw std::runtime_error("boxmot_hip DeepOCSORT handle is not initialized.");
@@ -1376,6 +1430,36 @@ int boxmot_hip_strongsort_step_device(BoxMOTHipStrongSort* handle, const float* 
         a.out = d_out; a.out_n = d_out_rows; a.stream_base = 0;
         ss_launch(handle, a, handle->S);
         BM_HIP(hipGetLastError());
+    });
+}
+
+int boxmot_hip_strongsort_step_device_frames(BoxMOTHipStrongSort* handle, const float* d_dets, const int* d_det_rows,
+                                              const uint8_t* const* d_frames, int image_rows, int image_cols, float* d_out,
+                                              int* d_out_rows) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip StrongSORT handle is not initialized.");
+        if (!d_dets || !d_det_rows || !d_out || !d_out_rows) throw std::runtime_error("boxmot_hip: null device pointers");
+        io_device_reid(handle, d_dets, d_det_rows, d_frames, image_rows, image_cols, handle->cfg.min_conf, 1);    // strongsort.py:74-91
+        bm::SsStepArgs a = handle->args;
+        a.dets = d_dets; a.n_dets = d_det_rows; a.embs = handle->d_embs; a.warp = nullptr;
+        a.out = d_out; a.out_n = d_out_rows; a.stream_base = 0;
+        ss_launch(handle, a, handle->S);
+        BM_HIP(hipGetLastError());
+    });
+}
+
+int boxmot_hip_strongsort_set_reid_mode(BoxMOTHipStrongSort* handle, int mode) {
+    return guard([&]() {
+        if (!handle || !handle->reid) throw std::runtime_error("boxmot_hip: no ReID weights are loaded in this handle");
+        handle->reid->set_mode(mode);
+    });
+}
+
+int boxmot_hip_strongsort_reid_kernel_ms(BoxMOTHipStrongSort* handle, double* out_ms, int* out_launches) {
+    return guard([&]() {
+        if (!handle || !out_ms || !out_launches) throw std::runtime_error("boxmot_hip: null argument");
+        *out_ms = 0; *out_launches = 0;
+        if (handle->reid) handle->reid->drain_kernel_timing(*out_ms, *out_launches);
     });
 }
 

@@ -110,7 +110,7 @@ private:
     void gemm(const _Float16* X, const _Float16* W, const float* bias, void* C, long M, int N, int K, hipStream_t st) {
         if (N % GEMM_BN != 0 || K % GEMM_BK != 0) throw std::runtime_error("CLIP-ReID: GEMM shape not tileable");
         hipLaunchKernelGGL((k_gemm_f16<EPI>), dim3((unsigned)((M + GEMM_BM - 1) / GEMM_BM), (unsigned)(N / GEMM_BN)), dim3(256), 0, st,
-                           X, W, bias, C, (int)M, N, K);
+                           X, W, bias, C, static_cast<const _Float16*>(nullptr), (int)M, N, K, 0);
     }
     void layernorm(const float* g, const float* b, long R, hipStream_t st) {
         hipLaunchKernelGGL(k_clip_layernorm_f16, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, x_, g, b, h16_, R, width);

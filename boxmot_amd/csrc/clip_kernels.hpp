@@ -21,13 +21,10 @@
 #include <stdint.h>
 
 #include "kernel_macros.hpp"
+#include "gemm_f16.hpp"
 
 namespace bm {
 
-typedef _Float16 ch4 __attribute__((ext_vector_type(4)));
-typedef _Float16 ch8 __attribute__((ext_vector_type(8)));
-typedef float cf4 __attribute__((ext_vector_type(4)));
-typedef unsigned int cu4 __attribute__((ext_vector_type(4)));
 
 constexpr int CLIP_WAVE = 64;
 constexpr float CLIP_LN_EPS = 1e-5f;
@@ -100,101 +97,6 @@ __global__ void __launch_bounds__(256) k_clip_layernorm_f16(const float* __restr
         ch4 o;
         for (int j = 0; j < 4; ++j) o[j] = (_Float16)((v[j] - mean) * rstd * gm[j] + bt[j]);
         *reinterpret_cast<ch4*>(out + r * D + c) = o;
-    }
-}
-
-// ---------------------------------------------------------------------------
-// GEMM: C[m][n] = sum_k X[m][k] * Wt[n][k] (+ bias[n]) with fp16 operands and fp32 accumulation.
-//   X  [M][K] fp16 row-major (token rows), Wt [N][K] fp16 row-major (nn.Linear weight layout), N % 128 == 0, K % 32 == 0.
-//   EPI 0: fp16 store            (qkv projection)
-//   EPI 1: QuickGELU, fp16 store (mlp.c_fc)
-//   EPI 2: fp32 C += result      (attention out_proj / mlp.c_proj onto the residual stream)
-//   EPI 3: fp32 store            (patch embedding: no bias in the reference conv, bias == nullptr)
-// ---------------------------------------------------------------------------
-constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 32, GEMM_LD = 40;       // LDS row = 32 halves + 8 of padding (80 bytes)
-
-template <int EPI>
-__global__ void __launch_bounds__(256) k_gemm_f16(const _Float16* __restrict__ X, const _Float16* __restrict__ Wt,
-                                                  const float* __restrict__ bias, void* __restrict__ Cout, int M, int N, int K) {
-    __shared__ __attribute__((aligned(16))) _Float16 sW[GEMM_BN * GEMM_LD];
-    __shared__ __attribute__((aligned(16))) _Float16 sX[GEMM_BM * GEMM_LD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l16 = lane & 15;
-    const int wn = wave >> 1, wm = wave & 1;                 // this wave: 64 output features x 64 token rows
-    const long m0 = (long)blockIdx.x * GEMM_BM;
-    const int n0 = blockIdx.y * GEMM_BN;
-    cf4 acc[4][4];                                           // [feature tile][token tile]
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = cf4{0.f, 0.f, 0.f, 0.f};
-    // staging: 512 chunks of 16 bytes per operand tile, two per thread; chunk q = (row q >> 2, k offset 8 (q & 3))
-    cu4 rw[2], rx[2];
-    auto load_tiles = [&](int k0) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int q = tid + 256 * j, r = q >> 2, c = (q & 3) * 8;
-            rw[j] = *reinterpret_cast<const cu4*>(Wt + (long)(n0 + r) * K + k0 + c);
-            const long m = m0 + r;
-            rx[j] = m < M ? *reinterpret_cast<const cu4*>(X + m * K + k0 + c) : cu4{0u, 0u, 0u, 0u};
-        }
-    };
-    auto store_tiles = [&]() {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int q = tid + 256 * j, r = q >> 2, c = (q & 3) * 8;
-            *reinterpret_cast<cu4*>(sW + r * GEMM_LD + c) = rw[j];
-            *reinterpret_cast<cu4*>(sX + r * GEMM_LD + c) = rx[j];
-        }
-    };
-    load_tiles(0);
-    for (int k0 = 0; k0 < K; k0 += GEMM_BK) {
-        __syncthreads();                    // the previous tile's fragment reads are done
-        store_tiles();
-        __syncthreads();
-        if (k0 + GEMM_BK < K) load_tiles(k0 + GEMM_BK);
-        ch8 a[4], b[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            a[t] = *reinterpret_cast<const ch8*>(sW + (wn * 64 + t * 16 + l16) * GEMM_LD + 8 * g);
-            b[t] = *reinterpret_cast<const ch8*>(sX + (wm * 64 + t * 16 + l16) * GEMM_LD + 8 * g);
-        }
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[p][t] = BM_MFMA_F16_K32(a[p], b[t], acc[p][t]);
-    }
-    // epilogue: D[row = feature 4 g + r][col = token l16]
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int n = n0 + wn * 64 + p * 16 + 4 * g;
-        cf4 bv = cf4{0.f, 0.f, 0.f, 0.f};
-        if (bias) bv = *reinterpret_cast<const cf4*>(bias + n);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const long m = m0 + wm * 64 + t * 16 + l16;
-            if (m >= M) continue;
-            cf4 v = acc[p][t];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += bv[r];
-            if constexpr (EPI == 1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + BM_EXPF(-1.702f * v[r]));        // x * sigmoid(1.702 x), model.py:181-183
-            }
-            if constexpr (EPI == 0 || EPI == 1) {
-                ch4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (_Float16)v[r];
-                *reinterpret_cast<ch4*>(static_cast<_Float16*>(Cout) + m * N + n) = o;
-            } else if constexpr (EPI == 2) {
-                float* c = static_cast<float*>(Cout) + m * N + n;
-                cf4 old = *reinterpret_cast<const cf4*>(c);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) old[r] += v[r];
-                *reinterpret_cast<cf4*>(c) = old;
-            } else {
-                *reinterpret_cast<cf4*>(static_cast<float*>(Cout) + m * N + n) = v;
-            }
-        }
     }
 }
 

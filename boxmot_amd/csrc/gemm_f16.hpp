@@ -1,0 +1,141 @@
+// fp16 GEMM on the gfx950 matrix pipe, shared by the two GEMM-shaped ReID backbones: the linear layers of CLIP-ReID
+// (clip_kernels.hpp) and the 1x1 convolutions of the wide OSNets (osnet_wide.hpp; NHWC activations make a 1x1 convolution a
+// plain [pixels][cin] x [cin][cout] product).
+//
+//   C[m][n] = sum_k X[m][k] * Wt[n][k]  (+ bias[n])      fp16 operands, fp32 accumulation
+//   X  [M][K] fp16 row-major (token / pixel rows), Wt [N][K] fp16 row-major (nn.Linear / conv weight layout as stored)
+//   N % BN == 0 with BN in {32, 64, 96, 128}; K % 32 == 0; any M.
+//
+// C^T tiles on v_mfma_f32_16x16x32_f16 with the WEIGHT rows as the MFMA A operand and the activation rows as B, so that a lane
+// ends up with 4 consecutive output features of one row: bias / activation / residual run in the epilogue on those and the
+// store is 8 (fp16) or 16 (fp32) contiguous bytes per lane.  128 (rows) x BN (features) x 32 tiles, 4 waves as 2 x 2 of
+// 64 rows x BN/2 features, operands staged through LDS (rows padded to 40 halves: conflict-free 16-byte fragment reads), the
+// next k-tile's global loads in flight while the current one multiplies.
+//   EPI 0: fp16 store                          EPI 1: QuickGELU, fp16 store          EPI 2: fp32 C += result
+//   EPI 3: fp32 store                          EPI 4: (+ fp16 residual[m][n]) (ReLU when relu != 0), fp16 store
+#pragma once
+
+#include <stdint.h>
+
+#include "kernel_macros.hpp"
+
+namespace bm {
+
+typedef _Float16 ch4 __attribute__((ext_vector_type(4)));
+typedef _Float16 ch8 __attribute__((ext_vector_type(8)));
+typedef float cf4 __attribute__((ext_vector_type(4)));
+typedef unsigned int cu4 __attribute__((ext_vector_type(4)));
+
+constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 32, GEMM_LD = 40;       // LDS row = 32 halves + 8 of padding (80 bytes)
+
+template <int EPI, int BN = GEMM_BN>
+__global__ void __launch_bounds__(256) k_gemm_f16(const _Float16* __restrict__ X, const _Float16* __restrict__ Wt,
+                                                  const float* __restrict__ bias, void* __restrict__ Cout,
+                                                  const _Float16* __restrict__ res, int M, int N, int K, int relu) {
+    static_assert(BN == 32 || BN == 64 || BN == 96 || BN == 128, "feature tile");
+    constexpr int NT = BN / 32;                              // 16-feature MFMA tiles per wave
+    constexpr int WCH = BN * 4, WJ = (WCH + 255) / 256;      // 16-byte chunks of the weight tile, chunks per thread
+    __shared__ __attribute__((aligned(16))) _Float16 sW[BN * GEMM_LD];
+    __shared__ __attribute__((aligned(16))) _Float16 sX[GEMM_BM * GEMM_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l16 = lane & 15;
+    const int wn = wave >> 1, wm = wave & 1;                 // this wave: BN/2 output features x 64 rows
+    const long m0 = (long)blockIdx.x * GEMM_BM;
+    const int n0 = blockIdx.y * BN;
+    cf4 acc[NT][4];                                          // [feature tile][row tile]
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = cf4{0.f, 0.f, 0.f, 0.f};
+    // staging: chunk q = (row q >> 2, k offset 8 (q & 3)); 512 chunks of the activation tile, WCH of the weight tile
+    cu4 rw[WJ], rx[2];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) {
+            const int q = tid + 256 * j, r = q >> 2, c = (q & 3) * 8;
+            if (WCH % 256 == 0 || q < WCH) rw[j] = *reinterpret_cast<const cu4*>(Wt + (long)(n0 + r) * K + k0 + c);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = tid + 256 * j, r = q >> 2, c = (q & 3) * 8;
+            const long m = m0 + r;
+            rx[j] = m < M ? *reinterpret_cast<const cu4*>(X + m * K + k0 + c) : cu4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) {
+            const int q = tid + 256 * j, r = q >> 2, c = (q & 3) * 8;
+            if (WCH % 256 == 0 || q < WCH) *reinterpret_cast<cu4*>(sW + r * GEMM_LD + c) = rw[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = tid + 256 * j, r = q >> 2, c = (q & 3) * 8;
+            *reinterpret_cast<cu4*>(sX + r * GEMM_LD + c) = rx[j];
+        }
+    };
+    load_tiles(0);
+    for (int k0 = 0; k0 < K; k0 += GEMM_BK) {
+        __syncthreads();                    // the previous tile's fragment reads are done
+        store_tiles();
+        __syncthreads();
+        if (k0 + GEMM_BK < K) load_tiles(k0 + GEMM_BK);
+        ch8 a[NT], b[4];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) a[t] = *reinterpret_cast<const ch8*>(sW + (wn * (BN / 2) + t * 16 + l16) * GEMM_LD + 8 * g);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[t] = *reinterpret_cast<const ch8*>(sX + (wm * 64 + t * 16 + l16) * GEMM_LD + 8 * g);
+#pragma unroll
+        for (int p = 0; p < NT; ++p)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[p][t] = BM_MFMA_F16_K32(a[p], b[t], acc[p][t]);
+    }
+    // epilogue: D[row = feature 4 g + r][col = activation row l16]
+#pragma unroll
+    for (int p = 0; p < NT; ++p) {
+        const int n = n0 + wn * (BN / 2) + p * 16 + 4 * g;
+        cf4 bv = cf4{0.f, 0.f, 0.f, 0.f};
+        if (bias) {                         // scalar loads: bias tensors inside a weight blob are only 4-byte aligned
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[r] = bias[n + r];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const long m = m0 + wm * 64 + t * 16 + l16;
+            if (m >= M) continue;
+            cf4 v = acc[p][t];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += bv[r];
+            if constexpr (EPI == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + BM_EXPF(-1.702f * v[r]));        // x * sigmoid(1.702 x), clip/model.py:181-183
+            }
+            if constexpr (EPI == 4) {
+                if (res) {
+                    const ch4 rv = *reinterpret_cast<const ch4*>(res + m * N + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+                }
+                if (relu) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+                }
+            }
+            if constexpr (EPI == 0 || EPI == 1 || EPI == 4) {
+                ch4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (_Float16)v[r];
+                *reinterpret_cast<ch4*>(static_cast<_Float16*>(Cout) + m * N + n) = o;
+            } else if constexpr (EPI == 2) {
+                float* c = static_cast<float*>(Cout) + m * N + n;
+                cf4 old = *reinterpret_cast<const cf4*>(c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) old[r] += v[r];
+                *reinterpret_cast<cf4*>(c) = old;
+            } else {
+                *reinterpret_cast<cf4*>(static_cast<float*>(Cout) + m * N + n) = v;
+            }
+        }
+    }
+}
+
+}  // namespace bm

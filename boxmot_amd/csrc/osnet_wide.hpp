@@ -1,0 +1,176 @@
+// Host side of the wide-OSNet kernel family (osnet_wide_kernels.hpp): owns the fp16 weight copies and the activation buffers
+// for up to max_crops crops and sequences the launches of OSNet.forward (boxmot/reid/backbones/osnet.py:380-405).  Used by
+// ReidEngine (reid_engine.hpp) in mode 1 when the OSN1 blob's widths are multiples of 32 (osnet_x1_0).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "osnet_wide_kernels.hpp"
+#include "osnet_wide_pack.hpp"
+
+namespace bm {
+
+// ---------------------------------------------------------------------------
+// Host side: owns the fp16 weight copies and the activation buffers for up to max_crops crops, sequences the launches.
+// ---------------------------------------------------------------------------
+class WideOsnet {
+public:
+    static bool supports(const OsnetLayout& L) { return wide_osnet_supports(L); }
+
+    WideOsnet(const float* h_w, const OsnetLayout& L, const float* d_w32, int max_crops, std::vector<void*>& owned)
+        : L_(L), d_w_(d_w32), max_crops_(max_crops) {
+        if (!supports(L)) throw std::runtime_error("wide OSNet kernels: channel widths must be multiples of 32 (middle widths <= 128)");
+        pk_ = wide_pack_w16(h_w, L, STEM_K);
+        d_w16_ = alloc<_Float16>(pk_.data.size(), owned);
+        check(hipMemcpy(d_w16_, pk_.data.data(), pk_.data.size() * 2, hipMemcpyHostToDevice), "upload fp16 weights");
+        d_stem16_ = d_w16_ + pk_.stem;
+        pk_.data.clear(); pk_.data.shrink_to_fit();
+        const int c0 = L.c[0];
+        const size_t n = (size_t)max_crops;
+        crops16_ = alloc<_Float16>(n * REID_IN_H * REID_IN_W * 3, owned);
+        im2col_ = alloc<_Float16>(n * 8192 * STEM_K, owned);
+        stem_out_ = alloc<_Float16>(n * 8192 * c0, owned);
+        size_t blk = 0, mid = 0;
+        int P = 2048;
+        for (int s = 0; s < 3; ++s, P /= 4) {
+            const size_t a = n * P * (size_t)L.c[s + 1], m = n * P * (size_t)(L.c[s + 1] / 4);
+            blk = a > blk ? a : blk; mid = m > mid ? m : mid;
+        }
+        const size_t first = n * 2048 * (size_t)c0;
+        blk = first > blk ? first : blk;
+        act_a_ = alloc<_Float16>(blk, owned); act_b_ = alloc<_Float16>(blk, owned); idn_ = alloc<_Float16>(blk, owned);
+        for (auto& m : mid_) m = alloc<_Float16>(mid, owned);
+        gap_part_ = alloc<float>(4 * n * (64 / WIDE_BAND) * 128, owned);
+        set_light_lds<32>(); set_light_lds<64>(); set_light_lds<96>(); set_light_lds<128>();
+    }
+
+    _Float16* crops_buffer() { return crops16_; }
+    int max_crops() const { return max_crops_; }
+
+    // crops16_: normalised fp16 NHWC crops of n <= max_crops boxes (k_crop_resize<_Float16>); out rows of L.feat floats
+    void forward(int n, float* d_out, const int* d_out_rows, hipStream_t st) {
+        if (n > max_crops_) throw std::runtime_error("wide OSNet: crop batch exceeds the engine capacity");
+        if (n == 0) return;
+        const int c0 = L_.c[0];
+        const long stem_rows = (long)n * 8192;
+        hipLaunchKernelGGL(k_stem_im2col, dim3((unsigned)((stem_rows * 8 + 255) / 256)), dim3(256), 0, st, crops16_, im2col_, stem_rows);
+        gemm(im2col_, d_stem16_, d_w_ + L_.stem_b, stem_out_, nullptr, stem_rows, c0, STEM_K, 1, st);
+        long t8 = (long)n * 2048 * (c0 / 8);
+        hipLaunchKernelGGL(k_maxpool3x3s2_h8, dim3((unsigned)((t8 + 255) / 256)), dim3(256), 0, st, stem_out_, act_a_, 128, 64, c0, t8);
+        _Float16 *cur = act_a_, *other = act_b_;
+        int H = 64, W = 32;
+        for (int s = 0; s < 3; ++s) {
+            for (int k = 0; k < 2; ++k) {
+                osblock(L_.block[s * 2 + k], cur, other, n, H, W, st);
+                std::swap(cur, other);
+            }
+            if (s < 2) {
+                const int c = L_.c[s + 1];
+                gemm(cur, d_w16_ + pk_.of(L_.trans_w[s]), d_w_ + L_.trans_b[s], other, nullptr, (long)n * H * W, c, c, 1, st);
+                t8 = (long)n * (H / 2) * (W / 2) * (c / 8);
+                hipLaunchKernelGGL(k_avgpool2x2_h8, dim3((unsigned)((t8 + 255) / 256)), dim3(256), 0, st, other, cur, H, W, c, t8);
+                H /= 2; W /= 2;
+            }
+        }
+        const int c3 = L_.c[3];
+        gemm(cur, d_w16_ + pk_.of(L_.conv5_w), d_w_ + L_.conv5_b, other, nullptr, (long)n * H * W, c3, c3, 1, st);
+        hipLaunchKernelGGL(k_wide_head, dim3(n), dim3(256), 0, st, other, d_w_ + L_.fc_w, d_w_ + L_.fc_b, d_out, d_out_rows, H * W, c3, L_.feat);
+        check(hipGetLastError(), "wide OSNet launch");
+    }
+
+private:
+    static void check(hipError_t e, const char* what) {
+        if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+    }
+    template <typename T>
+    static T* alloc(size_t n, std::vector<void*>& owned) {
+        void* p = nullptr;
+        check(hipMalloc(&p, (n ? n : 1) * sizeof(T)), "hipMalloc");
+        owned.push_back(p);
+        return static_cast<T*>(p);
+    }
+    template <int C>
+    static void set_light_lds() {
+        check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_light_fused<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  light_lds_bytes<C>(32)), "LightConv LDS");
+    }
+    // 1x1 convolution over n_pix pixels: out = [relu](X . W^T + bias [+ res])
+    void gemm(const _Float16* X, const _Float16* W, const float* bias, _Float16* out, const _Float16* res, long M, int N, int K,
+              int relu, hipStream_t st) {
+        if (K % GEMM_BK != 0 || N % 32 != 0) throw std::runtime_error("wide OSNet: GEMM shape not tileable");
+        const unsigned gx = (unsigned)((M + GEMM_BM - 1) / GEMM_BM);
+        if (N % 128 == 0) hipLaunchKernelGGL((k_gemm_f16<4, 128>), dim3(gx, N / 128), dim3(256), 0, st, X, W, bias, out, res, (int)M, N, K, relu);
+        else if (N % 96 == 0) hipLaunchKernelGGL((k_gemm_f16<4, 96>), dim3(gx, N / 96), dim3(256), 0, st, X, W, bias, out, res, (int)M, N, K, relu);
+        else if (N % 64 == 0) hipLaunchKernelGGL((k_gemm_f16<4, 64>), dim3(gx, N / 64), dim3(256), 0, st, X, W, bias, out, res, (int)M, N, K, relu);
+        else hipLaunchKernelGGL((k_gemm_f16<4, 32>), dim3(gx, N / 32), dim3(256), 0, st, X, W, bias, out, res, (int)M, N, K, relu);
+    }
+    template <int C>
+    void light_t(const _Float16* in, const LightW& lw, _Float16* out, float* gap, int n, int H, int W, hipStream_t st) {
+        hipLaunchKernelGGL(k_light_fused<C>, dim3(H / WIDE_BAND, n), dim3(256), (size_t)light_lds_bytes<C>(W), st, in, d_w16_ + pk_.of(lw.pw),
+                           d_w_ + lw.dw, d_w_ + lw.b, out, gap, H, W);
+    }
+    void light(int C, const _Float16* in, const LightW& lw, _Float16* out, float* gap, int n, int H, int W, hipStream_t st) {
+        switch (C) {
+            case 32: light_t<32>(in, lw, out, gap, n, H, W, st); break;
+            case 64: light_t<64>(in, lw, out, gap, n, H, W, st); break;
+            case 96: light_t<96>(in, lw, out, gap, n, H, W, st); break;
+            case 128: light_t<128>(in, lw, out, gap, n, H, W, st); break;
+            default: throw std::runtime_error("wide OSNet: unsupported middle width");
+        }
+    }
+    template <int C>
+    void gate_t(const BlockW& B, _Float16* const* br, _Float16* out, int n, int P, int nbands, hipStream_t st) {
+        const int ppb = 128;
+        hipLaunchKernelGGL(k_gate_sum4<C>, dim3(n, (P + ppb - 1) / ppb), dim3(256), 0, st, br[0], br[1], br[2], br[3], gap_part_,
+                           d_w_ + B.fc1_w, d_w_ + B.fc1_b, d_w_ + B.fc2_w, d_w_ + B.fc2_b, out, P, nbands, (long)n, ppb);
+    }
+    void osblock(const BlockW& B, const _Float16* x, _Float16* out, int n, int H, int W, hipStream_t st) {
+        const long n_pix = (long)n * H * W;
+        const int nbands = H / WIDE_BAND;
+        _Float16* x1 = mid_[0];
+        _Float16* brs[4] = {mid_[1], mid_[2], mid_[3], mid_[4]};
+        _Float16* tmp[2] = {mid_[5], mid_[6]};
+        gemm(x, d_w16_ + pk_.of(B.conv1_w), d_w_ + B.conv1_b, x1, nullptr, n_pix, B.mid, B.cin, 1, st);
+        int li = 0;
+        for (int br = 0; br < 4; ++br) {
+            const _Float16* cur = x1;
+            for (int k = 0; k <= br; ++k, ++li) {
+                const bool last = k == br;
+                _Float16* dst = last ? brs[br] : tmp[k & 1];
+                light(B.mid, cur, B.light[li], dst, last ? gap_part_ + (long)br * n * nbands * B.mid : nullptr, n, H, W, st);
+                cur = dst;
+            }
+        }
+        _Float16* x2 = mid_[7];
+        switch (B.mid) {
+            case 32: gate_t<32>(B, brs, x2, n, H * W, nbands, st); break;
+            case 64: gate_t<64>(B, brs, x2, n, H * W, nbands, st); break;
+            case 96: gate_t<96>(B, brs, x2, n, H * W, nbands, st); break;
+            case 128: gate_t<128>(B, brs, x2, n, H * W, nbands, st); break;
+            default: throw std::runtime_error("wide OSNet: unsupported middle width");
+        }
+        const _Float16* identity = x;
+        if (B.down_w >= 0) {
+            gemm(x, d_w16_ + pk_.of(B.down_w), d_w_ + B.down_b, idn_, nullptr, n_pix, B.cout, B.cin, 0, st);
+            identity = idn_;
+        }
+        gemm(x2, d_w16_ + pk_.of(B.conv3_w), d_w_ + B.conv3_b, out, identity, n_pix, B.cout, B.mid, 1, st);
+    }
+
+    OsnetLayout L_;
+    WideW16 pk_;
+    const float* d_w_;                       // the engine's fp32 blob on the device (biases, depthwise taps, gate and FC weights)
+    int max_crops_;
+    _Float16 *d_w16_ = nullptr, *d_stem16_ = nullptr;
+    _Float16 *crops16_ = nullptr, *im2col_ = nullptr, *stem_out_ = nullptr, *act_a_ = nullptr, *act_b_ = nullptr, *idn_ = nullptr;
+    _Float16* mid_[8] = {};
+    float* gap_part_ = nullptr;
+};
+
+}  // namespace bm

@@ -1,0 +1,332 @@
+// Wide OSNets (osnet_x1_0: 64 / 256 / 384 / 512 channels, the backbone of BASELINE.json configuration 3) on the gfx950 matrix
+// pipe.  Reference computation: OSNet.forward (eval), boxmot/reid/backbones/osnet.py:380-405, OSBlock :212-260,
+// LightConv3x3 :141-155, ChannelGate :161-209; weights: the same "OSN1" blob as the other two OSNet kernel families.
+//
+// The x0.25 kernels (reid_fused.hpp) keep a whole block of one crop inside one workgroup because its 16...32-channel layers
+// are too thin to fill MFMA tiles on their own; at x1.0 the middle widths are 64 / 96 / 128, every 1x1 convolution is a real
+// [pixels][cin] x [cin][cout] GEMM over ALL crops of the batch, and the layer-per-launch shape below keeps the matrix pipe
+// fed without per-crop workgroups:
+//   * activations: fp16 NHWC [crop][pixel][channel] in HBM, fp32 accumulation everywhere, fp32 folded-BN biases
+//   * every 1x1 convolution (conv1, conv3 + shortcut + ReLU, downsample, transitions, conv5, the im2col'd 7x7 stem) is one
+//     launch of k_gemm_f16 (gemm_f16.hpp) with bias / residual / ReLU in its epilogue
+//   * LightConv3x3 = 1x1 (linear) -> depthwise 3x3 + BN + ReLU is ONE kernel (k_light_fused): a workgroup owns a band of 8
+//     image rows of one crop, runs the 1x1 of the band + a one-row halo on the matrix pipe straight from global memory
+//     (weights are <= 32 KB: L1 / L2 resident) into an LDS tile, and the depthwise 3x3 reads that tile with a sliding
+//     3-row window: the intermediate tensor never reaches HBM.  The last LightConv of a branch also emits the band's
+//     per-channel sums, so the gate's global average pool costs no extra pass.
+//   * the four gated branches are summed by one kernel (k_gate_sum4), each workgroup recomputing the four tiny gate MLPs.
+// Algorithmic HBM bytes per crop (every layer input read once, every layer output written once): see DESIGN.md section 4.6.
+#pragma once
+
+#include <stdint.h>
+
+#include "gemm_f16.hpp"
+#include "reid_layout.hpp"
+
+namespace bm {
+
+constexpr int WIDE_BAND = 8;                 // image rows per k_light_fused workgroup
+constexpr int STEM_K = 160;                  // 7 x 7 x 3 = 147 taps, padded to a multiple of the MFMA k-step
+
+// widths this kernel family takes: GEMM k-steps of 32, 16-channel MFMA tiles, k_light_fused's thread mapping
+inline bool wide_osnet_supports(const OsnetLayout& L) {
+    if (L.c[0] % 32 != 0 || L.feat > 512 || L.c[3] > 512) return false;
+    for (int b = 0; b < 6; ++b) {
+        const BlockW& B = L.block[b];
+        if (B.cin % 32 || B.cout % 32 || B.mid % 32 || B.mid > 128) return false;
+        if ((32 >> (b / 2)) * (B.mid / 8) > 256) return false;      // k_light_fused: one thread per (column, 8 channels) of an image row
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// Stem patch gather: normalised crops fp16 NHWC [n][256][128][3] -> rows [n * 128 * 64][160], k = (ky, kx, c) + zero padding;
+// thread = (output pixel, ky): 7 pixels x 3 channels are contiguous in the crop row.  conv 7x7, stride 2, pad 3 (osnet.py:294).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_stem_im2col(const _Float16* __restrict__ crops, _Float16* __restrict__ out, long n_rows) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long row = e >> 3;
+    const int part = (int)(e & 7);
+    if (row >= n_rows) return;
+    _Float16* o = out + row * STEM_K;
+    if (part == 7) {
+        for (int j = 147; j < STEM_K; ++j) o[j] = (_Float16)0.f;
+        return;
+    }
+    const int ox = (int)(row % 64), oy = (int)((row / 64) % 128);
+    const long n = row / (64 * 128);
+    const int iy = oy * 2 - 3 + part, ix0 = ox * 2 - 3;
+    o += part * 21;
+    if (iy < 0 || iy >= REID_IN_H) {
+        for (int j = 0; j < 21; ++j) o[j] = (_Float16)0.f;
+        return;
+    }
+    const _Float16* src = crops + ((n * REID_IN_H + iy) * REID_IN_W) * 3;
+    for (int kx = 0; kx < 7; ++kx) {
+        const int ix = ix0 + kx;
+        const bool in = ix >= 0 && ix < REID_IN_W;
+        for (int c = 0; c < 3; ++c) o[kx * 3 + c] = in ? src[ix * 3 + c] : (_Float16)0.f;
+    }
+}
+
+// max pool 3x3 stride 2 pad 1 (osnet.py:295) / 2x2 average pool (osnet.py:349), fp16 NHWC, 8 channels per thread
+__global__ void __launch_bounds__(256) k_maxpool3x3s2_h8(const _Float16* __restrict__ in, _Float16* __restrict__ out, int H, int W, int C, long total8) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total8) return;
+    const int C8 = C / 8, OW = W / 2, OH = H / 2;
+    const int cg = (int)(e % C8);
+    const int ox = (int)((e / C8) % OW), oy = (int)((e / ((long)C8 * OW)) % OH);
+    const long n = e / ((long)C8 * OW * OH);
+    float m[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[j] = -3.0e38f;
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int iy = oy * 2 + dy;
+        if (iy < 0 || iy >= H) continue;
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int ix = ox * 2 + dx;
+            if (ix < 0 || ix >= W) continue;
+            const ch8 v = *reinterpret_cast<const ch8*>(in + ((n * H + iy) * W + ix) * C + cg * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m[j] = (float)v[j] > m[j] ? (float)v[j] : m[j];
+        }
+    }
+    ch8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (_Float16)m[j];
+    *reinterpret_cast<ch8*>(out + e * 8) = o;
+}
+
+__global__ void __launch_bounds__(256) k_avgpool2x2_h8(const _Float16* __restrict__ in, _Float16* __restrict__ out, int H, int W, int C, long total8) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total8) return;
+    const int C8 = C / 8, OW = W / 2, OH = H / 2;
+    const int cg = (int)(e % C8);
+    const int ox = (int)((e / C8) % OW), oy = (int)((e / ((long)C8 * OW)) % OH);
+    const long n = e / ((long)C8 * OW * OH);
+    const _Float16* p = in + ((n * H + oy * 2) * W + ox * 2) * C + cg * 8;
+    const ch8 a = *reinterpret_cast<const ch8*>(p), b = *reinterpret_cast<const ch8*>(p + C);
+    const ch8 c = *reinterpret_cast<const ch8*>(p + (long)W * C), d = *reinterpret_cast<const ch8*>(p + (long)W * C + C);
+    ch8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (_Float16)(((float)a[j] + (float)b[j] + (float)c[j] + (float)d[j]) * 0.25f);
+    *reinterpret_cast<ch8*>(out + e * 8) = o;
+}
+
+// ---------------------------------------------------------------------------
+// LightConv3x3 (osnet.py:141-155) in one launch.  grid (H / 8 bands, crops), 256 threads.
+//   in / out  fp16 NHWC [n][H][W][C];  pw fp16 [C][C] (out-major, as stored);  dw fp32 [C][9] with BN folded;  bias fp32 [C]
+//   gap_part  nullptr, or fp32 [n][bands][C]: sum over the band's pixels of the output (for the channel gate's average pool)
+// Phase 1: T[(8 + 2) W pixels][C] = pw . in on the matrix pipe (rows outside the image are zero: the 1x1 has no bias, so the
+//          zero padding of the depthwise input is exactly a zero row); D layout = 4 consecutive channels of one pixel per lane.
+// Phase 2: thread = (column, 8-channel group), sliding 3 x 3 window down the band, fp32 accumulation.
+// LDS pixel stride C + 8 halves: 16-byte aligned rows, phase-1 8-byte writes at most 2-way conflicted.
+// ---------------------------------------------------------------------------
+template <int C>
+__host__ __device__ constexpr int light_lds_bytes(int W) { return (WIDE_BAND + 2) * W * (C + 8) * 2; }
+
+template <int C>
+__global__ void __launch_bounds__(256) k_light_fused(const _Float16* __restrict__ in, const _Float16* __restrict__ pw,
+                                                     const float* __restrict__ dw, const float* __restrict__ bias,
+                                                     _Float16* __restrict__ out, float* __restrict__ gap_part, int H, int W) {
+    static_assert(C % 32 == 0 && C <= 128, "middle width");
+    BM_DYNAMIC_LDS_T(unsigned char, lds_raw);
+    _Float16* T = reinterpret_cast<_Float16*>(lds_raw);
+    constexpr int LD = C + 8, KS = C / 32, CT = C / 16, CG = C / 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l16 = lane & 15;
+    const int band = blockIdx.x, nbands = gridDim.x;
+    const long crop = blockIdx.y;
+    const int r0 = band * WIDE_BAND;
+    const _Float16* img = in + crop * H * W * (long)C;
+    // ---- phase 1 ----
+    const int n_ptiles = (WIDE_BAND + 2) * W / 16;
+    for (int pt = wave; pt < n_ptiles; pt += 4) {
+        const int px = pt * 16 + l16;
+        const int lrow = px / W, col = px - lrow * W;
+        const int grow = r0 - 1 + lrow;
+        const bool valid = grow >= 0 && grow < H;
+        ch8 b[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            b[s] = ch8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (valid) b[s] = *reinterpret_cast<const ch8*>(img + ((long)grow * W + col) * C + 32 * s + 8 * g);
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            cf4 acc = cf4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const ch8 a = *reinterpret_cast<const ch8*>(pw + (long)(16 * ct + l16) * C + 32 * s + 8 * g);
+                acc = BM_MFMA_F16_K32(a, b[s], acc);
+            }
+            ch4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (_Float16)acc[r];
+            *reinterpret_cast<ch4*>(T + px * LD + 16 * ct + 4 * g) = o;
+        }
+    }
+    __syncthreads();
+    // ---- phase 2 ----
+    const int TPR = W * CG;                         // threads per image row
+    const int NG = TPR <= 64 ? 4 : (TPR <= 128 ? 2 : 1);    // row groups (a power of two <= 4: the band sums below reuse the tile's LDS)
+    const int RPG = WIDE_BAND / NG;                 // rows per thread
+    float gsum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gsum[j] = 0.f;
+    const bool active = tid < NG * TPR && TPR <= 256;
+    int x = 0, cg = 0, grp = 0;
+    if (active) {
+        grp = tid / TPR;
+        const int rem = tid - grp * TPR;
+        x = rem / CG; cg = rem - x * CG;
+        float w[9][8], bv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            bv[j] = bias[cg * 8 + j];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) w[k][j] = dw[(cg * 8 + j) * 9 + k];
+        }
+        const ch8 zero = ch8{0, 0, 0, 0, 0, 0, 0, 0};
+        auto load_row = [&](int trow, ch8& l, ch8& m, ch8& r) {
+            const _Float16* p = T + (trow * W + x) * LD + cg * 8;
+            m = *reinterpret_cast<const ch8*>(p);
+            l = x > 0 ? *reinterpret_cast<const ch8*>(p - LD) : zero;
+            r = x < W - 1 ? *reinterpret_cast<const ch8*>(p + LD) : zero;
+        };
+        const int lr0 = grp * RPG;                  // first output row of this thread inside the band; its tile rows are lr .. lr + 2
+        ch8 t0, t1, t2, m0, m1, m2, b0, b1, b2;
+        load_row(lr0, t0, t1, t2);
+        load_row(lr0 + 1, m0, m1, m2);
+        _Float16* orow = out + ((crop * H + r0 + lr0) * W + x) * (long)C + cg * 8;
+        for (int lr = 0; lr < RPG; ++lr) {
+            load_row(lr0 + lr + 2, b0, b1, b2);
+            ch8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float a = (float)t0[j] * w[0][j];
+                a += (float)t1[j] * w[1][j]; a += (float)t2[j] * w[2][j];
+                a += (float)m0[j] * w[3][j]; a += (float)m1[j] * w[4][j]; a += (float)m2[j] * w[5][j];
+                a += (float)b0[j] * w[6][j]; a += (float)b1[j] * w[7][j]; a += (float)b2[j] * w[8][j];
+                a += bv[j];
+                a = a > 0.f ? a : 0.f;
+                o[j] = (_Float16)a;
+                gsum[j] += (float)o[j];             // the gate pools the tensor the next layer sees (fp16-rounded)
+            }
+            *reinterpret_cast<ch8*>(orow + (long)lr * W * C) = o;
+            t0 = m0; t1 = m1; t2 = m2; m0 = b0; m1 = b1; m2 = b2;
+        }
+    }
+    if (gap_part == nullptr) return;
+    // band sums for the channel gate: per-thread sums -> LDS -> one thread per channel adds them in a fixed order
+    __syncthreads();
+    float* S = reinterpret_cast<float*>(lds_raw);           // [NG * W][C]
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) S[(grp * W + x) * C + cg * 8 + j] = gsum[j];
+    }
+    __syncthreads();
+    if (tid < C) {
+        float s = 0.f;
+        for (int k = 0; k < NG * W; ++k) s += S[k * C + tid];
+        gap_part[(crop * nbands + band) * C + tid] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Unified aggregation gate over the four branches (osnet.py:247-258, ChannelGate :161-209):
+//   out[p][c] = sum_b x_b[p][c] * sigmoid(fc2(relu(fc1(mean_p x_b))))[c]
+// grid (crops, pixel blocks), 256 threads.  gap_part fp32 [4][n][bands][C] from k_light_fused.
+// ---------------------------------------------------------------------------
+template <int C>
+__global__ void __launch_bounds__(256) k_gate_sum4(const _Float16* __restrict__ xa, const _Float16* __restrict__ xb,
+                                                   const _Float16* __restrict__ xc, const _Float16* __restrict__ xd,
+                                                   const float* __restrict__ gap_part, const float* __restrict__ fc1_w,
+                                                   const float* __restrict__ fc1_b, const float* __restrict__ fc2_w,
+                                                   const float* __restrict__ fc2_b, _Float16* __restrict__ out, int P, int nbands,
+                                                   long n_crops, int pix_per_block) {
+    constexpr int HID = C / 16, CG = C / 8;
+    __shared__ float s_mean[4][C];
+    __shared__ float s_h[4][HID];
+    __shared__ __attribute__((aligned(16))) float s_g[4][C];
+    const long n = blockIdx.x;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < 4 * C; e += 256) {
+        const int b = e / C, c = e - b * C;
+        const float* gp = gap_part + ((long)b * n_crops + n) * nbands * C + c;
+        float s = 0.f;
+        for (int k = 0; k < nbands; ++k) s += gp[(long)k * C];
+        s_mean[b][c] = s / (float)P;
+    }
+    __syncthreads();
+    if (tid < 4 * HID) {
+        const int b = tid / HID, k = tid - b * HID;
+        float h = fc1_b[k];
+        for (int c = 0; c < C; ++c) h += fc1_w[k * C + c] * s_mean[b][c];
+        s_h[b][k] = h > 0.f ? h : 0.f;
+    }
+    __syncthreads();
+    for (int e = tid; e < 4 * C; e += 256) {
+        const int b = e / C, c = e - b * C;
+        float v = fc2_b[c];
+        for (int k = 0; k < HID; ++k) v += fc2_w[c * HID + k] * s_h[b][k];
+        s_g[b][c] = 1.f / (1.f + BM_EXPF(-v));
+    }
+    __syncthreads();
+    const long p0 = (long)blockIdx.y * pix_per_block;
+    const int items = pix_per_block * CG;
+    for (int e = tid; e < items; e += 256) {
+        const int pl = e / CG, cg = e - pl * CG;
+        if (p0 + pl >= P) break;
+        const long off = ((n * P + p0 + pl) * C) + cg * 8;
+        const ch8 a = *reinterpret_cast<const ch8*>(xa + off), b = *reinterpret_cast<const ch8*>(xb + off);
+        const ch8 c = *reinterpret_cast<const ch8*>(xc + off), d = *reinterpret_cast<const ch8*>(xd + off);
+        ch8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ch = cg * 8 + j;
+            float v = (float)a[j] * s_g[0][ch];
+            v += (float)b[j] * s_g[1][ch];
+            v += (float)c[j] * s_g[2][ch];
+            v += (float)d[j] * s_g[3][ch];
+            o[j] = (_Float16)v;
+        }
+        *reinterpret_cast<ch8*>(out + off) = o;
+    }
+}
+
+// head: global average pool -> Linear + folded BatchNorm1d -> ReLU -> L2 (osnet.py:393-396 + base_backend.py:206), fp16 NHWC in.
+// One workgroup per crop; the FC rows are read 16 bytes per lane by a wavefront per output feature group.
+__global__ void __launch_bounds__(256) k_wide_head(const _Float16* __restrict__ in, const float* __restrict__ fc_w,
+                                                   const float* __restrict__ fc_b, float* __restrict__ out_base,
+                                                   const int* __restrict__ out_rows, int P, int C, int F) {
+    __shared__ float s_v[512];
+    __shared__ float s_red[4];
+    const long n = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = tid; c < C; c += 256) {
+        float s = 0.f;
+        for (int p = 0; p < P; ++p) s += (float)in[(n * P + p) * C + c];
+        s_v[c] = s / (float)P;
+    }
+    __syncthreads();
+    float* out = out_base + (out_rows ? (long)out_rows[n] : n) * F;
+    float sq = 0.f;
+    for (int f = wave; f < F; f += 4) {
+        const float* wr = fc_w + (long)f * C;
+        float a = 0.f;
+        for (int c = lane; c < C; c += 64) a += wr[c] * s_v[c];
+        for (int m = 32; m > 0; m >>= 1) a += __shfl_xor(a, m, 64);
+        a += fc_b[f];
+        a = a > 0.f ? a : 0.f;
+        if (lane == 0) out[f] = a;
+        sq += a * a;                        // every lane holds the same value
+    }
+    if (lane == 0) s_red[wave] = sq;
+    __syncthreads();
+    const float nrm = sqrtf(s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+    __syncthreads();
+    for (int f = wave; f < F; f += 4)
+        if (lane == 0) out[f] = out[f] / nrm;
+}
+
+}  // namespace bm

@@ -19,6 +19,7 @@
 #include "reid_kernels_v1.hpp"
 #include "reid_fused.hpp"
 #include "clip_engine.hpp"
+#include "osnet_wide.hpp"
 
 #ifndef BM_STAGE1_HANDOVER
 #define BM_STAGE1_HANDOVER 0
@@ -98,6 +99,8 @@ public:
             h_w_.assign(blob + REID_HEADER_INTS, blob + REID_HEADER_INTS + L_.total);
             alloc_buffers();
             if (ch[0] == 16 && ch[1] == 64 && ch[2] == 96 && ch[3] == 128 && L_.feat == 512) prepare_fused();
+            else if (WideOsnet::supports(L_))       // osnet_x1_0: layer-per-launch fp16 MFMA kernels (osnet_wide.hpp)
+                wide_.reset(new WideOsnet(h_w_.data(), L_, d_w_, max_crops_ < 1024 ? max_crops_ : 1024, owned_));
         }
         BM_HIP(hipEventCreate(&ev_[0]));
         BM_HIP(hipEventCreate(&ev_[1]));
@@ -113,10 +116,13 @@ public:
     void set_mode(int m) {
         if (m != 0 && m != 1) throw std::runtime_error("ReID mode must be 0 (per-layer fp32) or 1 (fused fp16 MFMA)");
         if (clip_) return;                  // CLIP-ReID has one kernel family; the mode switch is OSNet's
-        if (m == 1 && !fused_ready_) throw std::runtime_error("fused fp16 ReID kernels are built for OSNet-x0.25 only");
+        if (m == 1 && !fused_ready_ && !wide_)
+            throw std::runtime_error("fp16 MFMA ReID kernels exist for OSNet-x0.25 (fused) and for widths that are multiples of 32 (osnet_x1_0)");
         mode_ = m;
     }
     int mode() const { return mode_; }
+    // the crop count may stay on the device (run_counted): only the fused x0.25 kernels take it
+    bool counted_ok() const { return mode_ == 1 && fused_ready_; }
     void set_fuse_stem(bool on) { fuse_stem_ = on; }     // A/B switch: fused crop+stem kernel vs resize kernel + stem kernel
     // 0 = "resize" (default), 1 = "resize_pad" (reid/core/preprocessing.py:12-45); resize_pad runs the separate crop kernel
     void set_preprocess(int pad) { pad_ = pad; }
@@ -127,11 +133,15 @@ public:
     // crops only (normalised NHWC fp32) for `n` boxes
     void preprocess(const uint8_t* const* d_frames, const int* d_crop_stream, const float* d_boxes,
                     int box_stride, int n, int W, int H, hipStream_t st) {
-        const bool fused = mode_ == 1 && !force_fp32_crops_;
-        if (n > (fused ? fused_cap_ : max_crops_)) throw std::runtime_error("ReID: crop batch exceeds the engine capacity");
+        const bool fused = mode_ == 1 && fused_ready_ && !force_fp32_crops_;
+        const bool wide = mode_ == 1 && wide_ && !force_fp32_crops_;
+        if (n > (fused ? fused_cap_ : (wide ? wide_->max_crops() : max_crops_))) throw std::runtime_error("ReID: crop batch exceeds the engine capacity");
         if (n == 0) return;
         const int rows_per_block = 16;
-        if (fused)
+        if (wide)
+            hipLaunchKernelGGL(k_crop_resize<_Float16>, dim3(n, REID_IN_H / rows_per_block), dim3(REID_IN_W), 0, st,
+                               d_frames, d_crop_stream, d_boxes, box_stride, W, H, d_lut_, wide_->crops_buffer(), rows_per_block, pad_);
+        else if (fused)
             hipLaunchKernelGGL(k_crop_resize_rgbx, dim3(n, REID_IN_H / rows_per_block), dim3(REID_IN_W), 0, st,
                                d_frames, d_crop_stream, d_boxes, box_stride, W, H, d_lut_, crops_h_, rows_per_block, d_count_, pad_);
         else
@@ -152,10 +162,11 @@ public:
              int n, int W, int H, float* d_out, const int* d_out_rows, hipStream_t st) {
         if (n == 0) return;
         BM_HIP(hipEventRecord(ev_[0], st));
-        const int step = mode_ == 1 ? fused_cap_ : max_crops_;
+        const bool wide = mode_ == 1 && wide_;
+        const int step = wide ? wide_->max_crops() : (mode_ == 1 ? fused_cap_ : max_crops_);
         for (int i0 = 0; i0 < n; i0 += step) {
             const int m = (n - i0) < step ? (n - i0) : step;
-            const bool fuse_stem = mode_ == 1 && fuse_stem_ && !pad_;
+            const bool fuse_stem = mode_ == 1 && fused_ready_ && fuse_stem_ && !pad_;
             if (!fuse_stem) preprocess(d_frames, d_crop_stream + i0, d_boxes + (long)i0 * box_stride, box_stride, m, W, H, st);
             if (i0 == 0) BM_HIP(hipEventRecord(ev_[1], st));
             hipEvent_t a = take_event(), b = take_event();
@@ -163,6 +174,7 @@ public:
             float* o = d_out_rows ? d_out : d_out + (long)i0 * L_.feat;
             const int* orow = d_out_rows ? d_out_rows + i0 : nullptr;
             if (clip_) clip_->forward(crops_, m, o, orow, st);
+            else if (wide) wide_->forward(m, o, orow, st);
             else if (mode_ == 1) {
                 const FrameArgs fa{d_frames, d_crop_stream + i0, d_boxes + (long)i0 * box_stride, box_stride, W, H};
                 forward_fused(m, fuse_stem ? &fa : nullptr, o, orow, st);
@@ -178,7 +190,7 @@ public:
     // beyond *d_count exit immediately -- no host round trip between the crop list and the ReID kernels.
     void run_counted(const uint8_t* const* d_frames, const int* d_crop_stream, const float* d_boxes, int box_stride,
                      const int* d_count, int n_max, int W, int H, float* d_out, const int* d_out_rows, hipStream_t st) {
-        if (mode_ != 1) throw std::runtime_error("ReID: run_counted needs the fused kernels (mode 1)");
+        if (!counted_ok()) throw std::runtime_error("ReID: run_counted needs the fused x0.25 kernels (mode 1)");
         if (n_max > fused_cap_) throw std::runtime_error("ReID: crop batch exceeds the engine capacity");
         if (n_max == 0) return;
         d_count_ = d_count;
@@ -433,6 +445,7 @@ private:
     float *x1_ = nullptr, *ta_ = nullptr, *tb_ = nullptr, *tt_ = nullptr, *acc_ = nullptr, *gap_ = nullptr;
     // fused path
     std::unique_ptr<ClipNet> clip_;         // non-null: the weights are a CLP1 blob (CLIP-ReID ViT-B/16)
+    std::unique_ptr<WideOsnet> wide_;       // non-null: OSNet widths the layer-per-launch fp16 MFMA kernels take (osnet_x1_0)
     bool fused_ready_ = false, force_fp32_crops_ = false, fuse_stem_ = true;
     int pad_ = 0;
     BlkPack bp_[6];

@@ -51,6 +51,17 @@ def infer_arch(sd) -> str:
     raise ValueError(f"unsupported OSNet stem width {c0}")
 
 
+def infer_channels(sd) -> tuple:
+    """(stem, stage 1, stage 2, stage 3) output widths read off the tensors themselves (osnet.py:281-309)."""
+    sd = _clean(sd)
+    return (int(sd["conv1.conv.weight"].shape[0]), int(sd["conv2.0.conv3.conv.weight"].shape[0]),
+            int(sd["conv3.0.conv3.conv.weight"].shape[0]), int(sd["conv4.0.conv3.conv.weight"].shape[0]))
+
+
+def _channels(arch) -> tuple:
+    return tuple(int(c) for c in arch) if isinstance(arch, (tuple, list)) else ARCH_CHANNELS[arch]
+
+
 def _fold(w, sd, bn):
     """conv/linear weight (out, ...) + BN named ``bn`` -> (W', b')."""
     scale = _np(sd[bn + ".weight"]) / np.sqrt(_np(sd[bn + ".running_var"]) + BN_EPS)
@@ -61,8 +72,7 @@ def _fold(w, sd, bn):
 def pack_osnet(state_dict) -> np.ndarray:
     """Returns the fp32 blob (header viewed as int32) consumed by the C ABI."""
     sd = _clean(state_dict)
-    arch = infer_arch(sd)
-    ch = ARCH_CHANNELS[arch]
+    ch = infer_channels(sd)
     parts = []
 
     def put(a):
@@ -145,7 +155,7 @@ def reference_init_state_dict(arch: str = "osnet_x0_25", seed: int = 0):
     This is the "random-init weights of that architecture" the benchmark uses."""
     import torch
 
-    ch = ARCH_CHANNELS[arch]
+    ch = _channels(arch)
     g = torch.Generator().manual_seed(seed)
     sd = {}
 
@@ -206,7 +216,7 @@ def random_osnet_state_dict(arch: str = "osnet_x0_25", seed: int = 0, num_classe
     import torch
     import torch.nn.functional as F
 
-    ch = ARCH_CHANNELS[arch]
+    ch = _channels(arch)
     g = torch.Generator().manual_seed(seed)
     sd = {}
 

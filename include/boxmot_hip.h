@@ -269,6 +269,15 @@ int boxmot_hip_deepocsort_update_batch(
  * d_dets [S][max_dets][6], d_det_rows [S], d_embs [S][max_dets][emb_dim], d_out [S][max_tracks][8], d_out_rows [S]. */
 int boxmot_hip_deepocsort_step_device(BoxMOTHipDeepOcSort* handle, const float* d_dets, const int* d_det_rows,
                                        const float* d_embs, float* d_out, int* d_out_rows);
+/* the same with the embeddings computed on the device from frames already resident in HBM (d_frames: one pointer per stream,
+ * all image_rows x image_cols x 3 uint8 BGR): crop list -> ReID backbone of the loaded weights -> step; no host copies */
+int boxmot_hip_deepocsort_step_device_frames(BoxMOTHipDeepOcSort* handle, const float* d_dets, const int* d_det_rows,
+                                              const uint8_t* const* d_frames, int image_rows, int image_cols, float* d_out,
+                                              int* d_out_rows);
+/* accumulated device milliseconds of the ReID forward region since the last call (and the number of passes) */
+int boxmot_hip_deepocsort_reid_kernel_ms(BoxMOTHipDeepOcSort* handle, double* out_ms, int* out_launches);
+/* 0 = per-layer fp32 kernels, 1 = fp16 MFMA kernels (fused for OSNet-x0.25, layer-per-launch for osnet_x1_0); CLIP-ReID has one family */
+int boxmot_hip_deepocsort_set_reid_mode(BoxMOTHipDeepOcSort* handle, int mode);
 int boxmot_hip_deepocsort_synchronize(BoxMOTHipDeepOcSort* handle);
 /* parity debugging: live tracks of `stream` in list order -- ints5 (rows,5) = id, age, time_since_update, hit_streak,
  * observed; kf72 (rows,72) = x[8] ++ P[8][8] fp64 (index 7 unused); emb (rows, emb_dim) fp64.  NULL skips an output. */
@@ -325,6 +334,11 @@ int boxmot_hip_strongsort_update_batch(
  * d_dets [S][max_dets][6], d_det_rows [S], d_embs [S][max_dets][emb_dim], d_out [S][max_tracks][8], d_out_rows [S]. */
 int boxmot_hip_strongsort_step_device(BoxMOTHipStrongSort* handle, const float* d_dets, const int* d_det_rows,
                                        const float* d_embs, float* d_out, int* d_out_rows);
+int boxmot_hip_strongsort_step_device_frames(BoxMOTHipStrongSort* handle, const float* d_dets, const int* d_det_rows,
+                                              const uint8_t* const* d_frames, int image_rows, int image_cols, float* d_out,
+                                              int* d_out_rows);
+int boxmot_hip_strongsort_reid_kernel_ms(BoxMOTHipStrongSort* handle, double* out_ms, int* out_launches);
+int boxmot_hip_strongsort_set_reid_mode(BoxMOTHipStrongSort* handle, int mode);
 int boxmot_hip_strongsort_synchronize(BoxMOTHipStrongSort* handle);
 /* len(self.tracker.tracks) of `stream` (tentative + confirmed): the reference asks its camera-motion estimator for a warp only
  * when this is >= 1 (strongsort.py:83-86), and that estimator is stateful -- a caller that owns one needs the same gate. */

@@ -136,8 +136,55 @@ def test_osnet_x1_0_features_on_device_vs_oracle(seed):
     print(f"osnet_x1_0 seed {seed}: max|diff| = {err:.2e}")
     assert err < 1e-3
     assert np.allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-5)
-    with pytest.raises(RuntimeError, match="x0.25"):
-        reid.set_mode(1)                                  # the fused fp16 kernels exist for x0.25 only: loud, not silent
+    reid.close()
+
+
+def test_osnet_x1_0_fp16_mfma_kernels_vs_oracle_and_unsupported_width_is_loud():
+    """mode 1 at x1.0 = the layer-per-launch fp16 MFMA family (csrc/osnet_wide.hpp): <= 1e-3 on the reference's own init
+    (the benchmark weights of configuration 3), chunking over max_crops, scattered empty / clipped boxes; widths that are not
+    multiples of 32 (osnet_x0_5: middle width 48) have no fp16 family and say so."""
+    from boxmot_amd.reid import HipReID
+    from boxmot_amd.reid_weights import reference_init_state_dict
+    from oracle.osnet import OracleReID
+    sd = reference_init_state_dict("osnet_x1_0", seed=0)
+    img = np.random.default_rng(17).integers(0, 255, (720, 1280, 3), dtype=np.uint8)
+    boxes = np.concatenate([_boxes(np.random.default_rng(3), 10, 1280, 720),
+                            np.array([[-10, -5, 60, 120], [1200, 650, 1300, 740], [100, 100, 100, 150]], dtype=np.float32)])
+    reid = HipReID(sd, max_crops=8, mode=1)
+    got = reid.get_features(boxes, img)
+    want = OracleReID(sd).get_features(boxes, img)
+    err = float(np.abs(got - want).max())
+    print(f"osnet_x1_0 fp16 MFMA kernels: max|diff| = {err:.2e}, min cosine {(got * want).sum(1).min():.6f}")
+    assert err < 1e-3
+    assert np.allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-5)
+    reid.set_mode(0)
+    assert np.abs(reid.get_features(boxes, img) - want).max() < 1e-4
+    reid.close()
+    half = HipReID(reference_init_state_dict("osnet_x0_5", seed=0), max_crops=4)
+    with pytest.raises(RuntimeError, match="multiples of 32"):
+        half.set_mode(1)
+    half.close()
+
+
+def test_deepocsort_with_osnet_x1_0_fp16_inside_update_matches_oracle_ids():
+    """BASELINE configuration 3's pairing on the fp16 MFMA kernels, ReID inside update."""
+    from boxmot_amd import DeepOcSort
+    from boxmot_amd.reid import HipReID
+    from boxmot_amd.reid_weights import reference_init_state_dict
+    from boxmot_amd.scenario import Scenario
+    from oracle.deepocsort import DeepOcSortOracle
+    from oracle.osnet import OracleReID
+    sd = reference_init_state_dict("osnet_x1_0", seed=0)
+    sc = Scenario(12, 24, width=960, height=540, random_image=True)
+    reid = HipReID(sd, max_crops=32, mode=1)
+    trk = DeepOcSort(reid_model=reid, cmc_off=True, max_tracks=128, max_dets=64)
+    orc = DeepOcSortOracle(reid=OracleReID(sd), lap_rule="lowest_index")
+    for t in range(14):
+        dets, _ = sc.frame(t, with_embs=False)
+        got = np.asarray(trk.update(dets, sc.image)).reshape(-1, 8)
+        want = np.asarray(orc.update(dets, sc.image), dtype=np.float32).reshape(-1, 8)
+        assert_rows_match(got, want, t, box_atol=1e-3)
+    trk.close()
     reid.close()
 
 

@@ -1,0 +1,167 @@
+"""End-to-end rate (mode M2: ReID inside the update, frames and detections resident in HBM) of BASELINE.json's configurations 3 and 5
+on one MI355X.  Development / evidence tool (results under profiles/); the contract benchmark for configuration 2 is bench.py.
+
+    python tools/config_bench.py --config c3 [--streams 8]   DeepOCSORT + OSNet_x1_0,            128 dets x 512 tracks,  1080p
+    python tools/config_bench.py --config c5 [--streams 2]   StrongSORT + CLIP-ReID (ViT-B/16),  256 dets x 1024 tracks, 4K (1280-d)
+
+One step = one frame of every stream: crop list -> backbone (fp16 MFMA kernels) -> tracker step, through
+boxmot_hip_{deepocsort,strongsort}_step_device_frames.  Prints one JSON line: frames/s over all streams, ms per step, the ReID
+forward region (HIP events on the launch stream) with its achieved TFLOP/s against the 2.5 PFLOP/s dense fp16 MFMA peak, and a
+parity gate (ReID embeddings of the first detections of stream 0 vs the torch fp32 oracle; ids of the first frames vs the
+oracle tracker for c3).  Random-init weights of the architecture (no network access for checkpoints)."""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+
+def osnet_macs(ch):
+    """multiply-accumulates of OSNet.forward per 256 x 128 crop (osnet.py:380-405)."""
+    m = 128 * 64 * ch[0] * 147
+    cin, P = ch[0], 2048
+    for s in range(3):
+        cout, mid = ch[s + 1], ch[s + 1] // 4
+        for _ in range(2):
+            m += P * (cin * mid + 10 * (mid * mid + 9 * mid) + mid * cout + (cin * cout if cin != cout else 0))
+            cin = cout
+        if s < 2:
+            m += P * cout * cout
+            P //= 4
+    return m + P * ch[3] * ch[3] + 512 * ch[3]
+
+
+def vit_flops(width=768, layers=12, tokens=129, patch_k=768, out_dim=512):
+    d, t = width, tokens
+    return 2 * (t - 1) * patch_k * d + layers * (2 * t * d * 3 * d + 4 * t * t * d + 2 * t * d * d + 4 * t * d * 4 * d) + 2 * d * out_dim
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="c3", choices=["c3", "c5"])
+    ap.add_argument("--streams", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--check-frames", type=int, default=-1)
+    ap.add_argument("--reid-mode", type=int, default=1)
+    a = ap.parse_args()
+    import torch
+
+    from boxmot_amd import _lib
+    from boxmot_amd.reid_weights import save_blob
+    from boxmot_amd.scenario import Scenario
+    lib = _lib.load()
+    c3 = a.config == "c3"
+    nd, ntr, dim, W, H = (128, 512, 512, 1920, 1080) if c3 else (256, 1024, 1280, 3840, 2160)
+    S = a.streams or (8 if c3 else 2)
+    T = a.warmup + a.steps
+    check = a.check_frames if a.check_frames >= 0 else (2 if c3 else 0)
+    dev = torch.device("cuda", 0)
+    if c3:
+        from boxmot_amd.reid_weights import pack_osnet, reference_init_state_dict
+        sd = reference_init_state_dict("osnet_x1_0", seed=0)
+        blob = pack_osnet(sd)
+        flops_per_crop = 2 * osnet_macs((64, 256, 384, 512))
+    else:
+        from boxmot_amd.clip_weights import pack_clipreid, random_clipreid_state_dict
+        sd = random_clipreid_state_dict(0)
+        blob = pack_clipreid(sd)
+        flops_per_crop = vit_flops()
+    fd, path = tempfile.mkstemp(suffix=".reidblob")
+    os.close(fd)
+    save_blob(blob, path)
+    scen = [Scenario(nd, ntr, width=W, height=H, emb_dim=8, stream=s, random_image=True) for s in range(S)]
+    cap_nd, cap = ntr, 2 * ntr
+    dets_h = np.zeros((T, S, cap_nd, 6), np.float32)
+    cnt_h = np.zeros((T, S), np.int32)
+    for t in range(T):
+        for s in range(S):
+            d, _ = scen[s].frame(t, with_embs=False)
+            cnt_h[t, s] = len(d)
+            dets_h[t, s, : len(d)] = d
+    d_dets, d_cnt = torch.from_numpy(dets_h).to(dev), torch.from_numpy(cnt_h).to(dev)
+    frames = torch.stack([torch.from_numpy(sc.image) for sc in scen]).to(dev)
+    ptrs = torch.tensor([frames[s].data_ptr() for s in range(S)], dtype=torch.int64, device=dev)
+    if c3:
+        cfg = _lib.DeepOcSortConfig()
+        lib.boxmot_hip_deepocsort_default_config(ctypes.byref(cfg))
+        cfg.cmc_off = 1
+        mk, step_fn, sync, destroy = lib.boxmot_hip_deepocsort_create, lib.boxmot_hip_deepocsort_step_device_frames, \
+            lib.boxmot_hip_deepocsort_synchronize, lib.boxmot_hip_deepocsort_destroy
+        reid_ms, set_mode = lib.boxmot_hip_deepocsort_reid_kernel_ms, lib.boxmot_hip_deepocsort_set_reid_mode
+    else:
+        cfg = _lib.StrongSortConfig()
+        lib.boxmot_hip_strongsort_default_config(ctypes.byref(cfg))
+        mk, step_fn, sync, destroy = lib.boxmot_hip_strongsort_create, lib.boxmot_hip_strongsort_step_device_frames, \
+            lib.boxmot_hip_strongsort_synchronize, lib.boxmot_hip_strongsort_destroy
+        reid_ms, set_mode = lib.boxmot_hip_strongsort_reid_kernel_ms, lib.boxmot_hip_strongsort_set_reid_mode
+    cfg.n_streams, cfg.max_tracks, cfg.max_dets, cfg.emb_dim = S, cap, cap_nd, dim
+    cfg.reid_model_path = path.encode()
+    h = mk(ctypes.byref(cfg))
+    os.unlink(path)
+    if not h:
+        raise RuntimeError(_lib.last_error())
+    if c3:
+        _lib.check(set_mode(h, a.reid_mode))
+    d_out = torch.zeros((T, S, cap, 8), dtype=torch.float32, device=dev)
+    d_out_n = torch.zeros((T, S), dtype=torch.int32, device=dev)
+    step = lambda t: _lib.check(step_fn(h, d_dets[t].data_ptr(), d_cnt[t].data_ptr(), ptrs.data_ptr(), H, W, d_out[t].data_ptr(), d_out_n[t].data_ptr()))
+    ms, nl = ctypes.c_double(0), ctypes.c_int(0)
+    for t in range(a.warmup):
+        step(t)
+    _lib.check(sync(h))
+    _lib.check(reid_ms(h, ctypes.byref(ms), ctypes.byref(nl)))
+    t0 = time.perf_counter()
+    for t in range(a.warmup, T):
+        step(t)
+    _lib.check(sync(h))
+    dt = time.perf_counter() - t0
+    _lib.check(reid_ms(h, ctypes.byref(ms), ctypes.byref(nl)))
+    crops = int(cnt_h[a.warmup:].sum())
+    out_h, out_n = d_out.cpu().numpy(), d_out_n.cpu().numpy()
+    # parity gates
+    gates = {}
+    from boxmot_amd.reid import HipReID
+    if c3:
+        from oracle.osnet import OracleReID
+        orc_reid = OracleReID(sd)
+    else:
+        from oracle.clipreid import OracleClipReID
+        orc_reid = OracleClipReID(sd)
+    hr = HipReID(blob, max_crops=8, mode=a.reid_mode if c3 else 0)
+    bx = dets_h[0, 0, :8, :4]
+    gates["reid_max_abs_err_vs_fp32_oracle"] = float(np.abs(hr.get_features(bx, scen[0].image) - orc_reid.get_features(bx, scen[0].image)).max())
+    hr.close()
+    if check:
+        from oracle.deepocsort import DeepOcSortOracle
+        orc = DeepOcSortOracle(reid=orc_reid, lap_rule="lowest_index")
+        ok = True
+        for t in range(check):
+            n = cnt_h[t, 0]
+            want = np.asarray(orc.update(dets_h[t, 0, :n], scen[0].image), dtype=np.float32).reshape(-1, 8)
+            got = out_h[t, 0, : out_n[t, 0]]
+            ok = ok and got.shape == want.shape and np.array_equal(np.sort(got[:, 4]), np.sort(want[:, 4]))
+        gates["ids_first_frames_vs_oracle_stream0"] = bool(ok)
+    destroy(h)
+    tfl = crops * flops_per_crop / (ms.value * 1e9) if ms.value > 0 else None
+    print(json.dumps({
+        "workload": ("DeepOCSORT + OSNet_x1_0 ReID, 128 dets x 512 tracks, 1080p" if c3 else
+                     "StrongSORT + CLIP-ReID (ViT-B/16), 256 dets x 1024 tracks, 4K frames, 1280-d"),
+        "mode": "M2 reid-in-update, device-resident inputs", "streams": S, "steps": a.steps, "warmup": a.warmup,
+        "frames_per_s": S * a.steps / dt, "ms_per_step": 1e3 * dt / a.steps, "crops_per_step": crops / a.steps,
+        "reid_forward_ms_per_step": ms.value / a.steps, "reid_passes": nl.value, "gflop_per_crop": flops_per_crop / 1e9,
+        "roofline": {"bound": "mfma", "achieved": tfl, "peak": 2500.0, "unit": "TFLOP/s", "frac": (tfl / 2500.0) if tfl else None,
+                     "kernel": "ReID forward region (HIP events on the launch stream)"},
+        "rows_stream0_last": int(out_n[-1, 0]), "dtype": "f16", **gates}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
