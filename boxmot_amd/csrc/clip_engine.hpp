@@ -63,7 +63,7 @@ public:
         qkv16_ = alloc<_Float16>(R * 3 * D, owned);
         mlp16_ = alloc<_Float16>(R * 4 * D, owned);
         check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_clip_attention), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  clip_attn_lds_bytes(tokens, 4)), "attention LDS");
+                                  clip_attn_lds_bytes(tokens)), "attention LDS");
     }
     int feature_dim() const { return width + out_dim; }
 
@@ -83,7 +83,7 @@ public:
         for (const ClipLayerOff& l : L_) {
             layernorm(d_w_ + l.ln1_w, d_w_ + l.ln1_b, R, st);
             gemm<0>(h16_, d_w16_ + l.qkv_w, d_w_ + l.qkv_b, qkv16_, R, 3 * D, D, st);
-            hipLaunchKernelGGL(k_clip_attention, dim3((unsigned)(n * heads)), dim3(256), (size_t)clip_attn_lds_bytes(T, 4), st,
+            hipLaunchKernelGGL(k_clip_attention, dim3((unsigned)(n * heads)), dim3(256), (size_t)clip_attn_lds_bytes(T), st,
                                qkv16_, h16_, T, D, heads);
             gemm<2>(h16_, d_w16_ + l.out_w, d_w_ + l.out_b, x_, R, D, D, st);
             layernorm(d_w_ + l.ln2_w, d_w_ + l.ln2_b, R, st);

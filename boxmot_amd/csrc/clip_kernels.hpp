@@ -15,7 +15,8 @@
 // features of one token: bias / QuickGELU / residual add run in the epilogue on those and the store is 8 (fp16) or 16 (fp32)
 // contiguous bytes per lane.  128 x 128 x 32 tiles, 4 waves of 64 x 64, operands staged through LDS (rows padded to 40 halves:
 // conflict-free 16-byte fragment reads), the next k-tile's global loads in flight while the current one multiplies.
-// Attention is 0.2 % of the FLOPs (129 tokens): one workgroup per (crop, head) on the vector ALUs, fp32 softmax.
+// Attention (129 tokens, 0.2 % of the FLOPs): one workgroup per (crop, head), both products on the matrix pipe with the softmax
+// in registers between them (k_clip_attention).
 #pragma once
 
 #include <stdint.h>
@@ -101,70 +102,123 @@ __global__ void __launch_bounds__(256) k_clip_layernorm_f16(const float* __restr
 }
 
 // ---------------------------------------------------------------------------
-// Multi-head attention for one (crop, head): q, k, v fp16 [T][64] slices of qkv16, out fp16 [T][64] slice of h16
-// (nn.MultiheadAttention: q scaled by 1 / sqrt(64), softmax over the keys, no mask; model.py:200-206).  K, V and Q rows in
-// LDS (row stride 66 halves: a lane per key / per dimension reads conflict-free), one wavefront per query row: scores for
-// the keys lane, lane + 64, ..., fp32 softmax by wave reductions, then lane d accumulates sum_k p[k] * V[k][d].
+// Multi-head attention for one (crop, head) on the matrix pipe: q, k, v fp16 [T][64] slices of qkv16, out fp16 [T][64] slice of
+// h16 (nn.MultiheadAttention: q scaled by 1 / sqrt(64), softmax over the keys, no mask; model.py:200-206).
+//   S^T = K . Q^T   per 16-query tile: MFMA A = K rows, B = Q rows -> a lane holds, for ITS query (lane & 15), the scores of the
+//                   keys 16 kt + 4 (lane >> 4) + r: the softmax is an in-lane reduction plus two xor-shuffles (16, 32)
+//   O^T = V^T . P^T MFMA A = V^T rows (from an LDS image transposed at load), B = the probabilities the lane already holds:
+//                   the k-slot (g, j) of step ks is DEFINED as key 32 ks + 4 g + j (j < 4) / 32 ks + 16 + 4 g + j - 4 (j >= 4),
+//                   i.e. exactly the accumulator rows of score tiles 2 ks and 2 ks + 1 -- a sum over keys does not care
+//                   about their order, so P never moves between lanes; V^T is read with the same permutation (two 8-byte reads)
+// fp32 scores / softmax / accumulation, fp16 operands (probabilities <= 1 after the max subtraction).  T <= 192.
+// LDS: K and Q as [TP][72] halves (TP = T rounded up to 16; rows 144 bytes apart), V^T as [64][KP + 8] (KP = T rounded up to 32),
+// pad rows / columns zeroed (a zero probability times an uninitialised value could still be NaN).
 // ---------------------------------------------------------------------------
-constexpr int ATT_DH = 64, ATT_LD = 66, ATT_MAX_T = 192;
-__host__ __device__ inline int clip_attn_lds_bytes(int T, int nwaves) { return 3 * T * ATT_LD * 2 + nwaves * ATT_MAX_T * 4; }
+constexpr int ATT_DH = 64, ATT_LD = 72, ATT_MAX_T = 192;
+__host__ __device__ inline int clip_attn_tp(int T) { return (T + 15) / 16 * 16; }
+__host__ __device__ inline int clip_attn_kp(int T) { return (T + 31) / 32 * 32; }
+__host__ __device__ inline int clip_attn_lds_bytes(int T) { return (2 * clip_attn_tp(T) * ATT_LD + ATT_DH * (clip_attn_kp(T) + 8)) * 2; }
 
 __global__ void __launch_bounds__(256) k_clip_attention(const _Float16* __restrict__ qkv, _Float16* __restrict__ out, int T, int D, int heads) {
     BM_DYNAMIC_LDS_T(unsigned char, lds);
+    const int TP = clip_attn_tp(T), KP = clip_attn_kp(T), VLD = KP + 8;
     _Float16* sQ = reinterpret_cast<_Float16*>(lds);
-    _Float16* sK = sQ + T * ATT_LD;
-    _Float16* sV = sK + T * ATT_LD;
-    float* sP = reinterpret_cast<float*>(sV + T * ATT_LD);              // [waves][ATT_MAX_T]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    _Float16* sK = sQ + TP * ATT_LD;
+    _Float16* sVt = sK + TP * ATT_LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l16 = lane & 15;
     const long crop = blockIdx.x / heads;
     const int head = blockIdx.x % heads;
     const _Float16* base = qkv + crop * T * (3L * D) + head * ATT_DH;
-    for (int e = tid; e < T * (ATT_DH / 2); e += blockDim.x) {           // pairs of halves
-        const int t = e / (ATT_DH / 2), d2 = (e % (ATT_DH / 2)) * 2;
-        const _Float16* row = base + (long)t * 3 * D + d2;
-        *reinterpret_cast<unsigned*>(sQ + t * ATT_LD + d2) = *reinterpret_cast<const unsigned*>(row);
-        *reinterpret_cast<unsigned*>(sK + t * ATT_LD + d2) = *reinterpret_cast<const unsigned*>(row + D);
-        *reinterpret_cast<unsigned*>(sV + t * ATT_LD + d2) = *reinterpret_cast<const unsigned*>(row + 2 * D);
+    const ch8 zero8 = ch8{0, 0, 0, 0, 0, 0, 0, 0};
+    for (int e = tid; e < TP * 8; e += 256) {                   // 16-byte chunks: row t, halves 8 c .. 8 c + 7
+        const int t = e >> 3, c = (e & 7) * 8;
+        ch8 q = zero8, k = zero8, v = zero8;
+        if (t < T) {
+            const _Float16* row = base + (long)t * 3 * D + c;
+            q = *reinterpret_cast<const ch8*>(row);
+            k = *reinterpret_cast<const ch8*>(row + D);
+            v = *reinterpret_cast<const ch8*>(row + 2 * D);
+        }
+        *reinterpret_cast<ch8*>(sQ + t * ATT_LD + c) = q;
+        *reinterpret_cast<ch8*>(sK + t * ATT_LD + c) = k;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sVt[(c + j) * VLD + t] = v[j];
+    }
+    for (int e = tid; e < ATT_DH * (KP - TP); e += 256) {       // key columns TP .. KP - 1 of V^T
+        const int d = e / (KP - TP), t = TP + e % (KP - TP);
+        sVt[d * VLD + t] = (_Float16)0.f;
     }
     __syncthreads();
-    float* p = sP + wave * ATT_MAX_T;
-    for (int q = wave; q < T; q += nw) {
-        float sc[ATT_MAX_T / 64];
+    const int nkt = TP / 16, nks = KP / 32;
+    constexpr int MAX_KT = ATT_MAX_T / 16;
+    for (int qt = wave; qt < nkt; qt += 4) {
+        ch8 bq[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) bq[s] = *reinterpret_cast<const ch8*>(sQ + (16 * qt + l16) * ATT_LD + 32 * s + 8 * g);
+        cf4 sc[MAX_KT];
         float mx = -3.0e38f;
 #pragma unroll
-        for (int j = 0; j < ATT_MAX_T / 64; ++j) {
-            const int k = lane + 64 * j;
-            float s = -3.0e38f;
-            if (k < T) {
-                s = 0.f;
-                for (int d = 0; d < ATT_DH; d += 2) {                   // two halves per LDS dword: the Q read is a broadcast
-                    typedef _Float16 ch2 __attribute__((ext_vector_type(2)));
-                    const ch2 qv = *reinterpret_cast<const ch2*>(sQ + q * ATT_LD + d), kv = *reinterpret_cast<const ch2*>(sK + k * ATT_LD + d);
-                    s += (float)qv[0] * (float)kv[0];
-                    s += (float)qv[1] * (float)kv[1];
+        for (int kt = 0; kt < MAX_KT; ++kt) {
+            sc[kt] = cf4{-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+            if (kt < nkt) {
+                cf4 acc = cf4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const ch8 a = *reinterpret_cast<const ch8*>(sK + (16 * kt + l16) * ATT_LD + 32 * s + 8 * g);
+                    acc = BM_MFMA_F16_K32(a, bq[s], acc);
                 }
-                s *= 0.125f;                                              // head_dim ** -0.5
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = (16 * kt + 4 * g + r) < T ? acc[r] * 0.125f : -3.0e38f;      // head_dim ** -0.5; pad keys masked
+                    sc[kt][r] = v;
+                    mx = v > mx ? v : mx;
+                }
             }
-            sc[j] = s;
-            mx = s > mx ? s : mx;
         }
-        mx = clip_wave_max(mx);
+        { float o = __shfl_xor(mx, 16, 64); mx = o > mx ? o : mx; o = __shfl_xor(mx, 32, 64); mx = o > mx ? o : mx; }
         float sum = 0.f;
 #pragma unroll
-        for (int j = 0; j < ATT_MAX_T / 64; ++j) {
-            const int k = lane + 64 * j;
-            if (k < T) {
-                const float e = BM_EXPF(sc[j] - mx);
-                p[k] = e;
-                sum += e;
+        for (int kt = 0; kt < MAX_KT; ++kt) {
+            if (kt < nkt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = (16 * kt + 4 * g + r) < T ? BM_EXPF(sc[kt][r] - mx) : 0.f;
+                    sc[kt][r] = e;
+                    sum += e;
+                }
+            } else sc[kt] = cf4{0.f, 0.f, 0.f, 0.f};
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        cf4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = cf4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < MAX_KT / 2; ++ks) {
+            if (ks < nks) {
+                ch8 pb;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { pb[j] = (_Float16)sc[2 * ks][j]; pb[4 + j] = (_Float16)sc[2 * ks + 1][j]; }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const _Float16* vr = sVt + (16 * dt + l16) * VLD + 32 * ks + 4 * g;
+                    const ch4 lo = *reinterpret_cast<const ch4*>(vr), hi = *reinterpret_cast<const ch4*>(vr + 16);
+                    const ch8 a = ch8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    o[dt] = BM_MFMA_F16_K32(a, pb, o[dt]);
+                }
             }
         }
-        sum = clip_wave_sum(sum);
-        BM_WAVE_LDS_SYNC();                 // p[] written by the lanes of this wave is read by all of them below
-        float o = 0.f;
-        for (int k = 0; k < T; ++k) o += p[k] * (float)sV[k * ATT_LD + lane];
-        out[(crop * T + q) * D + head * ATT_DH + lane] = (_Float16)(o / sum);
-        BM_WAVE_LDS_SYNC();                 // ... before the next query row overwrites it
+        const int q = 16 * qt + l16;
+        if (q < T) {
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                ch4 w;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) w[r] = (_Float16)(o[dt][r] * inv);
+                *reinterpret_cast<ch4*>(out + (crop * T + q) * D + head * ATT_DH + 16 * dt + 4 * g) = w;
+            }
+        }
     }
 }
 

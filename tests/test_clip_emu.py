@@ -24,7 +24,7 @@ def _build():
 
 
 @pytest.mark.skipif(CLANG is None, reason="needs a host clang with _Float16")
-@pytest.mark.parametrize("width,layers,out_dim,hw,n", [(128, 2, 128, (32, 32), 3), (256, 1, 128, (48, 16), 2)])
+@pytest.mark.parametrize("width,layers,out_dim,hw,n", [(128, 2, 128, (32, 32), 3), (256, 1, 128, (48, 16), 2), (128, 1, 128, (128, 64), 2)])
 def test_clip_kernels_emulated_vs_oracle(width, layers, out_dim, hw, n):
     import torch
 
