@@ -167,6 +167,17 @@ SIGNATURES = {
     "boxmot_hip_reid_compute_features": (_I, [_VP, _VP, _I, _I, _I, _VP, _I, _I, _VP, _I]),
     "boxmot_hip_reid_preprocess": (_I, [_VP, _VP, _I, _I, _I, _VP, _I, _I, _VP]),
     "boxmot_hip_reid_last_time_ms": (_I, [_VP, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "boxmot_hip_botsort_update_batch_frames": (_I, [_VP, _I, _VP, _VP, _VP, _I, _VP, _I, _I, _VP, _I, _VP]),
+    "boxmot_hip_deepocsort_stream": (_VP, [_VP]),
+    "boxmot_hip_strongsort_stream": (_VP, [_VP]),
+    "boxmot_hip_ingest_create": (_VP, [_I, _I, _I, _I]),
+    "boxmot_hip_ingest_destroy": (None, [_VP]),
+    "boxmot_hip_ingest_host_ptr": (_VP, [_VP, _I, _I]),
+    "boxmot_hip_ingest_device_frames": (_VP, [_VP, _I]),
+    "boxmot_hip_ingest_submit": (_I, [_VP, _I, _I]),
+    "boxmot_hip_ingest_wait": (_I, [_VP, _I, _VP]),
+    "boxmot_hip_ingest_release": (_I, [_VP, _I, _VP]),
+    "boxmot_hip_ingest_host_done": (_I, [_VP, _I]),
     "boxmot_hip_last_error": (ctypes.c_char_p, []),
     "boxmot_hip_device_count": (_I, []),
 }

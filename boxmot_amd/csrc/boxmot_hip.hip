@@ -138,6 +138,29 @@ struct BoxMOTHipReID {
     }
 };
 
+// Frame ingest ring: n_slots x n_streams page-locked host frames, their device twins, a copy stream and
+// one "uploaded" + one "consumed" event per slot.  The caller decodes frame t + 1 straight into slot (t + 1) % n_slots while the
+// kernels of frame t run; submit() queues the slot's H2D DMA on the copy stream, wait() makes the consuming stream wait for it,
+// release() lets the next upload into the slot wait for the consumer -- no host synchronisation anywhere.
+struct BoxMOTHipIngest {
+    int n_slots = 0, n_streams = 0, rows = 0, cols = 0;
+    size_t frame_bytes = 0;
+    hipStream_t copy_stream = nullptr;
+    std::vector<uint8_t*> h_slot, d_slot;           // [n_slots]: n_streams contiguous frames each
+    std::vector<const uint8_t**> d_ptrs;            // [n_slots]: device table of n_streams frame pointers
+    std::vector<hipEvent_t> uploaded, consumed;
+    std::vector<char> has_consumer;
+    ~BoxMOTHipIngest() {
+        if (copy_stream) (void)hipStreamSynchronize(copy_stream);
+        for (auto p : h_slot) if (p) (void)hipHostFree(p);
+        for (auto p : d_slot) if (p) (void)hipFree(p);
+        for (auto p : d_ptrs) if (p) (void)hipFree(p);
+        for (auto e : uploaded) (void)hipEventDestroy(e);
+        for (auto e : consumed) (void)hipEventDestroy(e);
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    }
+};
+
 struct BoxMOTHipBotSort {
     BoxMOTHipBotSortConfig cfg{};
     std::string reid_path;
@@ -410,7 +433,7 @@ struct StreamIn {
 // Shared host path: stage inputs of streams [s0, s0+n), run ReID if needed, step, read back.
 void host_update(BoxMOTHipBotSort* h, int s0, int n, const StreamIn* in, int det_cols, int emb_cols,
                  int image_rows, int image_cols, int image_channels, const int* list_sel, const int* fc_set,
-                 float* const* out, int out_capacity_rows, int* out_rows) {
+                 float* const* out, int out_capacity_rows, int* out_rows, const uint8_t* const* d_frames_ext = nullptr) {
     const int nd = h->nd, dim = h->dim;
     bool need_reid = false;
     for (int k = 0; k < n; ++k) {
@@ -455,7 +478,10 @@ void host_update(BoxMOTHipBotSort* h, int s0, int n, const StreamIn* in, int det
             BM_HIP(hipMemcpyAsync(d_embs + (size_t)k * nd * dim, in[k].embs, (size_t)in[k].det_rows * dim * 4,
                                   hipMemcpyHostToDevice, h->stream));
     h->last_reid_pre_ms = h->last_reid_proc_ms = 0;
-    if (need_reid) {
+    if (need_reid && d_frames_ext) {       // frames already on the device (ingest ring slot): no upload
+        if (s0 != 0) throw std::runtime_error("boxmot_hip: device frames are addressed from stream 0");
+        run_reid(h, s0, n, h->d_dets, h->d_ndets, d_frames_ext, image_rows, image_cols, h->d_embs);
+    } else if (need_reid) {
         for (int k = 0; k < n; ++k) {
             if (in[k].image) upload_frame(h, s0 + k, in[k].image, image_rows, image_cols, image_channels);
             else if (h->frame_bufs[s0 + k] == nullptr) throw std::runtime_error("Image data pointer is null.");
@@ -889,6 +915,22 @@ int boxmot_hip_botsort_update_batch(BoxMOTHipBotSort* handle, int n_streams, con
     });
 }
 
+int boxmot_hip_botsort_update_batch_frames(BoxMOTHipBotSort* handle, int n_streams, const float* const* dets,
+                                           const int* det_rows, const float* const* embs, int emb_cols,
+                                           const uint8_t* const* d_frames, int image_rows, int image_cols,
+                                           float* const* out_tracks, int out_capacity_rows, int* out_rows) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip BoT-SORT handle is not initialized.");
+        if (n_streams < 1 || n_streams > handle->S) throw std::runtime_error("boxmot_hip: n_streams out of range");
+        if (!dets || !det_rows || !out_tracks || !out_rows) throw std::runtime_error("boxmot_hip: null batch pointers");
+        if (!d_frames || image_rows < 1 || image_cols < 1) throw std::runtime_error("boxmot_hip: update_batch_frames needs device frames");
+        std::vector<StreamIn> in(n_streams);
+        for (int s = 0; s < n_streams; ++s) in[s] = StreamIn{dets[s], det_rows[s], (embs && emb_cols > 0) ? embs[s] : nullptr, nullptr};
+        host_update(handle, 0, n_streams, in.data(), 6, emb_cols, image_rows, image_cols, 3, nullptr, nullptr, out_tracks,
+                    out_capacity_rows, out_rows, d_frames);
+    });
+}
+
 int boxmot_hip_botsort_step_device(BoxMOTHipBotSort* handle, const float* d_dets, const int* d_det_rows,
                                    const float* d_embs, const uint8_t* const* d_frames, int image_rows, int image_cols,
                                    float* d_out, int* d_out_rows) {
@@ -1166,6 +1208,97 @@ int boxmot_hip_reid_preprocess(BoxMOTHipReID* handle, const uint8_t* image, int 
     });
 }
 
+// ---- frame ingest ring ----
+BoxMOTHipIngest* boxmot_hip_ingest_create(int n_slots, int n_streams, int image_rows, int image_cols) {
+    BoxMOTHipIngest* h = nullptr;
+    const int ok = guard([&]() {
+        require_device();
+        if (n_slots < 2 || n_streams < 1 || image_rows < 1 || image_cols < 1)
+            throw std::runtime_error("boxmot_hip: ingest ring needs >= 2 slots, >= 1 stream and positive frame dimensions");
+        h = new BoxMOTHipIngest();
+        h->n_slots = n_slots; h->n_streams = n_streams; h->rows = image_rows; h->cols = image_cols;
+        h->frame_bytes = (size_t)image_rows * image_cols * 3;
+        BM_HIP(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        const size_t slot_bytes = h->frame_bytes * n_streams;
+        for (int k = 0; k < n_slots; ++k) {
+            void *hp = nullptr, *dp = nullptr, *tp = nullptr;
+            BM_HIP(hipHostMalloc(&hp, slot_bytes, hipHostMallocDefault));
+            h->h_slot.push_back(static_cast<uint8_t*>(hp));
+            BM_HIP(hipMalloc(&dp, slot_bytes));
+            h->d_slot.push_back(static_cast<uint8_t*>(dp));
+            BM_HIP(hipMalloc(&tp, n_streams * sizeof(uint8_t*)));
+            h->d_ptrs.push_back(static_cast<const uint8_t**>(tp));
+            std::vector<const uint8_t*> table(n_streams);
+            for (int s = 0; s < n_streams; ++s) table[s] = h->d_slot[k] + (size_t)s * h->frame_bytes;
+            BM_HIP(hipMemcpy(tp, table.data(), n_streams * sizeof(uint8_t*), hipMemcpyHostToDevice));
+            hipEvent_t a, b;
+            BM_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+            BM_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+            h->uploaded.push_back(a); h->consumed.push_back(b);
+        }
+        h->has_consumer.assign(n_slots, 0);
+    });
+    if (!ok) { delete h; return nullptr; }
+    return h;
+}
+
+void boxmot_hip_ingest_destroy(BoxMOTHipIngest* handle) { delete handle; }
+
+static void ingest_slot(BoxMOTHipIngest* h, int slot) {
+    if (!h) throw std::runtime_error("boxmot_hip: null ingest handle");
+    if (slot < 0 || slot >= h->n_slots) throw std::runtime_error("boxmot_hip: ingest slot out of range");
+}
+
+uint8_t* boxmot_hip_ingest_host_ptr(BoxMOTHipIngest* handle, int slot, int stream) {
+    uint8_t* p = nullptr;
+    guard([&]() {
+        ingest_slot(handle, slot);
+        if (stream < 0 || stream >= handle->n_streams) throw std::runtime_error("boxmot_hip: stream index out of range");
+        p = handle->h_slot[slot] + (size_t)stream * handle->frame_bytes;
+    });
+    return p;
+}
+
+const uint8_t* const* boxmot_hip_ingest_device_frames(BoxMOTHipIngest* handle, int slot) {
+    const uint8_t* const* p = nullptr;
+    guard([&]() { ingest_slot(handle, slot); p = handle->d_ptrs[slot]; });
+    return p;
+}
+
+int boxmot_hip_ingest_submit(BoxMOTHipIngest* handle, int slot, int n_streams) {
+    return guard([&]() {
+        ingest_slot(handle, slot);
+        if (n_streams < 1 || n_streams > handle->n_streams) throw std::runtime_error("boxmot_hip: stream count out of range");
+        // the previous consumer of this slot must be done with the device frames before they are overwritten
+        if (handle->has_consumer[slot]) BM_HIP(hipStreamWaitEvent(handle->copy_stream, handle->consumed[slot], 0));
+        BM_HIP(hipMemcpyAsync(handle->d_slot[slot], handle->h_slot[slot], handle->frame_bytes * n_streams, hipMemcpyHostToDevice,
+                              handle->copy_stream));
+        BM_HIP(hipEventRecord(handle->uploaded[slot], handle->copy_stream));
+    });
+}
+
+int boxmot_hip_ingest_wait(BoxMOTHipIngest* handle, int slot, void* consumer_stream) {
+    return guard([&]() {
+        ingest_slot(handle, slot);
+        BM_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(consumer_stream), handle->uploaded[slot], 0));
+    });
+}
+
+int boxmot_hip_ingest_release(BoxMOTHipIngest* handle, int slot, void* consumer_stream) {
+    return guard([&]() {
+        ingest_slot(handle, slot);
+        BM_HIP(hipEventRecord(handle->consumed[slot], static_cast<hipStream_t>(consumer_stream)));
+        handle->has_consumer[slot] = 1;
+    });
+}
+
+int boxmot_hip_ingest_host_done(BoxMOTHipIngest* handle, int slot) {
+    return guard([&]() {
+        ingest_slot(handle, slot);
+        BM_HIP(hipEventSynchronize(handle->uploaded[slot]));       // the host buffer of the slot may be refilled
+    });
+}
+
 // ---- DeepOCSORT ----
 void boxmot_hip_deepocsort_default_config(BoxMOTHipDeepOcSortConfig* c) {
     if (!c) return;
@@ -1308,6 +1441,8 @@ int boxmot_hip_deepocsort_reid_kernel_ms(BoxMOTHipDeepOcSort* handle, double* ou
         if (handle->reid) handle->reid->drain_kernel_timing(*out_ms, *out_launches);
     });
 }
+
+void* boxmot_hip_deepocsort_stream(BoxMOTHipDeepOcSort* handle) { return handle ? (void*)handle->stream : nullptr; }
 
 int boxmot_hip_deepocsort_synchronize(BoxMOTHipDeepOcSort* handle) {
     return guard([&]() {
@@ -1472,6 +1607,8 @@ int boxmot_hip_strongsort_track_count(BoxMOTHipStrongSort* handle, int stream, i
         BM_HIP(hipMemcpy(out_tracks, handle->args.st.n_tracks + stream, 4, hipMemcpyDeviceToHost));
     });
 }
+
+void* boxmot_hip_strongsort_stream(BoxMOTHipStrongSort* handle) { return handle ? (void*)handle->stream : nullptr; }
 
 int boxmot_hip_strongsort_synchronize(BoxMOTHipStrongSort* handle) {
     return guard([&]() {

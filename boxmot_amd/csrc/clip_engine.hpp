@@ -62,6 +62,7 @@ public:
         h16_ = alloc<_Float16>(R * D, owned);
         qkv16_ = alloc<_Float16>(R * 3 * D, owned);
         mlp16_ = alloc<_Float16>(R * 4 * D, owned);
+        set_gemm_lds<0>(); set_gemm_lds<1>(); set_gemm_lds<2>(); set_gemm_lds<3>();
         check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_clip_attention), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   clip_attn_lds_bytes(tokens)), "attention LDS");
     }
@@ -107,10 +108,19 @@ private:
         return static_cast<T*>(p);
     }
     template <int EPI>
+    static void set_gemm_lds() {
+        check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_glds<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  GEMM2_LDS_BYTES), "GEMM LDS");
+    }
+    template <int EPI>
     void gemm(const _Float16* X, const _Float16* W, const float* bias, void* C, long M, int N, int K, hipStream_t st) {
         if (N % GEMM_BN != 0 || K % GEMM_BK != 0) throw std::runtime_error("CLIP-ReID: GEMM shape not tileable");
-        hipLaunchKernelGGL((k_gemm_f16<EPI>), dim3((unsigned)((M + GEMM_BM - 1) / GEMM_BM), (unsigned)(N / GEMM_BN)), dim3(256), 0, st,
-                           X, W, bias, C, static_cast<const _Float16*>(nullptr), (int)M, N, K, 0);
+        const dim3 grid((unsigned)((M + GEMM_BM - 1) / GEMM_BM), (unsigned)(N / GEMM_BN));
+        if (K % GEMM2_BK == 0)
+            hipLaunchKernelGGL((k_gemm_f16_glds<EPI>), grid, dim3(256), GEMM2_LDS_BYTES, st, X, W, bias, C,
+                               static_cast<const _Float16*>(nullptr), (int)M, N, K, 0);
+        else
+            hipLaunchKernelGGL((k_gemm_f16<EPI>), grid, dim3(256), 0, st, X, W, bias, C, static_cast<const _Float16*>(nullptr), (int)M, N, K, 0);
     }
     void layernorm(const float* g, const float* b, long R, hipStream_t st) {
         hipLaunchKernelGGL(k_clip_layernorm_f16, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, x_, g, b, h16_, R, width);

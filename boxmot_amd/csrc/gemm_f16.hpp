@@ -138,4 +138,120 @@ __global__ void __launch_bounds__(256) k_gemm_f16(const _Float16* __restrict__ X
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same product for the large shapes (N % 128 == 0, K % 64 == 0): 128 x 128 x 64 tiles whose operands go HBM -> LDS by
+// global_load_lds (no staging registers, no ds_write pass), two LDS buffers, ONE barrier per k-tile: the copies of tile t + 1
+// are issued right after the barrier that publishes tile t and fly while tile t multiplies (32 MFMAs per wave per barrier).
+// LDS image: rows of 64 halves = 8 chunks of 16 bytes, chunk c of row r stored at slot c ^ (r & 7) -- the copy's destination is
+// lane-linear, so the swizzle is applied to the per-lane SOURCE address; a 16-byte fragment read of 8 consecutive rows then
+// covers all 32 banks.  Rows beyond M re-read row M - 1 (their results are never stored).
+// ---------------------------------------------------------------------------
+constexpr int GEMM2_BK = 64;
+constexpr int GEMM2_LDS_BYTES = 2 * 2 * 128 * GEMM2_BK * 2;      // 2 buffers x (W tile + X tile) = 64 KiB
+
+template <int EPI>
+__global__ void __launch_bounds__(256) k_gemm_f16_glds(const _Float16* __restrict__ X, const _Float16* __restrict__ Wt,
+                                                       const float* __restrict__ bias, void* __restrict__ Cout,
+                                                       const _Float16* __restrict__ res, int M, int N, int K, int relu) {
+    BM_DYNAMIC_LDS_T(unsigned char, lds_raw);
+    _Float16* lds = reinterpret_cast<_Float16*>(lds_raw);
+    constexpr int TILE = 128 * GEMM2_BK;                         // halves per operand tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = BM_UNIFORM_I32(tid >> 6), g = lane >> 4, l16 = lane & 15;
+    const int wn = wave >> 1, wm = wave & 1;
+    const long m0 = (long)blockIdx.x * GEMM_BM;
+    const int n0 = blockIdx.y * GEMM_BN;
+    cf4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = cf4{0.f, 0.f, 0.f, 0.f};
+    // copy i (0..3) of this wave moves LDS chunks p = (4 wave + i) * 64 + lane of an operand tile: row p >> 3, slot p & 7
+    const _Float16 *gw[4], *gx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = (4 * wave + i) * 64 + lane, r = p >> 3, c = (p & 7) ^ (r & 7);
+        long m = m0 + r;
+        if (m >= M) m = M - 1;
+        gw[i] = Wt + (long)(n0 + r) * K + 8 * c;
+        gx[i] = X + m * K + 8 * c;
+    }
+    auto issue = [&](int k0, int buf) {
+        _Float16* dW = lds + buf * 2 * TILE;
+        _Float16* dX = dW + TILE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            BM_GLDS16(gw[i] + k0, dW + (4 * wave + i) * 512, lane);
+            BM_GLDS16(gx[i] + k0, dX + (4 * wave + i) * 512, lane);
+        }
+    };
+    issue(0, 0);
+    const int nk = K / GEMM2_BK;
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();                    // tile kt has landed (the barrier drains the copies) and buffer (kt + 1) & 1 is free
+        if (kt + 1 < nk) issue((kt + 1) * GEMM2_BK, (kt + 1) & 1);
+        const _Float16* sW = lds + (kt & 1) * 2 * TILE;
+        const _Float16* sX = sW + TILE;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            ch8 a[4], b[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int ra = wn * 64 + t * 16 + l16, rb = wm * 64 + t * 16 + l16;
+                a[t] = *reinterpret_cast<const ch8*>(sW + ra * GEMM2_BK + 8 * ((4 * s + g) ^ (ra & 7)));
+                b[t] = *reinterpret_cast<const ch8*>(sX + rb * GEMM2_BK + 8 * ((4 * s + g) ^ (rb & 7)));
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[p][t] = BM_MFMA_F16_K32(a[p], b[t], acc[p][t]);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int n = n0 + wn * 64 + p * 16 + 4 * g;
+        cf4 bv = cf4{0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[r] = bias[n + r];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const long m = m0 + wm * 64 + t * 16 + l16;
+            if (m >= M) continue;
+            cf4 v = acc[p][t];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += bv[r];
+            if constexpr (EPI == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + BM_EXPF(-1.702f * v[r]));
+            }
+            if constexpr (EPI == 4) {
+                if (res) {
+                    const ch4 rv = *reinterpret_cast<const ch4*>(res + m * N + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+                }
+                if (relu) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+                }
+            }
+            if constexpr (EPI == 0 || EPI == 1 || EPI == 4) {
+                ch4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (_Float16)v[r];
+                *reinterpret_cast<ch4*>(static_cast<_Float16*>(Cout) + m * N + n) = o;
+            } else if constexpr (EPI == 2) {
+                float* c = static_cast<float*>(Cout) + m * N + n;
+                cf4 old = *reinterpret_cast<const cf4*>(c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) old[r] += v[r];
+                *reinterpret_cast<cf4*>(c) = old;
+            } else {
+                *reinterpret_cast<cf4*>(static_cast<float*>(Cout) + m * N + n) = v;
+            }
+        }
+    }
+}
+
 }  // namespace bm

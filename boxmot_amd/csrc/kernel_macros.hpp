@@ -40,6 +40,14 @@
 // order, so only the compiler has to be kept from reordering them (no workgroup barrier)
 #define BM_WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 #endif
+#ifndef BM_GLDS16
+// asynchronous 16-byte global -> LDS copy (global_load_lds_dwordx4): every lane names its own global source, the LDS
+// destination is the wave-uniform `lds_wave_base` + 16 * lane.  Completion is tracked by vmcnt (a following __syncthreads()
+// drains it).
+#define BM_GLDS16(gptr, lds_wave_base, lane) \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), \
+                                     (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0)
+#endif
 #ifndef BM_RELU_F32
 // max(v, 0) as one integer max on the bit pattern (negative floats are negative ints); a float max costs a second,
 // canonicalising v_max under IEEE mode

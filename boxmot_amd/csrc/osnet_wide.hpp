@@ -26,15 +26,16 @@ public:
     WideOsnet(const float* h_w, const OsnetLayout& L, const float* d_w32, int max_crops, std::vector<void*>& owned)
         : L_(L), d_w_(d_w32), max_crops_(max_crops) {
         if (!supports(L)) throw std::runtime_error("wide OSNet kernels: channel widths must be multiples of 32 (middle widths <= 128)");
-        pk_ = wide_pack_w16(h_w, L, STEM_K);
+        pk_ = wide_pack_w16(h_w, L);
         d_w16_ = alloc<_Float16>(pk_.data.size(), owned);
         check(hipMemcpy(d_w16_, pk_.data.data(), pk_.data.size() * 2, hipMemcpyHostToDevice), "upload fp16 weights");
         d_stem16_ = d_w16_ + pk_.stem;
         pk_.data.clear(); pk_.data.shrink_to_fit();
         const int c0 = L.c[0];
         const size_t n = (size_t)max_crops;
-        crops16_ = alloc<_Float16>(n * REID_IN_H * REID_IN_W * 3, owned);
-        im2col_ = alloc<_Float16>(n * 8192 * STEM_K, owned);
+        const size_t crop_halves = n * WSTEM_ROWS * WSTEM_COLS * 4;
+        crops16_ = alloc<_Float16>(crop_halves, owned);
+        check(hipMemset(crops16_, 0, crop_halves * 2), "clear crop buffer");       // the 3-pixel border and the X channel stay zero
         stem_out_ = alloc<_Float16>(n * 8192 * c0, owned);
         size_t blk = 0, mid = 0;
         int P = 2048;
@@ -48,19 +49,21 @@ public:
         for (auto& m : mid_) m = alloc<_Float16>(mid, owned);
         gap_part_ = alloc<float>(4 * n * (64 / WIDE_BAND) * 128, owned);
         set_light_lds<32>(); set_light_lds<64>(); set_light_lds<96>(); set_light_lds<128>();
+        check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_glds<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  GEMM2_LDS_BYTES), "GEMM LDS");
     }
 
     _Float16* crops_buffer() { return crops16_; }
     int max_crops() const { return max_crops_; }
 
-    // crops16_: normalised fp16 NHWC crops of n <= max_crops boxes (k_crop_resize<_Float16>); out rows of L.feat floats
+    // crops16_: normalised fp16 RGBX crops with a zero border, [n][262][136][4] (k_crop_resize_rgbx); out rows of L.feat floats
     void forward(int n, float* d_out, const int* d_out_rows, hipStream_t st) {
         if (n > max_crops_) throw std::runtime_error("wide OSNet: crop batch exceeds the engine capacity");
         if (n == 0) return;
         const int c0 = L_.c[0];
-        const long stem_rows = (long)n * 8192;
-        hipLaunchKernelGGL(k_stem_im2col, dim3((unsigned)((stem_rows * 8 + 255) / 256)), dim3(256), 0, st, crops16_, im2col_, stem_rows);
-        gemm(im2col_, d_stem16_, d_w_ + L_.stem_b, stem_out_, nullptr, stem_rows, c0, STEM_K, 1, st);
+        if (c0 == 64) hipLaunchKernelGGL(k_wide_stem<64>, dim3(128 / WSTEM_BAND, n), dim3(256), 0, st, crops16_, d_stem16_, d_w_ + L_.stem_b, stem_out_);
+        else if (c0 == 32) hipLaunchKernelGGL(k_wide_stem<32>, dim3(128 / WSTEM_BAND, n), dim3(256), 0, st, crops16_, d_stem16_, d_w_ + L_.stem_b, stem_out_);
+        else throw std::runtime_error("wide OSNet: stem width must be 32 or 64");
         long t8 = (long)n * 2048 * (c0 / 8);
         hipLaunchKernelGGL(k_maxpool3x3s2_h8, dim3((unsigned)((t8 + 255) / 256)), dim3(256), 0, st, stem_out_, act_a_, 128, 64, c0, t8);
         _Float16 *cur = act_a_, *other = act_b_;
@@ -105,7 +108,9 @@ private:
               int relu, hipStream_t st) {
         if (K % GEMM_BK != 0 || N % 32 != 0) throw std::runtime_error("wide OSNet: GEMM shape not tileable");
         const unsigned gx = (unsigned)((M + GEMM_BM - 1) / GEMM_BM);
-        if (N % 128 == 0) hipLaunchKernelGGL((k_gemm_f16<4, 128>), dim3(gx, N / 128), dim3(256), 0, st, X, W, bias, out, res, (int)M, N, K, relu);
+        if (N % 128 == 0 && K % GEMM2_BK == 0)
+            hipLaunchKernelGGL((k_gemm_f16_glds<4>), dim3(gx, N / 128), dim3(256), GEMM2_LDS_BYTES, st, X, W, bias, static_cast<void*>(out), res, (int)M, N, K, relu);
+        else if (N % 128 == 0) hipLaunchKernelGGL((k_gemm_f16<4, 128>), dim3(gx, N / 128), dim3(256), 0, st, X, W, bias, out, res, (int)M, N, K, relu);
         else if (N % 96 == 0) hipLaunchKernelGGL((k_gemm_f16<4, 96>), dim3(gx, N / 96), dim3(256), 0, st, X, W, bias, out, res, (int)M, N, K, relu);
         else if (N % 64 == 0) hipLaunchKernelGGL((k_gemm_f16<4, 64>), dim3(gx, N / 64), dim3(256), 0, st, X, W, bias, out, res, (int)M, N, K, relu);
         else hipLaunchKernelGGL((k_gemm_f16<4, 32>), dim3(gx, N / 32), dim3(256), 0, st, X, W, bias, out, res, (int)M, N, K, relu);
@@ -168,7 +173,7 @@ private:
     const float* d_w_;                       // the engine's fp32 blob on the device (biases, depthwise taps, gate and FC weights)
     int max_crops_;
     _Float16 *d_w16_ = nullptr, *d_stem16_ = nullptr;
-    _Float16 *crops16_ = nullptr, *im2col_ = nullptr, *stem_out_ = nullptr, *act_a_ = nullptr, *act_b_ = nullptr, *idn_ = nullptr;
+    _Float16 *crops16_ = nullptr, *stem_out_ = nullptr, *act_a_ = nullptr, *act_b_ = nullptr, *idn_ = nullptr;
     _Float16* mid_[8] = {};
     float* gap_part_ = nullptr;
 };

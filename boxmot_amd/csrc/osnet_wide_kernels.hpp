@@ -7,8 +7,9 @@
 // [pixels][cin] x [cin][cout] GEMM over ALL crops of the batch, and the layer-per-launch shape below keeps the matrix pipe
 // fed without per-crop workgroups:
 //   * activations: fp16 NHWC [crop][pixel][channel] in HBM, fp32 accumulation everywhere, fp32 folded-BN biases
-//   * every 1x1 convolution (conv1, conv3 + shortcut + ReLU, downsample, transitions, conv5, the im2col'd 7x7 stem) is one
-//     launch of k_gemm_f16 (gemm_f16.hpp) with bias / residual / ReLU in its epilogue
+//   * every 1x1 convolution (conv1, conv3 + shortcut + ReLU, downsample, transitions, conv5) is one
+//     launch of k_gemm_f16 / k_gemm_f16_glds (gemm_f16.hpp) with bias / residual / ReLU in its epilogue; the 7x7 stem is an
+//     implicit GEMM over an LDS-staged band of the RGBX crop (k_wide_stem)
 //   * LightConv3x3 = 1x1 (linear) -> depthwise 3x3 + BN + ReLU is ONE kernel (k_light_fused): a workgroup owns a band of 8
 //     image rows of one crop, runs the 1x1 of the band + a one-row halo on the matrix pipe straight from global memory
 //     (weights are <= 32 KB: L1 / L2 resident) into an LDS tile, and the depthwise 3x3 reads that tile with a sliding
@@ -26,11 +27,10 @@
 namespace bm {
 
 constexpr int WIDE_BAND = 8;                 // image rows per k_light_fused workgroup
-constexpr int STEM_K = 160;                  // 7 x 7 x 3 = 147 taps, padded to a multiple of the MFMA k-step
 
 // widths this kernel family takes: GEMM k-steps of 32, 16-channel MFMA tiles, k_light_fused's thread mapping
 inline bool wide_osnet_supports(const OsnetLayout& L) {
-    if (L.c[0] % 32 != 0 || L.feat > 512 || L.c[3] > 512) return false;
+    if ((L.c[0] != 32 && L.c[0] != 64) || L.feat > 512 || L.c[3] > 512) return false;
     for (int b = 0; b < 6; ++b) {
         const BlockW& B = L.block[b];
         if (B.cin % 32 || B.cout % 32 || B.mid % 32 || B.mid > 128) return false;
@@ -40,32 +40,56 @@ inline bool wide_osnet_supports(const OsnetLayout& L) {
 }
 
 // ---------------------------------------------------------------------------
-// Stem patch gather: normalised crops fp16 NHWC [n][256][128][3] -> rows [n * 128 * 64][160], k = (ky, kx, c) + zero padding;
-// thread = (output pixel, ky): 7 pixels x 3 channels are contiguous in the crop row.  conv 7x7, stride 2, pad 3 (osnet.py:294).
+// Stem: conv 7x7, stride 2, pad 3 (3 -> C0) + folded BN + ReLU (osnet.py:294) as an implicit GEMM on the matrix pipe.
+//   crops  fp16 RGBX with a 3-pixel zero border, [n][262][136][4] (k_crop_resize_rgbx): 8 input pixels x RGBX = 32 halves = one
+//          MFMA k-step per kernel row, and the B fragment of conv pixel cx, lane group g is the 16 bytes at pixel 2 cx + 2 g
+//   wts    fp16 A fragments [ky][channel tile][lane][8]: lane (co = lane & 15, g), k-slot j -> tap kx = 2 g + (j >> 2), channel
+//          j & 3 (zero for kx = 7 and the X channel), packed by wide_pack_w16
+//   out    fp16 NHWC [n][128 * 64][C0]
+// grid (16 bands of 8 conv rows, crops), 256 threads.  The 21 input rows of a band are staged once into LDS (16-byte copies);
+// wave w owns channel tile w % (C0 / 16) and every (4 * 16 / C0)-th conv row of the band, with its seven A fragments in
+// registers: 7 x (ds_read_b128 + MFMA) per 16 conv pixels.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_stem_im2col(const _Float16* __restrict__ crops, _Float16* __restrict__ out, long n_rows) {
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long row = e >> 3;
-    const int part = (int)(e & 7);
-    if (row >= n_rows) return;
-    _Float16* o = out + row * STEM_K;
-    if (part == 7) {
-        for (int j = 147; j < STEM_K; ++j) o[j] = (_Float16)0.f;
-        return;
-    }
-    const int ox = (int)(row % 64), oy = (int)((row / 64) % 128);
-    const long n = row / (64 * 128);
-    const int iy = oy * 2 - 3 + part, ix0 = ox * 2 - 3;
-    o += part * 21;
-    if (iy < 0 || iy >= REID_IN_H) {
-        for (int j = 0; j < 21; ++j) o[j] = (_Float16)0.f;
-        return;
-    }
-    const _Float16* src = crops + ((n * REID_IN_H + iy) * REID_IN_W) * 3;
-    for (int kx = 0; kx < 7; ++kx) {
-        const int ix = ix0 + kx;
-        const bool in = ix >= 0 && ix < REID_IN_W;
-        for (int c = 0; c < 3; ++c) o[kx * 3 + c] = in ? src[ix * 3 + c] : (_Float16)0.f;
+constexpr int WSTEM_ROWS = 262, WSTEM_COLS = 136, WSTEM_BAND = 8;
+constexpr int WSTEM_LDS_BYTES = (2 * WSTEM_BAND + 5) * WSTEM_COLS * 8;
+
+template <int C0>
+__global__ void __launch_bounds__(256) k_wide_stem(const _Float16* __restrict__ crops, const _Float16* __restrict__ wts,
+                                                   const float* __restrict__ bias, _Float16* __restrict__ out) {
+    static_assert(C0 == 32 || C0 == 64, "stem width");
+    constexpr int NCT = C0 / 16, NRG = 4 / NCT, IN_ROWS = 2 * WSTEM_BAND + 5;
+    __shared__ __attribute__((aligned(16))) _Float16 sIn[IN_ROWS * WSTEM_COLS * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l16 = lane & 15;
+    const int band = blockIdx.x;
+    const long crop = blockIdx.y;
+    const int cy0 = band * WSTEM_BAND;
+    const _Float16* src = crops + (crop * WSTEM_ROWS + 2 * cy0) * (long)(WSTEM_COLS * 4);
+    for (int e = tid; e < IN_ROWS * WSTEM_COLS / 2; e += 256)          // 16-byte chunks = 2 pixels
+        *reinterpret_cast<cu4*>(sIn + e * 8) = *reinterpret_cast<const cu4*>(src + e * 8);
+    const int ct = wave % NCT, rg = wave / NCT;
+    ch8 a[7];
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky) a[ky] = *reinterpret_cast<const ch8*>(wts + ((long)(ky * NCT + ct) * 64 + lane) * 8);
+    float bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = bias[16 * ct + 4 * g + r];
+    __syncthreads();
+    for (int lr = rg; lr < WSTEM_BAND; lr += NRG) {
+        _Float16* orow = out + ((crop * 128 + cy0 + lr) * 64) * (long)C0 + 16 * ct + 4 * g;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int cx = 16 * t + l16;
+            cf4 acc = cf4{bv[0], bv[1], bv[2], bv[3]};
+#pragma unroll
+            for (int ky = 0; ky < 7; ++ky) {
+                const ch8 b = *reinterpret_cast<const ch8*>(sIn + ((2 * lr + ky) * WSTEM_COLS + 2 * cx + 2 * g) * 4);
+                acc = BM_MFMA_F16_K32(a[ky], b, acc);
+            }
+            ch4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (_Float16)(acc[r] > 0.f ? acc[r] : 0.f);
+            *reinterpret_cast<ch4*>(orow + (long)cx * C0) = o;
+        }
     }
 }
 

@@ -93,7 +93,7 @@ public:
             L_ = make_osnet_layout(ch, hdr[5]);
             if (hdr[6] != (int32_t)L_.total || n_floats != REID_HEADER_INTS + L_.total)
                 throw std::runtime_error("ReID blob: size does not match the declared architecture");
-            if (ch[0] != 16 && ch[0] != 64) throw std::runtime_error("ReID: unsupported stem width");
+            if (ch[0] != 16 && ch[0] != 32 && ch[0] != 48 && ch[0] != 64) throw std::runtime_error("ReID: unsupported stem width");
             d_w_ = dev_alloc<float>((size_t)L_.total, owned_);
             BM_HIP(hipMemcpy(d_w_, blob + REID_HEADER_INTS, (size_t)L_.total * 4, hipMemcpyHostToDevice));
             h_w_.assign(blob + REID_HEADER_INTS, blob + REID_HEADER_INTS + L_.total);
@@ -139,8 +139,9 @@ public:
         if (n == 0) return;
         const int rows_per_block = 16;
         if (wide)
-            hipLaunchKernelGGL(k_crop_resize<_Float16>, dim3(n, REID_IN_H / rows_per_block), dim3(REID_IN_W), 0, st,
-                               d_frames, d_crop_stream, d_boxes, box_stride, W, H, d_lut_, wide_->crops_buffer(), rows_per_block, pad_);
+            hipLaunchKernelGGL(k_crop_resize_rgbx, dim3(n, REID_IN_H / rows_per_block), dim3(REID_IN_W), 0, st,
+                               d_frames, d_crop_stream, d_boxes, box_stride, W, H, d_lut_, wide_->crops_buffer(), rows_per_block,
+                               static_cast<const int*>(nullptr), pad_);
         else if (fused)
             hipLaunchKernelGGL(k_crop_resize_rgbx, dim3(n, REID_IN_H / rows_per_block), dim3(REID_IN_W), 0, st,
                                d_frames, d_crop_stream, d_boxes, box_stride, W, H, d_lut_, crops_h_, rows_per_block, d_count_, pad_);
@@ -294,6 +295,12 @@ private:
         const long stem_pix = (long)n * 128 * 64;
         if (c0 == 16)
             hipLaunchKernelGGL((k_stem_conv<float, 16>), dim3((unsigned)((stem_pix + bs - 1) / bs)), dim3(bs), 0, st,
+                               crops_, d_w_ + L_.stem_w, d_w_ + L_.stem_b, big_a_, stem_pix);
+        else if (c0 == 32)
+            hipLaunchKernelGGL((k_stem_conv<float, 32>), dim3((unsigned)((stem_pix + 127) / 128)), dim3(128), 0, st,
+                               crops_, d_w_ + L_.stem_w, d_w_ + L_.stem_b, big_a_, stem_pix);
+        else if (c0 == 48)
+            hipLaunchKernelGGL((k_stem_conv<float, 48>), dim3((unsigned)((stem_pix + 63) / 64)), dim3(64), 0, st,
                                crops_, d_w_ + L_.stem_w, d_w_ + L_.stem_b, big_a_, stem_pix);
         else
             hipLaunchKernelGGL((k_stem_conv<float, 64>), dim3((unsigned)((stem_pix + 63) / 64)), dim3(64), 0, st,

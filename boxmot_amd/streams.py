@@ -57,7 +57,10 @@ class MultiStreamBotSort:
             _lib.check(self._lib.boxmot_hip_botsort_set_reid_blob(self._handle, self._blob.ctypes.data, int(self._blob.size)))
 
     # ---- host buffers: list of (n_s, 6) dets, optional list of embs / frames ----
-    def update_batch(self, dets_list, imgs=None, embs_list=None):
+    def update_batch(self, dets_list, imgs=None, embs_list=None, ring=None, slot: int = 0):
+        """One frame of every stream.  ``imgs``: host frames (uploaded by the call), or ``ring`` + ``slot``: frames already
+        submitted to a ``boxmot_amd.ingest.FrameRing`` slot -- the call makes the device wait for that upload, tracks, and
+        releases the slot; the host never waits for a frame copy."""
         S = len(dets_list)
         dets = [np.ascontiguousarray(d, dtype=np.float32).reshape(-1, 6) for d in dets_list]
         rows = np.array([len(d) for d in dets], dtype=np.int32)
@@ -79,6 +82,15 @@ class MultiStreamBotSort:
         outs = [np.empty((cap, 9), dtype=np.float32) for _ in range(S)]
         out_ptrs = (ctypes.c_void_p * S)(*[o.ctypes.data for o in outs])
         out_rows = np.zeros(S, dtype=np.int32)
+        if ring is not None:
+            stream = self._lib.boxmot_hip_botsort_stream(self._handle)
+            ring.wait(slot, stream)
+            ok = self._lib.boxmot_hip_botsort_update_batch_frames(
+                self._handle, S, det_ptrs, rows.ctypes.data, emb_ptrs, self.emb_dim if embs is not None else 0,
+                ctypes.c_void_p(ring.device_frames(slot)), ring.rows, ring.cols, out_ptrs, cap, out_rows.ctypes.data)
+            ring.release(slot, stream)
+            _lib.check(ok)
+            return [TrackResults(o[:n, :8].copy()) for o, n in zip(outs, out_rows)]
         _lib.check(self._lib.boxmot_hip_botsort_update_batch(
             self._handle, S, det_ptrs, rows.ctypes.data, emb_ptrs, self.emb_dim if embs is not None else 0,
             img_ptrs, ir, ic, 3, out_ptrs, cap, out_rows.ctypes.data))

@@ -121,6 +121,14 @@ int boxmot_hip_botsort_update_batch(
     const float* const* embs, int emb_cols,
     const uint8_t* const* images, int image_rows, int image_cols, int image_channels,
     float* const* out_tracks, int out_capacity_rows, int* out_rows);
+/* the same with the frames already on the device (one pointer per stream, e.g. boxmot_hip_ingest_device_frames(ring, slot)):
+ * detections in, rows out over PCIe, no frame copy in this call */
+int boxmot_hip_botsort_update_batch_frames(
+    BoxMOTHipBotSort* handle, int n_streams,
+    const float* const* dets, const int* det_rows,
+    const float* const* embs, int emb_cols,
+    const uint8_t* const* d_frames, int image_rows, int image_cols,
+    float* const* out_tracks, int out_capacity_rows, int* out_rows);
 
 /* Device-resident step for all streams (asynchronous on the handle's stream):
  *   d_dets   [n_streams][max_dets][6] fp32, d_det_rows [n_streams] int32,
@@ -195,6 +203,27 @@ int boxmot_hip_reid_last_time_ms(BoxMOTHipReID* handle, double* out_preprocess_m
 const char* boxmot_hip_last_error(void);
 /* number of visible HIP devices (0 when none / runtime unusable) */
 int boxmot_hip_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Frame ingest ring (no counterpart in the reference: its trackers receive a numpy frame per call, basetracker.py:120-147, and
+ * its native binding copies it, native/trackers/botsort.py:200-230).  n_slots x n_streams page-locked host frames with device
+ * twins: decode frame t + 1 into slot (t + 1) % n_slots while frame t is tracked.
+ *   host_ptr(slot, stream)   where the caller writes the rows x cols x 3 uint8 BGR frame of `stream`
+ *   submit(slot, n)          asynchronous H2D copy of the first n streams' frames on the ring's copy stream
+ *   wait(slot, hip_stream)   makes that stream wait for the slot's upload (no host wait) -- pass the tracker handle's stream
+ *   device_frames(slot)      device table of per-stream frame pointers = the d_frames argument of *_step_device[_frames]
+ *   release(slot, stream)    marks the slot consumed once the work queued on `stream` so far is done; the next submit waits for it
+ *   host_done(slot)          blocks until the slot's upload has left the host buffer (only needed before refilling it)
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct BoxMOTHipIngest BoxMOTHipIngest;
+BoxMOTHipIngest* boxmot_hip_ingest_create(int n_slots, int n_streams, int image_rows, int image_cols);
+void boxmot_hip_ingest_destroy(BoxMOTHipIngest* handle);
+uint8_t* boxmot_hip_ingest_host_ptr(BoxMOTHipIngest* handle, int slot, int stream);
+const uint8_t* const* boxmot_hip_ingest_device_frames(BoxMOTHipIngest* handle, int slot);
+int boxmot_hip_ingest_submit(BoxMOTHipIngest* handle, int slot, int n_streams);
+int boxmot_hip_ingest_wait(BoxMOTHipIngest* handle, int slot, void* consumer_hip_stream);
+int boxmot_hip_ingest_release(BoxMOTHipIngest* handle, int slot, void* consumer_hip_stream);
+int boxmot_hip_ingest_host_done(BoxMOTHipIngest* handle, int slot);
 
 /* ------------------------------------------------------------------------------------------------
  * DeepOCSORT (boxmot/trackers/bbox/deepocsort/deepocsort.py:235-492).  The reference has no native backend
@@ -278,6 +307,7 @@ int boxmot_hip_deepocsort_step_device_frames(BoxMOTHipDeepOcSort* handle, const 
 int boxmot_hip_deepocsort_reid_kernel_ms(BoxMOTHipDeepOcSort* handle, double* out_ms, int* out_launches);
 /* 0 = per-layer fp32 kernels, 1 = fp16 MFMA kernels (fused for OSNet-x0.25, layer-per-launch for osnet_x1_0); CLIP-ReID has one family */
 int boxmot_hip_deepocsort_set_reid_mode(BoxMOTHipDeepOcSort* handle, int mode);
+void* boxmot_hip_deepocsort_stream(BoxMOTHipDeepOcSort* handle);
 int boxmot_hip_deepocsort_synchronize(BoxMOTHipDeepOcSort* handle);
 /* parity debugging: live tracks of `stream` in list order -- ints5 (rows,5) = id, age, time_since_update, hit_streak,
  * observed; kf72 (rows,72) = x[8] ++ P[8][8] fp64 (index 7 unused); emb (rows, emb_dim) fp64.  NULL skips an output. */
@@ -339,6 +369,7 @@ int boxmot_hip_strongsort_step_device_frames(BoxMOTHipStrongSort* handle, const 
                                               int* d_out_rows);
 int boxmot_hip_strongsort_reid_kernel_ms(BoxMOTHipStrongSort* handle, double* out_ms, int* out_launches);
 int boxmot_hip_strongsort_set_reid_mode(BoxMOTHipStrongSort* handle, int mode);
+void* boxmot_hip_strongsort_stream(BoxMOTHipStrongSort* handle);
 int boxmot_hip_strongsort_synchronize(BoxMOTHipStrongSort* handle);
 /* len(self.tracker.tracks) of `stream` (tentative + confirmed): the reference asks its camera-motion estimator for a warp only
  * when this is >= 1 (strongsort.py:83-86), and that estimator is stateful -- a caller that owns one needs the same gate. */

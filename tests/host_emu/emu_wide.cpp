@@ -61,15 +61,20 @@ extern "C" int emu_wide_forward(const float* blob, long n_floats, const float* c
     if (n_floats != REID_HEADER_INTS + L.total) return -2;
     if (!wide_osnet_supports(L)) return -3;
     const float* W32 = blob + REID_HEADER_INTS;
-    const WideW16 pk = wide_pack_w16(W32, L, STEM_K);
+    const WideW16 pk = wide_pack_w16(W32, L);
     std::vector<_Float16> w16(pk.data.size());
     std::memcpy(w16.data(), pk.data.data(), pk.data.size() * 2);
     const _Float16* W16 = w16.data();
     const int c0 = ch[0];
     const _Float16* stem16 = W16 + pk.stem;
     const size_t N = (size_t)n;
-    std::vector<_Float16> crops16(N * REID_IN_H * REID_IN_W * 3), im2col(N * 8192 * STEM_K), stem_out(N * 8192 * c0);
-    for (size_t i = 0; i < crops16.size(); ++i) crops16[i] = (_Float16)crops[i];
+    // the stem's input layout: fp16 RGBX with a 3-pixel zero border (what k_crop_resize_rgbx writes on the device)
+    std::vector<_Float16> crops16(N * WSTEM_ROWS * WSTEM_COLS * 4, (_Float16)0.f), stem_out(N * 8192 * c0);
+    for (size_t i = 0; i < N; ++i)
+        for (int y = 0; y < REID_IN_H; ++y)
+            for (int x = 0; x < REID_IN_W; ++x)
+                for (int c = 0; c < 3; ++c)
+                    crops16[((i * WSTEM_ROWS + y + 3) * WSTEM_COLS + x + 3) * 4 + c] = (_Float16)crops[((i * REID_IN_H + y) * REID_IN_W + x) * 3 + c];
     size_t blk = N * 2048 * (size_t)c0, mid = 0;
     { int P = 2048; for (int s = 0; s < 3; ++s, P /= 4) { blk = std::max(blk, N * P * (size_t)ch[s + 1]); mid = std::max(mid, N * P * (size_t)(ch[s + 1] / 4)); } }
     std::vector<_Float16> act_a(blk), act_b(blk), idn(blk);
@@ -78,7 +83,8 @@ extern "C" int emu_wide_forward(const float* blob, long n_floats, const float* c
 
     auto gemm = [&](const _Float16* X, const _Float16* Wt, const float* bias, _Float16* out, const _Float16* res, long M, int Nn, int K, int relu) {
         const long gx = (M + GEMM_BM - 1) / GEMM_BM;
-        if (Nn % 128 == 0) launch(gx, Nn / 128, 256, [=]() { k_gemm_f16<4, 128>(X, Wt, bias, out, res, (int)M, Nn, K, relu); });
+        if (Nn % 128 == 0 && K % GEMM2_BK == 0) launch(gx, Nn / 128, 256, [=]() { k_gemm_f16_glds<4>(X, Wt, bias, out, res, (int)M, Nn, K, relu); });
+        else if (Nn % 128 == 0) launch(gx, Nn / 128, 256, [=]() { k_gemm_f16<4, 128>(X, Wt, bias, out, res, (int)M, Nn, K, relu); });
         else if (Nn % 96 == 0) launch(gx, Nn / 96, 256, [=]() { k_gemm_f16<4, 96>(X, Wt, bias, out, res, (int)M, Nn, K, relu); });
         else if (Nn % 64 == 0) launch(gx, Nn / 64, 256, [=]() { k_gemm_f16<4, 64>(X, Wt, bias, out, res, (int)M, Nn, K, relu); });
         else launch(gx, Nn / 32, 256, [=]() { k_gemm_f16<4, 32>(X, Wt, bias, out, res, (int)M, Nn, K, relu); });
@@ -122,10 +128,9 @@ extern "C" int emu_wide_forward(const float* blob, long n_floats, const float* c
         gemm(x2, W16 + pk.of(B.conv3_w), W32 + B.conv3_b, out, identity, n_pix, B.cout, B.mid, 1);
     };
 
-    const long stem_rows = (long)n * 8192;
-    { const _Float16* c = crops16.data(); _Float16* o = im2col.data();
-      launch((stem_rows * 8 + 255) / 256, 1, 256, [=]() { k_stem_im2col(c, o, stem_rows); }); }
-    gemm(im2col.data(), stem16, W32 + L.stem_b, stem_out.data(), nullptr, stem_rows, c0, STEM_K, 1);
+    { const _Float16* c = crops16.data(); _Float16* o = stem_out.data(); const float* sb = W32 + L.stem_b;
+      if (c0 == 64) launch(128 / WSTEM_BAND, n, 256, [=]() { k_wide_stem<64>(c, stem16, sb, o); });
+      else launch(128 / WSTEM_BAND, n, 256, [=]() { k_wide_stem<32>(c, stem16, sb, o); }); }
     long t8 = (long)n * 2048 * (c0 / 8);
     { const _Float16* i = stem_out.data(); _Float16* o = act_a.data();
       launch((t8 + 255) / 256, 1, 256, [=]() { k_maxpool3x3s2_h8(i, o, 128, 64, c0, t8); }); }

@@ -160,7 +160,9 @@ def test_osnet_x1_0_fp16_mfma_kernels_vs_oracle_and_unsupported_width_is_loud():
     reid.set_mode(0)
     assert np.abs(reid.get_features(boxes, img) - want).max() < 1e-4
     reid.close()
-    half = HipReID(reference_init_state_dict("osnet_x0_5", seed=0), max_crops=4)
+    sd5 = reference_init_state_dict("osnet_x0_5", seed=0)       # 32 / 128 / 192 / 256: middle width 48
+    half = HipReID(sd5, max_crops=4)
+    assert np.abs(half.get_features(boxes[:4], img) - OracleReID(sd5).get_features(boxes[:4], img)).max() < 1e-4     # per-layer fp32 kernels
     with pytest.raises(RuntimeError, match="multiples of 32"):
         half.set_mode(1)
     half.close()
