@@ -109,15 +109,15 @@ private:
     }
     template <int EPI>
     static void set_gemm_lds() {
-        check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_glds<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  GEMM2_LDS_BYTES), "GEMM LDS");
+        check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_glds<EPI, 64>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  gemm_glds_lds_bytes<64>()), "GEMM LDS");
     }
     template <int EPI>
     void gemm(const _Float16* X, const _Float16* W, const float* bias, void* C, long M, int N, int K, hipStream_t st) {
         if (N % GEMM_BN != 0 || K % GEMM_BK != 0) throw std::runtime_error("CLIP-ReID: GEMM shape not tileable");
-        const dim3 grid((unsigned)((M + GEMM_BM - 1) / GEMM_BM), (unsigned)(N / GEMM_BN));
-        if (K % GEMM2_BK == 0)
-            hipLaunchKernelGGL((k_gemm_f16_glds<EPI>), grid, dim3(256), GEMM2_LDS_BYTES, st, X, W, bias, C,
+        const dim3 grid((unsigned)(((M + GEMM_BM - 1) / GEMM_BM) * (N / GEMM_BN)));       // 1-D: the kernels map ids to tiles XCD-aware
+        if (K % 64 == 0)
+            hipLaunchKernelGGL((k_gemm_f16_glds<EPI, 64>), grid, dim3(256), gemm_glds_lds_bytes<64>(), st, X, W, bias, C,
                                static_cast<const _Float16*>(nullptr), (int)M, N, K, 0);
         else
             hipLaunchKernelGGL((k_gemm_f16<EPI>), grid, dim3(256), 0, st, X, W, bias, C, static_cast<const _Float16*>(nullptr), (int)M, N, K, 0);

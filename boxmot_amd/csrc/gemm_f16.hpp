@@ -28,6 +28,18 @@ typedef unsigned int cu4 __attribute__((ext_vector_type(4)));
 
 constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 32, GEMM_LD = 40;       // LDS row = 32 halves + 8 of padding (80 bytes)
 
+// Workgroup -> output tile.  The grid is 1-D (M tiles x N tiles workgroups).  Workgroups are dealt round-robin to the 8 XCDs
+// (each with its own L2), so the linear id is first remapped such that one XCD receives a contiguous range of tile ids
+// (bijective for any count), and inside that range the N tiles of one M tile are neighbours: the activation rows of an M tile
+// are fetched into that XCD's L2 once and reused by all of its N tiles instead of being re-read from HBM N / BN times.
+__device__ inline void gemm_tile_of_block(int m_tiles, int n_tiles, int& mt, int& nt) {
+    const int total = m_tiles * n_tiles, orig = (int)blockIdx.x;
+    const int q = total / 8, r = total % 8, xcd = orig % 8, idx = orig / 8;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    nt = wg % n_tiles;
+    mt = wg / n_tiles;
+}
+
 template <int EPI, int BN = GEMM_BN>
 __global__ void __launch_bounds__(256) k_gemm_f16(const _Float16* __restrict__ X, const _Float16* __restrict__ Wt,
                                                   const float* __restrict__ bias, void* __restrict__ Cout,
@@ -39,8 +51,10 @@ __global__ void __launch_bounds__(256) k_gemm_f16(const _Float16* __restrict__ X
     __shared__ __attribute__((aligned(16))) _Float16 sX[GEMM_BM * GEMM_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l16 = lane & 15;
     const int wn = wave >> 1, wm = wave & 1;                 // this wave: BN/2 output features x 64 rows
-    const long m0 = (long)blockIdx.x * GEMM_BM;
-    const int n0 = blockIdx.y * BN;
+    int mt, nt;
+    gemm_tile_of_block((M + GEMM_BM - 1) / GEMM_BM, N / BN, mt, nt);
+    const long m0 = (long)mt * GEMM_BM;
+    const int n0 = nt * BN;
     cf4 acc[NT][4];                                          // [feature tile][row tile]
 #pragma unroll
     for (int a = 0; a < NT; ++a)
@@ -73,6 +87,19 @@ __global__ void __launch_bounds__(256) k_gemm_f16(const _Float16* __restrict__ X
             *reinterpret_cast<cu4*>(sX + r * GEMM_LD + c) = rx[j];
         }
     };
+    // the shortcut operand of the epilogue does not depend on the product: fetch it now, its latency hides behind the k-loop
+    ch4 rres[NT][4];
+    if constexpr (EPI == 4) {
+        if (res) {
+#pragma unroll
+            for (int p = 0; p < NT; ++p)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const long m = m0 + wm * 64 + t * 16 + l16;
+                    rres[p][t] = m < M ? *reinterpret_cast<const ch4*>(res + m * N + n0 + wn * (BN / 2) + p * 16 + 4 * g) : ch4{0, 0, 0, 0};
+                }
+        }
+    }
     load_tiles(0);
     for (int k0 = 0; k0 < K; k0 += GEMM_BK) {
         __syncthreads();                    // the previous tile's fragment reads are done
@@ -111,9 +138,8 @@ __global__ void __launch_bounds__(256) k_gemm_f16(const _Float16* __restrict__ X
             }
             if constexpr (EPI == 4) {
                 if (res) {
-                    const ch4 rv = *reinterpret_cast<const ch4*>(res + m * N + n);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+                    for (int r = 0; r < 4; ++r) v[r] += (float)rres[p][t][r];
                 }
                 if (relu) {
 #pragma unroll
@@ -139,37 +165,44 @@ __global__ void __launch_bounds__(256) k_gemm_f16(const _Float16* __restrict__ X
 }
 
 // ---------------------------------------------------------------------------
-// The same product for the large shapes (N % 128 == 0, K % 64 == 0): 128 x 128 x 64 tiles whose operands go HBM -> LDS by
-// global_load_lds (no staging registers, no ds_write pass), two LDS buffers, ONE barrier per k-tile: the copies of tile t + 1
-// are issued right after the barrier that publishes tile t and fly while tile t multiplies (32 MFMAs per wave per barrier).
-// LDS image: rows of 64 halves = 8 chunks of 16 bytes, chunk c of row r stored at slot c ^ (r & 7) -- the copy's destination is
-// lane-linear, so the swizzle is applied to the per-lane SOURCE address; a 16-byte fragment read of 8 consecutive rows then
-// covers all 32 banks.  Rows beyond M re-read row M - 1 (their results are never stored).
+// The same product for N % 128 == 0, K % BK == 0: 128 x 128 x BK tiles whose operands go HBM -> LDS by global_load_lds (no
+// staging registers, no ds_write pass), two LDS buffers, ONE barrier per k-tile: the copies of tile t + 1 are issued right after
+// the barrier that publishes tile t and fly while tile t multiplies.  BK = 64 (64 KiB of LDS, 32 MFMAs per wave per barrier) for
+// the compute-bound shapes (CLIP-ReID's K = 768 / 3072), BK = 32 (32 KiB: twice the resident workgroups) for the short-K,
+// store-bound 1x1 convolutions of the wide OSNets.
+// LDS image: rows of BK halves = BK / 8 chunks of 16 bytes, chunk c of row r stored at slot c ^ swz(r) with swz(r) = r & 7
+// (BK = 64) or (r >> 1) & 3 (BK = 32) -- the copy's destination is lane-linear, so the swizzle is applied to the per-lane SOURCE
+// address; with ds_read_b128's lane groups ({0-3, 12-15, 20-27}, ...) every 16-byte fragment read is then bank-conflict free.
+// Rows beyond M re-read row M - 1 (their results are never stored).
 // ---------------------------------------------------------------------------
-constexpr int GEMM2_BK = 64;
-constexpr int GEMM2_LDS_BYTES = 2 * 2 * 128 * GEMM2_BK * 2;      // 2 buffers x (W tile + X tile) = 64 KiB
+template <int BK>
+__host__ __device__ constexpr int gemm_glds_lds_bytes() { return 2 * 2 * 128 * BK * 2; }
 
-template <int EPI>
+template <int EPI, int BK>
 __global__ void __launch_bounds__(256) k_gemm_f16_glds(const _Float16* __restrict__ X, const _Float16* __restrict__ Wt,
                                                        const float* __restrict__ bias, void* __restrict__ Cout,
                                                        const _Float16* __restrict__ res, int M, int N, int K, int relu) {
+    static_assert(BK == 32 || BK == 64, "k-tile");
     BM_DYNAMIC_LDS_T(unsigned char, lds_raw);
     _Float16* lds = reinterpret_cast<_Float16*>(lds_raw);
-    constexpr int TILE = 128 * GEMM2_BK;                         // halves per operand tile
+    constexpr int TILE = 128 * BK, CH = BK / 8, NI = CH / 2;      // halves per operand tile, chunks per row, copies per wave and operand
     const int tid = threadIdx.x, lane = tid & 63, wave = BM_UNIFORM_I32(tid >> 6), g = lane >> 4, l16 = lane & 15;
     const int wn = wave >> 1, wm = wave & 1;
-    const long m0 = (long)blockIdx.x * GEMM_BM;
-    const int n0 = blockIdx.y * GEMM_BN;
+    int mt, nt;
+    gemm_tile_of_block((M + GEMM_BM - 1) / GEMM_BM, N / GEMM_BN, mt, nt);
+    const long m0 = (long)mt * GEMM_BM;
+    const int n0 = nt * GEMM_BN;
+    auto swz = [](int r) { return BK == 64 ? (r & 7) : ((r >> 1) & 3); };
     cf4 acc[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = cf4{0.f, 0.f, 0.f, 0.f};
-    // copy i (0..3) of this wave moves LDS chunks p = (4 wave + i) * 64 + lane of an operand tile: row p >> 3, slot p & 7
-    const _Float16 *gw[4], *gx[4];
+    // copy i of this wave moves LDS chunks p = (NI wave + i) * 64 + lane of an operand tile: row p / CH, slot p % CH
+    const _Float16 *gw[NI], *gx[NI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int p = (4 * wave + i) * 64 + lane, r = p >> 3, c = (p & 7) ^ (r & 7);
+    for (int i = 0; i < NI; ++i) {
+        const int p = (NI * wave + i) * 64 + lane, r = p / CH, c = (p % CH) ^ swz(r);
         long m = m0 + r;
         if (m >= M) m = M - 1;
         gw[i] = Wt + (long)(n0 + r) * K + 8 * c;
@@ -179,26 +212,40 @@ __global__ void __launch_bounds__(256) k_gemm_f16_glds(const _Float16* __restric
         _Float16* dW = lds + buf * 2 * TILE;
         _Float16* dX = dW + TILE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            BM_GLDS16(gw[i] + k0, dW + (4 * wave + i) * 512, lane);
-            BM_GLDS16(gx[i] + k0, dX + (4 * wave + i) * 512, lane);
+        for (int i = 0; i < NI; ++i) {
+            BM_GLDS16(gw[i] + k0, dW + (NI * wave + i) * 512, lane);
+            BM_GLDS16(gx[i] + k0, dX + (NI * wave + i) * 512, lane);
         }
     };
     issue(0, 0);
-    const int nk = K / GEMM2_BK;
+    // the shortcut operand of the epilogue does not depend on the product: fetch it now, its latency hides behind the k-loop
+    ch4 rres[4][4];
+    if constexpr (EPI == 4) {
+        if (res) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    long m = m0 + wm * 64 + t * 16 + l16;
+                    if (m >= M) m = M - 1;
+                    rres[p][t] = *reinterpret_cast<const ch4*>(res + m * N + n0 + wn * 64 + p * 16 + 4 * g);
+                }
+        }
+    }
+    const int nk = K / BK;
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();                    // tile kt has landed (the barrier drains the copies) and buffer (kt + 1) & 1 is free
-        if (kt + 1 < nk) issue((kt + 1) * GEMM2_BK, (kt + 1) & 1);
+        if (kt + 1 < nk) issue((kt + 1) * BK, (kt + 1) & 1);
         const _Float16* sW = lds + (kt & 1) * 2 * TILE;
         const _Float16* sX = sW + TILE;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < BK / 32; ++s) {
             ch8 a[4], b[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int ra = wn * 64 + t * 16 + l16, rb = wm * 64 + t * 16 + l16;
-                a[t] = *reinterpret_cast<const ch8*>(sW + ra * GEMM2_BK + 8 * ((4 * s + g) ^ (ra & 7)));
-                b[t] = *reinterpret_cast<const ch8*>(sX + rb * GEMM2_BK + 8 * ((4 * s + g) ^ (rb & 7)));
+                a[t] = *reinterpret_cast<const ch8*>(sW + ra * BK + 8 * ((4 * s + g) ^ swz(ra)));
+                b[t] = *reinterpret_cast<const ch8*>(sX + rb * BK + 8 * ((4 * s + g) ^ swz(rb)));
             }
 #pragma unroll
             for (int p = 0; p < 4; ++p)
@@ -227,9 +274,8 @@ __global__ void __launch_bounds__(256) k_gemm_f16_glds(const _Float16* __restric
             }
             if constexpr (EPI == 4) {
                 if (res) {
-                    const ch4 rv = *reinterpret_cast<const ch4*>(res + m * N + n);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+                    for (int r = 0; r < 4; ++r) v[r] += (float)rres[p][t][r];
                 }
                 if (relu) {
 #pragma unroll

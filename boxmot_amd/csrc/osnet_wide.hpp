@@ -49,8 +49,8 @@ public:
         for (auto& m : mid_) m = alloc<_Float16>(mid, owned);
         gap_part_ = alloc<float>(4 * n * (64 / WIDE_BAND) * 128, owned);
         set_light_lds<32>(); set_light_lds<64>(); set_light_lds<96>(); set_light_lds<128>();
-        check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_glds<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  GEMM2_LDS_BYTES), "GEMM LDS");
+        check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_glds<4, 32>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  gemm_glds_lds_bytes<32>()), "GEMM LDS");
     }
 
     _Float16* crops_buffer() { return crops16_; }
@@ -107,13 +107,13 @@ private:
     void gemm(const _Float16* X, const _Float16* W, const float* bias, _Float16* out, const _Float16* res, long M, int N, int K,
               int relu, hipStream_t st) {
         if (K % GEMM_BK != 0 || N % 32 != 0) throw std::runtime_error("wide OSNet: GEMM shape not tileable");
-        const unsigned gx = (unsigned)((M + GEMM_BM - 1) / GEMM_BM);
-        if (N % 128 == 0 && K % GEMM2_BK == 0)
-            hipLaunchKernelGGL((k_gemm_f16_glds<4>), dim3(gx, N / 128), dim3(256), GEMM2_LDS_BYTES, st, X, W, bias, static_cast<void*>(out), res, (int)M, N, K, relu);
-        else if (N % 128 == 0) hipLaunchKernelGGL((k_gemm_f16<4, 128>), dim3(gx, N / 128), dim3(256), 0, st, X, W, bias, out, res, (int)M, N, K, relu);
-        else if (N % 96 == 0) hipLaunchKernelGGL((k_gemm_f16<4, 96>), dim3(gx, N / 96), dim3(256), 0, st, X, W, bias, out, res, (int)M, N, K, relu);
-        else if (N % 64 == 0) hipLaunchKernelGGL((k_gemm_f16<4, 64>), dim3(gx, N / 64), dim3(256), 0, st, X, W, bias, out, res, (int)M, N, K, relu);
-        else hipLaunchKernelGGL((k_gemm_f16<4, 32>), dim3(gx, N / 32), dim3(256), 0, st, X, W, bias, out, res, (int)M, N, K, relu);
+        const long mt = (M + GEMM_BM - 1) / GEMM_BM;          // 1-D grids: the kernels map workgroup ids to tiles XCD-aware
+        void* o = static_cast<void*>(out);
+        if (N % 128 == 0)
+            hipLaunchKernelGGL((k_gemm_f16_glds<4, 32>), dim3((unsigned)(mt * (N / 128))), dim3(256), gemm_glds_lds_bytes<32>(), st, X, W, bias, o, res, (int)M, N, K, relu);
+        else if (N % 96 == 0) hipLaunchKernelGGL((k_gemm_f16<4, 96>), dim3((unsigned)(mt * (N / 96))), dim3(256), 0, st, X, W, bias, o, res, (int)M, N, K, relu);
+        else if (N % 64 == 0) hipLaunchKernelGGL((k_gemm_f16<4, 64>), dim3((unsigned)(mt * (N / 64))), dim3(256), 0, st, X, W, bias, o, res, (int)M, N, K, relu);
+        else hipLaunchKernelGGL((k_gemm_f16<4, 32>), dim3((unsigned)(mt * (N / 32))), dim3(256), 0, st, X, W, bias, o, res, (int)M, N, K, relu);
     }
     template <int C>
     void light_t(const _Float16* in, const LightW& lw, _Float16* out, float* gap, int n, int H, int W, hipStream_t st) {

@@ -77,17 +77,17 @@ extern "C" int emu_clip_forward(const float* blob, long n_floats, const float* c
     { _Float16* o = patches.data(); launch(4, 1, 256, [=]() { k_clip_patches(crops, o, n, H, W, patch, gh, gw); }); }
     auto gemm = [&](int epi, const _Float16* X, const _Float16* Wt, const float* bias, void* C, long M, int N, int K) {
         const int gx = (int)((M + GEMM_BM - 1) / GEMM_BM), gy = N / GEMM_BN;
-        if (K % GEMM2_BK == 0) {            // the engine's choice (clip_engine.hpp): global_load_lds tiles for the large shapes
-            if (epi == 0) launch(gx, gy, 256, [=]() { k_gemm_f16_glds<0>(X, Wt, bias, C, nullptr, (int)M, N, K, 0); });
-            if (epi == 1) launch(gx, gy, 256, [=]() { k_gemm_f16_glds<1>(X, Wt, bias, C, nullptr, (int)M, N, K, 0); });
-            if (epi == 2) launch(gx, gy, 256, [=]() { k_gemm_f16_glds<2>(X, Wt, bias, C, nullptr, (int)M, N, K, 0); });
-            if (epi == 3) launch(gx, gy, 256, [=]() { k_gemm_f16_glds<3>(X, Wt, bias, C, nullptr, (int)M, N, K, 0); });
+        if (K % 64 == 0) {            // the engine's choice (clip_engine.hpp): global_load_lds tiles for the large shapes
+            if (epi == 0) launch(gx * gy, 1, 256, [=]() { k_gemm_f16_glds<0, 64>(X, Wt, bias, C, nullptr, (int)M, N, K, 0); });
+            if (epi == 1) launch(gx * gy, 1, 256, [=]() { k_gemm_f16_glds<1, 64>(X, Wt, bias, C, nullptr, (int)M, N, K, 0); });
+            if (epi == 2) launch(gx * gy, 1, 256, [=]() { k_gemm_f16_glds<2, 64>(X, Wt, bias, C, nullptr, (int)M, N, K, 0); });
+            if (epi == 3) launch(gx * gy, 1, 256, [=]() { k_gemm_f16_glds<3, 64>(X, Wt, bias, C, nullptr, (int)M, N, K, 0); });
             return;
         }
-        if (epi == 0) launch(gx, gy, 256, [=]() { k_gemm_f16<0>(X, Wt, bias, C, nullptr, (int)M, N, K, 0); });
-        if (epi == 1) launch(gx, gy, 256, [=]() { k_gemm_f16<1>(X, Wt, bias, C, nullptr, (int)M, N, K, 0); });
-        if (epi == 2) launch(gx, gy, 256, [=]() { k_gemm_f16<2>(X, Wt, bias, C, nullptr, (int)M, N, K, 0); });
-        if (epi == 3) launch(gx, gy, 256, [=]() { k_gemm_f16<3>(X, Wt, bias, C, nullptr, (int)M, N, K, 0); });
+        if (epi == 0) launch(gx * gy, 1, 256, [=]() { k_gemm_f16<0>(X, Wt, bias, C, nullptr, (int)M, N, K, 0); });
+        if (epi == 1) launch(gx * gy, 1, 256, [=]() { k_gemm_f16<1>(X, Wt, bias, C, nullptr, (int)M, N, K, 0); });
+        if (epi == 2) launch(gx * gy, 1, 256, [=]() { k_gemm_f16<2>(X, Wt, bias, C, nullptr, (int)M, N, K, 0); });
+        if (epi == 3) launch(gx * gy, 1, 256, [=]() { k_gemm_f16<3>(X, Wt, bias, C, nullptr, (int)M, N, K, 0); });
     };
     gemm(3, patches.data(), W16 + o_conv, nullptr, pe.data(), RP, D, K0);
     { const float* p = pe.data(); float* xo = x.data();

@@ -83,11 +83,10 @@ extern "C" int emu_wide_forward(const float* blob, long n_floats, const float* c
 
     auto gemm = [&](const _Float16* X, const _Float16* Wt, const float* bias, _Float16* out, const _Float16* res, long M, int Nn, int K, int relu) {
         const long gx = (M + GEMM_BM - 1) / GEMM_BM;
-        if (Nn % 128 == 0 && K % GEMM2_BK == 0) launch(gx, Nn / 128, 256, [=]() { k_gemm_f16_glds<4>(X, Wt, bias, out, res, (int)M, Nn, K, relu); });
-        else if (Nn % 128 == 0) launch(gx, Nn / 128, 256, [=]() { k_gemm_f16<4, 128>(X, Wt, bias, out, res, (int)M, Nn, K, relu); });
-        else if (Nn % 96 == 0) launch(gx, Nn / 96, 256, [=]() { k_gemm_f16<4, 96>(X, Wt, bias, out, res, (int)M, Nn, K, relu); });
-        else if (Nn % 64 == 0) launch(gx, Nn / 64, 256, [=]() { k_gemm_f16<4, 64>(X, Wt, bias, out, res, (int)M, Nn, K, relu); });
-        else launch(gx, Nn / 32, 256, [=]() { k_gemm_f16<4, 32>(X, Wt, bias, out, res, (int)M, Nn, K, relu); });
+        if (Nn % 128 == 0) launch(gx * (Nn / 128), 1, 256, [=]() { k_gemm_f16_glds<4, 32>(X, Wt, bias, out, res, (int)M, Nn, K, relu); });
+        else if (Nn % 96 == 0) launch(gx * (Nn / 96), 1, 256, [=]() { k_gemm_f16<4, 96>(X, Wt, bias, out, res, (int)M, Nn, K, relu); });
+        else if (Nn % 64 == 0) launch(gx * (Nn / 64), 1, 256, [=]() { k_gemm_f16<4, 64>(X, Wt, bias, out, res, (int)M, Nn, K, relu); });
+        else launch(gx * (Nn / 32), 1, 256, [=]() { k_gemm_f16<4, 32>(X, Wt, bias, out, res, (int)M, Nn, K, relu); });
     };
     auto light = [&](int C, const _Float16* in, const LightW& lw, _Float16* out, float* gap, int H, int W) {
         const _Float16* pw = W16 + pk.of(lw.pw); const float* dw = W32 + lw.dw; const float* b = W32 + lw.b;
