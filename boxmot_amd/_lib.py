@@ -170,6 +170,11 @@ SIGNATURES = {
     "boxmot_hip_botsort_update_batch_frames": (_I, [_VP, _I, _VP, _VP, _VP, _I, _VP, _I, _I, _VP, _I, _VP]),
     "boxmot_hip_deepocsort_stream": (_VP, [_VP]),
     "boxmot_hip_strongsort_stream": (_VP, [_VP]),
+    "boxmot_hip_ecc_create": (_VP, [_I, _I, _I, ctypes.c_double, ctypes.c_double, _I]),
+    "boxmot_hip_ecc_destroy": (None, [_VP]),
+    "boxmot_hip_ecc_reset": (_I, [_VP, _I]),
+    "boxmot_hip_ecc_apply": (_I, [_VP, _I, _VP, _I, _I, _I, _VP, c_int_p]),
+    "boxmot_hip_ecc_apply_device": (_I, [_VP, _I, _VP, _VP, c_int_p]),
     "boxmot_hip_ingest_create": (_VP, [_I, _I, _I, _I]),
     "boxmot_hip_ingest_destroy": (None, [_VP]),
     "boxmot_hip_ingest_host_ptr": (_VP, [_VP, _I, _I]),

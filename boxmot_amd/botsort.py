@@ -9,7 +9,7 @@ ctypes wrapper for its native backend (boxmot/native/trackers/botsort.py:94-274)
 
 Camera-motion compensation: applying a warp to the track state runs on the device
 (STrack.multi_gmc); *estimating* it from images (the reference's ECC / SOF objects,
-boxmot/motion/cmc) is not implemented here, so ``use_cmc=True`` needs a ``cmc=`` object
+boxmot/motion/cmc) exists on the device for ``cmc_method="ecc"`` (boxmot_amd.cmc.HipECC); "sof" needs a ``cmc=`` object
 exposing the reference's ``apply(img, dets) -> 2x3 warp`` (e.g. the reference's own).
 Not implemented, and rejected loudly rather than approximated: OBB detections, masks.
 """
@@ -60,11 +60,15 @@ class BotSort(BaseTracker):
     ):
         super().__init__(_tracker_name=_tracker_name, **kwargs)
         if use_cmc and cmc is None:
-            raise NotImplementedError(
-                "boxmot_amd.BotSort: camera-motion estimation (cmc_method=%r) is not implemented on the HIP path; "
-                "construct with use_cmc=False, or pass cmc=<object with apply(img, dets) -> 2x3 warp> "
-                "(the reference default is use_cmc=True, cmc_method='ecc')." % (cmc_method,)
-            )
+            # botsort.py:116-117: get_cmc_method(cmc_method)(); "ecc" (the constructor default) is estimated on the device
+            # (boxmot_amd.cmc.HipECC), the sparse-optical-flow estimator of the YAML default ("sof") is not built
+            if cmc_method != "ecc":
+                raise NotImplementedError(
+                    "boxmot_amd.BotSort: camera-motion estimator cmc_method=%r is not implemented on the HIP path (have: 'ecc'); "
+                    "construct with cmc_method='ecc', use_cmc=False, or pass cmc=<object with apply(img, dets) -> 2x3 warp>." % (cmc_method,)
+                )
+            from boxmot_amd.cmc import HipECC
+            cmc = HipECC()
         self.track_high_thresh = track_high_thresh
         self.track_low_thresh = track_low_thresh
         self.new_track_thresh = new_track_thresh

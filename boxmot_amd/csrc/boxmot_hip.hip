@@ -19,6 +19,7 @@
 #include "deepocsort_step.hpp"
 #include "strongsort_step.hpp"
 #include "reid_engine.hpp"
+#include "cmc_ecc.hpp"
 
 namespace {
 
@@ -134,6 +135,25 @@ struct BoxMOTHipReID {
         engine.reset();
         for (void* p : owned) (void)hipFree(p);
         if (d_frame) (void)hipFree(d_frame);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+// ECC camera-motion estimator (csrc/cmc_ecc.hpp): per stream two small grayscale images (previous / current), gradients, scratch
+struct BoxMOTHipEcc {
+    int S = 0, rows = 0, cols = 0, h = 0, w = 0, max_iter = 100;
+    double scale = 0.15, eps = 1e-5;
+    hipStream_t stream = nullptr;
+    std::vector<void*> owned;
+    float *img = nullptr, *gx = nullptr, *gy = nullptr, *scratch = nullptr;      // img: [S][2][h * w]
+    double* d_warp = nullptr; int* d_info = nullptr;
+    const uint8_t** d_frames = nullptr;          // host-API staging: one device frame per stream
+    std::vector<uint8_t*> frame_bufs;
+    std::vector<int> cur;                        // per stream: which of its two image buffers holds the newest frame
+    std::vector<char> has_prev;
+    ~BoxMOTHipEcc() {
+        for (void* p : owned) (void)hipFree(p);
+        for (auto p : frame_bufs) if (p) (void)hipFree(p);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -1205,6 +1225,96 @@ int boxmot_hip_reid_preprocess(BoxMOTHipReID* handle, const uint8_t* image, int 
         BM_HIP(hipMemcpyAsync(out_crops, handle->engine->crops_buffer(),
                               (size_t)n_boxes * bm::REID_IN_H * bm::REID_IN_W * 3 * 4, hipMemcpyDeviceToHost, handle->stream));
         BM_HIP(hipStreamSynchronize(handle->stream));
+    });
+}
+
+// ---- ECC camera-motion estimation ----
+BoxMOTHipEcc* boxmot_hip_ecc_create(int n_streams, int image_rows, int image_cols, double scale, double eps, int max_iter) {
+    BoxMOTHipEcc* h = nullptr;
+    const int ok = guard([&]() {
+        require_device();
+        if (n_streams < 1 || image_rows < 8 || image_cols < 8) throw std::runtime_error("boxmot_hip: ECC needs >= 1 stream and a frame of at least 8 x 8");
+        if (!(scale > 0.0) || scale > 1.0 || !(eps > 0.0) || max_iter < 1) throw std::runtime_error("boxmot_hip: ECC scale must be in (0, 1], eps > 0, max_iter >= 1");
+        h = new BoxMOTHipEcc();
+        h->S = n_streams; h->rows = image_rows; h->cols = image_cols; h->scale = scale; h->eps = eps; h->max_iter = max_iter;
+        h->w = (int)std::nearbyint(image_cols * scale); h->h = (int)std::nearbyint(image_rows * scale);     // saturate_cast<int>(ssize * fx)
+        if (h->w < 4 || h->h < 4) throw std::runtime_error("boxmot_hip: ECC image too small after scaling");
+        BM_HIP(hipStreamCreate(&h->stream));
+        const size_t P = (size_t)h->h * h->w, S = n_streams;
+        h->img = zalloc<float>(S * 2 * P, h->owned);
+        h->gx = zalloc<float>(S * P, h->owned); h->gy = zalloc<float>(S * P, h->owned);
+        h->scratch = zalloc<float>(S * 3 * P, h->owned);
+        h->d_warp = zalloc<double>(S * 6, h->owned); h->d_info = zalloc<int>(S * 2, h->owned);
+        h->d_frames = zalloc<const uint8_t*>(S, h->owned);
+        h->frame_bufs.assign(S, nullptr); h->cur.assign(S, 0); h->has_prev.assign(S, 0);
+    });
+    if (!ok) { delete h; return nullptr; }
+    return h;
+}
+
+void boxmot_hip_ecc_destroy(BoxMOTHipEcc* handle) { delete handle; }
+
+int boxmot_hip_ecc_reset(BoxMOTHipEcc* handle, int stream) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip: null ECC handle");
+        if (stream >= handle->S) throw std::runtime_error("boxmot_hip: stream index out of range");
+        for (int s = 0; s < handle->S; ++s) if (stream < 0 || s == stream) handle->has_prev[s] = 0;
+    });
+}
+
+// one stream, frames d_frames[0]: preprocess into the stream's other buffer; estimate against the previous one when there is one
+static void ecc_run_one(BoxMOTHipEcc* h, int s, const uint8_t* const* d_frame_ptr, double* out_warp6, int* out_iterations) {
+    const long P = (long)h->h * h->w;
+    const int nxt = 1 - h->cur[s];
+    float* imgs = h->img + (size_t)s * 2 * P;
+    const unsigned blocks = (unsigned)((P + 255) / 256);
+    hipLaunchKernelGGL(bm::k_ecc_preprocess, dim3(blocks, 1), dim3(256), 0, h->stream, d_frame_ptr, imgs + nxt * P, P, h->rows, h->cols, h->h,
+                       h->w, 1.0 / h->scale);
+    double warp[6] = {1, 0, 0, 0, 1, 0};
+    int info[2] = {0, 0};
+    if (h->has_prev[s]) {
+        hipLaunchKernelGGL(bm::k_ecc_gradients, dim3(blocks, 1), dim3(256), 0, h->stream, imgs + nxt * P, P, h->gx + s * P, h->gy + s * P, h->h, h->w);
+        hipLaunchKernelGGL(bm::k_ecc_solve, dim3(1), dim3(bm::ECC_THREADS), 0, h->stream, imgs + h->cur[s] * P, imgs + nxt * P, P, h->gx + s * P,
+                           h->gy + s * P, h->scratch + (size_t)s * 3 * P, h->d_warp + s * 6, h->d_info + s * 2, h->h, h->w, h->eps, h->max_iter,
+                           (float)h->scale);
+        BM_HIP(hipMemcpyAsync(warp, h->d_warp + s * 6, sizeof(warp), hipMemcpyDeviceToHost, h->stream));
+        BM_HIP(hipMemcpyAsync(info, h->d_info + s * 2, sizeof(info), hipMemcpyDeviceToHost, h->stream));
+    }
+    BM_HIP(hipStreamSynchronize(h->stream));
+    BM_HIP(hipGetLastError());
+    h->cur[s] = nxt; h->has_prev[s] = 1;
+    for (int k = 0; k < 6; ++k) out_warp6[k] = warp[k];
+    if (out_iterations) *out_iterations = info[1];
+}
+
+int boxmot_hip_ecc_apply(BoxMOTHipEcc* handle, int stream, const uint8_t* image, int image_rows, int image_cols, int image_channels,
+                         double* out_warp_2x3, int* out_iterations) {
+    return guard([&]() {
+        if (!handle || !out_warp_2x3) throw std::runtime_error("boxmot_hip: null argument");
+        if (stream < 0 || stream >= handle->S) throw std::runtime_error("boxmot_hip: stream index out of range");
+        if (!image) throw std::runtime_error("Image data pointer is null.");
+        if (image_channels != 3 || image_rows != handle->rows || image_cols != handle->cols)
+            throw std::runtime_error("boxmot_hip: ECC was created for a different frame size (3-channel BGR uint8)");
+        const size_t bytes = (size_t)image_rows * image_cols * 3;
+        if (!handle->frame_bufs[stream]) {
+            void* p = nullptr;
+            BM_HIP(hipMalloc(&p, bytes));
+            handle->frame_bufs[stream] = static_cast<uint8_t*>(p);
+            BM_HIP(hipMemcpy(handle->d_frames, handle->frame_bufs.data(), handle->S * sizeof(uint8_t*), hipMemcpyHostToDevice));
+        }
+        BM_HIP(hipMemcpyAsync(handle->frame_bufs[stream], image, bytes, hipMemcpyHostToDevice, handle->stream));
+        ecc_run_one(handle, stream, handle->d_frames + stream, out_warp_2x3, out_iterations);
+    });
+}
+
+int boxmot_hip_ecc_apply_device(BoxMOTHipEcc* handle, int stream, const uint8_t* d_frame, double* out_warp_2x3, int* out_iterations) {
+    return guard([&]() {
+        if (!handle || !out_warp_2x3 || !d_frame) throw std::runtime_error("boxmot_hip: null argument");
+        if (stream < 0 || stream >= handle->S) throw std::runtime_error("boxmot_hip: stream index out of range");
+        // the pointer table lives on the device: one slot per stream, written on the handle's stream before the kernels read it
+        BM_HIP(hipMemcpyAsync(handle->d_frames + stream, &d_frame, sizeof(uint8_t*), hipMemcpyHostToDevice, handle->stream));
+        BM_HIP(hipStreamSynchronize(handle->stream));       // &d_frame is a stack address
+        ecc_run_one(handle, stream, handle->d_frames + stream, out_warp_2x3, out_iterations);
     });
 }
 

@@ -8,9 +8,9 @@ sample bank to every detection, and the frame step (camera update, 8-state XYAH 
 confidence scaling, gated appearance stage, IoU stage -- both assigned with a restatement of SciPy's
 ``linear_sum_assignment`` -- track management, sample banks).
 
-Camera motion: the reference applies an ECC estimate unconditionally; estimation is not implemented here, so the
-tracker applies the identity (static camera) unless a ``cmc=`` object exposing the reference's
-``apply(img, boxes) -> 2x3 warp`` is given.  Rejected loudly: OBB detections, ``nn_budget=None``.
+Camera motion: the reference applies an ECC estimate unconditionally (strongsort.py:67,83-86).  ``cmc="ecc"`` (what
+``create_tracker("strongsort")`` passes by default) runs that estimator on the device (boxmot_amd.cmc.HipECC); any object with
+the reference's ``apply(img, boxes) -> 2x3 warp`` is accepted; ``cmc=None`` applies the identity (static camera).  Rejected loudly: OBB detections, ``nn_budget=None``.
 """
 from __future__ import annotations
 
@@ -52,6 +52,9 @@ class StrongSort(BaseTracker):
             raise NotImplementedError("boxmot_amd.StrongSort: nn_budget=None (unbounded sample bank) is not supported")
         self.min_conf = min_conf
         self.model = reid_model
+        if isinstance(cmc, str):        # cmc="ecc": the estimator the reference always constructs (strongsort.py:67), on the device
+            from boxmot_amd.cmc import get_cmc_method
+            cmc = get_cmc_method(cmc)()
         self.cmc = cmc
         self._lib = _lib.load()
         self._emb_dim = emb_dim or getattr(self.model, "feature_dim", None) or 512

@@ -58,11 +58,11 @@ def flatten_yaml_config(cfg: dict) -> dict:
 def create_tracker(tracker_type: str = "botsort", tracker_config=None, reid_weights=None, device=None, half=None,
                    per_class: bool = False, evolve_param_dict: dict | None = None, reid_preprocess=None,
                    reid_model=None, tracker_backend: str = "hip", **overrides):
-    """``overrides`` are constructor arguments laid over the YAML defaults.  Camera-motion compensation: the HIP trackers
-    apply a warp on the device but do not estimate it, so the reference's YAML defaults (BoT-SORT ``use_cmc=True``,
-    DeepOCSORT ``cmc_off=False``, StrongSORT's built-in ECC) need either ``cmc=<object with apply(img, dets) -> 2x3 warp>``
-    or ``use_cmc=False`` / ``cmc_off=True`` among the overrides; BoT-SORT / DeepOCSORT raise NotImplementedError otherwise
-    and StrongSORT warns that it runs with the identity warp (= the reference on a static camera)."""
+    """``overrides`` are constructor arguments laid over the YAML defaults.  Camera-motion compensation: the ECC estimator
+    runs on the device (boxmot_amd.cmc.HipECC): StrongSORT gets it by default like the reference (``cmc=None`` opts out), and
+    BoT-SORT with ``cmc_method="ecc"``.  The sparse-optical-flow estimator ("sof": BoT-SORT's YAML default and DeepOCSORT's
+    built-in one) is not built: those defaults need ``cmc=<object with apply(img, dets) -> 2x3 warp>`` (e.g. ``HipECC()``),
+    ``cmc_method="ecc"`` or ``use_cmc=False`` / ``cmc_off=True`` among the overrides and raise NotImplementedError otherwise."""
     if tracker_backend != "hip":
         raise ValueError(f"tracker_backend={tracker_backend!r}: boxmot_amd provides the 'hip' backend only")
     if tracker_type not in SUPPORTED:
@@ -87,12 +87,7 @@ def create_tracker(tracker_type: str = "botsort", tracker_config=None, reid_weig
             from boxmot_amd.reid import HipReID
 
             reid_model = HipReID(reid_weights, preprocess=reid_preprocess)
-        if kwargs.get("cmc") is None:
-            import warnings
-
-            warnings.warn("boxmot_amd StrongSort: no cmc= estimator supplied; tracks get the identity camera warp (the reference "
-                          "always runs ECC, strongsort.py:67,83-86). Pass cmc=<object with apply(img, dets)> for moving cameras.",
-                          RuntimeWarning, stacklevel=2)
+        kwargs.setdefault("cmc", "ecc")       # strongsort.py:67: the reference's StrongSort always runs ECC; cmc=None opts out (identity)
         return StrongSort(reid_model=reid_model, **kwargs)
     if tracker_type == "bytetrack":
         from boxmot_amd.bytetrack import ByteTrack

@@ -107,7 +107,7 @@ int boxmot_hip_botsort_update_stream(
  * BotSort._apply_aabb_camera_motion_compensation, botsort.py:134-145).  `warp_2x3` = the row-major 2x3 matrix
  * the reference's cmc.apply(img, dets) returns ([r00 r01 tx; r10 r11 ty]); it is applied to the predicted pool and
  * to the unconfirmed tracks in the NEXT update / update_stream / update_batch of `stream` and then dropped.
- * NULL clears a pending warp.  Estimating the warp from images (ECC / SOF) is not part of this library. */
+ * NULL clears a pending warp.  The ECC estimator is boxmot_hip_ecc_* below; the sparse-optical-flow one (SOF) is not built. */
 int boxmot_hip_botsort_set_warp(BoxMOTHipBotSort* handle, int stream, const double* warp_2x3);
 
 /* One frame for each of the first n_streams streams in one launch set.  det_rows[s] == -1 leaves stream s untouched
@@ -203,6 +203,23 @@ int boxmot_hip_reid_last_time_ms(BoxMOTHipReID* handle, double* out_preprocess_m
 const char* boxmot_hip_last_error(void);
 /* number of visible HIP devices (0 when none / runtime unusable) */
 int boxmot_hip_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Camera-motion estimation: the ECC estimator (boxmot/motion/cmc/ecc.py:14-96; the reference's StrongSORT applies it on every
+ * frame, strongsort.py:63,83-86, and BoT-SORT / DeepOCSORT accept it as cmc_method "ecc").  Arguments = the constructor's
+ * (scale 0.15, eps 1e-5, max_iter 100; MOTION_TRANSLATION, grayscale, no alignment are fixed).  apply = ECC.apply(img, dets):
+ * the first call of a stream stores the frame and returns the identity; later calls return the 2 x 3 warp (row-major doubles,
+ * translation in full-resolution pixels) between the previous and this frame, or the identity when the iteration hits one of
+ * OpenCV's "did not converge" exits (ecc.py:67-76).  Feed the result to boxmot_hip_*_set_warp.  apply_device takes a frame that
+ * already is in HBM (e.g. an ingest-ring slot).  reset(stream < 0: all) forgets the previous frame.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct BoxMOTHipEcc BoxMOTHipEcc;
+BoxMOTHipEcc* boxmot_hip_ecc_create(int n_streams, int image_rows, int image_cols, double scale, double eps, int max_iter);
+void boxmot_hip_ecc_destroy(BoxMOTHipEcc* handle);
+int boxmot_hip_ecc_reset(BoxMOTHipEcc* handle, int stream);
+int boxmot_hip_ecc_apply(BoxMOTHipEcc* handle, int stream, const uint8_t* image, int image_rows, int image_cols, int image_channels,
+                         double* out_warp_2x3, int* out_iterations);
+int boxmot_hip_ecc_apply_device(BoxMOTHipEcc* handle, int stream, const uint8_t* d_frame, double* out_warp_2x3, int* out_iterations);
 
 /* ------------------------------------------------------------------------------------------------
  * Frame ingest ring (no counterpart in the reference: its trackers receive a numpy frame per call, basetracker.py:120-147, and

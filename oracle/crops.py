@@ -26,14 +26,15 @@ MEAN_RGB = np.array([0.485, 0.456, 0.406], dtype=np.float32)
 STD_RGB = np.array([0.229, 0.224, 0.225], dtype=np.float32)
 
 
-def _axis_tables(dst_n: int, src_n: int):
+def _axis_tables(dst_n: int, src_n: int, scale: float | None = None):
     """Per-output-index source offset and the two int16 coefficients.
 
     resize.cpp: ``f = (float)((d + 0.5) * scale - 0.5); s = cvFloor(f); f -= s``;
     the x axis clamps (s<0 -> s=0,f=0 ; s>=n-1 -> s=n-1,f=0); the y axis keeps
     its coefficients and clips the two row indices instead.
     """
-    scale = float(src_n) / float(dst_n)  # double, = 1 / inv_scale
+    if scale is None:
+        scale = float(src_n) / float(dst_n)  # double, = 1 / inv_scale
     d = np.arange(dst_n, dtype=np.float64)
     f = ((d + 0.5) * scale - 0.5).astype(np.float32)
     s = np.floor(f).astype(np.int64)
@@ -49,8 +50,9 @@ def _coef(f: np.ndarray):
     return a0, a1
 
 
-def cv2_resize_linear_u8(src: np.ndarray, dsize_wh) -> np.ndarray:
-    """``cv2.resize(src, (W, H), interpolation=cv2.INTER_LINEAR)`` for uint8 HxWxC."""
+def cv2_resize_linear_u8(src: np.ndarray, dsize_wh, inv_scale_xy=None) -> np.ndarray:
+    """``cv2.resize(src, (W, H), interpolation=cv2.INTER_LINEAR)`` for uint8 HxWxC.  ``inv_scale_xy = (1 / fx, 1 / fy)`` restates
+    the ``cv2.resize(src, (0, 0), fx=, fy=)`` form, where the coordinate scale is 1 / fx whatever the rounded output size is."""
     src = np.ascontiguousarray(src, dtype=np.uint8)
     squeeze = src.ndim == 2
     if squeeze:
@@ -67,7 +69,7 @@ def cv2_resize_linear_u8(src: np.ndarray, dsize_wh) -> np.ndarray:
         out = out.astype(np.uint8)
         return out[:, :, 0] if squeeze else out
 
-    sx, fx = _axis_tables(dw, sw)
+    sx, fx = _axis_tables(dw, sw, None if inv_scale_xy is None else inv_scale_xy[0])
     lo = sx < 0
     fx = np.where(lo, np.float32(0), fx).astype(np.float32)
     sx = np.where(lo, 0, sx)
@@ -77,7 +79,7 @@ def cv2_resize_linear_u8(src: np.ndarray, dsize_wh) -> np.ndarray:
     ax0, ax1 = _coef(fx)
     sx1 = np.minimum(sx + 1, sw - 1)
 
-    sy, fy = _axis_tables(dh, sh)
+    sy, fy = _axis_tables(dh, sh, None if inv_scale_xy is None else inv_scale_xy[1])
     by0, by1 = _coef(fy)
     sy0 = np.clip(sy, 0, sh - 1)
     sy1 = np.clip(sy + 1, 0, sh - 1)

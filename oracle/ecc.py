@@ -35,7 +35,7 @@ def preprocess(img: np.ndarray, scale: float = 0.15) -> np.ndarray:
     gray = bgr2gray_u8(np.asarray(img, dtype=np.uint8))
     h, w = gray.shape
     dw, dh = int(np.rint(w * scale)), int(np.rint(h * scale))          # saturate_cast<int>(ssize * fx)
-    return cv2_resize_linear_u8(gray, (dw, dh))
+    return cv2_resize_linear_u8(gray, (dw, dh), (1.0 / scale, 1.0 / scale))
 
 
 def gradients(im: np.ndarray):

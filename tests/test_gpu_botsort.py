@@ -131,9 +131,14 @@ def test_edge_inputs_like_the_reference_tests():
     trk.reset()
     assert trk.update(det, img, emb).id.tolist() == [1, 2]              # reset restarts the id counter
     trk.close()
+    from boxmot_amd.botsort import BotSort
+    from boxmot_amd.cmc import HipECC
     with pytest.raises(NotImplementedError, match="camera-motion"):
-        from boxmot_amd.botsort import BotSort
-        BotSort()                                                       # reference default use_cmc=True
+        BotSort(cmc_method="sof")                                       # the YAML default's estimator is not built: loud
+    dflt = BotSort(with_reid=False)                                     # constructor defaults: use_cmc=True, cmc_method="ecc" -> device ECC
+    assert isinstance(dflt.cmc, HipECC)
+    assert dflt.update(det, img).id.tolist() == [1, 2]
+    dflt.close()
 
 
 def test_per_class_matches_reference_semantics():
