@@ -15,10 +15,6 @@
 #include "clip_kernels.hpp"
 #include "reid_pack.hpp"
 
-#ifndef BM_GEMM_PIPE3
-#define BM_GEMM_PIPE3 0      // 1: three-buffer global_load_lds GEMM (two k-tiles of look-ahead) for the linear layers
-#endif
-
 namespace bm {
 
 constexpr int CLIP_MAGIC = 0x434C5031;       // "CLP1"
@@ -113,8 +109,6 @@ private:
     }
     template <int EPI>
     static void set_gemm_lds() {
-        check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_glds3<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  GEMM3_LDS_BYTES), "GEMM LDS");
         check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_glds<EPI, 64>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   gemm_glds_lds_bytes<64>()), "GEMM LDS");
     }
@@ -122,11 +116,6 @@ private:
     void gemm(const _Float16* X, const _Float16* W, const float* bias, void* C, long M, int N, int K, hipStream_t st) {
         if (N % GEMM_BN != 0 || K % GEMM_BK != 0) throw std::runtime_error("CLIP-ReID: GEMM shape not tileable");
         const dim3 grid((unsigned)(((M + GEMM_BM - 1) / GEMM_BM) * (N / GEMM_BN)));       // 1-D: the kernels map ids to tiles XCD-aware
-#if BM_GEMM_PIPE3
-        hipLaunchKernelGGL((k_gemm_f16_glds3<EPI>), grid, dim3(256), GEMM3_LDS_BYTES, st, X, W, bias, C,
-                           static_cast<const _Float16*>(nullptr), (int)M, N, K, 0);
-        return;
-#endif
         if (K % 64 == 0)
             hipLaunchKernelGGL((k_gemm_f16_glds<EPI, 64>), grid, dim3(256), gemm_glds_lds_bytes<64>(), st, X, W, bias, C,
                                static_cast<const _Float16*>(nullptr), (int)M, N, K, 0);

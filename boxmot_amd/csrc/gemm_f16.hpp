@@ -300,110 +300,4 @@ __global__ void __launch_bounds__(256) k_gemm_f16_glds(const _Float16* __restric
     }
 }
 
-// ---------------------------------------------------------------------------
-// Three-buffer variant of k_gemm_f16_glds (BK = 32, 48 KiB of LDS, 3 workgroups per CU): the copies of tiles t + 1 AND t + 2 are
-// in flight while tile t multiplies.  One k-tile of MFMAs (16 per wave, ~0.2 us) is far shorter than an HBM / MALL round trip, so
-// with a single tile of look-ahead every barrier waits for memory; two tiles of look-ahead need a counted wait (all but the newest
-// tile's copies retired) and a barrier that does not drain the copy queue: BM_WAIT_VMCNT + BM_RAW_BARRIER.
-//   iteration t:  wait until this wave's copies of tile t have landed  ->  barrier (everybody's have; buffer (t + 2) % 3, read in
-//                 iteration t - 1, is free)  ->  issue the copies of tile t + 2  ->  multiply tile t
-// ---------------------------------------------------------------------------
-constexpr int GEMM3_BK = 32, GEMM3_LDS_BYTES = 3 * 2 * 128 * GEMM3_BK * 2;
-
-template <int EPI>
-__global__ void __launch_bounds__(256) k_gemm_f16_glds3(const _Float16* __restrict__ X, const _Float16* __restrict__ Wt,
-                                                        const float* __restrict__ bias, void* __restrict__ Cout,
-                                                        const _Float16* __restrict__ res, int M, int N, int K, int relu) {
-    constexpr int BK = GEMM3_BK, TILE = 128 * BK, CH = BK / 8, NI = CH / 2;
-    BM_DYNAMIC_LDS_T(unsigned char, lds_raw);
-    _Float16* lds = reinterpret_cast<_Float16*>(lds_raw);
-    const int tid = threadIdx.x, lane = tid & 63, wave = BM_UNIFORM_I32(tid >> 6), g = lane >> 4, l16 = lane & 15;
-    const int wn = wave >> 1, wm = wave & 1;
-    int mt, nt;
-    gemm_tile_of_block((M + GEMM_BM - 1) / GEMM_BM, N / GEMM_BN, mt, nt);
-    const long m0 = (long)mt * GEMM_BM;
-    const int n0 = nt * GEMM_BN;
-    auto swz = [](int r) { return (r >> 1) & 3; };
-    cf4 acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = cf4{0.f, 0.f, 0.f, 0.f};
-    const _Float16 *gw[NI], *gx[NI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int p = (NI * wave + i) * 64 + lane, r = p / CH, c = (p % CH) ^ swz(r);
-        long m = m0 + r;
-        if (m >= M) m = M - 1;
-        gw[i] = Wt + (long)(n0 + r) * K + 8 * c;
-        gx[i] = X + m * K + 8 * c;
-    }
-    auto issue = [&](int k0, int buf) {
-        _Float16* dW = lds + buf * 2 * TILE;
-        _Float16* dX = dW + TILE;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            BM_GLDS16(gw[i] + k0, dW + (NI * wave + i) * 512, lane);
-            BM_GLDS16(gx[i] + k0, dX + (NI * wave + i) * 512, lane);
-        }
-    };
-    const int nk = K / BK;
-    issue(0, 0);
-    if (nk > 1) issue(BK, 1);
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) BM_WAIT_VMCNT(2 * NI);     // every copy but the newest tile's (2 NI instructions per wave and tile) has retired
-        else BM_WAIT_VMCNT(0);
-        BM_RAW_BARRIER();
-        if (kt + 2 < nk) issue((kt + 2) * BK, (kt + 2) % 3);
-        const _Float16* sW = lds + (kt % 3) * 2 * TILE;
-        const _Float16* sX = sW + TILE;
-        ch8 a[4], b[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int ra = wn * 64 + t * 16 + l16, rb = wm * 64 + t * 16 + l16;
-            a[t] = *reinterpret_cast<const ch8*>(sW + ra * BK + 8 * (g ^ swz(ra)));
-            b[t] = *reinterpret_cast<const ch8*>(sX + rb * BK + 8 * (g ^ swz(rb)));
-        }
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[p][t] = BM_MFMA_F16_K32(a[p], b[t], acc[p][t]);
-    }
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int n = n0 + wn * 64 + p * 16 + 4 * g;
-        cf4 bv = cf4{0.f, 0.f, 0.f, 0.f};
-        if (bias) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bv[r] = bias[n + r];
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const long m = m0 + wm * 64 + t * 16 + l16;
-            if (m >= M) continue;
-            cf4 v = acc[p][t];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += bv[r];
-            if constexpr (EPI == 1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + BM_EXPF(-1.702f * v[r]));
-            }
-            if constexpr (EPI == 0 || EPI == 1) {
-                ch4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (_Float16)v[r];
-                *reinterpret_cast<ch4*>(static_cast<_Float16*>(Cout) + m * N + n) = o;
-            } else if constexpr (EPI == 2) {
-                float* c = static_cast<float*>(Cout) + m * N + n;
-                cf4 old = *reinterpret_cast<const cf4*>(c);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) old[r] += v[r];
-                *reinterpret_cast<cf4*>(c) = old;
-            } else {
-                *reinterpret_cast<cf4*>(static_cast<float*>(Cout) + m * N + n) = v;
-            }
-        }
-    }
-}
-
 }  // namespace bm

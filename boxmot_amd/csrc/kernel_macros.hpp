@@ -48,13 +48,6 @@
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), \
                                      (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0)
 #endif
-#ifndef BM_WAIT_VMCNT
-// counted wait on this wave's outstanding vector-memory operations (global loads and global_load_lds copies retire in issue
-// order), and the bare workgroup barrier without the compiler's fence (which would drain every copy in flight): together they
-// let LDS copies of later k-tiles stay in flight across the barrier that publishes an earlier one
-#define BM_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
-#define BM_RAW_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
-#endif
 #ifndef BM_RELU_F32
 // max(v, 0) as one integer max on the bit pattern (negative floats are negative ints); a float max costs a second,
 // canonicalising v_max under IEEE mode
