@@ -238,20 +238,22 @@ __global__ void __launch_bounds__(256) k_gemm_f16_glds(const _Float16* __restric
         if (kt + 1 < nk) issue((kt + 1) * BK, (kt + 1) & 1);
         const _Float16* sW = lds + (kt & 1) * 2 * TILE;
         const _Float16* sX = sW + TILE;
+        // every fragment of the tile is requested before the first MFMA: the reads of k-step 1 land under the MFMAs of k-step 0
+        ch8 a[BK / 32][4], b[BK / 32][4];
 #pragma unroll
-        for (int s = 0; s < BK / 32; ++s) {
-            ch8 a[4], b[4];
+        for (int s = 0; s < BK / 32; ++s)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int ra = wn * 64 + t * 16 + l16, rb = wm * 64 + t * 16 + l16;
-                a[t] = *reinterpret_cast<const ch8*>(sW + ra * BK + 8 * ((4 * s + g) ^ swz(ra)));
-                b[t] = *reinterpret_cast<const ch8*>(sX + rb * BK + 8 * ((4 * s + g) ^ swz(rb)));
+                a[s][t] = *reinterpret_cast<const ch8*>(sW + ra * BK + 8 * ((4 * s + g) ^ swz(ra)));
+                b[s][t] = *reinterpret_cast<const ch8*>(sX + rb * BK + 8 * ((4 * s + g) ^ swz(rb)));
             }
+#pragma unroll
+        for (int s = 0; s < BK / 32; ++s)
 #pragma unroll
             for (int p = 0; p < 4; ++p)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[p][t] = BM_MFMA_F16_K32(a[p], b[t], acc[p][t]);
-        }
+                for (int t = 0; t < 4; ++t) acc[p][t] = BM_MFMA_F16_K32(a[s][p], b[s][t], acc[p][t]);
     }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {

@@ -98,8 +98,9 @@ class _Det:
 
 
 class _Track:
-    def __init__(self, det, tid, n_init, max_age, ema_alpha):
+    def __init__(self, det, tid, n_init, max_age, ema_alpha, norm=np.linalg.norm):
         self.id = tid
+        self.norm = norm                            # np.linalg.norm (reference) or the device's summation order (dot_rule="device")
         self.conf, self.cls, self.det_ind = det.conf, det.cls, det.det_ind
         self.hits = self.age = 1
         self.time_since_update = 0
@@ -107,7 +108,7 @@ class _Track:
         self.state = TENTATIVE                      # GITHUB_ACTIONS unset (track.py:91-98)
         self.features = []
         if det.feat is not None:
-            det.feat /= np.linalg.norm(det.feat)
+            det.feat /= self.norm(det.feat)
             self.features.append(det.feat)
         self.n_init, self.max_age = n_init, max_age
         self.mean, self.cov = kf_initiate(det.to_xyah())
@@ -141,9 +142,9 @@ class _Track:
     def update(self, det):
         self.conf, self.cls, self.det_ind = det.conf, det.cls, det.det_ind
         self.mean, self.cov = kf_update(self.mean, self.cov, det.to_xyah(), self.conf)
-        feature = det.feat / np.linalg.norm(det.feat)
+        feature = det.feat / self.norm(det.feat)
         smooth = self.ema_alpha * self.features[-1] + (1 - self.ema_alpha) * feature
-        smooth /= np.linalg.norm(smooth)
+        smooth /= self.norm(smooth)
         self.features = [smooth]
         self.hits += 1
         self.time_since_update = 0
@@ -169,6 +170,45 @@ def _nn_cosine_distance(x, y):                      # :266-284
     return _cosine_distance(x_, y_).min(axis=0)
 
 
+# ---- the device's documented fp32 summation order ("dot_rule = device") ----
+# The reference hands the appearance product to NumPy -> OpenBLAS sgemm, whose summation order depends on the operand shapes
+# and on the host CPU's kernel: the cost is only defined to a few fp32 ulps, and SciPy's choice among exactly tied (clamped)
+# rows can hang on those bits.  The HIP kernels use ONE documented order (strongsort_step.hpp):
+#   |v|    : lane l of a 64-lane wavefront accumulates v[k]^2 for k = l, l + 64, ... with fmaf, the 64 partial sums are added
+#            as a butterfly (offsets 32, 16, ..., 1), sqrtf
+#   <a, b> : one fmaf per k, k ascending, from 0 (v_mfma_f32_16x16x4_f32 is bit-for-bit that chain)
+#   dist   : 1 - <a, b> / (|a| * |b|) in fp32, min over the bank
+# Under this rule the oracle's cost matrix is bit-identical to the device's, which makes the id comparison exact on every
+# sequence (like lap_rule="lowest_index" for the DeepOCSORT assignment ties).  fmaf is emulated in 80-bit long double
+# (a 24 x 24-bit product is exact there; the sum is rounded once more, which matters with probability ~2^-40 per operation).
+def _fma32(a, b, c):
+    return (a.astype(np.longdouble) * b.astype(np.longdouble) + c.astype(np.longdouble)).astype(np.float32)
+
+
+def _norm_device_rule(v):
+    v = np.ascontiguousarray(v, dtype=np.float32)
+    n, dim = v.shape
+    ss = np.zeros((n, 64), dtype=np.float32)
+    for k0 in range(0, dim, 64):
+        blk = v[:, k0:k0 + 64]
+        w = blk.shape[1]
+        ss[:, :w] = _fma32(blk, blk, ss[:, :w])
+    for off in (32, 16, 8, 4, 2, 1):
+        ss = (ss[:, :off] + ss[:, off:2 * off]).astype(np.float32)
+    return np.sqrt(ss[:, 0]).astype(np.float32)
+
+
+def _nn_cosine_distance_device_rule(x, y):
+    x = np.ascontiguousarray(np.asarray(x), dtype=np.float32)
+    y = np.ascontiguousarray(np.asarray(y), dtype=np.float32)
+    acc = np.zeros((len(x), len(y)), dtype=np.float32)
+    for k in range(x.shape[1]):
+        acc = _fma32(x[:, k:k + 1], y[None, :, k], acc)
+    den = (_norm_device_rule(x)[:, None] * _norm_device_rule(y)[None, :]).astype(np.float32)
+    dist = (np.float32(1.0) - (acc / den).astype(np.float32)).astype(np.float32)
+    return dist.min(axis=0)
+
+
 def iou_tlwh(bbox, candidates):                     # iou_matching.py:10-46
     bbox_tl, bbox_br = bbox[:2], bbox[:2] + bbox[2:]
     c_tl, c_br = candidates[:, :2], candidates[:, :2] + candidates[:, 2:]
@@ -180,7 +220,12 @@ def iou_tlwh(bbox, candidates):                     # iou_matching.py:10-46
 
 
 class StrongSortOracle:
-    def __init__(self, reid=None, **kw):
+    def __init__(self, reid=None, dot_rule: str = "numpy", **kw):
+        """``dot_rule``: "numpy" = the reference's calls (NumPy / OpenBLAS float32 product); "device" = the HIP kernels'
+        documented fp32 summation order (see _nn_cosine_distance_device_rule) -- same algorithm, a defined rounding."""
+        if dot_rule not in ("numpy", "device"):
+            raise ValueError("dot_rule must be 'numpy' or 'device'")
+        self.dot_rule = dot_rule
         cfg = dict(DEFAULTS)
         unknown = set(kw) - set(cfg)
         if unknown:
@@ -220,8 +265,11 @@ class StrongSortOracle:
     def _gated_metric(self, tracks, dets, track_idx, det_idx):       # tracker.py:110-125, linear_assignment.py:145-198
         feats = np.array([dets[i].feat for i in det_idx])
         cost = np.zeros((len(track_idx), len(feats)))
+        self.last_app = {}                  # (track id, detection index) -> raw appearance distance of this frame (parity debugging)
         for i, t in enumerate(track_idx):
-            cost[i, :] = _nn_cosine_distance(self.samples[tracks[t].id], feats)
+            cost[i, :] = (_nn_cosine_distance_device_rule if self.dot_rule == "device" else _nn_cosine_distance)(self.samples[tracks[t].id], feats)
+            for j, di in enumerate(det_idx):
+                self.last_app[(tracks[t].id, int(dets[di].det_ind))] = np.float32(cost[i, j])
         meas = np.asarray([dets[i].to_xyah() for i in det_idx])
         for row, t in enumerate(track_idx):
             gd = kf_gating_distance(tracks[t].mean, tracks[t].cov, meas)
@@ -244,6 +292,7 @@ class StrongSortOracle:
         """dets (N,6) [x1,y1,x2,y2,conf,cls] -> (M,8) fp32 rows (what ``StrongSort.update`` hands back)."""
         c = self.cfg
         self.frame_count += 1
+        self.last_app = {}
         dets = np.asarray(dets)
         if dets.size == 0:
             dets = np.empty((0, 7), dtype=np.float32)
@@ -281,7 +330,8 @@ class StrongSortOracle:
         for ti in un_t:
             tracks[ti].mark_missed()
         for di in un_d:
-            tracks.append(_Track(D[di], self.next_id, c["n_init"], c["max_age"], c["ema_alpha"]))
+            norm = (lambda v: _norm_device_rule(np.asarray(v, dtype=np.float32)[None, :])[0]) if self.dot_rule == "device" else np.linalg.norm
+            tracks.append(_Track(D[di], self.next_id, c["n_init"], c["max_age"], c["ema_alpha"], norm))
             self.next_id += 1
         self.tracks = tracks = [t for t in tracks if t.state != DELETED]
         active = [t.id for t in tracks if t.state == CONFIRMED]

@@ -187,6 +187,13 @@ class EmuStrongSort:
             raise RuntimeError(f"emulated kernel status {status}")
         return out[: out_n.value].copy()
 
+    def app(self, rows: int, cols: int) -> np.ndarray:
+        """Appearance distances of the last step: [list position before the step][detection index], fp32."""
+        out = np.zeros((max(rows, 1), max(cols, 1)), dtype=np.float32)
+        self.lib.emu_ss_app.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        self.lib.emu_ss_app(self.h, out.ctypes.data, out.shape[0], out.shape[1])
+        return out[:rows, :cols]
+
     def dump(self):
         ints = np.zeros((self.cap, 6), dtype=np.int32)
         kf = np.zeros((self.cap, 72), dtype=np.float64)

@@ -108,3 +108,28 @@ def test_emulated_kernels_clean_under_asan():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900)
     assert "ASAN-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+
+
+def test_device_dot_rule_reproduces_the_kernels_appearance_costs_bit_for_bit():
+    """StrongSortOracle(dot_rule="device") restates the kernels' documented fp32 summation order (lane-strided fmaf + butterfly
+    for the norms, one fmaf per k for the products, 1 - dot / (|a| |b|)): every appearance distance the bank kernel produces is
+    bit-identical to the oracle's, frame after frame -- the cost matrix, not just the ids, is pinned."""
+    frames = stress_frames(40, seed=13, max_objects=24)
+    cfg = dict(DEFAULTS)
+    orc, emu = StrongSortOracle(dot_rule="device"), EmuStrongSort(cfg, cap=128, nd=64, dim=32)
+    checked = 0
+    try:
+        prev_ids = []
+        for t, (d, e) in enumerate(frames):
+            want = orc.update(d.copy(), None, e.copy()).reshape(-1, 8)
+            got = emu.update(d, e)
+            assert got.shape == want.shape and np.array_equal(got[:, 4:], want[:, 4:]), t
+            app = emu.app(len(prev_ids), len(d))
+            for (tid, j), v in getattr(orc, "last_app", {}).items():
+                r = prev_ids.index(tid)
+                assert app[r, j].tobytes() == np.float32(v).tobytes(), (t, tid, j, float(app[r, j]), float(v))
+                checked += 1
+            prev_ids = emu.dump()["ints"][:, 0].tolist()
+    finally:
+        emu.close()
+    assert checked > 500

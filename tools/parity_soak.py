@@ -1,5 +1,5 @@
 """Long parity soak (development tool): many seeds x long stress sequences, HIP trackers vs oracles, ids/rows exact.
-    python tools/parity_soak.py [n_seeds] [n_frames] [tracker,tracker,...]"""
+    python tools/parity_soak.py [n_seeds] [n_frames] [tracker,tracker,...] [first_seed = 100]      trackers: botsort deepocsort strongsort strongsort_blas bytetrack ocsort"""
 import sys
 import time
 from pathlib import Path
@@ -14,6 +14,7 @@ def main():
     n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 6
     n_frames = int(sys.argv[2]) if len(sys.argv) > 2 else 300
     only = set(sys.argv[3].split(",")) if len(sys.argv) > 3 else None
+    first = int(sys.argv[4]) if len(sys.argv) > 4 else 100
     from boxmot_amd import BotSort, ByteTrack, DeepOcSort, OcSort, StrongSort
     from boxmot_amd.scenario import camera_warps, stress_frames
     from oracle.botsort import BotSortOracle
@@ -32,8 +33,10 @@ def main():
 
     img = np.zeros((480, 640, 3), np.uint8)
     bad = 0
+    from collections import Counter
+    per = Counter()
     t0 = time.time()
-    for seed in range(100, 100 + n_seeds):
+    for seed in range(first, first + n_seeds):
         frames = stress_frames(n_frames, seed=seed, max_objects=20 + seed % 17)
         warps = camera_warps(n_frames, seed=seed)
         use_w = seed % 2 == 0
@@ -41,7 +44,11 @@ def main():
             ("botsort", lambda c: BotSort(use_cmc=use_w, cmc=c, emb_dim=32, max_tracks=1024, max_dets=64), lambda: BotSortOracle()),
             ("deepocsort", lambda c: DeepOcSort(cmc_off=not use_w, cmc=c, emb_dim=32, max_tracks=1024, max_dets=64),
              lambda: DeepOcSortOracle(lap_rule="lowest_index")),
-            ("strongsort", lambda c: StrongSort(cmc=c if use_w else None, emb_dim=32, max_tracks=1024, max_dets=64), lambda: StrongSortOracle()),
+            # StrongSORT against the oracle under the device's documented fp32 summation order (exact bar) and, as "strongsort_blas",
+            # against the reference's NumPy / OpenBLAS product (ids can differ where clamped costs tie)
+            ("strongsort", lambda c: StrongSort(cmc=c if use_w else None, emb_dim=32, max_tracks=1024, max_dets=64),
+             lambda: StrongSortOracle(dot_rule="device")),
+            ("strongsort_blas", lambda c: StrongSort(cmc=c if use_w else None, emb_dim=32, max_tracks=1024, max_dets=64), lambda: StrongSortOracle()),
             ("bytetrack", lambda c: ByteTrack(max_tracks=1024, max_dets=64), lambda: ByteTrackOracle()),
             ("ocsort", lambda c: OcSort(max_tracks=1024, max_dets=64), lambda: OcSortOracle(lap_rule="lowest_index")),
         ]
@@ -64,10 +71,11 @@ def main():
                           flush=True)
                     ok = False
                     bad += 1
+                    per[name] += 1
                     break
             trk.close()
             print(f"{name} seed {seed} warp={use_w} {'ok' if ok else 'FAIL'} ({time.time() - t0:.0f}s)", flush=True)
-    print("mismatches", bad)
+    print("mismatches", bad, dict(per))
 
 
 if __name__ == "__main__":
