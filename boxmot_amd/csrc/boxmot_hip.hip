@@ -461,7 +461,10 @@ void host_update(BoxMOTHipBotSort* h, int s0, int n, const StreamIn* in, int det
         if (rows < -1) throw std::runtime_error("Negative matrix dimensions are not allowed.");
         if (rows > 0 && det_cols == 7) throw std::runtime_error("boxmot_hip: OBB detections (7 columns) are not implemented");
         if (rows > 0 && det_cols != 6) throw std::runtime_error("boxmot_hip live tracking supports AABB detections with 6 columns.");
-        if (rows > nd) throw std::runtime_error("boxmot_hip: more detections than max_dets");
+        if (rows > nd)
+            throw std::runtime_error("boxmot_hip: more detections than max_dets (" + std::to_string(rows) + " > " + std::to_string(nd) +
+                                     "): max_dets / max_tracks are the capacities of the device-resident tables, fixed at create; the "
+                                     "reference has no such limit -- construct the tracker with a larger max_dets");
         if (rows > 0 && in[k].dets == nullptr) throw std::runtime_error("Detection data pointer is null.");
         if (out_capacity_rows < rows) throw std::runtime_error("boxmot_hip: output buffer is too small for the current frame.");
         if (in[k].embs != nullptr && emb_cols != dim && rows > 0)
@@ -603,7 +606,10 @@ bool io_stage(StreamIo* h, int n, const StreamIn* in, int det_cols, int emb_cols
         const int rows = in[k].det_rows;
         if (rows < -1) throw std::runtime_error("Negative matrix dimensions are not allowed.");
         if (rows > 0 && det_cols != 6) throw std::runtime_error("boxmot_hip live tracking supports AABB detections with 6 columns.");
-        if (rows > nd) throw std::runtime_error("boxmot_hip: more detections than max_dets");
+        if (rows > nd)
+            throw std::runtime_error("boxmot_hip: more detections than max_dets (" + std::to_string(rows) + " > " + std::to_string(nd) +
+                                     "): max_dets / max_tracks are the capacities of the device-resident tables, fixed at create; the "
+                                     "reference has no such limit -- construct the tracker with a larger max_dets");
         if (rows > 0 && in[k].dets == nullptr) throw std::runtime_error("Detection data pointer is null.");
         if (out_capacity_rows < rows) throw std::runtime_error("boxmot_hip: output buffer is too small for the current frame.");
         if (want_emb && in[k].embs != nullptr && emb_cols != dim && rows > 0)

@@ -112,19 +112,14 @@ private:
     static void set_gemm_lds() {
         check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_glds<EPI, 64>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   gemm_glds_lds_bytes<64>()), "GEMM LDS");
-        check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_glds<EPI, 32>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  gemm_glds_lds_bytes<32>()), "GEMM LDS");
     }
     template <int EPI>
     void gemm(const _Float16* X, const _Float16* W, const float* bias, void* C, long M, int N, int K, hipStream_t st) {
         if (N % GEMM_BN != 0 || K % GEMM_BK != 0) throw std::runtime_error("CLIP-ReID: GEMM shape not tileable");
         const dim3 grid((unsigned)(((M + GEMM_BM - 1) / GEMM_BM) * (N / GEMM_BN)));       // 1-D: the kernels map ids to tiles XCD-aware
-        if (bk32_)
-            hipLaunchKernelGGL((k_gemm_f16_glds<EPI, 32>), grid, dim3(256), gemm_glds_lds_bytes<32>(), st, X, W, bias, C,
-                               static_cast<const _Float16*>(nullptr), (int)M, N, K, 0);
-        else if (K % 64 == 0)
+        if (K % 64 == 0)     // 64-wide k-tiles: 11.7 ms per 256-crop forward vs 13.3 ms with 32-wide ones (profiles/r2_gemm_pipeline_ab.txt)
             hipLaunchKernelGGL((k_gemm_f16_glds<EPI, 64>), grid, dim3(256), gemm_glds_lds_bytes<64>(), st, X, W, bias, C,
-                               static_cast<const _Float16*>(nullptr), (int)M, N, K, 0);
+                               static_cast<const _Float16*>(nullptr), (int)M, N, K, 0, GemmExt{});
         else
             hipLaunchKernelGGL((k_gemm_f16<EPI>), grid, dim3(256), 0, st, X, W, bias, C, static_cast<const _Float16*>(nullptr), (int)M, N, K, 0);
     }
@@ -133,7 +128,6 @@ private:
     }
 
     int max_crops_;
-    bool bk32_ = std::getenv("BOXMOT_HIP_CLIP_BK32") != nullptr;       // A/B switch: 32-wide k-tiles (32 KiB of LDS) for the linear layers
     std::vector<ClipLayerOff> L_;
     long o_conv_ = 0, o_cls_ = 0, o_pos_ = 0, o_lnpre_w_ = 0, o_lnpre_b_ = 0, o_lnpost_w_ = 0, o_lnpost_b_ = 0, o_proj_ = 0;
     long o_bn_s_ = 0, o_bn_b_ = 0, o_bnp_s_ = 0, o_bnp_b_ = 0;

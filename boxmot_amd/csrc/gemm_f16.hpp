@@ -175,13 +175,25 @@ __global__ void __launch_bounds__(256) k_gemm_f16(const _Float16* __restrict__ X
 // address; with ds_read_b128's lane groups ({0-3, 12-15, 20-27}, ...) every 16-byte fragment read is then bank-conflict free.
 // Rows beyond M re-read row M - 1 (their results are never stored).
 // ---------------------------------------------------------------------------
+// optional extras of k_gemm_f16_glds:
+//   X2 / W2 / K2   a second (activation, weight) pair whose product is added into the same accumulators (K2 % BK == 0): two 1x1
+//                  convolutions with a common output -- an OSBlock's conv3(x2) + downsample(x) -- as ONE launch, the sum never in HBM
+//   pool_w         EPI 5 only: image width in pixels (16 or 32); the epilogue then applies ReLU and the 2 x 2 average pool of the
+//                  transition layers (osnet.py:349) on the accumulators and stores the POOLED tensor [rows / 4][N]
+struct GemmExt {
+    const _Float16* X2 = nullptr;
+    const _Float16* W2 = nullptr;
+    int K2 = 0;
+    int pool_w = 0;
+};
+
 template <int BK>
 __host__ __device__ constexpr int gemm_glds_lds_bytes() { return 2 * 2 * 128 * BK * 2; }
 
 template <int EPI, int BK>
 __global__ void __launch_bounds__(256) k_gemm_f16_glds(const _Float16* __restrict__ X, const _Float16* __restrict__ Wt,
                                                        const float* __restrict__ bias, void* __restrict__ Cout,
-                                                       const _Float16* __restrict__ res, int M, int N, int K, int relu) {
+                                                       const _Float16* __restrict__ res, int M, int N, int K, int relu, GemmExt ext) {
     static_assert(BK == 32 || BK == 64, "k-tile");
     BM_DYNAMIC_LDS_T(unsigned char, lds_raw);
     _Float16* lds = reinterpret_cast<_Float16*>(lds_raw);
@@ -199,7 +211,7 @@ __global__ void __launch_bounds__(256) k_gemm_f16_glds(const _Float16* __restric
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = cf4{0.f, 0.f, 0.f, 0.f};
     // copy i of this wave moves LDS chunks p = (NI wave + i) * 64 + lane of an operand tile: row p / CH, slot p % CH
-    const _Float16 *gw[NI], *gx[NI];
+    const _Float16 *gw[NI], *gx[NI], *gw2[NI], *gx2[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int p = (NI * wave + i) * 64 + lane, r = p / CH, c = (p % CH) ^ swz(r);
@@ -207,14 +219,19 @@ __global__ void __launch_bounds__(256) k_gemm_f16_glds(const _Float16* __restric
         if (m >= M) m = M - 1;
         gw[i] = Wt + (long)(n0 + r) * K + 8 * c;
         gx[i] = X + m * K + 8 * c;
+        gw2[i] = ext.W2 + (long)(n0 + r) * ext.K2 + 8 * c;
+        gx2[i] = ext.X2 + m * ext.K2 + 8 * c;
     }
-    auto issue = [&](int k0, int buf) {
+    const int nk1 = K / BK, nk = nk1 + ext.K2 / BK;
+    auto issue = [&](int kt, int buf) {          // k-tile kt: one of the first operand pair's nk1 tiles, then the second pair's
         _Float16* dW = lds + buf * 2 * TILE;
         _Float16* dX = dW + TILE;
+        const bool second = kt >= nk1;
+        const int k0 = (second ? kt - nk1 : kt) * BK;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            BM_GLDS16(gw[i] + k0, dW + (NI * wave + i) * 512, lane);
-            BM_GLDS16(gx[i] + k0, dX + (NI * wave + i) * 512, lane);
+            BM_GLDS16((second ? gw2[i] : gw[i]) + k0, dW + (NI * wave + i) * 512, lane);
+            BM_GLDS16((second ? gx2[i] : gx[i]) + k0, dX + (NI * wave + i) * 512, lane);
         }
     };
     issue(0, 0);
@@ -232,10 +249,9 @@ __global__ void __launch_bounds__(256) k_gemm_f16_glds(const _Float16* __restric
                 }
         }
     }
-    const int nk = K / BK;
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();                    // tile kt has landed (the barrier drains the copies) and buffer (kt + 1) & 1 is free
-        if (kt + 1 < nk) issue((kt + 1) * BK, (kt + 1) & 1);
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
         const _Float16* sW = lds + (kt & 1) * 2 * TILE;
         const _Float16* sX = sW + TILE;
         // every fragment of the tile is requested before the first MFMA: the reads of k-step 1 land under the MFMAs of k-step 0
@@ -254,6 +270,37 @@ __global__ void __launch_bounds__(256) k_gemm_f16_glds(const _Float16* __restric
             for (int p = 0; p < 4; ++p)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) acc[p][t] = BM_MFMA_F16_K32(a[s][p], b[s][t], acc[p][t]);
+    }
+    if constexpr (EPI == 5) {
+        // transition layer: ReLU(conv + bias) then the 2 x 2 average pool, on the accumulators.  A lane holds 4 features of pixel
+        // (row tile t, l16); its horizontal partner is lane l16 ^ 1 (quad swap), its vertical partner -- one image row = pool_w
+        // pixels further -- is row tile t + pool_w / 16 of the same lane (a 128-row tile holds whole pairs of image rows).
+        const int dt = ext.pool_w / 16;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int n = n0 + wn * 64 + p * 16 + 4 * g;
+            float bv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[r] = bias ? bias[n + r] : 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if ((t / dt) & 1) continue;                      // the lower image row of a pair: folded into its upper one
+                const long m = m0 + wm * 64 + t * 16 + l16;
+                ch4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float top = acc[p][t][r] + bv[r], bot = acc[p][(t + dt) & 3][r] + bv[r];
+                    float v = (top > 0.f ? top : 0.f) + (bot > 0.f ? bot : 0.f);
+                    v = v + BM_QUAD_SWAP1_F32(v);
+                    o[r] = (_Float16)(v * 0.25f);
+                }
+                if (m < M && (l16 & 1) == 0) {
+                    const long q = m / ext.pool_w, x = m - q * ext.pool_w;           // q = crop * H + y (y even)
+                    *reinterpret_cast<ch4*>(static_cast<_Float16*>(Cout) + ((q >> 1) * (ext.pool_w / 2) + (x >> 1)) * N + n) = o;
+                }
+            }
+        }
+        return;
     }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {

@@ -45,12 +45,25 @@ public:
         }
         const size_t first = n * 2048 * (size_t)c0;
         blk = first > blk ? first : blk;
-        act_a_ = alloc<_Float16>(blk, owned); act_b_ = alloc<_Float16>(blk, owned); idn_ = alloc<_Float16>(blk, owned);
+        act_a_ = alloc<_Float16>(blk, owned); act_b_ = alloc<_Float16>(blk, owned);
         for (auto& m : mid_) m = alloc<_Float16>(mid, owned);
         gap_part_ = alloc<float>(4 * n * (64 / WIDE_BAND) * 128, owned);
         set_light_lds<32>(); set_light_lds<64>(); set_light_lds<96>(); set_light_lds<128>();
         check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_glds<4, 32>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   gemm_glds_lds_bytes<32>()), "GEMM LDS");
+        check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_glds<5, 32>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  gemm_glds_lds_bytes<32>()), "GEMM LDS");
+        // conv3 + downsample run as one GEMM: their folded-BN biases add up
+        std::vector<float> bs;
+        for (int b = 0; b < 6; ++b) {
+            const BlockW& B = L.block[b];
+            bsum_off_[b] = -1;
+            if (B.down_w < 0) continue;
+            bsum_off_[b] = (long)bs.size();
+            for (int c = 0; c < B.cout; ++c) bs.push_back(h_w[B.conv3_b + c] + h_w[B.down_b + c]);
+        }
+        d_bsum_ = alloc<float>(bs.size(), owned);
+        if (!bs.empty()) check(hipMemcpy(d_bsum_, bs.data(), bs.size() * 4, hipMemcpyHostToDevice), "upload summed biases");
     }
 
     _Float16* crops_buffer() { return crops16_; }
@@ -75,9 +88,10 @@ public:
             }
             if (s < 2) {
                 const int c = L_.c[s + 1];
-                gemm(cur, d_w16_ + pk_.of(L_.trans_w[s]), d_w_ + L_.trans_b[s], other, nullptr, (long)n * H * W, c, c, 1, st);
-                t8 = (long)n * (H / 2) * (W / 2) * (c / 8);
-                hipLaunchKernelGGL(k_avgpool2x2_h8, dim3((unsigned)((t8 + 255) / 256)), dim3(256), 0, st, other, cur, H, W, c, t8);
+                GemmExt pool;
+                pool.pool_w = W;
+                gemm(cur, d_w16_ + pk_.of(L_.trans_w[s]), d_w_ + L_.trans_b[s], other, nullptr, (long)n * H * W, c, c, 1, st, pool);
+                std::swap(cur, other);
                 H /= 2; W /= 2;
             }
         }
@@ -105,12 +119,16 @@ private:
     }
     // 1x1 convolution over n_pix pixels: out = [relu](X . W^T + bias [+ res])
     void gemm(const _Float16* X, const _Float16* W, const float* bias, _Float16* out, const _Float16* res, long M, int N, int K,
-              int relu, hipStream_t st) {
+              int relu, hipStream_t st, GemmExt ext = GemmExt{}) {
         if (K % GEMM_BK != 0 || N % 32 != 0) throw std::runtime_error("wide OSNet: GEMM shape not tileable");
         const long mt = (M + GEMM_BM - 1) / GEMM_BM;          // 1-D grids: the kernels map workgroup ids to tiles XCD-aware
         void* o = static_cast<void*>(out);
-        if (N % 128 == 0)
-            hipLaunchKernelGGL((k_gemm_f16_glds<4, 32>), dim3((unsigned)(mt * (N / 128))), dim3(256), gemm_glds_lds_bytes<32>(), st, X, W, bias, o, res, (int)M, N, K, relu);
+        if (ext.pool_w) {       // transition: conv + ReLU + 2 x 2 average pool in one launch (M must hold whole pairs of image rows per tile)
+            if (N % 128 != 0 || (ext.pool_w != 16 && ext.pool_w != 32)) throw std::runtime_error("wide OSNet: pooled GEMM shape");
+            hipLaunchKernelGGL((k_gemm_f16_glds<5, 32>), dim3((unsigned)(mt * (N / 128))), dim3(256), gemm_glds_lds_bytes<32>(), st, X, W, bias, o, res, (int)M, N, K, relu, ext);
+        } else if (N % 128 == 0)
+            hipLaunchKernelGGL((k_gemm_f16_glds<4, 32>), dim3((unsigned)(mt * (N / 128))), dim3(256), gemm_glds_lds_bytes<32>(), st, X, W, bias, o, res, (int)M, N, K, relu, ext);
+        else if (ext.K2) throw std::runtime_error("wide OSNet: the two-operand GEMM needs N % 128 == 0");
         else if (N % 96 == 0) hipLaunchKernelGGL((k_gemm_f16<4, 96>), dim3((unsigned)(mt * (N / 96))), dim3(256), 0, st, X, W, bias, o, res, (int)M, N, K, relu);
         else if (N % 64 == 0) hipLaunchKernelGGL((k_gemm_f16<4, 64>), dim3((unsigned)(mt * (N / 64))), dim3(256), 0, st, X, W, bias, o, res, (int)M, N, K, relu);
         else hipLaunchKernelGGL((k_gemm_f16<4, 32>), dim3((unsigned)(mt * (N / 32))), dim3(256), 0, st, X, W, bias, o, res, (int)M, N, K, relu);
@@ -160,12 +178,12 @@ private:
             case 128: gate_t<128>(B, brs, x2, n, H * W, nbands, st); break;
             default: throw std::runtime_error("wide OSNet: unsupported middle width");
         }
-        const _Float16* identity = x;
-        if (B.down_w >= 0) {
-            gemm(x, d_w16_ + pk_.of(B.down_w), d_w_ + B.down_b, idn_, nullptr, n_pix, B.cout, B.cin, 0, st);
-            identity = idn_;
-        }
-        gemm(x2, d_w16_ + pk_.of(B.conv3_w), d_w_ + B.conv3_b, out, identity, n_pix, B.cout, B.mid, 1, st);
+        if (B.down_w >= 0) {        // out = relu(conv3(x2) + downsample(x)): one GEMM over the two operand pairs, the shortcut tensor never exists
+            GemmExt two;
+            two.X2 = x; two.W2 = d_w16_ + pk_.of(B.down_w); two.K2 = B.cin;
+            gemm(x2, d_w16_ + pk_.of(B.conv3_w), d_bsum_ + bsum_off_[&B - L_.block], out, nullptr, n_pix, B.cout, B.mid, 1, st, two);
+        } else
+            gemm(x2, d_w16_ + pk_.of(B.conv3_w), d_w_ + B.conv3_b, out, x, n_pix, B.cout, B.mid, 1, st);
     }
 
     OsnetLayout L_;
@@ -173,9 +191,11 @@ private:
     const float* d_w_;                       // the engine's fp32 blob on the device (biases, depthwise taps, gate and FC weights)
     int max_crops_;
     _Float16 *d_w16_ = nullptr, *d_stem16_ = nullptr;
-    _Float16 *crops16_ = nullptr, *stem_out_ = nullptr, *act_a_ = nullptr, *act_b_ = nullptr, *idn_ = nullptr;
+    _Float16 *crops16_ = nullptr, *stem_out_ = nullptr, *act_a_ = nullptr, *act_b_ = nullptr;
     _Float16* mid_[8] = {};
     float* gap_part_ = nullptr;
+    float* d_bsum_ = nullptr;
+    long bsum_off_[6] = {};
 };
 
 }  // namespace bm

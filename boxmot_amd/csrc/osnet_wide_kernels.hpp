@@ -8,8 +8,9 @@
 // fed without per-crop workgroups:
 //   * activations: fp16 NHWC [crop][pixel][channel] in HBM, fp32 accumulation everywhere, fp32 folded-BN biases
 //   * every 1x1 convolution (conv1, conv3 + shortcut + ReLU, downsample, transitions, conv5) is one
-//     launch of k_gemm_f16 / k_gemm_f16_glds (gemm_f16.hpp) with bias / residual / ReLU in its epilogue; the 7x7 stem is an
-//     implicit GEMM over an LDS-staged band of the RGBX crop (k_wide_stem)
+//     launch of k_gemm_f16 / k_gemm_f16_glds (gemm_f16.hpp) with bias / residual / ReLU in its epilogue -- conv3 + downsample as ONE
+//     launch over two operand pairs, the transitions with their 2x2 average pool in the epilogue; the 7x7 stem is an
+//     implicit GEMM over an LDS-staged band of the RGBX crop with the 3x3 max pool on its accumulators (k_wide_stem)
 //   * LightConv3x3 = 1x1 (linear) -> depthwise 3x3 + BN + ReLU is ONE kernel (k_light_fused): a workgroup owns a band of 8
 //     image rows of one crop, runs the 1x1 of the band + a one-row halo on the matrix pipe straight from global memory
 //     (weights are <= 32 KB: L1 / L2 resident) into an LDS tile, and the depthwise 3x3 reads that tile with a sliding
@@ -40,101 +41,102 @@ inline bool wide_osnet_supports(const OsnetLayout& L) {
 }
 
 // ---------------------------------------------------------------------------
-// Stem: conv 7x7, stride 2, pad 3 (3 -> C0) + folded BN + ReLU (osnet.py:294) as an implicit GEMM on the matrix pipe.
+// Stem: conv 7x7, stride 2, pad 3 (3 -> C0) + folded BN + ReLU + max pool 3x3, stride 2, pad 1 (osnet.py:294-295) in one launch: an
+// implicit GEMM on the matrix pipe with the pool on the accumulators (the 128 x 64 x C0 convolution output never reaches HBM).
 //   crops  fp16 RGBX with a 3-pixel zero border, [n][262][136][4] (k_crop_resize_rgbx): 8 input pixels x RGBX = 32 halves = one
 //          MFMA k-step per kernel row, and the B fragment of conv pixel cx, lane group g is the 16 bytes at pixel 2 cx + 2 g
 //   wts    fp16 A fragments [ky][channel tile][lane][8]: lane (co = lane & 15, g), k-slot j -> tap kx = 2 g + (j >> 2), channel
 //          j & 3 (zero for kx = 7 and the X channel), packed by wide_pack_w16
-//   out    fp16 NHWC [n][128 * 64][C0]
-// grid (16 bands of 8 conv rows, crops), 256 threads.  The 21 input rows of a band are staged once into LDS (16-byte copies);
-// wave w owns channel tile w % (C0 / 16) and every (4 * 16 / C0)-th conv row of the band, with its seven A fragments in
-// registers: 7 x (ds_read_b128 + MFMA) per 16 conv pixels.
+//   out    fp16 NHWC [n][64 * 32][C0]
+// grid (16 bands of 4 pooled rows, crops), 256 threads.  The 23 input rows of a band (its 9 conv rows: 8 + the one above) are
+// staged once into LDS (16-byte copies); wave w owns channel tile w % (C0 / 16) -- its seven A fragments stay in registers -- and
+// a run of consecutive pooled rows, sliding over the conv rows: 7 x (ds_read_b128 + MFMA) per 16 conv pixels, vertical max in
+// registers, horizontal max by DPP row shifts (conv values are >= 0 after the ReLU, so a missing neighbour reads as 0).
 // ---------------------------------------------------------------------------
-constexpr int WSTEM_ROWS = 262, WSTEM_COLS = 136, WSTEM_BAND = 8;
-constexpr int WSTEM_LDS_BYTES = (2 * WSTEM_BAND + 5) * WSTEM_COLS * 8;
+constexpr int WSTEM_ROWS = 262, WSTEM_COLS = 136, WSTEM_PBAND = 4;
+constexpr int WSTEM_IN_ROWS = 4 * WSTEM_PBAND + 7;                   // conv rows 8 b - 1 .. 8 b + 7 read input rows 16 b - 2 .. 16 b + 20
 
 template <int C0>
 __global__ void __launch_bounds__(256) k_wide_stem(const _Float16* __restrict__ crops, const _Float16* __restrict__ wts,
                                                    const float* __restrict__ bias, _Float16* __restrict__ out) {
     static_assert(C0 == 32 || C0 == 64, "stem width");
-    constexpr int NCT = C0 / 16, NRG = 4 / NCT, IN_ROWS = 2 * WSTEM_BAND + 5;
-    __shared__ __attribute__((aligned(16))) _Float16 sIn[IN_ROWS * WSTEM_COLS * 4];
+    constexpr int NCT = C0 / 16, NRG = 4 / NCT, PR = WSTEM_PBAND / NRG;          // channel tiles, row groups, pooled rows per wave
+    __shared__ __attribute__((aligned(16))) _Float16 sIn[WSTEM_IN_ROWS * WSTEM_COLS * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l16 = lane & 15;
     const int band = blockIdx.x;
     const long crop = blockIdx.y;
-    const int cy0 = band * WSTEM_BAND;
-    const _Float16* src = crops + (crop * WSTEM_ROWS + 2 * cy0) * (long)(WSTEM_COLS * 4);
-    for (int e = tid; e < IN_ROWS * WSTEM_COLS / 2; e += 256)          // 16-byte chunks = 2 pixels
-        *reinterpret_cast<cu4*>(sIn + e * 8) = *reinterpret_cast<const cu4*>(src + e * 8);
+    const int in0 = 16 * band - 2;                                    // first staged (padded) input row; negative rows do not exist
+    const _Float16* img = crops + crop * WSTEM_ROWS * (long)(WSTEM_COLS * 4);
+    for (int e = tid; e < WSTEM_IN_ROWS * WSTEM_COLS / 2; e += 256) {            // 16-byte chunks = 2 pixels
+        const int r = e / (WSTEM_COLS / 2), row = in0 + r;
+        cu4 v = cu4{0u, 0u, 0u, 0u};
+        if (row >= 0 && row < WSTEM_ROWS) v = *reinterpret_cast<const cu4*>(img + (long)row * (WSTEM_COLS * 4) + (e - r * (WSTEM_COLS / 2)) * 8);
+        *reinterpret_cast<cu4*>(sIn + e * 8) = v;
+    }
     const int ct = wave % NCT, rg = wave / NCT;
     ch8 a[7];
 #pragma unroll
     for (int ky = 0; ky < 7; ++ky) a[ky] = *reinterpret_cast<const ch8*>(wts + ((long)(ky * NCT + ct) * 64 + lane) * 8);
-    float bv[4];
+    cf4 bv;
 #pragma unroll
     for (int r = 0; r < 4; ++r) bv[r] = bias[16 * ct + 4 * g + r];
     __syncthreads();
-    for (int lr = rg; lr < WSTEM_BAND; lr += NRG) {
-        _Float16* orow = out + ((crop * 128 + cy0 + lr) * 64) * (long)C0 + 16 * ct + 4 * g;
+    // conv row cy (global index) for the 4 tiles of 16 conv pixels; rows outside the image contribute 0 to the pool
+    auto conv_row = [&](int cy, cf4 (&row)[4]) {
+        if (cy < 0 || cy > 127) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) row[t] = cf4{0.f, 0.f, 0.f, 0.f};
+            return;
+        }
+        const int lr = 2 * cy - in0;                                  // staged row of kernel row 0
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int cx = 16 * t + l16;
-            cf4 acc = cf4{bv[0], bv[1], bv[2], bv[3]};
+            cf4 acc = bv;
 #pragma unroll
             for (int ky = 0; ky < 7; ++ky) {
-                const ch8 b = *reinterpret_cast<const ch8*>(sIn + ((2 * lr + ky) * WSTEM_COLS + 2 * cx + 2 * g) * 4);
+                const ch8 b = *reinterpret_cast<const ch8*>(sIn + ((lr + ky) * WSTEM_COLS + 2 * cx + 2 * g) * 4);
                 acc = BM_MFMA_F16_K32(a[ky], b, acc);
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) row[t][r] = acc[r] > 0.f ? acc[r] : 0.f;
+        }
+    };
+    const int py0 = WSTEM_PBAND * band + rg * PR;
+    cf4 prev[4], mid[4], next[4];
+    conv_row(2 * py0 - 1, prev);
+#pragma unroll 1
+    for (int py = py0; py < py0 + PR; ++py) {
+        conv_row(2 * py, mid);
+        conv_row(2 * py + 1, next);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
             ch4 o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (_Float16)(acc[r] > 0.f ? acc[r] : 0.f);
-            *reinterpret_cast<ch4*>(orow + (long)cx * C0) = o;
+            for (int r = 0; r < 4; ++r) {
+                float v = prev[t][r] > mid[t][r] ? prev[t][r] : mid[t][r];
+                v = v > next[t][r] ? v : next[t][r];
+                float vp = 0.f;                                        // the same vertical max in the previous tile (for lane 0's left neighbour)
+                if (t > 0) {
+                    vp = prev[t - 1][r] > mid[t - 1][r] ? prev[t - 1][r] : mid[t - 1][r];
+                    vp = vp > next[t - 1][r] ? vp : next[t - 1][r];
+                }
+                const float right = BM_ROW_SHL1_F32(v);
+                float left = BM_ROW_SHR1_F32(v);
+                const float left_prev_tile = BM_ROW_ROR1_F32(vp);
+                if (l16 == 0) left = left_prev_tile;
+                float m = v > right ? v : right;
+                m = m > left ? m : left;
+                o[r] = (_Float16)m;
+            }
+            if ((l16 & 1) == 0) {                                      // pooled pixel ox = cx / 2 sits on the even lanes
+                const long p = (long)py * 32 + t * 8 + (l16 >> 1);
+                *reinterpret_cast<ch4*>(out + (crop * 2048 + p) * C0 + 16 * ct + 4 * g) = o;
+            }
         }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) prev[t] = next[t];
     }
-}
-
-// max pool 3x3 stride 2 pad 1 (osnet.py:295) / 2x2 average pool (osnet.py:349), fp16 NHWC, 8 channels per thread
-__global__ void __launch_bounds__(256) k_maxpool3x3s2_h8(const _Float16* __restrict__ in, _Float16* __restrict__ out, int H, int W, int C, long total8) {
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total8) return;
-    const int C8 = C / 8, OW = W / 2, OH = H / 2;
-    const int cg = (int)(e % C8);
-    const int ox = (int)((e / C8) % OW), oy = (int)((e / ((long)C8 * OW)) % OH);
-    const long n = e / ((long)C8 * OW * OH);
-    float m[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) m[j] = -3.0e38f;
-    for (int dy = -1; dy <= 1; ++dy) {
-        const int iy = oy * 2 + dy;
-        if (iy < 0 || iy >= H) continue;
-        for (int dx = -1; dx <= 1; ++dx) {
-            const int ix = ox * 2 + dx;
-            if (ix < 0 || ix >= W) continue;
-            const ch8 v = *reinterpret_cast<const ch8*>(in + ((n * H + iy) * W + ix) * C + cg * 8);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) m[j] = (float)v[j] > m[j] ? (float)v[j] : m[j];
-        }
-    }
-    ch8 o;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (_Float16)m[j];
-    *reinterpret_cast<ch8*>(out + e * 8) = o;
-}
-
-__global__ void __launch_bounds__(256) k_avgpool2x2_h8(const _Float16* __restrict__ in, _Float16* __restrict__ out, int H, int W, int C, long total8) {
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total8) return;
-    const int C8 = C / 8, OW = W / 2, OH = H / 2;
-    const int cg = (int)(e % C8);
-    const int ox = (int)((e / C8) % OW), oy = (int)((e / ((long)C8 * OW)) % OH);
-    const long n = e / ((long)C8 * OW * OH);
-    const _Float16* p = in + ((n * H + oy * 2) * W + ox * 2) * C + cg * 8;
-    const ch8 a = *reinterpret_cast<const ch8*>(p), b = *reinterpret_cast<const ch8*>(p + C);
-    const ch8 c = *reinterpret_cast<const ch8*>(p + (long)W * C), d = *reinterpret_cast<const ch8*>(p + (long)W * C + C);
-    ch8 o;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (_Float16)(((float)a[j] + (float)b[j] + (float)c[j] + (float)d[j]) * 0.25f);
-    *reinterpret_cast<ch8*>(out + e * 8) = o;
 }
 
 // ---------------------------------------------------------------------------

@@ -17,6 +17,8 @@ The reference applies its ECC camera-motion object unconditionally; the oracle t
 """
 from __future__ import annotations
 
+import math
+
 import numpy as np
 import scipy.linalg
 import torch
@@ -86,6 +88,96 @@ def kf_gating_distance(mean, cov, measurements):
     return np.sum(z * z, axis=0)
 
 
+# ---- the device's fp64 operation order for the Kalman update and the gating distance ("dot_rule = device") ----
+# The reference solves the 4 x 4 innovation system with LAPACK (cho_factor / cho_solve / solve_triangular) and forms
+# K S K^T with BLAS; the kernels (strongsort_step.hpp: ss_kf_update_wave, ss_gating_distance) use explicit scalar loops --
+# same algebra, sums in a fixed order, no fused multiply-add.  The two agree to ~1e-13 relative, which is enough to flip
+# SciPy's choice among exactly tied (clamped) assignment entries; restated here operation for operation so that the
+# oracle's filter state and gated costs are bit-identical to the device's.
+def _chol4(S):
+    L = [[0.0] * 4 for _ in range(4)]
+    for c in range(4):
+        d = S[c][c]
+        for k in range(c):
+            d -= L[c][k] * L[c][k]
+        d = math.sqrt(d)
+        L[c][c] = d
+        for r in range(c + 1, 4):
+            t = S[r][c]
+            for k in range(c):
+                t -= L[r][k] * L[c][k]
+            L[r][c] = t / d
+    return L
+
+
+def _innovation(mean, cov, confidence, scaled):
+    S = [[float(cov[a, b]) for b in range(4)] for a in range(4)]
+    for a in range(4):
+        base = 1e-1 if a == 2 else STD_POS * float(mean[3])
+        sd = (1 - confidence) * base if scaled else base
+        S[a][a] = S[a][a] + sd * sd
+    return S
+
+
+def kf_update_device_rule(mean, cov, z, confidence):
+    m = [float(x) for x in mean]
+    P = [[float(cov[a, b]) for b in range(8)] for a in range(8)]
+    S = _innovation(mean, cov, float(confidence), True)
+    L = _chol4(S)
+    K = []
+    for r in range(8):                              # row r of the gain: L y = P[r, :4], L^T K = y
+        y = [0.0] * 4
+        for k in range(4):
+            t = P[r][k]
+            for q in range(k):
+                t -= L[k][q] * y[q]
+            y[k] = t / L[k][k]
+        Kr = [0.0] * 4
+        for k in range(3, -1, -1):
+            t = y[k]
+            for q in range(k + 1, 4):
+                t -= L[q][k] * Kr[q]
+            Kr[k] = t / L[k][k]
+        K.append(Kr)
+    new_mean = np.empty(8)
+    for i in range(8):
+        acc = 0.0
+        for a in range(4):
+            acc += (float(z[a]) - m[a]) * K[i][a]
+        v = m[i] + acc
+        if i in (2, 3):
+            v = v if v > 1e-4 else 1e-4
+        new_mean[i] = v
+    new_cov = np.empty((8, 8))
+    for i in range(8):
+        for j in range(8):
+            ksk = 0.0
+            for a in range(4):
+                mj = 0.0
+                for b in range(4):
+                    mj += S[a][b] * K[j][b]
+                ksk += K[i][a] * mj
+            new_cov[i, j] = P[i][j] - ksk
+    return new_mean, new_cov
+
+
+def kf_gating_distance_device_rule(mean, cov, measurements):
+    L = _chol4(_innovation(mean, cov, 0.0, False))
+    out = np.empty(len(measurements))
+    for n, z in enumerate(measurements):
+        y = [0.0] * 4
+        s = 0.0
+        for k in range(4):
+            t = float(z[k]) - float(mean[k])
+            for q in range(k):
+                t -= L[k][q] * y[q]
+            y[k] = t / L[k][k]
+        for k in range(4):
+            s += y[k] * y[k]
+        out[n] = s
+    return out
+
+
 class _Det:
     def __init__(self, tlwh, conf, cls, det_ind, feat):
         self.tlwh, self.conf, self.cls, self.det_ind, self.feat = tlwh, conf, cls, det_ind, feat
@@ -101,6 +193,7 @@ class _Track:
     def __init__(self, det, tid, n_init, max_age, ema_alpha, norm=np.linalg.norm):
         self.id = tid
         self.norm = norm                            # np.linalg.norm (reference) or the device's summation order (dot_rule="device")
+        self.device_rule = norm is not np.linalg.norm
         self.conf, self.cls, self.det_ind = det.conf, det.cls, det.det_ind
         self.hits = self.age = 1
         self.time_since_update = 0
@@ -141,7 +234,7 @@ class _Track:
 
     def update(self, det):
         self.conf, self.cls, self.det_ind = det.conf, det.cls, det.det_ind
-        self.mean, self.cov = kf_update(self.mean, self.cov, det.to_xyah(), self.conf)
+        self.mean, self.cov = (kf_update_device_rule if self.device_rule else kf_update)(self.mean, self.cov, det.to_xyah(), self.conf)
         feature = det.feat / self.norm(det.feat)
         smooth = self.ema_alpha * self.features[-1] + (1 - self.ema_alpha) * feature
         smooth /= self.norm(smooth)
@@ -272,7 +365,7 @@ class StrongSortOracle:
                 self.last_app[(tracks[t].id, int(dets[di].det_ind))] = np.float32(cost[i, j])
         meas = np.asarray([dets[i].to_xyah() for i in det_idx])
         for row, t in enumerate(track_idx):
-            gd = kf_gating_distance(tracks[t].mean, tracks[t].cov, meas)
+            gd = (kf_gating_distance_device_rule if self.dot_rule == "device" else kf_gating_distance)(tracks[t].mean, tracks[t].cov, meas)
             cost[row, gd > CHI2_4] = INFTY_COST
             cost[row] = self.cfg["mc_lambda"] * cost[row] + (1 - self.cfg["mc_lambda"]) * gd
         return cost

@@ -78,10 +78,10 @@ extern "C" int emu_clip_forward(const float* blob, long n_floats, const float* c
     auto gemm = [&](int epi, const _Float16* X, const _Float16* Wt, const float* bias, void* C, long M, int N, int K) {
         const int gx = (int)((M + GEMM_BM - 1) / GEMM_BM), gy = N / GEMM_BN;
         if (K % 64 == 0) {            // the engine's choice (clip_engine.hpp): global_load_lds tiles for the large shapes
-            if (epi == 0) launch(gx * gy, 1, 256, [=]() { k_gemm_f16_glds<0, 64>(X, Wt, bias, C, nullptr, (int)M, N, K, 0); });
-            if (epi == 1) launch(gx * gy, 1, 256, [=]() { k_gemm_f16_glds<1, 64>(X, Wt, bias, C, nullptr, (int)M, N, K, 0); });
-            if (epi == 2) launch(gx * gy, 1, 256, [=]() { k_gemm_f16_glds<2, 64>(X, Wt, bias, C, nullptr, (int)M, N, K, 0); });
-            if (epi == 3) launch(gx * gy, 1, 256, [=]() { k_gemm_f16_glds<3, 64>(X, Wt, bias, C, nullptr, (int)M, N, K, 0); });
+            if (epi == 0) launch(gx * gy, 1, 256, [=]() { k_gemm_f16_glds<0, 64>(X, Wt, bias, C, nullptr, (int)M, N, K, 0, GemmExt{}); });
+            if (epi == 1) launch(gx * gy, 1, 256, [=]() { k_gemm_f16_glds<1, 64>(X, Wt, bias, C, nullptr, (int)M, N, K, 0, GemmExt{}); });
+            if (epi == 2) launch(gx * gy, 1, 256, [=]() { k_gemm_f16_glds<2, 64>(X, Wt, bias, C, nullptr, (int)M, N, K, 0, GemmExt{}); });
+            if (epi == 3) launch(gx * gy, 1, 256, [=]() { k_gemm_f16_glds<3, 64>(X, Wt, bias, C, nullptr, (int)M, N, K, 0, GemmExt{}); });
             return;
         }
         if (epi == 0) launch(gx * gy, 1, 256, [=]() { k_gemm_f16<0>(X, Wt, bias, C, nullptr, (int)M, N, K, 0); });

@@ -77,13 +77,16 @@ extern "C" int emu_wide_forward(const float* blob, long n_floats, const float* c
                     crops16[((i * WSTEM_ROWS + y + 3) * WSTEM_COLS + x + 3) * 4 + c] = (_Float16)crops[((i * REID_IN_H + y) * REID_IN_W + x) * 3 + c];
     size_t blk = N * 2048 * (size_t)c0, mid = 0;
     { int P = 2048; for (int s = 0; s < 3; ++s, P /= 4) { blk = std::max(blk, N * P * (size_t)ch[s + 1]); mid = std::max(mid, N * P * (size_t)(ch[s + 1] / 4)); } }
-    std::vector<_Float16> act_a(blk), act_b(blk), idn(blk);
+    std::vector<_Float16> act_a(blk), act_b(blk);
     std::vector<std::vector<_Float16>> midb(8, std::vector<_Float16>(mid));
     std::vector<float> gap_part(4 * N * 8 * 128);
+    std::vector<float> bsum[6];
 
-    auto gemm = [&](const _Float16* X, const _Float16* Wt, const float* bias, _Float16* out, const _Float16* res, long M, int Nn, int K, int relu) {
+    auto gemm = [&](const _Float16* X, const _Float16* Wt, const float* bias, _Float16* out, const _Float16* res, long M, int Nn, int K, int relu,
+                    GemmExt ext = GemmExt{}) {
         const long gx = (M + GEMM_BM - 1) / GEMM_BM;
-        if (Nn % 128 == 0) launch(gx * (Nn / 128), 1, 256, [=]() { k_gemm_f16_glds<4, 32>(X, Wt, bias, out, res, (int)M, Nn, K, relu); });
+        if (ext.pool_w) launch(gx * (Nn / 128), 1, 256, [=]() { k_gemm_f16_glds<5, 32>(X, Wt, bias, out, res, (int)M, Nn, K, relu, ext); });
+        else if (Nn % 128 == 0) launch(gx * (Nn / 128), 1, 256, [=]() { k_gemm_f16_glds<4, 32>(X, Wt, bias, out, res, (int)M, Nn, K, relu, ext); });
         else if (Nn % 96 == 0) launch(gx * (Nn / 96), 1, 256, [=]() { k_gemm_f16<4, 96>(X, Wt, bias, out, res, (int)M, Nn, K, relu); });
         else if (Nn % 64 == 0) launch(gx * (Nn / 64), 1, 256, [=]() { k_gemm_f16<4, 64>(X, Wt, bias, out, res, (int)M, Nn, K, relu); });
         else launch(gx * (Nn / 32), 1, 256, [=]() { k_gemm_f16<4, 32>(X, Wt, bias, out, res, (int)M, Nn, K, relu); });
@@ -122,9 +125,15 @@ extern "C" int emu_wide_forward(const float* blob, long n_floats, const float* c
         else if (B.mid == 64) launch(n, (P + ppb - 1) / ppb, 256, [=]() { k_gate_sum4<64>(ba, bb, bc, bd, gp, f1w, f1b, f2w, f2b, x2, P, nbands, nn, ppb); });
         else if (B.mid == 96) launch(n, (P + ppb - 1) / ppb, 256, [=]() { k_gate_sum4<96>(ba, bb, bc, bd, gp, f1w, f1b, f2w, f2b, x2, P, nbands, nn, ppb); });
         else launch(n, (P + ppb - 1) / ppb, 256, [=]() { k_gate_sum4<128>(ba, bb, bc, bd, gp, f1w, f1b, f2w, f2b, x2, P, nbands, nn, ppb); });
-        const _Float16* identity = x;
-        if (B.down_w >= 0) { gemm(x, W16 + pk.of(B.down_w), W32 + B.down_b, idn.data(), nullptr, n_pix, B.cout, B.cin, 0); identity = idn.data(); }
-        gemm(x2, W16 + pk.of(B.conv3_w), W32 + B.conv3_b, out, identity, n_pix, B.cout, B.mid, 1);
+        if (B.down_w >= 0) {        // conv3(x2) + downsample(x) as one GEMM over two operand pairs, summed biases
+            std::vector<float>& bs = bsum[&B - L.block];
+            bs.resize(B.cout);
+            for (int c = 0; c < B.cout; ++c) bs[c] = W32[B.conv3_b + c] + W32[B.down_b + c];
+            GemmExt two;
+            two.X2 = x; two.W2 = W16 + pk.of(B.down_w); two.K2 = B.cin;
+            gemm(x2, W16 + pk.of(B.conv3_w), bs.data(), out, nullptr, n_pix, B.cout, B.mid, 1, two);
+        } else
+            gemm(x2, W16 + pk.of(B.conv3_w), W32 + B.conv3_b, out, x, n_pix, B.cout, B.mid, 1);
     };
 
     { const _Float16* c = crops16.data(); _Float16* o = stem_out.data(); const float* sb = W32 + L.stem_b;
@@ -146,10 +155,10 @@ extern "C" int emu_wide_forward(const float* blob, long n_floats, const float* c
         }
         if (s < 2) {
             const int c = ch[s + 1];
-            gemm(cur, W16 + pk.of(L.trans_w[s]), W32 + L.trans_b[s], other, nullptr, (long)n * H * W, c, c, 1);
-            t8 = (long)n * (H / 2) * (W / 2) * (c / 8);
-            { const _Float16* i = other; _Float16* o = cur; const int hh = H, ww = W;
-              launch((t8 + 255) / 256, 1, 256, [=]() { k_avgpool2x2_h8(i, o, hh, ww, c, t8); }); }
+            GemmExt pool;
+            pool.pool_w = W;
+            gemm(cur, W16 + pk.of(L.trans_w[s]), W32 + L.trans_b[s], other, nullptr, (long)n * H * W, c, c, 1, pool);
+            std::swap(cur, other);
             H /= 2; W /= 2;
         }
     }

@@ -122,20 +122,22 @@ def test_strongsort_ids_exact_under_the_device_dot_rule(seed):
 
     class Sched:
         def __init__(self, w):
-            self.w, self.k = w, 0
-
+            self.w, self.t = w, 0           # .t = index of the frame being updated, set by the loop: an estimator is not asked on every
+                                            # frame (StrongSORT only while tracks exist, strongsort.py:83-86)
         def apply(self, img, d):
-            self.k += 1
-            return self.w[self.k - 1]
+            return self.w[self.t]
 
     n = 300
     frames = stress_frames(n, seed=seed, max_objects=20 + seed % 17)
     warps = camera_warps(n, seed=seed)
     use_w = seed % 2 == 0
-    trk = StrongSort(cmc=Sched(warps) if use_w else None, emb_dim=32, max_tracks=1024, max_dets=64)
+    sched = Sched(warps) if use_w else None
+    trk = StrongSort(cmc=sched, emb_dim=32, max_tracks=1024, max_dets=64)
     orc = StrongSortOracle(dot_rule="device")
     img = np.zeros((480, 640, 3), np.uint8)
     for t, (d, e) in enumerate(frames):
+        if sched is not None:
+            sched.t = t
         got = np.asarray(trk.update(d, img, e)).reshape(-1, 8)
         want = np.asarray(orc.update(d, img, e.copy(), warp=warps[t] if use_w else None)).reshape(-1, 8)
         assert got.shape == want.shape and np.array_equal(got[:, 4:], want[:, 4:]), (seed, t)

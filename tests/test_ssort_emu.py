@@ -112,8 +112,9 @@ def test_emulated_kernels_clean_under_asan():
 
 def test_device_dot_rule_reproduces_the_kernels_appearance_costs_bit_for_bit():
     """StrongSortOracle(dot_rule="device") restates the kernels' documented fp32 summation order (lane-strided fmaf + butterfly
-    for the norms, one fmaf per k for the products, 1 - dot / (|a| |b|)): every appearance distance the bank kernel produces is
-    bit-identical to the oracle's, frame after frame -- the cost matrix, not just the ids, is pinned."""
+    for the norms, one fmaf per k for the products, 1 - dot / (|a| |b|)) and their fp64 operation order in the Kalman update and
+    the gating distance: every appearance distance the bank kernel produces is bit-identical to the oracle's, frame after frame,
+    and so is the filter state -- the cost matrix, not just the ids, is pinned."""
     frames = stress_frames(40, seed=13, max_objects=24)
     cfg = dict(DEFAULTS)
     orc, emu = StrongSortOracle(dot_rule="device"), EmuStrongSort(cfg, cap=128, nd=64, dim=32)
@@ -130,6 +131,10 @@ def test_device_dot_rule_reproduces_the_kernels_appearance_costs_bit_for_bit():
                 assert app[r, j].tobytes() == np.float32(v).tobytes(), (t, tid, j, float(app[r, j]), float(v))
                 checked += 1
             prev_ids = emu.dump()["ints"][:, 0].tolist()
+        # ... and so is the fp64 filter state: the device rule also restates the kernels' Kalman update / gating operation order
+        od, d = orc.dump(), emu.dump()
+        ref = np.concatenate([od["mean"], od["cov"].reshape(-1, 64)], 1)
+        assert np.array_equal(d["kf"], ref)
     finally:
         emu.close()
     assert checked > 500

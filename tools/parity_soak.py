@@ -25,11 +25,10 @@ def main():
 
     class Sched:
         def __init__(self, w):
-            self.w, self.k = w, 0
-
+            self.w, self.t = w, 0           # .t = index of the frame being updated, set by the loop: an estimator is not asked on every
+                                            # frame (StrongSORT only while tracks exist, strongsort.py:83-86)
         def apply(self, img, d):
-            self.k += 1
-            return self.w[self.k - 1]
+            return self.w[self.t]
 
     img = np.zeros((480, 640, 3), np.uint8)
     bad = 0
@@ -56,9 +55,12 @@ def main():
             cases = [c for c in cases if c[0] in only]
         for name, mk, mko in cases:
             warped = use_w and name not in ("bytetrack", "ocsort")          # no camera-motion input in those two
-            trk, orc = mk(Sched(warps) if warped else None), mko()
+            sched = Sched(warps) if warped else None
+            trk, orc = mk(sched), mko()
             ok = True
             for t, (d, e) in enumerate(frames):
+                if sched is not None:
+                    sched.t = t
                 got = np.asarray(trk.update(d, img, e)).reshape(-1, 8)
                 want = (np.asarray(orc.update(d, img, e.copy(), warp=warps[t] if use_w else None)) if name not in ("bytetrack", "ocsort")
                         else np.asarray(orc.update(d, img))).reshape(-1, 8)
