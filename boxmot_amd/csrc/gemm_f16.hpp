@@ -275,7 +275,7 @@ __global__ void __launch_bounds__(256) k_gemm_f16_glds(const _Float16* __restric
         // transition layer: ReLU(conv + bias) then the 2 x 2 average pool, on the accumulators.  A lane holds 4 features of pixel
         // (row tile t, l16); its horizontal partner is lane l16 ^ 1 (quad swap), its vertical partner -- one image row = pool_w
         // pixels further -- is row tile t + pool_w / 16 of the same lane (a 128-row tile holds whole pairs of image rows).
-        const int dt = ext.pool_w / 16;
+        const int dt = ext.pool_w / 16, sh = ext.pool_w == 32 ? 5 : 4;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int n = n0 + wn * 64 + p * 16 + 4 * g;
@@ -295,7 +295,7 @@ __global__ void __launch_bounds__(256) k_gemm_f16_glds(const _Float16* __restric
                     o[r] = (_Float16)(v * 0.25f);
                 }
                 if (m < M && (l16 & 1) == 0) {
-                    const long q = m / ext.pool_w, x = m - q * ext.pool_w;           // q = crop * H + y (y even)
+                    const long q = m >> sh, x = m & (ext.pool_w - 1);                // q = crop * H + y (y even); pool_w is 16 or 32
                     *reinterpret_cast<ch4*>(static_cast<_Float16*>(Cout) + ((q >> 1) * (ext.pool_w / 2) + (x >> 1)) * N + n) = o;
                 }
             }

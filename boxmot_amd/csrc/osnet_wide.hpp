@@ -36,7 +36,6 @@ public:
         const size_t crop_halves = n * WSTEM_ROWS * WSTEM_COLS * 4;
         crops16_ = alloc<_Float16>(crop_halves, owned);
         check(hipMemset(crops16_, 0, crop_halves * 2), "clear crop buffer");       // the 3-pixel border and the X channel stay zero
-        stem_out_ = alloc<_Float16>(n * 8192 * c0, owned);
         size_t blk = 0, mid = 0;
         int P = 2048;
         for (int s = 0; s < 3; ++s, P /= 4) {
@@ -74,11 +73,10 @@ public:
         if (n > max_crops_) throw std::runtime_error("wide OSNet: crop batch exceeds the engine capacity");
         if (n == 0) return;
         const int c0 = L_.c[0];
-        if (c0 == 64) hipLaunchKernelGGL(k_wide_stem<64>, dim3(128 / WSTEM_BAND, n), dim3(256), 0, st, crops16_, d_stem16_, d_w_ + L_.stem_b, stem_out_);
-        else if (c0 == 32) hipLaunchKernelGGL(k_wide_stem<32>, dim3(128 / WSTEM_BAND, n), dim3(256), 0, st, crops16_, d_stem16_, d_w_ + L_.stem_b, stem_out_);
+        // stem conv + ReLU + 3x3 max pool in one launch: act_a_ = [n][64 * 32][c0]
+        if (c0 == 64) hipLaunchKernelGGL(k_wide_stem<64>, dim3(64 / WSTEM_PBAND, n), dim3(256), 0, st, crops16_, d_stem16_, d_w_ + L_.stem_b, act_a_);
+        else if (c0 == 32) hipLaunchKernelGGL(k_wide_stem<32>, dim3(64 / WSTEM_PBAND, n), dim3(256), 0, st, crops16_, d_stem16_, d_w_ + L_.stem_b, act_a_);
         else throw std::runtime_error("wide OSNet: stem width must be 32 or 64");
-        long t8 = (long)n * 2048 * (c0 / 8);
-        hipLaunchKernelGGL(k_maxpool3x3s2_h8, dim3((unsigned)((t8 + 255) / 256)), dim3(256), 0, st, stem_out_, act_a_, 128, 64, c0, t8);
         _Float16 *cur = act_a_, *other = act_b_;
         int H = 64, W = 32;
         for (int s = 0; s < 3; ++s) {
@@ -116,6 +114,8 @@ private:
     static void set_light_lds() {
         check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_light_fused<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   light_lds_bytes<C>(32)), "LightConv LDS");
+        check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_light_pair<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  light_pair_lds_bytes<C>(32)), "LightConv pair LDS");
     }
     // 1x1 convolution over n_pix pixels: out = [relu](X . W^T + bias [+ res])
     void gemm(const _Float16* X, const _Float16* W, const float* bias, _Float16* out, const _Float16* res, long M, int N, int K,
@@ -148,6 +148,20 @@ private:
         }
     }
     template <int C>
+    void light2_t(const _Float16* in, const LightW& a, const LightW& b, _Float16* out, float* gap, int n, int H, int W, hipStream_t st) {
+        hipLaunchKernelGGL(k_light_pair<C>, dim3(H / WIDE_BAND, n), dim3(512), (size_t)light_pair_lds_bytes<C>(W), st, in, d_w16_ + pk_.of(a.pw),
+                           d_w_ + a.dw, d_w_ + a.b, d_w16_ + pk_.of(b.pw), d_w_ + b.dw, d_w_ + b.b, out, gap, H, W);
+    }
+    void light2(int C, const _Float16* in, const LightW& a, const LightW& b, _Float16* out, float* gap, int n, int H, int W, hipStream_t st) {
+        switch (C) {
+            case 32: light2_t<32>(in, a, b, out, gap, n, H, W, st); break;
+            case 64: light2_t<64>(in, a, b, out, gap, n, H, W, st); break;
+            case 96: light2_t<96>(in, a, b, out, gap, n, H, W, st); break;
+            case 128: light2_t<128>(in, a, b, out, gap, n, H, W, st); break;
+            default: throw std::runtime_error("wide OSNet: unsupported middle width");
+        }
+    }
+    template <int C>
     void gate_t(const BlockW& B, _Float16* const* br, _Float16* out, int n, int P, int nbands, hipStream_t st) {
         const int ppb = 128;
         hipLaunchKernelGGL(k_gate_sum4<C>, dim3(n, (P + ppb - 1) / ppb), dim3(256), 0, st, br[0], br[1], br[2], br[3], gap_part_,
@@ -162,13 +176,20 @@ private:
         gemm(x, d_w16_ + pk_.of(B.conv1_w), d_w_ + B.conv1_b, x1, nullptr, n_pix, B.mid, B.cin, 1, st);
         int li = 0;
         for (int br = 0; br < 4; ++br) {
+            // a branch is a chain of br + 1 LightConvs: pairs go through k_light_pair (their intermediate tensor stays in LDS)
             const _Float16* cur = x1;
-            for (int k = 0; k <= br; ++k, ++li) {
-                const bool last = k == br;
-                _Float16* dst = last ? brs[br] : tmp[k & 1];
-                light(B.mid, cur, B.light[li], dst, last ? gap_part_ + (long)br * n * nbands * B.mid : nullptr, n, H, W, st);
+            const int L = br + 1;
+            for (int k = 0; k < L;) {
+                const bool pair = L - k >= 2;
+                const bool last = k + (pair ? 2 : 1) == L;
+                _Float16* dst = last ? brs[br] : tmp[(k >> 1) & 1];
+                float* gap = last ? gap_part_ + (long)br * n * nbands * B.mid : nullptr;
+                if (pair) light2(B.mid, cur, B.light[li + k], B.light[li + k + 1], dst, gap, n, H, W, st);
+                else light(B.mid, cur, B.light[li + k], dst, gap, n, H, W, st);
                 cur = dst;
+                k += pair ? 2 : 1;
             }
+            li += L;
         }
         _Float16* x2 = mid_[7];
         switch (B.mid) {
@@ -191,7 +212,7 @@ private:
     const float* d_w_;                       // the engine's fp32 blob on the device (biases, depthwise taps, gate and FC weights)
     int max_crops_;
     _Float16 *d_w16_ = nullptr, *d_stem16_ = nullptr;
-    _Float16 *crops16_ = nullptr, *stem_out_ = nullptr, *act_a_ = nullptr, *act_b_ = nullptr;
+    _Float16 *crops16_ = nullptr, *act_a_ = nullptr, *act_b_ = nullptr;
     _Float16* mid_[8] = {};
     float* gap_part_ = nullptr;
     float* d_bsum_ = nullptr;

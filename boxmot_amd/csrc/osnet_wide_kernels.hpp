@@ -140,43 +140,33 @@ __global__ void __launch_bounds__(256) k_wide_stem(const _Float16* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------
-// LightConv3x3 (osnet.py:141-155) in one launch.  grid (H / 8 bands, crops), 256 threads.
+// LightConv3x3 (osnet.py:141-155) = 1x1 (linear) -> depthwise 3x3 + folded BN + ReLU, fused: a workgroup owns a band of 8 image rows
+// of one crop.  Two building blocks:
+//   light_pw  the 1x1 of a run of 16-pixel tiles on the matrix pipe: B fragments from a caller-supplied source (global image rows
+//             or an LDS tile), A = the [C][C] weights straight from global (<= 32 KB: L1 / L2 resident), result into an LDS tile T
+//             (pixel stride C + 8 halves: 16-byte aligned rows, the 8-byte accumulator writes at most 2-way conflicted).  Rows
+//             outside the image are ZERO: the 1x1 has no bias, so the zero padding of the depthwise input is exactly a zero row.
+//   light_dw  depthwise 3x3 + bias + ReLU from T: thread = (column, 8-channel group), sliding 3 x 3 window down its rows, fp32.
+// k_light_fused (256 threads) = pw -> dw for one LightConv; k_light_pair (512 threads) = pw -> dw -> pw -> dw for TWO chained
+// LightConvs of a branch with a two-row halo: the intermediate tensor of the pair lives only in LDS (a pair reads 12 / 8 of the
+// input and writes the output once, instead of two reads and two writes).
 //   in / out  fp16 NHWC [n][H][W][C];  pw fp16 [C][C] (out-major, as stored);  dw fp32 [C][9] with BN folded;  bias fp32 [C]
 //   gap_part  nullptr, or fp32 [n][bands][C]: sum over the band's pixels of the output (for the channel gate's average pool)
-// Phase 1: T[(8 + 2) W pixels][C] = pw . in on the matrix pipe (rows outside the image are zero: the 1x1 has no bias, so the
-//          zero padding of the depthwise input is exactly a zero row); D layout = 4 consecutive channels of one pixel per lane.
-// Phase 2: thread = (column, 8-channel group), sliding 3 x 3 window down the band, fp32 accumulation.
-// LDS pixel stride C + 8 halves: 16-byte aligned rows, phase-1 8-byte writes at most 2-way conflicted.
 // ---------------------------------------------------------------------------
 template <int C>
 __host__ __device__ constexpr int light_lds_bytes(int W) { return (WIDE_BAND + 2) * W * (C + 8) * 2; }
-
 template <int C>
-__global__ void __launch_bounds__(256) k_light_fused(const _Float16* __restrict__ in, const _Float16* __restrict__ pw,
-                                                     const float* __restrict__ dw, const float* __restrict__ bias,
-                                                     _Float16* __restrict__ out, float* __restrict__ gap_part, int H, int W) {
-    static_assert(C % 32 == 0 && C <= 128, "middle width");
-    BM_DYNAMIC_LDS_T(unsigned char, lds_raw);
-    _Float16* T = reinterpret_cast<_Float16*>(lds_raw);
-    constexpr int LD = C + 8, KS = C / 32, CT = C / 16, CG = C / 8;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l16 = lane & 15;
-    const int band = blockIdx.x, nbands = gridDim.x;
-    const long crop = blockIdx.y;
-    const int r0 = band * WIDE_BAND;
-    const _Float16* img = in + crop * H * W * (long)C;
-    // ---- phase 1 ----
-    const int n_ptiles = (WIDE_BAND + 2) * W / 16;
-    for (int pt = wave; pt < n_ptiles; pt += 4) {
+__host__ __device__ constexpr int light_pair_lds_bytes(int W) { return ((WIDE_BAND + 4) + (WIDE_BAND + 2)) * W * (C + 8) * 2; }
+
+template <int C, class LoadB>
+__device__ inline void light_pw(int n_ptiles, int wave, int nwaves, int lane, const _Float16* __restrict__ pw, _Float16* T, LoadB loadb) {
+    constexpr int LD = C + 8, KS = C / 32, CT = C / 16;
+    const int g = lane >> 4, l16 = lane & 15;
+    for (int pt = wave; pt < n_ptiles; pt += nwaves) {
         const int px = pt * 16 + l16;
-        const int lrow = px / W, col = px - lrow * W;
-        const int grow = r0 - 1 + lrow;
-        const bool valid = grow >= 0 && grow < H;
         ch8 b[KS];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            b[s] = ch8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (valid) b[s] = *reinterpret_cast<const ch8*>(img + ((long)grow * W + col) * C + 32 * s + 8 * g);
-        }
+        for (int s = 0; s < KS; ++s) b[s] = loadb(px, s);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             cf4 acc = cf4{0.f, 0.f, 0.f, 0.f};
@@ -191,71 +181,174 @@ __global__ void __launch_bounds__(256) k_light_fused(const _Float16* __restrict_
             *reinterpret_cast<ch4*>(T + px * LD + 16 * ct + 4 * g) = o;
         }
     }
+}
+
+// output rows lr0 .. lr1 - 1 (tile rows lr .. lr + 2 each) of column x, channels 8 cg .. 8 cg + 7; store(lr, o) takes each result
+template <int C, class Store>
+__device__ inline void light_dw(const _Float16* T, int W, int x, int cg, int lr0, int lr1, const float* __restrict__ dw,
+                                const float* __restrict__ bias, Store store) {
+    constexpr int LD = C + 8;
+    if (lr0 >= lr1) return;
+    float w[9][8], bv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        bv[j] = bias[cg * 8 + j];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) w[k][j] = dw[(cg * 8 + j) * 9 + k];
+    }
+    const ch8 zero = ch8{0, 0, 0, 0, 0, 0, 0, 0};
+    auto load_row = [&](int trow, ch8& l, ch8& m, ch8& r) {
+        const _Float16* p = T + (trow * W + x) * LD + cg * 8;
+        m = *reinterpret_cast<const ch8*>(p);
+        l = x > 0 ? *reinterpret_cast<const ch8*>(p - LD) : zero;
+        r = x < W - 1 ? *reinterpret_cast<const ch8*>(p + LD) : zero;
+    };
+    ch8 t0, t1, t2, m0, m1, m2, b0, b1, b2;
+    load_row(lr0, t0, t1, t2);
+    load_row(lr0 + 1, m0, m1, m2);
+    for (int lr = lr0; lr < lr1; ++lr) {
+        load_row(lr + 2, b0, b1, b2);
+        ch8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float a = (float)t0[j] * w[0][j];
+            a += (float)t1[j] * w[1][j]; a += (float)t2[j] * w[2][j];
+            a += (float)m0[j] * w[3][j]; a += (float)m1[j] * w[4][j]; a += (float)m2[j] * w[5][j];
+            a += (float)b0[j] * w[6][j]; a += (float)b1[j] * w[7][j]; a += (float)b2[j] * w[8][j];
+            a += bv[j];
+            a = a > 0.f ? a : 0.f;
+            o[j] = (_Float16)a;
+        }
+        store(lr, o);
+        t0 = m0; t1 = m1; t2 = m2; m0 = b0; m1 = b1; m2 = b2;
+    }
+}
+
+// thread -> (row group, column, channel group) of the depthwise phase: NG row groups of TPR = W * C / 8 threads
+struct LightMap { int x, cg, grp, ng; bool active; };
+template <int C>
+__device__ inline LightMap light_map(int tid, int nthreads, int W, int max_groups) {
+    constexpr int CG = C / 8;
+    const int TPR = W * CG;
+    int ng = 1;
+    while (ng * 2 <= max_groups && ng * 2 * TPR <= nthreads) ng *= 2;
+    LightMap m;
+    m.ng = ng;
+    m.active = tid < ng * TPR && TPR <= nthreads;
+    m.grp = m.active ? tid / TPR : 0;
+    const int rem = tid - m.grp * TPR;
+    m.x = m.active ? rem / CG : 0;
+    m.cg = m.active ? rem - m.x * CG : 0;
+    return m;
+}
+
+// band sums of the output for the channel gate: per-thread sums -> LDS -> one thread per channel adds them in a fixed order
+template <int C>
+__device__ inline void light_gap(const float (&gsum)[8], const LightMap& m, int W, float* S, float* __restrict__ dst) {
     __syncthreads();
-    // ---- phase 2 ----
-    const int TPR = W * CG;                         // threads per image row
-    const int NG = TPR <= 64 ? 4 : (TPR <= 128 ? 2 : 1);    // row groups (a power of two <= 4: the band sums below reuse the tile's LDS)
-    const int RPG = WIDE_BAND / NG;                 // rows per thread
+    if (m.active) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) S[(m.grp * W + m.x) * C + m.cg * 8 + j] = gsum[j];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < C) {
+        float s = 0.f;
+        for (int k = 0; k < m.ng * W; ++k) s += S[k * C + threadIdx.x];
+        dst[threadIdx.x] = s;
+    }
+}
+
+template <int C>
+__global__ void __launch_bounds__(256) k_light_fused(const _Float16* __restrict__ in, const _Float16* __restrict__ pw,
+                                                     const float* __restrict__ dw, const float* __restrict__ bias,
+                                                     _Float16* __restrict__ out, float* __restrict__ gap_part, int H, int W) {
+    static_assert(C % 32 == 0 && C <= 128, "middle width");
+    BM_DYNAMIC_LDS_T(unsigned char, lds_raw);
+    _Float16* T = reinterpret_cast<_Float16*>(lds_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+    const int band = blockIdx.x, nbands = gridDim.x;
+    const long crop = blockIdx.y;
+    const int r0 = band * WIDE_BAND;
+    const _Float16* img = in + crop * H * W * (long)C;
+    light_pw<C>((WIDE_BAND + 2) * W / 16, wave, 4, lane, pw, T, [&](int px, int s) {
+        const int lrow = px / W, col = px - lrow * W, grow = r0 - 1 + lrow;
+        ch8 b = ch8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (grow >= 0 && grow < H) b = *reinterpret_cast<const ch8*>(img + ((long)grow * W + col) * C + 32 * s + 8 * g);
+        return b;
+    });
+    __syncthreads();
+    const LightMap m = light_map<C>(tid, 256, W, 4);        // <= 4 row groups: the band sums below reuse the tile's LDS
+    const int rpg = WIDE_BAND / m.ng;
     float gsum[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) gsum[j] = 0.f;
-    const bool active = tid < NG * TPR && TPR <= 256;
-    int x = 0, cg = 0, grp = 0;
-    if (active) {
-        grp = tid / TPR;
-        const int rem = tid - grp * TPR;
-        x = rem / CG; cg = rem - x * CG;
-        float w[9][8], bv[8];
+    if (m.active)
+        light_dw<C>(T, W, m.x, m.cg, m.grp * rpg, (m.grp + 1) * rpg, dw, bias, [&](int lr, const ch8& o) {
+            *reinterpret_cast<ch8*>(out + ((crop * H + r0 + lr) * W + m.x) * (long)C + m.cg * 8) = o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            bv[j] = bias[cg * 8 + j];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) w[k][j] = dw[(cg * 8 + j) * 9 + k];
-        }
+            for (int j = 0; j < 8; ++j) gsum[j] += (float)o[j];     // the gate pools the tensor the next layer sees (fp16-rounded)
+        });
+    if (gap_part) light_gap<C>(gsum, m, W, reinterpret_cast<float*>(lds_raw), gap_part + (crop * nbands + band) * C);
+}
+
+// two chained LightConvs (pw1, dw1, b1) -> (pw2, dw2, b2): 512 threads, LDS = T (12 rows, later reused for the second 1x1's
+// 10 rows) + U (the first LightConv's output on 10 rows, zero outside the image: the second 1x1 has no bias either)
+template <int C>
+__global__ void __launch_bounds__(512) k_light_pair(const _Float16* __restrict__ in, const _Float16* __restrict__ pw1,
+                                                    const float* __restrict__ dw1, const float* __restrict__ b1,
+                                                    const _Float16* __restrict__ pw2, const float* __restrict__ dw2,
+                                                    const float* __restrict__ b2, _Float16* __restrict__ out,
+                                                    float* __restrict__ gap_part, int H, int W) {
+    static_assert(C % 32 == 0 && C <= 128, "middle width");
+    BM_DYNAMIC_LDS_T(unsigned char, lds_raw);
+    constexpr int LD = C + 8;
+    _Float16* T = reinterpret_cast<_Float16*>(lds_raw);
+    _Float16* U = T + (WIDE_BAND + 4) * W * LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+    const int band = blockIdx.x, nbands = gridDim.x;
+    const long crop = blockIdx.y;
+    const int r0 = band * WIDE_BAND;
+    const _Float16* img = in + crop * H * W * (long)C;
+    // T rows 0 .. 11 <-> image rows r0 - 2 .. r0 + 9
+    light_pw<C>((WIDE_BAND + 4) * W / 16, wave, 8, lane, pw1, T, [&](int px, int s) {
+        const int lrow = px / W, col = px - lrow * W, grow = r0 - 2 + lrow;
+        ch8 b = ch8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (grow >= 0 && grow < H) b = *reinterpret_cast<const ch8*>(img + ((long)grow * W + col) * C + 32 * s + 8 * g);
+        return b;
+    });
+    __syncthreads();
+    // U rows 0 .. 9 <-> image rows r0 - 1 .. r0 + 8
+    const LightMap m = light_map<C>(tid, 512, W, 4);
+    {
+        constexpr int R = WIDE_BAND + 2;
+        const int rpg = (R + m.ng - 1) / m.ng;
+        const int lr0 = m.grp * rpg, lr1 = lr0 + rpg < R ? lr0 + rpg : R;
         const ch8 zero = ch8{0, 0, 0, 0, 0, 0, 0, 0};
-        auto load_row = [&](int trow, ch8& l, ch8& m, ch8& r) {
-            const _Float16* p = T + (trow * W + x) * LD + cg * 8;
-            m = *reinterpret_cast<const ch8*>(p);
-            l = x > 0 ? *reinterpret_cast<const ch8*>(p - LD) : zero;
-            r = x < W - 1 ? *reinterpret_cast<const ch8*>(p + LD) : zero;
-        };
-        const int lr0 = grp * RPG;                  // first output row of this thread inside the band; its tile rows are lr .. lr + 2
-        ch8 t0, t1, t2, m0, m1, m2, b0, b1, b2;
-        load_row(lr0, t0, t1, t2);
-        load_row(lr0 + 1, m0, m1, m2);
-        _Float16* orow = out + ((crop * H + r0 + lr0) * W + x) * (long)C + cg * 8;
-        for (int lr = 0; lr < RPG; ++lr) {
-            load_row(lr0 + lr + 2, b0, b1, b2);
-            ch8 o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float a = (float)t0[j] * w[0][j];
-                a += (float)t1[j] * w[1][j]; a += (float)t2[j] * w[2][j];
-                a += (float)m0[j] * w[3][j]; a += (float)m1[j] * w[4][j]; a += (float)m2[j] * w[5][j];
-                a += (float)b0[j] * w[6][j]; a += (float)b1[j] * w[7][j]; a += (float)b2[j] * w[8][j];
-                a += bv[j];
-                a = a > 0.f ? a : 0.f;
-                o[j] = (_Float16)a;
-                gsum[j] += (float)o[j];             // the gate pools the tensor the next layer sees (fp16-rounded)
-            }
-            *reinterpret_cast<ch8*>(orow + (long)lr * W * C) = o;
-            t0 = m0; t1 = m1; t2 = m2; m0 = b0; m1 = b1; m2 = b2;
-        }
-    }
-    if (gap_part == nullptr) return;
-    // band sums for the channel gate: per-thread sums -> LDS -> one thread per channel adds them in a fixed order
-    __syncthreads();
-    float* S = reinterpret_cast<float*>(lds_raw);           // [NG * W][C]
-    if (active) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) S[(grp * W + x) * C + cg * 8 + j] = gsum[j];
+        if (m.active)
+            light_dw<C>(T, W, m.x, m.cg, lr0, lr1, dw1, b1, [&](int lr, const ch8& o) {
+                const int grow = r0 - 1 + lr;
+                *reinterpret_cast<ch8*>(U + (lr * W + m.x) * LD + m.cg * 8) = (grow >= 0 && grow < H) ? o : zero;
+            });
     }
     __syncthreads();
-    if (tid < C) {
-        float s = 0.f;
-        for (int k = 0; k < NG * W; ++k) s += S[k * C + tid];
-        gap_part[(crop * nbands + band) * C + tid] = s;
+    // second 1x1 on U's 10 rows -> T rows 0 .. 9
+    light_pw<C>((WIDE_BAND + 2) * W / 16, wave, 8, lane, pw2, T, [&](int px, int s) {
+        return *reinterpret_cast<const ch8*>(U + px * LD + 32 * s + 8 * g);
+    });
+    __syncthreads();
+    float gsum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gsum[j] = 0.f;
+    {
+        const int rpg = WIDE_BAND / m.ng;
+        if (m.active)
+            light_dw<C>(T, W, m.x, m.cg, m.grp * rpg, (m.grp + 1) * rpg, dw2, b2, [&](int lr, const ch8& o) {
+                *reinterpret_cast<ch8*>(out + ((crop * H + r0 + lr) * W + m.x) * (long)C + m.cg * 8) = o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) gsum[j] += (float)o[j];
+            });
     }
+    if (gap_part) light_gap<C>(gsum, m, W, reinterpret_cast<float*>(U), gap_part + (crop * nbands + band) * C);
 }
 
 // ---------------------------------------------------------------------------

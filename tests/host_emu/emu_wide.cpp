@@ -69,7 +69,7 @@ extern "C" int emu_wide_forward(const float* blob, long n_floats, const float* c
     const _Float16* stem16 = W16 + pk.stem;
     const size_t N = (size_t)n;
     // the stem's input layout: fp16 RGBX with a 3-pixel zero border (what k_crop_resize_rgbx writes on the device)
-    std::vector<_Float16> crops16(N * WSTEM_ROWS * WSTEM_COLS * 4, (_Float16)0.f), stem_out(N * 8192 * c0);
+    std::vector<_Float16> crops16(N * WSTEM_ROWS * WSTEM_COLS * 4, (_Float16)0.f);
     for (size_t i = 0; i < N; ++i)
         for (int y = 0; y < REID_IN_H; ++y)
             for (int x = 0; x < REID_IN_W; ++x)
@@ -98,6 +98,14 @@ extern "C" int emu_wide_forward(const float* blob, long n_floats, const float* c
         else if (C == 96) launch(H / WIDE_BAND, n, 256, [=]() { k_light_fused<96>(in, pw, dw, b, out, gap, H, W); });
         else launch(H / WIDE_BAND, n, 256, [=]() { k_light_fused<128>(in, pw, dw, b, out, gap, H, W); });
     };
+    auto light2 = [&](int C, const _Float16* in, const LightW& la, const LightW& lb, _Float16* out, float* gap, int H, int W) {
+        const _Float16 *p1 = W16 + pk.of(la.pw), *p2 = W16 + pk.of(lb.pw);
+        const float *d1 = W32 + la.dw, *c1 = W32 + la.b, *d2 = W32 + lb.dw, *c2 = W32 + lb.b;
+        if (C == 32) launch(H / WIDE_BAND, n, 512, [=]() { k_light_pair<32>(in, p1, d1, c1, p2, d2, c2, out, gap, H, W); });
+        else if (C == 64) launch(H / WIDE_BAND, n, 512, [=]() { k_light_pair<64>(in, p1, d1, c1, p2, d2, c2, out, gap, H, W); });
+        else if (C == 96) launch(H / WIDE_BAND, n, 512, [=]() { k_light_pair<96>(in, p1, d1, c1, p2, d2, c2, out, gap, H, W); });
+        else launch(H / WIDE_BAND, n, 512, [=]() { k_light_pair<128>(in, p1, d1, c1, p2, d2, c2, out, gap, H, W); });
+    };
     auto osblock = [&](const BlockW& B, const _Float16* x, _Float16* out, int H, int W) {
         const long n_pix = (long)n * H * W;
         const int nbands = H / WIDE_BAND, P = H * W;
@@ -108,12 +116,18 @@ extern "C" int emu_wide_forward(const float* blob, long n_floats, const float* c
         int li = 0;
         for (int br = 0; br < 4; ++br) {
             const _Float16* cur = x1;
-            for (int k = 0; k <= br; ++k, ++li) {
-                const bool last = k == br;
-                _Float16* dst = last ? brs[br] : tmp[k & 1];
-                light(B.mid, cur, B.light[li], dst, last ? gap_part.data() + (long)br * n * nbands * B.mid : nullptr, H, W);
+            const int Lc = br + 1;
+            for (int k = 0; k < Lc;) {
+                const bool pair = Lc - k >= 2;
+                const bool last = k + (pair ? 2 : 1) == Lc;
+                _Float16* dst = last ? brs[br] : tmp[(k >> 1) & 1];
+                float* gap = last ? gap_part.data() + (long)br * n * nbands * B.mid : nullptr;
+                if (pair) light2(B.mid, cur, B.light[li + k], B.light[li + k + 1], dst, gap, H, W);
+                else light(B.mid, cur, B.light[li + k], dst, gap, H, W);
                 cur = dst;
+                k += pair ? 2 : 1;
             }
+            li += Lc;
         }
         _Float16* x2 = midb[7].data();
         const float* gp = gap_part.data();
@@ -136,12 +150,9 @@ extern "C" int emu_wide_forward(const float* blob, long n_floats, const float* c
             gemm(x2, W16 + pk.of(B.conv3_w), W32 + B.conv3_b, out, x, n_pix, B.cout, B.mid, 1);
     };
 
-    { const _Float16* c = crops16.data(); _Float16* o = stem_out.data(); const float* sb = W32 + L.stem_b;
-      if (c0 == 64) launch(128 / WSTEM_BAND, n, 256, [=]() { k_wide_stem<64>(c, stem16, sb, o); });
-      else launch(128 / WSTEM_BAND, n, 256, [=]() { k_wide_stem<32>(c, stem16, sb, o); }); }
-    long t8 = (long)n * 2048 * (c0 / 8);
-    { const _Float16* i = stem_out.data(); _Float16* o = act_a.data();
-      launch((t8 + 255) / 256, 1, 256, [=]() { k_maxpool3x3s2_h8(i, o, 128, 64, c0, t8); }); }
+    { const _Float16* c = crops16.data(); _Float16* o = act_a.data(); const float* sb = W32 + L.stem_b;
+      if (c0 == 64) launch(64 / WSTEM_PBAND, n, 256, [=]() { k_wide_stem<64>(c, stem16, sb, o); });
+      else launch(64 / WSTEM_PBAND, n, 256, [=]() { k_wide_stem<32>(c, stem16, sb, o); }); }
     _Float16 *cur = act_a.data(), *other = act_b.data();
     int H = 64, W = 32;
     for (int s = 0; s < 3; ++s) {
