@@ -47,7 +47,17 @@ public:
         act_a_ = alloc<_Float16>(blk, owned); act_b_ = alloc<_Float16>(blk, owned);
         for (auto& m : mid_) m = alloc<_Float16>(mid, owned);
         gap_part_ = alloc<float>(4 * n * (64 / WIDE_BAND) * 128, owned);
-        set_light_lds<32>(); set_light_lds<64>(); set_light_lds<96>(); set_light_lds<128>();
+        check(hipDeviceSynchronize(), "clear crop buffer");     // nothing asynchronous is pending if a later step of the constructor throws
+        for (int b = 0; b < 6; ++b) {                            // dynamic-LDS limits for the (middle width, image width) pairs this network uses
+            const int C = L.block[b].mid, W = 32 >> (b / 2);
+            switch (C) {
+                case 32: set_light_lds<32>(W); break;
+                case 64: set_light_lds<64>(W); break;
+                case 96: set_light_lds<96>(W); break;
+                case 128: set_light_lds<128>(W); break;
+                default: throw std::runtime_error("wide OSNet: unsupported middle width");
+            }
+        }
         check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_glds<4, 32>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   gemm_glds_lds_bytes<32>()), "GEMM LDS");
         check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_glds<5, 32>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -111,11 +121,12 @@ private:
         return static_cast<T*>(p);
     }
     template <int C>
-    static void set_light_lds() {
+    static void set_light_lds(int W) {
+        if (light_pair_lds_bytes<C>(W) > 160 * 1024) throw std::runtime_error("wide OSNet: LightConv pair tile exceeds the LDS");
         check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_light_fused<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  light_lds_bytes<C>(32)), "LightConv LDS");
+                                  light_lds_bytes<C>(W)), "LightConv LDS");
         check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_light_pair<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  light_pair_lds_bytes<C>(32)), "LightConv pair LDS");
+                                  light_pair_lds_bytes<C>(W)), "LightConv pair LDS");
     }
     // 1x1 convolution over n_pix pixels: out = [relu](X . W^T + bias [+ res])
     void gemm(const _Float16* X, const _Float16* W, const float* bias, _Float16* out, const _Float16* res, long M, int N, int K,
