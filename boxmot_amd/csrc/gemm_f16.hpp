@@ -13,6 +13,7 @@
 // next k-tile's global loads in flight while the current one multiplies.
 //   EPI 0: fp16 store                          EPI 1: QuickGELU, fp16 store          EPI 2: fp32 C += result
 //   EPI 3: fp32 store                          EPI 4: (+ fp16 residual[m][n]) (ReLU when relu != 0), fp16 store
+//   EPI 5 / 6 (k_gemm_f16_glds only): ReLU + 2 x 2 average pool over an image of width 32 / 16, fp16 store of the pooled tensor
 #pragma once
 
 #include <stdint.h>
@@ -178,7 +179,7 @@ __global__ void __launch_bounds__(256) k_gemm_f16(const _Float16* __restrict__ X
 // optional extras of k_gemm_f16_glds:
 //   X2 / W2 / K2   a second (activation, weight) pair whose product is added into the same accumulators (K2 % BK == 0): two 1x1
 //                  convolutions with a common output -- an OSBlock's conv3(x2) + downsample(x) -- as ONE launch, the sum never in HBM
-//   pool_w         EPI 5 only: image width in pixels (16 or 32); the epilogue then applies ReLU and the 2 x 2 average pool of the
+//   pool_w         EPI 5 (image width 32) / EPI 6 (image width 16): the epilogue applies ReLU and the 2 x 2 average pool of the
 //                  transition layers (osnet.py:349) on the accumulators and stores the POOLED tensor [rows / 4][N]
 struct GemmExt {
     const _Float16* X2 = nullptr;
@@ -271,11 +272,11 @@ __global__ void __launch_bounds__(256) k_gemm_f16_glds(const _Float16* __restric
 #pragma unroll
                 for (int t = 0; t < 4; ++t) acc[p][t] = BM_MFMA_F16_K32(a[s][p], b[s][t], acc[p][t]);
     }
-    if constexpr (EPI == 5) {
+    if constexpr (EPI == 5 || EPI == 6) {
         // transition layer: ReLU(conv + bias) then the 2 x 2 average pool, on the accumulators.  A lane holds 4 features of pixel
         // (row tile t, l16); its horizontal partner is lane l16 ^ 1 (quad swap), its vertical partner -- one image row = pool_w
         // pixels further -- is row tile t + pool_w / 16 of the same lane (a 128-row tile holds whole pairs of image rows).
-        const int dt = ext.pool_w / 16, sh = ext.pool_w == 32 ? 5 : 4;
+        constexpr int POOL_W = EPI == 5 ? 32 : 16, dt = POOL_W / 16, sh = EPI == 5 ? 5 : 4;     // compile-time: acc[][t + dt] must stay in registers
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int n = n0 + wn * 64 + p * 16 + 4 * g;
@@ -295,8 +296,8 @@ __global__ void __launch_bounds__(256) k_gemm_f16_glds(const _Float16* __restric
                     o[r] = (_Float16)(v * 0.25f);
                 }
                 if (m < M && (l16 & 1) == 0) {
-                    const long q = m >> sh, x = m & (ext.pool_w - 1);                // q = crop * H + y (y even); pool_w is 16 or 32
-                    *reinterpret_cast<ch4*>(static_cast<_Float16*>(Cout) + ((q >> 1) * (ext.pool_w / 2) + (x >> 1)) * N + n) = o;
+                    const long q = m >> sh, x = m & (POOL_W - 1);                    // q = crop * H + y (y even)
+                    *reinterpret_cast<ch4*>(static_cast<_Float16*>(Cout) + ((q >> 1) * (POOL_W / 2) + (x >> 1)) * N + n) = o;
                 }
             }
         }

@@ -62,6 +62,8 @@ public:
                                   gemm_glds_lds_bytes<32>()), "GEMM LDS");
         check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_glds<5, 32>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   gemm_glds_lds_bytes<32>()), "GEMM LDS");
+        check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_glds<6, 32>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  gemm_glds_lds_bytes<32>()), "GEMM LDS");
         // conv3 + downsample run as one GEMM: their folded-BN biases add up
         std::vector<float> bs;
         for (int b = 0; b < 6; ++b) {
@@ -122,11 +124,8 @@ private:
     }
     template <int C>
     static void set_light_lds(int W) {
-        if (light_pair_lds_bytes<C>(W) > 160 * 1024) throw std::runtime_error("wide OSNet: LightConv pair tile exceeds the LDS");
         check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_light_fused<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   light_lds_bytes<C>(W)), "LightConv LDS");
-        check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_light_pair<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  light_pair_lds_bytes<C>(W)), "LightConv pair LDS");
     }
     // 1x1 convolution over n_pix pixels: out = [relu](X . W^T + bias [+ res])
     void gemm(const _Float16* X, const _Float16* W, const float* bias, _Float16* out, const _Float16* res, long M, int N, int K,
@@ -136,7 +135,10 @@ private:
         void* o = static_cast<void*>(out);
         if (ext.pool_w) {       // transition: conv + ReLU + 2 x 2 average pool in one launch (M must hold whole pairs of image rows per tile)
             if (N % 128 != 0 || (ext.pool_w != 16 && ext.pool_w != 32)) throw std::runtime_error("wide OSNet: pooled GEMM shape");
-            hipLaunchKernelGGL((k_gemm_f16_glds<5, 32>), dim3((unsigned)(mt * (N / 128))), dim3(256), gemm_glds_lds_bytes<32>(), st, X, W, bias, o, res, (int)M, N, K, relu, ext);
+            if (ext.pool_w == 32)
+                hipLaunchKernelGGL((k_gemm_f16_glds<5, 32>), dim3((unsigned)(mt * (N / 128))), dim3(256), gemm_glds_lds_bytes<32>(), st, X, W, bias, o, res, (int)M, N, K, relu, ext);
+            else
+                hipLaunchKernelGGL((k_gemm_f16_glds<6, 32>), dim3((unsigned)(mt * (N / 128))), dim3(256), gemm_glds_lds_bytes<32>(), st, X, W, bias, o, res, (int)M, N, K, relu, ext);
         } else if (N % 128 == 0)
             hipLaunchKernelGGL((k_gemm_f16_glds<4, 32>), dim3((unsigned)(mt * (N / 128))), dim3(256), gemm_glds_lds_bytes<32>(), st, X, W, bias, o, res, (int)M, N, K, relu, ext);
         else if (ext.K2) throw std::runtime_error("wide OSNet: the two-operand GEMM needs N % 128 == 0");
@@ -159,20 +161,6 @@ private:
         }
     }
     template <int C>
-    void light2_t(const _Float16* in, const LightW& a, const LightW& b, _Float16* out, float* gap, int n, int H, int W, hipStream_t st) {
-        hipLaunchKernelGGL(k_light_pair<C>, dim3(H / WIDE_BAND, n), dim3(512), (size_t)light_pair_lds_bytes<C>(W), st, in, d_w16_ + pk_.of(a.pw),
-                           d_w_ + a.dw, d_w_ + a.b, d_w16_ + pk_.of(b.pw), d_w_ + b.dw, d_w_ + b.b, out, gap, H, W);
-    }
-    void light2(int C, const _Float16* in, const LightW& a, const LightW& b, _Float16* out, float* gap, int n, int H, int W, hipStream_t st) {
-        switch (C) {
-            case 32: light2_t<32>(in, a, b, out, gap, n, H, W, st); break;
-            case 64: light2_t<64>(in, a, b, out, gap, n, H, W, st); break;
-            case 96: light2_t<96>(in, a, b, out, gap, n, H, W, st); break;
-            case 128: light2_t<128>(in, a, b, out, gap, n, H, W, st); break;
-            default: throw std::runtime_error("wide OSNet: unsupported middle width");
-        }
-    }
-    template <int C>
     void gate_t(const BlockW& B, _Float16* const* br, _Float16* out, int n, int P, int nbands, hipStream_t st) {
         const int ppb = 128;
         hipLaunchKernelGGL(k_gate_sum4<C>, dim3(n, (P + ppb - 1) / ppb), dim3(256), 0, st, br[0], br[1], br[2], br[3], gap_part_,
@@ -187,18 +175,14 @@ private:
         gemm(x, d_w16_ + pk_.of(B.conv1_w), d_w_ + B.conv1_b, x1, nullptr, n_pix, B.mid, B.cin, 1, st);
         int li = 0;
         for (int br = 0; br < 4; ++br) {
-            // a branch is a chain of br + 1 LightConvs: pairs go through k_light_pair (their intermediate tensor stays in LDS)
+            // a branch is a chain of br + 1 LightConvs, one launch each
             const _Float16* cur = x1;
             const int L = br + 1;
-            for (int k = 0; k < L;) {
-                const bool pair = L - k >= 2;
-                const bool last = k + (pair ? 2 : 1) == L;
-                _Float16* dst = last ? brs[br] : tmp[(k >> 1) & 1];
-                float* gap = last ? gap_part_ + (long)br * n * nbands * B.mid : nullptr;
-                if (pair) light2(B.mid, cur, B.light[li + k], B.light[li + k + 1], dst, gap, n, H, W, st);
-                else light(B.mid, cur, B.light[li + k], dst, gap, n, H, W, st);
+            for (int k = 0; k < L; ++k) {
+                const bool last = k + 1 == L;
+                _Float16* dst = last ? brs[br] : tmp[k & 1];
+                light(B.mid, cur, B.light[li + k], dst, last ? gap_part_ + (long)br * n * nbands * B.mid : nullptr, n, H, W, st);
                 cur = dst;
-                k += pair ? 2 : 1;
             }
             li += L;
         }

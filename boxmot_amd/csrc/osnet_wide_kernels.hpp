@@ -147,16 +147,15 @@ __global__ void __launch_bounds__(256) k_wide_stem(const _Float16* __restrict__ 
 //             (pixel stride C + 8 halves: 16-byte aligned rows, the 8-byte accumulator writes at most 2-way conflicted).  Rows
 //             outside the image are ZERO: the 1x1 has no bias, so the zero padding of the depthwise input is exactly a zero row.
 //   light_dw  depthwise 3x3 + bias + ReLU from T: thread = (column, 8-channel group), sliding 3 x 3 window down its rows, fp32.
-// k_light_fused (256 threads) = pw -> dw for one LightConv; k_light_pair (512 threads) = pw -> dw -> pw -> dw for TWO chained
-// LightConvs of a branch with a two-row halo: the intermediate tensor of the pair lives only in LDS (a pair reads 12 / 8 of the
-// input and writes the output once, instead of two reads and two writes).
+// k_light_fused (256 threads) = pw -> dw for one LightConv.  (Two chained LightConvs in one launch -- pw -> dw -> pw -> dw with a
+// two-row halo, the intermediate tensor only in LDS, half the HBM traffic -- was built from the same two blocks and measured
+// 1.5x slower than two launches: 101 KB of LDS leave one workgroup per CU, whose four phases overlap with nothing;
+// profiles/r2_c3_fusion_ab.txt.)
 //   in / out  fp16 NHWC [n][H][W][C];  pw fp16 [C][C] (out-major, as stored);  dw fp32 [C][9] with BN folded;  bias fp32 [C]
 //   gap_part  nullptr, or fp32 [n][bands][C]: sum over the band's pixels of the output (for the channel gate's average pool)
 // ---------------------------------------------------------------------------
 template <int C>
 __host__ __device__ constexpr int light_lds_bytes(int W) { return (WIDE_BAND + 2) * W * (C + 8) * 2; }
-template <int C>
-__host__ __device__ constexpr int light_pair_lds_bytes(int W) { return ((WIDE_BAND + 4) + (WIDE_BAND + 2)) * W * (C + 8) * 2; }
 
 template <int C, class LoadB>
 __device__ inline void light_pw(int n_ptiles, int wave, int nwaves, int lane, const _Float16* __restrict__ pw, _Float16* T, LoadB loadb) {
@@ -289,66 +288,6 @@ __global__ void __launch_bounds__(256) k_light_fused(const _Float16* __restrict_
             for (int j = 0; j < 8; ++j) gsum[j] += (float)o[j];     // the gate pools the tensor the next layer sees (fp16-rounded)
         });
     if (gap_part) light_gap<C>(gsum, m, W, reinterpret_cast<float*>(lds_raw), gap_part + (crop * nbands + band) * C);
-}
-
-// two chained LightConvs (pw1, dw1, b1) -> (pw2, dw2, b2): 512 threads, LDS = T (12 rows, later reused for the second 1x1's
-// 10 rows) + U (the first LightConv's output on 10 rows, zero outside the image: the second 1x1 has no bias either)
-template <int C>
-__global__ void __launch_bounds__(512) k_light_pair(const _Float16* __restrict__ in, const _Float16* __restrict__ pw1,
-                                                    const float* __restrict__ dw1, const float* __restrict__ b1,
-                                                    const _Float16* __restrict__ pw2, const float* __restrict__ dw2,
-                                                    const float* __restrict__ b2, _Float16* __restrict__ out,
-                                                    float* __restrict__ gap_part, int H, int W) {
-    static_assert(C % 32 == 0 && C <= 128, "middle width");
-    BM_DYNAMIC_LDS_T(unsigned char, lds_raw);
-    constexpr int LD = C + 8;
-    _Float16* T = reinterpret_cast<_Float16*>(lds_raw);
-    _Float16* U = T + (WIDE_BAND + 4) * W * LD;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
-    const int band = blockIdx.x, nbands = gridDim.x;
-    const long crop = blockIdx.y;
-    const int r0 = band * WIDE_BAND;
-    const _Float16* img = in + crop * H * W * (long)C;
-    // T rows 0 .. 11 <-> image rows r0 - 2 .. r0 + 9
-    light_pw<C>((WIDE_BAND + 4) * W / 16, wave, 8, lane, pw1, T, [&](int px, int s) {
-        const int lrow = px / W, col = px - lrow * W, grow = r0 - 2 + lrow;
-        ch8 b = ch8{0, 0, 0, 0, 0, 0, 0, 0};
-        if (grow >= 0 && grow < H) b = *reinterpret_cast<const ch8*>(img + ((long)grow * W + col) * C + 32 * s + 8 * g);
-        return b;
-    });
-    __syncthreads();
-    // U rows 0 .. 9 <-> image rows r0 - 1 .. r0 + 8
-    const LightMap m = light_map<C>(tid, 512, W, 4);
-    {
-        constexpr int R = WIDE_BAND + 2;
-        const int rpg = (R + m.ng - 1) / m.ng;
-        const int lr0 = m.grp * rpg, lr1 = lr0 + rpg < R ? lr0 + rpg : R;
-        const ch8 zero = ch8{0, 0, 0, 0, 0, 0, 0, 0};
-        if (m.active)
-            light_dw<C>(T, W, m.x, m.cg, lr0, lr1, dw1, b1, [&](int lr, const ch8& o) {
-                const int grow = r0 - 1 + lr;
-                *reinterpret_cast<ch8*>(U + (lr * W + m.x) * LD + m.cg * 8) = (grow >= 0 && grow < H) ? o : zero;
-            });
-    }
-    __syncthreads();
-    // second 1x1 on U's 10 rows -> T rows 0 .. 9
-    light_pw<C>((WIDE_BAND + 2) * W / 16, wave, 8, lane, pw2, T, [&](int px, int s) {
-        return *reinterpret_cast<const ch8*>(U + px * LD + 32 * s + 8 * g);
-    });
-    __syncthreads();
-    float gsum[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) gsum[j] = 0.f;
-    {
-        const int rpg = WIDE_BAND / m.ng;
-        if (m.active)
-            light_dw<C>(T, W, m.x, m.cg, m.grp * rpg, (m.grp + 1) * rpg, dw2, b2, [&](int lr, const ch8& o) {
-                *reinterpret_cast<ch8*>(out + ((crop * H + r0 + lr) * W + m.x) * (long)C + m.cg * 8) = o;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) gsum[j] += (float)o[j];
-            });
-    }
-    if (gap_part) light_gap<C>(gsum, m, W, reinterpret_cast<float*>(U), gap_part + (crop * nbands + band) * C);
 }
 
 // ---------------------------------------------------------------------------

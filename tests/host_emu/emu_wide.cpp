@@ -85,7 +85,8 @@ extern "C" int emu_wide_forward(const float* blob, long n_floats, const float* c
     auto gemm = [&](const _Float16* X, const _Float16* Wt, const float* bias, _Float16* out, const _Float16* res, long M, int Nn, int K, int relu,
                     GemmExt ext = GemmExt{}) {
         const long gx = (M + GEMM_BM - 1) / GEMM_BM;
-        if (ext.pool_w) launch(gx * (Nn / 128), 1, 256, [=]() { k_gemm_f16_glds<5, 32>(X, Wt, bias, out, res, (int)M, Nn, K, relu, ext); });
+        if (ext.pool_w == 32) launch(gx * (Nn / 128), 1, 256, [=]() { k_gemm_f16_glds<5, 32>(X, Wt, bias, out, res, (int)M, Nn, K, relu, ext); });
+        else if (ext.pool_w == 16) launch(gx * (Nn / 128), 1, 256, [=]() { k_gemm_f16_glds<6, 32>(X, Wt, bias, out, res, (int)M, Nn, K, relu, ext); });
         else if (Nn % 128 == 0) launch(gx * (Nn / 128), 1, 256, [=]() { k_gemm_f16_glds<4, 32>(X, Wt, bias, out, res, (int)M, Nn, K, relu, ext); });
         else if (Nn % 96 == 0) launch(gx * (Nn / 96), 1, 256, [=]() { k_gemm_f16<4, 96>(X, Wt, bias, out, res, (int)M, Nn, K, relu); });
         else if (Nn % 64 == 0) launch(gx * (Nn / 64), 1, 256, [=]() { k_gemm_f16<4, 64>(X, Wt, bias, out, res, (int)M, Nn, K, relu); });
@@ -98,14 +99,6 @@ extern "C" int emu_wide_forward(const float* blob, long n_floats, const float* c
         else if (C == 96) launch(H / WIDE_BAND, n, 256, [=]() { k_light_fused<96>(in, pw, dw, b, out, gap, H, W); });
         else launch(H / WIDE_BAND, n, 256, [=]() { k_light_fused<128>(in, pw, dw, b, out, gap, H, W); });
     };
-    auto light2 = [&](int C, const _Float16* in, const LightW& la, const LightW& lb, _Float16* out, float* gap, int H, int W) {
-        const _Float16 *p1 = W16 + pk.of(la.pw), *p2 = W16 + pk.of(lb.pw);
-        const float *d1 = W32 + la.dw, *c1 = W32 + la.b, *d2 = W32 + lb.dw, *c2 = W32 + lb.b;
-        if (C == 32) launch(H / WIDE_BAND, n, 512, [=]() { k_light_pair<32>(in, p1, d1, c1, p2, d2, c2, out, gap, H, W); });
-        else if (C == 64) launch(H / WIDE_BAND, n, 512, [=]() { k_light_pair<64>(in, p1, d1, c1, p2, d2, c2, out, gap, H, W); });
-        else if (C == 96) launch(H / WIDE_BAND, n, 512, [=]() { k_light_pair<96>(in, p1, d1, c1, p2, d2, c2, out, gap, H, W); });
-        else launch(H / WIDE_BAND, n, 512, [=]() { k_light_pair<128>(in, p1, d1, c1, p2, d2, c2, out, gap, H, W); });
-    };
     auto osblock = [&](const BlockW& B, const _Float16* x, _Float16* out, int H, int W) {
         const long n_pix = (long)n * H * W;
         const int nbands = H / WIDE_BAND, P = H * W;
@@ -117,15 +110,11 @@ extern "C" int emu_wide_forward(const float* blob, long n_floats, const float* c
         for (int br = 0; br < 4; ++br) {
             const _Float16* cur = x1;
             const int Lc = br + 1;
-            for (int k = 0; k < Lc;) {
-                const bool pair = Lc - k >= 2;
-                const bool last = k + (pair ? 2 : 1) == Lc;
-                _Float16* dst = last ? brs[br] : tmp[(k >> 1) & 1];
-                float* gap = last ? gap_part.data() + (long)br * n * nbands * B.mid : nullptr;
-                if (pair) light2(B.mid, cur, B.light[li + k], B.light[li + k + 1], dst, gap, H, W);
-                else light(B.mid, cur, B.light[li + k], dst, gap, H, W);
+            for (int k = 0; k < Lc; ++k) {
+                const bool last = k + 1 == Lc;
+                _Float16* dst = last ? brs[br] : tmp[k & 1];
+                light(B.mid, cur, B.light[li + k], dst, last ? gap_part.data() + (long)br * n * nbands * B.mid : nullptr, H, W);
                 cur = dst;
-                k += pair ? 2 : 1;
             }
             li += Lc;
         }
