@@ -12,7 +12,7 @@
 // 64 rows x BN/2 features, operands staged through LDS (rows padded to 40 halves: conflict-free 16-byte fragment reads), the
 // next k-tile's global loads in flight while the current one multiplies.
 //   EPI 0: fp16 store                          EPI 1: QuickGELU, fp16 store          EPI 2: fp32 C += result
-//   EPI 3: fp32 store                          EPI 4: (+ fp16 residual[m][n]) (ReLU when relu != 0), fp16 store
+//   EPI 3: (ReLU when relu != 0) fp32 store    EPI 4: (+ fp16 residual[m][n]) (ReLU when relu != 0), fp16 store
 //   EPI 5 / 6 (k_gemm_f16_glds only): ReLU + 2 x 2 average pool over an image of width 32 / 16, fp16 store of the pooled tensor
 #pragma once
 
@@ -159,6 +159,10 @@ __global__ void __launch_bounds__(256) k_gemm_f16(const _Float16* __restrict__ X
                 for (int r = 0; r < 4; ++r) old[r] += v[r];
                 *reinterpret_cast<cf4*>(c) = old;
             } else {
+                if (relu) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+                }
                 *reinterpret_cast<cf4*>(static_cast<float*>(Cout) + m * N + n) = v;
             }
         }
@@ -344,6 +348,10 @@ __global__ void __launch_bounds__(256) k_gemm_f16_glds(const _Float16* __restric
                 for (int r = 0; r < 4; ++r) old[r] += v[r];
                 *reinterpret_cast<cf4*>(c) = old;
             } else {
+                if (relu) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+                }
                 *reinterpret_cast<cf4*>(static_cast<float*>(Cout) + m * N + n) = v;
             }
         }

@@ -47,6 +47,9 @@ public:
         act_a_ = alloc<_Float16>(blk, owned); act_b_ = alloc<_Float16>(blk, owned);
         for (auto& m : mid_) m = alloc<_Float16>(mid, owned);
         gap_part_ = alloc<float>(4 * n * (64 / WIDE_BAND) * 128, owned);
+        gap16_ = alloc<_Float16>(n * L.c[3], owned);
+        fc32_ = alloc<float>(n * L.feat, owned);
+        if (L.feat % 128 != 0 || L.c[3] % 32 != 0) throw std::runtime_error("wide OSNet: head GEMM shape");
         check(hipDeviceSynchronize(), "clear crop buffer");     // nothing asynchronous is pending if a later step of the constructor throws
         for (int b = 0; b < 6; ++b) {                            // dynamic-LDS limits for the (middle width, image width) pairs this network uses
             const int C = L.block[b].mid, W = 32 >> (b / 2);
@@ -63,6 +66,8 @@ public:
         check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_glds<5, 32>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   gemm_glds_lds_bytes<32>()), "GEMM LDS");
         check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_glds<6, 32>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  gemm_glds_lds_bytes<32>()), "GEMM LDS");
+        check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_glds<3, 32>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   gemm_glds_lds_bytes<32>()), "GEMM LDS");
         // conv3 + downsample run as one GEMM: their folded-BN biases add up
         std::vector<float> bs;
@@ -107,7 +112,16 @@ public:
         }
         const int c3 = L_.c[3];
         gemm(cur, d_w16_ + pk_.of(L_.conv5_w), d_w_ + L_.conv5_b, other, nullptr, (long)n * H * W, c3, c3, 1, st);
-        hipLaunchKernelGGL(k_wide_head, dim3(n), dim3(256), 0, st, other, d_w_ + L_.fc_w, d_w_ + L_.fc_b, d_out, d_out_rows, H * W, c3, L_.feat);
+        // head: GAP -> FC (+ folded BN, ReLU) as one GEMM over all crops -> L2 + scatter
+        const long g8 = (long)n * (c3 / 8);
+        hipLaunchKernelGGL(k_wide_gap, dim3((unsigned)((g8 + 255) / 256)), dim3(256), 0, st, other, gap16_, H * W, c3, g8);
+        {
+            const long mt = ((long)n + GEMM_BM - 1) / GEMM_BM;
+            hipLaunchKernelGGL((k_gemm_f16_glds<3, 32>), dim3((unsigned)(mt * (L_.feat / 128))), dim3(256), gemm_glds_lds_bytes<32>(), st, gap16_,
+                               d_w16_ + pk_.of(L_.fc_w), d_w_ + L_.fc_b, static_cast<void*>(fc32_), static_cast<const _Float16*>(nullptr), n, L_.feat, c3,
+                               1, GemmExt{});
+        }
+        hipLaunchKernelGGL(k_wide_l2, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, fc32_, d_out, d_out_rows, (long)n, L_.feat);
         check(hipGetLastError(), "wide OSNet launch");
     }
 
@@ -210,6 +224,8 @@ private:
     _Float16 *crops16_ = nullptr, *act_a_ = nullptr, *act_b_ = nullptr;
     _Float16* mid_[8] = {};
     float* gap_part_ = nullptr;
+    _Float16* gap16_ = nullptr;             // [n][c3] pooled features, the FC GEMM's activation operand
+    float* fc32_ = nullptr;                 // [n][feat] FC output before the L2 norm
     float* d_bsum_ = nullptr;
     long bsum_off_[6] = {};
 };

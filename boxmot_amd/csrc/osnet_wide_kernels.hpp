@@ -159,20 +159,28 @@ __host__ __device__ constexpr int light_lds_bytes(int W) { return (WIDE_BAND + 2
 
 template <int C, class LoadB>
 __device__ inline void light_pw(int n_ptiles, int wave, int nwaves, int lane, const _Float16* __restrict__ pw, _Float16* T, LoadB loadb) {
-    constexpr int LD = C + 8, KS = C / 32, CT = C / 16;
+    constexpr int LD = C + 8, KS = C / 32, CT = C / 16, MAXT = 5;      // a wave owns <= 5 tiles: (8 + 2) rows x 32 pixels / 16 / 4 waves
     const int g = lane >> 4, l16 = lane & 15;
-    for (int pt = wave; pt < n_ptiles; pt += nwaves) {
-        const int px = pt * 16 + l16;
-        ch8 b[KS];
+    // every B fragment of this wave's tiles is requested before the first MFMA: up to 10 KB per wave in flight instead of 2
+    ch8 b[MAXT][KS];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) b[s] = loadb(px, s);
+    for (int i = 0; i < MAXT; ++i) {
+        const int pt = wave + i * nwaves;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) b[i][s] = pt < n_ptiles ? loadb(pt * 16 + l16, s) : ch8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+        const int pt = wave + i * nwaves;
+        if (pt >= n_ptiles) break;
+        const int px = pt * 16 + l16;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             cf4 acc = cf4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const ch8 a = *reinterpret_cast<const ch8*>(pw + (long)(16 * ct + l16) * C + 32 * s + 8 * g);
-                acc = BM_MFMA_F16_K32(a, b[s], acc);
+                acc = BM_MFMA_F16_K32(a, b[i][s], acc);
             }
             ch4 o;
 #pragma unroll
@@ -352,39 +360,43 @@ __global__ void __launch_bounds__(256) k_gate_sum4(const _Float16* __restrict__ 
     }
 }
 
-// head: global average pool -> Linear + folded BatchNorm1d -> ReLU -> L2 (osnet.py:393-396 + base_backend.py:206), fp16 NHWC in.
-// One workgroup per crop; the FC rows are read 16 bytes per lane by a wavefront per output feature group.
-__global__ void __launch_bounds__(256) k_wide_head(const _Float16* __restrict__ in, const float* __restrict__ fc_w,
-                                                   const float* __restrict__ fc_b, float* __restrict__ out_base,
-                                                   const int* __restrict__ out_rows, int P, int C, int F) {
-    __shared__ float s_v[512];
-    __shared__ float s_red[4];
-    const long n = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int c = tid; c < C; c += 256) {
-        float s = 0.f;
-        for (int p = 0; p < P; ++p) s += (float)in[(n * P + p) * C + c];
-        s_v[c] = s / (float)P;
+// head (osnet.py:393-396 + base_backend.py:206): global average pool -> Linear + folded BatchNorm1d -> ReLU -> L2, batched over
+// the crops of the pass: k_wide_gap (fp16 [n][C]), the FC as one k_gemm_f16_glds launch over all crops (fp32 out, ReLU in the
+// epilogue), k_wide_l2 (row norm + scatter to the caller's rows).  A per-crop head re-read the 1 MB FC matrix once per crop.
+__global__ void __launch_bounds__(256) k_wide_gap(const _Float16* __restrict__ in, _Float16* __restrict__ out, int P, int C, long total8) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;          // (crop, 8-channel group)
+    if (e >= total8) return;
+    const int C8 = C / 8;
+    const long n = e / C8;
+    const int cg = (int)(e - n * C8);
+    float s[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = 0.f;
+    const _Float16* p = in + n * P * (long)C + cg * 8;
+    for (int k = 0; k < P; ++k) {
+        const ch8 v = *reinterpret_cast<const ch8*>(p + (long)k * C);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] += (float)v[j];
     }
-    __syncthreads();
-    float* out = out_base + (out_rows ? (long)out_rows[n] : n) * F;
+    ch8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (_Float16)(s[j] / (float)P);
+    *reinterpret_cast<ch8*>(out + e * 8) = o;
+}
+
+// one wavefront per crop: out row (out_rows ? out_rows[n] : n) = v / |v|
+__global__ void __launch_bounds__(256) k_wide_l2(const float* __restrict__ v, float* __restrict__ out_base, const int* __restrict__ out_rows,
+                                                 long n_rows, int F) {
+    const int lane = threadIdx.x & 63;
+    const long n = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (n >= n_rows) return;
+    const float* src = v + n * F;
     float sq = 0.f;
-    for (int f = wave; f < F; f += 4) {
-        const float* wr = fc_w + (long)f * C;
-        float a = 0.f;
-        for (int c = lane; c < C; c += 64) a += wr[c] * s_v[c];
-        for (int m = 32; m > 0; m >>= 1) a += __shfl_xor(a, m, 64);
-        a += fc_b[f];
-        a = a > 0.f ? a : 0.f;
-        if (lane == 0) out[f] = a;
-        sq += a * a;                        // every lane holds the same value
-    }
-    if (lane == 0) s_red[wave] = sq;
-    __syncthreads();
-    const float nrm = sqrtf(s_red[0] + s_red[1] + s_red[2] + s_red[3]);
-    __syncthreads();
-    for (int f = wave; f < F; f += 4)
-        if (lane == 0) out[f] = out[f] / nrm;
+    for (int f = lane; f < F; f += 64) sq += src[f] * src[f];
+    for (int m = 32; m > 0; m >>= 1) sq += __shfl_xor(sq, m, 64);
+    const float nrm = sqrtf(sq);
+    float* out = out_base + (out_rows ? (long)out_rows[n] : n) * F;
+    for (int f = lane; f < F; f += 64) out[f] = src[f] / nrm;
 }
 
 }  // namespace bm

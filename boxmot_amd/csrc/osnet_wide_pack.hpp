@@ -48,6 +48,7 @@ inline WideW16 wide_pack_w16(const float* w, const OsnetLayout& L) {
     }
     for (int s = 0; s < 2; ++s) add(L.trans_w[s], (long)L.c[s + 1] * L.c[s + 1]);
     add(L.conv5_w, (long)L.c[3] * L.c[3]);
+    add(L.fc_w, (long)L.feat * L.c[3]);
     align();
     return P;
 }

@@ -164,7 +164,16 @@ extern "C" int emu_wide_forward(const float* blob, long n_floats, const float* c
     }
     const int c3 = ch[3];
     gemm(cur, W16 + pk.of(L.conv5_w), W32 + L.conv5_b, other, nullptr, (long)n * H * W, c3, c3, 1);
-    { const _Float16* i = other; const int P = H * W, F = L.feat;
-      launch(n, 1, 256, [=]() { k_wide_head(i, W32 + L.fc_w, W32 + L.fc_b, feats, rows, P, c3, F); }); }
+    {   // head: GAP -> FC GEMM (bias + ReLU) -> L2 + scatter
+        const int P = H * W, F = L.feat;
+        std::vector<_Float16> gap16((size_t)n * c3);
+        std::vector<float> fc32((size_t)n * F);
+        const long g8 = (long)n * (c3 / 8);
+        { const _Float16* i = other; _Float16* o = gap16.data(); launch((g8 + 255) / 256, 1, 256, [=]() { k_wide_gap(i, o, P, c3, g8); }); }
+        { const _Float16* x = gap16.data(); const _Float16* w = W16 + pk.of(L.fc_w); const float* b = W32 + L.fc_b; float* o = fc32.data();
+          const long mt = ((long)n + GEMM_BM - 1) / GEMM_BM;
+          launch(mt * (F / 128), 1, 256, [=]() { k_gemm_f16_glds<3, 32>(x, w, b, o, nullptr, n, F, c3, 1, GemmExt{}); }); }
+        { const float* v = fc32.data(); launch((n + 3) / 4, 1, 256, [=]() { k_wide_l2(v, feats, rows, (long)n, F); }); }
+    }
     return 0;
 }
