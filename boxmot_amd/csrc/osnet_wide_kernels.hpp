@@ -159,28 +159,21 @@ __host__ __device__ constexpr int light_lds_bytes(int W) { return (WIDE_BAND + 2
 
 template <int C, class LoadB>
 __device__ inline void light_pw(int n_ptiles, int wave, int nwaves, int lane, const _Float16* __restrict__ pw, _Float16* T, LoadB loadb) {
-    constexpr int LD = C + 8, KS = C / 32, CT = C / 16, MAXT = 5;      // a wave owns <= 5 tiles: (8 + 2) rows x 32 pixels / 16 / 4 waves
+    constexpr int LD = C + 8, KS = C / 32, CT = C / 16;
     const int g = lane >> 4, l16 = lane & 15;
-    // every B fragment of this wave's tiles is requested before the first MFMA: up to 10 KB per wave in flight instead of 2
-    ch8 b[MAXT][KS];
-#pragma unroll
-    for (int i = 0; i < MAXT; ++i) {
-        const int pt = wave + i * nwaves;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) b[i][s] = pt < n_ptiles ? loadb(pt * 16 + l16, s) : ch8{0, 0, 0, 0, 0, 0, 0, 0};
-    }
-#pragma unroll
-    for (int i = 0; i < MAXT; ++i) {
-        const int pt = wave + i * nwaves;
-        if (pt >= n_ptiles) break;
+    // (requesting all of a wave's B fragments before the first MFMA was measured: no gain at C = 64, 12-19 % slower at C = 96 / 128)
+    for (int pt = wave; pt < n_ptiles; pt += nwaves) {
         const int px = pt * 16 + l16;
+        ch8 b[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) b[s] = loadb(px, s);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             cf4 acc = cf4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const ch8 a = *reinterpret_cast<const ch8*>(pw + (long)(16 * ct + l16) * C + 32 * s + 8 * g);
-                acc = BM_MFMA_F16_K32(a, b[i][s], acc);
+                acc = BM_MFMA_F16_K32(a, b[s], acc);
             }
             ch4 o;
 #pragma unroll
