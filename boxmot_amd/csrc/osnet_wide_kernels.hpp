@@ -27,7 +27,10 @@
 
 namespace bm {
 
-constexpr int WIDE_BAND = 8;                 // image rows per k_light_fused workgroup
+#ifndef BM_WIDE_BAND
+#define BM_WIDE_BAND 8
+#endif
+constexpr int WIDE_BAND = BM_WIDE_BAND;       // image rows per k_light_fused workgroup (8 or 4: must divide the smallest image height, 16)
 
 // widths this kernel family takes: GEMM k-steps of 32, 16-channel MFMA tiles, k_light_fused's thread mapping
 inline bool wide_osnet_supports(const OsnetLayout& L) {
