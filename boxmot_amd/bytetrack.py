@@ -9,7 +9,8 @@ association, fixed 0.5 / 0.7 thresholds for the second / unconfirmed association
 unbounded removed list.  Pinned against the reference class through ``oracle/bytetrack.py``.
 
 Deviation: the id counter is per tracker (the reference's ``BaseTrack._count`` is process-global and is NOT rewound by the
-constructor, bytetrack/basetrack.py:16,37-40).  Rejected loudly: OBB detections, ``per_class=True``.
+constructor, bytetrack/basetrack.py:16,37-40).  ``per_class=True`` runs on the kernel's per-class active lists (shared lost list,
+removed flags and id counter, basetracker.py:213-271).  Rejected loudly: OBB detections.
 """
 from __future__ import annotations
 
@@ -23,8 +24,6 @@ class ByteTrack(BotSort):
 
     def __init__(self, min_conf: float = 0.1, track_thresh: float = 0.45, match_thresh: float = 0.8, track_buffer: int = 25,
                  frame_rate: int = 30, max_tracks: int = 1024, max_dets: int = 256, **kwargs: Any):
-        if kwargs.get("per_class", False):
-            raise NotImplementedError("boxmot_amd.ByteTrack: per_class=True is not implemented on the HIP path")
         for k in ("reid_model", "with_reid", "use_cmc", "cmc", "emb_dim"):
             if k in kwargs:
                 raise TypeError(f"ByteTrack() got an unexpected keyword argument {k!r}")

@@ -151,10 +151,11 @@ struct BoxMOTHipEcc {
     std::vector<uint8_t*> frame_bufs;
     std::vector<int> cur;                        // per stream: which of its two image buffers holds the newest frame
     std::vector<char> has_prev;
+    bool owns_stream = true;                     // false: launches on a tracker handle's stream (estimation inside update)
     ~BoxMOTHipEcc() {
         for (void* p : owned) (void)hipFree(p);
         for (auto p : frame_bufs) if (p) (void)hipFree(p);
-        if (stream) (void)hipStreamDestroy(stream);
+        if (stream && owns_stream) (void)hipStreamDestroy(stream);
     }
 };
 
@@ -211,6 +212,8 @@ struct BoxMOTHipBotSort {
     // reid
     std::unique_ptr<bm::ReidEngine> reid;
     int reid_mode = 0, reid_pad = 0;
+    bool use_ecc = false;                        // cmc_method = "ecc": the estimator runs inside update on the uploaded frame
+    std::unique_ptr<BoxMOTHipEcc> ecc;
     int* d_crop_count = nullptr;
     int* d_crop_stream = nullptr;
     float* d_crop_boxes = nullptr;
@@ -305,9 +308,10 @@ void zero_state(BoxMOTHipBotSort* h) {
 
 void build(BoxMOTHipBotSort* h) {
     const BoxMOTHipBotSortConfig& c = h->cfg;
-    if (c.cmc_method && c.cmc_method[0] && std::strcmp(c.cmc_method, "none") != 0)
-        throw std::runtime_error("boxmot_hip: camera-motion estimation (ecc/sof/...) is not implemented; pass cmc_method=none "
-                                 "and supply the warp per frame with boxmot_hip_botsort_set_warp");
+    h->use_ecc = c.cmc_method && std::strcmp(c.cmc_method, "ecc") == 0;
+    if (c.cmc_method && c.cmc_method[0] && std::strcmp(c.cmc_method, "none") != 0 && !h->use_ecc)
+        throw std::runtime_error(std::string("boxmot_hip: camera-motion estimator '") + c.cmc_method + "' is not implemented (have: ecc, none); "
+                                 "supply the warp per frame with boxmot_hip_botsort_set_warp");
     h->reid_pad = 0;
     if (c.reid_preprocess && c.reid_preprocess[0]) {
         if (std::strcmp(c.reid_preprocess, "resize_pad") == 0) h->reid_pad = 1;
@@ -320,7 +324,6 @@ void build(BoxMOTHipBotSort* h) {
     if (c.removed_stracks_buffer < 0) throw std::runtime_error("boxmot_hip: removed_stracks_buffer must be >= 0");
     if (c.tracker_kind != 0 && c.tracker_kind != 1) throw std::runtime_error("boxmot_hip: tracker_kind must be 0 (BoT-SORT) or 1 (ByteTrack)");
     if (c.tracker_kind == 1) {
-        if (c.n_class_lists != 1) throw std::runtime_error("boxmot_hip: ByteTrack with per-class track lists is not implemented");
         h->cfg.with_reid = 0; h->cfg.fuse_first_associate = 1;
     }
     h->S = c.n_streams; h->cap = c.max_tracks; h->nd = c.max_dets; h->dim = c.emb_dim; h->n_lists = c.n_class_lists;
@@ -444,6 +447,49 @@ void upload_frame(BoxMOTHipBotSort* h, int s, const uint8_t* image, int rows, in
     BM_HIP(hipMemcpyAsync(h->frame_bufs[s], image, bytes, hipMemcpyHostToDevice, h->stream));
 }
 
+// ---- ECC estimator plumbing (C ABI boxmot_hip_ecc_*; also owned by a BoT-SORT handle created with cmc_method = "ecc") ----
+void ecc_init(BoxMOTHipEcc* h, int n_streams, int image_rows, int image_cols, double scale, double eps, int max_iter, hipStream_t external) {
+    if (n_streams < 1 || image_rows < 8 || image_cols < 8) throw std::runtime_error("boxmot_hip: ECC needs >= 1 stream and a frame of at least 8 x 8");
+    if (!(scale > 0.0) || scale > 1.0 || !(eps > 0.0) || max_iter < 1) throw std::runtime_error("boxmot_hip: ECC scale must be in (0, 1], eps > 0, max_iter >= 1");
+    h->S = n_streams; h->rows = image_rows; h->cols = image_cols; h->scale = scale; h->eps = eps; h->max_iter = max_iter;
+    h->w = (int)std::nearbyint(image_cols * scale); h->h = (int)std::nearbyint(image_rows * scale);     // saturate_cast<int>(ssize * fx)
+    if (h->w < 4 || h->h < 4) throw std::runtime_error("boxmot_hip: ECC image too small after scaling");
+    if (external) { h->stream = external; h->owns_stream = false; }
+    else BM_HIP(hipStreamCreate(&h->stream));
+    const size_t P = (size_t)h->h * h->w, S = n_streams;
+    h->img = zalloc<float>(S * 2 * P, h->owned);
+    h->gx = zalloc<float>(S * P, h->owned); h->gy = zalloc<float>(S * P, h->owned);
+    h->scratch = zalloc<float>(S * 3 * P, h->owned);
+    h->d_warp = zalloc<double>(S * 6, h->owned); h->d_info = zalloc<int>(S * 2, h->owned);
+    h->d_frames = zalloc<const uint8_t*>(S, h->owned);
+    h->frame_bufs.assign(S, nullptr); h->cur.assign(S, 0); h->has_prev.assign(S, 0);
+}
+
+// one stream, frames d_frames[0]: preprocess into the stream's other buffer; estimate against the previous one when there is one
+void ecc_run_one(BoxMOTHipEcc* h, int s, const uint8_t* const* d_frame_ptr, double* out_warp6, int* out_iterations) {
+    const long P = (long)h->h * h->w;
+    const int nxt = 1 - h->cur[s];
+    float* imgs = h->img + (size_t)s * 2 * P;
+    const unsigned blocks = (unsigned)((P + 255) / 256);
+    hipLaunchKernelGGL(bm::k_ecc_preprocess, dim3(blocks, 1), dim3(256), 0, h->stream, d_frame_ptr, imgs + nxt * P, P, h->rows, h->cols, h->h,
+                       h->w, 1.0 / h->scale);
+    double warp[6] = {1, 0, 0, 0, 1, 0};
+    int info[2] = {0, 0};
+    if (h->has_prev[s]) {
+        hipLaunchKernelGGL(bm::k_ecc_gradients, dim3(blocks, 1), dim3(256), 0, h->stream, imgs + nxt * P, P, h->gx + s * P, h->gy + s * P, h->h, h->w);
+        hipLaunchKernelGGL(bm::k_ecc_solve, dim3(1), dim3(bm::ECC_THREADS), 0, h->stream, imgs + h->cur[s] * P, imgs + nxt * P, P, h->gx + s * P,
+                           h->gy + s * P, h->scratch + (size_t)s * 3 * P, h->d_warp + s * 6, h->d_info + s * 2, h->h, h->w, h->eps, h->max_iter,
+                           (float)h->scale);
+        BM_HIP(hipMemcpyAsync(warp, h->d_warp + s * 6, sizeof(warp), hipMemcpyDeviceToHost, h->stream));
+        BM_HIP(hipMemcpyAsync(info, h->d_info + s * 2, sizeof(info), hipMemcpyDeviceToHost, h->stream));
+    }
+    BM_HIP(hipStreamSynchronize(h->stream));
+    BM_HIP(hipGetLastError());
+    h->cur[s] = nxt; h->has_prev[s] = 1;
+    for (int k = 0; k < 6; ++k) out_warp6[k] = warp[k];
+    if (out_iterations) *out_iterations = info[1];
+}
+
 struct StreamIn {
     const float* dets; int det_rows;
     const float* embs;
@@ -489,6 +535,27 @@ void host_update(BoxMOTHipBotSort* h, int s0, int n, const StreamIn* in, int det
     BM_HIP(hipMemcpyAsync(h->d_ndets + s0, h->h_ndets.data() + s0, n * 4, hipMemcpyHostToDevice, h->stream));
     BM_HIP(hipMemcpyAsync(h->d_list_sel + s0, h->h_list_sel.data() + s0, n * 4, hipMemcpyHostToDevice, h->stream));
     if (fc_set) BM_HIP(hipMemcpyAsync(h->d_fc_set + s0, h->h_fc_set.data() + s0, n * 4, hipMemcpyHostToDevice, h->stream));
+    if (h->use_ecc && !list_sel) {
+        // cmc_method = "ecc" (botsort.py:116-117, :141-145): the estimator sees every frame of the stream; its warp is applied to
+        // the predicted pool by this update.  (Per-class fan-out calls pass list_sel: the frame is estimated once, by the caller.)
+        for (int k = 0; k < n; ++k) {
+            if (in[k].det_rows < 0) continue;
+            if (!in[k].image) throw std::runtime_error("boxmot_hip: cmc_method=ecc needs the frame (image pointer is null)");
+            if (image_channels != 3) throw std::runtime_error("boxmot_hip: cmc_method=ecc needs a 3-channel uint8 BGR image");
+            if (!d_frames_ext) upload_frame(h, s0 + k, in[k].image, image_rows, image_cols, image_channels);
+        }
+        if (!h->ecc) {
+            h->ecc.reset(new BoxMOTHipEcc());
+            ecc_init(h->ecc.get(), h->S, image_rows, image_cols, 0.15, 1e-5, 100, h->stream);
+        }
+        if (h->ecc->rows != image_rows || h->ecc->cols != image_cols) throw std::runtime_error("boxmot_hip: frame size changed between updates");
+        for (int k = 0; k < n; ++k) {
+            if (in[k].det_rows < 0) continue;
+            const uint8_t* const* fp = (d_frames_ext ? d_frames_ext : h->d_frames) + (s0 + k);
+            ecc_run_one(h->ecc.get(), s0 + k, fp, h->h_warp.data() + (size_t)(s0 + k) * 6, nullptr);
+            h->h_warp_flag[s0 + k] = 1;
+        }
+    }
     bool any_warp = false;
     for (int k = 0; k < n; ++k) any_warp = any_warp || h->h_warp_flag[s0 + k] != 0;
     if (any_warp) {     // warps set with boxmot_hip_botsort_set_warp are consumed by this update
@@ -506,7 +573,7 @@ void host_update(BoxMOTHipBotSort* h, int s0, int n, const StreamIn* in, int det
         run_reid(h, s0, n, h->d_dets, h->d_ndets, d_frames_ext, image_rows, image_cols, h->d_embs);
     } else if (need_reid) {
         for (int k = 0; k < n; ++k) {
-            if (in[k].image) upload_frame(h, s0 + k, in[k].image, image_rows, image_cols, image_channels);
+            if (in[k].image) { if (!(h->use_ecc && !list_sel)) upload_frame(h, s0 + k, in[k].image, image_rows, image_cols, image_channels); }
             else if (h->frame_bufs[s0 + k] == nullptr) throw std::runtime_error("Image data pointer is null.");
         }
         run_reid(h, s0, n, h->d_dets, h->d_ndets, h->d_frames, h->frame_rows, h->frame_cols, h->d_embs);
@@ -1239,20 +1306,8 @@ BoxMOTHipEcc* boxmot_hip_ecc_create(int n_streams, int image_rows, int image_col
     BoxMOTHipEcc* h = nullptr;
     const int ok = guard([&]() {
         require_device();
-        if (n_streams < 1 || image_rows < 8 || image_cols < 8) throw std::runtime_error("boxmot_hip: ECC needs >= 1 stream and a frame of at least 8 x 8");
-        if (!(scale > 0.0) || scale > 1.0 || !(eps > 0.0) || max_iter < 1) throw std::runtime_error("boxmot_hip: ECC scale must be in (0, 1], eps > 0, max_iter >= 1");
         h = new BoxMOTHipEcc();
-        h->S = n_streams; h->rows = image_rows; h->cols = image_cols; h->scale = scale; h->eps = eps; h->max_iter = max_iter;
-        h->w = (int)std::nearbyint(image_cols * scale); h->h = (int)std::nearbyint(image_rows * scale);     // saturate_cast<int>(ssize * fx)
-        if (h->w < 4 || h->h < 4) throw std::runtime_error("boxmot_hip: ECC image too small after scaling");
-        BM_HIP(hipStreamCreate(&h->stream));
-        const size_t P = (size_t)h->h * h->w, S = n_streams;
-        h->img = zalloc<float>(S * 2 * P, h->owned);
-        h->gx = zalloc<float>(S * P, h->owned); h->gy = zalloc<float>(S * P, h->owned);
-        h->scratch = zalloc<float>(S * 3 * P, h->owned);
-        h->d_warp = zalloc<double>(S * 6, h->owned); h->d_info = zalloc<int>(S * 2, h->owned);
-        h->d_frames = zalloc<const uint8_t*>(S, h->owned);
-        h->frame_bufs.assign(S, nullptr); h->cur.assign(S, 0); h->has_prev.assign(S, 0);
+        ecc_init(h, n_streams, image_rows, image_cols, scale, eps, max_iter, nullptr);
     });
     if (!ok) { delete h; return nullptr; }
     return h;
@@ -1266,31 +1321,6 @@ int boxmot_hip_ecc_reset(BoxMOTHipEcc* handle, int stream) {
         if (stream >= handle->S) throw std::runtime_error("boxmot_hip: stream index out of range");
         for (int s = 0; s < handle->S; ++s) if (stream < 0 || s == stream) handle->has_prev[s] = 0;
     });
-}
-
-// one stream, frames d_frames[0]: preprocess into the stream's other buffer; estimate against the previous one when there is one
-static void ecc_run_one(BoxMOTHipEcc* h, int s, const uint8_t* const* d_frame_ptr, double* out_warp6, int* out_iterations) {
-    const long P = (long)h->h * h->w;
-    const int nxt = 1 - h->cur[s];
-    float* imgs = h->img + (size_t)s * 2 * P;
-    const unsigned blocks = (unsigned)((P + 255) / 256);
-    hipLaunchKernelGGL(bm::k_ecc_preprocess, dim3(blocks, 1), dim3(256), 0, h->stream, d_frame_ptr, imgs + nxt * P, P, h->rows, h->cols, h->h,
-                       h->w, 1.0 / h->scale);
-    double warp[6] = {1, 0, 0, 0, 1, 0};
-    int info[2] = {0, 0};
-    if (h->has_prev[s]) {
-        hipLaunchKernelGGL(bm::k_ecc_gradients, dim3(blocks, 1), dim3(256), 0, h->stream, imgs + nxt * P, P, h->gx + s * P, h->gy + s * P, h->h, h->w);
-        hipLaunchKernelGGL(bm::k_ecc_solve, dim3(1), dim3(bm::ECC_THREADS), 0, h->stream, imgs + h->cur[s] * P, imgs + nxt * P, P, h->gx + s * P,
-                           h->gy + s * P, h->scratch + (size_t)s * 3 * P, h->d_warp + s * 6, h->d_info + s * 2, h->h, h->w, h->eps, h->max_iter,
-                           (float)h->scale);
-        BM_HIP(hipMemcpyAsync(warp, h->d_warp + s * 6, sizeof(warp), hipMemcpyDeviceToHost, h->stream));
-        BM_HIP(hipMemcpyAsync(info, h->d_info + s * 2, sizeof(info), hipMemcpyDeviceToHost, h->stream));
-    }
-    BM_HIP(hipStreamSynchronize(h->stream));
-    BM_HIP(hipGetLastError());
-    h->cur[s] = nxt; h->has_prev[s] = 1;
-    for (int k = 0; k < 6; ++k) out_warp6[k] = warp[k];
-    if (out_iterations) *out_iterations = info[1];
 }
 
 int boxmot_hip_ecc_apply(BoxMOTHipEcc* handle, int stream, const uint8_t* image, int image_rows, int image_cols, int image_channels,
@@ -1839,9 +1869,9 @@ BoxMOTBotSortHandle* boxmot_botsort_create(const BoxMOTBotSortConfig* c) {
         k.frame_rate = c->frame_rate; k.fuse_first_associate = c->fuse_first_associate; k.with_reid = c->with_reid ? 1 : 0;
         k.max_obs = c->max_obs;
         if (c->cmc_method) h->cmc = c->cmc_method;
-        if (!h->cmc.empty() && h->cmc != "none")        // checked here: the inner handle may only be built at the first update
-            throw std::runtime_error("boxmot_hip: camera-motion estimation (ecc/sof/...) is not implemented; pass cmc_method=none "
-                                     "and supply the warp per frame with boxmot_hip_botsort_set_warp");
+        if (!h->cmc.empty() && h->cmc != "none" && h->cmc != "ecc")     // checked here: the inner handle may only be built at the first update
+            throw std::runtime_error("boxmot_hip: camera-motion estimator '" + h->cmc + "' is not implemented (have: ecc, none); "
+                                     "supply the warp per frame with boxmot_hip_botsort_set_warp");
         if (c->reid_model_path) h->reid_path = c->reid_model_path;
         if (c->reid_preprocess) h->reid_pre = c->reid_preprocess;
         k.n_streams = 1; k.n_class_lists = 1; k.tracker_kind = 0;

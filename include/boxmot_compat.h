@@ -13,8 +13,9 @@
  *
  * Behaviour that differs from the reference library, all loud:
  *   - `reid_model_path` / `model_path` name an OSN1 weight blob (boxmot_amd.reid_weights.save_blob), not an ONNX file;
- *   - `cmc_method` must be NULL, "" or "none": warp ESTIMATION (OpenCV ECC / optical flow) is not part of this library;
- *     a caller that has a warp supplies it per frame through boxmot_hip_botsort_set_warp (boxmot_hip.h);
+ *   - `cmc_method`: "ecc" runs the reference's ECC estimator on the device inside update; NULL, "" or "none" estimate nothing (a
+ *     caller that has a warp supplies it per frame through boxmot_hip_botsort_set_warp, boxmot_hip.h); "sof" and the other
+ *     OpenCV estimators are not built: create fails loudly;
  *   - capacities are fixed at create: BOXMOT_HIP_MAX_TRACKS (default 1024) live + lost tracks, BOXMOT_HIP_MAX_DETS
  *     (default 512) detections per frame, BOXMOT_HIP_REID_MAX_CROPS (default 1024) boxes per ReID call; exceeding one
  *     fails the call with a message, it never truncates silently;

@@ -18,9 +18,10 @@
  *     tracker.cpp:435,465,476; the Python reference exposes them, botsort.py:81-85);
  *   - one handle owns n_streams independent trackers advanced by one launch set
  *     (boxmot_hip_botsort_update_batch / _step_device);
- *   - camera-motion compensation: the warp is APPLIED on the device (boxmot_hip_*_set_warp supplies the 2x3 matrix
- *     the reference's cmc.apply() returns); estimating it from images is the caller's: cmc_method must be NULL,
- *     "" or "none" (create fails otherwise);
+ *   - camera-motion compensation: cmc_method = "ecc" runs the reference's ECC estimator on the device inside update (it needs the
+ *     frame on every call); NULL / "" / "none" estimate nothing -- a 2x3 warp supplied with boxmot_hip_*_set_warp (what the
+ *     reference's cmc.apply() returns, e.g. from boxmot_hip_ecc_apply or a host-side estimator) is applied on the device;
+ *     "sof" and the other OpenCV estimators are not built (create fails);
  *   - the reference's own symbol names and struct layouts are exported next to these (boxmot_compat.h).
  * There is no CPU fallback: every entry point fails with an error when no HIP
  * device is usable.
@@ -43,7 +44,7 @@ typedef struct BoxMOTHipBotSortConfig {
     double match_thresh;
     double proximity_thresh;
     double appearance_thresh;
-    const char* cmc_method;          /* NULL / "" / "none" only (the warp itself: boxmot_hip_botsort_set_warp) */
+    const char* cmc_method;          /* NULL / "" / "none", or "ecc" (estimated on the device inside update) */
     int frame_rate;
     int fuse_first_associate;
     int with_reid;

@@ -260,3 +260,29 @@ class ByteTrackOracle:
                 det_ind=np.array([t.det_ind for t in recs], dtype=np.float32))
         return dict(frame_count=self.frame_count, id_count=self.id_count, active=pack(self.active), lost=pack(self.lost),
                     removed_ids=np.array(list(self.removed_ids), dtype=np.int64))
+
+
+class PerClassByteTrackOracle:
+    """``ByteTrack(per_class=True)``: BaseTracker._do_update (basetracker.py:213-271) runs ``_update_impl`` once per class id with
+    that class's active list swapped in; the lost list, the removed list, the id counter and the filter are shared, and the frame
+    counter is rewound for every class."""
+
+    def __init__(self, nr_classes: int, **kw):
+        self.o = ByteTrackOracle(**kw)
+        self.n = int(nr_classes)
+        self.lists = {c: [] for c in range(self.n)}
+
+    def update(self, dets, img=None, embs=None):
+        dets = np.asarray(dets, dtype=np.float32).reshape(-1, 6)
+        rows, fc = [], self.o.frame_count
+        for c in range(self.n):
+            idx = np.where(dets[:, 5] == c)[0]
+            self.o.active = self.lists[c]
+            self.o.frame_count = fc
+            r = np.asarray(self.o.update(dets[idx], img)).reshape(-1, 8)
+            # det_ind of a per-class call indexes the class's detections (basetracker.py get_class_dets_n_embs keeps the rows' order)
+            self.lists[c] = self.o.active
+            if r.size:
+                rows.append(r)
+        self.o.frame_count = fc + 1
+        return np.vstack(rows) if rows else np.empty((0, 8), dtype=np.float32)

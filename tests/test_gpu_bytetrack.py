@@ -58,8 +58,6 @@ def test_config0_bytetrack_32_dets_640x640():
 def test_bytetrack_surface():
     from boxmot_amd import ByteTrack, create_tracker
     from boxmot_amd.track_results import TrackResults
-    with pytest.raises(NotImplementedError):
-        ByteTrack(per_class=True)
     with pytest.raises(TypeError):
         ByteTrack(with_reid=True)
     trk = create_tracker("bytetrack", max_tracks=64, max_dets=32)                  # bytetrack.yaml: track_thresh 0.6, match 0.9
@@ -75,4 +73,19 @@ def test_bytetrack_surface():
     assert out.shape == (1, 8) and out[0, 4] == 1 and out[0, 7] == 0               # first frame activates immediately; 0.5 < track_thresh
     with pytest.raises(AssertionError):
         trk.update(np.zeros((2, 5), dtype=np.float32), img)
+    trk.close()
+
+
+def test_bytetrack_per_class_matches_reference_semantics():
+    """ByteTrack(per_class=True): per-class active lists, shared lost list / removed flags / id counter, frame counter rewound per
+    class (basetracker.py:213-271); the oracle wrapper is pinned on the reference class in tests/test_oracle_vs_reference.py."""
+    from boxmot_amd import ByteTrack
+    from boxmot_amd.scenario import stress_frames
+    from oracle.bytetrack import PerClassByteTrackOracle
+    img = np.zeros((480, 640, 3), dtype=np.uint8)
+    trk, orc = ByteTrack(max_tracks=256, max_dets=64, per_class=True, nr_classes=3), PerClassByteTrackOracle(3)
+    for t, (d, _) in enumerate(stress_frames(120, seed=9)):
+        if len(d) == 0:
+            continue
+        assert_rows_match(np.asarray(trk.update(d, img)).reshape(-1, 8), orc.update(d.copy(), img), t)
     trk.close()

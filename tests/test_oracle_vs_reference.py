@@ -88,6 +88,21 @@ def test_bytetrack_oracle_bit_exact_incl_kalman_state():
                 assert np.array_equal(k.mean, m) and np.array_equal(k.covariance, P)
 
 
+def test_bytetrack_per_class_oracle_matches_reference():
+    from boxmot_amd.scenario import stress_frames
+    from oracle.bytetrack import PerClassByteTrackOracle
+
+    logging.disable(logging.CRITICAL)
+    img = np.zeros((480, 640, 3), np.uint8)
+    ref, orc = ref_harness.load_bytetrack()(per_class=True, nr_classes=3), PerClassByteTrackOracle(3)
+    for t, (d, e) in enumerate(stress_frames(120, seed=9)):
+        if len(d) == 0:
+            continue
+        r = np.asarray(ref.update(d.copy(), img)).reshape(-1, 8)
+        o = orc.update(d.copy(), img)
+        assert r.shape == o.shape and np.array_equal(r, o), t
+
+
 def test_deepocsort_per_class_oracle_matches_reference():
     from boxmot_amd.scenario import stress_frames
     from oracle.deepocsort import PerClassDeepOcSortOracle
