@@ -535,9 +535,11 @@ void host_update(BoxMOTHipBotSort* h, int s0, int n, const StreamIn* in, int det
     BM_HIP(hipMemcpyAsync(h->d_ndets + s0, h->h_ndets.data() + s0, n * 4, hipMemcpyHostToDevice, h->stream));
     BM_HIP(hipMemcpyAsync(h->d_list_sel + s0, h->h_list_sel.data() + s0, n * 4, hipMemcpyHostToDevice, h->stream));
     if (fc_set) BM_HIP(hipMemcpyAsync(h->d_fc_set + s0, h->h_fc_set.data() + s0, n * 4, hipMemcpyHostToDevice, h->stream));
-    if (h->use_ecc && !list_sel) {
+    const bool ecc_here = h->use_ecc && !fc_set;
+    if (ecc_here) {
         // cmc_method = "ecc" (botsort.py:116-117, :141-145): the estimator sees every frame of the stream; its warp is applied to
-        // the predicted pool by this update.  (Per-class fan-out calls pass list_sel: the frame is estimated once, by the caller.)
+        // the predicted pool by this update.  (Per-class fan-out calls rewind the frame counter, fc_set: the same frame is updated
+        // once per class there -- the estimate is made once by the caller and supplied with set_warp.)
         for (int k = 0; k < n; ++k) {
             if (in[k].det_rows < 0) continue;
             if (!in[k].image) throw std::runtime_error("boxmot_hip: cmc_method=ecc needs the frame (image pointer is null)");
@@ -573,7 +575,7 @@ void host_update(BoxMOTHipBotSort* h, int s0, int n, const StreamIn* in, int det
         run_reid(h, s0, n, h->d_dets, h->d_ndets, d_frames_ext, image_rows, image_cols, h->d_embs);
     } else if (need_reid) {
         for (int k = 0; k < n; ++k) {
-            if (in[k].image) { if (!(h->use_ecc && !list_sel)) upload_frame(h, s0 + k, in[k].image, image_rows, image_cols, image_channels); }
+            if (in[k].image) { if (!ecc_here) upload_frame(h, s0 + k, in[k].image, image_rows, image_cols, image_channels); }
             else if (h->frame_bufs[s0 + k] == nullptr) throw std::runtime_error("Image data pointer is null.");
         }
         run_reid(h, s0, n, h->d_dets, h->d_ndets, h->d_frames, h->frame_rows, h->frame_cols, h->d_embs);
