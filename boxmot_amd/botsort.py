@@ -59,6 +59,9 @@ class BotSort(BaseTracker):
         **kwargs: Any,
     ):
         super().__init__(_tracker_name=_tracker_name, **kwargs)
+        if isinstance(cmc, str):
+            from boxmot_amd.cmc import get_cmc_method
+            cmc = get_cmc_method(cmc)()
         if use_cmc and cmc is None:
             # botsort.py:116-117: get_cmc_method(cmc_method)(); "ecc" (the constructor default) is estimated on the device
             # (boxmot_amd.cmc.HipECC), the sparse-optical-flow estimator of the YAML default ("sof") is not built

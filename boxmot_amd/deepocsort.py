@@ -48,10 +48,13 @@ class DeepOcSort(BaseTracker):
         **kwargs: Any,
     ):
         super().__init__(_tracker_name="DeepOcSort", **kwargs)
+        if isinstance(cmc, str):            # cmc="ecc": the device ECC estimator (boxmot_amd.cmc); the reference's built-in one is "sof"
+            from boxmot_amd.cmc import get_cmc_method
+            cmc = get_cmc_method(cmc)()
         if not cmc_off and cmc is None:
             raise NotImplementedError(
                 "boxmot_amd.DeepOcSort: camera-motion estimation is not implemented on the HIP path; construct with "
-                "cmc_off=True, or pass cmc=<object with apply(img, boxes) -> 2x3 warp> (the reference default is "
+                "cmc_off=True, cmc="ecc" (ECC on the device), or pass cmc=<object with apply(img, boxes) -> 2x3 warp> (the reference default is "
                 "cmc_off=False with the 'sof' estimator)."
             )
         self.delta_t, self.inertia = delta_t, inertia

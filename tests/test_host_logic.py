@@ -118,3 +118,25 @@ def test_scenario_is_deterministic_and_keeps_the_pool_full():
     assert a.n_groups < 30                        # ... well inside track_buffer
     s = stress_frames(50)
     assert any(len(d) == 0 for d, _ in s) and max(len(d) for d, _ in s) <= 25
+
+
+def test_cmc_provider_surface_without_a_device():
+    """boxmot_amd.cmc: the factory names what exists, argument checks are host-side, and nothing estimates on the CPU."""
+    from boxmot_amd.cmc import HipECC, get_cmc_method
+    assert get_cmc_method("ecc") is HipECC
+    with pytest.raises(NotImplementedError, match="sof"):
+        get_cmc_method("sof")
+    with pytest.raises(NotImplementedError):
+        HipECC(warp_mode=1)                          # MOTION_EUCLIDEAN: only the reference's default translation model is built
+    with pytest.raises(NotImplementedError):
+        HipECC(align=True)
+    e = HipECC()                                     # no handle until the first frame
+    with pytest.raises(ValueError):
+        e.apply(np.zeros((10, 10), np.uint8))
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):            # no CPU fallback: the estimator fails loudly without a HIP device
+            e.apply(np.zeros((64, 64, 3), np.uint8))
+        from boxmot_amd.ingest import FrameRing
+        with pytest.raises(RuntimeError):
+            FrameRing(2, 1, 64, 64)
