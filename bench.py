@@ -15,6 +15,11 @@ group's tracker step (one workgroup per stream: latency-bound, few CUs) overlaps
 kernels (+4 % at G = 2); the default keeps one group so that the HIP-event launch durations behind
 `roofline` are those of kernels running alone and agree with the rocprofv3 per-kernel averages.
 
+Extra objects on the JSON line (N = 1): `roofline`, `cpu_baseline` (the contract), `tracker_math_m1` (embeddings supplied), and
+`other_configs` -- short side measurements of BASELINE.json's configurations 3 (DeepOCSORT + OSNet_x1_0, 128 x 512) and 5 (StrongSORT +
+CLIP-ReID ViT-B/16, 256 x 1024, 4K) through tools/config_bench.py, each with its ReID roofline fraction and an embedding parity gate;
+they are never part of `value`.
+
 N > 1: launched by torch.distributed.run, one rank per GPU; streams are sharded by rank with no
 data-path collective; the per-frame result rows are gathered to rank 0 once after the timed loop
 (RCCL all_gather of a few hundred KB).
@@ -71,6 +76,8 @@ def parse():
                     help="0: per-layer fp32 kernels, 1: fused fp16 MFMA kernels (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-m1", action="store_true", help="skip the tracker-math-only (embeddings supplied) side measurement")
+    ap.add_argument("--no-side-configs", action="store_true",
+                    help="skip the short side measurements of BASELINE.json configurations 3 and 5 (tools/config_bench.py)")
     ap.add_argument("--cpu-frames", type=int, default=10)
     return ap.parse_args()
 
@@ -318,6 +325,20 @@ def main():
                 m.close()
             groups = []
             res["tracker_math_m1"] = m1_tracker_only(kw, dev, rank)
+        if world == 1 and a.mode == "reid" and not a.no_side_configs:
+            # BASELINE.json's other single-GPU configurations, measured briefly on the same box (not part of `value`): ReID inside
+            # update, frames and detections resident in HBM, parity gates against the oracles
+            sys.path.insert(0, str(Path(__file__).resolve().parent / "tools"))
+            import config_bench
+            side = {}
+            for key, kwargs in (("config3", dict(config="c3", streams=8, steps=16, warmup=6, check_frames=0)),
+                                ("config5", dict(config="c5", streams=2, steps=6, warmup=3, check_frames=0))):
+                try:
+                    side[key] = config_bench.run(**kwargs)
+                    log(f"side line {key}: {side[key]['frames_per_s']:.1f} frames/s")
+                except Exception as exc:                    # a side line never takes the headline down
+                    side[key] = {"error": f"{type(exc).__name__}: {exc}"}
+            res["other_configs"] = side
         if not a.no_cpu_baseline and world == 1:
             cb, rows = cpu_baseline(sd, a.mode, a.cpu_frames)
             res["cpu_baseline"] = cb

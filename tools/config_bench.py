@@ -44,27 +44,20 @@ def vit_flops(width=768, layers=12, tokens=129, patch_k=768, out_dim=512):
     return 2 * (t - 1) * patch_k * d + layers * (2 * t * d * 3 * d + 4 * t * t * d + 2 * t * d * d + 4 * t * d * 4 * d) + 2 * d * out_dim
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--config", default="c3", choices=["c3", "c5"])
-    ap.add_argument("--streams", type=int, default=0)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--check-frames", type=int, default=-1)
-    ap.add_argument("--reid-mode", type=int, default=1)
-    a = ap.parse_args()
+def run(config: str = "c3", streams: int = 0, steps: int = 40, warmup: int = 8, check_frames: int = -1, reid_mode: int = 1) -> dict:
+    """One measurement; returns the result dict (bench.py calls this for its side lines)."""
     import torch
 
     from boxmot_amd import _lib
     from boxmot_amd.reid_weights import save_blob
     from boxmot_amd.scenario import Scenario
     lib = _lib.load()
-    c3 = a.config == "c3"
+    c3 = config == "c3"
     nd, ntr, dim, W, H = (128, 512, 512, 1920, 1080) if c3 else (256, 1024, 1280, 3840, 2160)
-    S = a.streams or (8 if c3 else 2)
-    T = a.warmup + a.steps
-    check = a.check_frames if a.check_frames >= 0 else (2 if c3 else 0)
-    dev = torch.device("cuda", 0)
+    S = streams or (8 if c3 else 2)
+    T = warmup + steps
+    check = check_frames if check_frames >= 0 else (2 if c3 else 0)
+    dev = torch.device("cuda", torch.cuda.current_device())
     if c3:
         from boxmot_amd.reid_weights import pack_osnet, reference_init_state_dict
         sd = reference_init_state_dict("osnet_x1_0", seed=0)
@@ -110,22 +103,22 @@ def main():
     if not h:
         raise RuntimeError(_lib.last_error())
     if c3:
-        _lib.check(set_mode(h, a.reid_mode))
+        _lib.check(set_mode(h, reid_mode))
     d_out = torch.zeros((T, S, cap, 8), dtype=torch.float32, device=dev)
     d_out_n = torch.zeros((T, S), dtype=torch.int32, device=dev)
     step = lambda t: _lib.check(step_fn(h, d_dets[t].data_ptr(), d_cnt[t].data_ptr(), ptrs.data_ptr(), H, W, d_out[t].data_ptr(), d_out_n[t].data_ptr()))
     ms, nl = ctypes.c_double(0), ctypes.c_int(0)
-    for t in range(a.warmup):
+    for t in range(warmup):
         step(t)
     _lib.check(sync(h))
     _lib.check(reid_ms(h, ctypes.byref(ms), ctypes.byref(nl)))
     t0 = time.perf_counter()
-    for t in range(a.warmup, T):
+    for t in range(warmup, T):
         step(t)
     _lib.check(sync(h))
     dt = time.perf_counter() - t0
     _lib.check(reid_ms(h, ctypes.byref(ms), ctypes.byref(nl)))
-    crops = int(cnt_h[a.warmup:].sum())
+    crops = int(cnt_h[warmup:].sum())
     out_h, out_n = d_out.cpu().numpy(), d_out_n.cpu().numpy()
     # parity gates
     gates = {}
@@ -136,7 +129,7 @@ def main():
     else:
         from oracle.clipreid import OracleClipReID
         orc_reid = OracleClipReID(sd)
-    hr = HipReID(blob, max_crops=8, mode=a.reid_mode if c3 else 0)
+    hr = HipReID(blob, max_crops=8, mode=reid_mode if c3 else 0)
     bx = dets_h[0, 0, :8, :4]
     gates["reid_max_abs_err_vs_fp32_oracle"] = float(np.abs(hr.get_features(bx, scen[0].image) - orc_reid.get_features(bx, scen[0].image)).max())
     hr.close()
@@ -152,15 +145,27 @@ def main():
         gates["ids_first_frames_vs_oracle_stream0"] = bool(ok)
     destroy(h)
     tfl = crops * flops_per_crop / (ms.value * 1e9) if ms.value > 0 else None
-    print(json.dumps({
+    return {
         "workload": ("DeepOCSORT + OSNet_x1_0 ReID, 128 dets x 512 tracks, 1080p" if c3 else
                      "StrongSORT + CLIP-ReID (ViT-B/16), 256 dets x 1024 tracks, 4K frames, 1280-d"),
-        "mode": "M2 reid-in-update, device-resident inputs", "streams": S, "steps": a.steps, "warmup": a.warmup,
-        "frames_per_s": S * a.steps / dt, "ms_per_step": 1e3 * dt / a.steps, "crops_per_step": crops / a.steps,
-        "reid_forward_ms_per_step": ms.value / a.steps, "reid_passes": nl.value, "gflop_per_crop": flops_per_crop / 1e9,
-        "roofline": {"bound": "mfma", "achieved": tfl, "peak": 2500.0, "unit": "TFLOP/s", "frac": (tfl / 2500.0) if tfl else None,
-                     "kernel": "ReID forward region (HIP events on the launch stream)"},
-        "rows_stream0_last": int(out_n[-1, 0]), "dtype": "f16", **gates}), flush=True)
+        "mode": "M2 reid-in-update, device-resident inputs", "streams": S, "steps": steps, "warmup": warmup,
+        "frames_per_s": S * steps / dt, "ms_per_step": 1e3 * dt / steps, "crops_per_step": crops / steps,
+        "reid_forward_ms_per_step": ms.value / steps, "reid_passes": nl.value, "gflop_per_crop": flops_per_crop / 1e9,
+        "roofline": {"bound": "hbm (layer-per-launch fp16 kernels)" if c3 else "mfma", "achieved": tfl, "peak": 2500.0, "unit": "TFLOP/s",
+                     "frac": (tfl / 2500.0) if tfl else None, "kernel": "ReID forward region (HIP events on the launch stream)"},
+        "rows_stream0_last": int(out_n[-1, 0]), "dtype": "f16", **gates}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="c3", choices=["c3", "c5"])
+    ap.add_argument("--streams", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--check-frames", type=int, default=-1)
+    ap.add_argument("--reid-mode", type=int, default=1)
+    a = ap.parse_args()
+    print(json.dumps(run(a.config, a.streams, a.steps, a.warmup, a.check_frames, a.reid_mode)), flush=True)
 
 
 if __name__ == "__main__":
