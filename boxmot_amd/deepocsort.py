@@ -54,7 +54,7 @@ class DeepOcSort(BaseTracker):
         if not cmc_off and cmc is None:
             raise NotImplementedError(
                 "boxmot_amd.DeepOcSort: camera-motion estimation is not implemented on the HIP path; construct with "
-                "cmc_off=True, cmc="ecc" (ECC on the device), or pass cmc=<object with apply(img, boxes) -> 2x3 warp> (the reference default is "
+                "cmc_off=True, cmc='ecc' (ECC on the device), or pass cmc=<object with apply(img, boxes) -> 2x3 warp> (the reference default is "
                 "cmc_off=False with the 'sof' estimator)."
             )
         self.delta_t, self.inertia = delta_t, inertia

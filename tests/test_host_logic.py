@@ -140,3 +140,18 @@ def test_cmc_provider_surface_without_a_device():
         from boxmot_amd.ingest import FrameRing
         with pytest.raises(RuntimeError):
             FrameRing(2, 1, 64, 64)
+
+
+def test_every_module_of_the_package_and_tools_compiles():
+    """A syntax error in a lazily imported module must not wait for the GPU box to be found."""
+    import py_compile
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    files = sorted((root / "boxmot_amd").glob("*.py")) + sorted((root / "tools").glob("*.py")) + sorted((root / "oracle").glob("*.py")) \
+        + [root / "bench.py", root / "__graft_entry__.py"]
+    for f in files:
+        py_compile.compile(str(f), doraise=True)
+    import importlib
+    for f in sorted((root / "boxmot_amd").glob("*.py")):
+        if f.stem != "__init__":
+            importlib.import_module(f"boxmot_amd.{f.stem}")
