@@ -129,6 +129,8 @@ struct BoxMOTHipReID {
     int* d_crop_stream = nullptr;
     float* d_boxes = nullptr;
     float* d_feat = nullptr;
+    double* d_obb = nullptr;                     // [max_crops][8]: out_w, out_h, inverse 2x3 map of oriented boxes (base_backend.py:91-117)
+    bool obb = false;                            // the boxes of the last reid_stage were oriented (5 / 7 / 9 columns)
     int staged_n = -1, staged_rows = 0, staged_cols = 0;      // boxmot_reid_capi_preprocess -> process -> postprocess
     bool staged_done = false;
     ~BoxMOTHipReID() {
@@ -1215,6 +1217,7 @@ BoxMOTHipReID* boxmot_hip_reid_create(const char* model_path, const float* blob,
         h->d_crop_stream = zalloc<int>(max_crops, h->owned);
         h->d_boxes = dev_alloc<float>((size_t)max_crops * 4, h->owned);
         h->d_feat = dev_alloc<float>((size_t)max_crops * h->engine->feature_dim(), h->owned);
+        h->d_obb = dev_alloc<double>((size_t)max_crops * 8, h->owned);
     });
     if (!ok) { delete h; return nullptr; }
     return h;
@@ -1258,17 +1261,56 @@ static void reid_stage(BoxMOTHipReID* h, const uint8_t* image, int rows, int col
         BM_HIP(hipMemcpy(h->d_frames, &h->d_frame, sizeof(uint8_t*), hipMemcpyHostToDevice));
     }
     BM_HIP(hipMemcpyAsync(h->d_frame, image, bytes, hipMemcpyHostToDevice, h->stream));
+    // base_backend.py:119-122, 157: rows of 5 / 7 / 9 values are oriented boxes [cx, cy, w, h, angle, ...]
+    h->obb = n > 0 && (box_cols == 5 || box_cols == 7 || box_cols == 9);
     std::vector<float> b((size_t)n * 4);
-    for (int i = 0; i < n; ++i)
-        for (int q = 0; q < 4; ++q) b[i * 4 + q] = boxes[(size_t)i * box_cols + q];
+    std::vector<double> geo;
+    if (h->obb) {
+        // _crop_obb (base_backend.py:91-117): getRotationMatrix2D about the box centre, shifted so that the centre lands on the middle
+        // of the (round(w), round(h)) output; cv2.warpAffine inverts the matrix in double precision before it samples
+        geo.resize((size_t)n * 8);
+        const float rad2deg = 180.0f / 3.14159265358979323846f;         // np.degrees on a float32 scalar
+        for (int i = 0; i < n; ++i) {
+            const float* bx = boxes + (size_t)i * box_cols;
+            const double cx = bx[0], cy = bx[1];
+            const double bw = bx[2] > 1.0f ? (double)bx[2] : 1.0, bh = bx[3] > 1.0f ? (double)bx[3] : 1.0;
+            const int ow = std::max((int)std::nearbyint(bw), 1), oh = std::max((int)std::nearbyint(bh), 1);
+            const double a = (double)(bx[4] * rad2deg) * (3.14159265358979323846 / 180.0);
+            const double alpha = std::cos(a), beta = std::sin(a);
+            double m00 = alpha, m01 = beta, m02 = (1 - alpha) * cx - beta * cy, m10 = -beta, m11 = alpha, m12 = beta * cx + (1 - alpha) * cy;
+            m02 += ow / 2.0 - cx;
+            m12 += oh / 2.0 - cy;
+            double D = m00 * m11 - m01 * m10;
+            D = D != 0 ? 1.0 / D : 0.0;
+            const double A11 = m11 * D, A22 = m00 * D;
+            double* g = geo.data() + (size_t)i * 8;
+            g[0] = ow; g[1] = oh;
+            g[2] = A11; g[3] = m01 * (-D); g[5] = m10 * (-D); g[6] = A22;
+            g[4] = -g[2] * m02 - g[3] * m12;
+            g[7] = -g[5] * m02 - g[6] * m12;
+            for (int q = 0; q < 4; ++q) b[i * 4 + q] = 0.f;
+        }
+        BM_HIP(hipMemcpyAsync(h->d_obb, geo.data(), geo.size() * 8, hipMemcpyHostToDevice, h->stream));
+    } else {
+        for (int i = 0; i < n; ++i)
+            for (int q = 0; q < 4; ++q) b[i * 4 + q] = boxes[(size_t)i * box_cols + q];
+    }
     if (n) BM_HIP(hipMemcpyAsync(h->d_boxes, b.data(), b.size() * 4, hipMemcpyHostToDevice, h->stream));
     BM_HIP(hipStreamSynchronize(h->stream));
+    h->engine->set_obb_geometry(h->obb ? h->d_obb : nullptr);
 }
+
+// oriented-box geometry is valid for one staged batch only
+struct ObbScope {
+    BoxMOTHipReID* h;
+    ~ObbScope() { if (h && h->engine) h->engine->set_obb_geometry(nullptr); }
+};
 
 int boxmot_hip_reid_compute_features(BoxMOTHipReID* handle, const uint8_t* image, int image_rows, int image_cols,
                                      int image_channels, const float* boxes, int n_boxes, int box_cols,
                                      float* out_features, int out_capacity_rows) {
     return guard([&]() {
+        ObbScope scope{handle};
         reid_stage(handle, image, image_rows, image_cols, image_channels, boxes, n_boxes, box_cols);
         if (out_capacity_rows < n_boxes) throw std::runtime_error("boxmot_hip: feature buffer too small");
         if (n_boxes == 0) return;
@@ -1293,6 +1335,7 @@ int boxmot_hip_reid_last_time_ms(BoxMOTHipReID* handle, double* out_preprocess_m
 int boxmot_hip_reid_preprocess(BoxMOTHipReID* handle, const uint8_t* image, int image_rows, int image_cols,
                                int image_channels, const float* boxes, int n_boxes, int box_cols, float* out_crops) {
     return guard([&]() {
+        ObbScope scope{handle};
         reid_stage(handle, image, image_rows, image_cols, image_channels, boxes, n_boxes, box_cols);
         if (n_boxes == 0) return;
         handle->engine->preprocess_fp32(handle->d_frames, handle->d_crop_stream, handle->d_boxes, 4, n_boxes, image_cols,

@@ -126,6 +126,9 @@ public:
     void set_fuse_stem(bool on) { fuse_stem_ = on; }     // A/B switch: fused crop+stem kernel vs resize kernel + stem kernel
     // 0 = "resize" (default), 1 = "resize_pad" (reid/core/preprocessing.py:12-45); resize_pad runs the separate crop kernel
     void set_preprocess(int pad) { pad_ = pad; }
+    // oriented boxes for the next preprocess / run: device array [n][8] doubles (out_w, out_h, inverse 2x3 map) or nullptr (axis-aligned).
+    // In a chunked run the caller passes the chunk's slice (run() processes boxes from index 0 of what it is given).
+    void set_obb_geometry(const double* d_geo) { obb_geo_ = d_geo; }
     int preprocess_mode() const { return pad_; }
     const OsnetLayout& layout() const { return L_; }
     float* crops_buffer() { return crops_; }
@@ -138,6 +141,13 @@ public:
         if (n > (fused ? fused_cap_ : (wide ? wide_->max_crops() : max_crops_))) throw std::runtime_error("ReID: crop batch exceeds the engine capacity");
         if (n == 0) return;
         const int rows_per_block = 16;
+        if (obb_geo_) {         // oriented boxes: the rectified crop is sampled on demand (k_crop_resize_obb), same output layouts
+            const dim3 grid(n, REID_IN_H / rows_per_block), block(REID_IN_W);
+            if (wide) hipLaunchKernelGGL((k_crop_resize_obb<_Float16, true>), grid, block, 0, st, d_frames, d_crop_stream, obb_geo_, W, H, d_lut_, wide_->crops_buffer(), rows_per_block, pad_);
+            else if (fused) hipLaunchKernelGGL((k_crop_resize_obb<_Float16, true>), grid, block, 0, st, d_frames, d_crop_stream, obb_geo_, W, H, d_lut_, crops_h_, rows_per_block, pad_);
+            else hipLaunchKernelGGL((k_crop_resize_obb<float, false>), grid, block, 0, st, d_frames, d_crop_stream, obb_geo_, W, H, d_lut_, crops_, rows_per_block, pad_);
+            return;
+        }
         if (wide)
             hipLaunchKernelGGL(k_crop_resize_rgbx, dim3(n, REID_IN_H / rows_per_block), dim3(REID_IN_W), 0, st,
                                d_frames, d_crop_stream, d_boxes, box_stride, W, H, d_lut_, wide_->crops_buffer(), rows_per_block,
@@ -165,9 +175,11 @@ public:
         BM_HIP(hipEventRecord(ev_[0], st));
         const bool wide = mode_ == 1 && wide_;
         const int step = wide ? wide_->max_crops() : (mode_ == 1 ? fused_cap_ : max_crops_);
+        const double* geo_all = obb_geo_;
         for (int i0 = 0; i0 < n; i0 += step) {
             const int m = (n - i0) < step ? (n - i0) : step;
-            const bool fuse_stem = mode_ == 1 && fused_ready_ && fuse_stem_ && !pad_;
+            if (geo_all) obb_geo_ = geo_all + (long)i0 * 8;
+            const bool fuse_stem = mode_ == 1 && fused_ready_ && fuse_stem_ && !pad_ && !obb_geo_;
             if (!fuse_stem) preprocess(d_frames, d_crop_stream + i0, d_boxes + (long)i0 * box_stride, box_stride, m, W, H, st);
             if (i0 == 0) BM_HIP(hipEventRecord(ev_[1], st));
             hipEvent_t a = take_event(), b = take_event();
@@ -184,6 +196,7 @@ public:
             if (pending_.size() < 4096) pending_.emplace_back(a, b);
             else { free_events_.push_back(a); free_events_.push_back(b); }
         }
+        obb_geo_ = geo_all;
         BM_HIP(hipEventRecord(ev_[2], st));
         timed_ = true;
     }
@@ -454,6 +467,7 @@ private:
     std::unique_ptr<ClipNet> clip_;         // non-null: the weights are a CLP1 blob (CLIP-ReID ViT-B/16)
     std::unique_ptr<WideOsnet> wide_;       // non-null: OSNet widths the layer-per-launch fp16 MFMA kernels take (osnet_x1_0)
     bool fused_ready_ = false, force_fp32_crops_ = false, fuse_stem_ = true;
+    const double* obb_geo_ = nullptr;
     int pad_ = 0;
     BlkPack bp_[6];
     unsigned char* w_stem_ = nullptr;

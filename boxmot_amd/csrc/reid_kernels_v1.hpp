@@ -66,21 +66,24 @@ __device__ inline CropRect crop_rect(const float* box, int W, int H) {
     return r;
 }
 
-// One resized uint8 sample (BGR source channel c) at output (dy, dx).
+// One resized uint8 sample (BGR source channel c) at output (dy, dx).  `px(y, x, c)` fetches a pixel of the crop image (a slice of
+// the frame for axis-aligned boxes; the rectified image of an oriented box is virtual, see obb_pixel).
+template <class Fetch>
+__device__ inline int resize_sample_f(const Fetch& px, const CropRect& r, const ResizeAxis& ax, const ResizeAxis& ay, int dy, int dx,
+                                      int c, int out_w, int out_h) {
+    if (r.w == 0) return 0;
+    if (r.w == out_w && r.h == out_h) return px(dy, dx, c);
+    if (r.w == 2 * out_w && r.h == 2 * out_h)     // exact 2x shrink -> INTER_AREA box filter
+        return (px(2 * dy, 2 * dx, c) + px(2 * dy, 2 * dx + 1, c) + px(2 * dy + 1, 2 * dx, c) + px(2 * dy + 1, 2 * dx + 1, c) + 2) >> 2;
+    const int S0 = px(ay.s0, ax.s0, c) * ax.a0 + px(ay.s0, ax.s1, c) * ax.a1;
+    const int S1 = px(ay.s1, ax.s0, c) * ax.a0 + px(ay.s1, ax.s1, c) * ax.a1;
+    return (((ay.a0 * (S0 >> 4)) >> 16) + ((ay.a1 * (S1 >> 4)) >> 16) + 2) >> 2;
+}
+
 __device__ inline int resize_sample(const uint8_t* src, long row_stride, const CropRect& r,
                                     const ResizeAxis& ax, const ResizeAxis& ay, int dy, int dx, int c,
                                     int out_w, int out_h) {
-    if (r.w == 0) return 0;
-    if (r.w == out_w && r.h == out_h) return src[(long)dy * row_stride + dx * 3 + c];
-    if (r.w == 2 * out_w && r.h == 2 * out_h) {   // exact 2x shrink -> INTER_AREA box filter
-        const uint8_t* p = src + (long)(2 * dy) * row_stride + (2 * dx) * 3 + c;
-        return (p[0] + p[3] + p[row_stride] + p[row_stride + 3] + 2) >> 2;
-    }
-    const uint8_t* r0 = src + (long)ay.s0 * row_stride + c;
-    const uint8_t* r1 = src + (long)ay.s1 * row_stride + c;
-    const int S0 = r0[ax.s0 * 3] * ax.a0 + r0[ax.s1 * 3] * ax.a1;
-    const int S1 = r1[ax.s0 * 3] * ax.a0 + r1[ax.s1 * 3] * ax.a1;
-    return (((ay.a0 * (S0 >> 4)) >> 16) + ((ay.a1 * (S1 >> 4)) >> 16) + 2) >> 2;
+    return resize_sample_f([=](int y, int x, int ch) { return (int)src[(long)y * row_stride + x * 3 + ch]; }, r, ax, ay, dy, dx, c, out_w, out_h);
 }
 
 // resize_pad (reid/core/preprocessing.py:21-45): aspect-preserving resize to (new_w, new_h) = int(dim * scale) with
@@ -109,6 +112,75 @@ __device__ inline int preprocess_sample(const uint8_t* src, long row_stride, con
     if (yy < 0 || yy >= g.new_h || xx < 0 || xx >= g.new_w) return c == 0 ? 104 : (c == 1 ? 116 : 124);
     const ResizeAxis ax = resize_axis_x(xx, g.new_w, r.w), ay = resize_axis_y(yy, g.new_h, r.h);
     return resize_sample(src, row_stride, r, ax, ay, yy, xx, c, g.new_w, g.new_h);
+}
+
+// the same over a fetch functor (oriented boxes)
+template <class Fetch>
+__device__ inline int preprocess_sample_f(const Fetch& px, const CropRect& r, const PadGeom& g, int pad, const ResizeAxis& ax_plain, int dy,
+                                          int dx, int c, int out_w, int out_h) {
+    if (!pad) {
+        const ResizeAxis ay = resize_axis_y(dy, out_h, r.h > 0 ? r.h : 1);
+        return resize_sample_f(px, r, ax_plain, ay, dy, dx, c, out_w, out_h);
+    }
+    if (r.w == 0) return 0;
+    const int yy = dy - g.top, xx = dx - g.left;
+    if (yy < 0 || yy >= g.new_h || xx < 0 || xx >= g.new_w) return c == 0 ? 104 : (c == 1 ? 116 : 124);
+    const ResizeAxis ax = resize_axis_x(xx, g.new_w, r.w), ay = resize_axis_y(yy, g.new_h, r.h);
+    return resize_sample_f(px, r, ax, ay, yy, xx, c, g.new_w, g.new_h);
+}
+
+// ---------------------------------------------------------------------------
+// Oriented boxes: BaseModelBackend._crop_obb (base_backend.py:91-117) = cv2.getRotationMatrix2D + cv2.warpAffine(INTER_LINEAR,
+// BORDER_CONSTANT 0).  The rectified crop is never materialised: pixel (y, x) of it is computed on demand from the frame with
+// warpAffine's arithmetic -- inverse 2x3 map `im` (inverted on the host in double precision, boxmot_hip.hip), fixed-point sampling
+// position on the 1/32-pixel grid, integer bilinear weights (32 - fx)(32 - fy) * 32 ... summing to 2^15, taps outside the frame = 0
+// -- and the ordinary resize / resize_pad runs on top of it.  geo = [out_w, out_h, im0 .. im5] (8 doubles per box).
+// ---------------------------------------------------------------------------
+__device__ inline int obb_pixel(const uint8_t* frame, int W, int H, const double* im, int y, int x, int c) {
+    const long adelta = (long)rint(im[0] * (double)x * 1024.0), bdelta = (long)rint(im[3] * (double)x * 1024.0);
+    const long X0 = (long)rint((im[1] * (double)y + im[2]) * 1024.0) + 16, Y0 = (long)rint((im[4] * (double)y + im[5]) * 1024.0) + 16;
+    const long X = (X0 + adelta) >> 5, Y = (Y0 + bdelta) >> 5;
+    long sx = X >> 5, sy = Y >> 5;
+    sx = sx < -32768 ? -32768 : (sx > 32767 ? 32767 : sx);            // saturate_cast<short>
+    sy = sy < -32768 ? -32768 : (sy > 32767 ? 32767 : sy);
+    const int fx = (int)(X & 31), fy = (int)(Y & 31);
+    auto tap = [&](long yy, long xx) { return (xx >= 0 && xx < W && yy >= 0 && yy < H) ? (int)frame[(yy * W + xx) * 3 + c] : 0; };
+    const int acc = tap(sy, sx) * ((32 - fx) * (32 - fy) * 32) + tap(sy, sx + 1) * (fx * (32 - fy) * 32) + tap(sy + 1, sx) * ((32 - fx) * fy * 32) +
+                    tap(sy + 1, sx + 1) * (fx * fy * 32);
+    const int v = (acc + (1 << 14)) >> 15;
+    return v > 255 ? 255 : v;
+}
+
+// RGBX = false: out T [n][256][128][3] normalised (k_crop_resize's layout); RGBX = true: fp16 RGBX with a 3-pixel zero border,
+// [n][262][136][4] (k_crop_resize_rgbx's layout: interior only, border and X channel stay zero from allocation)
+template <typename T, bool RGBX>
+__global__ void k_crop_resize_obb(const uint8_t* const* frames, const int* crop_stream, const double* geo, int W, int H, const float* lut,
+                                  T* out, int rows_per_block, int pad) {
+    const int i = blockIdx.x;
+    const int dx = threadIdx.x;               // 0..127
+    const uint8_t* frame = frames[crop_stream[i]];
+    const double* gi = geo + (long)i * 8;
+    CropRect r;
+    r.x1 = 0; r.y1 = 0; r.w = (int)gi[0]; r.h = (int)gi[1];
+    const double* im = gi + 2;
+    const auto px = [=](int y, int x, int c) { return obb_pixel(frame, W, H, im, y, x, c); };
+    const ResizeAxis ax = resize_axis_x(dx, REID_IN_W, r.w > 0 ? r.w : 1);
+    const PadGeom g = pad_geom(r, REID_IN_W, REID_IN_H);
+    const int y0 = blockIdx.y * rows_per_block;
+    for (int dy = y0; dy < y0 + rows_per_block && dy < REID_IN_H; ++dy) {
+        T v3[3];
+        for (int c = 0; c < 3; ++c) {         // c = RGB output channel; source is BGR
+            const int v = preprocess_sample_f(px, r, g, pad, ax, dy, dx, 2 - c, REID_IN_W, REID_IN_H);
+            v3[c] = (T)lut[c * 256 + v];
+        }
+        if constexpr (RGBX) {
+            T* o = out + (((long)i * 262 + dy + 3) * 136 + dx + 3) * 4;
+            o[0] = v3[0]; o[1] = v3[1]; o[2] = v3[2]; o[3] = (T)0.f;
+        } else {
+            T* o = out + (((long)i * REID_IN_H + dy) * REID_IN_W + dx) * 3;
+            o[0] = v3[0]; o[1] = v3[1]; o[2] = v3[2];
+        }
+    }
 }
 
 template <typename T>

@@ -52,8 +52,8 @@ class HipReID:
             return b.reshape(0, 4)
         if b.ndim == 1:
             b = b.reshape(1, -1)
-        if b.shape[1] in (5, 7, 9):
-            raise NotImplementedError("boxmot_amd ReID: OBB boxes are not implemented")
+        if b.shape[1] in (5, 7, 9):           # oriented boxes [cx, cy, w, h, angle, ...] (base_backend.py:119-122, 157)
+            return np.ascontiguousarray(b[:, :5])
         if b.shape[1] < 4:
             raise ValueError("Expected detections with at least 4 coordinates")
         return np.ascontiguousarray(b[:, :4])
@@ -75,7 +75,7 @@ class HipReID:
         for i0 in range(0, n, self.max_crops):
             chunk = boxes[i0:i0 + self.max_crops]
             _lib.check(self._lib.boxmot_hip_reid_compute_features(
-                self._handle, a.ctypes.data, a.shape[0], a.shape[1], 3, chunk.ctypes.data, len(chunk), 4,
+                self._handle, a.ctypes.data, a.shape[0], a.shape[1], 3, chunk.ctypes.data, len(chunk), chunk.shape[1],
                 out[i0:].ctypes.data, len(chunk)))
         return out
 
@@ -89,7 +89,7 @@ class HipReID:
             if n > self.max_crops:
                 raise ValueError("more boxes than max_crops")
             _lib.check(self._lib.boxmot_hip_reid_preprocess(
-                self._handle, a.ctypes.data, a.shape[0], a.shape[1], 3, boxes.ctypes.data, n, 4, out.ctypes.data))
+                self._handle, a.ctypes.data, a.shape[0], a.shape[1], 3, boxes.ctypes.data, n, boxes.shape[1], out.ctypes.data))
         return np.ascontiguousarray(np.transpose(out, (0, 3, 1, 2)))
 
     def last_time_ms(self):

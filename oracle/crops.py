@@ -16,6 +16,8 @@ PARITY UNPINNED against real OpenCV: it cannot be imported here.
 """
 from __future__ import annotations
 
+import math
+
 import numpy as np
 
 COEF_BITS = 11
@@ -124,16 +126,85 @@ def resize_pad_u8(crop: np.ndarray, target_shape) -> np.ndarray:
     return out
 
 
+# ---- oriented boxes: base_backend.py:91-117 (_crop_obb) = cv2.getRotationMatrix2D + cv2.warpAffine(INTER_LINEAR, BORDER_CONSTANT 0) ----
+# Restated from OpenCV's published algorithm (imgwarp.cpp): the 2x3 matrix is inverted in double precision, destination pixel
+# (x, y) samples the source at the fixed-point position X = (cvRound((M01 y + M02) 2^10) + 16 + cvRound(M00 x 2^10)) >> 5 (1/32-pixel
+# grid, likewise Y), and the uint8 bilinear kernel is integer: weights (32 - fx)(32 - fy) * 32 ... (they sum to 2^15 exactly, so
+# initInterTab2D's sum correction never fires), result (sum + 2^14) >> 15, taps outside the image are the constant border 0.
+# PARITY UNPINNED against real OpenCV (absent offline), like cv2_resize_linear_u8.
+def obb_crop_geometry(box):
+    """(out_w, out_h, inverse 2x3 map as 6 float64) of ``_crop_obb`` for ``box = [cx, cy, w, h, angle]`` (float32 fields)."""
+    b = np.asarray(box, dtype=np.float32).reshape(-1)
+    cx, cy, bw, bh, angle = (b[k] for k in range(5))
+    bw, bh = max(float(bw), 1.0), max(float(bh), 1.0)
+    out_w, out_h = max(int(round(bw)), 1), max(int(round(bh)), 1)
+    angle_deg = float(np.degrees(angle))                     # float32 degrees -> Python float
+    a = angle_deg * (np.pi / 180.0)                          # getRotationMatrix2D: angle *= CV_PI / 180
+    alpha, beta = math.cos(a), math.sin(a)                   # libm, as OpenCV's std::cos / std::sin
+    fcx, fcy = float(cx), float(cy)
+    M = np.array([[alpha, beta, (1 - alpha) * fcx - beta * fcy], [-beta, alpha, beta * fcx + (1 - alpha) * fcy]], dtype=np.float64)
+    M[0, 2] += out_w / 2.0 - fcx
+    M[1, 2] += out_h / 2.0 - fcy
+    D = M[0, 0] * M[1, 1] - M[0, 1] * M[1, 0]               # warpAffine without WARP_INVERSE_MAP inverts the matrix
+    D = 1.0 / D if D != 0 else 0.0
+    A11, A22 = M[1, 1] * D, M[0, 0] * D
+    iM = np.empty(6, dtype=np.float64)
+    iM[0], iM[1], iM[3], iM[4] = A11, M[0, 1] * (-D), M[1, 0] * (-D), A22
+    iM[2] = -iM[0] * M[0, 2] - iM[1] * M[1, 2]
+    iM[5] = -iM[3] * M[0, 2] - iM[4] * M[1, 2]
+    return out_w, out_h, iM
+
+
+def cv2_warp_affine_inverse_linear_u8(img: np.ndarray, iM, out_wh) -> np.ndarray:
+    """The remap half of ``cv2.warpAffine(img, M, (w, h), INTER_LINEAR, BORDER_CONSTANT, 0)`` given the INVERTED matrix ``iM``."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape[:2]
+    ow, oh = out_wh
+    x = np.arange(ow, dtype=np.float64)
+    y = np.arange(oh, dtype=np.float64)
+    adelta = np.rint(iM[0] * x * 1024.0).astype(np.int64)
+    bdelta = np.rint(iM[3] * x * 1024.0).astype(np.int64)
+    X0 = np.rint((iM[1] * y + iM[2]) * 1024.0).astype(np.int64) + 16
+    Y0 = np.rint((iM[4] * y + iM[5]) * 1024.0).astype(np.int64) + 16
+    X = (X0[:, None] + adelta[None, :]) >> 5
+    Y = (Y0[:, None] + bdelta[None, :]) >> 5
+    sx, sy = np.clip(X >> 5, -32768, 32767), np.clip(Y >> 5, -32768, 32767)      # saturate_cast<short>
+    fx, fy = (X & 31).astype(np.int64), (Y & 31).astype(np.int64)
+    w00, w01, w10, w11 = (32 - fx) * (32 - fy) * 32, fx * (32 - fy) * 32, (32 - fx) * fy * 32, fx * fy * 32
+
+    def tap(yy, xx):
+        ok = (xx >= 0) & (xx < w) & (yy >= 0) & (yy < h)
+        v = img[np.clip(yy, 0, h - 1), np.clip(xx, 0, w - 1)].astype(np.int64)
+        return np.where(ok[..., None], v, 0)
+    acc = tap(sy, sx) * w00[..., None] + tap(sy, sx + 1) * w01[..., None] + tap(sy + 1, sx) * w10[..., None] + tap(sy + 1, sx + 1) * w11[..., None]
+    return np.clip((acc + (1 << 14)) >> 15, 0, 255).astype(np.uint8)
+
+
+def crop_obb(box, img: np.ndarray) -> np.ndarray:
+    """``BaseModelBackend._crop_obb`` (base_backend.py:91-117): the rectified (out_h, out_w, 3) BGR crop of an oriented box."""
+    ow, oh, iM = obb_crop_geometry(box)
+    return cv2_warp_affine_inverse_linear_u8(img, iM, (ow, oh))
+
+
+def is_obb(boxes: np.ndarray) -> bool:
+    """base_backend.py:119-122: a row of 5, 7 or 9 values is an oriented box."""
+    return boxes.ndim == 2 and boxes.shape[0] > 0 and boxes.shape[1] in (5, 7, 9)
+
+
 def get_crops_u8(xyxys: np.ndarray, img: np.ndarray, input_shape=(256, 128), preprocess: str = "resize") -> np.ndarray:
     """uint8 RGB crops (N, H, W, 3): slice -> resize (or resize_pad) -> BGR2RGB (blank if empty)."""
     h, w = img.shape[:2]
     xyxys = np.asarray(xyxys, dtype=np.float32)
     if xyxys.size == 0:
         return np.zeros((0, input_shape[0], input_shape[1], 3), dtype=np.uint8)
-    boxes = crop_boxes_int(xyxys.reshape(-1, xyxys.shape[-1]), w, h)
+    rows = xyxys.reshape(-1, xyxys.shape[-1])
+    obb = is_obb(rows)                                       # base_backend.py:157: decided on the first row
+    boxes = crop_boxes_int(rows, w, h) if not obb else np.zeros((len(rows), 4), dtype=int)
     out = np.empty((len(boxes), input_shape[0], input_shape[1], 3), dtype=np.uint8)
     for i, (x1, y1, x2, y2) in enumerate(boxes):
-        if x2 > x1 and y2 > y1:
+        if obb:
+            crop = crop_obb(rows[i, :5], img)
+        elif x2 > x1 and y2 > y1:
             crop = img[y1:y2, x1:x2]
         else:
             crop = np.zeros((input_shape[0], input_shape[1], 3), dtype=np.uint8)

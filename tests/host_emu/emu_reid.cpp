@@ -126,6 +126,24 @@ int emu_crop_resize(const uint8_t* frame, int W, int H, const float* boxes, int 
     return 0;
 }
 
+// Oriented boxes: k_crop_resize_obb<float, false> with the per-box geometry [out_w, out_h, inverse map] the C ABI computes on the host
+int emu_crop_resize_obb(const uint8_t* frame, int W, int H, const double* geo, int n, int pad, float* out) {
+    using namespace bm;
+    float lut[768];
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    for (int c = 0; c < 3; ++c)
+        for (int v = 0; v < 256; ++v) {
+            volatile float a = (float)v / 255.0f;
+            volatile float b = a - mean[c];
+            lut[c * 256 + v] = b / stdv[c];
+        }
+    std::vector<int> streams(n, 0);
+    const uint8_t* frames[1] = {frame};
+    const uint8_t* const* fr = frames; const int* cs = streams.data(); const float* lp = lut;
+    launch(n, REID_IN_H / 16, REID_IN_W, [=]() { k_crop_resize_obb<float, false>(fr, cs, geo, W, H, lp, out, 16, pad); });
+    return 0;
+}
+
 // Head kernels alone on given stage-2 activations (fp32 natural NHWC, (n, 128, 128)): the batched head (16 crops per
 // workgroup, FC on the matrix pipe) and the per-crop head of round 1, with an optional output-row map and device-style count.
 int emu_head_pair(const float* blob, long n_floats, const float* act, int n, int count, const int* rows, float* feats_batched,

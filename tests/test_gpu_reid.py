@@ -252,3 +252,40 @@ def test_resize_pad_preprocess_matches_oracle_in_both_modes():
         assert np.abs(r.get_features(boxes, img) - want).max() < tol
     with pytest.raises(RuntimeError):
         HipReID(sd, preprocess="letterbox")
+
+
+@pytest.mark.parametrize("cols", [5, 7, 9])
+def test_oriented_box_crops_bit_exact_and_features_in_both_modes(cols):
+    """Rows of 5 / 7 / 9 values are oriented boxes [cx, cy, w, h, angle, ...] (base_backend.py:119-122, 157): the rectified
+    crop of _crop_obb (getRotationMatrix2D + warpAffine, base_backend.py:91-117) is sampled on the device -- crops bit for
+    bit against the restated warpAffine, features within the ReID tolerance in the fp32 and the fused fp16 kernels, for
+    both preprocess modes; more boxes than one engine chunk."""
+    from boxmot_amd.reid import MODE_FP16_FUSED, MODE_FP32_LAYERWISE, HipReID
+    from boxmot_amd.reid_weights import reference_init_state_dict
+    from oracle.crops import get_crops
+    from oracle.osnet import OracleReID
+    sd = reference_init_state_dict("osnet_x0_25", seed=0)
+    rng = np.random.default_rng(21)
+    img = rng.integers(0, 255, (480, 641, 3), dtype=np.uint8)
+    fixed = np.array([[320, 240, 80, 160, 0.3], [10, 20, 60, 90, -1.2], [630, 470, 50, 120, 2.0], [300, 200, 33.4, 71.6, 0.77],
+                      [200, 200, 128, 256, 0.0], [200.5, 100.5, 256, 512, 0.0], [100, 300, 0.2, 40, 0.5], [400, 100, 300.5, 20.5, 1.5708],
+                      [-50, -60, 40, 40, 0.1]], dtype=np.float32)
+    rand = np.stack([rng.uniform(-20, 660, 30), rng.uniform(-20, 500, 30), rng.uniform(2, 200, 30), rng.uniform(2, 400, 30),
+                     rng.uniform(-np.pi, np.pi, 30)], 1).astype(np.float32)
+    boxes = np.concatenate([fixed, rand])
+    if cols > 5:
+        boxes = np.concatenate([boxes, rng.uniform(0, 1, (len(boxes), cols - 5)).astype(np.float32)], 1)
+    for pre in ("resize", "resize_pad"):
+        want_crops = get_crops(boxes, img, preprocess=pre)
+        want = OracleReID(sd, preprocess=pre).get_features(boxes, img)
+        for mode, tol in ((MODE_FP32_LAYERWISE, 2e-5), (MODE_FP16_FUSED, 1e-3)):
+            r = HipReID(sd, mode=mode, preprocess=pre, max_crops=16)
+            if mode == MODE_FP32_LAYERWISE:
+                got = np.concatenate([r.get_crops(boxes[i:i + 16], img) for i in range(0, len(boxes), 16)])
+                assert np.array_equal(got, want_crops)
+            err = np.abs(r.get_features(boxes, img) - want).max()
+            assert err < tol, (pre, mode, err)
+            # an axis-aligned call right after an oriented one does not see stale geometry
+            aabb = np.array([[136, 72, 264, 328]], dtype=np.float32)
+            assert np.abs(r.get_features(aabb, img) - OracleReID(sd, preprocess=pre).get_features(aabb, img)).max() < tol
+            r.close()

@@ -123,6 +123,33 @@ def test_crop_kernel_resize_and_resize_pad_equal_the_oracle_emulated(pad):
 
 
 @pytest.mark.skipif(CLANG is None, reason="needs a host clang with _Float16")
+@pytest.mark.parametrize("pad", [0, 1])
+def test_oriented_box_crop_kernel_equals_the_oracle_emulated(pad):
+    """k_crop_resize_obb (device source on CPU threads) vs oracle.crops for oriented boxes [cx, cy, w, h, angle]
+    (base_backend.py:91-117): boxes inside the frame, hanging over its edges, degenerate sizes, angle 0 -- bit for bit."""
+    from oracle.crops import get_crops, obb_crop_geometry
+
+    lib = ctypes.CDLL(str(_build()))
+    lib.emu_crop_resize_obb.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    wd, hd = 641, 480
+    img = np.random.default_rng(6).integers(0, 255, (hd, wd, 3), dtype=np.uint8)
+    boxes = np.array([[320, 240, 80, 160, 0.3], [10, 20, 60, 90, -1.2], [630, 470, 50, 120, 2.0], [300, 200, 33.4, 71.6, 0.77],
+                      [200, 200, 128, 256, 0.0], [200.5, 100.5, 256, 512, 0.0], [100, 300, 0.2, 40, 0.5], [400, 100, 300.5, 20.5, 1.5708],
+                      [-50, -60, 40, 40, 0.1]], dtype=np.float32)
+    geo = np.empty((len(boxes), 8), dtype=np.float64)
+    for i, b in enumerate(boxes):
+        ow, oh, im = obb_crop_geometry(b)
+        geo[i, 0], geo[i, 1], geo[i, 2:] = ow, oh, im
+    out = np.zeros((len(boxes), 256, 128, 3), np.float32)
+    assert lib.emu_crop_resize_obb(img.ctypes.data, wd, hd, geo.ctypes.data, len(boxes), pad, out.ctypes.data) == 0
+    want = get_crops(boxes, img, preprocess="resize_pad" if pad else "resize").transpose(0, 2, 3, 1)
+    assert np.array_equal(out, want)
+    # an unrotated oriented box with integer corners inside the frame is the axis-aligned crop of the same rectangle
+    aabb = get_crops(np.array([[136, 72, 264, 328]], dtype=np.float32), img).transpose(0, 2, 3, 1)
+    assert np.array_equal(out[4], aabb[0]) or pad
+
+
+@pytest.mark.skipif(CLANG is None, reason="needs a host clang with _Float16")
 def test_batched_head_equals_per_crop_head_and_oracle_emulated():
     """k_head_batched (16 crops per workgroup, conv5 from an LDS-staged swizzled crop, FC as hi + lo MFMAs) against the
     per-crop head and against torch on random stage-2 activations: 37 crops = two full batches + a ragged one, an output
