@@ -1093,10 +1093,21 @@ __global__ void __launch_bounds__(512) k_stem_fused(const _Float16* __restrict__
 //      (one ds_read_b128 per MFMA), vertical + horizontal max, store.
 // Same arithmetic (and bit-identical fp16 output) as k_crop_resize_rgbx + k_stem_fused.
 // ---------------------------------------------------------------------------
+// BM_STEM_STREAM = 1: in the conv phase a wave owns one 16-pixel column strip and FOUR pooled rows (nine conv rows) and
+// streams the 23 input rows of the strip once: one ds_read_b128 per input row feeds the 3-4 conv rows that row contributes to
+// (kernel rows ky of the same parity), each into its own accumulator in ascending ky -- the same sums in the same order as
+// BM_STEM_STREAM = 0 (a wave owns one pooled row across the width: 84 reads and 84 MFMAs per band against 23 and 63 here; the
+// phase was bound by the LDS read bandwidth, 1 KiB per MFMA).  The pooled pixel on a strip's first column needs the last conv
+// column of the strip to its left, which another wave computes: it crosses through a 4 KiB LDS edge buffer (double-buffered
+// by band parity) under the barrier that ends the band.
+#ifndef BM_STEM_STREAM
+#define BM_STEM_STREAM 1
+#endif
 constexpr int RING_ROWS = 40;
 constexpr int RING_ROW_BYTES = STEM_COLS * 8;                    // 136 px * RGBX fp16
 constexpr int SRC_STAGE_BYTES = 20 * 1024;
-constexpr int STEM2_LDS = RING_ROWS * RING_ROW_BYTES + SRC_STAGE_BYTES + 768 * 2 + 256 * 8;   // ring, staging, LUT, y table
+constexpr int STEM_EDGE_BYTES = BM_STEM_STREAM ? 2 * 2 * 4 * 4 * 16 * 4 : 0;   // [band parity][half][strip][pooled row][channel] fp32
+constexpr int STEM2_LDS = RING_ROWS * RING_ROW_BYTES + SRC_STAGE_BYTES + 768 * 2 + 256 * 8 + STEM_EDGE_BYTES;   // ring, staging, LUT, y table, edges
 
 __global__ void __launch_bounds__(512) k_stem_resize_fused(const uint8_t* const* frames, const int* crop_stream,
                                                            const float* boxes, int box_stride, int W, int H,
@@ -1253,6 +1264,59 @@ __global__ void __launch_bounds__(512) k_stem_resize_fused(const uint8_t* const*
             *reinterpret_cast<h4*>(ring + (pr % RING_ROWS) * RING_ROW_BYTES + (dx + 3) * 8) = px;
         }
         __syncthreads();
+#if BM_STEM_STREAM
+        // ---- 3. conv rows + pooling: strip t (16 conv pixels), pooled rows oy0 .. oy0 + 3 ----
+        {
+            const int t = wave & 3, half = wave >> 2;
+            const int oy0 = 8 * band + 4 * half;
+            const int rbase = 4 * oy0 - 2;                 // padded input row of (conv row 2 oy0 - 1, ky 0); conv row j of 9 is 2 oy0 - 1 + j
+            const unsigned char* bcol = ring + (2 * (t * 16 + l16) + 2 * g) * 8;
+            f4 acc[9];
+#pragma unroll
+            for (int i = 0; i < 23; ++i) {                 // input row rbase + i feeds conv row j with ky = i - 2 j
+                const int jlo = i > 6 ? (i - 5) >> 1 : 0, jhi = (i >> 1) < 8 ? (i >> 1) : 8;
+                if (oy0 == 0 && jlo == 0 && jhi == 0) continue;         // only conv row -1 (outside the image) reads these rows
+                const int slot = (rbase + i + RING_ROWS) % RING_ROWS;
+                const h8 b = *reinterpret_cast<const h8*>(bcol + slot * RING_ROW_BYTES);
+#pragma unroll
+                for (int j = jlo; j <= jhi; ++j) {
+                    if (j == 0 && oy0 == 0) continue;                   // wave-uniform
+                    const int ky = i - 2 * j;
+                    acc[j] = BM_MFMA_F16_K32(a[ky], b, ky == 0 ? bias : acc[j]);
+                }
+            }
+            float* edge = reinterpret_cast<float*>(stage + SRC_STAGE_BYTES + 768 * 2 + 256 * 8) + (((band & 1) * 2 + half) * 4) * (4 * 16);
+            f4 m[4];
+#pragma unroll
+            for (int p4 = 0; p4 < 4; ++p4) {
+                f4 vm = max4(relu4(acc[2 * p4 + 1]), relu4(acc[2 * p4 + 2]));
+                if (!(oy0 == 0 && p4 == 0)) vm = max4(vm, relu4(acc[2 * p4]));          // conv row -1 does not exist (wave-uniform)
+                if (l16 == 15) *reinterpret_cast<f4*>(edge + (t * 4 + p4) * 16 + g * 4) = vm;
+                m[p4] = vm;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {   // all values are >= 0 (post-ReLU), so a missing neighbour reads as 0
+                    const float right = BM_ROW_SHL1_F32(vm[rr]);
+                    float left = BM_ROW_SHR1_F32(vm[rr]);
+                    if (l16 == 0) left = 0.f;
+                    const float mm = m[p4][rr] > right ? m[p4][rr] : right;
+                    m[p4][rr] = mm > left ? mm : left;
+                }
+                if ((l16 & 1) == 0 && l16 != 0) {
+                    const int p = (oy0 + p4) * 32 + t * 8 + (l16 >> 1);
+                    *reinterpret_cast<h4*>(yout + (long)p * 16 + g * 4) = to_h4(m[p4]);
+                }
+            }
+            __syncthreads();
+            if (l16 == 0) {
+#pragma unroll
+                for (int p4 = 0; p4 < 4; ++p4) {
+                    if (t > 0) m[p4] = max4(m[p4], *reinterpret_cast<const f4*>(edge + ((t - 1) * 4 + p4) * 16 + g * 4));
+                    const int p = (oy0 + p4) * 32 + t * 8;
+                    *reinterpret_cast<h4*>(yout + (long)p * 16 + g * 4) = to_h4(m[p4]);
+                }
+            }
+        }
+#else
         // ---- 3. conv rows + pooling for pooled row oy ----
         const int oy = 8 * band + wave;
         f4 vprev = f4{0.f, 0.f, 0.f, 0.f};       // vertical max of the previous tile (for the left neighbour of lane 0)
@@ -1290,6 +1354,7 @@ __global__ void __launch_bounds__(512) k_stem_resize_fused(const uint8_t* const*
             vprev = vm;
         }
         __syncthreads();
+#endif
     }
 }
 
