@@ -62,6 +62,17 @@
 // everything derived from it (ring-buffer modulo, row offsets, base pointers) is computed once on the scalar unit
 #define BM_UNIFORM_I32(x) __builtin_amdgcn_readfirstlane((int)(x))
 #endif
+#ifndef BM_MUL24
+// unsigned multiplies of operands that fit 24 bits: the full-rate v_mul_u32_u24 / v_mul_hi_u32_u24 instead of the quarter-rate
+// 32-bit multiplies the compiler must pick when it cannot see the ranges (BM_MULHI24 = bits 32.. of the 48-bit product)
+#define BM_MUL24(a, b) ((unsigned)__umul24((unsigned)(a), (unsigned)(b)))
+__device__ inline unsigned bm_mulhi24(unsigned a, unsigned b) {
+    unsigned d;
+    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+#define BM_MULHI24(a, b) bm_mulhi24((unsigned)(a), (unsigned)(b))
+#endif
 #ifndef BM_CLOCK
 #define BM_CLOCK() wall_clock64()
 #endif

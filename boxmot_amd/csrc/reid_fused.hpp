@@ -1107,9 +1107,10 @@ constexpr int RING_ROWS = 40;
 constexpr int RING_ROW_BYTES = STEM_COLS * 8;                    // 136 px * RGBX fp16
 constexpr int SRC_STAGE_BYTES = 20 * 1024;
 constexpr int STEM_EDGE_BYTES = BM_STEM_STREAM ? 2 * 2 * 4 * 4 * 16 * 4 : 0;   // [band parity][half][strip][pooled row][channel] fp32
-constexpr int STEM2_LDS = RING_ROWS * RING_ROW_BYTES + SRC_STAGE_BYTES + 768 * 2 + 256 * 8 + STEM_EDGE_BYTES;   // ring, staging, LUT, y table, edges
+constexpr int STEM_LUT_BYTES = 768 * 4;                          // normalisation table, 4-byte entries (fp16 in the low half)
+constexpr int STEM2_LDS = RING_ROWS * RING_ROW_BYTES + SRC_STAGE_BYTES + STEM_LUT_BYTES + 256 * 8 + STEM_EDGE_BYTES;   // ring, staging, LUT, y table, edges
 
-__global__ void __launch_bounds__(512) k_stem_resize_fused(const uint8_t* const* frames, const int* crop_stream,
+__global__ void __launch_bounds__(512, 4) k_stem_resize_fused(const uint8_t* const* frames, const int* crop_stream,
                                                            const float* boxes, int box_stride, int W, int H,
                                                            const float* lut, _Float16* __restrict__ out,
                                                            const unsigned char* __restrict__ wts,
@@ -1119,14 +1120,14 @@ __global__ void __launch_bounds__(512) k_stem_resize_fused(const uint8_t* const*
     unsigned char* ring = lds;
     unsigned char* stage = lds + RING_ROWS * RING_ROW_BYTES;
     _Float16* lut_h = reinterpret_cast<_Float16*>(stage + SRC_STAGE_BYTES);
-    unsigned* ytab = reinterpret_cast<unsigned*>(stage + SRC_STAGE_BYTES + 768 * 2);   // [256]{s0 | s1 << 16, a0 | a1 << 16}
+    unsigned* ytab = reinterpret_cast<unsigned*>(stage + SRC_STAGE_BYTES + STEM_LUT_BYTES);   // [256]{s0 | s1 << 16, a0 | a1 << 16}
     const int tid = threadIdx.x, lane = tid & 63, wave = BM_UNIFORM_I32(tid >> 6), g = lane >> 4, l16 = lane & 15;
     const long crop = blockIdx.x;
     const uint8_t* frame = frames[crop_stream[crop]];
     const CropRect r = crop_rect(boxes + crop * box_stride, W, H);
     const long row_stride = (long)W * 3;
     _Float16* yout = out + crop * (64 * 32) * 16;
-    for (int e = tid; e < 768; e += 512) lut_h[e] = (_Float16)lut[e];
+    for (int e = tid; e < 768; e += 512) { lut_h[2 * e] = (_Float16)lut[e]; lut_h[2 * e + 1] = (_Float16)0.f; }      // 4-byte entries
     if (tid < REID_IN_H) {      // vertical taps of every resized row, once per crop
         const ResizeAxis ay = resize_axis_y(tid, REID_IN_H, r.h > 0 ? r.h : 1);
         ytab[2 * tid] = (unsigned)ay.s0 | ((unsigned)ay.s1 << 16);
@@ -1155,24 +1156,28 @@ __global__ void __launch_bounds__(512) k_stem_resize_fused(const uint8_t* const*
         if (r.w > 0 && dy1 > dy0) {
             if (identity) { sy_lo = dy0; sy_hi = dy1 - 1; }
             else if (area2) { sy_lo = 2 * dy0; sy_hi = 2 * dy1 - 1; }
-            else { sy_lo = resize_axis_y(dy0, REID_IN_H, r.h).s0; sy_hi = resize_axis_y(dy1 - 1, REID_IN_H, r.h).s1; }
+            else { sy_lo = (int)(ytab[2 * dy0] & 0xffffu); sy_hi = (int)(ytab[2 * (dy1 - 1)] >> 16); }      // the table of vertical taps
             const long byte0 = (long)r.x1 * 3;
             pitch = ((3 + r.w * 3 + 3) / 4) * 4;          // room for the per-row alignment offset (0..3)
             staged = (long)(sy_hi - sy_lo + 1) * pitch <= SRC_STAGE_BYTES;
             if (staged) {
-                const int ndw = pitch / 4, total = (sy_hi - sy_lo + 1) * ndw;
+                // wave w moves rows w, w + 8, ...: row addresses are wave-uniform (scalar unit), lanes take consecutive dwords
+                const int ndw = pitch / 4, nrow = sy_hi - sy_lo + 1;
                 const uint8_t* frame_end = frame + (long)H * row_stride;
-                for (int e = tid; e < total; e += 512) {
-                    const int rr = e / ndw, cw = e % ndw;
+                for (int rr = wave; rr < nrow; rr += 8) {
                     const uint8_t* rowp = frame + (long)(r.y1 + sy_lo + rr) * row_stride + byte0;
-                    const uint8_t* src = rowp - (reinterpret_cast<uintptr_t>(rowp) & 3) + 4L * cw;   // aligned dwords
-                    unsigned v;
-                    if (src + 4 <= frame_end) v = *reinterpret_cast<const unsigned*>(src);
-                    else {                                  // tail of the frame: stay inside the allocation
-                        v = 0;
-                        for (int q = 0; q < 4 && src + q < frame_end; ++q) v |= (unsigned)src[q] << (8 * q);
+                    const uint8_t* src0 = rowp - (reinterpret_cast<uintptr_t>(rowp) & 3);            // aligned dwords
+                    unsigned char* dst0 = stage + rr * pitch;
+                    for (int cw = lane; cw < ndw; cw += 64) {
+                        const uint8_t* src = src0 + 4 * cw;
+                        unsigned v;
+                        if (src + 4 <= frame_end) v = *reinterpret_cast<const unsigned*>(src);
+                        else {                                  // tail of the frame: stay inside the allocation
+                            v = 0;
+                            for (int q = 0; q < 4 && src + q < frame_end; ++q) v |= (unsigned)src[q] << (8 * q);
+                        }
+                        *reinterpret_cast<unsigned*>(dst0 + 4 * cw) = v;
                     }
-                    *reinterpret_cast<unsigned*>(stage + rr * pitch + 4 * cw) = v;
                 }
             }
         }
@@ -1187,8 +1192,11 @@ __global__ void __launch_bounds__(512) k_stem_resize_fused(const uint8_t* const*
             const unsigned abase = (unsigned)reinterpret_cast<uintptr_t>(frame + (long)r.y1 * row_stride + (long)r.x1 * 3);
             const unsigned rs = (unsigned)row_stride;
             const int xs0 = ax.s0 * 3, xs1 = ax.s1 * 3;
-            auto hrow = [&](int sy, int (&S)[3]) {
-                const int o = (sy - sy_lo) * pitch + (int)((abase + (unsigned)sy * rs) & 3u);
+            // Every product here has operands below 2^24 (bytes x 11-bit weights, row indices x pitches), so the multiplies are
+            // the full-rate 24-bit ones.  T = (S >> 4) << 8 is kept instead of S: with the vertical weight also shifted left by
+            // 8, (a * (S >> 4)) >> 16 is one v_mul_hi_u32_u24.
+            auto hrow = [&](int sy, unsigned (&T)[3]) {
+                const int o = (int)BM_MUL24(sy - sy_lo, pitch) + (int)((abase + BM_MUL24(sy, rs)) & 3u);
                 unsigned w[2];
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
@@ -1198,39 +1206,50 @@ __global__ void __launch_bounds__(512) k_stem_resize_fused(const uint8_t* const*
                     w[k] = (unsigned)(two >> (8 * (A & 3)));
                 }
 #pragma unroll
-                for (int c = 0; c < 3; ++c)         // output channel c (RGB) = source byte 2 - c (BGR)
-                    S[c] = (int)((w[0] >> (8 * (2 - c))) & 255u) * ax.a0 + (int)((w[1] >> (8 * (2 - c))) & 255u) * ax.a1;
+                for (int c = 0; c < 3; ++c) {       // output channel c (RGB) = source byte 2 - c (BGR)
+                    const unsigned S = BM_MUL24((w[0] >> (8 * (2 - c))) & 255u, ax.a0) + BM_MUL24((w[1] >> (8 * (2 - c))) & 255u, ax.a1);
+                    T[c] = (S >> 4) << 8;
+                }
             };
-            int S0[3] = {0, 0, 0}, S1[3] = {0, 0, 0}, have0 = -1, have1 = -1;
-            for (int k = 0; k < run; ++k) {
-                const int pr = pr0 + rp * run + k;
-                if (pr >= pr1) break;
+            unsigned T0[3] = {0, 0, 0}, T1[3] = {0, 0, 0};
+            int have0 = -1, have1 = -1;
+            int pr = pr0 + rp * run;
+            int slot = pr % RING_ROWS;             // once per run; the ring slot then advances with the row
+            unsigned char* dst = ring + slot * RING_ROW_BYTES + (dx + 3) * 8;
+            const unsigned* lut_w = reinterpret_cast<const unsigned*>(lut_h);      // 4-byte entries (fp16 in the low half)
+            for (int k = 0; k < run && pr < pr1; ++k, ++pr) {
                 const int dy = pr - 3;
-                h4 px = h4{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+                unsigned lo = 0, hi = 0;            // h4 {R, G, B, 0} as two dwords
                 if (dy >= 0 && dy < REID_IN_H) {
                     const unsigned ys = ytab[2 * dy], ya = ytab[2 * dy + 1];
-                    const int s0 = (int)(ys & 0xffffu), s1 = (int)(ys >> 16), a0 = (int)(ya & 0xffffu), a1 = (int)(ya >> 16);
+                    const int s0 = (int)(ys & 0xffffu), s1 = (int)(ys >> 16);
+                    const unsigned a0 = (ya & 0xffffu) << 8, a1 = (ya >> 16) << 8;
                     if (s0 != have0) {
                         if (s0 == have1) {
 #pragma unroll
-                            for (int c = 0; c < 3; ++c) S0[c] = S1[c];
-                        } else hrow(s0, S0);
+                            for (int c = 0; c < 3; ++c) T0[c] = T1[c];
+                        } else hrow(s0, T0);
                         have0 = s0;
                     }
                     if (s1 != have1) {
                         if (s1 == s0) {
 #pragma unroll
-                            for (int c = 0; c < 3; ++c) S1[c] = S0[c];
-                        } else hrow(s1, S1);
+                            for (int c = 0; c < 3; ++c) T1[c] = T0[c];
+                        } else hrow(s1, T1);
                         have1 = s1;
                     }
+                    unsigned px3[3];
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        const int v = (((a0 * (S0[c] >> 4)) >> 16) + ((a1 * (S1[c] >> 4)) >> 16) + 2) >> 2;
-                        px[c] = lut_h[c * 256 + v];
+                        const unsigned v4 = (BM_MULHI24(a0, T0[c]) + BM_MULHI24(a1, T1[c]) + 2u) & ~3u;       // 4 v: byte offset of the table entry
+                        px3[c] = *reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned char*>(lut_w + c * 256) + v4);
                     }
+                    lo = (px3[0] & 0xffffu) | (px3[1] << 16);
+                    hi = px3[2] & 0xffffu;
                 }
-                *reinterpret_cast<h4*>(ring + (pr % RING_ROWS) * RING_ROW_BYTES + (dx + 3) * 8) = px;
+                *reinterpret_cast<unsigned long long*>(dst) = ((unsigned long long)hi << 32) | lo;
+                dst += RING_ROW_BYTES;
+                if (++slot == RING_ROWS) { slot = 0; dst -= RING_ROWS * RING_ROW_BYTES; }
             }
         } else
         for (int pr = pr0 + rp; pr < pr1; pr += 4) {
@@ -1258,7 +1277,7 @@ __global__ void __launch_bounds__(512) k_stem_resize_fused(const uint8_t* const*
                         v = resize_sample(frame + (long)r.y1 * row_stride + r.x1 * 3, row_stride, r, ax, ay, dy, dx, 2 - c,
                                           REID_IN_W, REID_IN_H);
                     }
-                    px[c] = lut_h[c * 256 + v];
+                    px[c] = lut_h[2 * (c * 256 + v)];
                 }
             }
             *reinterpret_cast<h4*>(ring + (pr % RING_ROWS) * RING_ROW_BYTES + (dx + 3) * 8) = px;
@@ -1285,7 +1304,7 @@ __global__ void __launch_bounds__(512) k_stem_resize_fused(const uint8_t* const*
                     acc[j] = BM_MFMA_F16_K32(a[ky], b, ky == 0 ? bias : acc[j]);
                 }
             }
-            float* edge = reinterpret_cast<float*>(stage + SRC_STAGE_BYTES + 768 * 2 + 256 * 8) + (((band & 1) * 2 + half) * 4) * (4 * 16);
+            float* edge = reinterpret_cast<float*>(stage + SRC_STAGE_BYTES + STEM_LUT_BYTES + 256 * 8) + (((band & 1) * 2 + half) * 4) * (4 * 16);
             f4 m[4];
 #pragma unroll
             for (int p4 = 0; p4 < 4; ++p4) {

@@ -113,6 +113,8 @@ inline unsigned emu_dpp_u32(unsigned old, unsigned v, int ctrl, bool zero_fill) 
 #define BM_DPP_U32(old, v, ctrl, zero_fill) emu_dpp_u32(old, v, ctrl, zero_fill)
 #define BM_QUAD_SWAP1_F32(v) __shfl_xor((float)(v), 1, 64)
 #define BM_UNIFORM_I32(x) ((int)(x))
+#define BM_MUL24(a, b) ((unsigned)(((unsigned)(a) & 0xffffffu) * ((unsigned)(b) & 0xffffffu)))
+#define BM_MULHI24(a, b) ((unsigned)(((unsigned long long)((unsigned)(a) & 0xffffffu) * ((unsigned)(b) & 0xffffffu)) >> 32))
 #define BM_ROW_SHL1_F32(v) emu_row_shift(v, 1, false)
 #define BM_ROW_SHR1_F32(v) emu_row_shift(v, -1, false)
 #define BM_ROW_ROR1_F32(v) emu_row_shift(v, -1, true)
