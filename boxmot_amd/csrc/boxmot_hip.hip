@@ -40,6 +40,7 @@ int guard(F&& f) {
 }
 
 constexpr int STEP_THREADS = 512;
+constexpr int SS_STEP_THREADS_BIG = 1024;     // StrongSORT frame step with max_tracks >= 1024
 
 template <int NTHR>
 __global__ void __launch_bounds__(NTHR) botsort_step_kernel(bm::BotSortStepArgs args) {
@@ -61,7 +62,7 @@ __global__ void __launch_bounds__(NTHR) deepocsort_step_kernel(bm::DocsStepArgs 
 
 template <int NTHR>
 __global__ void __launch_bounds__(NTHR) strongsort_detnorm_kernel(bm::SsStepArgs args) {
-    bm::ss_det_norm_block<NTHR>(args, args.stream_base + blockIdx.x);
+    bm::ss_det_norm_block<NTHR>(args, args.stream_base + blockIdx.x, blockIdx.y, gridDim.y);
 }
 
 template <int NTHR>
@@ -884,19 +885,35 @@ void ss_build(BoxMOTHipStrongSort* h) {
     if (lds > 120 * 1024) throw std::runtime_error("boxmot_hip: max_tracks/max_dets too large for the assignment solver's LDS state");
     BM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(strongsort_step_kernel<STEP_THREADS>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    BM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(strongsort_step_kernel<SS_STEP_THREADS_BIG>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ss_zero_state(h);
 }
 
+#ifdef BM_SS_PROF
+// tools only: phase clocks of strongsort_step_kernel (workgroup 0), cleared on read
+extern "C" int boxmot_hip_debug_ss_prof(unsigned long long* out16) {
+    unsigned long long zero[16] = {0};
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(bm::g_ss_prof), sizeof(zero)) != hipSuccess) return 0;
+    return hipMemcpyToSymbol(HIP_SYMBOL(bm::g_ss_prof), zero, sizeof(zero)) == hipSuccess;
+}
+#endif
+
 // detection norms -> sample-bank distances of every confirmed track (state BEFORE this frame's step) -> frame step
 void ss_launch(BoxMOTHipStrongSort* h, const bm::SsStepArgs& a, int n) {
-    hipLaunchKernelGGL((strongsort_detnorm_kernel<SS_BANK_THREADS>), dim3(n), dim3(SS_BANK_THREADS), 0, h->stream, a);
+    hipLaunchKernelGGL((strongsort_detnorm_kernel<SS_BANK_THREADS>), dim3(n, h->nd >= 128 ? 16 : 1), dim3(SS_BANK_THREADS), 0, h->stream, a);
     // sample-bank distances: fp32 matrix pipe (budgets up to 112 samples; bit-identical sums), else / on request the scalar-FMA kernel
     if (h->cfg.nn_budget <= bm::SS_MT * 16 && !h->bank_valu)
         hipLaunchKernelGGL((strongsort_bank_mfma_kernel<SS_BANK_THREADS>), dim3(h->cap, n), dim3(SS_BANK_THREADS), 0, h->stream, a);
     else
         hipLaunchKernelGGL((strongsort_bank_kernel<SS_BANK_THREADS>), dim3(h->cap, n), dim3(SS_BANK_THREADS), 0, h->stream, a);
-    hipLaunchKernelGGL((strongsort_step_kernel<STEP_THREADS>), dim3(n), dim3(STEP_THREADS),
-                       (size_t)bm::ss_lsa_lds_bytes(h->cap > h->nd ? h->cap : h->nd), h->stream, a);
+    // one workgroup per stream: 16 waves when the track table is large (the per-match / per-track phases run a wave per item)
+    if (h->cap >= 1024)
+        hipLaunchKernelGGL((strongsort_step_kernel<SS_STEP_THREADS_BIG>), dim3(n), dim3(SS_STEP_THREADS_BIG),
+                           (size_t)bm::ss_lsa_lds_bytes(h->cap > h->nd ? h->cap : h->nd), h->stream, a);
+    else
+        hipLaunchKernelGGL((strongsort_step_kernel<STEP_THREADS>), dim3(n), dim3(STEP_THREADS),
+                           (size_t)bm::ss_lsa_lds_bytes(h->cap > h->nd ? h->cap : h->nd), h->stream, a);
 }
 
 // Stage the inputs of the first n streams (ReID on every detection with conf >= min_conf when embeddings are not supplied,

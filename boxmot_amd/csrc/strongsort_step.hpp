@@ -58,6 +58,7 @@ struct SsScratch {
     double* det_tlwh;     // [S][nd][4]   per kept detection
     double* det_xyah;     // [S][nd][4]
     double* cost;         // [S][max(cap,nd)][max(cap,nd)]
+    double* cost_t;       // same size: the transposed copy the assignment solver scans when there are more tracks than detections
     int* rows_a; int* rows_b; int* cols_b;       // track positions / detection indices of the two stages
     int* un_d; int* tmp_a; int* tmp_b;
     int* m_trk; int* m_det;
@@ -80,6 +81,19 @@ struct SsStepArgs {
 };
 
 struct SsSizes { int S, cap, nd, dim, budget; };
+
+// Optional phase clocks (tools only; never defined in the product build): thread 0 of workgroup 0 accumulates shader-clock
+// cycles per phase of the frame step, read back through boxmot_hip_debug_ss_prof.
+#ifdef BM_SS_PROF
+__device__ unsigned long long g_ss_prof[16];
+#define SS_PROF_DECL() do { if (threadIdx.x == 0 && blockIdx.x == 0) g_ss_prof[15] = clock64(); } while (0)
+#define SS_PROF(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long t_ = clock64(); g_ss_prof[k] += t_ - g_ss_prof[15]; g_ss_prof[15] = t_; } } while (0)
+#define SS_PROF_COUNT(k, n) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_ss_prof[k] += (n); } while (0)
+#else
+#define SS_PROF_DECL() ((void)0)
+#define SS_PROF(k) ((void)0)
+#define SS_PROF_COUNT(k, n) ((void)0)
+#endif
 
 // ---------------------------------------------------------------------------
 // `unmatched_tracks = list(set(track_indices) - set(k for k, _ in matches))` (linear_assignment.py:141): the order of
@@ -152,6 +166,25 @@ __device__ inline void pyset_add(PySetI& s, int key) {
     if ((long)s.fill * 5 < (long)s.mask * 3) return;
     pyset_resize(s, s.used > 50000 ? s.used * 2 : s.used * 4);
 }
+// table size CPython reaches after n distinct insertions into an empty set (growth x4 whenever fill * 5 >= mask * 3)
+__device__ inline int pyset_table_size(int n) {
+    int size = 8;
+    while (true) {
+        const int thr = ((size - 1) * 3 + 4) / 5;          // smallest fill that triggers the resize
+        if (n < thr) return size;
+        const int minused = thr > 50000 ? thr * 2 : thr * 4;
+        int ns = 8;
+        while (ns <= minused) ns <<= 1;
+        size = ns;
+    }
+}
+// ints per table that pyset_difference(a of na keys, b of nb keys) needs at most: the final table plus the rebuild area of its
+// last resize; the copy path sizes the result for 2 * na keys at once
+__device__ inline int pyset_need(int na, int nb) {
+    int f = pyset_table_size(na > nb ? na : nb), r = 8;
+    while (r <= 2 * na) r <<= 1;
+    return 2 * (f > r ? f : r);
+}
 // out[] = list(set(a) - set(b)); returns the length (or -1 when the tables would not fit)
 __device__ inline int pyset_difference(int* storage, int capacity, const int* a, int na, const int* b, int nb, int* out) {
     PySetI A, B, R;
@@ -188,6 +221,93 @@ __device__ inline int pyset_difference(int* storage, int capacity, const int* a,
     return n;
 }
 
+// ---------------------------------------------------------------------------
+// The same hash tables replayed by ONE WAVEFRONT out of LDS (the single-thread version above is the fallback when the tables
+// do not fit): a probe of the up to ten consecutive slots CPython examines is one LDS read across ten lanes plus a ballot, a
+// rebuild walks the old table 64 slots at a time, and the tables ping-pong between two LDS regions instead of being copied
+// down.  Same insertion order, same probe sequence, same growth rule -- the same layouts.  No deletions happen while a table
+// is being built (the discards of the copy path only turn keys into dummies, which the final walk skips by the flag array).
+// ---------------------------------------------------------------------------
+struct WSet { int* table; int* other; int mask, fill; };
+__device__ inline int wset_first_set(unsigned long long m) { return __popcll((m & (0ull - m)) - 1ull); }     // index of the lowest set bit
+__device__ inline void wset_insert(int* table, int mask, int key, int lane) {          // set_insert_clean / set_add_entry of a new key
+    unsigned perturb = (unsigned)key, i = (unsigned)key & (unsigned)mask;
+    while (true) {
+        const int probes = (i + 9 <= (unsigned)mask) ? 9 : 0;
+        const int val = lane <= probes ? table[i + lane] : 0;
+        const unsigned long long emp = __ballot(lane <= probes && val == PYSET_EMPTY);
+        if (emp) { if (lane == 0) table[i + wset_first_set(emp)] = key; break; }
+        perturb >>= 5;
+        i = (i * 5 + 1 + perturb) & (unsigned)mask;
+    }
+    BM_WAVE_LDS_SYNC();
+}
+__device__ inline void wset_clear(int* table, int size, int lane) {
+    for (int e = lane; e < size; e += WAVE) table[e] = PYSET_EMPTY;
+    BM_WAVE_LDS_SYNC();
+}
+// set_table_resize: the keys of the old table, in slot order, go into a fresh table of `newsize` slots in the other region
+__device__ inline void wset_rebuild(WSet& s, int newsize, int lane) {
+    wset_clear(s.other, newsize, lane);
+    for (int base = 0; base <= s.mask; base += WAVE) {
+        const int key = base + lane <= s.mask ? s.table[base + lane] : PYSET_EMPTY;
+        unsigned long long occ = __ballot(key >= 0);
+        while (occ) {
+            const int b = wset_first_set(occ);
+            occ &= occ - 1ull;
+            wset_insert(s.other, newsize - 1, __shfl(key, b, WAVE), lane);
+        }
+    }
+    int* t = s.table; s.table = s.other; s.other = t;
+    s.mask = newsize - 1;
+}
+// set(keys[0 .. n)) built key by key (set_add_entry with the growth rule); the tables alternate between regions a and b
+__device__ inline void wset_build(WSet& s, int* a, int* b, const int* keys, int n, int lane) {
+    s.table = a; s.other = b; s.mask = 7; s.fill = 0;
+    wset_clear(s.table, 8, lane);
+    for (int base = 0; base < n; base += WAVE) {
+        const int mine = base + lane < n ? keys[base + lane] : 0;
+        const int cnt = n - base < WAVE ? n - base : WAVE;
+        for (int q = 0; q < cnt; ++q) {
+            wset_insert(s.table, s.mask, __shfl(mine, q, WAVE), lane);
+            s.fill++;
+            if ((long)s.fill * 5 < (long)s.mask * 3) continue;
+            const int minused = s.fill > 50000 ? s.fill * 2 : s.fill * 4;
+            int newsize = 8;
+            while (newsize <= minused) newsize <<= 1;
+            wset_rebuild(s, newsize, lane);
+        }
+    }
+}
+// keys of a list, in order, those with skip[key] != 0 left out; returns the count
+__device__ inline int wset_filter(const int* keys, int n_keys, const int* skip, int* out, int lane) {
+    int n = 0;
+    for (int base = 0; base < n_keys; base += WAVE) {
+        const int key = base + lane < n_keys ? keys[base + lane] : -1;
+        const bool keep = key >= 0 && !skip[key];
+        const unsigned long long m = __ballot(keep);
+        if (keep) out[n + __popcll(m & ((1ull << lane) - 1ull))] = key;
+        n += __popcll(m);
+    }
+    BM_WAVE_LDS_SYNC();
+    return n;
+}
+// the keys of the table in slot order, those with skip[key] != 0 left out (skip may be null); returns the count
+__device__ inline int wset_walk(const WSet& s, const int* skip, int* out, int lane) {
+    int n = 0;
+    for (int base = 0; base <= s.mask; base += WAVE) {
+        const int key = base + lane <= s.mask ? s.table[base + lane] : PYSET_EMPTY;
+        const bool keep = key >= 0 && !(skip && skip[key]);
+        const unsigned long long m = __ballot(keep);
+        if (keep) out[n + __popcll(m & ((1ull << lane) - 1ull))] = key;
+        n += __popcll(m);
+    }
+    BM_WAVE_LDS_SYNC();
+    return n;
+}
+// ints of LDS the wave version needs: two table regions of `fmax` slots and two key lists of `nkeys`
+__host__ __device__ inline long wset_lds_ints(int fmax, int nkeys) { return 2L * fmax + 2L * nkeys + 256; }
+
 template <class A>
 void ss_allocate(SsStepArgs& args, const SsSizes& z, A& a) {
     const size_t S = z.S, cap = z.cap, nd = z.nd, dim = z.dim, big = cap > nd ? cap : nd;
@@ -211,6 +331,7 @@ void ss_allocate(SsStepArgs& args, const SsSizes& z, A& a) {
     sc.keep = a.template get<int>(S * nd);
     sc.det_tlwh = a.template get<double>(S * nd * 4); sc.det_xyah = a.template get<double>(S * nd * 4);
     sc.cost = a.template get<double>(S * big * big);
+    sc.cost_t = a.template get<double>(S * big * big);
     sc.rows_a = a.template get<int>(S * cap); sc.rows_b = a.template get<int>(S * cap); sc.cols_b = a.template get<int>(S * nd);
     sc.un_d = a.template get<int>(S * nd); sc.tmp_a = a.template get<int>(S * big); sc.tmp_b = a.template get<int>(S * big);
     sc.m_trk = a.template get<int>(S * big); sc.m_det = a.template get<int>(S * big);
@@ -229,15 +350,22 @@ void ss_allocate(SsStepArgs& args, const SsSizes& z, A& a) {
 // ---------------------------------------------------------------------------
 constexpr int SS_TILE = 64, SS_KC = 16;
 
-// |b| of every detection of stream s: one wavefront per detection
+// |b| of every detection of stream s: one wavefront per detection; `part` of `nparts` workgroups share a stream's detections
 template <int NTHR>
-__device__ inline void ss_det_norm_block(const SsStepArgs& a, int s) {
+__device__ inline void ss_det_norm_block(const SsStepArgs& a, int s, int part = 0, int nparts = 1) {
     const long dim = a.st.dim, nd = a.sc.max_dets;
     const int n_d = a.n_dets[s], lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
     const float* embs = a.embs + (long)s * nd * dim;
-    for (int j = wave; j < n_d; j += NTHR / WAVE) {
+    for (int j = part * (NTHR / WAVE) + wave; j < n_d; j += nparts * (NTHR / WAVE)) {
         float ss = 0.f;
-        for (int k = lane; k < dim; k += WAVE) ss = fmaf(embs[j * dim + k], embs[j * dim + k], ss);
+        const float* row = embs + j * dim;
+        for (int k0 = lane; k0 < dim; k0 += 4 * WAVE) {        // four loads in flight; the per-lane fmaf order is the plain loop's
+            float x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = k0 + u * WAVE < dim ? row[k0 + u * WAVE] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (k0 + u * WAVE < dim) ss = fmaf(x[u], x[u], ss);
+        }
         ss = wave_sum(ss);
         if (lane == 0) a.sc.det_norm[s * nd + j] = sqrtf(ss);
     }
@@ -508,31 +636,42 @@ __device__ inline bool ss_kf_update_wave(double* kf, const double* z, double con
 }
 
 // squared Mahalanobis distance of measurement z to the projected state (confidence 0), base.py:523-551
-__device__ inline double ss_gating_distance(const double* kf, const double* z) {
+// split in two so that the factor, which depends on the track only, is computed once per track: the same operations on the same
+// values as the one-piece form
+struct SsGate { double L[4][4]; double m[4]; };
+__device__ inline void ss_gating_factor(const double* kf, SsGate& g) {
     const double* P = kf + KF_DIM;
-    double S[4][4], L[4][4];
+    double S[4][4];
     for (int a = 0; a < 4; ++a)
         for (int b = 0; b < 4; ++b) S[a][b] = P[a * 8 + b];
     for (int a = 0; a < 4; ++a) { const double sd = (a == 2) ? 1e-1 : SS_STD_POS * kf[3]; S[a][a] = S[a][a] + sd * sd; }
     for (int c = 0; c < 4; ++c) {
         double d = S[c][c];
-        for (int k = 0; k < c; ++k) d -= L[c][k] * L[c][k];
+        for (int k = 0; k < c; ++k) d -= g.L[c][k] * g.L[c][k];
         d = sqrt(d);
-        L[c][c] = d;
+        g.L[c][c] = d;
         for (int r = c + 1; r < 4; ++r) {
             double t = S[r][c];
-            for (int k = 0; k < c; ++k) t -= L[r][k] * L[c][k];
-            L[r][c] = t / d;
+            for (int k = 0; k < c; ++k) t -= g.L[r][k] * g.L[c][k];
+            g.L[r][c] = t / d;
         }
     }
+    for (int k = 0; k < 4; ++k) g.m[k] = kf[k];
+}
+__device__ inline double ss_gating_apply(const SsGate& g, const double* z) {
     double y[4], s = 0.0;
     for (int k = 0; k < 4; ++k) {
-        double t = z[k] - kf[k];
-        for (int q = 0; q < k; ++q) t -= L[k][q] * y[q];
-        y[k] = t / L[k][k];
+        double t = z[k] - g.m[k];
+        for (int q = 0; q < k; ++q) t -= g.L[k][q] * y[q];
+        y[k] = t / g.L[k][k];
     }
     for (int k = 0; k < 4; ++k) s += y[k] * y[k];
     return s;
+}
+__device__ inline double ss_gating_distance(const double* kf, const double* z) {
+    SsGate g;
+    ss_gating_factor(kf, g);
+    return ss_gating_apply(g, z);
 }
 
 // ---------------------------------------------------------------------------
@@ -542,76 +681,93 @@ __device__ inline double ss_gating_distance(const double* kf, const double* z) {
 // cost_of(r, c) is the LOGICAL matrix (already transposed by the caller when it has more rows than columns).
 // Solver state in dynamic LDS.  Output: col_of[r] for r < nr (every row is assigned).
 // ---------------------------------------------------------------------------
-struct LsaLds { double* u; double* v; double* spc; int* path; int* col4row; int* row4col; int* sr; int* sc; int* remaining; };
-__host__ __device__ inline long ss_lsa_lds_bytes(int n) { return (long)n * (8 * 3 + 4 * 6) + 64; }
+struct LsaLds { double* u; double* v; double* spc; int* path; int* col4row; int* row4col; int* sr; int* sc; int* remaining; int cap_n; };
+__host__ __device__ inline long ss_lsa_lds_bytes(int n) { return (long)n * (8 * 3 + 4 * 6) + 64 + 2 * MAX_WAVES * 16; }
 __device__ inline LsaLds ss_carve_lsa(unsigned char* base, int n) {
     LsaLds l;
+    l.cap_n = n;
     l.u = reinterpret_cast<double*>(base); l.v = l.u + n; l.spc = l.v + n;
     l.path = reinterpret_cast<int*>(l.spc + n); l.col4row = l.path + n; l.row4col = l.col4row + n;
     l.sr = l.row4col + n; l.sc = l.sr + n; l.remaining = l.sc + n;
     return l;
 }
 
+// One barrier per scan.  Every wavefront reduces (lowest, first position among the minima, last unassigned position among the
+// minima) over its columns and leaves the result in a 16-byte slot of the current parity; after the barrier every thread
+// combines the slots itself (one ds_read_b128 each; the same comparisons a single combiner would make).  Positions travel
+// packed with their column (position << 16 | column: positions are distinct, so min / max on the packed word is min / max on
+// the position), so nobody reads `remaining` after the barrier; the swap that removes the chosen column from `remaining` is
+// deferred to the owner of that position at the start of the next scan, and the slots alternate between two parities, which
+// together make the single barrier sufficient.  sr / sc marks are only read by the dual update, behind its own barrier.
+// Measured on configuration 5 (256 rows x 1024 columns, 263 scans per frame): six barriers per scan with a serial combiner
+// 9.5 k cycles per scan; a single-wavefront solver without any barrier 14.7 k.
+struct alignas(16) LsaSlot { double lowest; int first; int last_un; };       // packed: position << 16 | column, -1 = none
+constexpr int LSA_SLOT_BYTES = 2 * MAX_WAVES * 16;
+__device__ inline LsaSlot* ss_lsa_slots(unsigned char* base, int n) { return reinterpret_cast<LsaSlot*>(base + (((long)n * (8 * 3 + 4 * 6) + 63) & ~63L)); }
 template <class CostFn>
 __device__ inline bool lsa_scipy(const Ctx& c, const LsaLds& L, int nr, int nc, CostFn cost_of, int* col_of) {
+    SS_PROF_COUNT(11, 1);
+    LsaSlot* const slot_base = ss_lsa_slots(reinterpret_cast<unsigned char*>(L.u), L.cap_n);
     for (int r = c.tid; r < nr; r += c.nthr) { L.u[r] = 0.0; L.col4row[r] = -1; }
     for (int j = c.tid; j < nc; j += c.nthr) { L.v[j] = 0.0; L.row4col[j] = -1; L.path[j] = -1; }
     __syncthreads();
     bool feasible = true;
+    int parity = 0;
     for (int cur = 0; cur < nr && feasible; ++cur) {
         double min_val = 0.0;
         int i = cur, num_remaining = nc, sink = -1;
+        int pend_pos = -1, pend_from = -1;           // remaining[pend_pos] = remaining[pend_from], owed by the owner of pend_pos
         for (int it = c.tid; it < nc; it += c.nthr) { L.remaining[it] = nc - it - 1; L.sc[it] = 0; L.spc[it] = SS_INF; }
         for (int r = c.tid; r < nr; r += c.nthr) L.sr[r] = 0;
         __syncthreads();
         while (sink == -1) {
+            SS_PROF_COUNT(10, 1);
             if (c.tid == 0) L.sr[i] = 1;
             const double ui = L.u[i];
             double lowest = SS_INF;
             int first = -1, last_un = -1;
             for (int it = c.tid; it < num_remaining; it += c.nthr) {
+                if (it == pend_pos) L.remaining[it] = L.remaining[pend_from];
                 const int j = L.remaining[it];
-                const double r = min_val + cost_of(i, j) - ui - L.v[j];
+                const double cij = cost_of(i, j), vj = L.v[j];
                 double sp = L.spc[j];
+                const bool un = L.row4col[j] == -1;
+                const double r = min_val + cij - ui - vj;
                 if (r < sp) { L.path[j] = i; L.spc[j] = r; sp = r; }
-                if (sp < lowest) { lowest = sp; first = it; last_un = (L.row4col[j] == -1) ? it : -1; }
-                else if (sp == lowest && L.row4col[j] == -1) last_un = it;
+                const int packed = (it << 16) | j;
+                if (sp < lowest) { lowest = sp; first = packed; last_un = un ? packed : -1; }
+                else if (sp == lowest && un) last_un = packed;
             }
-            // workgroup reduction of (lowest, first position, last unassigned position among the minima)
             for (int off = WAVE / 2; off > 0; off >>= 1) {
                 const double ov = __shfl_xor(lowest, off, WAVE);
                 const int of = __shfl_xor(first, off, WAVE), ol = __shfl_xor(last_un, off, WAVE);
                 if (of >= 0 && (first < 0 || ov < lowest)) { lowest = ov; first = of; last_un = ol; }
                 else if (of >= 0 && ov == lowest) { first = of < first ? of : first; last_un = ol > last_un ? ol : last_un; }
             }
-            if (c.lane == 0) { c.s_dbl[c.wave] = lowest; c.s_int[c.wave] = first; }
+            LsaSlot* slots = slot_base + parity * MAX_WAVES;
+            if (c.lane == 0) { LsaSlot o; o.lowest = lowest; o.first = first; o.last_un = last_un; slots[c.wave] = o; }
             __syncthreads();
             double gl = SS_INF;
-            int gf = -1;
+            int gf = -1, gu = -1;
             for (int w = 0; w < c.nwaves; ++w) {
-                const double ov = c.s_dbl[w];
-                const int of = c.s_int[w];
-                if (of >= 0 && (gf < 0 || ov < gl)) { gl = ov; gf = of; }
-                else if (of >= 0 && ov == gl) gf = of < gf ? of : gf;
+                const LsaSlot o = slots[w];
+                if (o.first < 0) continue;
+                if (gf < 0 || o.lowest < gl) { gl = o.lowest; gf = o.first; gu = o.last_un; }
+                else if (o.lowest == gl) { gf = o.first < gf ? o.first : gf; gu = o.last_un > gu ? o.last_un : gu; }
             }
-            __syncthreads();
-            // second pass for the last unassigned position among the global minima
-            if (c.lane == 0) c.s_int[c.wave] = (first >= 0 && lowest == gl) ? last_un : -1;
-            __syncthreads();
-            int gu = -1;
-            for (int w = 0; w < c.nwaves; ++w) gu = c.s_int[w] > gu ? c.s_int[w] : gu;
-            __syncthreads();
+            parity ^= 1;
             if (gf < 0 || !(gl < SS_INF)) { feasible = false; break; }
             min_val = gl;
-            const int index = gu >= 0 ? gu : gf;
-            const int j = L.remaining[index];
+            const int chosen = gu >= 0 ? gu : gf;
+            const int index = chosen >> 16, j = chosen & 0xffff;
             const int owner = L.row4col[j];
             if (owner == -1) sink = j; else i = owner;
-            __syncthreads();
-            if (c.tid == 0) { L.sc[j] = 1; L.remaining[index] = L.remaining[num_remaining - 1]; }
+            if (c.tid == 0) L.sc[j] = 1;
             --num_remaining;
-            __syncthreads();
+            pend_pos = index; pend_from = num_remaining;         // the last live position moves into the hole
+            if (pend_pos == pend_from) pend_pos = -1;
         }
+        __syncthreads();           // sr / sc marks and the last scan's spc are visible to the dual update
         if (!feasible) break;
         // dual variables (rectangular_lsap.cpp: u[curRow] += minVal; u[i] += minVal - spc[col4row[i]]; v[j] -= minVal - spc[j])
         for (int r = c.tid; r < nr; r += c.nthr) {
@@ -645,7 +801,7 @@ struct SSV {
     int* frame_count; int* next_id; int* n_tracks; int* status; int* list; int* slot_used;
     double* kf; float* feat; float* bank; float* bank_norm; int* bank_n; int* id; int* state; int* hits; int* age; int* tsu;
     float* conf; float* cls; float* det_ind;
-    float* app; int* keep; double* det_tlwh; double* det_xyah; double* cost;
+    float* app; int* keep; double* det_tlwh; double* det_xyah; double* cost; double* cost_t;
     int* rows_a; int* rows_b; int* cols_b; int* un_d; int* tmp_a; int* tmp_b; int* m_trk; int* m_det; int* row_of; int* col_of; int* flag_t; int* pyset;
     const float* dets; int n_dets; const float* embs; const double* warp; float* out; int* out_n;
 };
@@ -663,6 +819,7 @@ __device__ inline SSV ss_view(const SsStepArgs& a, int s) {
     v.conf = st.conf + s * cap; v.cls = st.cls + s * cap; v.det_ind = st.det_ind + s * cap;
     v.app = sc.app + s * cap * nd; v.keep = sc.keep + s * nd; v.det_tlwh = sc.det_tlwh + s * nd * 4; v.det_xyah = sc.det_xyah + s * nd * 4;
     v.cost = sc.cost + s * big * big;
+    v.cost_t = sc.cost_t + s * big * big;
     v.rows_a = sc.rows_a + s * cap; v.rows_b = sc.rows_b + s * cap; v.cols_b = sc.cols_b + s * nd; v.un_d = sc.un_d + s * nd;
     v.tmp_a = sc.tmp_a + s * big; v.tmp_b = sc.tmp_b + s * big; v.m_trk = sc.m_trk + s * big; v.m_det = sc.m_det + s * big;
     v.row_of = sc.row_of + s * big; v.col_of = sc.col_of + s * big; v.flag_t = sc.flag_t + s * cap;
@@ -671,6 +828,95 @@ __device__ inline SSV ss_view(const SsStepArgs& a, int s) {
     v.warp = a.warp ? a.warp + s * 6 : nullptr;
     v.out = a.out + s * cap * OUT_COLS; v.out_n = a.out_n + s;
     return v;
+}
+
+// `unmatched_tracks = list(set(rows_a) - set(m_trk))` in CPython's iteration order -> v.tmp_a, returns the length.
+// rows_a: the confirmed track positions (ascending), m_trk[0 .. n_match): the matched ones; nt = live tracks.
+__device__ inline int ss_unmatched_in_set_order(const Ctx& c, SSV& v, int n_conf, int n_match, int nt, int big, unsigned char* dyn_lds) {
+    int* s_int = c.s_int;
+    auto ident = [](int i) { return i; };
+    // The order of that list is the slot order of CPython's hash table (hash(i) == i).  B only matters as a set (a flag per
+    // track position).  A's slot order: track positions are small ascending ints, and whenever every key is below the table
+    // size in force when it is inserted (checked in parallel) no probe ever collides, each key sits in the slot of its own
+    // value and the order is ascending; otherwise wave 0 replays the table out of LDS (wset_*).  The result either shares A's
+    // layout (copy path with equal table sizes: the unmatched keys in A's order) or is rebuilt by the same wave.
+    const int na = n_conf, nb = n_match;
+    {
+        for (int t = c.tid; t < nt; t += c.nthr) v.flag_t[t] = 0;
+        __syncthreads();
+        for (int q = c.tid; q < nb; q += c.nthr) v.flag_t[v.m_trk[q]] = 1;
+        __syncthreads();
+        const int bad_a = block_append_if(c, na, [&](int i) { return v.rows_a[i] >= pyset_table_size(i); }, ident, v.tmp_b, 0);
+        // unmatched keys in ascending order: the answer whenever every table involved has the identity layout
+        const int n_asc = block_append_if(c, na, [&](int i) { return !v.flag_t[v.rows_a[i]]; }, [&](int i) { return v.rows_a[i]; }, v.tmp_a, 0);
+        const bool copy_path = (na >> 2) > nb;                 // set_difference -> set_copy_and_difference
+        const int ta = pyset_table_size(na);
+        int tr = 8;                                            // the copy is sized for 2 na keys at once (set_merge)
+        if (copy_path && (long)na * 5 >= 7 * 3) while (tr <= 2 * na) tr <<= 1;
+        int bad_r = 0;
+        if (!bad_a && na > 0) {
+            if (copy_path) bad_r = (tr != ta && v.rows_a[na - 1] >= tr) ? 1 : 0;
+            else bad_r = block_append_if(c, n_asc, [&](int i) { return v.tmp_a[i] >= pyset_table_size(i); }, ident, v.tmp_b, 0);
+        }
+        int n = n_asc;
+        if (bad_a || bad_r) {
+            int fmax = ta;
+            if (copy_path && tr > fmax) fmax = tr;
+            n = -2;
+            if (wset_lds_ints(fmax, na) * (long)sizeof(int) <= ss_lsa_lds_bytes(big)) {
+                if (c.wave == 0) {
+                    int* reg_a = reinterpret_cast<int*>(dyn_lds);
+                    int* reg_b = reg_a + fmax + 64;
+                    int* list_a = reg_b + fmax + 64;           // A's keys in slot order
+                    int* list_b = list_a + na + 64;            // the candidates of the growing result
+                    WSet A, R;
+                    const int* order = v.rows_a;
+                    int n_order = na;
+                    if (bad_a) {
+                        wset_build(A, reg_a, reg_b, v.rows_a, na, c.lane);
+                        n_order = wset_walk(A, nullptr, list_a, c.lane);
+                        order = list_a;
+                    }
+                    if (copy_path) {
+                        if (tr == ta) n = wset_filter(order, n_order, v.flag_t, v.tmp_a, c.lane);        // slots copied one to one
+                        else {             // set_insert_clean of A's keys, in slot order, into tr empty slots; the discards leave dummies
+                            wset_clear(reg_a, tr, c.lane);
+                            for (int base = 0; base < n_order; base += WAVE) {
+                                const int mine = base + c.lane < n_order ? order[base + c.lane] : 0;
+                                const int cnt = n_order - base < WAVE ? n_order - base : WAVE;
+                                for (int q = 0; q < cnt; ++q) wset_insert(reg_a, tr - 1, __shfl(mine, q, WAVE), c.lane);
+                            }
+                            R.table = reg_a; R.other = reg_b; R.mask = tr - 1; R.fill = n_order;
+                            n = wset_walk(R, v.flag_t, v.tmp_a, c.lane);
+                        }
+                    } else {               // the unmatched keys, in A's slot order, enter an empty set one by one
+                        const int m = wset_filter(order, n_order, v.flag_t, list_b, c.lane);
+                        wset_build(R, reg_a, reg_b, list_b, m, c.lane);
+                        n = wset_walk(R, nullptr, v.tmp_a, c.lane);
+                    }
+                    if (c.lane == 0) s_int[0] = n;
+                }
+                __syncthreads();
+                n = s_int[0];
+                __syncthreads();
+            }
+            if (n == -2) {                                     // tables larger than the LDS area: one thread, global memory
+                if (c.tid == 0) {
+                    int r = pyset_difference(v.pyset, pyset_capacity(v.cap), v.rows_a, na, v.m_trk, nb, v.tmp_a);
+                    if (r < 0) { *v.status = STATUS_TRACK_CAPACITY; r = 0; }
+                    s_int[0] = r;
+                }
+                __syncthreads();
+                n = s_int[0];
+                __syncthreads();
+            }
+        }
+        if (c.tid == 0) s_int[0] = n;
+    }
+    __syncthreads();
+    const int n_out = s_int[0];
+    __syncthreads();
+    return n_out;
 }
 
 // min_cost_matching (linear_assignment.py:14-79) on `cost` (nr x nc row-major, leading dimension ld), rows = track
@@ -690,26 +936,41 @@ __device__ inline MatchOut ss_min_cost_matching(const Ctx& c, SSV& v, const LsaL
         return o;
     }
     const double clamp = max_distance + 1e-5;
-    for (long e = c.tid; e < (long)nr * nc; e += c.nthr) {
-        const long r = e / nc, q = e % nc;
-        if (v.cost[r * ld + q] > max_distance) v.cost[r * ld + q] = clamp;
+    // the solver works on the matrix with no more rows than columns; it scans one solver row per step, so the transposed case
+    // gets a transposed copy (rows of length nr) and every scan reads consecutive addresses
+    const bool transposed = nr > nc;
+    double* cmT = v.cost_t;
+    // 8 x 8 micro-tiles per wave instruction: the read touches 8 full 64-byte lines of `cost`, the transposed write 8 full lines of
+    // the copy
+    {
+        const int rr = c.lane >> 3, qq = c.lane & 7;
+        const int tiles_q = (nc + 7) >> 3, tiles = ((nr + 7) >> 3) * tiles_q;
+        for (int tile = c.wave; tile < tiles; tile += c.nwaves) {
+            const int r = (tile / tiles_q) * 8 + rr, q = (tile % tiles_q) * 8 + qq;
+            if (r < nr && q < nc) {
+                double x = v.cost[r * ld + q];
+                if (x > max_distance) { x = clamp; v.cost[r * ld + q] = x; }
+                if (transposed) cmT[(long)q * ld + r] = x;
+            }
+        }
     }
     __syncthreads();
+    SS_PROF(12);
     const double* cm = v.cost;
-    // the solver works on the matrix with no more rows than columns
     bool ok;
-    if (nr <= nc) {
+    if (!transposed) {
         ok = lsa_scipy(c, lsa, nr, nc, [&](int r, int q) { return cm[r * ld + q]; }, v.row_of);       // row_of[r] = column
         for (int q = c.tid; q < nc; q += c.nthr) v.col_of[q] = -1;
         __syncthreads();
         for (int r = c.tid; r < nr; r += c.nthr) if (v.row_of[r] >= 0) v.col_of[v.row_of[r]] = r;
     } else {
-        ok = lsa_scipy(c, lsa, nc, nr, [&](int q, int r) { return cm[r * ld + q]; }, v.col_of);       // col_of[q] = row
+        ok = lsa_scipy(c, lsa, nc, nr, [&](int q, int r) { return cmT[(long)q * ld + r]; }, v.col_of);       // col_of[q] = row
         for (int r = c.tid; r < nr; r += c.nthr) v.row_of[r] = -1;
         __syncthreads();
         for (int q = c.tid; q < nc; q += c.nthr) if (v.col_of[q] >= 0) v.row_of[v.col_of[q]] = q;
     }
     __syncthreads();
+    SS_PROF(13);
     if (!ok && c.tid == 0) *v.status = STATUS_LAP_STALL;
     auto valid = [&](int r) { return v.row_of[r] >= 0 && !(cm[r * ld + v.row_of[r]] > max_distance); };
     o.n_un_cols = block_append_if(c, nc, [&](int q) { return v.col_of[q] < 0; }, [&](int q) { return cols[q]; }, un_cols, 0);
@@ -727,6 +988,30 @@ __device__ inline MatchOut ss_min_cost_matching(const Ctx& c, SSV& v, const LsaL
     return o;
 }
 
+// Per-wavefront passes over a dim-long fp32 vector (lane l owns elements l, l + 64, ...).  Four loads per lane are issued before
+// the first use (a plain loop over global memory exposes one round trip per element); the per-lane order of the operations, and
+// with it every rounding, is the order of the plain loop.
+template <class Load, class Use>
+__device__ inline void ss_wave_pass(int lane, int dim, Load load, Use use) {
+    for (int e0 = lane; e0 < dim; e0 += 4 * WAVE) {
+        float x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int e = e0 + u * WAVE; x[u] = e < dim ? load(e) : 0.f; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int e = e0 + u * WAVE; if (e < dim) use(e, x[u]); }
+    }
+}
+template <class Load1, class Load2, class Use>
+__device__ inline void ss_wave_pass2(int lane, int dim, Load1 load1, Load2 load2, Use use) {
+    for (int e0 = lane; e0 < dim; e0 += 4 * WAVE) {
+        float x[4], y[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int e = e0 + u * WAVE; x[u] = e < dim ? load1(e) : 0.f; y[u] = e < dim ? load2(e) : 0.f; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int e = e0 + u * WAVE; if (e < dim) use(e, x[u], y[u]); }
+    }
+}
+
 template <int NTHR>
 __device__ inline void ss_step_stream(const SsStepArgs& args, int s, int* s_int, double* s_dbl, unsigned char* dyn_lds) {
     if (args.n_dets[s] < 0) {                 // stream not stepped in this call
@@ -734,6 +1019,7 @@ __device__ inline void ss_step_stream(const SsStepArgs& args, int s, int* s_int,
         return;
     }
     const Ctx c = make_ctx(s_int, s_dbl);
+    SS_PROF_DECL();
     SSV v = ss_view(args, s);
     const SsConfigDev& cfg = v.cfg;
     const int big = v.cap > v.nd ? v.cap : v.nd;
@@ -784,32 +1070,35 @@ __device__ inline void ss_step_stream(const SsStepArgs& args, int s, int* s_int,
     }
     __syncthreads();
 
+    SS_PROF(0);
     // ---- stage A: confirmed tracks vs all detections by gated appearance (tracker.py:107-139) ----
     const int n_conf = block_append_if(c, nt, [&](int t) { return v.state[v.list[t]] == SS_CONFIRMED; }, ident, v.rows_a, 0);
     for (int k = c.tid; k < nk; k += c.nthr) v.tmp_a[k] = k;            // detection_indices = range(len(detections))
     __syncthreads();
     if (n_conf > 0 && nk > 0) {
-        for (long e = c.tid; e < (long)n_conf * nk; e += c.nthr) {
-            const int r = (int)(e / nk), k = (int)(e % nk);
+        for (int r = c.wave; r < n_conf; r += c.nwaves) {          // a wavefront per track: the gate's factor once, lanes over detections
             const int t = v.rows_a[r];
-            double cst = (double)v.app[(long)t * v.nd + v.keep[k]];
-            const double gd = ss_gating_distance(v.kf + (long)v.list[t] * KF_STRIDE, v.det_xyah + k * 4);
-            if (gd > SS_CHI2_4) cst = SS_INFTY_COST;
-            v.cost[r * ld + k] = cfg.mc_lambda * cst + (1 - cfg.mc_lambda) * gd;
+            SsGate g;
+            ss_gating_factor(v.kf + (long)v.list[t] * KF_STRIDE, g);
+            for (int k = c.lane; k < nk; k += WAVE) {
+                double cst = (double)v.app[(long)t * v.nd + v.keep[k]];
+                const double gd = ss_gating_apply(g, v.det_xyah + k * 4);
+                if (gd > SS_CHI2_4) cst = SS_INFTY_COST;
+                v.cost[r * ld + k] = cfg.mc_lambda * cst + (1 - cfg.mc_lambda) * gd;
+            }
         }
         __syncthreads();
     }
+    SS_PROF(1);
     // un_rows of stage A -> tmp list (flag_t reused as storage for unmatched confirmed rows)
     MatchOut a = ss_min_cost_matching(c, v, lsa, v.rows_a, n_conf, v.tmp_a, nk, ld, cfg.max_cos_dist, 0, v.flag_t, v.un_d);
-    // unmatched confirmed tracks = list(set(confirmed) - set(matched)) in CPython's set order (one thread, tiny)
-    if (c.tid == 0) {
-        const int n = pyset_difference(v.pyset, pyset_capacity(v.cap), v.rows_a, n_conf, v.m_trk, a.n_match, v.tmp_a);
-        if (n < 0) *v.status = STATUS_TRACK_CAPACITY;
-        s_int[0] = n < 0 ? 0 : n;
-    }
+    SS_PROF(3);
+    // unmatched confirmed tracks = list(set(confirmed) - set(matched)) in CPython's set order (ss_unmatched_in_set_order)
+    s_int[0] = ss_unmatched_in_set_order(c, v, n_conf, a.n_match, nt, big, dyn_lds);
     __syncthreads();
     const int n_un_a = s_int[0];
     __syncthreads();
+    SS_PROF(4);
     // ---- stage B: unconfirmed + just-missed confirmed tracks vs the remaining detections by IoU (tracker.py:141-158) ----
     int n_b = block_append_if(c, nt, [&](int t) { return v.state[v.list[t]] != SS_CONFIRMED; }, ident, v.rows_b, 0);
     n_b = block_append_if(c, n_un_a, [&](int q) { return v.tsu[v.list[v.tmp_a[q]]] == 1; }, [&](int q) { return v.tmp_a[q]; }, v.rows_b, n_b);
@@ -822,8 +1111,8 @@ __device__ inline void ss_step_stream(const SsStepArgs& args, int s, int* s_int,
     __syncthreads();
     const int n_cb = a.n_un_cols;
     if (n_b > 0 && n_cb > 0) {
-        for (long e = c.tid; e < (long)n_b * n_cb; e += c.nthr) {
-            const int r = (int)(e / n_cb), q = (int)(e % n_cb);
+        for (int r = c.wave; r < n_b; r += c.nwaves)
+        for (int q = c.lane; q < n_cb; q += WAVE) {
             const int slot = v.list[v.rows_b[r]];
             double cst;
             if (v.tsu[slot] > 1) cst = SS_INFTY_COST;
@@ -846,6 +1135,7 @@ __device__ inline void ss_step_stream(const SsStepArgs& args, int s, int* s_int,
     MatchOut b = ss_min_cost_matching(c, v, lsa, v.rows_b, n_b, v.cols_b, n_cb, ld, cfg.max_iou_dist, a.n_match, v.flag_t, v.un_d);
     const int n_match = b.n_match;
 
+    SS_PROF(5);
     // ---- Track.update for the matches (track.py:162-189), wave per match ----
     for (int base = 0; base < n_match; base += c.nwaves) {
         const int q = base + c.wave;
@@ -857,16 +1147,16 @@ __device__ inline void ss_step_stream(const SsStepArgs& args, int s, int* s_int,
             const float* de = v.embs + (long)j * dim;
             float* tf = v.feat + (long)slot * dim;
             float ss = 0.f;
-            for (int e = c.lane; e < dim; e += WAVE) ss = fmaf(de[e], de[e], ss);
+            ss_wave_pass(c.lane, dim, [&](int e) { return de[e]; }, [&](int, float x) { ss = fmaf(x, x, ss); });
             const float dn = sqrtf(wave_sum(ss));
             float s2 = 0.f;
-            for (int e = c.lane; e < dim; e += WAVE) {
-                const float sm = cfg.ema_alpha_f32 * tf[e] + cfg.one_minus_alpha_f32 * (de[e] / dn);
+            ss_wave_pass2(c.lane, dim, [&](int e) { return tf[e]; }, [&](int e) { return de[e]; }, [&](int e, float t0, float x) {
+                const float sm = cfg.ema_alpha_f32 * t0 + cfg.one_minus_alpha_f32 * (x / dn);
                 tf[e] = sm;
                 s2 = fmaf(sm, sm, s2);
-            }
+            });
             const float sn = sqrtf(wave_sum(s2));
-            for (int e = c.lane; e < dim; e += WAVE) tf[e] = tf[e] / sn;
+            ss_wave_pass(c.lane, dim, [&](int e) { return tf[e]; }, [&](int e, float x) { tf[e] = x / sn; });
             if (c.lane == 0) {
                 if (!ok) *v.status = STATUS_LAP_STALL + 1;
                 v.conf[slot] = d[4]; v.cls[slot] = d[5]; v.det_ind[slot] = (float)j;
@@ -875,6 +1165,7 @@ __device__ inline void ss_step_stream(const SsStepArgs& args, int s, int* s_int,
             }
         }
     }
+    SS_PROF(6);
     // ---- mark_missed (track.py:191-196): stale confirmed, unmatched of stage B ----
     auto missed = [&](int t) {
         const int slot = v.list[t];
@@ -914,9 +1205,10 @@ __device__ inline void ss_step_stream(const SsStepArgs& args, int s, int* s_int,
                 }
                 const float* de = v.embs + (long)j * dim;
                 float ss = 0.f;
-                for (int e = c.lane; e < dim; e += WAVE) ss = fmaf(de[e], de[e], ss);
+                ss_wave_pass(c.lane, dim, [&](int e) { return de[e]; }, [&](int, float x) { ss = fmaf(x, x, ss); });
                 const float dn = sqrtf(wave_sum(ss));
-                for (int e = c.lane; e < dim; e += WAVE) v.feat[(long)slot * dim + e] = de[e] / dn;
+                float* nf = v.feat + (long)slot * dim;
+                ss_wave_pass(c.lane, dim, [&](int e) { return de[e]; }, [&](int e, float x) { nf[e] = x / dn; });
                 if (c.lane == 0) {
                     v.slot_used[slot] = 1;
                     v.id[slot] = id0 + q;
@@ -932,6 +1224,7 @@ __device__ inline void ss_step_stream(const SsStepArgs& args, int s, int* s_int,
         __syncthreads();
     }
 
+    SS_PROF(7);
     // ---- drop deleted tracks (tracker.py:94), then feed the sample bank of every confirmed track (:96-106) ----
     const int n_live = block_append_if(c, nt, [&](int t) { return v.state[v.list[t]] != SS_DELETED; }, [&](int t) { return v.list[t]; }, v.tmp_a, 0);
     if (n_live != nt) {
@@ -950,7 +1243,8 @@ __device__ inline void ss_step_stream(const SsStepArgs& args, int s, int* s_int,
                 const int bn = __shfl(v.bank_n[slot], 0, WAVE);       // every lane has read the count before lane 0 bumps it
                 float* dst = v.bank + ((long)slot * v.budget + bn % v.budget) * dim;
                 float ss = 0.f;
-                for (int e = c.lane; e < dim; e += WAVE) { const float f = v.feat[(long)slot * dim + e]; dst[e] = f; ss = fmaf(f, f, ss); }
+                const float* sf = v.feat + (long)slot * dim;
+                ss_wave_pass(c.lane, dim, [&](int e) { return sf[e]; }, [&](int e, float f) { dst[e] = f; ss = fmaf(f, f, ss); });
                 ss = wave_sum(ss);
                 if (c.lane == 0) { v.bank_norm[(long)slot * v.budget + bn % v.budget] = sqrtf(ss); v.bank_n[slot] = bn + 1; }
             }
@@ -958,6 +1252,7 @@ __device__ inline void ss_step_stream(const SsStepArgs& args, int s, int* s_int,
     }
     __syncthreads();
 
+    SS_PROF(8);
     // ---- output rows (strongsort.py:103-123): confirmed and updated this frame, list order ----
     const int n_out = block_append_if(c, nt, [&](int t) { return v.state[v.list[t]] == SS_CONFIRMED && v.tsu[v.list[t]] < 1; },
                                       [&](int t) { return v.list[t]; }, v.tmp_a, 0);
@@ -971,6 +1266,7 @@ __device__ inline void ss_step_stream(const SsStepArgs& args, int s, int* s_int,
     }
     if (c.tid == 0) *v.out_n = n_out;
     __syncthreads();
+    SS_PROF(9);
 }
 
 }  // namespace bm

@@ -27,7 +27,7 @@ def build(sanitize: bool = False, dense: bool = False) -> Path:
             flags += ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"]
         if dense:
             flags += ["-DBM_SPARSE_MAX=0"]      # force the dense LDS-tiled cosine path
-        subprocess.check_call(["g++", *flags, "-o", str(out), str(src)])
+        subprocess.check_call(["g++", *flags, f"-DEMU_NTHR={threads}", "-o", str(out), str(src)])
     return out
 
 
@@ -144,12 +144,13 @@ SS_D = ("min_conf", "max_cos_dist", "max_iou_dist", "mc_lambda", "ema_alpha")
 SS_I = ("max_age", "n_init", "nn_budget")
 
 
-def build_ss(sanitize: bool = False) -> Path:
+def build_ss(sanitize: bool = False, threads: int = 64) -> Path:
+    """threads: workgroup size of the emulated kernels (64 = one wavefront; 256 exercises the cross-wavefront paths)."""
     src = HERE / "emu_ssort.cpp"
     csrc = HERE.parent.parent / "boxmot_amd" / "csrc"
     deps = [src, HERE / "hip_shim.hpp", csrc / "strongsort_step.hpp", csrc / "block_prims.hpp", csrc / "kernel_macros.hpp",
             csrc / "botsort_types.hpp"]
-    out = HERE / ("libemu_ssort_asan.so" if sanitize else "libemu_ssort.so")
+    out = HERE / ("libemu_ssort_asan.so" if sanitize else ("libemu_ssort.so" if threads == 64 else f"libemu_ssort_t{threads}.so"))
     if not out.exists() or any(d.stat().st_mtime > out.stat().st_mtime for d in deps):
         flags = ["-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-pthread"]
         if sanitize:

@@ -15,7 +15,10 @@ EmuMfmaBuf* g_emu_mfma = nullptr;
 
 namespace {
 
-constexpr int NTHR = 64;
+#ifndef EMU_NTHR
+#define EMU_NTHR 64
+#endif
+constexpr int NTHR = EMU_NTHR;
 
 struct HostAlloc {
     std::vector<void*> owned;
@@ -40,6 +43,7 @@ float (*g_sA)[bm::SS_TILE + 1]; float (*g_sB)[bm::SS_TILE + 1]; float (*g_sMin)[
 float* g_mfma_lds;
 
 const double* g_lsa_cost; int g_lsa_nr, g_lsa_nc; int* g_lsa_out;
+bm::SSV* g_set_view; int g_set_na, g_set_nb, g_set_nt, g_set_big, g_set_n;
 
 void* thread_main(void* p) {
     ThreadArg* ta = static_cast<ThreadArg*>(p);
@@ -51,6 +55,12 @@ void* thread_main(void* p) {
         const bm::LsaLds l = bm::ss_carve_lsa(g_dyn, n);
         const double* cm = g_lsa_cost; const int nc = g_lsa_nc;
         bm::lsa_scipy(c, l, g_lsa_nr, g_lsa_nc, [&](int r, int q) { return cm[r * nc + q]; }, g_lsa_out);
+        return nullptr;
+    }
+    if (ta->mode == 5) {
+        const bm::Ctx c = bm::make_ctx(g_s_int, g_s_dbl);
+        const int n = bm::ss_unmatched_in_set_order(c, *g_set_view, g_set_na, g_set_nb, g_set_nt, g_set_big, g_dyn);
+        if (ta->tid == 0) g_set_n = n;
         return nullptr;
     }
     if (ta->mode == 3) { bm::ss_det_norm_block<NTHR>(ta->e->args, 0); return nullptr; }
@@ -182,6 +192,31 @@ void emu_lsa(const double* cost, int nr, int nc, int* col_of) {
     g_emu_block = &e.block;
     blockDim.x = NTHR;
     run_block(&e, 2, 0);
+}
+
+// list(set(a) - set(b)) in CPython's iteration order as the frame step computes it (a ascending track positions < nt, b a subset);
+// lds_big sizes the LDS area like the kernel does (max(cap, max_dets)); returns the length
+int emu_set_order(const int* a, int na, const int* b, int nb, int nt, int cap, int lds_big, int* out) {
+    static Emu e;
+    static int s_int[bm::MAX_WAVES + 1];
+    static double s_dbl[bm::MAX_WAVES];
+    static std::vector<double> dyn;
+    dyn.assign((size_t)bm::ss_lsa_lds_bytes(lds_big) / 8 + 2, 0.0);
+    g_s_int = s_int; g_s_dbl = s_dbl; g_dyn = reinterpret_cast<unsigned char*>(dyn.data());
+    std::vector<int> rows_a(a, a + na), m_trk(b, b + nb), flag(cap + 1), tmp_a(cap + 1), tmp_b(cap + 1), pyset(3 * (size_t)bm::pyset_capacity(cap));
+    int status = 0;
+    bm::SSV v{};
+    v.cap = cap; v.rows_a = rows_a.data(); v.m_trk = m_trk.data(); v.flag_t = flag.data(); v.tmp_a = tmp_a.data(); v.tmp_b = tmp_b.data();
+    v.pyset = pyset.data(); v.status = &status;
+    g_set_view = &v; g_set_na = na; g_set_nb = nb; g_set_nt = nt; g_set_big = lds_big; g_set_n = -1;
+    e.block.block_barrier.init(NTHR);
+    for (int w = 0; w < EMU_MAX_WAVES; ++w) e.block.wave_barrier[w].init(EMU_WAVE);
+    g_emu_block = &e.block;
+    blockDim.x = NTHR;
+    run_block(&e, 5, 0);
+    if (status != 0) return -1;
+    std::memcpy(out, tmp_a.data(), (size_t)g_set_n * 4);
+    return g_set_n;
 }
 
 // tracks in list order: ints (rows,6) = id, state, hits, age, time_since_update, bank size; kf (rows,72); feat (rows,dim)

@@ -61,10 +61,12 @@ def test_emulated_strongsort_c2_shape():
     _run(sc.frames(6), 64, 512, 256, nn_budget=4)
 
 
-def test_device_assignment_solver_equals_scipy_incl_ties():
-    """lsa_scipy restates SciPy's rectangular_lsap.cpp; tie-heavy matrices (clamped costs) must give the same columns."""
+@pytest.mark.parametrize("threads", [64, 256])
+def test_device_assignment_solver_equals_scipy_incl_ties(threads):
+    """lsa_scipy restates SciPy's rectangular_lsap.cpp; tie-heavy matrices (clamped costs) must give the same columns.
+    threads = 256: four wavefronts, the cross-wavefront combine and the single barrier per scan."""
     from scipy.optimize import linear_sum_assignment
-    lib = ctypes.CDLL(str(build_ss()))
+    lib = ctypes.CDLL(str(build_ss(threads=threads)))
     lib.emu_lsa.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     rng = np.random.default_rng(2)
     for it in range(150):
@@ -77,6 +79,17 @@ def test_device_assignment_solver_equals_scipy_incl_ties():
         out = np.zeros(nr, np.int32)
         lib.emu_lsa(c.ctypes.data, nr, nc, out.ctypes.data)
         assert np.array_equal(linear_sum_assignment(c)[1], out), (it, c)
+    # wide problems: several wavefronts scan the columns, ties within and across wavefronts, long augmenting paths
+    for it in range(40):
+        nr = int(rng.integers(1, 60))
+        nc = int(rng.integers(max(nr, 65), 420))
+        c = rng.integers(0, 3 if it % 2 else 6, (nr, nc)).astype(float)
+        if it % 4 == 0:
+            c = np.where(rng.random((nr, nc)) < 0.7, 0.20001, np.round(rng.random((nr, nc)), 2))
+        c = np.ascontiguousarray(c)
+        out = np.zeros(nr, np.int32)
+        lib.emu_lsa(c.ctypes.data, nr, nc, out.ctypes.data)
+        assert np.array_equal(linear_sum_assignment(c)[1], out), (it, nr, nc)
     # stage-A shape of a crowded frame (parity soak seed 159): 21 confirmed tracks x 9 detections, every gated entry
     # clamped to the same 0.20001 -- SciPy solves the transpose, so the device does too
     c = np.full((21, 9), 0.20001)
@@ -138,3 +151,39 @@ def test_device_dot_rule_reproduces_the_kernels_appearance_costs_bit_for_bit():
     finally:
         emu.close()
     assert checked > 500
+
+
+def test_unmatched_track_order_equals_cpython_set_iteration():
+    """tracker.py / linear_assignment.py:141: `list(set(track_indices) - set(matched))` -- the frame step reproduces CPython's
+    iteration order (identity-layout shortcut, the wavefront replay of the hash tables out of LDS for both set_difference paths,
+    and the one-thread fallback when the tables outgrow the LDS area), checked against the interpreter itself."""
+    lib = ctypes.CDLL(str(build_ss(threads=256)))
+    lib.emu_set_order.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    rng = np.random.default_rng(3)
+    cases = []
+    for it in range(120):
+        nt = int(rng.integers(1, 700))
+        kind = it % 6
+        if kind == 0:                      # every track confirmed (dense keys): the shortcut
+            a = np.arange(nt)
+        elif kind == 1:                    # persistent objects first, then a sparse tail
+            a = np.sort(rng.choice(nt, size=max(1, nt // 2), replace=False))
+        elif kind == 2:                    # confirmed tracks start late in the list: collisions in the small tables
+            lo = int(rng.integers(0, nt))
+            a = np.arange(lo, nt)
+        else:
+            a = np.sort(rng.choice(nt, size=int(rng.integers(1, nt + 1)), replace=False))
+        frac = [0.0, 0.1, 0.24, 0.26, 0.6, 1.0][int(rng.integers(0, 6))]      # both sides of the len(a) / 4 > len(b) switch
+        nb = int(round(frac * len(a)))
+        if kind in (1, 4):                 # the matched ones are the first keys (persistent objects): the unmatched start late
+            b = a[:nb].copy()
+            rng.shuffle(b)
+        else:
+            b = rng.choice(a, size=nb, replace=False)
+        cases.append((a.astype(np.int32), b.astype(np.int32), nt))
+    for lds_big in (2048, 16):             # 16: the tables do not fit the LDS area -> the one-thread path
+        for a, b, nt in cases:
+            want = list(set(a.tolist()) - set(b.tolist()))
+            out = np.zeros(len(a) + 1, np.int32)
+            n = lib.emu_set_order(a.ctypes.data, len(a), b.ctypes.data, len(b), nt, 2048, lds_big, out.ctypes.data)
+            assert n == len(want) and out[:n].tolist() == want, (lds_big, len(a), len(b), nt)

@@ -92,11 +92,21 @@ def main():
         for t in range(a.warmup):
             _lib.check(step(t, d_out[t].data_ptr(), d_out_n[t].data_ptr()))
         _lib.check(sync(h))
+        prof_fn = getattr(lib, "boxmot_hip_debug_ss_prof", None) if name == "strongsort" else None     # a -DBM_SS_PROF build (BOXMOT_HIP_LIB)
+        prof = (ctypes.c_ulonglong * 16)()
+        if prof_fn:
+            prof_fn(prof)                                # clears the warm-up's clocks
         t0 = time.perf_counter()
         for t in range(a.warmup, T):
             _lib.check(step(t, d_out[t].data_ptr(), d_out_n[t].data_ptr()))
         _lib.check(sync(h))
         dt = time.perf_counter() - t0
+        phases = {}
+        if prof_fn and prof_fn(prof):
+            names = ["prologue+predict", "stageA cost build", "-", "stageA matching", "pyset", "stageB", "kf update", "missed+births",
+                     "drop+bank feed", "output", "lsa inner iterations", "lsa calls", "clamp pass", "lsa", "-", "-"]
+            phases = {"step_phase_kcycles_per_step_wg0": {n: round(prof[i] / a.steps / 1e3, 1) for i, n in enumerate(names) if n != "-" and i < 10 or i in (12, 13)},
+                      "lsa_inner_iterations_per_step": prof[10] / a.steps, "lsa_calls_per_step": prof[11] / a.steps}
         # parity gate on stream 0
         if name == "botsort":
             from oracle.botsort import BotSortOracle
@@ -128,7 +138,7 @@ def main():
         destroy(h)
         print(json.dumps({"tracker": name, "config": a.config, "streams": S, "steps": a.steps, "warmup": a.warmup, "frames_per_s": S * a.steps / dt,
                           "ms_per_step": 1e3 * dt / a.steps, "rows_stream0_last": int(out_n[-1, 0]),
-                          "parity_first_frames_vs_oracle": bool(ok), **extra}), flush=True)
+                          "parity_first_frames_vs_oracle": bool(ok), **extra, **phases}), flush=True)
 
 
 if __name__ == "__main__":
