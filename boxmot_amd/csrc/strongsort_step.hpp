@@ -701,6 +701,11 @@ __device__ inline LsaLds ss_carve_lsa(unsigned char* base, int n) {
 // together make the single barrier sufficient.  sr / sc marks are only read by the dual update, behind its own barrier.
 // Measured on configuration 5 (256 rows x 1024 columns, 263 scans per frame): six barriers per scan with a serial combiner
 // 9.5 k cycles per scan; a single-wavefront solver without any barrier 14.7 k.
+// Wavefronts beyond the first BM_LSA_SCAN_THREADS / 64 do not scan (they only follow the control flow): a scan is a thousand
+// columns at most, and with sixteen scanning waves the barrier and the combine cost more than the second column per thread saves.
+#ifndef BM_LSA_SCAN_THREADS
+#define BM_LSA_SCAN_THREADS 512
+#endif
 struct alignas(16) LsaSlot { double lowest; int first; int last_un; };       // packed: position << 16 | column, -1 = none
 constexpr int LSA_SLOT_BYTES = 2 * MAX_WAVES * 16;
 __device__ inline LsaSlot* ss_lsa_slots(unsigned char* base, int n) { return reinterpret_cast<LsaSlot*>(base + (((long)n * (8 * 3 + 4 * 6) + 63) & ~63L)); }
@@ -713,6 +718,8 @@ __device__ inline bool lsa_scipy(const Ctx& c, const LsaLds& L, int nr, int nc, 
     __syncthreads();
     bool feasible = true;
     int parity = 0;
+    const int nscan = c.nthr < BM_LSA_SCAN_THREADS ? c.nthr : BM_LSA_SCAN_THREADS, nscan_waves = nscan / WAVE;
+    const bool scans = c.tid < nscan;
     for (int cur = 0; cur < nr && feasible; ++cur) {
         double min_val = 0.0;
         int i = cur, num_remaining = nc, sink = -1;
@@ -726,7 +733,8 @@ __device__ inline bool lsa_scipy(const Ctx& c, const LsaLds& L, int nr, int nc, 
             const double ui = L.u[i];
             double lowest = SS_INF;
             int first = -1, last_un = -1;
-            for (int it = c.tid; it < num_remaining; it += c.nthr) {
+            if (scans)
+            for (int it = c.tid; it < num_remaining; it += nscan) {
                 if (it == pend_pos) L.remaining[it] = L.remaining[pend_from];
                 const int j = L.remaining[it];
                 const double cij = cost_of(i, j), vj = L.v[j];
@@ -738,18 +746,20 @@ __device__ inline bool lsa_scipy(const Ctx& c, const LsaLds& L, int nr, int nc, 
                 if (sp < lowest) { lowest = sp; first = packed; last_un = un ? packed : -1; }
                 else if (sp == lowest && un) last_un = packed;
             }
-            for (int off = WAVE / 2; off > 0; off >>= 1) {
-                const double ov = __shfl_xor(lowest, off, WAVE);
-                const int of = __shfl_xor(first, off, WAVE), ol = __shfl_xor(last_un, off, WAVE);
-                if (of >= 0 && (first < 0 || ov < lowest)) { lowest = ov; first = of; last_un = ol; }
-                else if (of >= 0 && ov == lowest) { first = of < first ? of : first; last_un = ol > last_un ? ol : last_un; }
-            }
             LsaSlot* slots = slot_base + parity * MAX_WAVES;
-            if (c.lane == 0) { LsaSlot o; o.lowest = lowest; o.first = first; o.last_un = last_un; slots[c.wave] = o; }
+            if (scans) {           // wave-uniform
+                for (int off = WAVE / 2; off > 0; off >>= 1) {
+                    const double ov = __shfl_xor(lowest, off, WAVE);
+                    const int of = __shfl_xor(first, off, WAVE), ol = __shfl_xor(last_un, off, WAVE);
+                    if (of >= 0 && (first < 0 || ov < lowest)) { lowest = ov; first = of; last_un = ol; }
+                    else if (of >= 0 && ov == lowest) { first = of < first ? of : first; last_un = ol > last_un ? ol : last_un; }
+                }
+                if (c.lane == 0) { LsaSlot o; o.lowest = lowest; o.first = first; o.last_un = last_un; slots[c.wave] = o; }
+            }
             __syncthreads();
             double gl = SS_INF;
             int gf = -1, gu = -1;
-            for (int w = 0; w < c.nwaves; ++w) {
+            for (int w = 0; w < nscan_waves; ++w) {
                 const LsaSlot o = slots[w];
                 if (o.first < 0) continue;
                 if (gf < 0 || o.lowest < gl) { gl = o.lowest; gf = o.first; gu = o.last_un; }

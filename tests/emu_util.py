@@ -27,7 +27,7 @@ def build(sanitize: bool = False, dense: bool = False) -> Path:
             flags += ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"]
         if dense:
             flags += ["-DBM_SPARSE_MAX=0"]      # force the dense LDS-tiled cosine path
-        subprocess.check_call(["g++", *flags, f"-DEMU_NTHR={threads}", "-o", str(out), str(src)])
+        subprocess.check_call(["g++", *flags, "-o", str(out), str(src)])
     return out
 
 
@@ -155,7 +155,7 @@ def build_ss(sanitize: bool = False, threads: int = 64) -> Path:
         flags = ["-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-pthread"]
         if sanitize:
             flags += ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"]
-        subprocess.check_call(["g++", *flags, "-o", str(out), str(src)])
+        subprocess.check_call(["g++", *flags, f"-DEMU_NTHR={threads}", *(["-DBM_LSA_SCAN_THREADS=128"] if threads > 128 else []), "-o", str(out), str(src)])
     return out
 
 
