@@ -188,7 +188,9 @@ int boxmot_hip_reid_feature_dim(BoxMOTHipReID* handle);
 /* "resize" (default) or "resize_pad" (reid/core/preprocessing.py:12-45; get_preprocess_fn :56-65) */
 int boxmot_hip_reid_set_preprocess(BoxMOTHipReID* handle, const char* name);
 int boxmot_hip_reid_set_mode(BoxMOTHipReID* handle, int mode);
-/* boxes (n, box_cols>=4) fp32 xyxy; out (n, feature_dim) fp32, L2-normalised */
+/* boxes (n, box_cols>=4) fp32 xyxy -- or, when box_cols is 5, 7 or 9, oriented boxes [cx, cy, w, h, angle, ...] whose rectified crop
+   is the reference's _crop_obb (boxmot/reid/backends/base_backend.py:91-122, 157: cv2.getRotationMatrix2D + cv2.warpAffine INTER_LINEAR,
+   zero border); out (n, feature_dim) fp32, L2-normalised */
 int boxmot_hip_reid_compute_features(
     BoxMOTHipReID* handle, const uint8_t* image, int image_rows, int image_cols, int image_channels,
     const float* boxes, int n_boxes, int box_cols, float* out_features, int out_capacity_rows);
