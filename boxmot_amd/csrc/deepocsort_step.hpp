@@ -655,8 +655,8 @@ __device__ inline void docs_step_stream(const DocsStepArgs& args, int s, int* s_
         for (int t = c.tid; t < nt; t += c.nthr) v.col_cnt[t] = 0;
         __syncthreads();
         const long total = (long)nk * nt;
-        for (long e = c.tid; e < total; e += c.nthr) {
-            const int k = (int)(e / nt), t = (int)(e % nt);
+        for (int k = c.wave; k < nk; k += c.nwaves)            // a wavefront per detection row, lanes over tracks (no per-element division)
+        for (int t = c.lane; t < nt; t += WAVE) {
             const float* df = v.dets + v.keep[k] * DET_COLS;
             const double db[4] = {(double)df[0], (double)df[1], (double)df[2], (double)df[3]};
             const double score = (double)df[4];
@@ -706,8 +706,8 @@ __device__ inline void docs_step_stream(const DocsStepArgs& args, int s, int* s_
             for (int t = c.tid; t < nt; t += c.nthr) v.lap_x[t] = -1;
             for (int k = c.tid; k < nk; k += c.nthr) v.lap_y[k] = -1;
             __syncthreads();
-            for (long e = c.tid; e < total; e += c.nthr) {
-                const int k = (int)(e / nt), t = (int)(e % nt);
+            for (int k = c.wave; k < nk; k += c.nwaves)
+            for (int t = c.lane; t < nt; t += WAVE) {
                 if (v.iou[k * ld + t] > cfg.iou_threshold) { v.lap_y[k] = t; v.lap_x[t] = k; }
             }
         } else {
@@ -751,8 +751,8 @@ __device__ inline void docs_step_stream(const DocsStepArgs& args, int s, int* s_
                 }
             }
             // final_cost = -(iou + angle_diff_cost + emb_cost)
-            for (long e = c.tid; e < total; e += c.nthr) {
-                const int k = (int)(e / nt), t = (int)(e % nt);
+            for (int k = c.wave; k < nk; k += c.nwaves)
+            for (int t = c.lane; t < nt; t += WAVE) {
                 double em = 0.0;
                 if (use_emb) {
                     const double raw = v.embc[k * ld + t];
@@ -792,10 +792,9 @@ __device__ inline void docs_step_stream(const DocsStepArgs& args, int s, int* s_
     // ---- OC-SORT only: BYTE association of the low-score detections with the predicted boxes of the unmatched tracks
     //      (ocsort.py:456-485); matched tracks take the detection, the rest stay unmatched (np.setdiff1d: ascending) ----
     if (cfg.use_byte && n_byte > 0 && n_ut > 0) {
-        const long total = (long)n_byte * n_ut;
         double mxi = -DOCS_INF;
-        for (long e = c.tid; e < total; e += c.nthr) {
-            const int a = (int)(e / n_ut), b = (int)(e % n_ut);
+        for (int a = c.wave; a < n_byte; a += c.nwaves)
+        for (int b = c.lane; b < n_ut; b += WAVE) {
             const float* df = v.dets + v.keep[nk + a] * DET_COLS;
             const double db[4] = {(double)df[0], (double)df[1], (double)df[2], (double)df[3]};
             const double io = iou_pair(db, v.trk_box + v.un_t[b] * 4);
@@ -836,10 +835,9 @@ __device__ inline void docs_step_stream(const DocsStepArgs& args, int s, int* s_
 
     // ---- second round: observation-centric recovery against the last observations (deepocsort.py:411-450) ----
     if (n_ud > 0 && n_ut > 0) {
-        const long total = (long)n_ud * n_ut;
         double mxi = -DOCS_INF;
-        for (long e = c.tid; e < total; e += c.nthr) {
-            const int a = (int)(e / n_ut), b = (int)(e % n_ut);
+        for (int a = c.wave; a < n_ud; a += c.nwaves)
+        for (int b = c.lane; b < n_ut; b += WAVE) {
             const float* df = v.dets + v.keep[v.un_d[a]] * DET_COLS;
             const double db[4] = {(double)df[0], (double)df[1], (double)df[2], (double)df[3]};
             const double io = iou_pair(db, v.last_obs + v.list[v.un_t[b]] * 5);
