@@ -1144,6 +1144,8 @@ __global__ void __launch_bounds__(512, 4) k_stem_resize_fused(const uint8_t* con
     const bool identity = r.w == REID_IN_W && r.h == REID_IN_H;
     const bool area2 = r.w == 2 * REID_IN_W && r.h == 2 * REID_IN_H;
     __syncthreads();
+    BM_PROF_DECL();
+    BM_PROF(0);
 
 #pragma unroll 1
     for (int band = 0; band < 8; ++band) {
@@ -1181,7 +1183,9 @@ __global__ void __launch_bounds__(512, 4) k_stem_resize_fused(const uint8_t* con
                 }
             }
         }
+        BM_PROF(1);
         __syncthreads();
+        BM_PROF(2);
         // ---- 2. resample the new rows into the ring ----
         if (staged && !identity && !area2) {
             // Bilinear fast path.  A thread owns one output column and a run of consecutive rows: the horizontal
@@ -1282,7 +1286,9 @@ __global__ void __launch_bounds__(512, 4) k_stem_resize_fused(const uint8_t* con
             }
             *reinterpret_cast<h4*>(ring + (pr % RING_ROWS) * RING_ROW_BYTES + (dx + 3) * 8) = px;
         }
+        BM_PROF(3);
         __syncthreads();
+        BM_PROF(4);
 #if BM_STEM_STREAM
         // ---- 3. conv rows + pooling: strip t (16 conv pixels), pooled rows oy0 .. oy0 + 3 ----
         {
@@ -1325,7 +1331,9 @@ __global__ void __launch_bounds__(512, 4) k_stem_resize_fused(const uint8_t* con
                     *reinterpret_cast<h4*>(yout + (long)p * 16 + g * 4) = to_h4(m[p4]);
                 }
             }
+            BM_PROF(5);
             __syncthreads();
+            BM_PROF(6);
             if (l16 == 0) {
 #pragma unroll
                 for (int p4 = 0; p4 < 4; ++p4) {
@@ -1374,7 +1382,9 @@ __global__ void __launch_bounds__(512, 4) k_stem_resize_fused(const uint8_t* con
         }
         __syncthreads();
 #endif
+        BM_PROF(7);
     }
+    BM_PROF_FLUSH();
 }
 
 // crop -> resize -> normalise into the stem's fp16 RGBX layout (interior only; the 3-pixel border and the

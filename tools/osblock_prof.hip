@@ -126,6 +126,22 @@ static void run_stem(int n, int iters) {
         if (ms < best) best = ms;
     }
     printf("stem_resize_fused: n=%d best %.3f ms\n", n, best);
+#ifdef BM_OSBLOCK_PROF
+    {   // phase clocks of the last launch (a -DBM_OSBLOCK_PROF build): shader-clock cycles per wave
+        unsigned long long zero[8] = {}, acc[8] = {};
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(bm::g_osblock_prof), zero, sizeof(zero)));
+        hipLaunchKernelGGL(bm::k_stem_resize_fused, dim3(n), dim3(512), bm::STEM2_LDS, 0, (const uint8_t* const*)d_frames, (const int*)d_cs,
+                           (const float*)d_boxes, 4, W, H, (const float*)d_lut, d_out, (const unsigned char*)d_w, (const int*)nullptr);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpyFromSymbol(acc, HIP_SYMBOL(bm::g_osblock_prof), sizeof(acc)));
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(bm::g_osblock_prof), zero, sizeof(zero)));
+        static const char* PH[8] = {"prologue", "stage rows", "barrier a", "resample", "barrier b", "conv+pool", "barrier c", "edge fix-up"};
+        const double waves = (double)n * 8;
+        double tot = 0; for (int k = 0; k < 8; ++k) tot += acc[k] / waves;
+        printf("stem_resize_fused phases, cycles per wave: total %.0f\n", tot);
+        for (int k = 0; k < 8; ++k) printf("    %-12s %9.0f  %5.1f%%\n", PH[k], acc[k] / waves, 100.0 * acc[k] / waves / tot);
+    }
+#endif
 }
 
 int main(int argc, char** argv) {
