@@ -162,8 +162,8 @@ def build_ss(sanitize: bool = False, threads: int = 64) -> Path:
 class EmuStrongSort:
     """The StrongSORT device kernels (strongsort_step.hpp) executed on CPU threads."""
 
-    def __init__(self, cfg: dict, cap=256, nd=64, dim=32, sanitize=False):
-        self.lib = ctypes.CDLL(str(build_ss(sanitize)))
+    def __init__(self, cfg: dict, cap=256, nd=64, dim=32, sanitize=False, threads=64):
+        self.lib = ctypes.CDLL(str(build_ss(sanitize, threads=threads)))
         self.lib.emu_ss_create.restype = ctypes.c_void_p
         self.lib.emu_ss_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         self.lib.emu_ss_update.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,

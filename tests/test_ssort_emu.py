@@ -12,10 +12,10 @@ from emu_util import EmuStrongSort, build_ss
 from oracle.strongsort import DEFAULTS, StrongSortOracle
 
 
-def _run(frames, dim, cap, nd, warps=None, sanitize=False, **kw):
+def _run(frames, dim, cap, nd, warps=None, sanitize=False, threads=64, **kw):
     cfg = dict(DEFAULTS)
     cfg.update(kw)
-    orc, emu = StrongSortOracle(**kw), EmuStrongSort(cfg, cap=cap, nd=nd, dim=dim, sanitize=sanitize)
+    orc, emu = StrongSortOracle(**kw), EmuStrongSort(cfg, cap=cap, nd=nd, dim=dim, sanitize=sanitize, threads=threads)
     try:
         for t, (d, e) in enumerate(frames):
             w = None if warps is None else warps[t]
@@ -46,6 +46,13 @@ def _run(frames, dim, cap, nd, warps=None, sanitize=False, **kw):
                                      (dict(max_cos_dist=0.4, max_iou_dist=0.9, mc_lambda=0.9, ema_alpha=0.8, min_conf=0.3), 3)])
 def test_emulated_strongsort_matches_oracle_stress(kw, seed):
     _run(stress_frames(45, seed=seed), 32, 128, 64, **kw)
+
+
+def test_emulated_strongsort_four_wavefronts():
+    """The same parity with a 256-thread workgroup (two scanning + two idle wavefronts in the assignment solver, the wave-0
+    replay of the set order next to waiting waves, wave-per-row cost build): the cross-wavefront paths of the frame step."""
+    frames = stress_frames(40, seed=9, max_objects=30)
+    _run(frames, 32, 128, 64, warps=camera_warps(len(frames), seed=9), threads=256)
 
 
 def test_emulated_strongsort_camera_update_and_set_order():
