@@ -82,25 +82,25 @@ DOCS_D = ("det_thresh", "iou_threshold", "inertia", "w_association_emb", "alpha_
 DOCS_I = ("max_age", "min_hits", "delta_t", "embedding_off", "aw_off", "use_byte")
 
 
-def build_docs(sanitize: bool = False) -> Path:
+def build_docs(sanitize: bool = False, threads: int = 64) -> Path:
     src = HERE / "emu_docs.cpp"
     csrc = HERE.parent.parent / "boxmot_amd" / "csrc"
     deps = [src, HERE / "hip_shim.hpp", csrc / "deepocsort_step.hpp", csrc / "block_prims.hpp", csrc / "kernel_macros.hpp",
             csrc / "botsort_types.hpp"]
-    out = HERE / ("libemu_docs_asan.so" if sanitize else "libemu_docs.so")
+    out = HERE / ("libemu_docs_asan.so" if sanitize else ("libemu_docs.so" if threads == 64 else f"libemu_docs_t{threads}.so"))
     if not out.exists() or any(d.stat().st_mtime > out.stat().st_mtime for d in deps):
         flags = ["-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-pthread"]
         if sanitize:
             flags += ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"]
-        subprocess.check_call(["g++", *flags, "-o", str(out), str(src)])
+        subprocess.check_call(["g++", *flags, f"-DEMU_NTHR={threads}", "-o", str(out), str(src)])
     return out
 
 
 class EmuDeepOcSort:
     """The DeepOCSORT device step (deepocsort_step.hpp) executed on CPU threads."""
 
-    def __init__(self, cfg: dict, cap=256, nd=64, dim=32, sanitize=False):
-        self.lib = ctypes.CDLL(str(build_docs(sanitize)))
+    def __init__(self, cfg: dict, cap=256, nd=64, dim=32, sanitize=False, threads=64):
+        self.lib = ctypes.CDLL(str(build_docs(sanitize, threads=threads)))
         self.lib.emu_docs_create.restype = ctypes.c_void_p
         self.lib.emu_docs_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         self.lib.emu_docs_update.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,

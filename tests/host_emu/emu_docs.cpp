@@ -14,7 +14,10 @@ EmuBlock* g_emu_block = nullptr;
 
 namespace {
 
-constexpr int NTHR = 64;
+#ifndef EMU_NTHR
+#define EMU_NTHR 64
+#endif
+constexpr int NTHR = EMU_NTHR;
 
 struct HostAlloc {
     std::vector<void*> owned;

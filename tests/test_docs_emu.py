@@ -9,10 +9,10 @@ from emu_util import EmuDeepOcSort
 from oracle.deepocsort import DEFAULTS, DeepOcSortOracle
 
 
-def _run(frames, dim, cap, nd, sanitize=False, lap_rule="jv", warps=None, **kw):
+def _run(frames, dim, cap, nd, sanitize=False, lap_rule="jv", warps=None, threads=64, **kw):
     cfg = dict(DEFAULTS)
     cfg.update(kw)
-    orc, emu = DeepOcSortOracle(lap_rule=lap_rule, **kw), EmuDeepOcSort(cfg, cap=cap, nd=nd, dim=dim, sanitize=sanitize)
+    orc, emu = DeepOcSortOracle(lap_rule=lap_rule, **kw), EmuDeepOcSort(cfg, cap=cap, nd=nd, dim=dim, sanitize=sanitize, threads=threads)
     try:
         for t, (d, e) in enumerate(frames):
             w = None if warps is None else warps[t]
@@ -43,6 +43,12 @@ def _run(frames, dim, cap, nd, sanitize=False, lap_rule="jv", warps=None, **kw):
                                      (dict(embedding_off=True), 5)])
 def test_emulated_deepocsort_matches_oracle_stress(kw, seed):
     _run(stress_frames(60, seed=seed), 32, 128, 64, **kw)
+
+
+def test_emulated_deepocsort_four_wavefronts():
+    """The same parity with a 256-thread workgroup: the wave-per-row cost loops, the cross-wavefront reductions and the solver
+    with more than one wavefront."""
+    _run(stress_frames(50, seed=13, max_objects=30), 32, 128, 64, lap_rule="lowest_index", threads=256)
 
 
 @pytest.mark.parametrize("seed", [22, 24, 28])
