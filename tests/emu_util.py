@@ -15,25 +15,26 @@ CFG_D = ("track_high_thresh", "track_low_thresh", "new_track_thresh", "match_thr
 CFG_I = ("fuse_first_associate", "with_reid", "frame_rate", "track_buffer", "removed_stracks_buffer", "kind")
 
 
-def build(sanitize: bool = False, dense: bool = False) -> Path:
+def build(sanitize: bool = False, dense: bool = False, threads: int = 64) -> Path:
     src = HERE / "emu_botsort.cpp"
     deps = [src, HERE / "hip_shim.hpp"] + list((HERE.parent.parent / "boxmot_amd" / "csrc").glob("botsort_*.hpp")) \
         + [HERE.parent.parent / "boxmot_amd" / "csrc" / "block_prims.hpp",
            HERE.parent.parent / "boxmot_amd" / "csrc" / "kernel_macros.hpp"]
-    out = HERE / ("libemu_botsort_asan.so" if sanitize else ("libemu_botsort_dense.so" if dense else "libemu_botsort.so"))
+    out = HERE / ("libemu_botsort_asan.so" if sanitize else ("libemu_botsort_dense.so" if dense else
+                                                              ("libemu_botsort.so" if threads == 64 else f"libemu_botsort_t{threads}.so")))
     if not out.exists() or any(d.stat().st_mtime > out.stat().st_mtime for d in deps):
         flags = ["-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-pthread"]
         if sanitize:
             flags += ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"]
         if dense:
             flags += ["-DBM_SPARSE_MAX=0"]      # force the dense LDS-tiled cosine path
-        subprocess.check_call(["g++", *flags, "-o", str(out), str(src)])
+        subprocess.check_call(["g++", *flags, f"-DEMU_NTHR={threads}", "-o", str(out), str(src)])
     return out
 
 
 class EmuBotSort:
-    def __init__(self, cfg: dict, cap=256, nd=64, dim=32, sanitize=False, dense=False):
-        self.lib = ctypes.CDLL(str(build(sanitize, dense)))
+    def __init__(self, cfg: dict, cap=256, nd=64, dim=32, sanitize=False, dense=False, threads=64):
+        self.lib = ctypes.CDLL(str(build(sanitize, dense, threads=threads)))
         self.lib.emu_create.restype = ctypes.c_void_p
         self.lib.emu_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         self.lib.emu_update.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,

@@ -15,7 +15,10 @@ EmuBlock* g_emu_block = nullptr;
 
 namespace {
 
-constexpr int NTHR = 64;   // one emulated wavefront per workgroup keeps barrier cost low
+#ifndef EMU_NTHR
+#define EMU_NTHR 64   // one emulated wavefront per workgroup keeps barrier cost low
+#endif
+constexpr int NTHR = EMU_NTHR;
 
 struct HostAlloc {
     std::vector<void*> owned;

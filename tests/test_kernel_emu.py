@@ -10,10 +10,10 @@ from emu_util import EmuBotSort
 from oracle.botsort import DEFAULTS, BotSortOracle
 
 
-def _run(frames, dim, cap, nd, sanitize=False, dense=False, warps=None, **kw):
+def _run(frames, dim, cap, nd, sanitize=False, dense=False, warps=None, threads=64, **kw):
     cfg = dict(DEFAULTS)
     cfg.update(kw)
-    orc, emu = BotSortOracle(**kw), EmuBotSort(cfg, cap=cap, nd=nd, dim=dim, sanitize=sanitize, dense=dense)
+    orc, emu = BotSortOracle(**kw), EmuBotSort(cfg, cap=cap, nd=nd, dim=dim, sanitize=sanitize, dense=dense, threads=threads)
     try:
         for t, (d, e) in enumerate(frames):
             w = None if warps is None else warps[t]
@@ -40,6 +40,12 @@ def _run(frames, dim, cap, nd, sanitize=False, dense=False, warps=None, **kw):
                                 dict(with_reid=False)])
 def test_emulated_kernel_matches_oracle_stress(kw):
     _run(stress_frames(80, seed=7), 32, 128, 64, **kw)
+
+
+def test_emulated_kernel_four_wavefronts():
+    """The same parity with a 256-thread workgroup: cross-wavefront reductions, stream compaction and the assignment solver
+    with more than one wavefront."""
+    _run(stress_frames(50, seed=17), 32, 128, 64, threads=256)
 
 
 def test_emulated_kernel_applies_camera_warp():
