@@ -20,9 +20,19 @@ Extra objects on the JSON line (N = 1): `roofline`, `cpu_baseline` (the contract
 CLIP-ReID ViT-B/16, 256 x 1024, 4K) through tools/config_bench.py, each with its ReID roofline fraction and an embedding parity gate;
 they are never part of `value`.
 
-N > 1: launched by torch.distributed.run, one rank per GPU; streams are sharded by rank with no
-data-path collective; the per-frame result rows are gathered to rank 0 once after the timed loop
-(RCCL all_gather of a few hundred KB).
+N > 1: one rank per GPU over torch.distributed (backend "nccl" = RCCL).  Either the driver launches the ranks
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`: RANK / LOCAL_RANK / WORLD_SIZE in the
+environment) or, when `--gpus N` is given without WORLD_SIZE, bench.py launches them itself (the same torch.distributed.run
+command on 127.0.0.1 with a free port) and relays rank 0's JSON line.  Streams are sharded by rank (rank r owns the global
+streams r*S .. r*S+S-1, S = --streams per GPU: weak scaling) with no data-path collective; the timed region is bracketed by a
+barrier + device synchronisation on both sides and the elapsed time is the MAX over ranks (all_reduce); the per-frame result
+rows are gathered to rank 0 once after the timed loop (`gather_results`: RCCL all_gather of a few hundred KB), timed and
+reported separately as `gather_ms`.  Rank 0 keeps the stream-0 id parity gate at every N; the CPU timing baseline runs at N = 1
+only (the contract).
+
+`--stub-tracker --backend gloo` is a TEST seam (tests/test_bench_dist.py): the same launch / sharding / barrier / all_reduce /
+gather / JSON code runs on CPU processes with a trivial stand-in for the device handle, so the N > 1 control flow is covered
+where no GPU exists.  Its line says `"data": "stub"`; it measures nothing.
 """
 from __future__ import annotations
 
@@ -43,12 +53,14 @@ FLOP_PER_CROP = 2 * 82_314_880          # OSNet x0.25 forward, BASELINE.md secti
 # HBM bytes per crop of the fused ReID launch set: read from the committed rocprofv3 FETCH_SIZE / WRITE_SIZE summary named
 # here (separate --pmc passes, gfx950 FETCH correction applied by profiles/summarize_pmc.py) -- counters cannot be collected
 # inside a timed run, so the line carries the profile's figure and says which file it came from
-TRAFFIC_PROFILES = ("profiles/r2_pmc_traffic.txt", "profiles/r1h_pmc_traffic.txt")
+# one committed profile per kernel family (mode): fused fp32-grade (2), fused fp16 (1)
+TRAFFIC_PROFILES = {2: ("profiles/r3_pmc_traffic_hp.txt",),
+                    1: ("profiles/r3_pmc_traffic.txt", "profiles/r2_pmc_traffic.txt", "profiles/r1h_pmc_traffic.txt")}
 
 
-def profile_traffic_bytes_per_crop():
+def profile_traffic_bytes_per_crop(mode):
     import re
-    for rel in TRAFFIC_PROFILES:
+    for rel in TRAFFIC_PROFILES.get(mode, ()):
         f = ROOT / rel
         if f.exists():
             m = re.search(r"->\s*([0-9.]+)\s*KB per crop", f.read_text())
@@ -57,11 +69,16 @@ def profile_traffic_bytes_per_crop():
     return None, None
 
 
-PEAK_TFLOPS = {0: 157.3, 1: 2500.0}     # dense MFMA peak of the dtype the ReID kernels compute in (fp32 / fp16)
-DTYPE = {0: "f32", 1: "f16"}
+# Dense matrix-pipe peak the ReID region is priced against, per kernel family.  Mode 2 (fp32-grade fused kernels) computes its wide
+# 1x1 convolutions and the stem as fp16 hi/lo operand pairs (three fp16 MFMAs per product tile) and the LightConv chains on the
+# fp32 matrix pipe; it is priced against the fp16 peak like mode 1 -- the stricter of the two peaks it touches -- on ALGORITHMIC flops
+# (the operand-splitting MFMAs are overhead, not work).
+PEAK_TFLOPS = {0: 157.3, 1: 2500.0, 2: 2500.0}
+DTYPE = {0: "f32", 1: "f16", 2: "f32 (fp16 hi+lo operand pairs / fp32 MFMA, fp32 accumulate)"}
+REID_KERNELS = {0: "per-layer fp32 (v1)", 1: "fused fp16 MFMA", 2: "fused fp32-grade (split-fp16 + fp32 MFMA)"}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--groups", type=int, default=1,
@@ -73,13 +90,16 @@ def parse():
     ap.add_argument("--mode", choices=("reid", "embs"), default="reid",
                     help="reid: ReID inside update (headline, M2); embs: embeddings supplied (tracker math only, M1)")
     ap.add_argument("--reid-mode", type=int, default=int(os.environ.get("BOXMOT_REID_MODE", "1")),
-                    help="0: per-layer fp32 kernels, 1: fused fp16 MFMA kernels (default)")
+                    help="0: per-layer fp32 kernels, 1: fused fp16 MFMA kernels, 2: fused fp32-grade kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-m1", action="store_true", help="skip the tracker-math-only (embeddings supplied) side measurement")
     ap.add_argument("--no-side-configs", action="store_true",
                     help="skip the short side measurements of BASELINE.json configurations 3 and 5 (tools/config_bench.py)")
     ap.add_argument("--cpu-frames", type=int, default=10)
-    return ap.parse_args()
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--stub-tracker", action="store_true",
+                    help="TEST ONLY: run the N > 1 control flow on CPU with a stand-in for the device handle (no measurement)")
+    return ap.parse_args(argv)
 
 
 def log(msg):
@@ -173,59 +193,222 @@ def m1_tracker_only(kw, dev, rank):
             "kernel": "botsort_step_kernel", "algorithmic_bytes_per_frame": 1.68e6, "hbm_GBps": gbs, "hbm_frac_of_8TBps": gbs / 8000.0}
 
 
-def main():
-    a = parse()
+def side_configs():
+    """BASELINE.json's other single-GPU configurations, measured briefly on the same box (never part of `value`): ReID inside update,
+    frames and detections resident in HBM, each with an embedding gate and an id gate against the oracle tracker."""
+    sys.path.insert(0, str(ROOT / "tools"))
+    import config_bench
+    side = {}
+    for key, kwargs in (("config3", dict(config="c3", streams=8, steps=16, warmup=6, check_frames=8)),
+                        ("config5", dict(config="c5", streams=2, steps=6, warmup=3, check_frames=8))):
+        try:
+            side[key] = config_bench.run(**kwargs)
+            log(f"side line {key}: {side[key]['frames_per_s']:.1f} frames/s")
+        except Exception as exc:                    # a side line never takes the headline down
+            side[key] = {"error": f"{type(exc).__name__}: {exc}"}
+    return side
+
+
+def alt_family_line(kw, sd, dev, reid_mode, S=256, W=10, K=40):
+    """The same workload through the OTHER fused kernel family (short run, same inputs, same handle type): printed next to the headline so
+    that the cost of the precision the headline family carries is on the line."""
+    import torch
+
+    from boxmot_amd.scenario import Scenario
+    from boxmot_amd.streams import MultiStreamBotSort
+    nd, T = N_TRACKS, W + K
+    ms = MultiStreamBotSort(S, max_tracks=2 * N_TRACKS, max_dets=nd, emb_dim=EMB_DIM, reid_weights=sd, **kw)
+    ms.set_reid_mode(reid_mode)
+    dets_h = np.zeros((T, S, nd, 6), dtype=np.float32)
+    cnt_h = np.zeros((T, S), dtype=np.int32)
+    frames_h = np.zeros((S, HEIGHT, WIDTH, 3), dtype=np.uint8)
+    for s in range(S):
+        sc = Scenario(N_DETS, N_TRACKS, WIDTH, HEIGHT, EMB_DIM, stream=s, random_image=True)
+        frames_h[s] = sc.image
+        for t in range(T):
+            d, _ = sc.frame(t, with_embs=False)
+            dets_h[t, s, : len(d)] = d
+            cnt_h[t, s] = len(d)
+    d_dets, d_cnt, d_frames = (torch.from_numpy(x).to(dev) for x in (dets_h, cnt_h, frames_h))
+    d_ptrs = torch.tensor([d_frames[s].data_ptr() for s in range(S)], dtype=torch.int64, device=dev)
+    d_out = torch.zeros((S, nd, 8), dtype=torch.float32, device=dev)
+    d_out_n = torch.zeros(S, dtype=torch.int32, device=dev)
+    step = lambda t: ms.step_device(d_dets[t].data_ptr(), d_cnt[t].data_ptr(), None, d_ptrs.data_ptr(), HEIGHT, WIDTH,
+                                    d_out.data_ptr(), d_out_n.data_ptr())
+    for t in range(W):
+        step(t)
+    ms.synchronize()
+    ms.reid_kernel_ms()
+    t0 = time.perf_counter()
+    for t in range(W, T):
+        step(t)
+    ms.synchronize()
+    dt = time.perf_counter() - t0
+    r_ms, r_n = ms.reid_kernel_ms()
+    assert (ms.status() == 0).all()
+    ms.close()
+    crops = int((dets_h[W:, :, :, 4] > kw["track_high_thresh"]).sum())
+    tfl = crops * FLOP_PER_CROP / (r_ms * 1e-3) / 1e12 if r_ms > 0 else None
+    out = {"reid_kernels": REID_KERNELS[reid_mode], "dtype": DTYPE[reid_mode], "frames_per_s": S * K / dt, "streams": S, "steps": K,
+           "warmup": W, "ms_per_step": 1000.0 * dt / K, "reid_launch_ms": r_ms / max(r_n, 1), "reid_tflops": tfl,
+           "frac_of_peak": tfl / PEAK_TFLOPS[reid_mode] if tfl else None}
+    out.update(reid_parity_gates(sd, reid_mode))
+    return out
+
+
+def reid_parity_gates(sd, reid_mode):
+    """Embeddings of a kernel family against the fp32 oracle (north_star tolerance 1e-3): on the benchmark's weights (the reference's
+    own random init, where BatchNorm is the identity) AND on BatchNorm-calibrated random weights of three seeds (non-trivial
+    running statistics and affine terms: the case that tells fp32-grade arithmetic from fp16 operands)."""
+    from boxmot_amd.reid import HipReID
+    from boxmot_amd.reid_weights import random_osnet_state_dict
+    from boxmot_amd.scenario import Scenario
+    from oracle.osnet import OracleReID
+    sc0 = Scenario(N_DETS, N_TRACKS, WIDTH, HEIGHT, EMB_DIM, stream=0, random_image=True)
+    boxes = sc0.frame(0, with_embs=False)[0][:32, :4]
+    out = {}
+    hr = HipReID(sd, max_crops=32, mode=reid_mode)
+    out["reid_max_abs_err_vs_fp32_oracle"] = float(np.abs(hr.get_features(boxes, sc0.image) - OracleReID(sd).get_features(boxes, sc0.image)).max())
+    hr.close()
+    errs = []
+    for seed in (0, 1, 2):
+        sdc = random_osnet_state_dict("osnet_x0_25", seed=seed)
+        hr = HipReID(sdc, max_crops=16, mode=reid_mode)
+        errs.append(float(np.abs(hr.get_features(boxes[:16], sc0.image) - OracleReID(sdc).get_features(boxes[:16], sc0.image)).max()))
+        hr.close()
+    out["reid_max_abs_err_vs_fp32_oracle_bn_calibrated_seeds012"] = errs
+    out["reid_within_1e-3_on_bn_calibrated_weights"] = bool(max(errs) < 1e-3)
+    return out
+
+
+class StubStreams:
+    """TEST-ONLY stand-in for MultiStreamBotSort (--stub-tracker): same call surface over host tensors, every detection becomes
+    one output row [box, id = index + 1, conf, cls, index].  It exists so that the launch / sharding / barrier / all_reduce /
+    gather / JSON code of this file runs under gloo on CPU processes; nothing it does is a measurement or a product path."""
+
+    def __init__(self, n_streams, max_dets):
+        self.S, self.nd = n_streams, max_dets
+        self._t0 = 0.0
+
+    @staticmethod
+    def _view(ptr, shape, dtype):
+        import ctypes
+        n = int(np.prod(shape))
+        buf = (ctypes.c_byte * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+        return np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
+
+    def step_device(self, d_dets, d_cnt, d_embs, d_frames, rows, cols, d_out, d_out_n):
+        dets = self._view(d_dets, (self.S, self.nd, 6), np.float32)
+        cnt = self._view(d_cnt, (self.S,), np.int32)
+        out = self._view(d_out, (self.S, self.nd, 8), np.float32)
+        out_n = self._view(d_out_n, (self.S,), np.int32)
+        idx = np.arange(self.nd, dtype=np.float32)
+        out[:, :, :4] = dets[:, :, :4]
+        out[:, :, 4] = idx + 1
+        out[:, :, 5:7] = dets[:, :, 4:6]
+        out[:, :, 7] = idx
+        out_n[:] = cnt
+
+    def set_reid_mode(self, mode): pass
+    def synchronize(self): pass
+    def timer_start(self): self._t0 = time.perf_counter()
+    def timer_stop_ms(self): return 1000.0 * (time.perf_counter() - self._t0)
+    def reid_kernel_ms(self): return 0.0, 0
+    def status(self): return np.zeros(self.S, dtype=np.int32)
+    def close(self): pass
+
+
+def self_launch(a) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves with the command the driver uses
+    (torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1) and relay their output."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    log(f"--gpus {a.gpus} without WORLD_SIZE: launching {a.gpus} ranks: {' '.join(cmd[1:8])} ...")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this host driver
+    return subprocess.call(cmd, env=env)
+
+
+def main(argv=None):
+    a = parse(argv)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(a)
     import torch
     import torch.distributed as dist
 
-    import __graft_entry__ as g
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if rank == 0:
-        g.build()
-    if world > 1:
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl")
-        dist.barrier()
+    if world != a.gpus:
+        log(f"rank {rank}: --gpus {a.gpus} but WORLD_SIZE {world}: the launcher's world size is what runs")
+    stub = bool(a.stub_tracker)
+    if stub:
+        # no device, no extension: control flow only
+        if world > 1:
+            dist.init_process_group(a.backend)
+            dist.barrier()
+        dev = torch.device("cpu")
+        dev_sync = lambda: None
     else:
-        torch.cuda.set_device(0)
-    if rank != 0:
-        g.build()
-    dev = torch.device("cuda", local if world > 1 else 0)
+        import __graft_entry__ as g
+        if rank == 0:
+            g.build()           # rank 0 compiles (or verifies the recorded source hash); the others wait at the barrier and reuse
+        if world > 1:
+            torch.cuda.set_device(local)
+            dist.init_process_group(a.backend)
+            dist.barrier()
+        else:
+            torch.cuda.set_device(0)
+        if rank != 0:
+            g.build()
+        dev = torch.device("cuda", local if world > 1 else 0)
+        dev_sync = torch.cuda.synchronize
 
-    from boxmot_amd.reid_weights import reference_init_state_dict
     from boxmot_amd.scenario import Scenario
-    from boxmot_amd.streams import MultiStreamBotSort
     from boxmot_amd.tracker_zoo import BOTSORT_YAML_DEFAULTS
 
     S, K, W = a.streams, a.steps, a.warmup
     T = W + K
-    log(f"rank {rank}/{world}: S={S} K={K} W={W} mode={a.mode}")
+    log(f"rank {rank}/{world}: S={S} K={K} W={W} mode={a.mode}" + (" [stub tracker: control-flow test]" if stub else ""))
     kw = {k: v for k, v in BOTSORT_YAML_DEFAULTS.items() if k not in ("use_cmc", "cmc_method")}
     torch.set_num_threads(min(os.cpu_count() or 1, 16))
-    sd = reference_init_state_dict("osnet_x0_25", seed=0)   # random init as OSNet._init_params does it
-    log("weights generated")
     nd = N_TRACKS                       # the 3 confirmation frames show every object
     G = max(1, min(a.groups, S))
     while S % G:
         G -= 1
     Sg = S // G
-    groups = [MultiStreamBotSort(Sg, max_tracks=2 * N_TRACKS, max_dets=nd, emb_dim=EMB_DIM,
-                                 reid_weights=sd if a.mode == "reid" else None, **kw) for _ in range(G)]
+    sd = None
+    if stub:
+        groups = [StubStreams(Sg, nd) for _ in range(G)]
+    else:
+        from boxmot_amd.reid_weights import reference_init_state_dict
+        from boxmot_amd.streams import MultiStreamBotSort
+        sd = reference_init_state_dict("osnet_x0_25", seed=0)   # random init as OSNet._init_params does it
+        log("weights generated")
+        groups = [MultiStreamBotSort(Sg, max_tracks=2 * N_TRACKS, max_dets=nd, emb_dim=EMB_DIM,
+                                     reid_weights=sd if a.mode == "reid" else None, **kw) for _ in range(G)]
     ms = groups[0]
     if a.mode == "reid":
         for m in groups:
             m.set_reid_mode(a.reid_mode)
 
-    # ---- synthetic inputs, resident in HBM before timing ----
+    # ---- synthetic inputs, resident in HBM before timing: rank r owns the global streams r*S .. r*S + S - 1 ----
+    fh, fw = (8, 8) if stub else (HEIGHT, WIDTH)            # the stub never reads pixels
     dets_h = np.zeros((T, S, nd, 6), dtype=np.float32)
     cnt_h = np.zeros((T, S), dtype=np.int32)
     embs_h = np.zeros((T, S, nd, EMB_DIM), dtype=np.float32) if a.mode == "embs" else None
-    frames_h = np.zeros((S, HEIGHT, WIDTH, 3), dtype=np.uint8)
+    frames_h = np.zeros((S, fh, fw, 3), dtype=np.uint8)
     for s in range(S):
-        sc = Scenario(N_DETS, N_TRACKS, WIDTH, HEIGHT, EMB_DIM, stream=rank * S + s, random_image=a.mode == "reid")
-        frames_h[s] = sc.image
+        sc = Scenario(N_DETS, N_TRACKS, WIDTH, HEIGHT, EMB_DIM, stream=rank * S + s, random_image=a.mode == "reid" and not stub)
+        if not stub:
+            frames_h[s] = sc.image
         for t in range(T):
             d, e = sc.frame(t, with_embs=(a.mode != "reid"))
             dets_h[t, s, : len(d)] = d
@@ -239,7 +422,7 @@ def main():
     d_ptrs = torch.tensor([d_frames[s].data_ptr() for s in range(S)], dtype=torch.int64, device=dev)
     d_out = torch.zeros((T, S, nd, 8), dtype=torch.float32, device=dev)
     d_out_n = torch.zeros((T, S), dtype=torch.int32, device=dev)
-    torch.cuda.synchronize()
+    dev_sync()
     log("inputs resident on the device")
 
     def step(t):
@@ -257,7 +440,8 @@ def main():
     log("warm-up done")
     for m in groups:
         m.reid_kernel_ms()              # drop warm-up timings
-    torch.cuda.synchronize()
+    # ---- the timed region: barrier + device sync on both sides, exactly K steps, MAX over ranks ----
+    dev_sync()
     if world > 1:
         dist.barrier()
     ms.timer_start()
@@ -267,7 +451,7 @@ def main():
     dev_ms = ms.timer_stop_ms()
     for m in groups:
         m.synchronize()
-    torch.cuda.synchronize()
+    dev_sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
@@ -284,11 +468,24 @@ def main():
         reid_ms += r_ms
         reid_launches += r_n
 
-    # ---- result gather (the only collective of the path), after the timed loop ----
+    # ---- result gather (the only collective of the path), after the timed loop; timed on its own ----
     out_h, out_n_h = d_out.cpu().numpy(), d_out_n.cpu().numpy()
+    gather_ms, gathered_ok = None, None
     if world > 1:
         from boxmot_amd.streams import gather_results
-        gather_results(d_out[W:].transpose(0, 1).contiguous(), d_out_n[W:].transpose(0, 1).contiguous(), dst=0)
+        send_rows = d_out[W:].transpose(0, 1).contiguous()           # (S, K, nd, 8)
+        send_cnt = d_out_n[W:].transpose(0, 1).contiguous()
+        dev_sync()
+        dist.barrier()
+        tg = time.perf_counter()
+        g_rows, g_cnt = gather_results(send_rows, send_cnt, dst=0)
+        dev_sync()
+        gather_ms = 1000.0 * (time.perf_counter() - tg)
+        if rank == 0:
+            # every rank's block arrived in rank order with the row counts its scenario implies, and rank 0's own block is intact
+            gathered_ok = len(g_rows) == world and all(tuple(r.shape) == tuple(send_rows.shape) for r in g_rows) \
+                and bool(torch.equal(g_rows[0], send_rows)) and bool(torch.equal(g_cnt[0], send_cnt)) \
+                and all(int(c.sum()) > 0 for c in g_cnt)
 
     if rank == 0:
         total_frames = world * S * K
@@ -298,17 +495,25 @@ def main():
             "metric": "tracker frames/sec (64 dets x 256 tracks, 1080p)", "value": fps, "unit": "frames/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1000.0 * elapsed / K,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": DTYPE[a.reid_mode] if a.mode == "reid" else "f64", "data": "synthetic",
+            "dtype": DTYPE[a.reid_mode] if a.mode == "reid" else "f64", "data": "stub" if stub else "synthetic",
             "config": {"workload": "BoT-SORT + OSNet_x0_25 ReID, 64 dets x 256 tracks, 1080p"
                                    if a.mode == "reid" else "BoT-SORT tracker math only (embeddings supplied), 64 dets x 256 tracks",
-                       "streams_per_gpu": S, "stream_groups": G, "mode": "M2 reid-in-update" if a.mode == "reid" else "M1 embs-supplied",
-                       "reid_kernels": {0: "per-layer fp32 (v1)", 1: "fused fp16 MFMA"}[a.reid_mode] if a.mode == "reid" else None,
+                       "streams_per_gpu": S, "streams_total": world * S, "stream_groups": G,
+                       "parallelism": f"{world} x {S} independent streams, sharded by rank, no data-path collective",
+                       "mode": "M2 reid-in-update" if a.mode == "reid" else "M1 embs-supplied",
+                       "reid_kernels": REID_KERNELS[a.reid_mode] if a.mode == "reid" else None,
                        "tracker_params": "botsort.yaml defaults, use_cmc=False", "weights": "random-init OSNet-x0.25 (reference _init_params scheme, seed 0)",
                        "device_ms_timed_region": dev_ms},
         }
-        if a.mode == "reid" and reid_ms > 0:
+        if world > 1:
+            res["gather_ms"] = gather_ms
+            res["config"]["gather"] = {"backend": a.backend, "bytes_per_rank": int(send_rows.numel() * 4 + send_cnt.numel() * 4),
+                                       "complete_on_rank0": gathered_ok}
+        if stub:
+            pass                                            # control-flow test: nothing below is a measurement
+        elif a.mode == "reid" and reid_ms > 0:
             tflops = n_first * FLOP_PER_CROP / (reid_ms * 1e-3) / 1e12
-            per_crop, traffic_src = profile_traffic_bytes_per_crop() if a.reid_mode == 1 else (None, None)
+            per_crop, traffic_src = profile_traffic_bytes_per_crop(a.reid_mode)
             res["roofline"] = {"bound": "mfma", "achieved": tflops, "peak": PEAK_TFLOPS[a.reid_mode], "unit": "TFLOP/s",
                                "frac": tflops / PEAK_TFLOPS[a.reid_mode],
                                "traffic": per_crop * n_first / max(reid_launches, 1) if per_crop else None,
@@ -320,50 +525,37 @@ def main():
             gbs = total_frames / world * bytes_per_frame / (dev_ms * 1e-3) / 1e9
             res["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
                                "traffic": None, "kernel": "botsort_step_kernel"}
+        for m in groups:
+            m.close()
+        groups = []
+        if stub:
+            a.no_m1 = a.no_side_configs = a.no_cpu_baseline = True
         if world == 1 and a.mode == "reid" and not a.no_m1:
-            for m in groups:
-                m.close()
-            groups = []
             res["tracker_math_m1"] = m1_tracker_only(kw, dev, rank)
         if world == 1 and a.mode == "reid" and not a.no_side_configs:
-            # BASELINE.json's other single-GPU configurations, measured briefly on the same box (not part of `value`): ReID inside
-            # update, frames and detections resident in HBM, parity gates against the oracles
-            sys.path.insert(0, str(Path(__file__).resolve().parent / "tools"))
-            import config_bench
-            side = {}
-            for key, kwargs in (("config3", dict(config="c3", streams=8, steps=16, warmup=6, check_frames=0)),
-                                ("config5", dict(config="c5", streams=2, steps=6, warmup=3, check_frames=0))):
-                try:
-                    side[key] = config_bench.run(**kwargs)
-                    log(f"side line {key}: {side[key]['frames_per_s']:.1f} frames/s")
-                except Exception as exc:                    # a side line never takes the headline down
-                    side[key] = {"error": f"{type(exc).__name__}: {exc}"}
-            res["other_configs"] = side
-        if not a.no_cpu_baseline and world == 1:
-            cb, rows = cpu_baseline(sd, a.mode, a.cpu_frames)
-            res["cpu_baseline"] = cb
-            # parity gate printed with the row: ids / det_ind / row order of stream 0 vs the oracle
+            res["other_configs"] = side_configs()
+        if world == 1 and a.mode == "reid" and not a.no_side_configs and a.reid_mode != 1:
+            res["fp16_family_line"] = alt_family_line(kw, sd, dev, 1)
+        if not a.no_cpu_baseline:
+            # the oracle on stream 0: at N = 1 timed as the CPU baseline (the contract); at every N the id parity gate
+            cb, rows = cpu_baseline(sd, a.mode, a.cpu_frames if world == 1 else min(a.cpu_frames, 4))
+            if world == 1:
+                res["cpu_baseline"] = cb
             ok = True
             for t in range(min(len(rows), T)):
                 got = out_h[t, 0, : out_n_h[t, 0]]
                 ok &= got.shape == rows[t].shape and bool(np.array_equal(got[:, 4:], rows[t][:, 4:]))
             res["config"]["parity_ids_exact_vs_oracle_stream0"] = bool(ok)
             if a.mode == "reid":
-                # embeddings of the benchmark kernels vs the fp32 oracle on stream 0's steady-state crops
-                from boxmot_amd.reid import HipReID
-                from oracle.osnet import OracleReID
-                sc0 = Scenario(N_DETS, N_TRACKS, WIDTH, HEIGHT, EMB_DIM, stream=0, random_image=True)
-                boxes = sc0.frame(0, with_embs=False)[0][:32, :4]
-                hr = HipReID(sd, max_crops=32, mode=a.reid_mode)
-                err = float(np.abs(hr.get_features(boxes, sc0.image) - OracleReID(sd).get_features(boxes, sc0.image)).max())
-                hr.close()
-                res["config"]["reid_max_abs_err_vs_fp32_oracle"] = err
+                res["config"].update(reid_parity_gates(sd, a.reid_mode))
         print(json.dumps(res))
     for m in groups:
         m.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

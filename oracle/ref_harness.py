@@ -128,6 +128,24 @@ def load_strongsort():
     return StrongSort
 
 
+def load_engine_callers():
+    """The reference's two per-frame tracker call sites, imported unmodified: ``TrackerRuntime``
+    (boxmot/engine/tracking/runtime.py:15-128) and ``Results`` (its ``_run_tracker``, engine/tracking/results.py:467-496).
+    Their import chain reaches ``boxmot.reid.core`` -> the CLIP backbone's ``torchvision.transforms`` names (clip.py:11), which are
+    only referenced inside functions the callers never run: an empty stand-in module with those names is injected."""
+    install_standins()
+    if "torchvision" not in sys.modules:
+        tv, tvt = types.ModuleType("torchvision"), types.ModuleType("torchvision.transforms")
+        for name in ("CenterCrop", "Compose", "Normalize", "Resize", "ToTensor", "InterpolationMode"):
+            setattr(tvt, name, type(name, (), {"BICUBIC": 3}))
+        tv.transforms = tvt
+        sys.modules["torchvision"], sys.modules["torchvision.transforms"] = tv, tvt
+    from boxmot.engine.tracking.results import Results
+    from boxmot.engine.tracking.runtime import TrackerRuntime
+
+    return TrackerRuntime, Results
+
+
 class IdentityCMC:
     """Stands where StrongSort's unconditional ECC object stands (strongsort.py:67): no camera motion."""
 

@@ -1,0 +1,83 @@
+"""The reference's OWN per-frame callers driving a boxmot_amd tracker unchanged (build container only: needs /root/reference).
+
+``TrackerRuntime`` (boxmot/engine/tracking/runtime.py:15-128) and ``Results._run_tracker`` (boxmot/engine/tracking/results.py:467-496)
+are imported from the reference tree and handed ``boxmot_amd.BotSort`` -- the real host class; its C-ABI calls are answered by the
+emulated device step (tests/emu_lib.py: botsort_step.hpp on CPU threads) because this container has no GPU.  The same callers
+drive the reference's own ``BotSort`` beside it: rows must agree frame by frame (ids / conf / cls / det_ind exact, boxes to 1e-3).
+The package carries no re-typed copy of these callers; a drop-in is shown by the originals accepting it."""
+import logging
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+from oracle import ref_harness
+
+pytestmark = pytest.mark.skipif(not ref_harness.reference_available(), reason="/root/reference is not mounted")
+
+
+@pytest.fixture()
+def emulated_abi(monkeypatch):
+    from boxmot_amd import _lib
+    from emu_lib import EmuHipLib
+    lib = EmuHipLib()
+    monkeypatch.setattr(_lib, "load", lambda: lib)
+    monkeypatch.setattr(_lib, "last_error", lambda: lib.boxmot_hip_last_error().decode())
+    return lib
+
+
+def _pair(**kw):
+    from boxmot_amd.botsort import BotSort as HipBotSort
+    RefBotSort = ref_harness.load_botsort()
+    ours = HipBotSort(use_cmc=False, max_tracks=128, max_dets=64, emb_dim=32, **kw)
+    ref = RefBotSort(reid_model=None, use_cmc=False, **({"with_reid": True} | kw))
+    return ours, ref
+
+
+def _same(a, b, t):
+    a, b = np.asarray(a, dtype=np.float32).reshape(-1, 8), np.asarray(b, dtype=np.float32).reshape(-1, 8)
+    assert a.shape == b.shape, (t, a.shape, b.shape)
+    assert np.array_equal(a[:, 4:], b[:, 4:]), t
+    assert np.allclose(a[:, :4], b[:, :4], rtol=0, atol=1e-3), t
+
+
+def test_reference_tracker_runtime_drives_boxmot_amd_botsort(emulated_abi):
+    from boxmot_amd.scenario import stress_frames
+    logging.disable(logging.CRITICAL)
+    TrackerRuntime, _ = ref_harness.load_engine_callers()
+    ours, ref = _pair()
+    rt_ours, rt_ref = TrackerRuntime(ours), TrackerRuntime(ref)
+    assert rt_ours._accepts_embs and rt_ours._accepts_masks            # the signature the reference inspects (runtime.py:25-35)
+    img = np.zeros((480, 640, 3), dtype=np.uint8)
+    for t, (d, e) in enumerate(stress_frames(40, seed=4)):
+        got, ms = rt_ours.update(d.copy(), img, embs=e.copy())
+        want, _ = rt_ref.update(d.copy(), img, embs=e.copy())
+        assert got.dtype == np.float32 and got.ndim == 2 and ms >= 0
+        _same(got, want, t)
+        if len(want):
+            # the reference's MOT formatter accepts our rows as it accepts its own (mot.py:239-344)
+            assert np.array_equal(TrackerRuntime.format_for_mot(got, t + 1)[:, :2], TrackerRuntime.format_for_mot(want, t + 1)[:, :2])
+    none, no_embs = np.empty((0, 6), dtype=np.float32), np.empty((0, 32), dtype=np.float32)     # a frame without detections
+    got, _ = rt_ours.update(none, img, embs=no_embs)
+    want, _ = rt_ref.update(none, img, embs=no_embs)
+    assert got.shape == want.shape
+    ours.close()
+
+
+def test_reference_results_run_tracker_drives_boxmot_amd_botsort(emulated_abi):
+    from boxmot_amd.scenario import stress_frames
+    from boxmot_amd.tracker_zoo import BOTSORT_YAML_DEFAULTS
+    logging.disable(logging.CRITICAL)
+    _, Results = ref_harness.load_engine_callers()
+    from boxmot.trackers.track_results import TrackResults as RefTrackResults
+    kw = {k: v for k, v in BOTSORT_YAML_DEFAULTS.items() if k not in ("use_cmc", "cmc_method")}
+    ours, ref = _pair(**kw)
+    img = np.zeros((480, 640, 3), dtype=np.uint8)
+    for t, (d, e) in enumerate(stress_frames(40, seed=7)):
+        # Results._run_tracker only touches self.tracker: call the reference method on a holder of our tracker
+        got = Results._run_tracker(SimpleNamespace(tracker=ours), d.copy(), img, e.copy())
+        want = Results._run_tracker(SimpleNamespace(tracker=ref), d.copy(), img, e.copy())
+        assert isinstance(got, RefTrackResults) and isinstance(want, RefTrackResults)
+        _same(got, want, t)
+        assert Results._extract_track_ids(got) == Results._extract_track_ids(want)
+    ours.close()

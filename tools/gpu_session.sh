@@ -1,0 +1,48 @@
+#!/bin/bash
+# One GPU-box session, built from named steps (run through gpurun from the repo root):
+#
+#   gpurun --timeout 1500 -- 'bash tools/gpu_session.sh r3a build tests bench trace traffic'
+#
+#   tools/gpu_session.sh <tag> <step> [<step> ...]          outputs under gpurun_out/<tag>/
+#
+# steps
+#   build      compile the tree's sources ON THIS BOX (BOXMOT_FORCE_BUILD=1), so the binary that runs is not a prebuilt one
+#   tests      python -m pytest tests -m gpu                                  -> pytest.log
+#   reid       the ReID GPU tests only                                        -> pytest_reid.log
+#   bench      default bench.py                                               -> bench.json / bench.err
+#   benchq     bench.py without CPU baseline / side lines (quick)             -> benchq.json
+#   trace      rocprofv3 --kernel-trace --stats of `bench.py --no-cpu-baseline --no-side-configs --no-m1` -> kernel_stats.txt
+#   traffic    FETCH_SIZE and WRITE_SIZE, separate --pmc passes, on tools/reid_microbench.py 4096 crops (mode $REID_MODE)  -> pmc_traffic.txt
+#   mfma       SQ_VALU_MFMA_BUSY_CYCLES pass on the same microbenchmark      -> mfma_busy.txt
+#   c3 / c5    tools/config_bench.py for configurations 3 / 5                 -> config_bench.jsonl
+#   soak       tools/parity_soak.py (all trackers, short)                     -> soak.log
+# Counters are collected in their own --pmc passes, never together with a trace (profiles/README.md).  Summaries a round wants
+# judged are copied from gpurun_out/<tag>/ into profiles/ by hand.
+set -u
+TAG=$1; shift
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/$TAG; mkdir -p $O
+MODE=${REID_MODE:-2}
+db() { find $O/$1 -name "*.db" | head -1; }
+cd $R
+for step in "$@"; do
+  echo "=== $step"
+  case $step in
+    build)   BOXMOT_FORCE_BUILD=1 python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1; tail -n 2 $O/build.log ;;
+    tests)   timeout 1200 python -m pytest tests -q -m gpu --maxfail=10 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -n 8 $O/pytest.log | cut -c1-220 ;;
+    reid)    timeout 600 python -m pytest tests/test_gpu_reid.py -q -s --maxfail=10 > $O/pytest_reid.log 2>&1; echo "pytest rc=$?" >> $O/pytest_reid.log; grep -E "calibrated|passed|failed|rc=" $O/pytest_reid.log | cut -c1-220 ;;
+    bench)   timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 1500 $O/bench.json; echo ;;
+    benchq)  timeout 400 python bench.py --no-cpu-baseline --no-side-configs --no-m1 --reid-mode $MODE > $O/benchq_m$MODE.json 2> $O/benchq.err; tail -c 900 $O/benchq_m$MODE.json; echo ;;
+    trace)   (cd /tmp && export TMPDIR=/tmp && timeout 500 rocprofv3 --kernel-trace --stats -d $O/kt -o bench -- python $R/bench.py --no-cpu-baseline --no-side-configs --no-m1 --reid-mode $MODE > $O/bench_kt.json 2> $O/bench_kt.err)
+             python profiles/summarize_rocpd.py $(db kt) > $O/kernel_stats_m$MODE.txt 2>&1; rm -rf $O/kt; head -n 16 $O/kernel_stats_m$MODE.txt | cut -c1-170 ;;
+    traffic) (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o p -- python $R/tools/reid_microbench.py 4096 $MODE 2 > $O/fetch.log 2>&1
+              timeout 300 rocprofv3 --pmc WRITE_SIZE -d $O/write -o p -- python $R/tools/reid_microbench.py 4096 $MODE 2 > $O/write.log 2>&1)
+             python profiles/summarize_pmc.py $(db fetch) $(db write) 4096 > $O/pmc_traffic_m$MODE.txt 2>&1; rm -rf $O/fetch $O/write; tail -n 14 $O/pmc_traffic_m$MODE.txt ;;
+    mfma)    (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $O/mfma -o p -- python $R/tools/reid_microbench.py 4096 $MODE 2 > $O/mfma.log 2>&1)
+             python profiles/summarize_mfma.py $(db mfma) > $O/mfma_busy_m$MODE.txt 2>&1; rm -rf $O/mfma; cat $O/mfma_busy_m$MODE.txt ;;
+    c3)      timeout 600 python tools/config_bench.py --config c3 >> $O/config_bench.jsonl 2> $O/c3.err; tail -n 1 $O/config_bench.jsonl | cut -c1-900 ;;
+    c5)      timeout 900 python tools/config_bench.py --config c5 >> $O/config_bench.jsonl 2> $O/c5.err; tail -n 1 $O/config_bench.jsonl | cut -c1-900 ;;
+    soak)    timeout 900 python tools/parity_soak.py 10 200 > $O/soak.log 2>&1; tail -n 12 $O/soak.log ;;
+    *)       echo "unknown step $step" ;;
+  esac
+done
