@@ -666,6 +666,22 @@ void io_set_warp(StreamIo* h, int stream, const double* warp_2x3) {
     h->h_warp_flag[stream] = 1;
 }
 
+// Device-resident steps: the warps set with *_set_warp since the last step are consumed by this one (identity for the streams
+// without a pending warp).  Returns whether any stream had one; the caller clears the flags after launching.
+bool io_consume_warps(StreamIo* h) {
+    bool any_warp = false;
+    for (int s = 0; s < h->S; ++s) any_warp = any_warp || h->h_warp_flag[s] != 0;
+    if (!any_warp) return false;
+    for (int s = 0; s < h->S; ++s)
+        if (!h->h_warp_flag[s]) { double* w = h->h_warp.data() + (size_t)s * 6; w[0] = 1; w[1] = 0; w[2] = 0; w[3] = 0; w[4] = 1; w[5] = 0; }
+    BM_HIP(hipMemcpyAsync(h->d_warp, h->h_warp.data(), (size_t)h->S * 6 * 8, hipMemcpyHostToDevice, h->stream));
+    BM_HIP(hipMemcpyAsync(h->d_warp_flag, h->h_warp_flag.data(), h->S * 4, hipMemcpyHostToDevice, h->stream));
+    // the staging vectors are reused by the next set_warp: the copies must have left the host before returning
+    BM_HIP(hipStreamSynchronize(h->stream));
+    return true;
+}
+void io_clear_warps(StreamIo* h) { for (int s = 0; s < h->S; ++s) h->h_warp_flag[s] = 0; }
+
 // Validate and upload the inputs of the first n streams; run the ReID engine on every detection passing the confidence
 // test (`conf > thresh`, or `>=` when inclusive) when embeddings are wanted and not supplied.  Streams without a pending
 // warp get the identity.  Returns whether any stream has a pending warp.
@@ -1609,11 +1625,13 @@ int boxmot_hip_deepocsort_step_device(BoxMOTHipDeepOcSort* handle, const float* 
         if (!handle->cfg.embedding_off && !d_embs) throw std::runtime_error("boxmot_hip: step_device needs d_embs unless embedding_off");
         bm::DocsStepArgs a = handle->args;
         a.dets = d_dets; a.n_dets = d_det_rows; a.embs = handle->cfg.embedding_off ? nullptr : d_embs;
-        a.warp = nullptr; a.warp_flag = nullptr;
+        const bool any_warp = io_consume_warps(handle);         // boxmot_hip_deepocsort_set_warp since the last step
+        a.warp = any_warp ? handle->d_warp : nullptr; a.warp_flag = any_warp ? handle->d_warp_flag : nullptr;
         a.out = d_out; a.out_n = d_out_rows; a.stream_base = 0;
         hipLaunchKernelGGL((deepocsort_step_kernel<STEP_THREADS>), dim3(handle->S), dim3(STEP_THREADS),
                            (size_t)bm::docs_lap_lds_bytes(handle->cap, handle->nd), handle->stream, a);
         BM_HIP(hipGetLastError());
+        io_clear_warps(handle);
     });
 }
 
@@ -1627,11 +1645,13 @@ int boxmot_hip_deepocsort_step_device_frames(BoxMOTHipDeepOcSort* handle, const 
             io_device_reid(handle, d_dets, d_det_rows, d_frames, image_rows, image_cols, (double)(float)handle->cfg.det_thresh, 0);
         bm::DocsStepArgs a = handle->args;
         a.dets = d_dets; a.n_dets = d_det_rows; a.embs = handle->cfg.embedding_off ? nullptr : handle->d_embs;
-        a.warp = nullptr; a.warp_flag = nullptr;
+        const bool any_warp = io_consume_warps(handle);
+        a.warp = any_warp ? handle->d_warp : nullptr; a.warp_flag = any_warp ? handle->d_warp_flag : nullptr;
         a.out = d_out; a.out_n = d_out_rows; a.stream_base = 0;
         hipLaunchKernelGGL((deepocsort_step_kernel<STEP_THREADS>), dim3(handle->S), dim3(STEP_THREADS),
                            (size_t)bm::docs_lap_lds_bytes(handle->cap, handle->nd), handle->stream, a);
         BM_HIP(hipGetLastError());
+        io_clear_warps(handle);
     });
 }
 
@@ -1769,10 +1789,12 @@ int boxmot_hip_strongsort_step_device(BoxMOTHipStrongSort* handle, const float* 
         if (!handle) throw std::runtime_error("boxmot_hip StrongSORT handle is not initialized.");
         if (!d_dets || !d_det_rows || !d_embs || !d_out || !d_out_rows) throw std::runtime_error("boxmot_hip: null device pointers");
         bm::SsStepArgs a = handle->args;
-        a.dets = d_dets; a.n_dets = d_det_rows; a.embs = d_embs; a.warp = nullptr;
+        a.dets = d_dets; a.n_dets = d_det_rows; a.embs = d_embs;
+        a.warp = io_consume_warps(handle) ? handle->d_warp : nullptr;       // boxmot_hip_strongsort_set_warp since the last step
         a.out = d_out; a.out_n = d_out_rows; a.stream_base = 0;
         ss_launch(handle, a, handle->S);
         BM_HIP(hipGetLastError());
+        io_clear_warps(handle);
     });
 }
 
@@ -1784,10 +1806,12 @@ int boxmot_hip_strongsort_step_device_frames(BoxMOTHipStrongSort* handle, const 
         if (!d_dets || !d_det_rows || !d_out || !d_out_rows) throw std::runtime_error("boxmot_hip: null device pointers");
         io_device_reid(handle, d_dets, d_det_rows, d_frames, image_rows, image_cols, handle->cfg.min_conf, 1);    // strongsort.py:74-91
         bm::SsStepArgs a = handle->args;
-        a.dets = d_dets; a.n_dets = d_det_rows; a.embs = handle->d_embs; a.warp = nullptr;
+        a.dets = d_dets; a.n_dets = d_det_rows; a.embs = handle->d_embs;
+        a.warp = io_consume_warps(handle) ? handle->d_warp : nullptr;
         a.out = d_out; a.out_n = d_out_rows; a.stream_base = 0;
         ss_launch(handle, a, handle->S);
         BM_HIP(hipGetLastError());
+        io_clear_warps(handle);
     });
 }
 
