@@ -2,7 +2,7 @@
 """bench.py -- tracker frames/sec for BASELINE.json config 2:
 BoT-SORT + OSNet-x0.25 ReID inside update, 64 detections x 256 live tracks, 1080p frames.
 
-  python bench.py --gpus N --steps K --warmup W [--streams S] [--groups G] [--mode embs|reid] [--reid-mode 0|1]
+  python bench.py --gpus N --steps K --warmup W [--streams S] [--groups G] [--mode embs|reid] [--reid-mode 0|1|2]
 
 One "step" = one pass of the hot path over one batch = every one of the S streams of this GPU
 advances by one frame (ReID crop/resize/normalise + OSNet + cost matrices + assignment + Kalman +
@@ -89,7 +89,7 @@ def parse(argv=None):
     ap.add_argument("--streams", type=int, default=256, help="streams per GPU")
     ap.add_argument("--mode", choices=("reid", "embs"), default="reid",
                     help="reid: ReID inside update (headline, M2); embs: embeddings supplied (tracker math only, M1)")
-    ap.add_argument("--reid-mode", type=int, default=int(os.environ.get("BOXMOT_REID_MODE", "1")),
+    ap.add_argument("--reid-mode", type=int, default=int(os.environ.get("BOXMOT_REID_MODE", "2")),
                     help="0: per-layer fp32 kernels, 1: fused fp16 MFMA kernels, 2: fused fp32-grade kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-m1", action="store_true", help="skip the tracker-math-only (embeddings supplied) side measurement")
@@ -200,7 +200,8 @@ def side_configs():
     import config_bench
     side = {}
     for key, kwargs in (("config3", dict(config="c3", streams=8, steps=16, warmup=6, check_frames=8)),
-                        ("config5", dict(config="c5", streams=2, steps=6, warmup=3, check_frames=8))):
+                        # configuration 5: 104 warm-up frames fill every sample bank (nn_budget 100), so the timed steps are steady state
+                        ("config5", dict(config="c5", streams=2, steps=8, warmup=104, check_frames=4))):
         try:
             side[key] = config_bench.run(**kwargs)
             log(f"side line {key}: {side[key]['frames_per_s']:.1f} frames/s")

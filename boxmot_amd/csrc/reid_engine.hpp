@@ -2,6 +2,7 @@
 // the device and sequences the kernels for a batch of crops.
 //   mode 0: per-layer fp32 kernels (reid_kernels_v1.hpp) -- first correct path
 //   mode 1: fused fp16 MFMA kernels (reid_fused.hpp)
+//   mode 2: fused fp32-grade kernels (reid_hp.hpp): the fused structure on fp16 (hi, lo) operand pairs, fp32 everywhere else
 // Reference path: BaseModelBackend.get_features, base_backend.py:197-207.
 #pragma once
 #include <cstdlib>
@@ -18,6 +19,7 @@
 #include "reid_layout.hpp"
 #include "reid_kernels_v1.hpp"
 #include "reid_fused.hpp"
+#include "reid_hp.hpp"
 #include "clip_engine.hpp"
 #include "osnet_wide.hpp"
 
@@ -114,15 +116,20 @@ public:
     int feature_dim() const { return L_.feat; }
     int max_crops() const { return max_crops_; }
     void set_mode(int m) {
-        if (m != 0 && m != 1) throw std::runtime_error("ReID mode must be 0 (per-layer fp32) or 1 (fused fp16 MFMA)");
+        if (m != 0 && m != 1 && m != 2)
+            throw std::runtime_error("ReID mode must be 0 (per-layer fp32), 1 (fused fp16 MFMA) or 2 (fused fp32-grade)");
         if (clip_) return;                  // CLIP-ReID has one kernel family; the mode switch is OSNet's
         if (m == 1 && !fused_ready_ && !wide_)
             throw std::runtime_error("fp16 MFMA ReID kernels exist for OSNet-x0.25 (fused) and for widths that are multiples of 32 (osnet_x1_0)");
+        if (m == 2) {
+            if (!fused_ready_) throw std::runtime_error("the fused fp32-grade ReID kernels (mode 2) exist for OSNet-x0.25");
+            if (!hp_ready_) prepare_hp();
+        }
         mode_ = m;
     }
     int mode() const { return mode_; }
     // the crop count may stay on the device (run_counted): only the fused x0.25 kernels take it
-    bool counted_ok() const { return mode_ == 1 && fused_ready_; }
+    bool counted_ok() const { return (mode_ == 1 || mode_ == 2) && fused_ready_; }
     void set_fuse_stem(bool on) { fuse_stem_ = on; }     // A/B switch: fused crop+stem kernel vs resize kernel + stem kernel
     // 0 = "resize" (default), 1 = "resize_pad" (reid/core/preprocessing.py:12-45); resize_pad runs the separate crop kernel
     void set_preprocess(int pad) { pad_ = pad; }
@@ -136,6 +143,15 @@ public:
     // crops only (normalised NHWC fp32) for `n` boxes
     void preprocess(const uint8_t* const* d_frames, const int* d_crop_stream, const float* d_boxes,
                     int box_stride, int n, int W, int H, hipStream_t st) {
+        const bool hp = mode_ == 2 && !force_fp32_crops_;
+        if (hp) {       // (hi, lo) fp16 RGBX planes for k_stem_hp
+            if (n > fused_cap_) throw std::runtime_error("ReID: crop batch exceeds the engine capacity");
+            if (n == 0) return;
+            if (obb_geo_) throw std::runtime_error("ReID mode 2 (fused fp32-grade kernels): oriented-box crops run in modes 0 / 1");
+            hipLaunchKernelGGL(k_crop_resize_rgbx_hl, dim3(n, REID_IN_H / 16), dim3(REID_IN_W), 0, st, d_frames, d_crop_stream, d_boxes,
+                               box_stride, W, H, d_lut_, crops_h_, crops_l_, 16, d_count_, pad_);
+            return;
+        }
         const bool fused = mode_ == 1 && fused_ready_ && !force_fp32_crops_;
         const bool wide = mode_ == 1 && wide_ && !force_fp32_crops_;
         if (n > (fused ? fused_cap_ : (wide ? wide_->max_crops() : max_crops_))) throw std::runtime_error("ReID: crop batch exceeds the engine capacity");
@@ -174,7 +190,7 @@ public:
         if (n == 0) return;
         BM_HIP(hipEventRecord(ev_[0], st));
         const bool wide = mode_ == 1 && wide_;
-        const int step = wide ? wide_->max_crops() : (mode_ == 1 ? fused_cap_ : max_crops_);
+        const int step = wide ? wide_->max_crops() : (mode_ >= 1 ? fused_cap_ : max_crops_);
         const double* geo_all = obb_geo_;
         for (int i0 = 0; i0 < n; i0 += step) {
             const int m = (n - i0) < step ? (n - i0) : step;
@@ -188,6 +204,7 @@ public:
             const int* orow = d_out_rows ? d_out_rows + i0 : nullptr;
             if (clip_) clip_->forward(crops_, m, o, orow, st);
             else if (wide) wide_->forward(m, o, orow, st);
+            else if (mode_ == 2) forward_hp(m, o, orow, st);
             else if (mode_ == 1) {
                 const FrameArgs fa{d_frames, d_crop_stream + i0, d_boxes + (long)i0 * box_stride, box_stride, W, H};
                 forward_fused(m, fuse_stem ? &fa : nullptr, o, orow, st);
@@ -204,18 +221,19 @@ public:
     // beyond *d_count exit immediately -- no host round trip between the crop list and the ReID kernels.
     void run_counted(const uint8_t* const* d_frames, const int* d_crop_stream, const float* d_boxes, int box_stride,
                      const int* d_count, int n_max, int W, int H, float* d_out, const int* d_out_rows, hipStream_t st) {
-        if (!counted_ok()) throw std::runtime_error("ReID: run_counted needs the fused x0.25 kernels (mode 1)");
+        if (!counted_ok()) throw std::runtime_error("ReID: run_counted needs the fused x0.25 kernels (mode 1 or 2)");
         if (n_max > fused_cap_) throw std::runtime_error("ReID: crop batch exceeds the engine capacity");
         if (n_max == 0) return;
         d_count_ = d_count;
         BM_HIP(hipEventRecord(ev_[0], st));
-        const bool fuse_stem = fuse_stem_ && !pad_;
+        const bool fuse_stem = mode_ == 1 && fuse_stem_ && !pad_;
         if (!fuse_stem) preprocess(d_frames, d_crop_stream, d_boxes, box_stride, n_max, W, H, st);
         BM_HIP(hipEventRecord(ev_[1], st));
         hipEvent_t a = take_event(), b = take_event();
         BM_HIP(hipEventRecord(a, st));
         const FrameArgs fa{d_frames, d_crop_stream, d_boxes, box_stride, W, H};
-        forward_fused(n_max, fuse_stem ? &fa : nullptr, d_out, d_out_rows, st);
+        if (mode_ == 2) forward_hp(n_max, d_out, d_out_rows, st);
+        else forward_fused(n_max, fuse_stem ? &fa : nullptr, d_out, d_out_rows, st);
         BM_HIP(hipEventRecord(b, st));
         if (pending_.size() < 4096) pending_.emplace_back(a, b);
         else { free_events_.push_back(a); free_events_.push_back(b); }
@@ -431,6 +449,56 @@ private:
                            w_c5_, w_fc_, d_out, d_out_rows, d_count_, n);
 #endif
     }
+    // ---- fused fp32-grade path (OSNet-x0.25, mode 2): reid_hp.hpp ----
+    void prepare_hp() {
+        const float* w = h_w_.data();
+        std::vector<uint8_t> buf;
+        pack_stem_hp(w + L_.stem_w, w + L_.stem_b, buf);
+        hw_stem_ = upload(buf);
+        static const int stage[6] = {0, 0, 1, 1, 2, 2}, cin[6] = {16, 64, 64, 96, 96, 128}, down[6] = {1, 0, 1, 0, 1, 0};
+        for (int b = 0; b < 6; ++b) {
+            hbp_[b] = make_blk_pack_hp(stage[b], cin[b], down[b]);
+            pack_osblock_hp(w, L_.block[b], hbp_[b], buf);
+            hw_blk_[b] = upload(buf);
+        }
+        pack_pointwise_hp(w + L_.trans_w[0], w + L_.trans_b[0], 64, 64, buf, 0.25f); hw_tr_[0] = upload(buf);
+        pack_pointwise_hp(w + L_.trans_w[1], w + L_.trans_b[1], 96, 96, buf, 0.25f); hw_tr_[1] = upload(buf);
+        pack_pointwise_hp(w + L_.conv5_w, w + L_.conv5_b, 128, 128, buf); hw_c5_ = upload(buf);
+        pack_fc_hp(w + L_.fc_w, w + L_.fc_b, 512, 128, buf); hw_fc_ = upload(buf);
+        const size_t n = (size_t)fused_cap_;
+        const size_t crop_halves = n * STEM_ROWS * STEM_COLS * 4;
+        crops_l_ = dev_alloc<_Float16>(crop_halves, owned_);
+        BM_HIP(hipMemset(crops_l_, 0, crop_halves * 2));
+        hact_al_ = dev_alloc<_Float16>(n * 2048 * 32, owned_);      // lo planes beside act_a_ / act_b_ (the hi planes)
+        hact_bl_ = dev_alloc<_Float16>(n * 2048 * 32, owned_);
+        hx1s_ = dev_alloc<float>(n * 2048 * 16, owned_);            // fp32 hand-over tensors of the stage-0 block pair
+        hx2s_ = dev_alloc<float>(n * 2048 * 16, owned_);
+        allow_lds(k_osblock_hp<0, 16, true, false, true, false>, GeoHP<0>::LDS_BYTES);
+        allow_lds(k_osblock_hp<0, 64, false, true, false, true>, GeoHP<0>::LDS_BYTES);
+        allow_lds(k_osblock_hp<1, 64, true, false>, GeoHP<1>::LDS_BYTES);
+        allow_lds(k_osblock_hp<1, 96, false, true>, GeoHP<1>::LDS_BYTES);
+        allow_lds(k_osblock_hp<2, 96, true, false>, GeoHP<2>::LDS_BYTES);
+        allow_lds(k_osblock_hp<2, 128, false, false>, GeoHP<2>::LDS_BYTES);
+        hp_ready_ = true;
+    }
+    void forward_hp(int n, float* d_out, const int* d_out_rows, hipStream_t st) {
+        hipLaunchKernelGGL(k_stem_hp, dim3(n), dim3(512), 0, st, crops_h_, crops_l_, act_a_, hact_al_, hw_stem_, d_count_);
+        auto blk = [&](auto kernel, int lds, const _Float16* ih, const _Float16* il, _Float16* oh, _Float16* ol, int b,
+                       const unsigned char* wtr, BlkLinkHP link) {
+            hipLaunchKernelGGL(kernel, dim3(n), dim3(512), lds, st, ih, il, oh, ol, hw_blk_[b], hbp_[b], d_count_, hx1s_, wtr, link);
+        };
+        // stage 0: block 1 hands block 2 its conv1 result and its branch sum (fp32) instead of its 64-channel output
+        blk(k_osblock_hp<0, 16, true, false, true, false>, GeoHP<0>::LDS_BYTES, act_a_, hact_al_, nullptr, nullptr, 0, nullptr,
+            BlkLinkHP{hw_blk_[1], hbp_[1].conv1_a, hbp_[1].conv1_b, 0, hx2s_});
+        blk(k_osblock_hp<0, 64, false, true, false, true>, GeoHP<0>::LDS_BYTES, act_a_, hact_al_, act_b_, hact_bl_, 1, hw_tr_[0],
+            BlkLinkHP{hw_blk_[0], hbp_[0].conv3_a, hbp_[0].conv3_b, hbp_[0].down_a, hx2s_});
+        blk(k_osblock_hp<1, 64, true, false>, GeoHP<1>::LDS_BYTES, act_b_, hact_bl_, act_a_, hact_al_, 2, nullptr, BlkLinkHP{});
+        blk(k_osblock_hp<1, 96, false, true>, GeoHP<1>::LDS_BYTES, act_a_, hact_al_, act_b_, hact_bl_, 3, hw_tr_[1], BlkLinkHP{});
+        blk(k_osblock_hp<2, 96, true, false>, GeoHP<2>::LDS_BYTES, act_b_, hact_bl_, act_a_, hact_al_, 4, nullptr, BlkLinkHP{});
+        blk(k_osblock_hp<2, 128, false, false>, GeoHP<2>::LDS_BYTES, act_a_, hact_al_, act_b_, hact_bl_, 5, nullptr, BlkLinkHP{});
+        hipLaunchKernelGGL((k_head_hp<128, 512>), dim3((n + HEAD_NB - 1) / HEAD_NB), dim3(256), 0, st, act_b_, hact_bl_, hw_c5_, hw_fc_,
+                           d_out, d_out_rows, d_count_, n);
+    }
     void alloc_buffers() {
         const size_t n = (size_t)max_crops_;
         crops_ = dev_alloc<float>(n * REID_IN_H * REID_IN_W * 3, owned_);
@@ -475,6 +543,15 @@ private:
     unsigned char* w_tr_[2] = {};
     unsigned char *w_c5_ = nullptr, *w_fc_ = nullptr;
     _Float16 *crops_h_ = nullptr, *act_a_ = nullptr, *act_b_ = nullptr, *x1s_ = nullptr, *x2s_ = nullptr;
+    // fused fp32-grade path (allocated when mode 2 is first selected)
+    bool hp_ready_ = false;
+    BlkPackHP hbp_[6];
+    unsigned char* hw_stem_ = nullptr;
+    unsigned char* hw_blk_[6] = {};
+    unsigned char* hw_tr_[2] = {};
+    unsigned char *hw_c5_ = nullptr, *hw_fc_ = nullptr;
+    _Float16 *crops_l_ = nullptr, *hact_al_ = nullptr, *hact_bl_ = nullptr;
+    float *hx1s_ = nullptr, *hx2s_ = nullptr;
     hipEvent_t ev_[3];
     std::vector<hipEvent_t> all_events_, free_events_;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_;

@@ -1,0 +1,737 @@
+// fp32-grade fused ReID kernels for OSNet-x0.25 (gfx950, wave64): ReID "mode 2".
+//
+// Reference computation: OSNet.forward, boxmot/reid/backbones/osnet.py:380-405 (OSBlock :212-260, LightConv3x3 :127-155,
+// ChannelGate :161-209) in fp32 on the CPU (reid/backends/base_backend.py:197-217) -- north_star's comparator, tolerance 1e-3.
+// The fp16-operand family (reid_fused.hpp, mode 1) meets that tolerance on the reference's own initialisation only; on
+// networks with non-trivial BatchNorm statistics fp16 activations alone cost 5e-3 (profiles/r2_reid_error_budget.txt).  This
+// family keeps the SAME structure -- one workgroup owns one crop for a whole OSBlock, every 1x1 convolution is an MFMA whose
+// accumulator layout is the next B operand, the depthwise 3x3 goes through an LDS image, gates meet in LDS -- with fp32-grade
+// arithmetic everywhere:
+//   * 1x1 convolutions: both operands as fp16 (hi, lo) pairs, three v_mfma_f32_16x16x32_f16 per K = 32 product tile, two for a
+//     K = 16 layer (reid_hp_pack.hpp); fp32 accumulation; weights split on the host, activations split in registers;
+//   * activations between MFMAs, the depthwise 3x3, the gates and the shortcut sums: fp32 registers / fp32 LDS image;
+//   * activations between kernels: two fp16 planes (hi, lo) in the lane-group-major NHWC layout (the B fragments of the
+//     consumer are plain 16-byte loads; same bytes as fp32).
+// LDS image: channel-group planes [ct][g][row][x] of 16-byte pixels (4 channels fp32), plane stride a multiple of 256 bytes:
+// the 16 lanes of a lane group touch 16 consecutive 16-byte slots and the four lane groups of a ds_read_b128 / ds_write_b128
+// service group land on disjoint slots -- conflict-free for the centre and the x +- 1 taps alike.
+// The depthwise 3x3 streams down a column strip: every input row is read once (3 reads: x - 1, x, x + 1) and feeds the three
+// output rows it touches (three live accumulators instead of a 3 x 3 window of registers).
+#pragma once
+
+#include "reid_fused.hpp"
+#include "reid_hp_pack.hpp"
+
+namespace bm {
+
+template <int STAGE>
+struct GeoHP {
+    static constexpr int H = 64 >> STAGE, W = 32 >> STAGE, P = H * W;
+    static constexpr int MID = STAGE == 0 ? 16 : (STAGE == 1 ? 24 : 32);
+    static constexpr int KT = STAGE == 0 ? 1 : 2;
+    static constexpr int MIDP = 16 * KT;
+    static constexpr int HID = MID / 16;
+    static constexpr int COUT = STAGE == 0 ? 64 : (STAGE == 1 ? 96 : 128);
+    static constexpr int NCT = COUT / 16;
+    static constexpr int NWAVES = 8;
+    static constexpr int NT = P / 16 / NWAVES;                       // 16, 4, 1 pixel tiles per wave
+    // stages 0 / 1: one workgroup per CU (the fp32 image is 141 / 78 KiB): two waves per SIMD, 256 registers each;
+    // stage 2: two workgroups per CU
+    static constexpr int WAVES_PER_SIMD = STAGE == 2 ? 4 : 2;
+    static constexpr int ROWP = STAGE == 0 ? 34 * 16 : (STAGE == 1 ? 18 * 16 : 384);     // stage 2: 8-pixel rows, pitch = 8 slots mod 16
+    static constexpr int PLANE = STAGE == 0 ? 141 * 256 : (STAGE == 1 ? 39 * 256 : 28 * 256);
+    static constexpr int IMG = 4 * KT * PLANE;
+    static constexpr int LDS_BYTES = IMG + 4 * NWAVES * HID * 4;
+    static_assert(PLANE >= (H + 2) * ROWP && PLANE % 256 == 0, "plane holds the haloed image; stride keeps the lane groups on disjoint slots");
+};
+
+__device__ inline f4 fma_f4(f4 a, f4 b, f4 c) { return __builtin_elementwise_fma(a, b, c); }
+// (hi, lo) fp16 parts of four fp32 values: v = hi + lo up to 2^-22 relative
+__device__ inline void split4(f4 v, h4& h, h4& l) {
+    h = to_h4(v);
+    l = to_h4(f4{v[0] - (float)h[0], v[1] - (float)h[1], v[2] - (float)h[2], v[3] - (float)h[3]});
+}
+// K = 32 product tile on (hi, lo) operands: the fragment pair at `a` (hi at +0, lo at +1024; 16 bytes per lane)
+__device__ inline f4 mm3(const unsigned char* a, int lane, h8 bh, h8 bl, f4 acc) {
+    const h8 ah = *reinterpret_cast<const h8*>(a + lane * 16), al = *reinterpret_cast<const h8*>(a + 1024 + lane * 16);
+    acc = BM_MFMA_F16_K32(ah, bh, acc);
+    acc = BM_MFMA_F16_K32(ah, bl, acc);
+    acc = BM_MFMA_F16_K32(al, bh, acc);
+    return acc;
+}
+// K = 16 layer in the duplicated form: b = [xh | xl] against [Wh | Wh] and [Wl | Wl]
+__device__ inline f4 mm2(const unsigned char* a, int lane, h8 b, f4 acc) {
+    const h8 ah = *reinterpret_cast<const h8*>(a + lane * 16), al = *reinterpret_cast<const h8*>(a + 1024 + lane * 16);
+    acc = BM_MFMA_F16_K32(ah, b, acc);
+    acc = BM_MFMA_F16_K32(al, b, acc);
+    return acc;
+}
+
+struct BlkLinkHP {
+    const unsigned char* w = nullptr;
+    long a0 = 0, a1 = 0, a2 = 0;
+    float* x2s = nullptr;
+};
+
+// ---------------------------------------------------------------------------
+// OSBlock: in (hi, lo) [n][P][CIN] -> out (hi, lo) [n][P or P/4][COUT]
+// TRANS / EMIT / RECON as in k_osblock (reid_fused.hpp): fused transition; first block of a pair hands the second its
+// conv1 result (`x1s`) and its gated branch sum (`link.x2s`), both fp32, instead of its 64-channel output.
+// ---------------------------------------------------------------------------
+template <int STAGE, int CIN, bool DOWN, bool TRANS, bool EMIT = false, bool RECON = false>
+__global__ void __launch_bounds__(64 * GeoHP<STAGE>::NWAVES, GeoHP<STAGE>::WAVES_PER_SIMD)
+k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_l, _Float16* __restrict__ out_h, _Float16* __restrict__ out_l,
+             const unsigned char* __restrict__ wts, BlkPackHP bp, const int* __restrict__ count, float* __restrict__ x1s,
+             const unsigned char* __restrict__ wtr, BlkLinkHP link) {
+    static_assert(!EMIT || (STAGE <= 1 && CIN == (STAGE == 0 ? 16 : 64) && DOWN && !TRANS), "EMIT: first block of stage 0 or 1");
+    static_assert(!RECON || (STAGE <= 1 && CIN == GeoHP<STAGE>::COUT && !DOWN && TRANS), "RECON: second block of stage 0 or 1");
+    using G = GeoHP<STAGE>;
+    if (count && (int)blockIdx.x >= *count) return;
+    constexpr int KT = G::KT, NT = G::NT, MIDP = G::MIDP, NCT = G::NCT, COUT = G::COUT, P = G::P;
+    constexpr int KIN = CIN == 16 ? 1 : CIN / 32;
+    constexpr int PREV_CIN = STAGE == 0 ? 16 : 64, KINP = PREV_CIN == 16 ? 1 : PREV_CIN / 32;
+    constexpr bool RECOMP = STAGE == 0 && CIN == 16;              // conv1 per branch: two 8-byte loads + two MFMAs per tile
+    constexpr bool X1_MEM = (STAGE == 0 && !RECOMP) || RECON;     // conv1 result in the fp32 scratch `x1s` (L2), read per branch
+    constexpr bool X1_REG = !RECOMP && !X1_MEM;
+    BM_DYNAMIC_LDS_T(unsigned char, lds);
+    unsigned char* tbuf = lds;
+    float* gap_part = reinterpret_cast<float*>(lds + G::IMG);       // [4 branches][NWAVES][HID]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l16 = lane & 15;
+    const long crop = blockIdx.x;
+    const _Float16* xh = in_h + crop * P * (RECON ? PREV_CIN : CIN);       // RECON: the previous block's input
+    const _Float16* xl = in_l + crop * P * (RECON ? PREV_CIN : CIN);
+    const long out_px = TRANS ? P / 4 : P;
+
+    for (int e = tid * 16; e < G::IMG; e += 64 * G::NWAVES * 16) *reinterpret_cast<f4*>(tbuf + e) = f4{0.f, 0.f, 0.f, 0.f};   // halo = zero padding
+
+    // this lane's pixel of tile 0 inside plane (ct = 0, g); tile i and channel tile ct add compile-time constants
+    const int y_l = STAGE == 0 ? wave * 8 : (STAGE == 1 ? wave * 4 : 2 * wave + (l16 >> 3));
+    const int x_l = STAGE == 2 ? (l16 & 7) : l16;
+    const int pix0 = g * G::PLANE + (y_l + 1) * G::ROWP + (x_l + 1) * 16;
+    auto tile_off = [](int i) constexpr { return STAGE == 0 ? (i >> 1) * G::ROWP + (i & 1) * 256 : (STAGE == 1 ? i * G::ROWP : 0); };
+    float* x1w = nullptr;       // this lane's slots in the scratch tensors: [(tile, ct)][lane] f4 = 1 KiB per wave access
+    if constexpr (X1_MEM || EMIT) x1w = x1s + crop * (P * MIDP) + (long)(wave * NT * KT * 64 + lane) * 4;
+    float* x2w = nullptr;
+    if constexpr (EMIT || RECON) x2w = link.x2s + crop * (P * MIDP) + (long)(wave * NT * KT * 64 + lane) * 4;
+
+    // ---- conv1: 1x1 CIN -> MID, + bias, ReLU (osnet.py:248) ----
+    auto conv1_into = [&](f4 (&x1)[NT][KT]) {
+        unsigned xo = 0;
+        if constexpr (RECOMP) BM_OPAQUE_U32(xo);       // re-read per branch, do not hoist 16 tiles of input out of the branch loop
+        f4 bias[KT];
+#pragma unroll
+        for (int ct = 0; ct < KT; ++ct) bias[ct] = *reinterpret_cast<const f4*>(wts + bp.conv1_b + (16 * ct + 4 * g) * 4);
+        if constexpr (CIN == 16) {
+            const h8 ah = *reinterpret_cast<const h8*>(wts + bp.conv1_a + lane * 16);
+            const h8 al = *reinterpret_cast<const h8*>(wts + bp.conv1_a + 1024 + lane * 16);
+            h8 b[NT];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const unsigned o = xo + (unsigned)(((wave * NT + i) * 16 + l16) * 16 + g * 4);
+                b[i] = cat8(*reinterpret_cast<const h4*>(xh + o), *reinterpret_cast<const h4*>(xl + o));
+            }
+            BM_SCHED_FENCE();
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                f4 acc = BM_MFMA_F16_K32(ah, b[i], bias[0]);
+                acc = BM_MFMA_F16_K32(al, b[i], acc);
+                x1[i][0] = relu4(acc);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const unsigned p = (wave * NT + i) * 16 + l16;
+                f4 acc[KT];
+#pragma unroll
+                for (int ct = 0; ct < KT; ++ct) acc[ct] = bias[ct];
+#pragma unroll
+                for (int ks = 0; ks < KIN; ++ks) {
+                    const unsigned o = p * CIN + g * (CIN / 4) + 8 * ks;
+                    const h8 bh = *reinterpret_cast<const h8*>(xh + o), bl = *reinterpret_cast<const h8*>(xl + o);
+#pragma unroll
+                    for (int ct = 0; ct < KT; ++ct) acc[ct] = mm3(wts + bp.conv1_a + (long)(ks * KT + ct) * HP_FRAG_PAIR, lane, bh, bl, acc[ct]);
+                }
+#pragma unroll
+                for (int ct = 0; ct < KT; ++ct) x1[i][ct] = relu4(acc[ct]);
+                if (i & 1) BM_SCHED_FENCE();
+            }
+        }
+    };
+    f4 x1[X1_REG ? NT : 1][KT];
+    if constexpr (X1_REG) conv1_into(x1);
+    if constexpr (X1_MEM && !RECON) {       // conv1 once, parked in the scratch
+        f4 t[NT][KT];
+        conv1_into(t);
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int ct = 0; ct < KT; ++ct) *reinterpret_cast<f4*>(x1w + (i * KT + ct) * 256) = t[i][ct];
+    }
+
+    // 1x1 (linear, mid -> mid) of LightConv `lw` on the fp32 tile set: operands split in registers
+    auto pointwise = [&](const unsigned char* lw, f4 (&c)[KT]) {
+        h4 hh[KT], ll[KT];
+#pragma unroll
+        for (int ct = 0; ct < KT; ++ct) split4(c[ct], hh[ct], ll[ct]);
+        const f4 z = f4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (KT == 1) {
+            c[0] = mm2(lw + bp.light_pw, lane, cat8(hh[0], ll[0]), z);
+        } else {
+            const h8 bh = cat8(hh[0], hh[1]), bl = cat8(ll[0], ll[1]);
+#pragma unroll
+            for (int ct = 0; ct < KT; ++ct) c[ct] = mm3(lw + bp.light_pw + (long)ct * HP_FRAG_PAIR, lane, bh, bl, z);
+        }
+    };
+
+    f4 x2[NT][KT];          // gated sum of the four branches
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int ct = 0; ct < KT; ++ct) x2[i][ct] = f4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    int li = 0;
+#pragma unroll 1
+    for (int br = 0; br < 4; ++br) {
+        f4 cur[NT][KT];
+        if constexpr (X1_MEM) {
+            unsigned xo = 0;
+            BM_OPAQUE_U32(xo);
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int ct = 0; ct < KT; ++ct) cur[i][ct] = *reinterpret_cast<const f4*>(x1w + (xo + (unsigned)((i * KT + ct) * 256)));
+        } else if constexpr (RECOMP) conv1_into(cur);
+        else {
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int ct = 0; ct < KT; ++ct) cur[i][ct] = x1[i][ct];
+        }
+        // `cur` holds, in turn: the branch input, the 1x1 output of the layer about to run its depthwise pass, the layer output
+        {
+            const unsigned char* lw0 = wts + bp.light0 + (long)li * bp.light_bytes;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) pointwise(lw0, cur[i]);
+        }
+#pragma unroll 1
+        for (int k = 0; k <= br; ++k, ++li) {
+            const unsigned char* lw = wts + bp.light0 + (long)li * bp.light_bytes;
+            const unsigned char* lw_next = lw + bp.light_bytes;
+            const bool more = k < br;
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int ct = 0; ct < KT; ++ct) *reinterpret_cast<f4*>(tbuf + pix0 + ct * 4 * G::PLANE + tile_off(i)) = cur[i][ct];
+            __syncthreads();
+            // depthwise 3x3 (pad 1) + bias + ReLU
+#pragma unroll
+            for (int ct = 0; ct < KT; ++ct) {
+                f4 wd[9];
+                const f4* wsrc = reinterpret_cast<const f4*>(lw + bp.light_dw) + (ct * 4 + g) * 9;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) wd[tap] = wsrc[tap];
+                const f4 bias = *reinterpret_cast<const f4*>(lw + bp.light_b + (16 * ct + 4 * g) * 4);
+                const unsigned char* cbase = tbuf + pix0 + ct * 4 * G::PLANE;
+                if constexpr (STAGE == 2) {
+                    f4 o = bias;
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap)
+                        o = fma_f4(wd[tap], *reinterpret_cast<const f4*>(cbase + (tap / 3 - 1) * G::ROWP + (tap % 3 - 1) * 16), o);
+                    cur[0][ct] = relu4(o);
+                } else {
+                    constexpr int NSEQ = STAGE == 0 ? 2 : 1, L = NT / NSEQ;
+#pragma unroll
+                    for (int sq = 0; sq < NSEQ; ++sq) {
+                        f4 acc[3];
+#pragma unroll
+                        for (int rr = 0; rr < L + 2; ++rr) {          // input row (first row of the strip) - 1 + rr
+                            const unsigned char* rp = cbase + sq * 256 + (rr - 1) * G::ROWP;
+                            const f4 v0 = *reinterpret_cast<const f4*>(rp - 16), v1 = *reinterpret_cast<const f4*>(rp),
+                                     v2 = *reinterpret_cast<const f4*>(rp + 16);
+                            if (rr >= 2) {                              // completes output row rr - 2
+                                f4 a = acc[(rr - 2) % 3];
+                                a = fma_f4(wd[6], v0, a); a = fma_f4(wd[7], v1, a); a = fma_f4(wd[8], v2, a);
+                                const int i = STAGE == 0 ? 2 * (rr - 2) + sq : rr - 2;
+                                cur[i][ct] = relu4(a);
+                                if constexpr (KT == 1) { if (more) pointwise(lw_next, cur[i]); }     // next layer's 1x1 under the next rows' taps
+                            }
+                            if (rr >= 1 && rr <= L) {
+                                f4 a = acc[(rr - 1) % 3];
+                                a = fma_f4(wd[3], v0, a); a = fma_f4(wd[4], v1, a); a = fma_f4(wd[5], v2, a);
+                                acc[(rr - 1) % 3] = a;
+                            }
+                            if (rr <= L - 1) {
+                                f4 a = fma_f4(wd[0], v0, bias);
+                                a = fma_f4(wd[1], v1, a); a = fma_f4(wd[2], v2, a);
+                                acc[rr % 3] = a;
+                            }
+                        }
+                    }
+                }
+            }
+            if constexpr (KT == 2) {
+                if (more) {
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) pointwise(lw_next, cur[i]);
+                }
+            }
+            __syncthreads();
+        }
+        // ChannelGate (osnet.py:194-209): crop-wide average -> fc1 -> ReLU -> fc2 -> sigmoid -> scale
+        float* part = gap_part + br * (G::NWAVES * G::HID);
+        {
+            float ph[G::HID];
+#pragma unroll
+            for (int h = 0; h < G::HID; ++h) ph[h] = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < KT; ++ct) {
+                f4 s = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < NT; ++i) s += cur[i][ct];
+#pragma unroll
+                for (int h = 0; h < G::HID; ++h) {
+                    const f4 w1 = *reinterpret_cast<const f4*>(wts + bp.fc1_w + 4 * (h * MIDP + 16 * ct + 4 * g));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ph[h] = __builtin_fmaf(w1[r], s[r], ph[h]);
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < G::HID; ++h) {
+                float v = ph[h];
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+                if (lane == 0) part[wave * G::HID + h] = v;
+            }
+        }
+        __syncthreads();
+        float hidv[G::HID];
+#pragma unroll
+        for (int h = 0; h < G::HID; ++h) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < G::NWAVES; ++w) sum += part[w * G::HID + h];
+            const float z = *reinterpret_cast<const float*>(wts + bp.fc1_b + 4 * h) + sum * (1.0f / P);
+            hidv[h] = z > 0.f ? z : 0.f;
+        }
+#pragma unroll
+        for (int ct = 0; ct < KT; ++ct) {
+            const f4 zb = *reinterpret_cast<const f4*>(wts + bp.fc2_b + 4 * (16 * ct + 4 * g));
+            f4 gate;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 16 * ct + 4 * g + r;
+                float z = zb[r];
+#pragma unroll
+                for (int h = 0; h < G::HID; ++h) z = __builtin_fmaf(*reinterpret_cast<const float*>(wts + bp.fc2_w + 4 * (c * G::HID + h)), hidv[h], z);
+                gate[r] = 1.f / (1.f + BM_EXPF(-z));
+            }
+#pragma unroll
+            for (int i = 0; i < NT; ++i) x2[i][ct] = fma_f4(gate, cur[i][ct], x2[i][ct]);
+        }
+    }
+
+    // ---- conv3 (1x1 MID -> COUT, linear) + downsample(x) or identity, ReLU (osnet.py:254-260) ----
+    const unsigned char* w3 = wts + bp.conv3_a;
+    const unsigned char* wdn = wts + bp.down_a;
+    const unsigned char* pv3 = RECON ? link.w + link.a0 : nullptr;      // previous block: conv3 pairs, bias, downsample pairs
+    const unsigned char* pvb = RECON ? link.w + link.a1 : nullptr;
+    const unsigned char* pvd = RECON ? link.w + link.a2 : nullptr;
+    h8 eye;                 // [I | I]: row l16, k-slots j <-> channel 4 g + (j & 3): adds the hi and the lo plane of the shortcut
+#pragma unroll
+    for (int j = 0; j < 8; ++j) eye[j] = (_Float16)(l16 == 4 * g + (j & 3) ? 1.f : 0.f);
+    auto block_tile = [&](int i, f4 (&y)[NCT]) {
+        unsigned p = (wave * NT + i) * 16 + l16;
+        if constexpr (STAGE == 0) BM_OPAQUE_U32(p);         // addresses are formed at the use
+        h4 xh4[KT], xl4[KT];
+#pragma unroll
+        for (int ct = 0; ct < KT; ++ct) split4(x2[i][ct], xh4[ct], xl4[ct]);
+        h8 b2h, b2l;
+        if constexpr (KT == 1) { b2h = cat8(xh4[0], xl4[0]); b2l = b2h; }
+        else { b2h = cat8(xh4[0], xh4[KT - 1]); b2l = cat8(xl4[0], xl4[KT - 1]); }
+        // operands of the shortcut
+        h8 dxh[KIN], dxl[KIN];          // DOWN: the block input
+        h8 rb2h, rb2l, rxh[KINP], rxl[KINP];      // RECON: previous block's branch sum and input
+        if constexpr (DOWN) {
+            if constexpr (CIN == 16) {
+                const unsigned o = p * 16 + g * 4;
+                dxh[0] = cat8(*reinterpret_cast<const h4*>(xh + o), *reinterpret_cast<const h4*>(xl + o));
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KIN; ++ks) {
+                    const unsigned o = p * CIN + g * (CIN / 4) + 8 * ks;
+                    dxh[ks] = *reinterpret_cast<const h8*>(xh + o); dxl[ks] = *reinterpret_cast<const h8*>(xl + o);
+                }
+            }
+        }
+        if constexpr (RECON) {
+            h4 ph4[KT], pl4[KT];
+#pragma unroll
+            for (int ct = 0; ct < KT; ++ct) split4(*reinterpret_cast<const f4*>(x2w + (i * KT + ct) * 256), ph4[ct], pl4[ct]);
+            if constexpr (KT == 1) { rb2h = cat8(ph4[0], pl4[0]); rb2l = rb2h; }
+            else { rb2h = cat8(ph4[0], ph4[KT - 1]); rb2l = cat8(pl4[0], pl4[KT - 1]); }
+            if constexpr (PREV_CIN == 16) {
+                const unsigned o = p * 16 + g * 4;
+                rxh[0] = cat8(*reinterpret_cast<const h4*>(xh + o), *reinterpret_cast<const h4*>(xl + o));
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KINP; ++ks) {
+                    const unsigned o = p * PREV_CIN + g * (PREV_CIN / 4) + 8 * ks;
+                    rxh[ks] = *reinterpret_cast<const h8*>(xh + o); rxl[ks] = *reinterpret_cast<const h8*>(xl + o);
+                }
+            }
+        }
+#pragma unroll
+        for (int co = 0; co < NCT; ++co) {
+            f4 acc = *reinterpret_cast<const f4*>(wts + bp.conv3_b + (16 * co + 4 * g) * 4);
+            if constexpr (KT == 1) acc = mm2(w3 + (long)co * HP_FRAG_PAIR, lane, b2h, acc);
+            else acc = mm3(w3 + (long)co * HP_FRAG_PAIR, lane, b2h, b2l, acc);
+            if constexpr (DOWN) {
+                if constexpr (CIN == 16) acc = mm2(wdn + (long)co * HP_FRAG_PAIR, lane, dxh[0], acc);
+                else {
+#pragma unroll
+                    for (int ks = 0; ks < KIN; ++ks) acc = mm3(wdn + (long)(co * KIN + ks) * HP_FRAG_PAIR, lane, dxh[ks], dxl[ks], acc);
+                }
+            } else if constexpr (RECON) {
+                // block input = ReLU(conv3_prev . x2_prev + down_prev . x_prev + bias), rebuilt in fp32 and added as it is
+                f4 ap = *reinterpret_cast<const f4*>(pvb + (16 * co + 4 * g) * 4);
+                if constexpr (KT == 1) ap = mm2(pv3 + (long)co * HP_FRAG_PAIR, lane, rb2h, ap);
+                else ap = mm3(pv3 + (long)co * HP_FRAG_PAIR, lane, rb2h, rb2l, ap);
+                if constexpr (PREV_CIN == 16) ap = mm2(pvd + (long)co * HP_FRAG_PAIR, lane, rxh[0], ap);
+                else {
+#pragma unroll
+                    for (int ks = 0; ks < KINP; ++ks) ap = mm3(pvd + (long)(co * KINP + ks) * HP_FRAG_PAIR, lane, rxh[ks], rxl[ks], ap);
+                }
+                acc += relu4(ap);
+            } else {
+                const unsigned o = p * CIN + g * (CIN / 4) + 4 * co;
+                acc = BM_MFMA_F16_K32(eye, cat8(*reinterpret_cast<const h4*>(xh + o), *reinterpret_cast<const h4*>(xl + o)), acc);
+            }
+            y[co] = relu4(acc);
+        }
+    };
+    if constexpr (EMIT) {
+        // next block's conv1 (COUT -> MID, + bias, ReLU) on the in-register block output
+        constexpr int KSN = COUT / 32;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            f4 y[NCT];
+            block_tile(i, y);
+            h4 yh[NCT], yl[NCT];
+#pragma unroll
+            for (int co = 0; co < NCT; ++co) split4(y[co], yh[co], yl[co]);
+#pragma unroll
+            for (int ct = 0; ct < KT; ++ct) {
+                f4 an = *reinterpret_cast<const f4*>(link.w + link.a1 + (16 * ct + 4 * g) * 4);
+#pragma unroll
+                for (int ks = 0; ks < KSN; ++ks)
+                    an = mm3(link.w + link.a0 + (long)(ks * KT + ct) * HP_FRAG_PAIR, lane, cat8(yh[2 * ks], yh[2 * ks + 1]), cat8(yl[2 * ks], yl[2 * ks + 1]), an);
+                *reinterpret_cast<f4*>(x1w + (i * KT + ct) * 256) = relu4(an);
+                *reinterpret_cast<f4*>(x2w + (i * KT + ct) * 256) = x2[i][ct];
+            }
+            BM_SCHED_FENCE();
+        }
+    } else if constexpr (!TRANS) {
+        _Float16* yh_out = out_h + crop * out_px * COUT;
+        _Float16* yl_out = out_l + crop * out_px * COUT;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const unsigned p = (wave * NT + i) * 16 + l16;
+            f4 y[NCT];
+            block_tile(i, y);
+#pragma unroll
+            for (int co = 0; co < NCT; ++co) {
+                h4 hh, ll;
+                split4(y[co], hh, ll);
+                const unsigned o = p * COUT + g * (COUT / 4) + 4 * co;
+                *reinterpret_cast<h4*>(yh_out + o) = hh;
+                *reinterpret_cast<h4*>(yl_out + o) = ll;
+            }
+            BM_SCHED_FENCE();
+        }
+    } else {
+        // two vertically adjacent tiles: transition conv on the in-register block output, ReLU, 2x2 average (vertical = the
+        // two tiles, horizontal = lane ^ 1; the 1/4 is folded into `wtr`), even lanes store the pooled pixel
+        static_assert(!TRANS || (STAGE < 2 && COUT % 32 == 0), "fused transition: stages 0 and 1");
+        constexpr int KS3 = COUT / 32, WP = G::W / 2;
+        const unsigned char* tbias = wtr + (long)NCT * KS3 * HP_FRAG_PAIR;
+        _Float16* yh_out = out_h + crop * out_px * COUT;
+        _Float16* yl_out = out_l + crop * out_px * COUT;
+#pragma unroll
+        for (int pr = 0; pr < NT / 2; ++pr) {
+            const int i0 = STAGE == 0 ? (pr >> 1) * 4 + (pr & 1) : 2 * pr, i1 = i0 + (STAGE == 0 ? 2 : 1);
+            h4 y0h[NCT], y0l[NCT], y1h[NCT], y1l[NCT];
+            {
+                f4 y[NCT];
+                block_tile(i0, y);
+#pragma unroll
+                for (int co = 0; co < NCT; ++co) split4(y[co], y0h[co], y0l[co]);
+                block_tile(i1, y);
+#pragma unroll
+                for (int co = 0; co < NCT; ++co) split4(y[co], y1h[co], y1l[co]);
+            }
+            const int row = STAGE == 0 ? wave * (NT / 2) + (i0 >> 1) : wave * NT + i0;     // even image row of tile i0
+            const int po = (row >> 1) * WP + (STAGE == 0 ? (i0 & 1) * 8 : 0) + (l16 >> 1);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const f4 bv = *reinterpret_cast<const f4*>(tbias + (16 * ct + 4 * g) * 4);
+                f4 a0 = bv, a1 = bv;
+#pragma unroll
+                for (int ks = 0; ks < KS3; ++ks) {
+                    const unsigned char* a = wtr + (long)(ct * KS3 + ks) * HP_FRAG_PAIR;
+                    a0 = mm3(a, lane, cat8(y0h[2 * ks], y0h[2 * ks + 1]), cat8(y0l[2 * ks], y0l[2 * ks + 1]), a0);
+                    a1 = mm3(a, lane, cat8(y1h[2 * ks], y1h[2 * ks + 1]), cat8(y1l[2 * ks], y1l[2 * ks + 1]), a1);
+                }
+                a0 = relu4(a0); a1 = relu4(a1);
+                f4 sp;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = a0[r] + a1[r];
+                    sp[r] = v + BM_QUAD_SWAP1_F32(v);
+                }
+                if ((l16 & 1) == 0) {
+                    h4 hh, ll;
+                    split4(sp, hh, ll);
+                    const unsigned o = po * COUT + g * (COUT / 4) + 4 * ct;
+                    *reinterpret_cast<h4*>(yh_out + o) = hh;
+                    *reinterpret_cast<h4*>(yl_out + o) = ll;
+                }
+            }
+            BM_SCHED_FENCE();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// head: conv5 (1x1 C->C + ReLU) -> GAP -> FC(C->F) + BN1d + ReLU -> L2 norm (osnet.py:310-315, 393-396; base_backend.py:206)
+// in (hi, lo) [n][128 px][C]; HEAD_NB crops per workgroup of 4 waves: conv5 on (hi, lo) operands (wave w owns output-channel
+// tiles 2w, 2w+1, fragments in registers), bias + ReLU + average in fp32; the FC for the 16 crops as one MFMA tile per 16
+// features with (hi, lo) parts of both the pooled vectors and the weights.
+// ---------------------------------------------------------------------------
+template <int C, int F>
+__global__ void __launch_bounds__(256, 2) k_head_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_l,
+                                                    const unsigned char* __restrict__ wts5, const unsigned char* __restrict__ wfc,
+                                                    float* __restrict__ out_base, const int* __restrict__ out_rows,
+                                                    const int* __restrict__ count, int n_total) {
+    static_assert(C == 128 && F % 64 == 0, "head: 128 channels in, a multiple of 64 features out");
+    constexpr int NCT = C / 16, KS = C / 32, P = 128, NB = HEAD_NB, VS = C + 4;
+    constexpr int FT_PER_WAVE = F / 16 / 4;
+    __shared__ __attribute__((aligned(16))) float vbuf[NB * VS];          // pooled vectors (L-layout channel order)
+    __shared__ float red[4 * NB];
+    int n_eff = n_total;
+    if (count) { const int c = *count; n_eff = c < n_total ? c : n_total; }
+    const long crop0 = (long)blockIdx.x * NB;
+    if (crop0 >= n_eff) return;
+    const int nb = n_eff - crop0 < NB ? (int)(n_eff - crop0) : NB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l16 = lane & 15;
+    const unsigned char* bias5 = wts5 + (long)NCT * KS * HP_FRAG_PAIR;
+    h8 ah[2][KS], al[2][KS];
+    f4 bias[2];
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2) {
+        const int ct = 2 * wave + c2;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            ah[c2][ks] = *reinterpret_cast<const h8*>(wts5 + (long)(ct * KS + ks) * HP_FRAG_PAIR + lane * 16);
+            al[c2][ks] = *reinterpret_cast<const h8*>(wts5 + (long)(ct * KS + ks) * HP_FRAG_PAIR + 1024 + lane * 16);
+        }
+        bias[c2] = *reinterpret_cast<const f4*>(bias5 + (16 * ct + 4 * g) * 4);
+    }
+    for (int e = tid; e < NB * VS; e += 256) vbuf[e] = 0.f;                 // rows of absent crops stay zero
+    __syncthreads();
+#pragma unroll 1
+    for (int k = 0; k < nb; ++k) {
+        const _Float16* xh = in_h + (crop0 + k) * (long)(P * C);
+        const _Float16* xl = in_l + (crop0 + k) * (long)(P * C);
+        f4 sum[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 2
+        for (int i = 0; i < P / 16; ++i) {
+            const int p = i * 16 + l16;
+            h8 bh[KS], bl[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bh[ks] = *reinterpret_cast<const h8*>(xh + p * C + g * (C / 4) + 8 * ks);
+                bl[ks] = *reinterpret_cast<const h8*>(xl + p * C + g * (C / 4) + 8 * ks);
+            }
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                f4 acc = bias[c2];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    acc = BM_MFMA_F16_K32(ah[c2][ks], bh[ks], acc);
+                    acc = BM_MFMA_F16_K32(ah[c2][ks], bl[ks], acc);
+                    acc = BM_MFMA_F16_K32(al[c2][ks], bh[ks], acc);
+                }
+                sum[c2] += relu4(acc);
+            }
+        }
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = sum[c2][r];
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                if (l16 == 0) vbuf[k * VS + g * (C / 4) + 4 * (2 * wave + c2) + r] = v * (1.0f / P);
+            }
+    }
+    __syncthreads();
+    // ---- FC + BN1d (folded) + ReLU for the NB crops: D[f][crop] = sum_c W[f][c] * v[crop][c], (hi, lo) on both sides ----
+    const _Float16* fch = reinterpret_cast<const _Float16*>(wfc);
+    const _Float16* fcl = fch + (long)F * C;
+    const float* fcb = reinterpret_cast<const float*>(wfc + (long)F * C * 4);
+    h8 vh[KS], vl[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const f4 v0 = *reinterpret_cast<const f4*>(vbuf + l16 * VS + 32 * ks + 8 * g);
+        const f4 v1 = *reinterpret_cast<const f4*>(vbuf + l16 * VS + 32 * ks + 8 * g + 4);
+        h4 h0, l0, h1, l1;
+        split4(v0, h0, l0); split4(v1, h1, l1);
+        vh[ks] = cat8(h0, h1); vl[ks] = cat8(l0, l1);
+    }
+    f4 vals[FT_PER_WAVE];
+    float sq = 0.f;
+#pragma unroll
+    for (int fi = 0; fi < FT_PER_WAVE; ++fi) {
+        const int ft = wave * FT_PER_WAVE + fi;
+        f4 acc = *reinterpret_cast<const f4*>(fcb + 16 * ft + 4 * g);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const h8 wh = *reinterpret_cast<const h8*>(fch + (long)(16 * ft + l16) * C + 32 * ks + 8 * g);
+            const h8 wl = *reinterpret_cast<const h8*>(fcl + (long)(16 * ft + l16) * C + 32 * ks + 8 * g);
+            acc = BM_MFMA_F16_K32(wh, vh[ks], acc);
+            acc = BM_MFMA_F16_K32(wh, vl[ks], acc);
+            acc = BM_MFMA_F16_K32(wl, vh[ks], acc);
+        }
+        acc = relu4(acc);
+        vals[fi] = acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sq = __builtin_fmaf(acc[r], acc[r], sq);
+    }
+    sq += __shfl_xor(sq, 16, 64);
+    sq += __shfl_xor(sq, 32, 64);
+    if (lane < 16) red[wave * NB + l16] = sq;
+    __syncthreads();
+    const float nrm = sqrtf(red[l16] + red[NB + l16] + red[2 * NB + l16] + red[3 * NB + l16]);
+    if (l16 < nb) {
+        float* out = out_base + (out_rows ? (long)out_rows[crop0 + l16] : crop0 + l16) * F;
+#pragma unroll
+        for (int fi = 0; fi < FT_PER_WAVE; ++fi) {
+            const int ft = wave * FT_PER_WAVE + fi;
+            f4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = vals[fi][r] / nrm;
+            *reinterpret_cast<f4*>(out + 16 * ft + 4 * g) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// stem: conv 7x7 stride 2 pad 3 (3 -> 16) + BN + ReLU + maxpool 3x3 stride 2 pad 1 (osnet.py:294-295) on (hi, lo) fp16 RGBX
+// crops with a 3-pixel zero border, [n][262][136][4] per plane (k_crop_resize_rgbx with a lo plane); output (hi, lo)
+// [n][64*32][16].  One workgroup (8 waves) per crop; wave w produces pooled rows 8w..8w+7; the 7x7x3 window is 7 k-steps (one
+// per kernel row) of three MFMAs.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(512) k_stem_hp(const _Float16* __restrict__ crops_h, const _Float16* __restrict__ crops_l,
+                                                 _Float16* __restrict__ out_h, _Float16* __restrict__ out_l,
+                                                 const unsigned char* __restrict__ wts, const int* __restrict__ count) {
+    if (count && (int)blockIdx.x >= *count) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l16 = lane & 15;
+    const long crop = blockIdx.x;
+    const _Float16* imh = crops_h + crop * (STEM_ROWS * STEM_COLS * 4);
+    const _Float16* iml = crops_l + crop * (STEM_ROWS * STEM_COLS * 4);
+    _Float16* yh = out_h + crop * (64 * 32) * 16;
+    _Float16* yl = out_l + crop * (64 * 32) * 16;
+    h8 ah[7], al[7];
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky) {
+        ah[ky] = *reinterpret_cast<const h8*>(wts + ky * HP_FRAG_PAIR + lane * 16);
+        al[ky] = *reinterpret_cast<const h8*>(wts + ky * HP_FRAG_PAIR + 1024 + lane * 16);
+    }
+    const f4 bias = *reinterpret_cast<const f4*>(wts + 7 * HP_FRAG_PAIR + 4 * g * 4);
+    auto conv_row = [&](int cy, f4 (&row)[4]) {
+        if (cy < 0 || cy > 127) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) row[t] = f4{0.f, 0.f, 0.f, 0.f};
+            return;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f4 acc = bias;
+            const int cx = t * 16 + l16;
+#pragma unroll
+            for (int ky = 0; ky < 7; ++ky) {
+                const long o = ((long)(2 * cy + ky) * STEM_COLS + 2 * cx + 2 * g) * 4;
+                const h8 bh = *reinterpret_cast<const h8*>(imh + o), bl = *reinterpret_cast<const h8*>(iml + o);
+                acc = BM_MFMA_F16_K32(ah[ky], bh, acc);
+                acc = BM_MFMA_F16_K32(ah[ky], bl, acc);
+                acc = BM_MFMA_F16_K32(al[ky], bh, acc);
+            }
+            row[t] = relu4(acc);
+        }
+    };
+    f4 prev[4], mid[4], next[4];
+    const int oy0 = wave * 8;
+    conv_row(2 * oy0 - 1, prev);
+#pragma unroll 1
+    for (int oy = oy0; oy < oy0 + 8; ++oy) {
+        conv_row(2 * oy, mid);
+        conv_row(2 * oy + 1, next);
+        f4 v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = max4(max4(prev[t], mid[t]), next[t]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f4 m = v[t];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {      // all values are >= 0 (post-ReLU), so a missing neighbour reads as 0
+                const float right = BM_ROW_SHL1_F32(v[t][r]);
+                float left = BM_ROW_SHR1_F32(v[t][r]);
+                const float left_prev_tile = BM_ROW_ROR1_F32(v[t > 0 ? t - 1 : 0][r]);
+                if (l16 == 0) left = t > 0 ? left_prev_tile : 0.f;
+                const float mm = m[r] > right ? m[r] : right;
+                m[r] = mm > left ? mm : left;
+            }
+            if ((l16 & 1) == 0) {
+                const int p = oy * 32 + t * 8 + (l16 >> 1);
+                h4 hh, ll;
+                split4(m, hh, ll);
+                *reinterpret_cast<h4*>(yh + (long)p * 16 + g * 4) = hh;
+                *reinterpret_cast<h4*>(yl + (long)p * 16 + g * 4) = ll;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) prev[t] = next[t];
+    }
+}
+
+// crop -> resize -> normalise into the stem's (hi, lo) fp16 RGBX planes (interior only; border and X channel stay zero)
+__global__ void k_crop_resize_rgbx_hl(const uint8_t* const* frames, const int* crop_stream, const float* boxes, int box_stride, int W,
+                                      int H, const float* lut, _Float16* out_hi, _Float16* out_lo, int rows_per_block, const int* count,
+                                      int pad) {
+    if (count && (int)blockIdx.x >= *count) return;
+    const int i = blockIdx.x;
+    const int dx = threadIdx.x;
+    const uint8_t* frame = frames[crop_stream[i]];
+    const CropRect r = crop_rect(boxes + (long)i * box_stride, W, H);
+    const long row_stride = (long)W * 3;
+    const uint8_t* src = frame + (long)r.y1 * row_stride + r.x1 * 3;
+    const ResizeAxis ax = resize_axis_x(dx, REID_IN_W, r.w > 0 ? r.w : 1);
+    const PadGeom pg = pad_geom(r, REID_IN_W, REID_IN_H);
+    const int y0 = blockIdx.y * rows_per_block;
+    for (int dy = y0; dy < y0 + rows_per_block && dy < REID_IN_H; ++dy) {
+        h4 ph, pl;
+        for (int c = 0; c < 3; ++c) {
+            const int v = preprocess_sample(src, row_stride, r, pg, pad, ax, dy, dx, 2 - c, REID_IN_W, REID_IN_H);
+            const float f = lut[c * 256 + v];
+            ph[c] = (_Float16)f;
+            pl[c] = (_Float16)(f - (float)ph[c]);
+        }
+        ph[3] = (_Float16)0.f; pl[3] = (_Float16)0.f;
+        const long o = (((long)i * STEM_ROWS + dy + 3) * STEM_COLS + dx + 3) * 4;
+        *reinterpret_cast<h4*>(out_hi + o) = ph;
+        *reinterpret_cast<h4*>(out_lo + o) = pl;
+    }
+}
+
+}  // namespace bm

@@ -4,8 +4,8 @@
 ``BaseModelBackend.get_features`` (boxmot/reid/backends/base_backend.py:197-217):
 boxes ``(N, >=4)`` xyxy + a BGR uint8 frame in, ``(N, 512)`` float32
 L2-normalised embeddings out (``np.array([])``-like empty result for no boxes);
-``warmup()`` exists.  Two backbones, chosen by the checkpoint's parameter names: OSNet (512-d; x0.25 has the fused fp16
-MFMA kernel family) and CLIP-ReID ViT-B/16 (1280-d, make_model.py:95-139; crops normalised with mean = std = 0.5 as
+``warmup()`` exists.  Two backbones, chosen by the checkpoint's parameter names: OSNet (512-d; x0.25 has two fused MFMA
+kernel families: fp16 operands (mode 1) and fp32-grade (mode 2, within 1e-3 of the fp32 CPU path on any weights)) and CLIP-ReID ViT-B/16 (1280-d, make_model.py:95-139; crops normalised with mean = std = 0.5 as
 base_backend.py:50-54 does for "clip" models).  Crop / resize / normalise / backbone / L2 all run in HIP
 kernels through the ReID C ABI (include/boxmot_hip.h, replacing
 boxmot/native/cpp/trackers/base/include/boxmot/trackers/base/reid_capi.h:36-94).
@@ -22,6 +22,7 @@ from boxmot_amd.reid_weights import load_weights
 
 MODE_FP32_LAYERWISE = 0
 MODE_FP16_FUSED = 1
+MODE_FP32_FUSED = 2          # fused kernels with fp32-grade arithmetic (fp16 hi + lo operand pairs, fp32 everything else): 1e-3 on any weights
 
 
 class HipReID:

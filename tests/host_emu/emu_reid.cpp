@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../boxmot_amd/csrc/reid_fused.hpp"
+#include "../../boxmot_amd/csrc/reid_hp.hpp"
 
 thread_local EmuDim3 threadIdx;
 thread_local EmuDim3 blockIdx;
@@ -260,6 +261,85 @@ int emu_reid_forward(const float* blob, long n_floats, const float* crops, int n
         const _Float16* in = cur; const unsigned char* p5 = w5.data(); const unsigned char* pf = wfc.data();
         if (g_head_per_crop) launch(n, 1, 128, [=]() { k_head_fused<128, 512>(in, p5, pf, feats, nullptr, nullptr); });
         else launch((n + HEAD_NB - 1) / HEAD_NB, 1, 256, [=]() { k_head_batched<128, 512>(in, p5, pf, feats, nullptr, nullptr, n); });
+    }
+    return 0;
+}
+
+
+// fp32-grade family (reid_hp.hpp, mode 2) as the engine runs it: frame + boxes -> (hi, lo) crops -> stem -> EMIT / RECON stage 0 ->
+// stage 1 -> stage 2 -> head.  stage_out[k] (may be null) receives hi + lo as fp32 natural NHWC after: 0 stem+maxpool, 3 stage-0
+// transition, 4 conv3.0, 6 stage-1 transition, 7 conv4.0, 8 conv4.1.
+int emu_reid_forward_hp(const float* blob, long n_floats, const uint8_t* frame, int W, int H, const float* boxes, int n, float* feats,
+                        float** stage_out) {
+    using namespace bm;
+    const int32_t* hdr = reinterpret_cast<const int32_t*>(blob);
+    if (hdr[0] != REID_MAGIC || hdr[1] != 16) return -1;
+    const int ch[4] = {hdr[1], hdr[2], hdr[3], hdr[4]};
+    const OsnetLayout L = make_osnet_layout(ch, hdr[5]);
+    if (n_floats != REID_HEADER_INTS + L.total) return -2;
+    const float* w = blob + REID_HEADER_INTS;
+    float lut[768];
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    for (int c = 0; c < 3; ++c)
+        for (int v = 0; v < 256; ++v) {
+            volatile float a = (float)v / 255.0f;
+            volatile float b = a - mean[c];
+            lut[c * 256 + v] = b / stdv[c];
+        }
+    std::vector<_Float16> cxh((size_t)n * STEM_ROWS * STEM_COLS * 4, (_Float16)0.f), cxl(cxh.size(), (_Float16)0.f);
+    std::vector<int> streams(n, 0);
+    const uint8_t* frames[1] = {frame};
+    {
+        const uint8_t* const* fr = frames; const int* cs = streams.data(); const float* lp = lut;
+        _Float16 *oh = cxh.data(), *ol = cxl.data();
+        launch(n, REID_IN_H / 16, REID_IN_W, [=]() { k_crop_resize_rgbx_hl(fr, cs, boxes, 4, W, H, lp, oh, ol, 16, nullptr, 0); });
+    }
+    std::vector<_Float16> Ah((size_t)n * 2048 * 32), Al(Ah.size()), Bh(Ah.size()), Bl(Ah.size());
+    std::vector<float> x1s((size_t)n * 2048 * 16), x2s((size_t)n * 2048 * 16);
+    std::vector<uint8_t> wst;
+    pack_stem_hp(w + L.stem_w, w + L.stem_b, wst);
+    {
+        const _Float16 *ih = cxh.data(), *il = cxl.data(); _Float16 *oh = Ah.data(), *ol = Al.data(); const unsigned char* wp = wst.data();
+        launch(n, 1, 512, [=]() { k_stem_hp(ih, il, oh, ol, wp, nullptr); });
+    }
+    auto dump = [&](int slot, const _Float16* h, const _Float16* l, long n_pix, int C) {
+        if (!stage_out || !stage_out[slot]) return;
+        std::vector<float> a((size_t)n_pix * C), b((size_t)n_pix * C);
+        unpack_act(h, a.data(), n_pix, C);
+        unpack_act(l, b.data(), n_pix, C);
+        for (size_t k = 0; k < a.size(); ++k) stage_out[slot][k] = a[k] + b[k];
+    };
+    dump(0, Ah.data(), Al.data(), (long)n * 2048, 16);
+    static const int stage[6] = {0, 0, 1, 1, 2, 2}, cin[6] = {16, 64, 64, 96, 96, 128}, down[6] = {1, 0, 1, 0, 1, 0};
+    BlkPackHP bp[6];
+    std::vector<uint8_t> wb[6], wt[2];
+    for (int b = 0; b < 6; ++b) { bp[b] = make_blk_pack_hp(stage[b], cin[b], down[b]); pack_osblock_hp(w, L.block[b], bp[b], wb[b]); }
+    pack_pointwise_hp(w + L.trans_w[0], w + L.trans_b[0], 64, 64, wt[0], 0.25f);
+    pack_pointwise_hp(w + L.trans_w[1], w + L.trans_b[1], 96, 96, wt[1], 0.25f);
+    float* x1p = x1s.data();
+    auto blk = [&](auto kernel, const _Float16* ih, const _Float16* il, _Float16* oh, _Float16* ol, int b, const unsigned char* wtr, BlkLinkHP link) {
+        const unsigned char* wp = wb[b].data(); const BlkPackHP bpb = bp[b];
+        launch(n, 1, 512, [=]() { kernel(ih, il, oh, ol, wp, bpb, nullptr, x1p, wtr, link); });
+    };
+    blk(k_osblock_hp<0, 16, true, false, true, false>, Ah.data(), Al.data(), nullptr, nullptr, 0, nullptr,
+        BlkLinkHP{wb[1].data(), bp[1].conv1_a, bp[1].conv1_b, 0, x2s.data()});
+    blk(k_osblock_hp<0, 64, false, true, false, true>, Ah.data(), Al.data(), Bh.data(), Bl.data(), 1, wt[0].data(),
+        BlkLinkHP{wb[0].data(), bp[0].conv3_a, bp[0].conv3_b, bp[0].down_a, x2s.data()});
+    dump(3, Bh.data(), Bl.data(), (long)n * 512, 64);
+    blk(k_osblock_hp<1, 64, true, false>, Bh.data(), Bl.data(), Ah.data(), Al.data(), 2, nullptr, BlkLinkHP{});
+    dump(4, Ah.data(), Al.data(), (long)n * 512, 96);
+    blk(k_osblock_hp<1, 96, false, true>, Ah.data(), Al.data(), Bh.data(), Bl.data(), 3, wt[1].data(), BlkLinkHP{});
+    dump(6, Bh.data(), Bl.data(), (long)n * 128, 96);
+    blk(k_osblock_hp<2, 96, true, false>, Bh.data(), Bl.data(), Ah.data(), Al.data(), 4, nullptr, BlkLinkHP{});
+    dump(7, Ah.data(), Al.data(), (long)n * 128, 128);
+    blk(k_osblock_hp<2, 128, false, false>, Ah.data(), Al.data(), Bh.data(), Bl.data(), 5, nullptr, BlkLinkHP{});
+    dump(8, Bh.data(), Bl.data(), (long)n * 128, 128);
+    std::vector<uint8_t> w5, wfc;
+    pack_pointwise_hp(w + L.conv5_w, w + L.conv5_b, 128, 128, w5);
+    pack_fc_hp(w + L.fc_w, w + L.fc_b, 512, 128, wfc);
+    {
+        const _Float16 *ih = Bh.data(), *il = Bl.data(); const unsigned char* p5 = w5.data(); const unsigned char* pf = wfc.data();
+        launch((n + HEAD_NB - 1) / HEAD_NB, 1, 256, [=]() { k_head_hp<128, 512>(ih, il, p5, pf, feats, nullptr, nullptr, n); });
     }
     return 0;
 }

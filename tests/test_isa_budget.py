@@ -20,10 +20,14 @@ def test_hot_kernels_keep_their_register_budget():
     for k, v in stem.items():
         assert v["vgpr"] <= 128 and v["scratch"] == 0, (k, v)               # two crops per CU, no spills
         assert v["mfma"] == 63, (k, v)                                      # strip-wise conv phase: 63 MFMAs per wave and band (84 before)
-    blocks = {k: v for k, v in find("k_osblock").items() if "ILi0E" in k or "ILi1E" in k}
+    blocks = {k: v for k, v in find("k_osblockI").items() if "ILi0E" in k or "ILi1E" in k}        # the fp16-operand family
     assert len(blocks) >= 4
     for k, v in blocks.items():
         assert v["vgpr"] <= 128 and v["scratch"] <= 64, (k, v)              # stages 0 and 1: two crops per CU
+    hp = find("k_osblock_hp")                                                # the fp32-grade family: one 8-wave workgroup per CU in
+    assert len(hp) == 6                                                      # stages 0 / 1 (<= 256 registers), two in stage 2 (<= 128)
+    for k, v in hp.items():
+        assert v["vgpr"] <= (128 if "ILi2E" in k else 256) and v["scratch"] <= 96, (k, v)
     for k, v in find("strongsort_step_kernelILi1024").items():
         assert v["vgpr"] <= 128, (k, v)                                     # 16 waves = 4 per SIMD
     for k, v in find("k_gemm_f16_glds").items():

@@ -44,7 +44,8 @@ def vit_flops(width=768, layers=12, tokens=129, patch_k=768, out_dim=512):
     return 2 * (t - 1) * patch_k * d + layers * (2 * t * d * 3 * d + 4 * t * t * d + 2 * t * d * d + 4 * t * d * 4 * d) + 2 * d * out_dim
 
 
-def run(config: str = "c3", streams: int = 0, steps: int = 40, warmup: int = 8, check_frames: int = -1, reid_mode: int = 1) -> dict:
+def run(config: str = "c3", streams: int = 0, steps: int = 40, warmup: int = 8, check_frames: int = -1, reid_mode: int = 1,
+        with_ecc: bool = True) -> dict:
     """One measurement; returns the result dict (bench.py calls this for its side lines)."""
     import torch
 
@@ -106,7 +107,23 @@ def run(config: str = "c3", streams: int = 0, steps: int = 40, warmup: int = 8, 
         _lib.check(set_mode(h, reid_mode))
     d_out = torch.zeros((T, S, cap, 8), dtype=torch.float32, device=dev)
     d_out_n = torch.zeros((T, S), dtype=torch.int32, device=dev)
-    step = lambda t: _lib.check(step_fn(h, d_dets[t].data_ptr(), d_cnt[t].data_ptr(), ptrs.data_ptr(), H, W, d_out[t].data_ptr(), d_out_n[t].data_ptr()))
+    raw_step = lambda t: _lib.check(step_fn(h, d_dets[t].data_ptr(), d_cnt[t].data_ptr(), ptrs.data_ptr(), H, W, d_out[t].data_ptr(), d_out_n[t].data_ptr()))
+    ecc = None
+    if not c3 and with_ecc:
+        # the reference's StrongSORT estimates camera motion with ECC on every frame that has tracks (strongsort.py:67, 83-86): the
+        # estimator of each stream sees every frame, its warp is set for the step (boxmot_hip_strongsort_set_warp -> camera_update)
+        ecc = lib.boxmot_hip_ecc_create(S, H, W, 0.15, 1e-5, 100)
+        if not ecc:
+            raise RuntimeError(_lib.last_error())
+        warp = np.zeros(6, np.float64)
+        iters = ctypes.c_int(0)
+
+    def step(t):
+        if ecc:
+            for s in range(S):
+                _lib.check(lib.boxmot_hip_ecc_apply_device(ecc, s, frames[s].data_ptr(), warp.ctypes.data, ctypes.byref(iters)))
+                _lib.check(lib.boxmot_hip_strongsort_set_warp(h, s, warp.ctypes.data))
+        raw_step(t)
     ms, nl = ctypes.c_double(0), ctypes.c_int(0)
     for t in range(warmup):
         step(t)
@@ -134,8 +151,13 @@ def run(config: str = "c3", streams: int = 0, steps: int = 40, warmup: int = 8, 
     gates["reid_max_abs_err_vs_fp32_oracle"] = float(np.abs(hr.get_features(bx, scen[0].image) - orc_reid.get_features(bx, scen[0].image)).max())
     hr.close()
     if check:
-        from oracle.deepocsort import DeepOcSortOracle
-        orc = DeepOcSortOracle(reid=orc_reid, lap_rule="lowest_index")
+        # id gate: the oracle tracker with the fp32 oracle backbone inside update on stream 0's first frames (full size)
+        if c3:
+            from oracle.deepocsort import DeepOcSortOracle
+            orc = DeepOcSortOracle(reid=orc_reid)
+        else:
+            from oracle.strongsort import StrongSortOracle
+            orc = StrongSortOracle(reid=orc_reid, dot_rule="device")
         ok = True
         for t in range(check):
             n = cnt_h[t, 0]
@@ -143,12 +165,15 @@ def run(config: str = "c3", streams: int = 0, steps: int = 40, warmup: int = 8, 
             got = out_h[t, 0, : out_n[t, 0]]
             ok = ok and got.shape == want.shape and np.array_equal(np.sort(got[:, 4]), np.sort(want[:, 4]))
         gates["ids_first_frames_vs_oracle_stream0"] = bool(ok)
+        gates["id_gate_frames"] = int(check)
     destroy(h)
+    if ecc:
+        lib.boxmot_hip_ecc_destroy(ecc)
     tfl = crops * flops_per_crop / (ms.value * 1e9) if ms.value > 0 else None
     return {
         "workload": ("DeepOCSORT + OSNet_x1_0 ReID, 128 dets x 512 tracks, 1080p" if c3 else
                      "StrongSORT + CLIP-ReID (ViT-B/16), 256 dets x 1024 tracks, 4K frames, 1280-d"),
-        "mode": "M2 reid-in-update, device-resident inputs", "streams": S, "steps": steps, "warmup": warmup,
+        "mode": "M2 reid-in-update, device-resident inputs" + ("" if c3 else (", ECC estimated per stream-frame on the device (static frames: converges at once)" if with_ecc else ", no camera-motion estimation")), "streams": S, "steps": steps, "warmup": warmup,
         "frames_per_s": S * steps / dt, "ms_per_step": 1e3 * dt / steps, "crops_per_step": crops / steps,
         "reid_forward_ms_per_step": ms.value / steps, "reid_passes": nl.value, "gflop_per_crop": flops_per_crop / 1e9,
         "roofline": {"bound": "hbm (layer-per-launch fp16 kernels)" if c3 else "mfma", "achieved": tfl, "peak": 2500.0, "unit": "TFLOP/s",
@@ -164,8 +189,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--check-frames", type=int, default=-1)
     ap.add_argument("--reid-mode", type=int, default=1)
+    ap.add_argument("--no-ecc", action="store_true", help="c5: skip the per-frame ECC estimate (the reference's StrongSORT always runs it)")
     a = ap.parse_args()
-    print(json.dumps(run(a.config, a.streams, a.steps, a.warmup, a.check_frames, a.reid_mode)), flush=True)
+    print(json.dumps(run(a.config, a.streams, a.steps, a.warmup, a.check_frames, a.reid_mode, not a.no_ecc)), flush=True)
 
 
 if __name__ == "__main__":
