@@ -195,7 +195,7 @@ public:
         for (int i0 = 0; i0 < n; i0 += step) {
             const int m = (n - i0) < step ? (n - i0) : step;
             if (geo_all) obb_geo_ = geo_all + (long)i0 * 8;
-            const bool fuse_stem = mode_ == 1 && fused_ready_ && fuse_stem_ && !pad_ && !obb_geo_;
+            const bool fuse_stem = mode_ >= 1 && fused_ready_ && fuse_stem_ && !pad_ && !obb_geo_;
             if (!fuse_stem) preprocess(d_frames, d_crop_stream + i0, d_boxes + (long)i0 * box_stride, box_stride, m, W, H, st);
             if (i0 == 0) BM_HIP(hipEventRecord(ev_[1], st));
             hipEvent_t a = take_event(), b = take_event();
@@ -204,10 +204,10 @@ public:
             const int* orow = d_out_rows ? d_out_rows + i0 : nullptr;
             if (clip_) clip_->forward(crops_, m, o, orow, st);
             else if (wide) wide_->forward(m, o, orow, st);
-            else if (mode_ == 2) forward_hp(m, o, orow, st);
-            else if (mode_ == 1) {
+            else if (mode_ >= 1) {
                 const FrameArgs fa{d_frames, d_crop_stream + i0, d_boxes + (long)i0 * box_stride, box_stride, W, H};
-                forward_fused(m, fuse_stem ? &fa : nullptr, o, orow, st);
+                if (mode_ == 2) forward_hp(m, fuse_stem ? &fa : nullptr, o, orow, st);
+                else forward_fused(m, fuse_stem ? &fa : nullptr, o, orow, st);
             } else forward_v1(m, o, orow, st);
             BM_HIP(hipEventRecord(b, st));
             if (pending_.size() < 4096) pending_.emplace_back(a, b);
@@ -226,13 +226,13 @@ public:
         if (n_max == 0) return;
         d_count_ = d_count;
         BM_HIP(hipEventRecord(ev_[0], st));
-        const bool fuse_stem = mode_ == 1 && fuse_stem_ && !pad_;
+        const bool fuse_stem = fuse_stem_ && !pad_;
         if (!fuse_stem) preprocess(d_frames, d_crop_stream, d_boxes, box_stride, n_max, W, H, st);
         BM_HIP(hipEventRecord(ev_[1], st));
         hipEvent_t a = take_event(), b = take_event();
         BM_HIP(hipEventRecord(a, st));
         const FrameArgs fa{d_frames, d_crop_stream, d_boxes, box_stride, W, H};
-        if (mode_ == 2) forward_hp(n_max, d_out, d_out_rows, st);
+        if (mode_ == 2) forward_hp(n_max, fuse_stem ? &fa : nullptr, d_out, d_out_rows, st);
         else forward_fused(n_max, fuse_stem ? &fa : nullptr, d_out, d_out_rows, st);
         BM_HIP(hipEventRecord(b, st));
         if (pending_.size() < 4096) pending_.emplace_back(a, b);
@@ -455,6 +455,12 @@ private:
         std::vector<uint8_t> buf;
         pack_stem_hp(w + L_.stem_w, w + L_.stem_b, buf);
         hw_stem_ = upload(buf);
+        {
+            const float mean_i[3] = {0.485f, 0.456f, 0.406f}, std_i[3] = {0.229f, 0.224f, 0.225f};     // base_backend.py:189-193
+            pack_stem_hp_fused(w + L_.stem_w, w + L_.stem_b, mean_i, std_i, buf);
+            hw_stem_fused_ = upload(buf);
+        }
+        allow_lds(k_stem_resize_fused_hp, STEM2_LDS);
         static const int stage[6] = {0, 0, 1, 1, 2, 2}, cin[6] = {16, 64, 64, 96, 96, 128}, down[6] = {1, 0, 1, 0, 1, 0};
         for (int b = 0; b < 6; ++b) {
             hbp_[b] = make_blk_pack_hp(stage[b], cin[b], down[b]);
@@ -481,8 +487,12 @@ private:
         allow_lds(k_osblock_hp<2, 128, false, false>, GeoHP<2>::LDS_BYTES);
         hp_ready_ = true;
     }
-    void forward_hp(int n, float* d_out, const int* d_out_rows, hipStream_t st) {
-        hipLaunchKernelGGL(k_stem_hp, dim3(n), dim3(512), 0, st, crops_h_, crops_l_, act_a_, hact_al_, hw_stem_, d_count_);
+    void forward_hp(int n, const FrameArgs* fa, float* d_out, const int* d_out_rows, hipStream_t st) {
+        if (fa)     // crop + resize + normalise fused into the stem on raw pixel values (the resized crop never reaches HBM)
+            hipLaunchKernelGGL(k_stem_resize_fused_hp, dim3(n), dim3(512), STEM2_LDS, st, fa->frames, fa->crop_stream, fa->boxes,
+                               fa->box_stride, fa->W, fa->H, act_a_, hact_al_, hw_stem_fused_, d_count_);
+        else
+            hipLaunchKernelGGL(k_stem_hp, dim3(n), dim3(512), 0, st, crops_h_, crops_l_, act_a_, hact_al_, hw_stem_, d_count_);
         auto blk = [&](auto kernel, int lds, const _Float16* ih, const _Float16* il, _Float16* oh, _Float16* ol, int b,
                        const unsigned char* wtr, BlkLinkHP link) {
             hipLaunchKernelGGL(kernel, dim3(n), dim3(512), lds, st, ih, il, oh, ol, hw_blk_[b], hbp_[b], d_count_, hx1s_, wtr, link);
@@ -546,7 +556,7 @@ private:
     // fused fp32-grade path (allocated when mode 2 is first selected)
     bool hp_ready_ = false;
     BlkPackHP hbp_[6];
-    unsigned char* hw_stem_ = nullptr;
+    unsigned char *hw_stem_ = nullptr, *hw_stem_fused_ = nullptr;
     unsigned char* hw_blk_[6] = {};
     unsigned char* hw_tr_[2] = {};
     unsigned char *hw_c5_ = nullptr, *hw_fc_ = nullptr;

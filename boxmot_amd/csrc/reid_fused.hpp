@@ -111,6 +111,7 @@ __device__ unsigned long long g_osblock_prof[8];
 #endif
 
 __device__ inline h4 to_h4(f4 v) { return h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]}; }
+__device__ inline h4 residual_h4(f4 v, h4 h) { return h4{(_Float16)(v[0] - (float)h[0]), (_Float16)(v[1] - (float)h[1]), (_Float16)(v[2] - (float)h[2]), (_Float16)(v[3] - (float)h[3])}; }
 __device__ inline f4 relu4(f4 v) { return f4{BM_RELU_F32(v[0]), BM_RELU_F32(v[1]), BM_RELU_F32(v[2]), BM_RELU_F32(v[3])}; }
 __device__ inline h4 relu_h4(h4 v) { return __builtin_elementwise_max(v, (h4)(_Float16)0.f); }
 __device__ inline h4 fma_h4(h4 a, h4 b, h4 c) { return __builtin_elementwise_fma(a, b, c); }
@@ -1110,9 +1111,17 @@ constexpr int STEM_EDGE_BYTES = BM_STEM_STREAM ? 2 * 2 * 4 * 4 * 16 * 4 : 0;   /
 constexpr int STEM_LUT_BYTES = 768 * 4;                          // normalisation table, 4-byte entries (fp16 in the low half)
 constexpr int STEM2_LDS = RING_ROWS * RING_ROW_BYTES + SRC_STAGE_BYTES + STEM_LUT_BYTES + 256 * 8 + STEM_EDGE_BYTES;   // ring, staging, LUT, y table, edges
 
-__global__ void __launch_bounds__(512, 4) k_stem_resize_fused(const uint8_t* const* frames, const int* crop_stream,
+// HP (the fp32-grade family, reid_hp.hpp): a pixel byte v is EXACT in fp16, and the normalisation (v / 255 - mean) / std = a v + b
+// is linear, so it is folded into the weights on the host (pack_stem_hp_fused): the ring holds [R, G, B, 1] raw values (the
+// fourth channel carries the bias term b of real pixels and is 0 in the zero padding, which reproduces the reference's zero
+// padding of the NORMALISED image exactly), the weights are fp16 (hi, lo) pairs -- the lo fragment pre-scaled by 2^11 and
+// multiplied with the operand scaled by 2^-11 (both exact) so that it stays in fp16's normal range -- two MFMAs per k-step into
+// the same fp32 accumulator; the pooled result leaves as an fp16 (hi, lo) pair of planes.  One workgroup per CU (the second
+// fragment set does not fit 128 registers).
+template <bool HP>
+__device__ __forceinline__ void stem_resize_fused_body(const uint8_t* const* frames, const int* crop_stream,
                                                            const float* boxes, int box_stride, int W, int H,
-                                                           const float* lut, _Float16* __restrict__ out,
+                                                           const float* lut, _Float16* __restrict__ out, _Float16* __restrict__ out_lo,
                                                            const unsigned char* __restrict__ wts,
                                                            const int* __restrict__ count) {
     if (count && (int)blockIdx.x >= *count) return;
@@ -1127,17 +1136,21 @@ __global__ void __launch_bounds__(512, 4) k_stem_resize_fused(const uint8_t* con
     const CropRect r = crop_rect(boxes + crop * box_stride, W, H);
     const long row_stride = (long)W * 3;
     _Float16* yout = out + crop * (64 * 32) * 16;
-    for (int e = tid; e < 768; e += 512) { lut_h[2 * e] = (_Float16)lut[e]; lut_h[2 * e + 1] = (_Float16)0.f; }      // 4-byte entries
+    _Float16* yout_lo = HP ? out_lo + crop * (64 * 32) * 16 : nullptr;
+    for (int e = tid; e < 768; e += 512) { lut_h[2 * e] = HP ? (_Float16)(float)(e & 255) : (_Float16)lut[e]; lut_h[2 * e + 1] = (_Float16)0.f; }      // 4-byte entries
     if (tid < REID_IN_H) {      // vertical taps of every resized row, once per crop
         const ResizeAxis ay = resize_axis_y(tid, REID_IN_H, r.h > 0 ? r.h : 1);
         ytab[2 * tid] = (unsigned)ay.s0 | ((unsigned)ay.s1 << 16);
         ytab[2 * tid + 1] = (unsigned)ay.a0 | ((unsigned)ay.a1 << 16);
     }
     for (int e = tid * 8; e < RING_ROWS * RING_ROW_BYTES; e += 512 * 8) *reinterpret_cast<unsigned long long*>(ring + e) = 0ull;
-    h8 a[7];
+    h8 a[7], a_lo[HP ? 7 : 1];
 #pragma unroll
-    for (int ky = 0; ky < 7; ++ky) a[ky] = *reinterpret_cast<const h8*>(wts + (ky * 64 + lane) * 16);
-    const f4 bias = *reinterpret_cast<const f4*>(wts + 7 * 1024 + 4 * g * 4);
+    for (int ky = 0; ky < 7; ++ky) {
+        a[ky] = *reinterpret_cast<const h8*>(wts + ((HP ? 2 * ky : ky) * 64 + lane) * 16);
+        if constexpr (HP) a_lo[ky] = *reinterpret_cast<const h8*>(wts + ((2 * ky + 1) * 64 + lane) * 16);
+    }
+    const f4 bias = *reinterpret_cast<const f4*>(wts + (HP ? 14 : 7) * 1024 + 4 * g * 4);
     // resampling role of this thread: output column dx, row phase rp (4 threads per column)
     const int dx = tid & 127, rp = tid >> 7;
     const ResizeAxis ax = resize_axis_x(dx, REID_IN_W, r.w > 0 ? r.w : 1);
@@ -1249,7 +1262,7 @@ __global__ void __launch_bounds__(512, 4) k_stem_resize_fused(const uint8_t* con
                         px3[c] = *reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned char*>(lut_w + c * 256) + v4);
                     }
                     lo = (px3[0] & 0xffffu) | (px3[1] << 16);
-                    hi = px3[2] & 0xffffu;
+                    hi = (px3[2] & 0xffffu) | (HP ? 0x3C000000u : 0u);          // HP: fourth channel = 1.0 on real pixels
                 }
                 *reinterpret_cast<unsigned long long*>(dst) = ((unsigned long long)hi << 32) | lo;
                 dst += RING_ROW_BYTES;
@@ -1283,6 +1296,7 @@ __global__ void __launch_bounds__(512, 4) k_stem_resize_fused(const uint8_t* con
                     }
                     px[c] = lut_h[2 * (c * 256 + v)];
                 }
+                if constexpr (HP) px[3] = (_Float16)1.f;
             }
             *reinterpret_cast<h4*>(ring + (pr % RING_ROWS) * RING_ROW_BYTES + (dx + 3) * 8) = px;
         }
@@ -1303,11 +1317,14 @@ __global__ void __launch_bounds__(512, 4) k_stem_resize_fused(const uint8_t* con
                 if (oy0 == 0 && jlo == 0 && jhi == 0) continue;         // only conv row -1 (outside the image) reads these rows
                 const int slot = (rbase + i + RING_ROWS) % RING_ROWS;
                 const h8 b = *reinterpret_cast<const h8*>(bcol + slot * RING_ROW_BYTES);
+                h8 b_s;
+                if constexpr (HP) b_s = b * (_Float16)0.00048828125f;       // 2^-11: exact on byte values and on 1.0
 #pragma unroll
                 for (int j = jlo; j <= jhi; ++j) {
                     if (j == 0 && oy0 == 0) continue;                   // wave-uniform
                     const int ky = i - 2 * j;
                     acc[j] = BM_MFMA_F16_K32(a[ky], b, ky == 0 ? bias : acc[j]);
+                    if constexpr (HP) acc[j] = BM_MFMA_F16_K32(a_lo[ky], b_s, acc[j]);
                 }
             }
             float* edge = reinterpret_cast<float*>(stage + SRC_STAGE_BYTES + STEM_LUT_BYTES + 256 * 8) + (((band & 1) * 2 + half) * 4) * (4 * 16);
@@ -1328,7 +1345,9 @@ __global__ void __launch_bounds__(512, 4) k_stem_resize_fused(const uint8_t* con
                 }
                 if ((l16 & 1) == 0 && l16 != 0) {
                     const int p = (oy0 + p4) * 32 + t * 8 + (l16 >> 1);
-                    *reinterpret_cast<h4*>(yout + (long)p * 16 + g * 4) = to_h4(m[p4]);
+                    const h4 hh = to_h4(m[p4]);
+                    *reinterpret_cast<h4*>(yout + (long)p * 16 + g * 4) = hh;
+                    if constexpr (HP) *reinterpret_cast<h4*>(yout_lo + (long)p * 16 + g * 4) = residual_h4(m[p4], hh);
                 }
             }
             BM_PROF(5);
@@ -1339,11 +1358,14 @@ __global__ void __launch_bounds__(512, 4) k_stem_resize_fused(const uint8_t* con
                 for (int p4 = 0; p4 < 4; ++p4) {
                     if (t > 0) m[p4] = max4(m[p4], *reinterpret_cast<const f4*>(edge + ((t - 1) * 4 + p4) * 16 + g * 4));
                     const int p = (oy0 + p4) * 32 + t * 8;
-                    *reinterpret_cast<h4*>(yout + (long)p * 16 + g * 4) = to_h4(m[p4]);
+                    const h4 hh = to_h4(m[p4]);
+                    *reinterpret_cast<h4*>(yout + (long)p * 16 + g * 4) = hh;
+                    if constexpr (HP) *reinterpret_cast<h4*>(yout_lo + (long)p * 16 + g * 4) = residual_h4(m[p4], hh);
                 }
             }
         }
 #else
+        static_assert(!HP, "the fp32-grade stem exists for the strip-wise conv phase (BM_STEM_STREAM)");
         // ---- 3. conv rows + pooling for pooled row oy ----
         const int oy = 8 * band + wave;
         f4 vprev = f4{0.f, 0.f, 0.f, 0.f};       // vertical max of the previous tile (for the left neighbour of lane 0)
@@ -1385,6 +1407,19 @@ __global__ void __launch_bounds__(512, 4) k_stem_resize_fused(const uint8_t* con
         BM_PROF(7);
     }
     BM_PROF_FLUSH();
+}
+
+__global__ void __launch_bounds__(512, 4) k_stem_resize_fused(const uint8_t* const* frames, const int* crop_stream, const float* boxes,
+                                                           int box_stride, int W, int H, const float* lut, _Float16* __restrict__ out,
+                                                           const unsigned char* __restrict__ wts, const int* __restrict__ count) {
+    stem_resize_fused_body<false>(frames, crop_stream, boxes, box_stride, W, H, lut, out, nullptr, wts, count);
+}
+// the fp32-grade family's stem: (hi, lo) output planes, weights from pack_stem_hp_fused
+__global__ void __launch_bounds__(512, 2) k_stem_resize_fused_hp(const uint8_t* const* frames, const int* crop_stream, const float* boxes,
+                                                              int box_stride, int W, int H, _Float16* __restrict__ out_hi,
+                                                              _Float16* __restrict__ out_lo, const unsigned char* __restrict__ wts,
+                                                              const int* __restrict__ count) {
+    stem_resize_fused_body<true>(frames, crop_stream, boxes, box_stride, W, H, nullptr, out_hi, out_lo, wts, count);
 }
 
 // crop -> resize -> normalise into the stem's fp16 RGBX layout (interior only; the 3-pixel border and the

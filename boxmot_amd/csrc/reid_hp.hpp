@@ -22,6 +22,11 @@
 #include "reid_fused.hpp"
 #include "reid_hp_pack.hpp"
 
+// stage-2 blocks: 4 = two workgroups per CU at <= 128 registers (spills ~35), 2 = one workgroup per CU at <= 256 (A/B switch)
+#ifndef BM_HP_S2_WPS
+#define BM_HP_S2_WPS 4
+#endif
+
 namespace bm {
 
 template <int STAGE>
@@ -37,12 +42,25 @@ struct GeoHP {
     static constexpr int NT = P / 16 / NWAVES;                       // 16, 4, 1 pixel tiles per wave
     // stages 0 / 1: one workgroup per CU (the fp32 image is 141 / 78 KiB): two waves per SIMD, 256 registers each;
     // stage 2: two workgroups per CU
-    static constexpr int WAVES_PER_SIMD = STAGE == 2 ? 4 : 2;
-    static constexpr int ROWP = STAGE == 0 ? 34 * 16 : (STAGE == 1 ? 18 * 16 : 384);     // stage 2: 8-pixel rows, pitch = 8 slots mod 16
-    static constexpr int PLANE = STAGE == 0 ? 141 * 256 : (STAGE == 1 ? 39 * 256 : 28 * 256);
+    static constexpr int WAVES_PER_SIMD = STAGE == 2 ? BM_HP_S2_WPS : 2;
+    // stage 2 (8-pixel rows): compact pitch (10 pixels): 2-way conflicts between the two rows of a tile, but two workgroups per CU
+    static constexpr int ROWP = STAGE == 0 ? 34 * 16 : (STAGE == 1 ? 18 * 16 : 160);
+    static constexpr int PLANE = STAGE == 0 ? 141 * 256 : (STAGE == 1 ? 39 * 256 : 12 * 256);
     static constexpr int IMG = 4 * KT * PLANE;
-    static constexpr int LDS_BYTES = IMG + 4 * NWAVES * HID * 4;
+    // LightConv weights of the whole block, staged once into LDS behind the image: no global load (and no exposed L2 / fabric
+    // round trip) inside the 10-layer loop.  Stages 1 / 2: everything (1x1 fragment pairs, depthwise taps, biases = the packed
+    // blob's light records); stage 0 has 19 KiB left beside its 141 KiB image: depthwise taps + biases only, the 1x1 fragments
+    // are requested a layer ahead into registers.
+    static constexpr bool W_ALL = STAGE != 0;
+    static constexpr int LIGHT_BYTES = KT * 2048 + MIDP * 9 * 4 + MIDP * 4;         // = BlkPackHP::light_bytes
+    static constexpr int WREC = W_ALL ? LIGHT_BYTES : MIDP * 9 * 4 + MIDP * 4;      // bytes staged per LightConv
+    static constexpr int GATE_BYTES = ((HID * MIDP * 4 + 15) / 16 + (HID * 4 + 15) / 16 + (MIDP * HID * 4 + 15) / 16 + (MIDP * 4 + 15) / 16) * 16;   // fc1_w, fc1_b, fc2_w, fc2_b
+    static constexpr int WBYTES = 10 * WREC + GATE_BYTES;          // + the ChannelGate's weights (no global load in the gate either)
+    // the epilogue stages its A fragments over the (then dead) image and weights; stage 2's downsample block needs 66048 bytes
+    static constexpr int TBUF = IMG + WBYTES;
+    static constexpr int LDS_BYTES = TBUF + 4 * NWAVES * HID * 4;
     static_assert(PLANE >= (H + 2) * ROWP && PLANE % 256 == 0, "plane holds the haloed image; stride keeps the lane groups on disjoint slots");
+    static_assert(LDS_BYTES <= 163840 / (STAGE == 2 ? 2 : 1), "LDS budget");
 };
 
 __device__ inline f4 fma_f4(f4 a, f4 b, f4 c) { return __builtin_elementwise_fma(a, b, c); }
@@ -62,6 +80,18 @@ __device__ inline f4 mm3(const unsigned char* a, int lane, h8 bh, h8 bl, f4 acc)
 // K = 16 layer in the duplicated form: b = [xh | xl] against [Wh | Wh] and [Wl | Wl]
 __device__ inline f4 mm2(const unsigned char* a, int lane, h8 b, f4 acc) {
     const h8 ah = *reinterpret_cast<const h8*>(a + lane * 16), al = *reinterpret_cast<const h8*>(a + 1024 + lane * 16);
+    acc = BM_MFMA_F16_K32(ah, b, acc);
+    acc = BM_MFMA_F16_K32(al, b, acc);
+    return acc;
+}
+
+__device__ inline f4 mm3r(h8 ah, h8 al, h8 bh, h8 bl, f4 acc) {
+    acc = BM_MFMA_F16_K32(ah, bh, acc);
+    acc = BM_MFMA_F16_K32(ah, bl, acc);
+    acc = BM_MFMA_F16_K32(al, bh, acc);
+    return acc;
+}
+__device__ inline f4 mm2r(h8 ah, h8 al, h8 b, f4 acc) {
     acc = BM_MFMA_F16_K32(ah, b, acc);
     acc = BM_MFMA_F16_K32(al, b, acc);
     return acc;
@@ -95,7 +125,8 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
     constexpr bool X1_REG = !RECOMP && !X1_MEM;
     BM_DYNAMIC_LDS_T(unsigned char, lds);
     unsigned char* tbuf = lds;
-    float* gap_part = reinterpret_cast<float*>(lds + G::IMG);       // [4 branches][NWAVES][HID]
+    unsigned char* wl = lds + G::IMG;           // staged LightConv weights, record l at wl + l * WREC
+    float* gap_part = reinterpret_cast<float*>(lds + G::TBUF);      // [4 branches][NWAVES][HID]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l16 = lane & 15;
     const long crop = blockIdx.x;
@@ -103,7 +134,7 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
     const _Float16* xl = in_l + crop * P * (RECON ? PREV_CIN : CIN);
     const long out_px = TRANS ? P / 4 : P;
 
-    for (int e = tid * 16; e < G::IMG; e += 64 * G::NWAVES * 16) *reinterpret_cast<f4*>(tbuf + e) = f4{0.f, 0.f, 0.f, 0.f};   // halo = zero padding
+    BM_PROF_DECL();
 
     // this lane's pixel of tile 0 inside plane (ct = 0, g); tile i and channel tile ct add compile-time constants
     const int y_l = STAGE == 0 ? wave * 8 : (STAGE == 1 ? wave * 4 : 2 * wave + (l16 >> 3));
@@ -139,23 +170,35 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
                 x1[i][0] = relu4(acc);
             }
         } else {
+            // fragment pairs [ks][ct] staged into LDS (the image area is not in use yet); the B operands of tile i + 1 are
+            // requested before tile i computes
+            for (int e = tid * 16; e < KIN * KT * (int)HP_FRAG_PAIR; e += 64 * G::NWAVES * 16)
+                *reinterpret_cast<f4*>(tbuf + e) = *reinterpret_cast<const f4*>(wts + bp.conv1_a + e);
+            h8 bh[2][KIN], bl[2][KIN];
+            auto loads = [&](int i, h8 (&h)[KIN], h8 (&l)[KIN]) {
+                const unsigned p = (wave * NT + i) * 16 + l16;
+#pragma unroll
+                for (int ks = 0; ks < KIN; ++ks) {
+                    const unsigned o = p * CIN + g * (CIN / 4) + 8 * ks;
+                    h[ks] = *reinterpret_cast<const h8*>(xh + o); l[ks] = *reinterpret_cast<const h8*>(xl + o);
+                }
+            };
+            loads(0, bh[0], bl[0]);
+            __syncthreads();
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
-                const unsigned p = (wave * NT + i) * 16 + l16;
+                if (i + 1 < NT) loads(i + 1, bh[(i + 1) & 1], bl[(i + 1) & 1]);
                 f4 acc[KT];
 #pragma unroll
                 for (int ct = 0; ct < KT; ++ct) acc[ct] = bias[ct];
 #pragma unroll
-                for (int ks = 0; ks < KIN; ++ks) {
-                    const unsigned o = p * CIN + g * (CIN / 4) + 8 * ks;
-                    const h8 bh = *reinterpret_cast<const h8*>(xh + o), bl = *reinterpret_cast<const h8*>(xl + o);
+                for (int ks = 0; ks < KIN; ++ks)
 #pragma unroll
-                    for (int ct = 0; ct < KT; ++ct) acc[ct] = mm3(wts + bp.conv1_a + (long)(ks * KT + ct) * HP_FRAG_PAIR, lane, bh, bl, acc[ct]);
-                }
+                    for (int ct = 0; ct < KT; ++ct) acc[ct] = mm3(tbuf + (long)(ks * KT + ct) * HP_FRAG_PAIR, lane, bh[i & 1][ks], bl[i & 1][ks], acc[ct]);
 #pragma unroll
                 for (int ct = 0; ct < KT; ++ct) x1[i][ct] = relu4(acc[ct]);
-                if (i & 1) BM_SCHED_FENCE();
             }
+            __syncthreads();            // every wave is done with the staged fragments before the image is zeroed over them
         }
     };
     f4 x1[X1_REG ? NT : 1][KT];
@@ -169,27 +212,51 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
             for (int ct = 0; ct < KT; ++ct) *reinterpret_cast<f4*>(x1w + (i * KT + ct) * 256) = t[i][ct];
     }
 
-    // 1x1 (linear, mid -> mid) of LightConv `lw` on the fp32 tile set: operands split in registers
-    auto pointwise = [&](const unsigned char* lw, f4 (&c)[KT]) {
+    // 1x1 (linear, mid -> mid) of a LightConv on the fp32 tile set: weight fragments held in registers for the layer, operands
+    // split in registers
+    auto load_pw = [&](int l, h8 (&A)[KT][2]) {         // 1x1 fragment pairs of LightConv l (0..9)
+        const unsigned char* src = G::W_ALL ? wl + l * G::WREC : wts + bp.light0 + (long)l * bp.light_bytes + bp.light_pw;
+#pragma unroll
+        for (int ct = 0; ct < KT; ++ct) {
+            A[ct][0] = *reinterpret_cast<const h8*>(src + (long)ct * HP_FRAG_PAIR + lane * 16);
+            A[ct][1] = *reinterpret_cast<const h8*>(src + (long)ct * HP_FRAG_PAIR + 1024 + lane * 16);
+        }
+    };
+    auto pointwise = [&](const h8 (&A)[KT][2], f4 (&c)[KT]) {
         h4 hh[KT], ll[KT];
 #pragma unroll
         for (int ct = 0; ct < KT; ++ct) split4(c[ct], hh[ct], ll[ct]);
         const f4 z = f4{0.f, 0.f, 0.f, 0.f};
         if constexpr (KT == 1) {
-            c[0] = mm2(lw + bp.light_pw, lane, cat8(hh[0], ll[0]), z);
+            c[0] = mm2r(A[0][0], A[0][1], cat8(hh[0], ll[0]), z);
         } else {
-            const h8 bh = cat8(hh[0], hh[1]), bl = cat8(ll[0], ll[1]);
+            const h8 bh = cat8(hh[0], hh[KT - 1]), bl = cat8(ll[0], ll[KT - 1]);
 #pragma unroll
-            for (int ct = 0; ct < KT; ++ct) c[ct] = mm3(lw + bp.light_pw + (long)ct * HP_FRAG_PAIR, lane, bh, bl, z);
+            for (int ct = 0; ct < KT; ++ct) c[ct] = mm3r(A[ct][0], A[ct][1], bh, bl, z);
         }
     };
 
+    for (int e = tid * 16; e < G::IMG; e += 64 * G::NWAVES * 16) *reinterpret_cast<f4*>(tbuf + e) = f4{0.f, 0.f, 0.f, 0.f};   // halo = zero padding
+    if constexpr (G::W_ALL) {           // light records and gate weights are contiguous in the packed blob
+        for (int e = tid * 16; e < G::WBYTES; e += 64 * G::NWAVES * 16)
+            *reinterpret_cast<f4*>(wl + e) = *reinterpret_cast<const f4*>(wts + bp.light0 + e);
+    } else {
+        for (int e = tid * 16; e < 10 * G::WREC; e += 64 * G::NWAVES * 16) {
+            const int l = e / G::WREC, o = e - l * G::WREC;
+            *reinterpret_cast<f4*>(wl + e) = *reinterpret_cast<const f4*>(wts + bp.light0 + (long)l * bp.light_bytes + bp.light_dw + o);
+        }
+        for (int e = tid * 16; e < G::GATE_BYTES; e += 64 * G::NWAVES * 16)
+            *reinterpret_cast<f4*>(wl + 10 * G::WREC + e) = *reinterpret_cast<const f4*>(wts + bp.fc1_w + e);
+    }
+    const unsigned char* wgate = wl + 10 * G::WREC;                 // gate weights: fc1_w at +0, then fc1_b, fc2_w, fc2_b as in the blob
+    const int g_fc1b = (int)(bp.fc1_b - bp.fc1_w), g_fc2w = (int)(bp.fc2_w - bp.fc1_w), g_fc2b = (int)(bp.fc2_b - bp.fc1_w);
     f4 x2[NT][KT];          // gated sum of the four branches
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int ct = 0; ct < KT; ++ct) x2[i][ct] = f4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
+    BM_PROF(0);
 
     int li = 0;
 #pragma unroll 1
@@ -210,29 +277,43 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
                 for (int ct = 0; ct < KT; ++ct) cur[i][ct] = x1[i][ct];
         }
         // `cur` holds, in turn: the branch input, the 1x1 output of the layer about to run its depthwise pass, the layer output
+        h8 An[KT][2];           // fragments of the NEXT layer's 1x1 (stage 0: requested a layer ahead of their use)
         {
-            const unsigned char* lw0 = wts + bp.light0 + (long)li * bp.light_bytes;
+            h8 A0[KT][2];
+            load_pw(li, A0);
+            if (br > 0) load_pw(li + 1, An);
 #pragma unroll
-            for (int i = 0; i < NT; ++i) pointwise(lw0, cur[i]);
+            for (int i = 0; i < NT; ++i) pointwise(A0, cur[i]);
         }
+        BM_PROF(1);
 #pragma unroll 1
         for (int k = 0; k <= br; ++k, ++li) {
-            const unsigned char* lw = wts + bp.light0 + (long)li * bp.light_bytes;
-            const unsigned char* lw_next = lw + bp.light_bytes;
             const bool more = k < br;
+            // depthwise taps and bias of this layer: from the staged weights (LDS)
+            const unsigned char* wdl = wl + li * G::WREC + (G::W_ALL ? KT * 2048 : 0);
+            constexpr int NWD = STAGE == 2 ? 1 : KT;          // depthwise tap sets in flight (stage 2 has 128 registers)
+            f4 wdv[NWD][9], dbias[NWD];
+            auto load_dw = [&](int ct, f4 (&wd)[9], f4& bias) {
+                const f4* wsrc = reinterpret_cast<const f4*>(wdl) + (ct * 4 + g) * 9;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) wd[tap] = wsrc[tap];
+                bias = *reinterpret_cast<const f4*>(wdl + MIDP * 9 * 4 + (16 * ct + 4 * g) * 4);
+            };
+#pragma unroll
+            for (int c = 0; c < NWD; ++c) load_dw(c, wdv[c], dbias[c]);
 #pragma unroll
             for (int i = 0; i < NT; ++i)
 #pragma unroll
                 for (int ct = 0; ct < KT; ++ct) *reinterpret_cast<f4*>(tbuf + pix0 + ct * 4 * G::PLANE + tile_off(i)) = cur[i][ct];
+            BM_PROF(2);
             __syncthreads();
+            BM_PROF(3);
             // depthwise 3x3 (pad 1) + bias + ReLU
 #pragma unroll
             for (int ct = 0; ct < KT; ++ct) {
-                f4 wd[9];
-                const f4* wsrc = reinterpret_cast<const f4*>(lw + bp.light_dw) + (ct * 4 + g) * 9;
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap) wd[tap] = wsrc[tap];
-                const f4 bias = *reinterpret_cast<const f4*>(lw + bp.light_b + (16 * ct + 4 * g) * 4);
+                if constexpr (NWD < KT) { if (ct > 0) load_dw(ct, wdv[0], dbias[0]); }
+                const f4 (&wd)[9] = wdv[NWD < KT ? 0 : ct];
+                const f4 bias = dbias[NWD < KT ? 0 : ct];
                 const unsigned char* cbase = tbuf + pix0 + ct * 4 * G::PLANE;
                 if constexpr (STAGE == 2) {
                     f4 o = bias;
@@ -255,7 +336,7 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
                                 a = fma_f4(wd[6], v0, a); a = fma_f4(wd[7], v1, a); a = fma_f4(wd[8], v2, a);
                                 const int i = STAGE == 0 ? 2 * (rr - 2) + sq : rr - 2;
                                 cur[i][ct] = relu4(a);
-                                if constexpr (KT == 1) { if (more) pointwise(lw_next, cur[i]); }     // next layer's 1x1 under the next rows' taps
+                                if constexpr (KT == 1) { if (more) pointwise(An, cur[i]); }     // next layer's 1x1 under the next rows' taps
                             }
                             if (rr >= 1 && rr <= L) {
                                 f4 a = acc[(rr - 1) % 3];
@@ -274,10 +355,13 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
             if constexpr (KT == 2) {
                 if (more) {
 #pragma unroll
-                    for (int i = 0; i < NT; ++i) pointwise(lw_next, cur[i]);
+                    for (int i = 0; i < NT; ++i) pointwise(An, cur[i]);
                 }
             }
+            if (k + 1 < br) load_pw(li + 2, An);        // next layer's fused 1x1 uses these; in flight across the barrier and the image write
+            BM_PROF(4);
             __syncthreads();
+            BM_PROF(5);
         }
         // ChannelGate (osnet.py:194-209): crop-wide average -> fc1 -> ReLU -> fc2 -> sigmoid -> scale
         float* part = gap_part + br * (G::NWAVES * G::HID);
@@ -292,7 +376,7 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
                 for (int i = 0; i < NT; ++i) s += cur[i][ct];
 #pragma unroll
                 for (int h = 0; h < G::HID; ++h) {
-                    const f4 w1 = *reinterpret_cast<const f4*>(wts + bp.fc1_w + 4 * (h * MIDP + 16 * ct + 4 * g));
+                    const f4 w1 = *reinterpret_cast<const f4*>(wgate + 4 * (h * MIDP + 16 * ct + 4 * g));
 #pragma unroll
                     for (int r = 0; r < 4; ++r) ph[h] = __builtin_fmaf(w1[r], s[r], ph[h]);
                 }
@@ -312,121 +396,180 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
             float sum = 0.f;
 #pragma unroll
             for (int w = 0; w < G::NWAVES; ++w) sum += part[w * G::HID + h];
-            const float z = *reinterpret_cast<const float*>(wts + bp.fc1_b + 4 * h) + sum * (1.0f / P);
+            const float z = *reinterpret_cast<const float*>(wgate + g_fc1b + 4 * h) + sum * (1.0f / P);
             hidv[h] = z > 0.f ? z : 0.f;
         }
 #pragma unroll
         for (int ct = 0; ct < KT; ++ct) {
-            const f4 zb = *reinterpret_cast<const f4*>(wts + bp.fc2_b + 4 * (16 * ct + 4 * g));
+            const f4 zb = *reinterpret_cast<const f4*>(wgate + g_fc2b + 4 * (16 * ct + 4 * g));
             f4 gate;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int c = 16 * ct + 4 * g + r;
                 float z = zb[r];
 #pragma unroll
-                for (int h = 0; h < G::HID; ++h) z = __builtin_fmaf(*reinterpret_cast<const float*>(wts + bp.fc2_w + 4 * (c * G::HID + h)), hidv[h], z);
+                for (int h = 0; h < G::HID; ++h) z = __builtin_fmaf(*reinterpret_cast<const float*>(wgate + g_fc2w + 4 * (c * G::HID + h)), hidv[h], z);
                 gate[r] = 1.f / (1.f + BM_EXPF(-z));
             }
 #pragma unroll
             for (int i = 0; i < NT; ++i) x2[i][ct] = fma_f4(gate, cur[i][ct], x2[i][ct]);
         }
+        BM_PROF(6);
     }
 
     // ---- conv3 (1x1 MID -> COUT, linear) + downsample(x) or identity, ReLU (osnet.py:254-260) ----
-    const unsigned char* w3 = wts + bp.conv3_a;
-    const unsigned char* wdn = wts + bp.down_a;
-    const unsigned char* pv3 = RECON ? link.w + link.a0 : nullptr;      // previous block: conv3 pairs, bias, downsample pairs
-    const unsigned char* pvb = RECON ? link.w + link.a1 : nullptr;
-    const unsigned char* pvd = RECON ? link.w + link.a2 : nullptr;
+    // The A fragments of the epilogue are staged ONCE per workgroup into LDS (the image is dead after the last layer): eight waves
+    // re-reading 20-60 KB of fragments per tile through the vector L1 (64 B/clk) was a large share of the block time; LDS
+    // delivers them at 256 B/clk (lane-linear 1 KiB reads, conflict-free).
+    //   [0, E_OWN)  this block's conv3 pairs, bias, downsample pairs (contiguous in the packed blob)
+    //   then: EMIT the next block's conv1 pairs | RECON the previous block's conv3 pairs .. downsample pairs | TRANS pairs + bias
+    constexpr int KS3 = COUT / 32, KSN = COUT / 32;
+    constexpr int E_OWN_C = NCT * (int)HP_FRAG_PAIR + COUT * 4 + (DOWN ? NCT * KIN * (int)HP_FRAG_PAIR : 0);
+    constexpr int E_PREV_C = RECON ? NCT * (int)HP_FRAG_PAIR + COUT * 4 + NCT * KINP * (int)HP_FRAG_PAIR : 0;
+    static_assert(E_OWN_C + (EMIT ? KSN * KT * (int)HP_FRAG_PAIR : 0) + E_PREV_C + (TRANS ? NCT * KS3 * (int)HP_FRAG_PAIR + COUT * 4 : 0) <= G::TBUF,
+                  "epilogue operands fit the (dead) image area");
+    const int e_own = (int)(bp.total - bp.conv3_a);         // (host side: prepare_hp checks e_own + the other regions <= TBUF)
+    constexpr int E_LINK = EMIT ? KSN * KT * (int)HP_FRAG_PAIR : 0;
+    const int e_prev = RECON ? (int)(link.a2 - link.a0) + NCT * KINP * (int)HP_FRAG_PAIR : 0;
+    constexpr int E_TR = TRANS ? NCT * KS3 * (int)HP_FRAG_PAIR + COUT * 4 : 0;
+    {
+        auto stage_in = [&](const unsigned char* src, int bytes, int off) {
+            for (int e = tid * 16; e < bytes; e += 64 * G::NWAVES * 16)
+                *reinterpret_cast<f4*>(tbuf + off + e) = *reinterpret_cast<const f4*>(src + e);
+        };
+        stage_in(wts + bp.conv3_a, e_own, 0);
+        if constexpr (EMIT) stage_in(link.w + link.a0, E_LINK, e_own);
+        if constexpr (RECON) stage_in(link.w + link.a0, e_prev, e_own);
+        if constexpr (TRANS) stage_in(wtr, E_TR, e_own + e_prev);
+    }
+    const unsigned char* w3 = tbuf;
+    const unsigned char* b3 = tbuf + (bp.conv3_b - bp.conv3_a);
+    const unsigned char* wdn = tbuf + (bp.down_a - bp.conv3_a);
+    const unsigned char* wln = tbuf + e_own;                            // EMIT: next block's conv1 pairs [ks][ct]
+    const unsigned char* pv3 = tbuf + e_own;                            // RECON: previous block's conv3 pairs, bias, downsample pairs
+    const unsigned char* pvb = pv3 + (link.a1 - link.a0);
+    const unsigned char* pvd = pv3 + (link.a2 - link.a0);
+    const unsigned char* wtl = tbuf + e_own + e_prev;                   // TRANS: pairs [ct][ks], then fp32 bias
     h8 eye;                 // [I | I]: row l16, k-slots j <-> channel 4 g + (j & 3): adds the hi and the lo plane of the shortcut
 #pragma unroll
     for (int j = 0; j < 8; ++j) eye[j] = (_Float16)(l16 == 4 * g + (j & 3) ? 1.f : 0.f);
-    auto block_tile = [&](int i, f4 (&y)[NCT]) {
+    // operands a tile takes from memory, requested one tile ahead of their use
+    struct TileOps {
+        h8 dxh[DOWN ? KIN : 1], dxl[DOWN ? KIN : 1];            // DOWN: the block input
+        f4 x2p[RECON ? KT : 1];                                  // RECON: previous block's branch sum ...
+        h8 rxh[RECON ? KINP : 1], rxl[RECON ? KINP : 1];         // ... and input
+        h4 idh[(!DOWN && !RECON) ? NCT : 1], idl[(!DOWN && !RECON) ? NCT : 1];     // identity shortcut
+    };
+    auto tile_loads = [&](int i, TileOps& t) {
         unsigned p = (wave * NT + i) * 16 + l16;
-        if constexpr (STAGE == 0) BM_OPAQUE_U32(p);         // addresses are formed at the use
+        if constexpr (STAGE == 0) BM_OPAQUE_U32(p);         // addresses are formed at the use, not kept for 16 tiles
+        if constexpr (DOWN) {
+            if constexpr (CIN == 16) {
+                const unsigned o = p * 16 + g * 4;
+                t.dxh[0] = cat8(*reinterpret_cast<const h4*>(xh + o), *reinterpret_cast<const h4*>(xl + o));
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KIN; ++ks) {
+                    const unsigned o = p * CIN + g * (CIN / 4) + 8 * ks;
+                    t.dxh[ks] = *reinterpret_cast<const h8*>(xh + o); t.dxl[ks] = *reinterpret_cast<const h8*>(xl + o);
+                }
+            }
+        } else if constexpr (RECON) {
+#pragma unroll
+            for (int ct = 0; ct < KT; ++ct) t.x2p[ct] = *reinterpret_cast<const f4*>(x2w + (i * KT + ct) * 256);
+            if constexpr (PREV_CIN == 16) {
+                const unsigned o = p * 16 + g * 4;
+                t.rxh[0] = cat8(*reinterpret_cast<const h4*>(xh + o), *reinterpret_cast<const h4*>(xl + o));
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KINP; ++ks) {
+                    const unsigned o = p * PREV_CIN + g * (PREV_CIN / 4) + 8 * ks;
+                    t.rxh[ks] = *reinterpret_cast<const h8*>(xh + o); t.rxl[ks] = *reinterpret_cast<const h8*>(xl + o);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int co = 0; co < NCT; ++co) {
+                const unsigned o = p * CIN + g * (CIN / 4) + 4 * co;
+                t.idh[co] = *reinterpret_cast<const h4*>(xh + o); t.idl[co] = *reinterpret_cast<const h4*>(xl + o);
+            }
+        }
+    };
+    auto block_tile = [&](int i, const TileOps& t, f4 (&y)[NCT]) {
         h4 xh4[KT], xl4[KT];
 #pragma unroll
         for (int ct = 0; ct < KT; ++ct) split4(x2[i][ct], xh4[ct], xl4[ct]);
         h8 b2h, b2l;
         if constexpr (KT == 1) { b2h = cat8(xh4[0], xl4[0]); b2l = b2h; }
         else { b2h = cat8(xh4[0], xh4[KT - 1]); b2l = cat8(xl4[0], xl4[KT - 1]); }
-        // operands of the shortcut
-        h8 dxh[KIN], dxl[KIN];          // DOWN: the block input
-        h8 rb2h, rb2l, rxh[KINP], rxl[KINP];      // RECON: previous block's branch sum and input
-        if constexpr (DOWN) {
-            if constexpr (CIN == 16) {
-                const unsigned o = p * 16 + g * 4;
-                dxh[0] = cat8(*reinterpret_cast<const h4*>(xh + o), *reinterpret_cast<const h4*>(xl + o));
-            } else {
-#pragma unroll
-                for (int ks = 0; ks < KIN; ++ks) {
-                    const unsigned o = p * CIN + g * (CIN / 4) + 8 * ks;
-                    dxh[ks] = *reinterpret_cast<const h8*>(xh + o); dxl[ks] = *reinterpret_cast<const h8*>(xl + o);
-                }
-            }
-        }
+        h8 rb2h, rb2l;
         if constexpr (RECON) {
             h4 ph4[KT], pl4[KT];
 #pragma unroll
-            for (int ct = 0; ct < KT; ++ct) split4(*reinterpret_cast<const f4*>(x2w + (i * KT + ct) * 256), ph4[ct], pl4[ct]);
+            for (int ct = 0; ct < KT; ++ct) split4(t.x2p[ct], ph4[ct], pl4[ct]);
             if constexpr (KT == 1) { rb2h = cat8(ph4[0], pl4[0]); rb2l = rb2h; }
             else { rb2h = cat8(ph4[0], ph4[KT - 1]); rb2l = cat8(pl4[0], pl4[KT - 1]); }
-            if constexpr (PREV_CIN == 16) {
-                const unsigned o = p * 16 + g * 4;
-                rxh[0] = cat8(*reinterpret_cast<const h4*>(xh + o), *reinterpret_cast<const h4*>(xl + o));
-            } else {
-#pragma unroll
-                for (int ks = 0; ks < KINP; ++ks) {
-                    const unsigned o = p * PREV_CIN + g * (PREV_CIN / 4) + 8 * ks;
-                    rxh[ks] = *reinterpret_cast<const h8*>(xh + o); rxl[ks] = *reinterpret_cast<const h8*>(xl + o);
-                }
-            }
         }
 #pragma unroll
         for (int co = 0; co < NCT; ++co) {
-            f4 acc = *reinterpret_cast<const f4*>(wts + bp.conv3_b + (16 * co + 4 * g) * 4);
+            f4 acc = *reinterpret_cast<const f4*>(b3 + (16 * co + 4 * g) * 4);
             if constexpr (KT == 1) acc = mm2(w3 + (long)co * HP_FRAG_PAIR, lane, b2h, acc);
             else acc = mm3(w3 + (long)co * HP_FRAG_PAIR, lane, b2h, b2l, acc);
             if constexpr (DOWN) {
-                if constexpr (CIN == 16) acc = mm2(wdn + (long)co * HP_FRAG_PAIR, lane, dxh[0], acc);
+                if constexpr (CIN == 16) acc = mm2(wdn + (long)co * HP_FRAG_PAIR, lane, t.dxh[0], acc);
                 else {
 #pragma unroll
-                    for (int ks = 0; ks < KIN; ++ks) acc = mm3(wdn + (long)(co * KIN + ks) * HP_FRAG_PAIR, lane, dxh[ks], dxl[ks], acc);
+                    for (int ks = 0; ks < KIN; ++ks) acc = mm3(wdn + (long)(co * KIN + ks) * HP_FRAG_PAIR, lane, t.dxh[ks], t.dxl[ks], acc);
                 }
             } else if constexpr (RECON) {
                 // block input = ReLU(conv3_prev . x2_prev + down_prev . x_prev + bias), rebuilt in fp32 and added as it is
                 f4 ap = *reinterpret_cast<const f4*>(pvb + (16 * co + 4 * g) * 4);
                 if constexpr (KT == 1) ap = mm2(pv3 + (long)co * HP_FRAG_PAIR, lane, rb2h, ap);
                 else ap = mm3(pv3 + (long)co * HP_FRAG_PAIR, lane, rb2h, rb2l, ap);
-                if constexpr (PREV_CIN == 16) ap = mm2(pvd + (long)co * HP_FRAG_PAIR, lane, rxh[0], ap);
+                if constexpr (PREV_CIN == 16) ap = mm2(pvd + (long)co * HP_FRAG_PAIR, lane, t.rxh[0], ap);
                 else {
 #pragma unroll
-                    for (int ks = 0; ks < KINP; ++ks) ap = mm3(pvd + (long)(co * KINP + ks) * HP_FRAG_PAIR, lane, rxh[ks], rxl[ks], ap);
+                    for (int ks = 0; ks < KINP; ++ks) ap = mm3(pvd + (long)(co * KINP + ks) * HP_FRAG_PAIR, lane, t.rxh[ks], t.rxl[ks], ap);
                 }
                 acc += relu4(ap);
             } else {
-                const unsigned o = p * CIN + g * (CIN / 4) + 4 * co;
-                acc = BM_MFMA_F16_K32(eye, cat8(*reinterpret_cast<const h4*>(xh + o), *reinterpret_cast<const h4*>(xl + o)), acc);
+                acc = BM_MFMA_F16_K32(eye, cat8(t.idh[co], t.idl[co]), acc);
             }
             y[co] = relu4(acc);
         }
     };
+    // Operand prefetch depth: the tensors these come from were written by an earlier launch (HBM), and one CU draws ~10 B/clk: a
+    // tile's operands are requested PF tiles ahead (ring of PF + 1 sets, static indices under full unrolling).
+    constexpr int PF = NT >= 8 ? 3 : (NT >= 4 ? 2 : 0), NR = PF + 1;
+    TileOps ops[NR];
+    // order in which the epilogue visits the tiles (TRANS: vertically adjacent pairs)
+    auto seq_tile = [](int k) constexpr {
+        if (!TRANS) return k;
+        const int pr = k >> 1, i0 = STAGE == 0 ? (pr >> 1) * 4 + (pr & 1) : 2 * pr;
+        return i0 + (k & 1) * (STAGE == 0 ? 2 : 1);
+    };
+#pragma unroll
+    for (int k = 0; k < NR && k < NT; ++k) tile_loads(seq_tile(k), ops[k]);       // the first sets fly under the staging barrier
+    __syncthreads();
     if constexpr (EMIT) {
         // next block's conv1 (COUT -> MID, + bias, ReLU) on the in-register block output
-        constexpr int KSN = COUT / 32;
+        f4 bn[KT];          // its bias: loaded once (a global load inside the tile loop drains the operand prefetch every tile)
+#pragma unroll
+        for (int ct = 0; ct < KT; ++ct) bn[ct] = *reinterpret_cast<const f4*>(link.w + link.a1 + (16 * ct + 4 * g) * 4);
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
             f4 y[NCT];
-            block_tile(i, y);
+            block_tile(i, ops[i % NR], y);
+            if (i + NR < NT) tile_loads(i + NR, ops[i % NR]);          // the set just consumed is free again
             h4 yh[NCT], yl[NCT];
 #pragma unroll
             for (int co = 0; co < NCT; ++co) split4(y[co], yh[co], yl[co]);
 #pragma unroll
             for (int ct = 0; ct < KT; ++ct) {
-                f4 an = *reinterpret_cast<const f4*>(link.w + link.a1 + (16 * ct + 4 * g) * 4);
+                f4 an = bn[ct];
 #pragma unroll
                 for (int ks = 0; ks < KSN; ++ks)
-                    an = mm3(link.w + link.a0 + (long)(ks * KT + ct) * HP_FRAG_PAIR, lane, cat8(yh[2 * ks], yh[2 * ks + 1]), cat8(yl[2 * ks], yl[2 * ks + 1]), an);
+                    an = mm3(wln + (long)(ks * KT + ct) * HP_FRAG_PAIR, lane, cat8(yh[2 * ks], yh[2 * ks + 1]), cat8(yl[2 * ks], yl[2 * ks + 1]), an);
                 *reinterpret_cast<f4*>(x1w + (i * KT + ct) * 256) = relu4(an);
                 *reinterpret_cast<f4*>(x2w + (i * KT + ct) * 256) = x2[i][ct];
             }
@@ -439,7 +582,8 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
         for (int i = 0; i < NT; ++i) {
             const unsigned p = (wave * NT + i) * 16 + l16;
             f4 y[NCT];
-            block_tile(i, y);
+            block_tile(i, ops[i % NR], y);
+            if (i + NR < NT) tile_loads(i + NR, ops[i % NR]);
 #pragma unroll
             for (int co = 0; co < NCT; ++co) {
                 h4 hh, ll;
@@ -454,20 +598,22 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
         // two vertically adjacent tiles: transition conv on the in-register block output, ReLU, 2x2 average (vertical = the
         // two tiles, horizontal = lane ^ 1; the 1/4 is folded into `wtr`), even lanes store the pooled pixel
         static_assert(!TRANS || (STAGE < 2 && COUT % 32 == 0), "fused transition: stages 0 and 1");
-        constexpr int KS3 = COUT / 32, WP = G::W / 2;
-        const unsigned char* tbias = wtr + (long)NCT * KS3 * HP_FRAG_PAIR;
+        constexpr int WP = G::W / 2;
+        const unsigned char* tbias = wtl + (long)NCT * KS3 * HP_FRAG_PAIR;
         _Float16* yh_out = out_h + crop * out_px * COUT;
         _Float16* yl_out = out_l + crop * out_px * COUT;
 #pragma unroll
         for (int pr = 0; pr < NT / 2; ++pr) {
-            const int i0 = STAGE == 0 ? (pr >> 1) * 4 + (pr & 1) : 2 * pr, i1 = i0 + (STAGE == 0 ? 2 : 1);
+            const int k0 = 2 * pr, k1 = 2 * pr + 1, i0 = seq_tile(k0), i1 = seq_tile(k1);
             h4 y0h[NCT], y0l[NCT], y1h[NCT], y1l[NCT];
             {
                 f4 y[NCT];
-                block_tile(i0, y);
+                block_tile(i0, ops[k0 % NR], y);
+                if (k0 + NR < NT) tile_loads(seq_tile(k0 + NR), ops[k0 % NR]);
 #pragma unroll
                 for (int co = 0; co < NCT; ++co) split4(y[co], y0h[co], y0l[co]);
-                block_tile(i1, y);
+                block_tile(i1, ops[k1 % NR], y);
+                if (k1 + NR < NT) tile_loads(seq_tile(k1 + NR), ops[k1 % NR]);
 #pragma unroll
                 for (int co = 0; co < NCT; ++co) split4(y[co], y1h[co], y1l[co]);
             }
@@ -479,9 +625,10 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
                 f4 a0 = bv, a1 = bv;
 #pragma unroll
                 for (int ks = 0; ks < KS3; ++ks) {
-                    const unsigned char* a = wtr + (long)(ct * KS3 + ks) * HP_FRAG_PAIR;
-                    a0 = mm3(a, lane, cat8(y0h[2 * ks], y0h[2 * ks + 1]), cat8(y0l[2 * ks], y0l[2 * ks + 1]), a0);
-                    a1 = mm3(a, lane, cat8(y1h[2 * ks], y1h[2 * ks + 1]), cat8(y1l[2 * ks], y1l[2 * ks + 1]), a1);
+                    const unsigned char* a = wtl + (long)(ct * KS3 + ks) * HP_FRAG_PAIR;
+                    const h8 ah = *reinterpret_cast<const h8*>(a + lane * 16), al = *reinterpret_cast<const h8*>(a + 1024 + lane * 16);
+                    a0 = mm3r(ah, al, cat8(y0h[2 * ks], y0h[2 * ks + 1]), cat8(y0l[2 * ks], y0l[2 * ks + 1]), a0);
+                    a1 = mm3r(ah, al, cat8(y1h[2 * ks], y1h[2 * ks + 1]), cat8(y1l[2 * ks], y1l[2 * ks + 1]), a1);
                 }
                 a0 = relu4(a0); a1 = relu4(a1);
                 f4 sp;
@@ -501,6 +648,8 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
             BM_SCHED_FENCE();
         }
     }
+    BM_PROF(7);
+    BM_PROF_FLUSH();
 }
 
 // ---------------------------------------------------------------------------

@@ -172,6 +172,37 @@ inline void pack_stem_hp(const float* W /*[16][7][7][3]*/, const float* bias, st
     std::memcpy(out.data() + 7 * HP_FRAG_PAIR, bias, 64);
 }
 
+
+// stem for the fused crop + resize + stem kernel of the fp32-grade family (k_stem_resize_fused_hp): the operand is the RAW pixel
+// [R, G, B, 1] (exact in fp16), the normalisation x = (v / 255 - mean_c) / std_c = a_c v + b_c is folded into the weights:
+//   colour slots:  W[co][ky][kx][c] * a_c          fourth slot:  sum_c W[co][ky][kx][c] * b_c   (0 in the zero padding)
+// per ky a (hi, lo) fragment pair; the lo fragment is stored times 2^11 (the kernel multiplies the operand by 2^-11, both exact),
+// which keeps the residual in fp16's normal range.  + fp32 bias[16].
+inline void pack_stem_hp_fused(const float* W /*[16][7][7][3]*/, const float* bias, const float mean[3], const float stdv[3],
+                               std::vector<uint8_t>& out) {
+    out.assign(14 * 1024 + 64, 0);
+    for (int ky = 0; ky < 7; ++ky) {
+        uint16_t* dh = reinterpret_cast<uint16_t*>(out.data() + (2 * ky) * 1024);
+        uint16_t* dl = reinterpret_cast<uint16_t*>(out.data() + (2 * ky + 1) * 1024);
+        for (int lane = 0; lane < 64; ++lane) {
+            const int co = lane & 15, g = lane >> 4;
+            for (int j = 0; j < 8; ++j) {
+                const int kx = 2 * g + (j >> 2), c = j & 3;
+                double v = 0.0;
+                if (kx < 7) {
+                    const float* w3 = W + ((co * 7 + ky) * 7 + kx) * 3;
+                    if (c < 3) v = (double)w3[c] / (255.0 * (double)stdv[c]);
+                    else for (int cc = 0; cc < 3; ++cc) v -= (double)w3[cc] * (double)mean[cc] / (double)stdv[cc];
+                }
+                const uint16_t hi = f32_to_f16_bits((float)v);
+                dh[lane * 8 + j] = hi;
+                dl[lane * 8 + j] = f32_to_f16_bits((float)((v - (double)f16_bits_to_f32(hi)) * 2048.0));
+            }
+        }
+    }
+    std::memcpy(out.data() + 14 * 1024, bias, 64);
+}
+
 // head FC [feat][C], input channels in L-layout memory order: fp16 hi [feat][C], fp16 lo [feat][C], fp32 bias
 inline void pack_fc_hp(const float* W, const float* bias, int feat, int C, std::vector<uint8_t>& out) {
     out.assign((size_t)feat * C * 4 + (size_t)feat * 4, 0);

@@ -270,7 +270,7 @@ int emu_reid_forward(const float* blob, long n_floats, const float* crops, int n
 // stage 1 -> stage 2 -> head.  stage_out[k] (may be null) receives hi + lo as fp32 natural NHWC after: 0 stem+maxpool, 3 stage-0
 // transition, 4 conv3.0, 6 stage-1 transition, 7 conv4.0, 8 conv4.1.
 int emu_reid_forward_hp(const float* blob, long n_floats, const uint8_t* frame, int W, int H, const float* boxes, int n, float* feats,
-                        float** stage_out) {
+                        float** stage_out, int fused_stem) {
     using namespace bm;
     const int32_t* hdr = reinterpret_cast<const int32_t*>(blob);
     if (hdr[0] != REID_MAGIC || hdr[1] != 16) return -1;
@@ -297,8 +297,13 @@ int emu_reid_forward_hp(const float* blob, long n_floats, const uint8_t* frame, 
     std::vector<_Float16> Ah((size_t)n * 2048 * 32), Al(Ah.size()), Bh(Ah.size()), Bl(Ah.size());
     std::vector<float> x1s((size_t)n * 2048 * 16), x2s((size_t)n * 2048 * 16);
     std::vector<uint8_t> wst;
-    pack_stem_hp(w + L.stem_w, w + L.stem_b, wst);
-    {
+    if (fused_stem) {       // crop + resize + stem in one kernel on raw pixel values (normalisation folded into the weights)
+        pack_stem_hp_fused(w + L.stem_w, w + L.stem_b, mean, stdv, wst);
+        const uint8_t* const* fr = frames; const int* cs = streams.data();
+        _Float16 *oh = Ah.data(), *ol = Al.data(); const unsigned char* wp = wst.data();
+        launch(n, 1, 512, [=]() { k_stem_resize_fused_hp(fr, cs, boxes, 4, W, H, oh, ol, wp, nullptr); });
+    } else {
+        pack_stem_hp(w + L.stem_w, w + L.stem_b, wst);
         const _Float16 *ih = cxh.data(), *il = cxl.data(); _Float16 *oh = Ah.data(), *ol = Al.data(); const unsigned char* wp = wst.data();
         launch(n, 1, 512, [=]() { k_stem_hp(ih, il, oh, ol, wp, nullptr); });
     }

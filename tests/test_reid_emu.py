@@ -187,10 +187,12 @@ def test_batched_head_equals_per_crop_head_and_oracle_emulated():
     assert np.abs(fb[rows[:count]] - want[:count]).max() < 1e-3
 
 
-@pytest.mark.parametrize("weights", ["init", "calib0", "calib1"])
+@pytest.mark.parametrize("weights,fused_stem", [("init", 1), ("calib0", 1), ("calib1", 0), ("calib2", 1)])
 @pytest.mark.skipif(CLANG is None, reason="needs a host clang with _Float16")
-def test_fp32_grade_fused_family_emulated_vs_oracle(weights):
-    """The fp32-grade fused family (reid_hp.hpp, ReID mode 2: fp16 (hi, lo) operand pairs, fp32 image / depthwise / gates) on CPU
+def test_fp32_grade_fused_family_emulated_vs_oracle(weights, fused_stem):
+    """fused_stem = 1: crop + resize + stem in one kernel on raw pixel values with the normalisation folded into (hi, lo) weights
+    (k_stem_resize_fused_hp, the engine's default); 0: crop kernel + k_stem_hp on (hi, lo) normalised planes (resize_pad path).
+    The fp32-grade fused family (reid_hp.hpp, ReID mode 2: fp16 (hi, lo) operand pairs, fp32 image / depthwise / gates) on CPU
     threads, every stored stage and the embeddings against the torch fp32 oracle -- on the reference's own initialisation and on
     BatchNorm-calibrated random networks (the case the fp16-operand family misses by 6-12x): 1e-3 is north_star's tolerance, the
     arithmetic delivers ~1e-5."""
@@ -202,18 +204,20 @@ def test_fp32_grade_fused_family_emulated_vs_oracle(weights):
 
     lib = ctypes.CDLL(str(_build()))
     lib.emu_reid_forward_hp.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
-                                        ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+                                        ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
     sd = reference_init_state_dict("osnet_x0_25", seed=0) if weights == "init" else random_osnet_state_dict("osnet_x0_25", seed=int(weights[-1]))
     blob = pack_osnet(sd)
     img = np.random.default_rng(5).integers(0, 255, (480, 641, 3), dtype=np.uint8)
-    boxes = np.array([[30.2, 40.7, 90.1, 200.3], [300.0, 100.0, 420.5, 330.0]], dtype=np.float32)
+    # a general box, a box clipped at the frame border, an identity-sized and an exact-2x box (the resampler's special cases)
+    boxes = np.array([[30.2, 40.7, 90.1, 200.3], [-12.0, 300.0, 120.5, 500.0], [100, 100, 228, 356], [300, 10, 556, 522]], dtype=np.float32)[: 4 if fused_stem else 2]
     crops = get_crops(boxes, img)
     n = len(boxes)
     feats = np.zeros((n, 512), np.float32)
     shapes = [(2048, 16), (2048, 64), (2048, 64), (512, 64), (512, 96), (512, 96), (128, 96), (128, 128), (128, 128)]
     bufs = [np.zeros((n,) + s, np.float32) for s in shapes]
     ptrs = (ctypes.c_void_p * 9)(*[b.ctypes.data for b in bufs])
-    assert lib.emu_reid_forward_hp(blob.ctypes.data, blob.size, img.ctypes.data, 641, 480, boxes.ctypes.data, n, feats.ctypes.data, ptrs) == 0
+    assert lib.emu_reid_forward_hp(blob.ctypes.data, blob.size, img.ctypes.data, 641, 480, boxes.ctypes.data, n, feats.ctypes.data, ptrs,
+                                   fused_stem) == 0
     want, st = osnet_forward(sd, torch.from_numpy(crops), return_stages=True)
     names = ["maxpool", "conv2.0", "conv2.1", "conv2.2", "conv3.0", "conv3.1", "conv3.2", "conv4.0", "conv4.1"]
     for nm, buf in zip(names, bufs):
