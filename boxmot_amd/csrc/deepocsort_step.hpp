@@ -19,6 +19,7 @@
 #pragma once
 
 #include "block_prims.hpp"
+#include "lap_jv.hpp"
 #include "botsort_types.hpp"
 #include "kernel_macros.hpp"
 
@@ -376,7 +377,15 @@ __device__ inline DV docs_view(const DocsStepArgs& a, int s) {
 // ---------------------------------------------------------------------------
 constexpr double DOCS_INF = 1e300;
 struct FullLapLds { double* v; double* minv; double* u; int* x; int* way; int* used; int* y; };
-__host__ __device__ inline long docs_lap_lds_bytes(int cap, int nd) { const long n = cap + nd; return n * (8 + 8 + 4 + 4 + 4) + (long)nd * (8 + 4) + 16; }
+// BM_DOCS_LAP_JV = 1 (default): the assignment is the Jonker-Volgenant code of lap_jv.hpp, tie for tie what lap.lapjv's algorithm
+// returns; 0: the round-1 / round-2 shortest-augmenting-path solver below (same optimum, lowest-index ties).
+#ifndef BM_DOCS_LAP_JV
+#define BM_DOCS_LAP_JV 1
+#endif
+__host__ __device__ inline long docs_lap_lds_bytes(int cap, int nd) {
+    const long n = cap + nd, a = n * (8 + 8 + 4 + 4 + 4) + (long)nd * (8 + 4) + 16, b = jv_lds_bytes((int)n);
+    return a > b ? a : b;
+}
 __device__ inline FullLapLds docs_carve_lap(unsigned char* base, int cap, int nd) {
     const int n = cap + nd;
     FullLapLds l;
@@ -441,6 +450,19 @@ __device__ inline bool lap_full(const Ctx& c, const FullLapLds& L, int R, int C,
     for (int d = c.tid; d < C; d += c.nthr) out_y[d] = (stalled || L.y[d] >= R) ? -1 : L.y[d];
     __syncthreads();
     return !stalled;
+}
+
+// linear_assignment(cost) of association.py:20-24 on a det-major matrix: R columns (tracks), C rows (detections);
+// out_x[t] = row of column t, out_y[d] = column of row d, -1 = unassigned
+template <class CostFn>
+__device__ inline bool docs_assign(const Ctx& c, unsigned char* dyn_lds, const FullLapLds& L, int R, int C, CostFn cost_of, int* out_x, int* out_y) {
+#if BM_DOCS_LAP_JV
+    (void)L;
+    return lap_jv_extended(c, jv_carve(dyn_lds, R + C), C, R, cost_of, false, 0.0, out_y, out_x);
+#else
+    (void)dyn_lds;
+    return lap_full(c, L, R, C, cost_of, out_x, out_y);
+#endif
 }
 
 __device__ inline double iou_pair(const double* a, const double* b) {      // iou.py:134-150
@@ -768,7 +790,7 @@ __device__ inline void docs_step_stream(const DocsStepArgs& args, int s, int* s_
             }
             __syncthreads();
             const double* cm = v.cost;
-            if (!lap_full(c, lap, nt, nk, [&](int d, int t) { return cm[d * ld + t]; }, v.lap_x, v.lap_y) && c.tid == 0)
+            if (!docs_assign(c, dyn_lds, lap, nt, nk, [&](int d, int t) { return cm[d * ld + t]; }, v.lap_x, v.lap_y) && c.tid == 0)
                 *v.status = STATUS_LAP_STALL;
         }
         __syncthreads();
@@ -813,7 +835,7 @@ __device__ inline void docs_step_stream(const DocsStepArgs& args, int s, int* s_
         }
         if (mxi > cfg.iou_threshold) {
             const double* cm = v.cost;
-            if (!lap_full(c, lap, n_ut, n_byte, [&](int d, int t) { return cm[d * ld + t]; }, v.lap_x, v.lap_y) && c.tid == 0)
+            if (!docs_assign(c, dyn_lds, lap, n_ut, n_byte, [&](int d, int t) { return cm[d * ld + t]; }, v.lap_x, v.lap_y) && c.tid == 0)
                 *v.status = STATUS_LAP_STALL;
             auto good_b = [&](int a) { return v.lap_y[a] >= 0 && !(v.iou[a * ld + v.lap_y[a]] < cfg.iou_threshold); };
             const int nb = block_append_if(c, n_byte, good_b, ident, v.tmp_a, 0);
@@ -856,7 +878,7 @@ __device__ inline void docs_step_stream(const DocsStepArgs& args, int s, int* s_
         }
         if (mxi > cfg.iou_threshold) {
             const double* cm = v.cost;
-            if (!lap_full(c, lap, n_ut, n_ud, [&](int d, int t) { return cm[d * ld + t]; }, v.lap_x, v.lap_y) && c.tid == 0)
+            if (!docs_assign(c, dyn_lds, lap, n_ut, n_ud, [&](int d, int t) { return cm[d * ld + t]; }, v.lap_x, v.lap_y) && c.tid == 0)
                 *v.status = STATUS_LAP_STALL;
             auto good2 = [&](int a) { return v.lap_y[a] >= 0 && !(v.iou[a * ld + v.lap_y[a]] < cfg.iou_threshold); };
             const int n2 = block_append_if(c, n_ud, good2, ident, v.tmp_a, 0);

@@ -76,6 +76,10 @@ __device__ inline unsigned bm_mulhi24(unsigned a, unsigned b) {
 #ifndef BM_CLOCK
 #define BM_CLOCK() wall_clock64()
 #endif
+#ifndef BM_SLEEP_8K
+// park the wavefront for ~8128 shader cycles (s_sleep 127)
+#define BM_SLEEP_8K() __builtin_amdgcn_s_sleep(127)
+#endif
 
 // fp32 matrix pipe: D = A.B + C on 16x16x4 tiles (v_mfma_f32_16x16x4_f32; A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15],
 // D: column lane & 15, rows 4 (lane >> 4) + r).  Exact fp32: bit-for-bit the k-ordered fmaf chain, so a kernel written on it

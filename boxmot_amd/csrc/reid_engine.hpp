@@ -460,7 +460,7 @@ private:
             pack_stem_hp_fused(w + L_.stem_w, w + L_.stem_b, mean_i, std_i, buf);
             hw_stem_fused_ = upload(buf);
         }
-        allow_lds(k_stem_resize_fused_hp, STEM2_LDS);
+        allow_lds(k_stem_resize_fused_hp, STEM2_LDS_HP);
         static const int stage[6] = {0, 0, 1, 1, 2, 2}, cin[6] = {16, 64, 64, 96, 96, 128}, down[6] = {1, 0, 1, 0, 1, 0};
         for (int b = 0; b < 6; ++b) {
             hbp_[b] = make_blk_pack_hp(stage[b], cin[b], down[b]);
@@ -489,7 +489,7 @@ private:
     }
     void forward_hp(int n, const FrameArgs* fa, float* d_out, const int* d_out_rows, hipStream_t st) {
         if (fa)     // crop + resize + normalise fused into the stem on raw pixel values (the resized crop never reaches HBM)
-            hipLaunchKernelGGL(k_stem_resize_fused_hp, dim3(n), dim3(512), STEM2_LDS, st, fa->frames, fa->crop_stream, fa->boxes,
+            hipLaunchKernelGGL(k_stem_resize_fused_hp, dim3(n), dim3(512), STEM2_LDS_HP, st, fa->frames, fa->crop_stream, fa->boxes,
                                fa->box_stride, fa->W, fa->H, act_a_, hact_al_, hw_stem_fused_, d_count_);
         else
             hipLaunchKernelGGL(k_stem_hp, dim3(n), dim3(512), 0, st, crops_h_, crops_l_, act_a_, hact_al_, hw_stem_, d_count_);

@@ -1110,6 +1110,12 @@ constexpr int SRC_STAGE_BYTES = 20 * 1024;
 constexpr int STEM_EDGE_BYTES = BM_STEM_STREAM ? 2 * 2 * 4 * 4 * 16 * 4 : 0;   // [band parity][half][strip][pooled row][channel] fp32
 constexpr int STEM_LUT_BYTES = 768 * 4;                          // normalisation table, 4-byte entries (fp16 in the low half)
 constexpr int STEM2_LDS = RING_ROWS * RING_ROW_BYTES + SRC_STAGE_BYTES + STEM_LUT_BYTES + 256 * 8 + STEM_EDGE_BYTES;   // ring, staging, LUT, y table, edges
+// the fp32-grade stem keeps its seven lo fragments in LDS (one ds_read_b128 per lo MFMA) instead of 28 registers: at <= 128
+// registers and 78.5 KiB two workgroups share a CU, like the fp16 stem (BM_HP_STEM_LDS_LO = 0: registers, one workgroup per CU)
+#ifndef BM_HP_STEM_LDS_LO
+#define BM_HP_STEM_LDS_LO 1
+#endif
+constexpr int STEM2_LDS_HP = STEM2_LDS + (BM_HP_STEM_LDS_LO ? 7 * 1024 : 0);
 
 // HP (the fp32-grade family, reid_hp.hpp): a pixel byte v is EXACT in fp16, and the normalisation (v / 255 - mean) / std = a v + b
 // is linear, so it is folded into the weights on the host (pack_stem_hp_fused): the ring holds [R, G, B, 1] raw values (the
@@ -1144,11 +1150,16 @@ __device__ __forceinline__ void stem_resize_fused_body(const uint8_t* const* fra
         ytab[2 * tid + 1] = (unsigned)ay.a0 | ((unsigned)ay.a1 << 16);
     }
     for (int e = tid * 8; e < RING_ROWS * RING_ROW_BYTES; e += 512 * 8) *reinterpret_cast<unsigned long long*>(ring + e) = 0ull;
-    h8 a[7], a_lo[HP ? 7 : 1];
+    constexpr bool LO_LDS = HP && BM_HP_STEM_LDS_LO;
+    h8 a[7], a_lo[(HP && !LO_LDS) ? 7 : 1];
+    unsigned char* alo_lds = stage + SRC_STAGE_BYTES + STEM_LUT_BYTES + 256 * 8 + STEM_EDGE_BYTES;      // [ky][lane] 16-byte fragments
 #pragma unroll
     for (int ky = 0; ky < 7; ++ky) {
         a[ky] = *reinterpret_cast<const h8*>(wts + ((HP ? 2 * ky : ky) * 64 + lane) * 16);
-        if constexpr (HP) a_lo[ky] = *reinterpret_cast<const h8*>(wts + ((2 * ky + 1) * 64 + lane) * 16);
+        if constexpr (HP && !LO_LDS) a_lo[ky] = *reinterpret_cast<const h8*>(wts + ((2 * ky + 1) * 64 + lane) * 16);
+    }
+    if constexpr (LO_LDS) {
+        if (tid < 7 * 64) *reinterpret_cast<h8*>(alo_lds + tid * 16) = *reinterpret_cast<const h8*>(wts + ((2 * (tid >> 6) + 1) * 64 + (tid & 63)) * 16);
     }
     const f4 bias = *reinterpret_cast<const f4*>(wts + (HP ? 14 : 7) * 1024 + 4 * g * 4);
     // resampling role of this thread: output column dx, row phase rp (4 threads per column)
@@ -1324,7 +1335,8 @@ __device__ __forceinline__ void stem_resize_fused_body(const uint8_t* const* fra
                     if (j == 0 && oy0 == 0) continue;                   // wave-uniform
                     const int ky = i - 2 * j;
                     acc[j] = BM_MFMA_F16_K32(a[ky], b, ky == 0 ? bias : acc[j]);
-                    if constexpr (HP) acc[j] = BM_MFMA_F16_K32(a_lo[ky], b_s, acc[j]);
+                    if constexpr (LO_LDS) acc[j] = BM_MFMA_F16_K32(*reinterpret_cast<const h8*>(alo_lds + (ky * 64 + lane) * 16), b_s, acc[j]);
+                    else if constexpr (HP) acc[j] = BM_MFMA_F16_K32(a_lo[ky], b_s, acc[j]);
                 }
             }
             float* edge = reinterpret_cast<float*>(stage + SRC_STAGE_BYTES + STEM_LUT_BYTES + 256 * 8) + (((band & 1) * 2 + half) * 4) * (4 * 16);
@@ -1415,7 +1427,7 @@ __global__ void __launch_bounds__(512, 4) k_stem_resize_fused(const uint8_t* con
     stem_resize_fused_body<false>(frames, crop_stream, boxes, box_stride, W, H, lut, out, nullptr, wts, count);
 }
 // the fp32-grade family's stem: (hi, lo) output planes, weights from pack_stem_hp_fused
-__global__ void __launch_bounds__(512, 2) k_stem_resize_fused_hp(const uint8_t* const* frames, const int* crop_stream, const float* boxes,
+__global__ void __launch_bounds__(512, BM_HP_STEM_LDS_LO ? 4 : 2) k_stem_resize_fused_hp(const uint8_t* const* frames, const int* crop_stream, const float* boxes,
                                                               int box_stride, int W, int H, _Float16* __restrict__ out_hi,
                                                               _Float16* __restrict__ out_lo, const unsigned char* __restrict__ wts,
                                                               const int* __restrict__ count) {

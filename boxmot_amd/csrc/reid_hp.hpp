@@ -26,6 +26,21 @@
 #ifndef BM_HP_S2_WPS
 #define BM_HP_S2_WPS 4
 #endif
+#ifndef BM_HP_STAGGER
+#define BM_HP_STAGGER 0
+#endif
+// streaming accesses (hand-over tensors and block outputs written once, operands read once) marked non-temporal so that the
+// tensor a kernel re-reads per branch (128 KiB per crop, one L2 share) is not evicted by them
+#ifndef BM_HP_NT
+#define BM_HP_NT 0
+#endif
+#if BM_HP_NT
+#define BM_NT_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#define BM_NT_LOAD(ptr) __builtin_nontemporal_load(ptr)
+#else
+#define BM_NT_STORE(ptr, val) (*(ptr) = (val))
+#define BM_NT_LOAD(ptr) (*(ptr))
+#endif
 
 namespace bm {
 
@@ -117,6 +132,15 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
     static_assert(!RECON || (STAGE <= 1 && CIN == GeoHP<STAGE>::COUT && !DOWN && TRANS), "RECON: second block of stage 0 or 1");
     using G = GeoHP<STAGE>;
     if (count && (int)blockIdx.x >= *count) return;
+    // Phase stagger: every workgroup of a launch does the same phases for the same time, so without it all 256 CUs read
+    // (branch inputs, epilogue operands) and write at the same moments and the fabric is idle in between.  The workgroups of the
+    // FIRST wave of the grid start a quarter period apart in four groups (neighbouring CUs of an XCD in different groups); the
+    // offset persists for the whole launch because a CU takes its next crop when it finishes the last.
+    if (BM_HP_STAGGER && blockIdx.x < 256 * (STAGE == 2 ? 2 : 1)) {
+        const int grp = (blockIdx.x >> 3) & 3;
+        constexpr int QUARTER_8K = STAGE == 0 ? 6 : (STAGE == 1 ? 4 : 2);       // ~quarter of the per-crop time in units of 8128 cycles
+        for (int k = 0; k < grp * QUARTER_8K; ++k) BM_SLEEP_8K();
+    }
     constexpr int KT = G::KT, NT = G::NT, MIDP = G::MIDP, NCT = G::NCT, COUT = G::COUT, P = G::P;
     constexpr int KIN = CIN == 16 ? 1 : CIN / 32;
     constexpr int PREV_CIN = STAGE == 0 ? 16 : 64, KINP = PREV_CIN == 16 ? 1 : PREV_CIN / 32;
@@ -476,7 +500,7 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
             }
         } else if constexpr (RECON) {
 #pragma unroll
-            for (int ct = 0; ct < KT; ++ct) t.x2p[ct] = *reinterpret_cast<const f4*>(x2w + (i * KT + ct) * 256);
+            for (int ct = 0; ct < KT; ++ct) t.x2p[ct] = BM_NT_LOAD(reinterpret_cast<const f4*>(x2w + (i * KT + ct) * 256));
             if constexpr (PREV_CIN == 16) {
                 const unsigned o = p * 16 + g * 4;
                 t.rxh[0] = cat8(*reinterpret_cast<const h4*>(xh + o), *reinterpret_cast<const h4*>(xl + o));
@@ -570,8 +594,8 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
 #pragma unroll
                 for (int ks = 0; ks < KSN; ++ks)
                     an = mm3(wln + (long)(ks * KT + ct) * HP_FRAG_PAIR, lane, cat8(yh[2 * ks], yh[2 * ks + 1]), cat8(yl[2 * ks], yl[2 * ks + 1]), an);
-                *reinterpret_cast<f4*>(x1w + (i * KT + ct) * 256) = relu4(an);
-                *reinterpret_cast<f4*>(x2w + (i * KT + ct) * 256) = x2[i][ct];
+                BM_NT_STORE(reinterpret_cast<f4*>(x1w + (i * KT + ct) * 256), relu4(an));
+                BM_NT_STORE(reinterpret_cast<f4*>(x2w + (i * KT + ct) * 256), x2[i][ct]);
             }
             BM_SCHED_FENCE();
         }
@@ -589,8 +613,8 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
                 h4 hh, ll;
                 split4(y[co], hh, ll);
                 const unsigned o = p * COUT + g * (COUT / 4) + 4 * co;
-                *reinterpret_cast<h4*>(yh_out + o) = hh;
-                *reinterpret_cast<h4*>(yl_out + o) = ll;
+                BM_NT_STORE(reinterpret_cast<h4*>(yh_out + o), hh);
+                BM_NT_STORE(reinterpret_cast<h4*>(yl_out + o), ll);
             }
             BM_SCHED_FENCE();
         }
@@ -641,8 +665,8 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
                     h4 hh, ll;
                     split4(sp, hh, ll);
                     const unsigned o = po * COUT + g * (COUT / 4) + 4 * ct;
-                    *reinterpret_cast<h4*>(yh_out + o) = hh;
-                    *reinterpret_cast<h4*>(yl_out + o) = ll;
+                    BM_NT_STORE(reinterpret_cast<h4*>(yh_out + o), hh);
+                    BM_NT_STORE(reinterpret_cast<h4*>(yl_out + o), ll);
                 }
             }
             BM_SCHED_FENCE();

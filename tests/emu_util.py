@@ -86,7 +86,7 @@ DOCS_I = ("max_age", "min_hits", "delta_t", "embedding_off", "aw_off", "use_byte
 def build_docs(sanitize: bool = False, threads: int = 64) -> Path:
     src = HERE / "emu_docs.cpp"
     csrc = HERE.parent.parent / "boxmot_amd" / "csrc"
-    deps = [src, HERE / "hip_shim.hpp", csrc / "deepocsort_step.hpp", csrc / "block_prims.hpp", csrc / "kernel_macros.hpp",
+    deps = [src, HERE / "hip_shim.hpp", csrc / "deepocsort_step.hpp", csrc / "lap_jv.hpp", csrc / "block_prims.hpp", csrc / "kernel_macros.hpp",
             csrc / "botsort_types.hpp"]
     out = HERE / ("libemu_docs_asan.so" if sanitize else ("libemu_docs.so" if threads == 64 else f"libemu_docs_t{threads}.so"))
     if not out.exists() or any(d.stat().st_mtime > out.stat().st_mtime for d in deps):

@@ -126,4 +126,42 @@ int emu_docs_dump(void* h, int* ints, double* kf, double* emb, int* counters) {
     return n;
 }
 
+
+// The Jonker-Volgenant solver of lap_jv.hpp alone on a given n_rows x n_cols matrix (row-major), as one workgroup of NTHR threads:
+// x[n_rows] = column of each row, y[n_cols] = row of each column (-1 = unassigned), what lap.lapjv(extend_cost=True[, cost_limit]) returns.
+struct JvArg { int nr, nc; const double* cost; int use_limit; double limit; int* x; int* y; int tid; int* ok; };
+static void* jv_main(void* p) {
+    JvArg* a = static_cast<JvArg*>(p);
+    threadIdx.x = a->tid;
+    blockIdx.x = 0;
+    const bm::Ctx c = bm::make_ctx(g_s_int, g_s_dbl);
+    const bm::JvLds L = bm::jv_carve(g_dyn, a->nr + a->nc);
+    const double* cm = a->cost;
+    const int nc = a->nc;
+    const bool ok = bm::lap_jv_extended(c, L, a->nr, a->nc, [&](int i, int j) { return cm[(long)i * nc + j]; }, a->use_limit != 0, a->limit, a->x, a->y);
+    if (a->tid == 0) *a->ok = ok ? 1 : 0;
+    return nullptr;
+}
+int emu_lap_jv(int nr, int nc, const double* cost, int use_limit, double limit, int* x, int* y) {
+    static int s_int[bm::MAX_WAVES + 1];
+    static double s_dbl[bm::MAX_WAVES];
+    std::vector<double> dyn((size_t)bm::jv_lds_bytes(nr + nc) / 8 + 2, 0.0);
+    g_s_int = s_int; g_s_dbl = s_dbl; g_dyn = reinterpret_cast<unsigned char*>(dyn.data());
+    static EmuBlock block;
+    g_emu_block = &block;
+    blockDim.x = NTHR;
+    block.block_barrier.init(NTHR);
+    for (int w = 0; w < EMU_MAX_WAVES; ++w) block.wave_barrier[w].init(EMU_WAVE);
+    int ok = 0;
+    std::vector<pthread_t> th(NTHR);
+    std::vector<JvArg> ta(NTHR);
+    pthread_attr_t attr;
+    pthread_attr_init(&attr);
+    pthread_attr_setstacksize(&attr, 1 << 20);
+    for (int t = 0; t < NTHR; ++t) { ta[t] = JvArg{nr, nc, cost, use_limit, limit, x, y, t, &ok}; pthread_create(&th[t], &attr, jv_main, &ta[t]); }
+    for (int t = 0; t < NTHR; ++t) pthread_join(th[t], nullptr);
+    pthread_attr_destroy(&attr);
+    return ok;
+}
+
 }  // extern "C"

@@ -29,6 +29,7 @@ extern EmuDim3 blockDim;
 extern EmuDim3 gridDim;
 
 #define BM_CLOCK() 0LL
+#define BM_SLEEP_8K() ((void)0)
 constexpr int EMU_WAVE = 64;
 constexpr int EMU_MAX_WAVES = 16;
 
@@ -88,6 +89,11 @@ inline unsigned long long __ballot(int pred) {
 }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline int atomicMax(int* p, int v) {
+    int old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (old < v && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return old;
+}
 
 // ---- additions for the fused ReID kernels (compiled with a host clang that knows _Float16) ----
 #define __restrict__

@@ -48,7 +48,7 @@ def test_emulated_deepocsort_matches_oracle_stress(kw, seed):
 def test_emulated_deepocsort_four_wavefronts():
     """The same parity with a 256-thread workgroup: the wave-per-row cost loops, the cross-wavefront reductions and the solver
     with more than one wavefront."""
-    _run(stress_frames(50, seed=13, max_objects=30), 32, 128, 64, lap_rule="lowest_index", threads=256)
+    _run(stress_frames(50, seed=13, max_objects=30), 32, 128, 64, threads=256)
 
 
 @pytest.mark.parametrize("seed", [22, 24, 28])
@@ -58,8 +58,8 @@ def test_emulated_deepocsort_tie_prone_scenes(seed):
     from lapx (unavailable, parity unpinned); here the oracle is run with the device solver's tie rule so that
     everything else -- costs, filters, recovery round, bookkeeping -- is still compared exactly."""
     frames = stress_frames(80, seed=seed, max_objects=30)
-    _run(frames, 32, 128, 64, lap_rule="lowest_index")
-    _run(frames, 32, 128, 64, lap_rule="lowest_index", max_age=8, min_hits=2, iou_threshold=0.2)
+    _run(frames, 32, 128, 64)
+    _run(frames, 32, 128, 64, max_age=8, min_hits=2, iou_threshold=0.2)
 
 
 def test_emulated_deepocsort_camera_motion_correction():
@@ -94,7 +94,7 @@ def test_emulated_kernels_clean_under_asan():
             "from emu_util import EmuDeepOcSort\n"
             "from oracle.deepocsort import DEFAULTS, OcSortOracle\n"
             "emu = EmuDeepOcSort({**DEFAULTS, 'embedding_off': 1, 'use_byte': 1, 'min_conf': 0.1}, cap=64, nd=32, dim=1, sanitize=True)\n"
-            "orc = OcSortOracle(lap_rule='lowest_index', use_byte=True)\n"
+            "orc = OcSortOracle(use_byte=True)\n"
             "for d, _ in stress_frames(20, seed=7):\n"
             "    g, w = emu.update(d[:32], None), np.asarray(orc.update(d[:32].copy()), dtype=np.float32).reshape(-1, 8)\n"
             "    assert g.shape == w.shape and np.array_equal(g[:, 4:], w[:, 4:])\n"
@@ -111,7 +111,7 @@ def test_emulated_ocsort_byte_association_matches_oracle(kw, seed):
     rows and the fp64 filter state of every track."""
     from oracle.deepocsort import OcSortOracle
     cfg = {**DEFAULTS, **{k: v for k, v in kw.items() if k in DEFAULTS}, "embedding_off": 1, "use_byte": 1, "min_conf": kw.get("min_conf", 0.1)}
-    orc, emu = OcSortOracle(lap_rule="lowest_index", use_byte=True, **kw), EmuDeepOcSort(cfg, cap=128, nd=64, dim=1)
+    orc, emu = OcSortOracle(use_byte=True, **kw), EmuDeepOcSort(cfg, cap=128, nd=64, dim=1)
     try:
         for t, (d, _) in enumerate(stress_frames(70, seed=seed)):
             want = np.asarray(orc.update(d.copy()), dtype=np.float32).reshape(-1, 8)

@@ -245,7 +245,7 @@ def test_reference_bytetrack_and_ocsort_bindings(lib):
     ocfg = _OcSortCConfig(0.1, 0.3, 0.3, 30, 3, 3, 1, 0.2, 0.01, 0.0001, 50)
     h = lib.boxmot_ocsort_create(ctypes.byref(ocfg))
     assert h, lib.boxmot_ocsort_last_error()
-    orc = OcSortOracle(lap_rule="lowest_index", min_conf=_f32(0.1), use_byte=True, det_thresh=_f32(0.3), iou_threshold=_f32(0.3), max_age=30, min_hits=3,
+    orc = OcSortOracle(min_conf=_f32(0.1), use_byte=True, det_thresh=_f32(0.3), iou_threshold=_f32(0.3), max_age=30, min_hits=3,
                        delta_t=3, inertia=_f32(0.2), Q_xy_scaling=_f32(0.01), Q_s_scaling=_f32(0.0001))
     for t, (dets, _) in enumerate(stress_frames(100, seed=5)):
         ok, got, _ = _call_update(lib.boxmot_ocsort_update, h, dets, None, img, with_embs=False)

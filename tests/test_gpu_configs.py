@@ -19,7 +19,7 @@ def test_config3_deepocsort_128_dets_512_tracks():
     sc = Scenario(128, 512, emb_dim=512, random_image=False)
     img = np.zeros((1080, 1920, 3), dtype=np.uint8)
     trk = DeepOcSort(cmc_off=True, emb_dim=512, max_tracks=1024, max_dets=512)
-    orc = DeepOcSortOracle(lap_rule="lowest_index")
+    orc = DeepOcSortOracle()
     rows = 0
     for t in range(9):
         d, e = sc.frame(t)

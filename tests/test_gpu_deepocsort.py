@@ -56,7 +56,7 @@ def test_hip_deepocsort_tie_prone_scenes(seed):
     from oracle.deepocsort import DeepOcSortOracle
     img = np.zeros((480, 640, 3), dtype=np.uint8)
     for kw in ({}, dict(max_age=8, min_hits=2, iou_threshold=0.2)):
-        trk, orc = _tracker(emb_dim=32, max_tracks=128, max_dets=64, **kw), DeepOcSortOracle(lap_rule="lowest_index", **kw)
+        trk, orc = _tracker(emb_dim=32, max_tracks=128, max_dets=64, **kw), DeepOcSortOracle(**kw)
         for t, (dets, embs) in enumerate(stress_frames(120, seed=seed, max_objects=30)):
             got = np.asarray(trk.update(dets, img, embs)).reshape(-1, 8)
             assert_rows_match(got, orc.update(dets, img, embs.copy()).reshape(-1, 8), t)
@@ -148,7 +148,7 @@ def test_hip_ocsort_matches_oracle_and_surface():
     img = np.zeros((480, 640, 3), dtype=np.uint8)
     for kw in ({}, dict(max_age=5, min_hits=1, delta_t=2), dict(det_thresh=0.6, inertia=0.1, iou_threshold=0.2), dict(use_byte=True),
                dict(use_byte=True, min_conf=0.2, det_thresh=0.6, inertia=0.1)):
-        trk, orc = OcSort(max_tracks=128, max_dets=64, **kw), OcSortOracle(lap_rule="lowest_index", **kw)
+        trk, orc = OcSort(max_tracks=128, max_dets=64, **kw), OcSortOracle(**kw)
         for t, (dets, embs) in enumerate(stress_frames(100, seed=3)):
             got = np.asarray(trk.update(dets, img, embs)).reshape(-1, 8)          # embeddings are accepted and ignored
             assert_rows_match(got, np.asarray(orc.update(dets, img), dtype=np.float32).reshape(-1, 8), t)

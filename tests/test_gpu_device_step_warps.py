@@ -38,7 +38,7 @@ def _run(name, n_frames=40, seed=11):
         h = lib.boxmot_hip_deepocsort_create(ctypes.byref(cfg))
         step, set_warp, sync, destroy = (lib.boxmot_hip_deepocsort_step_device, lib.boxmot_hip_deepocsort_set_warp,
                                           lib.boxmot_hip_deepocsort_synchronize, lib.boxmot_hip_deepocsort_destroy)
-        orc = DeepOcSortOracle(lap_rule="lowest_index")       # the warp is supplied per frame (cmc_off is a wrapper-level switch)
+        orc = DeepOcSortOracle()       # the warp is supplied per frame (cmc_off is a wrapper-level switch)
     assert h, _lib.last_error()
     d_dets = torch.zeros((nd, 6), dtype=torch.float32, device=dev)
     d_embs = torch.zeros((nd, dim), dtype=torch.float32, device=dev)

@@ -75,7 +75,7 @@ def test_long_config3_deepocsort_128x512_240_frames():
     sc = Scenario(128, 512, emb_dim=512, random_image=False)
     img = np.zeros((1080, 1920, 3), dtype=np.uint8)
     trk = DeepOcSort(cmc_off=True, emb_dim=512, max_tracks=1024, max_dets=512)
-    orc = DeepOcSortOracle(lap_rule="lowest_index")       # the device's choice among exactly tied optima
+    orc = DeepOcSortOracle()       # the device's choice among exactly tied optima
     rows = 0
     for t in range(240):
         d, e = sc.frame(t)
@@ -180,7 +180,7 @@ def test_deepocsort_with_osnet_x1_0_fp16_inside_update_matches_oracle_ids():
     sc = Scenario(12, 24, width=960, height=540, random_image=True)
     reid = HipReID(sd, max_crops=32, mode=1)
     trk = DeepOcSort(reid_model=reid, cmc_off=True, max_tracks=128, max_dets=64)
-    orc = DeepOcSortOracle(reid=OracleReID(sd), lap_rule="lowest_index")
+    orc = DeepOcSortOracle(reid=OracleReID(sd))
     for t in range(14):
         dets, _ = sc.frame(t, with_embs=False)
         got = np.asarray(trk.update(dets, sc.image)).reshape(-1, 8)
@@ -202,7 +202,7 @@ def test_deepocsort_with_osnet_x1_0_inside_update_matches_oracle_ids():
     sc = Scenario(12, 24, width=960, height=540, random_image=True)
     reid = HipReID(sd, max_crops=32)
     trk = DeepOcSort(reid_model=reid, cmc_off=True, max_tracks=128, max_dets=64)
-    orc = DeepOcSortOracle(reid=OracleReID(sd), lap_rule="lowest_index")
+    orc = DeepOcSortOracle(reid=OracleReID(sd))
     for t in range(14):
         dets, _ = sc.frame(t, with_embs=False)
         got = np.asarray(trk.update(dets, sc.image)).reshape(-1, 8)
@@ -249,7 +249,7 @@ def test_deepocsort_with_reid_inside_update_both_kernel_families(mode):
     sc = Scenario(12, 24, width=960, height=540, random_image=True)
     reid = HipReID(sd, max_crops=32, mode=mode)
     trk = DeepOcSort(reid_model=reid, cmc_off=True, max_tracks=128, max_dets=64)
-    orc = DeepOcSortOracle(reid=OracleReID(sd), lap_rule="lowest_index")
+    orc = DeepOcSortOracle(reid=OracleReID(sd))
     for t in range(16):
         dets, _ = sc.frame(t, with_embs=False)
         got = np.asarray(trk.update(dets, sc.image)).reshape(-1, 8)
@@ -296,3 +296,127 @@ def test_stateful_cmc_is_asked_only_while_tracks_exist():
         assert_rows_match(got, want, t, box_atol=1e-3)
     assert cmc_hip.calls == cmc_orc.calls and 0 < len(cmc_hip.calls) < len(frames)
     trk.close()
+
+
+def test_long_config3_deepocsort_240_frames_vs_reference_rows():
+    """Configuration 3's tracker at full size (128 dets x 512 tracks, 512-d embeddings supplied) against rows of the REAL reference
+    DeepOcSort (tests/golden/config3_deepocsort_golden.npz, tests/golden/make_config_golden.py c3): ids / det indices / classes /
+    confidences exact for 240 frames.  The device's assignment is the Jonker-Volgenant code (lap_jv.hpp): no tie rule is
+    switched anywhere."""
+    from boxmot_amd import DeepOcSort
+    from boxmot_amd.scenario import Scenario
+    want = _golden_frames("config3_deepocsort_golden.npz")
+    assert len(want) >= 240
+    sc = Scenario(128, 512, emb_dim=512, random_image=False)
+    img = np.zeros((1080, 1920, 3), dtype=np.uint8)
+    trk = DeepOcSort(cmc_off=True, emb_dim=512, max_tracks=1024, max_dets=512)
+    for t in range(240):
+        d, e = sc.frame(t)
+        got = np.asarray(trk.update(d, img, e)).reshape(-1, 8)
+        assert_rows_match(got, want[t], t, box_atol=2e-3)
+    trk.close()
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+def test_config3_reid_inside_update_full_size_vs_reference_rows(mode):
+    """Configuration 3 with its backbone inside update, at full size: the device-resident DeepOCSORT step with OSNet-x1.0 (fp16 MFMA
+    kernel family, and the per-layer fp32 kernels) against rows of the reference DeepOcSort + reference OSNet-x1.0 module on the
+    CPU (tests/golden/config3_reid_golden.npz), >= 60 frames: ids exact."""
+    import ctypes
+    import os
+    import tempfile
+
+    import torch
+
+    from boxmot_amd import _lib
+    from boxmot_amd.reid_weights import pack_osnet, reference_init_state_dict, save_blob
+    from boxmot_amd.scenario import Scenario
+    want = _golden_frames("config3_reid_golden.npz")
+    assert len(want) >= 60
+    n_frames = len(want) if mode == 1 else 24           # the fp32 per-layer kernels are ~30x slower: a shorter check
+    lib = _lib.load()
+    blob = pack_osnet(reference_init_state_dict("osnet_x1_0", seed=0))
+    fd, path = tempfile.mkstemp(suffix=".reidblob")
+    os.close(fd)
+    save_blob(blob, path)
+    sc = Scenario(128, 512, width=1920, height=1080, emb_dim=8, stream=0, random_image=True)
+    cfg = _lib.DeepOcSortConfig()
+    lib.boxmot_hip_deepocsort_default_config(ctypes.byref(cfg))
+    cfg.cmc_off = 1
+    cfg.n_streams, cfg.max_tracks, cfg.max_dets, cfg.emb_dim = 1, 1024, 512, 512
+    cfg.reid_model_path = path.encode()
+    h = lib.boxmot_hip_deepocsort_create(ctypes.byref(cfg))
+    os.unlink(path)
+    assert h, _lib.last_error()
+    _lib.check(lib.boxmot_hip_deepocsort_set_reid_mode(h, mode))
+    dev = torch.device("cuda:0")
+    frame = torch.from_numpy(sc.image).to(dev)
+    ptrs = torch.tensor([frame.data_ptr()], dtype=torch.int64, device=dev)
+    d_dets = torch.zeros((512, 6), dtype=torch.float32, device=dev)
+    d_n = torch.zeros(1, dtype=torch.int32, device=dev)
+    d_out = torch.zeros((1024, 8), dtype=torch.float32, device=dev)
+    d_out_n = torch.zeros(1, dtype=torch.int32, device=dev)
+    try:
+        for t in range(n_frames):
+            dets, _ = sc.frame(t, with_embs=False)
+            d_dets[: len(dets)] = torch.from_numpy(dets).to(dev)
+            d_n[0] = len(dets)
+            torch.cuda.synchronize()
+            _lib.check(lib.boxmot_hip_deepocsort_step_device_frames(h, d_dets.data_ptr(), d_n.data_ptr(), ptrs.data_ptr(), 1080, 1920,
+                                                                    d_out.data_ptr(), d_out_n.data_ptr()))
+            _lib.check(lib.boxmot_hip_deepocsort_synchronize(h))
+            got = d_out[: int(d_out_n[0])].cpu().numpy()
+            assert_rows_match(got, want[t], t, box_atol=5e-3)
+    finally:
+        lib.boxmot_hip_deepocsort_destroy(h)
+
+
+def test_config5_reid_inside_update_full_size_vs_reference_rows():
+    """Configuration 5 with its backbone inside update, at full size (StrongSORT + CLIP-ReID ViT-B/16, 256 dets x 1024 tracks, 4K frame):
+    the device-resident step against rows of the reference StrongSort + the reference CLIP-ReID modules on the CPU
+    (tests/golden/config5_reid_golden.npz), >= 60 frames: ids exact (the sample banks fill to 60 of their 100 entries)."""
+    import ctypes
+    import os
+    import tempfile
+
+    import torch
+
+    from boxmot_amd import _lib
+    from boxmot_amd.clip_weights import pack_clipreid, random_clipreid_state_dict
+    from boxmot_amd.reid_weights import save_blob
+    from boxmot_amd.scenario import Scenario
+    want = _golden_frames("config5_reid_golden.npz")
+    assert len(want) >= 60
+    lib = _lib.load()
+    blob = pack_clipreid(random_clipreid_state_dict(0))
+    fd, path = tempfile.mkstemp(suffix=".reidblob")
+    os.close(fd)
+    save_blob(blob, path)
+    sc = Scenario(256, 1024, width=3840, height=2160, emb_dim=8, stream=0, random_image=True)
+    cfg = _lib.StrongSortConfig()
+    lib.boxmot_hip_strongsort_default_config(ctypes.byref(cfg))
+    cfg.n_streams, cfg.max_tracks, cfg.max_dets, cfg.emb_dim = 1, 2048, 1024, 1280
+    cfg.reid_model_path = path.encode()
+    h = lib.boxmot_hip_strongsort_create(ctypes.byref(cfg))
+    os.unlink(path)
+    assert h, _lib.last_error()
+    dev = torch.device("cuda:0")
+    frame = torch.from_numpy(sc.image).to(dev)
+    ptrs = torch.tensor([frame.data_ptr()], dtype=torch.int64, device=dev)
+    d_dets = torch.zeros((1024, 6), dtype=torch.float32, device=dev)
+    d_n = torch.zeros(1, dtype=torch.int32, device=dev)
+    d_out = torch.zeros((2048, 8), dtype=torch.float32, device=dev)
+    d_out_n = torch.zeros(1, dtype=torch.int32, device=dev)
+    try:
+        for t in range(len(want)):
+            dets, _ = sc.frame(t, with_embs=False)
+            d_dets[: len(dets)] = torch.from_numpy(dets).to(dev)
+            d_n[0] = len(dets)
+            torch.cuda.synchronize()
+            _lib.check(lib.boxmot_hip_strongsort_step_device_frames(h, d_dets.data_ptr(), d_n.data_ptr(), ptrs.data_ptr(), 2160, 3840,
+                                                                    d_out.data_ptr(), d_out_n.data_ptr()))
+            _lib.check(lib.boxmot_hip_strongsort_synchronize(h))
+            got = d_out[: int(d_out_n[0])].cpu().numpy()
+            assert_rows_match(got, want[t], t, box_atol=2e-2)
+    finally:
+        lib.boxmot_hip_strongsort_destroy(h)

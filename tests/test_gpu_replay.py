@@ -30,7 +30,7 @@ def test_replay_all_sequences_at_once_equals_per_sequence_oracle(kind, tmp_path)
     seqs = _sequences()
     conf = 0.15
     got = replay_to_dir(seqs, tmp_path, tracker_type=kind, conf_threshold=conf, max_tracks=256, max_dets=64)
-    make = {"botsort": BotSortOracle, "deepocsort": lambda: DeepOcSortOracle(lap_rule="lowest_index"), "strongsort": StrongSortOracle}[kind]
+    make = {"botsort": BotSortOracle, "deepocsort": lambda: DeepOcSortOracle(), "strongsort": StrongSortOracle}[kind]
     for s in seqs:
         orc, want = make(), []
         for fid in s.frame_ids:

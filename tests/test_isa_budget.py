@@ -27,7 +27,8 @@ def test_hot_kernels_keep_their_register_budget():
     stem_hp = find("k_stem_resize_fused_hp")
     assert len(stem_hp) == 1
     for k, v in stem_hp.items():
-        assert v["vgpr"] <= 256 and v["scratch"] == 0 and v["mfma"] == 126, (k, v)     # (hi, lo) weights: two MFMAs per k-step
+        assert v["vgpr"] <= 128 and v["scratch"] <= 32 and v["mfma"] == 126, (k, v)    # (hi, lo) weights: two MFMAs per k-step; the lo
+                                                                                      # fragments live in LDS so two crops share a CU
     hp = find("k_osblock_hp")                                                # the fp32-grade family: one 8-wave workgroup per CU in
     assert len(hp) == 6                                                      # stages 0 / 1 (<= 256 registers), two in stage 2 (<= 128)
     for k, v in hp.items():

@@ -1,0 +1,67 @@
+"""The device's Jonker-Volgenant solver (boxmot_amd/csrc/lap_jv.hpp, executed unchanged on CPU threads) against the oracle's
+sequential restatement of lap.lapjv (oracle/lapjv.c) -- the SAME assignment, not just the same optimum: tie-heavy matrices (small
+integer costs, blocks of zeros as zero-IoU pairs produce them, clamped costs), both rectangular orientations, with and without
+cost_limit, one and four wavefronts per workgroup."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from emu_util import build_docs
+from oracle import lap as olap
+
+
+def _lib(threads):
+    lib = ctypes.CDLL(str(build_docs(threads=threads)))
+    lib.emu_lap_jv.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
+    lib.emu_lap_jv.restype = ctypes.c_int
+    return lib
+
+
+def _cases(rng, n_cases):
+    for k in range(n_cases):
+        nr, nc = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        kind = k % 6
+        if kind == 0:
+            c = rng.integers(0, 3, (nr, nc)).astype(np.float64)                     # heavy ties
+        elif kind == 1:
+            c = -np.where(rng.random((nr, nc)) < 0.15, rng.random((nr, nc)), 0.0)   # DeepOCSORT-like: mostly zero, a few negative
+        elif kind == 2:
+            c = rng.random((nr, nc))                                                # generic
+        elif kind == 3:
+            c = np.minimum(rng.random((nr, nc)) * 2.0, 1.0)                         # clamped
+        elif kind == 4:
+            c = np.zeros((nr, nc))                                                  # everything tied
+        else:
+            c = -np.round(rng.random((nr, nc)), 1)
+        yield np.ascontiguousarray(c)
+
+
+@pytest.mark.parametrize("threads", [64, 256])
+def test_device_jv_returns_the_oracles_assignment_tie_for_tie(threads):
+    lib = _lib(threads)
+    rng = np.random.default_rng(7)
+    n = 0
+    for c in _cases(rng, 72 if threads == 64 else 30):
+        nr, nc = c.shape
+        for limit in (None, 0.5, 1.5):
+            x = np.full(nr, -9, np.int32)
+            y = np.full(nc, -9, np.int32)
+            ok = lib.emu_lap_jv(nr, nc, c.ctypes.data, int(limit is not None), float(limit or 0.0), x.ctypes.data, y.ctypes.data)
+            assert ok == 1
+            _, wx, wy = olap.lapjv(c, extend_cost=True, cost_limit=np.inf if limit is None else limit)
+            assert np.array_equal(x, wx) and np.array_equal(y, wy), (c.shape, limit, c, x, wx)
+            n += 1
+    assert n == 3 * (72 if threads == 64 else 30)
+
+
+def test_device_jv_larger_problem_with_ties():
+    lib = _lib(256)
+    rng = np.random.default_rng(3)
+    for nr, nc in ((128, 90), (70, 150)):
+        c = -np.where(rng.random((nr, nc)) < 0.05, np.round(rng.random((nr, nc)), 2), 0.0)
+        x = np.full(nr, -9, np.int32)
+        y = np.full(nc, -9, np.int32)
+        assert lib.emu_lap_jv(nr, nc, c.ctypes.data, 0, 0.0, x.ctypes.data, y.ctypes.data) == 1
+        _, wx, wy = olap.lapjv(c, extend_cost=True)
+        assert np.array_equal(x, wx) and np.array_equal(y, wy)

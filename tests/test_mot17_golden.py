@@ -94,7 +94,7 @@ def test_hip_replay_reproduces_reference_on_mot17_detections(kind):
         if kind in ("deepocsort", "ocsort", "ocsort_yaml", "ocsort_byte"):
             # the device assignment breaks exact cost ties towards the lowest index, the reference's (stand-in) solver
             # otherwise; the oracle with the device's rule must still equal the reference here (no decisive tie)
-            orc, w2 = _oracle(kind, lap_rule="lowest_index"), {}
+            orc, w2 = _oracle(kind), {}
             for fid, d, e in _frames(g, seq):
                 if len(d):
                     w2[fid] = np.asarray(orc.update(d.copy(), None, e.copy()), dtype=np.float32).reshape(-1, 8)

@@ -3,7 +3,7 @@ real reference classes; CPU only)."""
 import numpy as np
 import pytest
 
-from common import CASES, golden_rows
+from common import CASES, GOLDEN, golden_rows
 from oracle.botsort import BotSortOracle
 
 
@@ -123,3 +123,21 @@ def test_oracle_reid_matches_reference_features():
     # same torch build -> identical; allow float noise in case the CPU dispatches other conv kernels
     assert np.abs(feats - g["feats"]).max() < 1e-5
     assert np.allclose(np.linalg.norm(feats, axis=1), 1.0, atol=1e-5)
+
+
+def test_deepocsort_oracle_matches_reference_rows_at_config3_scale():
+    """BASELINE.json configuration 3's tracker (128 dets x 512 tracks, 512-d) for the first 60 frames: the oracle against rows of
+    the real reference DeepOcSort (tests/golden/config3_deepocsort_golden.npz, tests/golden/make_config_golden.py c3)."""
+    from boxmot_amd.scenario import Scenario
+    from oracle.deepocsort import DeepOcSortOracle
+    g = np.load(GOLDEN / "config3_deepocsort_golden.npz")
+    offs = np.concatenate([[0], np.cumsum(g["counts"])])
+    sc = Scenario(128, 512, emb_dim=512, random_image=False)
+    orc = DeepOcSortOracle()
+    for t in range(60):
+        d, e = sc.frame(t)
+        got = np.asarray(orc.update(d, None, e), dtype=np.float32).reshape(-1, 8)
+        lo, hi = offs[t], offs[t + 1]
+        assert len(got) == hi - lo, t
+        assert np.array_equal(got[:, 4].astype(np.int32), g["ids"][lo:hi]) and np.array_equal(got[:, 7].astype(np.int32), g["det_ind"][lo:hi]), t
+        assert np.allclose(got[:, :4], g["boxes"][lo:hi], rtol=0, atol=1e-4), t

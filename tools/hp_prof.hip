@@ -97,12 +97,12 @@ static void run_stem(int n, int iters, const bm::OsnetLayout& L, const std::vect
     int* d_cs; CK(hipMalloc(&d_cs, n * 4)); CK(hipMemset(d_cs, 0, n * 4));
     float* d_boxes = dev(boxes);
     _Float16 *d_oh, *d_ol; CK(hipMalloc(&d_oh, (size_t)n * 2048 * 16 * 2)); CK(hipMalloc(&d_ol, (size_t)n * 2048 * 16 * 2));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(bm::k_stem_resize_fused_hp), hipFuncAttributeMaxDynamicSharedMemorySize, bm::STEM2_LDS));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(bm::k_stem_resize_fused_hp), hipFuncAttributeMaxDynamicSharedMemorySize, bm::STEM2_LDS_HP));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float best = 1e9f;
     for (int it = 0; it < iters; ++it) {
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(bm::k_stem_resize_fused_hp, dim3(n), dim3(512), bm::STEM2_LDS, 0, (const uint8_t* const*)d_frames, (const int*)d_cs,
+        hipLaunchKernelGGL(bm::k_stem_resize_fused_hp, dim3(n), dim3(512), bm::STEM2_LDS_HP, 0, (const uint8_t* const*)d_frames, (const int*)d_cs,
                            (const float*)d_boxes, 4, W, H, d_oh, d_ol, (const unsigned char*)d_w, (const int*)nullptr);
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -112,7 +112,7 @@ static void run_stem(int n, int iters, const bm::OsnetLayout& L, const std::vect
 #ifdef BM_OSBLOCK_PROF
     unsigned long long zero[8] = {}, acc[8] = {};
     CK(hipMemcpyToSymbol(HIP_SYMBOL(bm::g_osblock_prof), zero, sizeof(zero)));
-    hipLaunchKernelGGL(bm::k_stem_resize_fused_hp, dim3(n), dim3(512), bm::STEM2_LDS, 0, (const uint8_t* const*)d_frames, (const int*)d_cs,
+    hipLaunchKernelGGL(bm::k_stem_resize_fused_hp, dim3(n), dim3(512), bm::STEM2_LDS_HP, 0, (const uint8_t* const*)d_frames, (const int*)d_cs,
                        (const float*)d_boxes, 4, W, H, d_oh, d_ol, (const unsigned char*)d_w, (const int*)nullptr);
     CK(hipDeviceSynchronize());
     CK(hipMemcpyFromSymbol(acc, HIP_SYMBOL(bm::g_osblock_prof), sizeof(acc)));

@@ -42,14 +42,14 @@ def main():
         cases = [
             ("botsort", lambda c: BotSort(use_cmc=use_w, cmc=c, emb_dim=32, max_tracks=1024, max_dets=64), lambda: BotSortOracle()),
             ("deepocsort", lambda c: DeepOcSort(cmc_off=not use_w, cmc=c, emb_dim=32, max_tracks=1024, max_dets=64),
-             lambda: DeepOcSortOracle(lap_rule="lowest_index")),
+             lambda: DeepOcSortOracle()),
             # StrongSORT against the oracle under the device's documented fp32 summation order (exact bar) and, as "strongsort_blas",
             # against the reference's NumPy / OpenBLAS product (ids can differ where clamped costs tie)
             ("strongsort", lambda c: StrongSort(cmc=c if use_w else None, emb_dim=32, max_tracks=1024, max_dets=64),
              lambda: StrongSortOracle(dot_rule="device")),
             ("strongsort_blas", lambda c: StrongSort(cmc=c if use_w else None, emb_dim=32, max_tracks=1024, max_dets=64), lambda: StrongSortOracle()),
             ("bytetrack", lambda c: ByteTrack(max_tracks=1024, max_dets=64), lambda: ByteTrackOracle()),
-            ("ocsort", lambda c: OcSort(max_tracks=1024, max_dets=64), lambda: OcSortOracle(lap_rule="lowest_index")),
+            ("ocsort", lambda c: OcSort(max_tracks=1024, max_dets=64), lambda: OcSortOracle()),
         ]
         if only:
             cases = [c for c in cases if c[0] in only]
