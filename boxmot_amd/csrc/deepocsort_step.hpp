@@ -368,101 +368,17 @@ __device__ inline DV docs_view(const DocsStepArgs& a, int s) {
 }
 
 // ---------------------------------------------------------------------------
-// Full assignment of the smaller side (lap.lapjv(cost, extend_cost=True), association.py:20-24): detections are
-// inserted one by one with a shortest augmenting path over the tracks; when there are more detections than
-// tracks, zero-cost dummy tracks R..C-1 complete the square (what the zero padding of the reference's extension
-// amounts to).  cost is det-major: cost[d * ld + t].  Solver state in dynamic LDS.  Exact; ties towards the lower
-// index (the reference's Jonker-Volgenant code may break exact ties differently).
-// Output: lap_x[t] = det of track t (t < R) or -1, lap_y[d] = track of det d or -1.
+// linear_assignment(cost) of association.py:20-24 -- lap.lapjv(cost, extend_cost=True) -- on a det-major matrix
+// cost[d * ld + t]: R columns (tracks), C rows (detections).  The solver is the Jonker-Volgenant code of lap_jv.hpp, which
+// returns, tie for tie, the assignment the sequential algorithm returns (oracle/lapjv.c); its state lives in dynamic LDS.
+// out_x[t] = row of column t, out_y[d] = column of row d, -1 = unassigned.
 // ---------------------------------------------------------------------------
 constexpr double DOCS_INF = 1e300;
-struct FullLapLds { double* v; double* minv; double* u; int* x; int* way; int* used; int* y; };
-// BM_DOCS_LAP_JV = 1 (default): the assignment is the Jonker-Volgenant code of lap_jv.hpp, tie for tie what lap.lapjv's algorithm
-// returns; 0: the round-1 / round-2 shortest-augmenting-path solver below (same optimum, lowest-index ties).
-#ifndef BM_DOCS_LAP_JV
-#define BM_DOCS_LAP_JV 1
-#endif
-__host__ __device__ inline long docs_lap_lds_bytes(int cap, int nd) {
-    const long n = cap + nd, a = n * (8 + 8 + 4 + 4 + 4) + (long)nd * (8 + 4) + 16, b = jv_lds_bytes((int)n);
-    return a > b ? a : b;
-}
-__device__ inline FullLapLds docs_carve_lap(unsigned char* base, int cap, int nd) {
-    const int n = cap + nd;
-    FullLapLds l;
-    l.v = reinterpret_cast<double*>(base); l.minv = l.v + n; l.u = l.minv + n;
-    l.x = reinterpret_cast<int*>(l.u + nd); l.way = l.x + n; l.used = l.way + n; l.y = l.used + n;
-    return l;
-}
-
-template <class CostFn>
-__device__ inline bool lap_full(const Ctx& c, const FullLapLds& L, int R, int C, CostFn cost_of, int* out_x, int* out_y) {
-    const int Rp = R > C ? R : C;
-    for (int t = c.tid; t < Rp; t += c.nthr) { L.x[t] = -1; L.v[t] = 0.0; }
-    for (int d = c.tid; d < C; d += c.nthr) { L.y[d] = -1; L.u[d] = 0.0; }
-    __syncthreads();
-    bool stalled = false;
-    for (int s = 0; s < C && !stalled; ++s) {
-        for (int t = c.tid; t < Rp; t += c.nthr) { L.minv[t] = DOCS_INF; L.used[t] = 0; L.way[t] = -1; }
-        int cur = s, via = -1, end_track = -1, iter = 0;
-        const int max_iter = Rp + 2;
-        for (; iter < max_iter; ++iter) {
-            const double ucur = L.u[cur];
-            double best = DOCS_INF;
-            int best_t = -1;
-            for (int t = c.tid; t < Rp; t += c.nthr) {
-                if (L.used[t]) continue;
-                const double cst = t < R ? cost_of(cur, t) : 0.0;
-                double mv = L.minv[t];
-                const double cand = cst - ucur - L.v[t];
-                if (cand < mv) { mv = cand; L.minv[t] = cand; L.way[t] = via; }
-                if (mv < best || (mv == best && best_t < 0)) { best = mv; best_t = t; }
-            }
-            double gmin;
-            int gt;
-            block_argmin(c, best, best_t, gmin, gt);
-            if (gt < 0) { stalled = true; break; }
-            for (int t = c.tid; t < Rp; t += c.nthr) {
-                if (L.used[t]) { L.u[L.x[t]] += gmin; L.v[t] -= gmin; }
-                else if (L.minv[t] < DOCS_INF) L.minv[t] -= gmin;
-            }
-            if (c.tid == 0) L.u[s] += gmin;
-            if (c.tid == (gt % c.nthr)) L.used[gt] = 1;
-            __syncthreads();
-            if (L.x[gt] < 0) { end_track = gt; break; }
-            via = gt;
-            cur = L.x[gt];
-        }
-        __syncthreads();
-        if (stalled || iter >= max_iter) { stalled = true; break; }
-        if (c.tid == 0) {
-            int t = end_track, guard = 0;
-            while (t >= 0 && guard++ <= Rp) {
-                const int prev = L.way[t];
-                const int det = (prev >= 0) ? L.x[prev] : s;
-                L.x[t] = det;
-                L.y[det] = t;
-                t = prev;
-            }
-        }
-        __syncthreads();
-    }
-    for (int t = c.tid; t < R; t += c.nthr) out_x[t] = stalled ? -1 : L.x[t];
-    for (int d = c.tid; d < C; d += c.nthr) out_y[d] = (stalled || L.y[d] >= R) ? -1 : L.y[d];
-    __syncthreads();
-    return !stalled;
-}
-
-// linear_assignment(cost) of association.py:20-24 on a det-major matrix: R columns (tracks), C rows (detections);
-// out_x[t] = row of column t, out_y[d] = column of row d, -1 = unassigned
-template <class CostFn>
-__device__ inline bool docs_assign(const Ctx& c, unsigned char* dyn_lds, const FullLapLds& L, int R, int C, CostFn cost_of, int* out_x, int* out_y) {
-#if BM_DOCS_LAP_JV
-    (void)L;
-    return lap_jv_extended(c, jv_carve(dyn_lds, R + C), C, R, cost_of, false, 0.0, out_y, out_x);
-#else
-    (void)dyn_lds;
-    return lap_full(c, L, R, C, cost_of, out_x, out_y);
-#endif
+__host__ __device__ inline long docs_lap_lds_bytes(int cap, int nd) { return jv_lds_bytes(cap + nd); }
+// One out-of-line copy for the three call sites of a frame step (first association, BYTE, recovery round): the solver gets its
+// own register allocation instead of sharing the frame step's.
+__device__ __noinline__ inline bool docs_assign(const Ctx& c, unsigned char* dyn_lds, int R, int C, const double* cost, long ld, int* out_x, int* out_y) {
+    return lap_jv_extended(c, jv_carve(dyn_lds, R + C), C, R, [=](int d, int t) { return cost[d * ld + t]; }, false, 0.0, out_y, out_x);
 }
 
 __device__ inline double iou_pair(const double* a, const double* b) {      // iou.py:134-150
@@ -566,7 +482,6 @@ __device__ inline void docs_step_stream(const DocsStepArgs& args, int s, int* s_
     const Ctx c = make_ctx(s_int, s_dbl);
     DV v = docs_view(args, s);
     const DocsConfigDev& cfg = v.cfg;
-    const FullLapLds lap = docs_carve_lap(dyn_lds, v.cap, v.nd);
     const long ld = v.cap;
     const int dim = v.dim;
     const bool use_emb = !cfg.embedding_off && v.embs != nullptr;
@@ -790,7 +705,7 @@ __device__ inline void docs_step_stream(const DocsStepArgs& args, int s, int* s_
             }
             __syncthreads();
             const double* cm = v.cost;
-            if (!docs_assign(c, dyn_lds, lap, nt, nk, [&](int d, int t) { return cm[d * ld + t]; }, v.lap_x, v.lap_y) && c.tid == 0)
+            if (!docs_assign(c, dyn_lds, nt, nk, cm, ld, v.lap_x, v.lap_y) && c.tid == 0)
                 *v.status = STATUS_LAP_STALL;
         }
         __syncthreads();
@@ -835,7 +750,7 @@ __device__ inline void docs_step_stream(const DocsStepArgs& args, int s, int* s_
         }
         if (mxi > cfg.iou_threshold) {
             const double* cm = v.cost;
-            if (!docs_assign(c, dyn_lds, lap, n_ut, n_byte, [&](int d, int t) { return cm[d * ld + t]; }, v.lap_x, v.lap_y) && c.tid == 0)
+            if (!docs_assign(c, dyn_lds, n_ut, n_byte, cm, ld, v.lap_x, v.lap_y) && c.tid == 0)
                 *v.status = STATUS_LAP_STALL;
             auto good_b = [&](int a) { return v.lap_y[a] >= 0 && !(v.iou[a * ld + v.lap_y[a]] < cfg.iou_threshold); };
             const int nb = block_append_if(c, n_byte, good_b, ident, v.tmp_a, 0);
@@ -878,7 +793,7 @@ __device__ inline void docs_step_stream(const DocsStepArgs& args, int s, int* s_
         }
         if (mxi > cfg.iou_threshold) {
             const double* cm = v.cost;
-            if (!docs_assign(c, dyn_lds, lap, n_ut, n_ud, [&](int d, int t) { return cm[d * ld + t]; }, v.lap_x, v.lap_y) && c.tid == 0)
+            if (!docs_assign(c, dyn_lds, n_ut, n_ud, cm, ld, v.lap_x, v.lap_y) && c.tid == 0)
                 *v.status = STATUS_LAP_STALL;
             auto good2 = [&](int a) { return v.lap_y[a] >= 0 && !(v.iou[a * ld + v.lap_y[a]] < cfg.iou_threshold); };
             const int n2 = block_append_if(c, n_ud, good2, ident, v.tmp_a, 0);

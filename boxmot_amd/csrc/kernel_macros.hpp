@@ -35,6 +35,10 @@
 // raw DPP move: lanes whose source lane does not exist take 0 (zero_fill) or keep `old`
 #define BM_DPP_U32(old, v, ctrl, zero_fill) ((unsigned)__builtin_amdgcn_update_dpp((int)(old), (int)(v), ctrl, 0xf, 0xf, zero_fill))
 #endif
+#ifndef BM_READLANE_U32
+// the value a given (compile-time) lane holds, as a wave-uniform scalar
+#define BM_READLANE_U32(v, l) ((unsigned)__builtin_amdgcn_readlane((int)(v), l))
+#endif
 #ifndef BM_WAVE_LDS_SYNC
 // LDS written by some lanes of a wavefront and read by others of the SAME wavefront: the DS operations of one wave execute in
 // order, so only the compiler has to be kept from reordering them (no workgroup barrier)

@@ -23,6 +23,10 @@
 #include "block_prims.hpp"
 #include "kernel_macros.hpp"
 
+#ifndef BM_JV_PROF
+#define BM_JV_PROF(k)            // tools/jv_prof.hip defines it to record a wall clock per phase
+#endif
+
 namespace bm {
 
 constexpr double JV_LARGE = 1.7976931348623157e308;          // DBL_MAX, the sequential code's LARGE
@@ -36,29 +40,96 @@ __device__ inline JvLds jv_carve(unsigned char* base, int n) {
     return l;
 }
 
+// Wave reductions on the DPP path (row rotations inside the 16-lane rows, then the four row results as scalars): the sequential
+// part of the solver is a chain of a few thousand of these, and the LDS crossbar (__shfl) costs several times as much.
+template <int CTRL> __device__ inline double jv_dpp(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = BM_DPP_U32(0u, (unsigned)b, CTRL, false), hi = BM_DPP_U32(0u, (unsigned)(b >> 32), CTRL, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
+template <int CTRL> __device__ inline int jv_dpp(int v) { return (int)BM_DPP_U32(0u, (unsigned)v, CTRL, false); }
+template <int LANE> __device__ inline double jv_lane(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = BM_READLANE_U32((unsigned)b, LANE), hi = BM_READLANE_U32((unsigned)(b >> 32), LANE);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
+template <int LANE> __device__ inline int jv_lane(int v) { return (int)BM_READLANE_U32((unsigned)v, LANE); }
+
+__device__ inline double jv_min2(double a, double b) { return b < a ? b : a; }
 __device__ inline double jv_wave_min(double v) {
-    for (int off = WAVE / 2; off > 0; off >>= 1) { const double o = __shfl_xor(v, off, WAVE); v = o < v ? o : v; }
-    return v;
+    v = jv_min2(v, jv_dpp<0x128>(v)); v = jv_min2(v, jv_dpp<0x124>(v)); v = jv_min2(v, jv_dpp<0x122>(v)); v = jv_min2(v, jv_dpp<0x121>(v));
+    return jv_min2(jv_min2(jv_lane<0>(v), jv_lane<16>(v)), jv_min2(jv_lane<32>(v), jv_lane<48>(v)));
 }
-__device__ inline int jv_wave_max_int(int v) {
-    for (int off = WAVE / 2; off > 0; off >>= 1) { const int o = __shfl_xor(v, off, WAVE); v = o > v ? o : v; }
-    return v;
+__device__ inline int jv_wave_min(int v) {
+    int o;
+    o = jv_dpp<0x128>(v); v = o < v ? o : v; o = jv_dpp<0x124>(v); v = o < v ? o : v;
+    o = jv_dpp<0x122>(v); v = o < v ? o : v; o = jv_dpp<0x121>(v); v = o < v ? o : v;
+    const int a = jv_lane<0>(v), b = jv_lane<16>(v), c = jv_lane<32>(v), d = jv_lane<48>(v);
+    const int ab = b < a ? b : a, cd = d < c ? d : c;
+    return cd < ab ? cd : ab;
 }
-// the two lexicographically smallest (value, index) pairs of the wave's candidates (each lane brings its own two)
+// The two smallest (value, column) pairs of a row scan, lexicographic -- "first column wins" among equal values, as the sequential
+// scan keeps them.  A lane visits its columns in ascending order, so inside a lane strict comparisons keep the earlier column
+// (the form of the sequential loop); across the lanes: the minimum value, the lowest column holding it, then the same again
+// with the winning lane offering its runner-up.  (A NaN cost never enters: every comparison with it is false.)
 struct JvTwo { double v1, v2; int j1, j2; };
-__device__ inline bool jv_less(double va, int ja, double vb, int jb) { return va < vb || (va == vb && ja < jb); }
+constexpr int JV_NO_COL = 0x7fffffff;
 __device__ inline void jv_two_insert(JvTwo& t, double r, int j) {
-    if (jv_less(r, j, t.v1, t.j1)) { t.v2 = t.v1; t.j2 = t.j1; t.v1 = r; t.j1 = j; }
-    else if (jv_less(r, j, t.v2, t.j2)) { t.v2 = r; t.j2 = j; }
-}
-__device__ inline JvTwo jv_wave_two(JvTwo t) {
-    for (int off = WAVE / 2; off > 0; off >>= 1) {
-        const double ov1 = __shfl_xor(t.v1, off, WAVE), ov2 = __shfl_xor(t.v2, off, WAVE);
-        const int oj1 = __shfl_xor(t.j1, off, WAVE), oj2 = __shfl_xor(t.j2, off, WAVE);
-        jv_two_insert(t, ov1, oj1);
-        jv_two_insert(t, ov2, oj2);
+    if (r < t.v2) {
+        if (r < t.v1) { t.v2 = t.v1; t.j2 = t.j1; t.v1 = r; t.j1 = j; }
+        else { t.v2 = r; t.j2 = j; }
     }
-    return t;
+}
+__device__ inline JvTwo jv_wave_two(const JvTwo& t) {
+    JvTwo o;
+    o.v1 = jv_wave_min(t.v1);
+    o.j1 = jv_wave_min(t.v1 == o.v1 ? t.j1 : JV_NO_COL);
+    const bool own = t.j1 == o.j1;
+    const double cv = own ? t.v2 : t.v1;
+    const int cj = own ? t.j2 : t.j1;
+    o.v2 = jv_wave_min(cv);
+    o.j2 = jv_wave_min(cv == o.v2 ? cj : JV_NO_COL);
+    return o;
+}
+
+// The TODO-list permutation of _find_dense / _scan_dense for the lanes [l0, seg_end) of one 64-column chunk at list position
+// `base`, in one step.  The sequential loop visits the positions in order; a position whose column joins the ready run (bit set
+// in `q`) is swapped with position `hi`, which then advances.  Seen from the list, the positions [hi, k) are a queue of passed-over
+// columns: a passed-over column is appended, a joining column sends the queue's head to its tail.  Every visited position is
+// therefore one push; the t-th joining column takes list position hi + t and pushes what the queue's t-th pop returns -- the
+// t-th push overall (one of the g0 columns queued before this chunk, or the push of lane l0 + t - g0, itself possibly a
+// re-push: resolved by pointer jumping).  The queue ends as pushes r.. at positions hi + r.., so a passed-over column keeps its
+// place unless a joining column lands on it.  A leading run of joining columns on an empty queue swaps with itself.
+__device__ inline void jv_move(const JvLds& L, int base, int l0, unsigned long long q, int& hi, int j, int lane) {
+    int g0 = base + l0 - hi;
+    if (g0 == 0) {
+        const unsigned long long rest = ~(q >> l0);
+        const int run = rest ? __builtin_ctzll(rest) : WAVE;
+        hi += run; l0 += run;
+        q = l0 >= WAVE ? 0ull : (q >> l0) << l0;
+    }
+    const int r = __builtin_popcountll(q);
+    if (r == 0) return;
+    const int H = hi;
+    const bool isq = (q >> lane) & 1ull;
+    const int t = __builtin_popcountll(q & ((1ull << lane) - 1ull));
+    bool resolved = true;
+    int val = j, ptr = lane;
+    if (isq) {
+        if (t < g0) val = L.cols[H + t];
+        else { resolved = false; ptr = l0 + t - g0; }
+    }
+    while (__ballot(!resolved)) {
+        const int pv = __shfl(val, ptr, WAVE), pr = __shfl((int)resolved, ptr, WAVE), pp = __shfl(ptr, ptr, WAVE);
+        if (!resolved) { if (pr) { val = pv; resolved = true; } else ptr = pp; }
+    }
+    BM_WAVE_LDS_SYNC();                              // every old list entry is read before the first is overwritten
+    if (isq) {
+        L.cols[H + t] = j;
+        if (g0 + lane - l0 >= r) L.cols[base + lane] = val;
+    }
+    BM_WAVE_LDS_SYNC();
+    hi = H + r;
 }
 
 // n_rows x n_cols problem, cost_of(i, j).  out_col_of_row[i] (x) and out_row_of_col[j] (y), -1 = unassigned, as lapx returns
@@ -91,12 +162,21 @@ __device__ inline bool lap_jv_extended(const Ctx& c, const JvLds& L, int n_rows,
         if (i < n_rows) return j < n_cols ? cost_of(i, j) : fill;
         return j < n_cols ? fill : 0.0;
     };
+    BM_JV_PROF(0);
     // ---- column reduction (_ccrrt_dense): column minima, first row wins ----
     for (int i = c.tid; i < n; i += c.nthr) { L.x[i] = -1; L.pred[i] = 0; }
     for (int j = c.tid; j < n; j += c.nthr) {
         double vj = JV_LARGE;
         int yj = 0;
-        for (int i = 0; i < n; ++i) { const double e = e_of(i, j); if (e < vj) { vj = e; yj = i; } }
+        for (int i0 = 0; i0 < n_rows; i0 += 4) {                  // four independent loads in flight
+            double e[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) e[u] = i0 + u < n_rows ? e_of(i0 + u, j) : JV_LARGE;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (i0 + u < n_rows && e[u] < vj) { vj = e[u]; yj = i0 + u; }
+        }
+        const double ed = j < n_cols ? fill : 0.0;               // rows n_rows.. all hold this value: the first of them wins, if any
+        if (ed < vj) { vj = ed; yj = n_rows; }
         L.v[j] = vj; L.y[j] = yj;
     }
     __syncthreads();
@@ -106,6 +186,7 @@ __device__ inline bool lap_jv_extended(const Ctx& c, const JvLds& L, int n_rows,
     for (int j = c.tid; j < n; j += c.nthr) if (L.x[L.y[j]] != j) L.y[j] = -1;
     __syncthreads();
     bool ok = true;
+    BM_JV_PROF(1);
     if (c.wave == 0) {
         const int lane = c.lane;
         // ---- free rows (ascending) and reduction transfer, row by row: a transfer changes v for the rows after it ----
@@ -115,13 +196,20 @@ __device__ inline bool lap_jv_extended(const Ctx& c, const JvLds& L, int n_rows,
             if (xi < 0) { if (lane == 0) L.free_rows[n_free] = i; ++n_free; }
             else if (L.pred[i] == 1) {
                 double mn = JV_LARGE;
-                for (int j = lane; j < n; j += WAVE) if (j != xi) { const double r = e_of(i, j) - L.v[j]; mn = r < mn ? r : mn; }
+                for (int jb = lane; jb < n; jb += 4 * WAVE) {
+                    double e[4], vv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const int j = jb + u * WAVE; const bool in = j < n; e[u] = in ? e_of(i, j) : 0.0; vv[u] = in ? L.v[j] : 0.0; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const int j = jb + u * WAVE; if (j < n && j != xi) { const double r = e[u] - vv[u]; mn = r < mn ? r : mn; } }
+                }
                 mn = jv_wave_min(mn);
                 if (lane == 0) L.v[xi] -= mn;
                 BM_WAVE_LDS_SYNC();
             }
         }
         BM_WAVE_LDS_SYNC();
+        BM_JV_PROF(2);
         // ---- augmenting row reduction (_carr_dense), twice ----
         for (int round = 0; round < 2 && n_free > 0; ++round) {
             int current = 0, new_free = 0;
@@ -132,8 +220,14 @@ __device__ inline bool lap_jv_extended(const Ctx& c, const JvLds& L, int n_rows,
                 if (++guard > guard_max) { ok = false; break; }
                 ++rr_cnt;
                 const int fi = L.free_rows[current++];
-                JvTwo t{JV_LARGE, JV_LARGE, 0x7fffffff, 0x7fffffff};
-                for (int j = lane; j < n; j += WAVE) jv_two_insert(t, e_of(fi, j) - L.v[j], j);
+                JvTwo t{JV_LARGE, JV_LARGE, JV_NO_COL, JV_NO_COL};
+                for (int jb = lane; jb < n; jb += 4 * WAVE) {
+                    double e[4], vv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const int j = jb + u * WAVE; const bool in = j < n; e[u] = in ? e_of(fi, j) : 0.0; vv[u] = in ? L.v[j] : 0.0; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const int j = jb + u * WAVE; if (j < n) jv_two_insert(t, e[u] - vv[u], j); }
+                }
                 t = jv_wave_two(t);
                 int j1 = t.j1, j2 = n > 1 ? t.j2 : -1;
                 const double v1 = t.v1, v2 = n > 1 ? t.v2 : JV_LARGE;
@@ -159,46 +253,63 @@ __device__ inline bool lap_jv_extended(const Ctx& c, const JvLds& L, int n_rows,
             }
             n_free = new_free;
         }
+        BM_JV_PROF(3);
         // ---- augmentation (_ca_dense): shortest augmenting path per remaining free row ----
         for (int f = 0; f < n_free && ok; ++f) {
             const int fi = L.free_rows[f];
-            for (int j = lane; j < n; j += WAVE) { L.cols[j] = j; L.pred[j] = fi; L.d[j] = e_of(fi, j) - L.v[j]; }
+            for (int jb = lane; jb < n; jb += 4 * WAVE) {
+                double e[4], vv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int j = jb + u * WAVE; const bool in = j < n; e[u] = in ? e_of(fi, j) : 0.0; vv[u] = in ? L.v[j] : 0.0; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int j = jb + u * WAVE; if (j < n) { L.cols[j] = j; L.pred[j] = fi; L.d[j] = e[u] - vv[u]; } }
+            }
             BM_WAVE_LDS_SYNC();
             int lo = 0, hi = 0, final_j = -1, n_ready = 0;
             long guard = 0;
             while (final_j == -1) {
                 if (++guard > 4L * n + 64) { ok = false; break; }
                 if (lo == hi) {
-                    // _find_dense: move the columns at the minimum of d over cols[lo..n) to the front, in scan order
+                    // _find_dense: move the columns at the minimum of d over cols[lo..n) to the front, in scan order.  A column
+                    // below the running minimum restarts the ready run at `lo` (the earlier run stays where it was put).
                     n_ready = lo;
                     hi = lo + 1;
                     double mind = L.d[L.cols[lo]];
-                    for (int base = hi; base < n; base += WAVE) {
-                        const int k = base + lane;
-                        const bool in = k < n;
-                        const int j = in ? L.cols[k] : 0;
-                        const double s = in ? L.d[j] : JV_LARGE;
-                        // exclusive prefix minimum over the lanes, seeded with the running minimum
-                        double pm = s;
-                        for (int off = 1; off < WAVE; off <<= 1) { const double o = __shfl(pm, lane >= off ? lane - off : lane, WAVE); if (lane >= off && o < pm) pm = o; }
-                        double ex = __shfl(pm, lane > 0 ? lane - 1 : 0, WAVE);
-                        if (lane == 0 || mind < ex) ex = mind;
-                        unsigned long long ev = __ballot(in && s <= ex);
-                        while (ev) {
-                            const int el = __builtin_ctzll(ev);
-                            ev &= ev - 1;
-                            const double se = __shfl(s, el, WAVE);
-                            const int je = __shfl(j, el, WAVE);
-                            if (se < mind) { hi = lo; mind = se; }
-                            if (lane == 0) { L.cols[base + el] = L.cols[hi]; L.cols[hi] = je; }
-                            ++hi;
-                            BM_WAVE_LDS_SYNC();
+                    for (int base0 = hi; base0 < n; base0 += 4 * WAVE) {
+                        int jj[4];
+                        double ss[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { const int k = base0 + u * WAVE + lane; jj[u] = k < n ? L.cols[k] : 0; }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) ss[u] = base0 + u * WAVE + lane < n ? L.d[jj[u]] : JV_LARGE;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int base = base0 + u * WAVE;
+                            if (base >= n) break;
+                            const bool in = base + lane < n;
+                            const double s = ss[u];
+                            int l0 = 0;
+                            while (true) {
+                                const unsigned long long from = l0 >= WAVE ? 0ull : ~0ull << l0;
+                                if (!(__ballot(in && s <= mind) & from)) break;
+                                const unsigned long long lt = __ballot(in && s < mind) & from;
+                                const int seg_end = lt ? __builtin_ctzll(lt) : WAVE;
+                                const unsigned long long upto = seg_end >= WAVE ? ~0ull : (1ull << seg_end) - 1ull;
+                                jv_move(L, base, l0, __ballot(in && s == mind) & from & upto, hi, jj[u], lane);
+                                if (!lt) break;
+                                mind = __shfl(s, seg_end, WAVE);
+                                hi = lo;
+                                l0 = seg_end;
+                            }
                         }
                     }
                     // the last ready column without a row ends the search
                     int last = -1;
-                    for (int k = lo + lane; k < hi; k += WAVE) if (L.y[L.cols[k]] < 0) last = k;
-                    last = jv_wave_max_int(last);
+                    for (int kb = lo; kb < hi; kb += WAVE) {
+                        const int k = kb + lane;
+                        const unsigned long long fr = __ballot(k < hi && L.y[L.cols[k]] < 0);
+                        if (fr) last = kb + 63 - __builtin_clzll(fr);
+                    }
                     if (last >= 0) final_j = L.cols[last];
                 }
                 if (final_j == -1) {
@@ -210,25 +321,35 @@ __device__ inline bool lap_jv_extended(const Ctx& c, const JvLds& L, int n_rows,
                         const double mind = L.d[j0];
                         const double h = e_of(i, j0) - L.v[j0] - mind;
                         const int hi0 = hi;
-                        for (int base = hi0; base < n && found < 0; base += WAVE) {
-                            const int k = base + lane;
-                            const bool in = k < n;
-                            const int j = in ? L.cols[k] : 0;
-                            bool flag = false;
-                            if (in) {
-                                const double cred = e_of(i, j) - L.v[j] - h;
-                                if (cred < L.d[j]) { L.d[j] = cred; L.pred[j] = i; flag = cred == mind; }
+                        for (int base0 = hi0; base0 < n && found < 0; base0 += 4 * WAVE) {
+                            // four chunks of the TODO list in flight: the swaps of a chunk touch positions at or before it only
+                            int jj[4], yy[4];
+                            double e[4], vv[4], dd[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) { const int k = base0 + u * WAVE + lane; jj[u] = k < n ? L.cols[k] : 0; }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const bool in = base0 + u * WAVE + lane < n;
+                                e[u] = in ? e_of(i, jj[u]) : 0.0; vv[u] = in ? L.v[jj[u]] : 0.0; dd[u] = in ? L.d[jj[u]] : 0.0; yy[u] = in ? L.y[jj[u]] : 0;
                             }
-                            const bool unassigned = in && L.y[j] < 0;
-                            unsigned long long ev = __ballot(flag);
-                            while (ev) {
-                                const int el = __builtin_ctzll(ev);
-                                ev &= ev - 1;
-                                const int je = __shfl(j, el, WAVE);
-                                if (__shfl((int)unassigned, el, WAVE)) { found = je; break; }
-                                if (lane == 0) { L.cols[base + el] = L.cols[hi]; L.cols[hi] = je; }
-                                ++hi;
-                                BM_WAVE_LDS_SYNC();
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int base = base0 + u * WAVE;
+                                if (base >= n || found >= 0) break;
+                                const bool in = base + lane < n;
+                                const int j = jj[u];
+                                bool flag = false;
+                                if (in) {
+                                    const double cred = e[u] - vv[u] - h;
+                                    if (cred < dd[u]) { L.d[j] = cred; L.pred[j] = i; flag = cred == mind; }
+                                }
+                                const unsigned long long fl = __ballot(flag);
+                                if (fl) {
+                                    const unsigned long long un = __ballot(flag && yy[u] < 0);      // the first of these ends the search
+                                    const int seg_end = un ? __builtin_ctzll(un) : WAVE;
+                                    jv_move(L, base, 0, fl & (seg_end >= WAVE ? ~0ull : (1ull << seg_end) - 1ull), hi, j, lane);
+                                    if (un) found = __shfl(j, seg_end, WAVE);
+                                }
                             }
                         }
                         BM_WAVE_LDS_SYNC();
@@ -253,6 +374,7 @@ __device__ inline bool lap_jv_extended(const Ctx& c, const JvLds& L, int n_rows,
             BM_WAVE_LDS_SYNC();
             if (L.free_rows[0] == -2) ok = false;
         }
+        BM_JV_PROF(4);
         if (lane == 0) c.s_int[0] = ok ? 1 : 0;
     }
     __syncthreads();

@@ -276,12 +276,8 @@ def iou_batch(b1, b2):                              # iou.py:134-150
                  + (b2[..., 2] - b2[..., 0]) * (b2[..., 3] - b2[..., 1]) - wh)
 
 
-_LAP = {"jv": oracle_lap.lapjv, "lowest_index": oracle_lap.lap_full_lowest_index}
-_lap_rule = "jv"
-
-
 def _assign(cost):                                  # association.py:20-24
-    _, x, y = _LAP[_lap_rule](cost, extend_cost=True)
+    _, x, y = oracle_lap.lapjv(cost, extend_cost=True)
     return np.array([[y[i], i] for i in x if i >= 0])
 
 
@@ -362,10 +358,7 @@ def associate(dets, trks, iou_threshold, velocities, previous_obs, vdc_weight, e
 class DeepOcSortOracle:
     use_byte, min_conf = False, 0.1        # OC-SORT's BYTE branch; only OcSortOracle switches it on
 
-    def __init__(self, reid=None, lap_rule="jv", **kw):
-        """``lap_rule``: which exact solver stands in for ``lap.lapjv`` -- "jv" (oracle/lapjv.c, the default, used for
-        the golden fixtures) or "lowest_index" (same optimum, the device solver's choice among tied optima)."""
-        self.lap_rule = lap_rule
+    def __init__(self, reid=None, **kw):
         cfg = dict(DEFAULTS)
         unknown = set(kw) - set(cfg)
         if unknown:
@@ -383,8 +376,6 @@ class DeepOcSortOracle:
         """dets (N,6) [x1,y1,x2,y2,conf,cls] -> what ``DeepOcSort.update`` hands back: rows cast to fp32 by
         ``TrackResults`` (track_results.py:22-31), shape (M,8), or (0,0) when nothing is output.  ``warp``: the 2x3
         matrix ``cmc.apply`` returned (cmc_off=False, deepocsort.py:347-351), applied before the prediction."""
-        global _lap_rule
-        _lap_rule = self.lap_rule
         c = self.cfg
         dets = np.asarray(dets)
         if dets.size == 0:

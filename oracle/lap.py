@@ -47,8 +47,6 @@ def _load():
             ctypes.c_void_p, ctypes.c_void_p,
         ]
         lib.oracle_lapjv_extended.restype = ctypes.c_int
-        lib.oracle_lap_full_lowest_index.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
-        lib.oracle_lap_full_lowest_index.restype = ctypes.c_int
         _lib = lib
     return _lib
 
@@ -69,23 +67,6 @@ def lapjv(cost, extend_cost: bool = False, cost_limit: float = np.inf, return_co
             nr, nc, cost.ctypes.data, int(use_limit), float(cost_limit if use_limit else 0.0),
             x.ctypes.data, y.ctypes.data,
         )
-    x = x.astype(np.int64)
-    y = y.astype(np.int64)
-    if return_cost:
-        rows = np.nonzero(x >= 0)[0]
-        return float(cost[rows, x[rows]].sum()), x, y
-    return x, y
-
-
-def lap_full_lowest_index(cost, extend_cost: bool = True, return_cost: bool = True):
-    """Exact full assignment of the smaller side with the device solver's tie rule (lowest index); same optimum as
-    ``lapjv(cost, extend_cost=True)``, possibly a different optimal assignment under exact ties (see lapjv.c)."""
-    cost = np.ascontiguousarray(cost, dtype=np.float64)
-    nr, nc = cost.shape
-    x = np.full(nr, -1, dtype=np.int32)
-    y = np.full(nc, -1, dtype=np.int32)
-    if nr and nc and _load().oracle_lap_full_lowest_index(nr, nc, cost.ctypes.data, x.ctypes.data, y.ctypes.data) != 0:
-        raise RuntimeError("assignment did not converge")
     x = x.astype(np.int64)
     y = y.astype(np.int64)
     if return_cost:

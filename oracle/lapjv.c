@@ -239,73 +239,3 @@ int oracle_lapjv_extended(int n_rows, int n_cols, const double *cost, int use_li
     free(e); free(xe); free(ye);
     return 0;
 }
-
-/*
- * A second exact solver for the "no cost limit" call site (association.py:20-24): every element of the
- * smaller side is assigned, total cost minimal.  Detections (rows) are inserted one by one with a shortest
- * augmenting path over the tracks (columns); when there are more rows than columns, zero-cost dummy columns
- * complete the square; exact ties go to the lower column index.  Whenever the optimum is unique this returns
- * what oracle_lapjv_extended returns; when it is not, the two make different -- equally optimal -- choices
- * (and the real lapx, which is unavailable here, may make a third).  The parity tests use this rule on
- * tie-prone scenarios because it is the rule of the device solver (deepocsort_step.hpp lap_full), so that
- * everything except the arbitrary choice among optimal assignments is compared exactly.
- */
-int oracle_lap_full_lowest_index(int n_rows, int n_cols, const double *cost, int *x, int *y)
-{
-    const int C = n_rows, R = n_cols, Rp = R > C ? R : C;
-    const double INF = 1e300;
-    for (int i = 0; i < n_rows; i++) x[i] = -1;
-    for (int j = 0; j < n_cols; j++) y[j] = -1;
-    if (C == 0 || R == 0) return 0;
-    double *v = (double *)calloc((size_t)Rp, sizeof(double));
-    double *minv = (double *)malloc(sizeof(double) * (size_t)Rp);
-    double *u = (double *)calloc((size_t)C, sizeof(double));
-    int *tx = (int *)malloc(sizeof(int) * (size_t)Rp);      /* row of column t */
-    int *way = (int *)malloc(sizeof(int) * (size_t)Rp);
-    int *used = (int *)malloc(sizeof(int) * (size_t)Rp);
-    int *ry = (int *)malloc(sizeof(int) * (size_t)C);       /* column of row d */
-    for (int t = 0; t < Rp; t++) tx[t] = -1;
-    for (int d = 0; d < C; d++) ry[d] = -1;
-    int ok = 1;
-    for (int s = 0; s < C && ok; s++) {
-        for (int t = 0; t < Rp; t++) { minv[t] = INF; used[t] = 0; way[t] = -1; }
-        int cur = s, via = -1, end_track = -1, iter = 0;
-        for (; iter < Rp + 2; iter++) {
-            const double ucur = u[cur];
-            double best = INF;
-            int best_t = -1;
-            for (int t = 0; t < Rp; t++) {
-                if (used[t]) continue;
-                const double cst = t < R ? cost[(size_t)cur * n_cols + t] : 0.0;
-                const double cand = cst - ucur - v[t];
-                if (cand < minv[t]) { minv[t] = cand; way[t] = via; }
-                if (minv[t] < best) { best = minv[t]; best_t = t; }
-            }
-            if (best_t < 0) { ok = 0; break; }
-            for (int t = 0; t < Rp; t++) {
-                if (used[t]) { u[tx[t]] += best; v[t] -= best; }
-                else if (minv[t] < INF) minv[t] -= best;
-            }
-            u[s] += best;
-            used[best_t] = 1;
-            if (tx[best_t] < 0) { end_track = best_t; break; }
-            via = best_t;
-            cur = tx[best_t];
-        }
-        if (!ok || iter >= Rp + 2) { ok = 0; break; }
-        int t = end_track;
-        while (t >= 0) {
-            const int prev = way[t];
-            const int det = prev >= 0 ? tx[prev] : s;
-            tx[t] = det;
-            ry[det] = t;
-            t = prev;
-        }
-    }
-    if (ok) {
-        for (int d = 0; d < C; d++) x[d] = ry[d] >= R ? -1 : ry[d];
-        for (int t = 0; t < R; t++) y[t] = tx[t];
-    }
-    free(v); free(minv); free(u); free(tx); free(way); free(used); free(ry);
-    return ok ? 0 : 1;
-}

@@ -272,7 +272,7 @@ def _nn_cosine_distance(x, y):                      # :266-284
 #   <a, b> : one fmaf per k, k ascending, from 0 (v_mfma_f32_16x16x4_f32 is bit-for-bit that chain)
 #   dist   : 1 - <a, b> / (|a| * |b|) in fp32, min over the bank
 # Under this rule the oracle's cost matrix is bit-identical to the device's, which makes the id comparison exact on every
-# sequence (like lap_rule="lowest_index" for the DeepOCSORT assignment ties).  fmaf is emulated in 80-bit long double
+# sequence.  fmaf is emulated in 80-bit long double
 # (a 24 x 24-bit product is exact there; the sum is rounded once more, which matters with probability ~2^-40 per operation).
 def _fma32(a, b, c):
     return (a.astype(np.longdouble) * b.astype(np.longdouble) + c.astype(np.longdouble)).astype(np.float32)

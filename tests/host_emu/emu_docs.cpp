@@ -164,4 +164,35 @@ int emu_lap_jv(int nr, int nc, const double* cost, int use_limit, double limit, 
     return ok;
 }
 
+// jv_move alone (wave 0): the TODO-list permutation of one chunk segment against the sequential swap loop it replaces
+struct MvArg { int n; int* cols; int base, l0; unsigned long long q; int hi; int tid; int* out_hi; };
+static void* mv_main(void* p) {
+    MvArg* a = static_cast<MvArg*>(p);
+    threadIdx.x = a->tid;
+    blockIdx.x = 0;
+    if (a->tid >= bm::WAVE) return nullptr;
+    bm::JvLds L{};
+    L.cols = a->cols;
+    const int lane = a->tid;
+    int hi = a->hi;
+    const int j = a->base + lane < a->n ? a->cols[a->base + lane] : 0;
+    g_emu_block->wave_barrier[0].wait();
+    bm::jv_move(L, a->base, a->l0, a->q, hi, j, lane);
+    if (lane == 0) *a->out_hi = hi;
+    return nullptr;
+}
+int emu_jv_move(int n, int* cols, int base, int l0, unsigned long long q, int hi) {
+    static EmuBlock block;
+    g_emu_block = &block;
+    blockDim.x = NTHR;
+    block.block_barrier.init(NTHR);
+    for (int w = 0; w < EMU_MAX_WAVES; ++w) block.wave_barrier[w].init(EMU_WAVE);
+    int out = -1;
+    std::vector<pthread_t> th(NTHR);
+    std::vector<MvArg> ta(NTHR);
+    for (int t = 0; t < NTHR; ++t) { ta[t] = MvArg{n, cols, base, l0, q, hi, t, &out}; pthread_create(&th[t], nullptr, mv_main, &ta[t]); }
+    for (int t = 0; t < NTHR; ++t) pthread_join(th[t], nullptr);
+    return out;
+}
+
 }  // extern "C"

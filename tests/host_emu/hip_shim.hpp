@@ -20,6 +20,7 @@
 #define __device__
 #define __host__
 #define __forceinline__ inline
+#define __noinline__ __attribute__((noinline))
 #define __launch_bounds__(...)
 
 struct EmuDim3 { unsigned x = 0, y = 0, z = 0; };
@@ -117,6 +118,7 @@ inline unsigned emu_dpp_u32(unsigned old, unsigned v, int ctrl, bool zero_fill) 
     return (src16 >= 0 && src16 < 16) ? r : (zero_fill ? 0u : old);
 }
 #define BM_DPP_U32(old, v, ctrl, zero_fill) emu_dpp_u32(old, v, ctrl, zero_fill)
+#define BM_READLANE_U32(v, l) ((unsigned)__shfl((int)(v), l, 64))
 #define BM_QUAD_SWAP1_F32(v) __shfl_xor((float)(v), 1, 64)
 #define BM_UNIFORM_I32(x) ((int)(x))
 #define BM_MUL24(a, b) ((unsigned)(((unsigned)(a) & 0xffffffu) * ((unsigned)(b) & 0xffffffu)))

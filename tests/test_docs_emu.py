@@ -9,10 +9,10 @@ from emu_util import EmuDeepOcSort
 from oracle.deepocsort import DEFAULTS, DeepOcSortOracle
 
 
-def _run(frames, dim, cap, nd, sanitize=False, lap_rule="jv", warps=None, threads=64, **kw):
+def _run(frames, dim, cap, nd, sanitize=False, warps=None, threads=64, **kw):
     cfg = dict(DEFAULTS)
     cfg.update(kw)
-    orc, emu = DeepOcSortOracle(lap_rule=lap_rule, **kw), EmuDeepOcSort(cfg, cap=cap, nd=nd, dim=dim, sanitize=sanitize, threads=threads)
+    orc, emu = DeepOcSortOracle(**kw), EmuDeepOcSort(cfg, cap=cap, nd=nd, dim=dim, sanitize=sanitize, threads=threads)
     try:
         for t, (d, e) in enumerate(frames):
             w = None if warps is None else warps[t]

@@ -65,3 +65,52 @@ def test_device_jv_larger_problem_with_ties():
         assert lib.emu_lap_jv(nr, nc, c.ctypes.data, 0, 0.0, x.ctypes.data, y.ctypes.data) == 1
         _, wx, wy = olap.lapjv(c, extend_cost=True)
         assert np.array_equal(x, wx) and np.array_equal(y, wy)
+
+
+def test_device_jv_thin_recovery_round_shapes():
+    """The second association round of DeepOCSORT: a handful of leftover detections against hundreds of leftover tracks, nearly
+    all pairs at cost 0 -- hundreds of augmentations whose TODO lists are one long tie (the run fast path of the device's scan)."""
+    lib = _lib(64)
+    rng = np.random.default_rng(11)
+    for nr, nc in ((1, 300), (3, 290), (280, 2)):
+        c = -np.where(rng.random((nr, nc)) < 0.02, np.round(rng.random((nr, nc)), 2), 0.0)
+        x = np.full(nr, -9, np.int32)
+        y = np.full(nc, -9, np.int32)
+        assert lib.emu_lap_jv(nr, nc, c.ctypes.data, 0, 0.0, x.ctypes.data, y.ctypes.data) == 1
+        _, wx, wy = olap.lapjv(c, extend_cost=True)
+        assert np.array_equal(x, wx) and np.array_equal(y, wy), (nr, nc, x, wx)
+
+
+def test_list_permutation_of_a_chunk_matches_the_sequential_swaps():
+    """jv_move (one step per 64-column chunk segment) against the loop it replaces: `cols[k], cols[hi] = cols[hi], cols[k]; hi += 1`
+    for every joining position k in ascending order -- random join masks, queue lengths (positions between hi and the chunk),
+    segment starts, ragged list ends."""
+    lib = ctypes.CDLL(str(build_docs(threads=64)))
+    lib.emu_jv_move.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_int]
+    lib.emu_jv_move.restype = ctypes.c_int
+    rng = np.random.default_rng(5)
+    for case in range(300):
+        g0 = int(rng.choice([0, 0, 1, 2, 5, 40, 100]))
+        l0 = int(rng.choice([0, 0, 0, 3, 17, 63]))
+        hi = int(rng.integers(0, 4))
+        base = hi + g0 - l0
+        if base < 0:
+            continue
+        valid = int(rng.integers(l0 + 1, 65))                       # lanes of the chunk that hold list entries
+        seg_end = int(rng.integers(l0, valid + 1))
+        n = base + valid
+        dens = float(rng.choice([0.05, 0.5, 0.95, 1.0]))
+        q = 0
+        for l in range(l0, seg_end):
+            if rng.random() < dens:
+                q |= 1 << l
+        cols = rng.permutation(n).astype(np.int32)
+        want = cols.copy()
+        whi = hi
+        for l in range(l0, seg_end):
+            if (q >> l) & 1:
+                k = base + l
+                want[k], want[whi] = want[whi], want[k]
+                whi += 1
+        got_hi = lib.emu_jv_move(n, cols.ctypes.data, base, l0, ctypes.c_uint64(q), hi)
+        assert got_hi == whi and np.array_equal(cols, want), (case, g0, l0, hi, base, valid, seg_end, bin(q))
