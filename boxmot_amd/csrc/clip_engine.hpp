@@ -112,10 +112,17 @@ private:
     static void set_gemm_lds() {
         check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_glds<EPI, 64>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   gemm_glds_lds_bytes<64>()), "GEMM LDS");
+        check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_256<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  GEMM256_LDS_BYTES), "GEMM LDS");
     }
     template <int EPI>
     void gemm(const _Float16* X, const _Float16* W, const float* bias, void* C, long M, int N, int K, hipStream_t st) {
         if (N % GEMM_BN != 0 || K % GEMM_BK != 0) throw std::runtime_error("CLIP-ReID: GEMM shape not tileable");
+        if (N % 256 == 0 && K % 64 == 0 && M >= 1024) {     // 256 x 256 tiles, phased k-loop: 739-1054 TFLOP/s on the four layer shapes against
+            hipLaunchKernelGGL((k_gemm_f16_256<EPI>), dim3((unsigned)(((M + 255) / 256) * (N / 256))), dim3(512), GEMM256_LDS_BYTES, st, X, W, bias, C,       // 623-833 (profiles/r3_gemm_prof.txt)
+                               static_cast<const _Float16*>(nullptr), (int)M, N, K, 0);
+            return;
+        }
         const dim3 grid((unsigned)(((M + GEMM_BM - 1) / GEMM_BM) * (N / GEMM_BN)));       // 1-D: the kernels map ids to tiles XCD-aware
         if (K % 64 == 0)     // 64-wide k-tiles: 11.7 ms per 256-crop forward vs 13.3 ms with 32-wide ones (profiles/r2_gemm_pipeline_ab.txt)
             hipLaunchKernelGGL((k_gemm_f16_glds<EPI, 64>), grid, dim3(256), gemm_glds_lds_bytes<64>(), st, X, W, bias, C,

@@ -358,4 +358,258 @@ __global__ void __launch_bounds__(256) k_gemm_f16_glds(const _Float16* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// k_gemm_f16_256: the same product on 256 (features) x 256 (rows) x 64 tiles for the large GEMMs (CLIP-ReID's linear layers:
+// N a multiple of 256, tens of thousands of rows), one 8-wave workgroup per CU.
+//
+//   * wave (wr, wc) = (wave >> 2, wave & 3) owns 128 features x 64 rows: 8 x 4 accumulator tiles (128 registers), computed as four
+//     quadrants of 4 x 2 tiles x 2 k-steps = 16 MFMAs -- one quadrant per PHASE, four phases per k-tile:
+//         P1  read A-lo (8 fragments) + B-0 (4)   multiply (A-lo, B-0)
+//         P2  read A-hi (8)                       multiply (A-hi, B-0)
+//         P3  read B-1 (4)                        multiply (A-hi, B-1)
+//         P4  --                                  multiply (A-lo, B-1)
+//     128 + 96 registers: a wave reads (128 + 64) x 64 halves per 1 MFLOP instead of (64 + 64) x 64 per 0.5 (k_gemm_f16_glds).
+//   * the two wave groups (wr = 0 / 1; one wave of each per SIMD) run HALF A PHASE APART: a phase is  [reads, copies, waits]
+//     barrier [16 MFMAs] barrier, group 1 passes one extra barrier at the start, so one group's fragment reads and address work
+//     run under the other group's MFMAs on the same SIMD.
+//   * operands HBM -> LDS by global_load_lds in HALF tiles (128 rows x 64 halves = 16 KB = two copies per thread), the LDS image of
+//     k_gemm_f16_glds (chunk c of row r at slot c ^ (r & 7), swizzle on the source address), two buffers of four half tiles
+//     (128 KB).  The copies of k-tile T are issued 3-5 phases ahead -- A-0 in P3 and A-1 + B-0 in P4 of tile T - 2, B-1 in P1 of
+//     tile T - 1 -- each into a slot whose last fragment read finished (lgkmcnt(0) before the reading phase's first barrier) a
+//     phase earlier, and they are waited for ONCE per k-tile with a counted `s_waitcnt vmcnt(6)` in P4 of tile T - 1 (the six
+//     younger copies stay in flight), one phase before the first read.  Barriers are bare s_barrier: no vmcnt(0) drain anywhere
+//     in the loop.
+// N % 256 == 0, K % 64 == 0, any M (rows beyond M are clamped on load, skipped on store).  EPI 0 / 1 / 2 / 3 / 4 as above.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int GEMM256_EPI_LD = 136;                        // halves per row of a wave's epilogue region (128 + 8 of padding)
+constexpr int GEMM256_LDS_BYTES = 8 * 64 * GEMM256_EPI_LD * 2;       // 136 KB: the epilogue regions; the k-loop uses 2 x 4 half tiles = 128 KB of it
+
+#ifndef BM_GEMM_PHASE_SYNC
+#define BM_GEMM_PHASE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define BM_GEMM_BARRIER() asm volatile("s_barrier" ::: "memory")
+#define BM_GEMM_WAIT_COPIES_6() asm volatile("s_waitcnt vmcnt(6)" ::: "memory")
+#define BM_GEMM_WAIT_COPIES_0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+
+template <int EPI>
+__global__ void __launch_bounds__(512) k_gemm_f16_256(const _Float16* __restrict__ X, const _Float16* __restrict__ Wt,
+                                                      const float* __restrict__ bias, void* __restrict__ Cout,
+                                                      const _Float16* __restrict__ res, int M, int N, int K, int relu) {
+    BM_DYNAMIC_LDS_T(unsigned char, lds_raw);
+    _Float16* lds = reinterpret_cast<_Float16*>(lds_raw);
+    constexpr int HALF = 128 * 64;                          // halves per half tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = BM_UNIFORM_I32(tid >> 6), g = lane >> 4, l16 = lane & 15;
+    const int wr = wave >> 2, wc = wave & 3;
+    int mt, nt;
+    gemm_tile_of_block((M + 255) / 256, N / 256, mt, nt);
+    const long m0 = (long)mt * 256;
+    const int n0 = nt * 256;
+    // copy j of this wave moves LDS chunks p = (2 wave + j) * 64 + lane of a half tile: row p / 8, slot p % 8
+    const _Float16 *gA[2], *gB[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = (2 * wave + j) * 64 + lane, r = p >> 3, c = (p & 7) ^ (r & 7);
+        gA[j] = Wt + (long)(n0 + r) * K + 8 * c;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            long m = m0 + h * 128 + r;
+            if (m >= M) m = M - 1;
+            gB[h][j] = X + m * K + 8 * c;
+        }
+    }
+    const long a_half = 128L * K;
+    // slot s of buffer b: A-0, A-1, B-0, B-1
+    auto slot = [&](int b, int s) { return lds + (b * 4 + s) * HALF; };
+    auto copy_a = [&](int T, int h) {
+        _Float16* d = slot(T & 1, h);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) BM_GLDS16(gA[j] + h * a_half + (long)T * 64, d + (2 * wave + j) * 512, lane);
+    };
+    auto copy_b = [&](int T, int h) {
+        _Float16* d = slot(T & 1, 2 + h);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) BM_GLDS16(gB[h][j] + (long)T * 64, d + (2 * wave + j) * 512, lane);
+    };
+    cf4 acc[8][4];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = cf4{0.f, 0.f, 0.f, 0.f};
+    const int nk = K / 64;
+    // prologue: tile 0 whole, of tile 1 what the steady state has issued by the end of a P4
+    copy_a(0, 0); copy_a(0, 1); copy_b(0, 0); copy_b(0, 1);
+    if (nk > 1) { copy_a(1, 0); copy_a(1, 1); copy_b(1, 0); BM_GEMM_WAIT_COPIES_6(); }
+    else BM_GEMM_WAIT_COPIES_0();
+    BM_GEMM_BARRIER();
+    if (wr == 1) BM_GEMM_BARRIER();                         // group 1 runs half a phase behind group 0
+    ch8 alo[2][4], ahi[2][4], b0[2][2], b1[2][2];
+    const int brow = (wc & 1) * 64;
+    auto read_a = [&](const _Float16* sA, int p0, ch8 (&f)[2][4]) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int ra = (p0 + t) * 16 + l16;
+                f[s][t] = *reinterpret_cast<const ch8*>(sA + ra * 64 + 8 * ((4 * s + g) ^ (ra & 7)));
+            }
+    };
+    auto read_b = [&](const _Float16* sB, int t0, ch8 (&f)[2][2]) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int rb = brow + (t0 + t) * 16 + l16;
+                f[s][t] = *reinterpret_cast<const ch8*>(sB + rb * 64 + 8 * ((4 * s + g) ^ (rb & 7)));
+            }
+    };
+    auto quadrant = [&](const ch8 (&fa)[2][4], int p0, const ch8 (&fb)[2][2], int t0) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[p0 + p][t0 + t] = BM_MFMA_F16_K32(fa[s][p], fb[s][t], acc[p0 + p][t0 + t]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    for (int T = 0; T < nk; ++T) {
+        const _Float16* sA = slot(T & 1, wr);
+        const _Float16* sB = slot(T & 1, 2 + (wc >> 1));
+        // P1
+        read_a(sA, 0, alo);
+        read_b(sB, 0, b0);
+        if (T + 1 < nk) copy_b(T + 1, 1);
+        BM_GEMM_PHASE_SYNC();
+        quadrant(alo, 0, b0, 0);
+        BM_GEMM_BARRIER();
+        // P2
+        read_a(sA, 4, ahi);
+        BM_GEMM_PHASE_SYNC();
+        quadrant(ahi, 4, b0, 0);
+        BM_GEMM_BARRIER();
+        // P3
+        read_b(sB, 2, b1);
+        if (T + 2 < nk) copy_a(T + 2, 0);
+        BM_GEMM_PHASE_SYNC();
+        quadrant(ahi, 4, b1, 2);
+        BM_GEMM_BARRIER();
+        // P4: tile T + 1 must have landed before the next phase reads it
+        if (T + 2 < nk) { copy_a(T + 2, 1); copy_b(T + 2, 0); BM_GEMM_WAIT_COPIES_6(); }
+        else BM_GEMM_WAIT_COPIES_0();
+        BM_GEMM_PHASE_SYNC();
+        quadrant(alo, 0, b1, 2);
+        BM_GEMM_BARRIER();
+    }
+    if (wr == 0) BM_GEMM_BARRIER();                         // pairs with group 1's extra barrier
+    if constexpr (EPI == 0 || EPI == 1 || EPI == 4) {
+        // fp16 results leave through LDS (the operand slots are dead after the last barrier): a lane holds 4 features of 16 different
+        // rows, i.e. 8-byte pieces of 16 lines per store; transposed through a private 64 x 128 region (row stride 272 bytes: 2-way
+        // bank conflicts on the 8-byte writes, none on the 16-byte reads) every store instruction writes 4 rows x 256 contiguous bytes.
+        _Float16* reg = lds + wave * (64 * GEMM256_EPI_LD);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int n = n0 + wr * 128 + p * 16 + 4 * g;
+            cf4 bv = cf4{0.f, 0.f, 0.f, 0.f};
+            if (bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bv[r] = bias[n + r];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                cf4 v = acc[p][t];
+#ifdef BM_GEMM256_NO_STORE
+                if (v[0] != 12345.678f) continue;            // profiling build: the main loop alone
+#endif
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += bv[r];
+                if constexpr (EPI == 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + BM_EXPF(-1.702f * v[r]));
+                }
+                if constexpr (EPI == 4) {
+                    if (res) {              // (no prefetch here: the accumulators and fragments fill the register file)
+                        long m = m0 + wc * 64 + t * 16 + l16;
+                        if (m >= M) m = M - 1;
+                        const ch4 rv = *reinterpret_cast<const ch4*>(res + m * N + n);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+                    }
+                    if (relu) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+                    }
+                }
+                ch4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (_Float16)v[r];
+                *reinterpret_cast<ch4*>(reg + (t * 16 + l16) * GEMM256_EPI_LD + p * 16 + 4 * g) = o;
+            }
+        }
+        BM_WAVE_LDS_SYNC();
+#ifndef BM_GEMM256_NO_STORE
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = i * 4 + g;
+            const long m = m0 + wc * 64 + row;
+            const ch8 v = *reinterpret_cast<const ch8*>(reg + row * GEMM256_EPI_LD + l16 * 8);
+            if (m < M) *reinterpret_cast<ch8*>(static_cast<_Float16*>(Cout) + m * N + n0 + wr * 128 + l16 * 8) = v;
+        }
+#endif
+        return;
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int n = n0 + wr * 128 + p * 16 + 4 * g;
+        cf4 bv = cf4{0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[r] = bias[n + r];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const long m = m0 + wc * 64 + t * 16 + l16;
+            if (m >= M) continue;
+#ifdef BM_GEMM256_NO_STORE
+            if (acc[p][t][0] != 12345.678f) continue;        // profiling build: the main loop alone
+#endif
+            cf4 v = acc[p][t];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += bv[r];
+            if constexpr (EPI == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + BM_EXPF(-1.702f * v[r]));
+            }
+            if constexpr (EPI == 4) {
+                if (res) {                  // (no prefetch here: the accumulators and fragments fill the register file)
+                    const ch4 rv = *reinterpret_cast<const ch4*>(res + m * N + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+                }
+                if (relu) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+                }
+            }
+            if constexpr (EPI == 0 || EPI == 1 || EPI == 4) {
+                ch4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (_Float16)v[r];
+                *reinterpret_cast<ch4*>(static_cast<_Float16*>(Cout) + m * N + n) = o;
+            } else if constexpr (EPI == 2) {
+                float* c = static_cast<float*>(Cout) + m * N + n;
+                cf4 old = *reinterpret_cast<const cf4*>(c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) old[r] += v[r];
+                *reinterpret_cast<cf4*>(c) = old;
+            } else {
+                if (relu) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+                }
+                *reinterpret_cast<cf4*>(static_cast<float*>(Cout) + m * N + n) = v;
+            }
+        }
+    }
+}
+
 }  // namespace bm

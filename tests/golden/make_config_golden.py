@@ -152,6 +152,7 @@ class _RefClipReid:
         import importlib.util
 
         import torch
+        ref_harness.install_standins()               # clip/model.py imports boxmot.utils.logger
         spec = importlib.util.spec_from_file_location("_ref_clip_model", ref_harness.REFERENCE_ROOT / "boxmot/reid/backbones/clip/clip/model.py")
         m = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(m)
