@@ -109,6 +109,8 @@ SIGNATURES = {
     "boxmot_hip_botsort_create": (_VP, [ctypes.POINTER(BotSortConfig)]),
     "boxmot_hip_botsort_destroy": (None, [_VP]),
     "boxmot_hip_botsort_reset": (_I, [_VP]),
+    "boxmot_hip_botsort_reserve": (_I, [_VP, _I, _I]),
+    "boxmot_hip_botsort_capacity": (_I, [_VP, c_int_p, c_int_p, c_int_p]),
     "boxmot_hip_botsort_update": (_I, [_VP, _VP, _I, _I, _VP, _I, _I, _VP, _I, _I, _I, _VP, _I, _I, c_int_p, c_int_p]),
     "boxmot_hip_botsort_update_stream": (_I, [_VP, _I, _I, _I, _VP, _I, _I, _VP, _I, _I, _VP, _I, _I, _I, _VP, _I, _I,
                                               c_int_p, c_int_p]),
@@ -134,6 +136,8 @@ SIGNATURES = {
     "boxmot_hip_deepocsort_create": (_VP, [ctypes.POINTER(DeepOcSortConfig)]),
     "boxmot_hip_deepocsort_destroy": (None, [_VP]),
     "boxmot_hip_deepocsort_reset": (_I, [_VP]),
+    "boxmot_hip_deepocsort_reserve": (_I, [_VP, _I, _I]),
+    "boxmot_hip_deepocsort_capacity": (_I, [_VP, c_int_p, c_int_p, c_int_p]),
     "boxmot_hip_deepocsort_set_warp": (_I, [_VP, _I, _VP]),
     "boxmot_hip_deepocsort_update": (_I, [_VP, _VP, _I, _I, _VP, _I, _I, _VP, _I, _I, _I, _VP, _I, _I, c_int_p, c_int_p]),
     "boxmot_hip_deepocsort_update_stream": (_I, [_VP, _I, _I, c_int_p, _VP, _I, _I, _VP, _I, _I, _VP, _I, _I, _I, _VP, _I, _I,
@@ -149,6 +153,8 @@ SIGNATURES = {
     "boxmot_hip_strongsort_create": (_VP, [ctypes.POINTER(StrongSortConfig)]),
     "boxmot_hip_strongsort_destroy": (None, [_VP]),
     "boxmot_hip_strongsort_reset": (_I, [_VP]),
+    "boxmot_hip_strongsort_reserve": (_I, [_VP, _I, _I]),
+    "boxmot_hip_strongsort_capacity": (_I, [_VP, c_int_p, c_int_p, c_int_p]),
     "boxmot_hip_strongsort_set_warp": (_I, [_VP, _I, _VP]),
     "boxmot_hip_strongsort_update": (_I, [_VP, _VP, _I, _I, _VP, _I, _I, _VP, _I, _I, _I, _VP, _I, _I, c_int_p, c_int_p]),
     "boxmot_hip_strongsort_update_batch": (_I, [_VP, _I, _VP, _VP, _VP, _I, _VP, _I, _I, _I, _VP, _I, _VP]),

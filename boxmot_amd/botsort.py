@@ -169,10 +169,20 @@ class BotSort(BaseTracker):
         self._first_frame_processed = False
         self._first_dets_processed = False
 
+    def capacity(self) -> tuple[int, int, int]:
+        """(max_tracks, max_dets, times the device tables grew).  The tables start at the constructor's sizes and grow when a frame
+        would not fit, like the reference's lists (include/boxmot_hip.h, boxmot_hip_botsort_reserve)."""
+        a, b, c = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(self._lib.boxmot_hip_botsort_capacity(self._handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return a.value, b.value, c.value
+
+    def reserve(self, max_tracks: int = 0, max_dets: int = 0) -> None:
+        _lib.check(self._lib.boxmot_hip_botsort_reserve(self._handle, int(max_tracks), int(max_dets)))
+
     # ------------------------------------------------- introspection (read-only)
     def state_dump(self, which: int = 0, class_list: int = 0) -> dict:
         """Copy the live tracks back from the device (parity tests / debugging)."""
-        cap, dim = self._max_tracks, self._emb_dim
+        cap, dim = self.capacity()[0], self._emb_dim
         ints = np.zeros((cap, 6), dtype=np.int32)
         kf = np.zeros((cap, 72), dtype=np.float64)
         smooth = np.zeros((cap, dim), dtype=np.float32)

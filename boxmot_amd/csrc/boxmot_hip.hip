@@ -223,6 +223,11 @@ struct BoxMOTHipBotSort {
     int* d_crop_row = nullptr;
     long long* d_phase_clock = nullptr;
     double last_track_ms = 0, last_reid_pre_ms = 0, last_reid_proc_ms = 0;
+    // growth of the tables (grow_tables): what botsort_allocate handed out, in order; slots in use per stream after the last
+    // host update (-1 = unknown: a device-resident step ran since)
+    std::vector<std::pair<void*, size_t>> table_rec;
+    std::vector<int> h_used, h_count_buf;
+    int n_grows = 0;
 
     ~BoxMOTHipBotSort() {
         reid.reset();
@@ -251,7 +256,13 @@ struct StreamIo {
     int frame_rows = 0, frame_cols = 0;
     const uint8_t** d_frames = nullptr;
     std::unique_ptr<bm::ReidEngine> reid;
+    int reid_mode = -1;             // set_reid_mode's last value (-1: the engine's default), re-applied when the engine is re-made
     int* d_crop_count = nullptr; int* d_crop_stream = nullptr; float* d_crop_boxes = nullptr; int* d_crop_row = nullptr;
+    // growth of the tables: what the tracker's allocate function handed out, in order; tracks per stream after the last host
+    // update (-1 = unknown: a device-resident step ran since)
+    std::vector<std::pair<void*, size_t>> table_rec;
+    std::vector<int> h_used;
+    int n_grows = 0;
     ~StreamIo() {
         reid.reset();
         for (void* p : owned) (void)hipFree(p);
@@ -292,6 +303,88 @@ struct DevAlloc {
     std::vector<void*>* owned;
     template <typename T> T* get(size_t n) { return zalloc<T>(n, *owned); }
 };
+
+struct RecAlloc {         // DevAlloc that also notes every table (pointer, bytes) in allocation order
+    std::vector<void*>* owned;
+    std::vector<std::pair<void*, size_t>>* rec;
+    template <typename T> T* get(size_t n) { T* p = zalloc<T>(n, *owned); rec->push_back({p, n * sizeof(T)}); return p; }
+};
+
+void release(std::vector<void*>& owned, void* p) {
+    if (!p) return;
+    for (size_t i = 0; i < owned.size(); ++i)
+        if (owned[i] == p) { owned.erase(owned.begin() + (long)i); (void)hipFree(p); return; }
+}
+
+// per-frame buffers whose size follows max_dets (contents do not outlive an update)
+void alloc_det_io(BoxMOTHipBotSort* h) {
+    const size_t S = h->S, nd = h->nd, dim = h->dim;
+    auto& o = h->owned;
+    release(o, h->d_dets); release(o, h->d_embs); release(o, h->d_out);
+    release(o, h->d_crop_stream); release(o, h->d_crop_boxes); release(o, h->d_crop_row);
+    h->d_dets = zalloc<float>(S * nd * bm::DET_COLS, o);
+    h->d_embs = zalloc<float>(S * nd * dim, o);
+    h->d_out = zalloc<float>(S * nd * bm::OUT_COLS, o);
+    h->d_crop_stream = zalloc<int>(S * nd, o);
+    h->d_crop_boxes = zalloc<float>(S * nd * 4, o);
+    h->d_crop_row = zalloc<int>(S * nd, o);
+    h->h_dets.assign(S * nd * bm::DET_COLS, 0.f);
+    h->h_out.assign(S * nd * bm::OUT_COLS, 0.f);
+}
+
+void make_reid_engine(BoxMOTHipBotSort* h) {
+    const std::vector<float> blob = bm::read_blob_file(h->reid_path.c_str());
+    const long crops = (long)h->S * h->nd;
+    h->reid.reset(new bm::ReidEngine(blob.data(), (long)blob.size(), bm::reid_chunk_for(crops), (int)crops));
+    if (h->reid->feature_dim() != h->dim) throw std::runtime_error("boxmot_hip: ReID feature dim != emb_dim");
+    h->reid->set_preprocess(h->reid_pad);
+    if (h->reid_mode) h->reid->set_mode(h->reid_mode);
+}
+
+void set_step_lds(BoxMOTHipBotSort* h) {
+    const long lds = bm::lap_lds_bytes(h->cap, h->nd);
+    BM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(botsort_step_kernel<STEP_THREADS>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+}
+
+// The reference's lists have no capacity (botsort.py:177-250); the device tables do.  They are created at max_tracks / max_dets and
+// GROW when a host update would not fit: a new set of tables at the larger sizes, every state table copied stream by stream
+// (slot ids stay valid: a stream's slab only gets longer), scratch and per-frame buffers simply re-made, the ReID engine re-created
+// for the larger crop count.  The limit is the LDS state of the assignment solver (lap_lds_bytes <= 120 KB), reported loudly.
+void grow_tables(BoxMOTHipBotSort* h, int new_cap, int new_nd) {
+    if (bm::lap_lds_bytes(new_cap, new_nd) > 120 * 1024)
+        throw std::runtime_error("boxmot_hip: " + std::to_string(new_cap) + " tracks x " + std::to_string(new_nd) +
+                                 " detections per stream is beyond what the assignment solver's LDS state can hold");
+    BM_HIP(hipStreamSynchronize(h->stream));
+    bm::BotSortStepArgs na = h->args;
+    std::vector<std::pair<void*, size_t>> rec;
+    RecAlloc ra{&h->owned, &rec};
+    bm::BotSortSizes z{h->S, new_cap, new_nd, h->dim, h->n_lists, h->args.st.removed_alloc};
+    bm::botsort_allocate(na, z, ra);
+    if (rec.size() != h->table_rec.size()) throw std::runtime_error("boxmot_hip: table layout changed between allocations");
+    for (size_t i = 0; i < rec.size() && rec[i].first != (void*)na.sc.det_xywh; ++i) {          // the state tables come first
+        const auto& od = h->table_rec[i];
+        const size_t rows = (size_t)h->S * (rec[i].first == (void*)na.st.active_list ? h->n_lists : 1);
+        if (od.second == rec[i].second) BM_HIP(hipMemcpy(rec[i].first, od.first, od.second, hipMemcpyDeviceToDevice));
+        else BM_HIP(hipMemcpy2D(rec[i].first, rec[i].second / rows, od.first, od.second / rows, od.second / rows, rows, hipMemcpyDeviceToDevice));
+    }
+    for (const auto& od : h->table_rec) release(h->owned, od.first);
+    h->table_rec = rec;
+    h->args = na;
+    const bool more_dets = new_nd != h->nd;
+    h->cap = new_cap; h->nd = new_nd;
+    if (more_dets) {
+        alloc_det_io(h);
+        if (h->reid) make_reid_engine(h);
+    }
+    set_step_lds(h);
+    ++h->n_grows;
+}
+
+int grown(int have, int need) {           // at least double, in steps of 64
+    int v = have * 2 > need ? have * 2 : need;
+    return (v + 63) / 64 * 64;
+}
 
 void zero_state(BoxMOTHipBotSort* h) {
     bm::BotSortState& st = h->args.st;
@@ -343,41 +436,28 @@ void build(BoxMOTHipBotSort* h) {
                                       c.tracker_kind == 1 ? 0 : c.with_reid, c.frame_rate, c.track_buffer, c.removed_stracks_buffer,
                                       c.tracker_kind);
     bm::BotSortSizes z{h->S, h->cap, h->nd, h->dim, h->n_lists, c.removed_stracks_buffer > 0 ? c.removed_stracks_buffer : 1};
-    DevAlloc dev_allocator{&o};
-    bm::botsort_allocate(h->args, z, dev_allocator);
+    RecAlloc table_allocator{&o, &h->table_rec};
+    bm::botsort_allocate(h->args, z, table_allocator);
     // io
-    h->d_dets = zalloc<float>(S * nd * bm::DET_COLS, o);
+    alloc_det_io(h);
     h->d_ndets = zalloc<int>(S, o);
-    h->d_embs = zalloc<float>(S * nd * dim, o);
-    h->d_out = zalloc<float>(S * nd * bm::OUT_COLS, o);
     h->d_out_n = zalloc<int>(S, o);
     h->d_list_sel = zalloc<int>(S, o);
     h->d_fc_set = zalloc<int>(S, o);
     h->d_warp = zalloc<double>(S * 6, o);
     h->d_warp_flag = zalloc<int>(S, o);
     h->h_warp.assign(S * 6, 0.0); h->h_warp_flag.assign(S, 0);
-    h->h_dets.assign(S * nd * bm::DET_COLS, 0.f);
-    h->h_out.assign(S * nd * bm::OUT_COLS, 0.f);
     h->h_ndets.assign(S, 0); h->h_out_n.assign(S, 0); h->h_list_sel.assign(S, 0); h->h_fc_set.assign(S, 0);
+    h->h_used.assign(S, 0); h->h_count_buf.assign(S * (nl + 1), 0);
     h->frame_bufs.assign(S, nullptr);
     h->d_frames = zalloc<const uint8_t*>(S, o);
     h->d_crop_count = zalloc<int>(1, o);
-    h->d_crop_stream = zalloc<int>(S * nd, o);
-    h->d_crop_boxes = zalloc<float>(S * nd * 4, o);
-    h->d_crop_row = zalloc<int>(S * nd, o);
     h->d_phase_clock = zalloc<long long>(16, o);
-    {
-        const long lds = bm::lap_lds_bytes(h->cap, h->nd);
-        if (lds > 120 * 1024) throw std::runtime_error("boxmot_hip: max_tracks/max_dets too large for the assignment solver's LDS state");
-        BM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(botsort_step_kernel<STEP_THREADS>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
-    if (c.with_reid && !h->reid_path.empty()) {
-        const std::vector<float> blob = bm::read_blob_file(h->reid_path.c_str());
-        h->reid.reset(new bm::ReidEngine(blob.data(), (long)blob.size(), bm::reid_chunk_for((long)S * nd), (int)(S * nd)));
-        if (h->reid->feature_dim() != h->dim) throw std::runtime_error("boxmot_hip: ReID feature dim != emb_dim");
-        h->reid->set_preprocess(h->reid_pad);
-    }
+    if (bm::lap_lds_bytes(h->cap, h->nd) > 120 * 1024)
+        throw std::runtime_error("boxmot_hip: max_tracks/max_dets too large for the assignment solver's LDS state");
+    set_step_lds(h);
+    (void)cap; (void)nd; (void)dim;
+    if (c.with_reid && !h->reid_path.empty()) make_reid_engine(h);
 }
 
 void launch_step(BoxMOTHipBotSort* h, int s0, int n_streams, const float* d_dets, const int* d_ndets, const float* d_embs,
@@ -503,6 +583,26 @@ struct StreamIn {
 void host_update(BoxMOTHipBotSort* h, int s0, int n, const StreamIn* in, int det_cols, int emb_cols,
                  int image_rows, int image_cols, int image_channels, const int* list_sel, const int* fc_set,
                  float* const* out, int out_capacity_rows, int* out_rows, const uint8_t* const* d_frames_ext = nullptr) {
+    {   // the reference has no capacities: make room before the step (every detection of a frame can become a track)
+        int need_nd = h->nd, need_cap = h->cap;
+        for (int k = 0; k < n; ++k) {
+            const int rows = in[k].det_rows > 0 ? in[k].det_rows : 0;
+            need_nd = rows > need_nd ? rows : need_nd;
+            if (h->h_used[s0 + k] < 0) {                   // a device-resident step ran since the last count: ask the device
+                const bm::BotSortState& st = h->args.st;
+                std::vector<int> cnt(h->n_lists + 1);
+                BM_HIP(hipStreamSynchronize(h->stream));
+                BM_HIP(hipMemcpy(cnt.data(), st.n_active + (size_t)(s0 + k) * h->n_lists, h->n_lists * 4, hipMemcpyDeviceToHost));
+                BM_HIP(hipMemcpy(cnt.data() + h->n_lists, st.n_lost + s0 + k, 4, hipMemcpyDeviceToHost));
+                int used = 0;
+                for (int v : cnt) used += v;
+                h->h_used[s0 + k] = used;
+            }
+            need_cap = h->h_used[s0 + k] + rows > need_cap ? h->h_used[s0 + k] + rows : need_cap;
+        }
+        if (need_nd > h->nd || need_cap > h->cap)
+            grow_tables(h, need_cap > h->cap ? grown(h->cap, need_cap) : h->cap, need_nd > h->nd ? grown(h->nd, need_nd) : h->nd);
+    }
     const int nd = h->nd, dim = h->dim;
     bool need_reid = false;
     for (int k = 0; k < n; ++k) {
@@ -510,10 +610,6 @@ void host_update(BoxMOTHipBotSort* h, int s0, int n, const StreamIn* in, int det
         if (rows < -1) throw std::runtime_error("Negative matrix dimensions are not allowed.");
         if (rows > 0 && det_cols == 7) throw std::runtime_error("boxmot_hip: OBB detections (7 columns) are not implemented");
         if (rows > 0 && det_cols != 6) throw std::runtime_error("boxmot_hip live tracking supports AABB detections with 6 columns.");
-        if (rows > nd)
-            throw std::runtime_error("boxmot_hip: more detections than max_dets (" + std::to_string(rows) + " > " + std::to_string(nd) +
-                                     "): max_dets / max_tracks are the capacities of the device-resident tables, fixed at create; the "
-                                     "reference has no such limit -- construct the tracker with a larger max_dets");
         if (rows > 0 && in[k].dets == nullptr) throw std::runtime_error("Detection data pointer is null.");
         if (out_capacity_rows < rows) throw std::runtime_error("boxmot_hip: output buffer is too small for the current frame.");
         if (in[k].embs != nullptr && emb_cols != dim && rows > 0)
@@ -590,7 +686,15 @@ void host_update(BoxMOTHipBotSort* h, int s0, int n, const StreamIn* in, int det
     BM_HIP(hipMemcpyAsync(h->h_out_n.data(), h->d_out_n + s0, n * 4, hipMemcpyDeviceToHost, h->stream));
     BM_HIP(hipMemcpyAsync(h->h_out.data(), h->d_out + (size_t)s0 * nd * bm::OUT_COLS, (size_t)n * nd * bm::OUT_COLS * 4,
                           hipMemcpyDeviceToHost, h->stream));
+    const int nl = h->n_lists;
+    BM_HIP(hipMemcpyAsync(h->h_count_buf.data(), h->args.st.n_active + (size_t)s0 * nl, (size_t)n * nl * 4, hipMemcpyDeviceToHost, h->stream));
+    BM_HIP(hipMemcpyAsync(h->h_count_buf.data() + (size_t)n * nl, h->args.st.n_lost + s0, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
     BM_HIP(hipStreamSynchronize(h->stream));
+    for (int k = 0; k < n; ++k) {           // slots in use = tracked + lost tracks (removed ones give their slot back)
+        int used = h->h_count_buf[(size_t)n * nl + k];
+        for (int l = 0; l < nl; ++l) used += h->h_count_buf[(size_t)k * nl + l];
+        h->h_used[s0 + k] = used;
+    }
     for (int k = 0; k < n; ++k) h->h_warp_flag[s0 + k] = 0;
     float ms = 0;
     if (hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) == hipSuccess) h->last_track_ms = ms;
@@ -627,32 +731,81 @@ void host_update_one(BoxMOTHipBotSort* h, int stream, int class_list, int frame_
 // ---------------------------------------------------------------------------
 // StreamIo: shared host plumbing of the DeepOCSORT / StrongSORT handles
 // ---------------------------------------------------------------------------
+void io_make_reid(StreamIo* h) {
+    const std::vector<float> blob = bm::read_blob_file(h->reid_path.c_str());
+    const long crops = (long)h->S * h->nd;
+    h->reid.reset(new bm::ReidEngine(blob.data(), (long)blob.size(), bm::reid_chunk_for(crops), (int)crops));
+    if (h->reid->feature_dim() != h->dim) throw std::runtime_error("boxmot_hip: ReID feature dim != emb_dim");
+    if (h->reid_mode >= 0) h->reid->set_mode(h->reid_mode);
+}
+
+// per-frame buffers whose size follows max_dets / max_tracks (contents do not outlive an update)
+void io_alloc_sized(StreamIo* h) {
+    auto& o = h->owned;
+    const size_t s = h->S, c = h->cap, n = h->nd, d = h->dim;
+    release(o, h->d_dets); release(o, h->d_embs); release(o, h->d_out);
+    release(o, h->d_crop_stream); release(o, h->d_crop_boxes); release(o, h->d_crop_row);
+    h->d_dets = zalloc<float>(s * n * bm::DET_COLS, o);
+    h->d_embs = zalloc<float>(s * n * d, o);
+    h->d_out = zalloc<float>(s * c * bm::OUT_COLS, o);
+    h->d_crop_stream = zalloc<int>(s * n, o);
+    h->d_crop_boxes = zalloc<float>(s * n * 4, o);
+    h->d_crop_row = zalloc<int>(s * n, o);
+    h->h_dets.assign(s * n * bm::DET_COLS, 0.f);
+    h->h_out.assign(c * bm::OUT_COLS, 0.f);
+}
+
 void io_allocate(StreamIo* h, int S, int cap, int nd, int dim, bool with_reid) {
     h->S = S; h->cap = cap; h->nd = nd; h->dim = dim;
     BM_HIP(hipStreamCreate(&h->stream));
     auto& o = h->owned;
-    const size_t s = S, c = cap, n = nd, d = dim;
-    h->d_dets = zalloc<float>(s * n * bm::DET_COLS, o);
+    const size_t s = S;
+    io_alloc_sized(h);
     h->d_ndets = zalloc<int>(s, o);
-    h->d_embs = zalloc<float>(s * n * d, o);
-    h->d_out = zalloc<float>(s * c * bm::OUT_COLS, o);
     h->d_out_n = zalloc<int>(s, o);
     h->d_warp = zalloc<double>(s * 6, o);
     h->d_warp_flag = zalloc<int>(s, o);
-    h->h_dets.assign(s * n * bm::DET_COLS, 0.f);
-    h->h_out.assign(c * bm::OUT_COLS, 0.f);
-    h->h_ndets.assign(s, 0); h->h_out_n.assign(s, 0);
+    h->h_ndets.assign(s, 0); h->h_out_n.assign(s, 0); h->h_used.assign(s, 0);
     h->h_warp.assign(s * 6, 0.0); h->h_warp_flag.assign(s, 0);
     h->frame_bufs.assign(s, nullptr);
     h->d_frames = zalloc<const uint8_t*>(s, o);
     h->d_crop_count = zalloc<int>(1, o);
-    h->d_crop_stream = zalloc<int>(s * n, o);
-    h->d_crop_boxes = zalloc<float>(s * n * 4, o);
-    h->d_crop_row = zalloc<int>(s * n, o);
-    if (with_reid && !h->reid_path.empty()) {
-        const std::vector<float> blob = bm::read_blob_file(h->reid_path.c_str());
-        h->reid.reset(new bm::ReidEngine(blob.data(), (long)blob.size(), bm::reid_chunk_for((long)S * nd), (int)(S * nd)));
-        if (h->reid->feature_dim() != h->dim) throw std::runtime_error("boxmot_hip: ReID feature dim != emb_dim");
+    if (with_reid && !h->reid_path.empty()) io_make_reid(h);
+}
+
+// State tables of a tracker carried over into a larger set (see grow_tables): `rec` = the new tables in allocation order, the
+// state tables first, up to `first_scratch`; every state table is [stream][slot][...], so a stream's slab only gets longer.
+void io_migrate(StreamIo* h, const std::vector<std::pair<void*, size_t>>& rec, const void* first_scratch) {
+    if (rec.size() != h->table_rec.size()) throw std::runtime_error("boxmot_hip: table layout changed between allocations");
+    const size_t rows = (size_t)h->S;
+    for (size_t i = 0; i < rec.size() && rec[i].first != first_scratch; ++i) {
+        const auto& od = h->table_rec[i];
+        if (od.second == rec[i].second) BM_HIP(hipMemcpy(rec[i].first, od.first, od.second, hipMemcpyDeviceToDevice));
+        else BM_HIP(hipMemcpy2D(rec[i].first, rec[i].second / rows, od.first, od.second / rows, od.second / rows, rows, hipMemcpyDeviceToDevice));
+    }
+    for (const auto& od : h->table_rec) release(h->owned, od.first);
+    h->table_rec = rec;
+}
+
+// Room for the frames of streams [s0, s0 + n) before they are staged: more detections than max_dets, or live tracks + this
+// frame's detections > max_tracks, re-makes the tables through `grow(new_cap, new_nd)` (the reference's lists have no limit).
+template <class Grow>
+void io_make_room(StreamIo* h, int s0, int n, const StreamIn* in, const int* d_n_tracks, Grow grow) {
+    if (s0 < 0 || n < 1 || s0 + n > h->S) throw std::runtime_error("boxmot_hip: stream index out of range");
+    int need_nd = h->nd, need_cap = h->cap;
+    for (int k = 0; k < n; ++k) {
+        const int rows = in[k].det_rows > 0 ? in[k].det_rows : 0;
+        need_nd = rows > need_nd ? rows : need_nd;
+        if (h->h_used[s0 + k] < 0) {
+            BM_HIP(hipStreamSynchronize(h->stream));
+            BM_HIP(hipMemcpy(&h->h_used[s0 + k], d_n_tracks + s0 + k, 4, hipMemcpyDeviceToHost));
+        }
+        need_cap = h->h_used[s0 + k] + rows > need_cap ? h->h_used[s0 + k] + rows : need_cap;
+    }
+    if (need_nd > h->nd || need_cap > h->cap) {
+        BM_HIP(hipStreamSynchronize(h->stream));
+        grow(need_cap > h->cap ? grown(h->cap, need_cap) : h->cap, need_nd > h->nd ? grown(h->nd, need_nd) : h->nd);
+        ++h->n_grows;
     }
 }
 
@@ -680,7 +833,8 @@ bool io_consume_warps(StreamIo* h) {
     BM_HIP(hipStreamSynchronize(h->stream));
     return true;
 }
-void io_clear_warps(StreamIo* h) { for (int s = 0; s < h->S; ++s) h->h_warp_flag[s] = 0; }
+// after a device-resident step: pending warps are consumed, and the host no longer knows the track counts (io_make_room asks)
+void io_clear_warps(StreamIo* h) { for (int s = 0; s < h->S; ++s) { h->h_warp_flag[s] = 0; h->h_used[s] = -1; } }
 
 // Validate and upload the inputs of the first n streams; run the ReID engine on every detection passing the confidence
 // test (`conf > thresh`, or `>=` when inclusive) when embeddings are wanted and not supplied.  Streams without a pending
@@ -694,10 +848,7 @@ bool io_stage(StreamIo* h, int n, const StreamIn* in, int det_cols, int emb_cols
         const int rows = in[k].det_rows;
         if (rows < -1) throw std::runtime_error("Negative matrix dimensions are not allowed.");
         if (rows > 0 && det_cols != 6) throw std::runtime_error("boxmot_hip live tracking supports AABB detections with 6 columns.");
-        if (rows > nd)
-            throw std::runtime_error("boxmot_hip: more detections than max_dets (" + std::to_string(rows) + " > " + std::to_string(nd) +
-                                     "): max_dets / max_tracks are the capacities of the device-resident tables, fixed at create; the "
-                                     "reference has no such limit -- construct the tracker with a larger max_dets");
+        if (rows > nd) throw std::runtime_error("boxmot_hip: internal: detection tables were not grown before staging");
         if (rows > 0 && in[k].dets == nullptr) throw std::runtime_error("Detection data pointer is null.");
         if (out_capacity_rows < rows) throw std::runtime_error("boxmot_hip: output buffer is too small for the current frame.");
         if (want_emb && in[k].embs != nullptr && emb_cols != dim && rows > 0)
@@ -784,9 +935,10 @@ void io_device_reid(StreamIo* h, const float* d_dets, const int* d_ndets, const 
 
 // After the step kernel: wait, clear the consumed warps, turn a non-zero status word into an exception, copy the rows out.
 void io_read_back(StreamIo* h, int n, const int* d_status, const char* tracker, float* const* out, int out_capacity_rows, int* out_rows,
-                  int s0 = 0) {
+                  int s0 = 0, const int* d_n_tracks = nullptr) {
     BM_HIP(hipGetLastError());
     BM_HIP(hipMemcpyAsync(h->h_out_n.data(), h->d_out_n + s0, n * 4, hipMemcpyDeviceToHost, h->stream));
+    if (d_n_tracks) BM_HIP(hipMemcpyAsync(h->h_used.data() + s0, d_n_tracks + s0, n * 4, hipMemcpyDeviceToHost, h->stream));
     BM_HIP(hipStreamSynchronize(h->stream));
     for (int k = 0; k < n; ++k) h->h_warp_flag[s0 + k] = 0;
     const std::string status_msg = take_status(h->stream, const_cast<int*>(d_status), s0, n, tracker);
@@ -834,11 +986,31 @@ void docs_build(BoxMOTHipDeepOcSort* h) {
     d.embedding_off = c.embedding_off; d.aw_off = c.aw_off;
     if (c.use_byte && !c.embedding_off) throw std::runtime_error("boxmot_hip: use_byte is OC-SORT's option and needs embedding_off = 1");
     d.use_byte = c.use_byte ? 1 : 0; d.min_conf_f32 = (float)c.min_conf;
-    DevAlloc dev_allocator{&h->owned};
+    RecAlloc table_allocator{&h->owned, &h->table_rec};
     bm::DocsSizes z{h->S, h->cap, h->nd, h->dim};
-    bm::docs_allocate(h->args, z, dev_allocator);
+    bm::docs_allocate(h->args, z, table_allocator);
     const long lds = bm::docs_lap_lds_bytes(h->cap, h->nd);
     if (lds > 120 * 1024) throw std::runtime_error("boxmot_hip: max_tracks/max_dets too large for the assignment solver's LDS state");
+    BM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deepocsort_step_kernel<STEP_THREADS>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+}
+
+void docs_grow(BoxMOTHipDeepOcSort* h, int new_cap, int new_nd) {
+    const long lds = bm::docs_lap_lds_bytes(new_cap, new_nd);
+    if (lds > 120 * 1024)
+        throw std::runtime_error("boxmot_hip: " + std::to_string(new_cap) + " tracks x " + std::to_string(new_nd) +
+                                 " detections per stream is beyond what the assignment solver's LDS state can hold");
+    BM_HIP(hipStreamSynchronize(h->stream));
+    bm::DocsStepArgs na = h->args;
+    std::vector<std::pair<void*, size_t>> rec;
+    RecAlloc ra{&h->owned, &rec};
+    bm::docs_allocate(na, bm::DocsSizes{h->S, new_cap, new_nd, h->dim}, ra);
+    io_migrate(h, rec, na.sc.keep);
+    h->args = na;
+    const bool more_dets = new_nd != h->nd;
+    h->cap = new_cap; h->nd = new_nd;
+    io_alloc_sized(h);
+    if (more_dets && h->reid) io_make_reid(h);
     BM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deepocsort_step_kernel<STEP_THREADS>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 }
@@ -849,6 +1021,7 @@ void docs_host_update(BoxMOTHipDeepOcSort* h, int n, const StreamIn* in, int det
                       int image_cols, int image_channels, float* const* out, int out_capacity_rows, int* out_rows, int s0 = 0,
                       int frame_count = -1, int* id_count_inout = nullptr) {
     const bool want_emb = !h->cfg.embedding_off;
+    io_make_room(h, s0, n, in, h->args.st.n_tracks, [&](int cap, int nd) { docs_grow(h, cap, nd); });
     const bool any_warp = io_stage(h, n, in, det_cols, emb_cols, want_emb, image_rows, image_cols, image_channels, out_capacity_rows,
                                    (double)(float)h->cfg.det_thresh, 0, s0);
     // per-class fan-out (basetracker.py:223-263): the frame counter is rewound for every class and the id counter
@@ -861,7 +1034,7 @@ void docs_host_update(BoxMOTHipDeepOcSort* h, int n, const StreamIn* in, int det
     a.out = h->d_out; a.out_n = h->d_out_n; a.stream_base = s0;
     hipLaunchKernelGGL((deepocsort_step_kernel<STEP_THREADS>), dim3(n), dim3(STEP_THREADS),
                        (size_t)bm::docs_lap_lds_bytes(h->cap, h->nd), h->stream, a);
-    io_read_back(h, n, h->args.st.status, "DeepOCSORT", out, out_capacity_rows, out_rows, s0);
+    io_read_back(h, n, h->args.st.status, "DeepOCSORT", out, out_capacity_rows, out_rows, s0, h->args.st.n_tracks);
     if (id_count_inout) BM_HIP(hipMemcpy(id_count_inout, h->args.st.id_count + s0, 4, hipMemcpyDeviceToHost));
 }
 
@@ -894,9 +1067,9 @@ void ss_build(BoxMOTHipStrongSort* h) {
     d.min_conf = c.min_conf; d.max_cos_dist = c.max_cos_dist; d.max_iou_dist = c.max_iou_dist; d.mc_lambda = c.mc_lambda;
     d.ema_alpha_f32 = (float)c.ema_alpha; d.one_minus_alpha_f32 = (float)(1 - c.ema_alpha);
     d.max_age = c.max_age; d.n_init = c.n_init; d.budget = c.nn_budget;
-    DevAlloc dev_allocator{&h->owned};
+    RecAlloc table_allocator{&h->owned, &h->table_rec};
     bm::SsSizes z{h->S, h->cap, h->nd, h->dim, c.nn_budget};
-    bm::ss_allocate(h->args, z, dev_allocator);
+    bm::ss_allocate(h->args, z, table_allocator);
     const long lds = bm::ss_lsa_lds_bytes(h->cap > h->nd ? h->cap : h->nd);
     if (lds > 120 * 1024) throw std::runtime_error("boxmot_hip: max_tracks/max_dets too large for the assignment solver's LDS state");
     BM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(strongsort_step_kernel<STEP_THREADS>),
@@ -904,6 +1077,28 @@ void ss_build(BoxMOTHipStrongSort* h) {
     BM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(strongsort_step_kernel<SS_STEP_THREADS_BIG>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ss_zero_state(h);
+}
+
+void ss_grow(BoxMOTHipStrongSort* h, int new_cap, int new_nd) {
+    const long lds = bm::ss_lsa_lds_bytes(new_cap > new_nd ? new_cap : new_nd);
+    if (lds > 120 * 1024)
+        throw std::runtime_error("boxmot_hip: " + std::to_string(new_cap) + " tracks x " + std::to_string(new_nd) +
+                                 " detections per stream is beyond what the assignment solver's LDS state can hold");
+    BM_HIP(hipStreamSynchronize(h->stream));
+    bm::SsStepArgs na = h->args;
+    std::vector<std::pair<void*, size_t>> rec;
+    RecAlloc ra{&h->owned, &rec};
+    bm::ss_allocate(na, bm::SsSizes{h->S, new_cap, new_nd, h->dim, h->cfg.nn_budget}, ra);
+    io_migrate(h, rec, na.sc.app);
+    h->args = na;
+    const bool more_dets = new_nd != h->nd;
+    h->cap = new_cap; h->nd = new_nd;
+    io_alloc_sized(h);
+    if (more_dets && h->reid) io_make_reid(h);
+    BM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(strongsort_step_kernel<STEP_THREADS>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    BM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(strongsort_step_kernel<SS_STEP_THREADS_BIG>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 }
 
 #ifdef BM_SS_PROF
@@ -936,12 +1131,13 @@ void ss_launch(BoxMOTHipStrongSort* h, const bm::SsStepArgs& a, int n) {
 // strongsort.py:74-91), step, read back.
 void ss_host_update(BoxMOTHipStrongSort* h, int n, const StreamIn* in, int det_cols, int emb_cols, int image_rows,
                     int image_cols, int image_channels, float* const* out, int out_capacity_rows, int* out_rows) {
+    io_make_room(h, 0, n, in, h->args.st.n_tracks, [&](int cap, int nd) { ss_grow(h, cap, nd); });
     io_stage(h, n, in, det_cols, emb_cols, true, image_rows, image_cols, image_channels, out_capacity_rows, h->cfg.min_conf, 1);
     bm::SsStepArgs a = h->args;
     a.dets = h->d_dets; a.n_dets = h->d_ndets; a.embs = h->d_embs; a.warp = h->d_warp;     // identity where no warp is pending
     a.out = h->d_out; a.out_n = h->d_out_n; a.stream_base = 0;
     ss_launch(h, a, n);
-    io_read_back(h, n, h->args.st.status, "StrongSORT", out, out_capacity_rows, out_rows);
+    io_read_back(h, n, h->args.st.status, "StrongSORT", out, out_capacity_rows, out_rows, 0, h->args.st.n_tracks);
 }
 
 }  // namespace
@@ -999,6 +1195,25 @@ int boxmot_hip_botsort_reset(BoxMOTHipBotSort* handle) {
     return guard([&]() {
         if (!handle) throw std::runtime_error("boxmot_hip BoT-SORT handle is null.");
         zero_state(handle);
+        handle->h_used.assign(handle->S, 0);
+    });
+}
+
+int boxmot_hip_botsort_reserve(BoxMOTHipBotSort* handle, int max_tracks, int max_dets) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip BoT-SORT handle is null.");
+        const int cap = max_tracks > handle->cap ? (max_tracks + 63) / 64 * 64 : handle->cap;
+        const int nd = max_dets > handle->nd ? (max_dets + 63) / 64 * 64 : handle->nd;
+        if (cap != handle->cap || nd != handle->nd) grow_tables(handle, cap, nd);
+    });
+}
+
+int boxmot_hip_botsort_capacity(BoxMOTHipBotSort* handle, int* max_tracks, int* max_dets, int* n_grows) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip BoT-SORT handle is null.");
+        if (max_tracks) *max_tracks = handle->cap;
+        if (max_dets) *max_dets = handle->nd;
+        if (n_grows) *n_grows = handle->n_grows;
     });
 }
 
@@ -1084,7 +1299,7 @@ int boxmot_hip_botsort_step_device(BoxMOTHipBotSort* handle, const float* d_dets
         }
         launch_step(handle, 0, handle->S, d_dets, d_det_rows, handle->cfg.with_reid ? embs : nullptr, nullptr, nullptr,
                     d_out, d_out_rows, any_warp);
-        for (int s = 0; s < handle->S; ++s) handle->h_warp_flag[s] = 0;
+        for (int s = 0; s < handle->S; ++s) { handle->h_warp_flag[s] = 0; handle->h_used[s] = -1; }      // slot counts: unknown to the host now
     });
 }
 
@@ -1556,6 +1771,25 @@ int boxmot_hip_deepocsort_reset(BoxMOTHipDeepOcSort* handle) {
     return guard([&]() {
         if (!handle) throw std::runtime_error("boxmot_hip DeepOCSORT handle is null.");
         docs_zero_state(handle);
+        handle->h_used.assign(handle->S, 0);
+    });
+}
+
+int boxmot_hip_deepocsort_reserve(BoxMOTHipDeepOcSort* handle, int max_tracks, int max_dets) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip DeepOCSORT handle is null.");
+        const int cap = max_tracks > handle->cap ? (max_tracks + 63) / 64 * 64 : handle->cap;
+        const int nd = max_dets > handle->nd ? (max_dets + 63) / 64 * 64 : handle->nd;
+        if (cap != handle->cap || nd != handle->nd) { docs_grow(handle, cap, nd); ++handle->n_grows; }
+    });
+}
+
+int boxmot_hip_deepocsort_capacity(BoxMOTHipDeepOcSort* handle, int* max_tracks, int* max_dets, int* n_grows) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip DeepOCSORT handle is null.");
+        if (max_tracks) *max_tracks = handle->cap;
+        if (max_dets) *max_dets = handle->nd;
+        if (n_grows) *n_grows = handle->n_grows;
     });
 }
 
@@ -1659,6 +1893,7 @@ int boxmot_hip_deepocsort_set_reid_mode(BoxMOTHipDeepOcSort* handle, int mode) {
     return guard([&]() {
         if (!handle || !handle->reid) throw std::runtime_error("boxmot_hip: no ReID weights are loaded in this handle");
         handle->reid->set_mode(mode);
+        handle->reid_mode = mode;
     });
 }
 
@@ -1740,6 +1975,25 @@ int boxmot_hip_strongsort_reset(BoxMOTHipStrongSort* handle) {
     return guard([&]() {
         if (!handle) throw std::runtime_error("boxmot_hip StrongSORT handle is null.");
         ss_zero_state(handle);
+        handle->h_used.assign(handle->S, 0);
+    });
+}
+
+int boxmot_hip_strongsort_reserve(BoxMOTHipStrongSort* handle, int max_tracks, int max_dets) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip StrongSORT handle is null.");
+        const int cap = max_tracks > handle->cap ? (max_tracks + 63) / 64 * 64 : handle->cap;
+        const int nd = max_dets > handle->nd ? (max_dets + 63) / 64 * 64 : handle->nd;
+        if (cap != handle->cap || nd != handle->nd) { ss_grow(handle, cap, nd); ++handle->n_grows; }
+    });
+}
+
+int boxmot_hip_strongsort_capacity(BoxMOTHipStrongSort* handle, int* max_tracks, int* max_dets, int* n_grows) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip StrongSORT handle is null.");
+        if (max_tracks) *max_tracks = handle->cap;
+        if (max_dets) *max_dets = handle->nd;
+        if (n_grows) *n_grows = handle->n_grows;
     });
 }
 
@@ -1819,6 +2073,7 @@ int boxmot_hip_strongsort_set_reid_mode(BoxMOTHipStrongSort* handle, int mode) {
     return guard([&]() {
         if (!handle || !handle->reid) throw std::runtime_error("boxmot_hip: no ReID weights are loaded in this handle");
         handle->reid->set_mode(mode);
+        handle->reid_mode = mode;
     });
 }
 

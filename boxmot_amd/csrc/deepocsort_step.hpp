@@ -370,7 +370,7 @@ __device__ inline DV docs_view(const DocsStepArgs& a, int s) {
 // ---------------------------------------------------------------------------
 // linear_assignment(cost) of association.py:20-24 -- lap.lapjv(cost, extend_cost=True) -- on a det-major matrix
 // cost[d * ld + t]: R columns (tracks), C rows (detections).  The solver is the Jonker-Volgenant code of lap_jv.hpp, which
-// returns, tie for tie, the assignment the sequential algorithm returns (oracle/lapjv.c); its state lives in dynamic LDS.
+// returns, tie for tie, the assignment the sequential algorithm returns; its state lives in dynamic LDS.
 // out_x[t] = row of column t, out_y[d] = column of row d, -1 = unassigned.
 // ---------------------------------------------------------------------------
 constexpr double DOCS_INF = 1e300;

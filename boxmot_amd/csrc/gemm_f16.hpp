@@ -522,9 +522,9 @@ __global__ void __launch_bounds__(512) k_gemm_f16_256(const _Float16* __restrict
 #endif
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] += bv[r];
-                if constexpr (EPI == 1) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + BM_EXPF(-1.702f * v[r]));
+                if constexpr (EPI == 1) {    // QuickGELU; the quotient as a reciprocal (1 ulp of fp32, the result is rounded to fp16): the IEEE
+#pragma unroll                           // division sequence was a quarter of this kernel's epilogue
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + BM_EXPF(-1.702f * v[r]));
                 }
                 if constexpr (EPI == 4) {
                     if (res) {              // (no prefetch here: the accumulators and fragments fill the register file)
@@ -555,6 +555,55 @@ __global__ void __launch_bounds__(512) k_gemm_f16_256(const _Float16* __restrict
             if (m < M) *reinterpret_cast<ch8*>(static_cast<_Float16*>(Cout) + m * N + n0 + wr * 128 + l16 * 8) = v;
         }
 #endif
+        return;
+    }
+    if constexpr (EPI == 2) {
+        // fp32 C += result, the same way in two halves of 64 features: 4 rows x 256 contiguous bytes per load / store instruction
+        // instead of 16-byte pieces of 16 rows (the residual stream is read and rewritten once per projection: 2 x 101 MB at 256 crops)
+        float* reg = reinterpret_cast<float*>(lds_raw) + wave * (64 * 68);
+        float* c = static_cast<float*>(Cout);
+#pragma unroll
+        for (int hp = 0; hp < 2; ++hp) {
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                const int p = hp * 4 + pp, n = n0 + wr * 128 + p * 16 + 4 * g;
+                cf4 bv = cf4{0.f, 0.f, 0.f, 0.f};
+                if (bias) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bv[r] = bias[n + r];
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    cf4 v = acc[p][t];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += bv[r];
+                    *reinterpret_cast<cf4*>(reg + (t * 16 + l16) * 68 + pp * 16 + 4 * g) = v;
+                }
+            }
+            BM_WAVE_LDS_SYNC();
+#pragma unroll
+            for (int i0 = 0; i0 < 16; i0 += 8) {
+                cf4 old[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    long m = m0 + wc * 64 + (i0 + i) * 4 + g;
+                    if (m >= M) m = M - 1;
+                    old[i] = *reinterpret_cast<const cf4*>(c + m * N + n0 + wr * 128 + hp * 64 + l16 * 4);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int row = (i0 + i) * 4 + g;
+                    const long m = m0 + wc * 64 + row;
+                    const cf4 v = *reinterpret_cast<const cf4*>(reg + row * 68 + l16 * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) old[i][r] += v[r];
+#ifndef BM_GEMM256_NO_STORE
+                    if (m < M) *reinterpret_cast<cf4*>(c + m * N + n0 + wr * 128 + hp * 64 + l16 * 4) = old[i];
+#endif
+                }
+            }
+            BM_WAVE_LDS_SYNC();
+        }
         return;
     }
 #pragma unroll

@@ -140,8 +140,20 @@ class MultiStreamBotSort:
     def reset(self) -> None:
         _lib.check(self._lib.boxmot_hip_botsort_reset(self._handle))
 
+    def capacity(self) -> tuple[int, int, int]:
+        """(max_tracks, max_dets, times the tables grew): the tables grow on demand in the host-API updates; ``reserve`` sizes
+        them ahead of a device-resident burst (``step_device`` cannot grow them)."""
+        a, b, c = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(self._lib.boxmot_hip_botsort_capacity(self._handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        self.max_tracks, self.max_dets = a.value, b.value
+        return a.value, b.value, c.value
+
+    def reserve(self, max_tracks: int = 0, max_dets: int = 0) -> None:
+        _lib.check(self._lib.boxmot_hip_botsort_reserve(self._handle, int(max_tracks), int(max_dets)))
+        self.capacity()
+
     def state_dump(self, stream: int, which: int = 0) -> dict:
-        cap, dim = self.max_tracks, self.emb_dim
+        cap, dim = self.capacity()[0], self.emb_dim
         ints = np.zeros((cap, 6), dtype=np.int32)
         kf = np.zeros((cap, 72), dtype=np.float64)
         smooth = np.zeros((cap, dim), dtype=np.float32)

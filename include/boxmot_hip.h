@@ -84,6 +84,16 @@ BoxMOTHipBotSort* boxmot_hip_botsort_create(const BoxMOTHipBotSortConfig* config
 void boxmot_hip_botsort_destroy(BoxMOTHipBotSort* handle);
 int boxmot_hip_botsort_reset(BoxMOTHipBotSort* handle);
 
+/* Capacities.  The reference's track and detection lists are Python lists without a limit (botsort.py:177-250); the device tables are
+ * created at max_tracks / max_dets and GROW on demand: a host-API update (update / update_stream / update_batch[_frames]) that would
+ * not fit -- more detections than max_dets, or live tracks + this frame's detections > max_tracks -- first re-makes the tables at
+ * (at least) twice the size and carries the state over (ids, filters, lists unchanged), so results do not depend on the initial
+ * sizes.  The limit is the LDS state of the assignment solver (about 3000 tracks + detections per stream), reported as an error.
+ * The device-resident step has no host in the loop to do this: size the handle with _reserve before a burst (it reports an
+ * overflow through boxmot_hip_botsort_status as before).  _capacity returns the current sizes and how often the tables grew. */
+int boxmot_hip_botsort_reserve(BoxMOTHipBotSort* handle, int max_tracks, int max_dets);
+int boxmot_hip_botsort_capacity(BoxMOTHipBotSort* handle, int* max_tracks, int* max_dets, int* n_grows);
+
 /* boxmot_botsort_update, c_api.hpp:42-55: one frame of stream 0, synchronous. */
 int boxmot_hip_botsort_update(
     BoxMOTHipBotSort* handle,
@@ -285,6 +295,9 @@ void boxmot_hip_deepocsort_default_config(BoxMOTHipDeepOcSortConfig* config);
 BoxMOTHipDeepOcSort* boxmot_hip_deepocsort_create(const BoxMOTHipDeepOcSortConfig* config);
 void boxmot_hip_deepocsort_destroy(BoxMOTHipDeepOcSort* handle);
 int boxmot_hip_deepocsort_reset(BoxMOTHipDeepOcSort* handle);
+/* capacities grow on demand in the host-API updates (see boxmot_hip_botsort_reserve) */
+int boxmot_hip_deepocsort_reserve(BoxMOTHipDeepOcSort* handle, int max_tracks, int max_dets);
+int boxmot_hip_deepocsort_capacity(BoxMOTHipDeepOcSort* handle, int* max_tracks, int* max_dets, int* n_grows);
 /* KalmanBoxTracker.apply_affine_correction (deepocsort.py:190-209, xysr.py:311-366): the 2x3 warp cmc.apply returned,
  * applied to every track of `stream` at the start of its NEXT update (deepocsort.py:347-351) and then dropped. */
 int boxmot_hip_deepocsort_set_warp(BoxMOTHipDeepOcSort* handle, int stream, const double* warp_2x3);
@@ -361,6 +374,9 @@ void boxmot_hip_strongsort_default_config(BoxMOTHipStrongSortConfig* config);
 BoxMOTHipStrongSort* boxmot_hip_strongsort_create(const BoxMOTHipStrongSortConfig* config);
 void boxmot_hip_strongsort_destroy(BoxMOTHipStrongSort* handle);
 int boxmot_hip_strongsort_reset(BoxMOTHipStrongSort* handle);
+/* capacities grow on demand in the host-API updates (see boxmot_hip_botsort_reserve) */
+int boxmot_hip_strongsort_reserve(BoxMOTHipStrongSort* handle, int max_tracks, int max_dets);
+int boxmot_hip_strongsort_capacity(BoxMOTHipStrongSort* handle, int* max_tracks, int* max_dets, int* n_grows);
 /* Track.camera_update (sort/track.py:139-148): the 2x3 warp the reference's cmc.apply returned, applied to every track in
  * the NEXT update of `stream` (the reference applies its ECC estimate unconditionally, strongsort.py:83-86); without a
  * pending warp the identity is applied, which is what the reference computes for a static camera. */

@@ -116,9 +116,11 @@ def test_update_time_with_embeddings_supplied(kind, reid):       # test_tracking
 
 
 @pytest.mark.parametrize("kind", ["botsort", "bytetrack", "deepocsort", "ocsort", "strongsort"])
-def test_capacity_limits_fail_loudly(kind):
-    """Maximum sizes: one detection more than max_dets, or more simultaneous tracks than max_tracks, is an error with a
-    message -- never a silent truncation (the reference has no such limits; the device tables are sized at construction)."""
+def test_no_capacity_limits_like_the_reference(kind):
+    """The reference's lists have no maximum size; the device tables are created at max_tracks / max_dets and grow when a frame does
+    not fit -- one detection more than max_dets, more simultaneous tracks than max_tracks -- with the same rows as a tracker created
+    large (tests/test_gpu_capacity.py compares against the oracles).  Beyond what the assignment solver's LDS state holds the
+    update fails with a message, never with a silent truncation."""
     from boxmot_amd import BotSort, ByteTrack, DeepOcSort, OcSort, StrongSort
     mk = {"botsort": lambda **kw: BotSort(use_cmc=False, with_reid=False, **kw), "bytetrack": ByteTrack,
           "deepocsort": lambda **kw: DeepOcSort(cmc_off=True, embedding_off=True, **kw), "ocsort": OcSort,
@@ -131,16 +133,14 @@ def test_capacity_limits_fail_loudly(kind):
         y = 60.0 * (np.arange(n) // 14)
         return np.stack([x, y, x + 30, y + 50, np.full(n, 0.9), np.zeros(n)], 1).astype(np.float32)
 
-    trk = mk(max_tracks=64, max_dets=16)
-    embs = lambda n: rng.standard_normal((n, 8)).astype(np.float32)
-    assert len(trk.update(dets(16), img, embs(16))) >= 0                 # exactly max_dets is fine
-    with pytest.raises(RuntimeError, match="max_dets"):
-        trk.update(dets(17), img, embs(17))
-    trk.close()
-    trk = mk(max_tracks=16, max_dets=16)
-    for t in range(3):                                                    # 16 tracks, confirmed by every tracker's rule
-        trk.update(dets(16), img, embs(16))
-    with pytest.raises(RuntimeError, match="capacity"):
-        for t in range(1, 5):                                             # 16 new objects elsewhere per frame: no free slot
-            trk.update(dets(16) + np.array([3.0, 700.0 * t, 3.0, 700.0 * t, 0, 0], np.float32), img, embs(16))
-    trk.close()
+    small, large = mk(max_tracks=16, max_dets=16), mk(max_tracks=512, max_dets=64)
+    seq = [dets(16)] * 3 + [dets(17)] + [dets(16) + np.array([3.0, 700.0 * t, 3.0, 700.0 * t, 0, 0], np.float32) for t in range(1, 5)]
+    for d in seq:                                  # 16 confirmed tracks, a 17th detection, then 16 new objects elsewhere per frame
+        e = rng.standard_normal((len(d), 8)).astype(np.float32)
+        a, b = np.asarray(small.update(d, img, e)).reshape(-1, 8), np.asarray(large.update(d, img, e)).reshape(-1, 8)
+        assert np.array_equal(a, b)
+    cap, nd, grows = small.capacity()
+    assert grows >= 1 and nd >= 17 and cap > 16 and large.capacity()[2] == 0
+    with pytest.raises(RuntimeError, match="beyond what the assignment solver"):
+        small.reserve(max_tracks=200000)
+    small.close(); large.close()

@@ -65,6 +65,35 @@ int main(int argc, char** argv) {
             const double d = std::fabs(acc - (double)(float)c1[m * N + n]);
             max_cpu = d > max_cpu ? d : max_cpu;
         }
+        {   // the two other epilogues the ViT uses: QuickGELU (fp16 out) and fp32 accumulate into the residual stream
+            float* df; CK(hipMalloc(&df, (size_t)M * N * 4)); CK(hipMemset(df, 0, (size_t)M * N * 4));
+            static bool once = false;
+            if (!once) {
+                once = true;
+                CK(hipFuncSetAttribute(reinterpret_cast<const void*>(bm::k_gemm_f16_glds<1, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, bm::gemm_glds_lds_bytes<64>()));
+                CK(hipFuncSetAttribute(reinterpret_cast<const void*>(bm::k_gemm_f16_glds<2, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, bm::gemm_glds_lds_bytes<64>()));
+                CK(hipFuncSetAttribute(reinterpret_cast<const void*>(bm::k_gemm_f16_256<1>), hipFuncAttributeMaxDynamicSharedMemorySize, bm::GEMM256_LDS_BYTES));
+                CK(hipFuncSetAttribute(reinterpret_cast<const void*>(bm::k_gemm_f16_256<2>), hipFuncAttributeMaxDynamicSharedMemorySize, bm::GEMM256_LDS_BYTES));
+            }
+            auto o1 = [&]() { hipLaunchKernelGGL((bm::k_gemm_f16_glds<1, 64>), dim3(g128), dim3(256), bm::gemm_glds_lds_bytes<64>(), 0, dx, dw, db, dc0, (const _Float16*)nullptr, (int)M, N, K, 0, bm::GemmExt{}); };
+            auto n1 = [&]() { hipLaunchKernelGGL((bm::k_gemm_f16_256<1>), dim3(g256), dim3(512), bm::GEMM256_LDS_BYTES, 0, dx, dw, db, dc1, (const _Float16*)nullptr, (int)M, N, K, 0); };
+            auto o2 = [&]() { hipLaunchKernelGGL((bm::k_gemm_f16_glds<2, 64>), dim3(g128), dim3(256), bm::gemm_glds_lds_bytes<64>(), 0, dx, dw, db, df, (const _Float16*)nullptr, (int)M, N, K, 0, bm::GemmExt{}); };
+            auto n2 = [&]() { hipLaunchKernelGGL((bm::k_gemm_f16_256<2>), dim3(g256), dim3(512), bm::GEMM256_LDS_BYTES, 0, dx, dw, db, df, (const _Float16*)nullptr, (int)M, N, K, 0); };
+            const float a1 = time_ms(o1, 10), b1 = time_ms(n1, 10);
+            std::vector<_Float16> e0((size_t)M * N), e1((size_t)M * N);
+            CK(hipMemcpy(e0.data(), dc0, e0.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(e1.data(), dc1, e1.size() * 2, hipMemcpyDeviceToHost));
+            double dg = 0;
+            for (size_t i = 0; i < e0.size(); ++i) { const double d = std::fabs((double)(float)e0[i] - (double)(float)e1[i]); dg = d > dg ? d : dg; }
+            const float a2 = time_ms(o2, 10), b2 = time_ms(n2, 10);
+            // accumulate check: zero, one launch of each kernel, compare
+            std::vector<float> f0((size_t)M * N), f1((size_t)M * N);
+            CK(hipMemset(df, 0, (size_t)M * N * 4)); o2(); CK(hipMemcpy(f0.data(), df, f0.size() * 4, hipMemcpyDeviceToHost));
+            CK(hipMemset(df, 0, (size_t)M * N * 4)); n2(); n2(); CK(hipMemcpy(f1.data(), df, f1.size() * 4, hipMemcpyDeviceToHost));
+            double da = 0;
+            for (size_t i = 0; i < f0.size(); ++i) { const double d = std::fabs(2.0 * (double)f0[i] - (double)f1[i]); da = d > da ? d : da; }
+            printf("    QuickGELU epilogue: %.3f -> %.3f ms (max|new-old| %.5f)   fp32 accumulate epilogue: %.3f -> %.3f ms (max|2 old - new twice| %.6f)\n", a1, b1, dg, a2, b2, da);
+            hipFree(df);
+        }
         const double fl = 2.0 * M * N * K;
         printf("M=%ld N=%d K=%d: 128x128 glds %.3f ms %.0f TF | 256x256 phased %.3f ms %.0f TF | max|new-old| %.4f max|new-cpu| %.4f\n", M, N, K, t0, fl / t0 / 1e9, t1, fl / t1 / 1e9, max_pair, max_cpu);
         hipFree(dx); hipFree(dw); hipFree(db); hipFree(dc0); hipFree(dc1);
