@@ -181,6 +181,13 @@ SIGNATURES = {
     "boxmot_hip_ecc_reset": (_I, [_VP, _I]),
     "boxmot_hip_ecc_apply": (_I, [_VP, _I, _VP, _I, _I, _I, _VP, c_int_p]),
     "boxmot_hip_ecc_apply_device": (_I, [_VP, _I, _VP, _VP, c_int_p]),
+    "boxmot_hip_sof_create": (_VP, [_I, _I, _I, ctypes.c_double, _I, ctypes.c_double, ctypes.c_double]),
+    "boxmot_hip_sof_destroy": (None, [_VP]),
+    "boxmot_hip_sof_reset": (_I, [_VP, _I]),
+    "boxmot_hip_sof_apply": (_I, [_VP, _I, _VP, _I, _I, _I, _VP, _I, _I, _VP, c_int_p]),
+    "boxmot_hip_sof_apply_device": (_I, [_VP, _VP, _VP, _VP, _I, _I, _VP, _VP]),
+    "boxmot_hip_sof_keypoints": (_I, [_VP, _I, _VP, _I, c_int_p]),
+    "boxmot_hip_sof_debug_map": (_I, [_VP, _I, _I, _VP, _I, c_int_p, c_int_p]),
     "boxmot_hip_ingest_create": (_VP, [_I, _I, _I, _I]),
     "boxmot_hip_ingest_destroy": (None, [_VP]),
     "boxmot_hip_ingest_host_ptr": (_VP, [_VP, _I, _I]),

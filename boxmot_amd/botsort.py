@@ -8,9 +8,9 @@ through the C ABI (include/boxmot_hip.h).  Mirrors the shape of the reference's
 ctypes wrapper for its native backend (boxmot/native/trackers/botsort.py:94-274).
 
 Camera-motion compensation: applying a warp to the track state runs on the device
-(STrack.multi_gmc); *estimating* it from images (the reference's ECC / SOF objects,
-boxmot/motion/cmc) exists on the device for ``cmc_method="ecc"`` (boxmot_amd.cmc.HipECC); "sof" needs a ``cmc=`` object
-exposing the reference's ``apply(img, dets) -> 2x3 warp`` (e.g. the reference's own).
+(STrack.multi_gmc), and so does *estimating* it from images for both estimators the reference configures BoT-SORT with:
+``cmc_method="ecc"`` (the constructor default, boxmot_amd.cmc.HipECC) and ``"sof"`` (configs/trackers/botsort.yaml,
+boxmot_amd.cmc.HipSOF); ``cmc=`` accepts any object exposing the reference's ``apply(img, dets) -> 2x3 warp``.
 Not implemented, and rejected loudly rather than approximated: OBB detections, masks.
 """
 from __future__ import annotations
@@ -63,15 +63,10 @@ class BotSort(BaseTracker):
             from boxmot_amd.cmc import get_cmc_method
             cmc = get_cmc_method(cmc)()
         if use_cmc and cmc is None:
-            # botsort.py:116-117: get_cmc_method(cmc_method)(); "ecc" (the constructor default) is estimated on the device
-            # (boxmot_amd.cmc.HipECC), the sparse-optical-flow estimator of the YAML default ("sof") is not built
-            if cmc_method != "ecc":
-                raise NotImplementedError(
-                    "boxmot_amd.BotSort: camera-motion estimator cmc_method=%r is not implemented on the HIP path (have: 'ecc'); "
-                    "construct with cmc_method='ecc', use_cmc=False, or pass cmc=<object with apply(img, dets) -> 2x3 warp>." % (cmc_method,)
-                )
-            from boxmot_amd.cmc import HipECC
-            cmc = HipECC()
+            # botsort.py:116-117: get_cmc_method(cmc_method)() -- "ecc" (the constructor default) and "sof" (the YAML default) are
+            # estimated on the device (boxmot_amd.cmc.HipECC / HipSOF); anything else raises NotImplementedError there
+            from boxmot_amd.cmc import get_cmc_method
+            cmc = get_cmc_method(cmc_method)()
         self.track_high_thresh = track_high_thresh
         self.track_low_thresh = track_low_thresh
         self.new_track_thresh = new_track_thresh

@@ -20,6 +20,7 @@
 #include "strongsort_step.hpp"
 #include "reid_engine.hpp"
 #include "cmc_ecc.hpp"
+#include "cmc_sof.hpp"
 
 namespace {
 
@@ -162,6 +163,26 @@ struct BoxMOTHipEcc {
     }
 };
 
+// Sparse-optical-flow camera-motion estimator (csrc/cmc_sof.hpp): per stream the previous and the current frame's 8-bit pyramid and
+// Scharr derivatives, the keypoints the next frame tracks, scratch of the corner detector
+struct BoxMOTHipSof {
+    int S = 0, rows = 0, cols = 0, max_dets = 0;
+    bm::SofLevels lv{};
+    bm::SofParams prm{};
+    bm::SofBuffers buf{};
+    hipStream_t stream = nullptr;
+    std::vector<void*> owned;
+    float* d_dets = nullptr; int* d_ndets = nullptr;        // host-API staging: [S][max_dets][4], [S]
+    const uint8_t** d_frames = nullptr;
+    std::vector<uint8_t*> frame_bufs;
+    bool owns_stream = true;
+    ~BoxMOTHipSof() {
+        for (void* p : owned) (void)hipFree(p);
+        for (auto p : frame_bufs) if (p) (void)hipFree(p);
+        if (stream && owns_stream) (void)hipStreamDestroy(stream);
+    }
+};
+
 // Frame ingest ring: n_slots x n_streams page-locked host frames, their device twins, a copy stream and
 // one "uploaded" + one "consumed" event per slot.  The caller decodes frame t + 1 straight into slot (t + 1) % n_slots while the
 // kernels of frame t run; submit() queues the slot's H2D DMA on the copy stream, wait() makes the consuming stream wait for it,
@@ -217,6 +238,8 @@ struct BoxMOTHipBotSort {
     int reid_mode = 0, reid_pad = 0;
     bool use_ecc = false;                        // cmc_method = "ecc": the estimator runs inside update on the uploaded frame
     std::unique_ptr<BoxMOTHipEcc> ecc;
+    bool use_sof = false;                        // cmc_method = "sof" (configs/trackers/botsort.yaml): likewise, masked by the frame's detections
+    std::unique_ptr<BoxMOTHipSof> sof;
     int* d_crop_count = nullptr;
     int* d_crop_stream = nullptr;
     float* d_crop_boxes = nullptr;
@@ -405,8 +428,9 @@ void zero_state(BoxMOTHipBotSort* h) {
 void build(BoxMOTHipBotSort* h) {
     const BoxMOTHipBotSortConfig& c = h->cfg;
     h->use_ecc = c.cmc_method && std::strcmp(c.cmc_method, "ecc") == 0;
-    if (c.cmc_method && c.cmc_method[0] && std::strcmp(c.cmc_method, "none") != 0 && !h->use_ecc)
-        throw std::runtime_error(std::string("boxmot_hip: camera-motion estimator '") + c.cmc_method + "' is not implemented (have: ecc, none); "
+    h->use_sof = c.cmc_method && std::strcmp(c.cmc_method, "sof") == 0;
+    if (c.cmc_method && c.cmc_method[0] && std::strcmp(c.cmc_method, "none") != 0 && !h->use_ecc && !h->use_sof)
+        throw std::runtime_error(std::string("boxmot_hip: camera-motion estimator '") + c.cmc_method + "' is not implemented (have: sof, ecc, none); "
                                  "supply the warp per frame with boxmot_hip_botsort_set_warp");
     h->reid_pad = 0;
     if (c.reid_preprocess && c.reid_preprocess[0]) {
@@ -573,6 +597,83 @@ void ecc_run_one(BoxMOTHipEcc* h, int s, const uint8_t* const* d_frame_ptr, doub
     if (out_iterations) *out_iterations = info[1];
 }
 
+// ---- SOF estimator plumbing (C ABI boxmot_hip_sof_*; also owned by a BoT-SORT handle created with cmc_method = "sof") ----
+struct HipLaunch {            // sof_frame's launcher: the kernel sequence of cmc_sof.hpp on the handle's stream
+    hipStream_t stream;
+    template <class K, class... A>
+    void operator()(K kernel, int gx, int gy, int threads, A... args) {
+        hipLaunchKernelGGL(kernel, dim3((unsigned)gx, (unsigned)gy), dim3((unsigned)threads), 0, stream, args...);
+    }
+};
+
+void sof_alloc_dets(BoxMOTHipSof* h, int max_dets) {
+    release(h->owned, h->d_dets);
+    h->max_dets = max_dets;
+    h->d_dets = zalloc<float>((size_t)h->S * max_dets * 4, h->owned);
+}
+
+void sof_init(BoxMOTHipSof* h, int n_streams, int image_rows, int image_cols, double scale, int min_inliers, double min_inlier_ratio,
+              double thresh, hipStream_t external) {
+    if (n_streams < 1) throw std::runtime_error("boxmot_hip: SOF needs >= 1 stream");
+    if (!(scale > 0.0) || scale > 1.0 || min_inliers < 0 || !(thresh > 0.0)) throw std::runtime_error("boxmot_hip: SOF scale must be in (0, 1], ransac threshold > 0");
+    h->S = n_streams; h->rows = image_rows; h->cols = image_cols;
+    const int w = (int)std::nearbyint(image_cols * scale), hh = (int)std::nearbyint(image_rows * scale);     // saturate_cast<int>(ssize * fx)
+    // the 21-pixel window borders are reflected: every pyramid level (level 0 included) must be larger than the window
+    if (w <= bm::SOF_WIN + 1 || hh <= bm::SOF_WIN + 1) throw std::runtime_error("boxmot_hip: SOF image too small after scaling (needs > 22 x 22)");
+    h->lv = bm::sof_levels(hh, w);
+    h->prm = bm::SofParams{scale, min_inliers, min_inlier_ratio, thresh};
+    if (external) { h->stream = external; h->owns_stream = false; }
+    else BM_HIP(hipStreamCreate(&h->stream));
+    const size_t T = (size_t)h->lv.total, P = (size_t)hh * w, S = n_streams, K = bm::SOF_MAX_CORNERS;
+    auto& o = h->owned;
+    bm::SofBuffers& b = h->buf;
+    b.pyr_prev = zalloc<uint8_t>(S * T, o); b.pyr_cur = zalloc<uint8_t>(S * T, o);
+    b.der_prev = zalloc<short>(S * T * 2, o); b.der_cur = zalloc<short>(S * T * 2, o);
+    b.eig = zalloc<float>(S * P, o); b.mask = zalloc<uint8_t>(S * P, o); b.cand = zalloc<int>(S * P, o);
+    b.prev_kps = zalloc<float>(S * K * 2, o); b.new_kps = zalloc<float>(S * K * 2, o);
+    b.next_pts = zalloc<float>(S * K * 2, o); b.valid_to = zalloc<float>(S * K * 2, o);
+    b.status = zalloc<uint8_t>(S * K, o);
+    b.st = zalloc<bm::SofState>(S, o);
+    b.warp = zalloc<double>(S * 6, o);
+    h->d_ndets = zalloc<int>(S, o);
+    h->d_frames = zalloc<const uint8_t*>(S, o);
+    h->frame_bufs.assign(S, nullptr);
+    sof_alloc_dets(h, 64);
+}
+
+// streams [s0, s0 + n): d_frame_ptrs = device table of n frame pointers; dets already on the device (d_dets [n][max_dets][stride],
+// d_ndets [n], may be null); waits, copies the n warps (and the n state words, 8 ints each) out
+void sof_run(BoxMOTHipSof* h, int s0, int n, const uint8_t* const* d_frame_ptrs, const float* d_dets, const int* d_ndets, int max_dets,
+             int det_stride, double* out_warps, int* out_info8) {
+    HipLaunch launch{h->stream};
+    bm::sof_frame(launch, h->buf, h->lv, s0, n, d_frame_ptrs, h->rows, h->cols, d_dets, d_ndets, max_dets, det_stride, h->prm);
+    BM_HIP(hipGetLastError());
+    std::vector<bm::SofState> st((size_t)n);
+    BM_HIP(hipMemcpyAsync(out_warps, h->buf.warp + (size_t)s0 * 6, (size_t)n * 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (out_info8) BM_HIP(hipMemcpyAsync(st.data(), h->buf.st + s0, (size_t)n * sizeof(bm::SofState), hipMemcpyDeviceToHost, h->stream));
+    BM_HIP(hipStreamSynchronize(h->stream));
+    if (out_info8)
+        for (int k = 0; k < n; ++k) {
+            const bm::SofState& t = st[(size_t)k];
+            const int v[8] = {t.mode, t.n_prev, t.n_valid, t.n_inliers, t.ransac_iters, t.estimated, t.n_kps, t.initialized};
+            for (int i = 0; i < 8; ++i) out_info8[k * 8 + i] = v[i];
+        }
+}
+
+// host detections of one stream -> the handle's staging rows (first four columns: tlbr in frame pixels)
+void sof_stage_dets(BoxMOTHipSof* h, int stream, const float* dets, int n_dets, int det_stride) {
+    if (n_dets < 0 || (n_dets > 0 && (!dets || det_stride < 4))) throw std::runtime_error("boxmot_hip: SOF detections need >= 4 columns (tlbr)");
+    if (n_dets > h->max_dets) {
+        BM_HIP(hipStreamSynchronize(h->stream));
+        sof_alloc_dets(h, grown(h->max_dets, n_dets));
+    }
+    std::vector<float> rows((size_t)(n_dets > 0 ? n_dets : 1) * 4, 0.f);
+    for (int k = 0; k < n_dets; ++k) for (int c = 0; c < 4; ++c) rows[(size_t)k * 4 + c] = dets[(size_t)k * det_stride + c];
+    if (n_dets > 0) BM_HIP(hipMemcpyAsync(h->d_dets + (size_t)stream * h->max_dets * 4, rows.data(), (size_t)n_dets * 16, hipMemcpyHostToDevice, h->stream));
+    BM_HIP(hipMemcpyAsync(h->d_ndets + stream, &n_dets, 4, hipMemcpyHostToDevice, h->stream));
+    BM_HIP(hipStreamSynchronize(h->stream));            // rows / n_dets are stack and local storage
+}
+
 struct StreamIn {
     const float* dets; int det_rows;
     const float* embs;
@@ -634,8 +735,30 @@ void host_update(BoxMOTHipBotSort* h, int s0, int n, const StreamIn* in, int det
     BM_HIP(hipMemcpyAsync(h->d_ndets + s0, h->h_ndets.data() + s0, n * 4, hipMemcpyHostToDevice, h->stream));
     BM_HIP(hipMemcpyAsync(h->d_list_sel + s0, h->h_list_sel.data() + s0, n * 4, hipMemcpyHostToDevice, h->stream));
     if (fc_set) BM_HIP(hipMemcpyAsync(h->d_fc_set + s0, h->h_fc_set.data() + s0, n * 4, hipMemcpyHostToDevice, h->stream));
-    const bool ecc_here = h->use_ecc && !fc_set;
-    if (ecc_here) {
+    const bool sof_here = h->use_sof && !fc_set;
+    if (sof_here) {
+        // cmc_method = "sof" (botsort.py:116-117, :141-145): SOF.apply(img, dets) with the frame's whole detection table as the mask
+        for (int k = 0; k < n; ++k) {
+            if (in[k].det_rows < 0) continue;
+            if (!in[k].image && !d_frames_ext) throw std::runtime_error("boxmot_hip: cmc_method=sof needs the frame (image pointer is null)");
+            if (image_channels != 3) throw std::runtime_error("boxmot_hip: cmc_method=sof needs a 3-channel uint8 BGR image");
+            if (!d_frames_ext) upload_frame(h, s0 + k, in[k].image, image_rows, image_cols, image_channels);
+        }
+        if (!h->sof) {
+            h->sof.reset(new BoxMOTHipSof());
+            sof_init(h->sof.get(), h->S, image_rows, image_cols, 0.15, 8, 0.2, 3.0, h->stream);
+        }
+        if (h->sof->rows != image_rows || h->sof->cols != image_cols) throw std::runtime_error("boxmot_hip: frame size changed between updates");
+        for (int k = 0; k < n; ++k) {
+            if (in[k].det_rows < 0) continue;
+            const uint8_t* const* fp = (d_frames_ext ? d_frames_ext : h->d_frames) + (s0 + k);
+            sof_run(h->sof.get(), s0 + k, 1, fp, d_dets + (size_t)k * nd * bm::DET_COLS, h->d_ndets + s0 + k, nd, bm::DET_COLS,
+                    h->h_warp.data() + (size_t)(s0 + k) * 6, nullptr);
+            h->h_warp_flag[s0 + k] = 1;
+        }
+    }
+    const bool ecc_here = (h->use_ecc && !fc_set) || sof_here;       // below: "the frame is already uploaded"
+    if (h->use_ecc && !fc_set) {
         // cmc_method = "ecc" (botsort.py:116-117, :141-145): the estimator sees every frame of the stream; its warp is applied to
         // the predicted pool by this update.  (Per-class fan-out calls rewind the frame counter, fc_set: the same frame is updated
         // once per class there -- the estimate is made once by the caller and supplied with set_warp.)
@@ -1647,6 +1770,94 @@ int boxmot_hip_ecc_apply_device(BoxMOTHipEcc* handle, int stream, const uint8_t*
     });
 }
 
+// ---- SOF camera-motion estimation ----
+BoxMOTHipSof* boxmot_hip_sof_create(int n_streams, int image_rows, int image_cols, double scale, int min_inliers, double min_inlier_ratio,
+                                    double ransac_reproj_threshold) {
+    BoxMOTHipSof* h = nullptr;
+    const int ok = guard([&]() {
+        require_device();
+        h = new BoxMOTHipSof();
+        sof_init(h, n_streams, image_rows, image_cols, scale, min_inliers, min_inlier_ratio, ransac_reproj_threshold, nullptr);
+    });
+    if (!ok) { delete h; return nullptr; }
+    return h;
+}
+
+void boxmot_hip_sof_destroy(BoxMOTHipSof* handle) { delete handle; }
+
+int boxmot_hip_sof_reset(BoxMOTHipSof* handle, int stream) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip: null SOF handle");
+        if (stream >= handle->S) throw std::runtime_error("boxmot_hip: stream index out of range");
+        BM_HIP(hipStreamSynchronize(handle->stream));
+        if (stream < 0) BM_HIP(hipMemset(handle->buf.st, 0, (size_t)handle->S * sizeof(bm::SofState)));
+        else BM_HIP(hipMemset(handle->buf.st + stream, 0, sizeof(bm::SofState)));
+    });
+}
+
+int boxmot_hip_sof_apply(BoxMOTHipSof* handle, int stream, const uint8_t* image, int image_rows, int image_cols, int image_channels,
+                         const float* dets, int n_dets, int det_stride, double* out_warp_2x3, int* out_info8) {
+    return guard([&]() {
+        if (!handle || !out_warp_2x3) throw std::runtime_error("boxmot_hip: null argument");
+        if (stream < 0 || stream >= handle->S) throw std::runtime_error("boxmot_hip: stream index out of range");
+        if (!image) throw std::runtime_error("Image data pointer is null.");
+        if (image_channels != 3 || image_rows != handle->rows || image_cols != handle->cols)
+            throw std::runtime_error("boxmot_hip: SOF was created for a different frame size (3-channel BGR uint8)");
+        const size_t bytes = (size_t)image_rows * image_cols * 3;
+        if (!handle->frame_bufs[stream]) {
+            void* p = nullptr;
+            BM_HIP(hipMalloc(&p, bytes));
+            handle->frame_bufs[stream] = static_cast<uint8_t*>(p);
+            BM_HIP(hipMemcpy(handle->d_frames, handle->frame_bufs.data(), handle->S * sizeof(uint8_t*), hipMemcpyHostToDevice));
+        }
+        BM_HIP(hipMemcpyAsync(handle->frame_bufs[stream], image, bytes, hipMemcpyHostToDevice, handle->stream));
+        sof_stage_dets(handle, stream, dets, n_dets, det_stride);
+        sof_run(handle, stream, 1, handle->d_frames + stream, handle->d_dets + (size_t)stream * handle->max_dets * 4, handle->d_ndets + stream,
+                handle->max_dets, 4, out_warp_2x3, out_info8);
+    });
+}
+
+int boxmot_hip_sof_apply_device(BoxMOTHipSof* handle, const uint8_t* const* d_frames, const float* d_dets, const int* d_ndets, int max_dets,
+                                int det_stride, double* out_warps, int* out_info8) {
+    return guard([&]() {
+        if (!handle || !out_warps || !d_frames) throw std::runtime_error("boxmot_hip: null argument");
+        if (d_dets && (!d_ndets || max_dets < 1 || det_stride < 4)) throw std::runtime_error("boxmot_hip: SOF device detections need d_ndets, max_dets >= 1 and >= 4 columns");
+        sof_run(handle, 0, handle->S, d_frames, d_dets, d_dets ? d_ndets : nullptr, max_dets, det_stride, out_warps, out_info8);
+    });
+}
+
+int boxmot_hip_sof_keypoints(BoxMOTHipSof* handle, int stream, float* out_xy, int capacity, int* out_n) {
+    return guard([&]() {
+        if (!handle || !out_n) throw std::runtime_error("boxmot_hip: null argument");
+        if (stream < 0 || stream >= handle->S) throw std::runtime_error("boxmot_hip: stream index out of range");
+        bm::SofState st{};
+        BM_HIP(hipStreamSynchronize(handle->stream));
+        BM_HIP(hipMemcpy(&st, handle->buf.st + stream, sizeof(st), hipMemcpyDeviceToHost));
+        *out_n = st.n_prev;
+        const int n = st.n_prev < capacity ? st.n_prev : capacity;
+        if (n > 0 && out_xy) BM_HIP(hipMemcpy(out_xy, handle->buf.prev_kps + (size_t)stream * bm::SOF_MAX_CORNERS * 2, (size_t)n * 8, hipMemcpyDeviceToHost));
+    });
+}
+
+// test access to the detector's intermediate images of the last frame: which = 0 minimum-eigenvalue map (fp32 [h][w]), 1 detection mask
+// (uint8 [h][w]), 2 the scaled grayscale frame (uint8 [h][w])
+int boxmot_hip_sof_debug_map(BoxMOTHipSof* handle, int stream, int which, void* out, int capacity_bytes, int* out_h, int* out_w) {
+    return guard([&]() {
+        if (!handle || !out) throw std::runtime_error("boxmot_hip: null argument");
+        if (stream < 0 || stream >= handle->S) throw std::runtime_error("boxmot_hip: stream index out of range");
+        const size_t P = (size_t)handle->lv.h[0] * handle->lv.w[0];
+        const size_t bytes = which == 0 ? P * 4 : P;
+        if ((size_t)capacity_bytes < bytes) throw std::runtime_error("boxmot_hip: output buffer is too small");
+        BM_HIP(hipStreamSynchronize(handle->stream));
+        const void* src = which == 0 ? (const void*)(handle->buf.eig + stream * P)
+                        : which == 1 ? (const void*)(handle->buf.mask + stream * P)
+                                     : (const void*)(handle->buf.pyr_prev + (size_t)stream * handle->lv.total);
+        BM_HIP(hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
+        if (out_h) *out_h = handle->lv.h[0];
+        if (out_w) *out_w = handle->lv.w[0];
+    });
+}
+
 // ---- frame ingest ring ----
 BoxMOTHipIngest* boxmot_hip_ingest_create(int n_slots, int n_streams, int image_rows, int image_cols) {
     BoxMOTHipIngest* h = nullptr;
@@ -2210,8 +2421,8 @@ BoxMOTBotSortHandle* boxmot_botsort_create(const BoxMOTBotSortConfig* c) {
         k.frame_rate = c->frame_rate; k.fuse_first_associate = c->fuse_first_associate; k.with_reid = c->with_reid ? 1 : 0;
         k.max_obs = c->max_obs;
         if (c->cmc_method) h->cmc = c->cmc_method;
-        if (!h->cmc.empty() && h->cmc != "none" && h->cmc != "ecc")     // checked here: the inner handle may only be built at the first update
-            throw std::runtime_error("boxmot_hip: camera-motion estimator '" + h->cmc + "' is not implemented (have: ecc, none); "
+        if (!h->cmc.empty() && h->cmc != "none" && h->cmc != "ecc" && h->cmc != "sof")     // checked here: the inner handle may only be built at the first update
+            throw std::runtime_error("boxmot_hip: camera-motion estimator '" + h->cmc + "' is not implemented (have: sof, ecc, none); "
                                      "supply the warp per frame with boxmot_hip_botsort_set_warp");
         if (c->reid_model_path) h->reid_path = c->reid_model_path;
         if (c->reid_preprocess) h->reid_pre = c->reid_preprocess;

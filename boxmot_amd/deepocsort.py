@@ -7,9 +7,9 @@ basetracker.py:19-31) and ``update(dets, img, embs=None)`` returns the reference
 observation-centric re-update, IoU / velocity-direction / adaptive-weighted appearance costs, assignment,
 recovery round, bookkeeping -- runs in one HIP kernel through the C ABI (include/boxmot_hip.h).
 
-Camera motion: applying a warp to the tracks runs on the device (``apply_affine_correction``); estimating it from
-images (the reference's sparse-optical-flow object) is not implemented, so ``cmc_off=False`` needs a ``cmc=`` object
-exposing the reference's ``apply(img, boxes) -> 2x3 warp``.  ``per_class=True`` keeps one track list per class on the
+Camera motion: applying a warp to the tracks runs on the device (``apply_affine_correction``), and so does estimating it:
+the sparse-optical-flow estimator the reference constructs (deepocsort.py:297) is ``boxmot_amd.cmc.HipSOF`` (``cmc_off=False``,
+the default); ``cmc="ecc"`` or any object exposing ``apply(img, boxes) -> 2x3 warp`` replaces it.  ``per_class=True`` keeps one track list per class on the
 device (one stream per class) with the shared id counter and rewound frame counter of the reference's fan-out.
 Rejected loudly: OBB detections, ``max_age > 45``.
 """
@@ -48,15 +48,12 @@ class DeepOcSort(BaseTracker):
         **kwargs: Any,
     ):
         super().__init__(_tracker_name="DeepOcSort", **kwargs)
-        if isinstance(cmc, str):            # cmc="ecc": the device ECC estimator (boxmot_amd.cmc); the reference's built-in one is "sof"
+        if isinstance(cmc, str):            # cmc="ecc": the device ECC estimator instead of the built-in one
             from boxmot_amd.cmc import get_cmc_method
             cmc = get_cmc_method(cmc)()
-        if not cmc_off and cmc is None:
-            raise NotImplementedError(
-                "boxmot_amd.DeepOcSort: camera-motion estimation is not implemented on the HIP path; construct with "
-                "cmc_off=True, cmc='ecc' (ECC on the device), or pass cmc=<object with apply(img, boxes) -> 2x3 warp> (the reference default is "
-                "cmc_off=False with the 'sof' estimator)."
-            )
+        if not cmc_off and cmc is None:     # deepocsort.py:297: self.cmc = get_cmc_method("sof")()
+            from boxmot_amd.cmc import HipSOF
+            cmc = HipSOF()
         self.delta_t, self.inertia = delta_t, inertia
         self.w_association_emb, self.alpha_fixed_emb, self.aw_param = w_association_emb, alpha_fixed_emb, aw_param
         self.Q_xy_scaling, self.Q_s_scaling = Q_xy_scaling, Q_s_scaling

@@ -58,11 +58,10 @@ def flatten_yaml_config(cfg: dict) -> dict:
 def create_tracker(tracker_type: str = "botsort", tracker_config=None, reid_weights=None, device=None, half=None,
                    per_class: bool = False, evolve_param_dict: dict | None = None, reid_preprocess=None,
                    reid_model=None, tracker_backend: str = "hip", **overrides):
-    """``overrides`` are constructor arguments laid over the YAML defaults.  Camera-motion compensation: the ECC estimator
-    runs on the device (boxmot_amd.cmc.HipECC): StrongSORT gets it by default like the reference (``cmc=None`` opts out), and
-    BoT-SORT with ``cmc_method="ecc"``.  The sparse-optical-flow estimator ("sof": BoT-SORT's YAML default and DeepOCSORT's
-    built-in one) is not built: those defaults need ``cmc=<object with apply(img, dets) -> 2x3 warp>`` (e.g. ``HipECC()``),
-    ``cmc_method="ecc"`` or ``use_cmc=False`` / ``cmc_off=True`` among the overrides and raise NotImplementedError otherwise."""
+    """``overrides`` are constructor arguments laid over the YAML defaults.  Camera-motion compensation runs on the device with the
+    estimator the reference's defaults name: BoT-SORT ``cmc_method="sof"`` (botsort.yaml; ``"ecc"`` selects boxmot_amd.cmc.HipECC),
+    DeepOCSORT the built-in sparse-optical-flow estimator (boxmot_amd.cmc.HipSOF; ``cmc_off=True`` opts out), StrongSORT ECC
+    (``cmc=None`` opts out).  ``cmc=<object with apply(img, dets) -> 2x3 warp>`` overrides any of them."""
     if tracker_backend != "hip":
         raise ValueError(f"tracker_backend={tracker_backend!r}: boxmot_amd provides the 'hip' backend only")
     if tracker_type not in SUPPORTED:

@@ -13,12 +13,14 @@
  *
  * Behaviour that differs from the reference library, all loud:
  *   - `reid_model_path` / `model_path` name an OSN1 weight blob (boxmot_amd.reid_weights.save_blob), not an ONNX file;
- *   - `cmc_method`: "ecc" runs the reference's ECC estimator on the device inside update; NULL, "" or "none" estimate nothing (a
- *     caller that has a warp supplies it per frame through boxmot_hip_botsort_set_warp, boxmot_hip.h); "sof" and the other
- *     OpenCV estimators are not built: create fails loudly;
- *   - capacities are fixed at create: BOXMOT_HIP_MAX_TRACKS (default 1024) live + lost tracks, BOXMOT_HIP_MAX_DETS
- *     (default 512) detections per frame, BOXMOT_HIP_REID_MAX_CROPS (default 1024) boxes per ReID call; exceeding one
- *     fails the call with a message, it never truncates silently;
+ *   - `cmc_method`: "sof" (the YAML default) and "ecc" run that estimator of the reference on the device inside update; NULL, "" or
+ *     "none" estimate nothing (a caller that has a warp supplies it per frame through boxmot_hip_botsort_set_warp, boxmot_hip.h);
+ *     "orb" / "sift" are not built: create fails loudly.  Both estimators restate OpenCV algorithms (cv2 is absent offline):
+ *     their numerics are pinned against this repository's restatements only;
+ *   - the device tables start at BOXMOT_HIP_MAX_TRACKS (default 1024) live + lost tracks and BOXMOT_HIP_MAX_DETS (default 512)
+ *     detections per frame and grow when a frame does not fit (boxmot_hip_botsort_reserve, boxmot_hip.h);
+ *     BOXMOT_HIP_REID_MAX_CROPS (default 1024) boxes per standalone ReID call is a limit: exceeding it fails the call with a
+ *     message, it never truncates silently;
  *   - the track-id counter is per handle (the reference's is process-global, botsort/src/track.cpp:13);
  *   - there is no CPU fallback: without a HIP device `create` returns NULL / 0 with an error message.
  */

@@ -18,10 +18,11 @@
  *     tracker.cpp:435,465,476; the Python reference exposes them, botsort.py:81-85);
  *   - one handle owns n_streams independent trackers advanced by one launch set
  *     (boxmot_hip_botsort_update_batch / _step_device);
- *   - camera-motion compensation: cmc_method = "ecc" runs the reference's ECC estimator on the device inside update (it needs the
- *     frame on every call); NULL / "" / "none" estimate nothing -- a 2x3 warp supplied with boxmot_hip_*_set_warp (what the
- *     reference's cmc.apply() returns, e.g. from boxmot_hip_ecc_apply or a host-side estimator) is applied on the device;
- *     "sof" and the other OpenCV estimators are not built (create fails);
+ *   - camera-motion compensation: cmc_method = "sof" (configs/trackers/botsort.yaml) or "ecc" (the constructor default) runs that
+ *     estimator of the reference on the device inside update (it needs the frame on every call); NULL / "" / "none" estimate
+ *     nothing -- a 2x3 warp supplied with boxmot_hip_*_set_warp (what the reference's cmc.apply() returns, e.g. from
+ *     boxmot_hip_sof_apply / boxmot_hip_ecc_apply or a host-side estimator) is applied on the device; the feature-matching
+ *     estimators ("orb", "sift") are not built (create fails);
  *   - the reference's own symbol names and struct layouts are exported next to these (boxmot_compat.h).
  * There is no CPU fallback: every entry point fails with an error when no HIP
  * device is usable.
@@ -44,7 +45,7 @@ typedef struct BoxMOTHipBotSortConfig {
     double match_thresh;
     double proximity_thresh;
     double appearance_thresh;
-    const char* cmc_method;          /* NULL / "" / "none", or "ecc" (estimated on the device inside update) */
+    const char* cmc_method;          /* NULL / "" / "none", or "sof" / "ecc" (estimated on the device inside update) */
     int frame_rate;
     int fuse_first_associate;
     int with_reid;
@@ -118,7 +119,7 @@ int boxmot_hip_botsort_update_stream(
  * BotSort._apply_aabb_camera_motion_compensation, botsort.py:134-145).  `warp_2x3` = the row-major 2x3 matrix
  * the reference's cmc.apply(img, dets) returns ([r00 r01 tx; r10 r11 ty]); it is applied to the predicted pool and
  * to the unconfirmed tracks in the NEXT update / update_stream / update_batch of `stream` and then dropped.
- * NULL clears a pending warp.  The ECC estimator is boxmot_hip_ecc_* below; the sparse-optical-flow one (SOF) is not built. */
+ * NULL clears a pending warp.  The estimators are boxmot_hip_ecc_* and boxmot_hip_sof_* below. */
 int boxmot_hip_botsort_set_warp(BoxMOTHipBotSort* handle, int stream, const double* warp_2x3);
 
 /* One frame for each of the first n_streams streams in one launch set.  det_rows[s] == -1 leaves stream s untouched
@@ -233,6 +234,34 @@ int boxmot_hip_ecc_reset(BoxMOTHipEcc* handle, int stream);
 int boxmot_hip_ecc_apply(BoxMOTHipEcc* handle, int stream, const uint8_t* image, int image_rows, int image_cols, int image_channels,
                          double* out_warp_2x3, int* out_iterations);
 int boxmot_hip_ecc_apply_device(BoxMOTHipEcc* handle, int stream, const uint8_t* d_frame, double* out_warp_2x3, int* out_iterations);
+
+/* ------------------------------------------------------------------------------------------------
+ * Camera-motion estimation: the sparse-optical-flow estimator (boxmot/motion/cmc/sof.py:14-147) -- the cmc_method of
+ * configs/trackers/botsort.yaml and the estimator DeepOCSORT constructs (deepocsort.py:297).  Arguments = SOF.__init__'s (scale 0.15,
+ * min_inliers 8, min_inlier_ratio 0.2, ransac_reproj_threshold 3.0); the OpenCV arguments sof.py fixes (1000 corners at quality 0.01,
+ * 21 x 21 window, 3 pyramid levels, 30 iterations / 0.01) are fixed here too.  apply = SOF.apply(img, dets): dets = (n, >= 4) fp32 rows whose
+ * first four columns are tlbr boxes in frame pixels (masked out of the corner detector, base_cmc.py:63-105), NULL / 0 for none; the
+ * first call of a stream detects keypoints and returns the identity; later calls track them, fit the partial-affine 2 x 3 warp
+ * (row-major doubles, translation in full-resolution pixels) and refresh the keypoints; too few tracked points or a weak fit return
+ * the identity (sof.py:95-115).  out_info8 (optional) = mode (0 initialising, 1 tracked, 2 re-detected), keypoints kept for the next
+ * frame, tracked points, RANSAC inliers, RANSAC iterations, estimate accepted, corners detected, initialized.  Feed the warp to
+ * boxmot_hip_*_set_warp.  apply_device runs ALL streams of the handle on frames that already are in HBM (d_frames: device table of
+ * n_streams pointers; d_dets [n_streams][max_dets][det_stride] and d_ndets [n_streams] on the device, or NULL) and returns
+ * n_streams warps (and 8 ints each).  keypoints copies out the points the next frame will track.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct BoxMOTHipSof BoxMOTHipSof;
+BoxMOTHipSof* boxmot_hip_sof_create(int n_streams, int image_rows, int image_cols, double scale, int min_inliers, double min_inlier_ratio,
+                                    double ransac_reproj_threshold);
+void boxmot_hip_sof_destroy(BoxMOTHipSof* handle);
+int boxmot_hip_sof_reset(BoxMOTHipSof* handle, int stream);
+int boxmot_hip_sof_apply(BoxMOTHipSof* handle, int stream, const uint8_t* image, int image_rows, int image_cols, int image_channels,
+                         const float* dets, int n_dets, int det_stride, double* out_warp_2x3, int* out_info8);
+int boxmot_hip_sof_apply_device(BoxMOTHipSof* handle, const uint8_t* const* d_frames, const float* d_dets, const int* d_ndets, int max_dets,
+                                int det_stride, double* out_warps, int* out_info8);
+int boxmot_hip_sof_keypoints(BoxMOTHipSof* handle, int stream, float* out_xy, int capacity, int* out_n);
+/* test access to the corner detector's images of the last frame: which = 0 minimum-eigenvalue map (fp32 [h][w]), 1 detection mask
+ * (uint8 [h][w]), 2 the scaled grayscale frame (uint8 [h][w]) */
+int boxmot_hip_sof_debug_map(BoxMOTHipSof* handle, int stream, int which, void* out, int capacity_bytes, int* out_h, int* out_w);
 
 /* ------------------------------------------------------------------------------------------------
  * Frame ingest ring (no counterpart in the reference: its trackers receive a numpy frame per call, basetracker.py:120-147, and

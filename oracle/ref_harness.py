@@ -82,6 +82,57 @@ def install_standins():
         sys.path.insert(0, str(REFERENCE_ROOT))
 
 
+def load_sof():
+    """Return the reference ``SOF`` class (boxmot/motion/cmc/sof.py) with ``cv2``'s numerics answered by oracle/sof.py's
+    restatements (``cvtColor(BGR2GRAY)``, ``resize(fx, fy)``, ``goodFeaturesToTrack``, ``cornerSubPix``, ``calcOpticalFlowPyrLK``,
+    ``estimateAffinePartial2D``): what runs is the REFERENCE's control flow -- initialisation, re-detection, the inlier test,
+    the mask, the scaling of the translation -- which is what ``SofOracle`` is pinned against (tests/test_sof.py)."""
+    install_standins()
+    from oracle import crops, ecc, sof
+    cv2 = sys.modules["cv2"]
+    cv2.RANSAC = 8
+    base_cvt, base_resize = cv2.cvtColor, cv2.resize
+
+    def cvtColor(src, code):
+        return ecc.bgr2gray_u8(src) if code == cv2.COLOR_BGR2GRAY else base_cvt(src, code)
+
+    def resize(src, dsize, fx=0.0, fy=0.0, interpolation=1, **kw):
+        if tuple(dsize) == (0, 0):
+            assert interpolation == cv2.INTER_LINEAR and src.ndim == 2
+            h, w = src.shape
+            return crops.cv2_resize_linear_u8(src, (int(np.rint(w * fx)), int(np.rint(h * fy))), (1.0 / fx, 1.0 / fy))
+        return base_resize(src, dsize, interpolation=interpolation, **kw)
+
+    def goodFeaturesToTrack(img, mask=None, maxCorners=1000, qualityLevel=0.01, minDistance=1, blockSize=3, useHarrisDetector=False, k=0.04):
+        assert (maxCorners, qualityLevel, minDistance, blockSize, useHarrisDetector) == (1000, 0.01, 1, 3, False)
+        pts = sof.good_features(img, mask)
+        return None if pts is None else pts.reshape(-1, 1, 2)
+
+    def cornerSubPix(img, corners, winSize, zeroZone, criteria):
+        assert tuple(winSize) == (5, 5) and tuple(zeroZone) == (-1, -1) and tuple(criteria[1:]) == (30, 0.01)
+        corners[:] = sof.corner_subpix(img, corners.reshape(-1, 2)).reshape(corners.shape)      # in place, like OpenCV
+        return corners
+
+    def calcOpticalFlowPyrLK(prev, nxt, pts, _next, winSize=(21, 21), maxLevel=3, criteria=None):
+        assert tuple(winSize) == (21, 21) and maxLevel == 3 and tuple(criteria[1:]) == (30, 0.01)
+        p = np.asarray(pts, np.float32).reshape(-1, 2)
+        out, status = sof.lk_track(sof.build_pyramid(prev, maxLevel), sof.build_pyramid(nxt, maxLevel), p)
+        return out.reshape(-1, 1, 2), status.reshape(-1, 1), np.zeros((len(p), 1), np.float32)
+
+    def estimateAffinePartial2D(frm, to, method=None, ransacReprojThreshold=3.0):
+        assert method == cv2.RANSAC
+        H, inl = sof.estimate_affine_partial_2d(np.asarray(frm, np.float32).reshape(-1, 2), np.asarray(to, np.float32).reshape(-1, 2),
+                                                ransacReprojThreshold)
+        return H, inl.reshape(-1, 1)
+
+    cv2.cvtColor, cv2.resize = cvtColor, resize
+    cv2.goodFeaturesToTrack, cv2.cornerSubPix = goodFeaturesToTrack, cornerSubPix
+    cv2.calcOpticalFlowPyrLK, cv2.estimateAffinePartial2D = calcOpticalFlowPyrLK, estimateAffinePartial2D
+    from boxmot.motion.cmc.sof import SOF
+
+    return SOF
+
+
 def load_botsort():
     """Return the reference BotSort class (imported from /root/reference)."""
     install_standins()

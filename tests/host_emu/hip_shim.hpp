@@ -89,6 +89,13 @@ inline unsigned long long __ballot(int pred) {
     return m;
 }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline unsigned atomicMax(unsigned* p, unsigned v) {
+    unsigned old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (old < v && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return old;
+}
+inline unsigned __float_as_uint(float f) { unsigned u; std::memcpy(&u, &f, 4); return u; }
+inline float __uint_as_float(unsigned u) { float f; std::memcpy(&f, &u, 4); return f; }
 inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline int atomicMax(int* p, int v) {
     int old = __atomic_load_n(p, __ATOMIC_RELAXED);

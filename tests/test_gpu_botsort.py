@@ -133,9 +133,13 @@ def test_edge_inputs_like_the_reference_tests():
     assert trk.update(det, img, emb).id.tolist() == [1, 2]              # reset restarts the id counter
     trk.close()
     from boxmot_amd.botsort import BotSort
-    from boxmot_amd.cmc import HipECC
+    from boxmot_amd.cmc import HipECC, HipSOF
     with pytest.raises(NotImplementedError, match="camera-motion"):
-        BotSort(cmc_method="sof")                                       # the YAML default's estimator is not built: loud
+        BotSort(cmc_method="orb")                                       # an estimator that is not built: loud
+    yaml_dflt = BotSort(cmc_method="sof", with_reid=False)              # configs/trackers/botsort.yaml: sparse optical flow, on the device
+    assert isinstance(yaml_dflt.cmc, HipSOF)
+    assert yaml_dflt.update(det, img).id.tolist() == [1, 2]
+    yaml_dflt.close()
     dflt = BotSort(with_reid=False)                                     # constructor defaults: use_cmc=True, cmc_method="ecc" -> device ECC
     assert isinstance(dflt.cmc, HipECC)
     assert dflt.update(det, img).id.tolist() == [1, 2]

@@ -164,29 +164,32 @@ def test_reference_botsort_binding_drives_the_hip_library(lib):
                                      ctypes.byref(r), ctypes.byref(o)) == 0
     assert lib.boxmot_botsort_last_error()
     lib.boxmot_botsort_destroy(h)
-    # the sparse-optical-flow estimator is not part of the library: create fails loudly, as the header says
-    cfg.cmc_method = b"sof"
+    # an estimator the library does not have: create fails loudly, as the header says
+    cfg.cmc_method = b"orb"
     assert not lib.boxmot_botsort_create(ctypes.byref(cfg))
     assert b"camera-motion" in lib.boxmot_botsort_last_error()
 
 
-def test_reference_botsort_binding_with_cmc_method_ecc(lib):
-    """cmc_method = "ecc" in the reference's config struct: the library estimates the warp itself on every frame (ECC on the device,
-    include/boxmot_hip.h) and applies it -- rows equal the oracle tracker fed with the oracle estimator's warps on a panning camera."""
+@pytest.mark.parametrize("method", ["ecc", "sof"])
+def test_reference_botsort_binding_with_cmc_method_ecc(lib, method):
+    """cmc_method = "ecc" / "sof" (the YAML default) in the reference's config struct: the library estimates the warp itself on every
+    frame (on the device, include/boxmot_hip.h; SOF masked by the frame's detections, botsort.py:142) and applies it -- rows equal the
+    oracle tracker fed with the oracle estimator's warps on a panning camera."""
     from boxmot_amd.scenario import Scenario
     from oracle.botsort import BotSortOracle
     from oracle.ecc import EccOracle
+    from oracle.sof import SofOracle
     from scipy.ndimage import gaussian_filter
     kw = dict(track_high_thresh=0.5, track_low_thresh=0.1, new_track_thresh=0.6, track_buffer=30, match_thresh=0.8,
               proximity_thresh=0.5, appearance_thresh=0.25, frame_rate=30, fuse_first_associate=0, with_reid=1)
     cfg = _BotSortCConfig(kw["track_high_thresh"], kw["track_low_thresh"], kw["new_track_thresh"], kw["track_buffer"],
-                          kw["match_thresh"], kw["proximity_thresh"], kw["appearance_thresh"], b"ecc", kw["frame_rate"],
+                          kw["match_thresh"], kw["proximity_thresh"], kw["appearance_thresh"], method.encode(), kw["frame_rate"],
                           kw["fuse_first_associate"], kw["with_reid"], 50, None, None)
     h = lib.boxmot_botsort_create(ctypes.byref(cfg))
     assert h, lib.boxmot_botsort_last_error()
     okw = {k: (_f32(v) if isinstance(v, float) else v) for k, v in kw.items()}
     okw["fuse_first_associate"], okw["with_reid"] = False, True
-    orc, ecc = BotSortOracle(**okw), EccOracle()
+    orc, ecc = BotSortOracle(**okw), (EccOracle() if method == "ecc" else SofOracle())
     rng = np.random.default_rng(2)
     base = gaussian_filter(rng.integers(0, 255, (700, 1200, 3)).astype(np.float32), (6, 6, 0))
     base = ((base - base.min()) / (base.max() - base.min()) * 255).astype(np.uint8)
@@ -198,7 +201,7 @@ def test_reference_botsort_binding_with_cmc_method_ecc(lib):
         frame = np.ascontiguousarray(base[oy:oy + 540, ox:ox + 960])
         ok, got, _ = _call_update(lib.boxmot_botsort_update, h, dets, embs, frame)
         assert ok == 1, lib.boxmot_botsort_last_error()
-        want = orc.update(dets.copy(), frame, embs.copy(), warp=ecc.apply(frame, None).astype(np.float64))
+        want = orc.update(dets.copy(), frame, embs.copy(), warp=ecc.apply(frame, None if method == "ecc" else dets).astype(np.float64))
         assert got.shape == want.shape and np.array_equal(got[:, 4:], want[:, 4:]), t
         assert np.allclose(got[:, :4], want[:, :4], atol=2e-2), t
     lib.boxmot_botsort_destroy(h)

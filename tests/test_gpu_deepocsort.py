@@ -120,8 +120,10 @@ def test_deepocsort_surface_and_edge_inputs():
     from boxmot_amd import create_tracker
     from boxmot_amd.deepocsort import DeepOcSort
     from boxmot_amd.track_results import TrackResults
-    with pytest.raises(NotImplementedError):
-        DeepOcSort()                                   # reference default cmc_off=False
+    from boxmot_amd.cmc import HipSOF
+    dflt = DeepOcSort(embedding_off=True, max_tracks=64, max_dets=32)      # reference default cmc_off=False: the built-in SOF estimator
+    assert isinstance(dflt.cmc, HipSOF)
+    dflt.close()
     trk = create_tracker("deepocsort", cmc_off=True, embedding_off=True, max_tracks=64, max_dets=32)
     img = np.zeros((240, 320, 3), dtype=np.uint8)
     out = trk.update(np.empty((0, 6), dtype=np.float32), img)

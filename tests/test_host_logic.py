@@ -122,10 +122,10 @@ def test_scenario_is_deterministic_and_keeps_the_pool_full():
 
 def test_cmc_provider_surface_without_a_device():
     """boxmot_amd.cmc: the factory names what exists, argument checks are host-side, and nothing estimates on the CPU."""
-    from boxmot_amd.cmc import HipECC, get_cmc_method
-    assert get_cmc_method("ecc") is HipECC
-    with pytest.raises(NotImplementedError, match="sof"):
-        get_cmc_method("sof")
+    from boxmot_amd.cmc import HipECC, HipSOF, get_cmc_method
+    assert get_cmc_method("ecc") is HipECC and get_cmc_method("sof") is HipSOF
+    with pytest.raises(NotImplementedError, match="orb"):
+        get_cmc_method("orb")
     with pytest.raises(NotImplementedError):
         HipECC(warp_mode=1)                          # MOTION_EUCLIDEAN: only the reference's default translation model is built
     with pytest.raises(NotImplementedError):
