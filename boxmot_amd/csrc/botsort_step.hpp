@@ -23,6 +23,22 @@
 #include "botsort_types.hpp"
 #include "kernel_macros.hpp"
 
+// phase functions of the frame step: inlined by default.  -DBM_STEP_NOINLINE=1 compiles the three large ones that are instantiated
+// several times (cost build, IoU cost, assignment) as calls -- one copy of each, bounded live ranges; =2 the small per-track ones too
+#ifndef BM_STEP_NOINLINE
+#define BM_STEP_NOINLINE 0
+#endif
+#if BM_STEP_NOINLINE >= 1
+#define BM_STEP_BIG_FN __device__ __noinline__
+#else
+#define BM_STEP_BIG_FN __device__ inline
+#endif
+#if BM_STEP_NOINLINE >= 2
+#define BM_STEP_FN __device__ __noinline__
+#else
+#define BM_STEP_FN __device__ inline
+#endif
+
 namespace bm {
 
 constexpr double LAP_INF = 1.0e300;
@@ -117,7 +133,7 @@ constexpr double MIN_SIZE = 1e-4;
 // "zero (vw, vh) unless Tracked" rule of STrack.multi_predict (botsort_track.py:104-109).
 // `xyah`: KalmanFilterXYAH noise model (xyah.py:70-89: every std from the height, constants for the aspect ratio)
 // and ByteTrack's rule "zero vh unless Tracked" (bytetrack.py:63-74).
-__device__ inline void kf_predict_wave(double* kf, bool zero_size_vel, int lane, bool xyah = false) {
+BM_STEP_FN void kf_predict_wave(double* kf, bool zero_size_vel, int lane, bool xyah = false) {
     const int i = lane >> 3, j = lane & 7;
     double mj = kf[j];                       // mean[j]
     if (zero_size_vel && (xyah ? j == 7 : j >= 6)) mj = 0.0;
@@ -150,7 +166,7 @@ __device__ inline void kf_predict_wave(double* kf, bool zero_size_vel, int lane,
 // products; numpy evaluates the matrix-vector product as mul, mul, add and the two 8x8 matrix products as
 // fma(b_hi, a_hi, b_lo * a_lo) (k ascending, OpenBLAS dgemm micro-kernel) -- reproduced here so the fp64 state
 // follows the NumPy reference to the last bit on such hosts (the tests accept 1e-9 relative).
-__device__ inline void kf_warp_wave(double* kf, const double* W, int lane) {
+BM_STEP_FN void kf_warp_wave(double* kf, const double* W, int lane) {
     const int i = lane >> 3, j = lane & 7;
     const double m = kf[j];
     const double p = kf[KF_DIM + lane];
@@ -172,7 +188,7 @@ __device__ inline void kf_warp_wave(double* kf, const double* W, int lane) {
 // KalmanFilterXYWH.update for one track with measurement z (fp32 xywh);
 // base.py:286-355 (confidence = 0: BoT-SORT never passes it, botsort_track.py:269-271).
 // `xyah`: z is (x, y, aspect, height) and the measurement noise follows xyah.py:57-68.
-__device__ inline void kf_update_wave(double* kf, const float* z, int lane, bool xyah = false) {
+BM_STEP_FN void kf_update_wave(double* kf, const float* z, int lane, bool xyah = false) {
     const int i = lane >> 3, j = lane & 7;
     double m[8];
     for (int k = 0; k < 8; ++k) m[k] = kf[k];
@@ -238,7 +254,7 @@ __device__ inline void kf_update_wave(double* kf, const float* z, int lane, bool
 
 // KalmanFilterXYWH.initiate (xywh.py:136-142, base.py:234-244, std xywh.py:22-36)
 // `xyah`: xyah.py:22-37, 99-105.
-__device__ inline void kf_initiate_wave(double* kf, const float* z, int lane, bool xyah = false) {
+BM_STEP_FN void kf_initiate_wave(double* kf, const float* z, int lane, bool xyah = false) {
     const int i = lane >> 3, j = lane & 7;
     const double w = (double)z[2], h = (double)z[3];
     double c = 0.0;
@@ -287,7 +303,7 @@ constexpr int MAX_VEC_PER_LANE = 32;    // appearance vectors up to 64 * 32 = 20
 // STrack.update_features (botsort_track.py:58-67) for a live track: the matched
 // detection's vector is normalised once more, blended, renormalised.  One read of
 // each vector, one write; everything else in registers.
-__device__ inline void blend_feature_wave(float* smooth, const float* feat, int dim, int lane) {
+BM_STEP_FN void blend_feature_wave(float* smooth, const float* feat, int dim, int lane) {
     float f[MAX_VEC_PER_LANE], sm[MAX_VEC_PER_LANE];
     float s = 0.0f;
 #pragma unroll
@@ -315,7 +331,7 @@ __device__ inline void blend_feature_wave(float* smooth, const float* feat, int 
 
 // STrack constructor's update_features on a fresh detection (botsort_track.py:58-66):
 // feat /= |feat|; smooth = feat; smooth /= |smooth|  -> the vector is normalised twice.
-__device__ inline void normalize_twice_wave(const float* src, float* dst, int dim, int lane) {
+BM_STEP_FN void normalize_twice_wave(const float* src, float* dst, int dim, int lane) {
     float x[MAX_VEC_PER_LANE];
     float s = 0.0f;
 #pragma unroll
@@ -338,7 +354,7 @@ __device__ inline void normalize_twice_wave(const float* src, float* dst, int di
 
 // STrack.update / re_activate (botsort_track.py:244-282) for a list of
 // (slot, det) pairs, one wavefront per pair.
-__device__ inline void apply_matches(const Ctx& c, SV& v, int n_match, int frame, bool with_feat) {
+BM_STEP_FN void apply_matches(const Ctx& c, SV& v, int n_match, int frame, bool with_feat) {
     for (int base = 0; base < n_match; base += c.nwaves) {
         const int k = base + c.wave;
         if (k < n_match) {
@@ -431,7 +447,7 @@ __device__ inline double cosine_gate(double dot, double nu, double nv, double em
 __device__ inline double np_minimum(double a, double b) { return (a != a || b != b) ? (a != a ? a : b) : (a < b ? a : b); }
 
 template <int NTHR>
-__device__ inline void assoc_cost(const Ctx& c, SV& v, const int* rows, int n_rows, const int* cols,
+BM_STEP_BIG_FN void assoc_cost(const Ctx& c, SV& v, const int* rows, int n_rows, const int* cols,
                                   int n_cols, bool use_emb, double emb_scale, bool fuse,
                                   float (*sA)[COST_KC + 1], float (*sB)[COST_KC + 1], int* s_count) {
     if (n_rows == 0 || n_cols == 0) return;
@@ -555,7 +571,7 @@ __device__ inline void assoc_cost(const Ctx& c, SV& v, const int* rows, int n_ro
 }
 
 // IoU-only cost (second association, botsort.py:356), detection-major.
-__device__ inline void iou_cost(const Ctx& c, SV& v, const int* rows, int n_rows, const int* cols, int n_cols) {
+BM_STEP_BIG_FN void iou_cost(const Ctx& c, SV& v, const int* rows, int n_rows, const int* cols, int n_cols) {
     if (n_rows == 0 || n_cols == 0) return;
     track_boxes(c, v, rows, n_rows, v.box_a);
     const long ld = v.cap;
@@ -595,7 +611,7 @@ __device__ inline LapLds carve_lap(unsigned char* base, int cap, int nd) {
 }
 __host__ __device__ inline long lap_lds_bytes(int cap, int nd) { return (long)cap * (8 + 8 + 4 + 4 + 4) + (long)nd * (8 + 4) + 16; }
 
-__device__ inline void lap_solve(const Ctx& c, SV& v, const LapLds& L, int R, int C, double limit) {
+BM_STEP_BIG_FN void lap_solve(const Ctx& c, SV& v, const LapLds& L, int R, int C, double limit) {
     const long ld = v.cap;
     for (int t = c.tid; t < R; t += c.nthr) { L.x[t] = -1; L.v[t] = 0.0; }
     for (int d = c.tid; d < C; d += c.nthr) { L.y[d] = -1; L.u[d] = 0.0; }
