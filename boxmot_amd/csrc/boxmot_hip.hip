@@ -239,6 +239,8 @@ struct BoxMOTHipBotSort {
     bool use_ecc = false;                        // cmc_method = "ecc": the estimator runs inside update on the uploaded frame
     std::unique_ptr<BoxMOTHipEcc> ecc;
     bool use_sof = false;                        // cmc_method = "sof" (configs/trackers/botsort.yaml): likewise, masked by the frame's detections
+    bool cmc_with_fc_set = false;                // one update with a frame-counter preset that is NOT a per-class fan-out call (compat adapter's first
+                                                 // real frame after empty ones): the estimator sees the frame as it does in the reference
     std::unique_ptr<BoxMOTHipSof> sof;
     int* d_crop_count = nullptr;
     int* d_crop_stream = nullptr;
@@ -735,7 +737,8 @@ void host_update(BoxMOTHipBotSort* h, int s0, int n, const StreamIn* in, int det
     BM_HIP(hipMemcpyAsync(h->d_ndets + s0, h->h_ndets.data() + s0, n * 4, hipMemcpyHostToDevice, h->stream));
     BM_HIP(hipMemcpyAsync(h->d_list_sel + s0, h->h_list_sel.data() + s0, n * 4, hipMemcpyHostToDevice, h->stream));
     if (fc_set) BM_HIP(hipMemcpyAsync(h->d_fc_set + s0, h->h_fc_set.data() + s0, n * 4, hipMemcpyHostToDevice, h->stream));
-    const bool sof_here = h->use_sof && !fc_set;
+    const bool fanout = fc_set && !h->cmc_with_fc_set;          // per-class fan-out: the caller estimated once and supplied the warp
+    const bool sof_here = h->use_sof && !fanout;
     if (sof_here) {
         // cmc_method = "sof" (botsort.py:116-117, :141-145): SOF.apply(img, dets) with the frame's whole detection table as the mask
         for (int k = 0; k < n; ++k) {
@@ -757,8 +760,8 @@ void host_update(BoxMOTHipBotSort* h, int s0, int n, const StreamIn* in, int det
             h->h_warp_flag[s0 + k] = 1;
         }
     }
-    const bool ecc_here = (h->use_ecc && !fc_set) || sof_here;       // below: "the frame is already uploaded"
-    if (h->use_ecc && !fc_set) {
+    const bool ecc_here = (h->use_ecc && !fanout) || sof_here;       // below: "the frame is already uploaded"
+    if (h->use_ecc && !fanout) {
         // cmc_method = "ecc" (botsort.py:116-117, :141-145): the estimator sees every frame of the stream; its warp is applied to
         // the predicted pool by this update.  (Per-class fan-out calls rewind the frame counter, fc_set: the same frame is updated
         // once per class there -- the estimate is made once by the caller and supplied with set_warp.)
@@ -2463,9 +2466,14 @@ int boxmot_botsort_update(BoxMOTBotSortHandle* h, const float* dets, int det_row
         if (h->empty_frames > 0) {      // the frames that went by count (a first detection on frame > 1 is not activated at once)
             const int fc = h->empty_frames;
             h->empty_frames = 0;
-            return boxmot_hip_botsort_update_stream(h->inner, 0, 0, fc, dets, det_rows, det_cols, embs, emb_rows, emb_cols, image,
-                                                    image_rows, image_cols, image_channels, out_tracks, out_capacity_rows, out_cols,
-                                                    out_rows, out_is_obb);
+            // the reference's estimator saw the empty frames (botsort.py:141-145 runs cmc.apply on every frame); there were no tracks to
+            // warp, so all that matters is that it sees THIS frame as its newest: run it although the frame counter is preset
+            h->inner->cmc_with_fc_set = true;
+            const int rc = boxmot_hip_botsort_update_stream(h->inner, 0, 0, fc, dets, det_rows, det_cols, embs, emb_rows, emb_cols, image,
+                                                            image_rows, image_cols, image_channels, out_tracks, out_capacity_rows, out_cols,
+                                                            out_rows, out_is_obb);
+            h->inner->cmc_with_fc_set = false;
+            return rc;
         }
     }
     return boxmot_hip_botsort_update(h ? h->inner : nullptr, dets, det_rows, det_cols, embs, emb_rows, emb_cols, image,

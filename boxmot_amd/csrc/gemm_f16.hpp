@@ -463,14 +463,14 @@ __global__ void __launch_bounds__(512) k_gemm_f16_256(const _Float16* __restrict
             }
     };
     auto quadrant = [&](const ch8 (&fa)[2][4], int p0, const ch8 (&fb)[2][2], int t0) {
-        __builtin_amdgcn_s_setprio(1);
+        BM_SETPRIO(1);
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int p = 0; p < 4; ++p)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) acc[p0 + p][t0 + t] = BM_MFMA_F16_K32(fa[s][p], fb[s][t], acc[p0 + p][t0 + t]);
-        __builtin_amdgcn_s_setprio(0);
+        BM_SETPRIO(0);
     };
     for (int T = 0; T < nk; ++T) {
         const _Float16* sA = slot(T & 1, wr);
@@ -524,7 +524,7 @@ __global__ void __launch_bounds__(512) k_gemm_f16_256(const _Float16* __restrict
                 for (int r = 0; r < 4; ++r) v[r] += bv[r];
                 if constexpr (EPI == 1) {    // QuickGELU; the quotient as a reciprocal (1 ulp of fp32, the result is rounded to fp16): the IEEE
 #pragma unroll                           // division sequence was a quarter of this kernel's epilogue
-                    for (int r = 0; r < 4; ++r) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + BM_EXPF(-1.702f * v[r]));
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] * BM_RCPF(1.0f + BM_EXPF(-1.702f * v[r]));
                 }
                 if constexpr (EPI == 4) {
                     if (res) {              // (no prefetch here: the accumulators and fragments fill the register file)

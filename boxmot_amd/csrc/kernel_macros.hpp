@@ -52,6 +52,12 @@
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), \
                                      (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0)
 #endif
+#ifndef BM_WAIT_VM0
+// wait for this wave's outstanding vector-memory operations, BM_GLDS16 copies included: the compiler does not order a
+// global -> LDS copy against a later workgroup barrier, so the wave that issued copies waits here before the barrier that
+// publishes them (s_waitcnt vmcnt(0); vmcnt retires in order)
+#define BM_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
 #ifndef BM_RELU_F32
 // max(v, 0) as one integer max on the bit pattern (negative floats are negative ints); a float max costs a second,
 // canonicalising v_max under IEEE mode
@@ -83,6 +89,14 @@ __device__ inline unsigned bm_mulhi24(unsigned a, unsigned b) {
 #ifndef BM_SLEEP_8K
 // park the wavefront for ~8128 shader cycles (s_sleep 127)
 #define BM_SLEEP_8K() __builtin_amdgcn_s_sleep(127)
+#endif
+
+// wave priority around an MFMA burst (s_setprio) and the hardware reciprocal (v_rcp_f32, 1 ulp)
+#ifndef BM_SETPRIO
+#define BM_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+#endif
+#ifndef BM_RCPF
+#define BM_RCPF(x) __builtin_amdgcn_rcpf(x)
 #endif
 
 // fp32 matrix pipe: D = A.B + C on 16x16x4 tiles (v_mfma_f32_16x16x4_f32; A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15],

@@ -29,6 +29,22 @@
 #ifndef BM_HP_STAGGER
 #define BM_HP_STAGGER 0
 #endif
+// epilogue: tiles per group (the A fragments of an output-channel tile are read from LDS once per GROUP and held in registers
+// while the group's tiles run through them: 1 / TG of the fragment reads, TG independent MFMA chains)
+#ifndef BM_HP_EPI_TG0E
+#define BM_HP_EPI_TG0E 4            // stage 0, first block (EMIT)
+#endif
+#ifndef BM_HP_EPI_TG0R
+#define BM_HP_EPI_TG0R 2            // stage 0, second block (RECON + fused transition): 4 would spill
+#endif
+#ifndef BM_HP_EPI_TG1
+#define BM_HP_EPI_TG1 4             // stage 1: the wave's whole strip
+#endif
+// weights into LDS by asynchronous global -> LDS copies (no register round trip, no latency per loop trip) issued ahead of the
+// phase that needs them; 0 = load / store loops at the point of use (A/B switch)
+#ifndef BM_HP_ASYNC_STAGE
+#define BM_HP_ASYNC_STAGE 0
+#endif
 // streaming accesses (hand-over tensors and block outputs written once, operands read once) marked non-temporal so that the
 // tensor a kernel re-reads per branch (128 KiB per crop, one L2 share) is not evicted by them
 #ifndef BM_HP_NT
@@ -170,6 +186,31 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
     float* x2w = nullptr;
     if constexpr (EMIT || RECON) x2w = link.x2s + crop * (P * MIDP) + (long)(wave * NT * KT * 64 + lane) * 4;
 
+    // workgroup copy global -> LDS of `bytes` (a multiple of 16; src and dst 16-byte aligned).  Asynchronous form: one
+    // global_load_lds per KiB and wave, no registers, completion at the next __syncthreads(); `gather` maps a destination offset
+    // to its source offset (identity for contiguous records).
+    auto stage_copy = [&](const unsigned char* src, unsigned char* dst, int bytes, auto gather) {
+        if constexpr (BM_HP_ASYNC_STAGE) {
+            for (int c = wave * 1024; c < bytes; c += G::NWAVES * 1024)
+                if (c + lane * 16 < bytes) BM_GLDS16(src + gather(c + lane * 16), dst + c, lane);
+        } else {
+            for (int e = tid * 16; e < bytes; e += 64 * G::NWAVES * 16)
+                *reinterpret_cast<f4*>(dst + e) = *reinterpret_cast<const f4*>(src + gather(e));
+        }
+    };
+    auto same = [](int e) { return (long)e; };
+    // LightConv weights (stage 0: depthwise taps + biases only) and the gate's weights -> `wl`
+    auto stage_light = [&]() {
+        if constexpr (G::W_ALL) {           // light records and gate weights are contiguous in the packed blob
+            stage_copy(wts + bp.light0, wl, G::WBYTES, same);
+        } else {
+            const long lb = bp.light_bytes, ld = bp.light_dw;
+            stage_copy(wts + bp.light0, wl, 10 * G::WREC, [&](int e) { const int l = e / G::WREC; return l * lb + ld + (e - l * G::WREC); });
+            stage_copy(wts + bp.fc1_w, wl + 10 * G::WREC, G::GATE_BYTES, same);
+        }
+    };
+    if constexpr (BM_HP_ASYNC_STAGE) stage_light();          // in flight under conv1 / the image clear
+
     // ---- conv1: 1x1 CIN -> MID, + bias, ReLU (osnet.py:248) ----
     auto conv1_into = [&](f4 (&x1)[NT][KT]) {
         unsigned xo = 0;
@@ -196,8 +237,7 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
         } else {
             // fragment pairs [ks][ct] staged into LDS (the image area is not in use yet); the B operands of tile i + 1 are
             // requested before tile i computes
-            for (int e = tid * 16; e < KIN * KT * (int)HP_FRAG_PAIR; e += 64 * G::NWAVES * 16)
-                *reinterpret_cast<f4*>(tbuf + e) = *reinterpret_cast<const f4*>(wts + bp.conv1_a + e);
+            stage_copy(wts + bp.conv1_a, tbuf, KIN * KT * (int)HP_FRAG_PAIR, same);
             h8 bh[2][KIN], bl[2][KIN];
             auto loads = [&](int i, h8 (&h)[KIN], h8 (&l)[KIN]) {
                 const unsigned p = (wave * NT + i) * 16 + l16;
@@ -208,6 +248,7 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
                 }
             };
             loads(0, bh[0], bl[0]);
+            if constexpr (BM_HP_ASYNC_STAGE) BM_WAIT_VM0();         // the fragment copies (and the LightConv weights issued before them)
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
@@ -261,17 +302,7 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
     };
 
     for (int e = tid * 16; e < G::IMG; e += 64 * G::NWAVES * 16) *reinterpret_cast<f4*>(tbuf + e) = f4{0.f, 0.f, 0.f, 0.f};   // halo = zero padding
-    if constexpr (G::W_ALL) {           // light records and gate weights are contiguous in the packed blob
-        for (int e = tid * 16; e < G::WBYTES; e += 64 * G::NWAVES * 16)
-            *reinterpret_cast<f4*>(wl + e) = *reinterpret_cast<const f4*>(wts + bp.light0 + e);
-    } else {
-        for (int e = tid * 16; e < 10 * G::WREC; e += 64 * G::NWAVES * 16) {
-            const int l = e / G::WREC, o = e - l * G::WREC;
-            *reinterpret_cast<f4*>(wl + e) = *reinterpret_cast<const f4*>(wts + bp.light0 + (long)l * bp.light_bytes + bp.light_dw + o);
-        }
-        for (int e = tid * 16; e < G::GATE_BYTES; e += 64 * G::NWAVES * 16)
-            *reinterpret_cast<f4*>(wl + 10 * G::WREC + e) = *reinterpret_cast<const f4*>(wts + bp.fc1_w + e);
-    }
+    if constexpr (!BM_HP_ASYNC_STAGE) stage_light();
     const unsigned char* wgate = wl + 10 * G::WREC;                 // gate weights: fc1_w at +0, then fc1_b, fc2_w, fc2_b as in the blob
     const int g_fc1b = (int)(bp.fc1_b - bp.fc1_w), g_fc2w = (int)(bp.fc2_w - bp.fc1_w), g_fc2b = (int)(bp.fc2_b - bp.fc1_w);
     f4 x2[NT][KT];          // gated sum of the four branches
@@ -279,8 +310,32 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int ct = 0; ct < KT; ++ct) x2[i][ct] = f4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (BM_HP_ASYNC_STAGE) BM_WAIT_VM0();                 // this wave's share of the staged weights has landed
     __syncthreads();
     BM_PROF(0);
+
+    // The A fragments of the epilogue are staged ONCE per workgroup into LDS (the image is dead after the last layer): eight waves
+    // re-reading 20-60 KB of fragments per tile through the vector L1 (64 B/clk) was a large share of the block time; LDS
+    // delivers them at 256 B/clk (lane-linear 1 KiB reads, conflict-free).
+    //   [0, E_OWN)  this block's conv3 pairs, bias, downsample pairs (contiguous in the packed blob)
+    //   then: EMIT the next block's conv1 pairs | RECON the previous block's conv3 pairs .. downsample pairs | TRANS pairs + bias
+    // Stages 0 / 1: the operands fit the image area alone, so the (asynchronous) copies are issued as soon as the last depthwise
+    // pass has read the image -- BEFORE the last branch's gate, whose weights live behind the image -- and land under the gate.
+    constexpr int KS3 = COUT / 32, KSN = COUT / 32;
+    constexpr int E_OWN_C = NCT * (int)HP_FRAG_PAIR + COUT * 4 + (DOWN ? NCT * KIN * (int)HP_FRAG_PAIR : 0);
+    constexpr int E_PREV_C = RECON ? NCT * (int)HP_FRAG_PAIR + COUT * 4 + NCT * KINP * (int)HP_FRAG_PAIR : 0;
+    constexpr int E_LINK = EMIT ? KSN * KT * (int)HP_FRAG_PAIR : 0;
+    constexpr int E_TR = TRANS ? NCT * KS3 * (int)HP_FRAG_PAIR + COUT * 4 : 0;
+    static_assert(E_OWN_C + E_LINK + E_PREV_C + E_TR <= G::TBUF, "epilogue operands fit the (dead) image and weight area");
+    constexpr bool EPI_EARLY = BM_HP_ASYNC_STAGE && STAGE < 2 && E_OWN_C + E_LINK + E_PREV_C + E_TR <= G::IMG;
+    const int e_own = (int)(bp.total - bp.conv3_a);         // (host side: prepare_hp checks e_own + the other regions <= TBUF)
+    const int e_prev = RECON ? (int)(link.a2 - link.a0) + NCT * KINP * (int)HP_FRAG_PAIR : 0;
+    auto stage_epilogue = [&]() {
+        stage_copy(wts + bp.conv3_a, tbuf, e_own, same);
+        if constexpr (EMIT) stage_copy(link.w + link.a0, tbuf + e_own, E_LINK, same);
+        if constexpr (RECON) stage_copy(link.w + link.a0, tbuf + e_own, e_prev, same);
+        if constexpr (TRANS) stage_copy(wtr, tbuf + e_own + e_prev, E_TR, same);
+    };
 
     int li = 0;
 #pragma unroll 1
@@ -387,6 +442,7 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
             __syncthreads();
             BM_PROF(5);
         }
+        if constexpr (EPI_EARLY) { if (br == 3) stage_epilogue(); }        // every wave is past the last read of the image (barrier above)
         // ChannelGate (osnet.py:194-209): crop-wide average -> fc1 -> ReLU -> fc2 -> sigmoid -> scale
         float* part = gap_part + br * (G::NWAVES * G::HID);
         {
@@ -442,30 +498,7 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
     }
 
     // ---- conv3 (1x1 MID -> COUT, linear) + downsample(x) or identity, ReLU (osnet.py:254-260) ----
-    // The A fragments of the epilogue are staged ONCE per workgroup into LDS (the image is dead after the last layer): eight waves
-    // re-reading 20-60 KB of fragments per tile through the vector L1 (64 B/clk) was a large share of the block time; LDS
-    // delivers them at 256 B/clk (lane-linear 1 KiB reads, conflict-free).
-    //   [0, E_OWN)  this block's conv3 pairs, bias, downsample pairs (contiguous in the packed blob)
-    //   then: EMIT the next block's conv1 pairs | RECON the previous block's conv3 pairs .. downsample pairs | TRANS pairs + bias
-    constexpr int KS3 = COUT / 32, KSN = COUT / 32;
-    constexpr int E_OWN_C = NCT * (int)HP_FRAG_PAIR + COUT * 4 + (DOWN ? NCT * KIN * (int)HP_FRAG_PAIR : 0);
-    constexpr int E_PREV_C = RECON ? NCT * (int)HP_FRAG_PAIR + COUT * 4 + NCT * KINP * (int)HP_FRAG_PAIR : 0;
-    static_assert(E_OWN_C + (EMIT ? KSN * KT * (int)HP_FRAG_PAIR : 0) + E_PREV_C + (TRANS ? NCT * KS3 * (int)HP_FRAG_PAIR + COUT * 4 : 0) <= G::TBUF,
-                  "epilogue operands fit the (dead) image area");
-    const int e_own = (int)(bp.total - bp.conv3_a);         // (host side: prepare_hp checks e_own + the other regions <= TBUF)
-    constexpr int E_LINK = EMIT ? KSN * KT * (int)HP_FRAG_PAIR : 0;
-    const int e_prev = RECON ? (int)(link.a2 - link.a0) + NCT * KINP * (int)HP_FRAG_PAIR : 0;
-    constexpr int E_TR = TRANS ? NCT * KS3 * (int)HP_FRAG_PAIR + COUT * 4 : 0;
-    {
-        auto stage_in = [&](const unsigned char* src, int bytes, int off) {
-            for (int e = tid * 16; e < bytes; e += 64 * G::NWAVES * 16)
-                *reinterpret_cast<f4*>(tbuf + off + e) = *reinterpret_cast<const f4*>(src + e);
-        };
-        stage_in(wts + bp.conv3_a, e_own, 0);
-        if constexpr (EMIT) stage_in(link.w + link.a0, E_LINK, e_own);
-        if constexpr (RECON) stage_in(link.w + link.a0, e_prev, e_own);
-        if constexpr (TRANS) stage_in(wtr, E_TR, e_own + e_prev);
-    }
+    if constexpr (!EPI_EARLY) stage_epilogue();
     const unsigned char* w3 = tbuf;
     const unsigned char* b3 = tbuf + (bp.conv3_b - bp.conv3_a);
     const unsigned char* wdn = tbuf + (bp.down_a - bp.conv3_a);
@@ -519,158 +552,186 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
             }
         }
     };
-    auto block_tile = [&](int i, const TileOps& t, f4 (&y)[NCT]) {
-        h4 xh4[KT], xl4[KT];
-#pragma unroll
-        for (int ct = 0; ct < KT; ++ct) split4(x2[i][ct], xh4[ct], xl4[ct]);
-        h8 b2h, b2l;
-        if constexpr (KT == 1) { b2h = cat8(xh4[0], xl4[0]); b2l = b2h; }
-        else { b2h = cat8(xh4[0], xh4[KT - 1]); b2l = cat8(xl4[0], xl4[KT - 1]); }
-        h8 rb2h, rb2l;
-        if constexpr (RECON) {
-            h4 ph4[KT], pl4[KT];
-#pragma unroll
-            for (int ct = 0; ct < KT; ++ct) split4(t.x2p[ct], ph4[ct], pl4[ct]);
-            if constexpr (KT == 1) { rb2h = cat8(ph4[0], pl4[0]); rb2l = rb2h; }
-            else { rb2h = cat8(ph4[0], ph4[KT - 1]); rb2l = cat8(pl4[0], pl4[KT - 1]); }
-        }
-#pragma unroll
-        for (int co = 0; co < NCT; ++co) {
-            f4 acc = *reinterpret_cast<const f4*>(b3 + (16 * co + 4 * g) * 4);
-            if constexpr (KT == 1) acc = mm2(w3 + (long)co * HP_FRAG_PAIR, lane, b2h, acc);
-            else acc = mm3(w3 + (long)co * HP_FRAG_PAIR, lane, b2h, b2l, acc);
-            if constexpr (DOWN) {
-                if constexpr (CIN == 16) acc = mm2(wdn + (long)co * HP_FRAG_PAIR, lane, t.dxh[0], acc);
-                else {
-#pragma unroll
-                    for (int ks = 0; ks < KIN; ++ks) acc = mm3(wdn + (long)(co * KIN + ks) * HP_FRAG_PAIR, lane, t.dxh[ks], t.dxl[ks], acc);
-                }
-            } else if constexpr (RECON) {
-                // block input = ReLU(conv3_prev . x2_prev + down_prev . x_prev + bias), rebuilt in fp32 and added as it is
-                f4 ap = *reinterpret_cast<const f4*>(pvb + (16 * co + 4 * g) * 4);
-                if constexpr (KT == 1) ap = mm2(pv3 + (long)co * HP_FRAG_PAIR, lane, rb2h, ap);
-                else ap = mm3(pv3 + (long)co * HP_FRAG_PAIR, lane, rb2h, rb2l, ap);
-                if constexpr (PREV_CIN == 16) ap = mm2(pvd + (long)co * HP_FRAG_PAIR, lane, t.rxh[0], ap);
-                else {
-#pragma unroll
-                    for (int ks = 0; ks < KINP; ++ks) ap = mm3(pvd + (long)(co * KINP + ks) * HP_FRAG_PAIR, lane, t.rxh[ks], t.rxl[ks], ap);
-                }
-                acc += relu4(ap);
-            } else {
-                acc = BM_MFMA_F16_K32(eye, cat8(t.idh[co], t.idl[co]), acc);
-            }
-            y[co] = relu4(acc);
-        }
-    };
-    // Operand prefetch depth: the tensors these come from were written by an earlier launch (HBM), and one CU draws ~10 B/clk: a
-    // tile's operands are requested PF tiles ahead (ring of PF + 1 sets, static indices under full unrolling).
-    constexpr int PF = NT >= 8 ? 3 : (NT >= 4 ? 2 : 0), NR = PF + 1;
-    TileOps ops[NR];
+    // The epilogue visits the tiles in GROUPS of TG: the A fragments of an output-channel tile (conv3, downsample / the previous
+    // block's conv3 + downsample, then the transition / the next block's conv1) are read from LDS once per group and held in
+    // registers while the group's TG tiles run through them -- 1 / TG of the fragment reads of a tile-by-tile epilogue and TG
+    // independent accumulator chains on the matrix pipe.  Every (tile, output tile) accumulates in the same order as before.
+    constexpr int TG = STAGE == 0 ? (RECON ? BM_HP_EPI_TG0R : BM_HP_EPI_TG0E) : (STAGE == 1 ? BM_HP_EPI_TG1 : 1);
+    static_assert(NT % TG == 0 && (!TRANS || TG % 2 == 0), "groups tile the wave's strip; a fused transition pools tile pairs");
     // order in which the epilogue visits the tiles (TRANS: vertically adjacent pairs)
     auto seq_tile = [](int k) constexpr {
         if (!TRANS) return k;
         const int pr = k >> 1, i0 = STAGE == 0 ? (pr >> 1) * 4 + (pr & 1) : 2 * pr;
         return i0 + (k & 1) * (STAGE == 0 ? 2 : 1);
     };
+    // Operand prefetch: the tensors these come from were written by an earlier launch (HBM), and one CU draws ~10 B/clk: a
+    // group's operands are requested one group ahead (ring of 2 TG sets, static indices under full unrolling).
+    constexpr int NR = NT > TG ? 2 * TG : TG;
+    TileOps ops[NR];
+    // conv3 + shortcut of the TG tiles at sequence positions k0 .. k0 + TG - 1 -> block output as (hi, lo) halves
+    auto block_group = [&](int k0, h4 (&yh)[TG][NCT], h4 (&yl)[TG][NCT]) {
+        h8 b2h[TG], b2l[KT == 1 ? 1 : TG], rb2h[RECON ? TG : 1], rb2l[(RECON && KT > 1) ? TG : 1];
+#pragma unroll
+        for (int t = 0; t < TG; ++t) {
+            const int i = seq_tile(k0 + t);
+            h4 xh4[KT], xl4[KT];
+#pragma unroll
+            for (int ct = 0; ct < KT; ++ct) split4(x2[i][ct], xh4[ct], xl4[ct]);
+            if constexpr (KT == 1) b2h[t] = cat8(xh4[0], xl4[0]);
+            else { b2h[t] = cat8(xh4[0], xh4[KT - 1]); b2l[t] = cat8(xl4[0], xl4[KT - 1]); }
+            if constexpr (RECON) {
+                h4 ph4[KT], pl4[KT];
+#pragma unroll
+                for (int ct = 0; ct < KT; ++ct) split4(ops[(k0 + t) % NR].x2p[ct], ph4[ct], pl4[ct]);
+                if constexpr (KT == 1) rb2h[t] = cat8(ph4[0], pl4[0]);
+                else { rb2h[t] = cat8(ph4[0], ph4[KT - 1]); rb2l[t] = cat8(pl4[0], pl4[KT - 1]); }
+            }
+        }
+        auto pair_at = [&](const unsigned char* a, h8& hi, h8& lo) {
+            hi = *reinterpret_cast<const h8*>(a + lane * 16); lo = *reinterpret_cast<const h8*>(a + 1024 + lane * 16);
+        };
+#pragma unroll
+        for (int co = 0; co < NCT; ++co) {
+            const f4 bias3 = *reinterpret_cast<const f4*>(b3 + (16 * co + 4 * g) * 4);
+            h8 a3h, a3l;
+            pair_at(w3 + (long)co * HP_FRAG_PAIR, a3h, a3l);
+            h8 adh[DOWN ? KIN : 1], adl[DOWN ? KIN : 1];
+            if constexpr (DOWN) {
+#pragma unroll
+                for (int ks = 0; ks < KIN; ++ks) pair_at(wdn + (long)(co * KIN + ks) * HP_FRAG_PAIR, adh[ks], adl[ks]);
+            }
+            h8 p3h, p3l, pdh[RECON ? KINP : 1], pdl[RECON ? KINP : 1];
+            f4 biasp;
+            if constexpr (RECON) {
+                biasp = *reinterpret_cast<const f4*>(pvb + (16 * co + 4 * g) * 4);
+                pair_at(pv3 + (long)co * HP_FRAG_PAIR, p3h, p3l);
+#pragma unroll
+                for (int ks = 0; ks < KINP; ++ks) pair_at(pvd + (long)(co * KINP + ks) * HP_FRAG_PAIR, pdh[ks], pdl[ks]);
+            }
+#pragma unroll
+            for (int t = 0; t < TG; ++t) {
+                const TileOps& o = ops[(k0 + t) % NR];
+                f4 acc = bias3;
+                if constexpr (KT == 1) acc = mm2r(a3h, a3l, b2h[t], acc);
+                else acc = mm3r(a3h, a3l, b2h[t], b2l[t], acc);
+                if constexpr (DOWN) {
+                    if constexpr (CIN == 16) acc = mm2r(adh[0], adl[0], o.dxh[0], acc);
+                    else {
+#pragma unroll
+                        for (int ks = 0; ks < KIN; ++ks) acc = mm3r(adh[ks], adl[ks], o.dxh[ks], o.dxl[ks], acc);
+                    }
+                } else if constexpr (RECON) {
+                    // block input = ReLU(conv3_prev . x2_prev + down_prev . x_prev + bias), rebuilt in fp32 and added as it is
+                    f4 ap = biasp;
+                    if constexpr (KT == 1) ap = mm2r(p3h, p3l, rb2h[t], ap);
+                    else ap = mm3r(p3h, p3l, rb2h[t], rb2l[t], ap);
+                    if constexpr (PREV_CIN == 16) ap = mm2r(pdh[0], pdl[0], o.rxh[0], ap);
+                    else {
+#pragma unroll
+                        for (int ks = 0; ks < KINP; ++ks) ap = mm3r(pdh[ks], pdl[ks], o.rxh[ks], o.rxl[ks], ap);
+                    }
+                    acc += relu4(ap);
+                } else {
+                    acc = BM_MFMA_F16_K32(eye, cat8(o.idh[co], o.idl[co]), acc);
+                }
+                split4(relu4(acc), yh[t][co], yl[t][co]);
+            }
+        }
+    };
+    if constexpr (BM_HP_ASYNC_STAGE) BM_WAIT_VM0();         // this wave's operand copies have landed (issued a gate ago in stages 0 / 1)
 #pragma unroll
     for (int k = 0; k < NR && k < NT; ++k) tile_loads(seq_tile(k), ops[k]);       // the first sets fly under the staging barrier
     __syncthreads();
+    f4 bn[EMIT ? KT : 1];   // EMIT: the next block's conv1 bias, loaded once (a global load inside the loop drains the operand prefetch)
     if constexpr (EMIT) {
-        // next block's conv1 (COUT -> MID, + bias, ReLU) on the in-register block output
-        f4 bn[KT];          // its bias: loaded once (a global load inside the tile loop drains the operand prefetch every tile)
 #pragma unroll
         for (int ct = 0; ct < KT; ++ct) bn[ct] = *reinterpret_cast<const f4*>(link.w + link.a1 + (16 * ct + 4 * g) * 4);
+    }
+    _Float16* yh_out = EMIT ? nullptr : out_h + crop * out_px * COUT;         // (EMIT hands over fp32 scratch instead of its output)
+    _Float16* yl_out = EMIT ? nullptr : out_l + crop * out_px * COUT;
 #pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            f4 y[NCT];
-            block_tile(i, ops[i % NR], y);
-            if (i + NR < NT) tile_loads(i + NR, ops[i % NR]);          // the set just consumed is free again
-            h4 yh[NCT], yl[NCT];
+    for (int k0 = 0; k0 < NT; k0 += TG) {
+        h4 yh[TG][NCT], yl[TG][NCT];
+        block_group(k0, yh, yl);
 #pragma unroll
-            for (int co = 0; co < NCT; ++co) split4(y[co], yh[co], yl[co]);
+        for (int t = 0; t < TG; ++t)
+            if (k0 + t + NR < NT) tile_loads(seq_tile(k0 + t + NR), ops[(k0 + t) % NR]);          // the sets just consumed are free again
+        if constexpr (EMIT) {
+            // next block's conv1 (COUT -> MID, + bias, ReLU) on the in-register block output
 #pragma unroll
             for (int ct = 0; ct < KT; ++ct) {
-                f4 an = bn[ct];
+                f4 an[TG];
 #pragma unroll
-                for (int ks = 0; ks < KSN; ++ks)
-                    an = mm3(wln + (long)(ks * KT + ct) * HP_FRAG_PAIR, lane, cat8(yh[2 * ks], yh[2 * ks + 1]), cat8(yl[2 * ks], yl[2 * ks + 1]), an);
-                BM_NT_STORE(reinterpret_cast<f4*>(x1w + (i * KT + ct) * 256), relu4(an));
-                BM_NT_STORE(reinterpret_cast<f4*>(x2w + (i * KT + ct) * 256), x2[i][ct]);
+                for (int t = 0; t < TG; ++t) an[t] = bn[ct];
+#pragma unroll
+                for (int ks = 0; ks < KSN; ++ks) {
+                    const unsigned char* a = wln + (long)(ks * KT + ct) * HP_FRAG_PAIR;
+                    const h8 ah = *reinterpret_cast<const h8*>(a + lane * 16), al = *reinterpret_cast<const h8*>(a + 1024 + lane * 16);
+#pragma unroll
+                    for (int t = 0; t < TG; ++t)
+                        an[t] = mm3r(ah, al, cat8(yh[t][2 * ks], yh[t][2 * ks + 1]), cat8(yl[t][2 * ks], yl[t][2 * ks + 1]), an[t]);
+                }
+#pragma unroll
+                for (int t = 0; t < TG; ++t) {
+                    const int i = seq_tile(k0 + t);
+                    BM_NT_STORE(reinterpret_cast<f4*>(x1w + (i * KT + ct) * 256), relu4(an[t]));
+                    BM_NT_STORE(reinterpret_cast<f4*>(x2w + (i * KT + ct) * 256), x2[i][ct]);
+                }
             }
-            BM_SCHED_FENCE();
-        }
-    } else if constexpr (!TRANS) {
-        _Float16* yh_out = out_h + crop * out_px * COUT;
-        _Float16* yl_out = out_l + crop * out_px * COUT;
+        } else if constexpr (!TRANS) {
 #pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            const unsigned p = (wave * NT + i) * 16 + l16;
-            f4 y[NCT];
-            block_tile(i, ops[i % NR], y);
-            if (i + NR < NT) tile_loads(i + NR, ops[i % NR]);
+            for (int t = 0; t < TG; ++t) {
+                const unsigned p = (wave * NT + seq_tile(k0 + t)) * 16 + l16;
 #pragma unroll
-            for (int co = 0; co < NCT; ++co) {
-                h4 hh, ll;
-                split4(y[co], hh, ll);
-                const unsigned o = p * COUT + g * (COUT / 4) + 4 * co;
-                BM_NT_STORE(reinterpret_cast<h4*>(yh_out + o), hh);
-                BM_NT_STORE(reinterpret_cast<h4*>(yl_out + o), ll);
+                for (int co = 0; co < NCT; ++co) {
+                    const unsigned o = p * COUT + g * (COUT / 4) + 4 * co;
+                    BM_NT_STORE(reinterpret_cast<h4*>(yh_out + o), yh[t][co]);
+                    BM_NT_STORE(reinterpret_cast<h4*>(yl_out + o), yl[t][co]);
+                }
             }
-            BM_SCHED_FENCE();
-        }
-    } else {
-        // two vertically adjacent tiles: transition conv on the in-register block output, ReLU, 2x2 average (vertical = the
-        // two tiles, horizontal = lane ^ 1; the 1/4 is folded into `wtr`), even lanes store the pooled pixel
-        static_assert(!TRANS || (STAGE < 2 && COUT % 32 == 0), "fused transition: stages 0 and 1");
-        constexpr int WP = G::W / 2;
-        const unsigned char* tbias = wtl + (long)NCT * KS3 * HP_FRAG_PAIR;
-        _Float16* yh_out = out_h + crop * out_px * COUT;
-        _Float16* yl_out = out_l + crop * out_px * COUT;
-#pragma unroll
-        for (int pr = 0; pr < NT / 2; ++pr) {
-            const int k0 = 2 * pr, k1 = 2 * pr + 1, i0 = seq_tile(k0), i1 = seq_tile(k1);
-            h4 y0h[NCT], y0l[NCT], y1h[NCT], y1l[NCT];
-            {
-                f4 y[NCT];
-                block_tile(i0, ops[k0 % NR], y);
-                if (k0 + NR < NT) tile_loads(seq_tile(k0 + NR), ops[k0 % NR]);
-#pragma unroll
-                for (int co = 0; co < NCT; ++co) split4(y[co], y0h[co], y0l[co]);
-                block_tile(i1, ops[k1 % NR], y);
-                if (k1 + NR < NT) tile_loads(seq_tile(k1 + NR), ops[k1 % NR]);
-#pragma unroll
-                for (int co = 0; co < NCT; ++co) split4(y[co], y1h[co], y1l[co]);
-            }
-            const int row = STAGE == 0 ? wave * (NT / 2) + (i0 >> 1) : wave * NT + i0;     // even image row of tile i0
-            const int po = (row >> 1) * WP + (STAGE == 0 ? (i0 & 1) * 8 : 0) + (l16 >> 1);
+        } else {
+            // pairs of vertically adjacent tiles: transition conv on the in-register block output, ReLU, 2x2 average (vertical =
+            // the two tiles, horizontal = lane ^ 1; the 1/4 is folded into `wtr`), even lanes store the pooled pixel
+            static_assert(!TRANS || (STAGE < 2 && COUT % 32 == 0), "fused transition: stages 0 and 1");
+            constexpr int WP = G::W / 2;
+            const unsigned char* tbias = wtl + (long)NCT * KS3 * HP_FRAG_PAIR;
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
                 const f4 bv = *reinterpret_cast<const f4*>(tbias + (16 * ct + 4 * g) * 4);
-                f4 a0 = bv, a1 = bv;
+                f4 a[TG];
+#pragma unroll
+                for (int t = 0; t < TG; ++t) a[t] = bv;
 #pragma unroll
                 for (int ks = 0; ks < KS3; ++ks) {
-                    const unsigned char* a = wtl + (long)(ct * KS3 + ks) * HP_FRAG_PAIR;
-                    const h8 ah = *reinterpret_cast<const h8*>(a + lane * 16), al = *reinterpret_cast<const h8*>(a + 1024 + lane * 16);
-                    a0 = mm3r(ah, al, cat8(y0h[2 * ks], y0h[2 * ks + 1]), cat8(y0l[2 * ks], y0l[2 * ks + 1]), a0);
-                    a1 = mm3r(ah, al, cat8(y1h[2 * ks], y1h[2 * ks + 1]), cat8(y1l[2 * ks], y1l[2 * ks + 1]), a1);
-                }
-                a0 = relu4(a0); a1 = relu4(a1);
-                f4 sp;
+                    const unsigned char* af = wtl + (long)(ct * KS3 + ks) * HP_FRAG_PAIR;
+                    const h8 ah = *reinterpret_cast<const h8*>(af + lane * 16), al = *reinterpret_cast<const h8*>(af + 1024 + lane * 16);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = a0[r] + a1[r];
-                    sp[r] = v + BM_QUAD_SWAP1_F32(v);
+                    for (int t = 0; t < TG; ++t)
+                        a[t] = mm3r(ah, al, cat8(yh[t][2 * ks], yh[t][2 * ks + 1]), cat8(yl[t][2 * ks], yl[t][2 * ks + 1]), a[t]);
                 }
-                if ((l16 & 1) == 0) {
-                    h4 hh, ll;
-                    split4(sp, hh, ll);
-                    const unsigned o = po * COUT + g * (COUT / 4) + 4 * ct;
-                    BM_NT_STORE(reinterpret_cast<h4*>(yh_out + o), hh);
-                    BM_NT_STORE(reinterpret_cast<h4*>(yl_out + o), ll);
+#pragma unroll
+                for (int pr = 0; pr < TG / 2; ++pr) {
+                    const int i0 = seq_tile(k0 + 2 * pr);
+                    const int row = STAGE == 0 ? wave * (NT / 2) + (i0 >> 1) : wave * NT + i0;     // even image row of tile i0
+                    const int po = (row >> 1) * WP + (STAGE == 0 ? (i0 & 1) * 8 : 0) + (l16 >> 1);
+                    const f4 a0 = relu4(a[2 * pr]), a1 = relu4(a[2 * pr + 1]);
+                    f4 sp;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = a0[r] + a1[r];
+                        sp[r] = v + BM_QUAD_SWAP1_F32(v);
+                    }
+                    if ((l16 & 1) == 0) {
+                        h4 hh, ll;
+                        split4(sp, hh, ll);
+                        const unsigned o = po * COUT + g * (COUT / 4) + 4 * ct;
+                        BM_NT_STORE(reinterpret_cast<h4*>(yh_out + o), hh);
+                        BM_NT_STORE(reinterpret_cast<h4*>(yl_out + o), ll);
+                    }
                 }
             }
-            BM_SCHED_FENCE();
         }
+        BM_SCHED_FENCE();
     }
     BM_PROF(7);
     BM_PROF_FLUSH();

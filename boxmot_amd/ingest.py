@@ -18,6 +18,7 @@ Everything is a thin ctypes wrapper over boxmot_hip_ingest_* (include/boxmot_hip
 from __future__ import annotations
 
 import ctypes
+import sys
 
 import numpy as np
 
@@ -63,15 +64,21 @@ class FrameRing:
             raise RuntimeError(_lib.last_error())
         return int(p)
 
-    def close(self) -> None:
+    def close(self, force: bool = False) -> None:
+        """Free the ring.  The arrays ``host_view`` handed out alias the page-locked memory this frees: while the caller still
+        holds one (or a slice of one) ``close`` refuses, unless ``force`` (interpreter shutdown / ``__del__``)."""
         h = getattr(self, "_handle", None)
         if h:
+            if not force:
+                held = [s for s in self._views if sys.getrefcount(self._views[s]) > 2]     # the dict entry + the argument
+                if held:
+                    raise RuntimeError(f"FrameRing.close(): host views of slot(s) {held} are still referenced; drop them first")
             self._views.clear()
             self._lib.boxmot_hip_ingest_destroy(h)
             self._handle = None
 
     def __del__(self):
         try:
-            self.close()
+            self.close(force=True)
         except Exception:
             pass

@@ -111,6 +111,9 @@ inline double __dadd_rn(double a, double b) { return a + b; }
 inline double __dmul_rn(double a, double b) { return a * b; }
 #define BM_EXPF(x) expf(x)
 #define BM_SCHED_FENCE() ((void)0)
+#define BM_SETPRIO(n) ((void)0)
+#define BM_WAIT_VM0() ((void)0)
+#define BM_RCPF(x) (1.0f / (x))
 #define BM_OPAQUE_U32(x) ((void)0)
 inline float emu_row_shift(float v, int d, bool rotate) {
     const int lane = threadIdx.x % EMU_WAVE, src16 = (lane & 15) + d;

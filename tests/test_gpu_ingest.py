@@ -37,6 +37,10 @@ def test_ring_update_batch_equals_host_frame_update_batch():
             assert np.array_equal(np.asarray(got[s]), np.asarray(want[s])), (t, s)
     with pytest.raises(RuntimeError):
         ring.submit(7)
+    held = ring.host_view(2)[0]                 # a slice keeps the slot's view alive: close() must not free the memory under it
+    with pytest.raises(RuntimeError):
+        ring.close()
+    del held
     ring.close(); a.close(); b.close()
     with pytest.raises(RuntimeError):
         FrameRing(1, 1, 10, 10)
