@@ -58,6 +58,11 @@
 // publishes them (s_waitcnt vmcnt(0); vmcnt retires in order)
 #define BM_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #endif
+#ifndef BM_RESID_F16
+// v - (float)(fp16 half `hi` of the packed pair `hp`): one v_fma_mix_f32 (fma(h, -1.0, v): a single rounding, i.e. the fp32
+// subtraction itself) instead of a convert + a subtract
+#define BM_RESID_F16(hp, hi, v, out) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[" #hi ",0,0] op_sel_hi:[1,0,0]" : "=v"(out) : "v"(hp), "v"(v))
+#endif
 #ifndef BM_RELU_F32
 // max(v, 0) as one integer max on the bit pattern (negative floats are negative ints); a float max costs a second,
 // canonicalising v_max under IEEE mode

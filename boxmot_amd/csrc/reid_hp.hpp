@@ -32,18 +32,18 @@
 // epilogue: tiles per group (the A fragments of an output-channel tile are read from LDS once per GROUP and held in registers
 // while the group's tiles run through them: 1 / TG of the fragment reads, TG independent MFMA chains)
 #ifndef BM_HP_EPI_TG0E
-#define BM_HP_EPI_TG0E 4            // stage 0, first block (EMIT)
+#define BM_HP_EPI_TG0E 2            // stage 0, first block (EMIT)
 #endif
 #ifndef BM_HP_EPI_TG0R
 #define BM_HP_EPI_TG0R 2            // stage 0, second block (RECON + fused transition): 4 would spill
 #endif
 #ifndef BM_HP_EPI_TG1
-#define BM_HP_EPI_TG1 4             // stage 1: the wave's whole strip
+#define BM_HP_EPI_TG1 2             // stage 1 (2 and 4 measured equal; 2 keeps 12 registers free)
 #endif
 // weights into LDS by asynchronous global -> LDS copies (no register round trip, no latency per loop trip) issued ahead of the
 // phase that needs them; 0 = load / store loops at the point of use (A/B switch)
 #ifndef BM_HP_ASYNC_STAGE
-#define BM_HP_ASYNC_STAGE 0
+#define BM_HP_ASYNC_STAGE 1
 #endif
 // streaming accesses (hand-over tensors and block outputs written once, operands read once) marked non-temporal so that the
 // tensor a kernel re-reads per branch (128 KiB per crop, one L2 share) is not evicted by them
@@ -96,9 +96,21 @@ struct GeoHP {
 
 __device__ inline f4 fma_f4(f4 a, f4 b, f4 c) { return __builtin_elementwise_fma(a, b, c); }
 // (hi, lo) fp16 parts of four fp32 values: v = hi + lo up to 2^-22 relative
+#ifndef BM_HP_SPLIT_MIX
+#define BM_HP_SPLIT_MIX 1           // residuals by v_fma_mix_f32 (8 instructions per split4 instead of 12-13); 0: convert + subtract
+#endif
 __device__ inline void split4(f4 v, h4& h, h4& l) {
     h = to_h4(v);
+#if BM_HP_SPLIT_MIX
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    const u2v hp = __builtin_bit_cast(u2v, h);
+    f4 r;
+    BM_RESID_F16(hp[0], 0, v[0], r[0]); BM_RESID_F16(hp[0], 1, v[1], r[1]);
+    BM_RESID_F16(hp[1], 0, v[2], r[2]); BM_RESID_F16(hp[1], 1, v[3], r[3]);
+    l = to_h4(r);
+#else
     l = to_h4(f4{v[0] - (float)h[0], v[1] - (float)h[1], v[2] - (float)h[2], v[3] - (float)h[3]});
+#endif
 }
 // K = 32 product tile on (hi, lo) operands: the fragment pair at `a` (hi at +0, lo at +1024; 16 bytes per lane)
 __device__ inline f4 mm3(const unsigned char* a, int lane, h8 bh, h8 bl, f4 acc) {
@@ -743,6 +755,9 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
 // tiles 2w, 2w+1, fragments in registers), bias + ReLU + average in fp32; the FC for the 16 crops as one MFMA tile per 16
 // features with (hi, lo) parts of both the pooled vectors and the weights.
 // ---------------------------------------------------------------------------
+#ifndef BM_HP_HEAD_UNROLL
+#define BM_HP_HEAD_UNROLL 4         // pixel tiles whose operand loads are in flight together (2: 0.181, 4: 0.164, 8: 0.176 ms per 4096 crops)
+#endif
 template <int C, int F>
 __global__ void __launch_bounds__(256, 2) k_head_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_l,
                                                     const unsigned char* __restrict__ wts5, const unsigned char* __restrict__ wfc,
@@ -751,6 +766,7 @@ __global__ void __launch_bounds__(256, 2) k_head_hp(const _Float16* __restrict__
     static_assert(C == 128 && F % 64 == 0, "head: 128 channels in, a multiple of 64 features out");
     constexpr int NCT = C / 16, KS = C / 32, P = 128, NB = HEAD_NB, VS = C + 4;
     constexpr int FT_PER_WAVE = F / 16 / 4;
+    constexpr int HEAD_UNROLL = BM_HP_HEAD_UNROLL;          // (a constant expression: a macro inside a pragma does not survive -save-temps)
     __shared__ __attribute__((aligned(16))) float vbuf[NB * VS];          // pooled vectors (L-layout channel order)
     __shared__ float red[4 * NB];
     int n_eff = n_total;
@@ -779,7 +795,7 @@ __global__ void __launch_bounds__(256, 2) k_head_hp(const _Float16* __restrict__
         const _Float16* xh = in_h + (crop0 + k) * (long)(P * C);
         const _Float16* xl = in_l + (crop0 + k) * (long)(P * C);
         f4 sum[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll 2
+#pragma unroll HEAD_UNROLL
         for (int i = 0; i < P / 16; ++i) {
             const int p = i * 16 + l16;
             h8 bh[KS], bl[KS];

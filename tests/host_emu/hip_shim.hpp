@@ -113,6 +113,7 @@ inline double __dmul_rn(double a, double b) { return a * b; }
 #define BM_SCHED_FENCE() ((void)0)
 #define BM_SETPRIO(n) ((void)0)
 #define BM_WAIT_VM0() ((void)0)
+#define BM_RESID_F16(hp, hi, v, out) do { unsigned short b_ = (unsigned short)((hp) >> (16 * (hi))); _Float16 h_; std::memcpy(&h_, &b_, 2); (out) = (v) - (float)h_; } while (0)
 #define BM_RCPF(x) (1.0f / (x))
 #define BM_OPAQUE_U32(x) ((void)0)
 inline float emu_row_shift(float v, int d, bool rotate) {

@@ -16,6 +16,7 @@
 #   mfma       SQ_VALU_MFMA_BUSY_CYCLES pass on the same microbenchmark      -> mfma_busy.txt
 #   c3 / c5    tools/config_bench.py for configurations 3 / 5                 -> config_bench.jsonl
 #   soak       tools/parity_soak.py (all trackers, short)                     -> soak.log
+#   hpab       every tools/_build/hp_prof_* binary (variants of the fp32-grade kernels built with -D switches) -> hp_ab.txt
 # Counters are collected in their own --pmc passes, never together with a trace (profiles/README.md).  Summaries a round wants
 # judged are copied from gpurun_out/<tag>/ into profiles/ by hand.
 set -u
@@ -43,6 +44,7 @@ for step in "$@"; do
     c3)      timeout 600 python tools/config_bench.py --config c3 >> $O/config_bench.jsonl 2> $O/c3.err; tail -n 1 $O/config_bench.jsonl | cut -c1-900 ;;
     c5)      timeout 900 python tools/config_bench.py --config c5 >> $O/config_bench.jsonl 2> $O/c5.err; tail -n 1 $O/config_bench.jsonl | cut -c1-900 ;;
     soak)    timeout 900 python tools/parity_soak.py 10 200 > $O/soak.log 2>&1; tail -n 12 $O/soak.log ;;
+    hpab)    for b in tools/_build/hp_prof_*; do echo "## $b" >> $O/hp_ab.txt; timeout 120 $b 4096 5 >> $O/hp_ab.txt 2>&1; done; grep -c best $O/hp_ab.txt ;;
     *)       echo "unknown step $step" ;;
   esac
 done
