@@ -150,6 +150,16 @@ def run(config: str = "c3", streams: int = 0, steps: int = 40, warmup: int = 8, 
     bx = dets_h[0, 0, :8, :4]
     gates["reid_max_abs_err_vs_fp32_oracle"] = float(np.abs(hr.get_features(bx, scen[0].image) - orc_reid.get_features(bx, scen[0].image)).max())
     hr.close()
+    if c3:
+        # the same family on a BatchNorm-calibrated random network (the noise-amplifying case, tests/test_gpu_long_parity.py):
+        # reported, not gated -- fp16 operands sit at the reference half=True path's error class there, not at 1e-3
+        from boxmot_amd.reid_weights import pack_osnet, random_osnet_state_dict
+        sdc = random_osnet_state_dict("osnet_x1_0", seed=0)
+        hc = HipReID(pack_osnet(sdc), max_crops=8, mode=reid_mode)
+        e = float(np.abs(hc.get_features(bx, scen[0].image) - OracleReID(sdc).get_features(bx, scen[0].image)).max())
+        hc.close()
+        gates["reid_max_abs_err_vs_fp32_oracle_bn_calibrated_seed0"] = e
+        gates["reid_within_1e-3_on_bn_calibrated_weights"] = bool(e < 1e-3)
     if check:
         # id gate: the oracle tracker with the fp32 oracle backbone inside update on stream 0's first frames (full size)
         if c3:
