@@ -54,7 +54,7 @@ FLOP_PER_CROP = 2 * 82_314_880          # OSNet x0.25 forward, BASELINE.md secti
 # here (separate --pmc passes, gfx950 FETCH correction applied by profiles/summarize_pmc.py) -- counters cannot be collected
 # inside a timed run, so the line carries the profile's figure and says which file it came from
 # one committed profile per kernel family (mode): fused fp32-grade (2), fused fp16 (1)
-TRAFFIC_PROFILES = {2: ("profiles/r3_pmc_traffic_hp.txt",),
+TRAFFIC_PROFILES = {2: ("profiles/r3_pmc_traffic_final.txt", "profiles/r3_pmc_traffic_hp.txt"),
                     1: ("profiles/r3_pmc_traffic.txt", "profiles/r2_pmc_traffic.txt", "profiles/r1h_pmc_traffic.txt")}
 
 
@@ -213,6 +213,12 @@ def side_configs():
         try:
             side[key] = config_bench.run(**kwargs)
             log(f"side line {key}: {side[key]['frames_per_s']:.1f} frames/s")
+            if key == "config3":
+                # the same workload with the streams split over two handles / HIP streams: one group's frame step (8 workgroups,
+                # 4.5 ms with the tie-exact assignment solver) runs beside the other group's ReID kernels.  Its own entry: the
+                # ReID-region timing (and the roofline figure above) is only clean when nothing else shares the GPU.
+                two = config_bench.run(**{**kwargs, "check_frames": 0, "groups": 2})
+                side[key]["two_stream_groups"] = {k: two[k] for k in ("stream_groups", "frames_per_s", "ms_per_step")}
         except Exception as exc:                    # a side line never takes the headline down
             side[key] = {"error": f"{type(exc).__name__}: {exc}"}
     return side

@@ -33,6 +33,7 @@ class FrameRing:
         if not self._handle:
             raise RuntimeError(_lib.last_error())
         self._views = {}
+        self._roots = {}
 
     def host_view(self, slot: int) -> np.ndarray:
         """(n_streams, rows, cols, 3) uint8 view of the slot's page-locked host memory."""
@@ -42,7 +43,9 @@ class FrameRing:
                 raise RuntimeError(_lib.last_error())
             n = self.n_streams * self.rows * self.cols * 3
             buf = (ctypes.c_uint8 * n).from_address(p)
-            self._views[slot] = np.frombuffer(buf, dtype=np.uint8).reshape(self.n_streams, self.rows, self.cols, 3)
+            root = np.frombuffer(buf, dtype=np.uint8)        # numpy collapses view chains onto this array: every slice a caller
+            self._roots[slot] = root                         # keeps holds a reference to IT (close() counts them)
+            self._views[slot] = root.reshape(self.n_streams, self.rows, self.cols, 3)
         return self._views[slot]
 
     def submit(self, slot: int, n_streams: int | None = None) -> None:
@@ -70,10 +73,13 @@ class FrameRing:
         h = getattr(self, "_handle", None)
         if h:
             if not force:
-                held = [s for s in self._views if sys.getrefcount(self._views[s]) > 2]     # the dict entry + the argument
+                # a slot's root array is referenced by: _roots, the cached 4-D view's base, getrefcount's argument; and the 4-D
+                # view by: _views, getrefcount's argument
+                held = [s for s in self._views if sys.getrefcount(self._roots[s]) > 3 or sys.getrefcount(self._views[s]) > 2]
                 if held:
                     raise RuntimeError(f"FrameRing.close(): host views of slot(s) {held} are still referenced; drop them first")
             self._views.clear()
+            self._roots.clear()
             self._lib.boxmot_hip_ingest_destroy(h)
             self._handle = None
 

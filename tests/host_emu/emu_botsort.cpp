@@ -108,14 +108,9 @@ int emu_update(void* h, const float* dets, int n, const float* embs, float* out,
     g_s_int = s_int; g_s_dbl = s_dbl; g_sA = sA; g_sB = sB; g_dyn = reinterpret_cast<unsigned char*>(dyn.data());
     g_emu_block = &e->block;
     blockDim.x = NTHR;
-    std::vector<pthread_t> th(NTHR);
     std::vector<ThreadArg> ta(NTHR);
-    pthread_attr_t attr;
-    pthread_attr_init(&attr);
-    pthread_attr_setstacksize(&attr, 1 << 20);
-    for (int t = 0; t < NTHR; ++t) { ta[t] = ThreadArg{e, t}; pthread_create(&th[t], &attr, thread_main, &ta[t]); }
-    for (int t = 0; t < NTHR; ++t) pthread_join(th[t], nullptr);
-    pthread_attr_destroy(&attr);
+    for (int t = 0; t < NTHR; ++t) ta[t] = ThreadArg{e, t};
+    emu_run_threads(NTHR, thread_main, ta.data(), sizeof(ta[0]), 1 << 20);
     e->warp_flag[0] = 0;
     *out_n = e->out_n[0];
     std::memcpy(out, e->out, (size_t)e->out_n[0] * bm::OUT_COLS * 4);

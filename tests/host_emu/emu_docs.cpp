@@ -97,14 +97,9 @@ int emu_docs_update(void* h, const float* dets, int n, const float* embs, const 
     g_s_int = s_int; g_s_dbl = s_dbl; g_dyn = reinterpret_cast<unsigned char*>(dyn.data());
     g_emu_block = &e->block;
     blockDim.x = NTHR;
-    std::vector<pthread_t> th(NTHR);
     std::vector<ThreadArg> ta(NTHR);
-    pthread_attr_t attr;
-    pthread_attr_init(&attr);
-    pthread_attr_setstacksize(&attr, 1 << 20);
-    for (int t = 0; t < NTHR; ++t) { ta[t] = ThreadArg{e, t}; pthread_create(&th[t], &attr, thread_main, &ta[t]); }
-    for (int t = 0; t < NTHR; ++t) pthread_join(th[t], nullptr);
-    pthread_attr_destroy(&attr);
+    for (int t = 0; t < NTHR; ++t) ta[t] = ThreadArg{e, t};
+    emu_run_threads(NTHR, thread_main, ta.data(), sizeof(ta[0]), 1 << 20);
     *out_n = e->out_n[0];
     std::memcpy(out, e->out, (size_t)e->out_n[0] * bm::OUT_COLS * 4);
     return e->args.st.status[0];
@@ -153,14 +148,9 @@ int emu_lap_jv(int nr, int nc, const double* cost, int use_limit, double limit, 
     block.block_barrier.init(NTHR);
     for (int w = 0; w < EMU_MAX_WAVES; ++w) block.wave_barrier[w].init(EMU_WAVE);
     int ok = 0;
-    std::vector<pthread_t> th(NTHR);
     std::vector<JvArg> ta(NTHR);
-    pthread_attr_t attr;
-    pthread_attr_init(&attr);
-    pthread_attr_setstacksize(&attr, 1 << 20);
-    for (int t = 0; t < NTHR; ++t) { ta[t] = JvArg{nr, nc, cost, use_limit, limit, x, y, t, &ok}; pthread_create(&th[t], &attr, jv_main, &ta[t]); }
-    for (int t = 0; t < NTHR; ++t) pthread_join(th[t], nullptr);
-    pthread_attr_destroy(&attr);
+    for (int t = 0; t < NTHR; ++t) ta[t] = JvArg{nr, nc, cost, use_limit, limit, x, y, t, &ok};
+    emu_run_threads(NTHR, jv_main, ta.data(), sizeof(ta[0]), 1 << 20);
     return ok;
 }
 
@@ -188,10 +178,9 @@ int emu_jv_move(int n, int* cols, int base, int l0, unsigned long long q, int hi
     block.block_barrier.init(NTHR);
     for (int w = 0; w < EMU_MAX_WAVES; ++w) block.wave_barrier[w].init(EMU_WAVE);
     int out = -1;
-    std::vector<pthread_t> th(NTHR);
     std::vector<MvArg> ta(NTHR);
-    for (int t = 0; t < NTHR; ++t) { ta[t] = MvArg{n, cols, base, l0, q, hi, t, &out}; pthread_create(&th[t], nullptr, mv_main, &ta[t]); }
-    for (int t = 0; t < NTHR; ++t) pthread_join(th[t], nullptr);
+    for (int t = 0; t < NTHR; ++t) ta[t] = MvArg{n, cols, base, l0, q, hi, t, &out};
+    emu_run_threads(NTHR, mv_main, ta.data(), sizeof(ta[0]), 1 << 20);
     return out;
 }
 

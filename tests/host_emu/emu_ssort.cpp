@@ -71,14 +71,9 @@ void* thread_main(void* p) {
 }
 
 void run_block(Emu* e, int mode, int t) {
-    std::vector<pthread_t> th(NTHR);
     std::vector<ThreadArg> ta(NTHR);
-    pthread_attr_t attr;
-    pthread_attr_init(&attr);
-    pthread_attr_setstacksize(&attr, 1 << 20);
-    for (int k = 0; k < NTHR; ++k) { ta[k] = ThreadArg{e, k, mode, t}; pthread_create(&th[k], &attr, thread_main, &ta[k]); }
-    for (int k = 0; k < NTHR; ++k) pthread_join(th[k], nullptr);
-    pthread_attr_destroy(&attr);
+    for (int k = 0; k < NTHR; ++k) ta[k] = ThreadArg{e, k, mode, t};
+    emu_run_threads(NTHR, thread_main, ta.data(), sizeof(ta[0]), 1 << 20);
 }
 
 }  // namespace

@@ -36,18 +36,13 @@ void launch(long gx, int gy, int nthr, const std::function<void()>& fn) {
     blockDim.x = nthr; gridDim.x = (unsigned)gx; gridDim.y = gy;
     block.block_barrier.init(nthr);
     for (int w = 0; w < EMU_MAX_WAVES; ++w) block.wave_barrier[w].init(EMU_WAVE);
-    pthread_attr_t attr;
-    pthread_attr_init(&attr);
-    pthread_attr_setstacksize(&attr, 1 << 20);
     for (int by = 0; by < gy; ++by)
         for (long bx = 0; bx < gx; ++bx) {
             std::memset(lds.data(), 0xFF, lds.size());
-            std::vector<pthread_t> th(nthr);
             std::vector<TA> ta(nthr);
-            for (int t = 0; t < nthr; ++t) { ta[t] = TA{&fn, t, (int)bx, by}; pthread_create(&th[t], &attr, tmain, &ta[t]); }
-            for (int t = 0; t < nthr; ++t) pthread_join(th[t], nullptr);
+            for (int t = 0; t < nthr; ++t) ta[t] = TA{&fn, t, (int)bx, by};
+            emu_run_threads(nthr, tmain, ta.data(), sizeof(ta[0]), 1 << 20);
         }
-    pthread_attr_destroy(&attr);
 }
 }  // namespace
 

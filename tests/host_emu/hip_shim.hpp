@@ -34,20 +34,159 @@ extern EmuDim3 gridDim;
 constexpr int EMU_WAVE = 64;
 constexpr int EMU_MAX_WAVES = 16;
 
-// sense-reversing barrier that yields instead of sleeping: with more emulated
-// threads than cores a futex barrier costs ~100 us, yielding costs ~10 us
+// ---------------------------------------------------------------------------------------------------------------------
+// Emulated threads.  Default: FIBERS -- every emulated GPU thread of a workgroup is a user-level context on ONE OS thread;
+// a barrier wait is a stack switch to the next lane (tens of nanoseconds), not a trip through the kernel scheduler.  A
+// wave-scope wait (shuffles, ballots, emulated MFMAs) cycles through the 64 lanes of its own wave only, a workgroup barrier
+// through all threads.  With EMU_PTHREADS (and always under the sanitizers, which do not follow hand-made stack switches)
+// every emulated thread is a pthread and a wait is a sched_yield loop -- the original scheme, 10-50x slower.
+// ---------------------------------------------------------------------------------------------------------------------
+#if defined(__SANITIZE_ADDRESS__) || defined(__SANITIZE_THREAD__)
+#define EMU_PTHREADS 1
+#endif
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer) || __has_feature(thread_sanitizer)
+#ifndef EMU_PTHREADS
+#define EMU_PTHREADS 1
+#endif
+#endif
+#endif
+#if !defined(__x86_64__) && !defined(EMU_PTHREADS)
+#define EMU_PTHREADS 1
+#endif
+
+#ifndef EMU_PTHREADS
+#include <sys/mman.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+extern "C" void emu_ctx_switch(void** save_sp, void* load_sp);
+// callee-saved registers of the SysV x86-64 ABI on the stack, stack pointers exchanged
+asm(".text\n"
+    ".p2align 4\n"
+    ".globl emu_ctx_switch\n"
+    ".type emu_ctx_switch,@function\n"
+    "emu_ctx_switch:\n"
+    "    pushq %rbp\n    pushq %rbx\n    pushq %r12\n    pushq %r13\n    pushq %r14\n    pushq %r15\n"
+    "    movq %rsp, (%rdi)\n"
+    "    movq %rsi, %rsp\n"
+    "    popq %r15\n    popq %r14\n    popq %r13\n    popq %r12\n    popq %rbx\n    popq %rbp\n"
+    "    ret\n"
+    ".size emu_ctx_switch,.-emu_ctx_switch\n");
+
+struct EmuFiber { void* sp = nullptr; bool done = false; void* (*fn)(void*) = nullptr; void* arg = nullptr; };
+struct EmuSched {
+    std::vector<EmuFiber> f;
+    int cur = 0, alive = 0;
+    void* main_sp = nullptr;
+};
+inline EmuSched*& emu_sched() { static thread_local EmuSched* s = nullptr; return s; }
+
+// hand the OS thread to fiber `nx` (the caller continues when somebody switches back to it)
+inline void emu_switch_to(EmuSched* s, int nx) {
+    const int me = s->cur;
+    if (nx == me) return;
+    const EmuDim3 t = threadIdx;            // threadIdx lives in thread-local storage shared by the fibers: every fiber carries its own
+    s->cur = nx;
+    emu_ctx_switch(&s->f[me].sp, s->f[nx].sp);
+    threadIdx = t;
+}
+// next unfinished fiber after `me` inside [base, base + cnt); `me` itself if there is none
+inline int emu_next_in(EmuSched* s, int me, int base, int cnt) {
+    for (int k = 1; k <= cnt; ++k) {
+        const int c = base + (me - base + k) % cnt;
+        if (!s->f[c].done) return c;
+    }
+    return me;
+}
+inline void emu_yield_block() {
+    EmuSched* s = emu_sched();
+    emu_switch_to(s, emu_next_in(s, s->cur, 0, (int)s->f.size()));
+}
+inline void emu_yield_wave() {
+    EmuSched* s = emu_sched();
+    const int me = s->cur, base = me / 64 * 64, n = (int)s->f.size();
+    const int nx = emu_next_in(s, me, base, n - base < 64 ? n - base : 64);
+    if (nx != me) emu_switch_to(s, nx);
+    else emu_yield_block();                 // (the rest of the wave has exited: let the other waves run)
+}
+extern "C" inline void emu_fiber_main() {
+    EmuSched* s = emu_sched();
+    {
+        EmuFiber& me = s->f[s->cur];
+        me.fn(me.arg);
+        me.done = true;
+        s->alive -= 1;
+    }
+    void* dead = nullptr;
+    if (s->alive == 0) emu_ctx_switch(&dead, s->main_sp);
+    const int nx = emu_next_in(s, s->cur, 0, (int)s->f.size());
+    s->cur = nx;
+    emu_ctx_switch(&dead, s->f[nx].sp);
+    std::abort();                           // a finished fiber is never resumed
+}
+// run fn(args + t * stride) for t = 0 .. nthr - 1 as one workgroup; returns when every emulated thread has returned
+inline void emu_run_threads(int nthr, void* (*fn)(void*), void* args, size_t stride, size_t stack_bytes = 1 << 20) {
+    EmuSched sched;
+    sched.f.resize(nthr);
+    const size_t slot = (stack_bytes + 4095) / 4096 * 4096 + 4096;         // + a guard page below every stack
+    unsigned char* mem = static_cast<unsigned char*>(mmap(nullptr, slot * nthr, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0));
+    if (mem == MAP_FAILED) { std::perror("emu_run_threads: mmap"); std::abort(); }
+    for (int t = 0; t < nthr; ++t) {
+        mprotect(mem + slot * t, 4096, PROT_NONE);
+        uintptr_t top = reinterpret_cast<uintptr_t>(mem + slot * (t + 1)) & ~uintptr_t(15);
+        void** sp = reinterpret_cast<void**>(top);
+        *--sp = nullptr;                                        // (return address of emu_fiber_main: never used)
+        *--sp = reinterpret_cast<void*>(&emu_fiber_main);       // popped by the first switch's `ret`: rsp = top - 8 at entry, as after a call
+        for (int r = 0; r < 6; ++r) *--sp = nullptr;            // rbp rbx r12 r13 r14 r15
+        sched.f[t].sp = sp;
+        sched.f[t].fn = fn;
+        sched.f[t].arg = static_cast<unsigned char*>(args) + stride * t;
+    }
+    sched.alive = nthr;
+    sched.cur = 0;
+    EmuSched* outer = emu_sched();
+    emu_sched() = &sched;
+    const EmuDim3 t0 = threadIdx;
+    emu_ctx_switch(&sched.main_sp, sched.f[0].sp);
+    threadIdx = t0;
+    emu_sched() = outer;
+    munmap(mem, slot * nthr);
+}
+#else
+#include <vector>
+inline void emu_yield_block() { sched_yield(); }
+inline void emu_yield_wave() { sched_yield(); }
+inline void emu_run_threads(int nthr, void* (*fn)(void*), void* args, size_t stride, size_t stack_bytes = 1 << 20) {
+    std::vector<pthread_t> th(nthr);
+    pthread_attr_t attr;
+    pthread_attr_init(&attr);
+    pthread_attr_setstacksize(&attr, stack_bytes);
+    for (int t = 0; t < nthr; ++t) pthread_create(&th[t], &attr, fn, static_cast<unsigned char*>(args) + stride * t);
+    for (int t = 0; t < nthr; ++t) pthread_join(th[t], nullptr);
+    pthread_attr_destroy(&attr);
+}
+#endif
+
+// sense-reversing barrier; a waiter hands the processor on (fibers: to the next lane; pthreads: sched_yield -- with more
+// emulated threads than cores a futex barrier costs ~100 us, yielding ~10 us)
 struct EmuBarrier {
     std::atomic<int> count{0};
     std::atomic<int> generation{0};
     int parties = 1;
+    bool wave_scope = false;
     void init(int n) { parties = n; count = 0; generation = 0; }
     void wait() {
         const int gen = generation.load(std::memory_order_acquire);
         if (count.fetch_add(1, std::memory_order_acq_rel) + 1 == parties) {
             count.store(0, std::memory_order_relaxed);
             generation.store(gen + 1, std::memory_order_release);
+        } else if (wave_scope) {
+            while (generation.load(std::memory_order_acquire) == gen) emu_yield_wave();
         } else {
-            while (generation.load(std::memory_order_acquire) == gen) sched_yield();
+            while (generation.load(std::memory_order_acquire) == gen) emu_yield_block();
         }
     }
 };
@@ -56,6 +195,7 @@ struct EmuBlock {
     EmuBarrier block_barrier;
     EmuBarrier wave_barrier[EMU_MAX_WAVES];
     uint64_t xbuf[EMU_MAX_WAVES][EMU_WAVE];
+    EmuBlock() { for (auto& w : wave_barrier) w.wave_scope = true; }
 };
 extern EmuBlock* g_emu_block;
 

@@ -155,3 +155,45 @@ def test_every_module_of_the_package_and_tools_compiles():
     for f in sorted((root / "boxmot_amd").glob("*.py")):
         if f.stem != "__init__":
             importlib.import_module(f"boxmot_amd.{f.stem}")
+
+
+def test_frame_ring_close_refuses_while_host_views_are_held(monkeypatch):
+    """FrameRing.host_view hands out arrays that alias the ring's page-locked memory; close() frees it.  With a stand-in library
+    (plain host memory, no device) the wrapper's own logic is checked: a held view or slice blocks close(), dropping it unblocks."""
+    import ctypes
+
+    from boxmot_amd import ingest
+
+    class FakeLib:
+        def __init__(self):
+            self.bufs, self.destroyed = {}, 0
+
+        def boxmot_hip_ingest_create(self, n_slots, n_streams, rows, cols):
+            self.n = n_streams * rows * cols * 3
+            return 1
+
+        def boxmot_hip_ingest_host_ptr(self, h, slot, stream):
+            self.bufs.setdefault(slot, (ctypes.c_uint8 * self.n)())
+            return ctypes.addressof(self.bufs[slot])
+
+        def boxmot_hip_ingest_destroy(self, h):
+            self.destroyed += 1
+
+    fake = FakeLib()
+    monkeypatch.setattr(ingest._lib, "load", lambda: fake)
+    ring = ingest.FrameRing(2, 3, 4, 5)
+    ring.host_view(0)[...] = 7                      # temporaries do not count
+    assert ring.host_view(0).shape == (3, 4, 5, 3) and fake.bufs[0][0] == 7
+    held = ring.host_view(1)[2]                     # a slice: numpy hangs it on the slot's root array
+    with pytest.raises(RuntimeError, match="still referenced"):
+        ring.close()
+    assert fake.destroyed == 0
+    del held
+    whole = ring.host_view(0)
+    with pytest.raises(RuntimeError, match="still referenced"):
+        ring.close()
+    del whole
+    ring.close()
+    assert fake.destroyed == 1
+    ring.close()                                    # idempotent
+    assert fake.destroyed == 1

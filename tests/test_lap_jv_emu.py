@@ -37,12 +37,15 @@ def _cases(rng, n_cases):
         yield np.ascontiguousarray(c)
 
 
+N_CASES = {64: 72, 256: 30}
+
+
 @pytest.mark.parametrize("threads", [64, 256])
 def test_device_jv_returns_the_oracles_assignment_tie_for_tie(threads):
     lib = _lib(threads)
     rng = np.random.default_rng(7)
     n = 0
-    for c in _cases(rng, 72 if threads == 64 else 30):
+    for c in _cases(rng, N_CASES[threads]):
         nr, nc = c.shape
         for limit in (None, 0.5, 1.5):
             x = np.full(nr, -9, np.int32)
@@ -52,7 +55,7 @@ def test_device_jv_returns_the_oracles_assignment_tie_for_tie(threads):
             _, wx, wy = olap.lapjv(c, extend_cost=True, cost_limit=np.inf if limit is None else limit)
             assert np.array_equal(x, wx) and np.array_equal(y, wy), (c.shape, limit, c, x, wx)
             n += 1
-    assert n == 3 * (72 if threads == 64 else 30)
+    assert n == 3 * N_CASES[threads]
 
 
 def test_device_jv_larger_problem_with_ties():

@@ -45,8 +45,11 @@ def vit_flops(width=768, layers=12, tokens=129, patch_k=768, out_dim=512):
 
 
 def run(config: str = "c3", streams: int = 0, steps: int = 40, warmup: int = 8, check_frames: int = -1, reid_mode: int = 1,
-        with_ecc: bool = True) -> dict:
-    """One measurement; returns the result dict (bench.py calls this for its side lines)."""
+        with_ecc: bool = True, groups: int = 0) -> dict:
+    """One measurement; returns the result dict (bench.py calls this for its side lines).  `groups`: the streams are split over
+    that many handles, each with its own HIP stream (0 = 1) -- with 2, one group's frame step (a few workgroups: one per stream)
+    runs beside the other group's ReID kernels instead of after its own (configuration 3: 497 -> 541 frames/s; configuration 5:
+    no gain, the per-frame ECC estimate synchronises; profiles/r3_config_groups.jsonl).  The ReID-region timing is only clean with 1."""
     import torch
 
     from boxmot_amd import _lib
@@ -97,17 +100,41 @@ def run(config: str = "c3", streams: int = 0, steps: int = 40, warmup: int = 8, 
         mk, step_fn, sync, destroy = lib.boxmot_hip_strongsort_create, lib.boxmot_hip_strongsort_step_device_frames, \
             lib.boxmot_hip_strongsort_synchronize, lib.boxmot_hip_strongsort_destroy
         reid_ms, set_mode = lib.boxmot_hip_strongsort_reid_kernel_ms, lib.boxmot_hip_strongsort_set_reid_mode
-    cfg.n_streams, cfg.max_tracks, cfg.max_dets, cfg.emb_dim = S, cap, cap_nd, dim
+    G = max(1, min(groups or 1, S))
+    while S % G:
+        G -= 1
+    Sg = S // G
+    cfg.n_streams, cfg.max_tracks, cfg.max_dets, cfg.emb_dim = Sg, cap, cap_nd, dim
     cfg.reid_model_path = path.encode()
-    h = mk(ctypes.byref(cfg))
+    hs = []
+    for _ in range(G):
+        hg = mk(ctypes.byref(cfg))
+        if not hg:
+            raise RuntimeError(_lib.last_error())
+        if c3:
+            _lib.check(set_mode(hg, reid_mode))
+        hs.append(hg)
     os.unlink(path)
-    if not h:
-        raise RuntimeError(_lib.last_error())
-    if c3:
-        _lib.check(set_mode(h, reid_mode))
+    h = hs[0]
     d_out = torch.zeros((T, S, cap, 8), dtype=torch.float32, device=dev)
     d_out_n = torch.zeros((T, S), dtype=torch.int32, device=dev)
-    raw_step = lambda t: _lib.check(step_fn(h, d_dets[t].data_ptr(), d_cnt[t].data_ptr(), ptrs.data_ptr(), H, W, d_out[t].data_ptr(), d_out_n[t].data_ptr()))
+
+    def raw_step(t):        # asynchronous launches, group after group: group g's step kernel overlaps group g + 1's ReID kernels
+        for g, hg in enumerate(hs):
+            a, b = g * Sg, (g + 1) * Sg
+            _lib.check(step_fn(hg, d_dets[t, a:b].data_ptr(), d_cnt[t, a:b].data_ptr(), ptrs[a:b].data_ptr(), H, W,
+                               d_out[t, a:b].data_ptr(), d_out_n[t, a:b].data_ptr()))
+
+    def sync_all():
+        for hg in hs:
+            _lib.check(sync(hg))
+
+    def reid_ms_all():
+        tot, launches = 0.0, 0
+        for hg in hs:
+            _lib.check(reid_ms(hg, ctypes.byref(ms), ctypes.byref(nl)))
+            tot, launches = tot + ms.value, launches + nl.value
+        return tot, launches
     ecc = None
     if not c3 and with_ecc:
         # the reference's StrongSORT estimates camera motion with ECC on every frame that has tracks (strongsort.py:67, 83-86): the
@@ -122,19 +149,19 @@ def run(config: str = "c3", streams: int = 0, steps: int = 40, warmup: int = 8, 
         if ecc:
             for s in range(S):
                 _lib.check(lib.boxmot_hip_ecc_apply_device(ecc, s, frames[s].data_ptr(), warp.ctypes.data, ctypes.byref(iters)))
-                _lib.check(lib.boxmot_hip_strongsort_set_warp(h, s, warp.ctypes.data))
+                _lib.check(lib.boxmot_hip_strongsort_set_warp(hs[s // Sg], s % Sg, warp.ctypes.data))
         raw_step(t)
     ms, nl = ctypes.c_double(0), ctypes.c_int(0)
     for t in range(warmup):
         step(t)
-    _lib.check(sync(h))
-    _lib.check(reid_ms(h, ctypes.byref(ms), ctypes.byref(nl)))
+    sync_all()
+    reid_ms_all()           # (reading the counters resets them)
     t0 = time.perf_counter()
     for t in range(warmup, T):
         step(t)
-    _lib.check(sync(h))
+    sync_all()
     dt = time.perf_counter() - t0
-    _lib.check(reid_ms(h, ctypes.byref(ms), ctypes.byref(nl)))
+    reid_total_ms, reid_launches = reid_ms_all()
     crops = int(cnt_h[warmup:].sum())
     out_h, out_n = d_out.cpu().numpy(), d_out_n.cpu().numpy()
     # parity gates
@@ -176,16 +203,17 @@ def run(config: str = "c3", streams: int = 0, steps: int = 40, warmup: int = 8, 
             ok = ok and got.shape == want.shape and np.array_equal(np.sort(got[:, 4]), np.sort(want[:, 4]))
         gates["ids_first_frames_vs_oracle_stream0"] = bool(ok)
         gates["id_gate_frames"] = int(check)
-    destroy(h)
+    for hg in hs:
+        destroy(hg)
     if ecc:
         lib.boxmot_hip_ecc_destroy(ecc)
-    tfl = crops * flops_per_crop / (ms.value * 1e9) if ms.value > 0 else None
+    tfl = crops * flops_per_crop / (reid_total_ms * 1e9) if reid_total_ms > 0 else None
     return {
         "workload": ("DeepOCSORT + OSNet_x1_0 ReID, 128 dets x 512 tracks, 1080p" if c3 else
                      "StrongSORT + CLIP-ReID (ViT-B/16), 256 dets x 1024 tracks, 4K frames, 1280-d"),
-        "mode": "M2 reid-in-update, device-resident inputs" + ("" if c3 else (", ECC estimated per stream-frame on the device (static frames: converges at once)" if with_ecc else ", no camera-motion estimation")), "streams": S, "steps": steps, "warmup": warmup,
+        "mode": "M2 reid-in-update, device-resident inputs" + ("" if c3 else (", ECC estimated per stream-frame on the device (static frames: converges at once)" if with_ecc else ", no camera-motion estimation")), "streams": S, "stream_groups": G, "steps": steps, "warmup": warmup,
         "frames_per_s": S * steps / dt, "ms_per_step": 1e3 * dt / steps, "crops_per_step": crops / steps,
-        "reid_forward_ms_per_step": ms.value / steps, "reid_passes": nl.value, "gflop_per_crop": flops_per_crop / 1e9,
+        "reid_forward_ms_per_step": reid_total_ms / steps, "reid_passes": reid_launches, "gflop_per_crop": flops_per_crop / 1e9,
         "roofline": {"bound": "hbm (layer-per-launch fp16 kernels)" if c3 else "mfma", "achieved": tfl, "peak": 2500.0, "unit": "TFLOP/s",
                      "frac": (tfl / 2500.0) if tfl else None, "kernel": "ReID forward region (HIP events on the launch stream)"},
         "rows_stream0_last": int(out_n[-1, 0]), "dtype": "f16", **gates}
@@ -199,9 +227,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--check-frames", type=int, default=-1)
     ap.add_argument("--reid-mode", type=int, default=1)
+    ap.add_argument("--groups", type=int, default=0, help="handles (HIP streams) the streams are split over; 0 = 1")
     ap.add_argument("--no-ecc", action="store_true", help="c5: skip the per-frame ECC estimate (the reference's StrongSORT always runs it)")
     a = ap.parse_args()
-    print(json.dumps(run(a.config, a.streams, a.steps, a.warmup, a.check_frames, a.reid_mode, not a.no_ecc)), flush=True)
+    print(json.dumps(run(a.config, a.streams, a.steps, a.warmup, a.check_frames, a.reid_mode, not a.no_ecc, a.groups)), flush=True)
 
 
 if __name__ == "__main__":

@@ -16,6 +16,8 @@
 #   mfma       SQ_VALU_MFMA_BUSY_CYCLES pass on the same microbenchmark      -> mfma_busy.txt
 #   c3 / c5    tools/config_bench.py for configurations 3 / 5                 -> config_bench.jsonl
 #   soak       tools/parity_soak.py (all trackers, short)                     -> soak.log
+#   groups     tools/config_bench.py for configurations 3 and 5 with 1 and 2 stream groups (no id gate)     -> config_groups.jsonl
+#   ingest     tests/test_gpu_ingest.py                                        -> pytest_ingest.log
 #   hpab       every tools/_build/hp_prof_* binary (variants of the fp32-grade kernels built with -D switches) -> hp_ab.txt
 # Counters are collected in their own --pmc passes, never together with a trace (profiles/README.md).  Summaries a round wants
 # judged are copied from gpurun_out/<tag>/ into profiles/ by hand.
@@ -44,6 +46,13 @@ for step in "$@"; do
     c3)      timeout 600 python tools/config_bench.py --config c3 >> $O/config_bench.jsonl 2> $O/c3.err; tail -n 1 $O/config_bench.jsonl | cut -c1-900 ;;
     c5)      timeout 900 python tools/config_bench.py --config c5 >> $O/config_bench.jsonl 2> $O/c5.err; tail -n 1 $O/config_bench.jsonl | cut -c1-900 ;;
     soak)    timeout 900 python tools/parity_soak.py 10 200 > $O/soak.log 2>&1; tail -n 12 $O/soak.log ;;
+    groups)  timeout 800 python -c "
+import sys, json; sys.path.insert(0, 'tools'); import config_bench as cb
+for cfg, kw in (('c3', dict(steps=16, warmup=6)), ('c5', dict(steps=8, warmup=104))):
+    for g in (1, 2):
+        print(json.dumps(cb.run(cfg, check_frames=0, groups=g, **kw)), flush=True)
+" >> $O/config_groups.jsonl 2> $O/groups.err; cut -c1-420 $O/config_groups.jsonl ;;
+    ingest)  timeout 400 python -m pytest tests/test_gpu_ingest.py -q > $O/pytest_ingest.log 2>&1; tail -n 3 $O/pytest_ingest.log ;;
     hpab)    for b in tools/_build/hp_prof_*; do echo "## $b" >> $O/hp_ab.txt; timeout 120 $b 4096 5 >> $O/hp_ab.txt 2>&1; done; grep -c best $O/hp_ab.txt ;;
     *)       echo "unknown step $step" ;;
   esac
