@@ -495,7 +495,8 @@ private:
             hipLaunchKernelGGL(k_stem_hp, dim3(n), dim3(512), 0, st, crops_h_, crops_l_, act_a_, hact_al_, hw_stem_, d_count_);
         auto blk = [&](auto kernel, int lds, const _Float16* ih, const _Float16* il, _Float16* oh, _Float16* ol, int b,
                        const unsigned char* wtr, BlkLinkHP link) {
-            hipLaunchKernelGGL(kernel, dim3(n), dim3(512), lds, st, ih, il, oh, ol, hw_blk_[b], hbp_[b], d_count_, hx1s_, wtr, link);
+            const int stg = b / 2, nthr = 64 * (stg == 0 ? GeoHP<0>::NWAVES : (stg == 1 ? GeoHP<1>::NWAVES : GeoHP<2>::NWAVES));
+            hipLaunchKernelGGL(kernel, dim3(n), dim3(nthr), lds, st, ih, il, oh, ol, hw_blk_[b], hbp_[b], d_count_, hx1s_, wtr, link);
         };
         // stage 0: block 1 hands block 2 its conv1 result and its branch sum (fp32) instead of its 64-channel output
         blk(k_osblock_hp<0, 16, true, false, true, false>, GeoHP<0>::LDS_BYTES, act_a_, hact_al_, nullptr, nullptr, 0, nullptr,

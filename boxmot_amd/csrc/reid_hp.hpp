@@ -26,6 +26,13 @@
 #ifndef BM_HP_S2_WPS
 #define BM_HP_S2_WPS 4
 #endif
+// waves per workgroup in stages 0 / 1 (A/B switch): 8 = two waves per SIMD at <= 256 registers, 16 = four at <= 128
+#ifndef BM_HP_NW0
+#define BM_HP_NW0 8
+#endif
+#ifndef BM_HP_NW1
+#define BM_HP_NW1 8
+#endif
 #ifndef BM_HP_STAGGER
 #define BM_HP_STAGGER 0
 #endif
@@ -69,11 +76,11 @@ struct GeoHP {
     static constexpr int HID = MID / 16;
     static constexpr int COUT = STAGE == 0 ? 64 : (STAGE == 1 ? 96 : 128);
     static constexpr int NCT = COUT / 16;
-    static constexpr int NWAVES = 8;
-    static constexpr int NT = P / 16 / NWAVES;                       // 16, 4, 1 pixel tiles per wave
+    static constexpr int NWAVES = STAGE == 0 ? BM_HP_NW0 : (STAGE == 1 ? BM_HP_NW1 : 8);
+    static constexpr int NT = P / 16 / NWAVES;                       // 16, 4, 1 pixel tiles per wave (8 waves)
     // stages 0 / 1: one workgroup per CU (the fp32 image is 141 / 78 KiB): two waves per SIMD, 256 registers each;
     // stage 2: two workgroups per CU
-    static constexpr int WAVES_PER_SIMD = STAGE == 2 ? BM_HP_S2_WPS : 2;
+    static constexpr int WAVES_PER_SIMD = STAGE == 2 ? BM_HP_S2_WPS : NWAVES / 4;
     // stage 2 (8-pixel rows): compact pitch (10 pixels): 2-way conflicts between the two rows of a tile, but two workgroups per CU
     static constexpr int ROWP = STAGE == 0 ? 34 * 16 : (STAGE == 1 ? 18 * 16 : 160);
     static constexpr int PLANE = STAGE == 0 ? 141 * 256 : (STAGE == 1 ? 39 * 256 : 12 * 256);
@@ -189,7 +196,7 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
     BM_PROF_DECL();
 
     // this lane's pixel of tile 0 inside plane (ct = 0, g); tile i and channel tile ct add compile-time constants
-    const int y_l = STAGE == 0 ? wave * 8 : (STAGE == 1 ? wave * 4 : 2 * wave + (l16 >> 3));
+    const int y_l = STAGE == 0 ? wave * (NT / 2) : (STAGE == 1 ? wave * NT : 2 * wave + (l16 >> 3));
     const int x_l = STAGE == 2 ? (l16 & 7) : l16;
     const int pix0 = g * G::PLANE + (y_l + 1) * G::ROWP + (x_l + 1) * 16;
     auto tile_off = [](int i) constexpr { return STAGE == 0 ? (i >> 1) * G::ROWP + (i & 1) * 256 : (STAGE == 1 ? i * G::ROWP : 0); };

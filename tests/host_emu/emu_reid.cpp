@@ -319,7 +319,8 @@ int emu_reid_forward_hp(const float* blob, long n_floats, const uint8_t* frame, 
     float* x1p = x1s.data();
     auto blk = [&](auto kernel, const _Float16* ih, const _Float16* il, _Float16* oh, _Float16* ol, int b, const unsigned char* wtr, BlkLinkHP link) {
         const unsigned char* wp = wb[b].data(); const BlkPackHP bpb = bp[b];
-        launch(n, 1, 512, [=]() { kernel(ih, il, oh, ol, wp, bpb, nullptr, x1p, wtr, link); });
+        const int nthr = 64 * (stage[b] == 0 ? GeoHP<0>::NWAVES : (stage[b] == 1 ? GeoHP<1>::NWAVES : GeoHP<2>::NWAVES));
+        launch(n, 1, nthr, [=]() { kernel(ih, il, oh, ol, wp, bpb, nullptr, x1p, wtr, link); });
     };
     blk(k_osblock_hp<0, 16, true, false, true, false>, Ah.data(), Al.data(), nullptr, nullptr, 0, nullptr,
         BlkLinkHP{wb[1].data(), bp[1].conv1_a, bp[1].conv1_b, 0, x2s.data()});
