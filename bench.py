@@ -213,12 +213,11 @@ def side_configs():
         try:
             side[key] = config_bench.run(**kwargs)
             log(f"side line {key}: {side[key]['frames_per_s']:.1f} frames/s")
-            if key == "config3":
-                # the same workload with the streams split over two handles / HIP streams: one group's frame step (8 workgroups,
-                # 4.5 ms with the tie-exact assignment solver) runs beside the other group's ReID kernels.  Its own entry: the
-                # ReID-region timing (and the roofline figure above) is only clean when nothing else shares the GPU.
-                two = config_bench.run(**{**kwargs, "check_frames": 0, "groups": 2})
-                side[key]["two_stream_groups"] = {k: two[k] for k in ("stream_groups", "frames_per_s", "ms_per_step")}
+            # the same workload with the streams split over two handles / HIP streams: one group's frame step (a workgroup per
+            # stream; configuration 3: 4.5 ms with the tie-exact assignment solver) runs beside the other group's ReID kernels.
+            # Its own entry: the ReID-region timing (and the roofline figure above) is only clean when nothing else shares the GPU.
+            two = config_bench.run(**{**kwargs, "check_frames": 0, "groups": 2})
+            side[key]["two_stream_groups"] = {k: two[k] for k in ("stream_groups", "frames_per_s", "ms_per_step")}
         except Exception as exc:                    # a side line never takes the headline down
             side[key] = {"error": f"{type(exc).__name__}: {exc}"}
     return side

@@ -288,7 +288,15 @@ struct StreamIo {
     std::vector<std::pair<void*, size_t>> table_rec;
     std::vector<int> h_used;
     int n_grows = 0;
+    // device-resident steps upload pending warps from a small ring of staging slots (an event per slot): the host does not wait for
+    // the stream -- i.e. for the previous step's ReID pass -- every time a warp is set
+    static constexpr int WARP_SLOTS = 8;
+    std::vector<double> warp_stage[WARP_SLOTS];
+    std::vector<int> warp_flag_stage[WARP_SLOTS];
+    hipEvent_t warp_ev[WARP_SLOTS] = {};
+    unsigned warp_slot = 0;
     ~StreamIo() {
+        for (hipEvent_t e : warp_ev) if (e) (void)hipEventDestroy(e);
         reid.reset();
         for (void* p : owned) (void)hipFree(p);
         for (auto* p : frame_bufs) if (p) (void)hipFree(p);
@@ -953,10 +961,16 @@ bool io_consume_warps(StreamIo* h) {
     if (!any_warp) return false;
     for (int s = 0; s < h->S; ++s)
         if (!h->h_warp_flag[s]) { double* w = h->h_warp.data() + (size_t)s * 6; w[0] = 1; w[1] = 0; w[2] = 0; w[3] = 0; w[4] = 1; w[5] = 0; }
-    BM_HIP(hipMemcpyAsync(h->d_warp, h->h_warp.data(), (size_t)h->S * 6 * 8, hipMemcpyHostToDevice, h->stream));
-    BM_HIP(hipMemcpyAsync(h->d_warp_flag, h->h_warp_flag.data(), h->S * 4, hipMemcpyHostToDevice, h->stream));
-    // the staging vectors are reused by the next set_warp: the copies must have left the host before returning
-    BM_HIP(hipStreamSynchronize(h->stream));
+    // h_warp / h_warp_flag are rewritten by the next set_warp: the copies read a staging slot of their own, reused (after its event)
+    // eight steps later -- no wait for the stream here
+    const int k = (int)(h->warp_slot++ % StreamIo::WARP_SLOTS);
+    if (h->warp_ev[k]) BM_HIP(hipEventSynchronize(h->warp_ev[k]));
+    else BM_HIP(hipEventCreateWithFlags(&h->warp_ev[k], hipEventDisableTiming));
+    h->warp_stage[k].assign(h->h_warp.begin(), h->h_warp.begin() + (size_t)h->S * 6);
+    h->warp_flag_stage[k].assign(h->h_warp_flag.begin(), h->h_warp_flag.begin() + h->S);
+    BM_HIP(hipMemcpyAsync(h->d_warp, h->warp_stage[k].data(), (size_t)h->S * 6 * 8, hipMemcpyHostToDevice, h->stream));
+    BM_HIP(hipMemcpyAsync(h->d_warp_flag, h->warp_flag_stage[k].data(), h->S * 4, hipMemcpyHostToDevice, h->stream));
+    BM_HIP(hipEventRecord(h->warp_ev[k], h->stream));
     return true;
 }
 // after a device-resident step: pending warps are consumed, and the host no longer knows the track counts (io_make_room asks)
