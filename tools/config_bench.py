@@ -49,7 +49,7 @@ def run(config: str = "c3", streams: int = 0, steps: int = 40, warmup: int = 8, 
     """One measurement; returns the result dict (bench.py calls this for its side lines).  `groups`: the streams are split over
     that many handles, each with its own HIP stream (0 = 1) -- with 2, one group's frame step (a few workgroups: one per stream)
     runs beside the other group's ReID kernels instead of after its own (configuration 3: 497 -> 541 frames/s; configuration 5:
-    no gain, the per-frame ECC estimate synchronises; profiles/r3_config_groups.jsonl).  The ReID-region timing is only clean with 1."""
+    86 -> 92; profiles/r3_config_groups.jsonl).  The ReID-region timing is only clean with 1."""
     import torch
 
     from boxmot_amd import _lib

@@ -17,6 +17,7 @@
 #   c3 / c5    tools/config_bench.py for configurations 3 / 5                 -> config_bench.jsonl
 #   soak       tools/parity_soak.py (all trackers, short)                     -> soak.log
 #   groups     tools/config_bench.py for configurations 3 and 5 with 1 and 2 stream groups (no id gate)     -> config_groups.jsonl
+#   warps      the device-step warp, StrongSORT and ReID GPU tests                -> pytest_warps.log
 #   ingest     tests/test_gpu_ingest.py                                        -> pytest_ingest.log
 #   hpab       every tools/_build/hp_prof_* binary (variants of the fp32-grade kernels built with -D switches) -> hp_ab.txt
 # Counters are collected in their own --pmc passes, never together with a trace (profiles/README.md).  Summaries a round wants
@@ -52,6 +53,7 @@ for cfg, kw in (('c3', dict(steps=16, warmup=6)), ('c5', dict(steps=8, warmup=10
     for g in (1, 2):
         print(json.dumps(cb.run(cfg, check_frames=0, groups=g, **kw)), flush=True)
 " >> $O/config_groups.jsonl 2> $O/groups.err; cut -c1-420 $O/config_groups.jsonl ;;
+    warps)   timeout 600 python -m pytest tests/test_gpu_device_step_warps.py tests/test_gpu_strongsort.py tests/test_gpu_reid.py -q > $O/pytest_warps.log 2>&1; tail -n 3 $O/pytest_warps.log ;;
     ingest)  timeout 400 python -m pytest tests/test_gpu_ingest.py -q > $O/pytest_ingest.log 2>&1; tail -n 3 $O/pytest_ingest.log ;;
     hpab)    for b in tools/_build/hp_prof_*; do echo "## $b" >> $O/hp_ab.txt; timeout 120 $b 4096 5 >> $O/hp_ab.txt 2>&1; done; grep -c best $O/hp_ab.txt ;;
     *)       echo "unknown step $step" ;;
