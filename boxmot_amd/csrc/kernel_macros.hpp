@@ -52,6 +52,12 @@
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), \
                                      (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0)
 #endif
+#ifndef BM_GLDS4
+// the 4-byte form (global_load_lds_dword): LDS destination `lds_wave_base` + 4 * lane
+#define BM_GLDS4(gptr, lds_wave_base, lane) \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), \
+                                     (__attribute__((address_space(3))) void*)(lds_wave_base), 4, 0, 0)
+#endif
 #ifndef BM_WAIT_VM0
 // wait for this wave's outstanding vector-memory operations, BM_GLDS16 copies included: the compiler does not order a
 // global -> LDS copy against a later workgroup barrier, so the wave that issued copies waits here before the barrier that

@@ -1104,6 +1104,12 @@ __global__ void __launch_bounds__(512) k_stem_fused(const _Float16* __restrict__
 #ifndef BM_STEM_STREAM
 #define BM_STEM_STREAM 1
 #endif
+// BM_STEM_ASYNC = 1: the source rows of band b + 1 are requested by asynchronous global -> LDS copies (global_load_lds_dword)
+// right after the barrier that ends band b's resampling -- the staging area is idle from there to band b + 1's resampling -- and
+// land under band b's convolution phase: no registers, no exposed load latency per band (a register prefetch had cost 1.5 %).
+#ifndef BM_STEM_ASYNC
+#define BM_STEM_ASYNC 1
+#endif
 constexpr int RING_ROWS = 40;
 constexpr int RING_ROW_BYTES = STEM_COLS * 8;                    // 136 px * RGBX fp16
 constexpr int SRC_STAGE_BYTES = 20 * 1024;
@@ -1171,42 +1177,55 @@ __device__ __forceinline__ void stem_resize_fused_body(const uint8_t* const* fra
     BM_PROF_DECL();
     BM_PROF(0);
 
-#pragma unroll 1
-    for (int band = 0; band < 8; ++band) {
-        // padded input rows [pr0, pr1) are new in this band (padded row = resized row + 3)
-        const int pr0 = band == 0 ? 0 : 32 * band + 5, pr1 = 32 * band + 37 < STEM_ROWS ? 32 * band + 37 : STEM_ROWS;
-        const int dy0 = pr0 - 3 > 0 ? pr0 - 3 : 0, dy1 = pr1 - 3 < REID_IN_H ? pr1 - 3 : REID_IN_H;   // resized rows [dy0, dy1)
-        // ---- 1. stage the source rows of the band ----
-        int sy_lo = 0, sy_hi = -1, pitch = 0;
-        bool staged = false;
-        if (r.w > 0 && dy1 > dy0) {
-            if (identity) { sy_lo = dy0; sy_hi = dy1 - 1; }
-            else if (area2) { sy_lo = 2 * dy0; sy_hi = 2 * dy1 - 1; }
-            else { sy_lo = (int)(ytab[2 * dy0] & 0xffffu); sy_hi = (int)(ytab[2 * (dy1 - 1)] >> 16); }      // the table of vertical taps
-            const long byte0 = (long)r.x1 * 3;
-            pitch = ((3 + r.w * 3 + 3) / 4) * 4;          // room for the per-row alignment offset (0..3)
-            staged = (long)(sy_hi - sy_lo + 1) * pitch <= SRC_STAGE_BYTES;
-            if (staged) {
-                // wave w moves rows w, w + 8, ...: row addresses are wave-uniform (scalar unit), lanes take consecutive dwords
-                const int ndw = pitch / 4, nrow = sy_hi - sy_lo + 1;
-                const uint8_t* frame_end = frame + (long)H * row_stride;
-                for (int rr = wave; rr < nrow; rr += 8) {
-                    const uint8_t* rowp = frame + (long)(r.y1 + sy_lo + rr) * row_stride + byte0;
-                    const uint8_t* src0 = rowp - (reinterpret_cast<uintptr_t>(rowp) & 3);            // aligned dwords
-                    unsigned char* dst0 = stage + rr * pitch;
-                    for (int cw = lane; cw < ndw; cw += 64) {
-                        const uint8_t* src = src0 + 4 * cw;
-                        unsigned v;
-                        if (src + 4 <= frame_end) v = *reinterpret_cast<const unsigned*>(src);
-                        else {                                  // tail of the frame: stay inside the allocation
-                            v = 0;
-                            for (int q = 0; q < 4 && src + q < frame_end; ++q) v |= (unsigned)src[q] << (8 * q);
-                        }
-                        *reinterpret_cast<unsigned*>(dst0 + 4 * cw) = v;
-                    }
+    // geometry of a band: padded input rows [pr0, pr1) are new in it (padded row = resized row + 3) = resized rows [dy0, dy1),
+    // which read source rows [sy_lo, sy_hi] of the crop, staged at `pitch` bytes per row if they fit the staging area
+    struct BandGeom { int pr0, pr1, dy0, dy1, sy_lo, sy_hi, pitch; bool staged; };
+    auto band_geom = [&](int band) {
+        BandGeom b;
+        b.pr0 = band == 0 ? 0 : 32 * band + 5; b.pr1 = 32 * band + 37 < STEM_ROWS ? 32 * band + 37 : STEM_ROWS;
+        b.dy0 = b.pr0 - 3 > 0 ? b.pr0 - 3 : 0; b.dy1 = b.pr1 - 3 < REID_IN_H ? b.pr1 - 3 : REID_IN_H;
+        b.sy_lo = 0; b.sy_hi = -1; b.pitch = 0; b.staged = false;
+        if (r.w > 0 && b.dy1 > b.dy0) {
+            if (identity) { b.sy_lo = b.dy0; b.sy_hi = b.dy1 - 1; }
+            else if (area2) { b.sy_lo = 2 * b.dy0; b.sy_hi = 2 * b.dy1 - 1; }
+            else { b.sy_lo = (int)(ytab[2 * b.dy0] & 0xffffu); b.sy_hi = (int)(ytab[2 * (b.dy1 - 1)] >> 16); }      // the table of vertical taps
+            b.pitch = ((3 + r.w * 3 + 3) / 4) * 4;          // room for the per-row alignment offset (0..3)
+            b.staged = (long)(b.sy_hi - b.sy_lo + 1) * b.pitch <= SRC_STAGE_BYTES;
+        }
+        return b;
+    };
+    // ---- 1. stage the source rows of a band ----
+    auto stage_rows = [&](const BandGeom& b) {
+        if (!b.staged) return;
+        // wave w moves rows w, w + 8, ...: row addresses are wave-uniform (scalar unit), lanes take consecutive dwords
+        const long byte0 = (long)r.x1 * 3;
+        const int ndw = b.pitch / 4, nrow = b.sy_hi - b.sy_lo + 1;
+        const uint8_t* frame_end = frame + (long)H * row_stride;
+        for (int rr = wave; rr < nrow; rr += 8) {
+            const uint8_t* rowp = frame + (long)(r.y1 + b.sy_lo + rr) * row_stride + byte0;
+            const uint8_t* src0 = rowp - (reinterpret_cast<uintptr_t>(rowp) & 3);            // aligned dwords
+            unsigned char* dst0 = stage + rr * b.pitch;
+            for (int cw = lane; cw < ndw; cw += 64) {
+                const uint8_t* src = src0 + 4 * cw;
+                if (src + 4 <= frame_end) {
+                    if constexpr (BM_STEM_ASYNC) BM_GLDS4(src, dst0 + 4 * (cw - lane), lane);
+                    else *reinterpret_cast<unsigned*>(dst0 + 4 * cw) = *reinterpret_cast<const unsigned*>(src);
+                } else {                                  // tail of the frame: stay inside the allocation
+                    unsigned v = 0;
+                    for (int q = 0; q < 4 && src + q < frame_end; ++q) v |= (unsigned)src[q] << (8 * q);
+                    *reinterpret_cast<unsigned*>(dst0 + 4 * cw) = v;
                 }
             }
         }
+    };
+    if constexpr (BM_STEM_ASYNC) stage_rows(band_geom(0));
+#pragma unroll 1
+    for (int band = 0; band < 8; ++band) {
+        const BandGeom bg = band_geom(band);
+        const int pr0 = bg.pr0, pr1 = bg.pr1, sy_lo = bg.sy_lo, pitch = bg.pitch;
+        const bool staged = bg.staged;
+        if constexpr (BM_STEM_ASYNC) BM_WAIT_VM0();         // this wave's copies of the band's rows have landed
+        else stage_rows(bg);
         BM_PROF(1);
         __syncthreads();
         BM_PROF(2);
@@ -1314,6 +1333,7 @@ __device__ __forceinline__ void stem_resize_fused_body(const uint8_t* const* fra
         BM_PROF(3);
         __syncthreads();
         BM_PROF(4);
+        if constexpr (BM_STEM_ASYNC) { if (band + 1 < 8) stage_rows(band_geom(band + 1)); }     // the staging area is idle until then
 #if BM_STEM_STREAM
         // ---- 3. conv rows + pooling: strip t (16 conv pixels), pooled rows oy0 .. oy0 + 3 ----
         {

@@ -330,4 +330,5 @@ inline emu_f4 emu_mfma_f32_k4(float a, float b, emu_f4 c) {
 }
 #define BM_MFMA_F32_K4(a, b, c) emu_mfma_f32_k4(a, b, c)
 #define BM_WAVE_LDS_SYNC() g_emu_block->wave_barrier[threadIdx.x / EMU_WAVE].wait()
+#define BM_GLDS4(gptr, lds_wave_base, lane) std::memcpy(reinterpret_cast<unsigned char*>(lds_wave_base) + 4 * (lane), (gptr), 4)
 #define BM_GLDS16(gptr, lds_wave_base, lane) std::memcpy(reinterpret_cast<unsigned char*>(lds_wave_base) + 16 * (lane), (gptr), 16)

@@ -109,6 +109,14 @@ static void run_stem(int n, int iters, const bm::OsnetLayout& L, const std::vect
         if (ms < best) best = ms;
     }
     printf("stem_resize_fused_hp: n=%d best %.3f ms\n", n, best);
+    {   // order-independent checksum of the (hi, lo) output planes: equal across -D variants of the kernel = same results on the device
+        std::vector<unsigned short> oh((size_t)n * 2048 * 16), ol(oh.size());
+        CK(hipMemcpy(oh.data(), d_oh, oh.size() * 2, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(ol.data(), d_ol, ol.size() * 2, hipMemcpyDeviceToHost));
+        unsigned long long sum = 0;
+        for (size_t i = 0; i < oh.size(); ++i) sum += (unsigned long long)(oh[i] * 2654435761u + ol[i] * 40503u) * (i % 8191 + 1);
+        printf("    output checksum %016llx\n", sum);
+    }
 #ifdef BM_OSBLOCK_PROF
     unsigned long long zero[8] = {}, acc[8] = {};
     CK(hipMemcpyToSymbol(HIP_SYMBOL(bm::g_osblock_prof), zero, sizeof(zero)));
