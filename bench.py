@@ -146,11 +146,24 @@ def cpu_baseline(sd, mode, n_frames):
         if t_timed > 25.0:
             break
     n_frames = max(done, 1)
-    return dict(value=n_frames / max(t_timed, 1e-9), unit="frames/s", cores=cores, kind="port",
-                cpu_model=cpu_model, host_cores_total=total_cores,
-                sample=f"oracle (NumPy/SciPy BoT-SORT, one Python thread + torch-CPU OSNet-x0.25 on {cores} threads), stream 0, "
-                       f"{n_frames} steady-state frames after 3 confirmation frames, mode={mode}; host = {cpu_model}, "
-                       f"{total_cores} logical cores"), rows
+    out = dict(value=n_frames / max(t_timed, 1e-9), unit="frames/s", cores=cores, kind="port",
+               cpu_model=cpu_model, host_cores_total=total_cores,
+               sample=f"oracle (NumPy/SciPy BoT-SORT, one Python thread + torch-CPU OSNet-x0.25 on {cores} threads), stream 0, "
+                      f"{n_frames} steady-state frames after 3 confirmation frames, mode={mode}; host = {cpu_model}, "
+                      f"{total_cores} logical cores")
+    # The reference CLASSES cannot run on the GPU box (/root/reference does not travel).  Their timing on the same workload, taken
+    # in the build container by tools/reference_cpu_timing.py (a committed record, another host: NOT this run's measurement), is
+    # attached so that the port's figure can be set against the code it restates.
+    ref = ROOT / "profiles" / "r3_reference_cpu_timing.json"
+    if mode == "reid" and ref.exists():
+        try:
+            rec = json.loads(ref.read_text().strip().splitlines()[-1])
+            out["reference_classes_recorded_elsewhere"] = {
+                "value": rec["frames_per_s"], "unit": "frames/s", "cores": rec["torch_threads"], "kind": "reference",
+                "host": f"build container, {rec['host_logical_cores']} logical cores", "source": "profiles/r3_reference_cpu_timing.json"}
+        except Exception:
+            pass
+    return out, rows
 
 
 def m1_tracker_only(kw, dev, rank, streams=256):
