@@ -255,7 +255,8 @@ __global__ void __launch_bounds__(256) k_gemm_f16_glds(const _Float16* __restric
         }
     }
     for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();                    // tile kt has landed (the barrier drains the copies) and buffer (kt + 1) & 1 is free
+        BM_WAIT_VM0();                      // this wave's copies of tile kt have landed (explicit: the compiler orders a global -> LDS copy
+        __syncthreads();                    // against this wave's own LDS reads, not against the barrier) ... and buffer (kt + 1) & 1 is free
         if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
         const _Float16* sW = lds + (kt & 1) * 2 * TILE;
         const _Float16* sX = sW + TILE;
