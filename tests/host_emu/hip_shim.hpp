@@ -55,6 +55,26 @@ constexpr int EMU_MAX_WAVES = 16;
 #define EMU_PTHREADS 1
 #endif
 
+#if defined(EMU_DEFER_GLDS) && !defined(EMU_PTHREADS)
+#include <vector>
+struct EmuPendingCopy { unsigned char* dst; unsigned char src[16]; int bytes; unsigned tid; };
+inline std::vector<EmuPendingCopy>& emu_pending() { static thread_local std::vector<EmuPendingCopy> v; return v; }
+inline void emu_glds(const void* g, void* l, int bytes) {
+    EmuPendingCopy c;
+    c.dst = static_cast<unsigned char*>(l); std::memcpy(c.src, g, bytes); c.bytes = bytes; c.tid = threadIdx.x;
+    emu_pending().push_back(c);
+}
+inline void emu_complete_copies(bool all) {
+    auto& v = emu_pending();
+    size_t keep = 0;
+    for (size_t k = 0; k < v.size(); ++k) {
+        if (all || v[k].tid == threadIdx.x) std::memcpy(v[k].dst, v[k].src, v[k].bytes);
+        else v[keep++] = v[k];
+    }
+    v.resize(keep);
+}
+#endif
+
 #ifndef EMU_PTHREADS
 #include <sys/mman.h>
 
@@ -153,6 +173,9 @@ inline void emu_run_threads(int nthr, void* (*fn)(void*), void* args, size_t str
     emu_ctx_switch(&sched.main_sp, sched.f[0].sp);
     threadIdx = t0;
     emu_sched() = outer;
+#ifdef EMU_DEFER_GLDS
+    emu_complete_copies(true);              // copies nobody waited for land at the end of the workgroup
+#endif
     munmap(mem, slot * nthr);
 }
 #else
@@ -252,7 +275,6 @@ inline double __dmul_rn(double a, double b) { return a * b; }
 #define BM_EXPF(x) expf(x)
 #define BM_SCHED_FENCE() ((void)0)
 #define BM_SETPRIO(n) ((void)0)
-#define BM_WAIT_VM0() ((void)0)
 #define BM_RESID_F16(hp, hi, v, out) do { unsigned short b_ = (unsigned short)((hp) >> (16 * (hi))); _Float16 h_; std::memcpy(&h_, &b_, 2); (out) = (v) - (float)h_; } while (0)
 #define BM_RCPF(x) (1.0f / (x))
 #define BM_OPAQUE_U32(x) ((void)0)
@@ -330,5 +352,21 @@ inline emu_f4 emu_mfma_f32_k4(float a, float b, emu_f4 c) {
 }
 #define BM_MFMA_F32_K4(a, b, c) emu_mfma_f32_k4(a, b, c)
 #define BM_WAVE_LDS_SYNC() g_emu_block->wave_barrier[threadIdx.x / EMU_WAVE].wait()
-#define BM_GLDS4(gptr, lds_wave_base, lane) std::memcpy(reinterpret_cast<unsigned char*>(lds_wave_base) + 4 * (lane), (gptr), 4)
+// Asynchronous global -> LDS copies (BM_GLDS16 / BM_GLDS4) and the wait that completes them (BM_WAIT_VM0).
+// Default: the copy happens at once.  EMU_DEFER_GLDS (fiber mode): the copy is only QUEUED and lands when the issuing thread
+// executes BM_WAIT_VM0 -- the latest moment the hardware allows -- so a kernel that publishes such data through a barrier without
+// waiting first reads the launcher's LDS poison here too (a workgroup barrier does not complete anybody's copies).
+// EMU_NO_VM_WAIT turns the wait into nothing: the negative control of that check.
+#if defined(EMU_DEFER_GLDS) && !defined(EMU_PTHREADS)
+#define BM_GLDS16(gptr, lds_wave_base, lane) emu_glds((gptr), reinterpret_cast<unsigned char*>(lds_wave_base) + 16 * (lane), 16)
+#define BM_GLDS4(gptr, lds_wave_base, lane) emu_glds((gptr), reinterpret_cast<unsigned char*>(lds_wave_base) + 4 * (lane), 4)
+#ifdef EMU_NO_VM_WAIT
+#define BM_WAIT_VM0() ((void)0)
+#else
+#define BM_WAIT_VM0() emu_complete_copies(false)
+#endif
+#else
 #define BM_GLDS16(gptr, lds_wave_base, lane) std::memcpy(reinterpret_cast<unsigned char*>(lds_wave_base) + 16 * (lane), (gptr), 16)
+#define BM_GLDS4(gptr, lds_wave_base, lane) std::memcpy(reinterpret_cast<unsigned char*>(lds_wave_base) + 4 * (lane), (gptr), 4)
+#define BM_WAIT_VM0() ((void)0)
+#endif

@@ -19,7 +19,8 @@ def _build():
     deps = [HERE / "emu_clip.cpp", HERE / "hip_shim.hpp", csrc / "clip_kernels.hpp", csrc / "reid_pack.hpp", csrc / "kernel_macros.hpp"]
     if not out.exists() or any(d.stat().st_mtime > out.stat().st_mtime for d in deps):
         subprocess.check_call([CLANG, "-x", "c++", "-std=c++17", "-O1", "-fPIC", "-shared", "-pthread",
-                               "-ffp-contract=off", "-o", str(out), str(HERE / "emu_clip.cpp")])
+                               "-ffp-contract=off", "-DEMU_DEFER_GLDS=1",       # global -> LDS copies land at the issuing thread's BM_WAIT_VM0 (hip_shim.hpp)
+                               "-o", str(out), str(HERE / "emu_clip.cpp")])
     return out
 
 

@@ -13,12 +13,16 @@ HERE = Path(__file__).resolve().parent / "host_emu"
 CLANG = shutil.which("clang++", path="/opt/rocm/lib/llvm/bin") or shutil.which("clang++")
 
 
-def _build():
-    out = HERE / "libemu_reid.so"
+def _build(no_vm_wait=False):
+    """The kernels' asynchronous global -> LDS copies are emulated in their latest-completion form (EMU_DEFER_GLDS, hip_shim.hpp):
+    the data lands when the issuing thread executes BM_WAIT_VM0, not at the copy and not at a barrier.  no_vm_wait: the wait does
+    nothing -- the negative control of that check."""
+    out = HERE / ("libemu_reid_nowait.so" if no_vm_wait else "libemu_reid.so")
     deps = [HERE / "emu_reid.cpp", HERE / "hip_shim.hpp"] + list((HERE.parent.parent / "boxmot_amd" / "csrc").glob("*.hpp"))
     if not out.exists() or any(d.stat().st_mtime > out.stat().st_mtime for d in deps):
         subprocess.check_call([CLANG, "-x", "c++", "-std=c++17", "-O1", "-fPIC", "-shared", "-pthread",
-                               "-ffp-contract=off", "-o", str(out), str(HERE / "emu_reid.cpp")])
+                               "-ffp-contract=off", "-DEMU_DEFER_GLDS=1", *(["-DEMU_NO_VM_WAIT=1"] if no_vm_wait else []),
+                               "-o", str(out), str(HERE / "emu_reid.cpp")])
     return out
 
 
@@ -234,3 +238,33 @@ def test_fp32_grade_fused_family_emulated_vs_oracle(weights, fused_stem):
     print(f"{weights} embeddings: max|diff| {err:.2e}")
     assert err < 1e-4                       # north_star tolerance 1e-3; fp32-grade arithmetic
     assert np.allclose(np.linalg.norm(feats, axis=1), 1.0, atol=1e-5)
+
+
+@pytest.mark.skipif(CLANG is None, reason="needs a host clang with _Float16")
+def test_missing_wait_for_an_asynchronous_lds_copy_is_caught_by_the_emulation():
+    """Negative control of the deferred-copy emulation: the same fp32-grade kernels with BM_WAIT_VM0 compiled to nothing publish
+    their staged weights / source rows through barriers without waiting for them -- the embeddings must come out wrong (the launcher
+    poisons LDS).  With the waits in place the same build flags give the oracle's embeddings
+    (test_fp32_grade_fused_family_emulated_vs_oracle runs on that library)."""
+    import torch
+
+    from boxmot_amd.reid_weights import pack_osnet, random_osnet_state_dict
+    from oracle.crops import get_crops
+    from oracle.osnet import osnet_forward
+
+    lib = ctypes.CDLL(str(_build(no_vm_wait=True)))
+    lib.emu_reid_forward_hp.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                        ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    sd = random_osnet_state_dict("osnet_x0_25", seed=0)
+    blob = pack_osnet(sd)
+    img = np.random.default_rng(5).integers(0, 255, (480, 641, 3), dtype=np.uint8)
+    boxes = np.array([[30.2, 40.7, 90.1, 200.3]], dtype=np.float32)
+    feats = np.zeros((1, 512), np.float32)
+    shapes = [(2048, 16), (2048, 64), (2048, 64), (512, 64), (512, 96), (512, 96), (128, 96), (128, 128), (128, 128)]
+    bufs = [np.zeros((1,) + s, np.float32) for s in shapes]
+    ptrs = (ctypes.c_void_p * 9)(*[b.ctypes.data for b in bufs])
+    assert lib.emu_reid_forward_hp(blob.ctypes.data, blob.size, img.ctypes.data, 641, 480, boxes.ctypes.data, 1, feats.ctypes.data, ptrs, 1) == 0
+    want = osnet_forward(sd, torch.from_numpy(get_crops(boxes, img))).numpy()
+    want = want / np.linalg.norm(want, axis=1, keepdims=True)
+    err = np.abs(feats - want).max()
+    assert not (err < 1e-3), f"the emulation did not notice the missing waits (max|diff| {err})"
