@@ -13,15 +13,16 @@ HERE = Path(__file__).resolve().parent / "host_emu"
 CLANG = shutil.which("clang++", path="/opt/rocm/lib/llvm/bin") or shutil.which("clang++")
 
 
-def _build(no_vm_wait=False):
+def _build(no_vm_wait=False, immediate=False):
     """The kernels' asynchronous global -> LDS copies are emulated in their latest-completion form (EMU_DEFER_GLDS, hip_shim.hpp):
-    the data lands when the issuing thread executes BM_WAIT_VM0, not at the copy and not at a barrier.  no_vm_wait: the wait does
-    nothing -- the negative control of that check."""
-    out = HERE / ("libemu_reid_nowait.so" if no_vm_wait else "libemu_reid.so")
+    the data lands when the issuing thread executes BM_WAIT_VM0, not at the copy and not at a barrier (a missing wait shows).
+    immediate: the earliest-completion form -- the data lands at the copy (a copy issued while another wave still reads the
+    destination shows).  no_vm_wait: the wait does nothing -- the negative control of the first check."""
+    out = HERE / ("libemu_reid_nowait.so" if no_vm_wait else ("libemu_reid_immediate.so" if immediate else "libemu_reid.so"))
     deps = [HERE / "emu_reid.cpp", HERE / "hip_shim.hpp"] + list((HERE.parent.parent / "boxmot_amd" / "csrc").glob("*.hpp"))
     if not out.exists() or any(d.stat().st_mtime > out.stat().st_mtime for d in deps):
-        subprocess.check_call([CLANG, "-x", "c++", "-std=c++17", "-O1", "-fPIC", "-shared", "-pthread",
-                               "-ffp-contract=off", "-DEMU_DEFER_GLDS=1", *(["-DEMU_NO_VM_WAIT=1"] if no_vm_wait else []),
+        subprocess.check_call([CLANG, "-x", "c++", "-std=c++17", "-O1", "-fPIC", "-shared", "-pthread", "-ffp-contract=off",
+                               *([] if immediate else ["-DEMU_DEFER_GLDS=1"]), *(["-DEMU_NO_VM_WAIT=1"] if no_vm_wait else []),
                                "-o", str(out), str(HERE / "emu_reid.cpp")])
     return out
 
@@ -191,9 +192,10 @@ def test_batched_head_equals_per_crop_head_and_oracle_emulated():
     assert np.abs(fb[rows[:count]] - want[:count]).max() < 1e-3
 
 
-@pytest.mark.parametrize("weights,fused_stem", [("init", 1), ("calib0", 1), ("calib1", 0), ("calib2", 1)])
+@pytest.mark.parametrize("weights,fused_stem,immediate", [("init", 1, False), ("calib0", 1, False), ("calib1", 0, False), ("calib2", 1, False),
+                                                          ("calib0", 1, True)])
 @pytest.mark.skipif(CLANG is None, reason="needs a host clang with _Float16")
-def test_fp32_grade_fused_family_emulated_vs_oracle(weights, fused_stem):
+def test_fp32_grade_fused_family_emulated_vs_oracle(weights, fused_stem, immediate):
     """fused_stem = 1: crop + resize + stem in one kernel on raw pixel values with the normalisation folded into (hi, lo) weights
     (k_stem_resize_fused_hp, the engine's default); 0: crop kernel + k_stem_hp on (hi, lo) normalised planes (resize_pad path).
     The fp32-grade fused family (reid_hp.hpp, ReID mode 2: fp16 (hi, lo) operand pairs, fp32 image / depthwise / gates) on CPU
@@ -206,7 +208,7 @@ def test_fp32_grade_fused_family_emulated_vs_oracle(weights, fused_stem):
     from oracle.crops import get_crops
     from oracle.osnet import osnet_forward
 
-    lib = ctypes.CDLL(str(_build()))
+    lib = ctypes.CDLL(str(_build(immediate=immediate)))
     lib.emu_reid_forward_hp.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                         ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
     sd = reference_init_state_dict("osnet_x0_25", seed=0) if weights == "init" else random_osnet_state_dict("osnet_x0_25", seed=int(weights[-1]))
