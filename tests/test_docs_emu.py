@@ -75,6 +75,13 @@ def test_emulated_deepocsort_c2_shape():
     _run(sc.frames(8), 64, 512, 256)
 
 
+def test_emulated_deepocsort_c3_shape():
+    """BASELINE configuration 3's shape -- 128 detections, 512 live tracks, eight wavefronts -- for ten frames: the assignment is
+    a 640 x 640 extended problem per association round (fibers make this a seconds-long CPU test)."""
+    sc = Scenario(128, 512, emb_dim=64, random_image=False)
+    _run(sc.frames(10), 64, 1024, 512, threads=512)
+
+
 def test_emulated_kernels_clean_under_asan():
     """Same device source under AddressSanitizer / UBSan (index lists, LDS carving, scratch sizing)."""
     import ctypes.util

@@ -68,6 +68,13 @@ def test_emulated_strongsort_c2_shape():
     _run(sc.frames(6), 64, 512, 256, nn_budget=4)
 
 
+def test_emulated_strongsort_c5_shape():
+    """BASELINE configuration 5's table sizes -- 256 detections, 1024 live tracks -- for four frames, four wavefronts (embedding width
+    128 instead of 1280: the width only scales the dot products)."""
+    sc = Scenario(256, 1024, emb_dim=128, random_image=False)
+    _run(sc.frames(4), 128, 2048, 1024, nn_budget=4, threads=256)
+
+
 @pytest.mark.parametrize("threads", [64, 256])
 def test_device_assignment_solver_equals_scipy_incl_ties(threads):
     """lsa_scipy restates SciPy's rectangular_lsap.cpp; tie-heavy matrices (clamped costs) must give the same columns.
