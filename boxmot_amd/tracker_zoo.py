@@ -40,6 +40,8 @@ OCSORT_YAML_DEFAULTS = dict(min_conf=0.1, det_thresh=0.6, max_age=30, min_hits=3
 # boxmot/configs/trackers/bytetrack.yaml defaults
 BYTETRACK_YAML_DEFAULTS = dict(min_conf=0.1, track_thresh=0.6, match_thresh=0.9, track_buffer=30, frame_rate=30)
 SUPPORTED = ("botsort", "bytetrack", "deepocsort", "ocsort", "strongsort")
+# the names of the reference's TRACKER_MAPPING (tracker_zoo.py:14-25): the ones not in SUPPORTED are known but not built here
+REFERENCE_TRACKERS = SUPPORTED + ("sfsort", "hybridsort", "boosttrack", "occluboost", "sam2mot")
 
 
 def flatten_yaml_config(cfg: dict) -> dict:
@@ -65,6 +67,8 @@ def create_tracker(tracker_type: str = "botsort", tracker_config=None, reid_weig
     if tracker_backend != "hip":
         raise ValueError(f"tracker_backend={tracker_backend!r}: boxmot_amd provides the 'hip' backend only")
     if tracker_type not in SUPPORTED:
+        if tracker_type not in REFERENCE_TRACKERS:      # tracker_zoo.py:103-105: a name the reference does not know either
+            raise ValueError(f"Unknown tracker type: '{tracker_type}'. Available trackers are: {', '.join(SUPPORTED)}")
         raise NotImplementedError(f"tracker {tracker_type!r} is not implemented on the HIP backend (have: {SUPPORTED})")
     if reid_preprocess not in (None, "resize", "resize_pad"):
         raise ValueError(f"Unknown preprocess '{reid_preprocess}'. Available: ['resize', 'resize_pad']")   # preprocessing.py:60-64
