@@ -54,19 +54,35 @@ FLOP_PER_CROP = 2 * 82_314_880          # OSNet x0.25 forward, BASELINE.md secti
 # here (separate --pmc passes, gfx950 FETCH correction applied by profiles/summarize_pmc.py) -- counters cannot be collected
 # inside a timed run, so the line carries the profile's figure and says which file it came from
 # one committed profile per kernel family (mode): fused fp32-grade (2), fused fp16 (1)
-TRAFFIC_PROFILES = {2: ("profiles/r3_pmc_traffic_final.txt", "profiles/r3_pmc_traffic_hp.txt"),
-                    1: ("profiles/r3_pmc_traffic.txt", "profiles/r2_pmc_traffic.txt", "profiles/r1h_pmc_traffic.txt")}
+TRAFFIC_PROFILES = {2: ("profiles/r4_pmc_traffic_final.txt", "profiles/r3_pmc_traffic_final.txt", "profiles/r3_pmc_traffic_hp.txt"),
+                    1: ("profiles/r4_pmc_traffic_m1.txt", "profiles/r3_pmc_traffic.txt", "profiles/r2_pmc_traffic.txt", "profiles/r1h_pmc_traffic.txt")}
+
+
+def library_source_hash():
+    """The source hash __graft_entry__.build() recorded next to the library that is loaded (libboxmot_hip.so.buildinfo)."""
+    try:
+        return json.loads((ROOT / "boxmot_amd" / "libboxmot_hip.so.buildinfo").read_text()).get("source_hash")
+    except Exception:
+        return None
 
 
 def profile_traffic_bytes_per_crop(mode):
+    """(bytes per crop, profile file, stale): the PMC figure of the newest committed profile of this kernel family.  A profile
+    carries the source hash of the library it was taken with (`# source_hash: ...`, written by tools/gpu_session.sh); when that
+    differs from the loaded library's -- the kernels changed and nobody re-profiled -- the figure is NOT reported (stale = True)."""
     import re
+    have = library_source_hash()
     for rel in TRAFFIC_PROFILES.get(mode, ()):
         f = ROOT / rel
         if f.exists():
-            m = re.search(r"->\s*([0-9.]+)\s*KB per crop", f.read_text())
+            txt = f.read_text()
+            m = re.search(r"->\s*([0-9.]+)\s*KB per crop", txt)
             if m:
-                return float(m.group(1)) * 1024.0, rel
-    return None, None
+                h = re.search(r"source_hash:\s*([0-9a-f]+)", txt)
+                if not h or have is None or h.group(1) != have:
+                    return None, rel, True
+                return float(m.group(1)) * 1024.0, rel, False
+    return None, None, False
 
 
 # Dense matrix-pipe peak the ReID region is priced against, per kernel family.  Mode 2 (fp32-grade fused kernels) computes its wide
@@ -95,6 +111,9 @@ def parse(argv=None):
     ap.add_argument("--no-m1", action="store_true", help="skip the tracker-math-only (embeddings supplied) side measurement")
     ap.add_argument("--no-side-configs", action="store_true",
                     help="skip the short side measurements of BASELINE.json configurations 3 and 5 (tools/config_bench.py)")
+    ap.add_argument("--side-budget-s", type=float, default=300.0,
+                    help="wall budget of the side measurements (configurations 3 and 5, child processes): what does not fit is "
+                         "reported as skipped / timed out, the headline line is printed regardless")
     ap.add_argument("--cpu-frames", type=int, default=10)
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--stub-tracker", action="store_true",
@@ -214,26 +233,35 @@ def m1_tracker_only(kw, dev, rank, streams=256):
                               "note": "32 of 256 CUs busy: the latency of one workgroup's phase chain, not a throughput"}}
 
 
-def side_configs():
+def side_configs(budget_s):
     """BASELINE.json's other single-GPU configurations, measured briefly on the same box (never part of `value`): ReID inside update,
-    frames and detections resident in HBM, each with an embedding gate and an id gate against the oracle tracker."""
-    sys.path.insert(0, str(ROOT / "tools"))
-    import config_bench
+    frames and detections resident in HBM, each with an embedding gate and a 16-frame id gate against the oracle tracker, with one
+    and with two stream groups (both gated against the same oracle rows).  Each configuration runs in a CHILD process
+    (tools/config_bench.py --both-groups) under a share of the wall budget: a hang or a crash there costs that side line, not the
+    headline."""
+    import subprocess
     side = {}
-    for key, kwargs in (("config3", dict(config="c3", streams=8, steps=16, warmup=6, check_frames=8)),
-                        # configuration 5: 104 warm-up frames fill every sample bank (nn_budget 100), so the timed steps are steady state
-                        ("config5", dict(config="c5", streams=2, steps=8, warmup=104, check_frames=4))):
+    t_end = time.time() + budget_s
+    plan = (("config3", ["--config", "c3", "--streams", "8", "--steps", "16", "--warmup", "6", "--check-frames", "16", "--reid-mode", "2"]),
+            # configuration 5: 104 warm-up frames fill every sample bank (nn_budget 100), so the timed steps are steady state
+            ("config5", ["--config", "c5", "--streams", "2", "--steps", "8", "--warmup", "104", "--check-frames", "16"]))
+    for i, (key, args) in enumerate(plan):
+        left = t_end - time.time()
+        share = left / (len(plan) - i)
+        if share < 20:
+            side[key] = {"error": f"skipped: {left:.0f} s of the side budget left"}
+            continue
         try:
-            side[key] = config_bench.run(**kwargs)
+            cp = subprocess.run([sys.executable, str(ROOT / "tools" / "config_bench.py"), *args, "--both-groups"],
+                                capture_output=True, text=True, timeout=share)
+            lines = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+            if cp.returncode != 0 or not lines:
+                side[key] = {"error": f"rc {cp.returncode}: {cp.stderr.strip()[-300:]}"}
+                continue
+            side[key] = json.loads(lines[-1])
             log(f"side line {key}: {side[key]['frames_per_s']:.1f} frames/s")
-            # the same workload with the streams split over two handles / HIP streams: one group's frame step (a workgroup per
-            # stream; configuration 3: 4.5 ms with the tie-exact assignment solver) runs beside the other group's ReID kernels.
-            # Its own entry: the ReID-region timing (and the roofline figure above) is only clean when nothing else shares the GPU.
-            try:
-                two = config_bench.run(**{**kwargs, "check_frames": 0, "groups": 2, "embedding_gate": False})      # timing only: gated above
-                side[key]["two_stream_groups"] = {k: two[k] for k in ("stream_groups", "frames_per_s", "ms_per_step")}
-            except Exception as exc:                # (never takes the gated one-group line down)
-                side[key]["two_stream_groups"] = {"error": f"{type(exc).__name__}: {exc}"}
+        except subprocess.TimeoutExpired:
+            side[key] = {"error": f"timed out after {share:.0f} s (--side-budget-s)"}
         except Exception as exc:                    # a side line never takes the headline down
             side[key] = {"error": f"{type(exc).__name__}: {exc}"}
     return side
@@ -392,8 +420,13 @@ def main(argv=None):
             g.build()           # rank 0 compiles (or verifies the recorded source hash); the others wait at the barrier and reuse
         if world > 1:
             torch.cuda.set_device(local)
-            dist.init_process_group(a.backend)
-            dist.barrier()
+            # bind this rank's communicator to ITS GPU before the first collective (RCCL otherwise picks the device lazily)
+            if a.backend == "nccl":
+                dist.init_process_group(a.backend, device_id=torch.device("cuda", local))
+                dist.barrier(device_ids=[local])
+            else:
+                dist.init_process_group(a.backend)
+                dist.barrier()
         else:
             torch.cuda.set_device(0)
         if rank != 0:
@@ -543,11 +576,11 @@ def main(argv=None):
             pass                                            # control-flow test: nothing below is a measurement
         elif a.mode == "reid" and reid_ms > 0:
             tflops = n_first * FLOP_PER_CROP / (reid_ms * 1e-3) / 1e12
-            per_crop, traffic_src = profile_traffic_bytes_per_crop(a.reid_mode)
+            per_crop, traffic_src, traffic_stale = profile_traffic_bytes_per_crop(a.reid_mode)
             res["roofline"] = {"bound": "mfma", "achieved": tflops, "peak": PEAK_TFLOPS[a.reid_mode], "unit": "TFLOP/s",
                                "frac": tflops / PEAK_TFLOPS[a.reid_mode],
                                "traffic": per_crop * n_first / max(reid_launches, 1) if per_crop else None,
-                               "traffic_source": traffic_src,
+                               "traffic_source": traffic_src, "traffic_stale": traffic_stale,
                                "kernel": "OSNet-x0.25 forward (ReID) region, HIP events on the launch stream",
                                "launch_ms": reid_ms / max(reid_launches, 1), "crops_per_launch": n_first / max(reid_launches, 1)}
         else:
@@ -560,12 +593,6 @@ def main(argv=None):
         groups = []
         if stub:
             a.no_m1 = a.no_side_configs = a.no_cpu_baseline = True
-        if world == 1 and a.mode == "reid" and not a.no_m1:
-            res["tracker_math_m1"] = m1_tracker_only(kw, dev, rank, a.streams)
-        if world == 1 and a.mode == "reid" and not a.no_side_configs:
-            res["other_configs"] = side_configs()
-        if world == 1 and a.mode == "reid" and not a.no_side_configs and a.reid_mode != 1:
-            res["fp16_family_line"] = alt_family_line(kw, sd, dev, 1)
         if not a.no_cpu_baseline:
             # the oracle on stream 0: at N = 1 timed as the CPU baseline (the contract); at every N the id parity gate
             cb, rows = cpu_baseline(sd, a.mode, a.cpu_frames if world == 1 else min(a.cpu_frames, 4))
@@ -576,8 +603,26 @@ def main(argv=None):
                 got = out_h[t, 0, : out_n_h[t, 0]]
                 ok &= got.shape == rows[t].shape and bool(np.array_equal(got[:, 4:], rows[t][:, 4:]))
             res["config"]["parity_ids_exact_vs_oracle_stream0"] = bool(ok)
+            res["config"]["parity_id_gate_frames"] = int(min(len(rows), T))
             if a.mode == "reid":
                 res["config"].update(reid_parity_gates(sd, a.reid_mode))
+        # the headline with its gates, as soon as they exist (stderr; the ONE stdout line stays last): what follows are side
+        # measurements under a wall budget, none of which can change or lose these fields
+        log("headline (gates done): " + json.dumps({k: res[k] for k in res if k not in ("tracker_math_m1", "other_configs", "fp16_family_line")}))
+        if world == 1 and a.mode == "reid" and not a.no_m1:
+            try:
+                res["tracker_math_m1"] = m1_tracker_only(kw, dev, rank, a.streams)
+            except Exception as exc:
+                res["tracker_math_m1"] = {"error": f"{type(exc).__name__}: {exc}"}
+        if world == 1 and a.mode == "reid" and not a.no_side_configs and a.reid_mode != 1:
+            try:
+                res["fp16_family_line"] = alt_family_line(kw, sd, dev, 1)
+            except Exception as exc:
+                res["fp16_family_line"] = {"error": f"{type(exc).__name__}: {exc}"}
+        if world == 1 and a.mode == "reid" and not a.no_side_configs:
+            del d_frames, d_out, d_dets                # the child processes get the memory
+            torch.cuda.empty_cache()
+            res["other_configs"] = side_configs(a.side_budget_s)
         print(json.dumps(res))
     for m in groups:
         m.close()

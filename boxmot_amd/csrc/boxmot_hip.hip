@@ -209,6 +209,7 @@ struct BoxMOTHipIngest {
 struct BoxMOTHipBotSort {
     BoxMOTHipBotSortConfig cfg{};
     std::string reid_path;
+    std::vector<float> reid_blob;            // host copy of the weight blob the engine was built from (path or set_reid_blob): growth rebuilds from it
     bm::BotSortStepArgs args{};
     std::vector<void*> owned;
     hipStream_t stream = nullptr;
@@ -268,6 +269,7 @@ struct BoxMOTHipBotSort {
 // the frames and ReID engine for "embeddings not supplied", pending camera-motion warps, result read-back.
 struct StreamIo {
     std::string reid_path;
+    std::vector<float> reid_blob;            // host copy of the weight blob (see BoxMOTHipBotSort::reid_blob)
     std::vector<void*> owned;
     hipStream_t stream = nullptr;
     int S = 1, cap = 0, nd = 0, dim = 0;
@@ -365,14 +367,18 @@ void alloc_det_io(BoxMOTHipBotSort* h) {
     h->h_out.assign(S * nd * bm::OUT_COLS, 0.f);
 }
 
-void make_reid_engine(BoxMOTHipBotSort* h) {
-    const std::vector<float> blob = bm::read_blob_file(h->reid_path.c_str());
-    const long crops = (long)h->S * h->nd;
-    h->reid.reset(new bm::ReidEngine(blob.data(), (long)blob.size(), bm::reid_chunk_for(crops), (int)crops));
-    if (h->reid->feature_dim() != h->dim) throw std::runtime_error("boxmot_hip: ReID feature dim != emb_dim");
-    h->reid->set_preprocess(h->reid_pad);
-    if (h->reid_mode) h->reid->set_mode(h->reid_mode);
+// A ReID engine for S x nd crops from the handle's blob copy (read from reid_path the first time).  Returned, not installed: the
+// caller commits it together with whatever else changes size, so that a failure leaves the handle as it was.
+std::unique_ptr<bm::ReidEngine> new_reid_engine(BoxMOTHipBotSort* h, int nd) {
+    if (h->reid_blob.empty()) h->reid_blob = bm::read_blob_file(h->reid_path.c_str());
+    const long crops = (long)h->S * nd;
+    std::unique_ptr<bm::ReidEngine> e(new bm::ReidEngine(h->reid_blob.data(), (long)h->reid_blob.size(), bm::reid_chunk_for(crops), (int)crops));
+    if (e->feature_dim() != h->dim) throw std::runtime_error("boxmot_hip: ReID feature dim != emb_dim");
+    e->set_preprocess(h->reid_pad);
+    if (h->reid_mode) e->set_mode(h->reid_mode);
+    return e;
 }
+void make_reid_engine(BoxMOTHipBotSort* h) { h->reid = new_reid_engine(h, h->nd); }
 
 void set_step_lds(BoxMOTHipBotSort* h) {
     const long lds = bm::lap_lds_bytes(h->cap, h->nd);
@@ -389,6 +395,9 @@ void grow_tables(BoxMOTHipBotSort* h, int new_cap, int new_nd) {
         throw std::runtime_error("boxmot_hip: " + std::to_string(new_cap) + " tracks x " + std::to_string(new_nd) +
                                  " detections per stream is beyond what the assignment solver's LDS state can hold");
     BM_HIP(hipStreamSynchronize(h->stream));
+    // the larger ReID engine first: if it cannot be built (weights, memory) the handle keeps its tables, engine and LDS attribute
+    std::unique_ptr<bm::ReidEngine> new_reid;
+    if (h->reid && new_nd != h->nd) new_reid = new_reid_engine(h, new_nd);
     bm::BotSortStepArgs na = h->args;
     std::vector<std::pair<void*, size_t>> rec;
     RecAlloc ra{&h->owned, &rec};
@@ -408,7 +417,7 @@ void grow_tables(BoxMOTHipBotSort* h, int new_cap, int new_nd) {
     h->cap = new_cap; h->nd = new_nd;
     if (more_dets) {
         alloc_det_io(h);
-        if (h->reid) make_reid_engine(h);
+        if (new_reid) h->reid = std::move(new_reid);
     }
     set_step_lds(h);
     ++h->n_grows;
@@ -417,6 +426,19 @@ void grow_tables(BoxMOTHipBotSort* h, int new_cap, int new_nd) {
 int grown(int have, int need) {           // at least double, in steps of 64
     int v = have * 2 > need ? have * 2 : need;
     return (v + 63) / 64 * 64;
+}
+// Growth targets (cap, nd) for a frame that needs (need_cap, need_nd): doubled as above, but when the doubled pair exceeds what
+// `fits(cap, nd)` accepts (the assignment solver's LDS state) the sizes fall back towards the need itself in steps of 64 -- a frame
+// that fits is never refused because its DOUBLE would not.
+template <class Fits>
+void grown_pair(int have_cap, int need_cap, int have_nd, int need_nd, Fits fits, int& cap, int& nd) {
+    cap = need_cap > have_cap ? grown(have_cap, need_cap) : have_cap;
+    nd = need_nd > have_nd ? grown(have_nd, need_nd) : have_nd;
+    const int min_cap = need_cap > have_cap ? (need_cap + 63) / 64 * 64 : have_cap, min_nd = need_nd > have_nd ? (need_nd + 63) / 64 * 64 : have_nd;
+    while (!fits(cap, nd) && (cap > min_cap || nd > min_nd)) {
+        if (cap > min_cap) cap -= 64;
+        else nd -= 64;
+    }
 }
 
 void zero_state(BoxMOTHipBotSort* h) {
@@ -711,8 +733,11 @@ void host_update(BoxMOTHipBotSort* h, int s0, int n, const StreamIn* in, int det
             }
             need_cap = h->h_used[s0 + k] + rows > need_cap ? h->h_used[s0 + k] + rows : need_cap;
         }
-        if (need_nd > h->nd || need_cap > h->cap)
-            grow_tables(h, need_cap > h->cap ? grown(h->cap, need_cap) : h->cap, need_nd > h->nd ? grown(h->nd, need_nd) : h->nd);
+        if (need_nd > h->nd || need_cap > h->cap) {
+            int to_cap, to_nd;
+            grown_pair(h->cap, need_cap, h->nd, need_nd, [](int c, int d) { return bm::lap_lds_bytes(c, d) <= 120 * 1024; }, to_cap, to_nd);
+            grow_tables(h, to_cap, to_nd);
+        }
     }
     const int nd = h->nd, dim = h->dim;
     bool need_reid = false;
@@ -865,13 +890,15 @@ void host_update_one(BoxMOTHipBotSort* h, int stream, int class_list, int frame_
 // ---------------------------------------------------------------------------
 // StreamIo: shared host plumbing of the DeepOCSORT / StrongSORT handles
 // ---------------------------------------------------------------------------
-void io_make_reid(StreamIo* h) {
-    const std::vector<float> blob = bm::read_blob_file(h->reid_path.c_str());
-    const long crops = (long)h->S * h->nd;
-    h->reid.reset(new bm::ReidEngine(blob.data(), (long)blob.size(), bm::reid_chunk_for(crops), (int)crops));
-    if (h->reid->feature_dim() != h->dim) throw std::runtime_error("boxmot_hip: ReID feature dim != emb_dim");
-    if (h->reid_mode >= 0) h->reid->set_mode(h->reid_mode);
+std::unique_ptr<bm::ReidEngine> io_new_reid(StreamIo* h, int nd) {
+    if (h->reid_blob.empty()) h->reid_blob = bm::read_blob_file(h->reid_path.c_str());
+    const long crops = (long)h->S * nd;
+    std::unique_ptr<bm::ReidEngine> e(new bm::ReidEngine(h->reid_blob.data(), (long)h->reid_blob.size(), bm::reid_chunk_for(crops), (int)crops));
+    if (e->feature_dim() != h->dim) throw std::runtime_error("boxmot_hip: ReID feature dim != emb_dim");
+    if (h->reid_mode >= 0) e->set_mode(h->reid_mode);
+    return e;
 }
+void io_make_reid(StreamIo* h) { h->reid = io_new_reid(h, h->nd); }
 
 // per-frame buffers whose size follows max_dets / max_tracks (contents do not outlive an update)
 void io_alloc_sized(StreamIo* h) {
@@ -923,8 +950,8 @@ void io_migrate(StreamIo* h, const std::vector<std::pair<void*, size_t>>& rec, c
 
 // Room for the frames of streams [s0, s0 + n) before they are staged: more detections than max_dets, or live tracks + this
 // frame's detections > max_tracks, re-makes the tables through `grow(new_cap, new_nd)` (the reference's lists have no limit).
-template <class Grow>
-void io_make_room(StreamIo* h, int s0, int n, const StreamIn* in, const int* d_n_tracks, Grow grow) {
+template <class Grow, class Fits>
+void io_make_room(StreamIo* h, int s0, int n, const StreamIn* in, const int* d_n_tracks, Grow grow, Fits fits) {
     if (s0 < 0 || n < 1 || s0 + n > h->S) throw std::runtime_error("boxmot_hip: stream index out of range");
     int need_nd = h->nd, need_cap = h->cap;
     for (int k = 0; k < n; ++k) {
@@ -938,7 +965,9 @@ void io_make_room(StreamIo* h, int s0, int n, const StreamIn* in, const int* d_n
     }
     if (need_nd > h->nd || need_cap > h->cap) {
         BM_HIP(hipStreamSynchronize(h->stream));
-        grow(need_cap > h->cap ? grown(h->cap, need_cap) : h->cap, need_nd > h->nd ? grown(h->nd, need_nd) : h->nd);
+        int to_cap, to_nd;
+        grown_pair(h->cap, need_cap, h->nd, need_nd, fits, to_cap, to_nd);
+        grow(to_cap, to_nd);
         ++h->n_grows;
     }
 }
@@ -1141,6 +1170,8 @@ void docs_grow(BoxMOTHipDeepOcSort* h, int new_cap, int new_nd) {
         throw std::runtime_error("boxmot_hip: " + std::to_string(new_cap) + " tracks x " + std::to_string(new_nd) +
                                  " detections per stream is beyond what the assignment solver's LDS state can hold");
     BM_HIP(hipStreamSynchronize(h->stream));
+    std::unique_ptr<bm::ReidEngine> new_reid;           // first: a failure leaves the handle as it was
+    if (h->reid && new_nd != h->nd) new_reid = io_new_reid(h, new_nd);
     bm::DocsStepArgs na = h->args;
     std::vector<std::pair<void*, size_t>> rec;
     RecAlloc ra{&h->owned, &rec};
@@ -1150,7 +1181,7 @@ void docs_grow(BoxMOTHipDeepOcSort* h, int new_cap, int new_nd) {
     const bool more_dets = new_nd != h->nd;
     h->cap = new_cap; h->nd = new_nd;
     io_alloc_sized(h);
-    if (more_dets && h->reid) io_make_reid(h);
+    if (new_reid) h->reid = std::move(new_reid);
     BM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deepocsort_step_kernel<STEP_THREADS>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 }
@@ -1161,7 +1192,8 @@ void docs_host_update(BoxMOTHipDeepOcSort* h, int n, const StreamIn* in, int det
                       int image_cols, int image_channels, float* const* out, int out_capacity_rows, int* out_rows, int s0 = 0,
                       int frame_count = -1, int* id_count_inout = nullptr) {
     const bool want_emb = !h->cfg.embedding_off;
-    io_make_room(h, s0, n, in, h->args.st.n_tracks, [&](int cap, int nd) { docs_grow(h, cap, nd); });
+    io_make_room(h, s0, n, in, h->args.st.n_tracks, [&](int cap, int nd) { docs_grow(h, cap, nd); },
+                 [](int cap, int nd) { return bm::docs_lap_lds_bytes(cap, nd) <= 120 * 1024; });
     const bool any_warp = io_stage(h, n, in, det_cols, emb_cols, want_emb, image_rows, image_cols, image_channels, out_capacity_rows,
                                    (double)(float)h->cfg.det_thresh, 0, s0);
     // per-class fan-out (basetracker.py:223-263): the frame counter is rewound for every class and the id counter
@@ -1271,7 +1303,8 @@ void ss_launch(BoxMOTHipStrongSort* h, const bm::SsStepArgs& a, int n) {
 // strongsort.py:74-91), step, read back.
 void ss_host_update(BoxMOTHipStrongSort* h, int n, const StreamIn* in, int det_cols, int emb_cols, int image_rows,
                     int image_cols, int image_channels, float* const* out, int out_capacity_rows, int* out_rows) {
-    io_make_room(h, 0, n, in, h->args.st.n_tracks, [&](int cap, int nd) { ss_grow(h, cap, nd); });
+    io_make_room(h, 0, n, in, h->args.st.n_tracks, [&](int cap, int nd) { ss_grow(h, cap, nd); },
+                 [](int cap, int nd) { return bm::ss_lsa_lds_bytes(cap > nd ? cap : nd) <= 120 * 1024; });
     io_stage(h, n, in, det_cols, emb_cols, true, image_rows, image_cols, image_channels, out_capacity_rows, h->cfg.min_conf, 1);
     bm::SsStepArgs a = h->args;
     a.dets = h->d_dets; a.n_dets = h->d_ndets; a.embs = h->d_embs; a.warp = h->d_warp;     // identity where no warp is pending
@@ -1428,6 +1461,33 @@ int boxmot_hip_botsort_step_device(BoxMOTHipBotSort* handle, const float* d_dets
             run_reid(handle, 0, handle->S, d_dets, d_det_rows, d_frames, image_rows, image_cols, handle->d_embs);
             embs = handle->d_embs;
         }
+        // cmc_method = "sof" / "ecc": the estimator runs inside the step here too, on the device-resident frames, for every stream
+        // that was not given a warp with set_warp (the estimate comes back to the host: one synchronisation per step; callers that
+        // want none estimate ahead with boxmot_hip_sof_* / boxmot_hip_ecc_* and set_warp, or create the handle with cmc_method "none")
+        if (handle->use_sof || handle->use_ecc) {
+            BoxMOTHipBotSort* h = handle;
+            bool missing = false;
+            for (int s = 0; s < h->S; ++s) missing = missing || h->h_warp_flag[s] == 0;
+            if (missing) {
+                if (!d_frames || image_rows < 1 || image_cols < 1)
+                    throw std::runtime_error("boxmot_hip: cmc_method=sof/ecc in a device-resident step needs d_frames (or a warp per stream from set_warp)");
+                if (h->use_sof) {
+                    if (!h->sof) { h->sof.reset(new BoxMOTHipSof()); sof_init(h->sof.get(), h->S, image_rows, image_cols, 0.15, 8, 0.2, 3.0, h->stream); }
+                    if (h->sof->rows != image_rows || h->sof->cols != image_cols) throw std::runtime_error("boxmot_hip: frame size changed between updates");
+                } else {
+                    if (!h->ecc) { h->ecc.reset(new BoxMOTHipEcc()); ecc_init(h->ecc.get(), h->S, image_rows, image_cols, 0.15, 1e-5, 100, h->stream); }
+                    if (h->ecc->rows != image_rows || h->ecc->cols != image_cols) throw std::runtime_error("boxmot_hip: frame size changed between updates");
+                }
+                std::vector<double> w(6);
+                for (int s = 0; s < h->S; ++s) {
+                    if (h->h_warp_flag[s]) continue;
+                    if (h->use_sof) sof_run(h->sof.get(), s, 1, d_frames + s, d_dets + (size_t)s * h->nd * bm::DET_COLS, d_det_rows + s, h->nd, bm::DET_COLS, w.data(), nullptr);
+                    else ecc_run_one(h->ecc.get(), s, d_frames + s, w.data(), nullptr);
+                    for (int k = 0; k < 6; ++k) h->h_warp[(size_t)s * 6 + k] = w[k];
+                    h->h_warp_flag[s] = 1;
+                }
+            }
+        }
         // warps set with boxmot_hip_botsort_set_warp since the last step are consumed by this one
         bool any_warp = false;
         for (int s = 0; s < handle->S; ++s) any_warp = any_warp || handle->h_warp_flag[s] != 0;
@@ -1510,14 +1570,17 @@ int boxmot_hip_botsort_status(BoxMOTHipBotSort* handle, int* out_status, int cap
 
 int boxmot_hip_botsort_set_reid_blob(BoxMOTHipBotSort* handle, const float* blob, long n_floats) {
     return guard([&]() {
-        if (!handle || !blob) throw std::runtime_error("boxmot_hip: null argument");
-        handle->reid.reset(new bm::ReidEngine(blob, n_floats, bm::reid_chunk_for((long)handle->S * handle->nd), handle->S * handle->nd));
-        if (handle->reid->feature_dim() != handle->dim) {
-            handle->reid.reset();
-            throw std::runtime_error("boxmot_hip: ReID feature dim != emb_dim");
+        if (!handle || !blob || n_floats <= 0) throw std::runtime_error("boxmot_hip: null argument");
+        // the handle keeps a host copy: growing max_dets (reserve, or an update with more detections) rebuilds the engine from it
+        std::vector<float> keep(blob, blob + n_floats), old;
+        old.swap(handle->reid_blob);
+        handle->reid_blob.swap(keep);
+        try {
+            handle->reid = new_reid_engine(handle, handle->nd);
+        } catch (...) {
+            handle->reid_blob.swap(old);
+            throw;
         }
-        handle->reid->set_mode(handle->reid_mode);
-        handle->reid->set_preprocess(handle->reid_pad);
     });
 }
 

@@ -33,10 +33,11 @@ def shard_streams(n_streams_total: int, rank: int, world: int) -> list[int]:
 
 class MultiStreamBotSort:
     def __init__(self, n_streams: int, max_tracks: int = 1024, max_dets: int = 256, emb_dim: int = 512,
-                 reid_weights=None, use_cmc: bool = False, **botsort_kwargs):
+                 reid_weights=None, use_cmc: bool = False, cmc_method: str | None = None, **botsort_kwargs):
         # camera-motion compensation: the warp of a stream is supplied per frame with set_warp() (estimating it from the
-        # images is the caller's, as for BotSort(cmc=...)); use_cmc only documents the intent
-        self.use_cmc = bool(use_cmc)
+        # images is the caller's, as for BotSort(cmc=...)); use_cmc only documents the intent.  cmc_method = "sof" / "ecc"
+        # makes the handle estimate it itself from the frames it is given (host updates and device-resident steps alike)
+        self.use_cmc = bool(use_cmc) or cmc_method is not None
         unknown = set(botsort_kwargs) - set(BOTSORT_KEYS)
         if unknown:
             raise TypeError(f"unknown BoT-SORT options: {sorted(unknown)}")
@@ -46,6 +47,9 @@ class MultiStreamBotSort:
         for k, v in botsort_kwargs.items():
             setattr(cfg, k, int(v) if isinstance(v, bool) else v)
         cfg.n_streams, cfg.max_tracks, cfg.max_dets, cfg.emb_dim, cfg.n_class_lists = n_streams, max_tracks, max_dets, emb_dim, 1
+        if cmc_method is not None:
+            self._cmc_method = cmc_method.encode()          # (kept alive: the struct holds a char pointer)
+            cfg.cmc_method = self._cmc_method
         self.n_streams, self.max_tracks, self.max_dets, self.emb_dim = n_streams, max_tracks, max_dets, emb_dim
         self.with_reid = bool(cfg.with_reid)
         self._handle = self._lib.boxmot_hip_botsort_create(ctypes.byref(cfg))

@@ -239,7 +239,7 @@ int boxmot_hip_ecc_apply_device(BoxMOTHipEcc* handle, int stream, const uint8_t*
  * Camera-motion estimation: the sparse-optical-flow estimator (boxmot/motion/cmc/sof.py:14-147) -- the cmc_method of
  * configs/trackers/botsort.yaml and the estimator DeepOCSORT constructs (deepocsort.py:297).  Arguments = SOF.__init__'s (scale 0.15,
  * min_inliers 8, min_inlier_ratio 0.2, ransac_reproj_threshold 3.0); the OpenCV arguments sof.py fixes (1000 corners at quality 0.01,
- * 21 x 21 window, 3 pyramid levels, 30 iterations / 0.01) are fixed here too.  apply = SOF.apply(img, dets): dets = (n, >= 4) fp32 rows whose
+ * 21 x 21 window, maxLevel 3 = up to 4 pyramid levels, 30 iterations / 0.01) are fixed here too.  apply = SOF.apply(img, dets): dets = (n, >= 4) fp32 rows whose
  * first four columns are tlbr boxes in frame pixels (masked out of the corner detector, base_cmc.py:63-105), NULL / 0 for none; the
  * first call of a stream detects keypoints and returns the identity; later calls track them, fit the partial-affine 2 x 3 warp
  * (row-major doubles, translation in full-resolution pixels) and refresh the keypoints; too few tracked points or a weak fit return

@@ -117,3 +117,50 @@ def test_other_trackers_grow_and_match_their_oracles(kind):
         assert_rows_match(np.asarray(got).reshape(-1, 8), np.asarray(want).reshape(-1, 8), t)
     assert trk.capacity()[2] >= 1
     trk.close()
+
+
+def test_reserve_with_blob_installed_reid_engine_then_device_resident_frames():
+    """Weights installed through boxmot_hip_botsort_set_reid_blob (how MultiStreamBotSort(reid_weights=...) and bench.py load
+    them) have no file to re-read: growing max_dets rebuilds the ReID engine from the handle's own copy of the blob.  Reserve in
+    the middle of a sequence, keep stepping with the frame resident on the device and ReID inside the step: rows equal a handle
+    created large, frame for frame."""
+    import torch
+
+    from boxmot_amd.reid_weights import random_osnet_state_dict
+    from boxmot_amd.scenario import Scenario
+    from boxmot_amd.streams import MultiStreamBotSort
+    from boxmot_amd.tracker_zoo import BOTSORT_YAML_DEFAULTS
+    sd = random_osnet_state_dict("osnet_x0_25", seed=0)
+    kw = {k: v for k, v in BOTSORT_YAML_DEFAULTS.items() if k not in ("use_cmc", "cmc_method")}
+    sc = Scenario(12, 24, width=960, height=540, emb_dim=512, random_image=True)
+    dev = torch.device("cuda:0")
+    frame = torch.from_numpy(sc.image).to(dev)
+    ptrs = torch.tensor([frame.data_ptr()], dtype=torch.int64, device=dev)
+    NDBUF = 64
+    small = MultiStreamBotSort(1, max_tracks=64, max_dets=24, emb_dim=512, reid_weights=sd, **kw)
+    big = MultiStreamBotSort(1, max_tracks=128, max_dets=NDBUF, emb_dim=512, reid_weights=sd, **kw)
+    frames = [sc.frame(t, with_embs=False)[0] for t in range(12)]
+
+    def step(ms, nd, dets):
+        d = torch.zeros((1, nd, 6), dtype=torch.float32, device=dev)
+        d[0, : len(dets)] = torch.from_numpy(dets).to(dev)
+        n = torch.tensor([len(dets)], dtype=torch.int32, device=dev)
+        out = torch.zeros((1, nd, 8), dtype=torch.float32, device=dev)
+        out_n = torch.zeros(1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        ms.step_device(d.data_ptr(), n.data_ptr(), None, ptrs.data_ptr(), sc.height, sc.width, out.data_ptr(), out_n.data_ptr())
+        ms.synchronize()
+        return out[0, : int(out_n[0])].cpu().numpy()
+
+    for t, dets in enumerate(frames):
+        if t == 5:
+            before = small.capacity()
+            small.reserve(max_dets=NDBUF)              # blob-installed engine: used to throw "cannot open ReID weight blob: "
+            after = small.capacity()
+            assert after[1] >= NDBUF and after[2] == before[2] + 1
+        nd_small = small.capacity()[1]
+        got, want = step(small, nd_small, dets), step(big, big.capacity()[1], dets)
+        assert_rows_match(got, want, t, box_atol=1e-4)
+    assert small.status().tolist() == [0] and big.status().tolist() == [0]
+    small.close()
+    big.close()

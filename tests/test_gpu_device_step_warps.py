@@ -77,3 +77,50 @@ def test_strongsort_step_device_consumes_pending_warps():
 
 def test_deepocsort_step_device_consumes_pending_warps():
     _run("deepocsort")
+
+
+@pytest.mark.parametrize("method", ["sof", "ecc"])
+def test_botsort_device_resident_step_estimates_camera_motion_itself(method):
+    """cmc_method = "sof" / "ecc" on the handle: the estimator runs inside the DEVICE-RESIDENT step too (on the frames resident in
+    HBM), not only in the host updates -- a handle stepped with step_device returns the rows of a handle updated through the host
+    API with the same frames, on a panning camera (tracks stay compensated; before round 4 the step silently skipped the estimate)."""
+    import torch
+    from scipy.ndimage import gaussian_filter
+
+    from boxmot_amd.scenario import Scenario
+    from boxmot_amd.streams import MultiStreamBotSort
+    from boxmot_amd.tracker_zoo import BOTSORT_YAML_DEFAULTS
+    kw = {k: v for k, v in BOTSORT_YAML_DEFAULTS.items() if k not in ("use_cmc", "cmc_method")}
+    rng = np.random.default_rng(2)
+    base = gaussian_filter(rng.integers(0, 255, (700, 1200, 3)).astype(np.float32), (6, 6, 0))
+    base = ((base - base.min()) / (base.max() - base.min()) * 255).astype(np.uint8)
+    sc = Scenario(10, 16, width=960, height=540, emb_dim=32, random_image=False)
+    nd = 32
+    host = MultiStreamBotSort(1, max_tracks=64, max_dets=nd, emb_dim=32, cmc_method=method, **kw)
+    devh = MultiStreamBotSort(1, max_tracks=64, max_dets=nd, emb_dim=32, cmc_method=method, **kw)
+    dev = torch.device("cuda:0")
+    moved = 0.0
+    for t in range(12):
+        dets, embs = sc.frame(t)
+        ox, oy = 100 + 3 * t, 80 - 2 * t
+        dets = dets.copy(); dets[:, [0, 2]] -= 3 * t; dets[:, [1, 3]] += 2 * t
+        frame = np.ascontiguousarray(base[oy:oy + 540, ox:ox + 960])
+        want = host.update_batch([dets], [frame], [embs])[0]
+        d_frame = torch.from_numpy(frame).to(dev)
+        ptrs = torch.tensor([d_frame.data_ptr()], dtype=torch.int64, device=dev)
+        d_dets = torch.zeros((1, nd, 6), dtype=torch.float32, device=dev)
+        d_embs = torch.zeros((1, nd, 32), dtype=torch.float32, device=dev)
+        d_dets[0, : len(dets)] = torch.from_numpy(dets).to(dev)
+        d_embs[0, : len(dets)] = torch.from_numpy(embs).to(dev)
+        d_n = torch.tensor([len(dets)], dtype=torch.int32, device=dev)
+        d_out = torch.zeros((1, nd, 8), dtype=torch.float32, device=dev)
+        d_out_n = torch.zeros(1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        devh.step_device(d_dets.data_ptr(), d_n.data_ptr(), d_embs.data_ptr(), ptrs.data_ptr(), 540, 960, d_out.data_ptr(), d_out_n.data_ptr())
+        devh.synchronize()
+        got = d_out[0, : int(d_out_n[0])].cpu().numpy()
+        assert got.shape == np.asarray(want).shape and np.array_equal(got[:, 4:], np.asarray(want)[:, 4:]), t
+        assert np.allclose(got[:, :4], np.asarray(want)[:, :4], atol=1e-3), t
+        moved = max(moved, float(np.abs(got[:, :4]).max()))
+    assert moved > 0
+    host.close(); devh.close()

@@ -27,11 +27,12 @@ def _golden_frames(name):
     return [rows[offs[i]:offs[i + 1]] for i in range(len(g["counts"]))]
 
 
-@pytest.mark.parametrize("weights,mode", [("init", 1), ("calib", 0), ("calib", 1), ("init", 0)])
+@pytest.mark.parametrize("weights,mode", [("init", 2), ("calib", 2), ("init", 1), ("calib", 0), ("calib", 1), ("init", 0)])
 def test_long_config2_reid_inside_update_240_frames_vs_reference_rows(weights, mode):
     """The benchmarked configuration, as benchmarked (device-resident frame, crop list built on the device, fused or per-layer
     ReID kernels, one tracker step per frame), for 240 frames.  `calib` + mode 1 runs the fp16 kernels on the noise-amplifying
-    BN-calibrated network (embeddings within ~5e-3 of fp32 there): ids are still the reference's."""
+    BN-calibrated network (embeddings within ~5e-3 of fp32 there): ids are still the reference's.
+    Mode 2 is the fused fp32-grade family bench.py reports (reid_hp.hpp), on both weight sets."""
     import torch
 
     from boxmot_amd.reid_weights import random_osnet_state_dict, reference_init_state_dict

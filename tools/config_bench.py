@@ -45,7 +45,7 @@ def vit_flops(width=768, layers=12, tokens=129, patch_k=768, out_dim=512):
 
 
 def run(config: str = "c3", streams: int = 0, steps: int = 40, warmup: int = 8, check_frames: int = -1, reid_mode: int = 1,
-        with_ecc: bool = True, groups: int = 0, embedding_gate: bool = True) -> dict:
+        with_ecc: bool = True, groups: int = 0, embedding_gate: bool = True, both_groups: bool = False) -> dict:
     """One measurement; returns the result dict (bench.py calls this for its side lines).  `groups`: the streams are split over
     that many handles, each with its own HIP stream (0 = 1) -- with 2, one group's frame step (a few workgroups: one per stream)
     runs beside the other group's ReID kernels instead of after its own (configuration 3: 497 -> 541 frames/s; configuration 5:
@@ -100,70 +100,78 @@ def run(config: str = "c3", streams: int = 0, steps: int = 40, warmup: int = 8, 
         mk, step_fn, sync, destroy = lib.boxmot_hip_strongsort_create, lib.boxmot_hip_strongsort_step_device_frames, \
             lib.boxmot_hip_strongsort_synchronize, lib.boxmot_hip_strongsort_destroy
         reid_ms, set_mode = lib.boxmot_hip_strongsort_reid_kernel_ms, lib.boxmot_hip_strongsort_set_reid_mode
-    G = max(1, min(groups or 1, S))
-    while S % G:
-        G -= 1
-    Sg = S // G
-    cfg.n_streams, cfg.max_tracks, cfg.max_dets, cfg.emb_dim = Sg, cap, cap_nd, dim
-    cfg.reid_model_path = path.encode()
-    hs = []
-    for _ in range(G):
-        hg = mk(ctypes.byref(cfg))
-        if not hg:
-            raise RuntimeError(_lib.last_error())
-        if c3:
-            _lib.check(set_mode(hg, reid_mode))
-        hs.append(hg)
-    os.unlink(path)
-    h = hs[0]
-    d_out = torch.zeros((T, S, cap, 8), dtype=torch.float32, device=dev)
-    d_out_n = torch.zeros((T, S), dtype=torch.int32, device=dev)
-
-    def raw_step(t):        # asynchronous launches, group after group: group g's step kernel overlaps group g + 1's ReID kernels
-        for g, hg in enumerate(hs):
-            a, b = g * Sg, (g + 1) * Sg
-            _lib.check(step_fn(hg, d_dets[t, a:b].data_ptr(), d_cnt[t, a:b].data_ptr(), ptrs[a:b].data_ptr(), H, W,
-                               d_out[t, a:b].data_ptr(), d_out_n[t, a:b].data_ptr()))
-
-    def sync_all():
-        for hg in hs:
-            _lib.check(sync(hg))
-
-    def reid_ms_all():
-        tot, launches = 0.0, 0
-        for hg in hs:
-            _lib.check(reid_ms(hg, ctypes.byref(ms), ctypes.byref(nl)))
-            tot, launches = tot + ms.value, launches + nl.value
-        return tot, launches
-    ecc = None
-    if not c3 and with_ecc:
-        # the reference's StrongSORT estimates camera motion with ECC on every frame that has tracks (strongsort.py:67, 83-86): the
-        # estimator of each stream sees every frame, its warp is set for the step (boxmot_hip_strongsort_set_warp -> camera_update)
-        ecc = lib.boxmot_hip_ecc_create(S, H, W, 0.15, 1e-5, 100)
-        if not ecc:
-            raise RuntimeError(_lib.last_error())
-        warp = np.zeros(6, np.float64)
-        iters = ctypes.c_int(0)
-
-    def step(t):
-        if ecc:
-            for s in range(S):
-                _lib.check(lib.boxmot_hip_ecc_apply_device(ecc, s, frames[s].data_ptr(), warp.ctypes.data, ctypes.byref(iters)))
-                _lib.check(lib.boxmot_hip_strongsort_set_warp(hs[s // Sg], s % Sg, warp.ctypes.data))
-        raw_step(t)
     ms, nl = ctypes.c_double(0), ctypes.c_int(0)
-    for t in range(warmup):
-        step(t)
-    sync_all()
-    reid_ms_all()           # (reading the counters resets them)
-    t0 = time.perf_counter()
-    for t in range(warmup, T):
-        step(t)
-    sync_all()
-    dt = time.perf_counter() - t0
-    reid_total_ms, reid_launches = reid_ms_all()
+
+    def measure(groups_now):
+        """Fresh handles for `groups_now` stream groups, warm-up + timed loop; returns (seconds, ReID ms, ReID launches, rows, counts)."""
+        G = max(1, min(groups_now or 1, S))
+        while S % G:
+            G -= 1
+        Sg = S // G
+        cfg.n_streams, cfg.max_tracks, cfg.max_dets, cfg.emb_dim = Sg, cap, cap_nd, dim
+        cfg.reid_model_path = path.encode()
+        hs = []
+        for _ in range(G):
+            hg = mk(ctypes.byref(cfg))
+            if not hg:
+                raise RuntimeError(_lib.last_error())
+            if c3:
+                _lib.check(set_mode(hg, reid_mode))
+            hs.append(hg)
+        d_out = torch.zeros((T, S, cap, 8), dtype=torch.float32, device=dev)
+        d_out_n = torch.zeros((T, S), dtype=torch.int32, device=dev)
+
+        def raw_step(t):        # asynchronous launches, group after group: group g's step kernel overlaps group g + 1's ReID kernels
+            for g, hg in enumerate(hs):
+                a, b = g * Sg, (g + 1) * Sg
+                _lib.check(step_fn(hg, d_dets[t, a:b].data_ptr(), d_cnt[t, a:b].data_ptr(), ptrs[a:b].data_ptr(), H, W,
+                                   d_out[t, a:b].data_ptr(), d_out_n[t, a:b].data_ptr()))
+
+        def sync_all():
+            for hg in hs:
+                _lib.check(sync(hg))
+
+        def reid_ms_all():
+            tot, launches = 0.0, 0
+            for hg in hs:
+                _lib.check(reid_ms(hg, ctypes.byref(ms), ctypes.byref(nl)))
+                tot, launches = tot + ms.value, launches + nl.value
+            return tot, launches
+        ecc = None
+        if not c3 and with_ecc:
+            # the reference's StrongSORT estimates camera motion with ECC on every frame that has tracks (strongsort.py:67, 83-86): the
+            # estimator of each stream sees every frame, its warp is set for the step (boxmot_hip_strongsort_set_warp -> camera_update)
+            ecc = lib.boxmot_hip_ecc_create(S, H, W, 0.15, 1e-5, 100)
+            if not ecc:
+                raise RuntimeError(_lib.last_error())
+            warp = np.zeros(6, np.float64)
+            iters = ctypes.c_int(0)
+
+        def step(t):
+            if ecc:
+                for s in range(S):
+                    _lib.check(lib.boxmot_hip_ecc_apply_device(ecc, s, frames[s].data_ptr(), warp.ctypes.data, ctypes.byref(iters)))
+                    _lib.check(lib.boxmot_hip_strongsort_set_warp(hs[s // Sg], s % Sg, warp.ctypes.data))
+            raw_step(t)
+        for t in range(warmup):
+            step(t)
+        sync_all()
+        reid_ms_all()           # (reading the counters resets them)
+        t0 = time.perf_counter()
+        for t in range(warmup, T):
+            step(t)
+        sync_all()
+        dt_ = time.perf_counter() - t0
+        r_ms, r_n = reid_ms_all()
+        rows, counts = d_out.cpu().numpy(), d_out_n.cpu().numpy()
+        for hg in hs:
+            destroy(hg)
+        if ecc:
+            lib.boxmot_hip_ecc_destroy(ecc)
+        return G, dt_, r_ms, r_n, rows, counts
+
+    G, dt, reid_total_ms, reid_launches, out_h, out_n = measure(groups)
     crops = int(cnt_h[warmup:].sum())
-    out_h, out_n = d_out.cpu().numpy(), d_out_n.cpu().numpy()
     # parity gates
     gates = {}
     from boxmot_amd.reid import HipReID
@@ -196,18 +204,33 @@ def run(config: str = "c3", streams: int = 0, steps: int = 40, warmup: int = 8, 
         else:
             from oracle.strongsort import StrongSortOracle
             orc = StrongSortOracle(reid=orc_reid, dot_rule="device")
-        ok = True
+        want_rows = []
         for t in range(check):
             n = cnt_h[t, 0]
-            want = np.asarray(orc.update(dets_h[t, 0, :n], scen[0].image), dtype=np.float32).reshape(-1, 8)
-            got = out_h[t, 0, : out_n[t, 0]]
-            ok = ok and got.shape == want.shape and np.array_equal(np.sort(got[:, 4]), np.sort(want[:, 4]))
-        gates["ids_first_frames_vs_oracle_stream0"] = bool(ok)
+            want_rows.append(np.asarray(orc.update(dets_h[t, 0, :n], scen[0].image), dtype=np.float32).reshape(-1, 8))
+
+        def ids_ok(rows, counts):
+            ok = True
+            for t in range(check):
+                got = rows[t, 0, : counts[t, 0]]
+                ok = ok and got.shape == want_rows[t].shape and np.array_equal(np.sort(got[:, 4]), np.sort(want_rows[t][:, 4]))
+            return bool(ok)
+        gates["ids_first_frames_vs_oracle_stream0"] = ids_ok(out_h, out_n)
         gates["id_gate_frames"] = int(check)
-    for hg in hs:
-        destroy(hg)
-    if ecc:
-        lib.boxmot_hip_ecc_destroy(ecc)
+    if both_groups:
+        # the same workload with the streams split over two handles / HIP streams: one group's frame step (a workgroup per stream)
+        # runs beside the other group's ReID kernels.  Its own entry -- the ReID-region timing (and the roofline figure) is only clean
+        # when nothing else shares the GPU -- gated against the SAME oracle rows as the one-group run.
+        try:
+            G2, dt2, _, _, rows2, counts2 = measure(2)
+            two = {"stream_groups": G2, "frames_per_s": S * steps / dt2, "ms_per_step": 1e3 * dt2 / steps}
+            if check:
+                two["ids_first_frames_vs_oracle_stream0"] = ids_ok(rows2, counts2)
+                two["id_gate_frames"] = int(check)
+            gates["two_stream_groups"] = two
+        except Exception as exc:                # (never takes the gated one-group line down)
+            gates["two_stream_groups"] = {"error": f"{type(exc).__name__}: {exc}"}
+    os.unlink(path)
     tfl = crops * flops_per_crop / (reid_total_ms * 1e9) if reid_total_ms > 0 else None
     return {
         "workload": ("DeepOCSORT + OSNet_x1_0 ReID, 128 dets x 512 tracks, 1080p" if c3 else
@@ -229,9 +252,10 @@ def main():
     ap.add_argument("--check-frames", type=int, default=-1)
     ap.add_argument("--reid-mode", type=int, default=1)
     ap.add_argument("--groups", type=int, default=0, help="handles (HIP streams) the streams are split over; 0 = 1")
+    ap.add_argument("--both-groups", action="store_true", help="after the measurement, repeat it with 2 stream groups (same inputs, same oracle rows)")
     ap.add_argument("--no-ecc", action="store_true", help="c5: skip the per-frame ECC estimate (the reference's StrongSORT always runs it)")
     a = ap.parse_args()
-    print(json.dumps(run(a.config, a.streams, a.steps, a.warmup, a.check_frames, a.reid_mode, not a.no_ecc, a.groups)), flush=True)
+    print(json.dumps(run(a.config, a.streams, a.steps, a.warmup, a.check_frames, a.reid_mode, not a.no_ecc, a.groups, both_groups=a.both_groups)), flush=True)
 
 
 if __name__ == "__main__":
