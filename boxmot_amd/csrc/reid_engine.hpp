@@ -2,7 +2,8 @@
 // the device and sequences the kernels for a batch of crops.
 //   mode 0: per-layer fp32 kernels (reid_kernels_v1.hpp) -- first correct path
 //   mode 1: fused fp16 MFMA kernels (reid_fused.hpp)
-//   mode 2: fused fp32-grade kernels (reid_hp.hpp): the fused structure on fp16 (hi, lo) operand pairs, fp32 everywhere else
+//   mode 2: fused fp32-grade kernels (reid_hp.hpp): the fused structure on fp16 (hi, lo) operand pairs, fp32 everywhere else;
+//           for the wide OSNets (osnet_x1_0) the fp32-grade family of osnet_wide_hp.hpp (chain-fused LightConvs, (hi, lo) GEMMs)
 // Reference path: BaseModelBackend.get_features, base_backend.py:197-207.
 #pragma once
 #include <cstdlib>
@@ -22,6 +23,7 @@
 #include "reid_hp.hpp"
 #include "clip_engine.hpp"
 #include "osnet_wide.hpp"
+#include "osnet_wide_hp.hpp"
 
 #ifndef BM_STAGE1_HANDOVER
 #define BM_STAGE1_HANDOVER 0
@@ -122,8 +124,11 @@ public:
         if (m == 1 && !fused_ready_ && !wide_)
             throw std::runtime_error("fp16 MFMA ReID kernels exist for OSNet-x0.25 (fused) and for widths that are multiples of 32 (osnet_x1_0)");
         if (m == 2) {
-            if (!fused_ready_) throw std::runtime_error("the fused fp32-grade ReID kernels (mode 2) exist for OSNet-x0.25");
-            if (!hp_ready_) prepare_hp();
+            if (fused_ready_) { if (!hp_ready_) prepare_hp(); }
+            else if (WideOsnetHP::supports(L_)) {
+                if (!wide_hp_) wide_hp_.reset(new WideOsnetHP(h_w_.data(), L_, d_w_, max_crops_ < 1024 ? max_crops_ : 1024, owned_));
+            } else
+                throw std::runtime_error("the fp32-grade ReID kernels (mode 2) exist for OSNet-x0.25 (fused) and for widths that are multiples of 32 / 128 (osnet_x1_0)");
         }
         mode_ = m;
     }
@@ -144,12 +149,14 @@ public:
     void preprocess(const uint8_t* const* d_frames, const int* d_crop_stream, const float* d_boxes,
                     int box_stride, int n, int W, int H, hipStream_t st) {
         const bool hp = mode_ == 2 && !force_fp32_crops_;
-        if (hp) {       // (hi, lo) fp16 RGBX planes for k_stem_hp
-            if (n > fused_cap_) throw std::runtime_error("ReID: crop batch exceeds the engine capacity");
+        if (hp) {       // (hi, lo) fp16 RGBX planes for k_stem_hp / k_wide_stem_hp
+            const bool whp = !fused_ready_ && wide_hp_;
+            if (n > (whp ? wide_hp_->max_crops() : fused_cap_)) throw std::runtime_error("ReID: crop batch exceeds the engine capacity");
             if (n == 0) return;
             if (obb_geo_) throw std::runtime_error("ReID mode 2 (fused fp32-grade kernels): oriented-box crops run in modes 0 / 1");
             hipLaunchKernelGGL(k_crop_resize_rgbx_hl, dim3(n, REID_IN_H / 16), dim3(REID_IN_W), 0, st, d_frames, d_crop_stream, d_boxes,
-                               box_stride, W, H, d_lut_, crops_h_, crops_l_, 16, d_count_, pad_);
+                               box_stride, W, H, d_lut_, whp ? wide_hp_->crops_h() : crops_h_, whp ? wide_hp_->crops_l() : crops_l_, 16,
+                               whp ? static_cast<const int*>(nullptr) : d_count_, pad_);
             return;
         }
         const bool fused = mode_ == 1 && fused_ready_ && !force_fp32_crops_;
@@ -190,7 +197,8 @@ public:
         if (n == 0) return;
         BM_HIP(hipEventRecord(ev_[0], st));
         const bool wide = mode_ == 1 && wide_;
-        const int step = wide ? wide_->max_crops() : (mode_ >= 1 ? fused_cap_ : max_crops_);
+        const bool wide_hp = mode_ == 2 && !fused_ready_ && wide_hp_;
+        const int step = wide ? wide_->max_crops() : (wide_hp ? wide_hp_->max_crops() : (mode_ >= 1 ? fused_cap_ : max_crops_));
         const double* geo_all = obb_geo_;
         for (int i0 = 0; i0 < n; i0 += step) {
             const int m = (n - i0) < step ? (n - i0) : step;
@@ -204,6 +212,7 @@ public:
             const int* orow = d_out_rows ? d_out_rows + i0 : nullptr;
             if (clip_) clip_->forward(crops_, m, o, orow, st);
             else if (wide) wide_->forward(m, o, orow, st);
+            else if (wide_hp) wide_hp_->forward(m, o, orow, st);
             else if (mode_ >= 1) {
                 const FrameArgs fa{d_frames, d_crop_stream + i0, d_boxes + (long)i0 * box_stride, box_stride, W, H};
                 if (mode_ == 2) forward_hp(m, fuse_stem ? &fa : nullptr, o, orow, st);
@@ -545,6 +554,7 @@ private:
     // fused path
     std::unique_ptr<ClipNet> clip_;         // non-null: the weights are a CLP1 blob (CLIP-ReID ViT-B/16)
     std::unique_ptr<WideOsnet> wide_;       // non-null: OSNet widths the layer-per-launch fp16 MFMA kernels take (osnet_x1_0)
+    std::unique_ptr<WideOsnetHP> wide_hp_;  // the fp32-grade family for the same widths (created when mode 2 is first selected)
     bool fused_ready_ = false, force_fp32_crops_ = false, fuse_stem_ = true;
     const double* obb_geo_ = nullptr;
     int pad_ = 0;

@@ -4,6 +4,7 @@
     python tests/golden/make_config_golden.py c5 [frames]     # StrongSORT, 256 dets x 1024 tracks x 1280-d, ~17 s per frame
     python tests/golden/make_config_golden.py c2 [frames]     # BoT-SORT, 64 dets x 256 tracks, YAML defaults, embeddings supplied
     python tests/golden/make_config_golden.py c2reid init|calib [frames]
+    python tests/golden/make_config_golden.py c3reid [frames] [init|calib]
                                                               # the same with ReID INSIDE update: the reference BotSort asks the
                                                               # reference OSNet-x0.25 (random-init / BN-calibrated weights) per frame
     python tests/golden/make_config_golden.py c3 [frames]     # DeepOCSORT, 128 dets x 512 tracks x 512-d, embeddings supplied
@@ -117,15 +118,17 @@ def config3(frames: int):
     _save("config3_deepocsort_golden.npz", out, dict(frames=np.int32(frames)))
 
 
-def config3_reid(frames: int):
-    """Config 3 as tools/config_bench.py runs it: reference DeepOcSort (cmc_off) asking the reference OSNet-x1.0 (random init, seed 0)
-    for every detection above det_thresh, stream 0's random 1080p frame."""
+def config3_reid(frames: int, weights: str = "init"):
+    """Config 3 as tools/config_bench.py runs it: reference DeepOcSort (cmc_off) asking the reference OSNet-x1.0 (random init, seed 0;
+    `calib`: BatchNorm-calibrated random weights, the case that tells fp32-grade kernels from fp16 operands) for every detection
+    above det_thresh, stream 0's random 1080p frame."""
     import torch
 
-    from boxmot_amd.reid_weights import reference_init_state_dict
+    from boxmot_amd.reid_weights import random_osnet_state_dict, reference_init_state_dict
 
     torch.set_num_threads(8)
-    sd = reference_init_state_dict("osnet_x1_0", seed=0)
+    sd = reference_init_state_dict("osnet_x1_0", seed=0) if weights == "init" else random_osnet_state_dict("osnet_x1_0", seed=0)
+    fname = "config3_reid_golden.npz" if weights == "init" else "config3_reid_calib_golden.npz"
     mod = ref_harness.load_osnet_module()
     model = mod.osnet_x1_0(num_classes=1041, pretrained=False).eval()
     missing = model.load_state_dict(sd, strict=False)
@@ -140,8 +143,8 @@ def config3_reid(frames: int):
         out.append(np.asarray(trk.update(d, sc.image), dtype=np.float64).reshape(-1, 8))
         if t % 5 == 0:
             print(f"c3reid frame {t}: {len(out[-1])} rows, {time.time() - t0:.0f} s", flush=True)
-            _save("config3_reid_golden.npz", out, dict(frames=np.int32(len(out))))
-    _save("config3_reid_golden.npz", out, dict(frames=np.int32(frames)))
+            _save(fname, out, dict(frames=np.int32(len(out))))
+    _save(fname, out, dict(frames=np.int32(frames)))
 
 
 class _RefClipReid:
@@ -216,8 +219,10 @@ if __name__ == "__main__":
         mot17_mini_gt()
     elif which == "c2reid":
         config2_reid(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 240)
-    elif which in ("c3reid", "c5reid"):
-        {"c3reid": config3_reid, "c5reid": config5_reid}[which](int(sys.argv[2]) if len(sys.argv) > 2 else 64)
+    elif which == "c3reid":
+        config3_reid(int(sys.argv[2]) if len(sys.argv) > 2 else 64, sys.argv[3] if len(sys.argv) > 3 else "init")
+    elif which == "c5reid":
+        config5_reid(int(sys.argv[2]) if len(sys.argv) > 2 else 64)
     else:
         n = int(sys.argv[2]) if len(sys.argv) > 2 else 240
         {"c5": config5, "c2": config2, "c3": config3}[which](n)
