@@ -328,11 +328,26 @@ __global__ void __launch_bounds__(256) k_gemm_hp(const _Float16* __restrict__ Xh
 //                  neighbourhood (a sliding 3-row window down the wave's rows: 3 reads per input row).  Two slice buffers: the
 //                  write of slice ct + 1 and the reads of slice ct share a barrier interval.
 // ---------------------------------------------------------------------------------------------------------------------------
+// tools/wide_hp_prof -DBM_CHAIN_PROF: shader-clock cycles per wave of each phase of k_chain_hp, summed over all waves
+#ifdef BM_CHAIN_PROF
+__device__ unsigned long long g_chain_prof[8];
+#define BM_CPROF_DECL() unsigned long long cp_t = clock64(), cp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define BM_CPROF(k) do { unsigned long long t_ = clock64(); cp_acc[k] += t_ - cp_t; cp_t = t_; } while (0)
+#define BM_CPROF_FLUSH() do { if ((threadIdx.x & 63) == 0) for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&g_chain_prof[k_], cp_acc[k_]); } while (0)
+#else
+#define BM_CPROF_DECL() ((void)0)
+#define BM_CPROF(k) ((void)0)
+#define BM_CPROF_FLUSH() ((void)0)
+#endif
+#ifndef BM_CHAIN_TGP
+#define BM_CHAIN_TGP 2              // tiles whose B operands are resident while the A pairs stream by (A/B switch)
+#endif
+
 template <int C, int W, int WR, int HALO>
 struct ChainGeo {
     static constexpr int CT = C / 16, KS = C / 32, R = WR - 2 * HALO;
     static constexpr int NW = 8, NTILES = WR * W / 16, NT = NTILES / NW;
-    static constexpr int TGP = NT % 2 == 0 ? 2 : 1;                 // tiles whose B operands are resident while the A pairs stream by
+    static constexpr int TGP = NT % BM_CHAIN_TGP == 0 ? BM_CHAIN_TGP : 1;                 // tiles whose B operands are resident while the A pairs stream by
     static constexpr int ROWP = (W + 2) * 16;
     static constexpr int PLANE = ((WR + 2) * ROWP + 255) / 256 * 256;
     static constexpr int SLICE = 4 * PLANE;
@@ -376,10 +391,12 @@ __global__ void __launch_bounds__(512, 2) k_chain_hp(const _Float16* __restrict_
         for (int c = wave * 1024; c < G::DW_BYTES; c += G::NW * 1024)
             if (c + lane * 16 < G::DW_BYTES) BM_GLDS16(src + G::PW_BYTES + c + lane * 16, wd + c, lane);
     };
+    BM_CPROF_DECL();
     stage_weights(0);
     for (int e = tid * 16; e < 2 * G::SLICE; e += 512 * 16) *reinterpret_cast<f4*>(lds + e) = f4{0.f, 0.f, 0.f, 0.f};   // halo = zero padding
     BM_WAIT_VM0();
     __syncthreads();
+    BM_CPROF(0);
 
     int li = 0;
 #pragma unroll 1
@@ -399,6 +416,7 @@ __global__ void __launch_bounds__(512, 2) k_chain_hp(const _Float16* __restrict_
                 cur[i][ct] = v;
             }
         }
+        BM_CPROF(1);
 #pragma unroll 1
         for (int k = 0; k <= br; ++k, ++li) {
             // ---- 1x1 (linear, C -> C) ----
@@ -431,6 +449,7 @@ __global__ void __launch_bounds__(512, 2) k_chain_hp(const _Float16* __restrict_
                 }
                 BM_SCHED_FENCE();
             }
+            BM_CPROF(2);
             // ---- depthwise 3x3 (pad 1) + bias + ReLU, slice by slice ----
             const unsigned char* wdl = lds + G::OFF_DW + (li & 1) * G::DW_BYTES;
 #pragma unroll
@@ -440,6 +459,7 @@ __global__ void __launch_bounds__(512, 2) k_chain_hp(const _Float16* __restrict_
                 for (int i = 0; i < NT; ++i) *reinterpret_cast<f4*>(img + pix(i)) = cur[i][ct];
                 if (ct == CT - 1) BM_WAIT_VM0();            // the next layer's weights (requested below, at slice 0) have landed
                 __syncthreads();
+                BM_CPROF(3);
                 if (ct == 0 && li + 1 < 10) stage_weights(li + 1);       // every wave is past this layer's 1x1: wpw is free
                 f4 wd[9];
                 const f4* wsrc = reinterpret_cast<const f4*>(wdl) + (ct * 4 + g) * 9;
@@ -483,6 +503,7 @@ __global__ void __launch_bounds__(512, 2) k_chain_hp(const _Float16* __restrict_
                         }
                     }
                 }
+                BM_CPROF(4);
             }
         }
         // ---- branch output: the band's own rows -> (hi, lo) planes; channel sums of those rows for the gate ----
@@ -523,7 +544,9 @@ __global__ void __launch_bounds__(512, 2) k_chain_hp(const _Float16* __restrict_
             gap_part[(((long)br * n_crops + crop) * nbands + band) * C + tid] = s;
         }
         __syncthreads();
+        BM_CPROF(5);
     }
+    BM_CPROF_FLUSH();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

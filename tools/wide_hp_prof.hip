@@ -66,5 +66,16 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < out.size(); ++i) { unsigned u; memcpy(&u, &out[i], 4); sum += (unsigned long long)u * (i % 8191 + 1); bad += !(out[i] == out[i]); }
     printf("osnet_x1_0 fp32-grade forward: n=%d best %.3f ms = %.1f TFLOP/s algorithmic (1.9577 GFLOP per crop)\n", n, best, n * 1.957691392e9 / (best * 1e9));
     printf("    output checksum %016llx, %d NaNs\n", sum, bad);
+#ifdef BM_CHAIN_PROF
+    {
+        unsigned long long pr[8];
+        CK(hipMemcpyFromSymbol(pr, HIP_SYMBOL(bm::g_chain_prof), sizeof(pr)));
+        static const char* nm[6] = {"init (LDS clear, weights)", "x1 load", "1x1 (pointwise)", "dw: image write + barrier", "dw: taps", "branch output + band sums"};
+        unsigned long long tot = 0;
+        for (int k = 0; k < 6; ++k) tot += pr[k];
+        printf("    k_chain_hp phase clocks (all chain launches of %d passes, all waves): total %llu\n", iters + 1, tot);
+        for (int k = 0; k < 6; ++k) printf("      %-28s %6.1f %%\n", nm[k], 100.0 * pr[k] / (double)tot);
+    }
+#endif
     return 0;
 }
