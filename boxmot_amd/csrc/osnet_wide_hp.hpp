@@ -18,6 +18,10 @@
 #include "osnet_wide_hp_kernels.hpp"
 #include "osnet_wide_hp_pack.hpp"
 
+#ifndef BM_WIDE_HP_SHALLOW
+#define BM_WIDE_HP_SHALLOW 1
+#endif
+
 namespace bm {
 
 // device (or emulated-device) buffers of one pass of up to `n` crops
@@ -84,7 +88,11 @@ void wide_hp_forward(Launch& launch, const OsnetLayout& L, const WideHpPack& P, 
         const long mt = (M + GEMM_BM - 1) / GEMM_BM;
         const _Float16 *wh = H16(w.wh), *wl = H16(w.wl);
         const float* bias = F32(w.bias);
-#define BM_HP_GEMM(EPI, BN) launch(k_gemm_hp<EPI, BN>, (int)(mt * (N / BN)), 1, 256, gemm_hp_lds_bytes<BN>(), xh, xl, wh, wl, bias, oh, ol, rh, rl, (int)M, N, K, relu, ext)
+        // shallow products without a residual (conv1, conv3 + downsample) run the single-buffer form at four workgroups per CU
+        // (k_gemm_hp; profiles/r4_c3_gemm_occupancy_ab.txt: -8 %; the residual form loses its early residual fetch there: +13 %)
+        const bool shallow = BM_WIDE_HP_SHALLOW && K + (w2 ? w2->k : 0) <= 512 && epi == 0;
+#define BM_HP_GEMM(EPI, BN) do { if (EPI == 0 && shallow) launch(k_gemm_hp<EPI, BN, (EPI == 0 ? 1 : 2)>, (int)(mt * (N / BN)), 1, 256, gemm_hp_lds_bytes<BN, 1>(), xh, xl, wh, wl, bias, oh, ol, rh, rl, (int)M, N, K, relu, ext); \
+                                 else launch(k_gemm_hp<EPI, BN, 2>, (int)(mt * (N / BN)), 1, 256, gemm_hp_lds_bytes<BN, 2>(), xh, xl, wh, wl, bias, oh, ol, rh, rl, (int)M, N, K, relu, ext); } while (0)
         if (N % 128 == 0) {
             switch (epi) {
                 case 0: BM_HP_GEMM(0, 128); break;

@@ -30,6 +30,7 @@
 
 #include "gemm_f16.hpp"
 #include "osnet_wide_kernels.hpp"
+#include "osnet_wide_hp_pack.hpp"
 #include "reid_hp.hpp"
 
 namespace bm {
@@ -39,7 +40,7 @@ namespace bm {
 //   crops_h / crops_l  fp16 RGBX planes with a 3-pixel zero border, [n][262][136][4] (k_crop_resize_rgbx_hl)
 //   wts                A fragment pairs [ky][channel tile] (2 KiB each: hi then lo), k-slot j of lane group g -> tap kx = 2 g + (j >> 2),
 //                      channel j & 3 of the RGBX pixel (pack_wide_stem_hp)
-//   out_h / out_l      [n][64 * 32][C0]
+//   out_h / out_l      [n][64 * 32][C0], channels in the paired order (below)
 // grid (16 bands of 4 pooled rows, crops), 256 threads; the band's 23 input rows of BOTH planes are staged once into LDS.
 // ---------------------------------------------------------------------------------------------------------------------------
 template <int C0>
@@ -123,7 +124,7 @@ __global__ void __launch_bounds__(256) k_wide_stem_hp(const _Float16* __restrict
                 const long p = (long)py * 32 + t * 8 + (l16 >> 1);
                 h4 hh, ll;
                 split4(m, hh, ll);
-                const long o = (crop * 2048 + p) * C0 + 16 * ct + 4 * g;
+                const long o = (crop * 2048 + p) * C0 + 32 * (ct >> 1) + 8 * g + 4 * (ct & 1);       // paired order (hp_paired_pos)
                 *reinterpret_cast<h4*>(out_h + o) = hh;
                 *reinterpret_cast<h4*>(out_l + o) = ll;
             }
@@ -135,7 +136,8 @@ __global__ void __launch_bounds__(256) k_wide_stem_hp(const _Float16* __restrict
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // k_gemm_hp: C[m][n] = sum_k X[m][k] * Wt[n][k] (+ bias) with BOTH operands as (hi, lo) fp16 planes -- the 1x1 convolutions.
-//   Xh / Xl [M][K], Wh / Wl [N][K] row-major fp16;  N % BN == 0, BN in {32, 64, 96, 128};  K % 32 == 0;  any M.
+//   Xh / Xl [M][K], Wh / Wl [N][K] row-major fp16;  N % BN == 0, BN in {32, 64, 96, 128};  K % 32 == 0;  any M.  The k order of X
+//   and W only has to agree; outputs (and the residual) are in the paired order below (EPI 4: fp32 in logical order).
 // k_gemm_f16_glds's structure (gemm_f16.hpp): 128 rows x BN features x 32 k-tiles, operands HBM -> LDS by global_load_lds into a
 // swizzled image (chunk c of row r at slot c ^ ((r >> 1) & 3): conflict-free 16-byte fragment reads), two LDS buffers, ONE barrier
 // per k-tile, 4 waves as 2 x 2 of 64 rows x BN / 2 features, weight rows as the MFMA A operand.  A k-tile is four operand tiles
@@ -146,38 +148,68 @@ __global__ void __launch_bounds__(256) k_wide_stem_hp(const _Float16* __restrict
 //   EPI 4  (ReLU when relu) -> fp32 [M][N]                                              (the head's FC)
 // ext.X2h .. K2: a second operand pair accumulated into the same tile (conv3(x2) + downsample(x): the shortcut tensor never exists).
 // ---------------------------------------------------------------------------------------------------------------------------
+// Storage order of every (hi, lo) activation tensor this family writes from MFMA accumulators ("paired order"): inside each block
+// of 32 channels, logical channel 16 p + 4 g + r (p = 0, 1: the two 16-channel accumulator tiles, g = lane group, r = register) sits
+// at position 8 g + 4 p + r -- the eight values a lane holds of a tile PAIR are contiguous: one 16-byte store per plane instead of
+// two 8-byte ones (the store path is issue-bound: 16-byte stores run at about twice the bytes per clock of 8-byte ones), and as an
+// MFMA B operand chunk g of a k-tile is again one 16-byte load with k-slot j <-> channel 16 (j >> 2) + 4 g + (j & 3) (the weights'
+// k columns are permuted to match when they are packed, osnet_wide_hp_pack.hpp).  Elementwise kernels never notice.
+// (hp_paired_pos: osnet_wide_hp_pack.hpp)
+__device__ inline void hp_store_pair(_Float16* ph, _Float16* pl, f4 v0, f4 v1) {
+    h4 h0, l0, h1, l1;
+    split4(v0, h0, l0);
+    split4(v1, h1, l1);
+    *reinterpret_cast<h8*>(ph) = cat8(h0, h1);
+    *reinterpret_cast<h8*>(pl) = cat8(l0, l1);
+}
+__device__ inline void hp_load_pair(const _Float16* ph, const _Float16* pl, f4& v0, f4& v1) {
+    const h8 hh = *reinterpret_cast<const h8*>(ph), ll = *reinterpret_cast<const h8*>(pl);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { v0[r] = (float)hh[r] + (float)ll[r]; v1[r] = (float)hh[4 + r] + (float)ll[4 + r]; }
+}
+
 struct GemmHpExt {
     const _Float16 *X2h = nullptr, *X2l = nullptr, *W2h = nullptr, *W2l = nullptr;
     int K2 = 0;
 };
 
-template <int BN>
-__host__ __device__ constexpr int gemm_hp_lds_bytes() { return 2 * (2 * BN * 32 + 2 * 128 * 32) * 2; }
+// DB = 2: two LDS operand buffers, one barrier per k-tile (deep products: the transitions, conv5); DB = 1: one buffer, two barriers
+// per k-tile, half the LDS and <= 128 registers -- FOUR workgroups per CU instead of two: the 1x1 convolutions of the OSBlocks have
+// 2 .. 12 k-tiles and move 128 x (K + N) x 4 bytes per tile; they wait on HBM, and what hides that is more tiles in flight per CU
+template <int BN, int DB = 2>
+__host__ __device__ constexpr int gemm_hp_lds_bytes() { return DB * (2 * BN * 32 + 2 * 128 * 32) * 2; }
 
-template <int EPI, int BN>
-__global__ void __launch_bounds__(256) k_gemm_hp(const _Float16* __restrict__ Xh, const _Float16* __restrict__ Xl,
+template <int EPI, int BN, int DB = 2>
+__global__ void __launch_bounds__(256, DB == 1 ? 4 : 1) k_gemm_hp(const _Float16* __restrict__ Xh, const _Float16* __restrict__ Xl,
                                                  const _Float16* __restrict__ Wh, const _Float16* __restrict__ Wl,
                                                  const float* __restrict__ bias, void* __restrict__ Oh, void* __restrict__ Ol,
                                                  const _Float16* __restrict__ res_h, const _Float16* __restrict__ res_l, int M, int N, int K,
                                                  int relu, GemmHpExt ext) {
     static_assert(BN == 32 || BN == 64 || BN == 96 || BN == 128, "feature tile");
-    constexpr int NTW = BN / 32;                          // 16-feature MFMA tiles per wave
+    // waves as WM x WN: 2 x 2 of 64 rows x BN / 2 features when BN / 2 is a whole number of 32-channel storage blocks, else 4 x 1 of
+    // 32 rows x BN features -- a wave always owns PAIRS of 16-feature tiles (hp_store_pair)
+    constexpr int WN = BN % 64 == 0 ? 2 : 1, WM = 4 / WN;
+    constexpr int RT = 8 / WM;                            // 16-row tiles per wave
+    constexpr int NTW = BN / WN / 16;                     // 16-feature MFMA tiles per wave
+    static_assert(NTW % 2 == 0, "tile pairs");
+    static_assert(EPI < 2 || EPI > 3 || WN == 2, "the pooling epilogues fold row tiles of one wave");
     constexpr int TW = BN * 32, TX = 128 * 32;            // halves per operand tile
     constexpr int BUF = 2 * TW + 2 * TX;
     constexpr int WBLK = BN / 16;                         // 16-row copy blocks of a weight tile (an activation tile has 8)
     BM_DYNAMIC_LDS_T(unsigned char, lds_raw);
     _Float16* lds = reinterpret_cast<_Float16*>(lds_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = BM_UNIFORM_I32(tid >> 6), g = lane >> 4, l16 = lane & 15;
-    const int wn = wave >> 1, wm = wave & 1;
+    const int wn = WN == 2 ? wave >> 1 : 0, wm = WN == 2 ? wave & 1 : wave;
+    const int row_w = wm * (128 / WM), col_w = wn * (BN / WN);
     int mt, nt;
     gemm_tile_of_block((M + GEMM_BM - 1) / GEMM_BM, N / BN, mt, nt);
     const long m0 = (long)mt * GEMM_BM;
     const int n0 = nt * BN;
-    f4 acc[NTW][4];
+    f4 acc[NTW][RT];
 #pragma unroll
     for (int a = 0; a < NTW; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < RT; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
     // a copy moves one 16-row block of an operand tile (64 lanes x 16 bytes): lane -> (row lr of the block, chunk slot lc); the
     // swizzle is applied to the SOURCE chunk (the destination is lane-linear)
     const int lr = lane >> 2, lc = (lane & 3) ^ ((lr >> 1) & 3);
@@ -211,98 +243,112 @@ __global__ void __launch_bounds__(256) k_gemm_hp(const _Float16* __restrict__ Xh
     };
     issue(0, 0);
     // the shortcut operand of the epilogue does not depend on the product: fetch it now, its latency hides behind the k-loop
-    h4 rrh[EPI == 1 ? NTW : 1][4], rrl[EPI == 1 ? NTW : 1][4];
-    if constexpr (EPI == 1) {
+    // (DB = 1: the other workgroups of the CU hide it, and 64 registers of prefetch would not fit the 128 of that form)
+    constexpr bool RES_EARLY = EPI == 1 && DB == 2;
+    h8 rrh[RES_EARLY ? NTW / 2 : 1][RT], rrl[RES_EARLY ? NTW / 2 : 1][RT];
+    if constexpr (RES_EARLY) {
 #pragma unroll
-        for (int p = 0; p < NTW; ++p)
+        for (int q = 0; q < NTW / 2; ++q)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                long m = m0 + wm * 64 + t * 16 + l16;
+            for (int t = 0; t < RT; ++t) {
+                long m = m0 + row_w + t * 16 + l16;
                 if (m >= M) m = M - 1;
-                const long o = m * N + n0 + wn * (BN / 2) + p * 16 + 4 * g;
-                rrh[p][t] = *reinterpret_cast<const h4*>(res_h + o);
-                rrl[p][t] = *reinterpret_cast<const h4*>(res_l + o);
+                const long o = m * N + n0 + col_w + 32 * q + 8 * g;
+                rrh[q][t] = *reinterpret_cast<const h8*>(res_h + o);
+                rrl[q][t] = *reinterpret_cast<const h8*>(res_l + o);
             }
     }
     for (int kt = 0; kt < nk; ++kt) {
         BM_WAIT_VM0();                      // this wave's copies of tile kt have landed ...
         __syncthreads();                    // ... everybody's have, and buffer (kt + 1) & 1 is free
-        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-        const _Float16* sWh = lds + (kt & 1) * BUF;
+        if (DB == 2 && kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        const _Float16* sWh = lds + (DB == 2 ? (kt & 1) * BUF : 0);
         const _Float16* sWl = sWh + TW;
         const _Float16* sXh = sWh + 2 * TW;
         const _Float16* sXl = sXh + TX;
-        h8 ah[NTW], al[NTW], bh[4], bl[4];
+        h8 ah[NTW], al[NTW], bh[RT], bl[RT];
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
-            const int ra = wn * (BN / 2) + t * 16 + l16, o = ra * 32 + 8 * (g ^ ((ra >> 1) & 3));
+            const int ra = col_w + t * 16 + l16, o = ra * 32 + 8 * (g ^ ((ra >> 1) & 3));
             ah[t] = *reinterpret_cast<const h8*>(sWh + o);
             al[t] = *reinterpret_cast<const h8*>(sWl + o);
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int rb = wm * 64 + t * 16 + l16, o = rb * 32 + 8 * (g ^ ((rb >> 1) & 3));
+        for (int t = 0; t < RT; ++t) {
+            const int rb = row_w + t * 16 + l16, o = rb * 32 + 8 * (g ^ ((rb >> 1) & 3));
             bh[t] = *reinterpret_cast<const h8*>(sXh + o);
             bl[t] = *reinterpret_cast<const h8*>(sXl + o);
         }
 #pragma unroll
         for (int p = 0; p < NTW; ++p)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[p][t] = mm3r(ah[p], al[p], bh[t], bl[t], acc[p][t]);
+            for (int t = 0; t < RT; ++t) acc[p][t] = mm3r(ah[p], al[p], bh[t], bl[t], acc[p][t]);
+        if (DB == 1 && kt + 1 < nk) {
+            __syncthreads();                // every wave has read the tile out of the single buffer
+            issue(kt + 1, 0);
+        }
     }
     if constexpr (EPI == 2 || EPI == 3) {
         // transition layer: ReLU(conv + bias) then the 2 x 2 average pool, on the accumulators (k_gemm_f16_glds EPI 5 / 6)
         constexpr int POOL_W = EPI == 2 ? 32 : 16, dt = POOL_W / 16, sh = EPI == 2 ? 5 : 4;
 #pragma unroll
-        for (int p = 0; p < NTW; ++p) {
-            const int n = n0 + wn * (BN / 2) + p * 16 + 4 * g;
-            const f4 bv = *reinterpret_cast<const f4*>(bias + n);
+        for (int q = 0; q < NTW / 2; ++q) {
+            const int n = n0 + col_w + 32 * q;
+            const f4 bv0 = *reinterpret_cast<const f4*>(bias + n + 4 * g), bv1 = *reinterpret_cast<const f4*>(bias + n + 16 + 4 * g);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < RT; ++t) {
                 if ((t / dt) & 1) continue;                      // the lower image row of a pair: folded into its upper one
-                const long m = m0 + wm * 64 + t * 16 + l16;
-                f4 o;
+                const long m = m0 + row_w + t * 16 + l16;
+                f4 o[2];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float top = acc[p][t][r] + bv[r], bot = acc[p][(t + dt) & 3][r] + bv[r];
-                    float v = BM_RELU_F32(top) + BM_RELU_F32(bot);
-                    v = v + BM_QUAD_SWAP1_F32(v);
-                    o[r] = v * 0.25f;
-                }
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float b = p ? bv1[r] : bv0[r];
+                        const float top = acc[2 * q + p][t][r] + b, bot = acc[2 * q + p][(t + dt) % RT][r] + b;
+                        float v = BM_RELU_F32(top) + BM_RELU_F32(bot);
+                        v = v + BM_QUAD_SWAP1_F32(v);
+                        o[p][r] = v * 0.25f;
+                    }
                 if (m < M && (l16 & 1) == 0) {
-                    const long q = m >> sh, x = m & (POOL_W - 1);                    // q = crop * H + y (y even)
-                    const long off = ((q >> 1) * (POOL_W / 2) + (x >> 1)) * N + n;
-                    h4 hh, ll;
-                    split4(o, hh, ll);
-                    *reinterpret_cast<h4*>(static_cast<_Float16*>(Oh) + off) = hh;
-                    *reinterpret_cast<h4*>(static_cast<_Float16*>(Ol) + off) = ll;
+                    const long qq = m >> sh, x = m & (POOL_W - 1);                    // qq = crop * H + y (y even)
+                    const long off = ((qq >> 1) * (POOL_W / 2) + (x >> 1)) * N + n + 8 * g;
+                    hp_store_pair(static_cast<_Float16*>(Oh) + off, static_cast<_Float16*>(Ol) + off, o[0], o[1]);
                 }
             }
         }
         return;
     }
 #pragma unroll
-    for (int p = 0; p < NTW; ++p) {
-        const int n = n0 + wn * (BN / 2) + p * 16 + 4 * g;
-        f4 bv = f4{0.f, 0.f, 0.f, 0.f};
-        if (bias) bv = *reinterpret_cast<const f4*>(bias + n);
+    for (int q = 0; q < NTW / 2; ++q) {
+        const int n = n0 + col_w + 32 * q;
+        f4 bv0 = f4{0.f, 0.f, 0.f, 0.f}, bv1 = bv0;
+        if (bias) { bv0 = *reinterpret_cast<const f4*>(bias + n + 4 * g); bv1 = *reinterpret_cast<const f4*>(bias + n + 16 + 4 * g); }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const long m = m0 + wm * 64 + t * 16 + l16;
+        for (int t = 0; t < RT; ++t) {
+            const long m = m0 + row_w + t * 16 + l16;
             if (m >= M) continue;
-            f4 v = acc[p][t] + bv;
+            f4 v0 = acc[2 * q][t] + bv0, v1 = acc[2 * q + 1][t] + bv1;
             if constexpr (EPI == 1) {
+                h8 rh, rl;
+                if constexpr (RES_EARLY) { rh = rrh[q][t]; rl = rrl[q][t]; }
+                else {
+                    const long o = m * N + n + 8 * g;
+                    rh = *reinterpret_cast<const h8*>(res_h + o); rl = *reinterpret_cast<const h8*>(res_l + o);
+                }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += (float)rrh[p][t][r] + (float)rrl[p][t][r];
+                for (int r = 0; r < 4; ++r) {
+                    v0[r] += (float)rh[r] + (float)rl[r];
+                    v1[r] += (float)rh[4 + r] + (float)rl[4 + r];
+                }
             }
-            if (relu) v = relu4(v);
-            if constexpr (EPI == 4) {
-                *reinterpret_cast<f4*>(static_cast<float*>(Oh) + m * N + n) = v;
+            if (relu) { v0 = relu4(v0); v1 = relu4(v1); }
+            if constexpr (EPI == 4) {                  // fp32, logical channel order
+                *reinterpret_cast<f4*>(static_cast<float*>(Oh) + m * N + n + 4 * g) = v0;
+                *reinterpret_cast<f4*>(static_cast<float*>(Oh) + m * N + n + 16 + 4 * g) = v1;
             } else {
-                h4 hh, ll;
-                split4(v, hh, ll);
-                *reinterpret_cast<h4*>(static_cast<_Float16*>(Oh) + m * N + n) = hh;
-                *reinterpret_cast<h4*>(static_cast<_Float16*>(Ol) + m * N + n) = ll;
+                const long off = m * N + n + 8 * g;
+                hp_store_pair(static_cast<_Float16*>(Oh) + off, static_cast<_Float16*>(Ol) + off, v0, v1);
             }
         }
     }
@@ -311,7 +357,7 @@ __global__ void __launch_bounds__(256) k_gemm_hp(const _Float16* __restrict__ Xh
 // ---------------------------------------------------------------------------------------------------------------------------
 // k_chain_hp: the four LightConv chains of an OSBlock (osnet.py:223-241, 249-252: conv2a .. conv2d applied to x1) for a band of
 // image rows of one crop.
-//   x1h / x1l   (hi, lo) [n][H * W][C]: conv1's output
+//   x1h / x1l   (hi, lo) [n][H * W][C]: conv1's output (channels in the paired order, as every tensor here)
 //   wts         ten records (LightConv a0, b0, b1, c0 .. c2, d0 .. d3), each: 1x1 A fragment pairs [out tile][k-step] with the k-slots
 //               in the accumulator order (slot j of lane group g, step s <-> channel 16 (2 s + (j >> 2)) + 4 g + (j & 3)), then the
 //               depthwise taps fp32 [channel tile][g][tap][4] with BN folded, then the fp32 bias [C]   (pack_chain_hp)
@@ -402,18 +448,18 @@ __global__ void __launch_bounds__(512, 2) k_chain_hp(const _Float16* __restrict_
 #pragma unroll 1
     for (int br = 0; br < 4; ++br) {
         f4 cur[NT][CT];
-        // branch input: x1 (rows outside the image are the zero padding)
+        // branch input: x1 (rows outside the image are the zero padding); paired storage order: a tile pair per 16-byte load
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
             const bool ok = in_image(i);
-            const long o = (crop * P + (long)(ok ? y0 + wr_of(i) : 0) * W + x_of(i)) * C + 4 * g;
+            const long o = (crop * P + (long)(ok ? y0 + wr_of(i) : 0) * W + x_of(i)) * C + 8 * g;
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                const h4 hh = *reinterpret_cast<const h4*>(x1h + o + 16 * ct), ll = *reinterpret_cast<const h4*>(x1l + o + 16 * ct);
-                f4 v;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = ok ? (float)hh[r] + (float)ll[r] : 0.f;
-                cur[i][ct] = v;
+            for (int q = 0; q < CT / 2; ++q) {
+                f4 v0, v1;
+                hp_load_pair(x1h + o + 32 * q, x1l + o + 32 * q, v0, v1);
+                const f4 z = f4{0.f, 0.f, 0.f, 0.f};
+                cur[i][2 * q] = ok ? v0 : z;
+                cur[i][2 * q + 1] = ok ? v1 : z;
             }
         }
         BM_CPROF(1);
@@ -517,14 +563,12 @@ __global__ void __launch_bounds__(512, 2) k_chain_hp(const _Float16* __restrict_
             const int wr = wr_of(i);
             const bool own = wr >= HALO && wr < HALO + R;
             if (own) {
-                const long o = ((long)(y0 + wr) * W + x_of(i)) * C + 4 * g;
+                const long o = ((long)(y0 + wr) * W + x_of(i)) * C + 8 * g;
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    h4 hh, ll;
-                    split4(cur[i][ct], hh, ll);
-                    *reinterpret_cast<h4*>(oh + o + 16 * ct) = hh;
-                    *reinterpret_cast<h4*>(ol + o + 16 * ct) = ll;
-                    sum[ct] += cur[i][ct];
+                for (int q = 0; q < CT / 2; ++q) {
+                    hp_store_pair(oh + o + 32 * q, ol + o + 32 * q, cur[i][2 * q], cur[i][2 * q + 1]);
+                    sum[2 * q] += cur[i][2 * q];
+                    sum[2 * q + 1] += cur[i][2 * q + 1];
                 }
             }
         }
@@ -563,7 +607,7 @@ __global__ void __launch_bounds__(256) k_gate_sum4_hp(const _Float16* __restrict
     constexpr int HID = C / 16, CG = C / 8;
     __shared__ float s_mean[4][C];
     __shared__ float s_h[4][HID];
-    __shared__ __attribute__((aligned(16))) float s_g[4][C];
+    __shared__ __attribute__((aligned(16))) float s_g[4][C];            // indexed by the STORED position of the channel (paired order)
     const long n = blockIdx.x;
     const int tid = threadIdx.x;
     for (int e = tid; e < 4 * C; e += 256) {
@@ -585,7 +629,7 @@ __global__ void __launch_bounds__(256) k_gate_sum4_hp(const _Float16* __restrict
         const int b = e / C, c = e - b * C;
         float v = fc2_b[c];
         for (int k = 0; k < HID; ++k) v += fc2_w[c * HID + k] * s_h[b][k];
-        s_g[b][c] = 1.f / (1.f + BM_EXPF(-v));
+        s_g[b][hp_paired_pos(c)] = 1.f / (1.f + BM_EXPF(-v));
     }
     __syncthreads();
     const long p0 = (long)blockIdx.y * pix_per_block;

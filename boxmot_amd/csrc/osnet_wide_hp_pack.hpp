@@ -2,7 +2,8 @@
 // of an OSN1 blob split into fp16 (hi, lo) parts -- w = hi + lo, hi = fp16(w), lo = fp16(w - hi) -- and laid out the way its kernel
 // reads it; every tensor starts on a 16-byte boundary.  Shared by WideOsnetHP (osnet_wide_hp.hpp) and the emulation harness
 // (tests/host_emu/emu_wide_hp.cpp).
-//   GEMM operands (conv1, conv3, downsample, transitions, conv5, FC): two planes [N][K] as stored (k_gemm_hp)
+//   GEMM operands (conv1, conv3, downsample, transitions, conv5, FC): two planes [N][K], the k columns in the paired order of the
+//   activation tensors (k_gemm_hp)
 //   stem: A fragment pairs [ky][channel tile] (k_wide_stem_hp)
 //   LightConv chains: ten records per block (k_chain_hp): 1x1 pairs [out tile][k-step] with the k-slots in accumulator order,
 //   depthwise taps fp32 [channel tile][g][tap][4], bias fp32 [C]
@@ -17,6 +18,10 @@
 #include "reid_layout.hpp"
 
 namespace bm {
+
+// "paired" storage order of the family's activation tensors (osnet_wide_hp_kernels.hpp): inside each block of 32 channels, logical
+// channel 16 p + 4 g + r sits at position 8 g + 4 p + r
+constexpr int hp_paired_pos(int c) { return (c & ~31) + 8 * ((c >> 2) & 3) + 4 * ((c >> 4) & 1) + (c & 3); }
 
 struct GemmWHp { long wh = -1, wl = -1, bias = -1; int n = 0, k = 0; };
 struct BlockHp {
@@ -47,7 +52,8 @@ inline WideHpPack wide_pack_hp(const float* w, const OsnetLayout& L) {
         gw.wl = take((long)n * k * 2);
         uint16_t* dh = reinterpret_cast<uint16_t*>(P.data.data() + gw.wh);
         uint16_t* dl = reinterpret_cast<uint16_t*>(P.data.data() + gw.wl);
-        for (long i = 0; i < (long)n * k; ++i) split_hl(w[off + i] * scale, dh[i], dl[i]);
+        for (int r = 0; r < n; ++r)            // k columns in the order the consumed tensor is stored in
+            for (int c = 0; c < k; ++c) split_hl(w[off + (long)r * k + c] * scale, dh[(long)r * k + hp_paired_pos(c)], dl[(long)r * k + hp_paired_pos(c)]);
         return gw;
     };
     auto f32s = [&](const float* src, const float* add, int n) {

@@ -89,7 +89,11 @@ extern "C" int emu_wide_hp_forward(const float* blob, long n_floats, const float
     try {
         wide_hp_forward(launch, L, pk, wpa, W32, B, n, feats, rows, [&](int b, const _Float16* oh, const _Float16* ol, long n_pix, int cout) {
             if (stages && stages[b])
-                for (long i = 0; i < n_pix * cout; ++i) stages[b][i] = (float)oh[i] + (float)ol[i];
+                for (long px = 0; px < n_pix; ++px)            // block outputs are stored in the family's paired channel order
+                    for (int c = 0; c < cout; ++c) {
+                        const long i = px * cout + hp_paired_pos(c);
+                        stages[b][px * cout + c] = (float)oh[i] + (float)ol[i];
+                    }
         });
     } catch (const std::exception&) {
         return -4;
