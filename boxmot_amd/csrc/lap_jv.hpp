@@ -26,6 +26,10 @@
 #ifndef BM_JV_PROF
 #define BM_JV_PROF(k)            // tools/jv_prof.hip defines it to record a wall clock per phase
 #endif
+#ifndef BM_JV_T
+#define BM_JV_T_DECL
+#define BM_JV_T(k)               // tools/jv_prof.hip -DJV_FINE: shader clocks per segment of a row-reduction iteration / a fast augmentation
+#endif
 
 namespace bm {
 
@@ -74,11 +78,12 @@ __device__ inline int jv_wave_min(int v) {
 // with the winning lane offering its runner-up.  (A NaN cost never enters: every comparison with it is false.)
 struct JvTwo { double v1, v2; int j1, j2; };
 constexpr int JV_NO_COL = 0x7fffffff;
-__device__ inline void jv_two_insert(JvTwo& t, double r, int j) {
-    if (r < t.v2) {
-        if (r < t.v1) { t.v2 = t.v1; t.j2 = t.j1; t.v1 = r; t.j1 = j; }
-        else { t.v2 = r; t.j2 = j; }
-    }
+__device__ inline void jv_two_insert(JvTwo& t, double r, int j) {         // (selects: no divergent branches in the scans)
+    const bool lt1 = r < t.v1, lt2 = r < t.v2;
+    t.v2 = lt1 ? t.v1 : (lt2 ? r : t.v2);
+    t.j2 = lt1 ? t.j1 : (lt2 ? j : t.j2);
+    t.v1 = lt1 ? r : t.v1;
+    t.j1 = lt1 ? j : t.j1;
 }
 __device__ inline JvTwo jv_wave_two(const JvTwo& t) {
     JvTwo o;
@@ -89,6 +94,23 @@ __device__ inline JvTwo jv_wave_two(const JvTwo& t) {
     const int cj = own ? t.j2 : t.j1;
     o.v2 = jv_wave_min(cv);
     o.j2 = jv_wave_min(cv == o.v2 ? cj : JV_NO_COL);
+    return o;
+}
+
+// The same for lanes that each scanned a contiguous, ascending run of columns (lane l's columns all precede lane l + 1's): the
+// lowest lane holding the minimum holds its first column.
+__device__ inline JvTwo jv_wave_two_contig(const JvTwo& t, int lane) {
+    JvTwo o;
+    o.v1 = jv_wave_min(t.v1);
+    const unsigned long long b1 = __ballot(t.j1 != JV_NO_COL && t.v1 == o.v1);
+    const int l1 = b1 ? __builtin_ctzll(b1) : 0;
+    o.j1 = b1 ? (int)BM_READLANE_U32((unsigned)t.j1, l1) : JV_NO_COL;
+    const bool own = b1 && lane == l1;
+    const double cv = own ? t.v2 : t.v1;
+    const int cj = own ? t.j2 : t.j1;
+    o.v2 = jv_wave_min(cv);
+    const unsigned long long b2 = __ballot(cj != JV_NO_COL && cv == o.v2);
+    o.j2 = b2 ? (int)BM_READLANE_U32((unsigned)cj, __builtin_ctzll(b2)) : JV_NO_COL;
     return o;
 }
 
@@ -186,9 +208,33 @@ __device__ inline bool lap_jv_extended(const Ctx& c, const JvLds& L, int n_rows,
     for (int j = c.tid; j < n; j += c.nthr) if (L.x[L.y[j]] != j) L.y[j] = -1;
     __syncthreads();
     bool ok = true;
+    BM_JV_T_DECL
     BM_JV_PROF(1);
     if (c.wave == 0) {
         const int lane = c.lane;
+        // contiguous column run of a lane (row reduction, augmentation start); an odd run length keeps the 8-byte LDS accesses of the
+        // lanes (stride = run length) on distinct banks
+        const int cpl = ((n + WAVE - 1) / WAVE) | 1;
+        const int jbeg = lane * cpl < n ? lane * cpl : n, jend = jbeg + cpl < n ? jbeg + cpl : n;
+        // r(j) = e(i, j) - v[j] over the lane's run, eight columns' loads in flight at a time (the scans are latency chains otherwise)
+        // Branch-free (clamped addresses, selects): a column outside the run visits as r = LARGE with a row, which no comparison below
+        // lets win; the row kind (cost row | extension row: fill | 0) is a uniform branch.
+        auto scan_run = [&](int i, auto&& visit) {
+            const bool ext = i >= n_rows;
+            for (int jb = jbeg; jb < jend; jb += 8) {
+                double e[8], vv[8];
+                int yy[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int j = jb + u, jc = j < jend ? j : jend - 1;
+                    vv[u] = L.v[jc]; yy[u] = L.y[jc];
+                    if (ext) e[u] = jc < n_cols ? fill : 0.0;
+                    else { const double ce = cost_of(i, jc < n_cols ? jc : n_cols - 1); e[u] = jc < n_cols ? ce : fill; }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const bool in = jb + u < jend; visit(jb + u, in ? e[u] - vv[u] : JV_LARGE, in ? yy[u] : 0); }
+            }
+        };
         // ---- free rows (ascending) and reduction transfer, row by row: a transfer changes v for the rows after it ----
         int n_free = 0;
         for (int i = 0; i < n; ++i) {
@@ -219,16 +265,15 @@ __device__ inline bool lap_jv_extended(const Ctx& c, const JvLds& L, int n_rows,
             while (current < n_free) {
                 if (++guard > guard_max) { ok = false; break; }
                 ++rr_cnt;
+                BM_JV_T(0);
                 const int fi = L.free_rows[current++];
+                // each lane scans a CONTIGUOUS run of columns, ascending: "first column wins" across the lanes is then "lowest lane
+                // wins" -- one value reduction + a ballot per rank instead of a (value, column) reduction pair
                 JvTwo t{JV_LARGE, JV_LARGE, JV_NO_COL, JV_NO_COL};
-                for (int jb = lane; jb < n; jb += 4 * WAVE) {
-                    double e[4], vv[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { const int j = jb + u * WAVE; const bool in = j < n; e[u] = in ? e_of(fi, j) : 0.0; vv[u] = in ? L.v[j] : 0.0; }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { const int j = jb + u * WAVE; if (j < n) jv_two_insert(t, e[u] - vv[u], j); }
-                }
-                t = jv_wave_two(t);
+                scan_run(fi, [&](int j, double r, int) { jv_two_insert(t, r, j); });
+                BM_JV_T(1);
+                t = jv_wave_two_contig(t, lane);
+                BM_JV_T(2);
                 int j1 = t.j1, j2 = n > 1 ? t.j2 : -1;
                 const double v1 = t.v1, v2 = n > 1 ? t.v2 : JV_LARGE;
                 int i0 = L.y[j1];
@@ -250,6 +295,7 @@ __device__ inline bool lap_jv_extended(const Ctx& c, const JvLds& L, int n_rows,
                 }
                 if (lane == 0) { L.x[fi] = j1; L.y[j1] = fi; }
                 BM_WAVE_LDS_SYNC();
+                BM_JV_T(3);
             }
             n_free = new_free;
         }
@@ -257,6 +303,31 @@ __device__ inline bool lap_jv_extended(const Ctx& c, const JvLds& L, int n_rows,
         // ---- augmentation (_ca_dense): shortest augmenting path per remaining free row ----
         for (int f = 0; f < n_free && ok; ++f) {
             const int fi = L.free_rows[f];
+            {
+                // The first _find_dense of a search starts from the identity list: its ready run is every column at the minimum of
+                // d = e(fi, .) - v in ascending order (a restart discards what was gathered before the first occurrence of the final
+                // minimum), and the search ends there if one of them has no row -- the LAST such column (the loop over the run keeps
+                // overwriting).  That is the whole augmentation then (no dual update: n_ready = 0; the path is the single edge):
+                // two reductions instead of the list machinery.  DeepOCSORT's recovery rounds (a few rows against hundreds of
+                // columns, nearly all pairs tied at 0) are ~400 such searches per call.
+                double dm = JV_LARGE;
+                int last_free = -1;              // the lane's last column without a row among those at its own minimum
+                scan_run(fi, [&](int j, double r, int yj) {
+                    const bool lt = r < dm, fr = yj < 0;
+                    last_free = lt ? (fr ? j : -1) : ((r == dm && fr) ? j : last_free);
+                    dm = lt ? r : dm;
+                });
+                const double m = jv_wave_min(dm);
+                if (dm != m) last_free = -1;
+                const unsigned long long fb = __ballot(last_free >= 0);
+                if (fb) {
+                    const int fj = (int)BM_READLANE_U32((unsigned)last_free, 63 - __builtin_clzll(fb));
+                    BM_WAVE_LDS_SYNC();
+                    if (lane == 0) { L.x[fi] = fj; L.y[fj] = fi; }
+                    BM_WAVE_LDS_SYNC();
+                    continue;
+                }
+            }
             for (int jb = lane; jb < n; jb += 4 * WAVE) {
                 double e[4], vv[4];
 #pragma unroll
@@ -267,6 +338,12 @@ __device__ inline bool lap_jv_extended(const Ctx& c, const JvLds& L, int n_rows,
             BM_WAVE_LDS_SYNC();
             int lo = 0, hi = 0, final_j = -1, n_ready = 0;
             long guard = 0;
+            // A pop whose row is an EXTENSION row (all of them are the same row: fill | 0) relaxes with cred(j) = e_ext(j) - v[j] - h;
+            // if such a pop changed nothing (no d[j] lowered), any later one with the same h changes nothing either while d is
+            // unchanged (v is fixed during a search and the TODO list only shrinks): it is `lo++` and nothing else.  With thousands
+            // of tied ready columns these are 95 - 98 % of all pops (profiles/r4_jv_prof.txt); they are recognised 64 at a time.
+            bool memo_ok = false;
+            double memo_h = 0.0;
             while (final_j == -1) {
                 if (++guard > 4L * n + 64) { ok = false; break; }
                 if (lo == hi) {
@@ -316,6 +393,18 @@ __device__ inline bool lap_jv_extended(const Ctx& c, const JvLds& L, int n_rows,
                     // _scan_dense: relax from the ready columns; columns that reach the minimum join the ready set
                     int found = -1;
                     while (lo != hi && found < 0) {
+                        if (memo_ok) {
+                            const int kq = lo + lane;
+                            bool hit = false;
+                            if (kq < hi) {
+                                const int jq = L.cols[kq], iq = L.y[jq];
+                                if (iq >= n_rows) hit = e_of(iq, jq) - L.v[jq] - L.d[jq] == memo_h;
+                            }
+                            const unsigned long long miss = ~__ballot(hit);
+                            const int run = miss ? __builtin_ctzll(miss) : WAVE;
+                            if (run > 0) { lo += run; continue; }
+                        }
+                        bool any_lower = false;
                         const int j0 = L.cols[lo++];
                         const int i = L.y[j0];
                         const double mind = L.d[j0];
@@ -343,6 +432,7 @@ __device__ inline bool lap_jv_extended(const Ctx& c, const JvLds& L, int n_rows,
                                     const double cred = e[u] - vv[u] - h;
                                     if (cred < dd[u]) { L.d[j] = cred; L.pred[j] = i; flag = cred == mind; }
                                 }
+                                any_lower = any_lower || __ballot(in && e[u] - vv[u] - h < dd[u]) != 0ull;
                                 const unsigned long long fl = __ballot(flag);
                                 if (fl) {
                                     const unsigned long long un = __ballot(flag && yy[u] < 0);      // the first of these ends the search
@@ -353,6 +443,8 @@ __device__ inline bool lap_jv_extended(const Ctx& c, const JvLds& L, int n_rows,
                             }
                         }
                         BM_WAVE_LDS_SYNC();
+                        if (any_lower) memo_ok = false;
+                        else if (i >= n_rows && found < 0) { memo_ok = true; memo_h = h; }
                         if (found >= 0) --lo;      // the sequential code returns before writing `lo` back
                     }
                     final_j = found;

@@ -117,3 +117,20 @@ def test_list_permutation_of_a_chunk_matches_the_sequential_swaps():
                 whi += 1
         got_hi = lib.emu_jv_move(n, cols.ctypes.data, base, l0, ctypes.c_uint64(q), hi)
         assert got_hi == whi and np.array_equal(cols, want), (case, g0, l0, hi, base, valid, seg_end, bin(q))
+
+
+def test_device_jv_tie_heavy_shapes_of_the_fast_paths():
+    """Shapes and densities that put the solver on its three shortcuts -- the contiguous-run two-smallest reduction of the row
+    reduction, the single-reduction augmentation (first ready run already holds a free column) and the recognition of repeated
+    no-op pops of extension rows (95 - 98 % of the pops of these matrices, profiles/r4_jv_prof.txt) -- and off them again (denser
+    negatives: real rows relax, the memo is invalidated).  Tie for tie against the sequential code, with and without cost_limit."""
+    lib = _lib(64)
+    rng = np.random.default_rng(1)
+    for nr, nc, p in ((30, 400, 0.05), (60, 300, 0.1), (100, 512, 0.02), (20, 400, 0.3), (128, 512, 0.2), (17, 401, 0.0025), (40, 40, 0.5), (300, 20, 0.05)):
+        c = -np.where(rng.random((nr, nc)) < p, np.round(rng.random((nr, nc)), 2), 0.0)
+        for limit in (None, 0.5):
+            x = np.full(nr, -9, np.int32)
+            y = np.full(nc, -9, np.int32)
+            assert lib.emu_lap_jv(nr, nc, c.ctypes.data, int(limit is not None), float(limit or 0.0), x.ctypes.data, y.ctypes.data) == 1
+            _, wx, wy = olap.lapjv(c, extend_cost=True, cost_limit=np.inf if limit is None else limit)
+            assert np.array_equal(x, wx) and np.array_equal(y, wy), (nr, nc, p, limit)

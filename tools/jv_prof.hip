@@ -7,6 +7,11 @@
 #include <vector>
 __device__ long long g_jv_clk[8];
 #define BM_JV_PROF(k) do { if (threadIdx.x == 0) g_jv_clk[k] = wall_clock64(); } while (0)
+#ifdef JV_FINE
+__device__ long long g_jv_fine[8];
+#define BM_JV_T(k) do { const long long t_ = clock64(); if (threadIdx.x == 0) { g_jv_fine[k] += t_ - jv_t0; } jv_t0 = clock64(); } while (0)
+#define BM_JV_T_DECL long long jv_t0 = clock64();
+#endif
 #include "lap_jv.hpp"
 
 template <int NTHR>
@@ -40,5 +45,10 @@ int main(int argc, char** argv) {
         printf("%d x %d: %.3f ms | us (100 MHz clock): minima+claim %.1f transfer %.1f row-reduction %.1f augmentation %.1f tail %.1f\n", nr, nc, ms,
                (clk[1] - clk[0]) / 100.0, (clk[2] - clk[1]) / 100.0, (clk[3] - clk[2]) / 100.0, (clk[4] - clk[3]) / 100.0, (clk[5] - clk[4]) / 100.0);
     }
+#ifdef JV_FINE
+    long long fine[8];
+    hipMemcpyFromSymbol(fine, HIP_SYMBOL(g_jv_fine), sizeof(fine));
+    printf("  row-reduction iteration segments, shader clocks summed over 3 runs: [loop head -> fetch] %lld  scan %lld  reduce %lld  tail %lld\n", fine[0], fine[1], fine[2], fine[3]);
+#endif
     return 0;
 }
