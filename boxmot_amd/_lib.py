@@ -77,7 +77,14 @@ class DeepOcSortConfig(ctypes.Structure):
         ("emb_dim", ctypes.c_int),
         ("use_byte", ctypes.c_int),
         ("min_conf", ctypes.c_double),
+        ("asso_func", ctypes.c_int),
+        ("frame_w", ctypes.c_int),
+        ("frame_h", ctypes.c_int),
     ]
+
+
+# BOXMOT_HIP_ASSO_* (include/boxmot_hip.h): the axis-aligned entries of AssociationFunction._get_asso_func (iou.py:408-417)
+ASSO_FUNCS = {"iou": 0, "giou": 1, "diou": 2, "ciou": 3, "hmiou": 4, "centroid": 5}
 
 
 class StrongSortConfig(ctypes.Structure):

@@ -21,6 +21,8 @@ AABB_COLS = 6   # x1,y1,x2,y2,conf,cls     detection_layout.py:61-71
 OBB_COLS = 7    # cx,cy,w,h,angle,conf,cls  detection_layout.py:74-84
 CONF_IDX, CLS_IDX = 4, 5
 OUT_COLS = 8
+# the keys of AssociationFunction._get_asso_func's table (trackers/association/iou.py:408-417), in its order
+ASSO_NAMES = ("iou", "iou_obb", "hmiou", "giou", "ciou", "diou", "centroid", "centroid_obb")
 
 
 class BaseTracker:
@@ -32,8 +34,6 @@ class BaseTracker:
                  is_obb: bool = False, **kwargs):
         if is_obb:
             raise AssertionError(f"{type(self).__name__} does not support OBB detections.")
-        if asso_func != "iou":
-            raise NotImplementedError("boxmot_amd implements the 'iou' association function only")
         self.det_thresh = det_thresh
         self.max_age = max_age
         self.max_obs = max_obs
@@ -41,6 +41,7 @@ class BaseTracker:
         self.iou_threshold = iou_threshold
         self.per_class = per_class
         self.nr_classes = nr_classes
+        self._asso_func_base_name = asso_func      # resolved on the first frame, like the reference (basetracker.py:175-180)
         self.asso_func_name = asso_func
         self.is_obb = False
         self.frame_count = 0
@@ -80,6 +81,8 @@ class BaseTracker:
                 self._first_dets_processed = True
         if not self._first_frame_processed and img is not None:
             self.h, self.w = img.shape[0:2]
+            if self.asso_func_name not in ASSO_NAMES:      # AssociationFunction._get_asso_func (iou.py:419-422)
+                raise ValueError(f"Invalid association mode: {self.asso_func_name}. Choose from {list(ASSO_NAMES)}")
             self._first_frame_processed = True
         return dets, img
 

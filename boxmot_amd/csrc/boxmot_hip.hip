@@ -1139,6 +1139,19 @@ void docs_zero_state(BoxMOTHipDeepOcSort* h) {
     BM_HIP(hipStreamSynchronize(h->stream));
 }
 
+// centroid's norm_factor = np.sqrt(self.w**2 + self.h**2) (iou.py:266) of the frame size the tracker read off its first image
+// (basetracker.py:175-180); 0 x 0 = not known yet
+void docs_set_frame_size(BoxMOTHipDeepOcSort* h, int w, int hgt) {
+    if (w < 0 || hgt < 0) throw std::runtime_error("boxmot_hip: frame size must not be negative");
+    h->args.cfg.asso_diag = (w > 0 && hgt > 0) ? std::sqrt((double)((long)w * w + (long)hgt * hgt)) : 0.0;
+}
+// a step is about to run: `centroid` needs the frame size (host updates carry it with the image; device-resident steps do not)
+void docs_need_frame_size(BoxMOTHipDeepOcSort* h, int image_rows, int image_cols) {
+    if (h->args.cfg.asso_mode != BOXMOT_HIP_ASSO_CENTROID || h->args.cfg.asso_diag > 0.0) return;
+    if (image_rows > 0 && image_cols > 0) { docs_set_frame_size(h, image_cols, image_rows); return; }
+    throw std::runtime_error("boxmot_hip: asso_func centroid needs the frame size (config frame_w / frame_h, or a host update with an image first)");
+}
+
 void docs_build(BoxMOTHipDeepOcSort* h) {
     const BoxMOTHipDeepOcSortConfig& c = h->cfg;
     if (c.n_streams < 1 || c.max_tracks < 8 || c.max_dets < 4 || c.emb_dim < 1)
@@ -1155,6 +1168,10 @@ void docs_build(BoxMOTHipDeepOcSort* h) {
     d.embedding_off = c.embedding_off; d.aw_off = c.aw_off;
     if (c.use_byte && !c.embedding_off) throw std::runtime_error("boxmot_hip: use_byte is OC-SORT's option and needs embedding_off = 1");
     d.use_byte = c.use_byte ? 1 : 0; d.min_conf_f32 = (float)c.min_conf;
+    if (c.asso_func < BOXMOT_HIP_ASSO_IOU || c.asso_func > BOXMOT_HIP_ASSO_CENTROID)
+        throw std::runtime_error("boxmot_hip: asso_func must be one of BOXMOT_HIP_ASSO_* (iou, giou, diou, ciou, hmiou, centroid)");
+    d.asso_mode = c.asso_func;
+    docs_set_frame_size(h, c.frame_w, c.frame_h);
     RecAlloc table_allocator{&h->owned, &h->table_rec};
     bm::DocsSizes z{h->S, h->cap, h->nd, h->dim};
     bm::docs_allocate(h->args, z, table_allocator);
@@ -2039,6 +2056,7 @@ void boxmot_hip_deepocsort_default_config(BoxMOTHipDeepOcSortConfig* c) {
     c->reid_model_path = nullptr;
     c->n_streams = 1; c->max_tracks = 1024; c->max_dets = 256; c->emb_dim = 512;
     c->use_byte = 0; c->min_conf = 0.1;
+    c->asso_func = BOXMOT_HIP_ASSO_IOU; c->frame_w = 0; c->frame_h = 0;
 }
 
 BoxMOTHipDeepOcSort* boxmot_hip_deepocsort_create(const BoxMOTHipDeepOcSortConfig* config) {
@@ -2102,6 +2120,7 @@ int boxmot_hip_deepocsort_update_batch(BoxMOTHipDeepOcSort* handle, int n_stream
         std::vector<StreamIn> in(n_streams);
         for (int s = 0; s < n_streams; ++s)
             in[s] = StreamIn{dets[s], det_rows[s], (embs && emb_cols > 0) ? embs[s] : nullptr, images ? images[s] : nullptr};
+        docs_need_frame_size(handle, image_rows, image_cols);
         docs_host_update(handle, n_streams, in.data(), 6, emb_cols, image_rows, image_cols, image_channels, out_tracks,
                          out_capacity_rows, out_rows);
     });
@@ -2119,6 +2138,7 @@ int boxmot_hip_deepocsort_update(BoxMOTHipDeepOcSort* handle, const float* dets,
         if (image_rows <= 0 || image_cols <= 0) throw std::runtime_error("Image dimensions must be positive.");
         StreamIn in{dets, det_rows, (embs && emb_cols > 0) ? embs : nullptr, image};
         float* outs[1] = {out_tracks};
+        docs_need_frame_size(handle, image_rows, image_cols);
         docs_host_update(handle, 1, &in, det_cols, emb_cols, image_rows, image_cols, image_channels, outs, out_capacity_rows, out_rows);
         *out_is_obb = 0;
     });
@@ -2136,6 +2156,7 @@ int boxmot_hip_deepocsort_update_stream(BoxMOTHipDeepOcSort* handle, int stream,
         if (image_rows <= 0 || image_cols <= 0) throw std::runtime_error("Image dimensions must be positive.");
         StreamIn in{dets, det_rows, (embs && emb_cols > 0) ? embs : nullptr, image};
         float* outs[1] = {out_tracks};
+        docs_need_frame_size(handle, image_rows, image_cols);
         docs_host_update(handle, 1, &in, det_cols, emb_cols, image_rows, image_cols, image_channels, outs, out_capacity_rows, out_rows,
                          stream, frame_count, id_count_inout);
         *out_is_obb = 0;
@@ -2148,6 +2169,7 @@ int boxmot_hip_deepocsort_step_device(BoxMOTHipDeepOcSort* handle, const float* 
         if (!handle) throw std::runtime_error("boxmot_hip DeepOCSORT handle is not initialized.");
         if (!d_dets || !d_det_rows || !d_out || !d_out_rows) throw std::runtime_error("boxmot_hip: null device pointers");
         if (!handle->cfg.embedding_off && !d_embs) throw std::runtime_error("boxmot_hip: step_device needs d_embs unless embedding_off");
+        docs_need_frame_size(handle, 0, 0);
         bm::DocsStepArgs a = handle->args;
         a.dets = d_dets; a.n_dets = d_det_rows; a.embs = handle->cfg.embedding_off ? nullptr : d_embs;
         const bool any_warp = io_consume_warps(handle);         // boxmot_hip_deepocsort_set_warp since the last step
@@ -2168,6 +2190,7 @@ int boxmot_hip_deepocsort_step_device_frames(BoxMOTHipDeepOcSort* handle, const 
         if (!d_dets || !d_det_rows || !d_out || !d_out_rows) throw std::runtime_error("boxmot_hip: null device pointers");
         if (!handle->cfg.embedding_off)      // deepocsort.py:337-345: every detection above det_thresh is embedded
             io_device_reid(handle, d_dets, d_det_rows, d_frames, image_rows, image_cols, (double)(float)handle->cfg.det_thresh, 0);
+        docs_need_frame_size(handle, image_rows, image_cols);
         bm::DocsStepArgs a = handle->args;
         a.dets = d_dets; a.n_dets = d_det_rows; a.embs = handle->cfg.embedding_off ? nullptr : handle->d_embs;
         const bool any_warp = io_consume_warps(handle);

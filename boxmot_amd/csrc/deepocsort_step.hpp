@@ -35,6 +35,10 @@ struct DocsConfigDev {
     // after the first round, with the predicted boxes of the still unmatched tracks
     int use_byte;
     float min_conf_f32;
+    // association function (BaseTracker's asso_func, trackers/association/iou.py:408-417): 0 iou, 1 giou, 2 diou, 3 ciou, 4 hmiou,
+    // 5 centroid; asso_diag = sqrt(w^2 + h^2) of the frame (centroid's norm_factor, iou.py:266; basetracker.py:175-180)
+    int asso_mode;
+    double asso_diag;
 };
 
 struct DocsState {
@@ -390,6 +394,54 @@ __device__ inline double iou_pair(const double* a, const double* b) {      // io
     return wh / ((a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - wh);
 }
 
+// The association function the constructor named (AssociationFunction._get_asso_func, iou.py:408-423), a = detection, b = track
+// box: the elementwise expressions of the batch functions in their order of evaluation (fp64; +, -, *, /, sqrt round as NumPy's
+// do -- `ciou` alone calls a libm function, arctan).  np.maximum / np.minimum propagate a NaN operand; the comparisons below
+// return the second operand then, which differs only for boxes that are NaN already (no detection or live track is).
+enum { ASSO_IOU = 0, ASSO_GIOU = 1, ASSO_DIOU = 2, ASSO_CIOU = 3, ASSO_HMIOU = 4, ASSO_CENTROID = 5 };
+__device__ inline double asso_pair(int mode, double diag, const double* a, const double* b) {
+    if (mode == ASSO_IOU) return iou_pair(a, b);
+    if (mode == ASSO_CENTROID) {                                    // iou.py:253-268
+        const double dx = (a[0] + a[2]) / 2 - (b[0] + b[2]) / 2, dy = (a[1] + a[3]) / 2 - (b[1] + b[3]) / 2;
+        return 1 - sqrt(dx * dx + dy * dy) / diag;
+    }
+    const double xx1 = a[0] > b[0] ? a[0] : b[0], yy1 = a[1] > b[1] ? a[1] : b[1];
+    const double xx2 = a[2] < b[2] ? a[2] : b[2], yy2 = a[3] < b[3] ? a[3] : b[3];
+    double w = xx2 - xx1, h = yy2 - yy1;
+    w = w > 0.0 ? w : 0.0; h = h > 0.0 ? h : 0.0;
+    const double wh = w * h;
+    const double area1 = (a[2] - a[0]) * (a[3] - a[1]), area2 = (b[2] - b[0]) * (b[3] - b[1]);
+    const double xxc1 = a[0] < b[0] ? a[0] : b[0], yyc1 = a[1] < b[1] ? a[1] : b[1];
+    const double xxc2 = a[2] > b[2] ? a[2] : b[2], yyc2 = a[3] > b[3] ? a[3] : b[3];
+    if (mode == ASSO_HMIOU) {                                       // iou.py:153-203
+        double uh = yyc2 - yyc1;
+        uh = uh > 1e-10 ? uh : 1e-10;
+        const double o = h / uh;
+        return wh / (area1 + area2 - wh + 1e-10) * o;
+    }
+    if (mode == ASSO_GIOU) {                                        // iou.py:205-244 (its assert on the enclosing box is not restated)
+        const double uni = area1 + area2 - wh, iou = wh / uni;
+        const double enc = (xxc2 - xxc1) * (yyc2 - yyc1);
+        return (iou - (enc - uni) / enc + 1.0) / 2.0;
+    }
+    const double cdx = (a[0] + a[2]) / 2.0 - (b[0] + b[2]) / 2.0, cdy = (a[1] + a[3]) / 2.0 - (b[1] + b[3]) / 2.0;
+    const double inner = cdx * cdx + cdy * cdy;
+    const double ox = xxc2 - xxc1, oy = yyc2 - yyc1;
+    if (mode == ASSO_DIOU) {                                        // iou.py:346-391
+        const double iou = wh / (area1 + area2 - wh);
+        return (iou - inner / (ox * ox + oy * oy) + 1) / 2.0;
+    }
+    // ciou, iou.py:283-344
+    const double eps = 1e-7;
+    const double iou = wh / (area1 + area2 - wh + eps);
+    const double outer = ox * ox + oy * oy + eps;
+    const double w1 = a[2] - a[0], h1 = a[3] - a[1] + eps, w2 = b[2] - b[0], h2 = b[3] - b[1] + eps;
+    const double ad = atan(w2 / h2) - atan(w1 / h1);
+    const double vv = (4 / (3.141592653589793 * 3.141592653589793)) * (ad * ad);
+    const double alpha = vv / ((1 - iou) + vv + eps);
+    return (iou - inner / outer + alpha * vv + 1) / 2.0;
+}
+
 // KalmanBoxTracker.update(det) + update_emb for one matched (track slot, kept detection) pair: one wavefront.
 // deepocsort.py:143-185, xysr.py:383-476.
 __device__ inline void docs_apply_match(DV& v, int slot, int kd, int lane) {
@@ -597,7 +649,7 @@ __device__ inline void docs_step_stream(const DocsStepArgs& args, int s, int* s_
             const float* df = v.dets + v.keep[k] * DET_COLS;
             const double db[4] = {(double)df[0], (double)df[1], (double)df[2], (double)df[3]};
             const double score = (double)df[4];
-            const double io = iou_pair(db, v.trk_box + t * 4);
+            const double io = asso_pair(cfg.asso_mode, cfg.asso_diag, db, v.trk_box + t * 4);
             v.iou[k * ld + t] = io;
             const double* ko = v.kobs + t * 5;
             const double cx1 = (db[0] + db[2]) / 2.0, cy1 = (db[1] + db[3]) / 2.0;
@@ -734,7 +786,7 @@ __device__ inline void docs_step_stream(const DocsStepArgs& args, int s, int* s_
         for (int b = c.lane; b < n_ut; b += WAVE) {
             const float* df = v.dets + v.keep[nk + a] * DET_COLS;
             const double db[4] = {(double)df[0], (double)df[1], (double)df[2], (double)df[3]};
-            const double io = iou_pair(db, v.trk_box + v.un_t[b] * 4);
+            const double io = asso_pair(cfg.asso_mode, cfg.asso_diag, db, v.trk_box + v.un_t[b] * 4);
             v.iou[a * ld + b] = io;
             v.cost[a * ld + b] = -io;
             mxi = io > mxi ? io : mxi;
@@ -777,7 +829,7 @@ __device__ inline void docs_step_stream(const DocsStepArgs& args, int s, int* s_
         for (int b = c.lane; b < n_ut; b += WAVE) {
             const float* df = v.dets + v.keep[v.un_d[a]] * DET_COLS;
             const double db[4] = {(double)df[0], (double)df[1], (double)df[2], (double)df[3]};
-            const double io = iou_pair(db, v.last_obs + v.list[v.un_t[b]] * 5);
+            const double io = asso_pair(cfg.asso_mode, cfg.asso_diag, db, v.last_obs + v.list[v.un_t[b]] * 5);
             v.iou[a * ld + b] = io;
             v.cost[a * ld + b] = -io;
             mxi = io > mxi ? io : mxi;              // NaN (degenerate placeholder boxes) never wins: comparisons are false

@@ -71,6 +71,9 @@ class DeepOcSort(BaseTracker):
         cfg.embedding_off, cfg.cmc_off, cfg.aw_off = int(bool(embedding_off)), int(bool(cmc_off)), int(bool(aw_off))
         cfg.Q_xy_scaling, cfg.Q_s_scaling = Q_xy_scaling, Q_s_scaling
         cfg.use_byte, cfg.min_conf = (int(self._byte[0]), self._byte[1]) if hasattr(self, "_byte") else (0, 0.1)   # OcSort only
+        # the function behind the step's "iou" matrices (association.py:95, deepocsort.py:420, ocsort.py:457,486); a name
+        # outside the table raises on the first frame (BaseTracker._preprocess), where the reference resolves it
+        cfg.asso_func = _lib.ASSO_FUNCS.get(self.asso_func_name, 0)
         cfg.n_streams = self.nr_classes if self.per_class else 1
         cfg.max_tracks, cfg.max_dets, cfg.emb_dim = max_tracks, max_dets, self._emb_dim
         self._ids_issued = ctypes.c_int(0)           # KalmanBoxTracker.count - 1, shared by the per-class lists

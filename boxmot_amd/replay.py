@@ -111,14 +111,16 @@ class MultiStreamTracker:
             if "track_thresh" in kw:
                 cfg.track_high_thresh = cfg.new_track_thresh = kw.pop("track_thresh")
         if tracker_type == "ocsort":
-            kw.pop("asso_func", None)               # use_byte / min_conf are fields of the shared configuration
+            if "asso_func" in kw:                   # name -> BOXMOT_HIP_ASSO_* (use_byte / min_conf are fields of the shared configuration)
+                kw["asso_func"] = _lib.ASSO_FUNCS[kw["asso_func"]]
             cfg.embedding_off, cfg.cmc_off = 1, 1
         if tracker_type == "deepocsort":
             if not kw.pop("cmc_off", True):
                 raise NotImplementedError("DeepOCSORT camera-motion compensation is not implemented; pass cmc_off=True")
             cfg.cmc_off = 1
             kw.pop("iou_thresh", None)              # YAML key the reference swallows
-            kw.pop("asso_func", None)
+            if "asso_func" in kw:
+                kw["asso_func"] = _lib.ASSO_FUNCS[kw["asso_func"]]
         unknown = set(kw) - fields
         if unknown:
             raise TypeError(f"unknown {tracker_type} options: {sorted(unknown)}")

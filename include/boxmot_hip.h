@@ -290,6 +290,8 @@ int boxmot_hip_ingest_host_done(BoxMOTHipIngest* handle, int slot);
  * conventions, c_api.hpp:36-61).  Fields = the constructor arguments of DeepOcSort (deepocsort.py:263-281) and
  * of BaseTracker (basetracker.py:19-31).
  * ------------------------------------------------------------------------------------------------ */
+enum { BOXMOT_HIP_ASSO_IOU = 0, BOXMOT_HIP_ASSO_GIOU = 1, BOXMOT_HIP_ASSO_DIOU = 2, BOXMOT_HIP_ASSO_CIOU = 3,
+       BOXMOT_HIP_ASSO_HMIOU = 4, BOXMOT_HIP_ASSO_CENTROID = 5 };
 typedef struct BoxMOTHipDeepOcSortConfig {
     double det_thresh;
     int max_age;                     /* <= 45: the reference's filter keeps a 50-entry observation history (xysr.py:18) */
@@ -315,6 +317,12 @@ typedef struct BoxMOTHipDeepOcSortConfig {
      * association of detections with min_conf < score < det_thresh (ocsort.py:393-399, 456-485); use_byte needs embedding_off */
     int use_byte;
     double min_conf;
+    /* BaseTracker's asso_func (basetracker.py:28,69-71; AssociationFunction, trackers/association/iou.py:118-423): the function
+     * behind every "iou" matrix of the step (association.py:95, deepocsort.py:420, ocsort.py:457,486).  `centroid` normalises by
+     * the frame diagonal: frame_w / frame_h = the size the reference reads off its first image (basetracker.py:175-180); left 0
+     * they are taken from the first host update that carries an image (device-resident steps need them set). */
+    int asso_func;                   /* BOXMOT_HIP_ASSO_* */
+    int frame_w, frame_h;
 } BoxMOTHipDeepOcSortConfig;
 
 typedef struct BoxMOTHipDeepOcSort BoxMOTHipDeepOcSort;

@@ -10,7 +10,8 @@ Follows (statement order and NumPy calls kept, so results are bit-identical on o
     iou.py:134-150 (iou_batch), common/geometry.py:103-124 (xyxy2xysr).
 Pinned against the reference classes themselves (tests/test_oracle_vs_reference.py; fixtures
 tests/golden/deepocsort_golden.npz).  ``lap.lapjv`` is the oracle stand-in (oracle/lap.py, parity unpinned).
-Scope: axis-aligned boxes, ``cmc_off=True`` (or a warp supplied by the caller), asso_func "iou".
+Scope: axis-aligned boxes, ``cmc_off=True`` (or a warp supplied by the caller), every axis-aligned ``asso_func``
+(iou.py:118-423: iou, giou, diou, ciou, hmiou, centroid).
 """
 from __future__ import annotations
 
@@ -26,6 +27,8 @@ DEFAULTS = dict(
     det_thresh=0.3, max_age=30, max_obs=50, min_hits=3, iou_threshold=0.3,           # basetracker.py:19-31
     delta_t=3, inertia=0.2, w_association_emb=0.5, alpha_fixed_emb=0.95, aw_param=0.5,  # deepocsort.py:263-276
     embedding_off=False, aw_off=False, Q_xy_scaling=0.01, Q_s_scaling=0.0001,
+    asso_func="iou",                    # basetracker.py:28; the axis-aligned names of iou.py:408-417
+    frame_wh=None,                      # (w, h) for `centroid`; None: read off the first image (basetracker.py:175-180)
 )
 
 _F = np.eye(7)
@@ -276,6 +279,75 @@ def iou_batch(b1, b2):                              # iou.py:134-150
                  + (b2[..., 2] - b2[..., 0]) * (b2[..., 3] - b2[..., 1]) - wh)
 
 
+def _inter_enclose(b1, b2):
+    b2 = np.expand_dims(b2, 0)
+    b1 = np.expand_dims(b1, 1)
+    w = np.maximum(0.0, np.minimum(b1[..., 2], b2[..., 2]) - np.maximum(b1[..., 0], b2[..., 0]))
+    h = np.maximum(0.0, np.minimum(b1[..., 3], b2[..., 3]) - np.maximum(b1[..., 1], b2[..., 1]))
+    area1 = (b1[..., 2] - b1[..., 0]) * (b1[..., 3] - b1[..., 1])
+    area2 = (b2[..., 2] - b2[..., 0]) * (b2[..., 3] - b2[..., 1])
+    wc = np.maximum(b1[..., 2], b2[..., 2]) - np.minimum(b1[..., 0], b2[..., 0])
+    hc = np.maximum(b1[..., 3], b2[..., 3]) - np.minimum(b1[..., 1], b2[..., 1])
+    return b1, b2, w, h, area1, area2, wc, hc
+
+
+def hmiou_batch(b1, b2):                            # iou.py:153-203
+    b1, b2, w, h, area1, area2, wc, hc = _inter_enclose(b1, b2)
+    o = h / np.maximum(1e-10, hc)
+    inter = w * h
+    return inter / (area1 + area2 - inter + 1e-10) * o
+
+
+def giou_batch(b1, b2):                             # iou.py:205-244
+    b1, b2, w, h, area1, area2, wc, hc = _inter_enclose(b1, b2)
+    wh = w * h
+    union = area1 + area2 - wh
+    iou = wh / union
+    assert (wc > 0).all() and (hc > 0).all()
+    enclose = wc * hc
+    return (iou - (enclose - union) / enclose + 1.0) / 2.0
+
+
+def _centre_dist2(b1, b2):
+    return ((b1[..., 0] + b1[..., 2]) / 2.0 - (b2[..., 0] + b2[..., 2]) / 2.0) ** 2 \
+        + ((b1[..., 1] + b1[..., 3]) / 2.0 - (b2[..., 1] + b2[..., 3]) / 2.0) ** 2
+
+
+def diou_batch(b1, b2):                             # iou.py:346-391
+    b1, b2, w, h, area1, area2, wc, hc = _inter_enclose(b1, b2)
+    wh = w * h
+    iou = wh / (area1 + area2 - wh)
+    return (iou - _centre_dist2(b1, b2) / (wc ** 2 + hc ** 2) + 1) / 2.0
+
+
+def ciou_batch(b1, b2):                             # iou.py:283-344
+    eps = 1e-7
+    b1, b2, w, h, area1, area2, wc, hc = _inter_enclose(b1, b2)
+    wh = w * h
+    iou = wh / (area1 + area2 - wh + eps)
+    outer = wc ** 2 + hc ** 2 + eps
+    w1, h1 = b1[..., 2] - b1[..., 0], b1[..., 3] - b1[..., 1] + eps
+    w2, h2 = b2[..., 2] - b2[..., 0], b2[..., 3] - b2[..., 1] + eps
+    v = (4 / (np.pi ** 2)) * ((np.arctan(w2 / h2) - np.arctan(w1 / h1)) ** 2)
+    alpha = v / ((1 - iou) + v + eps)
+    return (iou - (_centre_dist2(b1, b2) / outer) + (alpha * v) + 1) / 2.0
+
+
+def centroid_batch(b1, b2, w, h):                   # iou.py:253-268
+    c1 = np.stack(((b1[..., 0] + b1[..., 2]) / 2, (b1[..., 1] + b1[..., 3]) / 2), axis=-1)
+    c2 = np.stack(((b2[..., 0] + b2[..., 2]) / 2, (b2[..., 1] + b2[..., 3]) / 2), axis=-1)
+    d = np.sqrt(np.sum((np.expand_dims(c1, 1) - np.expand_dims(c2, 0)) ** 2, axis=-1))
+    return 1 - d / np.sqrt(w ** 2 + h ** 2)
+
+
+def asso_function(name, w=None, h=None):            # AssociationFunction._get_asso_func, iou.py:396-423 (axis-aligned names)
+    table = {"iou": iou_batch, "hmiou": hmiou_batch, "giou": giou_batch, "ciou": ciou_batch, "diou": diou_batch,
+             "centroid": lambda a, b: centroid_batch(a, b, w, h)}
+    if name not in table:
+        raise ValueError(f"Invalid association mode: {name}. Choose from {list(table.keys())}")
+    return table[name]
+
+
 def _assign(cost):                                  # association.py:20-24
     _, x, y = oracle_lap.lapjv(cost, extend_cost=True)
     return np.array([[y[i], i] for i in x if i >= 0])
@@ -304,7 +376,7 @@ def aw_max_metric(emb_cost, w_emb0, bottom):        # association.py:29-58
     return w_emb * emb_cost
 
 
-def associate(dets, trks, iou_threshold, velocities, previous_obs, vdc_weight, emb_cost, w_assoc_emb, aw_off, aw_param):
+def associate(dets, trks, iou_threshold, velocities, previous_obs, vdc_weight, emb_cost, w_assoc_emb, aw_off, aw_param, asso=iou_batch):
     """association.py:61-152; returns (matches (K,2) [det, trk], unmatched_dets, unmatched_trks)."""
     if len(trks) == 0:
         return np.empty((0, 2), dtype=int), np.arange(len(dets)), np.empty((0, 5), dtype=int)
@@ -320,7 +392,7 @@ def associate(dets, trks, iou_threshold, velocities, previous_obs, vdc_weight, e
     diff_angle = (np.pi / 2.0 - np.abs(np.arccos(diff_cos))) / np.pi
     valid = np.ones(previous_obs.shape[0])
     valid[np.where(previous_obs[:, 4] < 0)] = 0
-    iou = iou_batch(dets, trks)
+    iou = asso(dets, trks)
     scores = np.repeat(dets[:, -1][:, np.newaxis], trks.shape[0], axis=1)
     valid = np.repeat(valid[:, np.newaxis], X.shape[1], axis=1)
     angle_cost = ((valid * diff_angle) * vdc_weight).T * scores
@@ -371,12 +443,17 @@ class DeepOcSortOracle:
         self.frame_count = 0
         self.count = 1                              # KalmanBoxTracker.count = 1 (deepocsort.py:293)
         self.tracks = []
+        self.asso = None
 
     def update(self, dets, img=None, embs=None, warp=None):
         """dets (N,6) [x1,y1,x2,y2,conf,cls] -> what ``DeepOcSort.update`` hands back: rows cast to fp32 by
         ``TrackResults`` (track_results.py:22-31), shape (M,8), or (0,0) when nothing is output.  ``warp``: the 2x3
         matrix ``cmc.apply`` returned (cmc_off=False, deepocsort.py:347-351), applied before the prediction."""
         c = self.cfg
+        if self.asso is None:                       # basetracker.py:175-180: the first frame fixes w, h and the function
+            wh = c["frame_wh"] if c["frame_wh"] is not None else ((img.shape[1], img.shape[0]) if img is not None else (None, None))
+            self.asso = asso_function(c["asso_func"], *wh)
+        asso = self.asso
         dets = np.asarray(dets)
         if dets.size == 0:
             dets = np.empty((0, 6), dtype=np.float32)
@@ -422,7 +499,7 @@ class DeepOcSortOracle:
         else:
             emb_cost = dets_embs @ trk_embs.T
         matched, un_d, un_t = associate(dets[:, 0:5], trks, c["iou_threshold"], velocities, k_obs, c["inertia"],
-                                        emb_cost, c["w_association_emb"], c["aw_off"], c["aw_param"])
+                                        emb_cost, c["w_association_emb"], c["aw_off"], c["aw_param"], asso)
         self.last = {"emb_cost": emb_cost, "matched": matched}
         for m in matched:
             self.tracks[m[1]].update(dets[m[0], :])
@@ -431,7 +508,7 @@ class DeepOcSortOracle:
         # OC-SORT only: BYTE association of the low-score detections with the predicted boxes of the unmatched tracks
         # (ocsort.py:456-485)
         if self.use_byte and len(dets_second) > 0 and un_t.shape[0] > 0:
-            iou_left = np.array(iou_batch(dets_second, trks[un_t]))
+            iou_left = np.array(asso(dets_second, trks[un_t]))
             if iou_left.max() > c["iou_threshold"]:
                 rem_t = []
                 for m in _assign(-iou_left):
@@ -446,7 +523,7 @@ class DeepOcSortOracle:
         if un_d.shape[0] > 0 and un_t.shape[0] > 0:
             left_dets = dets[un_d]
             left_trks = last_boxes[un_t]
-            iou_left = np.array(iou_batch(left_dets, left_trks))
+            iou_left = np.array(asso(left_dets, left_trks))
             if iou_left.max() > c["iou_threshold"]:
                 rem_d, rem_t = [], []
                 for m in _assign(-iou_left):

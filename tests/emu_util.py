@@ -79,8 +79,9 @@ class EmuBotSort:
 
 
 DOCS_D = ("det_thresh", "iou_threshold", "inertia", "w_association_emb", "alpha_fixed_emb", "aw_param", "Q_xy_scaling", "Q_s_scaling",
-          "min_conf")
-DOCS_I = ("max_age", "min_hits", "delta_t", "embedding_off", "aw_off", "use_byte")
+          "min_conf", "asso_diag")
+DOCS_I = ("max_age", "min_hits", "delta_t", "embedding_off", "aw_off", "use_byte", "asso_mode")
+ASSO_MODES = {"iou": 0, "giou": 1, "diou": 2, "ciou": 3, "hmiou": 4, "centroid": 5}
 
 
 def build_docs(sanitize: bool = False, threads: int = 64) -> Path:
@@ -108,7 +109,10 @@ class EmuDeepOcSort:
                                              ctypes.c_void_p, ctypes.c_void_p]
         self.lib.emu_docs_dump.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 4
         self.lib.emu_docs_destroy.argtypes = [ctypes.c_void_p]
-        cfg = {"min_conf": 0.1, "use_byte": 0, **cfg}
+        cfg = {"min_conf": 0.1, "use_byte": 0, "asso_func": "iou", "frame_wh": (0, 0), **cfg}
+        cfg["asso_mode"] = ASSO_MODES[cfg["asso_func"]]
+        fw, fh = cfg["frame_wh"] or (0, 0)
+        cfg["asso_diag"] = float(np.sqrt(fw ** 2 + fh ** 2))
         cd = np.array([cfg[k] for k in DOCS_D], dtype=np.float64)
         ci = np.array([int(cfg[k]) for k in DOCS_I], dtype=np.int32)
         self.cap, self.nd, self.dim = cap, nd, dim

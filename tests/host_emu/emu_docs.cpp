@@ -51,7 +51,7 @@ void* thread_main(void* p) {
 
 extern "C" {
 
-// cd: det_thresh, iou_threshold, inertia, w_emb, alpha_fixed, aw_param, q_xy, q_s, min_conf; ci: max_age, min_hits, delta_t, embedding_off, aw_off, use_byte
+// cd: det_thresh, iou_threshold, inertia, w_emb, alpha_fixed, aw_param, q_xy, q_s, min_conf, asso_diag; ci: max_age, min_hits, delta_t, embedding_off, aw_off, use_byte, asso_mode
 void* emu_docs_create(const double* cd, const int* ci, int cap, int nd, int dim) {
     Emu* e = new Emu();
     e->cap = cap; e->nd = nd; e->dim = dim;
@@ -60,6 +60,7 @@ void* emu_docs_create(const double* cd, const int* ci, int cap, int nd, int dim)
     c.alpha_fixed = cd[4]; c.aw_param = cd[5]; c.q_xy = cd[6]; c.q_s = cd[7];
     c.max_age = ci[0]; c.min_hits = ci[1]; c.delta_t = ci[2]; c.embedding_off = ci[3]; c.aw_off = ci[4];
     c.use_byte = ci[5]; c.min_conf_f32 = (float)cd[8];
+    c.asso_mode = ci[6]; c.asso_diag = cd[9];
     bm::DocsSizes z{1, cap, nd, dim};
     bm::docs_allocate(e->args, z, e->alloc);
     e->dets = e->alloc.get<float>((size_t)nd * bm::DET_COLS);

@@ -45,6 +45,35 @@ def test_emulated_deepocsort_matches_oracle_stress(kw, seed):
     _run(stress_frames(60, seed=seed), 32, 128, 64, **kw)
 
 
+def _run_oc(frames, **kw):
+    """OC-SORT (appearance off, optional BYTE round) on the emulated device step against OcSortOracle."""
+    from oracle.deepocsort import OcSortOracle
+    cfg = {**DEFAULTS, **{k: v for k, v in kw.items() if k in DEFAULTS}, "embedding_off": 1, "use_byte": int(kw.get("use_byte", False)),
+           "min_conf": kw.get("min_conf", 0.1)}
+    orc, emu = OcSortOracle(**kw), EmuDeepOcSort(cfg, cap=128, nd=64, dim=1)
+    try:
+        for t, (d, _) in enumerate(frames):
+            want = np.asarray(orc.update(d.copy()), dtype=np.float32).reshape(-1, 8)
+            got = emu.update(d, None)
+            assert got.shape == want.shape and np.array_equal(got[:, 4:], want[:, 4:]), t
+            assert np.allclose(got[:, :4], want[:, :4], rtol=0, atol=1e-4), t
+        od, dd = orc.dump(), emu.dump()
+        assert np.array_equal(dd["ints"][:, 0], od["id"]) and np.array_equal(dd["ints"][:, 3], od["hit_streak"])
+        if dd["n"]:
+            assert np.allclose(dd["kf"][:, :7], od["x"], rtol=1e-9, atol=1e-9)
+    finally:
+        emu.close()
+
+
+@pytest.mark.parametrize("asso_func,thr", [("giou", 0.6), ("diou", 0.6), ("ciou", 0.6), ("hmiou", 0.3), ("centroid", 0.9)])
+def test_emulated_deepocsort_association_functions(asso_func, thr):
+    """BaseTracker's asso_func (iou.py:118-423) on the device step: every "iou" matrix of the frame (first association, OC-SORT's
+    BYTE round, the recovery round) comes from the named function; rows, ids and filter state against the oracle, whose functions
+    are pinned bit for bit on the reference classes (tests/test_oracle_vs_reference.py)."""
+    _run(stress_frames(60, seed=9), 32, 128, 64, asso_func=asso_func, iou_threshold=thr, frame_wh=(640, 480))
+    _run_oc(stress_frames(60, seed=10), asso_func=asso_func, iou_threshold=thr, frame_wh=(640, 480), use_byte=True)
+
+
 def test_emulated_deepocsort_four_wavefronts():
     """The same parity with a 256-thread workgroup: the wave-per-row cost loops, the cross-wavefront reductions and the solver
     with more than one wavefront."""

@@ -163,3 +163,37 @@ def test_hip_ocsort_matches_oracle_and_surface():
     assert out.shape == (1, 8) and out[0, 4] == 1 and out[0, 7] == 0
     assert trk.update(np.empty((0, 6), dtype=np.float32), img).shape == (0, 0)
     trk.close()
+
+
+@pytest.mark.parametrize("asso_func,thr", [("giou", 0.6), ("diou", 0.6), ("ciou", 0.6), ("hmiou", 0.3), ("centroid", 0.9)])
+def test_hip_association_functions_match_the_oracle(asso_func, thr):
+    """BaseTracker's ``asso_func`` (basetracker.py:28; iou.py:118-423) through the plugin classes: DeepOcSort and OcSort (with its
+    BYTE round) constructed with each axis-aligned name, against the oracle whose functions are pinned bit for bit on the reference
+    classes (tests/test_oracle_vs_reference.py).  `centroid` takes the frame size from the first image, as the reference does."""
+    from boxmot_amd import DeepOcSort, OcSort
+    from boxmot_amd.scenario import stress_frames
+    from oracle.deepocsort import DeepOcSortOracle, OcSortOracle
+    img = np.zeros((480, 640, 3), dtype=np.uint8)
+    trk = DeepOcSort(reid_model=None, cmc_off=True, emb_dim=32, max_tracks=128, max_dets=64, asso_func=asso_func, iou_threshold=thr)
+    orc = DeepOcSortOracle(asso_func=asso_func, iou_threshold=thr)
+    rows = 0
+    for t, (dets, embs) in enumerate(stress_frames(80, seed=5)):
+        got = np.asarray(trk.update(dets, img, embs)).reshape(-1, 8)
+        assert_rows_match(got, np.asarray(orc.update(dets, img, embs), dtype=np.float32).reshape(-1, 8), t)
+        rows += len(got)
+    assert rows > 200
+    trk.close()
+    trk, orc = OcSort(max_tracks=128, max_dets=64, asso_func=asso_func, iou_threshold=thr, use_byte=True), \
+        OcSortOracle(asso_func=asso_func, iou_threshold=thr, use_byte=True)
+    for t, (dets, _) in enumerate(stress_frames(80, seed=6)):
+        got = np.asarray(trk.update(dets, img)).reshape(-1, 8)
+        assert_rows_match(got, np.asarray(orc.update(dets, img), dtype=np.float32).reshape(-1, 8), t)
+    trk.close()
+
+
+def test_hip_unknown_association_function_raises_on_the_first_frame():
+    from boxmot_amd import OcSort
+    trk = OcSort(max_tracks=64, max_dets=32, asso_func="nope")          # the reference resolves the name on the first frame too
+    with pytest.raises(ValueError, match="Invalid association mode: nope"):
+        trk.update(np.empty((0, 6), dtype=np.float32), np.zeros((64, 64, 3), np.uint8))
+    trk.close()
