@@ -39,6 +39,21 @@
 // the value a given (compile-time) lane holds, as a wave-uniform scalar
 #define BM_READLANE_U32(v, l) ((unsigned)__builtin_amdgcn_readlane((int)(v), l))
 #endif
+#ifndef BM_WAVE_SUM_F32
+// Sum over the 64 lanes with the value (and the rounding) of the xor butterfly v += shfl_xor(v, 1), 2, 4, 8, 16, 32, on the DPP
+// path instead of six LDS-crossbar round trips: quad swaps (quad_perm 1,0,3,2 and 2,3,0,1), then mirrors -- after the quad steps
+// the lanes of a quad agree, so l <-> 7 - l (row_half_mirror) and l <-> 15 - l (row_mirror) add what l ^ 4 and l ^ 8 would; the
+// four rows meet as (S0 + S1) + (S2 + S3), the value every lane of the butterfly ends with (fp32 addition commutes).
+#define BM_DPP_F32_RAW(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (float)(v)), ctrl, 0xf, 0xf, true))
+__device__ inline float bm_wave_sum_f32(float v) {
+    v += BM_DPP_F32_RAW(v, 0xB1); v += BM_DPP_F32_RAW(v, 0x4E); v += BM_DPP_F32_RAW(v, 0x141); v += BM_DPP_F32_RAW(v, 0x140);
+    const int b = __builtin_bit_cast(int, v);
+    const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16)),
+                s2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), s3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return (s0 + s1) + (s2 + s3);
+}
+#define BM_WAVE_SUM_F32(v) bm_wave_sum_f32(v)
+#endif
 #ifndef BM_WAVE_LDS_SYNC
 // LDS written by some lanes of a wavefront and read by others of the SAME wavefront: the DS operations of one wave execute in
 // order, so only the compiler has to be kept from reordering them (no workgroup barrier)

@@ -49,6 +49,14 @@
 #endif
 // weights into LDS by asynchronous global -> LDS copies (no register round trip, no latency per loop trip) issued ahead of the
 // phase that needs them; 0 = load / store loops at the point of use (A/B switch)
+// fused transition: pooled output stored as 16-byte channel-tile pairs (1) or 8-byte tiles (0; A/B switch)
+#ifndef BM_HP_TRANS_ST16
+#define BM_HP_TRANS_ST16 1
+#endif
+// ChannelGate's crop-wide sums: wave reduction on the DPP path (1) or through the LDS crossbar (__shfl_xor; 0)
+#ifndef BM_HP_GATE_DPP
+#define BM_HP_GATE_DPP 1
+#endif
 #ifndef BM_HP_ASYNC_STAGE
 #define BM_HP_ASYNC_STAGE 1
 #endif
@@ -483,8 +491,12 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
 #pragma unroll
             for (int h = 0; h < G::HID; ++h) {
                 float v = ph[h];
+#if BM_HP_GATE_DPP
+                v = BM_WAVE_SUM_F32(v);
+#else
                 v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
                 v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+#endif
                 if (lane == 0) part[wave * G::HID + h] = v;
             }
         }
@@ -714,6 +726,8 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
             static_assert(!TRANS || (STAGE < 2 && COUT % 32 == 0), "fused transition: stages 0 and 1");
             constexpr int WP = G::W / 2;
             const unsigned char* tbias = wtl + (long)NCT * KS3 * HP_FRAG_PAIR;
+            static_assert(NCT % 2 == 0, "pooled channel tiles leave in pairs");
+            h4 ph[TG / 2], pl[TG / 2];          // the even tile of a pair, held for one iteration
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
                 const f4 bv = *reinterpret_cast<const f4*>(tbias + (16 * ct + 4 * g) * 4);
@@ -740,9 +754,19 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
                         const float v = a0[r] + a1[r];
                         sp[r] = v + BM_QUAD_SWAP1_F32(v);
                     }
-                    if ((l16 & 1) == 0) {
-                        h4 hh, ll;
-                        split4(sp, hh, ll);
+                    // a lane's channel tiles are adjacent in the lane-group-major layout: tiles (ct - 1, ct) leave as ONE 16-byte
+                    // store per plane (8-byte pieces at a 32-byte stride fill a sector in four partial writes)
+                    h4 hh, ll;
+                    split4(sp, hh, ll);
+                    if constexpr (BM_HP_TRANS_ST16) {
+                        if (ct & 1) {
+                            if ((l16 & 1) == 0) {
+                                const unsigned o = po * COUT + g * (COUT / 4) + 4 * (ct - 1);
+                                BM_NT_STORE(reinterpret_cast<h8*>(yh_out + o), cat8(ph[pr], hh));
+                                BM_NT_STORE(reinterpret_cast<h8*>(yl_out + o), cat8(pl[pr], ll));
+                            }
+                        } else { ph[pr] = hh; pl[pr] = ll; }
+                    } else if ((l16 & 1) == 0) {
                         const unsigned o = po * COUT + g * (COUT / 4) + 4 * ct;
                         BM_NT_STORE(reinterpret_cast<h4*>(yh_out + o), hh);
                         BM_NT_STORE(reinterpret_cast<h4*>(yl_out + o), ll);

@@ -293,6 +293,11 @@ inline unsigned emu_dpp_u32(unsigned old, unsigned v, int ctrl, bool zero_fill) 
 #define BM_DPP_U32(old, v, ctrl, zero_fill) emu_dpp_u32(old, v, ctrl, zero_fill)
 #define BM_READLANE_U32(v, l) ((unsigned)__shfl((int)(v), l, 64))
 #define BM_QUAD_SWAP1_F32(v) __shfl_xor((float)(v), 1, 64)
+inline float emu_wave_sum_f32(float v) {       // the butterfly whose value the device's DPP sequence reproduces (kernel_macros.hpp)
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+#define BM_WAVE_SUM_F32(v) emu_wave_sum_f32(v)
 #define BM_UNIFORM_I32(x) ((int)(x))
 #define BM_MUL24(a, b) ((unsigned)(((unsigned)(a) & 0xffffffu) * ((unsigned)(b) & 0xffffffu)))
 #define BM_MULHI24(a, b) ((unsigned)(((unsigned long long)((unsigned)(a) & 0xffffffu) * ((unsigned)(b) & 0xffffffu)) >> 32))
