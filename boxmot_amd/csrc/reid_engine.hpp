@@ -103,8 +103,21 @@ public:
             h_w_.assign(blob + REID_HEADER_INTS, blob + REID_HEADER_INTS + L_.total);
             alloc_buffers();
             if (ch[0] == 16 && ch[1] == 64 && ch[2] == 96 && ch[3] == 128 && L_.feat == 512) prepare_fused();
-            else if (WideOsnet::supports(L_))       // osnet_x1_0: layer-per-launch fp16 MFMA kernels (osnet_wide.hpp)
-                wide_.reset(new WideOsnet(h_w_.data(), L_, d_w_, max_crops_ < 1024 ? max_crops_ : 1024, owned_));
+            else {
+                // the matrix-pipe families run the network itself (osnet_x1_0) or its zero-padded copy (osnet_x0_5, osnet_x0_75:
+                // middle widths 48 / 72, reid_layout.hpp: osnet_pad_weights); the per-layer fp32 kernels keep the original
+                Lw_ = L_; hw_w_ = h_w_.data(); dw_w_ = d_w_;
+                int cp[4];
+                if (!WideOsnet::supports(L_) && osnet_padded_channels(L_, cp)) {
+                    Lw_ = osnet_padded_layout(L_, cp);
+                    h_wpad_ = osnet_pad_weights(h_w_.data(), L_, Lw_);
+                    float* d = dev_alloc<float>((size_t)Lw_.total, owned_);
+                    BM_HIP(hipMemcpy(d, h_wpad_.data(), (size_t)Lw_.total * 4, hipMemcpyHostToDevice));
+                    hw_w_ = h_wpad_.data(); dw_w_ = d;
+                }
+                if (WideOsnet::supports(Lw_))       // layer-per-launch fp16 MFMA kernels (osnet_wide.hpp)
+                    wide_.reset(new WideOsnet(hw_w_, Lw_, dw_w_, max_crops_ < 1024 ? max_crops_ : 1024, owned_));
+            }
         }
         BM_HIP(hipEventCreate(&ev_[0]));
         BM_HIP(hipEventCreate(&ev_[1]));
@@ -122,13 +135,13 @@ public:
             throw std::runtime_error("ReID mode must be 0 (per-layer fp32), 1 (fused fp16 MFMA) or 2 (fused fp32-grade)");
         if (clip_) return;                  // CLIP-ReID has one kernel family; the mode switch is OSNet's
         if (m == 1 && !fused_ready_ && !wide_)
-            throw std::runtime_error("fp16 MFMA ReID kernels exist for OSNet-x0.25 (fused) and for widths that are multiples of 32 (osnet_x1_0)");
+            throw std::runtime_error("fp16 MFMA ReID kernels exist for OSNet-x0.25 (fused) and for widths that pad to multiples of 32 (osnet_x0_5, osnet_x0_75, osnet_x1_0)");
         if (m == 2) {
             if (fused_ready_) { if (!hp_ready_) prepare_hp(); }
-            else if (WideOsnetHP::supports(L_)) {
-                if (!wide_hp_) wide_hp_.reset(new WideOsnetHP(h_w_.data(), L_, d_w_, max_crops_ < 1024 ? max_crops_ : 1024, owned_));
+            else if (hw_w_ && WideOsnetHP::supports(Lw_)) {
+                if (!wide_hp_) wide_hp_.reset(new WideOsnetHP(hw_w_, Lw_, dw_w_, max_crops_ < 1024 ? max_crops_ : 1024, owned_));
             } else
-                throw std::runtime_error("the fp32-grade ReID kernels (mode 2) exist for OSNet-x0.25 (fused) and for widths that are multiples of 32 / 128 (osnet_x1_0)");
+                throw std::runtime_error("the fp32-grade ReID kernels (mode 2) exist for OSNet-x0.25 (fused) and for widths that pad to a stem of 32 / 64 and middle widths of 32 / 64 / 96 / 128 (osnet_x0_5, osnet_x0_75, osnet_x1_0)");
         }
         mode_ = m;
     }
@@ -547,6 +560,10 @@ private:
     bool timed_ = false;
     std::vector<void*> owned_;
     std::vector<float> h_w_;
+    OsnetLayout Lw_;                        // what the matrix-pipe families (wide_, wide_hp_) run: L_ or its zero-padded copy
+    std::vector<float> h_wpad_;
+    const float* hw_w_ = nullptr;           // host / device weights in Lw_'s layout
+    const float* dw_w_ = nullptr;
     float* d_w_ = nullptr;
     float* d_lut_ = nullptr;
     float *crops_ = nullptr, *big_a_ = nullptr, *big_b_ = nullptr, *idn_ = nullptr;

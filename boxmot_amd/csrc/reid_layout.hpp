@@ -47,7 +47,9 @@ struct OsnetLayout {
     long total;
 };
 
-inline OsnetLayout make_osnet_layout(const int channels[4], int feat) {
+// `like`: take "this block has a downsample convolution" from another layout's blocks instead of from cin != cout (a zero-padded
+// copy of a network can have cin == cout where the network itself projects, see osnet_pad_weights)
+inline OsnetLayout make_osnet_layout(const int channels[4], int feat, const BlockW* like = nullptr) {
     OsnetLayout L;
     long off = 0;
     auto take = [&](long n) { long o = off; off += n; return o; };
@@ -70,7 +72,7 @@ inline OsnetLayout make_osnet_layout(const int channels[4], int feat) {
             B.fc1_w = take((long)B.hid * B.mid); B.fc1_b = take(B.hid);
             B.fc2_w = take((long)B.mid * B.hid); B.fc2_b = take(B.mid);
             B.conv3_w = take((long)cout * B.mid); B.conv3_b = take(cout);
-            if (cin != cout) { B.down_w = take((long)cout * cin); B.down_b = take(cout); }
+            if (like ? like[s * 2 + k].down_w >= 0 : cin != cout) { B.down_w = take((long)cout * cin); B.down_b = take(cout); }
             else { B.down_w = -1; B.down_b = -1; }
             cin = cout;
         }
@@ -80,6 +82,57 @@ inline OsnetLayout make_osnet_layout(const int channels[4], int feat) {
     L.fc_w = take((long)feat * channels[3]); L.fc_b = take(feat);
     L.total = off;
     return L;
+}
+
+// ---------------------------------------------------------------------------
+// Zero-padded copy of a network for the matrix-pipe kernel families (osnet_wide.hpp, osnet_wide_hp.hpp), which are built for
+// stems of 32 / 64 channels and middle widths of 32 / 64 / 96 / 128 (at most 64 in stage 0 and 96 in stage 1): osnet_x0_5
+// (32, 128, 192, 256: middle 32 / 48 / 64) runs as (32, 128, 256, 256), osnet_x0_75 (48, 192, 288, 384: 48 / 72 / 96) as
+// (64, 256, 384, 384) (boxmot/reid/backbones/osnet.py:503-530).  Every added channel has zero weights and a zero bias on both sides:
+// it carries ReLU(0) = 0 through the block, its gate multiplies 0, and a sum that includes it adds an exact 0 -- the real channels
+// compute what they computed before.
+// ---------------------------------------------------------------------------
+inline bool osnet_padded_channels(const OsnetLayout& L, int (&cp)[4]) {
+    if (L.c[0] > 64) return false;
+    cp[0] = L.c[0] <= 32 ? 32 : 64;
+    for (int s = 0; s < 3; ++s) {
+        if (L.c[s + 1] % 4) return false;
+        const int mid = (L.c[s + 1] / 4 + 31) / 32 * 32;
+        if (mid > (s == 0 ? 64 : (s == 1 ? 96 : 128))) return false;
+        cp[s + 1] = 4 * mid;
+    }
+    return L.feat % 128 == 0 && L.feat <= 512;
+}
+inline OsnetLayout osnet_padded_layout(const OsnetLayout& L, const int (&cp)[4]) { return make_osnet_layout(cp, L.feat, L.block); }
+inline std::vector<float> osnet_pad_weights(const float* w, const OsnetLayout& L, const OsnetLayout& Lp) {
+    std::vector<float> o((size_t)Lp.total, 0.f);
+    // [rows][cols] at `src` -> the top-left corner of [.][cols_p] at `dst`
+    auto mat = [&](long src, long dst, int rows, int cols, int cols_p) {
+        for (int r = 0; r < rows; ++r)
+            for (int c = 0; c < cols; ++c) o[(size_t)(dst + (long)r * cols_p + c)] = w[src + (long)r * cols + c];
+    };
+    mat(L.stem_w, Lp.stem_w, L.c[0], 7 * 7 * 3, 7 * 7 * 3);
+    mat(L.stem_b, Lp.stem_b, 1, L.c[0], Lp.c[0]);
+    for (int b = 0; b < 6; ++b) {
+        const BlockW &A = L.block[b], &P = Lp.block[b];
+        mat(A.conv1_w, P.conv1_w, A.mid, A.cin, P.cin); mat(A.conv1_b, P.conv1_b, 1, A.mid, P.mid);
+        for (int l = 0; l < 10; ++l) {
+            mat(A.light[l].pw, P.light[l].pw, A.mid, A.mid, P.mid);
+            mat(A.light[l].dw, P.light[l].dw, A.mid, 9, 9);
+            mat(A.light[l].b, P.light[l].b, 1, A.mid, P.mid);
+        }
+        mat(A.fc1_w, P.fc1_w, A.hid, A.mid, P.mid); mat(A.fc1_b, P.fc1_b, 1, A.hid, P.hid);
+        mat(A.fc2_w, P.fc2_w, A.mid, A.hid, P.hid); mat(A.fc2_b, P.fc2_b, 1, A.mid, P.mid);
+        mat(A.conv3_w, P.conv3_w, A.cout, A.mid, P.mid); mat(A.conv3_b, P.conv3_b, 1, A.cout, P.cout);
+        if (A.down_w >= 0) { mat(A.down_w, P.down_w, A.cout, A.cin, P.cin); mat(A.down_b, P.down_b, 1, A.cout, P.cout); }
+    }
+    for (int s = 0; s < 2; ++s) {
+        mat(L.trans_w[s], Lp.trans_w[s], L.c[s + 1], L.c[s + 1], Lp.c[s + 1]);
+        mat(L.trans_b[s], Lp.trans_b[s], 1, L.c[s + 1], Lp.c[s + 1]);
+    }
+    mat(L.conv5_w, Lp.conv5_w, L.c[3], L.c[3], Lp.c[3]); mat(L.conv5_b, Lp.conv5_b, 1, L.c[3], Lp.c[3]);
+    mat(L.fc_w, Lp.fc_w, L.feat, L.c[3], Lp.c[3]); mat(L.fc_b, Lp.fc_b, 1, L.feat, L.feat);
+    return o;
 }
 
 }  // namespace bm

@@ -55,10 +55,20 @@ extern "C" int emu_wide_hp_forward(const float* blob, long n_floats, const float
     const int32_t* h = reinterpret_cast<const int32_t*>(blob);
     if (h[0] != REID_MAGIC) return -1;
     const int ch[4] = {h[1], h[2], h[3], h[4]};
-    const OsnetLayout L = make_osnet_layout(ch, h[5]);
-    if (n_floats != REID_HEADER_INTS + L.total) return -2;
-    if (!wide_hp_supports(L)) return -3;
+    const OsnetLayout L0 = make_osnet_layout(ch, h[5]);
+    if (n_floats != REID_HEADER_INTS + L0.total) return -2;
     const float* W32 = blob + REID_HEADER_INTS;
+    // widths the family does not take as they are run as their zero-padded copy, exactly as the engine does (reid_engine.hpp)
+    OsnetLayout L = L0;
+    std::vector<float> padded;
+    if (!wide_hp_supports(L0)) {
+        int cp[4];
+        if (!osnet_padded_channels(L0, cp)) return -3;
+        L = osnet_padded_layout(L0, cp);
+        padded = osnet_pad_weights(W32, L0, L);
+        W32 = padded.data();
+    }
+    if (!wide_hp_supports(L)) return -3;
     const WideHpPack pk = wide_pack_hp(W32, L);
     std::vector<unsigned char> wp(pk.data.size() + 16);
     unsigned char* wpa = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(wp.data()) + 15) & ~uintptr_t(15));
@@ -78,7 +88,7 @@ extern "C" int emu_wide_hp_forward(const float* blob, long n_floats, const float
                 }
     const size_t act = N * wide_hp_act_halves(L), mid = N * wide_hp_mid_halves(L);
     std::vector<_Float16> a_h(act), a_l(act), b_h(act), b_l(act), x1_h(mid), x1_l(mid), y_h(4 * mid), y_l(4 * mid), x2_h(mid), x2_l(mid);
-    std::vector<_Float16> gap_h(N * ch[3]), gap_l(N * ch[3]);
+    std::vector<_Float16> gap_h(N * L.c[3]), gap_l(N * L.c[3]);
     std::vector<float> gap_part(4 * N * WIDE_HP_MAX_BANDS * 128), fc32(N * L.feat);
     WideHpBuffers B;
     B.crops_h = crops_h.data(); B.crops_l = crops_l.data();
@@ -89,11 +99,15 @@ extern "C" int emu_wide_hp_forward(const float* blob, long n_floats, const float
     try {
         wide_hp_forward(launch, L, pk, wpa, W32, B, n, feats, rows, [&](int b, const _Float16* oh, const _Float16* ol, long n_pix, int cout) {
             if (stages && stages[b])
-                for (long px = 0; px < n_pix; ++px)            // block outputs are stored in the family's paired channel order
+                for (long px = 0; px < n_pix; ++px) {          // block outputs are stored in the family's paired channel order
+                    const int c_net = L0.block[b].cout;        // the network's own channels; a padded copy's extra ones must be 0
                     for (int c = 0; c < cout; ++c) {
                         const long i = px * cout + hp_paired_pos(c);
-                        stages[b][px * cout + c] = (float)oh[i] + (float)ol[i];
+                        const float v = (float)oh[i] + (float)ol[i];
+                        if (c < c_net) stages[b][px * c_net + c] = v;
+                        else if (v != 0.f) throw std::runtime_error("padded channel is not zero");
                     }
+                }
         });
     } catch (const std::exception&) {
         return -4;

@@ -28,7 +28,11 @@ def _build():
 
 
 @pytest.mark.skipif(CLANG is None, reason="needs a host clang with _Float16")
-@pytest.mark.parametrize("channels,weights", [((32, 128, 256, 384), "calib"), ((64, 256, 128, 128), "init")])
+@pytest.mark.parametrize("channels,weights", [((32, 128, 256, 384), "calib"), ((64, 256, 128, 128), "init"),
+                                              # widths the family takes as a zero-padded copy (reid_layout.hpp: osnet_pad_weights): osnet_x0_75's
+                                              # (48, 192, 288, 384) itself, and a reduced net with osnet_x0_5's 48-wide middle stage and a
+                                              # projection that the padding turns into cin == cout
+                                              ((48, 192, 288, 384), "calib"), ((32, 128, 192, 256), "calib")])
 def test_wide_hp_kernels_emulated_vs_oracle(channels, weights):
     import torch
 
