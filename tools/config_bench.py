@@ -45,7 +45,8 @@ def vit_flops(width=768, layers=12, tokens=129, patch_k=768, out_dim=512):
 
 
 def run(config: str = "c3", streams: int = 0, steps: int = 40, warmup: int = 8, check_frames: int = -1, reid_mode: int = 1,
-        with_ecc: bool = True, groups: int = 0, embedding_gate: bool = True, both_groups: bool = False) -> dict:
+        with_ecc: bool = True, groups: int = 0, embedding_gate: bool = True, both_groups: bool = False, gate_budget_s: float = 0.0,
+        cpu_threads: int = 32) -> dict:
     """One measurement; returns the result dict (bench.py calls this for its side lines).  `groups`: the streams are split over
     that many handles, each with its own HIP stream (0 = 1) -- with 2, one group's frame step (a few workgroups: one per stream)
     runs beside the other group's ReID kernels instead of after its own (configuration 3: 497 -> 541 frames/s; configuration 5:
@@ -55,6 +56,13 @@ def run(config: str = "c3", streams: int = 0, steps: int = 40, warmup: int = 8, 
     from boxmot_amd import _lib
     from boxmot_amd.reid_weights import save_blob
     from boxmot_amd.scenario import Scenario
+    t_start = time.perf_counter()
+    # the CPU oracle of the gates (torch fp32): a thread per logical core of a 256-thread host is 10x slower than 32 threads
+    # (measured: 15.6 s instead of ~1.5 s per 128-crop osnet_x1_0 frame, profiles/r4_side_line_timing.txt)
+    torch.set_num_threads(max(1, min(os.cpu_count() or 1, cpu_threads)))
+
+    def log(msg):           # wall-clock of every phase on stderr: the bench runs this under a budget and has to know where it goes
+        print(f"[config_bench {config} +{time.perf_counter() - t_start:6.1f}s] {msg}", file=sys.stderr, flush=True)
     lib = _lib.load()
     c3 = config == "c3"
     nd, ntr, dim, W, H = (128, 512, 512, 1920, 1080) if c3 else (256, 1024, 1280, 3840, 2160)
@@ -84,6 +92,7 @@ def run(config: str = "c3", streams: int = 0, steps: int = 40, warmup: int = 8, 
             d, _ = scen[s].frame(t, with_embs=False)
             cnt_h[t, s] = len(d)
             dets_h[t, s, : len(d)] = d
+    log("weights packed, scenarios generated")
     d_dets, d_cnt = torch.from_numpy(dets_h).to(dev), torch.from_numpy(cnt_h).to(dev)
     frames = torch.stack([torch.from_numpy(sc.image) for sc in scen]).to(dev)
     ptrs = torch.tensor([frames[s].data_ptr() for s in range(S)], dtype=torch.int64, device=dev)
@@ -171,6 +180,7 @@ def run(config: str = "c3", streams: int = 0, steps: int = 40, warmup: int = 8, 
         return G, dt_, r_ms, r_n, rows, counts
 
     G, dt, reid_total_ms, reid_launches, out_h, out_n = measure(groups)
+    log(f"measured: {S * steps / dt:.1f} frames/s")
     crops = int(cnt_h[warmup:].sum())
     # parity gates
     gates = {}
@@ -196,6 +206,7 @@ def run(config: str = "c3", streams: int = 0, steps: int = 40, warmup: int = 8, 
         hc.close()
         gates["reid_max_abs_err_vs_fp32_oracle_bn_calibrated_seed0"] = e
         gates["reid_within_1e-3_on_bn_calibrated_weights"] = bool(e < 1e-3)
+    log("embedding gates done")
     if check:
         # id gate: the oracle tracker with the fp32 oracle backbone inside update on stream 0's first frames (full size)
         if c3:
@@ -204,10 +215,16 @@ def run(config: str = "c3", streams: int = 0, steps: int = 40, warmup: int = 8, 
         else:
             from oracle.strongsort import StrongSortOracle
             orc = StrongSortOracle(reid=orc_reid, dot_rule="device")
+        # `gate_budget_s` > 0: the oracle (a CPU fp32 backbone per frame) stops after that many seconds, never before 2 frames; the
+        # line says how many frames it compared
         want_rows = []
+        t_gate = time.perf_counter()
         for t in range(check):
+            if gate_budget_s > 0 and t >= 2 and time.perf_counter() - t_gate > gate_budget_s:
+                break
             n = cnt_h[t, 0]
             want_rows.append(np.asarray(orc.update(dets_h[t, 0, :n], scen[0].image), dtype=np.float32).reshape(-1, 8))
+        check = len(want_rows)
 
         def ids_ok(rows, counts):
             ok = True
@@ -217,6 +234,27 @@ def run(config: str = "c3", streams: int = 0, steps: int = 40, warmup: int = 8, 
             return bool(ok)
         gates["ids_first_frames_vs_oracle_stream0"] = ids_ok(out_h, out_n)
         gates["id_gate_frames"] = int(check)
+        log(f"id gate over {check} frames done")
+        # second gate, all `check_frames` frames: the oracle TRACKER (NumPy, fp64) on the embeddings the device backbone returns for the
+        # same boxes -- the frame-step arithmetic over the whole window without the CPU backbone's seconds per frame (the backbone itself
+        # is held to the fp32 oracle by the embedding gates above and, for `id_gate_frames` frames, by the first gate)
+        ids_ok2 = None
+        full = check_frames if check_frames >= 0 else check
+        try:
+            hr2 = HipReID(blob, max_crops=cap_nd, mode=reid_mode if c3 else 0)
+            orc2 = DeepOcSortOracle(reid=hr2) if c3 else StrongSortOracle(reid=hr2, dot_rule="device")
+            want2 = [np.asarray(orc2.update(dets_h[t, 0, : cnt_h[t, 0]], scen[0].image), dtype=np.float32).reshape(-1, 8) for t in range(full)]
+            hr2.close()
+
+            def ids_ok2(rows, counts):
+                return bool(all(rows[t, 0, : counts[t, 0]].shape == want2[t].shape and
+                                np.array_equal(np.sort(rows[t, 0, : counts[t, 0]][:, 4]), np.sort(want2[t][:, 4])) for t in range(full)))
+            gates["ids_vs_oracle_tracker_on_device_embeddings_stream0"] = ids_ok2(out_h, out_n)
+            gates["id_gate_frames_device_embeddings"] = int(full)
+        except Exception as exc:                # (a failure here is reported, it does not take the line down)
+            gates["ids_vs_oracle_tracker_on_device_embeddings_stream0"] = f"error: {type(exc).__name__}: {exc}"
+            ids_ok2 = None
+        log(f"tracker-math id gate over {full} frames done")
     if both_groups:
         # the same workload with the streams split over two handles / HIP streams: one group's frame step (a workgroup per stream)
         # runs beside the other group's ReID kernels.  Its own entry -- the ReID-region timing (and the roofline figure) is only clean
@@ -227,9 +265,13 @@ def run(config: str = "c3", streams: int = 0, steps: int = 40, warmup: int = 8, 
             if check:
                 two["ids_first_frames_vs_oracle_stream0"] = ids_ok(rows2, counts2)
                 two["id_gate_frames"] = int(check)
+                if ids_ok2 is not None:
+                    two["ids_vs_oracle_tracker_on_device_embeddings_stream0"] = ids_ok2(rows2, counts2)
+                    two["id_gate_frames_device_embeddings"] = int(full)
             gates["two_stream_groups"] = two
         except Exception as exc:                # (never takes the gated one-group line down)
             gates["two_stream_groups"] = {"error": f"{type(exc).__name__}: {exc}"}
+    log("two-group run done")
     os.unlink(path)
     tfl = crops * flops_per_crop / (reid_total_ms * 1e9) if reid_total_ms > 0 else None
     return {
@@ -238,9 +280,13 @@ def run(config: str = "c3", streams: int = 0, steps: int = 40, warmup: int = 8, 
         "mode": "M2 reid-in-update, device-resident inputs" + ("" if c3 else (", ECC estimated per stream-frame on the device (static frames: converges at once)" if with_ecc else ", no camera-motion estimation")), "streams": S, "stream_groups": G, "steps": steps, "warmup": warmup,
         "frames_per_s": S * steps / dt, "ms_per_step": 1e3 * dt / steps, "crops_per_step": crops / steps,
         "reid_forward_ms_per_step": reid_total_ms / steps, "reid_passes": reid_launches, "gflop_per_crop": flops_per_crop / 1e9,
-        "roofline": {"bound": "hbm (layer-per-launch fp16 kernels)" if c3 else "mfma", "achieved": tfl, "peak": 2500.0, "unit": "TFLOP/s",
+        "reid_kernels": ({0: "per-layer fp32", 1: "layer-per-launch fp16 MFMA (osnet_wide)", 2: "fp32-grade: chain-fused LightConvs + (hi, lo) GEMMs (osnet_wide_hp)"}[reid_mode]
+                         if c3 else "CLIP-ReID fp16 GEMM operands, fp32 residual stream"),
+        "roofline": {"bound": ("hbm (GEMM / gate passes) + mfma (stage-0 chains), DESIGN.md 4.6b" if reid_mode == 2 else "hbm (layer-per-launch fp16 kernels)") if c3 else "mfma",
+                     "achieved": tfl, "peak": 2500.0, "unit": "TFLOP/s",
                      "frac": (tfl / 2500.0) if tfl else None, "kernel": "ReID forward region (HIP events on the launch stream)"},
-        "rows_stream0_last": int(out_n[-1, 0]), "dtype": "f16", **gates}
+        "rows_stream0_last": int(out_n[-1, 0]),
+        "dtype": ("f32 (fp16 hi+lo operand pairs, fp32 accumulate)" if reid_mode == 2 else ("f32" if reid_mode == 0 else "f16")) if c3 else "f16", **gates}
 
 
 def main():
@@ -253,9 +299,11 @@ def main():
     ap.add_argument("--reid-mode", type=int, default=1)
     ap.add_argument("--groups", type=int, default=0, help="handles (HIP streams) the streams are split over; 0 = 1")
     ap.add_argument("--both-groups", action="store_true", help="after the measurement, repeat it with 2 stream groups (same inputs, same oracle rows)")
+    ap.add_argument("--gate-budget-s", type=float, default=0.0, help="stop the CPU oracle of the id gate after this many seconds (never before 2 frames)")
     ap.add_argument("--no-ecc", action="store_true", help="c5: skip the per-frame ECC estimate (the reference's StrongSORT always runs it)")
     a = ap.parse_args()
-    print(json.dumps(run(a.config, a.streams, a.steps, a.warmup, a.check_frames, a.reid_mode, not a.no_ecc, a.groups, both_groups=a.both_groups)), flush=True)
+    print(json.dumps(run(a.config, a.streams, a.steps, a.warmup, a.check_frames, a.reid_mode, not a.no_ecc, a.groups, both_groups=a.both_groups,
+                         gate_budget_s=a.gate_budget_s)), flush=True)
 
 
 if __name__ == "__main__":
