@@ -7,6 +7,8 @@
 // stream compaction (`block_append_if`).
 #pragma once
 
+#include "kernel_macros.hpp"
+
 namespace bm {
 
 constexpr int WAVE = 64;
@@ -74,16 +76,45 @@ __device__ inline int block_append_if(const Ctx& c, int n, Pred pred, Val value,
     return dst_n;
 }
 
+// Wave minima on the DPP path (row rotations by 8, 4, 2, 1 inside the 16-lane rows, then the four row results as scalars): a
+// minimum does not depend on the order it is formed in, so these return exactly what a shuffle butterfly would, at a fraction of
+// its latency (six dependent LDS-crossbar round trips per 32-bit half).
+template <int CTRL> __device__ inline double dpp_ror(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = BM_DPP_U32(0u, (unsigned)b, CTRL, false), hi = BM_DPP_U32(0u, (unsigned)(b >> 32), CTRL, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
+template <int LANE> __device__ inline double lane_of(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = BM_READLANE_U32((unsigned)b, LANE), hi = BM_READLANE_U32((unsigned)(b >> 32), LANE);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
+__device__ inline double min_f64(double a, double b) { return b < a ? b : a; }
+__device__ inline double wave_min(double v) {
+    v = min_f64(v, dpp_ror<0x128>(v)); v = min_f64(v, dpp_ror<0x124>(v)); v = min_f64(v, dpp_ror<0x122>(v)); v = min_f64(v, dpp_ror<0x121>(v));
+    return min_f64(min_f64(lane_of<0>(v), lane_of<16>(v)), min_f64(lane_of<32>(v), lane_of<48>(v)));
+}
+__device__ inline int wave_min(int v) {
+    int o;
+    o = (int)BM_DPP_U32(0u, (unsigned)v, 0x128, false); v = o < v ? o : v; o = (int)BM_DPP_U32(0u, (unsigned)v, 0x124, false); v = o < v ? o : v;
+    o = (int)BM_DPP_U32(0u, (unsigned)v, 0x122, false); v = o < v ? o : v; o = (int)BM_DPP_U32(0u, (unsigned)v, 0x121, false); v = o < v ? o : v;
+    const int a = (int)BM_READLANE_U32((unsigned)v, 0), b = (int)BM_READLANE_U32((unsigned)v, 16), c = (int)BM_READLANE_U32((unsigned)v, 32),
+              d = (int)BM_READLANE_U32((unsigned)v, 48);
+    const int ab = b < a ? b : a, cd = d < c ? d : c;
+    return cd < ab ? cd : ab;
+}
+
 // Lexicographic (value, index) minimum over the workgroup.  Threads without a
 // candidate pass idx < 0.  Result is uniform; idx < 0 when nobody had one.
+// (The value minimum over the candidates, then the lowest index holding it -- in the wave on the DPP path.  A candidate's value
+// is finite or +inf, never NaN: the callers compare with `<` before they offer it.)
 __device__ inline void block_argmin(const Ctx& c, double v, int idx, double& out_v, int& out_i) {
-    for (int off = WAVE / 2; off > 0; off >>= 1) {
-        const double ov = __shfl_xor(v, off, WAVE);
-        const int oi = __shfl_xor(idx, off, WAVE);
-        const bool take = (oi >= 0) && (idx < 0 || ov < v || (ov == v && oi < idx));
-        if (take) { v = ov; idx = oi; }
-    }
-    if (c.lane == 0) { c.s_dbl[c.wave] = v; c.s_int[c.wave] = idx; }
+    constexpr double NONE_V = 1.7976931348623157e308;
+    constexpr int NONE_I = 0x7fffffff;
+    const bool any = __ballot(idx >= 0) != 0ull;
+    const double wv = wave_min(idx >= 0 ? v : NONE_V);
+    const int wi = wave_min((idx >= 0 && v == wv) ? idx : NONE_I);
+    if (c.lane == 0) { c.s_dbl[c.wave] = wv; c.s_int[c.wave] = (any && wi != NONE_I) ? wi : -1; }
     __syncthreads();
     double bv = 0.0;
     int bi = -1;

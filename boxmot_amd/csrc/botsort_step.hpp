@@ -133,12 +133,14 @@ constexpr double MIN_SIZE = 1e-4;
 // "zero (vw, vh) unless Tracked" rule of STrack.multi_predict (botsort_track.py:104-109).
 // `xyah`: KalmanFilterXYAH noise model (xyah.py:70-89: every std from the height, constants for the aspect ratio)
 // and ByteTrack's rule "zero vh unless Tracked" (bytetrack.py:63-74).
-BM_STEP_FN void kf_predict_wave(double* kf, bool zero_size_vel, int lane, bool xyah = false) {
+// (`mj_in`, `p_in`: the lane's mean[lane & 7] and covariance element, loaded by the caller -- the predict loop requests the next
+// track's state before it computes this one)
+BM_STEP_FN void kf_predict_wave(double* kf, double mj_in, double p_in, bool zero_size_vel, int lane, bool xyah = false) {
     const int i = lane >> 3, j = lane & 7;
-    double mj = kf[j];                       // mean[j]
+    double mj = mj_in;                       // mean[j]
     if (zero_size_vel && (xyah ? j == 7 : j >= 6)) mj = 0.0;
     const double w = __shfl(mj, 2, WAVE), h = __shfl(mj, 3, WAVE);   // pre-motion w, h
-    const double p = kf[KF_DIM + lane];
+    const double p = p_in;
     // mean' = mean . F^T  (one rounding: m_k + m_{k+4})
     const double mhi = __shfl(mj, (j + 4) & 7, WAVE);
     double mnew = (j < 4) ? (mj + mhi) : mj;
@@ -298,58 +300,80 @@ __device__ inline float wave_norm_f32(const float* x, int dim, int lane) {
     return sqrtf(wave_sum(s));
 }
 
-constexpr int MAX_VEC_PER_LANE = 32;    // appearance vectors up to 64 * 32 = 2048 floats stay in registers
+constexpr int VEC_REGS_PER_LANE = 8;    // appearance vectors up to 64 * 8 = 512 floats stay in registers; longer ones are streamed
 
 // STrack.update_features (botsort_track.py:58-67) for a live track: the matched
-// detection's vector is normalised once more, blended, renormalised.  One read of
-// each vector, one write; everything else in registers.
+// detection's vector is normalised once more, blended, renormalised.  Up to 512 floats: one read of each vector, one write,
+// everything else in registers.  Longer vectors (CLIP-ReID's 1280) are streamed in three passes with the SAME arithmetic per
+// element and the same per-lane summation order (k = lane, lane + 64, ...), so both forms return the same bits -- a register
+// form sized for 2048 floats kept 64 registers live across the frame step's largest phase and was most of its spill traffic.
 BM_STEP_FN void blend_feature_wave(float* smooth, const float* feat, int dim, int lane) {
-    float f[MAX_VEC_PER_LANE], sm[MAX_VEC_PER_LANE];
-    float s = 0.0f;
+    if (dim <= VEC_REGS_PER_LANE * WAVE) {
+        float f[VEC_REGS_PER_LANE], sm[VEC_REGS_PER_LANE];
+        float s = 0.0f;
 #pragma unroll
-    for (int q = 0; q < MAX_VEC_PER_LANE; ++q) {
-        const int k = lane + q * WAVE;
-        f[q] = k < dim ? feat[k] : 0.0f;
-        sm[q] = k < dim ? smooth[k] : 0.0f;
-        s += f[q] * f[q];
+        for (int q = 0; q < VEC_REGS_PER_LANE; ++q) {
+            const int k = lane + q * WAVE;
+            f[q] = k < dim ? feat[k] : 0.0f;
+            sm[q] = k < dim ? smooth[k] : 0.0f;
+            s += f[q] * f[q];
+        }
+        const float nf = sqrtf(wave_sum(s));
+        s = 0.0f;
+#pragma unroll
+        for (int q = 0; q < VEC_REGS_PER_LANE; ++q) {
+            const float b = 0.9f * sm[q] + 0.1f * (f[q] / nf);
+            sm[q] = b;
+            s += b * b;
+        }
+        const float ns = sqrtf(wave_sum(s));
+#pragma unroll
+        for (int q = 0; q < VEC_REGS_PER_LANE; ++q) {
+            const int k = lane + q * WAVE;
+            if (k < dim) smooth[k] = sm[q] / ns;
+        }
+        return;
     }
+    float s = 0.0f;
+    for (int k = lane; k < dim; k += WAVE) { const float f = feat[k]; s += f * f; }
     const float nf = sqrtf(wave_sum(s));
     s = 0.0f;
-#pragma unroll
-    for (int q = 0; q < MAX_VEC_PER_LANE; ++q) {
-        const float b = 0.9f * sm[q] + 0.1f * (f[q] / nf);
-        sm[q] = b;
-        s += b * b;
-    }
+    for (int k = lane; k < dim; k += WAVE) { const float b = 0.9f * smooth[k] + 0.1f * (feat[k] / nf); s += b * b; }
     const float ns = sqrtf(wave_sum(s));
-#pragma unroll
-    for (int q = 0; q < MAX_VEC_PER_LANE; ++q) {
-        const int k = lane + q * WAVE;
-        if (k < dim) smooth[k] = sm[q] / ns;
-    }
+    for (int k = lane; k < dim; k += WAVE) { const float b = 0.9f * smooth[k] + 0.1f * (feat[k] / nf); smooth[k] = b / ns; }
 }
 
 // STrack constructor's update_features on a fresh detection (botsort_track.py:58-66):
 // feat /= |feat|; smooth = feat; smooth /= |smooth|  -> the vector is normalised twice.
 BM_STEP_FN void normalize_twice_wave(const float* src, float* dst, int dim, int lane) {
-    float x[MAX_VEC_PER_LANE];
-    float s = 0.0f;
+    if (dim <= VEC_REGS_PER_LANE * WAVE) {
+        float x[VEC_REGS_PER_LANE];
+        float s = 0.0f;
 #pragma unroll
-    for (int q = 0; q < MAX_VEC_PER_LANE; ++q) {
-        const int k = lane + q * WAVE;
-        x[q] = k < dim ? src[k] : 0.0f;
-        s += x[q] * x[q];
+        for (int q = 0; q < VEC_REGS_PER_LANE; ++q) {
+            const int k = lane + q * WAVE;
+            x[q] = k < dim ? src[k] : 0.0f;
+            s += x[q] * x[q];
+        }
+        const float n1 = sqrtf(wave_sum(s));
+        s = 0.0f;
+#pragma unroll
+        for (int q = 0; q < VEC_REGS_PER_LANE; ++q) { x[q] = x[q] / n1; s += x[q] * x[q]; }
+        const float n2 = sqrtf(wave_sum(s));
+#pragma unroll
+        for (int q = 0; q < VEC_REGS_PER_LANE; ++q) {
+            const int k = lane + q * WAVE;
+            if (k < dim) dst[k] = x[q] / n2;
+        }
+        return;
     }
+    float s = 0.0f;
+    for (int k = lane; k < dim; k += WAVE) { const float x = src[k]; s += x * x; }
     const float n1 = sqrtf(wave_sum(s));
     s = 0.0f;
-#pragma unroll
-    for (int q = 0; q < MAX_VEC_PER_LANE; ++q) { x[q] = x[q] / n1; s += x[q] * x[q]; }
+    for (int k = lane; k < dim; k += WAVE) { const float x = src[k] / n1; s += x * x; }
     const float n2 = sqrtf(wave_sum(s));
-#pragma unroll
-    for (int q = 0; q < MAX_VEC_PER_LANE; ++q) {
-        const int k = lane + q * WAVE;
-        if (k < dim) dst[k] = x[q] / n2;
-    }
+    for (int k = lane; k < dim; k += WAVE) dst[k] = (src[k] / n1) / n2;
 }
 
 // STrack.update / re_activate (botsort_track.py:244-282) for a list of
@@ -784,11 +808,22 @@ __device__ inline void botsort_step_stream(const BotSortStepArgs& args, int s, i
 
     tick();
     // ---- Kalman prediction of the pool, one wavefront per track (botsort_track.py:96-115) ----
-    for (int base = 0; base < n_pool; base += c.nwaves) {
-        const int k = base + c.wave;
-        if (k < n_pool) {
-            const int slot = v.pool[k];
-            kf_predict_wave(v.kf + (long)slot * KF_STRIDE, v.state[slot] != ST_TRACKED, c.lane, cfg.kind == 1);
+    // (a wave's tracks are independent: the state of track k + nwaves is in flight while track k is computed -- the loop is a chain
+    // of global round trips otherwise)
+    {
+        int k = c.wave;
+        int slot = k < n_pool ? v.pool[k] : 0;
+        double mj = 0.0, p = 0.0;
+        int st = 0;
+        if (k < n_pool) { const double* kf = v.kf + (long)slot * KF_STRIDE; mj = kf[c.lane & 7]; p = kf[KF_DIM + c.lane]; st = v.state[slot]; }
+        while (k < n_pool) {
+            const int kn = k + c.nwaves;
+            const int slot_n = kn < n_pool ? v.pool[kn] : 0;
+            double mj_n = 0.0, p_n = 0.0;
+            int st_n = 0;
+            if (kn < n_pool) { const double* kf = v.kf + (long)slot_n * KF_STRIDE; mj_n = kf[c.lane & 7]; p_n = kf[KF_DIM + c.lane]; st_n = v.state[slot_n]; }
+            kf_predict_wave(v.kf + (long)slot * KF_STRIDE, mj, p, st != ST_TRACKED, c.lane, cfg.kind == 1);
+            k = kn; slot = slot_n; mj = mj_n; p = p_n; st = st_n;
         }
     }
     __syncthreads();
