@@ -642,7 +642,13 @@ BM_STEP_BIG_FN void lap_solve(const Ctx& c, SV& v, const LapLds& L, int R, int C
     __syncthreads();
     bool stalled = false;
     if (R > 0 && C > 0) {
+        // the first cost column of detection s + 1 is requested while detection s is inserted (one element per thread when the tracks
+        // fit the workgroup): the first relaxation of an insertion -- most insertions have no second -- does not wait for L2
+        const bool pre = R <= c.nthr;
+        double nxt = (pre && c.tid < R) ? v.cost[c.tid] : 0.0;
         for (int s = 0; s < C && !stalled; ++s) {
+            const double col0 = nxt;
+            if (pre && s + 1 < C && c.tid < R) nxt = v.cost[(long)(s + 1) * ld + c.tid];
             for (int t = c.tid; t < R; t += c.nthr) { L.minv[t] = LAP_INF; L.used[t] = 0; L.way[t] = -1; }
             int cur = s;          // detection being relaxed
             int via = -1;         // track through which `cur` was reached (-1 = root)
@@ -659,7 +665,7 @@ BM_STEP_BIG_FN void lap_solve(const Ctx& c, SV& v, const LapLds& L, int R, int C
                 int best_t = -1;
                 for (int t = c.tid; t < R; t += c.nthr) {
                     if (L.used[t]) continue;
-                    const double cst = col[t];
+                    const double cst = (pre && iter == 0) ? col0 : col[t];
                     double mv = L.minv[t];
                     if (cst < limit) {
                         const double cand = (cst - limit) - ucur - L.v[t];
