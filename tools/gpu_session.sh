@@ -41,7 +41,9 @@ for step in "$@"; do
              python profiles/summarize_rocpd.py $(db kt) > $O/kernel_stats_m$MODE.txt 2>&1; rm -rf $O/kt; head -n 16 $O/kernel_stats_m$MODE.txt | cut -c1-170 ;;
     traffic) (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o p -- python $R/tools/reid_microbench.py 4096 $MODE 2 > $O/fetch.log 2>&1
               timeout 300 rocprofv3 --pmc WRITE_SIZE -d $O/write -o p -- python $R/tools/reid_microbench.py 4096 $MODE 2 > $O/write.log 2>&1)
-             python profiles/summarize_pmc.py $(db fetch) $(db write) 4096 > $O/pmc_traffic_m$MODE.txt 2>&1; rm -rf $O/fetch $O/write; tail -n 14 $O/pmc_traffic_m$MODE.txt ;;
+             # (the library's source hash goes on the first line: bench.py reports this file's figure only while the hashes agree)
+             python -c "import json; print('# source_hash: ' + json.load(open('boxmot_amd/libboxmot_hip.so.buildinfo'))['source_hash'] + '   (boxmot_amd/libboxmot_hip.so.buildinfo of the library these counters were taken with)')" > $O/pmc_traffic_m$MODE.txt
+             python profiles/summarize_pmc.py $(db fetch) $(db write) 4096 >> $O/pmc_traffic_m$MODE.txt 2>&1; rm -rf $O/fetch $O/write; tail -n 14 $O/pmc_traffic_m$MODE.txt ;;
     mfma)    (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $O/mfma -o p -- python $R/tools/reid_microbench.py 4096 $MODE 2 > $O/mfma.log 2>&1)
              python profiles/summarize_mfma.py $(db mfma) > $O/mfma_busy_m$MODE.txt 2>&1; rm -rf $O/mfma; cat $O/mfma_busy_m$MODE.txt ;;
     c3)      timeout 600 python tools/config_bench.py --config c3 >> $O/config_bench.jsonl 2> $O/c3.err; tail -n 1 $O/config_bench.jsonl | cut -c1-900 ;;
