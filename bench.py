@@ -242,9 +242,9 @@ def side_configs(budget_s):
     import subprocess
     side = {}
     t_end = time.time() + budget_s
-    # the id gate's CPU oracle (an fp32 backbone per frame) gets 45 % of a line's share: 16 frames when the host is quick, fewer -- never
+    # the id gate's CPU oracle (an fp32 backbone per frame) gets 35 % of a line's share (the tracker-math gate a third of that again): 16 frames when the host is quick, fewer -- never
     # under 4 -- when it is not; the line reports the count (`id_gate_frames`)
-    gate_s = f"{0.45 * budget_s / 2:.0f}"
+    gate_s = f"{0.35 * budget_s / 2:.0f}"
     plan = (("config3", ["--config", "c3", "--streams", "8", "--steps", "16", "--warmup", "6", "--check-frames", "16", "--reid-mode", "2",
                          "--gate-budget-s", gate_s]),
             # configuration 5: 104 warm-up frames fill every sample bank (nn_budget 100), so the timed steps are steady state

@@ -243,7 +243,14 @@ def run(config: str = "c3", streams: int = 0, steps: int = 40, warmup: int = 8, 
         try:
             hr2 = HipReID(blob, max_crops=cap_nd, mode=reid_mode if c3 else 0)
             orc2 = DeepOcSortOracle(reid=hr2) if c3 else StrongSortOracle(reid=hr2, dot_rule="device")
-            want2 = [np.asarray(orc2.update(dets_h[t, 0, : cnt_h[t, 0]], scen[0].image), dtype=np.float32).reshape(-1, 8) for t in range(full)]
+            # (the StrongSORT oracle with full sample banks costs seconds per frame by itself: the same time bound, a third of it)
+            want2 = []
+            t_gate2 = time.perf_counter()
+            for t in range(full):
+                if gate_budget_s > 0 and t >= 2 and time.perf_counter() - t_gate2 > gate_budget_s / 3:
+                    break
+                want2.append(np.asarray(orc2.update(dets_h[t, 0, : cnt_h[t, 0]], scen[0].image), dtype=np.float32).reshape(-1, 8))
+            full = len(want2)
             hr2.close()
 
             def ids_ok2(rows, counts):
