@@ -155,6 +155,7 @@ SIGNATURES = {
     "boxmot_hip_deepocsort_reid_kernel_ms": (_I, [_VP, ctypes.POINTER(ctypes.c_double), c_int_p]),
     "boxmot_hip_deepocsort_set_reid_mode": (_I, [_VP, _I]),
     "boxmot_hip_deepocsort_synchronize": (_I, [_VP]),
+    "boxmot_hip_deepocsort_set_crop_bound": (_I, [_VP, _I]),
     "boxmot_hip_deepocsort_state_dump": (_I, [_VP, _I, _VP, _VP, _VP, c_int_p, c_int_p, c_int_p]),
     "boxmot_hip_strongsort_default_config": (None, [ctypes.POINTER(StrongSortConfig)]),
     "boxmot_hip_strongsort_create": (_VP, [ctypes.POINTER(StrongSortConfig)]),
@@ -170,6 +171,7 @@ SIGNATURES = {
     "boxmot_hip_strongsort_reid_kernel_ms": (_I, [_VP, ctypes.POINTER(ctypes.c_double), c_int_p]),
     "boxmot_hip_strongsort_set_reid_mode": (_I, [_VP, _I]),
     "boxmot_hip_strongsort_synchronize": (_I, [_VP]),
+    "boxmot_hip_strongsort_set_crop_bound": (_I, [_VP, _I]),
     "boxmot_hip_strongsort_track_count": (_I, [_VP, _I, c_int_p]),
     "boxmot_hip_strongsort_state_dump": (_I, [_VP, _I, _VP, _VP, _VP, c_int_p, c_int_p, c_int_p]),
     "boxmot_hip_reid_create": (_VP, [ctypes.c_char_p, _VP, ctypes.c_long, _I]),

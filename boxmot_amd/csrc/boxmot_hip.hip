@@ -119,6 +119,22 @@ __global__ void build_crop_list_kernel(const float* dets, const int* n_dets, int
     }
 }
 
+// A backbone family that sizes its launches on the host (the wide OSNets, CLIP-ReID) and a caller that declared an upper bound on the
+// step's crops (set_crop_bound): the list is filled up to the bound with copies of its first entry -- the same crop computes the same
+// embedding and writes it to the same row -- so the launches are sized by the bound and the count never travels to the host.  A
+// count above the bound raises `flag` (reported by the next synchronize).
+__global__ void pad_crop_list_kernel(const int* crop_count, int bound, int* crop_stream, float* crop_boxes, int* crop_row, int* flag) {
+    const int n = *crop_count;
+    if (n > bound) { if (threadIdx.x == 0 && blockIdx.x == 0) *flag = 1; return; }
+    const int s0 = n > 0 ? crop_stream[0] : 0, r0 = n > 0 ? crop_row[0] : 0;
+    float b0[4];
+    for (int q = 0; q < 4; ++q) b0[q] = n > 0 ? crop_boxes[q] : 0.0f;
+    for (int i = n + blockIdx.x * blockDim.x + threadIdx.x; i < bound; i += gridDim.x * blockDim.x) {
+        crop_stream[i] = s0; crop_row[i] = r0;
+        for (int q = 0; q < 4; ++q) crop_boxes[i * 4 + q] = b0[q];
+    }
+}
+
 }  // namespace
 
 struct BoxMOTHipReID {
@@ -285,6 +301,9 @@ struct StreamIo {
     std::unique_ptr<bm::ReidEngine> reid;
     int reid_mode = -1;             // set_reid_mode's last value (-1: the engine's default), re-applied when the engine is re-made
     int* d_crop_count = nullptr; int* d_crop_stream = nullptr; float* d_crop_boxes = nullptr; int* d_crop_row = nullptr;
+    // set_crop_bound: host-declared upper bound on the ReID crops of a device-resident step (-1: none, the count is read back);
+    // d_crop_count[1] = "the count exceeded the bound"
+    int crop_bound = -1;
     // growth of the tables: what the tracker's allocate function handed out, in order; tracks per stream after the last host
     // update (-1 = unknown: a device-resident step ran since)
     std::vector<std::pair<void*, size_t>> table_rec;
@@ -930,7 +949,7 @@ void io_allocate(StreamIo* h, int S, int cap, int nd, int dim, bool with_reid) {
     h->h_warp.assign(s * 6, 0.0); h->h_warp_flag.assign(s, 0);
     h->frame_bufs.assign(s, nullptr);
     h->d_frames = zalloc<const uint8_t*>(s, o);
-    h->d_crop_count = zalloc<int>(1, o);
+    h->d_crop_count = zalloc<int>(2, o);        // [0] the count, [1] the bound-overflow flag
     if (with_reid && !h->reid_path.empty()) io_make_reid(h);
 }
 
@@ -1094,11 +1113,34 @@ void io_device_reid(StreamIo* h, const float* d_dets, const int* d_ndets, const 
     if (h->reid->counted_ok()) {
         h->reid->run_counted(d_frames, h->d_crop_stream, h->d_crop_boxes, 4, h->d_crop_count, h->S * h->nd, image_cols, image_rows,
                              h->d_embs, h->d_crop_row, h->stream);
+    } else if (h->crop_bound >= 0) {
+        // launches sized by the caller's bound: no read-back, no stream synchronisation inside the step (the host keeps queueing)
+        const int n = h->crop_bound < h->S * h->nd ? h->crop_bound : h->S * h->nd;
+        if (n > 0) {
+            hipLaunchKernelGGL(pad_crop_list_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, (const int*)h->d_crop_count, n,
+                               h->d_crop_stream, h->d_crop_boxes, h->d_crop_row, h->d_crop_count + 1);
+            h->reid->run(d_frames, h->d_crop_stream, h->d_crop_boxes, 4, n, image_cols, image_rows, h->d_embs, h->d_crop_row, h->stream);
+        }
     } else {
         int n_crops = 0;
         BM_HIP(hipMemcpyAsync(&n_crops, h->d_crop_count, 4, hipMemcpyDeviceToHost, h->stream));
         BM_HIP(hipStreamSynchronize(h->stream));
         h->reid->run(d_frames, h->d_crop_stream, h->d_crop_boxes, 4, n_crops, image_cols, image_rows, h->d_embs, h->d_crop_row, h->stream);
+    }
+}
+
+void io_set_crop_bound(StreamIo* h, int max_total_crops) {
+    if (max_total_crops < -1) throw std::runtime_error("boxmot_hip: crop bound must be >= 0, or -1 to read the count back");
+    h->crop_bound = max_total_crops;
+}
+// after a stream synchronisation: a step whose crops exceeded the declared bound left detections without an embedding
+void io_check_crop_bound(StreamIo* h) {
+    if (h->crop_bound < 0 || !h->d_crop_count) return;
+    int flag = 0;
+    BM_HIP(hipMemcpy(&flag, h->d_crop_count + 1, 4, hipMemcpyDeviceToHost));
+    if (flag) {
+        BM_HIP(hipMemset(h->d_crop_count + 1, 0, 4));
+        throw std::runtime_error("boxmot_hip: a device-resident step had more ReID crops than the bound declared with set_crop_bound");
     }
 }
 
@@ -2225,6 +2267,14 @@ int boxmot_hip_deepocsort_synchronize(BoxMOTHipDeepOcSort* handle) {
     return guard([&]() {
         if (!handle) throw std::runtime_error("boxmot_hip DeepOCSORT handle is not initialized.");
         BM_HIP(hipStreamSynchronize(handle->stream));
+        io_check_crop_bound(handle);
+    });
+}
+
+int boxmot_hip_deepocsort_set_crop_bound(BoxMOTHipDeepOcSort* handle, int max_total_crops) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip DeepOCSORT handle is not initialized.");
+        io_set_crop_bound(handle, max_total_crops);
     });
 }
 
@@ -2415,6 +2465,14 @@ int boxmot_hip_strongsort_synchronize(BoxMOTHipStrongSort* handle) {
     return guard([&]() {
         if (!handle) throw std::runtime_error("boxmot_hip StrongSORT handle is not initialized.");
         BM_HIP(hipStreamSynchronize(handle->stream));
+        io_check_crop_bound(handle);
+    });
+}
+
+int boxmot_hip_strongsort_set_crop_bound(BoxMOTHipStrongSort* handle, int max_total_crops) {
+    return guard([&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip StrongSORT handle is not initialized.");
+        io_set_crop_bound(handle, max_total_crops);
     });
 }
 

@@ -378,7 +378,14 @@ int boxmot_hip_deepocsort_reid_kernel_ms(BoxMOTHipDeepOcSort* handle, double* ou
 /* 0 = per-layer fp32 kernels, 1 = fp16 MFMA kernels (fused for OSNet-x0.25, layer-per-launch for osnet_x1_0); CLIP-ReID has one family */
 int boxmot_hip_deepocsort_set_reid_mode(BoxMOTHipDeepOcSort* handle, int mode);
 void* boxmot_hip_deepocsort_stream(BoxMOTHipDeepOcSort* handle);
+/* waits for the handle's stream; throws if a step exceeded the bound below */
 int boxmot_hip_deepocsort_synchronize(BoxMOTHipDeepOcSort* handle);
+/* Host-known upper bound on the ReID crops of the following step_device_frames calls (all streams together; -1 = none, the
+ * default; a host call, cheap enough to repeat before every step with that step's detection total).  The backbone families that size their launches on the host (osnet_x0_5 ... x1_0, CLIP-ReID) otherwise read the
+ * crop count back -- a stream synchronisation inside every step, during which the GPU waits for the host to queue the pass.
+ * With a bound the crop list is filled up to it with copies of its first entry and nothing travels to the host; a step with
+ * more crops than the bound is reported by the next synchronize.  (OSNet-x0.25's fused kernels take the count on the device.) */
+int boxmot_hip_deepocsort_set_crop_bound(BoxMOTHipDeepOcSort* handle, int max_total_crops);
 /* parity debugging: live tracks of `stream` in list order -- ints5 (rows,5) = id, age, time_since_update, hit_streak,
  * observed; kf72 (rows,72) = x[8] ++ P[8][8] fp64 (index 7 unused); emb (rows, emb_dim) fp64.  NULL skips an output. */
 int boxmot_hip_deepocsort_state_dump(BoxMOTHipDeepOcSort* handle, int stream, int* ints5, double* kf72, double* emb,
@@ -444,6 +451,8 @@ int boxmot_hip_strongsort_reid_kernel_ms(BoxMOTHipStrongSort* handle, double* ou
 int boxmot_hip_strongsort_set_reid_mode(BoxMOTHipStrongSort* handle, int mode);
 void* boxmot_hip_strongsort_stream(BoxMOTHipStrongSort* handle);
 int boxmot_hip_strongsort_synchronize(BoxMOTHipStrongSort* handle);
+/* as boxmot_hip_deepocsort_set_crop_bound */
+int boxmot_hip_strongsort_set_crop_bound(BoxMOTHipStrongSort* handle, int max_total_crops);
 /* len(self.tracker.tracks) of `stream` (tentative + confirmed): the reference asks its camera-motion estimator for a warp only
  * when this is >= 1 (strongsort.py:83-86), and that estimator is stateful -- a caller that owns one needs the same gate. */
 int boxmot_hip_strongsort_track_count(BoxMOTHipStrongSort* handle, int stream, int* out_tracks);

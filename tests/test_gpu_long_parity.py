@@ -392,12 +392,14 @@ def test_long_config3_deepocsort_240_frames_vs_reference_rows():
     trk.close()
 
 
-@pytest.mark.parametrize("mode,weights", [(2, "calib"), (2, "init"), (1, "init"), (0, "init")])
-def test_config3_reid_inside_update_full_size_vs_reference_rows(mode, weights):
+@pytest.mark.parametrize("mode,weights,bound", [(2, "calib", 0), (2, "calib", 160), (2, "init", 0), (1, "init", 128), (0, "init", 0)])
+def test_config3_reid_inside_update_full_size_vs_reference_rows(mode, weights, bound):
     """Configuration 3 with its backbone inside update, at full size: the device-resident DeepOCSORT step with OSNet-x1.0 (the
     fp32-grade family tools/config_bench.py reports -- on the reference's init AND on BatchNorm-calibrated weights --, the fp16 MFMA
     family, and the per-layer fp32 kernels) against rows of the reference DeepOcSort + reference OSNet-x1.0 module on the CPU
-    (tests/golden/config3_reid_golden.npz, config3_reid_calib_golden.npz), >= 60 frames: ids exact."""
+    (tests/golden/config3_reid_golden.npz, config3_reid_calib_golden.npz), >= 60 frames: ids exact.  `bound` > 0: the step runs with
+    boxmot_hip_deepocsort_set_crop_bound -- launches sized by the host's bound (128 = exact, 160 = 32 padded entries), the crop
+    count never read back -- and must return the same rows."""
     import ctypes
     import os
     import tempfile
@@ -438,11 +440,18 @@ def test_config3_reid_inside_update_full_size_vs_reference_rows(mode, weights):
             d_dets[: len(dets)] = torch.from_numpy(dets).to(dev)
             d_n[0] = len(dets)
             torch.cuda.synchronize()
+            if bound:       # what the host knows about this step: its detections (+ 32 padded entries when bound = 160)
+                _lib.check(lib.boxmot_hip_deepocsort_set_crop_bound(h, len(dets) + bound - 128))
             _lib.check(lib.boxmot_hip_deepocsort_step_device_frames(h, d_dets.data_ptr(), d_n.data_ptr(), ptrs.data_ptr(), 1080, 1920,
                                                                     d_out.data_ptr(), d_out_n.data_ptr()))
             _lib.check(lib.boxmot_hip_deepocsort_synchronize(h))
             got = d_out[: int(d_out_n[0])].cpu().numpy()
             assert_rows_match(got, want[t], t, box_atol=5e-3)
+        if bound:           # a step with more crops than the declared bound is reported by the next synchronize
+            _lib.check(lib.boxmot_hip_deepocsort_set_crop_bound(h, 4))
+            _lib.check(lib.boxmot_hip_deepocsort_step_device_frames(h, d_dets.data_ptr(), d_n.data_ptr(), ptrs.data_ptr(), 1080, 1920,
+                                                                    d_out.data_ptr(), d_out_n.data_ptr()))
+            assert lib.boxmot_hip_deepocsort_synchronize(h) == 0 and "more ReID crops than the bound" in _lib.last_error()
     finally:
         lib.boxmot_hip_deepocsort_destroy(h)
 

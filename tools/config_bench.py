@@ -46,7 +46,7 @@ def vit_flops(width=768, layers=12, tokens=129, patch_k=768, out_dim=512):
 
 def run(config: str = "c3", streams: int = 0, steps: int = 40, warmup: int = 8, check_frames: int = -1, reid_mode: int = 1,
         with_ecc: bool = True, groups: int = 0, embedding_gate: bool = True, both_groups: bool = False, gate_budget_s: float = 0.0,
-        cpu_threads: int = 32) -> dict:
+        cpu_threads: int = 32, crop_bound: bool = True) -> dict:
     """One measurement; returns the result dict (bench.py calls this for its side lines).  `groups`: the streams are split over
     that many handles, each with its own HIP stream (0 = 1) -- with 2, one group's frame step (a few workgroups: one per stream)
     runs beside the other group's ReID kernels instead of after its own (configuration 3: 497 -> 541 frames/s; configuration 5:
@@ -103,12 +103,14 @@ def run(config: str = "c3", streams: int = 0, steps: int = 40, warmup: int = 8, 
         mk, step_fn, sync, destroy = lib.boxmot_hip_deepocsort_create, lib.boxmot_hip_deepocsort_step_device_frames, \
             lib.boxmot_hip_deepocsort_synchronize, lib.boxmot_hip_deepocsort_destroy
         reid_ms, set_mode = lib.boxmot_hip_deepocsort_reid_kernel_ms, lib.boxmot_hip_deepocsort_set_reid_mode
+        set_bound = lib.boxmot_hip_deepocsort_set_crop_bound
     else:
         cfg = _lib.StrongSortConfig()
         lib.boxmot_hip_strongsort_default_config(ctypes.byref(cfg))
         mk, step_fn, sync, destroy = lib.boxmot_hip_strongsort_create, lib.boxmot_hip_strongsort_step_device_frames, \
             lib.boxmot_hip_strongsort_synchronize, lib.boxmot_hip_strongsort_destroy
         reid_ms, set_mode = lib.boxmot_hip_strongsort_reid_kernel_ms, lib.boxmot_hip_strongsort_set_reid_mode
+        set_bound = lib.boxmot_hip_strongsort_set_crop_bound
     ms, nl = ctypes.c_double(0), ctypes.c_int(0)
 
     def measure(groups_now):
@@ -133,6 +135,10 @@ def run(config: str = "c3", streams: int = 0, steps: int = 40, warmup: int = 8, 
         def raw_step(t):        # asynchronous launches, group after group: group g's step kernel overlaps group g + 1's ReID kernels
             for g, hg in enumerate(hs):
                 a, b = g * Sg, (g + 1) * Sg
+                if crop_bound:
+                    # the host knows how many detections it hands over: the step's ReID launches are sized by that bound and the crop
+                    # count stays on the device (no stream synchronisation inside the step, include/boxmot_hip.h: set_crop_bound)
+                    _lib.check(set_bound(hg, int(cnt_h[t, a:b].sum())))
                 _lib.check(step_fn(hg, d_dets[t, a:b].data_ptr(), d_cnt[t, a:b].data_ptr(), ptrs[a:b].data_ptr(), H, W,
                                    d_out[t, a:b].data_ptr(), d_out_n[t, a:b].data_ptr()))
 
@@ -285,6 +291,7 @@ def run(config: str = "c3", streams: int = 0, steps: int = 40, warmup: int = 8, 
         "workload": ("DeepOCSORT + OSNet_x1_0 ReID, 128 dets x 512 tracks, 1080p" if c3 else
                      "StrongSORT + CLIP-ReID (ViT-B/16), 256 dets x 1024 tracks, 4K frames, 1280-d"),
         "mode": "M2 reid-in-update, device-resident inputs" + ("" if c3 else (", ECC estimated per stream-frame on the device (static frames: converges at once)" if with_ecc else ", no camera-motion estimation")), "streams": S, "stream_groups": G, "steps": steps, "warmup": warmup,
+        "crop_count": "host-declared bound (set_crop_bound): no read-back inside the step" if crop_bound else "read back inside every step",
         "frames_per_s": S * steps / dt, "ms_per_step": 1e3 * dt / steps, "crops_per_step": crops / steps,
         "reid_forward_ms_per_step": reid_total_ms / steps, "reid_passes": reid_launches, "gflop_per_crop": flops_per_crop / 1e9,
         "reid_kernels": ({0: "per-layer fp32", 1: "layer-per-launch fp16 MFMA (osnet_wide)", 2: "fp32-grade: chain-fused LightConvs + (hi, lo) GEMMs (osnet_wide_hp)"}[reid_mode]
@@ -307,10 +314,11 @@ def main():
     ap.add_argument("--groups", type=int, default=0, help="handles (HIP streams) the streams are split over; 0 = 1")
     ap.add_argument("--both-groups", action="store_true", help="after the measurement, repeat it with 2 stream groups (same inputs, same oracle rows)")
     ap.add_argument("--gate-budget-s", type=float, default=0.0, help="stop the CPU oracle of the id gate after this many seconds (never before 2 frames)")
+    ap.add_argument("--no-crop-bound", action="store_true", help="read the crop count back inside every step (the default before round 4) instead of declaring the host-known bound")
     ap.add_argument("--no-ecc", action="store_true", help="c5: skip the per-frame ECC estimate (the reference's StrongSORT always runs it)")
     a = ap.parse_args()
     print(json.dumps(run(a.config, a.streams, a.steps, a.warmup, a.check_frames, a.reid_mode, not a.no_ecc, a.groups, both_groups=a.both_groups,
-                         gate_budget_s=a.gate_budget_s)), flush=True)
+                         gate_budget_s=a.gate_budget_s, crop_bound=not a.no_crop_bound)), flush=True)
 
 
 if __name__ == "__main__":
