@@ -96,3 +96,18 @@ def bytetrack_device_config(**kw) -> dict:
                 match_thresh=c["match_thresh"], proximity_thresh=0.5, appearance_thresh=0.25, second_match_thresh=0.5,
                 unconfirmed_match_thresh=0.7, unconfirmed_emb_scale=2.0, fuse_first_associate=1, with_reid=0,
                 frame_rate=c["frame_rate"], track_buffer=c["track_buffer"], removed_stracks_buffer=100, kind=1)
+
+
+ASSO_FUNCS = {"giou": 0.6, "diou": 0.6, "ciou": 0.6, "hmiou": 0.3, "centroid": 0.9}     # keep in step with tests/golden/make_asso_golden.py
+
+
+def asso_golden_rows(tracker, name):
+    """Per-frame rows of the reference DeepOcSort / OcSort(use_byte=True) constructed with asso_func=name (tests/golden/asso_golden.npz,
+    written by tests/golden/make_asso_golden.py from the reference classes) and the frames factory that regenerates the inputs."""
+    g = np.load(GOLDEN / "asso_golden.npz")
+    rows, counts = g[f"{tracker}_{name}_rows"], g[f"{tracker}_{name}_counts"]
+    out, o = [], 0
+    for n in counts:
+        out.append(rows[o:o + n])
+        o += n
+    return out, (lambda: stress_frames(int(g["frames"]), seed=int(g["seed"])))

@@ -191,6 +191,23 @@ def test_hip_association_functions_match_the_oracle(asso_func, thr):
     trk.close()
 
 
+@pytest.mark.parametrize("name", ["giou", "diou", "ciou", "hmiou", "centroid"])
+def test_hip_association_functions_match_reference_golden_rows(name):
+    """The same plugin classes against rows the REFERENCE DeepOcSort / OcSort(use_byte=True) produced with each association function
+    (tests/golden/asso_golden.npz, tests/golden/make_asso_golden.py): ids, confidences, classes, detection indices and row order exact."""
+    from boxmot_amd import DeepOcSort, OcSort
+    from common import ASSO_FUNCS, asso_golden_rows
+    img = np.zeros((480, 640, 3), dtype=np.uint8)
+    for tracker in ("deepocsort", "ocsort"):
+        want, frames = asso_golden_rows(tracker, name)
+        kw = dict(max_tracks=128, max_dets=64, asso_func=name, iou_threshold=ASSO_FUNCS[name])
+        trk = DeepOcSort(reid_model=None, cmc_off=True, emb_dim=32, **kw) if tracker == "deepocsort" else OcSort(use_byte=True, **kw)
+        for t, (dets, embs) in enumerate(frames()):
+            got = np.asarray(trk.update(dets, img, embs) if tracker == "deepocsort" else trk.update(dets, img)).reshape(-1, 8)
+            assert_rows_match(got, want[t], t)
+        trk.close()
+
+
 def test_hip_unknown_association_function_raises_on_the_first_frame():
     from boxmot_amd import OcSort
     trk = OcSort(max_tracks=64, max_dets=32, asso_func="nope")          # the reference resolves the name on the first frame too

@@ -141,3 +141,19 @@ def test_deepocsort_oracle_matches_reference_rows_at_config3_scale():
         assert len(got) == hi - lo, t
         assert np.array_equal(got[:, 4].astype(np.int32), g["ids"][lo:hi]) and np.array_equal(got[:, 7].astype(np.int32), g["det_ind"][lo:hi]), t
         assert np.allclose(got[:, :4], g["boxes"][lo:hi], rtol=0, atol=1e-4), t
+
+
+@pytest.mark.parametrize("name", ["giou", "diou", "ciou", "hmiou", "centroid"])
+def test_association_function_oracles_match_reference_rows(name):
+    """BaseTracker's asso_func by name (iou.py:118-423): the oracle's restatement of each function inside DeepOCSORT and OC-SORT (with
+    its BYTE round) against rows the reference classes produced (tests/golden/asso_golden.npz) -- runs without /root/reference."""
+    from common import ASSO_FUNCS, asso_golden_rows
+    from oracle.deepocsort import DeepOcSortOracle, OcSortOracle
+    img = np.zeros((480, 640, 3), np.uint8)
+    for tracker in ("deepocsort", "ocsort"):
+        want, frames = asso_golden_rows(tracker, name)
+        orc = (DeepOcSortOracle(asso_func=name, iou_threshold=ASSO_FUNCS[name]) if tracker == "deepocsort"
+               else OcSortOracle(asso_func=name, iou_threshold=ASSO_FUNCS[name], use_byte=True))
+        for t, (d, e) in enumerate(frames()):
+            got = np.asarray(orc.update(d.copy(), img, e.copy()), dtype=np.float32).reshape(-1, 8)
+            assert got.shape == want[t].shape and np.array_equal(got, want[t]), (tracker, name, t)
