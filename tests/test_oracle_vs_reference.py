@@ -174,7 +174,7 @@ def test_osnet_functional_equals_reference_module():
     from oracle.osnet import osnet_forward
 
     mod = ref_harness.load_osnet_module()
-    for arch in ("osnet_x0_25", "osnet_x1_0"):
+    for arch in ("osnet_x0_25", "osnet_x0_5", "osnet_x0_75", "osnet_x1_0"):
         sd = random_osnet_state_dict(arch, seed=5, calib_batch=2)
         model = getattr(mod, arch)(num_classes=10, pretrained=False).eval()
         res = model.load_state_dict(sd, strict=False)
