@@ -111,6 +111,9 @@ def parse(argv=None):
     ap.add_argument("--no-m1", action="store_true", help="skip the tracker-math-only (embeddings supplied) side measurement")
     ap.add_argument("--no-side-configs", action="store_true",
                     help="skip the short side measurements of BASELINE.json configurations 3 and 5 (tools/config_bench.py)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and run the barriers / all_reduce / gather even with ONE rank: the RCCL code path of the "
+                         "multi-GPU run on a single-GPU box (profiles/r4_nccl_one_rank.txt)")
     ap.add_argument("--side-budget-s", type=float, default=300.0,
                     help="wall budget of the side measurements (configurations 3 and 5, child processes): what does not fit is "
                          "reported as skipped / timed out, the headline line is printed regardless")
@@ -411,9 +414,13 @@ def main(argv=None):
     if world != a.gpus:
         log(f"rank {rank}: --gpus {a.gpus} but WORLD_SIZE {world}: the launcher's world size is what runs")
     stub = bool(a.stub_tracker)
+    use_dist = world > 1 or a.force_dist        # collectives on (always with more than one rank)
+    if a.force_dist and world == 1:
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")):
+            os.environ.setdefault(k, v)
     if stub:
         # no device, no extension: control flow only
-        if world > 1:
+        if use_dist:
             dist.init_process_group(a.backend)
             dist.barrier()
         dev = torch.device("cpu")
@@ -422,7 +429,7 @@ def main(argv=None):
         import __graft_entry__ as g
         if rank == 0:
             g.build()           # rank 0 compiles (or verifies the recorded source hash); the others wait at the barrier and reuse
-        if world > 1:
+        if use_dist:
             torch.cuda.set_device(local)
             # bind this rank's communicator to ITS GPU before the first collective (RCCL otherwise picks the device lazily)
             if a.backend == "nccl":
@@ -435,7 +442,7 @@ def main(argv=None):
             torch.cuda.set_device(0)
         if rank != 0:
             g.build()
-        dev = torch.device("cuda", local if world > 1 else 0)
+        dev = torch.device("cuda", local if use_dist else 0)
         dev_sync = torch.cuda.synchronize
 
     from boxmot_amd.scenario import Scenario
@@ -509,7 +516,7 @@ def main(argv=None):
         m.reid_kernel_ms()              # drop warm-up timings
     # ---- the timed region: barrier + device sync on both sides, exactly K steps, MAX over ranks ----
     dev_sync()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     ms.timer_start()
     t0 = time.perf_counter()
@@ -520,7 +527,7 @@ def main(argv=None):
         m.synchronize()
     dev_sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         dist.barrier()
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -538,7 +545,7 @@ def main(argv=None):
     # ---- result gather (the only collective of the path), after the timed loop; timed on its own ----
     out_h, out_n_h = d_out.cpu().numpy(), d_out_n.cpu().numpy()
     gather_ms, gathered_ok = None, None
-    if world > 1:
+    if use_dist:
         from boxmot_amd.streams import gather_results
         send_rows = d_out[W:].transpose(0, 1).contiguous()           # (S, K, nd, 8)
         send_cnt = d_out_n[W:].transpose(0, 1).contiguous()
@@ -572,7 +579,7 @@ def main(argv=None):
                        "tracker_params": "botsort.yaml defaults, use_cmc=False", "weights": "random-init OSNet-x0.25 (reference _init_params scheme, seed 0)",
                        "device_ms_timed_region": dev_ms},
         }
-        if world > 1:
+        if use_dist:
             res["gather_ms"] = gather_ms
             res["config"]["gather"] = {"backend": a.backend, "bytes_per_rank": int(send_rows.numel() * 4 + send_cnt.numel() * 4),
                                        "complete_on_rank0": gathered_ok}
@@ -630,7 +637,7 @@ def main(argv=None):
         print(json.dumps(res))
     for m in groups:
         m.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     return 0

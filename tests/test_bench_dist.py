@@ -70,3 +70,13 @@ def test_rank_sharding_is_disjoint_and_by_rank():
     a = Scenario(64, 256, 1920, 1080, 512, stream=0, random_image=False).frame(5, with_embs=False)[0]
     b = Scenario(64, 256, 1920, 1080, 512, stream=3, random_image=False).frame(5, with_embs=False)[0]
     assert a.shape == b.shape and not (a == b).all()
+
+
+def test_force_dist_runs_the_collectives_with_one_rank():
+    """`--force-dist`: the process group, the barriers, the MAX all_reduce and the result gather with ONE rank -- the switch that lets a
+    single-GPU box execute the RCCL branch of the N > 1 run (`--backend nccl` there; gloo + the stub here)."""
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--force-dist", *ARGS], capture_output=True, text=True, timeout=300,
+                       env=_env(), cwd=str(ROOT))
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = _json_line(p.stdout)
+    assert d["n_gpus"] == 1 and d["config"]["gather"]["complete_on_rank0"] is True and d["gather_ms"] > 0
