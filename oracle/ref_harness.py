@@ -60,9 +60,31 @@ def _cv2_stub():
         out[top:top + h, left:left + w] = src
         return out
 
+    # oriented boxes (iou.py:5-115, bytetrack.py:147-189): the intersection polygon is represented by its area alone -- what the
+    # reference does with it is cv2.contourArea -- and that area is oracle/obb.py's fp64 clipping, NOT OpenCV's fp32 edge enumeration
+    # (parity unpinned for this one quantity, see oracle/obb.py)
+    class _Polygon:
+        def __init__(self, area):
+            self.area = area
+
+    def rotatedRectangleIntersection(r1, r2):
+        from oracle import obb
+        area = obb.rotated_intersection_area(r1, r2)
+        return (1 if area > 0.0 else 0), (_Polygon(area) if area > 0.0 else None)
+
+    def contourArea(poly):
+        return poly.area
+
+    def boxPoints(rect):
+        from oracle import obb
+        return obb.box_points(rect[0][0], rect[0][1], rect[1][0], rect[1][1], rect[2])
+
     cv2.resize = resize
     cv2.cvtColor = cvtColor
     cv2.copyMakeBorder = copyMakeBorder
+    cv2.rotatedRectangleIntersection = rotatedRectangleIntersection
+    cv2.contourArea = contourArea
+    cv2.boxPoints = boxPoints
     return cv2
 
 
