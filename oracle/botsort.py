@@ -133,6 +133,27 @@ def _minus(a, ids):
 
 
 class BotSortOracle:
+    # what the oriented-box variant (oracle/botsort_obb.py) replaces: the detection layout, the record type, the filter, the IoU
+    REC = _Rec
+    N_BOX, CONF_COL, N_DET_COLS, N_OUT_COLS = 4, 4, 6, 8
+    VEL_ZERO = slice(6, 8)                      # velocities zeroed for non-tracked tracks before prediction (botsort_track.py:104-109)
+
+    @staticmethod
+    def _kf_predict(mean, cov):
+        return kalman.multi_predict(mean, cov)
+
+    @staticmethod
+    def _kf_initiate(z):
+        return kalman.initiate(z)
+
+    @staticmethod
+    def _iou_d(a, b):
+        return matching.iou_distance(_boxes(a), _boxes(b))
+
+    @staticmethod
+    def _row(t):
+        return [*t.xyxy, t.id, t.conf, t.cls, t.det_ind]
+
     def __init__(self, reid=None, **kw):
         cfg = dict(DEFAULTS)
         unknown = set(kw) - set(cfg)
@@ -156,7 +177,7 @@ class BotSortOracle:
     def _assoc_cost(self, tracks, dets, emb_scale, fuse):
         """IoU gate + optional score fusion + appearance gate (botsort.py:306-317, 396-413)."""
         c = self.cfg
-        iou_d = matching.iou_distance(_boxes(tracks), _boxes(dets))
+        iou_d = self._iou_d(tracks, dets)
         gate = iou_d > c["proximity_thresh"]
         if fuse:
             iou_d = matching.fuse_score(iou_d, np.array([d.conf for d in dets]))
@@ -175,7 +196,7 @@ class BotSortOracle:
         c = self.cfg
         dets = np.asarray(dets)
         if dets.size == 0:
-            dets = np.empty((0, 6), dtype=np.float32)
+            dets = np.empty((0, self.N_DET_COLS), dtype=np.float32)
         self.frame_count += 1
         fc = self.frame_count
         activated, refound, newly_lost, newly_removed = [], [], [], []
@@ -184,22 +205,22 @@ class BotSortOracle:
         if len(dets):
             table = np.hstack([dets, np.arange(len(dets), dtype=np.int32).reshape(-1, 1)])
         else:
-            table = np.empty((0, 7), dtype=dets.dtype)
-        confs = table[:, 4]
+            table = np.empty((0, self.N_DET_COLS + 1), dtype=dets.dtype)
+        confs = table[:, self.CONF_COL]
         low = np.logical_and(confs > c["track_low_thresh"], confs < c["track_high_thresh"])
         high = confs > c["track_high_thresh"]
         dets_hi, dets_lo = table[high], table[low]
 
         if c["with_reid"] and embs is None:
-            feats = self.reid.get_features(dets_hi[:, :4], img)
+            feats = self.reid.get_features(dets_hi[:, :self.N_BOX], img)
         else:
             feats = np.asarray(embs)[high] if embs is not None else None
 
         if len(dets_hi):
             if c["with_reid"]:
-                cand = [_Rec(d, f) for d, f in zip(dets_hi, feats)]
+                cand = [self.REC(d, f) for d, f in zip(dets_hi, feats)]
             else:
-                cand = [_Rec(d) for d in dets_hi]
+                cand = [self.REC(d) for d in dets_hi]
         else:
             cand = []
 
@@ -213,10 +234,12 @@ class BotSortOracle:
             cov = np.asarray([t.cov for t in pool])
             for i, t in enumerate(pool):
                 if t.state != TRACKED:
-                    mean[i][6:8] = 0
-            mean, cov = kalman.multi_predict(mean, cov)
+                    mean[i][self.VEL_ZERO] = 0
+            mean, cov = self._kf_predict(mean, cov)
             for t, m, p in zip(pool, mean, cov):
                 t.mean, t.cov = m, p
+        if warp is not None and self.N_BOX != 4:
+            raise NotImplementedError("oracle: camera-motion compensation of oriented boxes (STrack.multi_gmc_obb: cv2.minAreaRect) is not restated")
         if warp is not None:
             # STrack.multi_gmc on the pool, then on the unconfirmed tracks (botsort.py:134-145, botsort_track.py:117-132)
             H = np.asarray(warp)
@@ -240,9 +263,9 @@ class BotSortOracle:
                 refound.append(t)
 
         # ---- second association, IoU only (botsort.py:335-378) ----
-        cand_lo = [_Rec(d) for d in dets_lo]
+        cand_lo = [self.REC(d) for d in dets_lo]
         remain = [pool[i] for i in u_trk1 if pool[i].state == TRACKED]
-        d2 = matching.iou_distance(_boxes(remain), _boxes(cand_lo))
+        d2 = self._iou_d(remain, cand_lo)
         m2, u_trk2, _ = matching.linear_assignment(d2, c["second_match_thresh"])
         for it, idet in m2:
             t = remain[it]
@@ -275,7 +298,7 @@ class BotSortOracle:
             if d.conf < c["new_track_thresh"]:
                 continue
             d.id = self._next_id()
-            d.mean, d.cov = kalman.initiate(d.xywh)
+            d.mean, d.cov = self._kf_initiate(d.xywh)
             d.tracklet_len = 0
             d.state = TRACKED
             if fc == 1:
@@ -299,15 +322,13 @@ class BotSortOracle:
         self.removed_ids.extend(t.id for t in newly_removed)
         self.active, self.lost = self._dedup(self.active, self.lost)
 
-        rows = [
-            [*t.xyxy, t.id, t.conf, t.cls, t.det_ind] for t in self.active if t.is_activated
-        ]
-        return np.asarray(rows, dtype=np.float32) if rows else np.empty((0, 8), dtype=np.float32)
+        rows = [self._row(t) for t in self.active if t.is_activated]
+        return np.asarray(rows, dtype=np.float32) if rows else np.empty((0, self.N_OUT_COLS), dtype=np.float32)
 
-    @staticmethod
-    def _dedup(a, b):
+    @classmethod
+    def _dedup(cls, a, b):
         """remove_duplicate_stracks (botsort_utils.py:55-82)."""
-        pd = matching.iou_distance(_boxes(a), _boxes(b))
+        pd = cls._iou_d(a, b)
         drop_a, drop_b = [], []
         for p, q in zip(*np.where(pd < 0.15)):
             tp = a[p].frame_id - a[p].start_frame

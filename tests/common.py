@@ -111,3 +111,30 @@ def asso_golden_rows(tracker, name):
         out.append(rows[o:o + n])
         o += n
     return out, (lambda: stress_frames(int(g["frames"]), seed=int(g["seed"])))
+
+
+def obb_frames(n_frames, seed):
+    """The seeded stress scenes with every detection turned into (cx, cy, w, h, angle, conf, cls): the angle follows the box centre
+    smoothly so that tracks see a slowly rotating target, with parameterisation flips (w <-> h, angle + pi / 2) thrown in -- the
+    ambiguity KalmanFilterXYWH._align_obb_measurement resolves."""
+    from boxmot_amd.scenario import stress_frames
+    rng = np.random.default_rng(seed)
+    for t, (d, _) in enumerate(stress_frames(n_frames, seed=seed)):
+        d = np.asarray(d, dtype=np.float32).reshape(-1, 6)
+        cx, cy, w, h = (d[:, 0] + d[:, 2]) / 2, (d[:, 1] + d[:, 3]) / 2, d[:, 2] - d[:, 0], d[:, 3] - d[:, 1]
+        ang = 0.6 * np.sin(0.02 * t + 0.004 * cx + 0.006 * cy) + rng.normal(0, 0.01, len(d))
+        flip = rng.random(len(d)) < 0.15
+        w2, h2, a2 = np.where(flip, h, w), np.where(flip, w, h), np.where(flip, ang + np.pi / 2, ang)
+        yield np.stack([cx, cy, w2, h2, a2, d[:, 4], d[:, 5]], axis=1).astype(np.float32)
+
+
+def obb_golden_rows(key):
+    """Per-frame 9-column rows of the reference ByteTrack / BotSort fed oriented detections (tests/golden/obb_golden.npz, written by
+    tests/golden/make_obb_golden.py) and the frame count / seed that regenerate the inputs with obb_frames."""
+    g = np.load(GOLDEN / "obb_golden.npz")
+    rows, counts = g[key + "_rows"], g[key + "_counts"]
+    out, o = [], 0
+    for n in counts:
+        out.append(rows[o:o + n])
+        o += n
+    return out, int(g["frames"]), int(g["seed"])

@@ -1,0 +1,50 @@
+"""Golden rows of the REAL reference ByteTrack and BotSort classes fed ORIENTED detections (7 columns: cx, cy, w, h, angle, conf, cls),
+on the seeded scenes of tests/common.py:obb_frames.  Build container only (/root/reference under the stand-ins of oracle/ref_harness.py;
+the rotated-intersection AREA behind cv2.rotatedRectangleIntersection / contourArea is oracle/obb.py's, see there):
+
+    python tests/golden/make_obb_golden.py
+
+-> tests/golden/obb_golden.npz.  No device step takes oriented detections yet: the fixture is there for the kernel work to start against
+("what comes next" item 0); tests/test_oracle_obb.py checks the oracles against it without /root/reference.
+"""
+from __future__ import annotations
+
+import logging
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+from boxmot_amd.scenario import stress_frames  # noqa: E402
+from common import obb_frames  # noqa: E402
+from oracle import ref_harness  # noqa: E402
+
+FRAMES, SEED = 90, 4
+CASES = {"bytetrack": ("bytetrack", {}), "botsort_noreid": ("botsort", dict(with_reid=False)), "botsort_reid": ("botsort", dict(with_reid=True))}
+
+
+def main():
+    logging.disable(logging.CRITICAL)
+    img = np.zeros((480, 640, 3), np.uint8)
+    embs = [e for _, e in stress_frames(FRAMES, seed=SEED)]
+    out = {}
+    for key, (kind, kw) in CASES.items():
+        trk = ref_harness.load_bytetrack()(**kw) if kind == "bytetrack" else ref_harness.load_botsort()(reid_model=None, use_cmc=False, **kw)
+        rows, counts = [], []
+        for t, d in enumerate(obb_frames(FRAMES, seed=SEED)):
+            e = embs[t].copy() if kw.get("with_reid") else None
+            r = np.asarray(trk.update(d.copy(), img, e) if kind == "botsort" else trk.update(d.copy(), img), dtype=np.float64).reshape(-1, 9)
+            rows.append(r)
+            counts.append(len(r))
+        out[key + "_counts"] = np.asarray(counts, dtype=np.int32)
+        out[key + "_rows"] = np.concatenate(rows).astype(np.float32)
+        print(key, sum(counts), "rows", flush=True)
+    np.savez_compressed(Path(__file__).resolve().parent / "obb_golden.npz", frames=np.int32(FRAMES), seed=np.int32(SEED), **out)
+
+
+if __name__ == "__main__":
+    main()

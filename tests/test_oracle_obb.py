@@ -5,22 +5,8 @@ import logging
 import numpy as np
 import pytest
 
+from common import obb_frames
 from oracle import obb, ref_harness
-
-
-def obb_frames(n_frames, seed):
-    """The seeded stress scenes with every detection turned into (cx, cy, w, h, angle, conf, cls): the angle follows the box centre
-    smoothly so that tracks see a slowly rotating target, with parameterisation flips (w <-> h, angle + pi / 2) thrown in -- the
-    ambiguity KalmanFilterXYWH._align_obb_measurement resolves."""
-    from boxmot_amd.scenario import stress_frames
-    rng = np.random.default_rng(seed)
-    for t, (d, _) in enumerate(stress_frames(n_frames, seed=seed)):
-        d = np.asarray(d, dtype=np.float32).reshape(-1, 6)
-        cx, cy, w, h = (d[:, 0] + d[:, 2]) / 2, (d[:, 1] + d[:, 3]) / 2, d[:, 2] - d[:, 0], d[:, 3] - d[:, 1]
-        ang = 0.6 * np.sin(0.02 * t + 0.004 * cx + 0.006 * cy) + rng.normal(0, 0.01, len(d))
-        flip = rng.random(len(d)) < 0.15
-        w2, h2, a2 = np.where(flip, h, w), np.where(flip, w, h), np.where(flip, ang + np.pi / 2, ang)
-        yield np.stack([cx, cy, w2, h2, a2, d[:, 4], d[:, 5]], axis=1).astype(np.float32)
 
 
 def test_rotated_intersection_area_known_answers():
@@ -102,3 +88,44 @@ def test_bytetrack_obb_oracle_bit_exact_on_the_reference_class(kw):
     for a, b in zip(ref.active_tracks, orc.active):
         assert a.id == b.id and np.array_equal(a.mean, b.mean) and np.array_equal(a.covariance, b.cov)
     assert [t.id for t in ref.lost_stracks] == [t.id for t in orc.lost]
+
+
+@pytest.mark.skipif(not ref_harness.reference_available(), reason="/root/reference is not mounted")
+@pytest.mark.parametrize("kw", [dict(with_reid=False), dict(with_reid=True), dict(with_reid=True, track_buffer=4, fuse_first_associate=True)])
+def test_botsort_obb_oracle_bit_exact_on_the_reference_class(kw):
+    """The reference BotSort (use_cmc=False) fed 7-column detections -- with and without appearance embeddings -- against
+    BotSortObbOracle: 9-column rows and the fp64 filter state."""
+    from boxmot_amd.scenario import stress_frames
+    from oracle.botsort_obb import BotSortObbOracle
+    logging.disable(logging.CRITICAL)
+    BotSort = ref_harness.load_botsort()
+    ref, orc = BotSort(reid_model=None, use_cmc=False, **kw), BotSortObbOracle(**kw)
+    img = np.zeros((480, 640, 3), np.uint8)
+    embs = [e for _, e in stress_frames(90, seed=4)]
+    rows = 0
+    for t, d in enumerate(obb_frames(90, seed=4)):
+        e = embs[t].copy() if kw["with_reid"] else None
+        r = np.asarray(ref.update(d.copy(), img, None if e is None else e.copy()))
+        o = orc.update(d.copy(), img, e)
+        assert r.shape == o.shape and np.array_equal(r.reshape(-1, 9), o.reshape(-1, 9)), (kw, t)
+        rows += len(o)
+    assert ref.is_obb and rows > 300
+    for a, b in zip(ref.active_tracks, orc.active):
+        assert a.id == b.id and np.array_equal(a.mean, b.mean) and np.array_equal(a.covariance, b.cov)
+    assert [t.id for t in ref.lost_stracks] == [t.id for t in orc.lost]
+
+
+@pytest.mark.parametrize("key", ["bytetrack", "botsort_noreid", "botsort_reid"])
+def test_obb_oracles_match_reference_golden_rows(key):
+    """The OBB oracles against rows the reference classes produced (tests/golden/obb_golden.npz) -- runs without /root/reference."""
+    from boxmot_amd.scenario import stress_frames
+    from common import obb_golden_rows
+    from oracle.botsort_obb import BotSortObbOracle
+    from oracle.bytetrack_obb import ByteTrackObbOracle
+    want, frames, seed = obb_golden_rows(key)
+    orc = ByteTrackObbOracle() if key == "bytetrack" else BotSortObbOracle(with_reid=key == "botsort_reid")
+    embs = [e for _, e in stress_frames(frames, seed=seed)]
+    img = np.zeros((480, 640, 3), np.uint8)
+    for t, d in enumerate(obb_frames(frames, seed=seed)):
+        got = np.asarray(orc.update(d.copy(), img, embs[t].copy() if key == "botsort_reid" else None), dtype=np.float32).reshape(-1, 9)
+        assert got.shape == want[t].shape and np.array_equal(got, want[t]), (key, t)
