@@ -11,11 +11,13 @@
 
 namespace bm {
 
-struct BotSortSizes { int S, cap, nd, dim, n_lists, removed_alloc; };
+// is_obb: the tables of the oriented-box step (bm::obb): a 10-state filter (110 doubles per track), 5-float boxes
+struct BotSortSizes { int S, cap, nd, dim, n_lists, removed_alloc; int is_obb = 0; };
 
 template <class A>
 void botsort_allocate(BotSortStepArgs& args, const BotSortSizes& z, A& a) {
     const size_t S = z.S, cap = z.cap, nd = z.nd, dim = z.dim, nl = z.n_lists;
+    const size_t kf_stride = z.is_obb ? 110 : KF_STRIDE, box_w = z.is_obb ? 5 : 4;
     BotSortState& st = args.st;
     st.cap = z.cap; st.dim = z.dim; st.n_lists = z.n_lists; st.removed_alloc = z.removed_alloc;
     st.frame_count = a.template get<int>(S); st.id_count = a.template get<int>(S);
@@ -24,7 +26,7 @@ void botsort_allocate(BotSortStepArgs& args, const BotSortSizes& z, A& a) {
     st.stamp = a.template get<int>(S); st.status = a.template get<int>(S);
     st.active_list = a.template get<int>(S * nl * cap); st.lost_list = a.template get<int>(S * cap);
     st.removed_ring = a.template get<int>(S * z.removed_alloc);
-    st.kf = a.template get<double>(S * cap * KF_STRIDE);
+    st.kf = a.template get<double>(S * cap * kf_stride);
     st.smooth = a.template get<float>(S * cap * dim);
     st.id = a.template get<int>(S * cap); st.state = a.template get<int>(S * cap);
     st.is_activated = a.template get<int>(S * cap); st.frame_id = a.template get<int>(S * cap);
@@ -36,7 +38,7 @@ void botsort_allocate(BotSortStepArgs& args, const BotSortSizes& z, A& a) {
     st.hist_cls = a.template get<float>(S * cap * KCLS); st.hist_w = a.template get<float>(S * cap * KCLS);
     BotSortScratch& sc = args.sc;
     sc.max_dets = z.nd;
-    sc.det_xywh = a.template get<float>(S * nd * 4); sc.det_xyxy = a.template get<float>(S * nd * 4);
+    sc.det_xywh = a.template get<float>(S * nd * box_w); sc.det_xyxy = a.template get<float>(S * nd * 4);
     sc.det_area = a.template get<float>(S * nd); sc.det_feat = a.template get<float>(S * nd * dim);
     sc.det_norm = a.template get<double>(S * nd); sc.trk_norm = a.template get<double>(S * cap);
     sc.first_idx = a.template get<int>(S * nd); sc.second_idx = a.template get<int>(S * nd);
@@ -54,7 +56,7 @@ void botsort_allocate(BotSortStepArgs& args, const BotSortSizes& z, A& a) {
     sc.lap_u = a.template get<double>(S * nd); sc.lap_v = a.template get<double>(S * cap);
     sc.lap_minv = a.template get<double>(S * cap);
     sc.lap_way = a.template get<int>(S * cap); sc.lap_used = a.template get<int>(S * cap);
-    sc.box_a = a.template get<double>(S * cap * 4);
+    sc.box_a = a.template get<double>(S * cap * box_w);
     sc.pair_list = a.template get<int>(S * 4096);
 }
 

@@ -15,26 +15,29 @@ CFG_D = ("track_high_thresh", "track_low_thresh", "new_track_thresh", "match_thr
 CFG_I = ("fuse_first_associate", "with_reid", "frame_rate", "track_buffer", "removed_stracks_buffer", "kind")
 
 
-def build(sanitize: bool = False, dense: bool = False, threads: int = 64) -> Path:
+def build(sanitize: bool = False, dense: bool = False, threads: int = 64, obb: bool = False) -> Path:
     src = HERE / "emu_botsort.cpp"
     deps = [src, HERE / "hip_shim.hpp"] + list((HERE.parent.parent / "boxmot_amd" / "csrc").glob("botsort_*.hpp")) \
         + [HERE.parent.parent / "boxmot_amd" / "csrc" / "block_prims.hpp",
            HERE.parent.parent / "boxmot_amd" / "csrc" / "kernel_macros.hpp"]
     out = HERE / ("libemu_botsort_asan.so" if sanitize else ("libemu_botsort_dense.so" if dense else
                                                               ("libemu_botsort.so" if threads == 64 else f"libemu_botsort_t{threads}.so")))
+    if obb:         # the oriented-box copy of the step (bm::obb)
+        out = out.with_name(out.name.replace("libemu_botsort", "libemu_botsort_obb"))
     if not out.exists() or any(d.stat().st_mtime > out.stat().st_mtime for d in deps):
         flags = ["-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-pthread"]
         if sanitize:
             flags += ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"]
         if dense:
             flags += ["-DBM_SPARSE_MAX=0"]      # force the dense LDS-tiled cosine path
-        subprocess.check_call(["g++", *flags, f"-DEMU_NTHR={threads}", "-o", str(out), str(src)])
+        subprocess.check_call(["g++", *flags, f"-DEMU_NTHR={threads}", f"-DEMU_OBB={int(obb)}", "-o", str(out), str(src)])
     return out
 
 
 class EmuBotSort:
-    def __init__(self, cfg: dict, cap=256, nd=64, dim=32, sanitize=False, dense=False, threads=64):
-        self.lib = ctypes.CDLL(str(build(sanitize, dense, threads=threads)))
+    def __init__(self, cfg: dict, cap=256, nd=64, dim=32, sanitize=False, dense=False, threads=64, obb=False):
+        self.lib = ctypes.CDLL(str(build(sanitize, dense, threads=threads, obb=obb)))
+        self.det_cols, self.out_cols, self.kf_stride = (7, 9, 110) if obb else (6, 8, 72)
         self.lib.emu_create.restype = ctypes.c_void_p
         self.lib.emu_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         self.lib.emu_update.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
@@ -51,10 +54,10 @@ class EmuBotSort:
             w = np.ascontiguousarray(warp, dtype=np.float64).reshape(6)
             self.lib.emu_set_warp.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
             self.lib.emu_set_warp(self.h, w.ctypes.data)
-        dets = np.ascontiguousarray(dets, dtype=np.float32).reshape(-1, 6)
+        dets = np.ascontiguousarray(dets, dtype=np.float32).reshape(-1, self.det_cols)
         n = len(dets)
         e = None if embs is None else np.ascontiguousarray(embs, dtype=np.float32)
-        out = np.zeros((self.nd, 8), dtype=np.float32)
+        out = np.zeros((self.nd, self.out_cols), dtype=np.float32)
         out_n = ctypes.c_int(0)
         status = self.lib.emu_update(self.h, dets.ctypes.data, n, None if e is None else e.ctypes.data,
                                      out.ctypes.data, ctypes.byref(out_n))
@@ -64,7 +67,7 @@ class EmuBotSort:
 
     def dump(self, which):
         ints = np.zeros((self.cap, 6), dtype=np.int32)
-        kf = np.zeros((self.cap, 72), dtype=np.float64)
+        kf = np.zeros((self.cap, self.kf_stride), dtype=np.float64)
         sm = np.zeros((self.cap, self.dim), dtype=np.float32)
         misc = np.zeros((self.cap, 3), dtype=np.float32)
         cnt = np.zeros(3, dtype=np.int32)

@@ -15,6 +15,16 @@ EmuBlock* g_emu_block = nullptr;
 
 namespace {
 
+// -DEMU_OBB=1: the oriented-box copy of the step (bm::obb), 7-column detections, 9-column rows, 110-double filter records
+#ifndef EMU_OBB
+#define EMU_OBB 0
+#endif
+#if EMU_OBB
+namespace geo = bm::obb;
+#else
+namespace geo = bm;
+#endif
+
 #ifndef EMU_NTHR
 #define EMU_NTHR 64   // one emulated wavefront per workgroup keeps barrier cost low
 #endif
@@ -41,14 +51,14 @@ struct Emu {
 struct ThreadArg { Emu* e; int tid; };
 
 int* g_s_int; double* g_s_dbl; unsigned char* g_dyn;
-float (*g_sA)[bm::COST_KC + 1];
+float (*g_sA)[bm::COST_KC + 1];      // (COST_KC / COST_TILE / lap_lds_bytes are the same in both copies)
 float (*g_sB)[bm::COST_KC + 1];
 
 void* thread_main(void* p) {
     ThreadArg* ta = static_cast<ThreadArg*>(p);
     threadIdx.x = ta->tid;
     blockIdx.x = 0;
-    bm::botsort_step_stream<NTHR>(ta->e->args, 0, g_s_int, g_s_dbl, g_sA, g_sB, g_dyn);
+    geo::botsort_step_stream<NTHR>(ta->e->args, 0, g_s_int, g_s_dbl, g_sA, g_sB, g_dyn);
     return nullptr;
 }
 
@@ -61,12 +71,12 @@ void* emu_create(const double* cd, const int* ci, int cap, int nd, int dim) {
     e->cap = cap; e->nd = nd; e->dim = dim;
     e->args.cfg = bm::make_config_dev(cd[0], cd[1], cd[2], cd[3], cd[4], cd[5], cd[6], cd[7], cd[8], ci[0], ci[1], ci[2],
                                       ci[3], ci[4], ci[5]);
-    bm::BotSortSizes z{1, cap, nd, dim, 1, ci[4] > 0 ? ci[4] : 1};
+    bm::BotSortSizes z{1, cap, nd, dim, 1, ci[4] > 0 ? ci[4] : 1, EMU_OBB};
     bm::botsort_allocate(e->args, z, e->alloc);
-    e->dets = e->alloc.get<float>((size_t)nd * bm::DET_COLS);
+    e->dets = e->alloc.get<float>((size_t)nd * geo::DET_COLS);
     e->n_dets = e->alloc.get<int>(1);
     e->embs = e->alloc.get<float>((size_t)nd * dim);
-    e->out = e->alloc.get<float>((size_t)nd * bm::OUT_COLS);
+    e->out = e->alloc.get<float>((size_t)nd * geo::OUT_COLS);
     e->out_n = e->alloc.get<int>(1);
     e->args.dets = e->dets; e->args.n_dets = e->n_dets; e->args.embs = e->embs;
     e->args.list_sel = nullptr; e->args.frame_count_set = nullptr;
@@ -96,7 +106,7 @@ void emu_set_warp(void* h, const double* w) {
 int emu_update(void* h, const float* dets, int n, const float* embs, float* out, int* out_n) {
     Emu* e = static_cast<Emu*>(h);
     if (n > e->nd) return -1;
-    std::memcpy(e->dets, dets, (size_t)n * bm::DET_COLS * 4);
+    std::memcpy(e->dets, dets, (size_t)n * geo::DET_COLS * 4);
     if (embs) std::memcpy(e->embs, embs, (size_t)n * e->dim * 4);
     e->n_dets[0] = n;
     static int s_int[bm::MAX_WAVES + 1];
@@ -113,7 +123,7 @@ int emu_update(void* h, const float* dets, int n, const float* embs, float* out,
     emu_run_threads(NTHR, thread_main, ta.data(), sizeof(ta[0]), 1 << 20);
     e->warp_flag[0] = 0;
     *out_n = e->out_n[0];
-    std::memcpy(out, e->out, (size_t)e->out_n[0] * bm::OUT_COLS * 4);
+    std::memcpy(out, e->out, (size_t)e->out_n[0] * geo::OUT_COLS * 4);
     return e->args.st.status[0];
 }
 
@@ -128,7 +138,7 @@ int emu_dump(void* h, int which, int* ints, double* kf, float* smooth, float* mi
         int* o = ints + r * 6;
         o[0] = st.id[sl]; o[1] = st.state[sl]; o[2] = st.is_activated[sl]; o[3] = st.frame_id[sl];
         o[4] = st.start_frame[sl]; o[5] = st.tracklet_len[sl];
-        std::memcpy(kf + (size_t)r * bm::KF_STRIDE, st.kf + (size_t)sl * bm::KF_STRIDE, bm::KF_STRIDE * 8);
+        std::memcpy(kf + (size_t)r * geo::KF_STRIDE, st.kf + (size_t)sl * geo::KF_STRIDE, geo::KF_STRIDE * 8);
         std::memcpy(smooth + (size_t)r * e->dim, st.smooth + (size_t)sl * e->dim, e->dim * 4);
         misc[r * 3] = st.conf[sl]; misc[r * 3 + 1] = st.cls[sl]; misc[r * 3 + 2] = st.det_ind[sl];
     }
