@@ -48,6 +48,7 @@ class BotSortConfig(ctypes.Structure):
         ("emb_dim", ctypes.c_int),
         ("n_class_lists", ctypes.c_int),
         ("tracker_kind", ctypes.c_int),
+        ("is_obb", ctypes.c_int),
     ]
 
 

@@ -4,8 +4,10 @@ Same names, argument meaning and error behaviour as
 boxmot/trackers/basetracker.py:120-372 (input unwrapping :153-183, mask handling
 :185-211, empty input and per-class fan-out :213-271, ``check_inputs`` :356-372,
 class split :306-335); the per-frame math itself lives behind the C ABI
-(``_update_impl`` of the subclasses).  AABB detections only: OBB input raises the
-same ``AssertionError`` the reference raises for a tracker without OBB support.
+(``_update_impl`` of the subclasses).  The detection layout -- axis-aligned (6 columns) or
+oriented (7 columns) -- is inferred from the first detection table like the reference does
+(basetracker.py:163-173 over common/detection_layout.py:87-108); a tracker class without
+``supports_obb`` raises the reference's ``AssertionError`` for oriented input.
 """
 from __future__ import annotations
 
@@ -21,6 +23,7 @@ AABB_COLS = 6   # x1,y1,x2,y2,conf,cls     detection_layout.py:61-71
 OBB_COLS = 7    # cx,cy,w,h,angle,conf,cls  detection_layout.py:74-84
 CONF_IDX, CLS_IDX = 4, 5
 OUT_COLS = 8
+OBB_OUT_COLS = 9
 # the keys of AssociationFunction._get_asso_func's table (trackers/association/iou.py:408-417), in its order
 ASSO_NAMES = ("iou", "iou_obb", "hmiou", "giou", "ciou", "diou", "centroid", "centroid_obb")
 
@@ -32,7 +35,7 @@ class BaseTracker:
     def __init__(self, det_thresh: float = 0.3, max_age: int = 30, max_obs: int = 50, min_hits: int = 3,
                  iou_threshold: float = 0.3, per_class: bool = False, nr_classes: int = 80, asso_func: str = "iou",
                  is_obb: bool = False, **kwargs):
-        if is_obb:
+        if is_obb and not self.supports_obb:
             raise AssertionError(f"{type(self).__name__} does not support OBB detections.")
         self.det_thresh = det_thresh
         self.max_age = max_age
@@ -42,8 +45,8 @@ class BaseTracker:
         self.per_class = per_class
         self.nr_classes = nr_classes
         self._asso_func_base_name = asso_func      # resolved on the first frame, like the reference (basetracker.py:175-180)
-        self.asso_func_name = asso_func
-        self.is_obb = False
+        self.is_obb = bool(is_obb)
+        self.asso_func_name = f"{asso_func}_obb" if self.is_obb else asso_func     # detection_layout.py:25-26
         self.frame_count = 0
         self.last_emb_size = None
         self._first_frame_processed = False
@@ -71,14 +74,16 @@ class BaseTracker:
             dets = dets.data
         if isinstance(dets, memoryview):          # ... which lands here: a float32 copy (basetracker.py:155-161)
             dets = np.array(dets, dtype=np.float32)
-        if not self._first_dets_processed and isinstance(dets, np.ndarray) and dets.ndim == 2:
-            if dets.shape[1] == OBB_COLS:
+        if (not self._first_dets_processed and isinstance(dets, np.ndarray) and dets.ndim == 2
+                and dets.shape[1] in (AABB_COLS, OBB_COLS)):
+            oriented = dets.shape[1] == OBB_COLS
+            if oriented and not self.supports_obb:
                 raise AssertionError(
                     f"{type(self).__name__} does not support OBB detections. "
                     "Use an OBB-capable tracker such as ByteTrack, BotSort, OCSort, or SFSORT."
                 )
-            if dets.shape[1] == AABB_COLS:
-                self._first_dets_processed = True
+            self._set_detection_mode(oriented)
+            self._first_dets_processed = True
         if not self._first_frame_processed and img is not None:
             self.h, self.w = img.shape[0:2]
             if self.asso_func_name not in ASSO_NAMES:      # AssociationFunction._get_asso_func (iou.py:419-422)
@@ -94,11 +99,22 @@ class BaseTracker:
             self._masks_warning_issued = True
         return None
 
+    def _set_detection_mode(self, is_obb: bool) -> None:        # basetracker.py:337-348
+        self.is_obb = bool(is_obb)
+        self.asso_func_name = f"{self._asso_func_base_name}_obb" if self.is_obb else self._asso_func_base_name
+
+    # the layout's numbers (detection_layout.py:61-84)
+    det_cols = property(lambda self: OBB_COLS if self.is_obb else AABB_COLS)
+    box_cols = property(lambda self: 5 if self.is_obb else 4)
+    conf_idx = property(lambda self: 5 if self.is_obb else CONF_IDX)
+    cls_idx = property(lambda self: 6 if self.is_obb else CLS_IDX)
+    output_cols = property(lambda self: OBB_OUT_COLS if self.is_obb else OUT_COLS)
+
     def empty_detections(self, dtype=np.float32):
-        return np.empty((0, AABB_COLS), dtype=dtype)
+        return np.empty((0, self.det_cols), dtype=dtype)
 
     def empty_output(self, dtype=float):
-        return np.empty((0, OUT_COLS), dtype=dtype)
+        return np.empty((0, self.output_cols), dtype=dtype)
 
     def _do_update(self, dets, img, embs=None, masks=None):
         if dets is None or len(dets) == 0:
@@ -121,7 +137,7 @@ class BaseTracker:
         class_embs = np.empty((0, self.last_emb_size)) if self.last_emb_size is not None else None
         if dets.size == 0:
             return class_dets, class_embs
-        idx = np.where(dets[:, CLS_IDX] == cls_id)[0]
+        idx = np.where(dets[:, self.cls_idx] == cls_id)[0]
         class_dets = dets[idx]
         if embs is None:
             return class_dets, class_embs
@@ -140,8 +156,9 @@ class BaseTracker:
         assert len(dets.shape) == 2, "Unsupported 'dets' dimensions, valid number of dimensions is two"
         if embs is not None:
             assert dets.shape[0] == embs.shape[0], "Missmatch between detections and embeddings sizes"
-        assert dets.shape[1] == AABB_COLS, (
-            f"Unsupported 'dets' 2nd dimension length, valid length is {AABB_COLS} (x1,y1,x2,y2,conf,cls)"
+        assert dets.shape[1] == self.det_cols, (
+            f"Unsupported 'dets' 2nd dimension length, valid length is {self.det_cols} "
+            + ("(cx,cy,w,h,angle,conf,cls)" if self.is_obb else "(x1,y1,x2,y2,conf,cls)")
         )
 
     def _update_impl(self, dets, img, embs=None, masks=None, class_list: int = 0) -> np.ndarray:

@@ -11,7 +11,13 @@ Camera-motion compensation: applying a warp to the track state runs on the devic
 (STrack.multi_gmc), and so does *estimating* it from images for both estimators the reference configures BoT-SORT with:
 ``cmc_method="ecc"`` (the constructor default, boxmot_amd.cmc.HipECC) and ``"sof"`` (configs/trackers/botsort.yaml,
 boxmot_amd.cmc.HipSOF); ``cmc=`` accepts any object exposing the reference's ``apply(img, dets) -> 2x3 warp``.
-Not implemented, and rejected loudly rather than approximated: OBB detections, masks.
+
+Oriented detections (7 columns, botsort.py:120-131): the frame step has an oriented twin on the device (10-state filter,
+rotated-rectangle IoU; ``is_obb`` of the handle's configuration).  The layout is inferred from the first detection table like
+the reference does; embeddings of oriented detections come from the caller (``embs``) or from ``reid_model.get_features`` given
+the (cx, cy, w, h, angle) boxes, as the reference calls it.  Not implemented, and rejected loudly rather than approximated:
+camera-motion compensation of oriented boxes (``STrack.multi_gmc_obb`` goes through ``cv2.minAreaRect``; use ``use_cmc=False``),
+masks.
 """
 from __future__ import annotations
 
@@ -28,7 +34,7 @@ TRACK_STATE_NAMES = {0: "New", 1: "Tracked", 2: "Lost", 3: "LongLost", 4: "Remov
 
 
 class BotSort(BaseTracker):
-    supports_obb = False
+    supports_obb = True
 
     def __init__(
         self,
@@ -109,11 +115,34 @@ class BotSort(BaseTracker):
         cfg.emb_dim = self._emb_dim
         cfg.n_class_lists = self.nr_classes if self.per_class else 1
         cfg.tracker_kind = int(_tracker_kind)
+        cfg.is_obb = int(self.is_obb)
         self._cfg = cfg
-        self._handle = self._lib.boxmot_hip_botsort_create(ctypes.byref(cfg))
+        self._handle = None
+        self._max_tracks = max_tracks
+        self._check_obb_options()
+        self._create_handle()
+
+    def _create_handle(self) -> None:
+        self.close()
+        self._handle = self._lib.boxmot_hip_botsort_create(ctypes.byref(self._cfg))
         if not self._handle:
             raise RuntimeError(_lib.last_error())
-        self._max_tracks = max_tracks
+
+    def _check_obb_options(self) -> None:
+        if self.is_obb and self.cmc is not None:
+            raise NotImplementedError(
+                "camera-motion compensation of oriented boxes (STrack.multi_gmc_obb) is not implemented; construct the tracker "
+                "with use_cmc=False")
+
+    def _set_detection_mode(self, is_obb: bool) -> None:
+        """The first detection table decides the layout (basetracker.py:163-173).  The device tables are sized for one layout
+        (8- or 10-state filter, 6- or 7-column detections): a tracker that has not stepped yet gets a handle of the other kind."""
+        changed = bool(is_obb) != bool(self._cfg.is_obb)
+        super()._set_detection_mode(is_obb)
+        if changed:
+            self._check_obb_options()
+            self._cfg.is_obb = int(self.is_obb)
+            self._create_handle()
 
     # ------------------------------------------------------------------ update
     def _update_impl(self, dets, img, embs=None, masks=None, class_list: int = 0) -> np.ndarray:
@@ -126,17 +155,17 @@ class BotSort(BaseTracker):
                 feats = np.ascontiguousarray(embs, dtype=np.float32)
             else:
                 # same call the reference makes (botsort.py:191-192): boxes of the high-confidence rows
-                first = det_arr[:, 4].astype(np.float64) > self.track_high_thresh
+                first = det_arr[:, self.conf_idx].astype(np.float64) > self.track_high_thresh
                 feats = np.zeros((n, self._emb_dim), dtype=np.float32)
                 if first.any():
-                    feats[first] = self.model.get_features(det_arr[first, :4], img)
+                    feats[first] = self.model.get_features(det_arr[first, :self.box_cols], img)
             if n and feats.shape[1] != self._emb_dim:
                 raise ValueError(f"embedding width {feats.shape[1]} != emb_dim {self._emb_dim}")
         img_arr = np.ascontiguousarray(img)
         if self.cmc is not None:
             # botsort.py:142: the estimator sees the detection table incl. the index column; the warp is applied
             # on the device after the Kalman prediction (boxmot_hip_botsort_set_warp)
-            table = np.hstack([det_arr, np.arange(n, dtype=np.int32).reshape(-1, 1)]) if n else np.empty((0, 7), det_arr.dtype)
+            table = np.hstack([det_arr, np.arange(n, dtype=np.int32).reshape(-1, 1)]) if n else np.empty((0, self.det_cols + 1), det_arr.dtype)
             warp = np.ascontiguousarray(np.asarray(self.cmc.apply(img, table), dtype=np.float64)[:2, :3])
             if warp.shape != (2, 3):
                 raise ValueError(f"cmc.apply returned shape {warp.shape}, expected (2, 3)")
@@ -146,7 +175,7 @@ class BotSort(BaseTracker):
         out_is_obb = ctypes.c_int(0)
         ok = self._lib.boxmot_hip_botsort_update_stream(
             self._handle, 0, int(class_list), int(self.frame_count) if self.per_class else -1,
-            det_arr.ctypes.data if n else None, n, 6,
+            det_arr.ctypes.data if n else None, n, self.det_cols,
             feats.ctypes.data if (feats is not None and n) else None, n if feats is not None else 0,
             self._emb_dim if feats is not None else 0,
             img_arr.ctypes.data, int(img_arr.shape[0]), int(img_arr.shape[1]),
@@ -156,7 +185,7 @@ class BotSort(BaseTracker):
         if _lib.step_ran(ok):       # a per-stream status report (capacity, solver) is raised after the step has run
             self.frame_count += 1
         _lib.check(ok)
-        return out[: out_rows.value, :OUT_COLS].copy()
+        return out[: out_rows.value, :self.output_cols].copy()
 
     def reset(self) -> None:
         _lib.check(self._lib.boxmot_hip_botsort_reset(self._handle))
@@ -179,7 +208,7 @@ class BotSort(BaseTracker):
         """Copy the live tracks back from the device (parity tests / debugging)."""
         cap, dim = self.capacity()[0], self._emb_dim
         ints = np.zeros((cap, 6), dtype=np.int32)
-        kf = np.zeros((cap, 72), dtype=np.float64)
+        kf = np.zeros((cap, 110 if self.is_obb else 72), dtype=np.float64)     # mean + covariance: 8 + 64, or 10 + 100 oriented
         smooth = np.zeros((cap, dim), dtype=np.float32)
         misc = np.zeros((cap, 3), dtype=np.float32)
         rows, fc, ic = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
@@ -195,11 +224,13 @@ class BotSort(BaseTracker):
         out = []
         for r in range(d["n"]):
             i = d["ints"][r]
-            mean = d["kf"][r, :8].copy()
+            nm = 10 if self.is_obb else 8
+            mean = d["kf"][r, :nm].copy()
             xyxy = np.array([mean[0] - mean[2] / 2, mean[1] - mean[3] / 2, mean[0] + mean[2] / 2, mean[1] + mean[3] / 2])
             out.append(SimpleNamespace(
                 id=int(i[0]), state=int(i[1]), is_activated=bool(i[2]), frame_id=int(i[3]), start_frame=int(i[4]),
-                tracklet_len=int(i[5]), mean=mean, covariance=d["kf"][r, 8:].reshape(8, 8).copy(), xyxy=xyxy,
+                tracklet_len=int(i[5]), mean=mean, covariance=d["kf"][r, nm:].reshape(nm, nm).copy(), xyxy=xyxy,
+                xywha=mean[:5].astype(np.float32) if self.is_obb else None,
                 smooth_feat=d["smooth"][r].copy(), conf=float(d["misc"][r, 0]), cls=float(d["misc"][r, 1]),
                 det_ind=float(d["misc"][r, 2])))
         return out

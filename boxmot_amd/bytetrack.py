@@ -10,7 +10,8 @@ unbounded removed list.  Pinned against the reference class through ``oracle/byt
 
 Deviation: the id counter is per tracker (the reference's ``BaseTrack._count`` is process-global and is NOT rewound by the
 constructor, bytetrack/basetrack.py:16,37-40).  ``per_class=True`` runs on the kernel's per-class active lists (shared lost list,
-removed flags and id counter, basetracker.py:213-271).  Rejected loudly: OBB detections.
+removed flags and id counter, basetracker.py:213-271).  Oriented detections (7 columns, bytetrack.py:266, :286, :303) run on
+the oriented twin of the step (boxmot_amd.botsort).
 """
 from __future__ import annotations
 
@@ -20,7 +21,7 @@ from boxmot_amd.botsort import BotSort
 
 
 class ByteTrack(BotSort):
-    supports_obb = False
+    supports_obb = True
 
     def __init__(self, min_conf: float = 0.1, track_thresh: float = 0.45, match_thresh: float = 0.8, track_buffer: int = 25,
                  frame_rate: int = 30, max_tracks: int = 1024, max_dets: int = 256, **kwargs: Any):

@@ -248,7 +248,8 @@ BM_STEP_FN void kf_initiate_wave(double* kf, const float* z, int lane, bool xyah
 // ---------------------------------------------------------------------------
 // Kalman filter for ORIENTED boxes: KalmanFilterXYWH(ndim=5), state (cx, cy, w, h, theta) + velocities, one wavefront per track.
 // kf[0..9] = mean, kf[10..109] = the 10 x 10 covariance, row-major; lane l owns covariance elements l and l + 64.
-// Restated from oracle/obb.py (pinned bit for bit on the reference filter): xywh.py:16-206 over base.py:116-355.
+// Follows boxmot/motion/kalman_filters/xywh.py:16-206 over base.py:116-355 (the checker's restatement of the same lines is
+// pinned bit for bit on the reference filter, tests/).
 // ---------------------------------------------------------------------------
 constexpr double STD_POS = 1.0 / 20;
 constexpr double STD_VEL = 1.0 / 160;
@@ -600,10 +601,10 @@ __device__ inline void track_boxes(const Ctx& c, const SV& v, const int* rows, i
     __syncthreads();
 }
 
-// Rotated IoU of two (cx, cy, w, h, theta) boxes, restated from oracle/obb.py: the reference's enclosing-AABB pre-filter
+// Rotated IoU of two (cx, cy, w, h, theta) boxes (boxmot/trackers/association/iou.py:5-115): the reference's enclosing-AABB pre-filter
 // (iou.py:38-84: pairs whose AABBs do not overlap are 0), corners in fp32 like RotatedRect::points, then the intersection polygon by
 // clipping a's corners with b's four half-planes and the shoelace area, fp64 (the reference: cv2.rotatedRectangleIntersection +
-// contourArea -- parity unpinned for this one quantity, see oracle/obb.py).
+// contourArea; OpenCV is absent offline, so parity is unpinned for this one quantity -- DESIGN.md section 4.6c).
 __device__ inline void obb_corners(const double* r, double (&p)[4][2]) {
     const double deg = r[4] * (180.0 / OBB_PI);             // np.degrees
     const double a = deg * OBB_PI / 180.0;

@@ -53,6 +53,17 @@ __global__ void __launch_bounds__(NTHR) botsort_step_kernel(bm::BotSortStepArgs 
     bm::botsort_step_stream<NTHR>(args, args.stream_base + blockIdx.x, s_int, s_dbl, sA, sB, dyn_lds);
 }
 
+// the same frame step for oriented detections (botsort_step.hpp: namespace bm::obb)
+template <int NTHR>
+__global__ void __launch_bounds__(NTHR) botsort_obb_step_kernel(bm::BotSortStepArgs args) {
+    __shared__ int s_int[bm::MAX_WAVES + 1];
+    __shared__ double s_dbl[bm::MAX_WAVES];
+    __shared__ float sA[bm::COST_TILE][bm::COST_KC + 1];
+    __shared__ float sB[bm::COST_TILE][bm::COST_KC + 1];
+    BM_DYNAMIC_LDS_T(unsigned char, dyn_lds);
+    bm::obb::botsort_step_stream<NTHR>(args, args.stream_base + blockIdx.x, s_int, s_dbl, sA, sB, dyn_lds);
+}
+
 template <int NTHR>
 __global__ void __launch_bounds__(NTHR) deepocsort_step_kernel(bm::DocsStepArgs args) {
     __shared__ int s_int[bm::MAX_WAVES + 1];
@@ -253,6 +264,10 @@ struct BoxMOTHipBotSort {
     // reid
     std::unique_ptr<bm::ReidEngine> reid;
     int reid_mode = 0, reid_pad = 0;
+    bool is_obb = false;                         // oriented detections (7 columns in, 9 out, 10-state filter): config.is_obb
+    int det_cols() const { return is_obb ? bm::obb::DET_COLS : bm::DET_COLS; }
+    int out_cols() const { return is_obb ? bm::obb::OUT_COLS : bm::OUT_COLS; }
+    int kf_stride() const { return is_obb ? bm::obb::KF_STRIDE : bm::KF_STRIDE; }
     bool use_ecc = false;                        // cmc_method = "ecc": the estimator runs inside update on the uploaded frame
     std::unique_ptr<BoxMOTHipEcc> ecc;
     bool use_sof = false;                        // cmc_method = "sof" (configs/trackers/botsort.yaml): likewise, masked by the frame's detections
@@ -376,14 +391,14 @@ void alloc_det_io(BoxMOTHipBotSort* h) {
     auto& o = h->owned;
     release(o, h->d_dets); release(o, h->d_embs); release(o, h->d_out);
     release(o, h->d_crop_stream); release(o, h->d_crop_boxes); release(o, h->d_crop_row);
-    h->d_dets = zalloc<float>(S * nd * bm::DET_COLS, o);
+    h->d_dets = zalloc<float>(S * nd * h->det_cols(), o);
     h->d_embs = zalloc<float>(S * nd * dim, o);
-    h->d_out = zalloc<float>(S * nd * bm::OUT_COLS, o);
+    h->d_out = zalloc<float>(S * nd * h->out_cols(), o);
     h->d_crop_stream = zalloc<int>(S * nd, o);
     h->d_crop_boxes = zalloc<float>(S * nd * 4, o);
     h->d_crop_row = zalloc<int>(S * nd, o);
-    h->h_dets.assign(S * nd * bm::DET_COLS, 0.f);
-    h->h_out.assign(S * nd * bm::OUT_COLS, 0.f);
+    h->h_dets.assign(S * nd * h->det_cols(), 0.f);
+    h->h_out.assign(S * nd * h->out_cols(), 0.f);
 }
 
 // A ReID engine for S x nd crops from the handle's blob copy (read from reid_path the first time).  Returned, not installed: the
@@ -401,7 +416,8 @@ void make_reid_engine(BoxMOTHipBotSort* h) { h->reid = new_reid_engine(h, h->nd)
 
 void set_step_lds(BoxMOTHipBotSort* h) {
     const long lds = bm::lap_lds_bytes(h->cap, h->nd);
-    BM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(botsort_step_kernel<STEP_THREADS>),
+    BM_HIP(hipFuncSetAttribute(h->is_obb ? reinterpret_cast<const void*>(botsort_obb_step_kernel<STEP_THREADS>)
+                                         : reinterpret_cast<const void*>(botsort_step_kernel<STEP_THREADS>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 }
 
@@ -420,7 +436,7 @@ void grow_tables(BoxMOTHipBotSort* h, int new_cap, int new_nd) {
     bm::BotSortStepArgs na = h->args;
     std::vector<std::pair<void*, size_t>> rec;
     RecAlloc ra{&h->owned, &rec};
-    bm::BotSortSizes z{h->S, new_cap, new_nd, h->dim, h->n_lists, h->args.st.removed_alloc};
+    bm::BotSortSizes z{h->S, new_cap, new_nd, h->dim, h->n_lists, h->args.st.removed_alloc, h->is_obb ? 1 : 0};
     bm::botsort_allocate(na, z, ra);
     if (rec.size() != h->table_rec.size()) throw std::runtime_error("boxmot_hip: table layout changed between allocations");
     for (size_t i = 0; i < rec.size() && rec[i].first != (void*)na.sc.det_xywh; ++i) {          // the state tables come first
@@ -497,6 +513,16 @@ void build(BoxMOTHipBotSort* h) {
     if (c.tracker_kind == 1) {
         h->cfg.with_reid = 0; h->cfg.fuse_first_associate = 1;
     }
+    h->is_obb = c.is_obb != 0;
+    if (h->is_obb) {
+        // oriented detections (botsort.py:120-131, bytetrack.py:266-303).  The reference's camera-motion compensation of oriented
+        // tracks (STrack.multi_gmc_obb, botsort_track.py:197-230) refits each warped box with cv2.minAreaRect: not restated (no
+        // OpenCV offline to pin it on), so it is refused here rather than approximated.  Embeddings of oriented detections come
+        // from the caller (the reference crops rotated rectangles with cv2.warpAffine, reid/backends/base_backend.py:92-118).
+        if (h->use_ecc || h->use_sof) throw std::runtime_error("boxmot_hip: camera-motion compensation is not applied to oriented detections (cmc_method must be none)");
+        if (c.reid_model_path && c.reid_model_path[0])
+            throw std::runtime_error("boxmot_hip: an oriented-box handle takes embeddings from the caller (embs), not from in-handle ReID weights");
+    }
     h->S = c.n_streams; h->cap = c.max_tracks; h->nd = c.max_dets; h->dim = c.emb_dim; h->n_lists = c.n_class_lists;
     BM_HIP(hipStreamCreate(&h->stream));
     BM_HIP(hipEventCreate(&h->ev[0]));
@@ -510,7 +536,7 @@ void build(BoxMOTHipBotSort* h) {
                                       c.unconfirmed_match_thresh, c.unconfirmed_emb_scale, c.fuse_first_associate,
                                       c.tracker_kind == 1 ? 0 : c.with_reid, c.frame_rate, c.track_buffer, c.removed_stracks_buffer,
                                       c.tracker_kind);
-    bm::BotSortSizes z{h->S, h->cap, h->nd, h->dim, h->n_lists, c.removed_stracks_buffer > 0 ? c.removed_stracks_buffer : 1};
+    bm::BotSortSizes z{h->S, h->cap, h->nd, h->dim, h->n_lists, c.removed_stracks_buffer > 0 ? c.removed_stracks_buffer : 1, h->is_obb ? 1 : 0};
     RecAlloc table_allocator{&o, &h->table_rec};
     bm::botsort_allocate(h->args, z, table_allocator);
     // io
@@ -541,8 +567,12 @@ void launch_step(BoxMOTHipBotSort* h, int s0, int n_streams, const float* d_dets
     a.dets = d_dets; a.n_dets = d_ndets; a.embs = d_embs; a.list_sel = d_list_sel; a.frame_count_set = d_fc_set;
     a.warp = with_warp ? h->d_warp : nullptr; a.warp_flag = with_warp ? h->d_warp_flag : nullptr;
     a.out = d_out; a.out_n = d_out_n; a.stream_base = s0; a.phase_clock = h->d_phase_clock;
-    hipLaunchKernelGGL((botsort_step_kernel<STEP_THREADS>), dim3(n_streams), dim3(STEP_THREADS),
-                       (size_t)bm::lap_lds_bytes(h->cap, h->nd), h->stream, a);
+    if (h->is_obb)
+        hipLaunchKernelGGL((botsort_obb_step_kernel<STEP_THREADS>), dim3(n_streams), dim3(STEP_THREADS),
+                           (size_t)bm::lap_lds_bytes(h->cap, h->nd), h->stream, a);
+    else
+        hipLaunchKernelGGL((botsort_step_kernel<STEP_THREADS>), dim3(n_streams), dim3(STEP_THREADS),
+                           (size_t)bm::lap_lds_bytes(h->cap, h->nd), h->stream, a);
     BM_HIP(hipGetLastError());
 }
 
@@ -759,33 +789,39 @@ void host_update(BoxMOTHipBotSort* h, int s0, int n, const StreamIn* in, int det
         }
     }
     const int nd = h->nd, dim = h->dim;
+    const int DC = h->det_cols(), OC = h->out_cols();
     bool need_reid = false;
     for (int k = 0; k < n; ++k) {
         const int rows = in[k].det_rows;
         if (rows < -1) throw std::runtime_error("Negative matrix dimensions are not allowed.");
-        if (rows > 0 && det_cols == 7) throw std::runtime_error("boxmot_hip: OBB detections (7 columns) are not implemented");
-        if (rows > 0 && det_cols != 6) throw std::runtime_error("boxmot_hip live tracking supports AABB detections with 6 columns.");
+        if (rows > 0 && det_cols == 7 && !h->is_obb)
+            throw std::runtime_error("boxmot_hip: oriented detections (7 columns) need a handle created with is_obb = 1");
+        if (rows > 0 && det_cols == 6 && h->is_obb)
+            throw std::runtime_error("boxmot_hip: this handle was created for oriented detections (7 columns)");
+        if (rows > 0 && det_cols != DC) throw std::runtime_error("boxmot_hip live tracking supports AABB detections with 6 columns (7 with is_obb).");
         if (rows > 0 && in[k].dets == nullptr) throw std::runtime_error("Detection data pointer is null.");
         if (out_capacity_rows < rows) throw std::runtime_error("boxmot_hip: output buffer is too small for the current frame.");
         if (in[k].embs != nullptr && emb_cols != dim && rows > 0)
             throw std::runtime_error("boxmot_hip: embedding width does not match emb_dim");
         if (h->cfg.with_reid && in[k].embs == nullptr && rows > 0) need_reid = true;
     }
+    if (need_reid && h->is_obb)
+        throw std::runtime_error("boxmot_hip: an oriented-box handle with with_reid = 1 needs the embeddings of the frame's detections (embs)");
     if (need_reid)
         for (int k = 0; k < n; ++k)
             if (in[k].embs != nullptr && in[k].det_rows > 0)
                 throw std::runtime_error("boxmot_hip: either every stream of a batch supplies embeddings or none does");
     // one staging buffer for the whole group
-    float* hd = h->h_dets.data() + (size_t)s0 * nd * bm::DET_COLS;
+    float* hd = h->h_dets.data() + (size_t)s0 * nd * DC;
     for (int k = 0; k < n; ++k) {
         h->h_ndets[s0 + k] = in[k].det_rows;
         if (in[k].det_rows > 0)
-            std::memcpy(hd + (size_t)k * nd * bm::DET_COLS, in[k].dets, (size_t)in[k].det_rows * bm::DET_COLS * 4);
+            std::memcpy(hd + (size_t)k * nd * DC, in[k].dets, (size_t)in[k].det_rows * DC * 4);
         h->h_list_sel[s0 + k] = list_sel ? list_sel[k] : 0;
         h->h_fc_set[s0 + k] = fc_set ? fc_set[k] : 0;
     }
-    float* d_dets = h->d_dets + (size_t)s0 * nd * bm::DET_COLS;
-    BM_HIP(hipMemcpyAsync(d_dets, hd, (size_t)n * nd * bm::DET_COLS * 4, hipMemcpyHostToDevice, h->stream));
+    float* d_dets = h->d_dets + (size_t)s0 * nd * DC;
+    BM_HIP(hipMemcpyAsync(d_dets, hd, (size_t)n * nd * DC * 4, hipMemcpyHostToDevice, h->stream));
     BM_HIP(hipMemcpyAsync(h->d_ndets + s0, h->h_ndets.data() + s0, n * 4, hipMemcpyHostToDevice, h->stream));
     BM_HIP(hipMemcpyAsync(h->d_list_sel + s0, h->h_list_sel.data() + s0, n * 4, hipMemcpyHostToDevice, h->stream));
     if (fc_set) BM_HIP(hipMemcpyAsync(h->d_fc_set + s0, h->h_fc_set.data() + s0, n * 4, hipMemcpyHostToDevice, h->stream));
@@ -807,7 +843,7 @@ void host_update(BoxMOTHipBotSort* h, int s0, int n, const StreamIn* in, int det
         for (int k = 0; k < n; ++k) {
             if (in[k].det_rows < 0) continue;
             const uint8_t* const* fp = (d_frames_ext ? d_frames_ext : h->d_frames) + (s0 + k);
-            sof_run(h->sof.get(), s0 + k, 1, fp, d_dets + (size_t)k * nd * bm::DET_COLS, h->d_ndets + s0 + k, nd, bm::DET_COLS,
+            sof_run(h->sof.get(), s0 + k, 1, fp, d_dets + (size_t)k * nd * DC, h->d_ndets + s0 + k, nd, DC,
                     h->h_warp.data() + (size_t)(s0 + k) * 6, nullptr);
             h->h_warp_flag[s0 + k] = 1;
         }
@@ -862,7 +898,7 @@ void host_update(BoxMOTHipBotSort* h, int s0, int n, const StreamIn* in, int det
                 fc_set ? h->d_fc_set : nullptr, h->d_out, h->d_out_n, any_warp);
     BM_HIP(hipEventRecord(h->ev[1], h->stream));
     BM_HIP(hipMemcpyAsync(h->h_out_n.data(), h->d_out_n + s0, n * 4, hipMemcpyDeviceToHost, h->stream));
-    BM_HIP(hipMemcpyAsync(h->h_out.data(), h->d_out + (size_t)s0 * nd * bm::OUT_COLS, (size_t)n * nd * bm::OUT_COLS * 4,
+    BM_HIP(hipMemcpyAsync(h->h_out.data(), h->d_out + (size_t)s0 * nd * OC, (size_t)n * nd * OC * 4,
                           hipMemcpyDeviceToHost, h->stream));
     const int nl = h->n_lists;
     BM_HIP(hipMemcpyAsync(h->h_count_buf.data(), h->args.st.n_active + (size_t)s0 * nl, (size_t)n * nl * 4, hipMemcpyDeviceToHost, h->stream));
@@ -881,11 +917,11 @@ void host_update(BoxMOTHipBotSort* h, int s0, int n, const StreamIn* in, int det
     for (int k = 0; k < n; ++k) {
         const int rows = h->h_out_n[k];
         if (rows > out_capacity_rows) throw std::runtime_error("boxmot_hip: output buffer is too small for the current frame.");
-        const float* src = h->h_out.data() + (size_t)k * nd * bm::OUT_COLS;
+        const float* src = h->h_out.data() + (size_t)k * nd * OC;
         for (int r = 0; r < rows; ++r) {
             float* dst = out[k] + (size_t)r * 9;
-            for (int q = 0; q < 8; ++q) dst[q] = src[r * bm::OUT_COLS + q];
-            dst[8] = 0.0f;
+            for (int q = 0; q < OC; ++q) dst[q] = src[r * OC + q];
+            if (OC < 9) dst[8] = 0.0f;
         }
         out_rows[k] = rows;
     }
@@ -1472,7 +1508,7 @@ int boxmot_hip_botsort_update_stream(BoxMOTHipBotSort* handle, int stream, int c
         StreamIn in{dets, det_rows, (embs && emb_cols > 0) ? embs : nullptr, image};
         host_update_one(handle, stream, class_list, frame_count, in, det_cols, emb_cols, image_rows, image_cols,
                         image_channels, out_tracks, out_capacity_rows, out_rows);
-        *out_is_obb = 0;
+        *out_is_obb = handle->is_obb ? 1 : 0;
     });
 }
 
@@ -1516,6 +1552,7 @@ int boxmot_hip_botsort_step_device(BoxMOTHipBotSort* handle, const float* d_dets
         if (!d_dets || !d_det_rows || !d_out || !d_out_rows) throw std::runtime_error("boxmot_hip: null device pointers");
         const float* embs = d_embs;
         if (handle->cfg.with_reid && d_embs == nullptr) {
+            if (handle->is_obb) throw std::runtime_error("boxmot_hip: an oriented-box handle with with_reid = 1 needs d_embs");
             if (!d_frames) throw std::runtime_error("boxmot_hip: with_reid needs d_embs or d_frames");
             run_reid(handle, 0, handle->S, d_dets, d_det_rows, d_frames, image_rows, image_cols, handle->d_embs);
             embs = handle->d_embs;
@@ -1567,6 +1604,7 @@ int boxmot_hip_botsort_set_warp(BoxMOTHipBotSort* handle, int stream, const doub
         if (!handle) throw std::runtime_error("boxmot_hip BoT-SORT handle is null.");
         if (stream < 0 || stream >= handle->S) throw std::runtime_error("boxmot_hip: stream index out of range");
         if (warp_2x3 == nullptr) { handle->h_warp_flag[stream] = 0; return; }
+        if (handle->is_obb) throw std::runtime_error("boxmot_hip: camera-motion warps are not applied to oriented detections");
         for (int k = 0; k < 6; ++k) {
             if (!std::isfinite(warp_2x3[k])) throw std::runtime_error("boxmot_hip: camera-motion warp has non-finite entries");
             handle->h_warp[(size_t)stream * 6 + k] = warp_2x3[k];
@@ -1693,14 +1731,15 @@ int boxmot_hip_botsort_state_dump(BoxMOTHipBotSort* handle, int stream, int whic
         const auto id = pull_i(st.id), state = pull_i(st.state), act = pull_i(st.is_activated), fid = pull_i(st.frame_id),
                    sf = pull_i(st.start_frame), tl = pull_i(st.tracklet_len);
         const auto conf = pull_f(st.conf), cls = pull_f(st.cls), di = pull_f(st.det_ind);
-        std::vector<double> kfall(cap * bm::KF_STRIDE);
-        BM_HIP(hipMemcpy(kfall.data(), st.kf + s * cap * bm::KF_STRIDE, kfall.size() * 8, hipMemcpyDeviceToHost));
+        const size_t KS = handle->kf_stride();        // 72 doubles per track (mean 8 + cov 64), 110 for oriented boxes (10 + 100)
+        std::vector<double> kfall(cap * KS);
+        BM_HIP(hipMemcpy(kfall.data(), st.kf + s * cap * KS, kfall.size() * 8, hipMemcpyDeviceToHost));
         std::vector<float> sm;
         if (smooth) { sm.resize(cap * dim); BM_HIP(hipMemcpy(sm.data(), st.smooth + s * cap * dim, sm.size() * 4, hipMemcpyDeviceToHost)); }
         for (int r = 0; r < n; ++r) {
             const int sl = list[r];
             if (ints) { int* o = ints + r * 6; o[0] = id[sl]; o[1] = state[sl]; o[2] = act[sl]; o[3] = fid[sl]; o[4] = sf[sl]; o[5] = tl[sl]; }
-            if (kf) std::memcpy(kf + (size_t)r * bm::KF_STRIDE, kfall.data() + (size_t)sl * bm::KF_STRIDE, bm::KF_STRIDE * 8);
+            if (kf) std::memcpy(kf + (size_t)r * KS, kfall.data() + (size_t)sl * KS, KS * 8);
             if (smooth) std::memcpy(smooth + (size_t)r * dim, sm.data() + (size_t)sl * dim, dim * 4);
             if (misc) { misc[r * 3] = conf[sl]; misc[r * 3 + 1] = cls[sl]; misc[r * 3 + 2] = di[sl]; }
         }

@@ -1,7 +1,8 @@
 """Result view returned by ``update`` -- same contract as the reference's
 ``TrackResults`` (boxmot/trackers/track_results.py:12-31, column layout from
 boxmot/trackers/common/detection_layout.py:61-84): a float32 ndarray subclass of
-shape (M, 8) ``[x1, y1, x2, y2, id, conf, cls, det_ind]`` with named accessors.
+shape (M, 8) ``[x1, y1, x2, y2, id, conf, cls, det_ind]`` -- or (M, 9) ``[cx, cy, w, h, angle, id, conf, cls, det_ind]`` for
+oriented boxes -- with named accessors.
 """
 from __future__ import annotations
 
@@ -27,10 +28,12 @@ class TrackResults(np.ndarray):
     masks = property(lambda self: self._masks)
     is_obb = property(lambda self: bool(self.ndim == 2 and self.shape[1] >= 9))
     xyxy = property(lambda self: np.asarray(self[:, :4]))
-    id = property(lambda self: np.asarray(self[:, 4], dtype=int))
-    conf = property(lambda self: np.asarray(self[:, 5]))
-    cls = property(lambda self: np.asarray(self[:, 6], dtype=int))
-    det_ind = property(lambda self: np.asarray(self[:, 7], dtype=int))
+    xywha = property(lambda self: np.asarray(self[:, :5]))
+    _meta = property(lambda self: 5 if self.is_obb else 4)            # first column after the box
+    id = property(lambda self: np.asarray(self[:, self._meta], dtype=int))
+    conf = property(lambda self: np.asarray(self[:, self._meta + 1]))
+    cls = property(lambda self: np.asarray(self[:, self._meta + 2], dtype=int))
+    det_ind = property(lambda self: np.asarray(self[:, self._meta + 3], dtype=int))
 
     @property
     def xywh(self):
@@ -40,6 +43,12 @@ class TrackResults(np.ndarray):
         return np.stack([(b[:, 0] + b[:, 2]) / 2, (b[:, 1] + b[:, 3]) / 2, b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]], axis=1)
 
     def summary(self):
+        if self.is_obb:
+            return [
+                {"id": int(r[5]), "conf": float(r[6]), "cls": int(r[7]),
+                 "box": {"cx": float(r[0]), "cy": float(r[1]), "w": float(r[2]), "h": float(r[3]), "angle": float(r[4])}}
+                for r in np.asarray(self)
+            ]
         return [
             {"id": int(r[4]), "conf": float(r[5]), "cls": int(r[6]),
              "box": {"x1": float(r[0]), "y1": float(r[1]), "x2": float(r[2]), "y2": float(r[3])}}
@@ -48,6 +57,11 @@ class TrackResults(np.ndarray):
 
     def to_mot_lines(self, frame_id: int):
         """MOT-challenge rows ``frame,id,left,top,w,h,conf,cls,-1`` (track_results.py save_mot)."""
+        if self.is_obb:         # frame,id,cx,cy,w,h,angle,conf,cls,-1
+            return [
+                f"{frame_id},{int(r[5])},{r[0]:.2f},{r[1]:.2f},{r[2]:.2f},{r[3]:.2f},{r[4]:.4f},{r[6]:.6f},{int(r[7])},-1"
+                for r in np.asarray(self)
+            ]
         return [
             f"{frame_id},{int(r[4])},{r[0]:.2f},{r[1]:.2f},{r[2] - r[0]:.2f},{r[3] - r[1]:.2f},{r[5]:.6f},{int(r[6])},-1"
             for r in np.asarray(self)

@@ -63,6 +63,11 @@ typedef struct BoxMOTHipBotSortConfig {
     int emb_dim;                     /* appearance vector length (512 for OSNet) */
     int n_class_lists;               /* 1, or nr_classes when per_class=True */
     int tracker_kind;                /* 0 = BoT-SORT; 1 = ByteTrack (set by boxmot_hip_bytetrack_default_config) */
+    int is_obb;                      /* 0 = axis-aligned detections [x1 y1 x2 y2 conf cls] -> rows [x1 y1 x2 y2 id conf cls det_ind];
+                                      * 1 = oriented detections [cx cy w h angle conf cls] -> rows [cx cy w h angle id conf cls det_ind]
+                                      * (basetracker.py:179-201 decides this from the first frame's column count; botsort.py:120-131,
+                                      * bytetrack.py:283-291, KalmanFilterXYWH(ndim=5), iou_batch_obb): the 10-state filter and the
+                                      * rotated-rectangle IoU run in the frame step; cmc_method must be none, embeddings come as embs */
 } BoxMOTHipBotSortConfig;
 
 typedef struct BoxMOTHipBotSort BoxMOTHipBotSort;

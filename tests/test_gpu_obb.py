@@ -1,0 +1,126 @@
+"""GPU parity tests for ORIENTED detections through BoT-SORT and ByteTrack (the bm::obb copy of the frame step: 10-state filter,
+rotated-rectangle IoU; include/boxmot_hip.h `is_obb`), through the C ABI: against the reference's own rows
+(tests/golden/obb_golden.npz -- the real BotSort / ByteTrack classes fed 7-column detections) and against the oracles
+(oracle/botsort_obb.py, oracle/bytetrack_obb.py, pinned bit-exact on those classes by tests/test_oracle_obb.py) including the fp64
+filter state.  Rows: id / conf / cls / det_ind and the row order exact; the box (fp32 of the fp64 state) within 2e-4 px / rad."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from common import obb_frames, obb_golden_rows
+
+pytestmark = pytest.mark.gpu
+
+EMB = 32
+
+
+def _rows_match(got, want, t):
+    got, want = np.asarray(got, dtype=np.float32).reshape(-1, 9), np.asarray(want, dtype=np.float32).reshape(-1, 9)
+    assert got.shape == want.shape, (t, got.shape, want.shape)
+    assert np.array_equal(got[:, 5:], want[:, 5:]), t
+    assert np.allclose(got[:, :5], want[:, :5], rtol=0, atol=2e-4), (t, np.abs(got[:, :5] - want[:, :5]).max())
+
+
+def _check_state(trk, orc):
+    for which, recs in ((0, orc.active), (1, orc.lost)):
+        d = trk.state_dump(which)
+        assert list(d["ints"][:, 0]) == [r.id for r in recs]
+        if d["n"]:
+            assert d["kf"].shape[1] == 110
+            ref = np.concatenate([np.array([r.mean for r in recs]), np.array([r.cov for r in recs]).reshape(-1, 100)], 1)
+            assert np.allclose(d["kf"], ref, rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.parametrize("key", ["bytetrack", "botsort_noreid", "botsort_reid"])
+def test_oriented_detections_reproduce_the_reference_rows(key):
+    from boxmot_amd import BotSort, ByteTrack
+    from boxmot_amd.scenario import stress_frames
+    want, frames, seed = obb_golden_rows(key)
+    img = np.zeros((480, 640, 3), np.uint8)
+    if key == "bytetrack":
+        trk = ByteTrack(max_tracks=128, max_dets=64)
+    else:
+        trk = BotSort(reid_model=None, use_cmc=False, with_reid=key == "botsort_reid", max_tracks=128, max_dets=64, emb_dim=EMB)
+    embs = [e for _, e in stress_frames(frames, seed=seed)]
+    rows = 0
+    for t, d in enumerate(obb_frames(frames, seed=seed)):
+        got = trk.update(d, img, embs[t] if key == "botsort_reid" else None)
+        assert got.shape[1] == 9 and got.is_obb
+        _rows_match(got, want[t], t)
+        rows += len(got)
+    assert rows > 500 and trk.is_obb
+    trk.close()
+
+
+@pytest.mark.parametrize("kind,kw", [("botsort", dict(with_reid=True, track_buffer=4, fuse_first_associate=True)),
+                                     ("botsort", dict(with_reid=False, match_thresh=0.7)),
+                                     ("bytetrack", dict(track_buffer=4, track_thresh=0.6, match_thresh=0.7))])
+def test_oriented_step_matches_the_oracle_and_its_filter_state(kind, kw):
+    """Other seeds and option sets than the golden file's, 150 frames, small initial tables (they grow: 10-state rows carried over)."""
+    from boxmot_amd import BotSort, ByteTrack
+    from boxmot_amd.scenario import stress_frames
+    from oracle.botsort_obb import BotSortObbOracle
+    from oracle.bytetrack_obb import ByteTrackObbOracle
+    img = np.zeros((480, 640, 3), np.uint8)
+    for seed in (9, 13):
+        if kind == "bytetrack":
+            trk, orc = ByteTrack(max_tracks=16, max_dets=8, **kw), ByteTrackObbOracle(**kw)
+        else:
+            trk, orc = BotSort(reid_model=None, use_cmc=False, max_tracks=16, max_dets=8, emb_dim=EMB, **kw), BotSortObbOracle(**kw)
+        embs = [e for _, e in stress_frames(150, seed=seed)]
+        for t, d in enumerate(obb_frames(150, seed=seed)):
+            e = embs[t] if kw.get("with_reid") else None
+            _rows_match(trk.update(d, img, e), orc.update(d.copy(), None, None if e is None else e.copy()) if kind == "botsort"
+                        else orc.update(d.copy(), img), t)
+        _check_state(trk, orc)
+        assert trk.capacity()[2] >= 1
+        trk.close()
+
+
+def test_reference_unit_tests_for_oriented_boxes():
+    """tests/unit/test_trackers.py:297-311, :382-392"""
+    from boxmot_amd import BotSort, ByteTrack
+    rgb = np.random.default_rng(0).integers(0, 255, size=(640, 640, 3), dtype=np.uint8)
+    det = np.array([[320, 240, 80, 40, 0.15, 0.95, 0]], dtype=np.float32)
+    for tracker in (BotSort(reid_model=None, with_reid=False, use_cmc=False), ByteTrack()):
+        out1 = tracker.update(det, rgb)
+        out2 = tracker.update(det, rgb)
+        assert out1.shape == (1, 9) and out2.shape == (1, 9)
+        np.testing.assert_allclose(out2[0, :5], det[0, :5], atol=1e-2)
+        tracker.reset()                                       # after a reset the next table decides the layout again
+        assert tracker.update(np.array([[10, 10, 60, 90, 0.9, 0]], dtype=np.float32), rgb).shape == (1, 8)
+        tracker.close()
+
+
+def test_c_abi_guards_of_the_oriented_handle():
+    from boxmot_amd import _lib
+    lib = _lib.load()
+    cfg = _lib.BotSortConfig()
+    lib.boxmot_hip_botsort_default_config(ctypes.byref(cfg))
+    assert cfg.is_obb == 0
+    cfg.with_reid, cfg.max_tracks, cfg.max_dets, cfg.emb_dim, cfg.is_obb = 0, 64, 32, 1, 1
+    cfg.cmc_method = b"ecc"
+    assert not lib.boxmot_hip_botsort_create(ctypes.byref(cfg)) and "oriented" in _lib.last_error()
+    cfg.cmc_method = None
+    h = lib.boxmot_hip_botsort_create(ctypes.byref(cfg))
+    assert h
+    img = np.zeros((64, 64, 3), np.uint8)
+    out = np.zeros((4, 9), np.float32)
+    rows, obb = ctypes.c_int(0), ctypes.c_int(0)
+
+    def update(d):
+        d = np.ascontiguousarray(d, dtype=np.float32)
+        return lib.boxmot_hip_botsort_update(h, d.ctypes.data, len(d), d.shape[1], None, 0, 0, img.ctypes.data, 64, 64, 3, out.ctypes.data,
+                                             4, 9, ctypes.byref(rows), ctypes.byref(obb))
+    assert update(np.array([[32, 32, 20, 10, 0.15, 0.95, 0]])) == 1 and rows.value == 1 and obb.value == 1
+    assert np.allclose(out[0], [32, 32, 20, 10, 0.15, 1, 0.95, 0, 0], atol=1e-6)
+    assert update(np.array([[22, 27, 42, 37, 0.95, 0]])) == 0 and "oriented" in _lib.last_error()        # 6 columns on an oriented handle
+    warp = np.eye(2, 3)
+    assert lib.boxmot_hip_botsort_set_warp(h, 0, warp.ctypes.data) == 0 and "oriented" in _lib.last_error()
+    lib.boxmot_hip_botsort_destroy(h)
+    # and the other way round: 7 columns on an axis-aligned handle
+    cfg.is_obb = 0
+    h = lib.boxmot_hip_botsort_create(ctypes.byref(cfg))
+    assert update(np.array([[32, 32, 20, 10, 0.15, 0.95, 0]])) == 0 and "is_obb" in _lib.last_error()
+    lib.boxmot_hip_botsort_destroy(h)

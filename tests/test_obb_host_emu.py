@@ -1,0 +1,150 @@
+"""ORIENTED detections through the real host classes (boxmot_amd.BotSort / ByteTrack) on the build container's CPU: the classes' C-ABI
+calls are answered by the emulated device step (tests/emu_lib.py: the bm::obb copy of botsort_step_body.hpp on CPU fibers).  Checks the
+host side of the row -- layout inference from the first detection table, handle re-creation, 7 columns in / 9 out, the result view --
+against the reference's own rows (tests/golden/obb_golden.npz) and restates the reference's OBB unit tests
+(tests/unit/test_trackers.py:286-304, :382-392).  The GPU versions live in tests/test_gpu_obb.py."""
+import numpy as np
+import pytest
+
+from common import obb_frames, obb_golden_rows
+
+EMB = 32
+
+
+@pytest.fixture()
+def emulated_abi(monkeypatch):
+    from boxmot_amd import _lib
+    from emu_lib import EmuHipLib
+    lib = EmuHipLib()
+    monkeypatch.setattr(_lib, "load", lambda: lib)
+    monkeypatch.setattr(_lib, "last_error", lambda: lib.boxmot_hip_last_error().decode())
+    return lib
+
+
+def _rows_match(got, want, t):
+    got, want = np.asarray(got, dtype=np.float32).reshape(-1, 9), np.asarray(want, dtype=np.float32).reshape(-1, 9)
+    assert got.shape == want.shape, (t, got.shape, want.shape)
+    assert np.array_equal(got[:, 5:], want[:, 5:]), t                   # id, conf, cls, det_ind, row order: exact
+    assert np.allclose(got[:, :5], want[:, :5], rtol=0, atol=2e-4), (t, np.abs(got[:, :5] - want[:, :5]).max())
+
+
+@pytest.mark.parametrize("key", ["bytetrack", "botsort_noreid", "botsort_reid"])
+def test_host_classes_reproduce_the_reference_rows_on_oriented_detections(emulated_abi, key):
+    from boxmot_amd import BotSort, ByteTrack
+    from boxmot_amd.scenario import stress_frames
+    from boxmot_amd.track_results import TrackResults
+    want, frames, seed = obb_golden_rows(key)
+    img = np.zeros((480, 640, 3), np.uint8)
+    if key == "bytetrack":
+        trk = ByteTrack(max_tracks=128, max_dets=64)
+    else:
+        trk = BotSort(reid_model=None, use_cmc=False, with_reid=key == "botsort_reid", max_tracks=128, max_dets=64, emb_dim=EMB)
+    assert trk.supports_obb and not trk.is_obb
+    embs = [e for _, e in stress_frames(frames, seed=seed)]
+    for t, d in enumerate(obb_frames(frames, seed=seed)):
+        got = trk.update(d, img, embs[t] if key == "botsort_reid" else None)
+        assert isinstance(got, TrackResults) and got.shape[1] == 9 and got.is_obb
+        _rows_match(got, want[t], t)
+        if len(got):
+            assert np.array_equal(got.id, want[t][:, 5].astype(int)) and np.array_equal(got.det_ind, want[t][:, 8].astype(int))
+            assert got.xywha.shape == (len(got), 5)
+    assert trk.is_obb and trk.asso_func_name == "iou_obb"
+    views = trk.active_tracks
+    assert views and views[0].mean.shape == (10,) and views[0].covariance.shape == (10, 10) and views[0].xywha.shape == (5,)
+    trk.close()
+
+
+# ---- the reference's unit tests, restated ----
+def test_botsort_supports_obb_without_reid(emulated_abi):
+    """tests/unit/test_trackers.py:297-311 -- with use_cmc=False: camera-motion compensation of oriented tracks is not implemented
+    (next test)."""
+    from boxmot_amd import BotSort
+    tracker = BotSort(reid_model=None, with_reid=False, use_cmc=False, max_tracks=64, max_dets=32)
+    rgb = np.random.default_rng(0).integers(0, 255, size=(640, 640, 3), dtype=np.uint8)
+    det = np.array([[320, 240, 80, 40, 0.15, 0.95, 0]], dtype=np.float32)
+    out1 = tracker.update(det, rgb)
+    out2 = tracker.update(det, rgb)
+    assert out1.shape[1] == 9
+    assert out2.shape[1] == 9
+    np.testing.assert_allclose(out2[0, :5], det[0, :5], atol=1e-2)
+    tracker.close()
+
+
+def test_botsort_with_an_estimator_refuses_oriented_detections_loudly(emulated_abi):
+    from boxmot_amd import BotSort
+
+    class Est:
+        def apply(self, img, dets):
+            return np.eye(2, 3)
+    tracker = BotSort(reid_model=None, with_reid=False, cmc=Est(), max_tracks=64, max_dets=32)
+    rgb = np.zeros((64, 64, 3), np.uint8)
+    with pytest.raises(NotImplementedError, match="multi_gmc_obb"):
+        tracker.update(np.array([[32, 32, 20, 10, 0.15, 0.95, 0]], dtype=np.float32), rgb)
+    with pytest.raises(NotImplementedError, match="multi_gmc_obb"):
+        BotSort(reid_model=None, with_reid=False, cmc=Est(), is_obb=True)
+    tracker.close()
+
+
+def test_bytetrack_supports_obb_outputs(emulated_abi):
+    """tests/unit/test_trackers.py:382-392"""
+    from boxmot_amd import ByteTrack
+    tracker = ByteTrack(max_tracks=64, max_dets=32)
+    rgb = np.random.default_rng(0).integers(0, 255, size=(640, 640, 3), dtype=np.uint8)
+    det = np.array([[320, 240, 80, 40, 0.15, 0.95, 0]], dtype=np.float32)
+    out1 = tracker.update(det, rgb)
+    out2 = tracker.update(det, rgb)
+    assert out1.shape == (1, 9)
+    assert out2.shape == (1, 9)
+    np.testing.assert_allclose(out2[0, :5], det[0, :5], atol=1e-2)
+    tracker.close()
+
+
+def test_rotating_target_keeps_its_identity(emulated_abi):
+    """The scene of test_bytetrack_obb_state_history_follows_rotation_without_flips (tests/unit/test_trackers.py:406-420): a box turning
+    through almost a full revolution in steps of 0.32 rad stays one track at a fixed centre; the state (the measurement's closest
+    parameterisation, theta-velocity damped) is the oracle's, row for row."""
+    from boxmot_amd import ByteTrack
+    from oracle.bytetrack_obb import ByteTrackObbOracle
+    kw = dict(track_thresh=0.1, min_conf=0.01, match_thresh=0.99)
+    tracker, orc = ByteTrack(max_tracks=64, max_dets=32, **kw), ByteTrackObbOracle(**kw)
+    rgb = np.zeros((640, 640, 3), np.uint8)
+    ids = set()
+    for t, angle in enumerate(np.linspace(0.0, 6.1, 20, dtype=np.float32)):
+        det = np.array([[320, 240, 90, 40, angle, 0.95, 0]], dtype=np.float32)
+        out = tracker.update(det, rgb)
+        assert out.shape == (1, 9)
+        _rows_match(out, orc.update(det.copy(), rgb), t)
+        ids.add(int(out.id[0]))
+        assert abs(out[0, 0] - 320) < 1e-2 and abs(out[0, 1] - 240) < 1e-2
+    assert len(ids) == 1
+    tracker.close()
+
+
+def test_layout_is_decided_once_and_wrong_widths_are_refused(emulated_abi):
+    from boxmot_amd import BotSort, DeepOcSort
+    rgb = np.zeros((64, 64, 3), np.uint8)
+    tracker = BotSort(reid_model=None, with_reid=False, use_cmc=False, max_tracks=64, max_dets=32)
+    assert tracker.update(np.empty((0, 7), np.float32), rgb).shape == (0, 9)          # an empty oriented table decides the layout too
+    assert tracker.is_obb
+    with pytest.raises(AssertionError, match="valid length is 7"):
+        tracker.update(np.array([[10, 10, 30, 30, 0.9, 0]], dtype=np.float32), rgb)
+    tracker.reset()                                                                   # reset: the next table decides again
+    assert tracker.update(np.array([[10, 10, 30, 30, 0.9, 0]], dtype=np.float32), rgb).shape[1] == 8
+    assert not tracker.is_obb and tracker.asso_func_name == "iou"
+    tracker.close()
+    # a tracker class without an oriented step: the reference's message (basetracker.py:167-171)
+    trk = DeepOcSort.__new__(DeepOcSort)
+    from boxmot_amd.basetracker import BaseTracker
+    BaseTracker.__init__(trk, asso_func="iou")
+    with pytest.raises(AssertionError, match="DeepOcSort does not support OBB detections"):
+        trk.update(np.array([[32, 32, 20, 10, 0.15, 0.95, 0]], dtype=np.float32), rgb)
+
+
+def test_track_results_names_the_oriented_columns():
+    from boxmot_amd.track_results import TrackResults
+    r = TrackResults(np.array([[320, 240, 80, 40, 0.15, 7, 0.95, 2, 0]], dtype=np.float32))
+    assert r.is_obb and r.id.tolist() == [7] and r.cls.tolist() == [2] and r.det_ind.tolist() == [0] and np.isclose(r.conf[0], 0.95)
+    assert r.summary()[0]["box"] == {"cx": 320.0, "cy": 240.0, "w": 80.0, "h": 40.0, "angle": float(np.float32(0.15))}
+    assert r.to_mot_lines(3) == ["3,7,320.00,240.00,80.00,40.00,0.1500,0.950000,2,-1"]
+    a = TrackResults(np.array([[1, 2, 3, 4, 7, 0.5, 1, 0]], dtype=np.float32))
+    assert not a.is_obb and a.id.tolist() == [7]
