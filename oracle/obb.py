@@ -1,7 +1,6 @@
-"""Oriented-box (OBB) pieces of the tracker path -- TEST INFRASTRUCTURE ONLY, and so far ORACLE ONLY: the device frame steps take
-axis-aligned detections ("what comes next" item 0).  This file is the first step of that row in the order the
-work is meant to go (oracle, then kernel): the parts of the reference's OBB path that are plain arithmetic, restated and pinned on
-the reference classes, so that the kernel work starts from a checked comparator.
+"""Oriented-box (OBB) pieces of the tracker path -- TEST INFRASTRUCTURE ONLY: the checker of the oriented frame step
+(boxmot_amd/csrc/botsort_step_body.hpp compiled with BM_OBB).  The parts of the reference's OBB path that are
+plain arithmetic, restated and pinned on the reference classes.
 
 Follows:
   * KalmanFilterXYWH(ndim=5)       boxmot/motion/kalman_filters/xywh.py:16-206 over base.py:116-355 (initiate, multi_predict, update with

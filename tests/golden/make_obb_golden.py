@@ -1,11 +1,11 @@
-"""Golden rows of the REAL reference ByteTrack and BotSort classes fed ORIENTED detections (7 columns: cx, cy, w, h, angle, conf, cls),
+"""Golden rows of the REAL reference ByteTrack, BotSort and OcSort classes fed ORIENTED detections (7 columns: cx, cy, w, h, angle, conf, cls),
 on the seeded scenes of tests/common.py:obb_frames.  Build container only (/root/reference under the stand-ins of oracle/ref_harness.py;
 the rotated-intersection AREA behind cv2.rotatedRectangleIntersection / contourArea is oracle/obb.py's, see there):
 
     python tests/golden/make_obb_golden.py
 
--> tests/golden/obb_golden.npz.  No device step takes oriented detections yet: the fixture is there for the kernel work to start against
-("what comes next" item 0); tests/test_oracle_obb.py checks the oracles against it without /root/reference.
+-> tests/golden/obb_golden.npz.  tests/test_oracle_obb.py checks the oracles against it without /root/reference, tests/test_gpu_obb.py
+the oriented frame step on the device, tests/test_obb_host_emu.py the host classes over the emulated step.
 """
 from __future__ import annotations
 
@@ -24,7 +24,8 @@ from common import obb_frames  # noqa: E402
 from oracle import ref_harness  # noqa: E402
 
 FRAMES, SEED = 90, 4
-CASES = {"bytetrack": ("bytetrack", {}), "botsort_noreid": ("botsort", dict(with_reid=False)), "botsort_reid": ("botsort", dict(with_reid=True))}
+CASES = {"bytetrack": ("bytetrack", {}), "botsort_noreid": ("botsort", dict(with_reid=False)), "botsort_reid": ("botsort", dict(with_reid=True)),
+         "ocsort": ("ocsort", {}), "ocsort_byte": ("ocsort", dict(use_byte=True, max_age=8, min_hits=1))}
 
 
 def main():
@@ -33,7 +34,12 @@ def main():
     embs = [e for _, e in stress_frames(FRAMES, seed=SEED)]
     out = {}
     for key, (kind, kw) in CASES.items():
-        trk = ref_harness.load_bytetrack()(**kw) if kind == "bytetrack" else ref_harness.load_botsort()(reid_model=None, use_cmc=False, **kw)
+        if kind == "bytetrack":
+            trk = ref_harness.load_bytetrack()(**kw)
+        elif kind == "ocsort":
+            trk = ref_harness.load_ocsort()(**kw)
+        else:
+            trk = ref_harness.load_botsort()(reid_model=None, use_cmc=False, **kw)
         rows, counts = [], []
         for t, d in enumerate(obb_frames(FRAMES, seed=SEED)):
             e = embs[t].copy() if kw.get("with_reid") else None

@@ -1,5 +1,6 @@
-"""Oriented-box oracle (oracle/obb.py, oracle/bytetrack_obb.py) -- groundwork for the OBB row of the plugin surface; no device step
-takes 7-column detections yet.  The reference-class comparisons need /root/reference (build container only)."""
+"""Oriented-box oracles (oracle/obb.py, oracle/bytetrack_obb.py, oracle/botsort_obb.py, oracle/ocsort_obb.py): pinned on the reference
+classes fed 7-column detections and on the rows those classes produced (tests/golden/obb_golden.npz).  The reference-class comparisons
+need /root/reference (build container only)."""
 import logging
 
 import numpy as np
@@ -128,4 +129,43 @@ def test_obb_oracles_match_reference_golden_rows(key):
     img = np.zeros((480, 640, 3), np.uint8)
     for t, d in enumerate(obb_frames(frames, seed=seed)):
         got = np.asarray(orc.update(d.copy(), img, embs[t].copy() if key == "botsort_reid" else None), dtype=np.float32).reshape(-1, 9)
+        assert got.shape == want[t].shape and np.array_equal(got, want[t]), (key, t)
+
+
+OCSORT_CASES = [{}, dict(use_byte=True), dict(max_age=5, min_hits=1, delta_t=2, inertia=0.4, iou_threshold=0.2),
+                dict(use_byte=True, max_age=8, min_hits=1)]
+
+
+@pytest.mark.skipif(not ref_harness.reference_available(), reason="/root/reference is not mounted")
+@pytest.mark.parametrize("kw", OCSORT_CASES)
+def test_ocsort_obb_oracle_bit_exact_on_the_reference_class(kw):
+    """The reference OcSort fed 7-column detections (KalmanFilterXYSR(dim_x=9, dim_z=5), rotated IoU, observation-centric re-update with
+    the interpolated angle) against OcSortObbOracle: 9-column rows and the fp64 filter state of every track, every frame."""
+    from oracle.ocsort_obb import OcSortObbOracle
+    logging.disable(logging.CRITICAL)
+    ref, orc = ref_harness.load_ocsort()(**kw), OcSortObbOracle(**kw)
+    img = np.zeros((480, 640, 3), np.uint8)
+    rows, thawed = 0, 0
+    for t, d in enumerate(obb_frames(120, seed=4)):
+        frozen = {k.id for k in orc.tracks if not k.kf.observed and k.kf.saved is not None}
+        r = np.asarray(ref.update(d.copy(), img))
+        o = orc.update(d.copy(), img)
+        assert np.array_equal(r.reshape(-1, 9).astype(np.float32), o.reshape(-1, 9)), (kw, t)
+        rows += len(o)
+        thawed += sum(1 for k in orc.tracks if k.id in frozen and k.kf.observed)
+        assert len(ref.active_tracks) == len(orc.tracks)
+        for a, b in zip(ref.active_tracks, orc.tracks):
+            assert a.id == b.id and np.array_equal(a.kf.x, b.kf.x) and np.array_equal(a.kf.P, b.kf.P), (kw, t)
+    assert ref.is_obb and rows > 200 and thawed > 5              # the re-update after a gap (unfreeze) is exercised
+
+
+@pytest.mark.parametrize("key", ["ocsort", "ocsort_byte"])
+def test_ocsort_obb_oracle_matches_reference_golden_rows(key):
+    from common import obb_golden_rows
+    from oracle.ocsort_obb import OcSortObbOracle
+    want, frames, seed = obb_golden_rows(key)
+    orc = OcSortObbOracle(**({} if key == "ocsort" else dict(use_byte=True, max_age=8, min_hits=1)))
+    img = np.zeros((480, 640, 3), np.uint8)
+    for t, d in enumerate(obb_frames(frames, seed=seed)):
+        got = np.asarray(orc.update(d.copy(), img), dtype=np.float32).reshape(-1, 9)
         assert got.shape == want[t].shape and np.array_equal(got, want[t]), (key, t)
