@@ -81,6 +81,7 @@ class DeepOcSortConfig(ctypes.Structure):
         ("asso_func", ctypes.c_int),
         ("frame_w", ctypes.c_int),
         ("frame_h", ctypes.c_int),
+        ("is_obb", ctypes.c_int),
     ]
 
 

@@ -22,6 +22,7 @@
 #include "block_prims.hpp"
 #include "botsort_types.hpp"
 #include "kernel_macros.hpp"
+#include "obb_geometry.hpp"
 
 // phase functions of the frame step: inlined by default.  -DBM_STEP_NOINLINE=1 compiles the three large ones that are instantiated
 // several times (cost build, IoU cost, assignment) as calls -- one copy of each, bounded live ranges; =2 the small per-track ones too

@@ -72,6 +72,15 @@ __global__ void __launch_bounds__(NTHR) deepocsort_step_kernel(bm::DocsStepArgs 
     bm::docs_step_stream<NTHR>(args, args.stream_base + blockIdx.x, s_int, s_dbl, dyn_lds);
 }
 
+// the same frame step for oriented detections: OC-SORT with is_obb (deepocsort_step.hpp: namespace bm::obb)
+template <int NTHR>
+__global__ void __launch_bounds__(NTHR) deepocsort_obb_step_kernel(bm::DocsStepArgs args) {
+    __shared__ int s_int[bm::MAX_WAVES + 1];
+    __shared__ double s_dbl[bm::MAX_WAVES];
+    BM_DYNAMIC_LDS_T(unsigned char, dyn_lds);
+    bm::obb::docs_step_stream<NTHR>(args, args.stream_base + blockIdx.x, s_int, s_dbl, dyn_lds);
+}
+
 template <int NTHR>
 __global__ void __launch_bounds__(NTHR) strongsort_detnorm_kernel(bm::SsStepArgs args) {
     bm::ss_det_norm_block<NTHR>(args, args.stream_base + blockIdx.x, blockIdx.y, gridDim.y);
@@ -304,6 +313,7 @@ struct StreamIo {
     std::vector<void*> owned;
     hipStream_t stream = nullptr;
     int S = 1, cap = 0, nd = 0, dim = 0;
+    int det_cols = bm::DET_COLS, out_cols = bm::OUT_COLS;      // 7 / 9 on an oriented handle (OC-SORT with is_obb)
     float* d_dets = nullptr; int* d_ndets = nullptr; float* d_embs = nullptr; float* d_out = nullptr; int* d_out_n = nullptr;
     double* d_warp = nullptr; int* d_warp_flag = nullptr;
     std::vector<float> h_dets, h_out;
@@ -343,6 +353,7 @@ struct StreamIo {
 struct BoxMOTHipDeepOcSort : StreamIo {
     BoxMOTHipDeepOcSortConfig cfg{};
     bm::DocsStepArgs args{};
+    bool is_obb = false;            // oriented detections: config.is_obb (7 columns in, 9 out, 9-state filter)
 };
 
 struct BoxMOTHipStrongSort : StreamIo {
@@ -961,14 +972,14 @@ void io_alloc_sized(StreamIo* h) {
     const size_t s = h->S, c = h->cap, n = h->nd, d = h->dim;
     release(o, h->d_dets); release(o, h->d_embs); release(o, h->d_out);
     release(o, h->d_crop_stream); release(o, h->d_crop_boxes); release(o, h->d_crop_row);
-    h->d_dets = zalloc<float>(s * n * bm::DET_COLS, o);
+    h->d_dets = zalloc<float>(s * n * h->det_cols, o);
     h->d_embs = zalloc<float>(s * n * d, o);
-    h->d_out = zalloc<float>(s * c * bm::OUT_COLS, o);
+    h->d_out = zalloc<float>(s * c * h->out_cols, o);
     h->d_crop_stream = zalloc<int>(s * n, o);
     h->d_crop_boxes = zalloc<float>(s * n * 4, o);
     h->d_crop_row = zalloc<int>(s * n, o);
-    h->h_dets.assign(s * n * bm::DET_COLS, 0.f);
-    h->h_out.assign(c * bm::OUT_COLS, 0.f);
+    h->h_dets.assign(s * n * h->det_cols, 0.f);
+    h->h_out.assign(c * h->out_cols, 0.f);
 }
 
 void io_allocate(StreamIo* h, int S, int cap, int nd, int dim, bool with_reid) {
@@ -1066,12 +1077,16 @@ void io_clear_warps(StreamIo* h) { for (int s = 0; s < h->S; ++s) { h->h_warp_fl
 bool io_stage(StreamIo* h, int n, const StreamIn* in, int det_cols, int emb_cols, bool want_emb, int image_rows, int image_cols,
               int image_channels, int out_capacity_rows, double reid_thresh, int inclusive, int s0 = 0) {
     const int nd = h->nd, dim = h->dim;
+    const size_t DC = h->det_cols;
     if (s0 < 0 || n < 1 || s0 + n > h->S) throw std::runtime_error("boxmot_hip: stream index out of range");
     bool need_reid = false;
     for (int k = 0; k < n; ++k) {
         const int rows = in[k].det_rows;
         if (rows < -1) throw std::runtime_error("Negative matrix dimensions are not allowed.");
-        if (rows > 0 && det_cols != 6) throw std::runtime_error("boxmot_hip live tracking supports AABB detections with 6 columns.");
+        if (rows > 0 && det_cols != h->det_cols)
+            throw std::runtime_error(h->det_cols == 7 ? "boxmot_hip: this handle was created for oriented detections (7 columns)"
+                                     : det_cols == 7 ? "boxmot_hip: oriented detections (7 columns) need a handle created with is_obb = 1 (BoT-SORT, ByteTrack, OC-SORT)"
+                                                     : "boxmot_hip live tracking supports AABB detections with 6 columns.");
         if (rows > nd) throw std::runtime_error("boxmot_hip: internal: detection tables were not grown before staging");
         if (rows > 0 && in[k].dets == nullptr) throw std::runtime_error("Detection data pointer is null.");
         if (out_capacity_rows < rows) throw std::runtime_error("boxmot_hip: output buffer is too small for the current frame.");
@@ -1088,12 +1103,12 @@ bool io_stage(StreamIo* h, int n, const StreamIn* in, int det_cols, int emb_cols
         const size_t sk = (size_t)(s0 + k);
         h->h_ndets[sk] = in[k].det_rows;
         if (in[k].det_rows > 0)
-            std::memcpy(h->h_dets.data() + sk * nd * bm::DET_COLS, in[k].dets, (size_t)in[k].det_rows * bm::DET_COLS * 4);
+            std::memcpy(h->h_dets.data() + sk * nd * DC, in[k].dets, (size_t)in[k].det_rows * DC * 4);
         if (h->h_warp_flag[sk]) any_warp = true;
         else { double* w = h->h_warp.data() + sk * 6; w[0] = 1; w[1] = 0; w[2] = 0; w[3] = 0; w[4] = 1; w[5] = 0; }
     }
     const size_t o = (size_t)s0;
-    BM_HIP(hipMemcpyAsync(h->d_dets + o * nd * bm::DET_COLS, h->h_dets.data() + o * nd * bm::DET_COLS, (size_t)n * nd * bm::DET_COLS * 4,
+    BM_HIP(hipMemcpyAsync(h->d_dets + o * nd * DC, h->h_dets.data() + o * nd * DC, (size_t)n * nd * DC * 4,
                           hipMemcpyHostToDevice, h->stream));
     BM_HIP(hipMemcpyAsync(h->d_ndets + o, h->h_ndets.data() + o, n * 4, hipMemcpyHostToDevice, h->stream));
     BM_HIP(hipMemcpyAsync(h->d_warp + o * 6, h->h_warp.data() + o * 6, (size_t)n * 6 * 8, hipMemcpyHostToDevice, h->stream));
@@ -1192,11 +1207,12 @@ void io_read_back(StreamIo* h, int n, const int* d_status, const char* tracker, 
     for (int k = 0; k < n; ++k) {
         const int rows = h->h_out_n[k];
         if (rows > out_capacity_rows) throw std::runtime_error("boxmot_hip: output buffer is too small for the current frame.");
-        if (rows) BM_HIP(hipMemcpy(h->h_out.data(), h->d_out + (size_t)(s0 + k) * h->cap * bm::OUT_COLS, (size_t)rows * bm::OUT_COLS * 4, hipMemcpyDeviceToHost));
+        const size_t OC = h->out_cols;
+        if (rows) BM_HIP(hipMemcpy(h->h_out.data(), h->d_out + (size_t)(s0 + k) * h->cap * OC, (size_t)rows * OC * 4, hipMemcpyDeviceToHost));
         for (int r = 0; r < rows; ++r) {
             float* dst = out[k] + (size_t)r * 9;
-            for (int q = 0; q < 8; ++q) dst[q] = h->h_out[(size_t)r * bm::OUT_COLS + q];
-            dst[8] = 0.0f;
+            for (size_t q = 0; q < OC; ++q) dst[q] = h->h_out[(size_t)r * OC + q];
+            if (OC < 9) dst[8] = 0.0f;
         }
         out_rows[k] = rows;
     }
@@ -1206,6 +1222,19 @@ void io_read_back(StreamIo* h, int n, const int* d_status, const char* tracker, 
 // ---------------------------------------------------------------------------
 // DeepOCSORT host path
 // ---------------------------------------------------------------------------
+const void* docs_kernel(const BoxMOTHipDeepOcSort* h) {
+    return h->is_obb ? reinterpret_cast<const void*>(deepocsort_obb_step_kernel<STEP_THREADS>)
+                     : reinterpret_cast<const void*>(deepocsort_step_kernel<STEP_THREADS>);
+}
+void docs_set_lds(BoxMOTHipDeepOcSort* h, long lds) {
+    BM_HIP(hipFuncSetAttribute(docs_kernel(h), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+}
+void docs_launch(BoxMOTHipDeepOcSort* h, int n_streams, const bm::DocsStepArgs& a) {
+    const size_t lds = (size_t)bm::docs_lap_lds_bytes(h->cap, h->nd);
+    if (h->is_obb) hipLaunchKernelGGL((deepocsort_obb_step_kernel<STEP_THREADS>), dim3(n_streams), dim3(STEP_THREADS), lds, h->stream, a);
+    else hipLaunchKernelGGL((deepocsort_step_kernel<STEP_THREADS>), dim3(n_streams), dim3(STEP_THREADS), lds, h->stream, a);
+}
+
 void docs_zero_state(BoxMOTHipDeepOcSort* h) {
     bm::DocsState& st = h->args.st;
     const size_t S = h->S, cap = h->cap;
@@ -1238,6 +1267,14 @@ void docs_build(BoxMOTHipDeepOcSort* h) {
         throw std::runtime_error("boxmot_hip: DeepOCSORT max_age must be in [0, 45] (the reference's 50-entry observation history, xysr.py:18)");
     if (c.delta_t < 1 || c.delta_t > 3) throw std::runtime_error("boxmot_hip: DeepOCSORT delta_t must be 1..3");
     if (!(c.aw_param < 1.0)) throw std::runtime_error("boxmot_hip: aw_param must be < 1");
+    h->is_obb = c.is_obb != 0;
+    if (h->is_obb) {
+        // oriented detections: OC-SORT (ocsort.py:332 supports_obb; DeepOcSort does not): no appearance, no camera motion, and the
+        // association function is the rotated IoU (detection_layout.py:25-26 turns "iou" into "iou_obb")
+        if (!c.embedding_off) throw std::runtime_error("boxmot_hip: oriented detections run on OC-SORT (embedding_off = 1); DeepOCSORT takes axis-aligned boxes only");
+        if (c.asso_func != BOXMOT_HIP_ASSO_IOU) throw std::runtime_error("boxmot_hip: the oriented step has the rotated IoU only (asso_func must be BOXMOT_HIP_ASSO_IOU)");
+        h->det_cols = bm::obb::DOCS_DET_COLS; h->out_cols = bm::obb::DOCS_OUT_COLS;
+    }
     io_allocate(h, c.n_streams, c.max_tracks, c.max_dets, c.embedding_off ? 1 : c.emb_dim, !c.embedding_off);
     bm::DocsConfigDev& d = h->args.cfg;
     d.det_thresh = c.det_thresh; d.det_thresh_f32 = (float)c.det_thresh; d.max_age = c.max_age; d.min_hits = c.min_hits;
@@ -1251,12 +1288,11 @@ void docs_build(BoxMOTHipDeepOcSort* h) {
     d.asso_mode = c.asso_func;
     docs_set_frame_size(h, c.frame_w, c.frame_h);
     RecAlloc table_allocator{&h->owned, &h->table_rec};
-    bm::DocsSizes z{h->S, h->cap, h->nd, h->dim};
+    bm::DocsSizes z{h->S, h->cap, h->nd, h->dim, h->is_obb ? 1 : 0};
     bm::docs_allocate(h->args, z, table_allocator);
     const long lds = bm::docs_lap_lds_bytes(h->cap, h->nd);
     if (lds > 120 * 1024) throw std::runtime_error("boxmot_hip: max_tracks/max_dets too large for the assignment solver's LDS state");
-    BM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deepocsort_step_kernel<STEP_THREADS>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    docs_set_lds(h, lds);
 }
 
 void docs_grow(BoxMOTHipDeepOcSort* h, int new_cap, int new_nd) {
@@ -1270,15 +1306,14 @@ void docs_grow(BoxMOTHipDeepOcSort* h, int new_cap, int new_nd) {
     bm::DocsStepArgs na = h->args;
     std::vector<std::pair<void*, size_t>> rec;
     RecAlloc ra{&h->owned, &rec};
-    bm::docs_allocate(na, bm::DocsSizes{h->S, new_cap, new_nd, h->dim}, ra);
+    bm::docs_allocate(na, bm::DocsSizes{h->S, new_cap, new_nd, h->dim, h->is_obb ? 1 : 0}, ra);
     io_migrate(h, rec, na.sc.keep);
     h->args = na;
     const bool more_dets = new_nd != h->nd;
     h->cap = new_cap; h->nd = new_nd;
     io_alloc_sized(h);
     if (new_reid) h->reid = std::move(new_reid);
-    BM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deepocsort_step_kernel<STEP_THREADS>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    docs_set_lds(h, lds);
 }
 
 // Stage the inputs of the first n streams (ReID on every detection above det_thresh when embeddings are not supplied,
@@ -1299,8 +1334,7 @@ void docs_host_update(BoxMOTHipDeepOcSort* h, int n, const StreamIn* in, int det
     a.dets = h->d_dets; a.n_dets = h->d_ndets; a.embs = want_emb ? h->d_embs : nullptr;
     a.warp = any_warp ? h->d_warp : nullptr; a.warp_flag = any_warp ? h->d_warp_flag : nullptr;
     a.out = h->d_out; a.out_n = h->d_out_n; a.stream_base = s0;
-    hipLaunchKernelGGL((deepocsort_step_kernel<STEP_THREADS>), dim3(n), dim3(STEP_THREADS),
-                       (size_t)bm::docs_lap_lds_bytes(h->cap, h->nd), h->stream, a);
+    docs_launch(h, n, a);
     io_read_back(h, n, h->args.st.status, "DeepOCSORT", out, out_capacity_rows, out_rows, s0, h->args.st.n_tracks);
     if (id_count_inout) BM_HIP(hipMemcpy(id_count_inout, h->args.st.id_count + s0, 4, hipMemcpyDeviceToHost));
 }
@@ -2186,6 +2220,7 @@ int boxmot_hip_deepocsort_capacity(BoxMOTHipDeepOcSort* handle, int* max_tracks,
 int boxmot_hip_deepocsort_set_warp(BoxMOTHipDeepOcSort* handle, int stream, const double* warp_2x3) {
     return guard([&]() {
         if (!handle) throw std::runtime_error("boxmot_hip DeepOCSORT handle is null.");
+        if (handle->is_obb && warp_2x3) throw std::runtime_error("boxmot_hip: camera-motion warps are not applied to oriented detections");
         io_set_warp(handle, stream, warp_2x3);
     });
 }
@@ -2202,7 +2237,7 @@ int boxmot_hip_deepocsort_update_batch(BoxMOTHipDeepOcSort* handle, int n_stream
         for (int s = 0; s < n_streams; ++s)
             in[s] = StreamIn{dets[s], det_rows[s], (embs && emb_cols > 0) ? embs[s] : nullptr, images ? images[s] : nullptr};
         docs_need_frame_size(handle, image_rows, image_cols);
-        docs_host_update(handle, n_streams, in.data(), 6, emb_cols, image_rows, image_cols, image_channels, out_tracks,
+        docs_host_update(handle, n_streams, in.data(), handle->det_cols, emb_cols, image_rows, image_cols, image_channels, out_tracks,
                          out_capacity_rows, out_rows);
     });
 }
@@ -2221,7 +2256,7 @@ int boxmot_hip_deepocsort_update(BoxMOTHipDeepOcSort* handle, const float* dets,
         float* outs[1] = {out_tracks};
         docs_need_frame_size(handle, image_rows, image_cols);
         docs_host_update(handle, 1, &in, det_cols, emb_cols, image_rows, image_cols, image_channels, outs, out_capacity_rows, out_rows);
-        *out_is_obb = 0;
+        *out_is_obb = handle->is_obb ? 1 : 0;
     });
 }
 
@@ -2240,7 +2275,7 @@ int boxmot_hip_deepocsort_update_stream(BoxMOTHipDeepOcSort* handle, int stream,
         docs_need_frame_size(handle, image_rows, image_cols);
         docs_host_update(handle, 1, &in, det_cols, emb_cols, image_rows, image_cols, image_channels, outs, out_capacity_rows, out_rows,
                          stream, frame_count, id_count_inout);
-        *out_is_obb = 0;
+        *out_is_obb = handle->is_obb ? 1 : 0;
     });
 }
 
@@ -2256,8 +2291,7 @@ int boxmot_hip_deepocsort_step_device(BoxMOTHipDeepOcSort* handle, const float* 
         const bool any_warp = io_consume_warps(handle);         // boxmot_hip_deepocsort_set_warp since the last step
         a.warp = any_warp ? handle->d_warp : nullptr; a.warp_flag = any_warp ? handle->d_warp_flag : nullptr;
         a.out = d_out; a.out_n = d_out_rows; a.stream_base = 0;
-        hipLaunchKernelGGL((deepocsort_step_kernel<STEP_THREADS>), dim3(handle->S), dim3(STEP_THREADS),
-                           (size_t)bm::docs_lap_lds_bytes(handle->cap, handle->nd), handle->stream, a);
+        docs_launch(handle, handle->S, a);
         BM_HIP(hipGetLastError());
         io_clear_warps(handle);
     });
@@ -2277,8 +2311,7 @@ int boxmot_hip_deepocsort_step_device_frames(BoxMOTHipDeepOcSort* handle, const 
         const bool any_warp = io_consume_warps(handle);
         a.warp = any_warp ? handle->d_warp : nullptr; a.warp_flag = any_warp ? handle->d_warp_flag : nullptr;
         a.out = d_out; a.out_n = d_out_rows; a.stream_base = 0;
-        hipLaunchKernelGGL((deepocsort_step_kernel<STEP_THREADS>), dim3(handle->S), dim3(STEP_THREADS),
-                           (size_t)bm::docs_lap_lds_bytes(handle->cap, handle->nd), handle->stream, a);
+        docs_launch(handle, handle->S, a);
         BM_HIP(hipGetLastError());
         io_clear_warps(handle);
     });
@@ -2339,7 +2372,8 @@ int boxmot_hip_deepocsort_state_dump(BoxMOTHipDeepOcSort* handle, int stream, in
         for (int r = 0; r < n; ++r) {
             const int sl = list[r];
             if (ints5) { int* o = ints5 + r * 5; o[0] = id[sl]; o[1] = age[sl]; o[2] = tsu[sl]; o[3] = hs[sl]; o[4] = obs[sl]; }
-            if (kf72) BM_HIP(hipMemcpy(kf72 + (size_t)r * bm::KF_STRIDE, st.kf + (off + sl) * bm::KF_STRIDE, bm::KF_STRIDE * 8, hipMemcpyDeviceToHost));
+            const size_t KS = bm::docs_kf_stride(handle->is_obb);      // 72 doubles per track, 90 (x[9] ++ P[9][9]) on an oriented handle
+            if (kf72) BM_HIP(hipMemcpy(kf72 + (size_t)r * KS, st.kf + (off + sl) * KS, KS * 8, hipMemcpyDeviceToHost));
             if (emb) BM_HIP(hipMemcpy(emb + (size_t)r * dim, st.emb + (off + sl) * dim, dim * 8, hipMemcpyDeviceToHost));
         }
         *out_rows = n;

@@ -73,15 +73,42 @@ class DeepOcSort(BaseTracker):
         cfg.use_byte, cfg.min_conf = (int(self._byte[0]), self._byte[1]) if hasattr(self, "_byte") else (0, 0.1)   # OcSort only
         # the function behind the step's "iou" matrices (association.py:95, deepocsort.py:420, ocsort.py:457,486); a name
         # outside the table raises on the first frame (BaseTracker._preprocess), where the reference resolves it
-        cfg.asso_func = _lib.ASSO_FUNCS.get(self.asso_func_name, 0)
+        cfg.asso_func = _lib.ASSO_FUNCS.get(self._asso_func_base_name, 0)
+        cfg.is_obb = int(self.is_obb)
         cfg.n_streams = self.nr_classes if self.per_class else 1
         cfg.max_tracks, cfg.max_dets, cfg.emb_dim = max_tracks, max_dets, self._emb_dim
         self._ids_issued = ctypes.c_int(0)           # KalmanBoxTracker.count - 1, shared by the per-class lists
         self._cfg = cfg
         self._max_tracks = max_tracks
-        self._handle = self._lib.boxmot_hip_deepocsort_create(ctypes.byref(cfg))
+        self._handle = None
+        self._check_obb_options()
+        self._create_handle()
+
+    def _create_handle(self) -> None:
+        self.close()
+        self._handle = self._lib.boxmot_hip_deepocsort_create(ctypes.byref(self._cfg))
         if not self._handle:
             raise RuntimeError(_lib.last_error())
+
+    def _check_obb_options(self) -> None:
+        from boxmot_amd.basetracker import ASSO_NAMES
+        if self.is_obb and self._asso_func_base_name != "iou" and self.asso_func_name in ASSO_NAMES:      # i.e. centroid_obb
+            raise NotImplementedError(
+                f"oriented detections are associated with the rotated IoU (asso_func='iou' -> 'iou_obb'); '{self.asso_func_name}' is not implemented")
+
+    def _set_detection_mode(self, is_obb: bool) -> None:
+        """The first detection table decides the layout (basetracker.py:163-173); a tracker that has not stepped yet gets a handle
+        of the other kind (the device tables are sized for one layout: 7- or 9-state filter, 6- or 7-column detections)."""
+        changed = bool(is_obb) != bool(self._cfg.is_obb)
+        super()._set_detection_mode(is_obb)
+        if changed:
+            self._check_obb_options()
+            self._cfg.is_obb = int(self.is_obb)
+            # the oriented step has one association function, the rotated IoU; a name without an oriented twin (giou_obb, ...) is
+            # reported by the first-frame check of BaseTracker._preprocess, as the reference reports it
+            self._cfg.asso_func = 0 if self.is_obb else _lib.ASSO_FUNCS.get(self._asso_func_base_name, 0)
+            self._create_handle()
+            self._ids_issued = ctypes.c_int(0)
 
     def _update_impl(self, dets, img, embs=None, masks=None, class_list: int = 0) -> np.ndarray:
         self.check_inputs(dets, img, embs)
@@ -89,7 +116,7 @@ class DeepOcSort(BaseTracker):
         n = int(det_arr.shape[0])
         feats = None
         if not self.embedding_off and n:
-            keep = det_arr[:, 4] > np.float32(self.det_thresh)          # deepocsort.py:334 (fp32 compare)
+            keep = det_arr[:, self.conf_idx] > np.float32(self.det_thresh)          # deepocsort.py:334 (fp32 compare)
             if embs is not None:
                 feats = np.ascontiguousarray(embs, dtype=np.float32)
             elif keep.any():
@@ -111,7 +138,7 @@ class DeepOcSort(BaseTracker):
         ok = self._lib.boxmot_hip_deepocsort_update_stream(
             self._handle, stream, int(self.frame_count) if self.per_class else -1,
             ctypes.byref(self._ids_issued) if self.per_class else None,
-            det_arr.ctypes.data if n else None, n, 6,
+            det_arr.ctypes.data if n else None, n, self.det_cols,
             feats.ctypes.data if feats is not None else None, n if feats is not None else 0,
             self._emb_dim if feats is not None else 0,
             img_arr.ctypes.data, int(img_arr.shape[0]), int(img_arr.shape[1]),
@@ -122,7 +149,7 @@ class DeepOcSort(BaseTracker):
         _lib.check(ok)
         if out_rows.value == 0:
             return np.array([])                      # deepocsort.py:490-492 -> TrackResults of shape (0, 0)
-        return out[: out_rows.value, :OUT_COLS].copy()
+        return out[: out_rows.value, :self.output_cols].copy()
 
     def reset(self) -> None:
         _lib.check(self._lib.boxmot_hip_deepocsort_reset(self._handle))
@@ -145,7 +172,7 @@ class DeepOcSort(BaseTracker):
         """Copy the live tracks back from the device in list order (parity tests / debugging)."""
         cap, dim = self.capacity()[0], self._emb_dim
         ints = np.zeros((cap, 5), dtype=np.int32)
-        kf = np.zeros((cap, 72), dtype=np.float64)
+        kf = np.zeros((cap, 90 if self.is_obb else 72), dtype=np.float64)     # x[8] ++ P[8][8], or x[9] ++ P[9][9] oriented
         emb = np.zeros((cap, dim), dtype=np.float64)
         rows, fc, ic = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
         _lib.check(self._lib.boxmot_hip_deepocsort_state_dump(
@@ -174,7 +201,13 @@ class OcSort(DeepOcSort):
     observation-centric recovery round and re-update, same output rule (ocsort.py:398-555 vs deepocsort.py:302-492);
     pinned bit-for-bit on the reference classes (tests/golden/mot17_golden.npz, tests/test_oracle_vs_reference.py).  So
     OC-SORT runs on the DeepOCSORT step kernel with those two terms off, plus its own optional BYTE association of the
-    detections with ``min_conf < score < det_thresh`` (``use_byte=True``, ocsort.py:393-399, 456-485)."""
+    detections with ``min_conf < score < det_thresh`` (``use_byte=True``, ocsort.py:393-399, 456-485).
+
+    Oriented detections (7 columns; ``supports_obb``, ocsort.py:332): the step has an oriented twin on the device -- the 9-state
+    ``KalmanFilterXYSR(dim_x=9, dim_z=5)`` with the aligned measurement, the interpolated angle of the re-update and the damped
+    angular velocity, the rotated IoU, 9-column rows -- chosen by the first detection table like in the reference."""
+
+    supports_obb = True
 
     def __init__(self, min_conf: float = 0.1, delta_t: int = 3, inertia: float = 0.2, use_byte: bool = False,
                  Q_xy_scaling: float = 0.01, Q_s_scaling: float = 0.0001, max_tracks: int = 1024, max_dets: int = 256,

@@ -328,6 +328,11 @@ typedef struct BoxMOTHipDeepOcSortConfig {
      * they are taken from the first host update that carries an image (device-resident steps need them set). */
     int asso_func;                   /* BOXMOT_HIP_ASSO_* */
     int frame_w, frame_h;
+    /* 1: oriented detections [cx cy w h angle conf cls] -> rows [cx cy w h angle id conf cls det_ind] -- OC-SORT with is_obb
+     * (ocsort.py:49-87, :121-154, :241-310, :363-555: the 9-state KalmanFilterXYSR(dim_x=9, dim_z=5) incl. the aligned measurement,
+     * the interpolated angle of the re-update and the damped angular velocity; iou_batch_obb).  Needs embedding_off = 1 (DeepOcSort
+     * has no oriented mode) and asso_func = BOXMOT_HIP_ASSO_IOU; warps are refused; state_dump returns 90 doubles per track */
+    int is_obb;
 } BoxMOTHipDeepOcSortConfig;
 
 typedef struct BoxMOTHipDeepOcSort BoxMOTHipDeepOcSort;

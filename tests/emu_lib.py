@@ -1,4 +1,4 @@
-"""TEST-ONLY: the part of the C ABI that ``boxmot_amd.BotSort`` calls (include/boxmot_hip.h), answered by the emulated device step
+"""TEST-ONLY: the part of the C ABI that ``boxmot_amd.BotSort`` / ``ByteTrack`` / ``OcSort`` call (include/boxmot_hip.h), answered by the emulated device steps
 (tests/host_emu: botsort_step.hpp executed unchanged on CPU threads).  It lets the build container -- which has the reference under
 /root/reference but no GPU -- run the real host class ``boxmot_amd.BotSort`` under the reference's own callers
 (tests/test_reference_callers.py).  Never imported by the package; the shipped library has no CPU path."""
@@ -94,6 +94,82 @@ class EmuHipLib:
         d = rec["emu"].dump(which)
         for ptr, arr, ct in ((ints, d["ints"], ctypes.c_int32), (kf, d["kf"], ctypes.c_double), (smooth, d["smooth"], ctypes.c_float),
                              (misc, d["misc"], ctypes.c_float)):
+            if ptr and arr.size:
+                np.ctypeslib.as_array((ct * arr.size).from_address(ptr))[:] = arr.reshape(-1)
+        rows._obj.value = d["n"]
+        fc._obj.value, ic._obj.value = int(d["counters"][0]), int(d["counters"][1])
+        return 1
+
+    # ---- OC-SORT / DeepOCSORT without appearance (boxmot_hip_deepocsort_*): one stream, embedding_off ----
+    def boxmot_hip_deepocsort_default_config(self, ref):
+        pass        # DeepOcSort.__init__ sets every field it uses
+
+    def boxmot_hip_deepocsort_create(self, ref):
+        from emu_util import ASSO_MODES, EmuDeepOcSort
+        c = ref._obj
+        if c.n_streams != 1 or not c.embedding_off:
+            raise NotImplementedError("emulated ABI: one stream, embedding_off")
+        if c.is_obb and c.asso_func != 0:
+            self._err = b"boxmot_hip: the oriented step has the rotated IoU only (asso_func must be BOXMOT_HIP_ASSO_IOU)"
+            return None
+        names = {v: k for k, v in ASSO_MODES.items()}
+        cfg = dict(det_thresh=c.det_thresh, iou_threshold=c.iou_threshold, inertia=c.inertia, w_association_emb=c.w_association_emb,
+                   alpha_fixed_emb=c.alpha_fixed_emb, aw_param=c.aw_param, Q_xy_scaling=c.Q_xy_scaling, Q_s_scaling=c.Q_s_scaling,
+                   min_conf=c.min_conf, max_age=c.max_age, min_hits=c.min_hits, delta_t=c.delta_t, embedding_off=1, aw_off=c.aw_off,
+                   use_byte=c.use_byte, asso_func=names[c.asso_func], frame_wh=(c.frame_w, c.frame_h))
+        h = self._next
+        self._next += 1
+        rec = dict(cfg=cfg, cap=c.max_tracks, nd=c.max_dets, obb=bool(c.is_obb), kind="docs")
+        rec["emu"] = EmuDeepOcSort(cfg, cap=rec["cap"], nd=rec["nd"], dim=1, threads=self._threads, obb=rec["obb"])
+        self._handles[h] = rec
+        return h
+
+    def boxmot_hip_deepocsort_destroy(self, h):
+        rec = self._handles.pop(h, None)
+        if rec:
+            rec["emu"].close()
+
+    def boxmot_hip_deepocsort_reset(self, h):
+        from emu_util import EmuDeepOcSort
+        rec = self._handles[h]
+        rec["emu"].close()
+        rec["emu"] = EmuDeepOcSort(rec["cfg"], cap=rec["cap"], nd=rec["nd"], dim=1, threads=self._threads, obb=rec["obb"])
+        return 1
+
+    def boxmot_hip_deepocsort_update_stream(self, h, stream, frame_count_set, id_count_ref, dets, n, det_cols, embs, emb_rows, emb_cols,
+                                            img, rows, cols, ch, out, out_cap, out_cols, out_rows_ref, out_is_obb_ref):
+        rec = self._handles[h]
+        dc, oc = (7, 9) if rec["obb"] else (6, 8)
+        if n and det_cols != dc:
+            self._err = (b"boxmot_hip: this handle was created for oriented detections (7 columns)" if rec["obb"] else
+                         b"boxmot_hip: oriented detections (7 columns) need a handle created with is_obb = 1 (BoT-SORT, ByteTrack, OC-SORT)")
+            return 0
+        assert out_cols == 9 and stream == 0 and frame_count_set < 0 and id_count_ref is None
+        d = np.ctypeslib.as_array((ctypes.c_float * (n * dc)).from_address(dets)).reshape(n, dc).copy() if n else np.empty((0, dc), np.float32)
+        try:
+            got = rec["emu"].update(d, None)
+        except RuntimeError as exc:
+            self._err = str(exc).encode()
+            return 0
+        m = len(got)
+        if m > out_cap:
+            self._err = b"boxmot_hip: output buffer is too small for the current frame."
+            return 0
+        o = np.ctypeslib.as_array((ctypes.c_float * (out_cap * 9)).from_address(out)).reshape(out_cap, 9)
+        o[:m, 8] = 0
+        o[:m, :oc] = got
+        out_rows_ref._obj.value = m
+        out_is_obb_ref._obj.value = int(rec["obb"])
+        return 1
+
+    def boxmot_hip_deepocsort_capacity(self, h, a, b, c):
+        rec = self._handles[h]
+        a._obj.value, b._obj.value, c._obj.value = rec["cap"], rec["nd"], 0
+        return 1
+
+    def boxmot_hip_deepocsort_state_dump(self, h, stream, ints, kf, emb, rows, fc, ic):
+        d = self._handles[h]["emu"].dump()
+        for ptr, arr, ct in ((ints, d["ints"], ctypes.c_int32), (kf, d["kf"], ctypes.c_double)):
             if ptr and arr.size:
                 np.ctypeslib.as_array((ct * arr.size).from_address(ptr))[:] = arr.reshape(-1)
         rows._obj.value = d["n"]

@@ -19,7 +19,8 @@ def build(sanitize: bool = False, dense: bool = False, threads: int = 64, obb: b
     src = HERE / "emu_botsort.cpp"
     deps = [src, HERE / "hip_shim.hpp"] + list((HERE.parent.parent / "boxmot_amd" / "csrc").glob("botsort_*.hpp")) \
         + [HERE.parent.parent / "boxmot_amd" / "csrc" / "block_prims.hpp",
-           HERE.parent.parent / "boxmot_amd" / "csrc" / "kernel_macros.hpp"]
+           HERE.parent.parent / "boxmot_amd" / "csrc" / "kernel_macros.hpp",
+           HERE.parent.parent / "boxmot_amd" / "csrc" / "obb_geometry.hpp"]
     out = HERE / ("libemu_botsort_asan.so" if sanitize else ("libemu_botsort_dense.so" if dense else
                                                               ("libemu_botsort.so" if threads == 64 else f"libemu_botsort_t{threads}.so")))
     if obb:         # the oriented-box copy of the step (bm::obb)
@@ -87,25 +88,28 @@ DOCS_I = ("max_age", "min_hits", "delta_t", "embedding_off", "aw_off", "use_byte
 ASSO_MODES = {"iou": 0, "giou": 1, "diou": 2, "ciou": 3, "hmiou": 4, "centroid": 5}
 
 
-def build_docs(sanitize: bool = False, threads: int = 64) -> Path:
+def build_docs(sanitize: bool = False, threads: int = 64, obb: bool = False) -> Path:
     src = HERE / "emu_docs.cpp"
     csrc = HERE.parent.parent / "boxmot_amd" / "csrc"
-    deps = [src, HERE / "hip_shim.hpp", csrc / "deepocsort_step.hpp", csrc / "lap_jv.hpp", csrc / "block_prims.hpp", csrc / "kernel_macros.hpp",
-            csrc / "botsort_types.hpp"]
+    deps = [src, HERE / "hip_shim.hpp", csrc / "deepocsort_step.hpp", csrc / "deepocsort_step_body.hpp", csrc / "obb_geometry.hpp", csrc / "lap_jv.hpp",
+            csrc / "block_prims.hpp", csrc / "kernel_macros.hpp", csrc / "botsort_types.hpp"]
     out = HERE / ("libemu_docs_asan.so" if sanitize else ("libemu_docs.so" if threads == 64 else f"libemu_docs_t{threads}.so"))
+    if obb:         # the oriented copy of the step (bm::obb)
+        out = out.with_name(out.name.replace("libemu_docs", "libemu_docs_obb"))
     if not out.exists() or any(d.stat().st_mtime > out.stat().st_mtime for d in deps):
         flags = ["-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-pthread"]
         if sanitize:
             flags += ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"]
-        subprocess.check_call(["g++", *flags, f"-DEMU_NTHR={threads}", "-o", str(out), str(src)])
+        subprocess.check_call(["g++", *flags, f"-DEMU_NTHR={threads}", f"-DEMU_OBB={int(obb)}", "-o", str(out), str(src)])
     return out
 
 
 class EmuDeepOcSort:
     """The DeepOCSORT device step (deepocsort_step.hpp) executed on CPU threads."""
 
-    def __init__(self, cfg: dict, cap=256, nd=64, dim=32, sanitize=False, threads=64):
-        self.lib = ctypes.CDLL(str(build_docs(sanitize, threads=threads)))
+    def __init__(self, cfg: dict, cap=256, nd=64, dim=32, sanitize=False, threads=64, obb=False):
+        self.lib = ctypes.CDLL(str(build_docs(sanitize, threads=threads, obb=obb)))
+        self.det_cols, self.out_cols, self.kf_stride = (7, 9, 90) if obb else (6, 8, 72)
         self.lib.emu_docs_create.restype = ctypes.c_void_p
         self.lib.emu_docs_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         self.lib.emu_docs_update.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
@@ -122,11 +126,11 @@ class EmuDeepOcSort:
         self.h = self.lib.emu_docs_create(cd.ctypes.data, ci.ctypes.data, cap, nd, dim)
 
     def update(self, dets, embs=None, warp=None):
-        dets = np.ascontiguousarray(dets, dtype=np.float32).reshape(-1, 6)
+        dets = np.ascontiguousarray(dets, dtype=np.float32).reshape(-1, self.det_cols)
         n = len(dets)
         e = None if embs is None else np.ascontiguousarray(embs, dtype=np.float32)
         w = None if warp is None else np.ascontiguousarray(warp, dtype=np.float64).reshape(6)
-        out = np.zeros((self.cap, 8), dtype=np.float32)
+        out = np.zeros((self.cap, self.out_cols), dtype=np.float32)
         out_n = ctypes.c_int(0)
         status = self.lib.emu_docs_update(self.h, dets.ctypes.data, n, None if e is None else e.ctypes.data,
                                           None if w is None else w.ctypes.data, out.ctypes.data, ctypes.byref(out_n))
@@ -136,7 +140,7 @@ class EmuDeepOcSort:
 
     def dump(self):
         ints = np.zeros((self.cap, 5), dtype=np.int32)
-        kf = np.zeros((self.cap, 72), dtype=np.float64)
+        kf = np.zeros((self.cap, self.kf_stride), dtype=np.float64)
         emb = np.zeros((self.cap, self.dim), dtype=np.float64)
         cnt = np.zeros(2, dtype=np.int32)
         n = self.lib.emu_docs_dump(self.h, ints.ctypes.data, kf.ctypes.data, emb.ctypes.data, cnt.ctypes.data)

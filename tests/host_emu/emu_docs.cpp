@@ -18,6 +18,14 @@ namespace {
 #define EMU_NTHR 64
 #endif
 constexpr int NTHR = EMU_NTHR;
+#ifndef EMU_OBB
+#define EMU_OBB 0
+#endif
+#if EMU_OBB          // the oriented copy of the step (bm::obb): 7-column detections, 9-column rows, 90 doubles of filter state
+namespace geo = bm::obb;
+#else
+namespace geo = bm;
+#endif
 
 struct HostAlloc {
     std::vector<void*> owned;
@@ -43,7 +51,7 @@ void* thread_main(void* p) {
     ThreadArg* ta = static_cast<ThreadArg*>(p);
     threadIdx.x = ta->tid;
     blockIdx.x = 0;
-    bm::docs_step_stream<NTHR>(ta->e->args, 0, g_s_int, g_s_dbl, g_dyn);
+    geo::docs_step_stream<NTHR>(ta->e->args, 0, g_s_int, g_s_dbl, g_dyn);
     return nullptr;
 }
 
@@ -61,12 +69,12 @@ void* emu_docs_create(const double* cd, const int* ci, int cap, int nd, int dim)
     c.max_age = ci[0]; c.min_hits = ci[1]; c.delta_t = ci[2]; c.embedding_off = ci[3]; c.aw_off = ci[4];
     c.use_byte = ci[5]; c.min_conf_f32 = (float)cd[8];
     c.asso_mode = ci[6]; c.asso_diag = cd[9];
-    bm::DocsSizes z{1, cap, nd, dim};
+    bm::DocsSizes z{1, cap, nd, dim, EMU_OBB};
     bm::docs_allocate(e->args, z, e->alloc);
-    e->dets = e->alloc.get<float>((size_t)nd * bm::DET_COLS);
+    e->dets = e->alloc.get<float>((size_t)nd * geo::DOCS_DET_COLS);
     e->n_dets = e->alloc.get<int>(1);
     e->embs = e->alloc.get<float>((size_t)nd * dim);
-    e->out = e->alloc.get<float>((size_t)cap * bm::OUT_COLS);
+    e->out = e->alloc.get<float>((size_t)cap * geo::DOCS_OUT_COLS);
     e->out_n = e->alloc.get<int>(1);
     e->args.dets = e->dets; e->args.n_dets = e->n_dets; e->args.embs = e->embs;
     e->warp = e->alloc.get<double>(6); e->warp_flag = e->alloc.get<int>(1);
@@ -88,7 +96,7 @@ int emu_docs_update(void* h, const float* dets, int n, const float* embs, const 
     e->warp_flag[0] = warp != nullptr;
     if (warp) std::memcpy(e->warp, warp, 48);
     if (n > e->nd) return -1;
-    std::memcpy(e->dets, dets, (size_t)n * bm::DET_COLS * 4);
+    std::memcpy(e->dets, dets, (size_t)n * geo::DOCS_DET_COLS * 4);
     if (embs) std::memcpy(e->embs, embs, (size_t)n * e->dim * 4);
     e->n_dets[0] = n;
     static int s_int[bm::MAX_WAVES + 1];
@@ -102,7 +110,7 @@ int emu_docs_update(void* h, const float* dets, int n, const float* embs, const 
     for (int t = 0; t < NTHR; ++t) ta[t] = ThreadArg{e, t};
     emu_run_threads(NTHR, thread_main, ta.data(), sizeof(ta[0]), 1 << 20);
     *out_n = e->out_n[0];
-    std::memcpy(out, e->out, (size_t)e->out_n[0] * bm::OUT_COLS * 4);
+    std::memcpy(out, e->out, (size_t)e->out_n[0] * geo::DOCS_OUT_COLS * 4);
     return e->args.st.status[0];
 }
 
@@ -115,7 +123,7 @@ int emu_docs_dump(void* h, int* ints, double* kf, double* emb, int* counters) {
         const int sl = st.list[r];
         int* o = ints + r * 5;
         o[0] = st.id[sl]; o[1] = st.age[sl]; o[2] = st.tsu[sl]; o[3] = st.hit_streak[sl]; o[4] = st.observed[sl];
-        std::memcpy(kf + (size_t)r * bm::KF_STRIDE, st.kf + (size_t)sl * bm::KF_STRIDE, bm::KF_STRIDE * 8);
+        std::memcpy(kf + (size_t)r * geo::DOCS_KF_STRIDE, st.kf + (size_t)sl * geo::DOCS_KF_STRIDE, geo::DOCS_KF_STRIDE * 8);
         std::memcpy(emb + (size_t)r * e->dim, st.emb + (size_t)sl * e->dim, (size_t)e->dim * 8);
     }
     counters[0] = st.frame_count[0]; counters[1] = st.id_count[0];

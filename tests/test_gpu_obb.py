@@ -1,8 +1,8 @@
-"""GPU parity tests for ORIENTED detections through BoT-SORT and ByteTrack (the bm::obb copy of the frame step: 10-state filter,
-rotated-rectangle IoU; include/boxmot_hip.h `is_obb`), through the C ABI: against the reference's own rows
-(tests/golden/obb_golden.npz -- the real BotSort / ByteTrack classes fed 7-column detections) and against the oracles
-(oracle/botsort_obb.py, oracle/bytetrack_obb.py, pinned bit-exact on those classes by tests/test_oracle_obb.py) including the fp64
-filter state.  Rows: id / conf / cls / det_ind and the row order exact; the box (fp32 of the fp64 state) within 2e-4 px / rad."""
+"""GPU parity tests for ORIENTED detections through BoT-SORT, ByteTrack and OC-SORT (the bm::obb copies of the frame steps: 10-state
+KalmanFilterXYWH / 9-state KalmanFilterXYSR, rotated-rectangle IoU; include/boxmot_hip.h `is_obb`), through the C ABI: against the
+reference's own rows (tests/golden/obb_golden.npz -- the real BotSort / ByteTrack / OcSort classes fed 7-column detections) and against
+the oracles (oracle/botsort_obb.py, oracle/bytetrack_obb.py, oracle/ocsort_obb.py, pinned bit-exact on those classes by
+tests/test_oracle_obb.py) including the fp64 filter state.  Rows: id / conf / cls / det_ind and the row order exact; the box (fp32 of the fp64 state) within 2e-4 px / rad."""
 import ctypes
 
 import numpy as np
@@ -124,3 +124,82 @@ def test_c_abi_guards_of_the_oriented_handle():
     h = lib.boxmot_hip_botsort_create(ctypes.byref(cfg))
     assert update(np.array([[32, 32, 20, 10, 0.15, 0.95, 0]])) == 0 and "is_obb" in _lib.last_error()
     lib.boxmot_hip_botsort_destroy(h)
+
+
+# ---- OC-SORT ----
+@pytest.mark.parametrize("key", ["ocsort", "ocsort_byte"])
+def test_ocsort_oriented_detections_reproduce_the_reference_rows(key):
+    from boxmot_amd import OcSort
+    want, frames, seed = obb_golden_rows(key)
+    img = np.zeros((480, 640, 3), np.uint8)
+    trk = OcSort(max_tracks=128, max_dets=64, **({} if key == "ocsort" else dict(use_byte=True, max_age=8, min_hits=1)))
+    rows = 0
+    for t, d in enumerate(obb_frames(frames, seed=seed)):
+        got = trk.update(d, img)
+        if len(want[t]) == 0:
+            assert got.size == 0, t
+            continue
+        assert got.shape[1] == 9 and got.is_obb
+        _rows_match(got, want[t], t)
+        rows += len(got)
+    assert rows > 200 and trk.is_obb
+    trk.close()
+
+
+@pytest.mark.parametrize("kw,seed", [(dict(use_byte=True), 9), (dict(max_age=5, min_hits=1, delta_t=2, inertia=0.4, iou_threshold=0.2), 13)])
+def test_ocsort_oriented_step_matches_the_oracle_and_its_filter_state(kw, seed):
+    """Other seeds / option sets than the golden file's, 100 frames, small initial tables (they grow: 90-double filter rows carried
+    over); the state of every track at the end: 9-state mean and covariance, ages, streaks."""
+    from boxmot_amd import OcSort
+    from oracle.ocsort_obb import OcSortObbOracle
+    img = np.zeros((480, 640, 3), np.uint8)
+    for seed in (seed,):
+        trk, orc = OcSort(max_tracks=16, max_dets=8, **kw), OcSortObbOracle(**kw)
+        for t, d in enumerate(obb_frames(100, seed=seed)):
+            want = np.asarray(orc.update(d.copy(), img), dtype=np.float32).reshape(-1, 9)
+            got = np.asarray(trk.update(d, img)).reshape(-1, 9)
+            _rows_match(got, want, t)
+        od, dd = orc.dump(), trk.state_dump()
+        assert np.array_equal(dd["ints"][:, 0], od["id"]) and np.array_equal(dd["ints"][:, 1], od["age"])
+        assert np.array_equal(dd["ints"][:, 2], od["time_since_update"]) and np.array_equal(dd["ints"][:, 3], od["hit_streak"])
+        assert dd["n"] > 0 and dd["kf"].shape[1] == 90
+        assert np.allclose(dd["kf"][:, :9], od["x"], rtol=1e-8, atol=1e-9)
+        assert np.allclose(dd["kf"][:, 9:].reshape(-1, 9, 9), od["P"], rtol=1e-7, atol=1e-8)
+        assert trk.capacity()[2] >= 1
+        trk.close()
+
+
+def test_ocsort_oriented_surface_and_c_abi_guards():
+    from boxmot_amd import _lib, OcSort
+    rgb = np.zeros((640, 640, 3), np.uint8)
+    det = np.array([[320, 240, 80, 40, 0.15, 0.95, 0]], dtype=np.float32)
+    tracker = OcSort()
+    out1 = tracker.update(det, rgb)
+    out2 = tracker.update(det, rgb)
+    assert out1.shape == (1, 9) and out2.shape == (1, 9)
+    np.testing.assert_allclose(out2[0, :5], det[0, :5], atol=1e-2)
+    tracker.reset()
+    assert tracker.update(np.array([[10, 10, 60, 90, 0.9, 0]], dtype=np.float32), rgb).shape == (1, 8)
+    tracker.close()
+    lib = _lib.load()
+    cfg = _lib.DeepOcSortConfig()
+    lib.boxmot_hip_deepocsort_default_config(ctypes.byref(cfg))
+    assert cfg.is_obb == 0
+    cfg.max_tracks, cfg.max_dets, cfg.is_obb = 64, 32, 1
+    assert not lib.boxmot_hip_deepocsort_create(ctypes.byref(cfg)) and "OC-SORT" in _lib.last_error()       # DeepOCSORT has no oriented mode
+    cfg.embedding_off, cfg.cmc_off, cfg.asso_func = 1, 1, 1
+    assert not lib.boxmot_hip_deepocsort_create(ctypes.byref(cfg)) and "rotated IoU" in _lib.last_error()
+    cfg.asso_func = 0
+    h = lib.boxmot_hip_deepocsort_create(ctypes.byref(cfg))
+    assert h
+    warp = np.eye(2, 3)
+    assert lib.boxmot_hip_deepocsort_set_warp(h, 0, warp.ctypes.data) == 0 and "oriented" in _lib.last_error()
+    out = np.zeros((4, 9), np.float32)
+    rows, obb = ctypes.c_int(0), ctypes.c_int(0)
+    d6 = np.array([[22, 27, 42, 37, 0.95, 0]], dtype=np.float32)
+    assert lib.boxmot_hip_deepocsort_update(h, d6.ctypes.data, 1, 6, None, 0, 0, rgb.ctypes.data, 640, 640, 3, out.ctypes.data, 4, 9,
+                                            ctypes.byref(rows), ctypes.byref(obb)) == 0 and "oriented" in _lib.last_error()
+    assert lib.boxmot_hip_deepocsort_update(h, det.ctypes.data, 1, 7, None, 0, 0, rgb.ctypes.data, 640, 640, 3, out.ctypes.data, 4, 9,
+                                            ctypes.byref(rows), ctypes.byref(obb)) == 1 and rows.value == 1 and obb.value == 1
+    assert np.allclose(out[0], [320, 240, 80, 40, 0.15, 1, 0.95, 0, 0], atol=1e-5)
+    lib.boxmot_hip_deepocsort_destroy(h)

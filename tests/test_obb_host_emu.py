@@ -140,6 +140,53 @@ def test_layout_is_decided_once_and_wrong_widths_are_refused(emulated_abi):
         trk.update(np.array([[32, 32, 20, 10, 0.15, 0.95, 0]], dtype=np.float32), rgb)
 
 
+@pytest.mark.parametrize("key", ["ocsort", "ocsort_byte"])
+def test_ocsort_host_class_reproduces_the_reference_rows_on_oriented_detections(emulated_abi, key):
+    from boxmot_amd import OcSort
+    from boxmot_amd.track_results import TrackResults
+    want, frames, seed = obb_golden_rows(key)
+    img = np.zeros((480, 640, 3), np.uint8)
+    trk = OcSort(max_tracks=128, max_dets=64, **({} if key == "ocsort" else dict(use_byte=True, max_age=8, min_hits=1)))
+    assert trk.supports_obb and not trk.is_obb
+    for t, d in enumerate(obb_frames(frames, seed=seed)):
+        got = trk.update(d, img)
+        assert isinstance(got, TrackResults)
+        if len(want[t]) == 0:
+            assert got.size == 0, t
+            continue
+        assert got.shape[1] == 9 and got.is_obb
+        _rows_match(got, want[t], t)
+    assert trk.is_obb and trk.asso_func_name == "iou_obb"
+    d = trk.state_dump()
+    assert d["n"] > 0 and d["kf"].shape[1] == 90
+    trk.close()
+
+
+def test_ocsort_supports_obb_outputs_and_refuses_what_it_has_not(emulated_abi):
+    """The shape of tests/unit/test_trackers.py:382-392 for OcSort (ocsort.py:332 supports_obb); the other association functions and a
+    DeepOcSort are refused like the reference refuses them / loudly."""
+    from boxmot_amd import DeepOcSort, OcSort
+    rgb = np.zeros((640, 640, 3), np.uint8)
+    det = np.array([[320, 240, 80, 40, 0.15, 0.95, 0]], dtype=np.float32)
+    tracker = OcSort(max_tracks=64, max_dets=32)
+    out1 = tracker.update(det, rgb)
+    out2 = tracker.update(det, rgb)
+    assert out1.shape == (1, 9) and out2.shape == (1, 9)
+    np.testing.assert_allclose(out2[0, :5], det[0, :5], atol=1e-2)
+    tracker.reset()
+    assert tracker.update(np.array([[10, 10, 60, 90, 0.9, 0]], dtype=np.float32), rgb).shape == (1, 8)
+    tracker.close()
+    with pytest.raises(ValueError, match="Invalid association mode: giou_obb"):          # AssociationFunction's table has no giou_obb
+        OcSort(asso_func="giou", max_tracks=64, max_dets=32).update(det, rgb)
+    with pytest.raises(NotImplementedError, match="centroid_obb"):
+        OcSort(asso_func="centroid", max_tracks=64, max_dets=32).update(det, rgb)
+    trk = DeepOcSort.__new__(DeepOcSort)
+    from boxmot_amd.basetracker import BaseTracker
+    BaseTracker.__init__(trk, asso_func="iou")
+    with pytest.raises(AssertionError, match="DeepOcSort does not support OBB detections"):
+        trk.update(det, rgb)
+
+
 def test_track_results_names_the_oriented_columns():
     from boxmot_amd.track_results import TrackResults
     r = TrackResults(np.array([[320, 240, 80, 40, 0.15, 7, 0.95, 2, 0]], dtype=np.float32))
