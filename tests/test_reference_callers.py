@@ -81,3 +81,35 @@ def test_reference_results_run_tracker_drives_boxmot_amd_botsort(emulated_abi):
         _same(got, want, t)
         assert Results._extract_track_ids(got) == Results._extract_track_ids(want)
     ours.close()
+
+
+@pytest.mark.parametrize("name", ["bytetrack", "ocsort", "botsort"])
+def test_reference_tracker_runtime_drives_the_oriented_trackers(emulated_abi, name):
+    """The same caller with ORIENTED detections (7 columns): our ByteTrack / OcSort / BotSort and the reference's own class under the
+    reference's TrackerRuntime, 9-column rows through its MMOT formatter (runtime.py:81-88 -> convert_to_mmot_obb_format)."""
+    import boxmot_amd
+    from common import obb_frames
+    logging.disable(logging.CRITICAL)
+    TrackerRuntime, _ = ref_harness.load_engine_callers()
+    if name == "bytetrack":
+        ours, ref = boxmot_amd.ByteTrack(max_tracks=128, max_dets=64), ref_harness.load_bytetrack()()
+    elif name == "ocsort":
+        ours, ref = boxmot_amd.OcSort(max_tracks=128, max_dets=64), ref_harness.load_ocsort()()
+    else:
+        ours = boxmot_amd.BotSort(reid_model=None, with_reid=False, use_cmc=False, max_tracks=128, max_dets=64)
+        ref = ref_harness.load_botsort()(reid_model=None, with_reid=False, use_cmc=False)
+    rt_ours, rt_ref = TrackerRuntime(ours), TrackerRuntime(ref)
+    img = np.zeros((480, 640, 3), dtype=np.uint8)
+    rows = 0
+    for t, d in enumerate(obb_frames(40, seed=4)):
+        got, _ = rt_ours.update(d.copy(), img)
+        want, _ = rt_ref.update(d.copy(), img)
+        assert got.shape == want.shape, (t, got.shape, want.shape)
+        if len(want):
+            assert got.shape[1] == 9 and np.array_equal(got[:, 5:], want[:, 5:]), t
+            assert np.allclose(got[:, :5], want[:, :5], rtol=0, atol=1e-3), t
+            a, b = TrackerRuntime.format_for_mot(got, t + 1), TrackerRuntime.format_for_mot(want, t + 1)
+            assert a.shape == b.shape and np.array_equal(a[:, :2], b[:, :2])
+            rows += len(want)
+    assert rows > 50 and ours.is_obb and ref.is_obb
+    ours.close()
