@@ -78,14 +78,54 @@ def format_for_mot(tracks: np.ndarray, frame_idx: int) -> np.ndarray:
     ))
 
 
+def xywha_to_corners(boxes: np.ndarray) -> np.ndarray:
+    """(cx, cy, w, h, angle) -> the four corners, ordered top-left, top-right, bottom-right, bottom-left by the reference's rule
+    (smallest / largest x + y, smallest / largest y - x), fp32 like the reference (mot.py:27-66)."""
+    arr = np.asarray(boxes, dtype=np.float32).reshape(-1, 5)
+    corners = np.empty((arr.shape[0], 4, 2), dtype=np.float32)
+    for i, (cx, cy, w, h, angle) in enumerate(arr):
+        c, sn = float(np.cos(angle)), float(np.sin(angle))
+        rot = np.array([[c, -sn], [sn, c]], dtype=np.float32)
+        rect = np.array([[-w / 2, -h / 2], [w / 2, -h / 2], [w / 2, h / 2], [-w / 2, h / 2]], dtype=np.float32)
+        corners[i] = rect @ rot.T + np.array([cx, cy], dtype=np.float32)
+    ordered = np.empty_like(corners)
+    rows = np.arange(len(corners))
+    sums, diffs = corners.sum(axis=2), np.diff(corners, axis=2).reshape(len(corners), 4)
+    ordered[:, 0] = corners[rows, np.argmin(sums, axis=1)]
+    ordered[:, 2] = corners[rows, np.argmax(sums, axis=1)]
+    ordered[:, 1] = corners[rows, np.argmin(diffs, axis=1)]
+    ordered[:, 3] = corners[rows, np.argmax(diffs, axis=1)]
+    return ordered.reshape(len(corners), 8)
+
+
+def format_for_mmot_obb(tracks: np.ndarray, frame_idx: int) -> np.ndarray:
+    """(M, 9) oriented tracker rows -> (M, 13) MMOT rows [frame, id, x1, y1, ..., x4, y4, conf, cls, det_ind]
+    (convert_to_mmot_obb_format, mot.py:297-315; TrackerRuntime.format_for_mot picks it for 9-column rows, runtime.py:81-88)."""
+    t = np.asarray(tracks, dtype=np.float32)
+    if t.size == 0:
+        return np.empty((0, 13), dtype=np.float32)
+    t = t.reshape(-1, t.shape[-1])
+    if t.shape[1] < 9:
+        raise ValueError(f"Expected OBB tracking results with at least 9 columns, got {t.shape[1]}")
+    col = lambda v: np.asarray(v, dtype=np.float32).reshape(-1, 1)
+    return np.concatenate((np.full((len(t), 1), frame_idx, dtype=np.float32), col(t[:, 5].astype(int)), xywha_to_corners(t[:, :5]),
+                           col(t[:, 6]), col(t[:, 7].astype(int)), col(t[:, 8].astype(int))), axis=1)
+
+
 def write_mot_results(txt_path, mot_rows: np.ndarray) -> None:
-    """mot.py:318-344 (the file is created even when there is nothing to write)."""
+    """mot.py:318-344 (the file is created even when there is nothing to write; 9-column MOT rows in the fixed format, the 13-column
+    MMOT rows of oriented trackers with ``%g``)."""
     txt_path = Path(txt_path)
     txt_path.parent.mkdir(parents=True, exist_ok=True)
     txt_path.touch(exist_ok=True)
     if mot_rows is not None and mot_rows.size:
+        if mot_rows.ndim == 1:
+            mot_rows = mot_rows.reshape(1, -1)
         with open(txt_path, "a") as fh:
-            np.savetxt(fh, mot_rows.reshape(-1, 9), fmt="%d,%d,%d,%d,%d,%d,%.6f,%d,%d")
+            if mot_rows.shape[1] == 9:
+                np.savetxt(fh, mot_rows, fmt="%d,%d,%d,%d,%d,%d,%.6f,%d,%d")
+            else:
+                np.savetxt(fh, mot_rows, fmt="%g", delimiter=",")
 
 
 class MultiStreamTracker:

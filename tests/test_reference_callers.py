@@ -113,3 +113,24 @@ def test_reference_tracker_runtime_drives_the_oriented_trackers(emulated_abi, na
             rows += len(want)
     assert rows > 50 and ours.is_obb and ref.is_obb
     ours.close()
+
+
+def test_mmot_rows_of_oriented_tracks_match_the_reference_formatter(tmp_path):
+    """boxmot_amd.replay.format_for_mmot_obb / write_mot_results against convert_to_mmot_obb_format / write_mot_results
+    (boxmot/engine/tracking/mot.py:297-344) on the reference's own oriented rows (tests/golden/obb_golden.npz)."""
+    from boxmot_amd.replay import format_for_mmot_obb, write_mot_results
+    from common import obb_golden_rows
+    ref_harness.install_standins()
+    from boxmot.engine.tracking import mot as ref_mot
+    rows, _, _ = obb_golden_rows("bytetrack")
+    ours_txt, ref_txt = tmp_path / "a.txt", tmp_path / "b.txt"
+    n = 0
+    for t, r in enumerate(rows[:40]):
+        got, want = format_for_mmot_obb(r, t + 1), ref_mot.convert_to_mmot_obb_format(r.copy(), t + 1)
+        assert got.shape == want.shape and got.dtype == want.dtype and np.array_equal(got, want), t
+        write_mot_results(ours_txt, got)
+        ref_mot.write_mot_results(ref_txt, want)
+        n += len(r)
+    assert n > 100 and ours_txt.read_text() == ref_txt.read_text()
+    with pytest.raises(ValueError, match="at least 9 columns"):
+        format_for_mmot_obb(np.zeros((1, 8), np.float32), 1)
