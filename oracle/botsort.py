@@ -190,6 +190,18 @@ class BotSortOracle:
         emb[gate] = 1.0
         return np.minimum(iou_d, emb)
 
+    @staticmethod
+    def _warp_tracks(tracks, warp):
+        """STrack.multi_gmc on the pool, then on the unconfirmed tracks (botsort.py:134-145, botsort_track.py:117-132)."""
+        H = np.asarray(warp)
+        R8 = np.kron(np.eye(4), H[:2, :2])
+        tvec = H[:2, 2]
+        for t in tracks:
+            m = R8.dot(t.mean)
+            m[:2] += tvec
+            t.mean = m
+            t.cov = R8.dot(t.cov).dot(R8.T)
+
     def update(self, dets, img=None, embs=None, warp=None):
         """dets (N,6) [x1,y1,x2,y2,conf,cls]; returns (M,8) fp32 rows.  ``warp``: optional 2x3 camera-motion
         matrix (what ``cmc.apply`` returns in the reference), applied after prediction."""
@@ -238,18 +250,8 @@ class BotSortOracle:
             mean, cov = self._kf_predict(mean, cov)
             for t, m, p in zip(pool, mean, cov):
                 t.mean, t.cov = m, p
-        if warp is not None and self.N_BOX != 4:
-            raise NotImplementedError("oracle: camera-motion compensation of oriented boxes (STrack.multi_gmc_obb: cv2.minAreaRect) is not restated")
         if warp is not None:
-            # STrack.multi_gmc on the pool, then on the unconfirmed tracks (botsort.py:134-145, botsort_track.py:117-132)
-            H = np.asarray(warp)
-            R8 = np.kron(np.eye(4), H[:2, :2])
-            tvec = H[:2, 2]
-            for t in list(pool) + list(unconfirmed):
-                m = R8.dot(t.mean)
-                m[:2] += tvec
-                t.mean = m
-                t.cov = R8.dot(t.cov).dot(R8.T)
+            self._warp_tracks(list(pool) + list(unconfirmed), warp)
         dists = self._assoc_cost(pool, cand, None, c["fuse_first_associate"])
         m1, u_trk1, u_det1 = matching.linear_assignment(dists, c["match_thresh"])
         self.last = {"dists_first": dists, "matches_first": m1}

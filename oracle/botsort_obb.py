@@ -1,9 +1,10 @@
-"""Oracle BoT-SORT frame step for ORIENTED detections -- TEST INFRASTRUCTURE ONLY, and so far ORACLE ONLY (oracle/obb.py's header).
+"""Oracle BoT-SORT frame step for ORIENTED detections -- TEST INFRASTRUCTURE ONLY.
 
 BotSortOracle with the pieces the reference switches on `is_obb` (boxmot/trackers/bbox/botsort/botsort.py:105, 267-271, 306, 357, 396,
 495; botsort_track.py:16-56, 84-115, 244-330): detections (cx, cy, w, h, angle, conf, cls), KalmanFilterXYWH(ndim=5) with (vw, vh,
 vtheta) zeroed for non-tracked tracks, rotated IoU of the fp32 `xywha`, rows (cx, cy, w, h, angle, id, conf, cls, det_ind).  The
-appearance path is unchanged.  Camera-motion compensation of oriented boxes (multi_gmc_obb: cv2.minAreaRect) is not restated: use_cmc=False.
+appearance path is unchanged.  Camera-motion compensation of oriented boxes (multi_gmc_obb, botsort.py:147-158) goes through
+oracle/obb.py's restatements of cv2.transform / cv2.minAreaRect (unpinned); the device step refuses a warp on an oriented handle.
 """
 from __future__ import annotations
 
@@ -64,6 +65,13 @@ class BotSortObbOracle(BotSortOracle):
     @staticmethod
     def _kf_initiate(z):
         return obb.kf5_initiate(z)
+
+    @staticmethod
+    def _warp_tracks(tracks, warp):                         # STrack.multi_gmc_obb, botsort_track.py:197-230
+        for t in tracks:
+            if t.mean is None or t.cov is None:
+                continue
+            t.mean, t.cov = obb.gmc_obb(t.mean, t.cov, warp)
 
     @staticmethod
     def _iou_d(a, b):                                       # matching.py:46-80 with is_obb

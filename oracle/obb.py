@@ -8,6 +8,10 @@ Follows:
   * iou_batch_obb / _iou_obb_matrix boxmot/trackers/association/iou.py:5-115 (AABB pre-filter, then the rotated intersection)
   * STrack's OBB accessors         boxmot/trackers/bbox/bytetrack/bytetrack.py:45-54, 147-198 (xywha as fp32 of the filter mean)
 
+Camera-motion compensation of oriented tracks (STrack.multi_gmc_obb, botsort_track.py:134-230) is restated here for the oracle only --
+the device steps refuse a warp on an oriented handle; it goes through two more OpenCV calls, cv2.transform and
+cv2.minAreaRect, restated below and UNPINNED like the intersection area.
+
 PARITY UNPINNED for one piece: the reference gets the intersection polygon from cv2.rotatedRectangleIntersection + cv2.contourArea
 (OpenCV is absent offline).  `rotated_intersection_area` computes the same quantity by clipping one rectangle with the other's four
 half-planes (Sutherland-Hodgman) in fp64 and the shoelace formula -- not OpenCV's edge-intersection enumeration in fp32 -- so areas
@@ -165,3 +169,67 @@ def iou_obb_matrix(b1, b2):                      # iou.py:38-115 (N, 5) x (M, 5)
         if union > 0:
             out[i, j] = inter / union
     return out
+
+
+# ---- camera-motion compensation of oriented tracks (botsort_track.py:134-230) ----
+def transform_points(pts, m):
+    """cv2.transform of (N, 1, 2) fp32 points with a 2x3 fp32 matrix: x' = m00 x + m01 y + m02, fp32 (UNPINNED: OpenCV's own
+    evaluation order / fused operations are not checkable offline)."""
+    p = np.asarray(pts, dtype=np.float32).reshape(-1, 2)
+    m = np.asarray(m, dtype=np.float32)
+    x, y = p[:, 0], p[:, 1]
+    return np.stack([m[0, 0] * x + m[0, 1] * y + m[0, 2], m[1, 0] * x + m[1, 1] * y + m[1, 2]], axis=1).astype(np.float32)
+
+
+def min_area_rect(pts):
+    """cv2.minAreaRect of the four corners of a warped rectangle: ((cx, cy), (w, h), angle in degrees).  A minimum-area enclosing
+    rectangle has a side collinear with an edge of the convex hull (rotating calipers): every edge of the quadrilateral is tried, the
+    first smallest area wins, `w` runs along that edge.  UNPINNED: OpenCV's fp32 calipers and its angle / side-order convention are
+    not checkable offline -- the caller (_corners_to_xywha) re-aligns (w, h, angle) to the track's previous box, which removes the
+    convention but not the rounding."""
+    p = np.asarray(pts, dtype=np.float64).reshape(-1, 2)
+    best = None
+    for i in range(len(p)):
+        e = p[(i + 1) % len(p)] - p[i]
+        n = np.hypot(e[0], e[1])
+        if n == 0.0:
+            continue
+        u = e / n
+        v = np.array([-u[1], u[0]])
+        a, b = p @ u, p @ v
+        w, h = a.max() - a.min(), b.max() - b.min()
+        if best is None or w * h < best[0]:
+            c = u * ((a.max() + a.min()) / 2) + v * ((b.max() + b.min()) / 2)
+            best = (w * h, c, w, h, np.degrees(np.arctan2(u[1], u[0])))
+    if best is None:                                  # all four points coincide
+        return (float(p[0, 0]), float(p[0, 1])), (0.0, 0.0), 0.0
+    _, c, w, h, ang = best
+    return (float(np.float32(c[0])), float(np.float32(c[1]))), (float(np.float32(w)), float(np.float32(h))), float(np.float32(ang))
+
+
+def corners_to_xywha(corners, reference):            # STrack._corners_to_xywha, botsort_track.py:176-195
+    (cx, cy), (w, h), angle_deg = min_area_rect(np.asarray(corners, dtype=np.float32))
+    xywha = np.array([cx, cy, max(w, 1e-4), max(h, 1e-4), np.deg2rad(angle_deg)], dtype=np.float32)
+    return align_obb_measurement(xywha, reference).astype(np.float32)
+
+
+def gmc_obb(mean, cov, H):                           # one track of STrack.multi_gmc_obb, botsort_track.py:197-230
+    warp = np.asarray(H, dtype=np.float32)
+    linear = warp[:2, :2]
+    scale_x = max(float(np.linalg.norm(linear[:, 0])), 1e-6)          # _affine_components, botsort_track.py:145-157
+    scale_y = max(float(np.linalg.norm(linear[:, 1])), 1e-6)
+    transform = np.eye(10, dtype=np.float32)
+    transform[:2, :2] = linear
+    transform[5:7, 5:7] = linear
+    transform[2, 2] = transform[7, 7] = scale_x
+    transform[3, 3] = transform[8, 8] = scale_y
+    ref_box = np.asarray(mean[:5], dtype=np.float32)
+    rect_w, rect_h = max(float(ref_box[2]), 1e-4), max(float(ref_box[3]), 1e-4)
+    corners = box_points(float(ref_box[0]), float(ref_box[1]), rect_w, rect_h, float(np.degrees(ref_box[4]))).astype(np.float32)
+    warped_box = corners_to_xywha(transform_points(corners, warp), ref_box)
+    out = mean.copy()
+    out[:5] = warped_box
+    out[5:7] = linear @ out[5:7]
+    out[7] *= scale_x
+    out[8] *= scale_y
+    return out, transform @ cov @ transform.T

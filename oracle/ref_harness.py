@@ -79,6 +79,17 @@ def _cv2_stub():
         from oracle import obb
         return obb.box_points(rect[0][0], rect[0][1], rect[1][0], rect[1][1], rect[2])
 
+    # camera-motion compensation of oriented tracks (botsort_track.py:134-195): oracle/obb.py's restatements, unpinned
+    def transform(pts, m):
+        from oracle import obb
+        return obb.transform_points(pts, m).reshape(-1, 1, 2)
+
+    def minAreaRect(pts):
+        from oracle import obb
+        return obb.min_area_rect(pts)
+
+    cv2.transform = transform
+    cv2.minAreaRect = minAreaRect
     cv2.resize = resize
     cv2.cvtColor = cvtColor
     cv2.copyMakeBorder = copyMakeBorder
