@@ -6,6 +6,11 @@ oriented boxes -- with named accessors.
 """
 from __future__ import annotations
 
+import csv
+import io
+import json
+from pathlib import Path
+
 import numpy as np
 
 COLUMNS = ("x1", "y1", "x2", "y2", "id", "conf", "cls", "det_ind")
@@ -66,3 +71,38 @@ class TrackResults(np.ndarray):
             f"{frame_id},{int(r[4])},{r[0]:.2f},{r[1]:.2f},{r[2] - r[0]:.2f},{r[3] - r[1]:.2f},{r[5]:.6f},{int(r[6])},-1"
             for r in np.asarray(self)
         ]
+
+    # ---- export methods (track_results.py:100-200) ----
+    @property
+    def _csv_fields(self):
+        return ["cx", "cy", "w", "h", "angle", "id", "conf", "cls", "det_ind"] if self.is_obb else list(COLUMNS)
+
+    def _row(self, i: int):
+        box = [float(v) for v in (self.xywha[i] if self.is_obb else self.xyxy[i])]
+        return box + [int(self.id[i]), float(self.conf[i]), int(self.cls[i]), int(self.det_ind[i])]
+
+    def to_json(self, indent=None) -> str:
+        return json.dumps(self.summary(), indent=indent)
+
+    def to_csv(self, frame_id=None) -> str:
+        buf = io.StringIO()
+        writer = csv.writer(buf)
+        for i in range(len(self)):
+            writer.writerow([frame_id] + self._row(i) if frame_id is not None else self._row(i))
+        return buf.getvalue()
+
+    def save_csv(self, path, frame_id=None, header: bool = True) -> None:
+        path = Path(path)
+        write_header = header and not path.exists()
+        path.parent.mkdir(parents=True, exist_ok=True)
+        with open(path, "a", newline="") as f:
+            if write_header:
+                csv.writer(f).writerow((["frame"] + self._csv_fields) if frame_id is not None else self._csv_fields)
+            f.write(self.to_csv(frame_id=frame_id))
+
+    def save_mot(self, path, frame_id: int = 0) -> None:
+        path = Path(path)
+        path.parent.mkdir(parents=True, exist_ok=True)
+        with open(path, "a") as f:
+            for line in self.to_mot_lines(frame_id):
+                f.write(line + "\n")

@@ -131,3 +131,36 @@ def test_create_tracker_invalid_tracker_name():
         create_tracker(tracker_type="nonexistent_tracker", per_class=False)
     with pytest.raises(NotImplementedError, match="not implemented on the HIP backend"):
         create_tracker(tracker_type="boosttrack")
+
+
+@pytest.mark.skipif(not ref_harness.reference_available(), reason="/root/reference is not mounted")
+@pytest.mark.parametrize("key", ["aabb", "obb", "empty"])
+def test_track_results_surface_equals_the_reference_class(tmp_path, key):
+    """boxmot_amd.TrackResults beside boxmot/trackers/track_results.py:12-200 on the same rows: every accessor, summary / to_json /
+    to_csv, the files save_csv / save_mot write -- axis-aligned (8 columns), oriented (9) and empty."""
+    from boxmot_amd.track_results import TrackResults as Ours
+    ref_harness.install_standins()
+    from boxmot.trackers.track_results import TrackResults as Ref
+    rng = np.random.default_rng(5)
+    if key == "aabb":
+        rows = np.column_stack([rng.uniform(0, 600, (7, 2)), rng.uniform(600, 900, (7, 2)), np.arange(1, 8), rng.uniform(0.2, 1, 7),
+                                rng.integers(0, 80, 7), rng.integers(-1, 20, 7)]).astype(np.float32)
+    elif key == "obb":
+        rows = np.column_stack([rng.uniform(0, 600, (5, 2)), rng.uniform(10, 90, (5, 2)), rng.uniform(-3, 3, 5), np.arange(1, 6),
+                                rng.uniform(0.2, 1, 5), rng.integers(0, 80, 5), rng.integers(-1, 20, 5)]).astype(np.float32)
+    else:
+        rows = np.empty((0, 8), dtype=np.float32)
+    a, b = Ours(rows), Ref(rows.copy())
+    assert a.is_obb == b.is_obb
+    for name in ("id", "conf", "cls", "det_ind", "xyxy", "xywh") + (("xywha",) if key == "obb" else ()):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
+    assert a.summary() == b.summary() and a.to_json() == b.to_json() and a.to_json(indent=2) == b.to_json(indent=2)
+    assert a.to_csv() == b.to_csv() and a.to_csv(frame_id=3) == b.to_csv(frame_id=3)
+    for t in (1, 2):
+        a.save_csv(tmp_path / "a.csv", frame_id=t)
+        b.save_csv(tmp_path / "b.csv", frame_id=t)
+        a.save_mot(tmp_path / "a.txt", frame_id=t)
+        b.save_mot(tmp_path / "b.txt", frame_id=t)
+    assert (tmp_path / "a.csv").read_text() == (tmp_path / "b.csv").read_text()
+    assert (tmp_path / "a.txt").read_text() == (tmp_path / "b.txt").read_text()
+    assert isinstance(a[:2], Ours) and a[:2].is_obb == a.is_obb                  # slices stay views of the class
