@@ -9,7 +9,8 @@ Follows (statement order and NumPy calls kept, so results are bit-identical on o
     :366-459 (predict_state / update_state, Joseph form);
   * boxmot/trackers/association/association.py:8-152 (associate -- the restatement of oracle/deepocsort.py is reused: the reference
     runs the SAME column arithmetic on oriented rows, i.e. its "centres" are (cx + w) / 2, (cy + h) / 2 and its "valid previous
-    observation" test reads the angle column; reproduced, not corrected) with iou.py:38-115 as the association function.
+    observation" test reads the angle column; reproduced, not corrected) with iou.py:38-115 (iou_obb) or iou.py:263-274
+    (centroid_obb) as the association function -- the device step has the first only.
 Pinned against the reference class itself (tests/test_oracle_obb.py; fixture tests/golden/obb_golden.npz key "ocsort").  The
 rotated-intersection AREA is oracle/obb.py's (the reference: cv2.rotatedRectangleIntersection + contourArea, OpenCV absent offline:
 PARITY UNPINNED for that one quantity); ``lap.lapjv`` is the oracle stand-in (oracle/lap.py).  The display-only corner history
@@ -29,6 +30,8 @@ from oracle.obb import iou_obb_matrix, wrap_angle
 DEFAULTS = dict(
     det_thresh=0.3, max_age=30, max_obs=50, min_hits=3, iou_threshold=0.3,           # basetracker.py:19-31
     min_conf=0.1, delta_t=3, inertia=0.2, use_byte=False, Q_xy_scaling=0.01, Q_s_scaling=0.0001,      # ocsort.py:334-344
+    asso_func="iou",        # basetracker.py:28 -> "iou_obb" / "centroid_obb" for oriented detections (detection_layout.py:25-26)
+    frame_wh=None,          # (w, h) for centroid_obb; None: read off the first image (basetracker.py:175-180)
 )
 
 _F = np.eye(9)                                      # xysr.py:54-66: [x, y, s, r, theta, vx, vy, vs, vtheta]
@@ -53,6 +56,13 @@ def x_to_obb(x):                                    # ocsort.py:62-72 (score=Non
 
 def iou_obb(a, b):                                  # AssociationFunction.iou_batch_obb, iou.py:152-154
     return iou_obb_matrix(np.asarray(a, dtype=float)[:, :5], np.asarray(b, dtype=float)[:, :5])
+
+
+def centroid_obb(a, b, w, h):                       # AssociationFunction.centroid_batch_obb, iou.py:263-274
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    c1 = np.expand_dims(np.stack((a[..., 0], a[..., 1]), axis=-1), 1)
+    c2 = np.expand_dims(np.stack((b[..., 0], b[..., 1]), axis=-1), 0)
+    return 1 - np.sqrt(np.sum((c1 - c2) ** 2, axis=-1)) / np.sqrt(w ** 2 + h ** 2)
 
 
 def align_xysr_measurement(m, ref):                 # xysr.py:96-136 over base.py:131-157
@@ -253,11 +263,21 @@ class OcSortObbOracle:
         self.frame_count = 0
         self.count = 0                              # KalmanBoxTracker.count = 0 (ocsort.py:358); rows carry id + 1
         self.tracks = []
+        self.asso = None
 
     def update(self, dets, img=None, embs=None):
         """dets (N, 7) [cx, cy, w, h, angle, conf, cls] -> the fp32 rows ``OcSort.update`` hands back, (M, 9)
         [cx, cy, w, h, angle, id, conf, cls, det_ind], or (0, 0) when nothing is output."""
         c = self.cfg
+        if self.asso is None:                       # basetracker.py:175-180: the first frame fixes w, h and the function
+            if c["asso_func"] == "iou":
+                self.asso = iou_obb
+            elif c["asso_func"] == "centroid":
+                fw, fh = c["frame_wh"] if c["frame_wh"] is not None else (img.shape[1], img.shape[0])
+                self.asso = lambda a, b: centroid_obb(a, b, fw, fh)
+            else:                                   # AssociationFunction._get_asso_func, iou.py:418-422
+                raise ValueError(f"Invalid association mode: {c['asso_func']}_obb")
+        asso = self.asso
         dets = np.asarray(dets)
         if dets.size == 0:
             dets = np.empty((0, 7), dtype=np.float32)
@@ -282,12 +302,12 @@ class OcSortObbOracle:
         k_obs = np.array([_k_previous_obs(t.observations, t.age, c["delta_t"]) for t in self.tracks])
 
         matched, un_d, un_t = associate(dets[:, 0:6], trks, c["iou_threshold"], velocities, k_obs, c["inertia"],
-                                        None, None, None, None, iou_obb)
+                                        None, None, None, None, asso)
         for m in matched:
             self.tracks[m[1]].update(dets[m[0], :-2], dets[m[0], -2], dets[m[0], -1])
 
         if c["use_byte"] and len(dets_second) > 0 and un_t.shape[0] > 0:          # ocsort.py:456-485
-            iou_left = np.array(iou_obb(dets_second, trks[un_t]))
+            iou_left = np.array(asso(dets_second, trks[un_t]))
             if iou_left.max() > c["iou_threshold"]:
                 rem_t = []
                 for m in _assign(-iou_left):
@@ -299,7 +319,7 @@ class OcSortObbOracle:
                 un_t = np.setdiff1d(un_t, np.array(rem_t))
 
         if un_d.shape[0] > 0 and un_t.shape[0] > 0:                               # ocsort.py:487-517
-            iou_left = np.array(iou_obb(dets[un_d], last_boxes[un_t]))
+            iou_left = np.array(asso(dets[un_d], last_boxes[un_t]))
             if iou_left.max() > c["iou_threshold"]:
                 rem_d, rem_t = [], []
                 for m in _assign(-iou_left):

@@ -133,7 +133,7 @@ def test_obb_oracles_match_reference_golden_rows(key):
 
 
 OCSORT_CASES = [{}, dict(use_byte=True), dict(max_age=5, min_hits=1, delta_t=2, inertia=0.4, iou_threshold=0.2),
-                dict(use_byte=True, max_age=8, min_hits=1)]
+                dict(use_byte=True, max_age=8, min_hits=1), dict(asso_func="centroid", iou_threshold=0.9, use_byte=True)]
 
 
 @pytest.mark.skipif(not ref_harness.reference_available(), reason="/root/reference is not mounted")
