@@ -196,11 +196,12 @@ def min_area_rect(pts):
             continue
         u = e / n
         v = np.array([-u[1], u[0]])
-        a, b = p @ u, p @ v
+        a, b = p[:, 0] * u[0] + p[:, 1] * u[1], p[:, 0] * v[0] + p[:, 1] * v[1]      # (elementwise: a defined rounding, no BLAS)
         w, h = a.max() - a.min(), b.max() - b.min()
         if best is None or w * h < best[0]:
-            c = u * ((a.max() + a.min()) / 2) + v * ((b.max() + b.min()) / 2)
-            best = (w * h, c, w, h, np.degrees(np.arctan2(u[1], u[0])))
+            ca, cb = (a.max() + a.min()) / 2, (b.max() + b.min()) / 2
+            c = np.array([u[0] * ca + v[0] * cb, u[1] * ca + v[1] * cb])
+            best = (w * h, c, w, h, np.arctan2(u[1], u[0]) * (180.0 / np.pi))
     if best is None:                                  # all four points coincide
         return (float(p[0, 0]), float(p[0, 1])), (0.0, 0.0), 0.0
     _, c, w, h, ang = best
