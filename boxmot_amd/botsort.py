@@ -118,6 +118,7 @@ class BotSort(BaseTracker):
         cfg.is_obb = int(self.is_obb)
         self._cfg = cfg
         self._handle = None
+        self._reserved = (0, 0)
         self._max_tracks = max_tracks
         self._check_obb_options()
         self._create_handle()
@@ -127,6 +128,8 @@ class BotSort(BaseTracker):
         self._handle = self._lib.boxmot_hip_botsort_create(ctypes.byref(self._cfg))
         if not self._handle:
             raise RuntimeError(_lib.last_error())
+        if any(self._reserved):          # a reserve() made before the layout was known survives the re-creation of the handle
+            _lib.check(self._lib.boxmot_hip_botsort_reserve(self._handle, *self._reserved))
 
     def _check_obb_options(self) -> None:
         if self.is_obb and self.cmc is not None:
@@ -202,6 +205,7 @@ class BotSort(BaseTracker):
 
     def reserve(self, max_tracks: int = 0, max_dets: int = 0) -> None:
         _lib.check(self._lib.boxmot_hip_botsort_reserve(self._handle, int(max_tracks), int(max_dets)))
+        self._reserved = (max(int(max_tracks), self._reserved[0]), max(int(max_dets), self._reserved[1]))      # re-applied if the handle is re-made
 
     # ------------------------------------------------- introspection (read-only)
     def state_dump(self, which: int = 0, class_list: int = 0) -> dict:

@@ -81,6 +81,7 @@ class DeepOcSort(BaseTracker):
         self._cfg = cfg
         self._max_tracks = max_tracks
         self._handle = None
+        self._reserved = (0, 0)
         self._check_obb_options()
         self._create_handle()
 
@@ -89,6 +90,8 @@ class DeepOcSort(BaseTracker):
         self._handle = self._lib.boxmot_hip_deepocsort_create(ctypes.byref(self._cfg))
         if not self._handle:
             raise RuntimeError(_lib.last_error())
+        if any(self._reserved):          # a reserve() made before the layout was known survives the re-creation of the handle
+            _lib.check(self._lib.boxmot_hip_deepocsort_reserve(self._handle, *self._reserved))
 
     def _check_obb_options(self) -> None:
         from boxmot_amd.basetracker import ASSO_NAMES
@@ -167,6 +170,7 @@ class DeepOcSort(BaseTracker):
 
     def reserve(self, max_tracks: int = 0, max_dets: int = 0) -> None:
         _lib.check(self._lib.boxmot_hip_deepocsort_reserve(self._handle, int(max_tracks), int(max_dets)))
+        self._reserved = (max(int(max_tracks), self._reserved[0]), max(int(max_dets), self._reserved[1]))      # re-applied if the handle is re-made
 
     def state_dump(self) -> dict:
         """Copy the live tracks back from the device in list order (parity tests / debugging)."""

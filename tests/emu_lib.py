@@ -83,6 +83,14 @@ class EmuHipLib:
         out_is_obb_ref._obj.value = int(rec["obb"])
         return 1
 
+    def boxmot_hip_botsort_reserve(self, h, max_tracks, max_dets):
+        """(emulated ABI: only before the first step -- the tables are simply made again at the larger size)"""
+        rec = self._handles[h]
+        rec["cap"], rec["nd"] = max(rec["cap"], max_tracks), max(rec["nd"], max_dets)
+        rec["emu"].close()
+        rec["emu"] = EmuBotSort(rec["cfg"], cap=rec["cap"], nd=rec["nd"], dim=rec["dim"], threads=self._threads, obb=rec["obb"])
+        return 1
+
     # ---- read-only introspection ----
     def boxmot_hip_botsort_capacity(self, h, a, b, c):
         rec = self._handles[h]

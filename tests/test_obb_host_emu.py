@@ -187,6 +187,16 @@ def test_ocsort_supports_obb_outputs_and_refuses_what_it_has_not(emulated_abi):
         trk.update(det, rgb)
 
 
+def test_a_reserve_made_before_the_layout_is_known_survives_the_switch(emulated_abi):
+    from boxmot_amd import BotSort
+    trk = BotSort(reid_model=None, with_reid=False, use_cmc=False, max_tracks=64, max_dets=32)
+    trk.reserve(max_tracks=256, max_dets=96)
+    assert trk.capacity()[:2] == (256, 96)
+    trk.update(np.array([[32, 32, 20, 10, 0.15, 0.95, 0]], dtype=np.float32), np.zeros((64, 64, 3), np.uint8))      # oriented: the handle is re-made
+    assert trk.is_obb and trk.capacity()[:2] == (256, 96)
+    trk.close()
+
+
 def test_track_results_names_the_oriented_columns():
     from boxmot_amd.track_results import TrackResults
     r = TrackResults(np.array([[320, 240, 80, 40, 0.15, 7, 0.95, 2, 0]], dtype=np.float32))
