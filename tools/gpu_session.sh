@@ -20,6 +20,7 @@
 #   warps      the device-step warp, StrongSORT and ReID GPU tests                -> pytest_warps.log
 #   ingest     tests/test_gpu_ingest.py                                        -> pytest_ingest.log
 #   hpab       every tools/_build/hp_prof_* binary (variants of the fp32-grade kernels built with -D switches) -> hp_ab.txt
+#   obb        the oriented-detection GPU tests + the reference-named ABI file, then tools/obb_step_time.py         -> pytest_obb.log, obb_step_time.txt
 # Counters are collected in their own --pmc passes, never together with a trace (profiles/README.md).  Summaries a round wants
 # judged are copied from gpurun_out/<tag>/ into profiles/ by hand.
 set -u
@@ -57,6 +58,8 @@ for cfg, kw in (('c3', dict(steps=16, warmup=6)), ('c5', dict(steps=8, warmup=10
 " >> $O/config_groups.jsonl 2> $O/groups.err; cut -c1-420 $O/config_groups.jsonl ;;
     warps)   timeout 600 python -m pytest tests/test_gpu_device_step_warps.py tests/test_gpu_strongsort.py tests/test_gpu_reid.py -q > $O/pytest_warps.log 2>&1; tail -n 3 $O/pytest_warps.log ;;
     ingest)  timeout 400 python -m pytest tests/test_gpu_ingest.py -q > $O/pytest_ingest.log 2>&1; tail -n 3 $O/pytest_ingest.log ;;
+    obb)     timeout 400 python -m pytest tests/test_gpu_obb.py tests/test_gpu_compat_abi.py -q > $O/pytest_obb.log 2>&1; tail -n 3 $O/pytest_obb.log
+             timeout 120 python tools/obb_step_time.py 150 > $O/obb_step_time.txt 2>&1; grep -v amdgpu.ids $O/obb_step_time.txt | tail -n 5 ;;
     hpab)    for b in tools/_build/hp_prof_*; do echo "## $b" >> $O/hp_ab.txt; timeout 120 $b 4096 5 >> $O/hp_ab.txt 2>&1; done; grep -c best $O/hp_ab.txt ;;
     *)       echo "unknown step $step" ;;
   esac
