@@ -20,32 +20,67 @@ class EmuHipLib:
 
     # ---- config / lifetime ----
     def boxmot_hip_botsort_default_config(self, ref):
-        pass        # BotSort.__init__ sets every field it uses
+        """the constructor defaults of BotSort, as boxmot_hip_botsort_default_config fills them (boxmot_hip.hip; botsort.py:66-86)"""
+        c = ref._obj
+        c.track_high_thresh, c.track_low_thresh, c.new_track_thresh, c.track_buffer = 0.5, 0.1, 0.6, 30
+        c.match_thresh, c.proximity_thresh, c.appearance_thresh, c.cmc_method = 0.8, 0.5, 0.25, None
+        c.frame_rate, c.fuse_first_associate, c.with_reid, c.max_obs = 30, 0, 1, 50
+        c.second_match_thresh, c.unconfirmed_match_thresh, c.unconfirmed_emb_scale, c.removed_stracks_buffer = 0.5, 0.7, 2.0, 100
+        c.n_streams, c.max_tracks, c.max_dets, c.emb_dim, c.n_class_lists, c.tracker_kind, c.is_obb = 1, 1024, 256, 512, 1, 0, 0
 
     def boxmot_hip_botsort_create(self, ref):
         c = ref._obj
-        if c.n_streams != 1 or c.n_class_lists != 1:
-            raise NotImplementedError("emulated ABI: one stream, one class list")
+        if c.n_class_lists != 1:
+            raise NotImplementedError("emulated ABI: one class list")
         cfg = {k: getattr(c, k) for k in CFG_D}
         cfg.update({k: getattr(c, k) for k in CFG_I if k != "kind"})
         cfg["kind"] = c.tracker_kind
         h = self._next
         self._next += 1
         obb = bool(c.is_obb)
-        self._handles[h] = dict(cfg=cfg, cap=c.max_tracks, nd=c.max_dets, dim=c.emb_dim, obb=obb,
-                                emu=EmuBotSort(cfg, cap=c.max_tracks, nd=c.max_dets, dim=c.emb_dim, threads=self._threads, obb=obb), warp=None)
+        mk = lambda: EmuBotSort(cfg, cap=c.max_tracks, nd=c.max_dets, dim=c.emb_dim, threads=self._threads, obb=obb)
+        # streams of a handle are independent trackers: one emulated step each (`emu` = stream 0, the single-stream entry points)
+        streams = [mk() for _ in range(c.n_streams)]
+        self._handles[h] = dict(cfg=cfg, cap=c.max_tracks, nd=c.max_dets, dim=c.emb_dim, obb=obb, emu=streams[0], streams=streams, warp=None)
         return h
 
     def boxmot_hip_botsort_destroy(self, h):
         rec = self._handles.pop(h, None)
         if rec:
-            rec["emu"].close()
+            for e in rec["streams"]:
+                e.close()
+
+    def boxmot_hip_botsort_update_batch(self, h, n_streams, det_ptrs, rows_ptr, emb_ptrs, emb_cols, img_ptrs, ir, ic, ch, out_ptrs, out_cap, out_rows_ptr):
+        """one frame of each of the first n_streams streams (include/boxmot_hip.h boxmot_hip_botsort_update_batch)"""
+        rec = self._handles[h]
+        dc, oc = (7, 9) if rec["obb"] else (6, 8)
+        rows = np.ctypeslib.as_array((ctypes.c_int32 * n_streams).from_address(rows_ptr))
+        out_rows = np.ctypeslib.as_array((ctypes.c_int32 * n_streams).from_address(out_rows_ptr))
+        for s in range(n_streams):
+            n = int(rows[s])
+            d = np.ctypeslib.as_array((ctypes.c_float * (n * dc)).from_address(det_ptrs[s])).reshape(n, dc).copy() if n else np.empty((0, dc), np.float32)
+            e = None
+            if emb_ptrs is not None and n:
+                e = np.ctypeslib.as_array((ctypes.c_float * (n * emb_cols)).from_address(emb_ptrs[s])).reshape(n, emb_cols).copy()
+            got = rec["streams"][s].update(d, e)
+            m = len(got)
+            assert m <= out_cap
+            o = np.ctypeslib.as_array((ctypes.c_float * (out_cap * 9)).from_address(out_ptrs[s])).reshape(out_cap, 9)
+            o[:m, 8] = 0
+            o[:m, :oc] = got
+            out_rows[s] = m
+        return 1
 
     def boxmot_hip_botsort_reset(self, h):
-        rec = self._handles[h]
-        rec["emu"].close()
-        rec["emu"] = EmuBotSort(rec["cfg"], cap=rec["cap"], nd=rec["nd"], dim=rec["dim"], threads=self._threads, obb=rec["obb"])
+        self._remake(self._handles[h])
         return 1
+
+    def _remake(self, rec):
+        for e in rec["streams"]:
+            e.close()
+        rec["streams"] = [EmuBotSort(rec["cfg"], cap=rec["cap"], nd=rec["nd"], dim=rec["dim"], threads=self._threads, obb=rec["obb"])
+                          for _ in rec["streams"]]
+        rec["emu"] = rec["streams"][0]
 
     def boxmot_hip_botsort_set_warp(self, h, stream, ptr):
         rec = self._handles[h]
@@ -87,8 +122,7 @@ class EmuHipLib:
         """(emulated ABI: only before the first step -- the tables are simply made again at the larger size)"""
         rec = self._handles[h]
         rec["cap"], rec["nd"] = max(rec["cap"], max_tracks), max(rec["nd"], max_dets)
-        rec["emu"].close()
-        rec["emu"] = EmuBotSort(rec["cfg"], cap=rec["cap"], nd=rec["nd"], dim=rec["dim"], threads=self._threads, obb=rec["obb"])
+        self._remake(rec)
         return 1
 
     # ---- read-only introspection ----

@@ -197,3 +197,28 @@ def test_frame_ring_close_refuses_while_host_views_are_held(monkeypatch):
     assert fake.destroyed == 1
     ring.close()                                    # idempotent
     assert fake.destroyed == 1
+
+
+def test_multi_stream_handle_over_the_emulated_abi_equals_per_stream_oracles(monkeypatch):
+    """boxmot_amd.streams.MultiStreamBotSort (the bench's tracker object) on the build container's CPU: update_batch over the emulated
+    ABI (tests/emu_lib.py: one emulated step per stream) -- every stream equals its own oracle, empty streams included."""
+    from boxmot_amd import _lib
+    from boxmot_amd.scenario import stress_frames
+    from boxmot_amd.streams import MultiStreamBotSort
+    from emu_lib import EmuHipLib
+    from oracle.botsort import BotSortOracle
+    lib = EmuHipLib()
+    monkeypatch.setattr(_lib, "load", lambda: lib)
+    monkeypatch.setattr(_lib, "last_error", lambda: lib.boxmot_hip_last_error().decode())
+    S, n = 3, 40
+    ms = MultiStreamBotSort(S, max_tracks=128, max_dets=64, emb_dim=32)
+    orcs = [BotSortOracle() for _ in range(S)]
+    frames = [list(stress_frames(n, seed=11 + s)) for s in range(S)]
+    for t in range(n):
+        got = ms.update_batch([frames[s][t][0] for s in range(S)], None, [frames[s][t][1] for s in range(S)])
+        for s in range(S):
+            want = np.asarray(orcs[s].update(frames[s][t][0].copy(), None, frames[s][t][1].copy()), dtype=np.float32).reshape(-1, 8)
+            g = np.asarray(got[s]).reshape(-1, 8)
+            assert g.shape == want.shape and np.array_equal(g[:, 4:], want[:, 4:]), (t, s)
+            assert np.allclose(g[:, :4], want[:, :4], rtol=0, atol=1e-3), (t, s)
+    ms.close()
