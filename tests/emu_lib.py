@@ -30,18 +30,17 @@ class EmuHipLib:
 
     def boxmot_hip_botsort_create(self, ref):
         c = ref._obj
-        if c.n_class_lists != 1:
-            raise NotImplementedError("emulated ABI: one class list")
         cfg = {k: getattr(c, k) for k in CFG_D}
         cfg.update({k: getattr(c, k) for k in CFG_I if k != "kind"})
         cfg["kind"] = c.tracker_kind
         h = self._next
         self._next += 1
         obb = bool(c.is_obb)
-        mk = lambda: EmuBotSort(cfg, cap=c.max_tracks, nd=c.max_dets, dim=c.emb_dim, threads=self._threads, obb=obb)
+        nl = int(c.n_class_lists)
+        mk = lambda: EmuBotSort(cfg, cap=c.max_tracks, nd=c.max_dets, dim=c.emb_dim, threads=self._threads, obb=obb, n_lists=nl)
         # streams of a handle are independent trackers: one emulated step each (`emu` = stream 0, the single-stream entry points)
         streams = [mk() for _ in range(c.n_streams)]
-        self._handles[h] = dict(cfg=cfg, cap=c.max_tracks, nd=c.max_dets, dim=c.emb_dim, obb=obb, emu=streams[0], streams=streams, warp=None)
+        self._handles[h] = dict(cfg=cfg, cap=c.max_tracks, nd=c.max_dets, dim=c.emb_dim, obb=obb, nl=nl, emu=streams[0], streams=streams, warp=None)
         return h
 
     def boxmot_hip_botsort_destroy(self, h):
@@ -78,7 +77,7 @@ class EmuHipLib:
     def _remake(self, rec):
         for e in rec["streams"]:
             e.close()
-        rec["streams"] = [EmuBotSort(rec["cfg"], cap=rec["cap"], nd=rec["nd"], dim=rec["dim"], threads=self._threads, obb=rec["obb"])
+        rec["streams"] = [EmuBotSort(rec["cfg"], cap=rec["cap"], nd=rec["nd"], dim=rec["dim"], threads=self._threads, obb=rec["obb"], n_lists=rec["nl"])
                           for _ in rec["streams"]]
         rec["emu"] = rec["streams"][0]
 
@@ -96,13 +95,13 @@ class EmuHipLib:
         if n and det_cols != dc:        # the library's wording (boxmot_hip.hip host_update)
             self._err = b"boxmot_hip live tracking supports AABB detections with 6 columns (7 with is_obb)."
             return 0
-        assert out_cols == 9 and class_list == 0 and frame_count_set < 0
+        assert out_cols == 9 and 0 <= class_list < rec["nl"]
         d = np.ctypeslib.as_array((ctypes.c_float * (n * dc)).from_address(dets)).reshape(n, dc).copy() if n else np.empty((0, dc), np.float32)
         e = None
         if embs and emb_rows:
             e = np.ctypeslib.as_array((ctypes.c_float * (emb_rows * emb_cols)).from_address(embs)).reshape(emb_rows, emb_cols).copy()
         try:
-            got = rec["emu"].update(d, e, warp=rec["warp"])
+            got = rec["emu"].update(d, e, warp=rec["warp"], class_list=class_list, frame_count=frame_count_set)
         except RuntimeError as exc:
             self._err = str(exc).encode()
             return 0

@@ -36,21 +36,21 @@ def build(sanitize: bool = False, dense: bool = False, threads: int = 64, obb: b
 
 
 class EmuBotSort:
-    def __init__(self, cfg: dict, cap=256, nd=64, dim=32, sanitize=False, dense=False, threads=64, obb=False):
+    def __init__(self, cfg: dict, cap=256, nd=64, dim=32, sanitize=False, dense=False, threads=64, obb=False, n_lists=1):
         self.lib = ctypes.CDLL(str(build(sanitize, dense, threads=threads, obb=obb)))
         self.det_cols, self.out_cols, self.kf_stride = (7, 9, 110) if obb else (6, 8, 72)
-        self.lib.emu_create.restype = ctypes.c_void_p
-        self.lib.emu_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
-        self.lib.emu_update.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
-                                        ctypes.c_void_p, ctypes.c_void_p]
+        self.lib.emu_create_lists.restype = ctypes.c_void_p
+        self.lib.emu_create_lists.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        self.lib.emu_update_list.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         self.lib.emu_dump.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 5
         self.lib.emu_destroy.argtypes = [ctypes.c_void_p]
         cd = np.array([cfg[k] for k in CFG_D], dtype=np.float64)
         ci = np.array([int(cfg.get(k, 0)) for k in CFG_I], dtype=np.int32)
         self.cap, self.nd, self.dim = cap, nd, dim
-        self.h = self.lib.emu_create(cd.ctypes.data, ci.ctypes.data, cap, nd, dim)
+        self.h = self.lib.emu_create_lists(cd.ctypes.data, ci.ctypes.data, cap, nd, dim, n_lists)
 
-    def update(self, dets, embs=None, warp=None):
+    def update(self, dets, embs=None, warp=None, class_list=0, frame_count=-1):
         if warp is not None:
             w = np.ascontiguousarray(warp, dtype=np.float64).reshape(6)
             self.lib.emu_set_warp.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
@@ -60,8 +60,8 @@ class EmuBotSort:
         e = None if embs is None else np.ascontiguousarray(embs, dtype=np.float32)
         out = np.zeros((self.nd, self.out_cols), dtype=np.float32)
         out_n = ctypes.c_int(0)
-        status = self.lib.emu_update(self.h, dets.ctypes.data, n, None if e is None else e.ctypes.data,
-                                     out.ctypes.data, ctypes.byref(out_n))
+        status = self.lib.emu_update_list(self.h, dets.ctypes.data, n, None if e is None else e.ctypes.data,
+                                          out.ctypes.data, ctypes.byref(out_n), int(class_list), int(frame_count))
         if status != 0:
             raise RuntimeError(f"emulated kernel status {status}")
         return out[: out_n.value].copy()

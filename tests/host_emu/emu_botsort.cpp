@@ -45,6 +45,7 @@ struct Emu {
     int cap, nd, dim;
     float* dets; int* n_dets; float* embs; float* out; int* out_n;
     double* warp; int* warp_flag;
+    int* list_sel; int* fc_set;
     EmuBlock block;
 };
 
@@ -66,12 +67,15 @@ void* thread_main(void* p) {
 
 extern "C" {
 
-void* emu_create(const double* cd, const int* ci, int cap, int nd, int dim) {
+// n_lists: per-class active lists (per_class=True: basetracker.py:223-263; 1 otherwise)
+void* emu_create_lists(const double* cd, const int* ci, int cap, int nd, int dim, int n_lists);
+void* emu_create(const double* cd, const int* ci, int cap, int nd, int dim) { return emu_create_lists(cd, ci, cap, nd, dim, 1); }
+void* emu_create_lists(const double* cd, const int* ci, int cap, int nd, int dim, int n_lists) {
     Emu* e = new Emu();
     e->cap = cap; e->nd = nd; e->dim = dim;
     e->args.cfg = bm::make_config_dev(cd[0], cd[1], cd[2], cd[3], cd[4], cd[5], cd[6], cd[7], cd[8], ci[0], ci[1], ci[2],
                                       ci[3], ci[4], ci[5]);
-    bm::BotSortSizes z{1, cap, nd, dim, 1, ci[4] > 0 ? ci[4] : 1, EMU_OBB};
+    bm::BotSortSizes z{1, cap, nd, dim, n_lists, ci[4] > 0 ? ci[4] : 1, EMU_OBB};
     bm::botsort_allocate(e->args, z, e->alloc);
     e->dets = e->alloc.get<float>((size_t)nd * geo::DET_COLS);
     e->n_dets = e->alloc.get<int>(1);
@@ -79,6 +83,7 @@ void* emu_create(const double* cd, const int* ci, int cap, int nd, int dim) {
     e->out = e->alloc.get<float>((size_t)nd * geo::OUT_COLS);
     e->out_n = e->alloc.get<int>(1);
     e->args.dets = e->dets; e->args.n_dets = e->n_dets; e->args.embs = e->embs;
+    e->list_sel = e->alloc.get<int>(1); e->fc_set = e->alloc.get<int>(1);
     e->args.list_sel = nullptr; e->args.frame_count_set = nullptr;
     e->args.out = e->out; e->args.out_n = e->out_n; e->args.stream_base = 0; e->args.phase_clock = nullptr;
     e->warp = e->alloc.get<double>(6);
@@ -102,10 +107,18 @@ void emu_set_warp(void* h, const double* w) {
     e->warp_flag[0] = 1;
 }
 
-// returns the status word; out rows (n_out, 8)
+// returns the status word; out rows (n_out, 8).  class_list: the active list of this call; frame_count >= 0 presets the frame counter
+// (the per-class fan-out rewinds it for every class), -1 leaves it alone
+int emu_update_list(void* h, const float* dets, int n, const float* embs, float* out, int* out_n, int class_list, int frame_count);
 int emu_update(void* h, const float* dets, int n, const float* embs, float* out, int* out_n) {
+    return emu_update_list(h, dets, n, embs, out, out_n, 0, -1);
+}
+int emu_update_list(void* h, const float* dets, int n, const float* embs, float* out, int* out_n, int class_list, int frame_count) {
     Emu* e = static_cast<Emu*>(h);
     if (n > e->nd) return -1;
+    e->list_sel[0] = class_list; e->fc_set[0] = frame_count;
+    e->args.list_sel = e->list_sel;
+    e->args.frame_count_set = frame_count >= 0 ? e->fc_set : nullptr;
     std::memcpy(e->dets, dets, (size_t)n * geo::DET_COLS * 4);
     if (embs) std::memcpy(e->embs, embs, (size_t)n * e->dim * 4);
     e->n_dets[0] = n;
