@@ -148,20 +148,23 @@ class EmuHipLib:
     def boxmot_hip_deepocsort_create(self, ref):
         from emu_util import ASSO_MODES, EmuDeepOcSort
         c = ref._obj
-        if c.n_streams != 1 or not c.embedding_off:
-            raise NotImplementedError("emulated ABI: one stream, embedding_off")
+        if c.n_streams != 1:
+            raise NotImplementedError("emulated ABI: one stream")
+        if c.is_obb and not c.embedding_off:
+            self._err = b"boxmot_hip: oriented detections run on OC-SORT (embedding_off = 1); DeepOCSORT takes axis-aligned boxes only"
+            return None
         if c.is_obb and c.asso_func != 0:
             self._err = b"boxmot_hip: the oriented step has the rotated IoU only (asso_func must be BOXMOT_HIP_ASSO_IOU)"
             return None
         names = {v: k for k, v in ASSO_MODES.items()}
         cfg = dict(det_thresh=c.det_thresh, iou_threshold=c.iou_threshold, inertia=c.inertia, w_association_emb=c.w_association_emb,
                    alpha_fixed_emb=c.alpha_fixed_emb, aw_param=c.aw_param, Q_xy_scaling=c.Q_xy_scaling, Q_s_scaling=c.Q_s_scaling,
-                   min_conf=c.min_conf, max_age=c.max_age, min_hits=c.min_hits, delta_t=c.delta_t, embedding_off=1, aw_off=c.aw_off,
+                   min_conf=c.min_conf, max_age=c.max_age, min_hits=c.min_hits, delta_t=c.delta_t, embedding_off=int(c.embedding_off), aw_off=c.aw_off,
                    use_byte=c.use_byte, asso_func=names[c.asso_func], frame_wh=(c.frame_w, c.frame_h))
         h = self._next
         self._next += 1
-        rec = dict(cfg=cfg, cap=c.max_tracks, nd=c.max_dets, obb=bool(c.is_obb), kind="docs")
-        rec["emu"] = EmuDeepOcSort(cfg, cap=rec["cap"], nd=rec["nd"], dim=1, threads=self._threads, obb=rec["obb"])
+        rec = dict(cfg=cfg, cap=c.max_tracks, nd=c.max_dets, dim=1 if c.embedding_off else int(c.emb_dim), obb=bool(c.is_obb), kind="docs")
+        rec["emu"] = EmuDeepOcSort(cfg, cap=rec["cap"], nd=rec["nd"], dim=rec["dim"], threads=self._threads, obb=rec["obb"])
         self._handles[h] = rec
         return h
 
@@ -174,7 +177,7 @@ class EmuHipLib:
         from emu_util import EmuDeepOcSort
         rec = self._handles[h]
         rec["emu"].close()
-        rec["emu"] = EmuDeepOcSort(rec["cfg"], cap=rec["cap"], nd=rec["nd"], dim=1, threads=self._threads, obb=rec["obb"])
+        rec["emu"] = EmuDeepOcSort(rec["cfg"], cap=rec["cap"], nd=rec["nd"], dim=rec["dim"], threads=self._threads, obb=rec["obb"])
         return 1
 
     def boxmot_hip_deepocsort_update_stream(self, h, stream, frame_count_set, id_count_ref, dets, n, det_cols, embs, emb_rows, emb_cols,
@@ -187,8 +190,11 @@ class EmuHipLib:
             return 0
         assert out_cols == 9 and stream == 0 and frame_count_set < 0 and id_count_ref is None
         d = np.ctypeslib.as_array((ctypes.c_float * (n * dc)).from_address(dets)).reshape(n, dc).copy() if n else np.empty((0, dc), np.float32)
+        e = None
+        if embs and emb_rows and not rec["cfg"]["embedding_off"]:
+            e = np.ctypeslib.as_array((ctypes.c_float * (emb_rows * emb_cols)).from_address(embs)).reshape(emb_rows, emb_cols).copy()
         try:
-            got = rec["emu"].update(d, None)
+            got = rec["emu"].update(d, e)
         except RuntimeError as exc:
             self._err = str(exc).encode()
             return 0

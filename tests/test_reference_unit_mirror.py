@@ -192,3 +192,35 @@ def test_per_class_tracking_over_the_emulated_abi(emulated_abi, kind):
         rows += len(want)
     assert rows > 100
     _close(ours)
+
+
+@pytest.mark.skipif(not ref_harness.reference_available(), reason="/root/reference is not mounted")
+@pytest.mark.parametrize("kind,kw", [("ocsort", {}), ("ocsort", dict(use_byte=True, max_age=8, min_hits=1)),
+                                     ("deepocsort", {}), ("deepocsort", dict(aw_off=True, inertia=0.4, w_association_emb=0.75))])
+def test_ocsort_and_deepocsort_host_classes_beside_the_reference_classes(emulated_abi, kind, kw):
+    """boxmot_amd.OcSort / DeepOcSort (embeddings supplied, cmc off) over the emulated DeepOCSORT step: OcSort against the reference class
+    run beside it on the same frames, DeepOcSort against the oracle pinned on the reference class."""
+    from boxmot_amd import DeepOcSort, OcSort
+    from boxmot_amd.scenario import stress_frames
+    from common import assert_rows_match
+    img = np.zeros((480, 640, 3), dtype=np.uint8)
+    if kind == "ocsort":
+        ours, ref = OcSort(max_tracks=128, max_dets=64, **kw), ref_harness.load_ocsort()(**kw)
+    else:
+        # the reference DeepOcSort constructs a ReID backend from weights in its constructor: the oracle (pinned on it bit for bit with
+        # a stubbed backend, tests/test_oracle_vs_reference.py) stands in
+        from oracle.deepocsort import DeepOcSortOracle
+        ours, ref = DeepOcSort(reid_model=None, cmc_off=True, max_tracks=128, max_dets=64, emb_dim=32, **kw), DeepOcSortOracle(**kw)
+    rows = 0
+    for t, (dets, embs) in enumerate(stress_frames(80, seed=6)):
+        if kind == "ocsort":
+            got, want = ours.update(dets, img), ref.update(dets.copy(), img)
+        else:
+            got, want = ours.update(dets, img, embs), ref.update(dets.copy(), img, embs.copy())
+        want = np.asarray(want, dtype=np.float32)
+        assert np.asarray(got).size == want.size, t
+        if want.size:
+            assert_rows_match(np.asarray(got).reshape(-1, 8), want.reshape(-1, 8), t, box_atol=1e-3)
+            rows += len(want.reshape(-1, 8))
+    assert rows > 150
+    _close(ours)
