@@ -223,5 +223,72 @@ class EmuHipLib:
         fc._obj.value, ic._obj.value = int(d["counters"][0]), int(d["counters"][1])
         return 1
 
+    # ---- StrongSORT (boxmot_hip_strongsort_*): one stream, embeddings supplied ----
+    def boxmot_hip_strongsort_default_config(self, ref):
+        pass        # StrongSort.__init__ sets every field it uses
+
+    def boxmot_hip_strongsort_create(self, ref):
+        from emu_util import EmuStrongSort
+        c = ref._obj
+        if c.n_streams != 1 or c.reid_model_path:
+            raise NotImplementedError("emulated ABI: one stream, embeddings from the caller")
+        cfg = dict(min_conf=c.min_conf, max_cos_dist=c.max_cos_dist, max_iou_dist=c.max_iou_dist, mc_lambda=c.mc_lambda, ema_alpha=c.ema_alpha,
+                   max_age=c.max_age, n_init=c.n_init, nn_budget=c.nn_budget)
+        h = self._next
+        self._next += 1
+        rec = dict(cfg=cfg, cap=c.max_tracks, nd=c.max_dets, dim=int(c.emb_dim), kind="ss", warp=None)
+        rec["emu"] = EmuStrongSort(cfg, cap=rec["cap"], nd=rec["nd"], dim=rec["dim"], threads=self._threads)
+        self._handles[h] = rec
+        return h
+
+    def boxmot_hip_strongsort_destroy(self, h):
+        rec = self._handles.pop(h, None)
+        if rec:
+            rec["emu"].close()
+
+    def boxmot_hip_strongsort_reset(self, h):
+        from emu_util import EmuStrongSort
+        rec = self._handles[h]
+        rec["emu"].close()
+        rec["emu"] = EmuStrongSort(rec["cfg"], cap=rec["cap"], nd=rec["nd"], dim=rec["dim"], threads=self._threads)
+        return 1
+
+    def boxmot_hip_strongsort_set_warp(self, h, stream, ptr):
+        rec = self._handles[h]
+        rec["warp"] = None if not ptr else np.ctypeslib.as_array((ctypes.c_double * 6).from_address(ptr)).copy().reshape(2, 3)
+        return 1
+
+    def boxmot_hip_strongsort_update(self, h, dets, n, det_cols, embs, emb_rows, emb_cols, img, rows, cols, ch, out, out_cap, out_cols,
+                                     out_rows_ref, out_is_obb_ref):
+        rec = self._handles[h]
+        if n and det_cols != 6:
+            self._err = b"boxmot_hip live tracking supports AABB detections with 6 columns."
+            return 0
+        assert out_cols == 9
+        d = np.ctypeslib.as_array((ctypes.c_float * (n * 6)).from_address(dets)).reshape(n, 6).copy() if n else np.empty((0, 6), np.float32)
+        e = np.zeros((n, rec["dim"]), np.float32)
+        if embs and emb_rows:
+            e = np.ctypeslib.as_array((ctypes.c_float * (emb_rows * emb_cols)).from_address(embs)).reshape(emb_rows, emb_cols).copy()
+        try:
+            got = rec["emu"].update(d, e, warp=rec["warp"])
+        except RuntimeError as exc:
+            self._err = str(exc).encode()
+            return 0
+        rec["warp"] = None
+        m = len(got)
+        if m > out_cap:
+            self._err = b"boxmot_hip: output buffer is too small for the current frame."
+            return 0
+        o = np.ctypeslib.as_array((ctypes.c_float * (out_cap * 9)).from_address(out)).reshape(out_cap, 9)
+        o[:m, 8] = 0
+        o[:m, :8] = got
+        out_rows_ref._obj.value = m
+        out_is_obb_ref._obj.value = 0
+        return 1
+
+    def boxmot_hip_strongsort_track_count(self, h, stream, ref):
+        ref._obj.value = int(self._handles[h]["emu"].dump()["n"])
+        return 1
+
     def boxmot_hip_last_error(self):
         return self._err

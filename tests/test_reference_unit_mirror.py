@@ -224,3 +224,39 @@ def test_ocsort_and_deepocsort_host_classes_beside_the_reference_classes(emulate
             rows += len(want.reshape(-1, 8))
     assert rows > 150
     _close(ours)
+
+
+@pytest.mark.parametrize("kw,with_cmc", [({}, False), (dict(max_age=5, n_init=1, nn_budget=3), True)])
+def test_strongsort_host_class_over_the_emulated_abi(emulated_abi, kw, with_cmc):
+    """boxmot_amd.StrongSort (embeddings supplied) over the emulated StrongSORT kernels against the oracle pinned on the reference class;
+    with a camera-motion provider: asked only while tracks exist (strongsort.py:83-86), its warp applied by the step (Track.camera_update)."""
+    from boxmot_amd import StrongSort
+    from boxmot_amd.scenario import camera_warps, stress_frames
+    from common import assert_rows_match
+    from oracle.strongsort import StrongSortOracle
+    n = 45
+    warps = camera_warps(n, seed=7)
+
+    class Provider:
+        def __init__(self):
+            self.calls = []
+
+        def apply(self, img, dets):
+            self.calls.append(len(self.calls))
+            return warps[self.t]
+    prov = Provider() if with_cmc else None
+    ours = StrongSort(reid_model=None, cmc=prov, max_tracks=128, max_dets=64, emb_dim=32, **kw)
+    orc = StrongSortOracle(**kw)
+    img = np.zeros((480, 640, 3), dtype=np.uint8)
+    asked = 0
+    for t, (dets, embs) in enumerate(stress_frames(n, seed=7)):
+        if prov is not None:
+            prov.t = t
+        had_tracks = len(orc.dump()["id"]) >= 1
+        want = orc.update(dets.copy(), None, embs.copy(), warp=warps[t] if (with_cmc and had_tracks) else None)
+        got = ours.update(dets, img, embs)
+        asked += int(with_cmc and had_tracks)
+        assert_rows_match(np.asarray(got).reshape(-1, 8), np.asarray(want, dtype=np.float32).reshape(-1, 8), t)
+    if prov is not None:
+        assert len(prov.calls) == asked and asked > 20
+    _close(ours)
