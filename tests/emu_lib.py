@@ -57,9 +57,12 @@ class EmuHipLib:
         out_rows = np.ctypeslib.as_array((ctypes.c_int32 * n_streams).from_address(out_rows_ptr))
         for s in range(n_streams):
             n = int(rows[s])
+            if n < 0:                       # det_rows = -1: the stream is not stepped in this call
+                out_rows[s] = 0
+                continue
             d = np.ctypeslib.as_array((ctypes.c_float * (n * dc)).from_address(det_ptrs[s])).reshape(n, dc).copy() if n else np.empty((0, dc), np.float32)
             e = None
-            if emb_ptrs is not None and n:
+            if emb_ptrs is not None and n and emb_ptrs[s]:
                 e = np.ctypeslib.as_array((ctypes.c_float * (n * emb_cols)).from_address(emb_ptrs[s])).reshape(n, emb_cols).copy()
             got = rec["streams"][s].update(d, e)
             m = len(got)
@@ -143,13 +146,70 @@ class EmuHipLib:
 
     # ---- OC-SORT / DeepOCSORT without appearance (boxmot_hip_deepocsort_*): one stream, embedding_off ----
     def boxmot_hip_deepocsort_default_config(self, ref):
-        pass        # DeepOcSort.__init__ sets every field it uses
+        """the constructor defaults of DeepOcSort, as boxmot_hip_deepocsort_default_config fills them (deepocsort.py:263-281)"""
+        c = ref._obj
+        c.det_thresh, c.max_age, c.max_obs, c.min_hits, c.iou_threshold = 0.3, 30, 50, 3, 0.3
+        c.delta_t, c.inertia, c.w_association_emb, c.alpha_fixed_emb, c.aw_param = 3, 0.2, 0.5, 0.95, 0.5
+        c.embedding_off, c.cmc_off, c.aw_off, c.Q_xy_scaling, c.Q_s_scaling, c.reid_model_path = 0, 0, 0, 0.01, 0.0001, None
+        c.n_streams, c.max_tracks, c.max_dets, c.emb_dim, c.use_byte, c.min_conf = 1, 1024, 256, 512, 0, 0.1
+        c.asso_func, c.frame_w, c.frame_h, c.is_obb = 0, 0, 0, 0
+
+    def boxmot_hip_bytetrack_default_config(self, ref):
+        """boxmot_hip_bytetrack_default_config: ByteTrack's constructor defaults in the shared configuration (bytetrack.py:225-233)"""
+        self.boxmot_hip_botsort_default_config(ref)
+        c = ref._obj
+        c.tracker_kind, c.track_low_thresh, c.track_high_thresh, c.new_track_thresh = 1, 0.1, 0.45, 0.45
+        c.match_thresh, c.track_buffer, c.frame_rate, c.second_match_thresh, c.unconfirmed_match_thresh = 0.8, 25, 30, 0.5, 0.7
+        c.with_reid, c.fuse_first_associate, c.emb_dim = 0, 1, 1
+
+    # one emulated step per stream; stream 0 is rec["emu"], the others are made when a batch call first touches them
+    def _stream_emu(self, rec, s):
+        if s == 0:
+            return rec["emu"]
+        extra = rec.setdefault("extra", {})
+        if s not in extra:
+            if rec["kind"] == "docs":
+                from emu_util import EmuDeepOcSort
+                extra[s] = EmuDeepOcSort(rec["cfg"], cap=rec["cap"], nd=rec["nd"], dim=rec["dim"], threads=self._threads, obb=rec["obb"])
+            else:
+                from emu_util import EmuStrongSort
+                extra[s] = EmuStrongSort(rec["cfg"], cap=rec["cap"], nd=rec["nd"], dim=rec["dim"], threads=self._threads)
+        return extra[s]
+
+    def _update_batch(self, h, n_streams, det_ptrs, rows_ptr, emb_ptrs, emb_cols, out_ptrs, out_cap, out_rows_ptr, cols_in, cols_out):
+        rec = self._handles[h]
+        rows = np.ctypeslib.as_array((ctypes.c_int32 * n_streams).from_address(rows_ptr))
+        out_rows = np.ctypeslib.as_array((ctypes.c_int32 * n_streams).from_address(out_rows_ptr))
+        use_emb = rec["kind"] == "ss" or not rec["cfg"]["embedding_off"]
+        for s in range(n_streams):
+            n = int(rows[s])
+            if n < 0:                       # det_rows = -1: the stream is not stepped in this call
+                out_rows[s] = 0
+                continue
+            d = np.ctypeslib.as_array((ctypes.c_float * (n * cols_in)).from_address(det_ptrs[s])).reshape(n, cols_in).copy() if n else np.empty((0, cols_in), np.float32)
+            e = np.zeros((n, rec["dim"]), np.float32) if rec["kind"] == "ss" else None
+            if use_emb and emb_ptrs is not None and n and emb_ptrs[s]:
+                e = np.ctypeslib.as_array((ctypes.c_float * (n * emb_cols)).from_address(emb_ptrs[s])).reshape(n, emb_cols).copy()
+            got = self._stream_emu(rec, s).update(d, e)
+            m = len(got)
+            assert m <= out_cap
+            o = np.ctypeslib.as_array((ctypes.c_float * (out_cap * 9)).from_address(out_ptrs[s])).reshape(out_cap, 9)
+            o[:m, 8] = 0
+            o[:m, :cols_out] = got
+            out_rows[s] = m
+        return 1
+
+    def boxmot_hip_deepocsort_update_batch(self, h, n_streams, det_ptrs, rows_ptr, emb_ptrs, emb_cols, img_ptrs, ir, ic, ch, out_ptrs, out_cap, out_rows_ptr):
+        rec = self._handles[h]
+        return self._update_batch(h, n_streams, det_ptrs, rows_ptr, emb_ptrs, emb_cols, out_ptrs, out_cap, out_rows_ptr,
+                                  7 if rec["obb"] else 6, 9 if rec["obb"] else 8)
+
+    def boxmot_hip_strongsort_update_batch(self, h, n_streams, det_ptrs, rows_ptr, emb_ptrs, emb_cols, img_ptrs, ir, ic, ch, out_ptrs, out_cap, out_rows_ptr):
+        return self._update_batch(h, n_streams, det_ptrs, rows_ptr, emb_ptrs, emb_cols, out_ptrs, out_cap, out_rows_ptr, 6, 8)
 
     def boxmot_hip_deepocsort_create(self, ref):
         from emu_util import ASSO_MODES, EmuDeepOcSort
         c = ref._obj
-        if c.n_streams != 1:
-            raise NotImplementedError("emulated ABI: one stream")
         if c.is_obb and not c.embedding_off:
             self._err = b"boxmot_hip: oriented detections run on OC-SORT (embedding_off = 1); DeepOCSORT takes axis-aligned boxes only"
             return None
@@ -172,6 +232,8 @@ class EmuHipLib:
         rec = self._handles.pop(h, None)
         if rec:
             rec["emu"].close()
+            for e in rec.get("extra", {}).values():
+                e.close()
 
     def boxmot_hip_deepocsort_reset(self, h):
         from emu_util import EmuDeepOcSort
@@ -225,13 +287,16 @@ class EmuHipLib:
 
     # ---- StrongSORT (boxmot_hip_strongsort_*): one stream, embeddings supplied ----
     def boxmot_hip_strongsort_default_config(self, ref):
-        pass        # StrongSort.__init__ sets every field it uses
+        """the constructor defaults of StrongSort, as boxmot_hip_strongsort_default_config fills them (strongsort.py:41-66)"""
+        c = ref._obj
+        c.max_age, c.min_conf, c.max_cos_dist, c.max_iou_dist, c.n_init, c.nn_budget = 30, 0.1, 0.2, 0.7, 3, 100
+        c.mc_lambda, c.ema_alpha, c.reid_model_path, c.n_streams, c.max_tracks, c.max_dets, c.emb_dim = 0.98, 0.9, None, 1, 1024, 256, 512
 
     def boxmot_hip_strongsort_create(self, ref):
         from emu_util import EmuStrongSort
         c = ref._obj
-        if c.n_streams != 1 or c.reid_model_path:
-            raise NotImplementedError("emulated ABI: one stream, embeddings from the caller")
+        if c.reid_model_path:
+            raise NotImplementedError("emulated ABI: embeddings from the caller")
         cfg = dict(min_conf=c.min_conf, max_cos_dist=c.max_cos_dist, max_iou_dist=c.max_iou_dist, mc_lambda=c.mc_lambda, ema_alpha=c.ema_alpha,
                    max_age=c.max_age, n_init=c.n_init, nn_budget=c.nn_budget)
         h = self._next
@@ -245,6 +310,8 @@ class EmuHipLib:
         rec = self._handles.pop(h, None)
         if rec:
             rec["emu"].close()
+            for e in rec.get("extra", {}).values():
+                e.close()
 
     def boxmot_hip_strongsort_reset(self, h):
         from emu_util import EmuStrongSort

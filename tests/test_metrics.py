@@ -124,3 +124,32 @@ def test_hip_replay_scores_like_the_reference_on_mot17_mini(kind):
         mot = got[seq]
         have = evaluate_mot(gt[seq], mot[mot[:, 0] <= n], n)
         assert have["summary"] == want["summary"], (seq, have["summary"], want["summary"])
+
+
+@pytest.mark.parametrize("kind", ["botsort", "bytetrack", "deepocsort", "strongsort", "ocsort"])
+def test_replay_over_the_emulated_abi_scores_like_the_reference_on_mot17_mini(monkeypatch, kind):
+    """The CPU twin of the GPU test above: boxmot_amd.replay (both MOT17-mini sequences as streams of one handle, update_batch) with the
+    C-ABI calls answered by the emulated device steps (tests/emu_lib.py) -> MOT rows -> HOTA / MOTA / IDF1: the same summary as the
+    reference trackers' own rows."""
+    from boxmot_amd import _lib
+    from boxmot_amd.metrics import evaluate_mot
+    from boxmot_amd.replay import CachedSequence, replay
+    from common import BOTSORT_YAML_DEFAULTS, mot17_embeddings
+    from emu_lib import EmuHipLib
+    from test_mot17_golden import _golden_rows
+    lib = EmuHipLib()
+    monkeypatch.setattr(_lib, "load", lambda: lib)
+    monkeypatch.setattr(_lib, "last_error", lambda: lib.boxmot_hip_last_error().decode())
+    g, gt = np.load(GOLDEN / "mot17_golden.npz"), np.load(GOLDEN / "mot17_mini_gt.npz")
+    seqs = []
+    for seq in ("MOT17-02-FRCNN", "MOT17-04-FRCNN"):
+        rows = g[seq + "_dets"]
+        seqs.append(CachedSequence(seq, np.arange(1, len(g[f"{seq}_botsort_counts"]) + 1), rows, mot17_embeddings(rows)))
+    kw = {k: v for k, v in BOTSORT_YAML_DEFAULTS.items() if k not in ("use_cmc", "cmc_method", "with_reid")} if kind == "botsort" else {}
+    got = replay(seqs, tracker_type=kind, max_tracks=256, max_dets=64, **kw)
+    for seq in ("MOT17-02-FRCNN", "MOT17-04-FRCNN"):
+        n = int(gt[seq][:, 0].max())
+        want = _score(_golden_rows(g, seq, kind), gt[seq], n)
+        mot = got[seq]
+        have = evaluate_mot(gt[seq], mot[mot[:, 0] <= n], n)
+        assert have["summary"] == want["summary"], (seq, have["summary"], want["summary"])
