@@ -51,3 +51,44 @@ def test_emulated_oriented_ocsort_step_matches_the_oracle(kw):
 
 def test_emulated_oriented_ocsort_step_four_wavefronts():
     _run(60, 9, threads=256, use_byte=True)
+
+
+def test_oriented_steps_under_the_address_and_ub_sanitizers():
+    """Both oriented frame steps (OC-SORT's with the BYTE round, BoT-SORT's with embeddings) compiled with -fsanitize=address,undefined
+    and run on small tables that fill up (capacity pressure, growth of the lists): no out-of-bounds access of the 6-wide observation /
+    5-wide box / 90- and 110-double filter rows, no undefined behaviour; results still equal to the oracles."""
+    import glob
+    import os
+    import subprocess
+    import sys
+    libasan = sorted(glob.glob("/usr/lib/gcc/x86_64-linux-gnu/*/libasan.so"))
+    if not libasan:
+        pytest.skip("libasan.so not found")
+    code = ("import sys; sys.path[:0]=['.', 'tests']\n"
+            "import numpy as np\n"
+            "from common import obb_frames\n"
+            "from boxmot_amd.scenario import stress_frames\n"
+            "from emu_util import EmuBotSort, EmuDeepOcSort\n"
+            "from oracle.botsort import DEFAULTS as BD\n"
+            "from oracle.botsort_obb import BotSortObbOracle\n"
+            "from oracle.deepocsort import DEFAULTS as DD\n"
+            "from oracle.ocsort_obb import OcSortObbOracle\n"
+            "kw = dict(use_byte=True, max_age=6, min_hits=1)\n"
+            "cfg = {**DD, **{k: v for k, v in kw.items() if k in DD}, 'embedding_off': 1, 'use_byte': 1, 'min_conf': 0.1, 'frame_wh': (640, 480)}\n"
+            "emu, orc = EmuDeepOcSort(cfg, cap=64, nd=32, dim=1, sanitize=True, obb=True), OcSortObbOracle(**kw)\n"
+            "for d in obb_frames(30, seed=7):\n"
+            "    g, w = emu.update(d[:32], None), np.asarray(orc.update(d[:32].copy()), dtype=np.float32).reshape(-1, 9)\n"
+            "    assert g.shape == w.shape and np.array_equal(g[:, 5:], w[:, 5:])\n"
+            "emu.close()\n"
+            "cfg = dict(BD); cfg.update(with_reid=True)\n"
+            "emu, orc = EmuBotSort(cfg, cap=64, nd=32, dim=32, sanitize=True, obb=True), BotSortObbOracle(with_reid=True)\n"
+            "embs = [e for _, e in stress_frames(30, seed=7)]\n"
+            "for t, d in enumerate(obb_frames(30, seed=7)):\n"
+            "    g = emu.update(d[:32], embs[t][:32])\n"
+            "    w = np.asarray(orc.update(d[:32].copy(), None, embs[t][:32].copy()), dtype=np.float32).reshape(-1, 9)\n"
+            "    assert g.shape == w.shape and np.array_equal(g[:, 5:], w[:, 5:])\n"
+            "emu.close()\nprint('ASAN-OK')\n")
+    env = dict(os.environ, LD_PRELOAD=libasan[-1], ASAN_OPTIONS="detect_leaks=0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900)
+    assert "ASAN-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
