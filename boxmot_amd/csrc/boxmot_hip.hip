@@ -526,11 +526,12 @@ void build(BoxMOTHipBotSort* h) {
     }
     h->is_obb = c.is_obb != 0;
     if (h->is_obb) {
-        // oriented detections (botsort.py:120-131, bytetrack.py:266-303).  The reference's camera-motion compensation of oriented
-        // tracks (STrack.multi_gmc_obb, botsort_track.py:197-230) refits each warped box with cv2.minAreaRect: not restated (no
-        // OpenCV offline to pin it on), so it is refused here rather than approximated.  Embeddings of oriented detections come
+        // oriented detections (botsort.py:120-131, bytetrack.py:266-303).  Camera motion: a warp supplied with set_warp is applied to
+        // the oriented tracks (STrack.multi_gmc_obb, botsort_track.py:197-230: kf_warp_wave of the oriented layout); the in-handle
+        // estimators mask by axis-aligned detection boxes and are not wired to oriented tables (the reference estimates on the
+        // enclosing boxes, botsort.py:147-158: the caller does that and supplies the warp).  Embeddings of oriented detections come
         // from the caller (the reference crops rotated rectangles with cv2.warpAffine, reid/backends/base_backend.py:92-118).
-        if (h->use_ecc || h->use_sof) throw std::runtime_error("boxmot_hip: camera-motion compensation is not applied to oriented detections (cmc_method must be none)");
+        if (h->use_ecc || h->use_sof) throw std::runtime_error("boxmot_hip: the in-handle camera-motion estimators take axis-aligned detections (cmc_method must be none on an oriented handle; supply the warp with boxmot_hip_botsort_set_warp)");
         if (c.reid_model_path && c.reid_model_path[0])
             throw std::runtime_error("boxmot_hip: an oriented-box handle takes embeddings from the caller (embs), not from in-handle ReID weights");
     }
@@ -1272,7 +1273,8 @@ void docs_build(BoxMOTHipDeepOcSort* h) {
         // oriented detections: OC-SORT (ocsort.py:332 supports_obb; DeepOcSort does not): no appearance, no camera motion, and the
         // association function is the rotated IoU (detection_layout.py:25-26 turns "iou" into "iou_obb")
         if (!c.embedding_off) throw std::runtime_error("boxmot_hip: oriented detections run on OC-SORT (embedding_off = 1); DeepOCSORT takes axis-aligned boxes only");
-        if (c.asso_func != BOXMOT_HIP_ASSO_IOU) throw std::runtime_error("boxmot_hip: the oriented step has the rotated IoU only (asso_func must be BOXMOT_HIP_ASSO_IOU)");
+        if (c.asso_func != BOXMOT_HIP_ASSO_IOU && c.asso_func != BOXMOT_HIP_ASSO_CENTROID)
+            throw std::runtime_error("boxmot_hip: the oriented step has the rotated IoU and the centroid distance (asso_func must be BOXMOT_HIP_ASSO_IOU or _CENTROID)");
         h->det_cols = bm::obb::DOCS_DET_COLS; h->out_cols = bm::obb::DOCS_OUT_COLS;
     }
     io_allocate(h, c.n_streams, c.max_tracks, c.max_dets, c.embedding_off ? 1 : c.emb_dim, !c.embedding_off);
@@ -1557,7 +1559,7 @@ int boxmot_hip_botsort_update_batch(BoxMOTHipBotSort* handle, int n_streams, con
         std::vector<StreamIn> in(n_streams);
         for (int s = 0; s < n_streams; ++s)
             in[s] = StreamIn{dets[s], det_rows[s], (embs && emb_cols > 0) ? embs[s] : nullptr, images ? images[s] : nullptr};
-        host_update(handle, 0, n_streams, in.data(), 6, emb_cols, image_rows, image_cols, image_channels, nullptr, nullptr,
+        host_update(handle, 0, n_streams, in.data(), handle->det_cols(), emb_cols, image_rows, image_cols, image_channels, nullptr, nullptr,
                     out_tracks, out_capacity_rows, out_rows);
     });
 }
@@ -1573,7 +1575,7 @@ int boxmot_hip_botsort_update_batch_frames(BoxMOTHipBotSort* handle, int n_strea
         if (!d_frames || image_rows < 1 || image_cols < 1) throw std::runtime_error("boxmot_hip: update_batch_frames needs device frames");
         std::vector<StreamIn> in(n_streams);
         for (int s = 0; s < n_streams; ++s) in[s] = StreamIn{dets[s], det_rows[s], (embs && emb_cols > 0) ? embs[s] : nullptr, nullptr};
-        host_update(handle, 0, n_streams, in.data(), 6, emb_cols, image_rows, image_cols, 3, nullptr, nullptr, out_tracks,
+        host_update(handle, 0, n_streams, in.data(), handle->det_cols(), emb_cols, image_rows, image_cols, 3, nullptr, nullptr, out_tracks,
                     out_capacity_rows, out_rows, d_frames);
     });
 }
@@ -1638,7 +1640,6 @@ int boxmot_hip_botsort_set_warp(BoxMOTHipBotSort* handle, int stream, const doub
         if (!handle) throw std::runtime_error("boxmot_hip BoT-SORT handle is null.");
         if (stream < 0 || stream >= handle->S) throw std::runtime_error("boxmot_hip: stream index out of range");
         if (warp_2x3 == nullptr) { handle->h_warp_flag[stream] = 0; return; }
-        if (handle->is_obb) throw std::runtime_error("boxmot_hip: camera-motion warps are not applied to oriented detections");
         for (int k = 0; k < 6; ++k) {
             if (!std::isfinite(warp_2x3[k])) throw std::runtime_error("boxmot_hip: camera-motion warp has non-finite entries");
             handle->h_warp[(size_t)stream * 6 + k] = warp_2x3[k];

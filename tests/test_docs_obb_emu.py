@@ -12,7 +12,7 @@ from oracle.ocsort_obb import OcSortObbOracle
 
 def _run(n_frames, seed, threads=64, check_every=0, **kw):
     cfg = {**DOCS_DEFAULTS, **{k: v for k, v in kw.items() if k in DOCS_DEFAULTS}, "embedding_off": 1,
-           "use_byte": int(kw.get("use_byte", False)), "min_conf": kw.get("min_conf", 0.1)}
+           "use_byte": int(kw.get("use_byte", False)), "min_conf": kw.get("min_conf", 0.1), "frame_wh": kw.get("frame_wh", (640, 480))}
     orc, emu = OcSortObbOracle(**kw), EmuDeepOcSort(cfg, cap=128, nd=64, dim=1, threads=threads, obb=True)
 
     def check_state(t):
@@ -43,7 +43,8 @@ def _run(n_frames, seed, threads=64, check_every=0, **kw):
 
 
 @pytest.mark.parametrize("kw", [{}, dict(use_byte=True), dict(max_age=5, min_hits=1, delta_t=2, inertia=0.4, iou_threshold=0.2),
-                                dict(use_byte=True, max_age=8, min_hits=1)])
+                                dict(use_byte=True, max_age=8, min_hits=1),
+                                dict(asso_func="centroid", frame_wh=(640, 480), iou_threshold=0.9, use_byte=True)])
 def test_emulated_oriented_ocsort_step_matches_the_oracle(kw):
     thawed = _run(100, 4, check_every=10, **kw)
     assert thawed > 3          # the observation-centric re-update (interpolated boxes incl. the angle) ran
