@@ -2601,15 +2601,24 @@ int boxmot_hip_strongsort_state_dump(BoxMOTHipStrongSort* handle, int stream, in
 // The embedding width is a create-time capacity of the device state; the reference learns it from the first embeddings it
 // sees.  The adapter therefore builds the inner handle at create when the width is known (ReID weights given: their feature
 // width; with_reid = 0: none needed) and otherwise at the first update that brings embeddings.
-struct BoxMOTBotSortHandle {
+// The reference's native trackers take a table of 6 (AABB) or 7 (OBB) columns per call (live_c_api.hpp:22-60: `detection.is_obb =
+// det_cols == 7`, out_is_obb = det_cols == 7, :147-149) and its Python wrappers fix the layout with the first table ("cannot switch
+// between AABB and OBB inputs", native/trackers/botsort.py).  A device handle is sized for one layout, so the adapters keep the
+// configuration, decide the layout with the first non-empty table and re-make the (still unused) inner handle when it is oriented.
+struct CompatLayout {
+    int layout = -1;                // -1 undecided, 0 axis-aligned, 1 oriented
+    bool stepped = false;           // an update has run on the inner handle: its layout is final
+    int empty_frames = 0;           // updates that only counted: before the inner handle exists (BoT-SORT without an embedding width yet,
+                                    // botsort.py:183) or 0 x 0 tables before the layout is known; replayed into the frame counter
+};
+struct BoxMOTBotSortHandle : CompatLayout {
     BoxMOTHipBotSortConfig cfg{};
     std::string reid_path, reid_pre, cmc;
-    int empty_frames = 0;           // updates seen before the inner handle exists (they advance the frame counter, botsort.py:183)
     BoxMOTHipBotSort* inner = nullptr;
     ~BoxMOTBotSortHandle() { delete inner; }
 };
-struct BoxMOTByteTrackHandle { BoxMOTHipBotSort* inner = nullptr; ~BoxMOTByteTrackHandle() { delete inner; } };
-struct BoxMOTOCSORTHandle { BoxMOTHipDeepOcSort* inner = nullptr; ~BoxMOTOCSORTHandle() { delete inner; } };
+struct BoxMOTByteTrackHandle : CompatLayout { BoxMOTHipBotSortConfig cfg{}; BoxMOTHipBotSort* inner = nullptr; ~BoxMOTByteTrackHandle() { delete inner; } };
+struct BoxMOTOCSORTHandle : CompatLayout { BoxMOTHipDeepOcSortConfig cfg{}; BoxMOTHipDeepOcSort* inner = nullptr; ~BoxMOTOCSORTHandle() { delete inner; } };
 
 namespace {
 int env_int(const char* name, int dflt) {
@@ -2618,6 +2627,23 @@ int env_int(const char* name, int dflt) {
     const int x = std::atoi(v);
     return x > 0 ? x : dflt;
 }
+// Layout of this call's table against the handle's: returns true when the inner handle has to be (re-)made with `is_obb`.
+// ValidateLiveDetectionShape (live_c_api.hpp:22-33): an empty 0 x 0 table is accepted and keeps the layout.
+bool compat_layout(CompatLayout* h, int det_rows, int det_cols, int& is_obb, const char* tracker) {
+    is_obb = h->layout == 1 ? 1 : 0;
+    if (det_rows < 0 || det_cols < 0) throw std::runtime_error("Negative matrix dimensions are not allowed.");
+    if (det_cols == 0 && det_rows == 0) return false;
+    if (det_cols != 6 && det_cols != 7)
+        throw std::runtime_error(std::string(tracker) + " live tracking expects detections with 6 (AABB) or 7 (OBB) columns.");
+    const int want = det_cols == 7 ? 1 : 0;
+    if (h->layout == want) return false;
+    if (h->layout >= 0 && h->stepped)
+        throw std::runtime_error(std::string(tracker) + ": cannot switch between AABB and OBB inputs");
+    h->layout = want;
+    is_obb = want;
+    return true;
+}
+
 void compat_build_inner(BoxMOTBotSortHandle* h, int emb_dim) {
     h->cfg.emb_dim = emb_dim;
     h->cfg.reid_model_path = h->reid_path.empty() ? nullptr : h->reid_path.c_str();
@@ -2625,6 +2651,7 @@ void compat_build_inner(BoxMOTBotSortHandle* h, int emb_dim) {
     h->cfg.cmc_method = h->cmc.empty() ? nullptr : h->cmc.c_str();
     BoxMOTHipBotSort* inner = boxmot_hip_botsort_create(&h->cfg);
     if (!inner) throw std::runtime_error(g_last_error);
+    delete h->inner;
     h->inner = inner;
 }
 // feature width declared in the header of an OSN1 weight blob (reid_layout.hpp)
@@ -2673,44 +2700,51 @@ BoxMOTBotSortHandle* boxmot_botsort_create(const BoxMOTBotSortConfig* c) {
 }
 void boxmot_botsort_destroy(BoxMOTBotSortHandle* h) { delete h; }
 int boxmot_botsort_reset(BoxMOTBotSortHandle* h) {
-    if (h && !h->inner) { h->empty_frames = 0; return guard([]() {}); }
+    if (h) { h->empty_frames = 0; h->stepped = false; h->layout = -1; }          // the next table decides the layout again
+    if (h && !h->inner) return guard([]() {});
     return boxmot_hip_botsort_reset(h ? h->inner : nullptr);
 }
 int boxmot_botsort_update(BoxMOTBotSortHandle* h, const float* dets, int det_rows, int det_cols, const float* embs,
                           int emb_rows, int emb_cols, const uint8_t* image, int image_rows, int image_cols,
                           int image_channels, float* out_tracks, int out_capacity_rows, int out_cols, int* out_rows,
                           int* out_is_obb) {
-    if (h && !h->inner) {
-        const int ok = guard([&]() {
-            if (embs == nullptr || emb_cols <= 0) {
-                if (det_rows > 0) throw std::runtime_error("BoTSORT: with_reid is set, no ReID weights were given and no embeddings were supplied.");
-                return;
-            }
-            compat_build_inner(h, emb_cols);
-        });
-        if (!ok) return 0;
-        if (!h->inner) {        // nothing to track yet and no width known: an empty frame
-            h->empty_frames += 1;
-            if (out_rows) *out_rows = 0;
-            if (out_is_obb) *out_is_obb = 0;
-            return 1;
+    if (!h) return boxmot_hip_botsort_update(nullptr, dets, det_rows, det_cols, embs, emb_rows, emb_cols, image, image_rows, image_cols,
+                                             image_channels, out_tracks, out_capacity_rows, out_cols, out_rows, out_is_obb);
+    const int ok = guard([&]() {
+        int is_obb = 0;
+        if (compat_layout(h, det_rows, det_cols, is_obb, "BoTSORT")) {
+            h->cfg.is_obb = is_obb;
+            if (h->inner) compat_build_inner(h, h->cfg.emb_dim);           // not stepped yet: the tables of the other layout
         }
-        if (h->empty_frames > 0) {      // the frames that went by count (a first detection on frame > 1 is not activated at once)
-            const int fc = h->empty_frames;
-            h->empty_frames = 0;
-            // the reference's estimator saw the empty frames (botsort.py:141-145 runs cmc.apply on every frame); there were no tracks to
-            // warp, so all that matters is that it sees THIS frame as its newest: run it although the frame counter is preset
-            h->inner->cmc_with_fc_set = true;
-            const int rc = boxmot_hip_botsort_update_stream(h->inner, 0, 0, fc, dets, det_rows, det_cols, embs, emb_rows, emb_cols, image,
-                                                            image_rows, image_cols, image_channels, out_tracks, out_capacity_rows, out_cols,
-                                                            out_rows, out_is_obb);
-            h->inner->cmc_with_fc_set = false;
-            return rc;
-        }
+        if (!h->inner && embs != nullptr && emb_cols > 0) compat_build_inner(h, emb_cols);
+        if (!h->inner && det_rows > 0)
+            throw std::runtime_error("BoTSORT: with_reid is set, no ReID weights were given and no embeddings were supplied.");
+    });
+    if (!ok) return 0;
+    if (det_rows == 0 && det_cols == 0) det_cols = h->layout == 1 ? 7 : 6;
+    if (!h->inner || (h->layout < 0 && det_rows == 0)) {        // nothing to track yet (no width / no layout known): the frame only counts
+        h->empty_frames += 1;
+        if (out_rows) *out_rows = 0;
+        if (out_is_obb) *out_is_obb = h->layout == 1 ? 1 : 0;
+        return 1;
     }
-    return boxmot_hip_botsort_update(h ? h->inner : nullptr, dets, det_rows, det_cols, embs, emb_rows, emb_cols, image,
-                                     image_rows, image_cols, image_channels, out_tracks, out_capacity_rows, out_cols,
-                                     out_rows, out_is_obb);
+    int rc;
+    if (h->empty_frames > 0) {      // the frames that went by count (a first detection on frame > 1 is not activated at once)
+        const int fc = h->empty_frames;
+        h->empty_frames = 0;
+        // the reference's estimator saw the empty frames (botsort.py:141-145 runs cmc.apply on every frame); there were no tracks to
+        // warp, so all that matters is that it sees THIS frame as its newest: run it although the frame counter is preset
+        h->inner->cmc_with_fc_set = true;
+        rc = boxmot_hip_botsort_update_stream(h->inner, 0, 0, fc, dets, det_rows, det_cols, embs, emb_rows, emb_cols, image,
+                                              image_rows, image_cols, image_channels, out_tracks, out_capacity_rows, out_cols,
+                                              out_rows, out_is_obb);
+        h->inner->cmc_with_fc_set = false;
+    } else {
+        rc = boxmot_hip_botsort_update(h->inner, dets, det_rows, det_cols, embs, emb_rows, emb_cols, image, image_rows, image_cols,
+                                       image_channels, out_tracks, out_capacity_rows, out_cols, out_rows, out_is_obb);
+    }
+    if (rc) h->stepped = true;
+    return rc;
 }
 #define BM_COMPAT_TIME(name, fn)                                                         \
     int name(BoxMOTBotSortHandle* h, double* out) {                                      \
@@ -2737,6 +2771,7 @@ BoxMOTByteTrackHandle* boxmot_bytetrack_create(const BoxMOTByteTrackConfig* c) {
         k.max_tracks = env_int("BOXMOT_HIP_MAX_TRACKS", 1024);
         k.max_dets = env_int("BOXMOT_HIP_MAX_DETS", 512);
         h = new BoxMOTByteTrackHandle();
+        h->cfg = k;
         h->inner = boxmot_hip_botsort_create(&k);
         if (!h->inner) throw std::runtime_error(g_last_error);
     });
@@ -2744,12 +2779,39 @@ BoxMOTByteTrackHandle* boxmot_bytetrack_create(const BoxMOTByteTrackConfig* c) {
     return h;
 }
 void boxmot_bytetrack_destroy(BoxMOTByteTrackHandle* h) { delete h; }
-int boxmot_bytetrack_reset(BoxMOTByteTrackHandle* h) { return boxmot_hip_botsort_reset(h ? h->inner : nullptr); }
+int boxmot_bytetrack_reset(BoxMOTByteTrackHandle* h) {
+    if (h) { h->empty_frames = 0; h->stepped = false; h->layout = -1; }
+    return boxmot_hip_botsort_reset(h ? h->inner : nullptr);
+}
 int boxmot_bytetrack_update(BoxMOTByteTrackHandle* h, const float* dets, int det_rows, int det_cols, const uint8_t* image,
                             int image_rows, int image_cols, int image_channels, float* out_tracks, int out_capacity_rows,
                             int out_cols, int* out_rows, int* out_is_obb) {
-    return boxmot_hip_botsort_update(h ? h->inner : nullptr, dets, det_rows, det_cols, nullptr, 0, 0, image, image_rows,
-                                     image_cols, image_channels, out_tracks, out_capacity_rows, out_cols, out_rows, out_is_obb);
+    if (!h) return boxmot_hip_botsort_update(nullptr, dets, det_rows, det_cols, nullptr, 0, 0, image, image_rows, image_cols,
+                                             image_channels, out_tracks, out_capacity_rows, out_cols, out_rows, out_is_obb);
+    const int ok = guard([&]() {
+        int is_obb = 0;
+        if (compat_layout(h, det_rows, det_cols, is_obb, "ByteTrack") && is_obb != h->cfg.is_obb) {
+            h->cfg.is_obb = is_obb;
+            BoxMOTHipBotSort* inner = boxmot_hip_botsort_create(&h->cfg);          // not stepped yet: the tables of the other layout
+            if (!inner) throw std::runtime_error(g_last_error);
+            delete h->inner;
+            h->inner = inner;
+        }
+    });
+    if (!ok) return 0;
+    if (det_rows == 0 && det_cols == 0) det_cols = h->layout == 1 ? 7 : 6;
+    if (h->layout < 0 && det_rows == 0) {          // a 0 x 0 table before the layout is known: the frame only counts
+        h->empty_frames += 1;
+        if (out_rows) *out_rows = 0;
+        if (out_is_obb) *out_is_obb = 0;
+        return 1;
+    }
+    const int fc = h->empty_frames > 0 ? h->empty_frames : -1;
+    h->empty_frames = 0;
+    const int rc = boxmot_hip_botsort_update_stream(h->inner, 0, 0, fc, dets, det_rows, det_cols, nullptr, 0, 0, image, image_rows,
+                                                    image_cols, image_channels, out_tracks, out_capacity_rows, out_cols, out_rows, out_is_obb);
+    if (rc) h->stepped = true;
+    return rc;
 }
 const char* boxmot_bytetrack_last_error() { return g_last_error.c_str(); }
 
@@ -2767,6 +2829,7 @@ BoxMOTOCSORTHandle* boxmot_ocsort_create(const BoxMOTOCSORTConfig* c) {
         k.max_tracks = env_int("BOXMOT_HIP_MAX_TRACKS", 1024);
         k.max_dets = env_int("BOXMOT_HIP_MAX_DETS", 512);
         h = new BoxMOTOCSORTHandle();
+        h->cfg = k;
         h->inner = boxmot_hip_deepocsort_create(&k);
         if (!h->inner) throw std::runtime_error(g_last_error);
     });
@@ -2774,12 +2837,39 @@ BoxMOTOCSORTHandle* boxmot_ocsort_create(const BoxMOTOCSORTConfig* c) {
     return h;
 }
 void boxmot_ocsort_destroy(BoxMOTOCSORTHandle* h) { delete h; }
-int boxmot_ocsort_reset(BoxMOTOCSORTHandle* h) { return boxmot_hip_deepocsort_reset(h ? h->inner : nullptr); }
+int boxmot_ocsort_reset(BoxMOTOCSORTHandle* h) {
+    if (h) { h->empty_frames = 0; h->stepped = false; h->layout = -1; }
+    return boxmot_hip_deepocsort_reset(h ? h->inner : nullptr);
+}
 int boxmot_ocsort_update(BoxMOTOCSORTHandle* h, const float* dets, int det_rows, int det_cols, const uint8_t* image,
                          int image_rows, int image_cols, int image_channels, float* out_tracks, int out_capacity_rows,
                          int out_cols, int* out_rows, int* out_is_obb) {
-    return boxmot_hip_deepocsort_update(h ? h->inner : nullptr, dets, det_rows, det_cols, nullptr, 0, 0, image, image_rows,
-                                        image_cols, image_channels, out_tracks, out_capacity_rows, out_cols, out_rows, out_is_obb);
+    if (!h) return boxmot_hip_deepocsort_update(nullptr, dets, det_rows, det_cols, nullptr, 0, 0, image, image_rows, image_cols,
+                                                image_channels, out_tracks, out_capacity_rows, out_cols, out_rows, out_is_obb);
+    const int ok = guard([&]() {
+        int is_obb = 0;
+        if (compat_layout(h, det_rows, det_cols, is_obb, "OCSORT") && is_obb != h->cfg.is_obb) {
+            h->cfg.is_obb = is_obb;
+            BoxMOTHipDeepOcSort* inner = boxmot_hip_deepocsort_create(&h->cfg);    // not stepped yet: the tables of the other layout
+            if (!inner) throw std::runtime_error(g_last_error);
+            delete h->inner;
+            h->inner = inner;
+        }
+    });
+    if (!ok) return 0;
+    if (det_rows == 0 && det_cols == 0) det_cols = h->layout == 1 ? 7 : 6;
+    if (h->layout < 0 && det_rows == 0) {          // a 0 x 0 table before the layout is known: the frame only counts
+        h->empty_frames += 1;
+        if (out_rows) *out_rows = 0;
+        if (out_is_obb) *out_is_obb = 0;
+        return 1;
+    }
+    const int fc = h->empty_frames > 0 ? h->empty_frames : -1;
+    h->empty_frames = 0;
+    const int rc = boxmot_hip_deepocsort_update_stream(h->inner, 0, fc, nullptr, dets, det_rows, det_cols, nullptr, 0, 0, image, image_rows,
+                                                       image_cols, image_channels, out_tracks, out_capacity_rows, out_cols, out_rows, out_is_obb);
+    if (rc) h->stepped = true;
+    return rc;
 }
 const char* boxmot_ocsort_last_error() { return g_last_error.c_str(); }
 
