@@ -232,3 +232,19 @@ def test_track_results_names_the_oriented_columns():
     assert r.to_mot_lines(3) == ["3,7,320.00,240.00,80.00,40.00,0.1500,0.950000,2,-1"]
     a = TrackResults(np.array([[1, 2, 3, 4, 7, 0.5, 1, 0]], dtype=np.float32))
     assert not a.is_obb and a.id.tolist() == [7]
+
+
+def test_oriented_multi_stream_handle_equals_per_stream_oracles(emulated_abi):
+    """MultiStreamBotSort(is_obb=True).update_batch over the emulated ABI: every stream's 9-column rows equal its own oracle's."""
+    from boxmot_amd.streams import MultiStreamBotSort
+    from oracle.botsort_obb import BotSortObbOracle
+    S, n = 3, 40
+    ms = MultiStreamBotSort(S, max_tracks=128, max_dets=64, emb_dim=1, is_obb=True, with_reid=False)
+    orcs = [BotSortObbOracle(with_reid=False) for _ in range(S)]
+    frames = [list(obb_frames(n, seed=4 + s)) for s in range(S)]
+    for t in range(n):
+        got = ms.update_batch([frames[s][t] for s in range(S)])
+        for s in range(S):
+            assert got[s].shape[1] == 9 and got[s].is_obb
+            _rows_match(got[s], orcs[s].update(frames[s][t].copy(), None, None), t)
+    ms.close()
