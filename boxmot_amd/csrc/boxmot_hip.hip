@@ -64,6 +64,28 @@ __global__ void __launch_bounds__(NTHR) botsort_obb_step_kernel(bm::BotSortStepA
     bm::obb::botsort_step_stream<NTHR>(args, args.stream_base + blockIdx.x, s_int, s_dbl, sA, sB, dyn_lds);
 }
 
+// BotSort._obb_detections_to_cmc_boxes (botsort.py:126-132 over STrack.obb_to_xyxy, botsort_track.py:159-174): the enclosing axis-aligned
+// box of every oriented detection of stream blockIdx.x + s0 -- what the reference hands its camera-motion estimator as the mask boxes --
+// from the four corners as cv2.boxPoints lays them out (fp32; w, h floored at 1e-4; the angle in degrees as the fp32 product np.degrees is)
+__global__ void obb_enclosing_boxes_kernel(const float* dets, const int* n_dets, int max_dets, float* boxes, int s0) {
+    const int s = s0 + blockIdx.x;
+    const int n = n_dets[s] > 0 ? n_dets[s] : 0;
+    const float* d = dets + (long)s * max_dets * bm::obb::DET_COLS;
+    float* o = boxes + (long)s * max_dets * 4;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        const float* r = d + j * bm::obb::DET_COLS;
+        const double rect[5] = {(double)r[0], (double)r[1], (double)r[2] > 1e-4 ? (double)r[2] : 1e-4, (double)r[3] > 1e-4 ? (double)r[3] : 1e-4, (double)r[4]};
+        double p[4][2];
+        bm::obb::obb_corners_deg(rect, (double)(r[4] * (180.0f / 3.14159274f)), p);
+        float x0 = (float)p[0][0], x1 = x0, y0 = (float)p[0][1], y1 = y0;
+        for (int k = 1; k < 4; ++k) {
+            const float x = (float)p[k][0], y = (float)p[k][1];
+            x0 = x < x0 ? x : x0; x1 = x > x1 ? x : x1; y0 = y < y0 ? y : y0; y1 = y > y1 ? y : y1;
+        }
+        o[j * 4 + 0] = x0; o[j * 4 + 1] = y0; o[j * 4 + 2] = x1; o[j * 4 + 3] = y1;
+    }
+}
+
 template <int NTHR>
 __global__ void __launch_bounds__(NTHR) deepocsort_step_kernel(bm::DocsStepArgs args) {
     __shared__ int s_int[bm::MAX_WAVES + 1];
@@ -274,6 +296,7 @@ struct BoxMOTHipBotSort {
     std::unique_ptr<bm::ReidEngine> reid;
     int reid_mode = 0, reid_pad = 0;
     bool is_obb = false;                         // oriented detections (7 columns in, 9 out, 10-state filter): config.is_obb
+    float* d_cmc_boxes = nullptr;                // [S][nd][4] enclosing boxes of the oriented detections: the SOF estimator's mask boxes
     int det_cols() const { return is_obb ? bm::obb::DET_COLS : bm::DET_COLS; }
     int out_cols() const { return is_obb ? bm::obb::OUT_COLS : bm::OUT_COLS; }
     int kf_stride() const { return is_obb ? bm::obb::KF_STRIDE : bm::KF_STRIDE; }
@@ -408,6 +431,8 @@ void alloc_det_io(BoxMOTHipBotSort* h) {
     h->d_crop_stream = zalloc<int>(S * nd, o);
     h->d_crop_boxes = zalloc<float>(S * nd * 4, o);
     h->d_crop_row = zalloc<int>(S * nd, o);
+    release(o, h->d_cmc_boxes);
+    h->d_cmc_boxes = h->is_obb ? zalloc<float>(S * nd * 4, o) : nullptr;
     h->h_dets.assign(S * nd * h->det_cols(), 0.f);
     h->h_out.assign(S * nd * h->out_cols(), 0.f);
 }
@@ -531,7 +556,7 @@ void build(BoxMOTHipBotSort* h) {
         // estimators mask by axis-aligned detection boxes and are not wired to oriented tables (the reference estimates on the
         // enclosing boxes, botsort.py:147-158: the caller does that and supplies the warp).  Embeddings of oriented detections come
         // from the caller (the reference crops rotated rectangles with cv2.warpAffine, reid/backends/base_backend.py:92-118).
-        if (h->use_ecc || h->use_sof) throw std::runtime_error("boxmot_hip: the in-handle camera-motion estimators take axis-aligned detections (cmc_method must be none on an oriented handle; supply the warp with boxmot_hip_botsort_set_warp)");
+        // (cmc_method ecc / sof run on an oriented handle too: SOF is masked by the enclosing boxes, obb_enclosing_boxes_kernel)
         if (c.reid_model_path && c.reid_model_path[0])
             throw std::runtime_error("boxmot_hip: an oriented-box handle takes embeddings from the caller (embs), not from in-handle ReID weights");
     }
@@ -855,6 +880,11 @@ void host_update(BoxMOTHipBotSort* h, int s0, int n, const StreamIn* in, int det
         for (int k = 0; k < n; ++k) {
             if (in[k].det_rows < 0) continue;
             const uint8_t* const* fp = (d_frames_ext ? d_frames_ext : h->d_frames) + (s0 + k);
+            if (h->is_obb) {        // botsort.py:147-158: the estimator sees the enclosing boxes of the oriented detections
+                hipLaunchKernelGGL(obb_enclosing_boxes_kernel, dim3(1), dim3(256), 0, h->stream, h->d_dets, h->d_ndets, nd, h->d_cmc_boxes, s0 + k);
+                sof_run(h->sof.get(), s0 + k, 1, fp, h->d_cmc_boxes + (size_t)(s0 + k) * nd * 4, h->d_ndets + s0 + k, nd, 4,
+                        h->h_warp.data() + (size_t)(s0 + k) * 6, nullptr);
+            } else
             sof_run(h->sof.get(), s0 + k, 1, fp, d_dets + (size_t)k * nd * DC, h->d_ndets + s0 + k, nd, DC,
                     h->h_warp.data() + (size_t)(s0 + k) * 6, nullptr);
             h->h_warp_flag[s0 + k] = 1;
@@ -1613,7 +1643,10 @@ int boxmot_hip_botsort_step_device(BoxMOTHipBotSort* handle, const float* d_dets
                 std::vector<double> w(6);
                 for (int s = 0; s < h->S; ++s) {
                     if (h->h_warp_flag[s]) continue;
-                    if (h->use_sof) sof_run(h->sof.get(), s, 1, d_frames + s, d_dets + (size_t)s * h->nd * bm::DET_COLS, d_det_rows + s, h->nd, bm::DET_COLS, w.data(), nullptr);
+                    if (h->use_sof && h->is_obb) {
+                        hipLaunchKernelGGL(obb_enclosing_boxes_kernel, dim3(1), dim3(256), 0, h->stream, d_dets, d_det_rows, h->nd, h->d_cmc_boxes, s);
+                        sof_run(h->sof.get(), s, 1, d_frames + s, h->d_cmc_boxes + (size_t)s * h->nd * 4, d_det_rows + s, h->nd, 4, w.data(), nullptr);
+                    } else if (h->use_sof) sof_run(h->sof.get(), s, 1, d_frames + s, d_dets + (size_t)s * h->nd * bm::DET_COLS, d_det_rows + s, h->nd, bm::DET_COLS, w.data(), nullptr);
                     else ecc_run_one(h->ecc.get(), s, d_frames + s, w.data(), nullptr);
                     for (int k = 0; k < 6; ++k) h->h_warp[(size_t)s * 6 + k] = w[k];
                     h->h_warp_flag[s] = 1;

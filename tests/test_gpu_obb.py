@@ -100,9 +100,10 @@ def test_c_abi_guards_of_the_oriented_handle():
     lib.boxmot_hip_botsort_default_config(ctypes.byref(cfg))
     assert cfg.is_obb == 0
     cfg.with_reid, cfg.max_tracks, cfg.max_dets, cfg.emb_dim, cfg.is_obb = 0, 64, 32, 1, 1
-    cfg.cmc_method = b"ecc"
-    assert not lib.boxmot_hip_botsort_create(ctypes.byref(cfg)) and "oriented" in _lib.last_error()
-    cfg.cmc_method = None
+    cfg.reid_model_path = b"/nonexistent/weights.bin"
+    cfg.with_reid = 1
+    assert not lib.boxmot_hip_botsort_create(ctypes.byref(cfg)) and "oriented" in _lib.last_error()       # in-handle ReID: embeddings come as embs
+    cfg.reid_model_path, cfg.with_reid = None, 0
     h = lib.boxmot_hip_botsort_create(ctypes.byref(cfg))
     assert h
     img = np.zeros((64, 64, 3), np.uint8)
@@ -180,6 +181,29 @@ def test_oriented_streams_in_one_handle_equal_single_stream_trackers():
     ms.close()
     for trk in singles:
         trk.close()
+
+
+@pytest.mark.parametrize("method", ["ecc", "sof"])
+def test_in_handle_estimators_on_an_oriented_handle_equal_the_estimator_objects(method):
+    """cmc_method = "ecc" / "sof" inside an oriented handle (SOF masked by the enclosing boxes computed on the device) against the same
+    estimator as a Python object handing its warp to set_warp (BotSort(cmc=...), which computes the enclosing boxes on the host): the same
+    warps, therefore the same rows."""
+    from boxmot_amd import BotSort
+    from boxmot_amd.cmc import get_cmc_method
+    from boxmot_amd.streams import MultiStreamBotSort
+    rng = np.random.default_rng(2)
+    base = rng.integers(0, 255, (480, 640, 3), dtype=np.uint8)
+    n = 40
+    frames = list(obb_frames(n, seed=6))
+    inside = MultiStreamBotSort(1, max_tracks=128, max_dets=64, emb_dim=1, is_obb=True, with_reid=False, cmc_method=method)
+    outside = BotSort(reid_model=None, with_reid=False, cmc=get_cmc_method(method)(), max_tracks=128, max_dets=64)
+    for t, d in enumerate(frames):
+        img = np.roll(base, (t % 5, 2 * (t % 3)), axis=(0, 1))
+        got = inside.update_batch([d], [img])[0]
+        want = outside.update(d, img)
+        assert got.shape == want.shape and np.array_equal(np.asarray(got), np.asarray(want)), t
+    inside.close()
+    outside.close()
 
 
 def test_ocsort_centroid_obb_matches_the_oracle():
