@@ -164,7 +164,7 @@ class EmuHipLib:
     # one emulated step per stream; stream 0 is rec["emu"], the others are made when a batch call first touches them
     def _stream_emu(self, rec, s):
         if s == 0:
-            return rec["emu"]
+            return self._docs_emu(rec) if rec["kind"] == "docs" else rec["emu"]
         extra = rec.setdefault("extra", {})
         if s not in extra:
             if rec["kind"] == "docs":
@@ -241,8 +241,8 @@ class EmuHipLib:
         rec = self._handles.pop(h, None)
         if rec and rec["emu"]:
             rec["emu"].close()
-            for e in rec.get("extra", {}).values():
-                e.close()
+        for e in (rec or {}).get("extra", {}).values():
+            e.close()
 
     def boxmot_hip_deepocsort_reset(self, h):
         rec = self._handles[h]
