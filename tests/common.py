@@ -128,6 +128,22 @@ def obb_frames(n_frames, seed):
         yield np.stack([cx, cy, w2, h2, a2, d[:, 4], d[:, 5]], axis=1).astype(np.float32)
 
 
+def obb_config2_frames(n_frames, emb_dim=32):
+    """BASELINE configuration 2's shape with ORIENTED detections: 64 detections per frame on 256 tracks, 1920 x 1080 (all 256 in the first
+    three frames), every box turned into (cx, cy, w, h, angle) with an angle that drifts slowly per object and occasional equivalent
+    re-parameterisations (w <-> h, angle + pi / 2).  Yields (dets (n, 7) fp32, embs (n, emb_dim) fp32)."""
+    from boxmot_amd.scenario import Scenario
+    sc = Scenario(64, 256, emb_dim=emb_dim, random_image=False)
+    rng = np.random.default_rng(11)
+    for t in range(n_frames):
+        d, e = sc.frame(t)
+        cx, cy, w, h = (d[:, 0] + d[:, 2]) / 2, (d[:, 1] + d[:, 3]) / 2, d[:, 2] - d[:, 0], d[:, 3] - d[:, 1]
+        ang = 0.5 * np.sin(0.03 * t + 0.002 * cx + 0.003 * cy) + rng.normal(0, 0.01, len(d))
+        flip = rng.random(len(d)) < 0.1
+        w2, h2, a2 = np.where(flip, h, w), np.where(flip, w, h), np.where(flip, ang + np.pi / 2, ang)
+        yield np.stack([cx, cy, w2, h2, a2, d[:, 4], d[:, 5]], axis=1).astype(np.float32), e
+
+
 def obb_golden_rows(key):
     """Per-frame 9-column rows of the reference ByteTrack / BotSort fed oriented detections (tests/golden/obb_golden.npz, written by
     tests/golden/make_obb_golden.py) and the frame count / seed that regenerate the inputs with obb_frames."""

@@ -50,6 +50,27 @@ def main():
         out[key + "_rows"] = np.concatenate(rows).astype(np.float32)
         print(key, sum(counts), "rows", flush=True)
     np.savez_compressed(Path(__file__).resolve().parent / "obb_golden.npz", frames=np.int32(FRAMES), seed=np.int32(SEED), **out)
+    # the same three trackers at BASELINE configuration 2's shape (64 detections on 256 tracks, 1080p): tests/golden/obb_config2_golden.npz
+    from common import obb_config2_frames
+    big, n = {}, 60
+    scene = list(obb_config2_frames(n))
+    img = np.zeros((1080, 1920, 3), np.uint8)
+    for key, (kind, kw) in {"bytetrack": ("bytetrack", {}), "botsort_reid": ("botsort", dict(with_reid=True)), "ocsort": ("ocsort", dict(use_byte=True))}.items():
+        if kind == "bytetrack":
+            trk = ref_harness.load_bytetrack()(**kw)
+        elif kind == "ocsort":
+            trk = ref_harness.load_ocsort()(**kw)
+        else:
+            trk = ref_harness.load_botsort()(reid_model=None, use_cmc=False, **kw)
+        rows, counts = [], []
+        for d, e in scene:
+            r = np.asarray(trk.update(d.copy(), img, e.copy()) if kind == "botsort" else trk.update(d.copy(), img), dtype=np.float64).reshape(-1, 9)
+            rows.append(r)
+            counts.append(len(r))
+        big[key + "_counts"] = np.asarray(counts, dtype=np.int32)
+        big[key + "_rows"] = np.concatenate(rows).astype(np.float32)
+        print("config 2 shape:", key, sum(counts), "rows", flush=True)
+    np.savez_compressed(Path(__file__).resolve().parent / "obb_config2_golden.npz", frames=np.int32(n), **big)
 
 
 if __name__ == "__main__":

@@ -77,15 +77,16 @@ def test_oriented_steps_under_the_address_and_ub_sanitizers():
             "kw = dict(use_byte=True, max_age=6, min_hits=1)\n"
             "cfg = {**DD, **{k: v for k, v in kw.items() if k in DD}, 'embedding_off': 1, 'use_byte': 1, 'min_conf': 0.1, 'frame_wh': (640, 480)}\n"
             "emu, orc = EmuDeepOcSort(cfg, cap=64, nd=32, dim=1, sanitize=True, obb=True), OcSortObbOracle(**kw)\n"
-            "for d in obb_frames(30, seed=7):\n"
+            "for d in obb_frames(18, seed=7):\n"
             "    g, w = emu.update(d[:32], None), np.asarray(orc.update(d[:32].copy()), dtype=np.float32).reshape(-1, 9)\n"
             "    assert g.shape == w.shape and np.array_equal(g[:, 5:], w[:, 5:])\n"
             "emu.close()\n"
             "cfg = dict(BD); cfg.update(with_reid=True)\n"
             "emu, orc = EmuBotSort(cfg, cap=64, nd=32, dim=32, sanitize=True, obb=True), BotSortObbOracle(with_reid=True)\n"
-            "embs = [e for _, e in stress_frames(30, seed=7)]\n"            "from boxmot_amd.scenario import camera_warps\n"
-            "warps = camera_warps(30, seed=7)\n"
-            "for t, d in enumerate(obb_frames(30, seed=7)):\n"
+            "embs = [e for _, e in stress_frames(18, seed=7)]\n"
+            "from boxmot_amd.scenario import camera_warps\n"
+            "warps = camera_warps(18, seed=7)\n"
+            "for t, d in enumerate(obb_frames(18, seed=7)):\n"
             "    g = emu.update(d[:32], embs[t][:32], warp=warps[t])\n"
             "    w = np.asarray(orc.update(d[:32].copy(), None, embs[t][:32].copy(), warp=warps[t]), dtype=np.float32).reshape(-1, 9)\n"
             "    assert g.shape == w.shape and np.array_equal(g[:, 5:], w[:, 5:])\n"

@@ -88,3 +88,53 @@ def test_emulated_obb_step_with_camera_motion(with_reid):
                 assert np.allclose(dd["kf"], ref, rtol=1e-8, atol=1e-10), np.abs(dd["kf"] - ref).max()
     finally:
         emu.close()
+
+
+def _config2_golden(key):
+    from common import GOLDEN
+    g = np.load(GOLDEN / "obb_config2_golden.npz")
+    rows, counts, out, o = g[key + "_rows"], g[key + "_counts"], [], 0
+    for n in counts:
+        out.append(rows[o:o + n])
+        o += n
+    return out, int(g["frames"])
+
+
+@pytest.mark.parametrize("key", ["bytetrack", "botsort_reid", "ocsort"])
+def test_oriented_steps_at_the_configuration_2_shape_reproduce_the_reference_rows(key):
+    """64 oriented detections per frame on 256 tracks, 1080p (all 256 in the first three frames) -- BASELINE configuration 2's shape:
+    the emulated oriented steps and the oracles against rows of the reference classes themselves (tests/golden/obb_config2_golden.npz,
+    tests/golden/make_obb_golden.py), 40 of its 60 frames."""
+    from common import obb_config2_frames
+    from emu_util import EmuDeepOcSort
+    from oracle.botsort_obb import BotSortObbOracle
+    from oracle.bytetrack_obb import ByteTrackObbOracle
+    from oracle.deepocsort import DEFAULTS as DD
+    from oracle.ocsort_obb import OcSortObbOracle
+    want, _ = _config2_golden(key)
+    n = 40
+    cfg = dict(DEFAULTS)
+    if key == "bytetrack":
+        cfg.update(track_low_thresh=0.1, track_high_thresh=0.45, new_track_thresh=0.45, match_thresh=0.8, track_buffer=25, frame_rate=30,
+                   with_reid=False, second_match_thresh=0.5, unconfirmed_match_thresh=0.7, fuse_first_associate=True, removed_stracks_buffer=0, kind=1)
+        orc, emu = ByteTrackObbOracle(), EmuBotSort(cfg, cap=512, nd=256, dim=32, obb=True)
+    elif key == "botsort_reid":
+        cfg.update(with_reid=True)
+        orc, emu = BotSortObbOracle(with_reid=True), EmuBotSort(cfg, cap=512, nd=256, dim=32, obb=True)
+    else:
+        c = {**DD, "embedding_off": 1, "use_byte": 1, "min_conf": 0.1, "frame_wh": (1920, 1080)}
+        orc, emu = OcSortObbOracle(use_byte=True), EmuDeepOcSort(c, cap=512, nd=256, dim=1, obb=True)
+    try:
+        for t, (d, e) in enumerate(obb_config2_frames(n)):
+            if key == "ocsort":
+                got, o = emu.update(d, None), orc.update(d.copy())
+            elif key == "bytetrack":
+                got, o = emu.update(d, np.zeros((len(d), 32), np.float32)), orc.update(d.copy(), None, None)
+            else:
+                got, o = emu.update(d, e), orc.update(d.copy(), None, e.copy())
+            o = np.asarray(o, dtype=np.float32).reshape(-1, 9)
+            assert o.shape == want[t].shape and np.array_equal(o, want[t]), (key, t)                   # the oracle: the reference's rows, bit for bit
+            assert got.shape == want[t].shape and np.array_equal(got[:, 5:], want[t][:, 5:]), (key, t)
+            assert np.allclose(got[:, :5], want[t][:, :5], rtol=0, atol=2e-4), (key, t)
+    finally:
+        emu.close()
