@@ -298,3 +298,27 @@ def test_ocsort_oriented_surface_and_c_abi_guards():
                                             ctypes.byref(rows), ctypes.byref(obb)) == 1 and rows.value == 1 and obb.value == 1
     assert np.allclose(out[0], [320, 240, 80, 40, 0.15, 1, 0.95, 0, 0], atol=1e-5)
     lib.boxmot_hip_deepocsort_destroy(h)
+
+
+@pytest.mark.parametrize("key", ["bytetrack", "botsort_reid", "ocsort"])
+def test_oriented_trackers_at_the_configuration_2_shape_reproduce_the_reference_rows(key):
+    """64 oriented detections per frame on 256 tracks, 1080p -- BASELINE configuration 2's shape -- against rows of the reference classes
+    (tests/golden/obb_config2_golden.npz), all 60 frames, tables starting small (they grow)."""
+    from boxmot_amd import BotSort, ByteTrack, OcSort
+    from common import GOLDEN, obb_config2_frames
+    g = np.load(GOLDEN / "obb_config2_golden.npz")
+    rows, counts = g[key + "_rows"], g[key + "_counts"]
+    img = np.zeros((1080, 1920, 3), np.uint8)
+    if key == "bytetrack":
+        trk = ByteTrack(max_tracks=64, max_dets=32)
+    elif key == "ocsort":
+        trk = OcSort(use_byte=True, max_tracks=64, max_dets=32)
+    else:
+        trk = BotSort(reid_model=None, use_cmc=False, with_reid=True, max_tracks=64, max_dets=32, emb_dim=EMB)
+    o = 0
+    for t, (d, e) in enumerate(obb_config2_frames(int(g["frames"]))):
+        got = trk.update(d, img, e) if key == "botsort_reid" else trk.update(d, img)
+        _rows_match(got, rows[o:o + counts[t]], t)
+        o += counts[t]
+    assert o == len(rows) and trk.capacity()[2] >= 1
+    trk.close()
