@@ -2745,7 +2745,7 @@ int boxmot_botsort_update(BoxMOTBotSortHandle* h, const float* dets, int det_row
                                              image_channels, out_tracks, out_capacity_rows, out_cols, out_rows, out_is_obb);
     const int ok = guard([&]() {
         int is_obb = 0;
-        if (compat_layout(h, det_rows, det_cols, is_obb, "BoTSORT")) {
+        if (compat_layout(h, det_rows, det_cols, is_obb, "BoTSORT") && is_obb != h->cfg.is_obb) {
             h->cfg.is_obb = is_obb;
             if (h->inner) compat_build_inner(h, h->cfg.emb_dim);           // not stepped yet: the tables of the other layout
         }
