@@ -15,9 +15,9 @@ boxmot_amd.cmc.HipSOF); ``cmc=`` accepts any object exposing the reference's ``a
 Oriented detections (7 columns, botsort.py:120-131): the frame step has an oriented twin on the device (10-state filter,
 rotated-rectangle IoU; ``is_obb`` of the handle's configuration).  The layout is inferred from the first detection table like
 the reference does; embeddings of oriented detections come from the caller (``embs``) or from ``reid_model.get_features`` given
-the (cx, cy, w, h, angle) boxes, as the reference calls it.  Not implemented, and rejected loudly rather than approximated:
-camera-motion compensation of oriented boxes (``STrack.multi_gmc_obb`` goes through ``cv2.minAreaRect``; use ``use_cmc=False``),
-masks.
+the (cx, cy, w, h, angle) boxes, as the reference calls it.  Camera motion: the estimator sees the enclosing axis-aligned boxes of the
+oriented detections (botsort.py:147-158) and its warp is applied to the oriented tracks on the device (``STrack.multi_gmc_obb``:
+corner warp, minimum-area refit, re-alignment).  Not implemented, and rejected loudly rather than approximated: masks.
 """
 from __future__ import annotations
 
@@ -132,10 +132,26 @@ class BotSort(BaseTracker):
             _lib.check(self._lib.boxmot_hip_botsort_reserve(self._handle, *self._reserved))
 
     def _check_obb_options(self) -> None:
-        if self.is_obb and self.cmc is not None:
-            raise NotImplementedError(
-                "camera-motion compensation of oriented boxes (STrack.multi_gmc_obb) is not implemented; construct the tracker "
-                "with use_cmc=False")
+        pass        # (every BoT-SORT option has an oriented twin now)
+
+    @staticmethod
+    def _obb_detections_to_cmc_boxes(dets: np.ndarray) -> np.ndarray:
+        """botsort.py:126-132 over STrack.obb_to_xyxy (botsort_track.py:159-174): the enclosing axis-aligned box of every oriented
+        detection, from its four corners as cv2.boxPoints lays them out (fp32; the angle in degrees as an fp32 product)."""
+        if len(dets) == 0:
+            return np.empty((0, 4), dtype=np.float32)
+        out = np.empty((len(dets), 4), dtype=np.float32)
+        for i, det in enumerate(np.asarray(dets, dtype=np.float32)):
+            cx, cy, w, h, ang = (np.float32(v) for v in det[:5])
+            w, h = np.float32(max(float(w), 1e-4)), np.float32(max(float(h), 1e-4))
+            a = np.float64(float(np.degrees(ang))) * np.pi / 180.0
+            b, sn = np.float32(np.cos(a)) * np.float32(0.5), np.float32(np.sin(a)) * np.float32(0.5)
+            p0 = (cx - sn * h - b * w, cy + b * h - sn * w)
+            p1 = (cx + sn * h - b * w, cy - b * h - sn * w)
+            xs = np.array([p0[0], p1[0], np.float32(2) * cx - p0[0], np.float32(2) * cx - p1[0]], dtype=np.float32)
+            ys = np.array([p0[1], p1[1], np.float32(2) * cy - p0[1], np.float32(2) * cy - p1[1]], dtype=np.float32)
+            out[i] = [xs.min(), ys.min(), xs.max(), ys.max()]
+        return out
 
     def _set_detection_mode(self, is_obb: bool) -> None:
         """The first detection table decides the layout (basetracker.py:163-173).  The device tables are sized for one layout
@@ -168,7 +184,10 @@ class BotSort(BaseTracker):
         if self.cmc is not None:
             # botsort.py:142: the estimator sees the detection table incl. the index column; the warp is applied
             # on the device after the Kalman prediction (boxmot_hip_botsort_set_warp)
-            table = np.hstack([det_arr, np.arange(n, dtype=np.int32).reshape(-1, 1)]) if n else np.empty((0, self.det_cols + 1), det_arr.dtype)
+            if self.is_obb:     # botsort.py:147-158: the estimator sees the enclosing boxes of the oriented detections
+                table = self._obb_detections_to_cmc_boxes(np.hstack([det_arr, np.arange(n, dtype=np.int32).reshape(-1, 1)])) if n else np.empty((0, 4), np.float32)
+            else:
+                table = np.hstack([det_arr, np.arange(n, dtype=np.int32).reshape(-1, 1)]) if n else np.empty((0, self.det_cols + 1), det_arr.dtype)
             warp = np.ascontiguousarray(np.asarray(self.cmc.apply(img, table), dtype=np.float64)[:2, :3])
             if warp.shape != (2, 3):
                 raise ValueError(f"cmc.apply returned shape {warp.shape}, expected (2, 3)")

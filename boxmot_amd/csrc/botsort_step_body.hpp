@@ -413,6 +413,105 @@ BM_STEP_FN void kf_initiate_wave(double* kf, const float* z32, int lane, bool /*
     }
 }
 
+// STrack.multi_gmc_obb for one track (botsort_track.py:134-230): the box is warped as its four corners (fp32, cv2.boxPoints /
+// cv2.transform), refitted by the minimum-area enclosing rectangle (cv2.minAreaRect: every edge of the warped quadrilateral is tried,
+// fp64 on the fp32 points, result in fp32) and re-aligned to the box it came from; (vx, vy) <- L (vx, vy), vw *= sx, vh *= sy and
+// cov <- T cov T^T with T = diag-blocks (L, sx, sy, 1, L, sx, sy, 1), all of them the fp32 values of the warp.  W = [l00 l01 tx; l10 l11 ty].
+// The two OpenCV calls are restated (OpenCV is absent offline: parity unpinned for them).
+BM_STEP_FN void kf_warp_wave(double* kf, const double* W, int lane) {
+    float w32[6];
+    for (int k = 0; k < 6; ++k) w32[k] = (float)W[k];
+    const float sxf = sqrtf(w32[0] * w32[0] + w32[3] * w32[3]), syf = sqrtf(w32[1] * w32[1] + w32[4] * w32[4]);     // column norms, fp32
+    const double sx = (double)sxf > 1e-6 ? (double)sxf : 1e-6, sy = (double)syf > 1e-6 ? (double)syf : 1e-6;
+    double m[10];
+    for (int k = 0; k < 10; ++k) m[k] = kf[k];
+    // the box as fp32, its corners, the warped corners
+    double ref[5];
+    for (int k = 0; k < 5; ++k) ref[k] = (double)(float)m[k];
+    double rect[5] = {ref[0], ref[1], ref[2] > 1e-4 ? ref[2] : 1e-4, ref[3] > 1e-4 ? ref[3] : 1e-4, ref[4]};
+    double p[4][2];
+    obb_corners_deg(rect, (double)((float)m[4] * (180.0f / 3.14159274f)), p);      // np.degrees of an fp32 angle: x * (180.0f / NPY_PIf), fp32
+    double q[4][2];
+    for (int k = 0; k < 4; ++k) {
+        const float x = (float)p[k][0], y = (float)p[k][1];
+        q[k][0] = (double)(w32[0] * x + w32[1] * y + w32[2]);
+        q[k][1] = (double)(w32[3] * x + w32[4] * y + w32[5]);
+    }
+    // minimum-area enclosing rectangle: a side lies on an edge
+    double best_area = 0.0, bcx = q[0][0], bcy = q[0][1], bw = 0.0, bh = 0.0, bang = 0.0;
+    bool have = false;
+    for (int e = 0; e < 4; ++e) {
+        const int n = (e + 1) & 3;
+        const double ex = q[n][0] - q[e][0], ey = q[n][1] - q[e][1];
+        const double len = hypot(ex, ey);
+        if (len == 0.0) continue;
+        const double ux = ex / len, uy = ey / len, vx = -uy, vy = ux;
+        double amin = 0, amax = 0, bmin = 0, bmax = 0;
+        for (int k = 0; k < 4; ++k) {
+            const double a = q[k][0] * ux + q[k][1] * uy, b = q[k][0] * vx + q[k][1] * vy;
+            if (k == 0 || a < amin) amin = a;
+            if (k == 0 || a > amax) amax = a;
+            if (k == 0 || b < bmin) bmin = b;
+            if (k == 0 || b > bmax) bmax = b;
+        }
+        const double ww = amax - amin, hh = bmax - bmin;
+        if (!have || ww * hh < best_area) {
+            have = true; best_area = ww * hh;
+            const double ca = (amax + amin) / 2, cb = (bmax + bmin) / 2;
+            bcx = ux * ca + vx * cb; bcy = uy * ca + vy * cb; bw = ww; bh = hh;
+            bang = atan2(uy, ux) * (180.0 / OBB_PI);
+        }
+    }
+    double z[5];
+    z[0] = (double)(float)bcx; z[1] = (double)(float)bcy;
+    const double fw = (double)(float)bw, fh = (double)(float)bh, fang = (double)(float)bang;
+    z[2] = (double)(float)(fw > 1e-4 ? fw : 1e-4); z[3] = (double)(float)(fh > 1e-4 ? fh : 1e-4);
+    z[4] = (double)(float)(fang * (OBB_PI / 180.0));                                       // np.deg2rad into the fp32 box
+    obb_align_measurement(z, ref);
+    double mn = 0.0;
+    if (lane < 10) {
+        if (lane < 5) mn = (double)(float)z[lane];
+        else if (lane == 5) mn = (double)w32[0] * m[5] + (double)w32[1] * m[6];
+        else if (lane == 6) mn = (double)w32[3] * m[5] + (double)w32[4] * m[6];
+        else if (lane == 7) mn = m[7] * sx;
+        else if (lane == 8) mn = m[8] * sy;
+        else mn = m[9];
+    }
+    // cov <- (T P) T^T: a row of T has the entries of L in rows 0, 1 (columns 0, 1) and 5, 6 (columns 5, 6), one diagonal entry elsewhere
+    const double* P = kf + KF_DIM;
+    auto trow = [&](int i, int (&idx)[2], double (&cf)[2]) {
+        if (i == 0 || i == 1 || i == 5 || i == 6) {
+            const int b0 = i < 2 ? 0 : 5, r = i - b0;
+            idx[0] = b0; idx[1] = b0 + 1; cf[0] = (double)w32[r * 3 + 0]; cf[1] = (double)w32[r * 3 + 1];
+            return 2;
+        }
+        idx[0] = i; idx[1] = i;
+        cf[0] = (i == 2 || i == 7) ? (double)(float)sx : ((i == 3 || i == 8) ? (double)(float)sy : 1.0); cf[1] = 0.0;
+        return 1;
+    };
+    double cnew[2];
+    for (int qq = 0; qq < 2; ++qq) {
+        const int e = lane + qq * WAVE;
+        cnew[qq] = 0.0;
+        if (e >= 100) continue;
+        const int i = e / 10, j = e % 10;
+        int ia[2], jb[2];
+        double ca[2], cb[2];
+        const int na = trow(i, ia, ca), nb = trow(j, jb, cb);
+        double acc = 0.0;
+        for (int b = 0; b < nb; ++b) {
+            double tp = 0.0;                                   // (T P)[i][jb[b]]
+            for (int a = 0; a < na; ++a) tp = a == 0 ? ca[a] * P[ia[a] * 10 + jb[b]] : fma(ca[a], P[ia[a] * 10 + jb[b]], tp);
+            acc = b == 0 ? tp * cb[b] : fma(tp, cb[b], acc);
+        }
+        cnew[qq] = acc;
+    }
+    const double c0 = __shfl(cnew[0], lane, WAVE), c1 = __shfl(cnew[1], lane, WAVE);      // wave-wide dependency: every load precedes the stores
+    kf[KF_DIM + lane] = c0;
+    if (lane + WAVE < 100) kf[KF_DIM + lane + WAVE] = c1;
+    if (lane < 10) kf[lane] = mn;
+}
+
 #endif
 
 // STrack.update_cls (botsort_track.py:69-82); single lane.
@@ -1011,8 +1110,7 @@ __device__ inline void botsort_step_stream(const BotSortStepArgs& args, int s, i
     __syncthreads();
 #endif
     // ---- camera-motion warp of the pool and the unconfirmed tracks (botsort.py:134-145, :300-303) ----
-#if !BM_OBB        // (oriented boxes: multi_gmc_obb fits cv2.minAreaRect -- not built; the host rejects a warp for such a handle)
-    if (args.warp_flag && args.warp_flag[s]) {
+    if (args.warp_flag && args.warp_flag[s]) {          // (oriented boxes: STrack.multi_gmc_obb, kf_warp_wave of the oriented layout)
         const double* W = args.warp + (long)s * 6;
         for (int base = 0; base < n_pool + n_unconf; base += c.nwaves) {
             const int k = base + c.wave;
@@ -1024,7 +1122,6 @@ __device__ inline void botsort_step_stream(const BotSortStepArgs& args, int s, i
         __syncthreads();
     }
 
-#endif
     tick();
     // ---- first association (botsort.py:285-333) ----
     assoc_cost<NTHR>(c, v, v.pool, n_pool, v.first_idx, n_first, reid, 0.0, cfg.fuse_first_associate != 0, sA, sB, s_count);

@@ -64,6 +64,28 @@ __global__ void __launch_bounds__(NTHR) botsort_obb_step_kernel(bm::BotSortStepA
     bm::obb::botsort_step_stream<NTHR>(args, args.stream_base + blockIdx.x, s_int, s_dbl, sA, sB, dyn_lds);
 }
 
+// BotSort._obb_detections_to_cmc_boxes (botsort.py:126-132 over STrack.obb_to_xyxy, botsort_track.py:159-174): the enclosing axis-aligned
+// box of every oriented detection of stream blockIdx.x + s0 -- what the reference hands its camera-motion estimator as the mask boxes --
+// from the four corners as cv2.boxPoints lays them out (fp32; w, h floored at 1e-4; the angle in degrees as the fp32 product np.degrees is)
+__global__ void obb_enclosing_boxes_kernel(const float* dets, const int* n_dets, int max_dets, float* boxes, int s0) {
+    const int s = s0 + blockIdx.x;
+    const int n = n_dets[s] > 0 ? n_dets[s] : 0;
+    const float* d = dets + (long)s * max_dets * bm::obb::DET_COLS;
+    float* o = boxes + (long)s * max_dets * 4;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        const float* r = d + j * bm::obb::DET_COLS;
+        const double rect[5] = {(double)r[0], (double)r[1], (double)r[2] > 1e-4 ? (double)r[2] : 1e-4, (double)r[3] > 1e-4 ? (double)r[3] : 1e-4, (double)r[4]};
+        double p[4][2];
+        bm::obb::obb_corners_deg(rect, (double)(r[4] * (180.0f / 3.14159274f)), p);
+        float x0 = (float)p[0][0], x1 = x0, y0 = (float)p[0][1], y1 = y0;
+        for (int k = 1; k < 4; ++k) {
+            const float x = (float)p[k][0], y = (float)p[k][1];
+            x0 = x < x0 ? x : x0; x1 = x > x1 ? x : x1; y0 = y < y0 ? y : y0; y1 = y > y1 ? y : y1;
+        }
+        o[j * 4 + 0] = x0; o[j * 4 + 1] = y0; o[j * 4 + 2] = x1; o[j * 4 + 3] = y1;
+    }
+}
+
 template <int NTHR>
 __global__ void __launch_bounds__(NTHR) deepocsort_step_kernel(bm::DocsStepArgs args) {
     __shared__ int s_int[bm::MAX_WAVES + 1];
@@ -274,6 +296,7 @@ struct BoxMOTHipBotSort {
     std::unique_ptr<bm::ReidEngine> reid;
     int reid_mode = 0, reid_pad = 0;
     bool is_obb = false;                         // oriented detections (7 columns in, 9 out, 10-state filter): config.is_obb
+    float* d_cmc_boxes = nullptr;                // [S][nd][4] enclosing boxes of the oriented detections: the SOF estimator's mask boxes
     int det_cols() const { return is_obb ? bm::obb::DET_COLS : bm::DET_COLS; }
     int out_cols() const { return is_obb ? bm::obb::OUT_COLS : bm::OUT_COLS; }
     int kf_stride() const { return is_obb ? bm::obb::KF_STRIDE : bm::KF_STRIDE; }
@@ -408,6 +431,8 @@ void alloc_det_io(BoxMOTHipBotSort* h) {
     h->d_crop_stream = zalloc<int>(S * nd, o);
     h->d_crop_boxes = zalloc<float>(S * nd * 4, o);
     h->d_crop_row = zalloc<int>(S * nd, o);
+    release(o, h->d_cmc_boxes);
+    h->d_cmc_boxes = h->is_obb ? zalloc<float>(S * nd * 4, o) : nullptr;
     h->h_dets.assign(S * nd * h->det_cols(), 0.f);
     h->h_out.assign(S * nd * h->out_cols(), 0.f);
 }
@@ -526,11 +551,12 @@ void build(BoxMOTHipBotSort* h) {
     }
     h->is_obb = c.is_obb != 0;
     if (h->is_obb) {
-        // oriented detections (botsort.py:120-131, bytetrack.py:266-303).  The reference's camera-motion compensation of oriented
-        // tracks (STrack.multi_gmc_obb, botsort_track.py:197-230) refits each warped box with cv2.minAreaRect: not restated (no
-        // OpenCV offline to pin it on), so it is refused here rather than approximated.  Embeddings of oriented detections come
+        // oriented detections (botsort.py:120-131, bytetrack.py:266-303).  Camera motion: a warp supplied with set_warp is applied to
+        // the oriented tracks (STrack.multi_gmc_obb, botsort_track.py:197-230: kf_warp_wave of the oriented layout); the in-handle
+        // estimators mask by axis-aligned detection boxes and are not wired to oriented tables (the reference estimates on the
+        // enclosing boxes, botsort.py:147-158: the caller does that and supplies the warp).  Embeddings of oriented detections come
         // from the caller (the reference crops rotated rectangles with cv2.warpAffine, reid/backends/base_backend.py:92-118).
-        if (h->use_ecc || h->use_sof) throw std::runtime_error("boxmot_hip: camera-motion compensation is not applied to oriented detections (cmc_method must be none)");
+        // (cmc_method ecc / sof run on an oriented handle too: SOF is masked by the enclosing boxes, obb_enclosing_boxes_kernel)
         if (c.reid_model_path && c.reid_model_path[0])
             throw std::runtime_error("boxmot_hip: an oriented-box handle takes embeddings from the caller (embs), not from in-handle ReID weights");
     }
@@ -854,6 +880,11 @@ void host_update(BoxMOTHipBotSort* h, int s0, int n, const StreamIn* in, int det
         for (int k = 0; k < n; ++k) {
             if (in[k].det_rows < 0) continue;
             const uint8_t* const* fp = (d_frames_ext ? d_frames_ext : h->d_frames) + (s0 + k);
+            if (h->is_obb) {        // botsort.py:147-158: the estimator sees the enclosing boxes of the oriented detections
+                hipLaunchKernelGGL(obb_enclosing_boxes_kernel, dim3(1), dim3(256), 0, h->stream, h->d_dets, h->d_ndets, nd, h->d_cmc_boxes, s0 + k);
+                sof_run(h->sof.get(), s0 + k, 1, fp, h->d_cmc_boxes + (size_t)(s0 + k) * nd * 4, h->d_ndets + s0 + k, nd, 4,
+                        h->h_warp.data() + (size_t)(s0 + k) * 6, nullptr);
+            } else
             sof_run(h->sof.get(), s0 + k, 1, fp, d_dets + (size_t)k * nd * DC, h->d_ndets + s0 + k, nd, DC,
                     h->h_warp.data() + (size_t)(s0 + k) * 6, nullptr);
             h->h_warp_flag[s0 + k] = 1;
@@ -1272,7 +1303,8 @@ void docs_build(BoxMOTHipDeepOcSort* h) {
         // oriented detections: OC-SORT (ocsort.py:332 supports_obb; DeepOcSort does not): no appearance, no camera motion, and the
         // association function is the rotated IoU (detection_layout.py:25-26 turns "iou" into "iou_obb")
         if (!c.embedding_off) throw std::runtime_error("boxmot_hip: oriented detections run on OC-SORT (embedding_off = 1); DeepOCSORT takes axis-aligned boxes only");
-        if (c.asso_func != BOXMOT_HIP_ASSO_IOU) throw std::runtime_error("boxmot_hip: the oriented step has the rotated IoU only (asso_func must be BOXMOT_HIP_ASSO_IOU)");
+        if (c.asso_func != BOXMOT_HIP_ASSO_IOU && c.asso_func != BOXMOT_HIP_ASSO_CENTROID)
+            throw std::runtime_error("boxmot_hip: the oriented step has the rotated IoU and the centroid distance (asso_func must be BOXMOT_HIP_ASSO_IOU or _CENTROID)");
         h->det_cols = bm::obb::DOCS_DET_COLS; h->out_cols = bm::obb::DOCS_OUT_COLS;
     }
     io_allocate(h, c.n_streams, c.max_tracks, c.max_dets, c.embedding_off ? 1 : c.emb_dim, !c.embedding_off);
@@ -1557,7 +1589,7 @@ int boxmot_hip_botsort_update_batch(BoxMOTHipBotSort* handle, int n_streams, con
         std::vector<StreamIn> in(n_streams);
         for (int s = 0; s < n_streams; ++s)
             in[s] = StreamIn{dets[s], det_rows[s], (embs && emb_cols > 0) ? embs[s] : nullptr, images ? images[s] : nullptr};
-        host_update(handle, 0, n_streams, in.data(), 6, emb_cols, image_rows, image_cols, image_channels, nullptr, nullptr,
+        host_update(handle, 0, n_streams, in.data(), handle->det_cols(), emb_cols, image_rows, image_cols, image_channels, nullptr, nullptr,
                     out_tracks, out_capacity_rows, out_rows);
     });
 }
@@ -1573,7 +1605,7 @@ int boxmot_hip_botsort_update_batch_frames(BoxMOTHipBotSort* handle, int n_strea
         if (!d_frames || image_rows < 1 || image_cols < 1) throw std::runtime_error("boxmot_hip: update_batch_frames needs device frames");
         std::vector<StreamIn> in(n_streams);
         for (int s = 0; s < n_streams; ++s) in[s] = StreamIn{dets[s], det_rows[s], (embs && emb_cols > 0) ? embs[s] : nullptr, nullptr};
-        host_update(handle, 0, n_streams, in.data(), 6, emb_cols, image_rows, image_cols, 3, nullptr, nullptr, out_tracks,
+        host_update(handle, 0, n_streams, in.data(), handle->det_cols(), emb_cols, image_rows, image_cols, 3, nullptr, nullptr, out_tracks,
                     out_capacity_rows, out_rows, d_frames);
     });
 }
@@ -1611,7 +1643,10 @@ int boxmot_hip_botsort_step_device(BoxMOTHipBotSort* handle, const float* d_dets
                 std::vector<double> w(6);
                 for (int s = 0; s < h->S; ++s) {
                     if (h->h_warp_flag[s]) continue;
-                    if (h->use_sof) sof_run(h->sof.get(), s, 1, d_frames + s, d_dets + (size_t)s * h->nd * bm::DET_COLS, d_det_rows + s, h->nd, bm::DET_COLS, w.data(), nullptr);
+                    if (h->use_sof && h->is_obb) {
+                        hipLaunchKernelGGL(obb_enclosing_boxes_kernel, dim3(1), dim3(256), 0, h->stream, d_dets, d_det_rows, h->nd, h->d_cmc_boxes, s);
+                        sof_run(h->sof.get(), s, 1, d_frames + s, h->d_cmc_boxes + (size_t)s * h->nd * 4, d_det_rows + s, h->nd, 4, w.data(), nullptr);
+                    } else if (h->use_sof) sof_run(h->sof.get(), s, 1, d_frames + s, d_dets + (size_t)s * h->nd * bm::DET_COLS, d_det_rows + s, h->nd, bm::DET_COLS, w.data(), nullptr);
                     else ecc_run_one(h->ecc.get(), s, d_frames + s, w.data(), nullptr);
                     for (int k = 0; k < 6; ++k) h->h_warp[(size_t)s * 6 + k] = w[k];
                     h->h_warp_flag[s] = 1;
@@ -1638,7 +1673,6 @@ int boxmot_hip_botsort_set_warp(BoxMOTHipBotSort* handle, int stream, const doub
         if (!handle) throw std::runtime_error("boxmot_hip BoT-SORT handle is null.");
         if (stream < 0 || stream >= handle->S) throw std::runtime_error("boxmot_hip: stream index out of range");
         if (warp_2x3 == nullptr) { handle->h_warp_flag[stream] = 0; return; }
-        if (handle->is_obb) throw std::runtime_error("boxmot_hip: camera-motion warps are not applied to oriented detections");
         for (int k = 0; k < 6; ++k) {
             if (!std::isfinite(warp_2x3[k])) throw std::runtime_error("boxmot_hip: camera-motion warp has non-finite entries");
             handle->h_warp[(size_t)stream * 6 + k] = warp_2x3[k];
@@ -2600,15 +2634,24 @@ int boxmot_hip_strongsort_state_dump(BoxMOTHipStrongSort* handle, int stream, in
 // The embedding width is a create-time capacity of the device state; the reference learns it from the first embeddings it
 // sees.  The adapter therefore builds the inner handle at create when the width is known (ReID weights given: their feature
 // width; with_reid = 0: none needed) and otherwise at the first update that brings embeddings.
-struct BoxMOTBotSortHandle {
+// The reference's native trackers take a table of 6 (AABB) or 7 (OBB) columns per call (live_c_api.hpp:22-60: `detection.is_obb =
+// det_cols == 7`, out_is_obb = det_cols == 7, :147-149) and its Python wrappers fix the layout with the first table ("cannot switch
+// between AABB and OBB inputs", native/trackers/botsort.py).  A device handle is sized for one layout, so the adapters keep the
+// configuration, decide the layout with the first non-empty table and re-make the (still unused) inner handle when it is oriented.
+struct CompatLayout {
+    int layout = -1;                // -1 undecided, 0 axis-aligned, 1 oriented
+    bool stepped = false;           // an update has run on the inner handle: its layout is final
+    int empty_frames = 0;           // updates that only counted: before the inner handle exists (BoT-SORT without an embedding width yet,
+                                    // botsort.py:183) or 0 x 0 tables before the layout is known; replayed into the frame counter
+};
+struct BoxMOTBotSortHandle : CompatLayout {
     BoxMOTHipBotSortConfig cfg{};
     std::string reid_path, reid_pre, cmc;
-    int empty_frames = 0;           // updates seen before the inner handle exists (they advance the frame counter, botsort.py:183)
     BoxMOTHipBotSort* inner = nullptr;
     ~BoxMOTBotSortHandle() { delete inner; }
 };
-struct BoxMOTByteTrackHandle { BoxMOTHipBotSort* inner = nullptr; ~BoxMOTByteTrackHandle() { delete inner; } };
-struct BoxMOTOCSORTHandle { BoxMOTHipDeepOcSort* inner = nullptr; ~BoxMOTOCSORTHandle() { delete inner; } };
+struct BoxMOTByteTrackHandle : CompatLayout { BoxMOTHipBotSortConfig cfg{}; BoxMOTHipBotSort* inner = nullptr; ~BoxMOTByteTrackHandle() { delete inner; } };
+struct BoxMOTOCSORTHandle : CompatLayout { BoxMOTHipDeepOcSortConfig cfg{}; BoxMOTHipDeepOcSort* inner = nullptr; ~BoxMOTOCSORTHandle() { delete inner; } };
 
 namespace {
 int env_int(const char* name, int dflt) {
@@ -2617,6 +2660,23 @@ int env_int(const char* name, int dflt) {
     const int x = std::atoi(v);
     return x > 0 ? x : dflt;
 }
+// Layout of this call's table against the handle's: returns true when the inner handle has to be (re-)made with `is_obb`.
+// ValidateLiveDetectionShape (live_c_api.hpp:22-33): an empty 0 x 0 table is accepted and keeps the layout.
+bool compat_layout(CompatLayout* h, int det_rows, int det_cols, int& is_obb, const char* tracker) {
+    is_obb = h->layout == 1 ? 1 : 0;
+    if (det_rows < 0 || det_cols < 0) throw std::runtime_error("Negative matrix dimensions are not allowed.");
+    if (det_cols == 0 && det_rows == 0) return false;
+    if (det_cols != 6 && det_cols != 7)
+        throw std::runtime_error(std::string(tracker) + " live tracking expects detections with 6 (AABB) or 7 (OBB) columns.");
+    const int want = det_cols == 7 ? 1 : 0;
+    if (h->layout == want) return false;
+    if (h->layout >= 0 && h->stepped)
+        throw std::runtime_error(std::string(tracker) + ": cannot switch between AABB and OBB inputs");
+    h->layout = want;
+    is_obb = want;
+    return true;
+}
+
 void compat_build_inner(BoxMOTBotSortHandle* h, int emb_dim) {
     h->cfg.emb_dim = emb_dim;
     h->cfg.reid_model_path = h->reid_path.empty() ? nullptr : h->reid_path.c_str();
@@ -2624,6 +2684,7 @@ void compat_build_inner(BoxMOTBotSortHandle* h, int emb_dim) {
     h->cfg.cmc_method = h->cmc.empty() ? nullptr : h->cmc.c_str();
     BoxMOTHipBotSort* inner = boxmot_hip_botsort_create(&h->cfg);
     if (!inner) throw std::runtime_error(g_last_error);
+    delete h->inner;
     h->inner = inner;
 }
 // feature width declared in the header of an OSN1 weight blob (reid_layout.hpp)
@@ -2672,44 +2733,51 @@ BoxMOTBotSortHandle* boxmot_botsort_create(const BoxMOTBotSortConfig* c) {
 }
 void boxmot_botsort_destroy(BoxMOTBotSortHandle* h) { delete h; }
 int boxmot_botsort_reset(BoxMOTBotSortHandle* h) {
-    if (h && !h->inner) { h->empty_frames = 0; return guard([]() {}); }
+    if (h) { h->empty_frames = 0; h->stepped = false; h->layout = -1; }          // the next table decides the layout again
+    if (h && !h->inner) return guard([]() {});
     return boxmot_hip_botsort_reset(h ? h->inner : nullptr);
 }
 int boxmot_botsort_update(BoxMOTBotSortHandle* h, const float* dets, int det_rows, int det_cols, const float* embs,
                           int emb_rows, int emb_cols, const uint8_t* image, int image_rows, int image_cols,
                           int image_channels, float* out_tracks, int out_capacity_rows, int out_cols, int* out_rows,
                           int* out_is_obb) {
-    if (h && !h->inner) {
-        const int ok = guard([&]() {
-            if (embs == nullptr || emb_cols <= 0) {
-                if (det_rows > 0) throw std::runtime_error("BoTSORT: with_reid is set, no ReID weights were given and no embeddings were supplied.");
-                return;
-            }
-            compat_build_inner(h, emb_cols);
-        });
-        if (!ok) return 0;
-        if (!h->inner) {        // nothing to track yet and no width known: an empty frame
-            h->empty_frames += 1;
-            if (out_rows) *out_rows = 0;
-            if (out_is_obb) *out_is_obb = 0;
-            return 1;
+    if (!h) return boxmot_hip_botsort_update(nullptr, dets, det_rows, det_cols, embs, emb_rows, emb_cols, image, image_rows, image_cols,
+                                             image_channels, out_tracks, out_capacity_rows, out_cols, out_rows, out_is_obb);
+    const int ok = guard([&]() {
+        int is_obb = 0;
+        if (compat_layout(h, det_rows, det_cols, is_obb, "BoTSORT") && is_obb != h->cfg.is_obb) {
+            h->cfg.is_obb = is_obb;
+            if (h->inner) compat_build_inner(h, h->cfg.emb_dim);           // not stepped yet: the tables of the other layout
         }
-        if (h->empty_frames > 0) {      // the frames that went by count (a first detection on frame > 1 is not activated at once)
-            const int fc = h->empty_frames;
-            h->empty_frames = 0;
-            // the reference's estimator saw the empty frames (botsort.py:141-145 runs cmc.apply on every frame); there were no tracks to
-            // warp, so all that matters is that it sees THIS frame as its newest: run it although the frame counter is preset
-            h->inner->cmc_with_fc_set = true;
-            const int rc = boxmot_hip_botsort_update_stream(h->inner, 0, 0, fc, dets, det_rows, det_cols, embs, emb_rows, emb_cols, image,
-                                                            image_rows, image_cols, image_channels, out_tracks, out_capacity_rows, out_cols,
-                                                            out_rows, out_is_obb);
-            h->inner->cmc_with_fc_set = false;
-            return rc;
-        }
+        if (!h->inner && embs != nullptr && emb_cols > 0) compat_build_inner(h, emb_cols);
+        if (!h->inner && det_rows > 0)
+            throw std::runtime_error("BoTSORT: with_reid is set, no ReID weights were given and no embeddings were supplied.");
+    });
+    if (!ok) return 0;
+    if (det_rows == 0 && det_cols == 0) det_cols = h->layout == 1 ? 7 : 6;
+    if (!h->inner || (h->layout < 0 && det_rows == 0)) {        // nothing to track yet (no width / no layout known): the frame only counts
+        h->empty_frames += 1;
+        if (out_rows) *out_rows = 0;
+        if (out_is_obb) *out_is_obb = h->layout == 1 ? 1 : 0;
+        return 1;
     }
-    return boxmot_hip_botsort_update(h ? h->inner : nullptr, dets, det_rows, det_cols, embs, emb_rows, emb_cols, image,
-                                     image_rows, image_cols, image_channels, out_tracks, out_capacity_rows, out_cols,
-                                     out_rows, out_is_obb);
+    int rc;
+    if (h->empty_frames > 0) {      // the frames that went by count (a first detection on frame > 1 is not activated at once)
+        const int fc = h->empty_frames;
+        h->empty_frames = 0;
+        // the reference's estimator saw the empty frames (botsort.py:141-145 runs cmc.apply on every frame); there were no tracks to
+        // warp, so all that matters is that it sees THIS frame as its newest: run it although the frame counter is preset
+        h->inner->cmc_with_fc_set = true;
+        rc = boxmot_hip_botsort_update_stream(h->inner, 0, 0, fc, dets, det_rows, det_cols, embs, emb_rows, emb_cols, image,
+                                              image_rows, image_cols, image_channels, out_tracks, out_capacity_rows, out_cols,
+                                              out_rows, out_is_obb);
+        h->inner->cmc_with_fc_set = false;
+    } else {
+        rc = boxmot_hip_botsort_update(h->inner, dets, det_rows, det_cols, embs, emb_rows, emb_cols, image, image_rows, image_cols,
+                                       image_channels, out_tracks, out_capacity_rows, out_cols, out_rows, out_is_obb);
+    }
+    if (rc) h->stepped = true;
+    return rc;
 }
 #define BM_COMPAT_TIME(name, fn)                                                         \
     int name(BoxMOTBotSortHandle* h, double* out) {                                      \
@@ -2736,6 +2804,7 @@ BoxMOTByteTrackHandle* boxmot_bytetrack_create(const BoxMOTByteTrackConfig* c) {
         k.max_tracks = env_int("BOXMOT_HIP_MAX_TRACKS", 1024);
         k.max_dets = env_int("BOXMOT_HIP_MAX_DETS", 512);
         h = new BoxMOTByteTrackHandle();
+        h->cfg = k;
         h->inner = boxmot_hip_botsort_create(&k);
         if (!h->inner) throw std::runtime_error(g_last_error);
     });
@@ -2743,12 +2812,39 @@ BoxMOTByteTrackHandle* boxmot_bytetrack_create(const BoxMOTByteTrackConfig* c) {
     return h;
 }
 void boxmot_bytetrack_destroy(BoxMOTByteTrackHandle* h) { delete h; }
-int boxmot_bytetrack_reset(BoxMOTByteTrackHandle* h) { return boxmot_hip_botsort_reset(h ? h->inner : nullptr); }
+int boxmot_bytetrack_reset(BoxMOTByteTrackHandle* h) {
+    if (h) { h->empty_frames = 0; h->stepped = false; h->layout = -1; }
+    return boxmot_hip_botsort_reset(h ? h->inner : nullptr);
+}
 int boxmot_bytetrack_update(BoxMOTByteTrackHandle* h, const float* dets, int det_rows, int det_cols, const uint8_t* image,
                             int image_rows, int image_cols, int image_channels, float* out_tracks, int out_capacity_rows,
                             int out_cols, int* out_rows, int* out_is_obb) {
-    return boxmot_hip_botsort_update(h ? h->inner : nullptr, dets, det_rows, det_cols, nullptr, 0, 0, image, image_rows,
-                                     image_cols, image_channels, out_tracks, out_capacity_rows, out_cols, out_rows, out_is_obb);
+    if (!h) return boxmot_hip_botsort_update(nullptr, dets, det_rows, det_cols, nullptr, 0, 0, image, image_rows, image_cols,
+                                             image_channels, out_tracks, out_capacity_rows, out_cols, out_rows, out_is_obb);
+    const int ok = guard([&]() {
+        int is_obb = 0;
+        if (compat_layout(h, det_rows, det_cols, is_obb, "ByteTrack") && is_obb != h->cfg.is_obb) {
+            h->cfg.is_obb = is_obb;
+            BoxMOTHipBotSort* inner = boxmot_hip_botsort_create(&h->cfg);          // not stepped yet: the tables of the other layout
+            if (!inner) throw std::runtime_error(g_last_error);
+            delete h->inner;
+            h->inner = inner;
+        }
+    });
+    if (!ok) return 0;
+    if (det_rows == 0 && det_cols == 0) det_cols = h->layout == 1 ? 7 : 6;
+    if (h->layout < 0 && det_rows == 0) {          // a 0 x 0 table before the layout is known: the frame only counts
+        h->empty_frames += 1;
+        if (out_rows) *out_rows = 0;
+        if (out_is_obb) *out_is_obb = 0;
+        return 1;
+    }
+    const int fc = h->empty_frames > 0 ? h->empty_frames : -1;
+    h->empty_frames = 0;
+    const int rc = boxmot_hip_botsort_update_stream(h->inner, 0, 0, fc, dets, det_rows, det_cols, nullptr, 0, 0, image, image_rows,
+                                                    image_cols, image_channels, out_tracks, out_capacity_rows, out_cols, out_rows, out_is_obb);
+    if (rc) h->stepped = true;
+    return rc;
 }
 const char* boxmot_bytetrack_last_error() { return g_last_error.c_str(); }
 
@@ -2766,6 +2862,7 @@ BoxMOTOCSORTHandle* boxmot_ocsort_create(const BoxMOTOCSORTConfig* c) {
         k.max_tracks = env_int("BOXMOT_HIP_MAX_TRACKS", 1024);
         k.max_dets = env_int("BOXMOT_HIP_MAX_DETS", 512);
         h = new BoxMOTOCSORTHandle();
+        h->cfg = k;
         h->inner = boxmot_hip_deepocsort_create(&k);
         if (!h->inner) throw std::runtime_error(g_last_error);
     });
@@ -2773,12 +2870,39 @@ BoxMOTOCSORTHandle* boxmot_ocsort_create(const BoxMOTOCSORTConfig* c) {
     return h;
 }
 void boxmot_ocsort_destroy(BoxMOTOCSORTHandle* h) { delete h; }
-int boxmot_ocsort_reset(BoxMOTOCSORTHandle* h) { return boxmot_hip_deepocsort_reset(h ? h->inner : nullptr); }
+int boxmot_ocsort_reset(BoxMOTOCSORTHandle* h) {
+    if (h) { h->empty_frames = 0; h->stepped = false; h->layout = -1; }
+    return boxmot_hip_deepocsort_reset(h ? h->inner : nullptr);
+}
 int boxmot_ocsort_update(BoxMOTOCSORTHandle* h, const float* dets, int det_rows, int det_cols, const uint8_t* image,
                          int image_rows, int image_cols, int image_channels, float* out_tracks, int out_capacity_rows,
                          int out_cols, int* out_rows, int* out_is_obb) {
-    return boxmot_hip_deepocsort_update(h ? h->inner : nullptr, dets, det_rows, det_cols, nullptr, 0, 0, image, image_rows,
-                                        image_cols, image_channels, out_tracks, out_capacity_rows, out_cols, out_rows, out_is_obb);
+    if (!h) return boxmot_hip_deepocsort_update(nullptr, dets, det_rows, det_cols, nullptr, 0, 0, image, image_rows, image_cols,
+                                                image_channels, out_tracks, out_capacity_rows, out_cols, out_rows, out_is_obb);
+    const int ok = guard([&]() {
+        int is_obb = 0;
+        if (compat_layout(h, det_rows, det_cols, is_obb, "OCSORT") && is_obb != h->cfg.is_obb) {
+            h->cfg.is_obb = is_obb;
+            BoxMOTHipDeepOcSort* inner = boxmot_hip_deepocsort_create(&h->cfg);    // not stepped yet: the tables of the other layout
+            if (!inner) throw std::runtime_error(g_last_error);
+            delete h->inner;
+            h->inner = inner;
+        }
+    });
+    if (!ok) return 0;
+    if (det_rows == 0 && det_cols == 0) det_cols = h->layout == 1 ? 7 : 6;
+    if (h->layout < 0 && det_rows == 0) {          // a 0 x 0 table before the layout is known: the frame only counts
+        h->empty_frames += 1;
+        if (out_rows) *out_rows = 0;
+        if (out_is_obb) *out_is_obb = 0;
+        return 1;
+    }
+    const int fc = h->empty_frames > 0 ? h->empty_frames : -1;
+    h->empty_frames = 0;
+    const int rc = boxmot_hip_deepocsort_update_stream(h->inner, 0, fc, nullptr, dets, det_rows, det_cols, nullptr, 0, 0, image, image_rows,
+                                                       image_cols, image_channels, out_tracks, out_capacity_rows, out_cols, out_rows, out_is_obb);
+    if (rc) h->stepped = true;
+    return rc;
 }
 const char* boxmot_ocsort_last_error() { return g_last_error.c_str(); }
 

@@ -493,8 +493,15 @@ __device__ inline double asso_pair(int mode, double diag, const double* a, const
     return (iou - inner / outer + alpha * vv + 1) / 2.0;
 }
 #else
-// the association function of an oriented tracker: AssociationFunction.iou_batch_obb (iou.py:38-115, :152-154), a = detection, b = track
-__device__ inline double asso_pair(int /*mode*/, double /*diag*/, const double* a, const double* b) { return obb_iou(a, b); }
+// the association function of an oriented tracker (AssociationFunction._get_asso_func, iou.py:408-417: "iou_obb" and "centroid_obb" are
+// the oriented names): iou_batch_obb (iou.py:38-115, :152-154) or centroid_batch_obb (iou.py:263-274); a = detection, b = track
+__device__ inline double asso_pair(int mode, double diag, const double* a, const double* b) {
+    if (mode == bm::ASSO_CENTROID) {
+        const double dx = a[0] - b[0], dy = a[1] - b[1];
+        return 1 - sqrt(dx * dx + dy * dy) / diag;
+    }
+    return obb_iou(a, b);
+}
 #endif
 
 #if !BM_OBB

@@ -20,8 +20,8 @@ __device__ inline double obb_wrap_angle(double a) {
 // (iou.py:38-84: pairs whose AABBs do not overlap are 0), corners in fp32 like RotatedRect::points, then the intersection polygon by
 // clipping a's corners with b's four half-planes and the shoelace area, fp64 (the reference: cv2.rotatedRectangleIntersection +
 // contourArea; OpenCV is absent offline, so parity is unpinned for this one quantity -- DESIGN.md section 4.6c).
-__device__ inline void obb_corners(const double* r, double (&p)[4][2]) {
-    const double deg = r[4] * (180.0 / OBB_PI);             // np.degrees
+// cv2.boxPoints of ((cx, cy), (w, h), deg): `deg` as the caller's NumPy expression produced it
+__device__ inline void obb_corners_deg(const double* r, double deg, double (&p)[4][2]) {
     const double a = deg * OBB_PI / 180.0;
     const float b = (float)cos(a) * 0.5f, s = (float)sin(a) * 0.5f;
     const float cx = (float)r[0], cy = (float)r[1], w = (float)r[2], h = (float)r[3];
@@ -29,6 +29,9 @@ __device__ inline void obb_corners(const double* r, double (&p)[4][2]) {
     const float p1x = cx + s * h - b * w, p1y = cy - b * h - s * w;
     p[0][0] = p0x; p[0][1] = p0y; p[1][0] = p1x; p[1][1] = p1y;
     p[2][0] = 2.0f * cx - p0x; p[2][1] = 2.0f * cy - p0y; p[3][0] = 2.0f * cx - p1x; p[3][1] = 2.0f * cy - p1y;
+}
+__device__ inline void obb_corners(const double* r, double (&p)[4][2]) {
+    obb_corners_deg(r, r[4] * (180.0 / OBB_PI), p);          // np.degrees of an fp64 angle (iou.py:14-15)
 }
 __device__ inline double obb_iou(const double* r1, const double* r2) {
     const double hw1 = r1[2] / 2, hh1 = r1[3] / 2, c1 = fabs(cos(r1[4])), s1 = fabs(sin(r1[4]));

@@ -94,10 +94,7 @@ class DeepOcSort(BaseTracker):
             _lib.check(self._lib.boxmot_hip_deepocsort_reserve(self._handle, *self._reserved))
 
     def _check_obb_options(self) -> None:
-        from boxmot_amd.basetracker import ASSO_NAMES
-        if self.is_obb and self._asso_func_base_name != "iou" and self.asso_func_name in ASSO_NAMES:      # i.e. centroid_obb
-            raise NotImplementedError(
-                f"oriented detections are associated with the rotated IoU (asso_func='iou' -> 'iou_obb'); '{self.asso_func_name}' is not implemented")
+        pass        # iou_obb and centroid_obb are the oriented association functions (iou.py:408-417), both on the device
 
     def _set_detection_mode(self, is_obb: bool) -> None:
         """The first detection table decides the layout (basetracker.py:163-173); a tracker that has not stepped yet gets a handle
@@ -109,7 +106,8 @@ class DeepOcSort(BaseTracker):
             self._cfg.is_obb = int(self.is_obb)
             # the oriented step has one association function, the rotated IoU; a name without an oriented twin (giou_obb, ...) is
             # reported by the first-frame check of BaseTracker._preprocess, as the reference reports it
-            self._cfg.asso_func = 0 if self.is_obb else _lib.ASSO_FUNCS.get(self._asso_func_base_name, 0)
+            oriented = {"iou": _lib.ASSO_FUNCS["iou"], "centroid": _lib.ASSO_FUNCS["centroid"]}
+            self._cfg.asso_func = oriented.get(self._asso_func_base_name, 0) if self.is_obb else _lib.ASSO_FUNCS.get(self._asso_func_base_name, 0)
             self._create_handle()
             self._ids_issued = ctypes.c_int(0)
 

@@ -33,7 +33,7 @@ def shard_streams(n_streams_total: int, rank: int, world: int) -> list[int]:
 
 class MultiStreamBotSort:
     def __init__(self, n_streams: int, max_tracks: int = 1024, max_dets: int = 256, emb_dim: int = 512,
-                 reid_weights=None, use_cmc: bool = False, cmc_method: str | None = None, **botsort_kwargs):
+                 reid_weights=None, use_cmc: bool = False, cmc_method: str | None = None, is_obb: bool = False, **botsort_kwargs):
         # camera-motion compensation: the warp of a stream is supplied per frame with set_warp() (estimating it from the
         # images is the caller's, as for BotSort(cmc=...)); use_cmc only documents the intent.  cmc_method = "sof" / "ecc"
         # makes the handle estimate it itself from the frames it is given (host updates and device-resident steps alike)
@@ -47,6 +47,10 @@ class MultiStreamBotSort:
         for k, v in botsort_kwargs.items():
             setattr(cfg, k, int(v) if isinstance(v, bool) else v)
         cfg.n_streams, cfg.max_tracks, cfg.max_dets, cfg.emb_dim, cfg.n_class_lists = n_streams, max_tracks, max_dets, emb_dim, 1
+        # oriented detections (7 columns in, 9 out; include/boxmot_hip.h is_obb): every stream of the handle has the same layout
+        self.is_obb = bool(is_obb)
+        cfg.is_obb = int(self.is_obb)
+        self._det_cols, self._out_cols = (7, 9) if self.is_obb else (6, 8)
         if cmc_method is not None:
             self._cmc_method = cmc_method.encode()          # (kept alive: the struct holds a char pointer)
             cfg.cmc_method = self._cmc_method
@@ -66,7 +70,7 @@ class MultiStreamBotSort:
         submitted to a ``boxmot_amd.ingest.FrameRing`` slot -- the call makes the device wait for that upload, tracks, and
         releases the slot; the host never waits for a frame copy."""
         S = len(dets_list)
-        dets = [np.ascontiguousarray(d, dtype=np.float32).reshape(-1, 6) for d in dets_list]
+        dets = [np.ascontiguousarray(d, dtype=np.float32).reshape(-1, self._det_cols) for d in dets_list]
         rows = np.array([len(d) for d in dets], dtype=np.int32)
         det_ptrs = (ctypes.c_void_p * S)(*[d.ctypes.data if len(d) else None for d in dets])
         emb_ptrs = None
@@ -94,11 +98,11 @@ class MultiStreamBotSort:
                 ctypes.c_void_p(ring.device_frames(slot)), ring.rows, ring.cols, out_ptrs, cap, out_rows.ctypes.data)
             ring.release(slot, stream)
             _lib.check(ok)
-            return [TrackResults(o[:n, :8].copy()) for o, n in zip(outs, out_rows)]
+            return [TrackResults(o[:n, :self._out_cols].copy()) for o, n in zip(outs, out_rows)]
         _lib.check(self._lib.boxmot_hip_botsort_update_batch(
             self._handle, S, det_ptrs, rows.ctypes.data, emb_ptrs, self.emb_dim if embs is not None else 0,
             img_ptrs, ir, ic, 3, out_ptrs, cap, out_rows.ctypes.data))
-        return [TrackResults(o[:n, :8].copy()) for o, n in zip(outs, out_rows)]
+        return [TrackResults(o[:n, :self._out_cols].copy()) for o, n in zip(outs, out_rows)]
 
     # ---- device-resident step: arguments are raw device addresses (ints) ----
     def step_device(self, d_dets: int, d_det_rows: int, d_embs: int | None, d_frames: int | None, rows: int, cols: int,
@@ -159,7 +163,7 @@ class MultiStreamBotSort:
     def state_dump(self, stream: int, which: int = 0) -> dict:
         cap, dim = self.capacity()[0], self.emb_dim
         ints = np.zeros((cap, 6), dtype=np.int32)
-        kf = np.zeros((cap, 72), dtype=np.float64)
+        kf = np.zeros((cap, 110 if self.is_obb else 72), dtype=np.float64)
         smooth = np.zeros((cap, dim), dtype=np.float32)
         misc = np.zeros((cap, 3), dtype=np.float32)
         rows, fc, ic = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)

@@ -86,7 +86,6 @@ class EmuHipLib:
 
     def boxmot_hip_botsort_set_warp(self, h, stream, ptr):
         rec = self._handles[h]
-        assert not rec["obb"], "the library rejects warps on an oriented-box handle"
         rec["warp"] = None if not ptr else np.ctypeslib.as_array((ctypes.c_double * 6).from_address(ptr)).copy().reshape(2, 3)
         return 1
 
@@ -165,7 +164,7 @@ class EmuHipLib:
     # one emulated step per stream; stream 0 is rec["emu"], the others are made when a batch call first touches them
     def _stream_emu(self, rec, s):
         if s == 0:
-            return rec["emu"]
+            return self._docs_emu(rec) if rec["kind"] == "docs" else rec["emu"]
         extra = rec.setdefault("extra", {})
         if s not in extra:
             if rec["kind"] == "docs":
@@ -213,8 +212,8 @@ class EmuHipLib:
         if c.is_obb and not c.embedding_off:
             self._err = b"boxmot_hip: oriented detections run on OC-SORT (embedding_off = 1); DeepOCSORT takes axis-aligned boxes only"
             return None
-        if c.is_obb and c.asso_func != 0:
-            self._err = b"boxmot_hip: the oriented step has the rotated IoU only (asso_func must be BOXMOT_HIP_ASSO_IOU)"
+        if c.is_obb and c.asso_func not in (0, 5):
+            self._err = b"boxmot_hip: the oriented step has the rotated IoU and the centroid distance (asso_func must be BOXMOT_HIP_ASSO_IOU or _CENTROID)"
             return None
         names = {v: k for k, v in ASSO_MODES.items()}
         cfg = dict(det_thresh=c.det_thresh, iou_threshold=c.iou_threshold, inertia=c.inertia, w_association_emb=c.w_association_emb,
@@ -223,23 +222,33 @@ class EmuHipLib:
                    use_byte=c.use_byte, asso_func=names[c.asso_func], frame_wh=(c.frame_w, c.frame_h))
         h = self._next
         self._next += 1
-        rec = dict(cfg=cfg, cap=c.max_tracks, nd=c.max_dets, dim=1 if c.embedding_off else int(c.emb_dim), obb=bool(c.is_obb), kind="docs")
-        rec["emu"] = EmuDeepOcSort(cfg, cap=rec["cap"], nd=rec["nd"], dim=rec["dim"], threads=self._threads, obb=rec["obb"])
-        self._handles[h] = rec
+        # (the step is made at the first update: the library takes the frame size of `centroid` from the first image it sees,
+        # docs_need_frame_size in boxmot_hip.hip)
+        self._handles[h] = dict(cfg=cfg, cap=c.max_tracks, nd=c.max_dets, dim=1 if c.embedding_off else int(c.emb_dim), obb=bool(c.is_obb), kind="docs",
+                                emu=None)
         return h
+
+    def _docs_emu(self, rec, rows=0, cols=0):
+        from emu_util import EmuDeepOcSort
+        if rec["emu"] is None:
+            cfg = dict(rec["cfg"])
+            if tuple(cfg["frame_wh"]) == (0, 0):
+                cfg["frame_wh"] = (cols, rows)
+            rec["emu"] = EmuDeepOcSort(cfg, cap=rec["cap"], nd=rec["nd"], dim=rec["dim"], threads=self._threads, obb=rec["obb"])
+        return rec["emu"]
 
     def boxmot_hip_deepocsort_destroy(self, h):
         rec = self._handles.pop(h, None)
-        if rec:
+        if rec and rec["emu"]:
             rec["emu"].close()
-            for e in rec.get("extra", {}).values():
-                e.close()
+        for e in (rec or {}).get("extra", {}).values():
+            e.close()
 
     def boxmot_hip_deepocsort_reset(self, h):
-        from emu_util import EmuDeepOcSort
         rec = self._handles[h]
-        rec["emu"].close()
-        rec["emu"] = EmuDeepOcSort(rec["cfg"], cap=rec["cap"], nd=rec["nd"], dim=rec["dim"], threads=self._threads, obb=rec["obb"])
+        if rec["emu"]:
+            rec["emu"].close()
+        rec["emu"] = None
         return 1
 
     def boxmot_hip_deepocsort_update_stream(self, h, stream, frame_count_set, id_count_ref, dets, n, det_cols, embs, emb_rows, emb_cols,
@@ -256,7 +265,7 @@ class EmuHipLib:
         if embs and emb_rows and not rec["cfg"]["embedding_off"]:
             e = np.ctypeslib.as_array((ctypes.c_float * (emb_rows * emb_cols)).from_address(embs)).reshape(emb_rows, emb_cols).copy()
         try:
-            got = rec["emu"].update(d, e)
+            got = self._docs_emu(rec, rows, cols).update(d, e)
         except RuntimeError as exc:
             self._err = str(exc).encode()
             return 0
@@ -277,7 +286,7 @@ class EmuHipLib:
         return 1
 
     def boxmot_hip_deepocsort_state_dump(self, h, stream, ints, kf, emb, rows, fc, ic):
-        d = self._handles[h]["emu"].dump()
+        d = self._docs_emu(self._handles[h]).dump()
         for ptr, arr, ct in ((ints, d["ints"], ctypes.c_int32), (kf, d["kf"], ctypes.c_double)):
             if ptr and arr.size:
                 np.ctypeslib.as_array((ct * arr.size).from_address(ptr))[:] = arr.reshape(-1)

@@ -295,3 +295,66 @@ def test_reference_reid_capi_binding(lib, tmp_path, monkeypatch, mode):
         lib.boxmot_reid_capi_destroy(h)
     h = ctypes.c_void_p()
     assert lib.boxmot_reid_capi_create(str(path).encode(), b"letterbox", ctypes.byref(h)) == 0 and not h.value
+
+
+# The reference's native trackers take a 6- or 7-column table per call (live_c_api.hpp:22-60) and write 9-column oriented rows with
+# out_is_obb = 1 (:118-149); its Python wrappers fix the layout with the first table (native/trackers/*.py: "cannot switch between AABB
+# and OBB inputs").  The same calls on this library's reference-named entry points:
+def _call_update_obb(fn, handle, dets, img, cols):
+    dets = np.ascontiguousarray(dets, dtype=np.float32)
+    n = len(dets)
+    out = np.zeros((max(n, 1), 9), dtype=np.float32)
+    out_rows, out_is_obb = ctypes.c_int(0), ctypes.c_int(0)
+    img = np.ascontiguousarray(img)
+    ok = fn(handle, _fp(dets) if n else None, n, cols, img.ctypes.data_as(_U8), img.shape[0], img.shape[1], 3, _fp(out), out.shape[0], 9,
+            ctypes.byref(out_rows), ctypes.byref(out_is_obb))
+    return ok, out[: out_rows.value].copy(), out_is_obb.value
+
+
+def test_reference_bytetrack_and_ocsort_bindings_with_oriented_tables(lib):
+    """ByteTrack and OC-SORT against the oriented oracles (float-typed configuration like the C structs), an empty 0 x 0 table before and
+    after, the refused layout switch, reset."""
+    from common import obb_frames
+    from oracle.bytetrack_obb import ByteTrackObbOracle
+    from oracle.ocsort_obb import OcSortObbOracle
+    img = np.zeros((480, 640, 3), dtype=np.uint8)
+
+    def rows_match(got, want, t):
+        want = np.asarray(want, dtype=np.float32).reshape(-1, 9)
+        assert got.shape == want.shape and np.array_equal(got[:, 5:], want[:, 5:]), t
+        assert np.allclose(got[:, :5], want[:, :5], rtol=0, atol=1e-3), t
+
+    bcfg = _ByteTrackCConfig(0.1, 0.45, 0.8, 25, 30, 50)
+    h = lib.boxmot_bytetrack_create(ctypes.byref(bcfg))
+    assert h, lib.boxmot_bytetrack_last_error()
+    orc = ByteTrackObbOracle(min_conf=_f32(0.1), track_thresh=_f32(0.45), match_thresh=_f32(0.8), track_buffer=25, frame_rate=30)
+    ok, got, is_obb = _call_update_obb(lib.boxmot_bytetrack_update, h, np.empty((0, 0), np.float32), img, 0)      # before the layout is known
+    assert ok == 1 and len(got) == 0 and is_obb == 0
+    orc.update(np.empty((0, 7), np.float32), img)
+    for t, d in enumerate(obb_frames(80, seed=5)):
+        ok, got, is_obb = _call_update_obb(lib.boxmot_bytetrack_update, h, d, img, 7)
+        assert ok == 1, lib.boxmot_bytetrack_last_error()
+        assert is_obb == 1
+        rows_match(got, orc.update(d.copy(), img), t)
+    ok, got, is_obb = _call_update_obb(lib.boxmot_bytetrack_update, h, np.empty((0, 0), np.float32), img, 0)      # keeps the layout
+    assert ok == 1 and is_obb == 1
+    ok, _, _ = _call_update_obb(lib.boxmot_bytetrack_update, h, np.array([[10, 10, 40, 60, 0.9, 0]], np.float32), img, 6)
+    assert ok == 0 and b"cannot switch between AABB and OBB inputs" in lib.boxmot_bytetrack_last_error()
+    assert lib.boxmot_bytetrack_reset(h) == 1                                       # after a reset the next table decides again
+    ok, got, is_obb = _call_update_obb(lib.boxmot_bytetrack_update, h, np.array([[10, 10, 40, 60, 0.9, 0]], np.float32), img, 6)
+    assert ok == 1 and is_obb == 0 and got.shape == (1, 9) and got[0, 8] == 0
+    lib.boxmot_bytetrack_destroy(h)
+
+    ocfg = _OcSortCConfig(0.1, 0.3, 0.3, 30, 3, 3, 1, 0.2, 0.01, 0.0001, 50)
+    h = lib.boxmot_ocsort_create(ctypes.byref(ocfg))
+    assert h, lib.boxmot_ocsort_last_error()
+    orc = OcSortObbOracle(min_conf=_f32(0.1), use_byte=True, det_thresh=_f32(0.3), iou_threshold=_f32(0.3), max_age=30, min_hits=3,
+                          delta_t=3, inertia=_f32(0.2), Q_xy_scaling=_f32(0.01), Q_s_scaling=_f32(0.0001))
+    for t, d in enumerate(obb_frames(80, seed=5)):
+        ok, got, is_obb = _call_update_obb(lib.boxmot_ocsort_update, h, d, img, 7)
+        assert ok == 1, lib.boxmot_ocsort_last_error()
+        assert is_obb == 1
+        rows_match(got, orc.update(d.copy(), img), t)
+    ok, _, _ = _call_update_obb(lib.boxmot_ocsort_update, h, np.zeros((1, 5), np.float32), img, 5)
+    assert ok == 0 and b"6 (AABB) or 7 (OBB) columns" in lib.boxmot_ocsort_last_error()
+    lib.boxmot_ocsort_destroy(h)

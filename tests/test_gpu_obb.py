@@ -100,9 +100,10 @@ def test_c_abi_guards_of_the_oriented_handle():
     lib.boxmot_hip_botsort_default_config(ctypes.byref(cfg))
     assert cfg.is_obb == 0
     cfg.with_reid, cfg.max_tracks, cfg.max_dets, cfg.emb_dim, cfg.is_obb = 0, 64, 32, 1, 1
-    cfg.cmc_method = b"ecc"
-    assert not lib.boxmot_hip_botsort_create(ctypes.byref(cfg)) and "oriented" in _lib.last_error()
-    cfg.cmc_method = None
+    cfg.reid_model_path = b"/nonexistent/weights.bin"
+    cfg.with_reid = 1
+    assert not lib.boxmot_hip_botsort_create(ctypes.byref(cfg)) and "oriented" in _lib.last_error()       # in-handle ReID: embeddings come as embs
+    cfg.reid_model_path, cfg.with_reid = None, 0
     h = lib.boxmot_hip_botsort_create(ctypes.byref(cfg))
     assert h
     img = np.zeros((64, 64, 3), np.uint8)
@@ -117,13 +118,107 @@ def test_c_abi_guards_of_the_oriented_handle():
     assert np.allclose(out[0], [32, 32, 20, 10, 0.15, 1, 0.95, 0, 0], atol=1e-6)
     assert update(np.array([[22, 27, 42, 37, 0.95, 0]])) == 0 and "oriented" in _lib.last_error()        # 6 columns on an oriented handle
     warp = np.eye(2, 3)
-    assert lib.boxmot_hip_botsort_set_warp(h, 0, warp.ctypes.data) == 0 and "oriented" in _lib.last_error()
+    assert lib.boxmot_hip_botsort_set_warp(h, 0, warp.ctypes.data) == 1          # applied to the oriented tracks by the next step
+    assert update(np.array([[32, 32, 20, 10, 0.15, 0.95, 0]])) == 1 and rows.value == 1
     lib.boxmot_hip_botsort_destroy(h)
     # and the other way round: 7 columns on an axis-aligned handle
     cfg.is_obb = 0
     h = lib.boxmot_hip_botsort_create(ctypes.byref(cfg))
     assert update(np.array([[32, 32, 20, 10, 0.15, 0.95, 0]])) == 0 and "is_obb" in _lib.last_error()
     lib.boxmot_hip_botsort_destroy(h)
+
+
+@pytest.mark.parametrize("with_reid", [False, True])
+def test_oriented_tracks_follow_camera_motion_like_the_reference_flow(with_reid):
+    """BotSort(cmc=...) on oriented detections: the estimator sees the enclosing boxes, its warp is applied on the device
+    (STrack.multi_gmc_obb) -- rows and the fp64 filter state against the oracle, whose flow is pinned on the reference class under
+    scheduled warps (tests/test_oracle_obb.py; cv2.transform / cv2.minAreaRect restated on both sides)."""
+    from boxmot_amd import BotSort
+    from boxmot_amd.scenario import camera_warps, stress_frames
+    from oracle.botsort_obb import BotSortObbOracle
+
+    class Scheduled:
+        def __init__(self, w):
+            self.w, self.k = w, 0
+
+        def apply(self, img, dets):
+            assert np.asarray(dets).shape[1:] == (4,)
+            self.k += 1
+            return self.w[self.k - 1]
+    n = 120
+    warps = camera_warps(n, seed=7)
+    trk = BotSort(reid_model=None, with_reid=with_reid, cmc=Scheduled(warps), max_tracks=128, max_dets=64, emb_dim=EMB)
+    orc = BotSortObbOracle(with_reid=with_reid)
+    img = np.zeros((480, 640, 3), np.uint8)
+    embs = [e for _, e in stress_frames(n, seed=7)]
+    for t, d in enumerate(obb_frames(n, seed=7)):
+        e = embs[t] if with_reid else None
+        _rows_match(trk.update(d, img, e), orc.update(d.copy(), img, None if e is None else e.copy(), warp=warps[t]), t)
+    for which, recs in ((0, orc.active), (1, orc.lost)):
+        d = trk.state_dump(which)
+        assert list(d["ints"][:, 0]) == [r.id for r in recs]
+        if d["n"]:
+            ref = np.concatenate([np.array([r.mean for r in recs]), np.array([r.cov for r in recs]).reshape(-1, 100)], 1)
+            assert np.allclose(d["kf"], ref, rtol=2e-6, atol=1e-6)       # the refit goes through fp32 corner points: device libm vs host libm
+    trk.close()
+
+
+def test_oriented_streams_in_one_handle_equal_single_stream_trackers():
+    """update_batch on an oriented multi-stream handle: every stream's rows equal those of a single-stream ByteTrack-free BoT-SORT fed
+    the same oriented detections."""
+    from boxmot_amd import BotSort
+    from boxmot_amd.streams import MultiStreamBotSort
+    S, n = 3, 60
+    ms = MultiStreamBotSort(S, max_tracks=128, max_dets=64, emb_dim=1, is_obb=True, with_reid=False)
+    singles = [BotSort(reid_model=None, with_reid=False, use_cmc=False, max_tracks=128, max_dets=64) for _ in range(S)]
+    frames = [list(obb_frames(n, seed=4 + s)) for s in range(S)]
+    img = np.zeros((480, 640, 3), np.uint8)
+    for t in range(n):
+        got = ms.update_batch([frames[s][t] for s in range(S)])
+        for s in range(S):
+            want = singles[s].update(frames[s][t], img)
+            assert got[s].shape == want.shape and np.array_equal(np.asarray(got[s]), np.asarray(want)), (t, s)
+    ms.close()
+    for trk in singles:
+        trk.close()
+
+
+@pytest.mark.parametrize("method", ["ecc", "sof"])
+def test_in_handle_estimators_on_an_oriented_handle_equal_the_estimator_objects(method):
+    """cmc_method = "ecc" / "sof" inside an oriented handle (SOF masked by the enclosing boxes computed on the device) against the same
+    estimator as a Python object handing its warp to set_warp (BotSort(cmc=...), which computes the enclosing boxes on the host): the same
+    warps, therefore the same rows."""
+    from boxmot_amd import BotSort
+    from boxmot_amd.cmc import get_cmc_method
+    from boxmot_amd.streams import MultiStreamBotSort
+    rng = np.random.default_rng(2)
+    base = rng.integers(0, 255, (480, 640, 3), dtype=np.uint8)
+    n = 40
+    frames = list(obb_frames(n, seed=6))
+    inside = MultiStreamBotSort(1, max_tracks=128, max_dets=64, emb_dim=1, is_obb=True, with_reid=False, cmc_method=method)
+    outside = BotSort(reid_model=None, with_reid=False, cmc=get_cmc_method(method)(), max_tracks=128, max_dets=64)
+    for t, d in enumerate(frames):
+        img = np.roll(base, (t % 5, 2 * (t % 3)), axis=(0, 1))
+        got = inside.update_batch([d], [img])[0]
+        want = outside.update(d, img)
+        assert got.shape == want.shape and np.array_equal(np.asarray(got), np.asarray(want)), t
+    inside.close()
+    outside.close()
+
+
+def test_ocsort_centroid_obb_matches_the_oracle():
+    from boxmot_amd import OcSort
+    from oracle.ocsort_obb import OcSortObbOracle
+    kw = dict(asso_func="centroid", iou_threshold=0.9, use_byte=True)
+    trk, orc = OcSort(max_tracks=128, max_dets=64, **kw), OcSortObbOracle(**kw)
+    img = np.zeros((480, 640, 3), np.uint8)
+    for t, d in enumerate(obb_frames(90, seed=4)):
+        got, want = np.asarray(trk.update(d, img)), orc.update(d.copy(), img)
+        assert got.size == want.size, t
+        if want.size:
+            _rows_match(got, want, t)
+    assert trk.asso_func_name == "centroid_obb"
+    trk.close()
 
 
 # ---- OC-SORT ----
@@ -187,7 +282,7 @@ def test_ocsort_oriented_surface_and_c_abi_guards():
     assert cfg.is_obb == 0
     cfg.max_tracks, cfg.max_dets, cfg.is_obb = 64, 32, 1
     assert not lib.boxmot_hip_deepocsort_create(ctypes.byref(cfg)) and "OC-SORT" in _lib.last_error()       # DeepOCSORT has no oriented mode
-    cfg.embedding_off, cfg.cmc_off, cfg.asso_func = 1, 1, 1
+    cfg.embedding_off, cfg.cmc_off, cfg.asso_func = 1, 1, 1                   # giou has no oriented twin
     assert not lib.boxmot_hip_deepocsort_create(ctypes.byref(cfg)) and "rotated IoU" in _lib.last_error()
     cfg.asso_func = 0
     h = lib.boxmot_hip_deepocsort_create(ctypes.byref(cfg))
@@ -203,3 +298,27 @@ def test_ocsort_oriented_surface_and_c_abi_guards():
                                             ctypes.byref(rows), ctypes.byref(obb)) == 1 and rows.value == 1 and obb.value == 1
     assert np.allclose(out[0], [320, 240, 80, 40, 0.15, 1, 0.95, 0, 0], atol=1e-5)
     lib.boxmot_hip_deepocsort_destroy(h)
+
+
+@pytest.mark.parametrize("key", ["bytetrack", "botsort_reid", "ocsort"])
+def test_oriented_trackers_at_the_configuration_2_shape_reproduce_the_reference_rows(key):
+    """64 oriented detections per frame on 256 tracks, 1080p -- BASELINE configuration 2's shape -- against rows of the reference classes
+    (tests/golden/obb_config2_golden.npz), all 60 frames, tables starting small (they grow)."""
+    from boxmot_amd import BotSort, ByteTrack, OcSort
+    from common import GOLDEN, obb_config2_frames
+    g = np.load(GOLDEN / "obb_config2_golden.npz")
+    rows, counts = g[key + "_rows"], g[key + "_counts"]
+    img = np.zeros((1080, 1920, 3), np.uint8)
+    if key == "bytetrack":
+        trk = ByteTrack(max_tracks=64, max_dets=32)
+    elif key == "ocsort":
+        trk = OcSort(use_byte=True, max_tracks=64, max_dets=32)
+    else:
+        trk = BotSort(reid_model=None, use_cmc=False, with_reid=True, max_tracks=64, max_dets=32, emb_dim=EMB)
+    o = 0
+    for t, (d, e) in enumerate(obb_config2_frames(int(g["frames"]))):
+        got = trk.update(d, img, e) if key == "botsort_reid" else trk.update(d, img)
+        _rows_match(got, rows[o:o + counts[t]], t)
+        o += counts[t]
+    assert o == len(rows) and trk.capacity()[2] >= 1
+    trk.close()

@@ -59,6 +59,37 @@ def test_emulated_obb_step_four_wavefronts():
     _run(50, 9, 0, threads=256, with_reid=True)
 
 
+@pytest.mark.parametrize("with_reid", [False, True])
+def test_emulated_obb_step_with_camera_motion(with_reid):
+    """STrack.multi_gmc_obb in the oriented step (kf_warp_wave of the bm::obb layout) against the oracle's restatement under scheduled
+    warps: rows exact, the fp64 filter state to 1e-8 (the refit goes through fp32 corner points and back -- the same roundings on both sides)."""
+    from boxmot_amd.scenario import camera_warps
+    from oracle.botsort_obb import BotSortObbOracle
+    cfg = dict(DEFAULTS)
+    cfg.update(with_reid=with_reid)
+    orc = BotSortObbOracle(with_reid=with_reid)
+    emu = EmuBotSort(cfg, cap=128, nd=64, dim=32, obb=True)
+    n = 80
+    warps = camera_warps(n, seed=4)
+    embs = [e for _, e in stress_frames(n, seed=4)]
+    try:
+        for t, d in enumerate(obb_frames(n, seed=4)):
+            e = embs[t] if with_reid else None
+            want = np.asarray(orc.update(d.copy(), None, None if e is None else e.copy(), warp=warps[t]), dtype=np.float32).reshape(-1, 9)
+            got = emu.update(d, e if e is not None else np.zeros((len(d), 32), np.float32), warp=warps[t])
+            assert got.shape == want.shape, (t, got.shape, want.shape)
+            assert np.array_equal(got[:, 5:], want[:, 5:]), t
+            assert np.allclose(got[:, :5], want[:, :5], rtol=0, atol=2e-4), (t, np.abs(got[:, :5] - want[:, :5]).max())
+        for which, recs in ((0, orc.active), (1, orc.lost)):
+            dd = emu.dump(which)
+            assert list(dd["ints"][:, 0]) == [r.id for r in recs]
+            if dd["n"]:
+                ref = np.concatenate([np.array([r.mean for r in recs]), np.array([r.cov for r in recs]).reshape(-1, 100)], 1)
+                assert np.allclose(dd["kf"], ref, rtol=1e-8, atol=1e-10), np.abs(dd["kf"] - ref).max()
+    finally:
+        emu.close()
+
+
 def _config2_golden(key):
     from common import GOLDEN
     g = np.load(GOLDEN / "obb_config2_golden.npz")

@@ -56,8 +56,8 @@ def test_host_classes_reproduce_the_reference_rows_on_oriented_detections(emulat
 
 # ---- the reference's unit tests, restated ----
 def test_botsort_supports_obb_without_reid(emulated_abi):
-    """tests/unit/test_trackers.py:297-311 -- with use_cmc=False: camera-motion compensation of oriented tracks is not implemented
-    (next test)."""
+    """tests/unit/test_trackers.py:297-311 (use_cmc=False here: the default estimator, ECC, needs the device; the test after this one
+    drives the oriented camera-motion path with a scheduled estimator)."""
     from boxmot_amd import BotSort
     tracker = BotSort(reid_model=None, with_reid=False, use_cmc=False, max_tracks=64, max_dets=32)
     rgb = np.random.default_rng(0).integers(0, 255, size=(640, 640, 3), dtype=np.uint8)
@@ -70,18 +70,35 @@ def test_botsort_supports_obb_without_reid(emulated_abi):
     tracker.close()
 
 
-def test_botsort_with_an_estimator_refuses_oriented_detections_loudly(emulated_abi):
+def test_botsort_with_an_estimator_tracks_oriented_detections_like_the_reference_flow(emulated_abi):
+    """BotSort(cmc=...) on oriented detections: the estimator is handed the enclosing axis-aligned boxes (botsort.py:147-158), its warp
+    is applied to the oriented tracks on the device (STrack.multi_gmc_obb) -- against the oracle, whose flow is pinned on the reference
+    class under scheduled warps (tests/test_oracle_obb.py)."""
     from boxmot_amd import BotSort
+    from boxmot_amd.scenario import camera_warps
+    from oracle.botsort_obb import BotSortObbOracle
+    from oracle import obb
 
-    class Est:
+    class Scheduled:
+        def __init__(self, w):
+            self.w, self.k, self.seen = w, 0, []
+
         def apply(self, img, dets):
-            return np.eye(2, 3)
-    tracker = BotSort(reid_model=None, with_reid=False, cmc=Est(), max_tracks=64, max_dets=32)
-    rgb = np.zeros((64, 64, 3), np.uint8)
-    with pytest.raises(NotImplementedError, match="multi_gmc_obb"):
-        tracker.update(np.array([[32, 32, 20, 10, 0.15, 0.95, 0]], dtype=np.float32), rgb)
-    with pytest.raises(NotImplementedError, match="multi_gmc_obb"):
-        BotSort(reid_model=None, with_reid=False, cmc=Est(), is_obb=True)
+            self.seen.append(np.asarray(dets).copy())
+            self.k += 1
+            return self.w[self.k - 1]
+    n = 50
+    warps = camera_warps(n, seed=4)
+    est = Scheduled(warps)
+    tracker, orc = BotSort(reid_model=None, with_reid=False, cmc=est, max_tracks=128, max_dets=64), BotSortObbOracle(with_reid=False)
+    img = np.zeros((480, 640, 3), np.uint8)
+    for t, d in enumerate(obb_frames(n, seed=4)):
+        _rows_match(tracker.update(d, img), orc.update(d.copy(), img, None, warp=warps[t]), t)
+        boxes = est.seen[-1]
+        assert boxes.shape == (len(d), 4)
+        for k in range(min(len(d), 3)):            # the enclosing box of a detection = min / max of its cv2.boxPoints corners
+            c = obb.box_points(float(d[k, 0]), float(d[k, 1]), max(float(d[k, 2]), 1e-4), max(float(d[k, 3]), 1e-4), float(np.degrees(d[k, 4])))
+            assert np.array_equal(boxes[k], np.array([c[:, 0].min(), c[:, 1].min(), c[:, 0].max(), c[:, 1].max()], dtype=np.float32))
     tracker.close()
 
 
@@ -178,8 +195,18 @@ def test_ocsort_supports_obb_outputs_and_refuses_what_it_has_not(emulated_abi):
     tracker.close()
     with pytest.raises(ValueError, match="Invalid association mode: giou_obb"):          # AssociationFunction's table has no giou_obb
         OcSort(asso_func="giou", max_tracks=64, max_dets=32).update(det, rgb)
-    with pytest.raises(NotImplementedError, match="centroid_obb"):
-        OcSort(asso_func="centroid", max_tracks=64, max_dets=32).update(det, rgb)
+    # centroid_obb (iou.py:263-274), the other oriented association function: against the oracle pinned on the reference class
+    from oracle.ocsort_obb import OcSortObbOracle
+    kw = dict(asso_func="centroid", iou_threshold=0.9, use_byte=True)
+    trk, orc = OcSort(max_tracks=128, max_dets=64, **kw), OcSortObbOracle(**kw)
+    img = np.zeros((480, 640, 3), np.uint8)
+    for t, d in enumerate(obb_frames(40, seed=4)):
+        got, want = np.asarray(trk.update(d, img)), orc.update(d.copy(), img)
+        assert got.size == want.size, t
+        if want.size:
+            _rows_match(got, want, t)
+    assert trk.asso_func_name == "centroid_obb"
+    trk.close()
     trk = DeepOcSort.__new__(DeepOcSort)
     from boxmot_amd.basetracker import BaseTracker
     BaseTracker.__init__(trk, asso_func="iou")
@@ -205,3 +232,19 @@ def test_track_results_names_the_oriented_columns():
     assert r.to_mot_lines(3) == ["3,7,320.00,240.00,80.00,40.00,0.1500,0.950000,2,-1"]
     a = TrackResults(np.array([[1, 2, 3, 4, 7, 0.5, 1, 0]], dtype=np.float32))
     assert not a.is_obb and a.id.tolist() == [7]
+
+
+def test_oriented_multi_stream_handle_equals_per_stream_oracles(emulated_abi):
+    """MultiStreamBotSort(is_obb=True).update_batch over the emulated ABI: every stream's 9-column rows equal its own oracle's."""
+    from boxmot_amd.streams import MultiStreamBotSort
+    from oracle.botsort_obb import BotSortObbOracle
+    S, n = 3, 40
+    ms = MultiStreamBotSort(S, max_tracks=128, max_dets=64, emb_dim=1, is_obb=True, with_reid=False)
+    orcs = [BotSortObbOracle(with_reid=False) for _ in range(S)]
+    frames = [list(obb_frames(n, seed=4 + s)) for s in range(S)]
+    for t in range(n):
+        got = ms.update_batch([frames[s][t] for s in range(S)])
+        for s in range(S):
+            assert got[s].shape[1] == 9 and got[s].is_obb
+            _rows_match(got[s], orcs[s].update(frames[s][t].copy(), None, None), t)
+    ms.close()
