@@ -128,20 +128,8 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def cpu_baseline(sd, mode, n_frames):
-    """The oracle (a port of the reference Python path) timed on this box's host cores:
-    stream 0 of the same workload, 3 confirmation frames untimed, then n_frames timed."""
-    import torch
-
-    from boxmot_amd.scenario import Scenario
-    from boxmot_amd.tracker_zoo import BOTSORT_YAML_DEFAULTS
-    from oracle.botsort import BotSortOracle
-    from oracle.osnet import OracleReID
-
-    kw = {k: v for k, v in BOTSORT_YAML_DEFAULTS.items() if k not in ("use_cmc", "cmc_method")}
+def _host_info():
     total_cores = os.cpu_count() or 1
-    cores = min(total_cores, 32)      # OSNet-x0.25 at batch 64 does not scale past ~32 threads
-    torch.set_num_threads(cores)
     cpu_model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -150,42 +138,151 @@ def cpu_baseline(sd, mode, n_frames):
                 break
     except OSError:
         pass
-    sc = Scenario(N_DETS, N_TRACKS, WIDTH, HEIGHT, EMB_DIM, stream=0, random_image=True)
-    orc = BotSortOracle(reid=OracleReID(sd) if mode == "reid" else None, **kw)
-    rows = []
-    t_timed = 0.0
-    done = 0
+    return total_cores, cpu_model
+
+
+def _botsort_kw():
+    from boxmot_amd.tracker_zoo import BOTSORT_YAML_DEFAULTS
+    return {k: v for k, v in BOTSORT_YAML_DEFAULTS.items() if k not in ("use_cmc", "cmc_method")}
+
+
+def _run_cpu_tracker(trk_update, sc, mode, n_frames, budget_s, tag):
+    """3 confirmation frames untimed, then up to n_frames timed (bounded by budget_s of timed work)."""
+    rows, t_timed, done = [], 0.0, 0
     for t in range(3 + n_frames):
         dets, embs = sc.frame(t, with_embs=(mode != "reid"))
         t0 = time.perf_counter()
-        r = orc.update(dets, sc.image, None if mode == "reid" else embs)
+        r = trk_update(dets, sc.image, None if mode == "reid" else embs)
         dt = time.perf_counter() - t0
         if t >= 3:
             t_timed += dt
             done += 1
-        rows.append(r)
-        log(f"cpu baseline frame {t}: {dt:.2f}s")
-        if t_timed > 25.0:
+        rows.append(np.asarray(r))
+        log(f"{tag} frame {t}: {dt:.2f}s")
+        if t_timed > budget_s:
             break
-    n_frames = max(done, 1)
-    out = dict(value=n_frames / max(t_timed, 1e-9), unit="frames/s", cores=cores, kind="port",
-               cpu_model=cpu_model, host_cores_total=total_cores,
-               sample=f"oracle (NumPy/SciPy BoT-SORT, one Python thread + torch-CPU OSNet-x0.25 on {cores} threads), stream 0, "
-                      f"{n_frames} steady-state frames after 3 confirmation frames, mode={mode}; host = {cpu_model}, "
-                      f"{total_cores} logical cores")
-    # The reference CLASSES cannot run on the GPU box (/root/reference does not travel).  Their timing on the same workload, taken
-    # in the build container by tools/reference_cpu_timing.py (a committed record, another host: NOT this run's measurement), is
-    # attached so that the port's figure can be set against the code it restates.
-    ref = ROOT / "profiles" / "r3_reference_cpu_timing.json"
-    if mode == "reid" and ref.exists():
-        try:
-            rec = json.loads(ref.read_text().strip().splitlines()[-1])
-            out["reference_classes_recorded_elsewhere"] = {
-                "value": rec["frames_per_s"], "unit": "frames/s", "cores": rec["torch_threads"], "kind": "reference",
-                "host": f"build container, {rec['host_logical_cores']} logical cores", "source": "profiles/r3_reference_cpu_timing.json"}
-        except Exception:
-            pass
+    return rows, t_timed, max(done, 1)
+
+
+def oracle_rows(sd, mode, n_frames, stream, budget_s=25.0):
+    """The oracle (the pinned port of the reference Python path) on one stream of the workload: the id gate's checker."""
+    from boxmot_amd.scenario import Scenario
+    from oracle.botsort import BotSortOracle
+    from oracle.osnet import OracleReID
+
+    sc = Scenario(N_DETS, N_TRACKS, WIDTH, HEIGHT, EMB_DIM, stream=stream, random_image=(mode == "reid"))
+    orc = BotSortOracle(reid=OracleReID(sd) if mode == "reid" else None, **_botsort_kw())
+    return _run_cpu_tracker(lambda d, img, e: orc.update(d, img, e), sc, mode, n_frames, budget_s, f"oracle stream {stream}")
+
+
+def reference_rows(sd, mode, n_frames, stream, budget_s=25.0):
+    """The REFERENCE classes themselves (oracle/ref_harness.py: /root/reference in the build container, the byte-compiled
+    oracle/_ref/ on the GPU box; cv2.resize / lap.lapjv answered by the documented stand-ins) on one stream of the workload."""
+    from boxmot_amd.scenario import Scenario
+    from oracle import ref_harness
+
+    BotSort = ref_harness.load_botsort()
+    trk = BotSort(reid_model=None, use_cmc=False, **_botsort_kw())
+    if mode == "reid":
+        osnet = ref_harness.load_osnet_module()
+        model = osnet.osnet_x0_25(num_classes=1, pretrained=False).eval()
+        model.load_state_dict(sd, strict=False)
+        trk.model = ref_harness.RefReID(model)      # the constructor builds its ReID through the registry (not importable offline)
+    sc = Scenario(N_DETS, N_TRACKS, WIDTH, HEIGHT, EMB_DIM, stream=stream, random_image=(mode == "reid"))
+    return _run_cpu_tracker(lambda d, img, e: trk.update(d, img, e), sc, mode, n_frames, budget_s, f"reference stream {stream}")
+
+
+def cpu_baseline(sd, mode, n_frames):
+    """The CPU path timed on THIS box's host cores: stream 0 of the same workload, 3 confirmation frames untimed, then n_frames
+    timed.  kind = "reference" when the reference classes can be imported (always in the build container; on the GPU box when the
+    byte-compiled oracle/_ref/ travelled with the snapshot), else kind = "port" (the oracle).  Returns (record, oracle rows)."""
+    import torch
+
+    total_cores, cpu_model = _host_info()
+    cores = min(total_cores, 32)      # OSNet-x0.25 at batch 64 does not scale past ~32 threads
+    torch.set_num_threads(cores)
+    rows, t_port, n_port = oracle_rows(sd, mode, n_frames, 0)
+    port = dict(value=n_port / max(t_port, 1e-9), unit="frames/s", cores=cores, kind="port", frames=n_port)
+    host = f"host = {cpu_model}, {total_cores} logical cores"
+    out = None
+    try:
+        from oracle import ref_harness
+        if ref_harness.reference_runnable():
+            r_rows, t_ref, n_ref = reference_rows(sd, mode, n_frames, 0)
+            same = all(a.shape == b.shape and np.array_equal(a, b) for a, b in zip(r_rows, rows))
+            out = dict(value=n_ref / max(t_ref, 1e-9), unit="frames/s", cores=cores, kind="reference", cpu_model=cpu_model,
+                       host_cores_total=total_cores, reference_form=ref_harness.reference_kind(),
+                       rows_equal_oracle_rows=bool(same),
+                       sample=f"reference boxmot BotSort.update + reference OSNet-x0.25 (torch CPU, {cores} threads; tracker math one Python "
+                              f"thread; cv2.resize / lap.lapjv = the documented stand-ins), stream 0, {n_ref} steady-state frames after 3 "
+                              f"confirmation frames, mode={mode}; {host}",
+                       port=port)
+    except Exception as exc:        # the reference leg never costs the line its baseline
+        log(f"reference classes not timed: {type(exc).__name__}: {exc}")
+    if out is None:
+        out = dict(port, cpu_model=cpu_model, host_cores_total=total_cores,
+                   sample=f"oracle (NumPy/SciPy BoT-SORT, one Python thread + torch-CPU OSNet-x0.25 on {cores} threads), stream 0, "
+                          f"{n_port} steady-state frames after 3 confirmation frames, mode={mode}; {host}")
     return out, rows
+
+
+def cpu_side_baselines(budget_s=20.0):
+    """Two more CPU figures SURVEY.md section 8(d) asks for, reference classes when runnable (else the oracle port):
+    M1 (BoT-SORT tracker math only, embeddings supplied, 64 dets x 256 tracks) and BASELINE.json configuration 1 (ByteTrack, 32
+    synthetic detections per frame, 640 x 640: the reference's own CPU-runnable case, tests/performance/benchmark_fps.py:171-220)
+    with boxmot_amd.ByteTrack's host-API rate on the same detections beside it."""
+    from boxmot_amd.scenario import Scenario
+    from oracle import ref_harness
+
+    total_cores, cpu_model = _host_info()
+    use_ref = ref_harness.reference_runnable()
+    out = {"kind": "reference" if use_ref else "port", "cpu_model": cpu_model, "cores": 1}
+    # M1: supplied embeddings
+    try:
+        fn = reference_rows if use_ref else oracle_rows
+        _, t1, n1 = fn(None, "embs", 40, 0, budget_s=budget_s / 2)
+        out["m1_tracker_math_64x256"] = {"value": n1 / t1, "unit": "frames/s", "frames": n1}
+    except Exception as exc:
+        out["m1_tracker_math_64x256"] = {"error": f"{type(exc).__name__}: {exc}"}
+    # configuration 1: ByteTrack, 32 dets, 640 x 640
+    try:
+        sc = Scenario(32, 32, width=640, height=640, emb_dim=8, random_image=False)
+        frames = [sc.frame(t)[0] for t in range(20 + 400)]
+        img = np.zeros((640, 640, 3), dtype=np.uint8)
+        if use_ref:
+            trk = ref_harness.load_bytetrack()()
+            upd = lambda d: trk.update(d, img)
+        else:
+            from oracle.bytetrack import ByteTrackOracle
+            trk = ByteTrackOracle()
+            upd = lambda d: trk.update(d, img)
+        for d in frames[:20]:
+            upd(d)
+        t0 = time.perf_counter()
+        n = 0
+        for d in frames[20:]:
+            upd(d)
+            n += 1
+            if time.perf_counter() - t0 > budget_s / 2:
+                break
+        cpu_fps = n / (time.perf_counter() - t0)
+        from boxmot_amd.bytetrack import ByteTrack
+        dt = ByteTrack(max_tracks=128, max_dets=64)
+        for d in frames[:20]:
+            dt.update(d, img)
+        t0 = time.perf_counter()
+        for d in frames[20:20 + n]:
+            dt.update(d, img)
+        dev_fps = n / (time.perf_counter() - t0)
+        dt.close()
+        out["config1_bytetrack_32dets_640x640"] = {
+            "cpu": {"value": cpu_fps, "unit": "frames/s", "frames": n, "what": ("reference ByteTrack.update" if use_ref else "oracle ByteTrack port") + ", one Python thread"},
+            "boxmot_amd_host_api": {"value": dev_fps, "unit": "frames/s", "frames": n,
+                                    "what": "boxmot_amd.ByteTrack.update, ONE stream through the synchronous plugin call (upload, one-workgroup frame "
+                                            "step, read-back per frame): a latency figure, not the device's throughput"}}
+    except Exception as exc:
+        out["config1_bytetrack_32dets_640x640"] = {"error": f"{type(exc).__name__}: {exc}"}
+    return out
 
 
 def m1_tracker_only(kw, dev, rank, streams=256):
@@ -605,15 +702,26 @@ def main(argv=None):
         if stub:
             a.no_m1 = a.no_side_configs = a.no_cpu_baseline = True
         if not a.no_cpu_baseline:
-            # the oracle on stream 0: at N = 1 timed as the CPU baseline (the contract); at every N the id parity gate
+            # the CPU path on stream 0: at N = 1 timed as the CPU baseline (the contract); at every N the id parity gate -- on
+            # streams 0, S/2 and S - 1 of rank 0's shard (the first, a middle and the LAST workgroup / crop range of the launch the
+            # headline times: an indexing fault at high stream or crop indices fails the gate)
             cb, rows = cpu_baseline(sd, a.mode, a.cpu_frames if world == 1 else min(a.cpu_frames, 4))
             if world == 1:
                 res["cpu_baseline"] = cb
-            ok = True
-            for t in range(min(len(rows), T)):
-                got = out_h[t, 0, : out_n_h[t, 0]]
-                ok &= got.shape == rows[t].shape and bool(np.array_equal(got[:, 4:], rows[t][:, 4:]))
-            res["config"]["parity_ids_exact_vs_oracle_stream0"] = bool(ok)
+
+            def ids_equal(stream, want):
+                ok = True
+                for t in range(min(len(want), T)):
+                    got = out_h[t, stream, : out_n_h[t, stream]]
+                    ok &= got.shape == want[t].shape and bool(np.array_equal(got[:, 4:], want[t][:, 4:]))
+                return bool(ok)
+            gate = {0: ids_equal(0, rows)}
+            for s_chk in sorted({S // 2, S - 1} - {0}):
+                r_s, _, _ = oracle_rows(sd, a.mode, min(len(rows) - 3, a.cpu_frames), s_chk, budget_s=12.0)
+                gate[s_chk] = ids_equal(s_chk, r_s)
+            res["config"]["parity_ids_exact_vs_oracle_stream0"] = gate[0]
+            res["config"]["parity_ids_exact_vs_oracle_streams"] = {str(k): v for k, v in gate.items()}
+            res["config"]["parity_ids_exact_all_gated_streams"] = all(gate.values())
             res["config"]["parity_id_gate_frames"] = int(min(len(rows), T))
             if a.mode == "reid":
                 res["config"].update(reid_parity_gates(sd, a.reid_mode))
@@ -625,6 +733,11 @@ def main(argv=None):
                 res["tracker_math_m1"] = m1_tracker_only(kw, dev, rank, a.streams)
             except Exception as exc:
                 res["tracker_math_m1"] = {"error": f"{type(exc).__name__}: {exc}"}
+        if world == 1 and a.mode == "reid" and not a.no_cpu_baseline and not a.no_m1:
+            try:
+                res["cpu_side_baselines"] = cpu_side_baselines()
+            except Exception as exc:
+                res["cpu_side_baselines"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and a.mode == "reid" and not a.no_side_configs and a.reid_mode != 1:
             try:
                 res["fp16_family_line"] = alt_family_line(kw, sd, dev, 1)

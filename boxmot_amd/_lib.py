@@ -209,6 +209,7 @@ SIGNATURES = {
     "boxmot_hip_ingest_host_done": (_I, [_VP, _I]),
     "boxmot_hip_last_error": (ctypes.c_char_p, []),
     "boxmot_hip_device_count": (_I, []),
+    "boxmot_hip_botsort_device": (_I, [_VP]),
 }
 
 

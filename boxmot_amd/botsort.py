@@ -117,6 +117,7 @@ class BotSort(BaseTracker):
         cfg.tracker_kind = int(_tracker_kind)
         cfg.is_obb = int(self.is_obb)
         self._cfg = cfg
+        self._seed_frame_count = False
         self._handle = None
         self._reserved = (0, 0)
         self._max_tracks = max_tracks
@@ -162,6 +163,9 @@ class BotSort(BaseTracker):
             self._check_obb_options()
             self._cfg.is_obb = int(self.is_obb)
             self._create_handle()
+            # frames that carried no layout (update(None, img), 1-D empty tables) have already advanced the replaced handle's
+            # device frame counter; the reference keeps counting through them, so the new handle starts from the host's count
+            self._seed_frame_count = self.frame_count > 0
 
     # ------------------------------------------------------------------ update
     def _update_impl(self, dets, img, embs=None, masks=None, class_list: int = 0) -> np.ndarray:
@@ -196,7 +200,7 @@ class BotSort(BaseTracker):
         out_rows = ctypes.c_int(0)
         out_is_obb = ctypes.c_int(0)
         ok = self._lib.boxmot_hip_botsort_update_stream(
-            self._handle, 0, int(class_list), int(self.frame_count) if self.per_class else -1,
+            self._handle, 0, int(class_list), int(self.frame_count) if (self.per_class or self._seed_frame_count) else -1,
             det_arr.ctypes.data if n else None, n, self.det_cols,
             feats.ctypes.data if (feats is not None and n) else None, n if feats is not None else 0,
             self._emb_dim if feats is not None else 0,
@@ -206,6 +210,7 @@ class BotSort(BaseTracker):
         )
         if _lib.step_ran(ok):       # a per-stream status report (capacity, solver) is raised after the step has run
             self.frame_count += 1
+            self._seed_frame_count = False
         _lib.check(ok)
         return out[: out_rows.value, :self.output_cols].copy()
 

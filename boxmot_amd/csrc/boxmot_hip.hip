@@ -40,6 +40,53 @@ int guard(F&& f) {
     return 0;
 }
 
+// Handle <-> device affinity (include/boxmot_hip.h, "Devices"): a handle lives on the HIP device that was current on the thread
+// that created it (its tables, streams, events and engines are that device's); every entry point that takes a handle makes that
+// device current for the duration of the call and restores the caller's device on exit, so one process can drive handles of
+// several GPUs from any thread (SURVEY.md section 8(e)'s "one process, G HIP devices" layout) without a handle silently following
+// the caller's current device.  The reference's threading contract (reid_capi.h:61-70): distinct handles on distinct threads.
+struct DeviceBound {
+    int device = -1;
+    DeviceBound() { if (hipGetDevice(&device) != hipSuccess) device = -1; }
+};
+
+class DeviceScope {
+    int prev_ = -1;
+    bool switched_ = false;
+public:
+    explicit DeviceScope(int device) {
+        if (device < 0) return;
+        if (hipGetDevice(&prev_) != hipSuccess) prev_ = -1;
+        if (prev_ != device) {
+            if (hipSetDevice(device) != hipSuccess) throw std::runtime_error("boxmot_hip: cannot make the handle's device current (hipSetDevice failed)");
+            switched_ = true;
+        }
+    }
+    ~DeviceScope() { if (switched_ && prev_ >= 0) (void)hipSetDevice(prev_); }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+};
+
+template <class H, class F>
+int guard_on(H* h, F&& f) {
+    return guard([&]() {
+        DeviceScope scope(h ? h->device : -1);
+        f();
+    });
+}
+
+// destroy on the handle's own device (streams / events / allocations are released where they were made)
+template <class H>
+void destroy_on(H* h) {
+    if (!h) return;
+    try {
+        DeviceScope scope(h->device);
+        delete h;
+    } catch (...) {
+        delete h;
+    }
+}
+
 constexpr int STEP_THREADS = 512;
 constexpr int SS_STEP_THREADS_BIG = 1024;     // StrongSORT frame step with max_tracks >= 1024
 
@@ -179,7 +226,7 @@ __global__ void pad_crop_list_kernel(const int* crop_count, int bound, int* crop
 
 }  // namespace
 
-struct BoxMOTHipReID {
+struct BoxMOTHipReID : DeviceBound {
     std::unique_ptr<bm::ReidEngine> engine;
     std::vector<void*> owned;
     hipStream_t stream = nullptr;
@@ -202,7 +249,7 @@ struct BoxMOTHipReID {
 };
 
 // ECC camera-motion estimator (csrc/cmc_ecc.hpp): per stream two small grayscale images (previous / current), gradients, scratch
-struct BoxMOTHipEcc {
+struct BoxMOTHipEcc : DeviceBound {
     int S = 0, rows = 0, cols = 0, h = 0, w = 0, max_iter = 100;
     double scale = 0.15, eps = 1e-5;
     hipStream_t stream = nullptr;
@@ -223,7 +270,7 @@ struct BoxMOTHipEcc {
 
 // Sparse-optical-flow camera-motion estimator (csrc/cmc_sof.hpp): per stream the previous and the current frame's 8-bit pyramid and
 // Scharr derivatives, the keypoints the next frame tracks, scratch of the corner detector
-struct BoxMOTHipSof {
+struct BoxMOTHipSof : DeviceBound {
     int S = 0, rows = 0, cols = 0, max_dets = 0;
     bm::SofLevels lv{};
     bm::SofParams prm{};
@@ -245,7 +292,7 @@ struct BoxMOTHipSof {
 // one "uploaded" + one "consumed" event per slot.  The caller decodes frame t + 1 straight into slot (t + 1) % n_slots while the
 // kernels of frame t run; submit() queues the slot's H2D DMA on the copy stream, wait() makes the consuming stream wait for it,
 // release() lets the next upload into the slot wait for the consumer -- no host synchronisation anywhere.
-struct BoxMOTHipIngest {
+struct BoxMOTHipIngest : DeviceBound {
     int n_slots = 0, n_streams = 0, rows = 0, cols = 0;
     size_t frame_bytes = 0;
     hipStream_t copy_stream = nullptr;
@@ -264,7 +311,7 @@ struct BoxMOTHipIngest {
     }
 };
 
-struct BoxMOTHipBotSort {
+struct BoxMOTHipBotSort : DeviceBound {
     BoxMOTHipBotSortConfig cfg{};
     std::string reid_path;
     std::vector<float> reid_blob;            // host copy of the weight blob the engine was built from (path or set_reid_blob): growth rebuilds from it
@@ -330,7 +377,7 @@ struct BoxMOTHipBotSort {
 
 // Host-side plumbing shared by the DeepOCSORT and StrongSORT handles: pinned-down staging of the per-stream inputs,
 // the frames and ReID engine for "embeddings not supplied", pending camera-motion warps, result read-back.
-struct StreamIo {
+struct StreamIo : DeviceBound {
     std::string reid_path;
     std::vector<float> reid_blob;            // host copy of the weight blob (see BoxMOTHipBotSort::reid_blob)
     std::vector<void*> owned;
@@ -1486,6 +1533,8 @@ int boxmot_hip_device_count(void) {
     return n;
 }
 
+int boxmot_hip_botsort_device(BoxMOTHipBotSort* handle) { return handle ? handle->device : -1; }
+
 void boxmot_hip_botsort_default_config(BoxMOTHipBotSortConfig* c) {
     if (!c) return;
     std::memset(c, 0, sizeof(*c));
@@ -1523,10 +1572,10 @@ BoxMOTHipBotSort* boxmot_hip_botsort_create(const BoxMOTHipBotSortConfig* config
     return h;
 }
 
-void boxmot_hip_botsort_destroy(BoxMOTHipBotSort* handle) { delete handle; }
+void boxmot_hip_botsort_destroy(BoxMOTHipBotSort* handle) { destroy_on(handle); }
 
 int boxmot_hip_botsort_reset(BoxMOTHipBotSort* handle) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip BoT-SORT handle is null.");
         zero_state(handle);
         handle->h_used.assign(handle->S, 0);
@@ -1534,7 +1583,7 @@ int boxmot_hip_botsort_reset(BoxMOTHipBotSort* handle) {
 }
 
 int boxmot_hip_botsort_reserve(BoxMOTHipBotSort* handle, int max_tracks, int max_dets) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip BoT-SORT handle is null.");
         const int cap = max_tracks > handle->cap ? (max_tracks + 63) / 64 * 64 : handle->cap;
         const int nd = max_dets > handle->nd ? (max_dets + 63) / 64 * 64 : handle->nd;
@@ -1543,7 +1592,7 @@ int boxmot_hip_botsort_reserve(BoxMOTHipBotSort* handle, int max_tracks, int max
 }
 
 int boxmot_hip_botsort_capacity(BoxMOTHipBotSort* handle, int* max_tracks, int* max_dets, int* n_grows) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip BoT-SORT handle is null.");
         if (max_tracks) *max_tracks = handle->cap;
         if (max_dets) *max_dets = handle->nd;
@@ -1565,7 +1614,7 @@ int boxmot_hip_botsort_update_stream(BoxMOTHipBotSort* handle, int stream, int c
                                      int emb_cols, const uint8_t* image, int image_rows, int image_cols,
                                      int image_channels, float* out_tracks, int out_capacity_rows, int out_cols,
                                      int* out_rows, int* out_is_obb) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip BoT-SORT handle is not initialized.");
         if (!out_rows || !out_is_obb) throw std::runtime_error("Output pointers are null.");
         if (out_cols != 9) throw std::runtime_error("boxmot_hip live tracking expects an output buffer with 9 columns.");
@@ -1582,7 +1631,7 @@ int boxmot_hip_botsort_update_batch(BoxMOTHipBotSort* handle, int n_streams, con
                                     const int* det_rows, const float* const* embs, int emb_cols,
                                     const uint8_t* const* images, int image_rows, int image_cols, int image_channels,
                                     float* const* out_tracks, int out_capacity_rows, int* out_rows) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip BoT-SORT handle is not initialized.");
         if (n_streams < 1 || n_streams > handle->S) throw std::runtime_error("boxmot_hip: n_streams out of range");
         if (!dets || !det_rows || !out_tracks || !out_rows) throw std::runtime_error("boxmot_hip: null batch pointers");
@@ -1598,7 +1647,7 @@ int boxmot_hip_botsort_update_batch_frames(BoxMOTHipBotSort* handle, int n_strea
                                            const int* det_rows, const float* const* embs, int emb_cols,
                                            const uint8_t* const* d_frames, int image_rows, int image_cols,
                                            float* const* out_tracks, int out_capacity_rows, int* out_rows) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip BoT-SORT handle is not initialized.");
         if (n_streams < 1 || n_streams > handle->S) throw std::runtime_error("boxmot_hip: n_streams out of range");
         if (!dets || !det_rows || !out_tracks || !out_rows) throw std::runtime_error("boxmot_hip: null batch pointers");
@@ -1613,7 +1662,7 @@ int boxmot_hip_botsort_update_batch_frames(BoxMOTHipBotSort* handle, int n_strea
 int boxmot_hip_botsort_step_device(BoxMOTHipBotSort* handle, const float* d_dets, const int* d_det_rows,
                                    const float* d_embs, const uint8_t* const* d_frames, int image_rows, int image_cols,
                                    float* d_out, int* d_out_rows) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip BoT-SORT handle is not initialized.");
         if (!d_dets || !d_det_rows || !d_out || !d_out_rows) throw std::runtime_error("boxmot_hip: null device pointers");
         const float* embs = d_embs;
@@ -1669,7 +1718,7 @@ int boxmot_hip_botsort_step_device(BoxMOTHipBotSort* handle, const float* d_dets
 }
 
 int boxmot_hip_botsort_set_warp(BoxMOTHipBotSort* handle, int stream, const double* warp_2x3) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip BoT-SORT handle is null.");
         if (stream < 0 || stream >= handle->S) throw std::runtime_error("boxmot_hip: stream index out of range");
         if (warp_2x3 == nullptr) { handle->h_warp_flag[stream] = 0; return; }
@@ -1682,21 +1731,21 @@ int boxmot_hip_botsort_set_warp(BoxMOTHipBotSort* handle, int stream, const doub
 }
 
 int boxmot_hip_botsort_synchronize(BoxMOTHipBotSort* handle) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip BoT-SORT handle is not initialized.");
         BM_HIP(hipStreamSynchronize(handle->stream));
     });
 }
 
 int boxmot_hip_botsort_timer_start(BoxMOTHipBotSort* handle) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip BoT-SORT handle is not initialized.");
         BM_HIP(hipEventRecord(handle->timer_ev[0], handle->stream));
     });
 }
 
 int boxmot_hip_botsort_timer_stop_ms(BoxMOTHipBotSort* handle, double* out_ms) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle || !out_ms) throw std::runtime_error("boxmot_hip: null argument");
         BM_HIP(hipEventRecord(handle->timer_ev[1], handle->stream));
         BM_HIP(hipEventSynchronize(handle->timer_ev[1]));
@@ -1707,7 +1756,7 @@ int boxmot_hip_botsort_timer_stop_ms(BoxMOTHipBotSort* handle, double* out_ms) {
 }
 
 int boxmot_hip_botsort_reid_kernel_ms(BoxMOTHipBotSort* handle, double* out_ms, int* out_launches) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle || !out_ms || !out_launches) throw std::runtime_error("boxmot_hip: null argument");
         *out_ms = 0; *out_launches = 0;
         if (handle->reid) handle->reid->drain_kernel_timing(*out_ms, *out_launches);
@@ -1715,7 +1764,7 @@ int boxmot_hip_botsort_reid_kernel_ms(BoxMOTHipBotSort* handle, double* out_ms, 
 }
 
 int boxmot_hip_botsort_phase_clocks(BoxMOTHipBotSort* handle, long long* out16) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle || !out16) throw std::runtime_error("boxmot_hip: null argument");
         BM_HIP(hipStreamSynchronize(handle->stream));
         BM_HIP(hipMemcpy(out16, handle->d_phase_clock, 16 * sizeof(long long), hipMemcpyDeviceToHost));
@@ -1725,7 +1774,7 @@ int boxmot_hip_botsort_phase_clocks(BoxMOTHipBotSort* handle, long long* out16) 
 void* boxmot_hip_botsort_stream(BoxMOTHipBotSort* handle) { return handle ? (void*)handle->stream : nullptr; }
 
 int boxmot_hip_botsort_status(BoxMOTHipBotSort* handle, int* out_status, int capacity) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle || !out_status) throw std::runtime_error("boxmot_hip: null argument");
         const int n = capacity < handle->S ? capacity : handle->S;
         BM_HIP(hipStreamSynchronize(handle->stream));
@@ -1734,7 +1783,7 @@ int boxmot_hip_botsort_status(BoxMOTHipBotSort* handle, int* out_status, int cap
 }
 
 int boxmot_hip_botsort_set_reid_blob(BoxMOTHipBotSort* handle, const float* blob, long n_floats) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle || !blob || n_floats <= 0) throw std::runtime_error("boxmot_hip: null argument");
         // the handle keeps a host copy: growing max_dets (reserve, or an update with more detections) rebuilds the engine from it
         std::vector<float> keep(blob, blob + n_floats), old;
@@ -1750,7 +1799,7 @@ int boxmot_hip_botsort_set_reid_blob(BoxMOTHipBotSort* handle, const float* blob
 }
 
 int boxmot_hip_botsort_set_reid_mode(BoxMOTHipBotSort* handle, int mode) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip: null argument");
         if (handle->reid) handle->reid->set_mode(mode);
         handle->reid_mode = mode;
@@ -1758,7 +1807,7 @@ int boxmot_hip_botsort_set_reid_mode(BoxMOTHipBotSort* handle, int mode) {
 }
 
 static int get_ms(BoxMOTHipBotSort* h, double* out, double BoxMOTHipBotSort::*field, bool sum_reid) {
-    return guard([&]() {
+    return guard_on(h, [&]() {
         if (!h) throw std::runtime_error("boxmot_hip BoT-SORT handle is not initialized.");
         if (!out) throw std::runtime_error("Output timing pointer is null.");
         *out = sum_reid ? h->last_reid_pre_ms + h->last_reid_proc_ms : h->*field;
@@ -1768,7 +1817,7 @@ int boxmot_hip_botsort_last_reid_time_ms(BoxMOTHipBotSort* h, double* o) { retur
 int boxmot_hip_botsort_last_reid_preprocess_time_ms(BoxMOTHipBotSort* h, double* o) { return get_ms(h, o, &BoxMOTHipBotSort::last_reid_pre_ms, false); }
 int boxmot_hip_botsort_last_reid_process_time_ms(BoxMOTHipBotSort* h, double* o) { return get_ms(h, o, &BoxMOTHipBotSort::last_reid_proc_ms, false); }
 int boxmot_hip_botsort_last_reid_postprocess_time_ms(BoxMOTHipBotSort* h, double* o) {
-    return guard([&]() {
+    return guard_on(h, [&]() {
         if (!h) throw std::runtime_error("boxmot_hip BoT-SORT handle is not initialized.");
         if (!o) throw std::runtime_error("Output timing pointer is null.");
         *o = 0.0;   // L2 normalisation is fused into the head kernel
@@ -1779,7 +1828,7 @@ int boxmot_hip_botsort_last_track_time_ms(BoxMOTHipBotSort* h, double* o) { retu
 int boxmot_hip_botsort_state_dump(BoxMOTHipBotSort* handle, int stream, int which, int class_list, int* ints,
                                   double* kf, float* smooth, float* misc, int* out_rows, int* out_frame_count,
                                   int* out_id_count) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle || !out_rows) throw std::runtime_error("boxmot_hip: null argument");
         if (stream < 0 || stream >= handle->S) throw std::runtime_error("boxmot_hip: stream index out of range");
         BM_HIP(hipStreamSynchronize(handle->stream));
@@ -1840,12 +1889,12 @@ BoxMOTHipReID* boxmot_hip_reid_create(const char* model_path, const float* blob,
     return h;
 }
 
-void boxmot_hip_reid_destroy(BoxMOTHipReID* handle) { delete handle; }
+void boxmot_hip_reid_destroy(BoxMOTHipReID* handle) { destroy_on(handle); }
 
 int boxmot_hip_reid_feature_dim(BoxMOTHipReID* handle) { return handle && handle->engine ? handle->engine->feature_dim() : 0; }
 
 int boxmot_hip_reid_set_preprocess(BoxMOTHipReID* handle, const char* name) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip: null ReID handle");
         if (name == nullptr || std::strcmp(name, "resize") == 0) handle->engine->set_preprocess(0);
         else if (std::strcmp(name, "resize_pad") == 0) handle->engine->set_preprocess(1);
@@ -1854,7 +1903,7 @@ int boxmot_hip_reid_set_preprocess(BoxMOTHipReID* handle, const char* name) {
 }
 
 int boxmot_hip_reid_set_mode(BoxMOTHipReID* handle, int mode) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip: null ReID handle");
         handle->engine->set_mode(mode);
     });
@@ -1926,7 +1975,7 @@ struct ObbScope {
 int boxmot_hip_reid_compute_features(BoxMOTHipReID* handle, const uint8_t* image, int image_rows, int image_cols,
                                      int image_channels, const float* boxes, int n_boxes, int box_cols,
                                      float* out_features, int out_capacity_rows) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         ObbScope scope{handle};
         reid_stage(handle, image, image_rows, image_cols, image_channels, boxes, n_boxes, box_cols);
         if (out_capacity_rows < n_boxes) throw std::runtime_error("boxmot_hip: feature buffer too small");
@@ -1940,7 +1989,7 @@ int boxmot_hip_reid_compute_features(BoxMOTHipReID* handle, const uint8_t* image
 }
 
 int boxmot_hip_reid_last_time_ms(BoxMOTHipReID* handle, double* out_preprocess_ms, double* out_process_ms) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip: null ReID handle");
         double pre = 0, proc = 0;
         handle->engine->last_times(pre, proc);
@@ -1951,7 +2000,7 @@ int boxmot_hip_reid_last_time_ms(BoxMOTHipReID* handle, double* out_preprocess_m
 
 int boxmot_hip_reid_preprocess(BoxMOTHipReID* handle, const uint8_t* image, int image_rows, int image_cols,
                                int image_channels, const float* boxes, int n_boxes, int box_cols, float* out_crops) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         ObbScope scope{handle};
         reid_stage(handle, image, image_rows, image_cols, image_channels, boxes, n_boxes, box_cols);
         if (n_boxes == 0) return;
@@ -1975,10 +2024,10 @@ BoxMOTHipEcc* boxmot_hip_ecc_create(int n_streams, int image_rows, int image_col
     return h;
 }
 
-void boxmot_hip_ecc_destroy(BoxMOTHipEcc* handle) { delete handle; }
+void boxmot_hip_ecc_destroy(BoxMOTHipEcc* handle) { destroy_on(handle); }
 
 int boxmot_hip_ecc_reset(BoxMOTHipEcc* handle, int stream) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip: null ECC handle");
         if (stream >= handle->S) throw std::runtime_error("boxmot_hip: stream index out of range");
         for (int s = 0; s < handle->S; ++s) if (stream < 0 || s == stream) handle->has_prev[s] = 0;
@@ -1987,7 +2036,7 @@ int boxmot_hip_ecc_reset(BoxMOTHipEcc* handle, int stream) {
 
 int boxmot_hip_ecc_apply(BoxMOTHipEcc* handle, int stream, const uint8_t* image, int image_rows, int image_cols, int image_channels,
                          double* out_warp_2x3, int* out_iterations) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle || !out_warp_2x3) throw std::runtime_error("boxmot_hip: null argument");
         if (stream < 0 || stream >= handle->S) throw std::runtime_error("boxmot_hip: stream index out of range");
         if (!image) throw std::runtime_error("Image data pointer is null.");
@@ -2006,7 +2055,7 @@ int boxmot_hip_ecc_apply(BoxMOTHipEcc* handle, int stream, const uint8_t* image,
 }
 
 int boxmot_hip_ecc_apply_device(BoxMOTHipEcc* handle, int stream, const uint8_t* d_frame, double* out_warp_2x3, int* out_iterations) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle || !out_warp_2x3 || !d_frame) throw std::runtime_error("boxmot_hip: null argument");
         if (stream < 0 || stream >= handle->S) throw std::runtime_error("boxmot_hip: stream index out of range");
         // the pointer table lives on the device: one slot per stream, written on the handle's stream before the kernels read it
@@ -2029,10 +2078,10 @@ BoxMOTHipSof* boxmot_hip_sof_create(int n_streams, int image_rows, int image_col
     return h;
 }
 
-void boxmot_hip_sof_destroy(BoxMOTHipSof* handle) { delete handle; }
+void boxmot_hip_sof_destroy(BoxMOTHipSof* handle) { destroy_on(handle); }
 
 int boxmot_hip_sof_reset(BoxMOTHipSof* handle, int stream) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip: null SOF handle");
         if (stream >= handle->S) throw std::runtime_error("boxmot_hip: stream index out of range");
         BM_HIP(hipStreamSynchronize(handle->stream));
@@ -2043,7 +2092,7 @@ int boxmot_hip_sof_reset(BoxMOTHipSof* handle, int stream) {
 
 int boxmot_hip_sof_apply(BoxMOTHipSof* handle, int stream, const uint8_t* image, int image_rows, int image_cols, int image_channels,
                          const float* dets, int n_dets, int det_stride, double* out_warp_2x3, int* out_info8) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle || !out_warp_2x3) throw std::runtime_error("boxmot_hip: null argument");
         if (stream < 0 || stream >= handle->S) throw std::runtime_error("boxmot_hip: stream index out of range");
         if (!image) throw std::runtime_error("Image data pointer is null.");
@@ -2065,7 +2114,7 @@ int boxmot_hip_sof_apply(BoxMOTHipSof* handle, int stream, const uint8_t* image,
 
 int boxmot_hip_sof_apply_device(BoxMOTHipSof* handle, const uint8_t* const* d_frames, const float* d_dets, const int* d_ndets, int max_dets,
                                 int det_stride, double* out_warps, int* out_info8) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle || !out_warps || !d_frames) throw std::runtime_error("boxmot_hip: null argument");
         if (d_dets && (!d_ndets || max_dets < 1 || det_stride < 4)) throw std::runtime_error("boxmot_hip: SOF device detections need d_ndets, max_dets >= 1 and >= 4 columns");
         sof_run(handle, 0, handle->S, d_frames, d_dets, d_dets ? d_ndets : nullptr, max_dets, det_stride, out_warps, out_info8);
@@ -2073,7 +2122,7 @@ int boxmot_hip_sof_apply_device(BoxMOTHipSof* handle, const uint8_t* const* d_fr
 }
 
 int boxmot_hip_sof_keypoints(BoxMOTHipSof* handle, int stream, float* out_xy, int capacity, int* out_n) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle || !out_n) throw std::runtime_error("boxmot_hip: null argument");
         if (stream < 0 || stream >= handle->S) throw std::runtime_error("boxmot_hip: stream index out of range");
         bm::SofState st{};
@@ -2088,7 +2137,7 @@ int boxmot_hip_sof_keypoints(BoxMOTHipSof* handle, int stream, float* out_xy, in
 // test access to the detector's intermediate images of the last frame: which = 0 minimum-eigenvalue map (fp32 [h][w]), 1 detection mask
 // (uint8 [h][w]), 2 the scaled grayscale frame (uint8 [h][w])
 int boxmot_hip_sof_debug_map(BoxMOTHipSof* handle, int stream, int which, void* out, int capacity_bytes, int* out_h, int* out_w) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle || !out) throw std::runtime_error("boxmot_hip: null argument");
         if (stream < 0 || stream >= handle->S) throw std::runtime_error("boxmot_hip: stream index out of range");
         const size_t P = (size_t)handle->lv.h[0] * handle->lv.w[0];
@@ -2138,7 +2187,7 @@ BoxMOTHipIngest* boxmot_hip_ingest_create(int n_slots, int n_streams, int image_
     return h;
 }
 
-void boxmot_hip_ingest_destroy(BoxMOTHipIngest* handle) { delete handle; }
+void boxmot_hip_ingest_destroy(BoxMOTHipIngest* handle) { destroy_on(handle); }
 
 static void ingest_slot(BoxMOTHipIngest* h, int slot) {
     if (!h) throw std::runtime_error("boxmot_hip: null ingest handle");
@@ -2147,7 +2196,7 @@ static void ingest_slot(BoxMOTHipIngest* h, int slot) {
 
 uint8_t* boxmot_hip_ingest_host_ptr(BoxMOTHipIngest* handle, int slot, int stream) {
     uint8_t* p = nullptr;
-    guard([&]() {
+    guard_on(handle, [&]() {
         ingest_slot(handle, slot);
         if (stream < 0 || stream >= handle->n_streams) throw std::runtime_error("boxmot_hip: stream index out of range");
         p = handle->h_slot[slot] + (size_t)stream * handle->frame_bytes;
@@ -2157,12 +2206,12 @@ uint8_t* boxmot_hip_ingest_host_ptr(BoxMOTHipIngest* handle, int slot, int strea
 
 const uint8_t* const* boxmot_hip_ingest_device_frames(BoxMOTHipIngest* handle, int slot) {
     const uint8_t* const* p = nullptr;
-    guard([&]() { ingest_slot(handle, slot); p = handle->d_ptrs[slot]; });
+    guard_on(handle, [&]() { ingest_slot(handle, slot); p = handle->d_ptrs[slot]; });
     return p;
 }
 
 int boxmot_hip_ingest_submit(BoxMOTHipIngest* handle, int slot, int n_streams) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         ingest_slot(handle, slot);
         if (n_streams < 1 || n_streams > handle->n_streams) throw std::runtime_error("boxmot_hip: stream count out of range");
         // the previous consumer of this slot must be done with the device frames before they are overwritten
@@ -2174,14 +2223,14 @@ int boxmot_hip_ingest_submit(BoxMOTHipIngest* handle, int slot, int n_streams) {
 }
 
 int boxmot_hip_ingest_wait(BoxMOTHipIngest* handle, int slot, void* consumer_stream) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         ingest_slot(handle, slot);
         BM_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(consumer_stream), handle->uploaded[slot], 0));
     });
 }
 
 int boxmot_hip_ingest_release(BoxMOTHipIngest* handle, int slot, void* consumer_stream) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         ingest_slot(handle, slot);
         BM_HIP(hipEventRecord(handle->consumed[slot], static_cast<hipStream_t>(consumer_stream)));
         handle->has_consumer[slot] = 1;
@@ -2189,7 +2238,7 @@ int boxmot_hip_ingest_release(BoxMOTHipIngest* handle, int slot, void* consumer_
 }
 
 int boxmot_hip_ingest_host_done(BoxMOTHipIngest* handle, int slot) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         ingest_slot(handle, slot);
         BM_HIP(hipEventSynchronize(handle->uploaded[slot]));       // the host buffer of the slot may be refilled
     });
@@ -2223,10 +2272,10 @@ BoxMOTHipDeepOcSort* boxmot_hip_deepocsort_create(const BoxMOTHipDeepOcSortConfi
     return h;
 }
 
-void boxmot_hip_deepocsort_destroy(BoxMOTHipDeepOcSort* handle) { delete handle; }
+void boxmot_hip_deepocsort_destroy(BoxMOTHipDeepOcSort* handle) { destroy_on(handle); }
 
 int boxmot_hip_deepocsort_reset(BoxMOTHipDeepOcSort* handle) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip DeepOCSORT handle is null.");
         docs_zero_state(handle);
         handle->h_used.assign(handle->S, 0);
@@ -2234,7 +2283,7 @@ int boxmot_hip_deepocsort_reset(BoxMOTHipDeepOcSort* handle) {
 }
 
 int boxmot_hip_deepocsort_reserve(BoxMOTHipDeepOcSort* handle, int max_tracks, int max_dets) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip DeepOCSORT handle is null.");
         const int cap = max_tracks > handle->cap ? (max_tracks + 63) / 64 * 64 : handle->cap;
         const int nd = max_dets > handle->nd ? (max_dets + 63) / 64 * 64 : handle->nd;
@@ -2243,7 +2292,7 @@ int boxmot_hip_deepocsort_reserve(BoxMOTHipDeepOcSort* handle, int max_tracks, i
 }
 
 int boxmot_hip_deepocsort_capacity(BoxMOTHipDeepOcSort* handle, int* max_tracks, int* max_dets, int* n_grows) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip DeepOCSORT handle is null.");
         if (max_tracks) *max_tracks = handle->cap;
         if (max_dets) *max_dets = handle->nd;
@@ -2252,7 +2301,7 @@ int boxmot_hip_deepocsort_capacity(BoxMOTHipDeepOcSort* handle, int* max_tracks,
 }
 
 int boxmot_hip_deepocsort_set_warp(BoxMOTHipDeepOcSort* handle, int stream, const double* warp_2x3) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip DeepOCSORT handle is null.");
         if (handle->is_obb && warp_2x3) throw std::runtime_error("boxmot_hip: camera-motion warps are not applied to oriented detections");
         io_set_warp(handle, stream, warp_2x3);
@@ -2263,7 +2312,7 @@ int boxmot_hip_deepocsort_update_batch(BoxMOTHipDeepOcSort* handle, int n_stream
                                        const int* det_rows, const float* const* embs, int emb_cols,
                                        const uint8_t* const* images, int image_rows, int image_cols, int image_channels,
                                        float* const* out_tracks, int out_capacity_rows, int* out_rows) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip DeepOCSORT handle is not initialized.");
         if (n_streams < 1 || n_streams > handle->S) throw std::runtime_error("boxmot_hip: n_streams out of range");
         if (!dets || !det_rows || !out_tracks || !out_rows) throw std::runtime_error("boxmot_hip: null batch pointers");
@@ -2280,7 +2329,7 @@ int boxmot_hip_deepocsort_update(BoxMOTHipDeepOcSort* handle, const float* dets,
                                  const float* embs, int emb_rows, int emb_cols, const uint8_t* image, int image_rows,
                                  int image_cols, int image_channels, float* out_tracks, int out_capacity_rows,
                                  int out_cols, int* out_rows, int* out_is_obb) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip DeepOCSORT handle is not initialized.");
         if (!out_rows || !out_is_obb) throw std::runtime_error("Output pointers are null.");
         if (out_cols != 9) throw std::runtime_error("boxmot_hip live tracking expects an output buffer with 9 columns.");
@@ -2298,7 +2347,7 @@ int boxmot_hip_deepocsort_update_stream(BoxMOTHipDeepOcSort* handle, int stream,
                                         const float* dets, int det_rows, int det_cols, const float* embs, int emb_rows,
                                         int emb_cols, const uint8_t* image, int image_rows, int image_cols, int image_channels,
                                         float* out_tracks, int out_capacity_rows, int out_cols, int* out_rows, int* out_is_obb) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip DeepOCSORT handle is not initialized.");
         if (!out_rows || !out_is_obb) throw std::runtime_error("Output pointers are null.");
         if (out_cols != 9) throw std::runtime_error("boxmot_hip live tracking expects an output buffer with 9 columns.");
@@ -2315,7 +2364,7 @@ int boxmot_hip_deepocsort_update_stream(BoxMOTHipDeepOcSort* handle, int stream,
 
 int boxmot_hip_deepocsort_step_device(BoxMOTHipDeepOcSort* handle, const float* d_dets, const int* d_det_rows,
                                        const float* d_embs, float* d_out, int* d_out_rows) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip DeepOCSORT handle is not initialized.");
         if (!d_dets || !d_det_rows || !d_out || !d_out_rows) throw std::runtime_error("boxmot_hip: null device pointers");
         if (!handle->cfg.embedding_off && !d_embs) throw std::runtime_error("boxmot_hip: step_device needs d_embs unless embedding_off");
@@ -2334,7 +2383,7 @@ int boxmot_hip_deepocsort_step_device(BoxMOTHipDeepOcSort* handle, const float* 
 int boxmot_hip_deepocsort_step_device_frames(BoxMOTHipDeepOcSort* handle, const float* d_dets, const int* d_det_rows,
                                               const uint8_t* const* d_frames, int image_rows, int image_cols, float* d_out,
                                               int* d_out_rows) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip DeepOCSORT handle is not initialized.");
         if (!d_dets || !d_det_rows || !d_out || !d_out_rows) throw std::runtime_error("boxmot_hip: null device pointers");
         if (!handle->cfg.embedding_off)      // deepocsort.py:337-345: every detection above det_thresh is embedded
@@ -2352,7 +2401,7 @@ int boxmot_hip_deepocsort_step_device_frames(BoxMOTHipDeepOcSort* handle, const 
 }
 
 int boxmot_hip_deepocsort_set_reid_mode(BoxMOTHipDeepOcSort* handle, int mode) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle || !handle->reid) throw std::runtime_error("boxmot_hip: no ReID weights are loaded in this handle");
         handle->reid->set_mode(mode);
         handle->reid_mode = mode;
@@ -2360,7 +2409,7 @@ int boxmot_hip_deepocsort_set_reid_mode(BoxMOTHipDeepOcSort* handle, int mode) {
 }
 
 int boxmot_hip_deepocsort_reid_kernel_ms(BoxMOTHipDeepOcSort* handle, double* out_ms, int* out_launches) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle || !out_ms || !out_launches) throw std::runtime_error("boxmot_hip: null argument");
         *out_ms = 0; *out_launches = 0;
         if (handle->reid) handle->reid->drain_kernel_timing(*out_ms, *out_launches);
@@ -2370,7 +2419,7 @@ int boxmot_hip_deepocsort_reid_kernel_ms(BoxMOTHipDeepOcSort* handle, double* ou
 void* boxmot_hip_deepocsort_stream(BoxMOTHipDeepOcSort* handle) { return handle ? (void*)handle->stream : nullptr; }
 
 int boxmot_hip_deepocsort_synchronize(BoxMOTHipDeepOcSort* handle) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip DeepOCSORT handle is not initialized.");
         BM_HIP(hipStreamSynchronize(handle->stream));
         io_check_crop_bound(handle);
@@ -2378,7 +2427,7 @@ int boxmot_hip_deepocsort_synchronize(BoxMOTHipDeepOcSort* handle) {
 }
 
 int boxmot_hip_deepocsort_set_crop_bound(BoxMOTHipDeepOcSort* handle, int max_total_crops) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip DeepOCSORT handle is not initialized.");
         io_set_crop_bound(handle, max_total_crops);
     });
@@ -2386,7 +2435,7 @@ int boxmot_hip_deepocsort_set_crop_bound(BoxMOTHipDeepOcSort* handle, int max_to
 
 int boxmot_hip_deepocsort_state_dump(BoxMOTHipDeepOcSort* handle, int stream, int* ints5, double* kf72, double* emb,
                                      int* out_rows, int* out_frame_count, int* out_id_count) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle || !out_rows) throw std::runtime_error("boxmot_hip: null argument");
         if (stream < 0 || stream >= handle->S) throw std::runtime_error("boxmot_hip: stream index out of range");
         BM_HIP(hipStreamSynchronize(handle->stream));
@@ -2440,10 +2489,10 @@ BoxMOTHipStrongSort* boxmot_hip_strongsort_create(const BoxMOTHipStrongSortConfi
     return h;
 }
 
-void boxmot_hip_strongsort_destroy(BoxMOTHipStrongSort* handle) { delete handle; }
+void boxmot_hip_strongsort_destroy(BoxMOTHipStrongSort* handle) { destroy_on(handle); }
 
 int boxmot_hip_strongsort_reset(BoxMOTHipStrongSort* handle) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip StrongSORT handle is null.");
         ss_zero_state(handle);
         handle->h_used.assign(handle->S, 0);
@@ -2451,7 +2500,7 @@ int boxmot_hip_strongsort_reset(BoxMOTHipStrongSort* handle) {
 }
 
 int boxmot_hip_strongsort_reserve(BoxMOTHipStrongSort* handle, int max_tracks, int max_dets) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip StrongSORT handle is null.");
         const int cap = max_tracks > handle->cap ? (max_tracks + 63) / 64 * 64 : handle->cap;
         const int nd = max_dets > handle->nd ? (max_dets + 63) / 64 * 64 : handle->nd;
@@ -2460,7 +2509,7 @@ int boxmot_hip_strongsort_reserve(BoxMOTHipStrongSort* handle, int max_tracks, i
 }
 
 int boxmot_hip_strongsort_capacity(BoxMOTHipStrongSort* handle, int* max_tracks, int* max_dets, int* n_grows) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip StrongSORT handle is null.");
         if (max_tracks) *max_tracks = handle->cap;
         if (max_dets) *max_dets = handle->nd;
@@ -2469,7 +2518,7 @@ int boxmot_hip_strongsort_capacity(BoxMOTHipStrongSort* handle, int* max_tracks,
 }
 
 int boxmot_hip_strongsort_set_warp(BoxMOTHipStrongSort* handle, int stream, const double* warp_2x3) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip StrongSORT handle is null.");
         io_set_warp(handle, stream, warp_2x3);
     });
@@ -2479,7 +2528,7 @@ int boxmot_hip_strongsort_update_batch(BoxMOTHipStrongSort* handle, int n_stream
                                        const int* det_rows, const float* const* embs, int emb_cols,
                                        const uint8_t* const* images, int image_rows, int image_cols, int image_channels,
                                        float* const* out_tracks, int out_capacity_rows, int* out_rows) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip StrongSORT handle is not initialized.");
         if (n_streams < 1 || n_streams > handle->S) throw std::runtime_error("boxmot_hip: n_streams out of range");
         if (!dets || !det_rows || !out_tracks || !out_rows) throw std::runtime_error("boxmot_hip: null batch pointers");
@@ -2495,7 +2544,7 @@ int boxmot_hip_strongsort_update(BoxMOTHipStrongSort* handle, const float* dets,
                                  const float* embs, int emb_rows, int emb_cols, const uint8_t* image, int image_rows,
                                  int image_cols, int image_channels, float* out_tracks, int out_capacity_rows,
                                  int out_cols, int* out_rows, int* out_is_obb) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip StrongSORT handle is not initialized.");
         if (!out_rows || !out_is_obb) throw std::runtime_error("Output pointers are null.");
         if (out_cols != 9) throw std::runtime_error("boxmot_hip live tracking expects an output buffer with 9 columns.");
@@ -2510,7 +2559,7 @@ int boxmot_hip_strongsort_update(BoxMOTHipStrongSort* handle, const float* dets,
 
 int boxmot_hip_strongsort_step_device(BoxMOTHipStrongSort* handle, const float* d_dets, const int* d_det_rows,
                                        const float* d_embs, float* d_out, int* d_out_rows) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip StrongSORT handle is not initialized.");
         if (!d_dets || !d_det_rows || !d_embs || !d_out || !d_out_rows) throw std::runtime_error("boxmot_hip: null device pointers");
         bm::SsStepArgs a = handle->args;
@@ -2526,7 +2575,7 @@ int boxmot_hip_strongsort_step_device(BoxMOTHipStrongSort* handle, const float* 
 int boxmot_hip_strongsort_step_device_frames(BoxMOTHipStrongSort* handle, const float* d_dets, const int* d_det_rows,
                                               const uint8_t* const* d_frames, int image_rows, int image_cols, float* d_out,
                                               int* d_out_rows) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip StrongSORT handle is not initialized.");
         if (!d_dets || !d_det_rows || !d_out || !d_out_rows) throw std::runtime_error("boxmot_hip: null device pointers");
         io_device_reid(handle, d_dets, d_det_rows, d_frames, image_rows, image_cols, handle->cfg.min_conf, 1);    // strongsort.py:74-91
@@ -2541,7 +2590,7 @@ int boxmot_hip_strongsort_step_device_frames(BoxMOTHipStrongSort* handle, const 
 }
 
 int boxmot_hip_strongsort_set_reid_mode(BoxMOTHipStrongSort* handle, int mode) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle || !handle->reid) throw std::runtime_error("boxmot_hip: no ReID weights are loaded in this handle");
         handle->reid->set_mode(mode);
         handle->reid_mode = mode;
@@ -2549,7 +2598,7 @@ int boxmot_hip_strongsort_set_reid_mode(BoxMOTHipStrongSort* handle, int mode) {
 }
 
 int boxmot_hip_strongsort_reid_kernel_ms(BoxMOTHipStrongSort* handle, double* out_ms, int* out_launches) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle || !out_ms || !out_launches) throw std::runtime_error("boxmot_hip: null argument");
         *out_ms = 0; *out_launches = 0;
         if (handle->reid) handle->reid->drain_kernel_timing(*out_ms, *out_launches);
@@ -2557,7 +2606,7 @@ int boxmot_hip_strongsort_reid_kernel_ms(BoxMOTHipStrongSort* handle, double* ou
 }
 
 int boxmot_hip_strongsort_track_count(BoxMOTHipStrongSort* handle, int stream, int* out_tracks) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip StrongSORT handle is null.");
         if (stream < 0 || stream >= handle->S) throw std::runtime_error("boxmot_hip: stream index out of range");
         if (!out_tracks) throw std::runtime_error("Output pointers are null.");
@@ -2569,7 +2618,7 @@ int boxmot_hip_strongsort_track_count(BoxMOTHipStrongSort* handle, int stream, i
 void* boxmot_hip_strongsort_stream(BoxMOTHipStrongSort* handle) { return handle ? (void*)handle->stream : nullptr; }
 
 int boxmot_hip_strongsort_synchronize(BoxMOTHipStrongSort* handle) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip StrongSORT handle is not initialized.");
         BM_HIP(hipStreamSynchronize(handle->stream));
         io_check_crop_bound(handle);
@@ -2577,7 +2626,7 @@ int boxmot_hip_strongsort_synchronize(BoxMOTHipStrongSort* handle) {
 }
 
 int boxmot_hip_strongsort_set_crop_bound(BoxMOTHipStrongSort* handle, int max_total_crops) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip StrongSORT handle is not initialized.");
         io_set_crop_bound(handle, max_total_crops);
     });
@@ -2585,7 +2634,7 @@ int boxmot_hip_strongsort_set_crop_bound(BoxMOTHipStrongSort* handle, int max_to
 
 int boxmot_hip_strongsort_state_dump(BoxMOTHipStrongSort* handle, int stream, int* ints6, double* kf72, float* feat,
                                      int* out_rows, int* out_frame_count, int* out_next_id) {
-    return guard([&]() {
+    return guard_on(handle, [&]() {
         if (!handle || !out_rows) throw std::runtime_error("boxmot_hip: null argument");
         if (stream < 0 || stream >= handle->S) throw std::runtime_error("boxmot_hip: stream index out of range");
         BM_HIP(hipStreamSynchronize(handle->stream));
@@ -2638,7 +2687,7 @@ int boxmot_hip_strongsort_state_dump(BoxMOTHipStrongSort* handle, int stream, in
 // det_cols == 7`, out_is_obb = det_cols == 7, :147-149) and its Python wrappers fix the layout with the first table ("cannot switch
 // between AABB and OBB inputs", native/trackers/botsort.py).  A device handle is sized for one layout, so the adapters keep the
 // configuration, decide the layout with the first non-empty table and re-make the (still unused) inner handle when it is oriented.
-struct CompatLayout {
+struct CompatLayout : DeviceBound {          // the device current at create: a lazily built inner handle lands there too
     int layout = -1;                // -1 undecided, 0 axis-aligned, 1 oriented
     bool stepped = false;           // an update has run on the inner handle: its layout is final
     int empty_frames = 0;           // updates that only counted: before the inner handle exists (BoT-SORT without an embedding width yet,
@@ -2731,7 +2780,7 @@ BoxMOTBotSortHandle* boxmot_botsort_create(const BoxMOTBotSortConfig* c) {
     if (!ok) { delete h; return nullptr; }
     return h;
 }
-void boxmot_botsort_destroy(BoxMOTBotSortHandle* h) { delete h; }
+void boxmot_botsort_destroy(BoxMOTBotSortHandle* h) { destroy_on(h); }
 int boxmot_botsort_reset(BoxMOTBotSortHandle* h) {
     if (h) { h->empty_frames = 0; h->stepped = false; h->layout = -1; }          // the next table decides the layout again
     if (h && !h->inner) return guard([]() {});
@@ -2743,7 +2792,7 @@ int boxmot_botsort_update(BoxMOTBotSortHandle* h, const float* dets, int det_row
                           int* out_is_obb) {
     if (!h) return boxmot_hip_botsort_update(nullptr, dets, det_rows, det_cols, embs, emb_rows, emb_cols, image, image_rows, image_cols,
                                              image_channels, out_tracks, out_capacity_rows, out_cols, out_rows, out_is_obb);
-    const int ok = guard([&]() {
+    const int ok = guard_on(h, [&]() {
         int is_obb = 0;
         if (compat_layout(h, det_rows, det_cols, is_obb, "BoTSORT") && is_obb != h->cfg.is_obb) {
             h->cfg.is_obb = is_obb;
@@ -2811,7 +2860,7 @@ BoxMOTByteTrackHandle* boxmot_bytetrack_create(const BoxMOTByteTrackConfig* c) {
     if (!ok) { delete h; return nullptr; }
     return h;
 }
-void boxmot_bytetrack_destroy(BoxMOTByteTrackHandle* h) { delete h; }
+void boxmot_bytetrack_destroy(BoxMOTByteTrackHandle* h) { destroy_on(h); }
 int boxmot_bytetrack_reset(BoxMOTByteTrackHandle* h) {
     if (h) { h->empty_frames = 0; h->stepped = false; h->layout = -1; }
     return boxmot_hip_botsort_reset(h ? h->inner : nullptr);
@@ -2821,7 +2870,7 @@ int boxmot_bytetrack_update(BoxMOTByteTrackHandle* h, const float* dets, int det
                             int out_cols, int* out_rows, int* out_is_obb) {
     if (!h) return boxmot_hip_botsort_update(nullptr, dets, det_rows, det_cols, nullptr, 0, 0, image, image_rows, image_cols,
                                              image_channels, out_tracks, out_capacity_rows, out_cols, out_rows, out_is_obb);
-    const int ok = guard([&]() {
+    const int ok = guard_on(h, [&]() {
         int is_obb = 0;
         if (compat_layout(h, det_rows, det_cols, is_obb, "ByteTrack") && is_obb != h->cfg.is_obb) {
             h->cfg.is_obb = is_obb;
@@ -2869,7 +2918,7 @@ BoxMOTOCSORTHandle* boxmot_ocsort_create(const BoxMOTOCSORTConfig* c) {
     if (!ok) { delete h; return nullptr; }
     return h;
 }
-void boxmot_ocsort_destroy(BoxMOTOCSORTHandle* h) { delete h; }
+void boxmot_ocsort_destroy(BoxMOTOCSORTHandle* h) { destroy_on(h); }
 int boxmot_ocsort_reset(BoxMOTOCSORTHandle* h) {
     if (h) { h->empty_frames = 0; h->stepped = false; h->layout = -1; }
     return boxmot_hip_deepocsort_reset(h ? h->inner : nullptr);
@@ -2879,7 +2928,7 @@ int boxmot_ocsort_update(BoxMOTOCSORTHandle* h, const float* dets, int det_rows,
                          int out_cols, int* out_rows, int* out_is_obb) {
     if (!h) return boxmot_hip_deepocsort_update(nullptr, dets, det_rows, det_cols, nullptr, 0, 0, image, image_rows, image_cols,
                                                 image_channels, out_tracks, out_capacity_rows, out_cols, out_rows, out_is_obb);
-    const int ok = guard([&]() {
+    const int ok = guard_on(h, [&]() {
         int is_obb = 0;
         if (compat_layout(h, det_rows, det_cols, is_obb, "OCSORT") && is_obb != h->cfg.is_obb) {
             h->cfg.is_obb = is_obb;
@@ -2927,7 +2976,7 @@ int boxmot_reid_capi_create(const char* model_path, const char* preprocess, void
         *out_handle = h;
     });
 }
-void boxmot_reid_capi_destroy(void* handle) { delete static_cast<BoxMOTHipReID*>(handle); }
+void boxmot_reid_capi_destroy(void* handle) { destroy_on(static_cast<BoxMOTHipReID*>(handle)); }
 int boxmot_reid_capi_feature_dim(void* handle, int* out_feature_dim) {
     return guard([&]() {
         if (!handle) throw std::runtime_error("ReID handle is null.");
@@ -2962,7 +3011,7 @@ int boxmot_reid_capi_compute_features(void* handle, const float* boxes_xyxy, int
 int boxmot_reid_capi_preprocess(void* handle, const float* boxes_xyxy, int n_boxes, const uint8_t* image_data, int image_rows,
                                 int image_cols, int image_channels) {
     BoxMOTHipReID* h = static_cast<BoxMOTHipReID*>(handle);
-    return guard([&]() {
+    return guard_on(h, [&]() {
         if (!h) throw std::runtime_error("ReID handle is null.");
         h->staged_n = -1;
         reid_stage(h, image_data, image_rows, image_cols, image_channels, boxes_xyxy, n_boxes, 4);
@@ -2971,7 +3020,7 @@ int boxmot_reid_capi_preprocess(void* handle, const float* boxes_xyxy, int n_box
 }
 int boxmot_reid_capi_process(void* handle) {
     BoxMOTHipReID* h = static_cast<BoxMOTHipReID*>(handle);
-    return guard([&]() {
+    return guard_on(h, [&]() {
         if (!h) throw std::runtime_error("ReID handle is null.");
         if (h->staged_n < 0) throw std::runtime_error("boxmot_reid_capi_process called before boxmot_reid_capi_preprocess.");
         if (h->staged_n > 0) {
@@ -2984,7 +3033,7 @@ int boxmot_reid_capi_process(void* handle) {
 }
 int boxmot_reid_capi_postprocess(void* handle, float* out_features, int out_capacity_floats) {
     BoxMOTHipReID* h = static_cast<BoxMOTHipReID*>(handle);
-    return guard([&]() {
+    return guard_on(h, [&]() {
         if (!h) throw std::runtime_error("ReID handle is null.");
         if (h->staged_n < 0 || !h->staged_done) throw std::runtime_error("boxmot_reid_capi_postprocess called before boxmot_reid_capi_process.");
         const long need = (long)h->staged_n * h->engine->feature_dim();

@@ -80,6 +80,7 @@ class DeepOcSort(BaseTracker):
         self._ids_issued = ctypes.c_int(0)           # KalmanBoxTracker.count - 1, shared by the per-class lists
         self._cfg = cfg
         self._max_tracks = max_tracks
+        self._seed_frame_count = False
         self._handle = None
         self._reserved = (0, 0)
         self._check_obb_options()
@@ -109,6 +110,9 @@ class DeepOcSort(BaseTracker):
             oriented = {"iou": _lib.ASSO_FUNCS["iou"], "centroid": _lib.ASSO_FUNCS["centroid"]}
             self._cfg.asso_func = oriented.get(self._asso_func_base_name, 0) if self.is_obb else _lib.ASSO_FUNCS.get(self._asso_func_base_name, 0)
             self._create_handle()
+            # frames that carried no layout (update(None, img), 1-D empty tables) have already advanced the replaced handle's
+            # device frame counter; the reference keeps counting through them, so the new handle starts from the host's count
+            self._seed_frame_count = self.frame_count > 0
             self._ids_issued = ctypes.c_int(0)
 
     def _update_impl(self, dets, img, embs=None, masks=None, class_list: int = 0) -> np.ndarray:
@@ -137,7 +141,7 @@ class DeepOcSort(BaseTracker):
         out = np.empty((max(n, 1), 9), dtype=np.float32)
         out_rows, out_is_obb = ctypes.c_int(0), ctypes.c_int(0)
         ok = self._lib.boxmot_hip_deepocsort_update_stream(
-            self._handle, stream, int(self.frame_count) if self.per_class else -1,
+            self._handle, stream, int(self.frame_count) if (self.per_class or self._seed_frame_count) else -1,
             ctypes.byref(self._ids_issued) if self.per_class else None,
             det_arr.ctypes.data if n else None, n, self.det_cols,
             feats.ctypes.data if feats is not None else None, n if feats is not None else 0,
@@ -147,6 +151,7 @@ class DeepOcSort(BaseTracker):
             out.ctypes.data, int(out.shape[0]), 9, ctypes.byref(out_rows), ctypes.byref(out_is_obb))
         if _lib.step_ran(ok):       # a per-stream status report (capacity, solver) is raised after the step has run
             self.frame_count += 1
+            self._seed_frame_count = False
         _lib.check(ok)
         if out_rows.value == 0:
             return np.array([])                      # deepocsort.py:490-492 -> TrackResults of shape (0, 0)

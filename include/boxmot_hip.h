@@ -9,7 +9,15 @@
  *     contiguous fp32 / uint8, output buffer caller-allocated (rows x 9 fp32);
  *   - return 1 on success, 0 on failure; the message of the last failure on the
  *     calling thread is returned by boxmot_hip_last_error();
- *   - a handle is not thread-safe; distinct handles may be used concurrently.
+ *   - a handle is not thread-safe; distinct handles may be used concurrently from
+ *     distinct threads (the reference's contract, reid_capi.h:61-70; tests/test_gpu_threads.py);
+ *   - Devices: a handle belongs to the HIP device that is current on the creating
+ *     thread at create (hipSetDevice before create selects it).  Every entry point
+ *     that takes a handle makes that device current for the call and restores the
+ *     caller's device before returning, so one process may own handles on several
+ *     GPUs and call them from any thread; device pointers passed to a handle
+ *     (_step_device, _apply_device, ingest rings) must live on the handle's device.
+ *     boxmot_hip_botsort_device() reports it.
  * Differences from the precedent, all deliberate (DESIGN.md "Boundary"):
  *   - thresholds are double: the Python tracker (the parity oracle) compares in
  *     fp64 and its YAML defaults are not representable in fp32;
@@ -222,6 +230,8 @@ int boxmot_hip_reid_last_time_ms(BoxMOTHipReID* handle, double* out_preprocess_m
 const char* boxmot_hip_last_error(void);
 /* number of visible HIP devices (0 when none / runtime unusable) */
 int boxmot_hip_device_count(void);
+/* the HIP device a handle was created on (the device every call on it runs on); -1 for NULL */
+int boxmot_hip_botsort_device(BoxMOTHipBotSort* handle);
 
 /* ------------------------------------------------------------------------------------------------
  * Camera-motion estimation: the ECC estimator (boxmot/motion/cmc/ecc.py:14-96; the reference's StrongSORT applies it on every

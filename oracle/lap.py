@@ -25,6 +25,14 @@ _HERE = Path(__file__).resolve().parent
 _LIB_PATH = _HERE / "_build" / "liboracle.so"
 _lib = None
 
+# How `extend_cost=True` WITHOUT a cost limit (the DeepOCSORT / OC-SORT call site, association.py:20-24) squares the matrix:
+#   "sum_max_plus_one"  (n_rows + n_cols)^2 filled with max(cost) + 1, zero bottom-right block -- the restatement of lapx's wrapper
+#                       this oracle (and the device solver, tie for tie) follows; the default;
+#   "zero_pad"          max(n_rows, n_cols)^2 zero-padded -- the alternative reading SURVEY.md section 8(c) flags.
+# Same optimum either way; the choice among exactly tied optima may differ.  tests/test_lap_forms.py runs every golden of that
+# call site under both and asserts identical rows, so the unpinnable choice is a tested invariance, not an assumption.
+NO_LIMIT_FORM = "sum_max_plus_one"
+
 
 def build_oracle_lib(force: bool = False) -> Path:
     """Compile oracle/lapjv.c with gcc (used by __graft_entry__.build())."""
@@ -47,6 +55,8 @@ def _load():
             ctypes.c_void_p, ctypes.c_void_p,
         ]
         lib.oracle_lapjv_extended.restype = ctypes.c_int
+        lib.oracle_lapjv_zero_padded.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        lib.oracle_lapjv_zero_padded.restype = ctypes.c_int
         _lib = lib
     return _lib
 
@@ -63,10 +73,14 @@ def lapjv(cost, extend_cost: bool = False, cost_limit: float = np.inf, return_co
     y = np.full(nc, -1, dtype=np.int32)
     if nr and nc:
         use_limit = bool(cost_limit < np.inf)
-        _load().oracle_lapjv_extended(
-            nr, nc, cost.ctypes.data, int(use_limit), float(cost_limit if use_limit else 0.0),
-            x.ctypes.data, y.ctypes.data,
-        )
+        if not use_limit and NO_LIMIT_FORM == "zero_pad":
+            _load().oracle_lapjv_zero_padded(nr, nc, cost.ctypes.data, x.ctypes.data, y.ctypes.data)
+        else:
+            assert use_limit or NO_LIMIT_FORM == "sum_max_plus_one", NO_LIMIT_FORM
+            _load().oracle_lapjv_extended(
+                nr, nc, cost.ctypes.data, int(use_limit), float(cost_limit if use_limit else 0.0),
+                x.ctypes.data, y.ctypes.data,
+            )
     x = x.astype(np.int64)
     y = y.astype(np.int64)
     if return_cost:

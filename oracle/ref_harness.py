@@ -1,10 +1,16 @@
 """Import the REAL reference (/root/reference) under documented stand-ins.
 
-TEST INFRASTRUCTURE ONLY, and only usable in the build container: the GPU box
-has no /root/reference, so nothing under ``-m gpu``, ``smoke()`` or ``bench.py``
-may call this module.  ``tests/golden/make_golden.py`` uses it to produce the
-committed fixtures; ``tests/test_oracle_vs_reference.py`` uses it (skipped when
-the reference is absent) to pin the oracle bit-for-bit.
+TEST / MEASUREMENT INFRASTRUCTURE ONLY.  The reference SOURCE tree exists in the build
+container only: ``tests/golden/make_golden.py`` uses it to produce the committed
+fixtures; ``tests/test_oracle_vs_reference.py`` uses it (skipped when the reference
+is absent) to pin the oracle bit-for-bit.  On the GPU box there is no /root/reference;
+what travels there is ``oracle/_ref/`` -- the same modules byte-compiled from
+/root/reference by ``oracle/make_ref.py`` (sourceless ``.pyc`` build outputs, git-ignored
+like ``liboracle.so``; no source text is copied) -- and ``bench.py``'s ``cpu_baseline``
+leg imports the reference classes from there so that the reference itself is timed on
+the GPU box's host cores (``cpu_baseline.kind = "reference"``).  ``reference_available()``
+still means "the source tree is mounted" (the pinning tests read other reference files
+by path); ``reference_runnable()`` is true for either form.
 
 Stand-ins injected through ``sys.modules``:
   * ``lap``  -> ``oracle.lap`` (lapx 0.9.4 is not installed; PARITY UNPINNED);
@@ -22,11 +28,56 @@ from pathlib import Path
 
 import numpy as np
 
-REFERENCE_ROOT = Path("/root/reference")
+SOURCE_ROOT = Path("/root/reference")
+COMPILED_ROOT = Path(__file__).resolve().parent / "_ref"
+
+
+def _pick_root() -> Path:
+    """The source tree when it is mounted; otherwise the byte-compiled copy (oracle/make_ref.py).  BOXMOT_ORACLE_REF=compiled forces
+    the compiled copy (the test of the fallback in the build container)."""
+    import os
+
+    have_src = (SOURCE_ROOT / "boxmot" / "trackers" / "bbox" / "botsort" / "botsort.py").exists()
+    if have_src and os.environ.get("BOXMOT_ORACLE_REF", "") != "compiled":
+        return SOURCE_ROOT
+    if (COMPILED_ROOT / "MANIFEST.json").exists():
+        return COMPILED_ROOT
+    return SOURCE_ROOT
+
+
+REFERENCE_ROOT = _pick_root()
+
+
+def reference_kind():
+    """"source" (/root/reference mounted), "compiled" (oracle/_ref/) or None."""
+    if REFERENCE_ROOT == SOURCE_ROOT:
+        return "source" if (SOURCE_ROOT / "boxmot" / "trackers" / "bbox" / "botsort" / "botsort.py").exists() else None
+    return "compiled"
 
 
 def reference_available() -> bool:
-    return (REFERENCE_ROOT / "boxmot" / "trackers" / "bbox" / "botsort" / "botsort.py").exists()
+    """The reference SOURCE tree is mounted (build container)."""
+    return reference_kind() == "source"
+
+
+def reference_runnable() -> bool:
+    """The reference classes can be imported: from the source tree or from the byte-compiled copy."""
+    return reference_kind() is not None
+
+
+def _load_by_path(rel: str, name: str):
+    """Load one reference module by its path relative to the reference root (source ``.py`` or compiled ``.pyc``)."""
+    import importlib.machinery
+
+    if reference_kind() == "compiled":
+        path = (REFERENCE_ROOT / rel).with_suffix(".pyc")
+        loader = importlib.machinery.SourcelessFileLoader(name, str(path))
+        spec = importlib.util.spec_from_loader(name, loader)
+    else:
+        spec = importlib.util.spec_from_file_location(name, REFERENCE_ROOT / rel)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
 
 
 def _cv2_stub():
@@ -240,11 +291,7 @@ class IdentityCMC:
 def load_osnet_module():
     """Load boxmot/reid/backbones/osnet.py by path (``boxmot.reid`` itself cannot import)."""
     install_standins()
-    path = REFERENCE_ROOT / "boxmot" / "reid" / "backbones" / "osnet.py"
-    spec = importlib.util.spec_from_file_location("_ref_osnet", path)
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    return mod
+    return _load_by_path("boxmot/reid/backbones/osnet.py", "_ref_osnet")
 
 
 class RefReID:
@@ -260,24 +307,20 @@ class RefReID:
         import torch
 
         install_standins()
-        src = (REFERENCE_ROOT / "boxmot" / "reid" / "backends" / "base_backend.py").read_text()
-        import ast
         import cv2
 
-        tree = ast.parse(src)
-        cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "BaseModelBackend")
-        keep = {"get_crops", "get_features", "_is_obb_box", "_boxes_to_xyxy", "inference_preprocess",
-                "inference_postprocess", "to_numpy"}
-        cls.body = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in keep]
-        cls.bases = []
-        module = ast.Module(body=[cls], type_ignores=[])
+        if reference_kind() == "compiled":
+            import marshal
+
+            code = marshal.loads((REFERENCE_ROOT / "base_backend_subset.marshal").read_bytes())
+        else:
+            from oracle.make_ref import BACKEND, backend_subset_code
+
+            code = backend_subset_code((REFERENCE_ROOT / BACKEND).read_text())
         ns = {"np": np, "torch": torch, "cv2": cv2}
-        exec(compile(module, "base_backend_subset", "exec"), ns)
+        exec(code, ns)
         Backend = ns["BaseModelBackend"]
-        pp_path = REFERENCE_ROOT / "boxmot" / "reid" / "core" / "preprocessing.py"
-        spec = importlib.util.spec_from_file_location("_ref_reid_preprocessing", pp_path)
-        pp = importlib.util.module_from_spec(spec)
-        spec.loader.exec_module(pp)
+        pp = _load_by_path("boxmot/reid/core/preprocessing.py", "_ref_reid_preprocessing")
         get_preprocess_fn = pp.get_preprocess_fn
 
         class _Bound(Backend):

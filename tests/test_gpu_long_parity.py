@@ -505,3 +505,51 @@ def test_config5_reid_inside_update_full_size_vs_reference_rows():
             assert_rows_match(got, want[t], t, box_atol=2e-2)
     finally:
         lib.boxmot_hip_strongsort_destroy(h)
+
+
+def test_config2_operating_point_256_streams_sampled_streams_vs_reference_rows():
+    """The launch bench.py times -- 256 streams x 64 crops (256 in the confirmation frames), fp32-grade fused ReID (mode 2), 1080p,
+    device-resident inputs, ONE step per frame for all streams -- with the golden scene (tests/golden/config2_reid_init_golden.npz,
+    rows of the REAL reference BotSort + reference OSNet) placed at streams 0, 128 and 255 (own copies of the frame) and 253 other
+    scenes in between: the first, a middle and the last workgroup / crop range of the launch must return the reference's rows for
+    30 frames.  An indexing fault at high stream or crop indices cannot hide behind stream 0."""
+    import torch
+
+    from boxmot_amd.reid_weights import reference_init_state_dict
+    from boxmot_amd.scenario import Scenario
+    from boxmot_amd.streams import MultiStreamBotSort
+    from boxmot_amd.tracker_zoo import BOTSORT_YAML_DEFAULTS
+    want = _golden_frames("config2_reid_init_golden.npz")
+    sd = reference_init_state_dict("osnet_x0_25", seed=0)
+    kw = {k: v for k, v in BOTSORT_YAML_DEFAULTS.items() if k not in ("use_cmc", "cmc_method")}
+    S, nd, T = 256, 256, 30
+    sampled = (0, S // 2, S - 1)
+    # stream index -> scenario seed: the golden scene (seed stream 0) at the sampled positions, distinct scenes elsewhere
+    scs = [Scenario(64, 256, emb_dim=512, stream=(0 if s in sampled else s), random_image=True) for s in range(S)]
+    dev = torch.device("cuda:0")
+    frames = torch.stack([torch.from_numpy(sc.image) for sc in scs]).to(dev)
+    ptrs = torch.tensor([frames[s].data_ptr() for s in range(S)], dtype=torch.int64, device=dev)
+    dets_h = np.zeros((T, S, nd, 6), dtype=np.float32)
+    cnt_h = np.zeros((T, S), dtype=np.int32)
+    for s, sc in enumerate(scs):
+        for t in range(T):
+            d, _ = sc.frame(t, with_embs=False)
+            dets_h[t, s, : len(d)] = d
+            cnt_h[t, s] = len(d)
+    d_dets, d_cnt = torch.from_numpy(dets_h).to(dev), torch.from_numpy(cnt_h).to(dev)
+    d_out = torch.zeros((T, S, nd, 8), dtype=torch.float32, device=dev)
+    d_out_n = torch.zeros((T, S), dtype=torch.int32, device=dev)
+    ms = MultiStreamBotSort(S, max_tracks=512, max_dets=nd, emb_dim=512, reid_weights=sd, **kw)
+    ms.set_reid_mode(2)
+    torch.cuda.synchronize()
+    for t in range(T):
+        ms.step_device(d_dets[t].data_ptr(), d_cnt[t].data_ptr(), None, ptrs.data_ptr(), 1080, 1920, d_out[t].data_ptr(), d_out_n[t].data_ptr())
+    ms.synchronize()
+    assert (ms.status() == 0).all()
+    out, cnt = d_out.cpu().numpy(), d_out_n.cpu().numpy()
+    for s in sampled:
+        for t in range(T):
+            assert_rows_match(out[t, s, : cnt[t, s]], want[t], (s, t), box_atol=2e-3)
+    # the scenes in between are different scenes (not copies): their rows differ from the golden ones somewhere
+    assert any(cnt[t, 1] != len(want[t]) or not np.array_equal(out[t, 1, : cnt[t, 1], :4], want[t][:, :4]) for t in range(T))
+    ms.close()

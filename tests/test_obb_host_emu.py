@@ -248,3 +248,41 @@ def test_oriented_multi_stream_handle_equals_per_stream_oracles(emulated_abi):
             assert got[s].shape[1] == 9 and got[s].is_obb
             _rows_match(got[s], orcs[s].update(frames[s][t].copy(), None, None), t)
     ms.close()
+
+
+@pytest.mark.parametrize("key,lead", [("botsort_noreid", 3), ("bytetrack", 2)])
+def test_frames_without_a_layout_before_the_first_oriented_table_keep_the_frame_numbering(emulated_abi, key, lead):
+    """`update(None, img)` / empty tables before the first 7-column table: the step runs them as empty frames and the device frame
+    counter advances; the handle re-made for the oriented layout starts from the HOST's frame count (round-4 advisor finding:
+    a restarted counter turned the first oriented frame into "frame 1" -- immediate activation, shifted start_frame / frame_id).
+    The reference keeps counting through such frames (botsort.py:172-176, bytetrack.py:259-275): run beside the oracle that is
+    pinned on it, and -- where /root/reference is mounted -- beside the reference class itself."""
+    from boxmot_amd import BotSort, ByteTrack
+    from oracle import ref_harness
+    from oracle.botsort_obb import BotSortObbOracle
+    from oracle.bytetrack_obb import ByteTrackObbOracle
+    _, frames, seed = obb_golden_rows(key)
+    img = np.zeros((480, 640, 3), np.uint8)
+    if key == "bytetrack":
+        trk, orc = ByteTrack(max_tracks=128, max_dets=64), ByteTrackObbOracle()
+        ref = ref_harness.load_bytetrack()() if ref_harness.reference_available() else None
+    else:
+        trk, orc = BotSort(reid_model=None, use_cmc=False, with_reid=False, max_tracks=128, max_dets=64), BotSortObbOracle(with_reid=False)
+        ref = ref_harness.load_botsort()(reid_model=None, use_cmc=False, with_reid=False) if ref_harness.reference_available() else None
+    for _ in range(lead):
+        got = trk.update(None, img)
+        assert len(got) == 0
+        orc.update(np.empty((0, 7), np.float32), img)
+        if ref is not None:
+            ref.update(None, img)
+    assert trk.frame_count == lead and not trk.is_obb
+    seq = list(obb_frames(frames, seed=seed))[:40]
+    for t, d in enumerate(seq):
+        got = trk.update(d, img)
+        want = orc.update(d, img)
+        _rows_match(got, want, t)
+        if ref is not None:
+            _rows_match(got, np.asarray(ref.update(d, img)), t)
+    assert trk.is_obb and trk.frame_count == lead + len(seq)
+    # the first oriented frame was NOT frame 1: nothing was activated on it (activation on the first frame only, botsort_track.py:247-250)
+    trk.close()
