@@ -604,7 +604,7 @@ void build(BoxMOTHipBotSort* h) {
         // enclosing boxes, botsort.py:147-158: the caller does that and supplies the warp).  Embeddings of oriented detections come
         // from the caller (the reference crops rotated rectangles with cv2.warpAffine, reid/backends/base_backend.py:92-118).
         // (cmc_method ecc / sof run on an oriented handle too: SOF is masked by the enclosing boxes, obb_enclosing_boxes_kernel)
-        if (c.reid_model_path && c.reid_model_path[0])
+        if ((c.reid_model_path && c.reid_model_path[0]) || !h->reid_path.empty())      // (create() moves the path into the handle)
             throw std::runtime_error("boxmot_hip: an oriented-box handle takes embeddings from the caller (embs), not from in-handle ReID weights");
     }
     h->S = c.n_streams; h->cap = c.max_tracks; h->nd = c.max_dets; h->dim = c.emb_dim; h->n_lists = c.n_class_lists;
