@@ -411,8 +411,26 @@ struct StreamIo : DeviceBound {
     std::vector<int> warp_flag_stage[WARP_SLOTS];
     hipEvent_t warp_ev[WARP_SLOTS] = {};
     unsigned warp_slot = 0;
+    // step_device_frames as a two-stage pipeline over consecutive (asynchronous) calls: the ReID pass of frame t + 1 is enqueued on
+    // `reid_stream` and runs while the frame step of frame t -- a handful of workgroups, one per stream, for milliseconds -- is
+    // still on `stream`.  A frame's embeddings do not depend on the previous frame's step (the crops come from the detections), so
+    // only the embedding table is double-buffered: ReID(t) writes table t & 1 after step(t - 2) has read it (ev_embs_free), step(t)
+    // starts after ReID(t) (ev_reid_done).  Every ReID pass is followed by its step on `stream`, so waiting for `stream` waits for
+    // both.  BOXMOT_HIP_PIPELINE=0 keeps everything on `stream` (A/B switch, profiles/r5_pipeline_ab.txt).
+    hipStream_t reid_stream = nullptr;
+    float* d_embs_alt = nullptr;
+    hipEvent_t ev_reid_done[2] = {}, ev_embs_free[2] = {}, ev_main = nullptr;
+    int pipe_slot = 0;
+    bool pipe = true;
+    bool engine_on_main = false;        // the engine / crop list were last used on `stream` (host-update paths)
     ~StreamIo() {
+        if (reid_stream) (void)hipStreamSynchronize(reid_stream);
+        if (stream) (void)hipStreamSynchronize(stream);
         for (hipEvent_t e : warp_ev) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ev_reid_done) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ev_embs_free) if (e) (void)hipEventDestroy(e);
+        if (ev_main) (void)hipEventDestroy(ev_main);
+        if (reid_stream) (void)hipStreamDestroy(reid_stream);
         reid.reset();
         for (void* p : owned) (void)hipFree(p);
         for (auto* p : frame_bufs) if (p) (void)hipFree(p);
@@ -1048,10 +1066,12 @@ void io_make_reid(StreamIo* h) { h->reid = io_new_reid(h, h->nd); }
 void io_alloc_sized(StreamIo* h) {
     auto& o = h->owned;
     const size_t s = h->S, c = h->cap, n = h->nd, d = h->dim;
-    release(o, h->d_dets); release(o, h->d_embs); release(o, h->d_out);
+    if (h->reid_stream) BM_HIP(hipStreamSynchronize(h->reid_stream));       // nothing in flight reads the tables being replaced
+    release(o, h->d_dets); release(o, h->d_embs); release(o, h->d_embs_alt); release(o, h->d_out);
     release(o, h->d_crop_stream); release(o, h->d_crop_boxes); release(o, h->d_crop_row);
     h->d_dets = zalloc<float>(s * n * h->det_cols, o);
     h->d_embs = zalloc<float>(s * n * d, o);
+    h->d_embs_alt = zalloc<float>(s * n * d, o);          // step_device_frames pipeline: frames alternate between the two tables
     h->d_out = zalloc<float>(s * c * h->out_cols, o);
     h->d_crop_stream = zalloc<int>(s * n, o);
     h->d_crop_boxes = zalloc<float>(s * n * 4, o);
@@ -1063,6 +1083,18 @@ void io_alloc_sized(StreamIo* h) {
 void io_allocate(StreamIo* h, int S, int cap, int nd, int dim, bool with_reid) {
     h->S = S; h->cap = cap; h->nd = nd; h->dim = dim;
     BM_HIP(hipStreamCreate(&h->stream));
+    {
+        const char* v = std::getenv("BOXMOT_HIP_PIPELINE");
+        h->pipe = !(v && v[0] == '0');
+        if (h->pipe) {
+            BM_HIP(hipStreamCreate(&h->reid_stream));
+            for (int k = 0; k < 2; ++k) {
+                BM_HIP(hipEventCreateWithFlags(&h->ev_reid_done[k], hipEventDisableTiming));
+                BM_HIP(hipEventCreateWithFlags(&h->ev_embs_free[k], hipEventDisableTiming));
+            }
+            BM_HIP(hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
+        }
+    }
     auto& o = h->owned;
     const size_t s = S;
     io_alloc_sized(h);
@@ -1213,6 +1245,7 @@ bool io_stage(StreamIo* h, int n, const StreamIn* in, int det_cols, int emb_cols
         }
         BM_HIP(hipMemcpyAsync(h->frame_bufs[sk], in[k].image, bytes, hipMemcpyHostToDevice, h->stream));
     }
+    h->engine_on_main = true;           // (a later pipelined step_device_frames orders its ReID pass after this use)
     BM_HIP(hipMemsetAsync(h->d_crop_count, 0, 4, h->stream));
     hipLaunchKernelGGL(build_crop_list_kernel, dim3(n), dim3(256), 0, h->stream, h->d_dets, h->d_ndets, nd, reid_thresh,
                        h->d_crop_count, h->d_crop_stream, h->d_crop_boxes, h->d_crop_row, s0, inclusive);
@@ -1232,30 +1265,54 @@ bool io_stage(StreamIo* h, int n, const StreamIn* in, int det_cols, int emb_cols
 // Device-resident ReID for the DeepOCSORT / StrongSORT step_device_frames entry points: crop list from the caller's device
 // detections, backbone over the caller's device frames, embeddings into h->d_embs (rows of skipped detections keep stale
 // values; the step kernels never read them).
-void io_device_reid(StreamIo* h, const float* d_dets, const int* d_ndets, const uint8_t* const* d_frames, int image_rows,
-                    int image_cols, double reid_thresh, int inclusive) {
+float* io_device_reid(StreamIo* h, const float* d_dets, const int* d_ndets, const uint8_t* const* d_frames, int image_rows,
+                      int image_cols, double reid_thresh, int inclusive) {
     if (!h->reid) throw std::runtime_error("boxmot_hip: embeddings are needed and none were supplied, but no ReID weights are loaded");
     if (!d_frames || image_rows <= 0 || image_cols <= 0) throw std::runtime_error("boxmot_hip: step_device_frames needs device frames");
-    BM_HIP(hipMemsetAsync(h->d_crop_count, 0, 4, h->stream));
-    hipLaunchKernelGGL(build_crop_list_kernel, dim3(h->S), dim3(256), 0, h->stream, d_dets, d_ndets, h->nd, reid_thresh,
+    // pipeline stage 1 (StreamIo): this frame's ReID on `reid_stream`, into the table the step before last has finished reading
+    const bool pipe = h->pipe && h->reid_stream;
+    hipStream_t rs = pipe ? h->reid_stream : h->stream;
+    float* embs = (pipe && h->pipe_slot) ? h->d_embs_alt : h->d_embs;
+    if (pipe) {
+        if (h->engine_on_main) {            // a host-update path used the engine / the crop list on `stream` since: order after it
+            BM_HIP(hipEventRecord(h->ev_main, h->stream));
+            BM_HIP(hipStreamWaitEvent(rs, h->ev_main, 0));
+            h->engine_on_main = false;
+        }
+        BM_HIP(hipStreamWaitEvent(rs, h->ev_embs_free[h->pipe_slot], 0));
+    }
+    BM_HIP(hipMemsetAsync(h->d_crop_count, 0, 4, rs));
+    hipLaunchKernelGGL(build_crop_list_kernel, dim3(h->S), dim3(256), 0, rs, d_dets, d_ndets, h->nd, reid_thresh,
                        h->d_crop_count, h->d_crop_stream, h->d_crop_boxes, h->d_crop_row, 0, inclusive);
     if (h->reid->counted_ok()) {
         h->reid->run_counted(d_frames, h->d_crop_stream, h->d_crop_boxes, 4, h->d_crop_count, h->S * h->nd, image_cols, image_rows,
-                             h->d_embs, h->d_crop_row, h->stream);
+                             embs, h->d_crop_row, rs);
     } else if (h->crop_bound >= 0) {
         // launches sized by the caller's bound: no read-back, no stream synchronisation inside the step (the host keeps queueing)
         const int n = h->crop_bound < h->S * h->nd ? h->crop_bound : h->S * h->nd;
         if (n > 0) {
-            hipLaunchKernelGGL(pad_crop_list_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, (const int*)h->d_crop_count, n,
+            hipLaunchKernelGGL(pad_crop_list_kernel, dim3((n + 255) / 256), dim3(256), 0, rs, (const int*)h->d_crop_count, n,
                                h->d_crop_stream, h->d_crop_boxes, h->d_crop_row, h->d_crop_count + 1);
-            h->reid->run(d_frames, h->d_crop_stream, h->d_crop_boxes, 4, n, image_cols, image_rows, h->d_embs, h->d_crop_row, h->stream);
+            h->reid->run(d_frames, h->d_crop_stream, h->d_crop_boxes, 4, n, image_cols, image_rows, embs, h->d_crop_row, rs);
         }
     } else {
         int n_crops = 0;
-        BM_HIP(hipMemcpyAsync(&n_crops, h->d_crop_count, 4, hipMemcpyDeviceToHost, h->stream));
-        BM_HIP(hipStreamSynchronize(h->stream));
-        h->reid->run(d_frames, h->d_crop_stream, h->d_crop_boxes, 4, n_crops, image_cols, image_rows, h->d_embs, h->d_crop_row, h->stream);
+        BM_HIP(hipMemcpyAsync(&n_crops, h->d_crop_count, 4, hipMemcpyDeviceToHost, rs));
+        BM_HIP(hipStreamSynchronize(rs));
+        h->reid->run(d_frames, h->d_crop_stream, h->d_crop_boxes, 4, n_crops, image_cols, image_rows, embs, h->d_crop_row, rs);
     }
+    if (pipe) {
+        BM_HIP(hipEventRecord(h->ev_reid_done[h->pipe_slot], rs));
+        BM_HIP(hipStreamWaitEvent(h->stream, h->ev_reid_done[h->pipe_slot], 0));
+    }
+    return embs;
+}
+// pipeline stage 2 enqueued (the frame step that reads this frame's embedding table is on `stream`): the table is free for the
+// ReID pass after next once that step has run
+void io_pipe_step_enqueued(StreamIo* h) {
+    if (!(h->pipe && h->reid_stream)) return;
+    BM_HIP(hipEventRecord(h->ev_embs_free[h->pipe_slot], h->stream));
+    h->pipe_slot ^= 1;
 }
 
 void io_set_crop_bound(StreamIo* h, int max_total_crops) {
@@ -2386,16 +2443,18 @@ int boxmot_hip_deepocsort_step_device_frames(BoxMOTHipDeepOcSort* handle, const 
     return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip DeepOCSORT handle is not initialized.");
         if (!d_dets || !d_det_rows || !d_out || !d_out_rows) throw std::runtime_error("boxmot_hip: null device pointers");
+        const float* embs = nullptr;
         if (!handle->cfg.embedding_off)      // deepocsort.py:337-345: every detection above det_thresh is embedded
-            io_device_reid(handle, d_dets, d_det_rows, d_frames, image_rows, image_cols, (double)(float)handle->cfg.det_thresh, 0);
+            embs = io_device_reid(handle, d_dets, d_det_rows, d_frames, image_rows, image_cols, (double)(float)handle->cfg.det_thresh, 0);
         docs_need_frame_size(handle, image_rows, image_cols);
         bm::DocsStepArgs a = handle->args;
-        a.dets = d_dets; a.n_dets = d_det_rows; a.embs = handle->cfg.embedding_off ? nullptr : handle->d_embs;
+        a.dets = d_dets; a.n_dets = d_det_rows; a.embs = embs;
         const bool any_warp = io_consume_warps(handle);
         a.warp = any_warp ? handle->d_warp : nullptr; a.warp_flag = any_warp ? handle->d_warp_flag : nullptr;
         a.out = d_out; a.out_n = d_out_rows; a.stream_base = 0;
         docs_launch(handle, handle->S, a);
         BM_HIP(hipGetLastError());
+        if (embs) io_pipe_step_enqueued(handle);
         io_clear_warps(handle);
     });
 }
@@ -2578,13 +2637,14 @@ int boxmot_hip_strongsort_step_device_frames(BoxMOTHipStrongSort* handle, const 
     return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip StrongSORT handle is not initialized.");
         if (!d_dets || !d_det_rows || !d_out || !d_out_rows) throw std::runtime_error("boxmot_hip: null device pointers");
-        io_device_reid(handle, d_dets, d_det_rows, d_frames, image_rows, image_cols, handle->cfg.min_conf, 1);    // strongsort.py:74-91
+        const float* embs = io_device_reid(handle, d_dets, d_det_rows, d_frames, image_rows, image_cols, handle->cfg.min_conf, 1);    // strongsort.py:74-91
         bm::SsStepArgs a = handle->args;
-        a.dets = d_dets; a.n_dets = d_det_rows; a.embs = handle->d_embs;
+        a.dets = d_dets; a.n_dets = d_det_rows; a.embs = embs;
         a.warp = io_consume_warps(handle) ? handle->d_warp : nullptr;
         a.out = d_out; a.out_n = d_out_rows; a.stream_base = 0;
         ss_launch(handle, a, handle->S);
         BM_HIP(hipGetLastError());
+        io_pipe_step_enqueued(handle);
         io_clear_warps(handle);
     });
 }

@@ -553,3 +553,64 @@ def test_config2_operating_point_256_streams_sampled_streams_vs_reference_rows()
     # the scenes in between are different scenes (not copies): their rows differ from the golden ones somewhere
     assert any(cnt[t, 1] != len(want[t]) or not np.array_equal(out[t, 1, : cnt[t, 1], :4], want[t][:, :4]) for t in range(T))
     ms.close()
+
+
+@pytest.mark.parametrize("pipeline", ["1", "0"])
+def test_config3_steps_queued_without_host_syncs_vs_reference_rows(pipeline, monkeypatch):
+    """step_device_frames as bench / tools/config_bench.py drive it: every frame's inputs resident, the calls queued back to back with
+    NO synchronisation in between, one synchronize at the end.  With the handle's two-stage pipeline (default; BOXMOT_HIP_PIPELINE=0
+    switches it off) the ReID pass of frame t + 1 runs on its own HIP stream while the frame step of frame t is still running, the
+    embedding tables alternate -- the rows of all 60 frames must still be the reference's (tests/golden/config3_reid_golden.npz),
+    with a bounded (frames 0..29) and with a read-back (30..59) crop count."""
+    import ctypes
+    import os
+    import tempfile
+
+    import torch
+
+    from boxmot_amd import _lib
+    from boxmot_amd.reid_weights import pack_osnet, reference_init_state_dict, save_blob
+    from boxmot_amd.scenario import Scenario
+    monkeypatch.setenv("BOXMOT_HIP_PIPELINE", pipeline)
+    want = _golden_frames("config3_reid_golden.npz")
+    T = 60
+    lib = _lib.load()
+    blob = pack_osnet(reference_init_state_dict("osnet_x1_0", seed=0))
+    fd, path = tempfile.mkstemp(suffix=".reidblob")
+    os.close(fd)
+    save_blob(blob, path)
+    sc = Scenario(128, 512, width=1920, height=1080, emb_dim=8, stream=0, random_image=True)
+    cfg = _lib.DeepOcSortConfig()
+    lib.boxmot_hip_deepocsort_default_config(ctypes.byref(cfg))
+    cfg.cmc_off = 1
+    cfg.n_streams, cfg.max_tracks, cfg.max_dets, cfg.emb_dim = 1, 1024, 512, 512
+    cfg.reid_model_path = path.encode()
+    h = lib.boxmot_hip_deepocsort_create(ctypes.byref(cfg))
+    os.unlink(path)
+    assert h, _lib.last_error()
+    _lib.check(lib.boxmot_hip_deepocsort_set_reid_mode(h, 2))
+    dev = torch.device("cuda:0")
+    frame = torch.from_numpy(sc.image).to(dev)
+    ptrs = torch.tensor([frame.data_ptr()], dtype=torch.int64, device=dev)
+    dets_h = np.zeros((T, 512, 6), np.float32)
+    cnt_h = np.zeros((T, 1), np.int32)
+    for t in range(T):
+        d, _ = sc.frame(t, with_embs=False)
+        dets_h[t, : len(d)] = d
+        cnt_h[t, 0] = len(d)
+    d_dets, d_cnt = torch.from_numpy(dets_h).to(dev), torch.from_numpy(cnt_h).to(dev)
+    d_out = torch.zeros((T, 1024, 8), dtype=torch.float32, device=dev)
+    d_out_n = torch.zeros((T, 1), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    try:
+        for t in range(T):
+            # frames 0..29: crop count bounded by the host (no read-back, nothing blocks the queue); 30..59: read back inside the step
+            _lib.check(lib.boxmot_hip_deepocsort_set_crop_bound(h, int(cnt_h[t, 0]) if t < 30 else -1))
+            _lib.check(lib.boxmot_hip_deepocsort_step_device_frames(h, d_dets[t].data_ptr(), d_cnt[t].data_ptr(), ptrs.data_ptr(), 1080, 1920,
+                                                                    d_out[t].data_ptr(), d_out_n[t].data_ptr()))
+        _lib.check(lib.boxmot_hip_deepocsort_synchronize(h))
+        out, cnt = d_out.cpu().numpy(), d_out_n.cpu().numpy()
+        for t in range(T):
+            assert_rows_match(out[t, : cnt[t, 0]], want[t], t, box_atol=5e-3)
+    finally:
+        lib.boxmot_hip_deepocsort_destroy(h)
