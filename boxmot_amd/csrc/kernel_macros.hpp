@@ -117,6 +117,30 @@ __device__ inline unsigned bm_mulhi24(unsigned a, unsigned b) {
 #define BM_SLEEP_8K() __builtin_amdgcn_s_sleep(127)
 #endif
 
+#ifndef BM_LDS_FLAG_SET
+// Wave-to-wave progress flags in LDS: neighbour synchronisation where a workgroup barrier would make eight waves wait for the
+// slowest.  The DS operations of ONE wave are executed in order by the LDS unit, so a flag stored after data stores becomes visible
+// after them, and a wave that has seen the flag reads the data with later (in-order) DS reads; the `memory` clobbers keep the
+// compiler from moving LDS accesses across either side.  The wait polls (s_sleep between polls) until *flag >= value and is BOUNDED:
+// a broken protocol must produce wrong numbers in a test, never a hung GPU -- after BM_LDS_SPIN_LIMIT polls it gives up.
+#define BM_LDS_SPIN_LIMIT (1 << 18)
+// (the flags are addressed as LDS -- ds_write_b32 / ds_read_b32 -- not through generic pointers: a flat access would also wait for
+// the wave's outstanding GLOBAL loads, i.e. for the weight fragments prefetched a layer ahead)
+typedef __attribute__((address_space(3))) int bm_lds_int_t;
+#define BM_LDS_FLAG_SET(ptr, val) do { asm volatile("" ::: "memory"); *(volatile bm_lds_int_t*)(ptr) = (val); asm volatile("" ::: "memory"); } while (0)
+__device__ inline bool bm_lds_flag_wait(const volatile bm_lds_int_t* p, int v) {
+    bool ok = false;
+#pragma unroll 1
+    for (int k = 0; k < BM_LDS_SPIN_LIMIT; ++k) {
+        if (__builtin_amdgcn_readfirstlane(*p) >= v) { ok = true; break; }       // wave-uniform: one scalar branch per poll
+        __builtin_amdgcn_s_sleep(2);
+    }
+    asm volatile("" ::: "memory");
+    return ok;
+}
+#define BM_LDS_FLAG_WAIT(ptr, val) bm_lds_flag_wait((const volatile bm_lds_int_t*)(ptr), (val))
+#endif
+
 // wave priority around an MFMA burst (s_setprio) and the hardware reciprocal (v_rcp_f32, 1 ulp)
 #ifndef BM_SETPRIO
 #define BM_SETPRIO(n) __builtin_amdgcn_s_setprio(n)

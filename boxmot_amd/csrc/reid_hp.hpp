@@ -62,6 +62,19 @@
 #endif
 // streaming accesses (hand-over tensors and block outputs written once, operands read once) marked non-temporal so that the
 // tensor a kernel re-reads per branch (128 KiB per crop, one L2 share) is not evicted by them
+// LightConv layer loop of stages 0 / 1: neighbour synchronisation (1) instead of two workgroup barriers per layer (0).  A wave's
+// depthwise pass reads its own rows and ONE row of each neighbouring wave, so wave w only has to know that waves w - 1 and w + 1 have
+// written the layer (flag `wr`) and, before it overwrites its first / last row, that they have read the previous one (flag `rd`):
+// 20 barriers per crop fewer, and waves may run up to a layer apart (the two waves of a SIMD are four waves apart: their LDS-heavy
+// depthwise phases and their MFMA / memory phases stop coinciding).  The gates stay workgroup barriers (crop-wide sums).
+#ifndef BM_HP_NBR_SYNC
+#define BM_HP_NBR_SYNC 0
+#endif
+// depthwise 3x3: reads of the next input row issued right after the last use of the current one (1) or at the top of its own
+// iteration (0: the compiler schedules them a few instructions before their first use); A/B switch, profiles/r5_hp_s0_ab.txt
+#ifndef BM_HP_DW_PREFETCH
+#define BM_HP_DW_PREFETCH 0
+#endif
 #ifndef BM_HP_NT
 #define BM_HP_NT 0
 #endif
@@ -104,7 +117,8 @@ struct GeoHP {
     static constexpr int WBYTES = 10 * WREC + GATE_BYTES;          // + the ChannelGate's weights (no global load in the gate either)
     // the epilogue stages its A fragments over the (then dead) image and weights; stage 2's downsample block needs 66048 bytes
     static constexpr int TBUF = IMG + WBYTES;
-    static constexpr int LDS_BYTES = TBUF + 4 * NWAVES * HID * 4;
+    static constexpr int FLAGS = TBUF + 4 * NWAVES * HID * 4;       // [2][NWAVES] int: layer written / layer read (BM_HP_NBR_SYNC)
+    static constexpr int LDS_BYTES = FLAGS + (BM_HP_NBR_SYNC ? 2 * NWAVES * 4 : 0);
     static_assert(PLANE >= (H + 2) * ROWP && PLANE % 256 == 0, "plane holds the haloed image; stride keeps the lane groups on disjoint slots");
     static_assert(LDS_BYTES <= 163840 / (STAGE == 2 ? 2 : 1), "LDS budget");
 };
@@ -329,6 +343,10 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
     };
 
     for (int e = tid * 16; e < G::IMG; e += 64 * G::NWAVES * 16) *reinterpret_cast<f4*>(tbuf + e) = f4{0.f, 0.f, 0.f, 0.f};   // halo = zero padding
+    constexpr bool NBR = BM_HP_NBR_SYNC && STAGE < 2;
+    volatile int* wr_flag = reinterpret_cast<volatile int*>(lds + G::FLAGS);        // wr_flag[w]: last layer (1-based) wave w has written
+    volatile int* rd_flag = wr_flag + G::NWAVES;                                     // rd_flag[w]: last layer wave w has finished reading
+    if constexpr (NBR) { if (tid < 2 * G::NWAVES) wr_flag[tid] = 0; }
     if constexpr (!BM_HP_ASYNC_STAGE) stage_light();
     const unsigned char* wgate = wl + 10 * G::WREC;                 // gate weights: fc1_w at +0, then fc1_b, fc2_w, fc2_b as in the blob
     const int g_fc1b = (int)(bp.fc1_b - bp.fc1_w), g_fc2w = (int)(bp.fc2_w - bp.fc1_w), g_fc2b = (int)(bp.fc2_b - bp.fc1_w);
@@ -407,13 +425,46 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
             };
 #pragma unroll
             for (int c = 0; c < NWD; ++c) load_dw(c, wdv[c], dbias[c]);
+            if constexpr (NBR) {
+                // rows of this wave's strip: tiles (2 r, 2 r + 1) in stage 0, tile r in stage 1; the first row is read by wave - 1, the last
+                // by wave + 1 -- those two are overwritten only after that neighbour has finished the previous layer's reads
+                constexpr int ROWS_W = STAGE == 0 ? NT / 2 : NT;
+                auto row_of = [](int i) constexpr { return STAGE == 0 ? i >> 1 : i; };
+                const int seq = li + 1;
 #pragma unroll
-            for (int i = 0; i < NT; ++i)
+                for (int i = 0; i < NT; ++i)
+                    if (row_of(i) != 0 && row_of(i) != ROWS_W - 1) {
 #pragma unroll
-                for (int ct = 0; ct < KT; ++ct) *reinterpret_cast<f4*>(tbuf + pix0 + ct * 4 * G::PLANE + tile_off(i)) = cur[i][ct];
-            BM_PROF(2);
-            __syncthreads();
-            BM_PROF(3);
+                        for (int ct = 0; ct < KT; ++ct) *reinterpret_cast<f4*>(tbuf + pix0 + ct * 4 * G::PLANE + tile_off(i)) = cur[i][ct];
+                    }
+                if (wave > 0) (void)BM_LDS_FLAG_WAIT(rd_flag + wave - 1, seq - 1);
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+                    if (row_of(i) == 0) {
+#pragma unroll
+                        for (int ct = 0; ct < KT; ++ct) *reinterpret_cast<f4*>(tbuf + pix0 + ct * 4 * G::PLANE + tile_off(i)) = cur[i][ct];
+                    }
+                if (wave < G::NWAVES - 1) (void)BM_LDS_FLAG_WAIT(rd_flag + wave + 1, seq - 1);
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+                    if (row_of(i) == ROWS_W - 1 && ROWS_W > 1) {
+#pragma unroll
+                        for (int ct = 0; ct < KT; ++ct) *reinterpret_cast<f4*>(tbuf + pix0 + ct * 4 * G::PLANE + tile_off(i)) = cur[i][ct];
+                    }
+                BM_LDS_FLAG_SET(wr_flag + wave, seq);
+                BM_PROF(2);
+                if (wave > 0) (void)BM_LDS_FLAG_WAIT(wr_flag + wave - 1, seq);
+                if (wave < G::NWAVES - 1) (void)BM_LDS_FLAG_WAIT(wr_flag + wave + 1, seq);
+                BM_PROF(3);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int ct = 0; ct < KT; ++ct) *reinterpret_cast<f4*>(tbuf + pix0 + ct * 4 * G::PLANE + tile_off(i)) = cur[i][ct];
+                BM_PROF(2);
+                __syncthreads();
+                BM_PROF(3);
+            }
             // depthwise 3x3 (pad 1) + bias + ReLU
 #pragma unroll
             for (int ct = 0; ct < KT; ++ct) {
@@ -429,6 +480,47 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
                     cur[0][ct] = relu4(o);
                 } else {
                     constexpr int NSEQ = STAGE == 0 ? 2 : 1, L = NT / NSEQ;
+#if BM_HP_DW_PREFETCH
+                    // The same taps in the same order, but the three reads of input row rr + 1 are issued as soon as row rr's values have
+                    // had their last use -- BEFORE the ReLU / (hi, lo) split / 1x1 MFMAs of the output row that row rr completed -- so
+                    // the LDS round trip runs under ~20 instructions of independent work instead of being waited for at once.
+#pragma unroll
+                    for (int sq = 0; sq < NSEQ; ++sq) {
+                        f4 acc[3];
+                        const unsigned char* rp0 = cbase + sq * 256 - G::ROWP;
+                        f4 v0 = *reinterpret_cast<const f4*>(rp0 - 16), v1 = *reinterpret_cast<const f4*>(rp0), v2 = *reinterpret_cast<const f4*>(rp0 + 16);
+#pragma unroll
+                        for (int rr = 0; rr < L + 2; ++rr) {
+                            f4 done = f4{0.f, 0.f, 0.f, 0.f};
+                            if (rr >= 2) {
+                                f4 a = acc[(rr - 2) % 3];
+                                a = fma_f4(wd[6], v0, a); a = fma_f4(wd[7], v1, a); a = fma_f4(wd[8], v2, a);
+                                done = a;
+                            }
+                            if (rr >= 1 && rr <= L) {
+                                f4 a = acc[(rr - 1) % 3];
+                                a = fma_f4(wd[3], v0, a); a = fma_f4(wd[4], v1, a); a = fma_f4(wd[5], v2, a);
+                                acc[(rr - 1) % 3] = a;
+                            }
+                            if (rr <= L - 1) {
+                                f4 a = fma_f4(wd[0], v0, bias);
+                                a = fma_f4(wd[1], v1, a); a = fma_f4(wd[2], v2, a);
+                                acc[rr % 3] = a;
+                            }
+                            if (rr + 1 < L + 2) {
+                                const unsigned char* rp = cbase + sq * 256 + rr * G::ROWP;
+                                BM_SCHED_FENCE();
+                                v0 = *reinterpret_cast<const f4*>(rp - 16); v1 = *reinterpret_cast<const f4*>(rp); v2 = *reinterpret_cast<const f4*>(rp + 16);
+                                BM_SCHED_FENCE();
+                            }
+                            if (rr >= 2) {
+                                const int i = STAGE == 0 ? 2 * (rr - 2) + sq : rr - 2;
+                                cur[i][ct] = relu4(done);
+                                if constexpr (KT == 1) { if (more) pointwise(An, cur[i]); }
+                            }
+                        }
+                    }
+#else
 #pragma unroll
                     for (int sq = 0; sq < NSEQ; ++sq) {
                         f4 acc[3];
@@ -456,6 +548,7 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
                             }
                         }
                     }
+#endif
                 }
             }
             if constexpr (KT == 2) {
@@ -466,10 +559,16 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
             }
             if (k + 1 < br) load_pw(li + 2, An);        // next layer's fused 1x1 uses these; in flight across the barrier and the image write
             BM_PROF(4);
-            __syncthreads();
+            if constexpr (NBR) BM_LDS_FLAG_SET(rd_flag + wave, li + 1);
+            else __syncthreads();
             BM_PROF(5);
         }
-        if constexpr (EPI_EARLY) { if (br == 3) stage_epilogue(); }        // every wave is past the last read of the image (barrier above)
+        if constexpr (EPI_EARLY) {
+            if (br == 3) {
+                if constexpr (NBR) __syncthreads();      // (neighbour flags only order neighbours: the copies below overwrite the whole image)
+                stage_epilogue();                        // every wave is past the last read of the image (barrier above)
+            }
+        }
         // ChannelGate (osnet.py:194-209): crop-wide average -> fc1 -> ReLU -> fc2 -> sigmoid -> scale
         float* part = gap_part + br * (G::NWAVES * G::HID);
         {

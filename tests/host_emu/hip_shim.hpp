@@ -273,6 +273,23 @@ inline int atomicMax(int* p, int v) {
 inline double __dadd_rn(double a, double b) { return a + b; }
 inline double __dmul_rn(double a, double b) { return a * b; }
 #define BM_EXPF(x) expf(x)
+// wave-to-wave LDS progress flags (kernel_macros.hpp): the waiter hands the processor on between polls (fibers: the flag's writer
+// is another fiber of this OS thread -- a poll loop that did not yield would never see it change)
+// (the lanes of an emulated wave do not run in lockstep: the flag may only be set once EVERY lane of the wave has issued the stores
+// that precede it -- on the device that is the in-order execution of the wave's DS instructions)
+#define BM_LDS_FLAG_SET(ptr, val) do { g_emu_block->wave_barrier[threadIdx.x / EMU_WAVE].wait(); *(volatile int*)(ptr) = (val); } while (0)
+inline bool emu_lds_flag_wait(const volatile int* p, int v) {
+    for (long k = 0; k < (1L << 24); ++k) {
+        if (*p >= v) return true;
+        emu_yield_block();
+    }
+    return false;
+}
+#ifdef EMU_NO_FLAG_WAIT            // negative control: the waits do nothing -- a kernel that needs them must come out wrong
+#define BM_LDS_FLAG_WAIT(ptr, val) (true)
+#else
+#define BM_LDS_FLAG_WAIT(ptr, val) emu_lds_flag_wait((const volatile int*)(ptr), (val))
+#endif
 #define BM_SCHED_FENCE() ((void)0)
 #define BM_SETPRIO(n) ((void)0)
 #define BM_RESID_F16(hp, hi, v, out) do { unsigned short b_ = (unsigned short)((hp) >> (16 * (hi))); _Float16 h_; std::memcpy(&h_, &b_, 2); (out) = (v) - (float)h_; } while (0)

@@ -47,7 +47,7 @@ for step in "$@"; do
              python profiles/summarize_pmc.py $(db fetch) $(db write) 4096 >> $O/pmc_traffic_m$MODE.txt 2>&1; rm -rf $O/fetch $O/write; tail -n 14 $O/pmc_traffic_m$MODE.txt ;;
     mfma)    (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $O/mfma -o p -- python $R/tools/reid_microbench.py 4096 $MODE 2 > $O/mfma.log 2>&1)
              python profiles/summarize_mfma.py $(db mfma) > $O/mfma_busy_m$MODE.txt 2>&1; rm -rf $O/mfma; cat $O/mfma_busy_m$MODE.txt ;;
-    c3)      timeout 600 python tools/config_bench.py --config c3 >> $O/config_bench.jsonl 2> $O/c3.err; tail -n 1 $O/config_bench.jsonl | cut -c1-900 ;;
+    c3)      timeout 600 python tools/config_bench.py --config c3 --reid-mode ${C3_MODE:-2} >> $O/config_bench.jsonl 2> $O/c3.err; tail -n 1 $O/config_bench.jsonl | cut -c1-900 ;;
     c5)      timeout 900 python tools/config_bench.py --config c5 >> $O/config_bench.jsonl 2> $O/c5.err; tail -n 1 $O/config_bench.jsonl | cut -c1-900 ;;
     soak)    timeout 900 python tools/parity_soak.py 10 200 > $O/soak.log 2>&1; tail -n 12 $O/soak.log ;;
     groups)  timeout 800 python -c "

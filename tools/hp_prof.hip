@@ -47,6 +47,7 @@ static void run(const char* name, int n, int iters, const bm::OsnetLayout& L, co
     float *d_x1 = dev(x1), *d_x2 = dev(x2);
     const size_t out_elems = (size_t)n * G::P * G::COUT;
     CK(hipMalloc(&d_oh, out_elems * 2)); CK(hipMalloc(&d_ol, out_elems * 2));
+    CK(hipMemset(d_oh, 0, out_elems * 2)); CK(hipMemset(d_ol, 0, out_elems * 2));
     const bm::BlkLinkHP link = EMIT ? bm::BlkLinkHP{d_wq, bq.conv1_a, bq.conv1_b, 0, d_x2}
                                     : (RECON ? bm::BlkLinkHP{d_wq, bq.conv3_a, bq.conv3_b, bq.down_a, d_x2} : bm::BlkLinkHP{});
     auto kern = bm::k_osblock_hp<STAGE, CIN, DOWN, TRANS, EMIT, RECON>;
@@ -66,6 +67,18 @@ static void run(const char* name, int n, int iters, const bm::OsnetLayout& L, co
         if (ms < best) best = ms;
     }
     printf("%s: n=%d best %.3f ms (%.1f us per crop per CU at 256 CUs)\n", name, n, best, best * 1e3 * 256 / n);
+    {   // position-weighted checksum of everything the kernel wrote (output planes; EMIT: the fp32 hand-over tensors): equal across
+        // -D variants of the kernel = the same results on the device
+        const size_t px_out = TRANS ? G::P / 4 : G::P;
+        std::vector<unsigned short> oh((size_t)n * px_out * G::COUT), ol(oh.size());
+        std::vector<unsigned> f1((size_t)n * G::P * G::MIDP), f2(f1.size());
+        CK(hipMemcpy(oh.data(), d_oh, oh.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(ol.data(), d_ol, ol.size() * 2, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(f1.data(), d_x1, f1.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(f2.data(), d_x2, f2.size() * 4, hipMemcpyDeviceToHost));
+        unsigned long long sum = 0;
+        for (size_t i = 0; i < oh.size(); ++i) sum += (unsigned long long)(oh[i] * 2654435761u + ol[i] * 40503u) * (i % 8191 + 1);
+        for (size_t i = 0; i < f1.size(); ++i) sum += (unsigned long long)(f1[i] * 2246822519u + f2[i] * 3266489917u) * (i % 8191 + 1);
+        printf("    output checksum %016llx\n", sum);
+    }
 #ifdef BM_OSBLOCK_PROF
     unsigned long long acc[8] = {};
     CK(hipMemcpyFromSymbol(acc, HIP_SYMBOL(bm::g_osblock_prof), sizeof(acc)));
