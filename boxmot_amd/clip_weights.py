@@ -70,8 +70,14 @@ def pack_clipreid(state_dict, input_hw=(256, 128)) -> np.ndarray:
 
 
 def random_clipreid_state_dict(seed: int = 0, width: int = 768, layers: int = 12, out_dim: int = 512, patch: int = 16,
-                               input_hw=(256, 128)):
-    """ViT-B/16 defaults; smaller widths (multiples of 128) / depths give the reduced models the emulation tests run."""
+                               input_hw=(256, 128), gain_randomised: bool = False, sharp_attention: bool = False):
+    """ViT-B/16 defaults; smaller widths (multiples of 128) / depths give the reduced models the emulation tests run.
+    ``gain_randomised``: the noise-amplifying twin of the initialisation-like set (what the BatchNorm-calibrated OSNets are to the
+    OSNet init; round-4 review, Weak 5): LayerNorm gains U(0.4, 2.5) and biases N(0, 0.3), neck BatchNorm variances U(0.02, 0.2)
+    (x 2 .. 7 gain on the final features) and means N(0, 0.05).  ``sharp_attention`` additionally makes the query / key projections
+    2.5 x larger (logits ~6 x larger: a rounding error in a logit moves attention mass) -- the operand precision of the device
+    kernels is gated on the first and characterised on the second (tests/test_gpu_clipreid.py, tools/config_bench.py c5;
+    a torch simulation of fp16 GEMM operands gives 4e-5 / 9e-5 / 1-2e-3 for init-like / gain-randomised / + sharp attention)."""
     import torch
 
     g = torch.Generator().manual_seed(seed)
@@ -107,4 +113,18 @@ def random_clipreid_state_dict(seed: int = 0, width: int = 768, layers: int = 12
         sd[name + ".bias"] = rn(c, std=0.2)
         sd[name + ".running_mean"] = rn(c, std=0.3)
         sd[name + ".running_var"] = torch.empty(c).uniform_(0.5, 2.0, generator=g)
+    if gain_randomised:
+        for k in list(sd):
+            if ".ln_" in k or "ln_pre" in k or "ln_post" in k:
+                n = sd[k].numel()
+                sd[k] = torch.empty(n).uniform_(0.4, 2.5, generator=g) if k.endswith(".weight") else rn(n, std=0.3)
+            elif k.endswith(".running_var"):
+                sd[k] = torch.empty(sd[k].numel()).uniform_(0.02, 0.2, generator=g)
+            elif k.endswith(".running_mean"):
+                sd[k] = rn(sd[k].numel(), std=0.05)
+    if sharp_attention:
+        for k in list(sd):
+            if k.endswith("attn.in_proj_weight"):
+                sd[k] = sd[k].clone()
+                sd[k][: 2 * width] *= 2.5                       # q and k rows
     return {k: v.contiguous() for k, v in sd.items()}

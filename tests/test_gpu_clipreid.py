@@ -45,6 +45,33 @@ def test_vitb16_features_and_crops_vs_oracle(vitb16):
     reid.close()
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_vitb16_features_on_gain_randomised_weights(seed):
+    """The fp16 GEMM operands of the CLIP-ReID kernels on something harder than the initialisation-like set (round-4 review, Weak 5):
+    LayerNorm gains U(0.4, 2.5) / biases N(0, 0.3) and neck BatchNorm variances U(0.02, 0.2) -- the tolerance is north_star's 1e-3 --
+    and, characterised rather than promised, the same set with 2.5 x larger query / key projections (attention logits ~6 x larger):
+    there a rounding error in a logit moves attention mass and fp16 operands reach 1-2e-3 in a torch simulation; the device figure is
+    printed and held to 5e-3 (an fp32-grade (hi, lo) operand path for the ViT would cost 3 x the matrix-pipe time of a kernel family
+    that is matrix-pipe bound: not built)."""
+    from boxmot_amd.clip_weights import pack_clipreid, random_clipreid_state_dict
+    from boxmot_amd.reid import HipReID
+    from oracle.clipreid import OracleClipReID
+    img = np.random.default_rng(5).integers(0, 255, (1080, 1920, 3), dtype=np.uint8)
+    boxes = _boxes(8, seed=3 + seed)
+    errs = {}
+    for name, kw in (("gain_randomised", dict(gain_randomised=True)), ("gain_randomised+sharp_attention", dict(gain_randomised=True, sharp_attention=True))):
+        sd = random_clipreid_state_dict(seed, **kw)
+        reid = HipReID(pack_clipreid(sd), max_crops=8)
+        got = reid.get_features(boxes, img)
+        reid.close()
+        want = OracleClipReID(sd).get_features(boxes, img)
+        errs[name] = float(np.abs(got - want).max())
+        cos = want @ want.T
+        print(f"CLIP-ReID ViT-B/16, {name}, seed {seed}: max|diff| vs fp32 oracle = {errs[name]:.2e} (mean cosine between crops {cos[np.triu_indices(8, 1)].mean():.3f})")
+    assert errs["gain_randomised"] < TOL, errs
+    assert errs["gain_randomised+sharp_attention"] < 5e-3, errs
+
+
 def test_strongsort_with_clipreid_inside_update_matches_oracle_ids(vitb16):
     """StrongSORT asks the ReID model itself (strongsort.py:95-99): BASELINE configuration 5's pairing at a small scene."""
     from boxmot_amd.reid import HipReID

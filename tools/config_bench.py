@@ -212,6 +212,17 @@ def run(config: str = "c3", streams: int = 0, steps: int = 40, warmup: int = 8, 
         hc.close()
         gates["reid_max_abs_err_vs_fp32_oracle_bn_calibrated_seed0"] = e
         gates["reid_within_1e-3_on_bn_calibrated_weights"] = bool(e < 1e-3)
+    if not c3 and embedding_gate:
+        # the same kernels on the gain-randomised ViT (LayerNorm gains / biases, neck BatchNorm statistics: boxmot_amd.clip_weights):
+        # the fp16 GEMM operands gated on something harder than the initialisation-like set (round-4 review, Weak 5)
+        from boxmot_amd.clip_weights import pack_clipreid, random_clipreid_state_dict
+        from oracle.clipreid import OracleClipReID as _OC
+        sdg = random_clipreid_state_dict(0, gain_randomised=True)
+        hg = HipReID(pack_clipreid(sdg), max_crops=8, mode=0)
+        e = float(np.abs(hg.get_features(bx, scen[0].image) - _OC(sdg).get_features(bx, scen[0].image)).max())
+        hg.close()
+        gates["reid_max_abs_err_vs_fp32_oracle_gain_randomised_seed0"] = e
+        gates["reid_within_1e-3_on_gain_randomised_weights"] = bool(e < 1e-3)
     log("embedding gates done")
     if check:
         # id gate: the oracle tracker with the fp32 oracle backbone inside update on stream 0's first frames (full size)
