@@ -364,8 +364,22 @@ struct BoxMOTHipBotSort : DeviceBound {
     std::vector<std::pair<void*, size_t>> table_rec;
     std::vector<int> h_used, h_count_buf;
     int n_grows = 0;
+    // step_device as a two-stage pipeline over consecutive asynchronous calls (see StreamIo below: the same scheme): the ReID pass of
+    // frame t + 1 on `reid_stream` while the frame step of frame t runs on `stream`, alternating embedding tables.
+    hipStream_t reid_stream = nullptr;
+    float* d_embs_alt = nullptr;
+    hipEvent_t ev_reid_done[2] = {}, ev_embs_free[2] = {}, ev_main = nullptr;
+    int pipe_slot = 0;
+    bool pipe = true;
+    bool engine_on_main = false;
 
     ~BoxMOTHipBotSort() {
+        if (reid_stream) (void)hipStreamSynchronize(reid_stream);
+        if (stream) (void)hipStreamSynchronize(stream);
+        for (hipEvent_t e : ev_reid_done) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ev_embs_free) if (e) (void)hipEventDestroy(e);
+        if (ev_main) (void)hipEventDestroy(ev_main);
+        if (reid_stream) (void)hipStreamDestroy(reid_stream);
         reid.reset();
         for (void* p : owned) (void)hipFree(p);
         for (auto* p : frame_bufs) if (p) (void)hipFree(p);
@@ -488,10 +502,12 @@ void release(std::vector<void*>& owned, void* p) {
 void alloc_det_io(BoxMOTHipBotSort* h) {
     const size_t S = h->S, nd = h->nd, dim = h->dim;
     auto& o = h->owned;
-    release(o, h->d_dets); release(o, h->d_embs); release(o, h->d_out);
+    if (h->reid_stream) BM_HIP(hipStreamSynchronize(h->reid_stream));
+    release(o, h->d_dets); release(o, h->d_embs); release(o, h->d_embs_alt); release(o, h->d_out);
     release(o, h->d_crop_stream); release(o, h->d_crop_boxes); release(o, h->d_crop_row);
     h->d_dets = zalloc<float>(S * nd * h->det_cols(), o);
     h->d_embs = zalloc<float>(S * nd * dim, o);
+    h->d_embs_alt = zalloc<float>(S * nd * dim, o);          // step_device pipeline: frames alternate between the two tables
     h->d_out = zalloc<float>(S * nd * h->out_cols(), o);
     h->d_crop_stream = zalloc<int>(S * nd, o);
     h->d_crop_boxes = zalloc<float>(S * nd * 4, o);
@@ -627,6 +643,18 @@ void build(BoxMOTHipBotSort* h) {
     }
     h->S = c.n_streams; h->cap = c.max_tracks; h->nd = c.max_dets; h->dim = c.emb_dim; h->n_lists = c.n_class_lists;
     BM_HIP(hipStreamCreate(&h->stream));
+    {
+        const char* v = std::getenv("BOXMOT_HIP_PIPELINE");
+        h->pipe = !(v && v[0] == '0');
+        if (h->pipe && !h->reid_stream) {
+            BM_HIP(hipStreamCreate(&h->reid_stream));
+            for (int k = 0; k < 2; ++k) {
+                BM_HIP(hipEventCreateWithFlags(&h->ev_reid_done[k], hipEventDisableTiming));
+                BM_HIP(hipEventCreateWithFlags(&h->ev_embs_free[k], hipEventDisableTiming));
+            }
+            BM_HIP(hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
+        }
+    }
     BM_HIP(hipEventCreate(&h->ev[0]));
     BM_HIP(hipEventCreate(&h->ev[1]));
     BM_HIP(hipEventCreate(&h->timer_ev[0]));
@@ -680,21 +708,22 @@ void launch_step(BoxMOTHipBotSort* h, int s0, int n_streams, const float* d_dets
 
 // ReID for every high-confidence detection of the first n_streams streams; writes d_embs rows.
 void run_reid(BoxMOTHipBotSort* h, int s0, int n_streams, const float* d_dets, const int* d_ndets,
-              const uint8_t* const* d_frames, int rows, int cols, float* d_embs) {
+              const uint8_t* const* d_frames, int rows, int cols, float* d_embs, hipStream_t st = nullptr) {
     if (!h->reid) throw std::runtime_error("boxmot_hip: with_reid=1 and no embeddings supplied, but no ReID weights are loaded");
-    BM_HIP(hipMemsetAsync(h->d_crop_count, 0, 4, h->stream));
-    hipLaunchKernelGGL(build_crop_list_kernel, dim3(n_streams), dim3(256), 0, h->stream, d_dets, d_ndets, h->nd,
+    if (!st) { st = h->stream; h->engine_on_main = true; }
+    BM_HIP(hipMemsetAsync(h->d_crop_count, 0, 4, st));
+    hipLaunchKernelGGL(build_crop_list_kernel, dim3(n_streams), dim3(256), 0, st, d_dets, d_ndets, h->nd,
                        h->cfg.track_high_thresh, h->d_crop_count, h->d_crop_stream, h->d_crop_boxes, h->d_crop_row, s0);
     if (h->reid->counted_ok()) {
         // crop count stays on the device: launches cover the capacity, surplus workgroups exit at once
         h->reid->run_counted(d_frames, h->d_crop_stream, h->d_crop_boxes, 4, h->d_crop_count, n_streams * h->nd, cols, rows,
-                             d_embs, h->d_crop_row, h->stream);
+                             d_embs, h->d_crop_row, st);
         return;
     }
     int n_crops = 0;
-    BM_HIP(hipMemcpyAsync(&n_crops, h->d_crop_count, 4, hipMemcpyDeviceToHost, h->stream));
-    BM_HIP(hipStreamSynchronize(h->stream));
-    h->reid->run(d_frames, h->d_crop_stream, h->d_crop_boxes, 4, n_crops, cols, rows, d_embs, h->d_crop_row, h->stream);
+    BM_HIP(hipMemcpyAsync(&n_crops, h->d_crop_count, 4, hipMemcpyDeviceToHost, st));
+    BM_HIP(hipStreamSynchronize(st));
+    h->reid->run(d_frames, h->d_crop_stream, h->d_crop_boxes, 4, n_crops, cols, rows, d_embs, h->d_crop_row, st);
 }
 
 // Status words of streams [s0, s0 + n): a non-zero word is reported once and cleared, so that one overflow neither poisons the
@@ -1723,11 +1752,29 @@ int boxmot_hip_botsort_step_device(BoxMOTHipBotSort* handle, const float* d_dets
         if (!handle) throw std::runtime_error("boxmot_hip BoT-SORT handle is not initialized.");
         if (!d_dets || !d_det_rows || !d_out || !d_out_rows) throw std::runtime_error("boxmot_hip: null device pointers");
         const float* embs = d_embs;
+        bool piped = false;
         if (handle->cfg.with_reid && d_embs == nullptr) {
             if (handle->is_obb) throw std::runtime_error("boxmot_hip: an oriented-box handle with with_reid = 1 needs d_embs");
             if (!d_frames) throw std::runtime_error("boxmot_hip: with_reid needs d_embs or d_frames");
-            run_reid(handle, 0, handle->S, d_dets, d_det_rows, d_frames, image_rows, image_cols, handle->d_embs);
-            embs = handle->d_embs;
+            // pipeline stage 1: this frame's ReID on `reid_stream`, into the table the step before last has finished reading
+            const bool pipe = handle->pipe && handle->reid_stream;
+            float* tab = (pipe && handle->pipe_slot) ? handle->d_embs_alt : handle->d_embs;
+            if (pipe) {
+                hipStream_t rs = handle->reid_stream;
+                if (handle->engine_on_main) {       // a host-update path used the engine / the crop list on `stream` since: order after it
+                    BM_HIP(hipEventRecord(handle->ev_main, handle->stream));
+                    BM_HIP(hipStreamWaitEvent(rs, handle->ev_main, 0));
+                    handle->engine_on_main = false;
+                }
+                BM_HIP(hipStreamWaitEvent(rs, handle->ev_embs_free[handle->pipe_slot], 0));
+                run_reid(handle, 0, handle->S, d_dets, d_det_rows, d_frames, image_rows, image_cols, tab, rs);
+                BM_HIP(hipEventRecord(handle->ev_reid_done[handle->pipe_slot], rs));
+                BM_HIP(hipStreamWaitEvent(handle->stream, handle->ev_reid_done[handle->pipe_slot], 0));
+                piped = true;
+            } else {
+                run_reid(handle, 0, handle->S, d_dets, d_det_rows, d_frames, image_rows, image_cols, tab);
+            }
+            embs = tab;
         }
         // cmc_method = "sof" / "ecc": the estimator runs inside the step here too, on the device-resident frames, for every stream
         // that was not given a warp with set_warp (the estimate comes back to the host: one synchronisation per step; callers that
@@ -1770,6 +1817,10 @@ int boxmot_hip_botsort_step_device(BoxMOTHipBotSort* handle, const float* d_dets
         }
         launch_step(handle, 0, handle->S, d_dets, d_det_rows, handle->cfg.with_reid ? embs : nullptr, nullptr, nullptr,
                     d_out, d_out_rows, any_warp);
+        if (piped) {        // pipeline stage 2 enqueued: the table is free for the ReID pass after next once this step has run
+            BM_HIP(hipEventRecord(handle->ev_embs_free[handle->pipe_slot], handle->stream));
+            handle->pipe_slot ^= 1;
+        }
         for (int s = 0; s < handle->S; ++s) { handle->h_warp_flag[s] = 0; handle->h_used[s] = -1; }      // slot counts: unknown to the host now
     });
 }
