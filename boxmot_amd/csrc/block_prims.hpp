@@ -106,10 +106,13 @@ __device__ inline int wave_min(int v) {
 
 // Lexicographic (value, index) minimum over the workgroup.  Threads without a
 // candidate pass idx < 0.  Result is uniform; idx < 0 when nobody had one.
-// (The value minimum over the candidates, then the lowest index holding it -- in the wave on the DPP path.  A candidate's value
-// is finite or +inf, never NaN: the callers compare with `<` before they offer it.)
+// (The value minimum over the candidates, then the lowest index holding it -- in the wave on the DPP path.  Threads without a
+// candidate take part with +infinity, so a candidate of ANY value up to and including +infinity is returned -- a wave whose only
+// candidates are +inf yields the lowest of their indices, as the shuffle version did (round-4 advisor finding: with DBL_MAX as the
+// filler an infinite candidate lost to the filler and came back as "none").  NaN is outside the contract (the minimum of a wave that
+// holds one is unspecified): the callers compare with `<` before they offer a value, which a NaN never passes.)
 __device__ inline void block_argmin(const Ctx& c, double v, int idx, double& out_v, int& out_i) {
-    constexpr double NONE_V = 1.7976931348623157e308;
+    const double NONE_V = __builtin_inf();
     constexpr int NONE_I = 0x7fffffff;
     const bool any = __ballot(idx >= 0) != 0ull;
     const double wv = wave_min(idx >= 0 ? v : NONE_V);

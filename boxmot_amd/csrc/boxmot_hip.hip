@@ -211,9 +211,15 @@ __global__ void build_crop_list_kernel(const float* dets, const int* n_dets, int
 // A backbone family that sizes its launches on the host (the wide OSNets, CLIP-ReID) and a caller that declared an upper bound on the
 // step's crops (set_crop_bound): the list is filled up to the bound with copies of its first entry -- the same crop computes the same
 // embedding and writes it to the same row -- so the launches are sized by the bound and the count never travels to the host.  A
-// count above the bound raises `flag` (reported by the next synchronize).
-__global__ void pad_crop_list_kernel(const int* crop_count, int bound, int* crop_stream, float* crop_boxes, int* crop_row, int* flag) {
+// count above the bound raises `flag` (reported by the next synchronize) and switches the frame off for the step.
+// `ndets_out` (the detection counts the frame step of this call reads) = the caller's counts, or -1 for EVERY stream when the count
+// exceeds the bound: the step kernels treat a negative count as "stream not stepped in this call", so a frame whose crops did not all
+// get an embedding changes no tracker state and returns no rows (round-4 advisor finding: it used to step with stale embeddings).
+__global__ void pad_crop_list_kernel(const int* crop_count, int bound, int* crop_stream, float* crop_boxes, int* crop_row, int* flag,
+                                     const int* ndets_in, int* ndets_out, int n_streams) {
     const int n = *crop_count;
+    if (blockIdx.x == 0)
+        for (int s = threadIdx.x; s < n_streams; s += blockDim.x) ndets_out[s] = n > bound ? -1 : ndets_in[s];
     if (n > bound) { if (threadIdx.x == 0 && blockIdx.x == 0) *flag = 1; return; }
     const int s0 = n > 0 ? crop_stream[0] : 0, r0 = n > 0 ? crop_row[0] : 0;
     float b0[4];
@@ -437,6 +443,8 @@ struct StreamIo : DeviceBound {
     int pipe_slot = 0;
     bool pipe = true;
     bool engine_on_main = false;        // the engine / crop list were last used on `stream` (host-update paths)
+    int* d_ndets_step[2] = {};          // [S] each: the detection counts a bounded step reads (-1 everywhere after a bound overflow)
+    const int* step_ndets = nullptr;    // what the frame step of the current step_device_frames call takes as n_dets
     ~StreamIo() {
         if (reid_stream) (void)hipStreamSynchronize(reid_stream);
         if (stream) (void)hipStreamSynchronize(stream);
@@ -1136,6 +1144,7 @@ void io_allocate(StreamIo* h, int S, int cap, int nd, int dim, bool with_reid) {
     h->frame_bufs.assign(s, nullptr);
     h->d_frames = zalloc<const uint8_t*>(s, o);
     h->d_crop_count = zalloc<int>(2, o);        // [0] the count, [1] the bound-overflow flag
+    h->d_ndets_step[0] = zalloc<int>(s, o); h->d_ndets_step[1] = zalloc<int>(s, o);
     if (with_reid && !h->reid_path.empty()) io_make_reid(h);
 }
 
@@ -1302,6 +1311,7 @@ float* io_device_reid(StreamIo* h, const float* d_dets, const int* d_ndets, cons
     const bool pipe = h->pipe && h->reid_stream;
     hipStream_t rs = pipe ? h->reid_stream : h->stream;
     float* embs = (pipe && h->pipe_slot) ? h->d_embs_alt : h->d_embs;
+    h->step_ndets = d_ndets;
     if (pipe) {
         if (h->engine_on_main) {            // a host-update path used the engine / the crop list on `stream` since: order after it
             BM_HIP(hipEventRecord(h->ev_main, h->stream));
@@ -1320,8 +1330,10 @@ float* io_device_reid(StreamIo* h, const float* d_dets, const int* d_ndets, cons
         // launches sized by the caller's bound: no read-back, no stream synchronisation inside the step (the host keeps queueing)
         const int n = h->crop_bound < h->S * h->nd ? h->crop_bound : h->S * h->nd;
         if (n > 0) {
+            int* nd_step = h->d_ndets_step[pipe ? h->pipe_slot : 0];        // (alternates with the embedding table: read by this call's step)
             hipLaunchKernelGGL(pad_crop_list_kernel, dim3((n + 255) / 256), dim3(256), 0, rs, (const int*)h->d_crop_count, n,
-                               h->d_crop_stream, h->d_crop_boxes, h->d_crop_row, h->d_crop_count + 1);
+                               h->d_crop_stream, h->d_crop_boxes, h->d_crop_row, h->d_crop_count + 1, d_ndets, nd_step, h->S);
+            h->step_ndets = nd_step;
             h->reid->run(d_frames, h->d_crop_stream, h->d_crop_boxes, 4, n, image_cols, image_rows, embs, h->d_crop_row, rs);
         }
     } else {
@@ -1366,6 +1378,7 @@ void io_read_back(StreamIo* h, int n, const int* d_status, const char* tracker, 
     BM_HIP(hipMemcpyAsync(h->h_out_n.data(), h->d_out_n + s0, n * 4, hipMemcpyDeviceToHost, h->stream));
     if (d_n_tracks) BM_HIP(hipMemcpyAsync(h->h_used.data() + s0, d_n_tracks + s0, n * 4, hipMemcpyDeviceToHost, h->stream));
     BM_HIP(hipStreamSynchronize(h->stream));
+    io_check_crop_bound(h);             // an earlier device-resident step whose crops exceeded the declared bound (that frame was not stepped)
     for (int k = 0; k < n; ++k) h->h_warp_flag[s0 + k] = 0;
     const std::string status_msg = take_status(h->stream, const_cast<int*>(d_status), s0, n, tracker);
     for (int k = 0; k < n; ++k) {
@@ -2499,7 +2512,7 @@ int boxmot_hip_deepocsort_step_device_frames(BoxMOTHipDeepOcSort* handle, const 
             embs = io_device_reid(handle, d_dets, d_det_rows, d_frames, image_rows, image_cols, (double)(float)handle->cfg.det_thresh, 0);
         docs_need_frame_size(handle, image_rows, image_cols);
         bm::DocsStepArgs a = handle->args;
-        a.dets = d_dets; a.n_dets = d_det_rows; a.embs = embs;
+        a.dets = d_dets; a.n_dets = embs ? handle->step_ndets : d_det_rows; a.embs = embs;
         const bool any_warp = io_consume_warps(handle);
         a.warp = any_warp ? handle->d_warp : nullptr; a.warp_flag = any_warp ? handle->d_warp_flag : nullptr;
         a.out = d_out; a.out_n = d_out_rows; a.stream_base = 0;
@@ -2690,7 +2703,7 @@ int boxmot_hip_strongsort_step_device_frames(BoxMOTHipStrongSort* handle, const 
         if (!d_dets || !d_det_rows || !d_out || !d_out_rows) throw std::runtime_error("boxmot_hip: null device pointers");
         const float* embs = io_device_reid(handle, d_dets, d_det_rows, d_frames, image_rows, image_cols, handle->cfg.min_conf, 1);    // strongsort.py:74-91
         bm::SsStepArgs a = handle->args;
-        a.dets = d_dets; a.n_dets = d_det_rows; a.embs = embs;
+        a.dets = d_dets; a.n_dets = handle->step_ndets; a.embs = embs;
         a.warp = io_consume_warps(handle) ? handle->d_warp : nullptr;
         a.out = d_out; a.out_n = d_out_rows; a.stream_base = 0;
         ss_launch(handle, a, handle->S);

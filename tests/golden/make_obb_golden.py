@@ -6,6 +6,14 @@ the rotated-intersection AREA behind cv2.rotatedRectangleIntersection / contourA
 
 -> tests/golden/obb_golden.npz.  tests/test_oracle_obb.py checks the oracles against it without /root/reference, tests/test_gpu_obb.py
 the oriented frame step on the device, tests/test_obb_host_emu.py the host classes over the emulated step.
+
+WHAT THESE ROWS PIN, AND WHAT THEY DO NOT (round-4 advisor finding): they are "reference control flow + stand-in rotated IoU".  The
+reference CLASSES run unmodified -- the Kalman filter with the angle state, measurement alignment, the association rounds, the
+bookkeeping, the output rows -- but the one number they take from OpenCV, the intersection area of two rotated rectangles, is answered
+by oracle/obb.py's fp64 polygon clipping (OpenCV is not installed).  cv2.rotatedRectangleIntersection works in fp32 and differs from
+that area at ~1e-6 relative; a pair whose IoU sits within that distance of match_thresh / iou_threshold could be assigned differently by
+the real library.  So the oriented fixtures are circular for that one quantity and must not be read as pinned on real OpenCV numerics;
+regenerating them on a machine with opencv-python (this script, unchanged, picks up the real cv2 when it imports) closes the gap.
 """
 from __future__ import annotations
 

@@ -140,6 +140,33 @@ int emu_update_list(void* h, const float* dets, int n, const float* embs, float*
     return e->args.st.status[0];
 }
 
+// block_argmin (block_prims.hpp) over NTHR emulated threads: thread t offers (v[t], idx[t]); idx < 0 = no candidate
+namespace {
+struct ArgminArg { const double* v; const int* idx; double* out_v; int* out_i; int tid; };
+void* argmin_main(void* p) {
+    ArgminArg* a = static_cast<ArgminArg*>(p);
+    threadIdx.x = a->tid; blockIdx.x = 0;
+    const bm::Ctx c = bm::make_ctx(g_s_int, g_s_dbl);
+    double ov; int oi;
+    bm::block_argmin(c, a->v[a->tid], a->idx[a->tid], ov, oi);
+    if (a->tid == 0) { *a->out_v = ov; *a->out_i = oi; }
+    return nullptr;
+}
+}  // namespace
+void emu_block_argmin(const double* v, const int* idx, double* out_v, int* out_i) {
+    static int s_int[bm::MAX_WAVES + 1];
+    static double s_dbl[bm::MAX_WAVES];
+    static EmuBlock block;
+    g_s_int = s_int; g_s_dbl = s_dbl; g_emu_block = &block;
+    blockDim.x = NTHR;
+    block.block_barrier.init(NTHR);
+    for (int w = 0; w < EMU_MAX_WAVES; ++w) block.wave_barrier[w].init(EMU_WAVE);
+    std::vector<ArgminArg> ta(NTHR);
+    for (int t = 0; t < NTHR; ++t) ta[t] = ArgminArg{v, idx, out_v, out_i, t};
+    emu_run_threads(NTHR, argmin_main, ta.data(), sizeof(ta[0]), 1 << 20);
+}
+int emu_nthr() { return NTHR; }
+
 // which: 0 active, 1 lost.  ints (rows,6), kf (rows,72), smooth (rows,dim), misc (rows,3)
 int emu_dump(void* h, int which, int* ints, double* kf, float* smooth, float* misc, int* counters) {
     Emu* e = static_cast<Emu*>(h);

@@ -435,7 +435,8 @@ def test_config3_reid_inside_update_full_size_vs_reference_rows(mode, weights, b
     d_out = torch.zeros((1024, 8), dtype=torch.float32, device=dev)
     d_out_n = torch.zeros(1, dtype=torch.int32, device=dev)
     try:
-        for t in range(n_frames):
+        last = n_frames - 1 if bound else n_frames          # (bound: the last golden frame is kept for the overflow check below)
+        for t in range(last):
             dets, _ = sc.frame(t, with_embs=False)
             d_dets[: len(dets)] = torch.from_numpy(dets).to(dev)
             d_n[0] = len(dets)
@@ -447,11 +448,24 @@ def test_config3_reid_inside_update_full_size_vs_reference_rows(mode, weights, b
             _lib.check(lib.boxmot_hip_deepocsort_synchronize(h))
             got = d_out[: int(d_out_n[0])].cpu().numpy()
             assert_rows_match(got, want[t], t, box_atol=5e-3)
-        if bound:           # a step with more crops than the declared bound is reported by the next synchronize
+        if bound:           # a step with more crops than the declared bound is reported by the next synchronize ...
+            dets, _ = sc.frame(last, with_embs=False)
+            d_dets.zero_()
+            d_dets[: len(dets)] = torch.from_numpy(dets).to(dev)
+            d_n[0] = len(dets)
+            torch.cuda.synchronize()
             _lib.check(lib.boxmot_hip_deepocsort_set_crop_bound(h, 4))
             _lib.check(lib.boxmot_hip_deepocsort_step_device_frames(h, d_dets.data_ptr(), d_n.data_ptr(), ptrs.data_ptr(), 1080, 1920,
                                                                     d_out.data_ptr(), d_out_n.data_ptr()))
             assert lib.boxmot_hip_deepocsort_synchronize(h) == 0 and "more ReID crops than the bound" in _lib.last_error()
+            # ... and that frame was switched off for the step (no rows, no state change on stale embeddings: round-4 advisor finding):
+            # the same frame stepped again with a sufficient bound returns the reference's rows for it
+            assert int(d_out_n[0]) == 0
+            _lib.check(lib.boxmot_hip_deepocsort_set_crop_bound(h, len(dets)))
+            _lib.check(lib.boxmot_hip_deepocsort_step_device_frames(h, d_dets.data_ptr(), d_n.data_ptr(), ptrs.data_ptr(), 1080, 1920,
+                                                                    d_out.data_ptr(), d_out_n.data_ptr()))
+            _lib.check(lib.boxmot_hip_deepocsort_synchronize(h))
+            assert_rows_match(d_out[: int(d_out_n[0])].cpu().numpy(), want[last], last, box_atol=5e-3)
     finally:
         lib.boxmot_hip_deepocsort_destroy(h)
 

@@ -95,3 +95,41 @@ def test_emulated_kernel_clean_under_asan():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert "ASAN-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("threads", [64, 256])
+def test_block_argmin_returns_infinite_candidates_and_breaks_ties_by_index(threads):
+    """block_prims.hpp: the workgroup (value, index) minimum on the DPP path.  Round-4 advisor finding: with DBL_MAX as the filler of
+    threads without a candidate, a candidate whose value is +inf lost to the filler and came back as "none" (the shuffle version had
+    returned it; only lap_solve's `best >= 1e300` guard hid that).  The filler is +inf now: any candidate up to +inf is returned,
+    ties go to the lowest index, no candidate at all gives -1.  (NaN stays outside the contract: the callers compare with `<` before
+    they offer a value.)"""
+    import ctypes
+
+    import emu_util
+    lib = ctypes.CDLL(str(emu_util.build(threads=threads)))
+    lib.emu_block_argmin.argtypes = [ctypes.c_void_p] * 4
+    assert lib.emu_nthr() == threads
+
+    def argmin(v, idx):
+        v, idx = np.ascontiguousarray(v, np.float64), np.ascontiguousarray(idx, np.int32)
+        ov, oi = ctypes.c_double(0), ctypes.c_int(0)
+        lib.emu_block_argmin(v.ctypes.data, idx.ctypes.data, ctypes.byref(ov), ctypes.byref(oi))
+        return ov.value, oi.value
+    rng = np.random.default_rng(0)
+    none = np.full(threads, -1, np.int32)
+    assert argmin(np.zeros(threads), none)[1] == -1
+    for _ in range(20):
+        v = rng.uniform(0, 10, threads).round(1)               # many exact ties
+        idx = np.where(rng.uniform(size=threads) < 0.4, rng.permutation(threads) + 5, -1).astype(np.int32)
+        if (idx >= 0).any():
+            cand = [(v[t], idx[t]) for t in range(threads) if idx[t] >= 0]
+            assert argmin(v, idx) == (float(min(cand)[0]), int(min(cand)[1]))
+    # the only candidates are +inf (one per wave and several in one wave): the lowest index among them, value +inf
+    v, idx = np.full(threads, 3.0), none.copy()
+    for t, i in ((5, 40), (threads - 3, 7), (9, 12)):
+        v[t], idx[t] = np.inf, i
+    assert argmin(v, idx) == (np.inf, 7)
+    # a finite candidate beats infinite ones; values at and above DBL_MAX are ordinary candidates
+    v[20], idx[20] = 1.7976931348623157e308, 99
+    assert argmin(v, idx) == (1.7976931348623157e308, 99)
