@@ -54,7 +54,7 @@ FLOP_PER_CROP = 2 * 82_314_880          # OSNet x0.25 forward, BASELINE.md secti
 # here (separate --pmc passes, gfx950 FETCH correction applied by profiles/summarize_pmc.py) -- counters cannot be collected
 # inside a timed run, so the line carries the profile's figure and says which file it came from
 # one committed profile per kernel family (mode): fused fp32-grade (2), fused fp16 (1)
-TRAFFIC_PROFILES = {2: ("profiles/r4_pmc_traffic_final.txt", "profiles/r3_pmc_traffic_final.txt", "profiles/r3_pmc_traffic_hp.txt"),
+TRAFFIC_PROFILES = {2: ("profiles/r5_pmc_traffic_final.txt", "profiles/r4_pmc_traffic_final.txt", "profiles/r3_pmc_traffic_final.txt", "profiles/r3_pmc_traffic_hp.txt"),
                     1: ("profiles/r4_pmc_traffic_m1.txt", "profiles/r3_pmc_traffic.txt", "profiles/r2_pmc_traffic.txt", "profiles/r1h_pmc_traffic.txt")}
 
 

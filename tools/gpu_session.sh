@@ -29,6 +29,9 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG; mkdir -p $O
 MODE=${REID_MODE:-2}
 db() { find $O/$1 -name "*.db" | head -1; }
+# first line of every profile summary: the source hash of the library it was taken with (bench.py reports a profile's figure only while
+# that hash equals the shipped library's; a reader can tell a stale summary from a current one)
+stamp() { python -c "import json; print('# source_hash: ' + json.load(open('boxmot_amd/libboxmot_hip.so.buildinfo'))['source_hash'] + '   (boxmot_amd/libboxmot_hip.so.buildinfo of the library this profile was taken with)')"; }
 cd $R
 for step in "$@"; do
   echo "=== $step"
@@ -39,14 +42,16 @@ for step in "$@"; do
     bench)   timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 1500 $O/bench.json; echo ;;
     benchq)  timeout 400 python bench.py --no-cpu-baseline --no-side-configs --no-m1 --reid-mode $MODE > $O/benchq_m$MODE.json 2> $O/benchq.err; tail -c 900 $O/benchq_m$MODE.json; echo ;;
     trace)   (cd /tmp && export TMPDIR=/tmp && timeout 500 rocprofv3 --kernel-trace --stats -d $O/kt -o bench -- python $R/bench.py --no-cpu-baseline --no-side-configs --no-m1 --reid-mode $MODE > $O/bench_kt.json 2> $O/bench_kt.err)
-             python profiles/summarize_rocpd.py $(db kt) > $O/kernel_stats_m$MODE.txt 2>&1; rm -rf $O/kt; head -n 16 $O/kernel_stats_m$MODE.txt | cut -c1-170 ;;
+             stamp > $O/kernel_stats_m$MODE.txt
+             python profiles/summarize_rocpd.py $(db kt) >> $O/kernel_stats_m$MODE.txt 2>&1; rm -rf $O/kt; head -n 17 $O/kernel_stats_m$MODE.txt | cut -c1-170 ;;
     traffic) (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o p -- python $R/tools/reid_microbench.py 4096 $MODE 2 > $O/fetch.log 2>&1
               timeout 300 rocprofv3 --pmc WRITE_SIZE -d $O/write -o p -- python $R/tools/reid_microbench.py 4096 $MODE 2 > $O/write.log 2>&1)
              # (the library's source hash goes on the first line: bench.py reports this file's figure only while the hashes agree)
-             python -c "import json; print('# source_hash: ' + json.load(open('boxmot_amd/libboxmot_hip.so.buildinfo'))['source_hash'] + '   (boxmot_amd/libboxmot_hip.so.buildinfo of the library these counters were taken with)')" > $O/pmc_traffic_m$MODE.txt
+             stamp > $O/pmc_traffic_m$MODE.txt
              python profiles/summarize_pmc.py $(db fetch) $(db write) 4096 >> $O/pmc_traffic_m$MODE.txt 2>&1; rm -rf $O/fetch $O/write; tail -n 14 $O/pmc_traffic_m$MODE.txt ;;
     mfma)    (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $O/mfma -o p -- python $R/tools/reid_microbench.py 4096 $MODE 2 > $O/mfma.log 2>&1)
-             python profiles/summarize_mfma.py $(db mfma) > $O/mfma_busy_m$MODE.txt 2>&1; rm -rf $O/mfma; cat $O/mfma_busy_m$MODE.txt ;;
+             stamp > $O/mfma_busy_m$MODE.txt
+             python profiles/summarize_mfma.py $(db mfma) >> $O/mfma_busy_m$MODE.txt 2>&1; rm -rf $O/mfma; cat $O/mfma_busy_m$MODE.txt ;;
     c3)      timeout 600 python tools/config_bench.py --config c3 --reid-mode ${C3_MODE:-2} >> $O/config_bench.jsonl 2> $O/c3.err; tail -n 1 $O/config_bench.jsonl | cut -c1-900 ;;
     c5)      timeout 900 python tools/config_bench.py --config c5 >> $O/config_bench.jsonl 2> $O/c5.err; tail -n 1 $O/config_bench.jsonl | cut -c1-900 ;;
     soak)    timeout 900 python tools/parity_soak.py 10 200 > $O/soak.log 2>&1; tail -n 12 $O/soak.log ;;
