@@ -652,8 +652,14 @@ void build(BoxMOTHipBotSort* h) {
     h->S = c.n_streams; h->cap = c.max_tracks; h->nd = c.max_dets; h->dim = c.emb_dim; h->n_lists = c.n_class_lists;
     BM_HIP(hipStreamCreate(&h->stream));
     {
+        // The frame step of this tracker is one 512-thread workgroup per stream at 256 registers: it owns a whole CU.  With fewer
+        // streams than CUs the rest of the device is free for the next frame's ReID pass (the pipeline pays, as in configurations 3 / 5);
+        // with a stream per CU (the headline's 256) nothing can run beside it -- measured flat, 12.04 vs 12.11 k frames/s,
+        // profiles/r5_pipeline_ab.txt -- so the pipeline is on by default only below half the device (BOXMOT_HIP_PIPELINE=1 / 0 forces it).
         const char* v = std::getenv("BOXMOT_HIP_PIPELINE");
-        h->pipe = !(v && v[0] == '0');
+        int cus = 0, dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+        h->pipe = (v && v[0]) ? v[0] != '0' : 2 * c.n_streams <= cus;
         if (h->pipe && !h->reid_stream) {
             BM_HIP(hipStreamCreate(&h->reid_stream));
             for (int k = 0; k < 2; ++k) {
