@@ -378,6 +378,7 @@ struct BoxMOTHipBotSort : DeviceBound {
     int pipe_slot = 0;
     bool pipe = true;
     bool engine_on_main = false;
+    bool stream_exposed = false;        // boxmot_hip_botsort_stream() was handed out (see StreamIo)
 
     ~BoxMOTHipBotSort() {
         if (reid_stream) (void)hipStreamSynchronize(reid_stream);
@@ -443,6 +444,7 @@ struct StreamIo : DeviceBound {
     int pipe_slot = 0;
     bool pipe = true;
     bool engine_on_main = false;        // the engine / crop list were last used on `stream` (host-update paths)
+    bool stream_exposed = false;        // *_stream() was handed out: the caller may order its inputs on `stream` -- every ReID pass waits for it
     int* d_ndets_step[2] = {};          // [S] each: the detection counts a bounded step reads (-1 everywhere after a bound overflow)
     const int* step_ndets = nullptr;    // what the frame step of the current step_device_frames call takes as n_dets
     ~StreamIo() {
@@ -1319,7 +1321,10 @@ float* io_device_reid(StreamIo* h, const float* d_dets, const int* d_ndets, cons
     float* embs = (pipe && h->pipe_slot) ? h->d_embs_alt : h->d_embs;
     h->step_ndets = d_ndets;
     if (pipe) {
-        if (h->engine_on_main) {            // a host-update path used the engine / the crop list on `stream` since: order after it
+        // a host-update path used the engine / the crop list on `stream` since, or the caller holds `stream` (it may have queued the
+        // producers of this step's detections / frames there, e.g. boxmot_hip_ingest_wait): the ReID pass is ordered after `stream` --
+        // correct always; such a caller gives up the overlap, its own stream order already serialises the frames
+        if (h->engine_on_main || h->stream_exposed) {
             BM_HIP(hipEventRecord(h->ev_main, h->stream));
             BM_HIP(hipStreamWaitEvent(rs, h->ev_main, 0));
             h->engine_on_main = false;
@@ -1780,7 +1785,7 @@ int boxmot_hip_botsort_step_device(BoxMOTHipBotSort* handle, const float* d_dets
             float* tab = (pipe && handle->pipe_slot) ? handle->d_embs_alt : handle->d_embs;
             if (pipe) {
                 hipStream_t rs = handle->reid_stream;
-                if (handle->engine_on_main) {       // a host-update path used the engine / the crop list on `stream` since: order after it
+                if (handle->engine_on_main || handle->stream_exposed) {       // (as io_device_reid: engine used on `stream`, or the caller holds `stream`)
                     BM_HIP(hipEventRecord(handle->ev_main, handle->stream));
                     BM_HIP(hipStreamWaitEvent(rs, handle->ev_main, 0));
                     handle->engine_on_main = false;
@@ -1898,7 +1903,7 @@ int boxmot_hip_botsort_phase_clocks(BoxMOTHipBotSort* handle, long long* out16) 
     });
 }
 
-void* boxmot_hip_botsort_stream(BoxMOTHipBotSort* handle) { return handle ? (void*)handle->stream : nullptr; }
+void* boxmot_hip_botsort_stream(BoxMOTHipBotSort* handle) { if (handle) handle->stream_exposed = true; return handle ? (void*)handle->stream : nullptr; }
 
 int boxmot_hip_botsort_status(BoxMOTHipBotSort* handle, int* out_status, int capacity) {
     return guard_on(handle, [&]() {
@@ -2545,7 +2550,7 @@ int boxmot_hip_deepocsort_reid_kernel_ms(BoxMOTHipDeepOcSort* handle, double* ou
     });
 }
 
-void* boxmot_hip_deepocsort_stream(BoxMOTHipDeepOcSort* handle) { return handle ? (void*)handle->stream : nullptr; }
+void* boxmot_hip_deepocsort_stream(BoxMOTHipDeepOcSort* handle) { if (handle) handle->stream_exposed = true; return handle ? (void*)handle->stream : nullptr; }
 
 int boxmot_hip_deepocsort_synchronize(BoxMOTHipDeepOcSort* handle) {
     return guard_on(handle, [&]() {
@@ -2745,7 +2750,7 @@ int boxmot_hip_strongsort_track_count(BoxMOTHipStrongSort* handle, int stream, i
     });
 }
 
-void* boxmot_hip_strongsort_stream(BoxMOTHipStrongSort* handle) { return handle ? (void*)handle->stream : nullptr; }
+void* boxmot_hip_strongsort_stream(BoxMOTHipStrongSort* handle) { if (handle) handle->stream_exposed = true; return handle ? (void*)handle->stream : nullptr; }
 
 int boxmot_hip_strongsort_synchronize(BoxMOTHipStrongSort* handle) {
     return guard_on(handle, [&]() {

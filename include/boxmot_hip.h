@@ -400,11 +400,18 @@ int boxmot_hip_deepocsort_set_reid_mode(BoxMOTHipDeepOcSort* handle, int mode);
 void* boxmot_hip_deepocsort_stream(BoxMOTHipDeepOcSort* handle);
 /* waits for the handle's stream; throws if a step exceeded the bound below */
 int boxmot_hip_deepocsort_synchronize(BoxMOTHipDeepOcSort* handle);
+/* Pipelining of device-resident steps (all three trackers; BoT-SORT: when its streams occupy at most half of the device's CUs):
+ * consecutive *_step_device / *_step_device_frames calls are asynchronous, and the ReID pass of call t + 1 runs on a second stream
+ * of the handle while the frame step of call t is still on *_stream().  Rows of call t are complete after *_synchronize (or after
+ * *_stream()'s work).  The inputs of a call (detections, counts, frames) must be complete when it is made -- or be ordered on
+ * *_stream(): once that accessor has been called, every ReID pass waits for the work queued there (correct, but such a caller's
+ * frames serialise).  BOXMOT_HIP_PIPELINE=0 / 1 (read at create) forces the pipeline off / on. */
 /* Host-known upper bound on the ReID crops of the following step_device_frames calls (all streams together; -1 = none, the
  * default; a host call, cheap enough to repeat before every step with that step's detection total).  The backbone families that size their launches on the host (osnet_x0_5 ... x1_0, CLIP-ReID) otherwise read the
  * crop count back -- a stream synchronisation inside every step, during which the GPU waits for the host to queue the pass.
  * With a bound the crop list is filled up to it with copies of its first entry and nothing travels to the host; a step with
- * more crops than the bound is reported by the next synchronize.  (OSNet-x0.25's fused kernels take the count on the device.) */
+ * more crops than the bound is NOT stepped (no rows, tracker state untouched: it would have consumed stale embeddings) and is reported
+ * by the next synchronize / host update -- step it again with a sufficient bound.  (OSNet-x0.25's fused kernels take the count on the device.) */
 int boxmot_hip_deepocsort_set_crop_bound(BoxMOTHipDeepOcSort* handle, int max_total_crops);
 /* parity debugging: live tracks of `stream` in list order -- ints5 (rows,5) = id, age, time_since_update, hit_streak,
  * observed; kf72 (rows,72) = x[8] ++ P[8][8] fp64 (index 7 unused); emb (rows, emb_dim) fp64.  NULL skips an output. */
