@@ -1340,13 +1340,12 @@ float* io_device_reid(StreamIo* h, const float* d_dets, const int* d_ndets, cons
     } else if (h->crop_bound >= 0) {
         // launches sized by the caller's bound: no read-back, no stream synchronisation inside the step (the host keeps queueing)
         const int n = h->crop_bound < h->S * h->nd ? h->crop_bound : h->S * h->nd;
-        if (n > 0) {
-            int* nd_step = h->d_ndets_step[pipe ? h->pipe_slot : 0];        // (alternates with the embedding table: read by this call's step)
-            hipLaunchKernelGGL(pad_crop_list_kernel, dim3((n + 255) / 256), dim3(256), 0, rs, (const int*)h->d_crop_count, n,
-                               h->d_crop_stream, h->d_crop_boxes, h->d_crop_row, h->d_crop_count + 1, d_ndets, nd_step, h->S);
-            h->step_ndets = nd_step;
-            h->reid->run(d_frames, h->d_crop_stream, h->d_crop_boxes, 4, n, image_cols, image_rows, embs, h->d_crop_row, rs);
-        }
+        int* nd_step = h->d_ndets_step[pipe ? h->pipe_slot : 0];        // (alternates with the embedding table: read by this call's step)
+        // (a bound of 0 -- "no crops in this step" -- is checked like any other: one workgroup compares the count with it)
+        hipLaunchKernelGGL(pad_crop_list_kernel, dim3(n > 0 ? (n + 255) / 256 : 1), dim3(256), 0, rs, (const int*)h->d_crop_count, n,
+                           h->d_crop_stream, h->d_crop_boxes, h->d_crop_row, h->d_crop_count + 1, d_ndets, nd_step, h->S);
+        h->step_ndets = nd_step;
+        if (n > 0) h->reid->run(d_frames, h->d_crop_stream, h->d_crop_boxes, 4, n, image_cols, image_rows, embs, h->d_crop_row, rs);
     } else {
         int n_crops = 0;
         BM_HIP(hipMemcpyAsync(&n_crops, h->d_crop_count, 4, hipMemcpyDeviceToHost, rs));
