@@ -15,7 +15,10 @@ group's tracker step (one workgroup per stream: latency-bound, few CUs) overlaps
 kernels (+4 % at G = 2); the default keeps one group so that the HIP-event launch durations behind
 `roofline` are those of kernels running alone and agree with the rocprofv3 per-kernel averages.
 
-Extra objects on the JSON line (N = 1): `roofline`, `cpu_baseline` (the contract), `tracker_math_m1` (embeddings supplied), and
+Extra objects on the JSON line (N = 1): `roofline`, `cpu_baseline` (the contract: kind = "reference" when the reference's own classes
+can be imported -- /root/reference in the build container, the byte-compiled oracle/_ref/ (oracle/make_ref.py) on the GPU box -- else
+"port" = the oracle; the other one is attached beside it), `cpu_side_baselines` (the reference's tracker math with supplied embeddings
+and the reference ByteTrack on BASELINE configuration 1, bounded samples), `tracker_math_m1` (embeddings supplied), and
 `other_configs` -- short side measurements of BASELINE.json's configurations 3 (DeepOCSORT + OSNet_x1_0, 128 x 512) and 5 (StrongSORT +
 CLIP-ReID ViT-B/16, 256 x 1024, 4K) through tools/config_bench.py, each with its ReID roofline fraction and an embedding parity gate;
 they are never part of `value`.
@@ -27,8 +30,9 @@ command on 127.0.0.1 with a free port) and relays rank 0's JSON line.  Streams a
 streams r*S .. r*S+S-1, S = --streams per GPU: weak scaling) with no data-path collective; the timed region is bracketed by a
 barrier + device synchronisation on both sides and the elapsed time is the MAX over ranks (all_reduce); the per-frame result
 rows are gathered to rank 0 once after the timed loop (`gather_results`: RCCL all_gather of a few hundred KB), timed and
-reported separately as `gather_ms`.  Rank 0 keeps the stream-0 id parity gate at every N; the CPU timing baseline runs at N = 1
-only (the contract).
+reported separately as `gather_ms`.  Rank 0 keeps the id parity gate at every N -- ids of streams 0, S / 2 and S - 1 of its shard
+against the oracle (the first, a middle and the last workgroup / crop range of the timed launch) -- ; the CPU timing baseline runs at
+N = 1 only (the contract).
 
 `--stub-tracker --backend gloo` is a TEST seam (tests/test_bench_dist.py): the same launch / sharding / barrier / all_reduce /
 gather / JSON code runs on CPU processes with a trivial stand-in for the device handle, so the N > 1 control flow is covered
