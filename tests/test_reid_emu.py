@@ -270,3 +270,25 @@ def test_missing_wait_for_an_asynchronous_lds_copy_is_caught_by_the_emulation():
     want = want / np.linalg.norm(want, axis=1, keepdims=True)
     err = np.abs(feats - want).max()
     assert not (err < 1e-3), f"the emulation did not notice the missing waits (max|diff| {err})"
+
+
+@pytest.mark.skipif(CLANG is None, reason="needs a host clang with _Float16")
+def test_barrier_free_layer_loop_and_depthwise_prefetch_are_bit_identical_emulated(tmp_path):
+    """The two structural switches of reid_hp.hpp measured in round 5 (profiles/r5_hp_s0_ab.txt; default off): BM_HP_NBR_SYNC -- the
+    LightConv layer loop of stages 0 / 1 synchronised by neighbour flags in LDS instead of two workgroup barriers per layer -- and
+    BM_HP_DW_PREFETCH -- the depthwise pass's LDS reads issued a row ahead.  On CPU threads both together return the default build's
+    embeddings and stored stages BIT FOR BIT; with the flag waits compiled out (EMU_NO_FLAG_WAIT: the negative control) the same
+    kernels read rows their neighbours have not written and come out wrong -- the emulation does check the protocol."""
+    import sys
+    sys.path.insert(0, str(HERE.parent.parent / "tools"))
+    import hp_variant_check as hv
+    from boxmot_amd.reid_weights import pack_osnet, random_osnet_state_dict
+    blob = pack_osnet(random_osnet_state_dict("osnet_x0_25", seed=0))
+    img = np.random.default_rng(5).integers(0, 255, (480, 641, 3), dtype=np.uint8)
+    boxes = np.array([[30.2, 40.7, 90.1, 200.3], [-12.0, 300.0, 120.5, 500.0]], dtype=np.float32)
+    base = hv.forward(hv.build([], tmp_path / "base.so"), blob, img, boxes)
+    both = hv.forward(hv.build(["-DBM_HP_NBR_SYNC=1", "-DBM_HP_DW_PREFETCH=1"], tmp_path / "both.so"), blob, img, boxes)
+    assert np.array_equal(base[0], both[0]) and all(np.array_equal(a, b) for a, b in zip(base[1], both[1]))
+    assert np.allclose(np.linalg.norm(both[0], axis=1), 1.0, atol=1e-5)
+    broken = hv.forward(hv.build(["-DBM_HP_NBR_SYNC=1", "-DEMU_NO_FLAG_WAIT=1"], tmp_path / "nowait.so"), blob, img, boxes)
+    assert not np.array_equal(base[0], broken[0])
