@@ -123,7 +123,30 @@ struct GeoHP {
     static_assert(LDS_BYTES <= 163840 / (STAGE == 2 ? 2 : 1), "LDS budget");
 };
 
-__device__ inline f4 fma_f4(f4 a, f4 b, f4 c) { return __builtin_elementwise_fma(a, b, c); }
+// fp32 multiply-adds / adds of four channels: packed (v_pk_fma_f32 / v_pk_add_f32: half the instructions) or four scalar
+// instructions (BM_HP_SCALAR_F32 = 1: packed f32 VALU operations are priced well above two scalar ones beside MFMAs on this part,
+// kernel_macros.hpp BM_FMA_F32; identical results; A/B switch, profiles/r5_hp_scalar_f32_ab.txt)
+#ifndef BM_HP_SCALAR_F32
+#define BM_HP_SCALAR_F32 0
+#endif
+__device__ inline f4 fma_f4(f4 a, f4 b, f4 c) {
+#if BM_HP_SCALAR_F32
+    f4 r;
+    BM_FMA_F32(a[0], b[0], c[0], r[0]); BM_FMA_F32(a[1], b[1], c[1], r[1]); BM_FMA_F32(a[2], b[2], c[2], r[2]); BM_FMA_F32(a[3], b[3], c[3], r[3]);
+    return r;
+#else
+    return __builtin_elementwise_fma(a, b, c);
+#endif
+}
+__device__ inline f4 add_f4(f4 a, f4 b) {
+#if BM_HP_SCALAR_F32
+    f4 r;
+    BM_ADD_F32(a[0], b[0], r[0]); BM_ADD_F32(a[1], b[1], r[1]); BM_ADD_F32(a[2], b[2], r[2]); BM_ADD_F32(a[3], b[3], r[3]);
+    return r;
+#else
+    return a + b;
+#endif
+}
 // (hi, lo) fp16 parts of four fp32 values: v = hi + lo up to 2^-22 relative
 #ifndef BM_HP_SPLIT_MIX
 #define BM_HP_SPLIT_MIX 1           // residuals by v_fma_mix_f32 (8 instructions per split4 instead of 12-13); 0: convert + subtract
@@ -579,7 +602,7 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
             for (int ct = 0; ct < KT; ++ct) {
                 f4 s = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int i = 0; i < NT; ++i) s += cur[i][ct];
+                for (int i = 0; i < NT; ++i) s = add_f4(s, cur[i][ct]);
 #pragma unroll
                 for (int h = 0; h < G::HID; ++h) {
                     const f4 w1 = *reinterpret_cast<const f4*>(wgate + 4 * (h * MIDP + 16 * ct + 4 * g));
@@ -760,7 +783,7 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
 #pragma unroll
                         for (int ks = 0; ks < KINP; ++ks) ap = mm3r(pdh[ks], pdl[ks], o.rxh[ks], o.rxl[ks], ap);
                     }
-                    acc += relu4(ap);
+                    acc = add_f4(acc, relu4(ap));
                 } else {
                     acc = BM_MFMA_F16_K32(eye, cat8(o.idh[co], o.idl[co]), acc);
                 }
@@ -850,8 +873,15 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
                     f4 sp;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
+#if BM_HP_SCALAR_F32
+                        float v, w;
+                        BM_ADD_F32(a0[r], a1[r], v);
+                        BM_ADD_F32(v, BM_QUAD_SWAP1_F32(v), w);
+                        sp[r] = w;
+#else
                         const float v = a0[r] + a1[r];
                         sp[r] = v + BM_QUAD_SWAP1_F32(v);
+#endif
                     }
                     // a lane's channel tiles are adjacent in the lane-group-major layout: tiles (ct - 1, ct) leave as ONE 16-byte
                     // store per plane (8-byte pieces at a 32-byte stride fill a sector in four partial writes)

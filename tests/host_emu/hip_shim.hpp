@@ -290,6 +290,8 @@ inline bool emu_lds_flag_wait(const volatile int* p, int v) {
 #else
 #define BM_LDS_FLAG_WAIT(ptr, val) emu_lds_flag_wait((const volatile int*)(ptr), (val))
 #endif
+#define BM_FMA_F32(a, b, c, out) ((out) = __builtin_fmaf((a), (b), (c)))
+#define BM_ADD_F32(a, b, out) ((out) = (a) + (b))
 #define BM_SCHED_FENCE() ((void)0)
 #define BM_SETPRIO(n) ((void)0)
 #define BM_RESID_F16(hp, hi, v, out) do { unsigned short b_ = (unsigned short)((hp) >> (16 * (hi))); _Float16 h_; std::memcpy(&h_, &b_, 2); (out) = (v) - (float)h_; } while (0)
