@@ -70,6 +70,9 @@
 #ifndef BM_HP_NBR_SYNC
 #define BM_HP_NBR_SYNC 0
 #endif
+#ifndef BM_HP_DW_STATIC_MORE
+#define BM_HP_DW_STATIC_MORE 0
+#endif
 // depthwise 3x3: reads of the next input row issued right after the last use of the current one (1) or at the top of its own
 // iteration (0: the compiler schedules them a few instructions before their first use); A/B switch, profiles/r5_hp_s0_ab.txt
 #ifndef BM_HP_DW_PREFETCH
@@ -85,6 +88,8 @@
 #define BM_NT_STORE(ptr, val) (*(ptr) = (val))
 #define BM_NT_LOAD(ptr) (*(ptr))
 #endif
+
+#include <type_traits>
 
 namespace bm {
 
@@ -488,6 +493,13 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
                 __syncthreads();
                 BM_PROF(3);
             }
+            // (the pass is a generic lambda so that "another layer follows" can be a compile-time fact: BM_HP_DW_STATIC_MORE = 1 instantiates
+            // it twice -- with the runtime flag every output row ends in a branch around the fused 1x1, i.e. in a basic-block boundary the
+            // instruction scheduler cannot move work across; without the branch a whole strip is one block and row r's split / MFMAs can
+            // be interleaved with row r + 1's taps.  A/B switch, profiles/r5_hp_static_more_ab.txt)
+            auto dw_pass = [&](auto more_c) {
+                bool do_pw;
+                if constexpr (std::is_same_v<decltype(more_c), bool>) do_pw = more_c; else do_pw = decltype(more_c)::value;
             // depthwise 3x3 (pad 1) + bias + ReLU
 #pragma unroll
             for (int ct = 0; ct < KT; ++ct) {
@@ -539,7 +551,7 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
                             if (rr >= 2) {
                                 const int i = STAGE == 0 ? 2 * (rr - 2) + sq : rr - 2;
                                 cur[i][ct] = relu4(done);
-                                if constexpr (KT == 1) { if (more) pointwise(An, cur[i]); }
+                                if constexpr (KT == 1) { if (do_pw) pointwise(An, cur[i]); }
                             }
                         }
                     }
@@ -557,7 +569,7 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
                                 a = fma_f4(wd[6], v0, a); a = fma_f4(wd[7], v1, a); a = fma_f4(wd[8], v2, a);
                                 const int i = STAGE == 0 ? 2 * (rr - 2) + sq : rr - 2;
                                 cur[i][ct] = relu4(a);
-                                if constexpr (KT == 1) { if (more) pointwise(An, cur[i]); }     // next layer's 1x1 under the next rows' taps
+                                if constexpr (KT == 1) { if (do_pw) pointwise(An, cur[i]); }     // next layer's 1x1 under the next rows' taps
                             }
                             if (rr >= 1 && rr <= L) {
                                 f4 a = acc[(rr - 1) % 3];
@@ -574,6 +586,12 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
 #endif
                 }
             }
+            };
+#if BM_HP_DW_STATIC_MORE
+            if (more) dw_pass(std::true_type{}); else dw_pass(std::false_type{});
+#else
+            dw_pass(more);
+#endif
             if constexpr (KT == 2) {
                 if (more) {
 #pragma unroll
