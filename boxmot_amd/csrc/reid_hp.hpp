@@ -70,6 +70,9 @@
 #ifndef BM_HP_NBR_SYNC
 #define BM_HP_NBR_SYNC 0
 #endif
+#ifndef BM_HP_S0_RECOMP
+#define BM_HP_S0_RECOMP 1
+#endif
 #ifndef BM_HP_DW_STATIC_MORE
 #define BM_HP_DW_STATIC_MORE 0
 #endif
@@ -229,7 +232,12 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
     constexpr int KT = G::KT, NT = G::NT, MIDP = G::MIDP, NCT = G::NCT, COUT = G::COUT, P = G::P;
     constexpr int KIN = CIN == 16 ? 1 : CIN / 32;
     constexpr int PREV_CIN = STAGE == 0 ? 16 : 64, KINP = PREV_CIN == 16 ? 1 : PREV_CIN / 32;
-    constexpr bool RECOMP = STAGE == 0 && CIN == 16;              // conv1 per branch: two 8-byte loads + two MFMAs per tile
+    // first block of stage 0: conv1 recomputed per branch from the (hi, lo) input planes (two 8-byte loads + two MFMAs per tile), or --
+    // BM_HP_S0_RECOMP = 0 -- computed once, parked in the fp32 hand-over scratch (which this block only overwrites in its epilogue, when
+    // the branches are done) and read back per branch with ONE 16-byte load per tile: half the vector-memory instructions of a branch
+    // start (phase clocks, profiles/r5_hp_phases.txt: the branch-input phase is 33 % of this kernel and 2.7 x the second block's, which
+    // moves the same bytes with 16-byte loads).  A/B switch.
+    constexpr bool RECOMP = STAGE == 0 && CIN == 16 && BM_HP_S0_RECOMP;
     constexpr bool X1_MEM = (STAGE == 0 && !RECOMP) || RECON;     // conv1 result in the fp32 scratch `x1s` (L2), read per branch
     constexpr bool X1_REG = !RECOMP && !X1_MEM;
     BM_DYNAMIC_LDS_T(unsigned char, lds);
