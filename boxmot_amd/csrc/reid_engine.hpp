@@ -32,6 +32,11 @@
 #define BM_HEAD_PER_CROP 0          // 1: the round-1 head (one workgroup of two waves per crop) instead of k_head_batched
 #endif
 
+// default of BOXMOT_HIP_REID_PERSIST (the fp32-grade x0.25 block kernels as persistent workgroups; A/B: profiles/r5_hp_persist_ab.txt)
+#ifndef BM_HP_PERSIST_DEFAULT
+#define BM_HP_PERSIST_DEFAULT 0
+#endif
+
 namespace bm {
 
 inline void hip_check(hipError_t e, const char* what) {
@@ -507,6 +512,12 @@ private:
         allow_lds(k_osblock_hp<1, 96, false, true>, GeoHP<1>::LDS_BYTES);
         allow_lds(k_osblock_hp<2, 96, true, false>, GeoHP<2>::LDS_BYTES);
         allow_lds(k_osblock_hp<2, 128, false, false>, GeoHP<2>::LDS_BYTES);
+        {
+            const char* v = std::getenv("BOXMOT_HIP_REID_PERSIST");
+            hp_persist_ = v && v[0] ? std::atoi(v) : BM_HP_PERSIST_DEFAULT;
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&hp_cus_, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || hp_cus_ <= 0) hp_cus_ = 256;
+        }
         hp_ready_ = true;
     }
     void forward_hp(int n, const FrameArgs* fa, float* d_out, const int* d_out_rows, hipStream_t st) {
@@ -518,7 +529,13 @@ private:
         auto blk = [&](auto kernel, int lds, const _Float16* ih, const _Float16* il, _Float16* oh, _Float16* ol, int b,
                        const unsigned char* wtr, BlkLinkHP link) {
             const int stg = b / 2, nthr = 64 * (stg == 0 ? GeoHP<0>::NWAVES : (stg == 1 ? GeoHP<1>::NWAVES : GeoHP<2>::NWAVES));
-            hipLaunchKernelGGL(kernel, dim3(n), dim3(nthr), lds, st, ih, il, oh, ol, hw_blk_[b], hbp_[b], d_count_, hx1s_, wtr, link);
+            int grid = n;
+            if (hp_persist_ > 0) {      // BOXMOT_HIP_REID_PERSIST: workgroups loop over crops instead of one launch per crop (BlkLinkHP::n_crops)
+                link.n_crops = n;
+                const int slots = hp_cus_ * (stg == 2 ? 2 : 1) * hp_persist_;
+                grid = n < slots ? n : slots;
+            }
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(nthr), lds, st, ih, il, oh, ol, hw_blk_[b], hbp_[b], d_count_, hx1s_, wtr, link);
         };
         // stage 0: block 1 hands block 2 its conv1 result and its branch sum (fp32) instead of its 64-channel output
         blk(k_osblock_hp<0, 16, true, false, true, false>, GeoHP<0>::LDS_BYTES, act_a_, hact_al_, nullptr, nullptr, 0, nullptr,
@@ -583,6 +600,7 @@ private:
     _Float16 *crops_h_ = nullptr, *act_a_ = nullptr, *act_b_ = nullptr, *x1s_ = nullptr, *x2s_ = nullptr;
     // fused fp32-grade path (allocated when mode 2 is first selected)
     bool hp_ready_ = false;
+    int hp_persist_ = 0, hp_cus_ = 256;          // persistent launch form of the fp32-grade block kernels (workgroups per CU slot; 0 = off)
     BlkPackHP hbp_[6];
     unsigned char *hw_stem_ = nullptr, *hw_stem_fused_ = nullptr;
     unsigned char* hw_blk_[6] = {};

@@ -204,6 +204,11 @@ struct BlkLinkHP {
     const unsigned char* w = nullptr;
     long a0 = 0, a1 = 0, a2 = 0;
     float* x2s = nullptr;
+    // > 0: PERSISTENT launch -- the grid is a fixed number of workgroups (one or two per CU) and workgroup b runs crops b, b + gridDim.x,
+    // ... < n_crops in a loop, instead of one workgroup launch per crop (64 launches per CU and kernel at the headline's 16384 crops:
+    // dispatch, wave start-up, LDS allocation and the argument loads once per workgroup instead of once per crop).  0: one crop per
+    // workgroup.  A/B: profiles/r5_hp_persist_ab.txt
+    int n_crops = 0;
 };
 
 // ---------------------------------------------------------------------------
@@ -219,7 +224,11 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
     static_assert(!EMIT || (STAGE <= 1 && CIN == (STAGE == 0 ? 16 : 64) && DOWN && !TRANS), "EMIT: first block of stage 0 or 1");
     static_assert(!RECON || (STAGE <= 1 && CIN == GeoHP<STAGE>::COUT && !DOWN && TRANS), "RECON: second block of stage 0 or 1");
     using G = GeoHP<STAGE>;
-    if (count && (int)blockIdx.x >= *count) return;
+    const long crop_end = link.n_crops > 0 ? (long)link.n_crops : (long)blockIdx.x + 1;
+    const long crop_step = link.n_crops > 0 ? (long)gridDim.x : 1;
+#pragma unroll 1
+    for (long crop = blockIdx.x; crop < crop_end; crop += crop_step) {
+    if (count && crop >= *count) break;
     // Phase stagger: every workgroup of a launch does the same phases for the same time, so without it all 256 CUs read
     // (branch inputs, epilogue operands) and write at the same moments and the fabric is idle in between.  The workgroups of the
     // FIRST wave of the grid start a quarter period apart in four groups (neighbouring CUs of an XCD in different groups); the
@@ -246,7 +255,6 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
     float* gap_part = reinterpret_cast<float*>(lds + G::TBUF);      // [4 branches][NWAVES][HID]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l16 = lane & 15;
-    const long crop = blockIdx.x;
     const _Float16* xh = in_h + crop * P * (RECON ? PREV_CIN : CIN);       // RECON: the previous block's input
     const _Float16* xl = in_l + crop * P * (RECON ? PREV_CIN : CIN);
     const long out_px = TRANS ? P / 4 : P;
@@ -933,6 +941,8 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
     }
     BM_PROF(7);
     BM_PROF_FLUSH();
+    if (link.n_crops > 0) __syncthreads();      // persistent: every wave is done with the staged operands before the next crop's copies land
+    }   // crops of this workgroup
 }
 
 // ---------------------------------------------------------------------------

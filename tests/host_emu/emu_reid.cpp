@@ -14,6 +14,7 @@
 thread_local EmuDim3 threadIdx;
 thread_local EmuDim3 blockIdx;
 EmuDim3 blockDim;
+EmuDim3 gridDim;
 EmuBlock* g_emu_block = nullptr;
 unsigned char* g_emu_dynamic_lds = nullptr;
 static int g_stage1_handover = 0;
@@ -38,7 +39,7 @@ void launch(int gx, int gy, int nthr, const std::function<void()>& fn) {
     static std::vector<unsigned char> lds(400000 + 64);
     g_emu_block = &block; g_emu_mfma = &mf;
     g_emu_dynamic_lds = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(lds.data()) + 15) & ~uintptr_t(15));
-    blockDim.x = nthr;
+    blockDim.x = nthr; gridDim.x = (unsigned)gx; gridDim.y = (unsigned)gy;
     block.block_barrier.init(nthr);
     for (int w = 0; w < EMU_MAX_WAVES; ++w) block.wave_barrier[w].init(EMU_WAVE);
     for (int by = 0; by < gy; ++by)
@@ -320,7 +321,11 @@ int emu_reid_forward_hp(const float* blob, long n_floats, const uint8_t* frame, 
     auto blk = [&](auto kernel, const _Float16* ih, const _Float16* il, _Float16* oh, _Float16* ol, int b, const unsigned char* wtr, BlkLinkHP link) {
         const unsigned char* wp = wb[b].data(); const BlkPackHP bpb = bp[b];
         const int nthr = 64 * (stage[b] == 0 ? GeoHP<0>::NWAVES : (stage[b] == 1 ? GeoHP<1>::NWAVES : GeoHP<2>::NWAVES));
-        launch(n, 1, nthr, [=]() { kernel(ih, il, oh, ol, wp, bpb, nullptr, x1p, wtr, link); });
+        // EMU_HP_PERSIST_GRID = G > 0: the persistent launch form (BlkLinkHP::n_crops): G workgroups loop over the crops
+        const char* pg = std::getenv("EMU_HP_PERSIST_GRID");
+        const int grid = pg && std::atoi(pg) > 0 ? (std::atoi(pg) < n ? std::atoi(pg) : n) : n;
+        if (grid != n || (pg && std::atoi(pg) > 0)) link.n_crops = n;
+        launch(grid, 1, nthr, [=]() { kernel(ih, il, oh, ol, wp, bpb, nullptr, x1p, wtr, link); });
     };
     blk(k_osblock_hp<0, 16, true, false, true, false>, Ah.data(), Al.data(), nullptr, nullptr, 0, nullptr,
         BlkLinkHP{wb[1].data(), bp[1].conv1_a, bp[1].conv1_b, 0, x2s.data()});

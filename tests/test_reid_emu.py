@@ -278,7 +278,9 @@ def test_barrier_free_layer_loop_and_depthwise_prefetch_are_bit_identical_emulat
     LightConv layer loop of stages 0 / 1 synchronised by neighbour flags in LDS instead of two workgroup barriers per layer -- and
     BM_HP_DW_PREFETCH -- the depthwise pass's LDS reads issued a row ahead.  On CPU threads both together return the default build's
     embeddings and stored stages BIT FOR BIT; with the flag waits compiled out (EMU_NO_FLAG_WAIT: the negative control) the same
-    kernels read rows their neighbours have not written and come out wrong -- the emulation does check the protocol."""
+    kernels read rows their neighbours have not written and come out wrong -- the emulation does check the protocol.  The round's
+    other switches ride along: conv1 of the first stage-0 block computed once (BM_HP_S0_RECOMP = 0), the depthwise pass instantiated
+    per "another layer follows" (BM_HP_DW_STATIC_MORE), and the persistent launch form."""
     import sys
     sys.path.insert(0, str(HERE.parent.parent / "tools"))
     import hp_variant_check as hv
@@ -292,3 +294,12 @@ def test_barrier_free_layer_loop_and_depthwise_prefetch_are_bit_identical_emulat
     assert np.allclose(np.linalg.norm(both[0], axis=1), 1.0, atol=1e-5)
     broken = hv.forward(hv.build(["-DBM_HP_NBR_SYNC=1", "-DEMU_NO_FLAG_WAIT=1"], tmp_path / "nowait.so"), blob, img, boxes)
     assert not np.array_equal(base[0], broken[0])
+    # the persistent launch form (BlkLinkHP::n_crops, BOXMOT_HIP_REID_PERSIST; profiles/r5_hp_persist_ab.txt): ONE workgroup runs both
+    # crops in a loop -- LDS is poisoned once per launch only, so whatever a crop leaves behind is what the next one finds
+    import os
+    os.environ["EMU_HP_PERSIST_GRID"] = "1"
+    try:
+        pers = hv.forward(hv.build(["-DBM_HP_S0_RECOMP=0", "-DBM_HP_DW_STATIC_MORE=1"], tmp_path / "pers.so"), blob, img, boxes)
+    finally:
+        os.environ.pop("EMU_HP_PERSIST_GRID", None)
+    assert np.array_equal(base[0], pers[0]) and all(np.array_equal(a, b) for a, b in zip(base[1], pers[1]))

@@ -26,6 +26,8 @@ static std::vector<float> rand_block_weights(const bm::OsnetLayout& L) {
     return w;
 }
 
+static int g_persist = 0;       // argv[3]: persistent launch form with this many workgroups per CU slot (0 = one workgroup per crop)
+
 template <int STAGE, int CIN, bool DOWN, bool TRANS, bool EMIT = false, bool RECON = false>
 static void run(const char* name, int n, int iters, const bm::OsnetLayout& L, const std::vector<float>& w, int bi) {
     using G = bm::GeoHP<STAGE>;
@@ -48,8 +50,14 @@ static void run(const char* name, int n, int iters, const bm::OsnetLayout& L, co
     const size_t out_elems = (size_t)n * G::P * G::COUT;
     CK(hipMalloc(&d_oh, out_elems * 2)); CK(hipMalloc(&d_ol, out_elems * 2));
     CK(hipMemset(d_oh, 0, out_elems * 2)); CK(hipMemset(d_ol, 0, out_elems * 2));
-    const bm::BlkLinkHP link = EMIT ? bm::BlkLinkHP{d_wq, bq.conv1_a, bq.conv1_b, 0, d_x2}
-                                    : (RECON ? bm::BlkLinkHP{d_wq, bq.conv3_a, bq.conv3_b, bq.down_a, d_x2} : bm::BlkLinkHP{});
+    bm::BlkLinkHP link = EMIT ? bm::BlkLinkHP{d_wq, bq.conv1_a, bq.conv1_b, 0, d_x2}
+                              : (RECON ? bm::BlkLinkHP{d_wq, bq.conv3_a, bq.conv3_b, bq.down_a, d_x2} : bm::BlkLinkHP{});
+    int grid = n;
+    if (g_persist > 0) {
+        link.n_crops = n;
+        const int slots = 256 * (STAGE == 2 ? 2 : 1) * g_persist;
+        grid = n < slots ? n : slots;
+    }
     auto kern = bm::k_osblock_hp<STAGE, CIN, DOWN, TRANS, EMIT, RECON>;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -60,7 +68,7 @@ static void run(const char* name, int n, int iters, const bm::OsnetLayout& L, co
         CK(hipMemcpyToSymbol(HIP_SYMBOL(bm::g_osblock_prof), zero, sizeof(zero)));
 #endif
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(kern, dim3(n), dim3(64 * G::NWAVES), G::LDS_BYTES, 0, (const _Float16*)d_xh, (const _Float16*)d_xl, d_oh, d_ol,
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * G::NWAVES), G::LDS_BYTES, 0, (const _Float16*)d_xh, (const _Float16*)d_xl, d_oh, d_ol,
                            (const unsigned char*)d_w, bp, (const int*)nullptr, d_x1, (const unsigned char*)d_wt, link);
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -169,6 +177,8 @@ static void run_head(int n, int iters, const bm::OsnetLayout& L, const std::vect
 
 int main(int argc, char** argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 4096, iters = argc > 2 ? atoi(argv[2]) : 5;
+    g_persist = argc > 3 ? atoi(argv[3]) : 0;
+    if (g_persist) printf("# persistent launch form: %d workgroup(s) per CU slot\n", g_persist);
     const int ch[4] = {16, 64, 96, 128};
     const bm::OsnetLayout L = bm::make_osnet_layout(ch, 512);
     const std::vector<float> w = rand_block_weights(L);

@@ -37,13 +37,19 @@ def forward(lib, blob, img, boxes):
 
 def main():
     from boxmot_amd.reid_weights import pack_osnet, random_osnet_state_dict
+    import os
     defs = [a for a in sys.argv[1:] if a.startswith("-D")]
+    persist = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("PERSIST=")), None)      # PERSIST=G: the variant runs the
+    os.environ.pop("EMU_HP_PERSIST_GRID", None)                                                          # persistent launch form on G workgroups
     blob = pack_osnet(random_osnet_state_dict("osnet_x0_25", seed=0))
     img = np.random.default_rng(5).integers(0, 255, (480, 641, 3), dtype=np.uint8)
     boxes = np.array([[30.2, 40.7, 90.1, 200.3], [-12.0, 300.0, 120.5, 500.0], [100, 100, 228, 356]], dtype=np.float32)
     with tempfile.TemporaryDirectory() as td:
         base = forward(build([], Path(td) / "base.so"), blob, img, boxes)
-        var = forward(build(defs, Path(td) / "var.so"), blob, img, boxes)
+        if persist:
+            os.environ["EMU_HP_PERSIST_GRID"] = persist
+            defs = defs + [f"(persistent launch on {persist} workgroups)"]
+        var = forward(build([d for d in defs if d.startswith("-D")], Path(td) / "var.so"), blob, img, boxes)
     same = np.array_equal(base[0], var[0]) and all(np.array_equal(a, b) for a, b in zip(base[1], var[1]))
     print(f"{' '.join(defs) or '(no switches)'}: embeddings max|diff| {np.abs(base[0] - var[0]).max():.3e}, "
           f"{'bit-identical to the default build' if same else 'DIFFERENT from the default build'}; |emb| {np.linalg.norm(var[0], axis=1)}")
