@@ -530,7 +530,7 @@ private:
                        const unsigned char* wtr, BlkLinkHP link) {
             const int stg = b / 2, nthr = 64 * (stg == 0 ? GeoHP<0>::NWAVES : (stg == 1 ? GeoHP<1>::NWAVES : GeoHP<2>::NWAVES));
             int grid = n;
-            if (hp_persist_ > 0) {      // BOXMOT_HIP_REID_PERSIST: workgroups loop over crops instead of one launch per crop (BlkLinkHP::n_crops)
+            if (BM_HP_PERSIST && hp_persist_ > 0) {      // BOXMOT_HIP_REID_PERSIST in a -DBM_HP_PERSIST=1 build: workgroups loop over crops (BlkLinkHP::n_crops)
                 link.n_crops = n;
                 const int slots = hp_cus_ * (stg == 2 ? 2 : 1) * hp_persist_;
                 grid = n < slots ? n : slots;

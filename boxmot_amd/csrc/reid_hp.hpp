@@ -70,6 +70,10 @@
 #ifndef BM_HP_NBR_SYNC
 #define BM_HP_NBR_SYNC 0
 #endif
+// persistent workgroups (BlkLinkHP::n_crops): compiled in only on request -- measured flat (profiles/r5_hp_persist_ab.txt)
+#ifndef BM_HP_PERSIST
+#define BM_HP_PERSIST 0
+#endif
 #ifndef BM_HP_S0_RECOMP
 #define BM_HP_S0_RECOMP 1
 #endif
@@ -204,7 +208,7 @@ struct BlkLinkHP {
     const unsigned char* w = nullptr;
     long a0 = 0, a1 = 0, a2 = 0;
     float* x2s = nullptr;
-    // > 0: PERSISTENT launch -- the grid is a fixed number of workgroups (one or two per CU) and workgroup b runs crops b, b + gridDim.x,
+    // BM_HP_PERSIST builds only; > 0: PERSISTENT launch -- the grid is a fixed number of workgroups (one or two per CU) and workgroup b runs crops b, b + gridDim.x,
     // ... < n_crops in a loop, instead of one workgroup launch per crop (64 launches per CU and kernel at the headline's 16384 crops:
     // dispatch, wave start-up, LDS allocation and the argument loads once per workgroup instead of once per crop).  0: one crop per
     // workgroup.  A/B: profiles/r5_hp_persist_ab.txt
@@ -224,11 +228,17 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
     static_assert(!EMIT || (STAGE <= 1 && CIN == (STAGE == 0 ? 16 : 64) && DOWN && !TRANS), "EMIT: first block of stage 0 or 1");
     static_assert(!RECON || (STAGE <= 1 && CIN == GeoHP<STAGE>::COUT && !DOWN && TRANS), "RECON: second block of stage 0 or 1");
     using G = GeoHP<STAGE>;
+#if BM_HP_PERSIST        // (compile-time: the loop's three live scalars cost the second stage-0 block 3 spilled registers in the library build)
     const long crop_end = link.n_crops > 0 ? (long)link.n_crops : (long)blockIdx.x + 1;
     const long crop_step = link.n_crops > 0 ? (long)gridDim.x : 1;
 #pragma unroll 1
     for (long crop = blockIdx.x; crop < crop_end; crop += crop_step) {
     if (count && crop >= *count) break;
+#else
+    if (count && (int)blockIdx.x >= *count) return;
+    const long crop = blockIdx.x;
+    {
+#endif
     // Phase stagger: every workgroup of a launch does the same phases for the same time, so without it all 256 CUs read
     // (branch inputs, epilogue operands) and write at the same moments and the fabric is idle in between.  The workgroups of the
     // FIRST wave of the grid start a quarter period apart in four groups (neighbouring CUs of an XCD in different groups); the
@@ -941,7 +951,9 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
     }
     BM_PROF(7);
     BM_PROF_FLUSH();
+#if BM_HP_PERSIST
     if (link.n_crops > 0) __syncthreads();      // persistent: every wave is done with the staged operands before the next crop's copies land
+#endif
     }   // crops of this workgroup
 }
 

@@ -299,7 +299,7 @@ def test_barrier_free_layer_loop_and_depthwise_prefetch_are_bit_identical_emulat
     import os
     os.environ["EMU_HP_PERSIST_GRID"] = "1"
     try:
-        pers = hv.forward(hv.build(["-DBM_HP_S0_RECOMP=0", "-DBM_HP_DW_STATIC_MORE=1"], tmp_path / "pers.so"), blob, img, boxes)
+        pers = hv.forward(hv.build(["-DBM_HP_PERSIST=1", "-DBM_HP_S0_RECOMP=0", "-DBM_HP_DW_STATIC_MORE=1"], tmp_path / "pers.so"), blob, img, boxes)
     finally:
         os.environ.pop("EMU_HP_PERSIST_GRID", None)
     assert np.array_equal(base[0], pers[0]) and all(np.array_equal(a, b) for a, b in zip(base[1], pers[1]))

@@ -178,6 +178,7 @@ static void run_head(int n, int iters, const bm::OsnetLayout& L, const std::vect
 int main(int argc, char** argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 4096, iters = argc > 2 ? atoi(argv[2]) : 5;
     g_persist = argc > 3 ? atoi(argv[3]) : 0;
+    if (g_persist && !BM_HP_PERSIST) { fprintf(stderr, "the persistent form needs a -DBM_HP_PERSIST=1 build\n"); return 1; }
     if (g_persist) printf("# persistent launch form: %d workgroup(s) per CU slot\n", g_persist);
     const int ch[4] = {16, 64, 96, 128};
     const bm::OsnetLayout L = bm::make_osnet_layout(ch, 512);
