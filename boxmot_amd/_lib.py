@@ -141,6 +141,8 @@ SIGNATURES = {
     "boxmot_hip_botsort_last_reid_postprocess_time_ms": (_I, [_VP, c_double_p]),
     "boxmot_hip_botsort_last_track_time_ms": (_I, [_VP, c_double_p]),
     "boxmot_hip_botsort_state_dump": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP, _VP, c_int_p, c_int_p, c_int_p]),
+    "boxmot_hip_botsort_debug_costs_enable": (_I, [_VP, _I]),
+    "boxmot_hip_botsort_debug_costs": (_I, [_VP, _I, _I, _I, _VP, ctypes.c_long, c_int_p, c_int_p]),
     "boxmot_hip_deepocsort_default_config": (None, [ctypes.POINTER(DeepOcSortConfig)]),
     "boxmot_hip_deepocsort_create": (_VP, [ctypes.POINTER(DeepOcSortConfig)]),
     "boxmot_hip_deepocsort_destroy": (None, [_VP]),
@@ -159,6 +161,8 @@ SIGNATURES = {
     "boxmot_hip_deepocsort_synchronize": (_I, [_VP]),
     "boxmot_hip_deepocsort_set_crop_bound": (_I, [_VP, _I]),
     "boxmot_hip_deepocsort_state_dump": (_I, [_VP, _I, _VP, _VP, _VP, c_int_p, c_int_p, c_int_p]),
+    "boxmot_hip_deepocsort_debug_costs_enable": (_I, [_VP, _I]),
+    "boxmot_hip_deepocsort_debug_costs": (_I, [_VP, _I, _I, _VP, ctypes.c_long, c_int_p, c_int_p, c_int_p]),
     "boxmot_hip_strongsort_default_config": (None, [ctypes.POINTER(StrongSortConfig)]),
     "boxmot_hip_strongsort_create": (_VP, [ctypes.POINTER(StrongSortConfig)]),
     "boxmot_hip_strongsort_destroy": (None, [_VP]),
@@ -176,6 +180,8 @@ SIGNATURES = {
     "boxmot_hip_strongsort_set_crop_bound": (_I, [_VP, _I]),
     "boxmot_hip_strongsort_track_count": (_I, [_VP, _I, c_int_p]),
     "boxmot_hip_strongsort_state_dump": (_I, [_VP, _I, _VP, _VP, _VP, c_int_p, c_int_p, c_int_p]),
+    "boxmot_hip_strongsort_debug_costs_enable": (_I, [_VP, _I]),
+    "boxmot_hip_strongsort_debug_costs": (_I, [_VP, _I, _I, _I, _VP, ctypes.c_long, c_int_p, c_int_p]),
     "boxmot_hip_reid_create": (_VP, [ctypes.c_char_p, _VP, ctypes.c_long, _I]),
     "boxmot_hip_reid_destroy": (None, [_VP]),
     "boxmot_hip_reid_feature_dim": (_I, [_VP]),

@@ -247,6 +247,21 @@ class BotSort(BaseTracker):
         return dict(n=n, ints=ints[:n], kf=kf[:n], smooth=smooth[:n], misc=misc[:n], frame_count=fc.value,
                     id_count=ic.value)
 
+    def debug_costs_enable(self, on: bool = True) -> None:
+        """Keep copies of the association cost matrices of every following update (parity tests; off by default)."""
+        _lib.check(self._lib.boxmot_hip_botsort_debug_costs_enable(self._handle, int(bool(on))))
+
+    def debug_costs(self, stage: int, plane: int = 0) -> np.ndarray:
+        """(tracks, detections) fp64 cost matrix of the last update: ``stage`` 0 first / 1 second / 2 unconfirmed association;
+        ``plane`` 0 the solver's matrix, 1 ``iou_distance``, 2 ``embedding_distance`` where evaluated (NaN elsewhere) --
+        include/boxmot_hip.h, boxmot_hip_botsort_debug_costs."""
+        cap, nd = self.capacity()[:2]
+        buf = np.zeros(cap * nd, dtype=np.float64)
+        r, c = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(self._lib.boxmot_hip_botsort_debug_costs(self._handle, 0, int(stage), int(plane), buf.ctypes.data, buf.size,
+                                                            ctypes.byref(r), ctypes.byref(c)))
+        return buf[: r.value * c.value].reshape(r.value, c.value).copy()
+
     def _track_views(self, which: int):
         d = self.state_dump(which)
         out = []

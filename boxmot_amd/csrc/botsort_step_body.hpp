@@ -718,11 +718,15 @@ __device__ inline double iou_dist_tt(const double* a, const double* b) { return 
 #endif
 constexpr int SPARSE_MAX = BM_SPARSE_MAX;     // tests build a variant with 0 to force the dense path
 
-__device__ inline double cosine_gate(double dot, double nu, double nv, double emb_scale, double app, bool gate) {
+// embedding_distance of one pair (matching.py:85-107): np.maximum(0.0, cdist(..., "cosine"))
+__device__ inline double cosine_dist(double dot, double nu, double nv) {
     double cosv = dot / (nu * nv);
     if (fabs(cosv) > 1.0) cosv = cosv > 0 ? 1.0 : -1.0;       // scipy clips rounding overshoot
-    double e = 1.0 - cosv;
-    e = e > 0.0 ? e : (e != e ? e : 0.0);                       // np.maximum(0.0, e)
+    const double e = 1.0 - cosv;
+    return e > 0.0 ? e : (e != e ? e : 0.0);                    // np.maximum(0.0, e)
+}
+__device__ inline double cosine_gate(double dot, double nu, double nv, double emb_scale, double app, bool gate) {
+    double e = cosine_dist(dot, nu, nv);
     if (emb_scale > 0.0) e = e / emb_scale;
     if (e > app) e = 1.0;
     if (gate) e = 1.0;
@@ -733,10 +737,13 @@ __device__ inline double np_minimum(double a, double b) { return (a != a || b !=
 template <int NTHR>
 BM_STEP_BIG_FN void assoc_cost(const Ctx& c, SV& v, const int* rows, int n_rows, const int* cols,
                                   int n_cols, bool use_emb, double emb_scale, bool fuse,
-                                  float (*sA)[COST_KC + 1], float (*sB)[COST_KC + 1], int* s_count) {
+                                  float (*sA)[COST_KC + 1], float (*sB)[COST_KC + 1], int* s_count, double* dbg = nullptr) {
     if (n_rows == 0 || n_cols == 0) return;
     track_boxes(c, v, rows, n_rows, v.box_a);
     const long ld = v.cap;
+    // parity debugging only (BotSortStepArgs::dbg_cost): planes 1 and 2 of this stage
+    double* dbg_iou = dbg ? dbg + (long)v.nd * ld : nullptr;
+    double* dbg_emb = dbg ? dbg + 2 * (long)v.nd * ld : nullptr;
     if (c.tid == 0) *s_count = 0;
     __syncthreads();
     // pass 1: IoU part for every pair; collect the pairs whose appearance term matters
@@ -745,6 +752,7 @@ BM_STEP_BIG_FN void assoc_cost(const Ctx& c, SV& v, const int* rows, int n_rows,
         const int d = cols[cc];
         double iou_d = iou_dist_td(v.box_a + r * BOX_W, DET_BOX(v, d), v.det_area[d]);
         const bool gate = iou_d > v.cfg.proximity_thresh;
+        if (dbg) { dbg_iou[cc * ld + r] = iou_d; dbg_emb[cc * ld + r] = __builtin_nan(""); }
         if (fuse) {
             const double sim = 1 - iou_d;
             iou_d = 1 - sim * (double)v.dets[d * DET_COLS + CONF_COL];
@@ -781,6 +789,7 @@ BM_STEP_BIG_FN void assoc_cost(const Ctx& c, SV& v, const int* rows, int n_rows,
                     const double e = cosine_gate(dot, sqrt(na), sqrt(nb), emb_scale, v.cfg.appearance_thresh, false);
                     double* dst = v.cost + cc * ld + r;
                     *dst = np_minimum(*dst, e);
+                    if (dbg) dbg_emb[cc * ld + r] = cosine_dist(dot, sqrt(na), sqrt(nb));
                 }
             }
         }
@@ -844,6 +853,7 @@ BM_STEP_BIG_FN void assoc_cost(const Ctx& c, SV& v, const int* rows, int n_rows,
                 // the gate is re-derived from the un-fused IoU distance
                 const double raw = iou_dist_td(v.box_a + r * BOX_W, DET_BOX(v, d), v.det_area[d]);
                 const bool gate = raw > v.cfg.proximity_thresh;
+                if (dbg) dbg_emb[cc * ld + r] = cosine_dist(acc[m], v.trk_norm[r], v.det_norm[cc]);
                 if (gate) continue;                                   // pass 1 already stored min(iou_d, 1)
                 const double e = cosine_gate(acc[m], v.trk_norm[r], v.det_norm[cc], emb_scale, v.cfg.appearance_thresh, false);
                 double* dst = v.cost + cc * ld + r;
@@ -851,6 +861,24 @@ BM_STEP_BIG_FN void assoc_cost(const Ctx& c, SV& v, const int* rows, int n_rows,
             }
         }
     }
+    __syncthreads();
+}
+
+// Parity debugging (BotSortStepArgs::dbg_cost): the matrix the solver is about to be given -> plane 0 of `stage`, and its shape.
+__device__ inline double* dbg_stage(const BotSortStepArgs& args, const SV& v, int s, int stage) {
+    return args.dbg_cost ? args.dbg_cost + ((long)s * DBG_STAGES + stage) * DBG_PLANES * (long)v.nd * v.cap : nullptr;
+}
+__device__ inline void dbg_copy_cost(const Ctx& c, const BotSortStepArgs& args, const SV& v, int s, int stage, int n_rows, int n_cols,
+                                     bool iou_only = false) {
+    double* dst = dbg_stage(args, v, s, stage);
+    if (!dst) return;
+    const long ld = v.cap;
+    for (int o = c.tid; o < n_rows * n_cols; o += c.nthr) {
+        const int cc = o / n_rows, r = o % n_rows;
+        dst[cc * ld + r] = v.cost[cc * ld + r];
+        if (iou_only) dst[(long)v.nd * ld + cc * ld + r] = v.cost[cc * ld + r];     // the IoU-only stage: plane 1 is the same matrix
+    }
+    if (c.tid == 0) { args.dbg_shape[(s * DBG_STAGES + stage) * 2] = n_rows; args.dbg_shape[(s * DBG_STAGES + stage) * 2 + 1] = n_cols; }
     __syncthreads();
 }
 
@@ -992,7 +1020,9 @@ BM_STEP_BIG_FN void lap_solve(const Ctx& c, SV& v, const LapLds& L, int R, int C
 // ---------------------------------------------------------------------------
 // The frame step
 // ---------------------------------------------------------------------------
-template <int NTHR>
+// DBG: the parity-debugging instantiation (writes BotSortStepArgs::dbg_cost when it is set).  The product kernel is compiled with
+// DBG = false: every debug branch folds away and its register allocation is what it was without the feature.
+template <int NTHR, bool DBG = false>
 __device__ inline void botsort_step_stream(const BotSortStepArgs& args, int s, int* s_int, double* s_dbl,
                                            float (*sA)[COST_KC + 1], float (*sB)[COST_KC + 1], unsigned char* dyn_lds) {
     if (args.n_dets[s] < 0) {                 // "no update for this stream in this call" (frames without detections are
@@ -1124,7 +1154,8 @@ __device__ inline void botsort_step_stream(const BotSortStepArgs& args, int s, i
 
     tick();
     // ---- first association (botsort.py:285-333) ----
-    assoc_cost<NTHR>(c, v, v.pool, n_pool, v.first_idx, n_first, reid, 0.0, cfg.fuse_first_associate != 0, sA, sB, s_count);
+    assoc_cost<NTHR>(c, v, v.pool, n_pool, v.first_idx, n_first, reid, 0.0, cfg.fuse_first_associate != 0, sA, sB, s_count, DBG ? dbg_stage(args, v, s, 0) : nullptr);
+    if (DBG) dbg_copy_cost(c, args, v, s, 0, n_pool, n_first);
     tick();
     lap_solve(c, v, lap, n_pool, n_first, cfg.match_thresh);
     tick();
@@ -1153,6 +1184,7 @@ __device__ inline void botsort_step_stream(const BotSortStepArgs& args, int s, i
 
     // ---- second association: IoU only, low-confidence detections (botsort.py:335-378) ----
     iou_cost(c, v, v.remain, n_remain, v.second_idx, n_second);
+    if (DBG) dbg_copy_cost(c, args, v, s, 1, n_remain, n_second, true);
     lap_solve(c, v, lap, n_remain, n_second, cfg.second_match_thresh);
     n_match = block_append_if(c, n_remain, [&](int r) { return v.lap_x[r] >= 0; }, [&](int r) { return r; }, v.match_slot, 0);
     for (int k = c.tid; k < n_match; k += c.nthr) {
@@ -1171,7 +1203,8 @@ __device__ inline void botsort_step_stream(const BotSortStepArgs& args, int s, i
 
     tick();
     // ---- unconfirmed tracks vs the left-over high-confidence detections (botsort.py:380-431) ----
-    assoc_cost<NTHR>(c, v, v.unconf, n_unconf, v.left_idx, n_left, reid, cfg.unconfirmed_emb_scale, true, sA, sB, s_count);
+    assoc_cost<NTHR>(c, v, v.unconf, n_unconf, v.left_idx, n_left, reid, cfg.unconfirmed_emb_scale, true, sA, sB, s_count, DBG ? dbg_stage(args, v, s, 2) : nullptr);
+    if (DBG) dbg_copy_cost(c, args, v, s, 2, n_unconf, n_left);
     lap_solve(c, v, lap, n_unconf, n_left, cfg.unconfirmed_match_thresh);
     n_match = block_append_if(c, n_unconf, [&](int r) { return v.lap_x[r] >= 0; }, [&](int r) { return r; }, v.match_slot, 0);
     for (int k = c.tid; k < n_match; k += c.nthr) {

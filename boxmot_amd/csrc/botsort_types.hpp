@@ -132,6 +132,18 @@ struct BotSortStepArgs {
     const int* warp_flag;     // [S] non-zero: apply warp[s] in this step
     int stream_base;          // workgroup b advances stream (stream_base + b)
     long long* phase_clock;   // optional [16] shader-clock stamps of stream stream_base's phases (profiling), or nullptr
+    // Parity debugging (boxmot_hip_botsort_debug_costs; nullptr = off, the default): copies of the three association cost
+    // matrices of this step, [S][DBG_STAGES][DBG_PLANES][max_dets][cap] fp64, detection-major like `cost` (plane[c * cap + r]),
+    // and their shapes [S][DBG_STAGES][2] = (n_rows tracks, n_cols detections).  Nothing reads them on the device.
+    double* dbg_cost;
+    int* dbg_shape;
 };
+
+// stages: the first association (botsort.py:285-333), the second, IoU-only one (:335-378), the unconfirmed tracks (:380-431)
+constexpr int DBG_STAGES = 3;
+// planes: 0 = the matrix the assignment solver was given (matching.py:46-107, 139-147 + the gates of botsort.py:306-317, 396-413);
+//         1 = iou_distance before score fusion; 2 = embedding_distance (cosine, clipped at 0) where the step evaluated it, NaN elsewhere
+//             (the sparse path evaluates the pairs that pass the IoU gate, the dense fallback every pair)
+constexpr int DBG_PLANES = 3;
 
 }  // namespace bm

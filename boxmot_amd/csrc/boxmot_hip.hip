@@ -90,14 +90,14 @@ void destroy_on(H* h) {
 constexpr int STEP_THREADS = 512;
 constexpr int SS_STEP_THREADS_BIG = 1024;     // StrongSORT frame step with max_tracks >= 1024
 
-template <int NTHR>
+template <int NTHR, bool DBG = false>
 __global__ void __launch_bounds__(NTHR) botsort_step_kernel(bm::BotSortStepArgs args) {
     __shared__ int s_int[bm::MAX_WAVES + 1];
     __shared__ double s_dbl[bm::MAX_WAVES];
     __shared__ float sA[bm::COST_TILE][bm::COST_KC + 1];
     __shared__ float sB[bm::COST_TILE][bm::COST_KC + 1];
     BM_DYNAMIC_LDS_T(unsigned char, dyn_lds);       // assignment-solver state, sized by lap_lds_bytes(cap, max_dets)
-    bm::botsort_step_stream<NTHR>(args, args.stream_base + blockIdx.x, s_int, s_dbl, sA, sB, dyn_lds);
+    bm::botsort_step_stream<NTHR, DBG>(args, args.stream_base + blockIdx.x, s_int, s_dbl, sA, sB, dyn_lds);
 }
 
 // the same frame step for oriented detections (botsort_step.hpp: namespace bm::obb)
@@ -364,6 +364,11 @@ struct BoxMOTHipBotSort : DeviceBound {
     float* d_crop_boxes = nullptr;
     int* d_crop_row = nullptr;
     long long* d_phase_clock = nullptr;
+    // parity debugging (boxmot_hip_botsort_debug_costs_enable): copies of the association cost matrices of the last step
+    bool dbg_costs = false;
+    double* d_dbg_cost = nullptr;
+    int* d_dbg_shape = nullptr;
+    int dbg_cap = 0, dbg_nd = 0;
     double last_track_ms = 0, last_reid_pre_ms = 0, last_reid_proc_ms = 0;
     // growth of the tables (grow_tables): what botsort_allocate handed out, in order; slots in use per stream after the last
     // host update (-1 = unknown: a device-resident step ran since)
@@ -420,6 +425,7 @@ struct StreamIo : DeviceBound {
     // set_crop_bound: host-declared upper bound on the ReID crops of a device-resident step (-1: none, the count is read back);
     // d_crop_count[1] = "the count exceeded the bound"
     int crop_bound = -1;
+    bool bounded_step_pending = false;      // a step sized by crop_bound was queued since the overflow flag was last read (io_check_crop_bound)
     // growth of the tables: what the tracker's allocate function handed out, in order; tracks per stream after the last host
     // update (-1 = unknown: a device-resident step ran since)
     std::vector<std::pair<void*, size_t>> table_rec;
@@ -465,12 +471,14 @@ struct StreamIo : DeviceBound {
 struct BoxMOTHipDeepOcSort : StreamIo {
     BoxMOTHipDeepOcSortConfig cfg{};
     bm::DocsStepArgs args{};
+    int dbg_cap = 0, dbg_nd = 0;    // sizes the debug cost planes (args.dbg_cost) were made at
     bool is_obb = false;            // oriented detections: config.is_obb (7 columns in, 9 out, 9-state filter)
 };
 
 struct BoxMOTHipStrongSort : StreamIo {
     BoxMOTHipStrongSortConfig cfg{};
     bm::SsStepArgs args{};
+    int dbg_big = 0;                // leading dimension the debug cost planes (args.dbg_cost) were made at
     bool bank_valu = false;         // BOXMOT_HIP_SS_BANK=valu: the scalar-FMA bank-distance kernel (A/B timing, cross-check)
 };
 
@@ -713,10 +721,26 @@ void launch_step(BoxMOTHipBotSort* h, int s0, int n_streams, const float* d_dets
     a.dets = d_dets; a.n_dets = d_ndets; a.embs = d_embs; a.list_sel = d_list_sel; a.frame_count_set = d_fc_set;
     a.warp = with_warp ? h->d_warp : nullptr; a.warp_flag = with_warp ? h->d_warp_flag : nullptr;
     a.out = d_out; a.out_n = d_out_n; a.stream_base = s0; a.phase_clock = h->d_phase_clock;
+    a.dbg_cost = nullptr; a.dbg_shape = nullptr;
+    if (h->dbg_costs) {
+        if (h->dbg_cap != h->cap || h->dbg_nd != h->nd) {           // (re-)made at the tables' current sizes (they may have grown)
+            BM_HIP(hipStreamSynchronize(h->stream));
+            if (h->d_dbg_cost) { release(h->owned, h->d_dbg_cost); release(h->owned, h->d_dbg_shape); }
+            h->d_dbg_cost = zalloc<double>((size_t)h->S * bm::DBG_STAGES * bm::DBG_PLANES * h->nd * h->cap, h->owned);
+            h->d_dbg_shape = zalloc<int>((size_t)h->S * bm::DBG_STAGES * 2, h->owned);
+            h->dbg_cap = h->cap; h->dbg_nd = h->nd;
+        }
+        a.dbg_cost = h->d_dbg_cost; a.dbg_shape = h->d_dbg_shape;
+    }
     if (h->is_obb)
         hipLaunchKernelGGL((botsort_obb_step_kernel<STEP_THREADS>), dim3(n_streams), dim3(STEP_THREADS),
                            (size_t)bm::lap_lds_bytes(h->cap, h->nd), h->stream, a);
-    else
+    else if (a.dbg_cost) {          // the parity-debugging instantiation (same source, debug writes compiled in)
+        BM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(botsort_step_kernel<STEP_THREADS, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)bm::lap_lds_bytes(h->cap, h->nd)));
+        hipLaunchKernelGGL((botsort_step_kernel<STEP_THREADS, true>), dim3(n_streams), dim3(STEP_THREADS),
+                           (size_t)bm::lap_lds_bytes(h->cap, h->nd), h->stream, a);
+    } else
         hipLaunchKernelGGL((botsort_step_kernel<STEP_THREADS>), dim3(n_streams), dim3(STEP_THREADS),
                            (size_t)bm::lap_lds_bytes(h->cap, h->nd), h->stream, a);
     BM_HIP(hipGetLastError());
@@ -1345,6 +1369,7 @@ float* io_device_reid(StreamIo* h, const float* d_dets, const int* d_ndets, cons
         hipLaunchKernelGGL(pad_crop_list_kernel, dim3(n > 0 ? (n + 255) / 256 : 1), dim3(256), 0, rs, (const int*)h->d_crop_count, n,
                            h->d_crop_stream, h->d_crop_boxes, h->d_crop_row, h->d_crop_count + 1, d_ndets, nd_step, h->S);
         h->step_ndets = nd_step;
+        h->bounded_step_pending = true;
         if (n > 0) h->reid->run(d_frames, h->d_crop_stream, h->d_crop_boxes, 4, n, image_cols, image_rows, embs, h->d_crop_row, rs);
     } else {
         int n_crops = 0;
@@ -1371,8 +1396,11 @@ void io_set_crop_bound(StreamIo* h, int max_total_crops) {
     h->crop_bound = max_total_crops;
 }
 // after a stream synchronisation: a step whose crops exceeded the declared bound left detections without an embedding
+// (latched on the host when a bounded step is queued, not read off the CURRENT bound: a caller that runs bounded steps and then
+// sets the bound back to -1 before synchronising still sees the overflow of the earlier steps)
 void io_check_crop_bound(StreamIo* h) {
-    if (h->crop_bound < 0 || !h->d_crop_count) return;
+    if (!h->bounded_step_pending || !h->d_crop_count) return;
+    h->bounded_step_pending = false;
     int flag = 0;
     BM_HIP(hipMemcpy(&flag, h->d_crop_count + 1, 4, hipMemcpyDeviceToHost));
     if (flag) {
@@ -1388,7 +1416,10 @@ void io_read_back(StreamIo* h, int n, const int* d_status, const char* tracker, 
     BM_HIP(hipMemcpyAsync(h->h_out_n.data(), h->d_out_n + s0, n * 4, hipMemcpyDeviceToHost, h->stream));
     if (d_n_tracks) BM_HIP(hipMemcpyAsync(h->h_used.data() + s0, d_n_tracks + s0, n * 4, hipMemcpyDeviceToHost, h->stream));
     BM_HIP(hipStreamSynchronize(h->stream));
-    io_check_crop_bound(h);             // an earlier device-resident step whose crops exceeded the declared bound (that frame was not stepped)
+    // an earlier device-resident step whose crops exceeded the declared bound (that frame was not stepped): reported AFTER this
+    // update's read-back is complete -- its step has run on the device, so its rows are returned and its warps are cleared first
+    std::string bound_msg;
+    try { io_check_crop_bound(h); } catch (const std::exception& e) { bound_msg = e.what(); }
     for (int k = 0; k < n; ++k) h->h_warp_flag[s0 + k] = 0;
     const std::string status_msg = take_status(h->stream, const_cast<int*>(d_status), s0, n, tracker);
     for (int k = 0; k < n; ++k) {
@@ -1404,6 +1435,8 @@ void io_read_back(StreamIo* h, int n, const int* d_status, const char* tracker, 
         out_rows[k] = rows;
     }
     if (!status_msg.empty()) throw std::runtime_error(status_msg);      // rows of this frame are in `out` all the same
+    if (!bound_msg.empty())         // (the "<tracker> stream <n>: " shape tells the host classes that this update's step ran: _lib.step_ran)
+        throw std::runtime_error(std::string("boxmot_hip: ") + tracker + " stream " + std::to_string(s0) + ": an EARLIER step reported: " + bound_msg);
 }
 
 // ---------------------------------------------------------------------------
@@ -1483,6 +1516,14 @@ void docs_build(BoxMOTHipDeepOcSort* h) {
     docs_set_lds(h, lds);
 }
 
+// debug cost planes of the DeepOCSORT step (boxmot_hip_deepocsort_debug_costs_enable): made at the tables' current sizes
+void docs_make_dbg(BoxMOTHipDeepOcSort* h) {
+    if (h->args.dbg_cost) { release(h->owned, h->args.dbg_cost); release(h->owned, h->args.dbg_shape); }
+    h->args.dbg_cost = zalloc<double>((size_t)h->S * bm::DOCS_DBG_PLANES * h->nd * h->cap, h->owned);
+    h->args.dbg_shape = zalloc<int>((size_t)h->S * 4, h->owned);
+    h->dbg_cap = h->cap; h->dbg_nd = h->nd;
+}
+
 void docs_grow(BoxMOTHipDeepOcSort* h, int new_cap, int new_nd) {
     const long lds = bm::docs_lap_lds_bytes(new_cap, new_nd);
     if (lds > 120 * 1024)
@@ -1502,6 +1543,7 @@ void docs_grow(BoxMOTHipDeepOcSort* h, int new_cap, int new_nd) {
     io_alloc_sized(h);
     if (new_reid) h->reid = std::move(new_reid);
     docs_set_lds(h, lds);
+    if (h->args.dbg_cost) docs_make_dbg(h);
 }
 
 // Stage the inputs of the first n streams (ReID on every detection above det_thresh when embeddings are not supplied,
@@ -1568,6 +1610,15 @@ void ss_build(BoxMOTHipStrongSort* h) {
     ss_zero_state(h);
 }
 
+// debug cost planes of the StrongSORT step (boxmot_hip_strongsort_debug_costs_enable)
+void ss_make_dbg(BoxMOTHipStrongSort* h) {
+    if (h->args.dbg_cost) { release(h->owned, h->args.dbg_cost); release(h->owned, h->args.dbg_shape); }
+    const size_t big = h->cap > h->nd ? h->cap : h->nd;
+    h->args.dbg_cost = zalloc<double>((size_t)h->S * 4 * big * big, h->owned);
+    h->args.dbg_shape = zalloc<int>((size_t)h->S * 4, h->owned);
+    h->dbg_big = (int)big;
+}
+
 void ss_grow(BoxMOTHipStrongSort* h, int new_cap, int new_nd) {
     const long lds = bm::ss_lsa_lds_bytes(new_cap > new_nd ? new_cap : new_nd);
     if (lds > 120 * 1024)
@@ -1588,6 +1639,7 @@ void ss_grow(BoxMOTHipStrongSort* h, int new_cap, int new_nd) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     BM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(strongsort_step_kernel<SS_STEP_THREADS_BIG>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (h->args.dbg_cost) ss_make_dbg(h);
 }
 
 #ifdef BM_SS_PROF
@@ -1994,6 +2046,40 @@ int boxmot_hip_botsort_state_dump(BoxMOTHipBotSort* handle, int stream, int whic
         *out_rows = n;
         if (out_frame_count) BM_HIP(hipMemcpy(out_frame_count, st.frame_count + s, 4, hipMemcpyDeviceToHost));
         if (out_id_count) BM_HIP(hipMemcpy(out_id_count, st.id_count + s, 4, hipMemcpyDeviceToHost));
+    });
+}
+
+int boxmot_hip_botsort_debug_costs_enable(BoxMOTHipBotSort* handle, int on) {
+    return guard_on(handle, [&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip: null argument");
+        if (on && handle->is_obb) throw std::runtime_error("boxmot_hip: debug_costs is built for the axis-aligned frame step only");
+        BM_HIP(hipStreamSynchronize(handle->stream));
+        handle->dbg_costs = on != 0;
+    });
+}
+
+int boxmot_hip_botsort_debug_costs(BoxMOTHipBotSort* handle, int stream, int stage, int plane, double* out, long out_capacity,
+                                   int* out_rows, int* out_cols) {
+    return guard_on(handle, [&]() {
+        if (!handle || !out_rows || !out_cols) throw std::runtime_error("boxmot_hip: null argument");
+        if (stream < 0 || stream >= handle->S) throw std::runtime_error("boxmot_hip: stream index out of range");
+        if (stage < 0 || stage >= bm::DBG_STAGES || plane < 0 || plane >= bm::DBG_PLANES)
+            throw std::runtime_error("boxmot_hip: debug_costs stage must be 0..2 and plane 0..2");
+        if (!handle->dbg_costs || !handle->d_dbg_cost)
+            throw std::runtime_error("boxmot_hip: debug_costs needs boxmot_hip_botsort_debug_costs_enable(handle, 1) before the update");
+        BM_HIP(hipStreamSynchronize(handle->stream));
+        int shape[2] = {0, 0};
+        BM_HIP(hipMemcpy(shape, handle->d_dbg_shape + ((size_t)stream * bm::DBG_STAGES + stage) * 2, 8, hipMemcpyDeviceToHost));
+        const int R = shape[0], C = shape[1];
+        *out_rows = R; *out_cols = C;
+        if (R == 0 || C == 0) return;
+        if (!out || out_capacity < (long)R * C) throw std::runtime_error("boxmot_hip: debug_costs output capacity is smaller than rows x cols");
+        const size_t cap = handle->dbg_cap, nd = handle->dbg_nd;
+        std::vector<double> m(nd * cap);
+        BM_HIP(hipMemcpy(m.data(), handle->d_dbg_cost + (((size_t)stream * bm::DBG_STAGES + stage) * bm::DBG_PLANES + plane) * nd * cap,
+                         m.size() * 8, hipMemcpyDeviceToHost));
+        for (int r = 0; r < R; ++r)                       // the device stores detection-major; the caller gets the reference's (tracks, dets)
+            for (int c = 0; c < C; ++c) out[(size_t)r * C + c] = m[(size_t)c * cap + r];
     });
 }
 
@@ -2763,6 +2849,75 @@ int boxmot_hip_strongsort_set_crop_bound(BoxMOTHipStrongSort* handle, int max_to
     return guard_on(handle, [&]() {
         if (!handle) throw std::runtime_error("boxmot_hip StrongSORT handle is not initialized.");
         io_set_crop_bound(handle, max_total_crops);
+    });
+}
+
+int boxmot_hip_deepocsort_debug_costs_enable(BoxMOTHipDeepOcSort* handle, int on) {
+    return guard_on(handle, [&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip: null argument");
+        BM_HIP(hipStreamSynchronize(handle->stream));
+        if (on) docs_make_dbg(handle);
+        else if (handle->args.dbg_cost) {
+            release(handle->owned, handle->args.dbg_cost); release(handle->owned, handle->args.dbg_shape);
+            handle->args.dbg_cost = nullptr; handle->args.dbg_shape = nullptr;
+        }
+    });
+}
+
+int boxmot_hip_deepocsort_debug_costs(BoxMOTHipDeepOcSort* handle, int stream, int plane, double* out, long out_capacity,
+                                      int* out_rows, int* out_cols, int* out_branch) {
+    return guard_on(handle, [&]() {
+        if (!handle || !out_rows || !out_cols) throw std::runtime_error("boxmot_hip: null argument");
+        if (stream < 0 || stream >= handle->S) throw std::runtime_error("boxmot_hip: stream index out of range");
+        if (plane < 0 || plane >= bm::DOCS_DBG_PLANES) throw std::runtime_error("boxmot_hip: debug_costs plane must be 0..2");
+        if (!handle->args.dbg_cost)
+            throw std::runtime_error("boxmot_hip: debug_costs needs boxmot_hip_deepocsort_debug_costs_enable(handle, 1) before the update");
+        BM_HIP(hipStreamSynchronize(handle->stream));
+        int shape[4] = {0, 0, 0, 0};
+        BM_HIP(hipMemcpy(shape, handle->args.dbg_shape + (size_t)stream * 4, 16, hipMemcpyDeviceToHost));
+        const int R = shape[0], C = shape[1];             // (detections, tracks): association.py's iou_matrix / final_cost orientation
+        *out_rows = R; *out_cols = C;
+        if (out_branch) *out_branch = shape[2];
+        if (R == 0 || C == 0) return;
+        if (!out || out_capacity < (long)R * C) throw std::runtime_error("boxmot_hip: debug_costs output capacity is smaller than rows x cols");
+        const size_t cap = handle->dbg_cap, nd = handle->dbg_nd;
+        std::vector<double> m(nd * cap);
+        BM_HIP(hipMemcpy(m.data(), handle->args.dbg_cost + ((size_t)stream * bm::DOCS_DBG_PLANES + plane) * nd * cap, m.size() * 8, hipMemcpyDeviceToHost));
+        for (int r = 0; r < R; ++r) std::memcpy(out + (size_t)r * C, m.data() + (size_t)r * cap, (size_t)C * 8);
+    });
+}
+
+int boxmot_hip_strongsort_debug_costs_enable(BoxMOTHipStrongSort* handle, int on) {
+    return guard_on(handle, [&]() {
+        if (!handle) throw std::runtime_error("boxmot_hip: null argument");
+        BM_HIP(hipStreamSynchronize(handle->stream));
+        if (on) ss_make_dbg(handle);
+        else if (handle->args.dbg_cost) {
+            release(handle->owned, handle->args.dbg_cost); release(handle->owned, handle->args.dbg_shape);
+            handle->args.dbg_cost = nullptr; handle->args.dbg_shape = nullptr;
+        }
+    });
+}
+
+int boxmot_hip_strongsort_debug_costs(BoxMOTHipStrongSort* handle, int stream, int stage, int plane, double* out, long out_capacity,
+                                      int* out_rows, int* out_cols) {
+    return guard_on(handle, [&]() {
+        if (!handle || !out_rows || !out_cols) throw std::runtime_error("boxmot_hip: null argument");
+        if (stream < 0 || stream >= handle->S) throw std::runtime_error("boxmot_hip: stream index out of range");
+        if (stage < 0 || stage > 1 || plane < 0 || plane > 1) throw std::runtime_error("boxmot_hip: debug_costs stage and plane must be 0 or 1");
+        if (!handle->args.dbg_cost)
+            throw std::runtime_error("boxmot_hip: debug_costs needs boxmot_hip_strongsort_debug_costs_enable(handle, 1) before the update");
+        BM_HIP(hipStreamSynchronize(handle->stream));
+        int shape[4] = {0, 0, 0, 0};
+        BM_HIP(hipMemcpy(shape, handle->args.dbg_shape + (size_t)stream * 4, 16, hipMemcpyDeviceToHost));
+        const int R = shape[stage * 2], C = shape[stage * 2 + 1];        // (tracks, detections)
+        *out_rows = R; *out_cols = C;
+        if (R == 0 || C == 0) return;
+        if (!out || out_capacity < (long)R * C) throw std::runtime_error("boxmot_hip: debug_costs output capacity is smaller than rows x cols");
+        const size_t big = handle->dbg_big;
+        std::vector<double> m(big * big);
+        BM_HIP(hipMemcpy(m.data(), handle->args.dbg_cost + ((size_t)stream * 4 + stage * 2 + plane) * big * big, m.size() * 8, hipMemcpyDeviceToHost));
+        for (int r = 0; r < R; ++r) std::memcpy(out + (size_t)r * C, m.data() + (size_t)r * big, (size_t)C * 8);
     });
 }
 

@@ -97,7 +97,14 @@ struct DocsStepArgs {
     float* out;               // [S][cap][8]  (a frame can output more rows than detections: new + matched)   (oriented: [9])
     int* out_n;               // [S]
     int stream_base;
+    // Parity debugging (boxmot_hip_deepocsort_debug_costs; nullptr = off, the default): the matrices of this step's `associate`
+    // (association.py:61-152), [S][DOCS_DBG_PLANES][max_dets][cap] fp64 detection-major (plane[k * cap + t]) and
+    // [S][4] = (n detections, n tracks, branch: 0 no matrix / 1 already-a-permutation early-out / 2 solver, 0).
+    // plane 0 = final_cost (branch 2 only), 1 = the association function's matrix (iou_matrix), 2 = the weighted emb_cost (branch 2).
+    double* dbg_cost;
+    int* dbg_shape;
 };
+constexpr int DOCS_DBG_PLANES = 3;
 
 struct DocsSizes { int S, cap, nd, dim; int is_obb = 0; };
 __host__ __device__ inline int docs_kf_stride(int is_obb) { return is_obb ? 90 : KF_STRIDE; }

@@ -795,6 +795,8 @@ __device__ inline void docs_step_stream(const DocsStepArgs& args, int s, int* s_
 
     // ---- first association (association.py:61-152) ----
     int n_match = 0, n_ud = 0, n_ut = 0;
+    double* dbg = args.dbg_cost ? args.dbg_cost + (long)s * DOCS_DBG_PLANES * v.nd * ld : nullptr;     // parity debugging only
+    if (dbg && c.tid == 0) { args.dbg_shape[s * 4] = nk; args.dbg_shape[s * 4 + 1] = nt; args.dbg_shape[s * 4 + 2] = 0; args.dbg_shape[s * 4 + 3] = 0; }
     if (nt == 0) {
         for (int k = c.tid; k < nk; k += c.nthr) v.un_d[k] = k;
         n_ud = nk;
@@ -851,6 +853,11 @@ __device__ inline void docs_step_stream(const DocsStepArgs& args, int s, int* s_
         }
         const bool have_matrix = nk > 0;   // min(iou.shape) != 0 (nt > 0 here)
         const bool permutation = have_matrix && mx == 1 && mn_needed;
+        if (dbg) {
+            for (int k = c.wave; k < nk; k += c.nwaves)
+                for (int t = c.lane; t < nt; t += WAVE) dbg[(long)v.nd * ld + k * ld + t] = v.iou[k * ld + t];
+            if (c.tid == 0) args.dbg_shape[s * 4 + 2] = !have_matrix ? 0 : (permutation ? 1 : 2);
+        }
         if (!have_matrix) {
             for (int t = c.tid; t < nt; t += c.nthr) v.lap_x[t] = -1;
         } else if (permutation) {
@@ -916,6 +923,7 @@ __device__ inline void docs_step_stream(const DocsStepArgs& args, int s, int* s_
                     }
                 }
                 v.cost[k * ld + t] = -((v.iou[k * ld + t] + v.cost[k * ld + t]) + em);
+                if (dbg) { dbg[k * ld + t] = v.cost[k * ld + t]; dbg[2 * (long)v.nd * ld + k * ld + t] = em; }
             }
             __syncthreads();
             const double* cm = v.cost;

@@ -78,6 +78,14 @@ struct SsStepArgs {
     float* out;               // [S][cap][8]
     int* out_n;               // [S]
     int stream_base;
+    // Parity debugging (boxmot_hip_strongsort_debug_costs; nullptr = off, the default): the cost matrices of the two
+    // min_cost_matching calls of this step (linear_assignment.py:14-79), [S][2 stages][2 planes][big][big] fp64 row-major
+    // (tracks x detections, leading dimension big = max(cap, nd)) and their shapes [S][2][2] = (rows, cols).
+    // stage 0: confirmed tracks x detections, the gated appearance metric (tracker.py:108-122, linear_assignment.py:145-198);
+    // stage 1: the IoU stage (iou_matching.py:49-87).  plane 0: the metric's matrix as returned; plane 1: after the
+    // `cost > max_distance -> max_distance + 1e-5` clamp, what linear_sum_assignment is given.
+    double* dbg_cost;
+    int* dbg_shape;
 };
 
 struct SsSizes { int S, cap, nd, dim, budget; };
@@ -935,8 +943,10 @@ __device__ inline int ss_unmatched_in_set_order(const Ctx& c, SSV& v, int n_conf
 // unmatched columns to un_cols likewise.
 struct MatchOut { int n_match, n_un_rows, n_un_cols; };
 __device__ inline MatchOut ss_min_cost_matching(const Ctx& c, SSV& v, const LsaLds& lsa, const int* rows, int nr, const int* cols, int nc,
-                                                long ld, double max_distance, int n_match0, int* un_rows, int* un_cols) {
+                                                long ld, double max_distance, int n_match0, int* un_rows, int* un_cols,
+                                                double* dbg = nullptr, int* dbg_shape = nullptr) {
     MatchOut o{n_match0, 0, 0};
+    if (dbg_shape && c.tid == 0) { dbg_shape[0] = nr; dbg_shape[1] = nc; }
     auto ident = [](int i) { return i; };
     if (nr == 0 || nc == 0) {
         for (int r = c.tid; r < nr; r += c.nthr) un_rows[r] = rows[r];
@@ -959,7 +969,9 @@ __device__ inline MatchOut ss_min_cost_matching(const Ctx& c, SSV& v, const LsaL
             const int r = (tile / tiles_q) * 8 + rr, q = (tile % tiles_q) * 8 + qq;
             if (r < nr && q < nc) {
                 double x = v.cost[r * ld + q];
+                if (dbg) dbg[r * ld + q] = x;
                 if (x > max_distance) { x = clamp; v.cost[r * ld + q] = x; }
+                if (dbg) dbg[ld * ld + r * ld + q] = x;
                 if (transposed) cmT[(long)q * ld + r] = x;
             }
         }
@@ -1101,7 +1113,9 @@ __device__ inline void ss_step_stream(const SsStepArgs& args, int s, int* s_int,
     }
     SS_PROF(1);
     // un_rows of stage A -> tmp list (flag_t reused as storage for unmatched confirmed rows)
-    MatchOut a = ss_min_cost_matching(c, v, lsa, v.rows_a, n_conf, v.tmp_a, nk, ld, cfg.max_cos_dist, 0, v.flag_t, v.un_d);
+    double* dbg = args.dbg_cost ? args.dbg_cost + (long)s * 4 * ld * ld : nullptr;          // parity debugging only
+    int* dbg_shape = args.dbg_cost ? args.dbg_shape + s * 4 : nullptr;
+    MatchOut a = ss_min_cost_matching(c, v, lsa, v.rows_a, n_conf, v.tmp_a, nk, ld, cfg.max_cos_dist, 0, v.flag_t, v.un_d, dbg, dbg_shape);
     SS_PROF(3);
     // unmatched confirmed tracks = list(set(confirmed) - set(matched)) in CPython's set order (ss_unmatched_in_set_order)
     s_int[0] = ss_unmatched_in_set_order(c, v, n_conf, a.n_match, nt, big, dyn_lds);
@@ -1142,7 +1156,8 @@ __device__ inline void ss_step_stream(const SsStepArgs& args, int s, int* s_int,
         }
         __syncthreads();
     }
-    MatchOut b = ss_min_cost_matching(c, v, lsa, v.rows_b, n_b, v.cols_b, n_cb, ld, cfg.max_iou_dist, a.n_match, v.flag_t, v.un_d);
+    MatchOut b = ss_min_cost_matching(c, v, lsa, v.rows_b, n_b, v.cols_b, n_cb, ld, cfg.max_iou_dist, a.n_match, v.flag_t, v.un_d,
+                                      dbg ? dbg + 2 * ld * ld : nullptr, dbg ? dbg_shape + 2 : nullptr);
     const int n_match = b.n_match;
 
     SS_PROF(5);

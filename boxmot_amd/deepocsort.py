@@ -188,6 +188,21 @@ class DeepOcSort(BaseTracker):
         n = rows.value
         return dict(n=n, ints=ints[:n], kf=kf[:n], emb=emb[:n], frame_count=fc.value, id_count=ic.value)
 
+    def debug_costs_enable(self, on: bool = True) -> None:
+        """Keep copies of ``associate``'s matrices of every following update (parity tests; off by default)."""
+        _lib.check(self._lib.boxmot_hip_deepocsort_debug_costs_enable(self._handle, int(bool(on))))
+
+    def debug_costs(self, plane: int = 0):
+        """``(matrix, branch)`` of the last update's ``associate`` call: (detections, tracks) fp64; ``plane`` 0 ``final_cost``,
+        1 ``iou_matrix``, 2 the weighted ``emb_cost``; ``branch`` 0 no matrix, 1 permutation early-out, 2 solver
+        (include/boxmot_hip.h, boxmot_hip_deepocsort_debug_costs)."""
+        cap, nd = self.capacity()[:2]
+        buf = np.zeros(cap * nd, dtype=np.float64)
+        r, c, b = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(self._lib.boxmot_hip_deepocsort_debug_costs(self._handle, 0, int(plane), buf.ctypes.data, buf.size,
+                                                               ctypes.byref(r), ctypes.byref(c), ctypes.byref(b)))
+        return buf[: r.value * c.value].reshape(r.value, c.value).copy(), b.value
+
     def close(self) -> None:
         if getattr(self, "_handle", None):
             self._lib.boxmot_hip_deepocsort_destroy(self._handle)

@@ -34,6 +34,7 @@ class Scenario:
     emb_dim: int = 512
     stream: int = 0
     random_image: bool = True
+    crowd: bool = False       # every odd object sits a third of a box beside its even neighbour (overlapping pairs: IoU ~ 0.4-0.6)
 
     def __post_init__(self):
         self.seed = 42 + self.n_dets + 1000 * self.stream
@@ -47,6 +48,11 @@ class Scenario:
         self.cy = (idx // cols + 0.5) * cell_h
         self.bw = rng.uniform(0.4, 0.8, nt) * cell_w
         self.bh = rng.uniform(0.4, 0.8, nt) * cell_h
+        if self.crowd:          # (drawn from no RNG: the other sequences of a scene stay what they are without the flag)
+            odd = np.arange(1, nt, 2)
+            self.cx[odd] = self.cx[odd - 1] + 0.3 * self.bw[odd - 1]
+            self.cy[odd] = self.cy[odd - 1]
+            self.bw[odd], self.bh[odd] = self.bw[odd - 1], self.bh[odd - 1]
         emb = rng.standard_normal((nt, self.emb_dim))
         self.emb = (emb / np.linalg.norm(emb, axis=1, keepdims=True)).astype(np.float32)
         self.perm = rng.permutation(nt)

@@ -163,6 +163,21 @@ class StrongSort(BaseTracker):
         n = rows.value
         return dict(n=n, ints=ints[:n], kf=kf[:n], feat=feat[:n], frame_count=fc.value, next_id=ni.value)
 
+    def debug_costs_enable(self, on: bool = True) -> None:
+        """Keep copies of the two ``min_cost_matching`` cost matrices of every following update (parity tests; off by default)."""
+        _lib.check(self._lib.boxmot_hip_strongsort_debug_costs_enable(self._handle, int(bool(on))))
+
+    def debug_costs(self, stage: int, plane: int = 0) -> np.ndarray:
+        """(tracks, detections) fp64: ``stage`` 0 gated appearance / 1 IoU; ``plane`` 0 the metric's matrix, 1 after the
+        ``max_distance`` clamp (include/boxmot_hip.h, boxmot_hip_strongsort_debug_costs)."""
+        cap, nd = self.capacity()[:2]
+        big = max(cap, nd)
+        buf = np.zeros(big * big, dtype=np.float64)
+        r, c = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(self._lib.boxmot_hip_strongsort_debug_costs(self._handle, 0, int(stage), int(plane), buf.ctypes.data, buf.size,
+                                                               ctypes.byref(r), ctypes.byref(c)))
+        return buf[: r.value * c.value].reshape(r.value, c.value).copy()
+
     def close(self) -> None:
         if getattr(self, "_handle", None):
             self._lib.boxmot_hip_strongsort_destroy(self._handle)

@@ -205,6 +205,22 @@ int boxmot_hip_botsort_state_dump(
     int* ints, double* kf, float* smooth, float* misc, int* out_rows,
     int* out_frame_count, int* out_id_count);
 
+/* Parity/debug, the other half of state_dump: the association cost matrices of the LAST update of one stream, as the reference's
+ * functions return them -- (tracks, detections) row-major fp64.  Off by default (the step writes nothing); _enable(handle, 1) makes
+ * every following step keep copies.
+ *   stage 0: first association     (boxmot/trackers/bbox/botsort/botsort.py:306-317: pool x high-confidence detections)
+ *   stage 1: second association    (botsort.py:356: remaining tracked x low-confidence detections, IoU only)
+ *   stage 2: unconfirmed tracks    (botsort.py:396-413: unconfirmed x left-over detections)
+ *   plane 0: the matrix handed to linear_assignment (after fuse_score, matching.py:139-147, the proximity / appearance gates and
+ *            np.minimum); plane 1: iou_distance (matching.py:46-80) before score fusion; plane 2: embedding_distance
+ *            (matching.py:85-107) where the step evaluated it -- NaN elsewhere: the pairs behind the IoU gate are never evaluated on
+ *            the sparse path, every pair is on the dense fallback (more than 4096 ungated pairs).
+ * Row r is the r-th track of the stage's track list, column c the c-th detection of its detection list, in the reference's order. */
+int boxmot_hip_botsort_debug_costs_enable(BoxMOTHipBotSort* handle, int on);
+int boxmot_hip_botsort_debug_costs(
+    BoxMOTHipBotSort* handle, int stream, int stage, int plane,
+    double* out, long out_capacity, int* out_rows, int* out_cols);
+
 /* ReID C ABI, replaces boxmot_reid_capi_* (boxmot/native/cpp/trackers/base/include/boxmot/trackers/base/reid_capi.h:36-94) */
 BoxMOTHipReID* boxmot_hip_reid_create(const char* model_path, const float* blob, long n_floats, int max_crops);
 void boxmot_hip_reid_destroy(BoxMOTHipReID* handle);
@@ -418,6 +434,14 @@ int boxmot_hip_deepocsort_set_crop_bound(BoxMOTHipDeepOcSort* handle, int max_to
 int boxmot_hip_deepocsort_state_dump(BoxMOTHipDeepOcSort* handle, int stream, int* ints5, double* kf72, double* emb,
                                      int* out_rows, int* out_frame_count, int* out_id_count);
 
+/* parity debugging, cost values: the matrices of the LAST update's `associate` call (boxmot/trackers/association/association.py:61-152)
+ * in its own orientation, (detections, tracks) row-major fp64.  plane 0 = final_cost = -(iou_matrix + angle_diff_cost + emb_cost), what
+ * linear_assignment was given; 1 = iou_matrix (the association function's return); 2 = the weighted emb_cost.  *out_branch: 0 = no matrix
+ * (no detections), 1 = the already-a-permutation early-out (:104-108: planes 0 and 2 are not computed), 2 = the solver ran.  Off by default. */
+int boxmot_hip_deepocsort_debug_costs_enable(BoxMOTHipDeepOcSort* handle, int on);
+int boxmot_hip_deepocsort_debug_costs(BoxMOTHipDeepOcSort* handle, int stream, int plane, double* out, long out_capacity,
+                                      int* out_rows, int* out_cols, int* out_branch);
+
 /* ------------------------------------------------------------------------------------------------
  * StrongSORT (boxmot/trackers/bbox/strongsort/strongsort.py:16-126, sort/tracker.py, sort/track.py,
  * sort/linear_assignment.py).  No native backend exists in the reference; conventions as above.
@@ -487,6 +511,14 @@ int boxmot_hip_strongsort_track_count(BoxMOTHipStrongSort* handle, int stream, i
  * time_since_update, sample-bank size; kf72 (rows,72) = mean[8] ++ cov[8][8]; feat (rows, emb_dim) fp32. */
 int boxmot_hip_strongsort_state_dump(BoxMOTHipStrongSort* handle, int stream, int* ints6, double* kf72, float* feat,
                                      int* out_rows, int* out_frame_count, int* out_next_id);
+
+/* parity debugging, cost values: the matrices of the LAST update's two min_cost_matching calls (sort/linear_assignment.py:14-79),
+ * (tracks, detections) row-major fp64.  stage 0 = confirmed tracks x detections under the gated appearance metric (sort/tracker.py:108-122,
+ * gate_cost_matrix linear_assignment.py:145-198); stage 1 = the IoU stage (sort/iou_matching.py:49-87).  plane 0 = the metric's matrix as
+ * returned, plane 1 = after `cost > max_distance -> max_distance + 1e-5`, what linear_sum_assignment is given.  Off by default. */
+int boxmot_hip_strongsort_debug_costs_enable(BoxMOTHipStrongSort* handle, int on);
+int boxmot_hip_strongsort_debug_costs(BoxMOTHipStrongSort* handle, int stream, int stage, int plane, double* out, long out_capacity,
+                                      int* out_rows, int* out_cols);
 
 #ifdef __cplusplus
 }

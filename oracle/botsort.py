@@ -179,11 +179,13 @@ class BotSortOracle:
         c = self.cfg
         iou_d = self._iou_d(tracks, dets)
         gate = iou_d > c["proximity_thresh"]
+        self._last_parts = {"iou": np.array(iou_d, dtype=np.float64).reshape(len(tracks), len(dets)), "emb": None}
         if fuse:
             iou_d = matching.fuse_score(iou_d, np.array([d.conf for d in dets]))
         if not c["with_reid"]:
             return iou_d
         emb = matching.embedding_distance([t.smooth for t in tracks], [d.curr for d in dets])
+        self._last_parts["emb"] = np.array(emb, dtype=np.float64).reshape(len(tracks), len(dets))
         if emb_scale is not None:
             emb = emb / emb_scale
         emb[emb > c["appearance_thresh"]] = 1.0
@@ -254,7 +256,10 @@ class BotSortOracle:
             self._warp_tracks(list(pool) + list(unconfirmed), warp)
         dists = self._assoc_cost(pool, cand, None, c["fuse_first_associate"])
         m1, u_trk1, u_det1 = matching.linear_assignment(dists, c["match_thresh"])
-        self.last = {"dists_first": dists, "matches_first": m1}
+        # (the cost matrices of the three associations, kept for the value-parity tests: "dists" is what linear_assignment was given,
+        # "iou" = matching.iou_distance before score fusion, "emb" = matching.embedding_distance before scale / gates)
+        self.last = {"dists_first": dists, "matches_first": m1,
+                     "stages": [dict(dists=np.asarray(dists, dtype=np.float64).reshape(len(pool), len(cand)), **self._last_parts)]}
         for it, idet in m1:
             t = pool[it]
             if t.state == TRACKED:
@@ -269,6 +274,8 @@ class BotSortOracle:
         remain = [pool[i] for i in u_trk1 if pool[i].state == TRACKED]
         d2 = self._iou_d(remain, cand_lo)
         m2, u_trk2, _ = matching.linear_assignment(d2, c["second_match_thresh"])
+        d2m = np.asarray(d2, dtype=np.float64).reshape(len(remain), len(cand_lo))
+        self.last["stages"].append(dict(dists=d2m, iou=d2m, emb=None))
         for it, idet in m2:
             t = remain[it]
             if t.state == TRACKED:
@@ -287,6 +294,7 @@ class BotSortOracle:
         left = [cand[i] for i in u_det1]
         d3 = self._assoc_cost(unconfirmed, left, c["unconfirmed_emb_scale"], True)
         m3, u_unc, u_det3 = matching.linear_assignment(d3, c["unconfirmed_match_thresh"])
+        self.last["stages"].append(dict(dists=np.asarray(d3, dtype=np.float64).reshape(len(unconfirmed), len(left)), **self._last_parts))
         for it, idet in m3:
             unconfirmed[it].absorb(left[idet], fc, reactivate=False)
             activated.append(unconfirmed[it])

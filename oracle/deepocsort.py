@@ -376,8 +376,13 @@ def aw_max_metric(emb_cost, w_emb0, bottom):        # association.py:29-58
     return w_emb * emb_cost
 
 
-def associate(dets, trks, iou_threshold, velocities, previous_obs, vdc_weight, emb_cost, w_assoc_emb, aw_off, aw_param, asso=iou_batch):
-    """association.py:61-152; returns (matches (K,2) [det, trk], unmatched_dets, unmatched_trks)."""
+def associate(dets, trks, iou_threshold, velocities, previous_obs, vdc_weight, emb_cost, w_assoc_emb, aw_off, aw_param, asso=iou_batch,
+              record=None):
+    """association.py:61-152; returns (matches (K,2) [det, trk], unmatched_dets, unmatched_trks).  ``record``: a dict that receives
+    the matrices of this call for the cost-value parity tests -- "iou" (dets, trks) and "final_cost" (None when the solver was not
+    asked: no matrix, or the already-a-permutation early-out of :104-108)."""
+    if record is not None:
+        record.update(iou=None, final_cost=None)
     if len(trks) == 0:
         return np.empty((0, 2), dtype=int), np.arange(len(dets)), np.empty((0, 5), dtype=int)
     tr = previous_obs[..., np.newaxis]
@@ -393,6 +398,8 @@ def associate(dets, trks, iou_threshold, velocities, previous_obs, vdc_weight, e
     valid = np.ones(previous_obs.shape[0])
     valid[np.where(previous_obs[:, 4] < 0)] = 0
     iou = asso(dets, trks)
+    if record is not None:
+        record["iou"] = np.array(iou, dtype=np.float64)
     scores = np.repeat(dets[:, -1][:, np.newaxis], trks.shape[0], axis=1)
     valid = np.repeat(valid[:, np.newaxis], X.shape[1], axis=1)
     angle_cost = ((valid * diff_angle) * vdc_weight).T * scores
@@ -409,7 +416,10 @@ def associate(dets, trks, iou_threshold, velocities, previous_obs, vdc_weight, e
                     emb_cost = aw_max_metric(emb_cost, w_assoc_emb, aw_param)
                 else:
                     emb_cost *= w_assoc_emb
-            matched = _assign(-(iou + angle_cost + emb_cost))
+            final_cost = -(iou + angle_cost + emb_cost)
+            if record is not None:
+                record["final_cost"] = np.array(final_cost, dtype=np.float64)
+            matched = _assign(final_cost)
             if matched.size == 0:
                 matched = np.empty(shape=(0, 2))
     else:
@@ -499,8 +509,8 @@ class DeepOcSortOracle:
         else:
             emb_cost = dets_embs @ trk_embs.T
         matched, un_d, un_t = associate(dets[:, 0:5], trks, c["iou_threshold"], velocities, k_obs, c["inertia"],
-                                        emb_cost, c["w_association_emb"], c["aw_off"], c["aw_param"], asso)
-        self.last = {"emb_cost": emb_cost, "matched": matched}
+                                        emb_cost, c["w_association_emb"], c["aw_off"], c["aw_param"], asso, record=(rec := {}))
+        self.last = {"emb_cost": emb_cost, "matched": matched, **rec}
         for m in matched:
             self.tracks[m[1]].update(dets[m[0], :])
             self.tracks[m[1]].update_emb(dets_embs[m[0]], alpha=dets_alpha[m[0]])

@@ -334,9 +334,13 @@ class StrongSortOracle:
     # ---- association ----
     def _min_cost_matching(self, metric, max_distance, tracks, dets, track_idx, det_idx):   # :14-79
         if len(det_idx) == 0 or len(track_idx) == 0:
+            self.last_costs.append(None)
             return [], track_idx, det_idx
         cost = metric(tracks, dets, track_idx, det_idx)
+        # (cost-value parity tests: the metric's matrix as returned -- gated appearance, or IoU -- and the clamped one the solver gets)
+        self.last_costs.append({"raw": np.array(cost, dtype=np.float64)})
         cost[cost > max_distance] = max_distance + 1e-5
+        self.last_costs[-1]["clamped"] = np.array(cost, dtype=np.float64)
         rows, cols = linear_sum_assignment(cost)
         matches, un_t, un_d = [], [], []
         for col, d in enumerate(det_idx):
@@ -386,6 +390,7 @@ class StrongSortOracle:
         c = self.cfg
         self.frame_count += 1
         self.last_app = {}
+        self.last_costs = []            # one entry per min_cost_matching call of this frame: stage A (appearance), stage B (IoU)
         dets = np.asarray(dets)
         if dets.size == 0:
             dets = np.empty((0, 7), dtype=np.float32)

@@ -66,6 +66,20 @@ class EmuBotSort:
             raise RuntimeError(f"emulated kernel status {status}")
         return out[: out_n.value].copy()
 
+    def debug_costs_enable(self):
+        self.lib.emu_debug_costs_enable.argtypes = [ctypes.c_void_p]
+        self.lib.emu_debug_costs_enable(self.h)
+
+    def debug_costs(self, stage, plane=0):
+        """(tracks, detections) fp64 cost matrix of the last update (boxmot_hip_botsort_debug_costs' planes)."""
+        self.lib.emu_debug_costs.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        buf = np.zeros(self.cap * self.nd, dtype=np.float64)
+        r, c = ctypes.c_int(0), ctypes.c_int(0)
+        n = self.lib.emu_debug_costs(self.h, stage, plane, buf.ctypes.data, ctypes.byref(r), ctypes.byref(c))
+        if n < 0:
+            raise RuntimeError("debug costs are not enabled")
+        return buf[:n].reshape(r.value, c.value).copy()
+
     def dump(self, which):
         ints = np.zeros((self.cap, 6), dtype=np.int32)
         kf = np.zeros((self.cap, self.kf_stride), dtype=np.float64)
@@ -138,6 +152,20 @@ class EmuDeepOcSort:
             raise RuntimeError(f"emulated kernel status {status}")
         return out[: out_n.value].copy()
 
+    def debug_costs_enable(self):
+        self.lib.emu_docs_debug_costs_enable.argtypes = [ctypes.c_void_p]
+        self.lib.emu_docs_debug_costs_enable(self.h)
+
+    def debug_costs(self, plane=0):
+        """((detections, tracks) fp64 matrix, branch) of the last update's ``associate`` (boxmot_hip_deepocsort_debug_costs' planes)."""
+        self.lib.emu_docs_debug_costs.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        buf = np.zeros(self.cap * self.nd, dtype=np.float64)
+        r, c = ctypes.c_int(0), ctypes.c_int(0)
+        branch = self.lib.emu_docs_debug_costs(self.h, plane, buf.ctypes.data, ctypes.byref(r), ctypes.byref(c))
+        if branch < 0:
+            raise RuntimeError("debug costs are not enabled")
+        return buf[: r.value * c.value].reshape(r.value, c.value).copy(), branch
+
     def dump(self):
         ints = np.zeros((self.cap, 5), dtype=np.int32)
         kf = np.zeros((self.cap, self.kf_stride), dtype=np.float64)
@@ -206,6 +234,21 @@ class EmuStrongSort:
         self.lib.emu_ss_app.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         self.lib.emu_ss_app(self.h, out.ctypes.data, out.shape[0], out.shape[1])
         return out[:rows, :cols]
+
+    def debug_costs_enable(self):
+        self.lib.emu_ss_debug_costs_enable.argtypes = [ctypes.c_void_p]
+        self.lib.emu_ss_debug_costs_enable(self.h)
+
+    def debug_costs(self, stage, plane=0):
+        """(tracks, detections) fp64 matrix of the last update's min_cost_matching call ``stage`` (boxmot_hip_strongsort_debug_costs' planes)."""
+        self.lib.emu_ss_debug_costs.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        big = max(self.cap, self.nd)
+        buf = np.zeros(big * big, dtype=np.float64)
+        r, c = ctypes.c_int(0), ctypes.c_int(0)
+        n = self.lib.emu_ss_debug_costs(self.h, stage, plane, buf.ctypes.data, ctypes.byref(r), ctypes.byref(c))
+        if n < 0:
+            raise RuntimeError("debug costs are not enabled")
+        return buf[:n].reshape(r.value, c.value).copy()
 
     def dump(self):
         ints = np.zeros((self.cap, 6), dtype=np.int32)

@@ -59,7 +59,7 @@ void* thread_main(void* p) {
     ThreadArg* ta = static_cast<ThreadArg*>(p);
     threadIdx.x = ta->tid;
     blockIdx.x = 0;
-    geo::botsort_step_stream<NTHR>(ta->e->args, 0, g_s_int, g_s_dbl, g_sA, g_sB, g_dyn);
+    geo::botsort_step_stream<NTHR, true>(ta->e->args, 0, g_s_int, g_s_dbl, g_sA, g_sB, g_dyn);
     return nullptr;
 }
 
@@ -92,6 +92,25 @@ void* emu_create_lists(const double* cd, const int* ci, int cap, int nd, int dim
     e->block.block_barrier.init(NTHR);
     for (int w = 0; w < EMU_MAX_WAVES; ++w) e->block.wave_barrier[w].init(EMU_WAVE);
     return e;
+}
+
+// parity debugging: BotSortStepArgs::dbg_cost / dbg_shape (what boxmot_hip_botsort_debug_costs_enable + _debug_costs do in the library)
+void emu_debug_costs_enable(void* h) {
+    Emu* e = static_cast<Emu*>(h);
+    if (e->args.dbg_cost) return;
+    e->args.dbg_cost = e->alloc.get<double>((size_t)bm::DBG_STAGES * bm::DBG_PLANES * e->nd * e->cap);
+    e->args.dbg_shape = e->alloc.get<int>(bm::DBG_STAGES * 2);
+}
+// out (rows, cols) row-major = (tracks, detections); returns rows * cols
+int emu_debug_costs(void* h, int stage, int plane, double* out, int* rows, int* cols) {
+    Emu* e = static_cast<Emu*>(h);
+    if (!e->args.dbg_cost) return -1;
+    const int R = e->args.dbg_shape[stage * 2], C = e->args.dbg_shape[stage * 2 + 1];
+    const double* m = e->args.dbg_cost + ((size_t)stage * bm::DBG_PLANES + plane) * e->nd * e->cap;
+    for (int r = 0; r < R; ++r)
+        for (int c = 0; c < C; ++c) out[(size_t)r * C + c] = m[(size_t)c * e->cap + r];
+    *rows = R; *cols = C;
+    return R * C;
 }
 
 void emu_destroy(void* h) {

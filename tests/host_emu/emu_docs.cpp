@@ -85,6 +85,24 @@ void* emu_docs_create(const double* cd, const int* ci, int cap, int nd, int dim)
     return e;
 }
 
+// parity debugging: DocsStepArgs::dbg_cost / dbg_shape (what boxmot_hip_deepocsort_debug_costs_enable + _debug_costs do in the library)
+void emu_docs_debug_costs_enable(void* h) {
+    Emu* e = static_cast<Emu*>(h);
+    if (e->args.dbg_cost) return;
+    e->args.dbg_cost = e->alloc.get<double>((size_t)bm::DOCS_DBG_PLANES * e->nd * e->cap);
+    e->args.dbg_shape = e->alloc.get<int>(4);
+}
+// out (detections, tracks) row-major; returns the branch (0 no matrix, 1 permutation early-out, 2 solver), -1 when not enabled
+int emu_docs_debug_costs(void* h, int plane, double* out, int* rows, int* cols) {
+    Emu* e = static_cast<Emu*>(h);
+    if (!e->args.dbg_cost) return -1;
+    const int R = e->args.dbg_shape[0], C = e->args.dbg_shape[1];
+    const double* m = e->args.dbg_cost + (size_t)plane * e->nd * e->cap;
+    for (int r = 0; r < R; ++r) std::memcpy(out + (size_t)r * C, m + (size_t)r * e->cap, (size_t)C * 8);
+    *rows = R; *cols = C;
+    return e->args.dbg_shape[2];
+}
+
 void emu_docs_destroy(void* h) {
     Emu* e = static_cast<Emu*>(h);
     for (void* p : e->alloc.owned) std::free(p);

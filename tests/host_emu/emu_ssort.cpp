@@ -104,6 +104,26 @@ void* emu_ss_create(const double* cd, const int* ci, int cap, int nd, int dim) {
     return e;
 }
 
+// parity debugging: SsStepArgs::dbg_cost / dbg_shape (what boxmot_hip_strongsort_debug_costs_enable + _debug_costs do in the library)
+void emu_ss_debug_costs_enable(void* h) {
+    Emu* e = static_cast<Emu*>(h);
+    if (e->args.dbg_cost) return;
+    const size_t big = e->cap > e->nd ? e->cap : e->nd;
+    e->args.dbg_cost = e->alloc.get<double>(4 * big * big);
+    e->args.dbg_shape = e->alloc.get<int>(4);
+}
+// out (tracks, detections) row-major; returns rows * cols, -1 when not enabled
+int emu_ss_debug_costs(void* h, int stage, int plane, double* out, int* rows, int* cols) {
+    Emu* e = static_cast<Emu*>(h);
+    if (!e->args.dbg_cost) return -1;
+    const size_t big = e->cap > e->nd ? e->cap : e->nd;
+    const int R = e->args.dbg_shape[stage * 2], C = e->args.dbg_shape[stage * 2 + 1];
+    const double* m = e->args.dbg_cost + (size_t)(stage * 2 + plane) * big * big;
+    for (int r = 0; r < R; ++r) std::memcpy(out + (size_t)r * C, m + (size_t)r * big, (size_t)C * 8);
+    *rows = R; *cols = C;
+    return R * C;
+}
+
 void emu_ss_destroy(void* h) {
     Emu* e = static_cast<Emu*>(h);
     for (void* p : e->alloc.owned) std::free(p);

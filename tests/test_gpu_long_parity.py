@@ -457,7 +457,10 @@ def test_config3_reid_inside_update_full_size_vs_reference_rows(mode, weights, b
             _lib.check(lib.boxmot_hip_deepocsort_set_crop_bound(h, 4))
             _lib.check(lib.boxmot_hip_deepocsort_step_device_frames(h, d_dets.data_ptr(), d_n.data_ptr(), ptrs.data_ptr(), 1080, 1920,
                                                                     d_out.data_ptr(), d_out_n.data_ptr()))
+            # (round-5 advisor finding: the report survives the bound being taken back to -1 before the synchronise)
+            _lib.check(lib.boxmot_hip_deepocsort_set_crop_bound(h, -1))
             assert lib.boxmot_hip_deepocsort_synchronize(h) == 0 and "more ReID crops than the bound" in _lib.last_error()
+            _lib.check(lib.boxmot_hip_deepocsort_synchronize(h))          # reported once
             # ... and that frame was switched off for the step (no rows, no state change on stale embeddings: round-4 advisor finding):
             # the same frame stepped again with a sufficient bound returns the reference's rows for it
             assert int(d_out_n[0]) == 0

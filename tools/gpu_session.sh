@@ -8,6 +8,8 @@
 # steps
 #   build      compile the tree's sources ON THIS BOX (BOXMOT_FORCE_BUILD=1), so the binary that runs is not a prebuilt one
 #   tests      python -m pytest tests -m gpu                                  -> pytest.log
+#   fast       python -m pytest tests -m "gpu and fast" (tests/conftest.py FAST_GPU: about a minute) -> pytest_fast.log
+#   costs      tests/test_gpu_cost_values.py (association cost values vs the reference's matrices) -> pytest_costs.log
 #   reid       the ReID GPU tests only                                        -> pytest_reid.log
 #   bench      default bench.py                                               -> bench.json / bench.err
 #   benchq     bench.py without CPU baseline / side lines (quick)             -> benchq.json
@@ -38,6 +40,8 @@ for step in "$@"; do
   case $step in
     build)   BOXMOT_FORCE_BUILD=1 python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1; tail -n 2 $O/build.log ;;
     tests)   timeout 1200 python -m pytest tests -q -m gpu --maxfail=10 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -n 8 $O/pytest.log | cut -c1-220 ;;
+    fast)    timeout 400 python -m pytest tests -q -m "gpu and fast" --durations=8 > $O/pytest_fast.log 2>&1; echo "pytest rc=$?" >> $O/pytest_fast.log; tail -n 16 $O/pytest_fast.log | cut -c1-220 ;;
+    costs)   timeout 400 python -m pytest tests/test_gpu_cost_values.py -q -s > $O/pytest_costs.log 2>&1; echo "pytest rc=$?" >> $O/pytest_costs.log; grep -E "max \||passed|failed|rc=|Error" $O/pytest_costs.log | cut -c1-220 ;;
     reid)    timeout 600 python -m pytest tests/test_gpu_reid.py -q -s --maxfail=10 > $O/pytest_reid.log 2>&1; echo "pytest rc=$?" >> $O/pytest_reid.log; grep -E "calibrated|passed|failed|rc=" $O/pytest_reid.log | cut -c1-220 ;;
     bench)   timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 1500 $O/bench.json; echo ;;
     benchq)  timeout 400 python bench.py --no-cpu-baseline --no-side-configs --no-m1 --reid-mode $MODE > $O/benchq_m$MODE.json 2> $O/benchq.err; tail -c 900 $O/benchq_m$MODE.json; echo ;;
