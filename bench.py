@@ -58,7 +58,7 @@ FLOP_PER_CROP = 2 * 82_314_880          # OSNet x0.25 forward, BASELINE.md secti
 # here (separate --pmc passes, gfx950 FETCH correction applied by profiles/summarize_pmc.py) -- counters cannot be collected
 # inside a timed run, so the line carries the profile's figure and says which file it came from
 # one committed profile per kernel family (mode): fused fp32-grade (2), fused fp16 (1)
-TRAFFIC_PROFILES = {2: ("profiles/r5_pmc_traffic_final.txt", "profiles/r4_pmc_traffic_final.txt", "profiles/r3_pmc_traffic_final.txt", "profiles/r3_pmc_traffic_hp.txt"),
+TRAFFIC_PROFILES = {2: ("profiles/r6_pmc_traffic_final.txt", "profiles/r5_pmc_traffic_final.txt", "profiles/r4_pmc_traffic_final.txt", "profiles/r3_pmc_traffic_final.txt", "profiles/r3_pmc_traffic_hp.txt"),
                     1: ("profiles/r4_pmc_traffic_m1.txt", "profiles/r3_pmc_traffic.txt", "profiles/r2_pmc_traffic.txt", "profiles/r1h_pmc_traffic.txt")}
 
 
@@ -89,13 +89,14 @@ def profile_traffic_bytes_per_crop(mode):
     return None, None, False
 
 
-# Dense matrix-pipe peak the ReID region is priced against, per kernel family.  Mode 2 (fp32-grade fused kernels) computes its wide
-# 1x1 convolutions and the stem as fp16 hi/lo operand pairs (three fp16 MFMAs per product tile) and the LightConv chains on the
-# fp32 matrix pipe; it is priced against the fp16 peak like mode 1 -- the stricter of the two peaks it touches -- on ALGORITHMIC flops
-# (the operand-splitting MFMAs are overhead, not work).
+# Dense matrix-pipe peak the ReID region is priced against, per kernel family.  Mode 2 (fp32-grade fused kernels) computes EVERY 1x1
+# convolution, the LightConv chains and the stem with fp16 (hi, lo) operand pairs on the fp16 matrix pipe (v_mfma_f32_16x16x32_f16 only:
+# three MFMAs per K = 32 product tile, two for a K = 16 layer), fp32 accumulation, and the depthwise taps / gates / shortcuts in fp32 on
+# the vector ALU -- there is no fp32 MFMA in the family (its fp32-pipe variant, BM_HP_PW32, measured 14 % slower: profiles/r6_hp_variants_ab.txt).
+# It is priced against the fp16 dense peak, like mode 1, on ALGORITHMIC flops (the operand-splitting MFMAs are overhead, not work).
 PEAK_TFLOPS = {0: 157.3, 1: 2500.0, 2: 2500.0}
-DTYPE = {0: "f32", 1: "f16", 2: "f32 (fp16 hi+lo operand pairs / fp32 MFMA, fp32 accumulate)"}
-REID_KERNELS = {0: "per-layer fp32 (v1)", 1: "fused fp16 MFMA", 2: "fused fp32-grade (split-fp16 + fp32 MFMA)"}
+DTYPE = {0: "f32", 1: "f16", 2: "f32-grade: fp16 (hi, lo) operand pairs on the fp16 matrix pipe, fp32 accumulate, fp32 vector taps"}
+REID_KERNELS = {0: "per-layer fp32 (v1)", 1: "fused fp16 MFMA", 2: "fused fp32-grade (split-fp16 operand pairs, fp16 MFMA, fp32 accumulate)"}
 
 
 def parse(argv=None):
@@ -121,7 +122,10 @@ def parse(argv=None):
     ap.add_argument("--side-budget-s", type=float, default=300.0,
                     help="wall budget of the side measurements (configurations 3 and 5, child processes): what does not fit is "
                          "reported as skipped / timed out, the headline line is printed regardless")
-    ap.add_argument("--cpu-frames", type=int, default=10)
+    # SURVEY.md section 8(d) asks the id gate over the measured frames; the reference leg costs ~0.4 s per frame on the GPU box's host
+    # (ReID inside update on the CPU), so 40 gated frames ~ 16 s: the default.  cpu_baseline() stops at its wall budget on a slow host
+    # and the line reports how many frames were actually gated (`parity_id_gate_frames`).
+    ap.add_argument("--cpu-frames", type=int, default=40)
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--stub-tracker", action="store_true",
                     help="TEST ONLY: run the N > 1 control flow on CPU with a stand-in for the device handle (no measurement)")
@@ -349,10 +353,10 @@ def side_configs(budget_s):
     # the id gate's CPU oracle (an fp32 backbone per frame) gets 35 % of a line's share (the tracker-math gate a third of that again): 16 frames when the host is quick, fewer -- never
     # under 4 -- when it is not; the line reports the count (`id_gate_frames`)
     gate_s = f"{0.35 * budget_s / 2:.0f}"
-    plan = (("config3", ["--config", "c3", "--streams", "8", "--steps", "16", "--warmup", "6", "--check-frames", "16", "--reid-mode", "2",
+    plan = (("config3", ["--config", "c3", "--streams", "8", "--steps", "24", "--warmup", "6", "--check-frames", "16", "--reid-mode", "2",
                          "--gate-budget-s", gate_s]),
             # configuration 5: 104 warm-up frames fill every sample bank (nn_budget 100), so the timed steps are steady state
-            ("config5", ["--config", "c5", "--streams", "2", "--steps", "8", "--warmup", "104", "--check-frames", "16", "--gate-budget-s", gate_s]))
+            ("config5", ["--config", "c5", "--streams", "2", "--steps", "24", "--warmup", "104", "--check-frames", "16", "--gate-budget-s", gate_s]))
     for i, (key, args) in enumerate(plan):
         left = t_end - time.time()
         share = left / (len(plan) - i)
@@ -420,6 +424,31 @@ def alt_family_line(kw, sd, dev, reid_mode, S=256, W=10, K=40):
            "frac_of_peak": tfl / PEAK_TFLOPS[reid_mode] if tfl else None}
     out.update(reid_parity_gates(sd, reid_mode))
     return out
+
+
+def all_stream_invariants(out_h, out_n_h, cnt_h, S, T):
+    """Oracle-free checks over EVERY stream and EVERY frame of the run (warm-up + timed), so that an indexing fault on a stream the id
+    gate does not sample cannot hide: in the benchmark scene every object is introduced in the first three frames and re-found
+    when it is shown again, so from frame 3 on a stream returns exactly one row per detection; ids are the per-stream track numbers
+    1 .. N_TRACKS; a frame never returns an id or a detection index twice; detection indices address the frame's detections."""
+    rows_ok = ids_ok = dup_ok = det_ok = True
+    bad = []
+    for t in range(T):
+        for s in range(S):
+            n = int(out_n_h[t, s])
+            r = out_h[t, s, :n]
+            ids, det = r[:, 4].astype(np.int64), r[:, 7].astype(np.int64)
+            a = (n == int(cnt_h[t, s])) if t >= 3 else (n <= int(cnt_h[t, s]))
+            b = bool(((ids >= 1) & (ids <= N_TRACKS)).all())
+            c = len(np.unique(ids)) == n and len(np.unique(det)) == n
+            d = bool(((det >= 0) & (det < int(cnt_h[t, s]))).all())
+            if not (a and b and c and d) and len(bad) < 4:
+                bad.append([t, s, n, int(cnt_h[t, s])])
+            rows_ok &= a; ids_ok &= b; dup_ok &= c; det_ok &= d
+    return {"all_streams_invariants": {"streams": S, "frames": T, "rows_equal_detections_from_frame_3": bool(rows_ok),
+                                       "ids_within_1_to_n_tracks": bool(ids_ok), "no_duplicate_id_or_det_ind_in_a_frame": bool(dup_ok),
+                                       "det_ind_addresses_a_detection": bool(det_ok), "all_true": bool(rows_ok and ids_ok and dup_ok and det_ok),
+                                       "first_violations_t_s_rows_dets": bad}}
 
 
 def reid_parity_gates(sd, reid_mode):
@@ -727,6 +756,7 @@ def main(argv=None):
             res["config"]["parity_ids_exact_vs_oracle_streams"] = {str(k): v for k, v in gate.items()}
             res["config"]["parity_ids_exact_all_gated_streams"] = all(gate.values())
             res["config"]["parity_id_gate_frames"] = int(min(len(rows), T))
+            res["config"].update(all_stream_invariants(out_h, out_n_h, cnt_h, S, T))
             if a.mode == "reid":
                 res["config"].update(reid_parity_gates(sd, a.reid_mode))
         # the headline with its gates, as soon as they exist (stderr; the ONE stdout line stays last): what follows are side

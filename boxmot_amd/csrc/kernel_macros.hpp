@@ -84,6 +84,14 @@ __device__ inline float bm_wave_sum_f32(float v) {
 // subtraction itself) instead of a convert + a subtract
 #define BM_RESID_F16(hp, hi, v, out) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[" #hi ",0,0] op_sel_hi:[1,0,0]" : "=v"(out) : "v"(hp), "v"(v))
 #endif
+#ifndef BM_RESID_PK_F16
+// the fp16 pair (fp16(v0 - h.lo), fp16(v1 - h.hi)) of the packed fp16 pair `hp`: v_fma_mixlo_f16 + v_fma_mixhi_f16 -- the residual AND its
+// conversion in one instruction per value (the difference of a value and its own fp16 rounding is exact in fp32, so the single rounding
+// to fp16 returns what BM_RESID_F16 followed by a conversion returns)
+#define BM_RESID_PK_F16(hp, v0, v1, out) \
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" \
+        : "=&v"(out) : "v"(hp), "v"(v0), "v"(v1))
+#endif
 #ifndef BM_RELU_F32
 // max(v, 0) as one integer max on the bit pattern (negative floats are negative ints); a float max costs a second,
 // canonicalising v_max under IEEE mode

@@ -85,10 +85,37 @@
 #ifndef BM_HP_DW_PREFETCH
 #define BM_HP_DW_PREFETCH 0
 #endif
+// Depthwise 3x3 of stages 0 / 1 ON REGISTERS (1) instead of through an LDS image (0; A/B switch, profiles/r6_hp_dwreg_ab.txt).
+// A wave owns whole image rows (8 rows x 32 pixels in stage 0, 4 x 16 in stage 1), so the vertical neighbours of a pixel are other
+// registers of the SAME lane and the horizontal ones are the adjacent lanes of its 16-lane row: x +- 1 come from DPP row shifts
+// (v_mov_b32_dpp row_shr:1 / row_shl:1, zero fill = the zero padding at the image edge; in stage 0 the seam between the two 16-pixel
+// halves of a row is closed with a row_ror of the other half's register as the `old` operand).  Only the rows at the edge of a wave's
+// strip go through LDS -- a double-buffered halo exchange of 4 KiB per wave and layer, ONE workgroup barrier per layer -- instead of
+// the whole 128 / 48 KiB tensor written and read three times with two barriers: the un-instrumented ablations (BM_HP_ABL,
+// profiles/r6_hp_ablation.txt) price the image writes at 28 % and the image reads at 30 % of a stage-0 block kernel.  Same taps in the
+// same order on the same fp32 values: bit-identical embeddings (tests/test_reid_emu.py).
+#ifndef BM_HP_DW_REG
+#define BM_HP_DW_REG 0
+#endif
+#ifndef BM_HP_PW_BATCH
+#define BM_HP_PW_BATCH 1            // measured -2 % / -5 % on the two stage-0 block kernels (profiles/r6_hp_variants_ab.txt)
+#endif
+#ifndef BM_HP_DW_PIPE
+#define BM_HP_DW_PIPE 0             // LDS reads of the depthwise pass issued this many input rows ahead of their taps (0: at their use)
+#endif
+#ifndef BM_HP_DWREG_FENCE
+#define BM_HP_DWREG_FENCE 1
+#endif
 #ifndef BM_HP_NT
 #define BM_HP_NT 0
 #endif
-#if BM_HP_NT
+#ifndef BM_HP_ABL
+#define BM_HP_ABL 0         // timing-only ablation mask (tools/hp_prof), described below
+#endif
+#if (BM_HP_ABL & 64)
+#define BM_NT_STORE(ptr, val) hp_keep(val)
+#define BM_NT_LOAD(ptr) (*(ptr))
+#elif BM_HP_NT
 #define BM_NT_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
 #define BM_NT_LOAD(ptr) __builtin_nontemporal_load(ptr)
 #else
@@ -96,9 +123,29 @@
 #define BM_NT_LOAD(ptr) (*(ptr))
 #endif
 
+// TIMING-ONLY ablations (tools/hp_prof built with -DBM_HP_ABL=<mask>; never set in the library): each bit compiles ONE phase's work out
+// of k_osblock_hp while everything else stays, so the un-instrumented cost of that phase in situ is time(base) - time(ablated) -- the
+// phase clocks of BM_OSBLOCK_PROF serialise the wave at every stamp (2.3 x slower) and say where a wave's dependent work is, not what
+// the overlapped kernel pays for it.  The results of an ablated build are garbage.  profiles/r6_hp_ablation.txt
+//   1 depthwise taps (LDS reads kept)        2 depthwise LDS reads (taps on registers)   4 LightConv 1x1 (split + MFMAs)
+//   8 image writes                          16 branch input (conv1 recompute / x1 reload)  32 epilogue MFMAs + output split
+//  64 epilogue global stores               128 epilogue operand loads                    256 ChannelGate arithmetic
+// 512 the two barriers of a LightConv layer 1024 conv1 (loads + MFMAs; not the per-branch recompute)  2048 epilogue fragment reads from LDS
+#ifndef BM_HP_ABL
+#define BM_HP_ABL 0
+#endif
+
 #include <type_traits>
 
 namespace bm {
+
+constexpr bool hp_abl(int bit) { return (BM_HP_ABL & bit) != 0; }
+#ifndef BM_OPAQUE_F4
+#define BM_OPAQUE_F4(v) asm volatile("" : "+v"((v)[0]), "+v"((v)[1]), "+v"((v)[2]), "+v"((v)[3]))
+#endif
+__device__ inline void hp_keep(f4 v) { asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); }
+__device__ inline void hp_keep(h8 v) { const f4 f = __builtin_bit_cast(f4, v); hp_keep(f); }
+__device__ inline void hp_keep(h4 v) { typedef float f2v __attribute__((ext_vector_type(2))); const f2v f = __builtin_bit_cast(f2v, v); asm volatile("" ::"v"(f[0]), "v"(f[1])); }
 
 template <int STAGE>
 struct GeoHP {
@@ -117,7 +164,11 @@ struct GeoHP {
     // stage 2 (8-pixel rows): compact pitch (10 pixels): 2-way conflicts between the two rows of a tile, but two workgroups per CU
     static constexpr int ROWP = STAGE == 0 ? 34 * 16 : (STAGE == 1 ? 18 * 16 : 160);
     static constexpr int PLANE = STAGE == 0 ? 141 * 256 : (STAGE == 1 ? 39 * 256 : 12 * 256);
-    static constexpr int IMG = 4 * KT * PLANE;
+    // BM_HP_DW_REG: no image -- the halo exchange [2 buffers][NWAVES][top row, bottom row][KT][NH] tiles of 1 KiB (lane-linear f4)
+    static constexpr bool DWREG = BM_HP_DW_REG && STAGE < 2;
+    static constexpr int NH = STAGE == 0 ? 2 : 1;                     // 16-pixel tiles per image row
+    static constexpr int HALO = 2 * NWAVES * 2 * KT * NH * 1024;
+    static constexpr int IMG = DWREG ? HALO : 4 * KT * PLANE;
     // LightConv weights of the whole block, staged once into LDS behind the image: no global load (and no exposed L2 / fabric
     // round trip) inside the 10-layer loop.  Stages 1 / 2: everything (1x1 fragment pairs, depthwise taps, biases = the packed
     // blob's light records); stage 0 has 19 KiB left beside its 141 KiB image: depthwise taps + biases only, the 1x1 fragments
@@ -132,6 +183,7 @@ struct GeoHP {
     static constexpr int FLAGS = TBUF + 4 * NWAVES * HID * 4;       // [2][NWAVES] int: layer written / layer read (BM_HP_NBR_SYNC)
     static constexpr int LDS_BYTES = FLAGS + (BM_HP_NBR_SYNC ? 2 * NWAVES * 4 : 0);
     static_assert(PLANE >= (H + 2) * ROWP && PLANE % 256 == 0, "plane holds the haloed image; stride keeps the lane groups on disjoint slots");
+    static_assert(!DWREG || (NWAVES == 8 && NT % NH == 0 && !BM_HP_NBR_SYNC), "register-resident depthwise: a wave owns whole rows");
     static_assert(LDS_BYTES <= 163840 / (STAGE == 2 ? 2 : 1), "LDS budget");
 };
 
@@ -165,7 +217,15 @@ __device__ inline f4 add_f4(f4 a, f4 b) {
 #endif
 __device__ inline void split4(f4 v, h4& h, h4& l) {
     h = to_h4(v);
-#if BM_HP_SPLIT_MIX
+#if BM_HP_SPLIT_MIX == 2
+    // residual and its conversion in ONE instruction per value (v_fma_mixlo_f16 / v_fma_mixhi_f16): 6 instructions per split4
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    const u2v hp = __builtin_bit_cast(u2v, h);
+    u2v lp;
+    BM_RESID_PK_F16(hp[0], v[0], v[1], lp[0]);
+    BM_RESID_PK_F16(hp[1], v[2], v[3], lp[1]);
+    l = __builtin_bit_cast(h4, lp);
+#elif BM_HP_SPLIT_MIX
     typedef unsigned u2v __attribute__((ext_vector_type(2)));
     const u2v hp = __builtin_bit_cast(u2v, h);
     f4 r;
@@ -308,6 +368,13 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
 
     // ---- conv1: 1x1 CIN -> MID, + bias, ReLU (osnet.py:248) ----
     auto conv1_into = [&](f4 (&x1)[NT][KT]) {
+        if constexpr (hp_abl(1024) && !(STAGE == 0 && CIN == 16)) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int ct = 0; ct < KT; ++ct) x1[i][ct] = f4{0.25f, 0.5f, 0.125f, 1.f};
+            return;
+        }
         unsigned xo = 0;
         if constexpr (RECOMP) BM_OPAQUE_U32(xo);       // re-read per branch, do not hoist 16 tiles of input out of the branch loop
         f4 bias[KT];
@@ -374,8 +441,19 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
 
     // 1x1 (linear, mid -> mid) of a LightConv on the fp32 tile set: weight fragments held in registers for the layer, operands
     // split in registers
+    // the next layer's 1x1 of a tile right after the tile's depthwise row (1: its MFMAs run "under" the next rows' taps) or for all tiles after
+    // the pass (0).  BM_HP_PW_BATCH = 1 un-fuses the mid-width-16 stage as well: a v_pk_fma_f32 issued beside an MFMA costs more than both
+    // apart (tools/coissue_bench.hip, profiles/r6_coissue_microbench.txt: 8 MFMAs + 32 packed FMAs take 743 cycles together, 594 apart), and the
+    // fused form alternates 18 packed taps and 2 MFMAs per tile.
+    constexpr bool PW_FUSED = KT == 1 && !BM_HP_PW_BATCH;
+    constexpr bool PW32 = BM_HP_PW32 && STAGE == 0;       // LightConv 1x1 on the fp32 matrix pipe (reid_hp_pack.hpp)
     auto load_pw = [&](int l, h8 (&A)[KT][2]) {         // 1x1 fragment pairs of LightConv l (0..9)
         const unsigned char* src = G::W_ALL ? wl + l * G::WREC : wts + bp.light0 + (long)l * bp.light_bytes + bp.light_pw;
+        if constexpr (PW32) {                           // one fp32 fragment (16 bytes per lane); kept in the first half of A[0][0]'s slot
+            const f4 a = *reinterpret_cast<const f4*>(src + lane * 16);
+            A[0][0] = __builtin_bit_cast(h8, a);
+            return;
+        }
 #pragma unroll
         for (int ct = 0; ct < KT; ++ct) {
             A[ct][0] = *reinterpret_cast<const h8*>(src + (long)ct * HP_FRAG_PAIR + lane * 16);
@@ -383,6 +461,16 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
         }
     };
     auto pointwise = [&](const h8 (&A)[KT][2], f4 (&c)[KT]) {
+        if constexpr (hp_abl(4)) return;
+        if constexpr (PW32) {
+            const f4 a = __builtin_bit_cast(f4, A[0][0]);
+            const f4 x = c[0];
+            f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc = BM_MFMA_F32_K4(a[kk], x[kk], acc);
+            c[0] = acc;
+            return;
+        }
         h4 hh[KT], ll[KT];
 #pragma unroll
         for (int ct = 0; ct < KT; ++ct) split4(c[ct], hh[ct], ll[ct]);
@@ -396,6 +484,7 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
         }
     };
 
+    if constexpr (!G::DWREG)
     for (int e = tid * 16; e < G::IMG; e += 64 * G::NWAVES * 16) *reinterpret_cast<f4*>(tbuf + e) = f4{0.f, 0.f, 0.f, 0.f};   // halo = zero padding
     constexpr bool NBR = BM_HP_NBR_SYNC && STAGE < 2;
     volatile int* wr_flag = reinterpret_cast<volatile int*>(lds + G::FLAGS);        // wr_flag[w]: last layer (1-based) wave w has written
@@ -440,7 +529,12 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
 #pragma unroll 1
     for (int br = 0; br < 4; ++br) {
         f4 cur[NT][KT];
-        if constexpr (X1_MEM) {
+        if constexpr (hp_abl(16)) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int ct = 0; ct < KT; ++ct) cur[i][ct] = x2[i][ct] + f4{0.5f, 0.25f, 0.125f, 1.f};
+        } else if constexpr (X1_MEM) {
             unsigned xo = 0;
             BM_OPAQUE_U32(xo);
 #pragma unroll
@@ -469,7 +563,10 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
             const bool more = k < br;
             // depthwise taps and bias of this layer: from the staged weights (LDS)
             const unsigned char* wdl = wl + li * G::WREC + (G::W_ALL ? KT * 2048 : 0);
-            constexpr int NWD = STAGE == 2 ? 1 : KT;          // depthwise tap sets in flight (stage 2 has 128 registers)
+#ifndef BM_HP_DWREG_NWD1
+#define BM_HP_DWREG_NWD1 1
+#endif
+            constexpr int NWD = (STAGE == 2 || (G::DWREG && STAGE == 1 && BM_HP_DWREG_NWD1)) ? 1 : KT;          // depthwise tap sets in flight (stage 2 has 128 registers)
             f4 wdv[NWD][9], dbias[NWD];
             auto load_dw = [&](int ct, f4 (&wd)[9], f4& bias) {
                 const f4* wsrc = reinterpret_cast<const f4*>(wdl) + (ct * 4 + g) * 9;
@@ -479,7 +576,26 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
             };
 #pragma unroll
             for (int c = 0; c < NWD; ++c) load_dw(c, wdv[c], dbias[c]);
-            if constexpr (NBR) {
+            constexpr int NH = G::NH, ROWS_W = NT / NH;
+            // halo exchange slot of (buffer, wave, edge: 0 = the strip's first row, 1 = its last, channel tile, row half)
+            auto halo_at = [&](int buf, int w, int edge, int ct, int h) {
+                return tbuf + (long)((((buf * G::NWAVES + w) * 2 + edge) * KT + ct) * NH + h) * 1024 + lane * 16;
+            };
+            if constexpr (G::DWREG) {
+                const int hb = li & 1;
+                if constexpr (!hp_abl(8)) {
+#pragma unroll
+                for (int ct = 0; ct < KT; ++ct)
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) {
+                        *reinterpret_cast<f4*>(halo_at(hb, wave, 0, ct, h)) = cur[h][ct];
+                        *reinterpret_cast<f4*>(halo_at(hb, wave, 1, ct, h)) = cur[(ROWS_W - 1) * NH + h][ct];
+                    }
+                }
+                BM_PROF(2);
+                if constexpr (!hp_abl(512)) __syncthreads();      // the only barrier of the layer: the buffers alternate, so the next layer's edge rows
+                BM_PROF(3);                                       // are written while a slow neighbour may still be reading this layer's
+            } else if constexpr (NBR) {
                 // rows of this wave's strip: tiles (2 r, 2 r + 1) in stage 0, tile r in stage 1; the first row is read by wave - 1, the last
                 // by wave + 1 -- those two are overwritten only after that neighbour has finished the previous layer's reads
                 constexpr int ROWS_W = STAGE == 0 ? NT / 2 : NT;
@@ -511,12 +627,14 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
                 if (wave < G::NWAVES - 1) (void)BM_LDS_FLAG_WAIT(wr_flag + wave + 1, seq);
                 BM_PROF(3);
             } else {
+                if constexpr (!hp_abl(8)) {
 #pragma unroll
                 for (int i = 0; i < NT; ++i)
 #pragma unroll
                     for (int ct = 0; ct < KT; ++ct) *reinterpret_cast<f4*>(tbuf + pix0 + ct * 4 * G::PLANE + tile_off(i)) = cur[i][ct];
+                }
                 BM_PROF(2);
-                __syncthreads();
+                if constexpr (!hp_abl(512)) __syncthreads();
                 BM_PROF(3);
             }
             // (the pass is a generic lambda so that "another layer follows" can be a compile-time fact: BM_HP_DW_STATIC_MORE = 1 instantiates
@@ -533,7 +651,73 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
                 const f4 (&wd)[9] = wdv[NWD < KT ? 0 : ct];
                 const f4 bias = dbias[NWD < KT ? 0 : ct];
                 const unsigned char* cbase = tbuf + pix0 + ct * 4 * G::PLANE;
-                if constexpr (STAGE == 2) {
+                if constexpr (G::DWREG) {
+                    const int hb = li & 1;
+                    const f4 zero4 = f4{0.f, 0.f, 0.f, 0.f};
+                    f4 acc[NH][3];
+#pragma unroll
+                    for (int rr = 0; rr < ROWS_W + 2; ++rr) {          // input row (first row of the strip) - 1 + rr
+                        f4 C[NH], Lv[NH], Rv[NH];
+#pragma unroll
+                        for (int h = 0; h < NH; ++h) {
+                            if (rr == 0) C[h] = (wave > 0 && !hp_abl(2)) ? *reinterpret_cast<const f4*>(halo_at(hb, wave - 1, 1, ct, h)) : zero4;
+                            else if (rr == ROWS_W + 1) C[h] = (wave < G::NWAVES - 1 && !hp_abl(2)) ? *reinterpret_cast<const f4*>(halo_at(hb, wave + 1, 0, ct, h)) : zero4;
+                            else C[h] = cur[(rr - 1) * NH + h][ct];
+                        }
+#if BM_HP_DWREG_FENCE
+                        // (the row's values made opaque here: the shifts below are pure moves the instruction selector would otherwise
+                        // hoist to the top of the unrolled pass -- every row's x +- 1 copies live at once)
+#pragma unroll
+                        for (int h = 0; h < NH; ++h) BM_OPAQUE_F4(C[h]);
+#endif
+                        // x - 1 / x + 1 of every pixel of the row: DPP shifts inside the 16-lane rows, zero at the image edge
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            auto u = [](float v) { return __builtin_bit_cast(unsigned, v); };
+                            auto f = [](unsigned v) { return __builtin_bit_cast(float, v); };
+                            if constexpr (NH == 1) {
+                                Lv[0][r] = f(BM_DPP_U32(0u, u(C[0][r]), 0x111, true));          // row_shr:1 -> lane - 1
+                                Rv[0][r] = f(BM_DPP_U32(0u, u(C[0][r]), 0x101, true));          // row_shl:1 -> lane + 1
+                            } else {
+                                Lv[0][r] = f(BM_DPP_U32(0u, u(C[0][r]), 0x111, true));
+                                const unsigned seam_l = BM_DPP_U32(0u, u(C[0][r]), 0x121, true);       // row_ror:1: lane 0 <- the left half's lane 15
+                                Lv[1][r] = f(BM_DPP_U32(seam_l, u(C[1][r]), 0x111, false));          // lanes 1..15 <- lane - 1, lane 0 keeps the seam value
+                                const unsigned seam_r = BM_DPP_U32(0u, u(C[1][r]), 0x12F, true);       // row_ror:15: lane 15 <- the right half's lane 0
+                                Rv[0][r] = f(BM_DPP_U32(seam_r, u(C[0][r]), 0x101, false));
+                                Rv[1][r] = f(BM_DPP_U32(0u, u(C[1][r]), 0x101, true));
+                            }
+                        }
+#pragma unroll
+                        for (int h = 0; h < NH; ++h) {
+                            const f4 v0 = Lv[h], v1 = C[h], v2 = Rv[h];
+                            if constexpr (hp_abl(1)) {
+                                hp_keep(v0); hp_keep(v2);
+                                if (rr >= 2) { const int i = (rr - 2) * NH + h; cur[i][ct] = relu4(v1); if constexpr (PW_FUSED) { if (do_pw) pointwise(An, cur[i]); } }
+                                continue;
+                            }
+                            if (rr >= 2) {                              // completes output row rr - 2 (its input role ended a step ago: in place)
+                                f4 a = acc[h][(rr - 2) % 3];
+                                a = fma_f4(wd[6], v0, a); a = fma_f4(wd[7], v1, a); a = fma_f4(wd[8], v2, a);
+                                const int i = (rr - 2) * NH + h;
+                                cur[i][ct] = relu4(a);
+                                if constexpr (PW_FUSED) { if (do_pw) pointwise(An, cur[i]); }
+                            }
+                            if (rr >= 1 && rr <= ROWS_W) {
+                                f4 a = acc[h][(rr - 1) % 3];
+                                a = fma_f4(wd[3], v0, a); a = fma_f4(wd[4], v1, a); a = fma_f4(wd[5], v2, a);
+                                acc[h][(rr - 1) % 3] = a;
+                            }
+                            if (rr <= ROWS_W - 1) {
+                                f4 a = fma_f4(wd[0], v0, bias);
+                                a = fma_f4(wd[1], v1, a); a = fma_f4(wd[2], v2, a);
+                                acc[h][rr % 3] = a;
+                            }
+                        }
+#if BM_HP_DWREG_FENCE
+                        BM_SCHED_FENCE();       // one input row's shifts and taps at a time (the scheduler would hoist every row's DPP moves)
+#endif
+                    }
+                } else if constexpr (STAGE == 2) {
                     f4 o = bias;
 #pragma unroll
                     for (int tap = 0; tap < 9; ++tap)
@@ -577,7 +761,50 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
                             if (rr >= 2) {
                                 const int i = STAGE == 0 ? 2 * (rr - 2) + sq : rr - 2;
                                 cur[i][ct] = relu4(done);
-                                if constexpr (KT == 1) { if (do_pw) pointwise(An, cur[i]); }
+                                if constexpr (PW_FUSED) { if (do_pw) pointwise(An, cur[i]); }
+                            }
+                        }
+                    }
+#elif BM_HP_DW_PIPE > 0
+                    // The same taps in the same order with the LDS reads SOFTWARE-PIPELINED: the three reads of the input row BM_HP_DW_PIPE
+                    // steps ahead are issued (into their own registers: a ring of BM_HP_DW_PIPE + 1 row sets) BEFORE this step's taps, so a
+                    // wave computes on one row while its next rows are in flight -- with three reads per wait a ds_read_b128 costs a wave
+                    // ~59 cycles at 8 waves per CU, with twelve in flight ~33 (tools/valu_chain_bench.hip, profiles/r6_valu_lds_microbench.txt);
+                    // the un-pipelined pass waits for every row before it issues the row's 25 vector instructions.  The steps of both
+                    // column halves form ONE sequence, so the pipeline does not drain between them.
+                    {
+                        constexpr int D = BM_HP_DW_PIPE, NS = NSEQ * (L + 2);
+                        f4 ring[D + 1][3];
+                        auto issue = [&](int s, f4 (&v)[3]) {
+                            const int sq = s / (L + 2), rr = s % (L + 2);
+                            const unsigned char* rp = cbase + sq * 256 + (rr - 1) * G::ROWP;
+                            v[0] = *reinterpret_cast<const f4*>(rp - 16); v[1] = *reinterpret_cast<const f4*>(rp); v[2] = *reinterpret_cast<const f4*>(rp + 16);
+                        };
+#pragma unroll
+                        for (int s = 0; s < D && s < NS; ++s) issue(s, ring[s % (D + 1)]);
+                        f4 acc[3];
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) {
+                            const int sq = s / (L + 2), rr = s % (L + 2);
+                            if (s + D < NS) issue(s + D, ring[(s + D) % (D + 1)]);
+                            BM_SCHED_FENCE();           // the requests above stay above this step's arithmetic
+                            const f4 v0 = ring[s % (D + 1)][0], v1 = ring[s % (D + 1)][1], v2 = ring[s % (D + 1)][2];
+                            if (rr >= 2) {                              // completes output row rr - 2
+                                f4 a = acc[(rr - 2) % 3];
+                                a = fma_f4(wd[6], v0, a); a = fma_f4(wd[7], v1, a); a = fma_f4(wd[8], v2, a);
+                                const int i = STAGE == 0 ? 2 * (rr - 2) + sq : rr - 2;
+                                cur[i][ct] = relu4(a);
+                                if constexpr (PW_FUSED) { if (do_pw) pointwise(An, cur[i]); }
+                            }
+                            if (rr >= 1 && rr <= L) {
+                                f4 a = acc[(rr - 1) % 3];
+                                a = fma_f4(wd[3], v0, a); a = fma_f4(wd[4], v1, a); a = fma_f4(wd[5], v2, a);
+                                acc[(rr - 1) % 3] = a;
+                            }
+                            if (rr <= L - 1) {
+                                f4 a = fma_f4(wd[0], v0, bias);
+                                a = fma_f4(wd[1], v1, a); a = fma_f4(wd[2], v2, a);
+                                acc[rr % 3] = a;
                             }
                         }
                     }
@@ -588,14 +815,24 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
 #pragma unroll
                         for (int rr = 0; rr < L + 2; ++rr) {          // input row (first row of the strip) - 1 + rr
                             const unsigned char* rp = cbase + sq * 256 + (rr - 1) * G::ROWP;
-                            const f4 v0 = *reinterpret_cast<const f4*>(rp - 16), v1 = *reinterpret_cast<const f4*>(rp),
-                                     v2 = *reinterpret_cast<const f4*>(rp + 16);
+                            f4 v0, v1, v2;
+                            if constexpr (hp_abl(2)) { v0 = bias; v1 = wd[4]; v2 = wd[0]; }
+                            else { v0 = *reinterpret_cast<const f4*>(rp - 16); v1 = *reinterpret_cast<const f4*>(rp); v2 = *reinterpret_cast<const f4*>(rp + 16); }
+                            if constexpr (hp_abl(1)) {           // reads kept alive, no taps
+                                hp_keep(v0); hp_keep(v1); hp_keep(v2);
+                                if (rr >= 2) {
+                                    const int i = STAGE == 0 ? 2 * (rr - 2) + sq : rr - 2;
+                                    cur[i][ct] = relu4(v1);
+                                    if constexpr (PW_FUSED) { if (do_pw) pointwise(An, cur[i]); }
+                                }
+                                continue;
+                            }
                             if (rr >= 2) {                              // completes output row rr - 2
                                 f4 a = acc[(rr - 2) % 3];
                                 a = fma_f4(wd[6], v0, a); a = fma_f4(wd[7], v1, a); a = fma_f4(wd[8], v2, a);
                                 const int i = STAGE == 0 ? 2 * (rr - 2) + sq : rr - 2;
                                 cur[i][ct] = relu4(a);
-                                if constexpr (KT == 1) { if (do_pw) pointwise(An, cur[i]); }     // next layer's 1x1 under the next rows' taps
+                                if constexpr (PW_FUSED) { if (do_pw) pointwise(An, cur[i]); }     // next layer's 1x1 under the next rows' taps
                             }
                             if (rr >= 1 && rr <= L) {
                                 f4 a = acc[(rr - 1) % 3];
@@ -618,7 +855,7 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
 #else
             dw_pass(more);
 #endif
-            if constexpr (KT == 2) {
+            if constexpr (!PW_FUSED) {
                 if (more) {
 #pragma unroll
                     for (int i = 0; i < NT; ++i) pointwise(An, cur[i]);
@@ -626,11 +863,12 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
             }
             if (k + 1 < br) load_pw(li + 2, An);        // next layer's fused 1x1 uses these; in flight across the barrier and the image write
             BM_PROF(4);
-            if constexpr (NBR) BM_LDS_FLAG_SET(rd_flag + wave, li + 1);
-            else __syncthreads();
+            if constexpr (G::DWREG) { /* no second barrier: the halo buffers alternate */ }
+            else if constexpr (NBR) BM_LDS_FLAG_SET(rd_flag + wave, li + 1);
+            else if constexpr (!hp_abl(512)) __syncthreads();
             BM_PROF(5);
         }
-        if constexpr (EPI_EARLY) {
+        if constexpr (EPI_EARLY && !G::DWREG) {
             if (br == 3) {
                 if constexpr (NBR) __syncthreads();      // (neighbour flags only order neighbours: the copies below overwrite the whole image)
                 stage_epilogue();                        // every wave is past the last read of the image (barrier above)
@@ -638,6 +876,15 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
         }
         // ChannelGate (osnet.py:194-209): crop-wide average -> fc1 -> ReLU -> fc2 -> sigmoid -> scale
         float* part = gap_part + br * (G::NWAVES * G::HID);
+        if constexpr (hp_abl(256)) {
+            __syncthreads();
+            if constexpr (EPI_EARLY && G::DWREG) { if (br == 3) stage_epilogue(); }
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int ct = 0; ct < KT; ++ct) x2[i][ct] = add_f4(x2[i][ct], cur[i][ct]);
+            continue;
+        }
         {
             float ph[G::HID];
 #pragma unroll
@@ -667,6 +914,9 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
             }
         }
         __syncthreads();
+        if constexpr (EPI_EARLY && G::DWREG) {
+            if (br == 3) stage_epilogue();               // every wave is past its last halo read (it has delivered its gate sums): the copies land under the gate
+        }
         float hidv[G::HID];
 #pragma unroll
         for (int h = 0; h < G::HID; ++h) {
@@ -715,6 +965,7 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
         h4 idh[(!DOWN && !RECON) ? NCT : 1], idl[(!DOWN && !RECON) ? NCT : 1];     // identity shortcut
     };
     auto tile_loads = [&](int i, TileOps& t) {
+        if constexpr (hp_abl(128)) { t = TileOps{}; return; }
         unsigned p = (wave * NT + i) * 16 + l16;
         if constexpr (STAGE == 0) BM_OPAQUE_U32(p);         // addresses are formed at the use, not kept for 16 tiles
         if constexpr (DOWN) {
@@ -767,6 +1018,19 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
     TileOps ops[NR];
     // conv3 + shortcut of the TG tiles at sequence positions k0 .. k0 + TG - 1 -> block output as (hi, lo) halves
     auto block_group = [&](int k0, h4 (&yh)[TG][NCT], h4 (&yl)[TG][NCT]) {
+        if constexpr (hp_abl(32)) {          // operands kept alive, no MFMAs, no output split
+#pragma unroll
+            for (int t = 0; t < TG; ++t) {
+                const TileOps& o = ops[(k0 + t) % NR];
+                const int i = seq_tile(k0 + t);
+                if constexpr (DOWN) { for (int ks = 0; ks < (CIN == 16 ? 1 : KIN); ++ks) { hp_keep(o.dxh[ks]); if (CIN != 16) hp_keep(o.dxl[ks]); } }
+                else if constexpr (RECON) { for (int ct = 0; ct < KT; ++ct) hp_keep(o.x2p[ct]); for (int ks = 0; ks < KINP; ++ks) { hp_keep(o.rxh[ks]); if (PREV_CIN != 16) hp_keep(o.rxl[ks]); } }
+                else { for (int co = 0; co < NCT; ++co) { hp_keep(o.idh[co]); hp_keep(o.idl[co]); } }
+#pragma unroll
+                for (int co = 0; co < NCT; ++co) { yh[t][co] = to_h4(x2[i][0]); yl[t][co] = to_h4(x2[i][KT - 1]); }
+            }
+            return;
+        }
         h8 b2h[TG], b2l[KT == 1 ? 1 : TG], rb2h[RECON ? TG : 1], rb2l[(RECON && KT > 1) ? TG : 1];
 #pragma unroll
         for (int t = 0; t < TG; ++t) {
@@ -785,6 +1049,7 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
             }
         }
         auto pair_at = [&](const unsigned char* a, h8& hi, h8& lo) {
+            if constexpr (hp_abl(2048)) { hi = eye; lo = eye; return; }
             hi = *reinterpret_cast<const h8*>(a + lane * 16); lo = *reinterpret_cast<const h8*>(a + 1024 + lane * 16);
         };
 #pragma unroll
@@ -861,7 +1126,7 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
 #pragma unroll
                 for (int t = 0; t < TG; ++t) an[t] = bn[ct];
 #pragma unroll
-                for (int ks = 0; ks < KSN; ++ks) {
+                for (int ks = 0; ks < (hp_abl(32) ? 0 : KSN); ++ks) {
                     const unsigned char* a = wln + (long)(ks * KT + ct) * HP_FRAG_PAIR;
                     const h8 ah = *reinterpret_cast<const h8*>(a + lane * 16), al = *reinterpret_cast<const h8*>(a + 1024 + lane * 16);
 #pragma unroll
@@ -901,7 +1166,7 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
 #pragma unroll
                 for (int t = 0; t < TG; ++t) a[t] = bv;
 #pragma unroll
-                for (int ks = 0; ks < KS3; ++ks) {
+                for (int ks = 0; ks < (hp_abl(32) ? 0 : KS3); ++ks) {
                     const unsigned char* af = wtl + (long)(ct * KS3 + ks) * HP_FRAG_PAIR;
                     const h8 ah = *reinterpret_cast<const h8*>(af + lane * 16), al = *reinterpret_cast<const h8*>(af + 1024 + lane * 16);
 #pragma unroll

@@ -62,6 +62,17 @@ inline void pack_a_frag_hl(uint8_t* dst, const float* W, int m_real, int k_real,
 
 constexpr long HP_FRAG_PAIR = 2048;      // bytes of one (hi, lo) fragment pair
 
+// Stage 0 (mid width 16): the linear 1x1 of a LightConv (osnet.py:127-155) on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32, four per
+// 16-pixel tile) instead of a (hi, lo) split of the activations + two fp16 MFMAs.  The block kernels are bound by vector-instruction
+// ISSUE (profiles/r6_valu_lds_microbench.txt: LDS reads and MFMAs aside, a SIMD retires one wave-instruction per ~4.4 cycles and its two
+// waves' depthwise taps, ReLUs and splits fill it), the matrix pipe is ~20 % busy: the fp32 form trades the split's 8 vector instructions
+// per tile and layer for 95 more matrix-pipe cycles that run beside the next rows' taps.  The layer's weights are then stored as fp32
+// A fragments in the record's `light_pw` region: [lane] f4 = W[out = lane & 15][in = 4 (lane >> 4) + 0..3]  (MFMA kk takes component kk;
+// its k index is the lane group, i.e. input channel 4 g + kk -- the channel component kk of the lane's activation f4 is the B operand).
+#ifndef BM_HP_PW32
+#define BM_HP_PW32 0
+#endif
+
 struct BlkPackHP {
     int stage, cin, down;
     int mid, kt, midp, cout, nct, hid, kin_steps;
@@ -116,6 +127,11 @@ inline void pack_osblock_hp(const float* w, const BlockW& B, const BlkPackHP& P,
     put_f32(out, P.conv1_b, w + B.conv1_b, P.mid, P.midp);
     for (int l = 0; l < 10; ++l) {
         const long base = P.light0 + l * P.light_bytes;
+        if (BM_HP_PW32 && P.stage == 0) {
+            float* a32 = reinterpret_cast<float*>(out.data() + base + P.light_pw);
+            for (int lane = 0; lane < 64; ++lane)
+                for (int r = 0; r < 4; ++r) a32[lane * 4 + r] = w[B.light[l].pw + (long)(lane & 15) * P.mid + 4 * (lane >> 4) + r];
+        } else
         for (int ct = 0; ct < P.kt; ++ct) frag_mid(base + P.light_pw + (long)ct * HP_FRAG_PAIR, w + B.light[l].pw, P.mid, ct);
         float* dw = reinterpret_cast<float*>(out.data() + base + P.light_dw);      // [ct][g][tap][r], channel 16 ct + 4 g + r
         for (int ct = 0; ct < P.kt; ++ct)

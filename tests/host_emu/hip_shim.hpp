@@ -295,6 +295,9 @@ inline bool emu_lds_flag_wait(const volatile int* p, int v) {
 #define BM_SCHED_FENCE() ((void)0)
 #define BM_SETPRIO(n) ((void)0)
 #define BM_RESID_F16(hp, hi, v, out) do { unsigned short b_ = (unsigned short)((hp) >> (16 * (hi))); _Float16 h_; std::memcpy(&h_, &b_, 2); (out) = (v) - (float)h_; } while (0)
+#define BM_RESID_PK_F16(hp, v0, v1, out) do { unsigned short b0_ = (unsigned short)(hp), b1_ = (unsigned short)((hp) >> 16); _Float16 h0_, h1_; \
+    std::memcpy(&h0_, &b0_, 2); std::memcpy(&h1_, &b1_, 2); const _Float16 r0_ = (_Float16)((v0) - (float)h0_), r1_ = (_Float16)((v1) - (float)h1_); \
+    unsigned short q0_, q1_; std::memcpy(&q0_, &r0_, 2); std::memcpy(&q1_, &r1_, 2); (out) = (unsigned)q0_ | ((unsigned)q1_ << 16); } while (0)
 #define BM_RCPF(x) (1.0f / (x))
 #define BM_OPAQUE_U32(x) ((void)0)
 inline float emu_row_shift(float v, int d, bool rotate) {

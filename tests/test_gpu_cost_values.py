@@ -47,7 +47,8 @@ def test_botsort_cost_matrices_match_the_reference(name):
                     worst = max(worst, check_stage(g, name, t, s, dists, iou, emb, prox, "device", tol=TIGHT))
                     n_checked += dists.size
                     if name == "c2_dense" and s == 0 and t > 0:
-                        assert emb.shape == (256, 64) and np.isfinite(emb).all(), "the dense fallback evaluates all 16 384 pairs"
+                        # (256 tracks x 256 detections while the scene introduces itself, x 64 from frame 3 on: > SPARSE_MAX ungated pairs)
+                        assert emb.shape[0] == 256 and emb.size >= 16384 and np.isfinite(emb).all(), "the dense fallback evaluates every pair"
     finally:
         trk.close()
     assert n_checked > 0 and worst <= TIGHT < COST_TOL
