@@ -97,6 +97,20 @@
 #ifndef BM_HP_DW_REG
 #define BM_HP_DW_REG 0
 #endif
+#ifndef BM_HP_IMGW_PIPE
+#define BM_HP_IMGW_PIPE 1
+#endif
+// Image writes of stages 0 / 1 issued UNDER the next layer's 1x1 (1): tile i - LAG goes to the image right after tile i's (hi, lo) split and
+// MFMAs, so the CU's one LDS store path (13.5 cycles per ds_write_b128, 16 per wave and layer) works while the vector unit converts --
+// instead of a burst of all eight waves with nothing to run under.  The layer's second barrier moves from behind the 1x1 to in front of it
+// (every wave is past its depthwise reads before the first tile is overwritten); still two barriers per layer.  Needs BM_HP_PW_BATCH; takes
+// the place of BM_HP_IMGW_PIPE.  A/B: profiles/r6_hp_variants_ab.txt
+#ifndef BM_HP_IMGW_PW
+#define BM_HP_IMGW_PW 1
+#endif
+#ifndef BM_HP_IMGW_LAG
+#define BM_HP_IMGW_LAG 1            // 1: 1.063 / 1.140 / 0.824 / 0.758 ms, 2: 1.079 / 1.154 / 0.824 / 0.777, 4: 1.083 / 1.173 / 0.842 / 0.798 (base 1.125 / 1.190 / 0.856 / 0.792)
+#endif
 #ifndef BM_HP_PW_BATCH
 #define BM_HP_PW_BATCH 1            // measured -2 % / -5 % on the two stage-0 block kernels (profiles/r6_hp_variants_ab.txt)
 #endif
@@ -190,6 +204,9 @@ struct GeoHP {
 // fp32 multiply-adds / adds of four channels: packed (v_pk_fma_f32 / v_pk_add_f32: half the instructions) or four scalar
 // instructions (BM_HP_SCALAR_F32 = 1: packed f32 VALU operations are priced well above two scalar ones beside MFMAs on this part,
 // kernel_macros.hpp BM_FMA_F32; identical results; A/B switch, profiles/r5_hp_scalar_f32_ab.txt)
+// (CAUTION, found in round 6: the scalar forms are inline assembly, and the compiler's hazard recogniser does not protect an inline-asm
+// vector instruction that reads an MFMA result -- the epilogue's shortcut sum under this switch returned run-to-run different checksums
+// on the device (profiles/r6_hp_variants_ab.txt).  Timing switch only; never the library default.)
 #ifndef BM_HP_SCALAR_F32
 #define BM_HP_SCALAR_F32 0
 #endif
@@ -484,6 +501,32 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
         }
     };
 
+    // the 1x1 of a layer on every tile of the wave; BM_HP_IMGW_PW: each tile's result goes to the image BM_HP_IMGW_LAG tiles later, under the
+    // following tiles' splits (the caller has passed the barrier that ends the previous layer's reads of the image)
+    constexpr bool IMGW_PW = BM_HP_IMGW_PW && BM_HP_PW_BATCH && STAGE < 2 && !G::DWREG && !(BM_HP_NBR_SYNC);
+    auto img_write = [&](int i, const f4 (&c)[KT]) {
+        if constexpr (!hp_abl(8)) {
+#pragma unroll
+            for (int ct = 0; ct < KT; ++ct) *reinterpret_cast<f4*>(tbuf + pix0 + ct * 4 * G::PLANE + tile_off(i)) = c[ct];
+        }
+    };
+    auto pw_all = [&](const h8 (&A)[KT][2], f4 (&c)[NT][KT]) {
+        if constexpr (IMGW_PW) {
+            constexpr int LAG = BM_HP_IMGW_LAG < NT ? BM_HP_IMGW_LAG : NT - 1;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                pointwise(A, c[i]);
+                if (i >= LAG) img_write(i - LAG, c[i - LAG]);
+                BM_SCHED_FENCE();
+            }
+#pragma unroll
+            for (int i = NT - LAG; i < NT; ++i) img_write(i, c[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NT; ++i) pointwise(A, c[i]);
+        }
+    };
+
     if constexpr (!G::DWREG)
     for (int e = tid * 16; e < G::IMG; e += 64 * G::NWAVES * 16) *reinterpret_cast<f4*>(tbuf + e) = f4{0.f, 0.f, 0.f, 0.f};   // halo = zero padding
     constexpr bool NBR = BM_HP_NBR_SYNC && STAGE < 2;
@@ -554,8 +597,7 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
             h8 A0[KT][2];
             load_pw(li, A0);
             if (br > 0) load_pw(li + 1, An);
-#pragma unroll
-            for (int i = 0; i < NT; ++i) pointwise(A0, cur[i]);
+            pw_all(A0, cur);
         }
         BM_PROF(1);
 #pragma unroll 1
@@ -577,6 +619,11 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
 #pragma unroll
             for (int c = 0; c < NWD; ++c) load_dw(c, wdv[c], dbias[c]);
             constexpr int NH = G::NH, ROWS_W = NT / NH;
+            // Image writes spread over the depthwise pass (1) instead of one burst of all eight waves before the barrier (0): a ds_write_b128
+            // costs 13.5 cycles on the CU's one store path but runs under OTHER instructions' issue (tools/coissue_bench.hip: 4 writes + 32 vector
+            // instructions per wave take what the longer of the two takes alone) -- in a burst there is nothing to run under.
+            constexpr bool IMGW_PIPE = BM_HP_IMGW_PIPE && !IMGW_PW && STAGE < 2 && !G::DWREG && !(BM_HP_NBR_SYNC) && ROWS_W > 2;
+            auto IMGW_ROW = [](int i) constexpr { return i / NH; };        // strip row of tile i (stage 0: tiles 2 r, 2 r + 1; stage 1: tile r)
             // halo exchange slot of (buffer, wave, edge: 0 = the strip's first row, 1 = its last, channel tile, row half)
             auto halo_at = [&](int buf, int w, int edge, int ct, int h) {
                 return tbuf + (long)((((buf * G::NWAVES + w) * 2 + edge) * KT + ct) * NH + h) * 1024 + lane * 16;
@@ -627,11 +674,16 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
                 if (wave < G::NWAVES - 1) (void)BM_LDS_FLAG_WAIT(wr_flag + wave + 1, seq);
                 BM_PROF(3);
             } else {
-                if constexpr (!hp_abl(8)) {
+                if constexpr (!hp_abl(8) && !IMGW_PW) {
 #pragma unroll
-                for (int i = 0; i < NT; ++i)
+                for (int i = 0; i < NT; ++i) {
+                    // BM_HP_IMGW_PIPE: only the rows a NEIGHBOURING wave reads (the first and the last of the strip) are written ahead of
+                    // the barrier; a wave's inner rows are read by nobody else, and its own LDS operations execute in order, so they are
+                    // written inside the depthwise pass, one row ahead of their first read (IMGW_ROW below)
+                    if constexpr (IMGW_PIPE) { if (IMGW_ROW(i) != 0 && IMGW_ROW(i) != ROWS_W - 1) continue; }
 #pragma unroll
                     for (int ct = 0; ct < KT; ++ct) *reinterpret_cast<f4*>(tbuf + pix0 + ct * 4 * G::PLANE + tile_off(i)) = cur[i][ct];
+                }
                 }
                 BM_PROF(2);
                 if constexpr (!hp_abl(512)) __syncthreads();
@@ -815,6 +867,15 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
 #pragma unroll
                         for (int rr = 0; rr < L + 2; ++rr) {          // input row (first row of the strip) - 1 + rr
                             const unsigned char* rp = cbase + sq * 256 + (rr - 1) * G::ROWP;
+                            if constexpr (IMGW_PIPE && !hp_abl(8)) {
+                                // strip row rr (read at step rr + 1) goes to the image now: every half of it, from the registers that still hold the
+                                // layer's input (outputs reach row rr at step rr + 2), during the first column half's pass only
+                                if (sq == 0 && rr >= 1 && rr <= ROWS_W - 2) {
+#pragma unroll
+                                    for (int h = 0; h < NH; ++h)
+                                        *reinterpret_cast<f4*>(tbuf + pix0 + ct * 4 * G::PLANE + tile_off(rr * NH + h)) = cur[rr * NH + h][ct];
+                                }
+                            }
                             f4 v0, v1, v2;
                             if constexpr (hp_abl(2)) { v0 = bias; v1 = wd[4]; v2 = wd[0]; }
                             else { v0 = *reinterpret_cast<const f4*>(rp - 16); v1 = *reinterpret_cast<const f4*>(rp); v2 = *reinterpret_cast<const f4*>(rp + 16); }
@@ -855,11 +916,16 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
 #else
             dw_pass(more);
 #endif
+            if constexpr (IMGW_PW) {
+                // every wave is past its reads of this layer's image before the next layer's tiles are written over it
+                if constexpr (!hp_abl(512)) __syncthreads();
+                if (more) pw_all(An, cur);
+                if (k + 1 < br) load_pw(li + 2, An);
+                BM_PROF(4);
+                BM_PROF(5);
+            } else {
             if constexpr (!PW_FUSED) {
-                if (more) {
-#pragma unroll
-                    for (int i = 0; i < NT; ++i) pointwise(An, cur[i]);
-                }
+                if (more) pw_all(An, cur);
             }
             if (k + 1 < br) load_pw(li + 2, An);        // next layer's fused 1x1 uses these; in flight across the barrier and the image write
             BM_PROF(4);
@@ -867,6 +933,7 @@ k_osblock_hp(const _Float16* __restrict__ in_h, const _Float16* __restrict__ in_
             else if constexpr (NBR) BM_LDS_FLAG_SET(rd_flag + wave, li + 1);
             else if constexpr (!hp_abl(512)) __syncthreads();
             BM_PROF(5);
+            }
         }
         if constexpr (EPI_EARLY && !G::DWREG) {
             if (br == 3) {

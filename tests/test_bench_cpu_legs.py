@@ -30,3 +30,40 @@ def test_cpu_baseline_times_the_reference_classes_and_their_rows_equal_the_oracl
     assert rec["kind"] == "reference" and rec["rows_equal_oracle_rows"] is True and rec["value"] > 0
     assert rec["port"]["kind"] == "port" and rec["port"]["value"] > 0 and rec["reference_form"] in ("source", "compiled")
     assert "reference boxmot BotSort.update" in rec["sample"] and len(rows) == 7
+
+
+def test_all_stream_invariants_and_the_oracle_confirmation_of_row_shortfalls():
+    """The bench's oracle-free checks over every stream-frame, and the anomaly-directed oracle re-run: rows the oracle itself returns pass
+    (a frame with fewer rows than detections counts as a shortfall, not a fault, and is CONFIRMED when the oracle shows the same rows); a
+    forged shortfall is refuted; a duplicated id is a hard violation."""
+    import bench
+    T, S, nd = 8, 2, bench.N_TRACKS
+    out_h = np.zeros((T, S, nd, 8), dtype=np.float32)
+    out_n = np.zeros((T, S), dtype=np.int32)
+    cnt = np.zeros((T, S), dtype=np.int32)
+    from boxmot_amd.scenario import Scenario
+    for s in range(S):
+        rows, _, _ = bench.oracle_rows(None, "embs", T - 3, s)
+        sc = Scenario(bench.N_DETS, bench.N_TRACKS, bench.WIDTH, bench.HEIGHT, bench.EMB_DIM, stream=s, random_image=False)
+        for t in range(T):
+            out_h[t, s, : len(rows[t])] = rows[t]
+            out_n[t, s] = len(rows[t])
+            cnt[t, s] = len(sc.frame(t, with_embs=False)[0])
+    inv = bench.all_stream_invariants(out_h, out_n, cnt, S, T)
+    rec = inv["all_streams_invariants"]
+    assert rec["all_true"] and rec["first_violations_t_s_rows_dets"] == [] and rec["of_stream_frames"] == S * (T - 3)
+    n0 = rec["stream_frames_with_fewer_rows_than_detections_from_frame_3"]
+    # forge a shortfall on stream 1, frame 5: drop the last row
+    out_n[5, 1] -= 1
+    inv = bench.all_stream_invariants(out_h, out_n, cnt, S, T)
+    rec = inv["all_streams_invariants"]
+    assert rec["all_true"] and rec["stream_frames_with_fewer_rows_than_detections_from_frame_3"] == n0 + 1
+    assert [5, 1, int(out_n[5, 1]), int(cnt[5, 1])] in rec["first_shortfalls_t_s_rows_dets"]
+    inv = bench.confirm_row_shortfalls(inv, out_h, out_n, None, "embs")
+    rec = inv["all_streams_invariants"]
+    assert rec["shortfalls_confirmed_by_oracle"] is False and rec["shortfalls_checked_against_oracle"][0]["stream"] == 1
+    out_n[5, 1] += 1
+    # a duplicated id is a hard violation
+    out_h[6, 0, 1, 4] = out_h[6, 0, 0, 4]
+    rec = bench.all_stream_invariants(out_h, out_n, cnt, S, T)["all_streams_invariants"]
+    assert not rec["all_true"] and not rec["no_duplicate_id_or_det_ind_in_a_frame"] and rec["first_violations_t_s_rows_dets"][0][:2] == [6, 0]

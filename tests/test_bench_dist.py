@@ -39,6 +39,12 @@ def test_gpus_flag_alone_launches_the_ranks(mode):
     # whole-job value: frames of all ranks over the max-over-ranks time
     assert abs(d["value"] - 2 * 3 * 4 / (d["ms_per_step"] * 4 / 1000.0)) < 1e-6 * d["value"]
     assert "rank 1/2" in p.stderr and "rank 0/2" in p.stderr          # both ranks ran, on different stream shards
+    # the N > 1 line's shape (what the driver's SCALE run parses): every contract key, no per-rank CPU baseline, no side lines
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["vs_baseline"] is None and "workload" in d["config"]
+    assert "model" not in d["config"] and "cpu_baseline" not in d and "other_configs" not in d and "tracker_math_m1" not in d
+    assert d["config"]["parallelism"].startswith("2 x 3 independent streams")
 
 
 def test_driver_style_launch_reads_the_environment():
