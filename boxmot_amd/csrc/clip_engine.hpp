@@ -16,6 +16,11 @@
 #include "clip_kernels.hpp"
 #include "reid_pack.hpp"
 
+// A/B switches (tools/clip_bench.py with BOXMOT_HIP_LIB pointing at a variant build)
+#ifndef BM_CLIP_ATTN_T
+#define BM_CLIP_ATTN_T 1
+#endif
+
 namespace bm {
 
 constexpr int CLIP_MAGIC = 0x434C5031;       // "CLP1"
@@ -66,6 +71,8 @@ public:
         set_gemm_lds<0>(); set_gemm_lds<1>(); set_gemm_lds<2>(); set_gemm_lds<3>();
         check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_clip_attention), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   clip_attn_lds_bytes(tokens)), "attention LDS");
+        check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_clip_attention_t<129>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  clip_attn_t_lds_bytes<129>()), "attention LDS");
     }
     int feature_dim() const { return width + out_dim; }
 
@@ -85,8 +92,12 @@ public:
         for (const ClipLayerOff& l : L_) {
             layernorm(d_w_ + l.ln1_w, d_w_ + l.ln1_b, R, st);
             gemm<0>(h16_, d_w16_ + l.qkv_w, d_w_ + l.qkv_b, qkv16_, R, 3 * D, D, st);
-            hipLaunchKernelGGL(k_clip_attention, dim3((unsigned)(n * heads)), dim3(256), (size_t)clip_attn_lds_bytes(T), st,
-                               qkv16_, h16_, T, D, heads);
+            if (BM_CLIP_ATTN_T && T == 129)        // ViT-B/16 on 256 x 128 crops: the compile-time-T kernel (identical bits, tools/attn_prof.hip)
+                hipLaunchKernelGGL((k_clip_attention_t<129>), dim3((unsigned)(n * heads)), dim3(192), (size_t)clip_attn_t_lds_bytes<129>(), st,
+                                   qkv16_, h16_, D, heads);
+            else
+                hipLaunchKernelGGL(k_clip_attention, dim3((unsigned)(n * heads)), dim3(256), (size_t)clip_attn_lds_bytes(T), st,
+                                   qkv16_, h16_, T, D, heads);
             gemm<2>(h16_, d_w16_ + l.out_w, d_w_ + l.out_b, x_, R, D, D, st);
             layernorm(d_w_ + l.ln2_w, d_w_ + l.ln2_b, R, st);
             gemm<1>(h16_, d_w16_ + l.fc_w, d_w_ + l.fc_b, mlp16_, R, 4 * D, D, st);
@@ -119,7 +130,9 @@ private:
     void gemm(const _Float16* X, const _Float16* W, const float* bias, void* C, long M, int N, int K, hipStream_t st) {
         if (N % GEMM_BN != 0 || K % GEMM_BK != 0) throw std::runtime_error("CLIP-ReID: GEMM shape not tileable");
         if (N % 256 == 0 && K % 64 == 0 && M >= 1024) {     // 256 x 256 tiles, phased k-loop: 739-1054 TFLOP/s on the four layer shapes against
-            hipLaunchKernelGGL((k_gemm_f16_256<EPI>), dim3((unsigned)(((M + 255) / 256) * (N / 256))), dim3(512), GEMM256_LDS_BYTES, st, X, W, bias, C,       // 623-833 (profiles/r3_gemm_prof.txt)
+            // 623-833 (profiles/r3_gemm_prof.txt).  (Tried in round 6 and dropped, profiles/r6_clip_ab.txt: stopping the 256-row tiles at the
+            // last full round of CUs and sending the remaining rows through the 128 x 128 kernel; starting every second CU half a tile late.)
+            hipLaunchKernelGGL((k_gemm_f16_256<EPI>), dim3((unsigned)(((M + 255) / 256) * (N / 256))), dim3(512), GEMM256_LDS_BYTES, st, X, W, bias, C,
                                static_cast<const _Float16*>(nullptr), (int)M, N, K, 0);
             return;
         }

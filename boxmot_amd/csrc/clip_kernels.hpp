@@ -86,6 +86,29 @@ __global__ void __launch_bounds__(256) k_clip_layernorm_f16(const float* __restr
     if (r >= rows) return;
     const float* src = x + r * D;
     float s = 0.f, ss = 0.f;
+    if (D == 768) {
+        // ViT-B: the row (3 x 16 bytes per lane) is read ONCE and held in registers for the three passes (same operations in the same order as
+        // the generic loop below: identical bits) -- the launch moves 304 MB at 512 crops and is bound by HBM, not by the re-reads' L2 hits alone
+        cf4 v[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) v[i] = *reinterpret_cast<const cf4*>(src + lane * 4 + 256 * i);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        const float mean = clip_wave_sum(s) / D;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 4; ++j) ss += (v[i][j] - mean) * (v[i][j] - mean);
+        const float rstd = 1.0f / sqrtf(clip_wave_sum(ss) / D + CLIP_LN_EPS);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int c = lane * 4 + 256 * i;
+            const cf4 gm = *reinterpret_cast<const cf4*>(gamma + c), bt = *reinterpret_cast<const cf4*>(beta + c);
+            ch4 o;
+            for (int j = 0; j < 4; ++j) o[j] = (_Float16)((v[i][j] - mean) * rstd * gm[j] + bt[j]);
+            *reinterpret_cast<ch4*>(out + r * D + c) = o;
+        }
+        return;
+    }
     for (int c = lane * 4; c < D; c += 256) { const cf4 v = *reinterpret_cast<const cf4*>(src + c); s += v[0] + v[1] + v[2] + v[3]; }
     const float mean = clip_wave_sum(s) / D;
     for (int c = lane * 4; c < D; c += 256) {
@@ -216,6 +239,147 @@ __global__ void __launch_bounds__(256) k_clip_attention(const _Float16* __restri
                 ch4 w;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) w[r] = (_Float16)(o[dt][r] * inv);
+                *reinterpret_cast<ch4*>(out + (crop * T + q) * D + head * ATT_DH + 16 * dt + 4 * g) = w;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The same attention for a COMPILE-TIME token count (ViT-B/16 on 256 x 128 crops: T = 129), three wavefronts per (crop, head):
+//   * the 9 query tiles are dealt 3 per wave and a wave runs ITS THREE TILES TOGETHER: every K fragment and every V^T fragment read from
+//     LDS feeds three MFMAs (a third of the fragment reads of a tile-by-tile loop, three independent accumulator chains on the matrix pipe);
+//     k_clip_attention's four waves take 3 / 2 / 2 / 2 tiles one after the other;
+//   * Q never touches LDS: a lane's B fragments are two 16-byte global loads per tile;
+//   * V stays ROW-MAJOR in LDS ([key][64] halves, rows 160 bytes apart) and the V^T fragments come from ds_read_b64_tr_b16 (BM_DS_READ_TR16_B64:
+//     the 16 lanes of a lane group name the sixteen 8-byte chunks of a [4 keys][16 features] block, lane c receives column c = feature c
+//     of the four keys) -- no element-wise transposed store pass (8 ds_write_b16 per 16 bytes of V in k_clip_attention);
+//   * no run-time tile guards: the loops are over the compile-time tile counts, only the last key tile is masked.
+// Arithmetic, operand rounding and every summation order are those of k_clip_attention: the two kernels return identical bits
+// (tools/attn_prof.hip compares them; tests/test_gpu_clipreid.py runs the network through this one).
+// LDS: K [TP][72] halves + V [KP][80] halves = 20.7 + 25.6 KB at T = 129: three workgroups per CU.
+// ---------------------------------------------------------------------------
+#ifndef BM_DS_READ_TR16_B64
+typedef short cs4 __attribute__((ext_vector_type(4)));
+#define BM_DS_READ_TR16_B64(lds_ptr) \
+    __builtin_bit_cast(ch4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) cs4*)(lds_ptr)))
+#endif
+constexpr int ATT_VLD = 80;             // halves per V row in LDS: 8 consecutive keys land on disjoint 8-bank windows (40 dwords apart)
+template <int T>
+__host__ __device__ constexpr int clip_attn_t_lds_bytes() { return (((T + 15) / 16 * 16) * ATT_LD + ((T + 31) / 32 * 32) * ATT_VLD) * 2; }
+
+template <int T>
+__global__ void __launch_bounds__(192) k_clip_attention_t(const _Float16* __restrict__ qkv, _Float16* __restrict__ out, int D, int heads) {
+    constexpr int TP = (T + 15) / 16 * 16, NKT = TP / 16, KP = (T + 31) / 32 * 32, NKS = KP / 32, NQ = NKT / 3;
+    static_assert(NKT % 3 == 0 && T <= ATT_MAX_T, "three waves share the query tiles evenly");
+    BM_DYNAMIC_LDS_T(unsigned char, lds);
+    _Float16* sK = reinterpret_cast<_Float16*>(lds);
+    _Float16* sV = sK + TP * ATT_LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = BM_UNIFORM_I32(tid >> 6), g = lane >> 4, l16 = lane & 15;
+    const long crop = blockIdx.x / heads;
+    const int head = blockIdx.x % heads;
+    const _Float16* base = qkv + crop * T * (3L * D) + head * ATT_DH;
+    const ch8 zero8 = ch8{0, 0, 0, 0, 0, 0, 0, 0};
+    // this wave's Q fragments (rows beyond T re-read row T - 1: their results are never stored)
+    ch8 bq[NQ][2];
+#pragma unroll
+    for (int a = 0; a < NQ; ++a) {
+        int q = 16 * (wave + 3 * a) + l16;
+        q = q < T ? q : T - 1;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) bq[a][s] = *reinterpret_cast<const ch8*>(base + (long)q * 3 * D + 32 * s + 8 * g);
+    }
+    for (int e = tid; e < KP * 8; e += 192) {                   // 16-byte chunks: row t, halves 8 c .. 8 c + 7; pad rows zero
+        const int t = e >> 3, c = (e & 7) * 8;
+        ch8 k = zero8, v = zero8;
+        if (t < T) {
+            const _Float16* row = base + (long)t * 3 * D + c;
+            k = *reinterpret_cast<const ch8*>(row + D);
+            v = *reinterpret_cast<const ch8*>(row + 2 * D);
+        }
+        if (t < TP) *reinterpret_cast<ch8*>(sK + t * ATT_LD + c) = k;
+        *reinterpret_cast<ch8*>(sV + t * ATT_VLD + c) = v;
+    }
+    __syncthreads();
+    // S^T = K . Q^T for the wave's three query tiles
+    cf4 sc[NQ][NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        ch8 ak[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) ak[s] = *reinterpret_cast<const ch8*>(sK + (16 * kt + l16) * ATT_LD + 32 * s + 8 * g);
+#pragma unroll
+        for (int a = 0; a < NQ; ++a) {
+            cf4 acc = cf4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 2; ++s) acc = BM_MFMA_F16_K32(ak[s], bq[a][s], acc);
+            sc[a][kt] = acc;
+        }
+    }
+    float inv[NQ];
+#pragma unroll
+    for (int a = 0; a < NQ; ++a) {
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool valid = 16 * kt + 12 + 3 < T || (16 * kt + 4 * g + r) < T;          // (compile-time true except in the last key tile)
+                const float v = valid ? sc[a][kt][r] * 0.125f : -3.0e38f;                       // head_dim ** -0.5; pad keys masked
+                sc[a][kt][r] = v;
+                mx = v > mx ? v : mx;
+            }
+        { float o = __shfl_xor(mx, 16, 64); mx = o > mx ? o : mx; o = __shfl_xor(mx, 32, 64); mx = o > mx ? o : mx; }
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool valid = 16 * kt + 12 + 3 < T || (16 * kt + 4 * g + r) < T;
+                const float e = valid ? BM_EXPF(sc[a][kt][r] - mx) : 0.f;
+                sc[a][kt][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        inv[a] = 1.0f / sum;
+    }
+    // O^T = V^T . P^T: k-slot (g, j) of step ks is key 32 ks + 4 g + j (j < 4) / 32 ks + 16 + 4 g + j - 4 (j >= 4), as in k_clip_attention
+    cf4 o[NQ][4];
+#pragma unroll
+    for (int a = 0; a < NQ; ++a)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[a][dt] = cf4{0.f, 0.f, 0.f, 0.f};
+    // the lane's chunk of a [4 keys][16 features] block: key l16 / 4, features 4 (l16 % 4) ..
+    const _Float16* vchunk = sV + (4 * g + (l16 >> 2)) * ATT_VLD + 4 * (l16 & 3);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        ch8 pb[NQ];
+#pragma unroll
+        for (int a = 0; a < NQ; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                pb[a][j] = (_Float16)sc[a][2 * ks][j];
+                pb[a][4 + j] = 2 * ks + 1 < NKT ? (_Float16)sc[a][(2 * ks + 1) % NKT][j] : (_Float16)0.f;
+            }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const ch4 lo = BM_DS_READ_TR16_B64(vchunk + (32 * ks) * ATT_VLD + 16 * dt);
+            const ch4 hi = BM_DS_READ_TR16_B64(vchunk + (32 * ks + 16) * ATT_VLD + 16 * dt);
+            const ch8 av = ch8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+            for (int a = 0; a < NQ; ++a) o[a][dt] = BM_MFMA_F16_K32(av, pb[a], o[a][dt]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < NQ; ++a) {
+        const int q = 16 * (wave + 3 * a) + l16;
+        if (q < T) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                ch4 w;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) w[r] = (_Float16)(o[a][dt][r] * inv[a]);
                 *reinterpret_cast<ch4*>(out + (crop * T + q) * D + head * ATT_DH + 16 * dt + 4 * g) = w;
             }
         }

@@ -103,3 +103,16 @@ extern "C" int emu_clip_forward(const float* blob, long n_floats, const float* c
       launch(n, 1, 256, [=]() { k_clip_head(xi, W32 + o_postw, W32 + o_postb, W32 + o_proj, W32 + o_bs, W32 + o_bb, W32 + o_ps, W32 + o_pb, feats, rows, T, D, E); }); }
     return 0;
 }
+
+// the two attention kernels on the same q | k | v rows (T = 33 tokens: three key / query tiles, the last with ONE valid key, as 129 tokens have):
+// k_clip_attention (run-time T) -> out_a, k_clip_attention_t<33> (compile-time T, ds_read_b64_tr_b16 fragments) -> out_b
+extern "C" int emu_clip_attention_pair(const uint16_t* qkv_bits, uint16_t* out_a, uint16_t* out_b, int n, int heads, int D) {
+    using namespace bm;
+    constexpr int T = 33;
+    const _Float16* q = reinterpret_cast<const _Float16*>(qkv_bits);
+    _Float16* a = reinterpret_cast<_Float16*>(out_a);
+    _Float16* b = reinterpret_cast<_Float16*>(out_b);
+    launch(n * heads, 1, 256, [=]() { k_clip_attention(q, a, T, D, heads); });
+    launch(n * heads, 1, 192, [=]() { k_clip_attention_t<T>(q, b, D, heads); });
+    return 0;
+}

@@ -25,7 +25,7 @@ def _build():
 
 
 @pytest.mark.skipif(CLANG is None, reason="needs a host clang with _Float16")
-@pytest.mark.parametrize("width,layers,out_dim,hw,n", [(128, 2, 128, (32, 32), 3), (256, 1, 128, (48, 16), 2), (128, 1, 128, (128, 64), 2)])
+@pytest.mark.parametrize("width,layers,out_dim,hw,n", [(128, 2, 128, (32, 32), 3), (256, 1, 128, (48, 16), 2), (128, 1, 128, (128, 64), 2), (768, 1, 128, (32, 16), 2)])
 def test_clip_kernels_emulated_vs_oracle(width, layers, out_dim, hw, n):
     import torch
 
@@ -49,3 +49,28 @@ def test_clip_kernels_emulated_vs_oracle(width, layers, out_dim, hw, n):
     print(f"CLIP-ReID emulated (width {width}, {layers} layers): max|diff| = {err:.2e}")
     assert err < 1e-3
     assert np.allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-5)
+
+
+@pytest.mark.skipif(CLANG is None, reason="needs a host clang with _Float16")
+def test_compile_time_attention_kernel_equals_the_run_time_one_and_softmax():
+    """k_clip_attention_t<T> (three query tiles per wave, V^T fragments by the emulated ds_read_b64_tr_b16) against k_clip_attention on the
+    same q | k | v rows: identical halves, and both equal softmax(q k^T / 8) v in float64 (random, non-symmetric inputs: a transposed
+    fragment or a permuted key order shows)."""
+    lib = ctypes.CDLL(str(_build()))
+    lib.emu_clip_attention_pair.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    n, heads, D, T = 2, 2, 128, 33
+    rng = np.random.default_rng(11)
+    qkv = (rng.standard_normal((n * T, 3 * D)) * 1.5).astype(np.float16)
+    a = np.full((n * T, D), np.nan, np.float16)
+    b = np.full((n * T, D), np.nan, np.float16)
+    assert lib.emu_clip_attention_pair(qkv.ctypes.data, a.ctypes.data, b.ctypes.data, n, heads, D) == 0
+    assert np.array_equal(a.view(np.uint16), b.view(np.uint16))
+    x = qkv.astype(np.float64).reshape(n, T, 3, heads, 64)
+    q, k, v = x[:, :, 0], x[:, :, 1], x[:, :, 2]                           # [n][T][heads][64]
+    s = np.einsum("nqhd,nkhd->nhqk", q, k) * 0.125
+    p = np.exp(s - s.max(-1, keepdims=True))
+    p /= p.sum(-1, keepdims=True)
+    want = np.einsum("nhqk,nkhd->nqhd", p, v).reshape(n * T, D)
+    err = np.abs(b.astype(np.float64) - want).max()
+    print(f"attention (T = {T}) emulated: max|diff vs float64| = {err:.2e}")
+    assert err < 4e-3
