@@ -16,6 +16,7 @@
 #   trace      rocprofv3 --kernel-trace --stats of `bench.py --no-cpu-baseline --no-side-configs --no-m1` -> kernel_stats.txt
 #   traffic    FETCH_SIZE and WRITE_SIZE, separate --pmc passes, on tools/reid_microbench.py 4096 crops (mode $REID_MODE)  -> pmc_traffic.txt
 #   mfma       SQ_VALU_MFMA_BUSY_CYCLES pass on the same microbenchmark      -> mfma_busy.txt
+#   sq         wave-time counters (SQ_WAVE_CYCLES / WAIT / ACTIVE / INSTS, four --pmc passes) on the same microbenchmark -> hp_sq_counters.txt
 #   c3 / c5    tools/config_bench.py for configurations 3 / 5                 -> config_bench.jsonl
 #   soak       tools/parity_soak.py (all trackers, short)                     -> soak.log
 #   groups     tools/config_bench.py for configurations 3 and 5 with 1 and 2 stream groups (no id gate)     -> config_groups.jsonl
@@ -56,6 +57,19 @@ for step in "$@"; do
     mfma)    (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $O/mfma -o p -- python $R/tools/reid_microbench.py 4096 $MODE 2 > $O/mfma.log 2>&1)
              stamp > $O/mfma_busy_m$MODE.txt
              python profiles/summarize_mfma.py $(db mfma) >> $O/mfma_busy_m$MODE.txt 2>&1; rm -rf $O/mfma; cat $O/mfma_busy_m$MODE.txt ;;
+    sq)      # what a wave does with its time: four --pmc passes (no trace) on the ReID microbenchmark -> hp_sq_counters.txt
+             stamp > $O/hp_sq_counters_m$MODE.txt
+             i=0
+             for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS" \
+                        "SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_MFMA SQ_INSTS_SALU" \
+                        "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA" \
+                        "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE"; do
+               i=$((i+1))
+               (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --pmc $set -d $O/sq$i -o p -- python $R/tools/reid_microbench.py 4096 $MODE 2 > $O/sq$i.log 2>&1)
+               echo "## pass $i: $set" >> $O/hp_sq_counters_m$MODE.txt
+               python profiles/summarize_sq.py $(db sq$i) >> $O/hp_sq_counters_m$MODE.txt 2>&1; rm -rf $O/sq$i
+             done
+             grep -c SQ_ $O/hp_sq_counters_m$MODE.txt ;;
     c3)      timeout 600 python tools/config_bench.py --config c3 --reid-mode ${C3_MODE:-2} >> $O/config_bench.jsonl 2> $O/c3.err; tail -n 1 $O/config_bench.jsonl | cut -c1-900 ;;
     c5)      timeout 900 python tools/config_bench.py --config c5 >> $O/config_bench.jsonl 2> $O/c5.err; tail -n 1 $O/config_bench.jsonl | cut -c1-900 ;;
     soak)    timeout 900 python tools/parity_soak.py 10 200 > $O/soak.log 2>&1; tail -n 12 $O/soak.log ;;
