@@ -40,9 +40,25 @@ def _pick_root() -> Path:
     have_src = (SOURCE_ROOT / "boxmot" / "trackers" / "bbox" / "botsort" / "botsort.py").exists()
     if have_src and os.environ.get("BOXMOT_ORACLE_REF", "") != "compiled":
         return SOURCE_ROOT
-    if (COMPILED_ROOT / "MANIFEST.json").exists():
+    if _compiled_usable():
         return COMPILED_ROOT
     return SOURCE_ROOT
+
+
+def _compiled_usable() -> bool:
+    """oracle/_ref/ exists AND was byte-compiled for THIS interpreter: a .pyc carries the bytecode magic of the Python that wrote it,
+    and a different minor version refuses every import with "bad magic number" -- then the copy is as good as absent and the callers
+    fall back to the port (bench.py: cpu_baseline.kind = "port")."""
+    import importlib.util
+    import json
+
+    man = COMPILED_ROOT / "MANIFEST.json"
+    if not man.exists():
+        return False
+    try:
+        return json.loads(man.read_text()).get("magic") == importlib.util.MAGIC_NUMBER.hex()
+    except (OSError, ValueError):
+        return False
 
 
 REFERENCE_ROOT = _pick_root()
@@ -52,7 +68,7 @@ def reference_kind():
     """"source" (/root/reference mounted), "compiled" (oracle/_ref/) or None."""
     if REFERENCE_ROOT == SOURCE_ROOT:
         return "source" if (SOURCE_ROOT / "boxmot" / "trackers" / "bbox" / "botsort" / "botsort.py").exists() else None
-    return "compiled"
+    return "compiled" if _compiled_usable() else None
 
 
 def reference_available() -> bool:

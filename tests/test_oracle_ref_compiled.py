@@ -65,3 +65,21 @@ print("OK")
     env = dict(os.environ, BOXMOT_ORACLE_REF="compiled")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stderr[-2000:]
+
+
+def test_a_compiled_copy_of_another_interpreter_counts_as_absent(tmp_path, monkeypatch):
+    """oracle/_ref/ byte-compiled by a different Python minor version cannot be imported ("bad magic number"): the harness must say
+    "not runnable" so that bench.py falls back to the port instead of recording errors (the MANIFEST's magic is compared)."""
+    import importlib.util
+    import json
+
+    from oracle import ref_harness
+
+    monkeypatch.setattr(ref_harness, "COMPILED_ROOT", tmp_path)
+    assert ref_harness._compiled_usable() is False                       # no manifest
+    (tmp_path / "MANIFEST.json").write_text(json.dumps({"python": "3.99.0", "magic": "deadbeef"}))
+    assert ref_harness._compiled_usable() is False
+    (tmp_path / "MANIFEST.json").write_text(json.dumps({"python": "this", "magic": importlib.util.MAGIC_NUMBER.hex()}))
+    assert ref_harness._compiled_usable() is True
+    (tmp_path / "MANIFEST.json").write_text("not json")
+    assert ref_harness._compiled_usable() is False
