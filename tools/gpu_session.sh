@@ -17,6 +17,8 @@
 #   traffic    FETCH_SIZE and WRITE_SIZE, separate --pmc passes, on tools/reid_microbench.py 4096 crops (mode $REID_MODE)  -> pmc_traffic.txt
 #   mfma       SQ_VALU_MFMA_BUSY_CYCLES pass on the same microbenchmark      -> mfma_busy.txt
 #   sq         wave-time counters (SQ_WAVE_CYCLES / WAIT / ACTIVE / INSTS, four --pmc passes) on the same microbenchmark -> hp_sq_counters.txt
+#   c3trace    kernel trace + FETCH_SIZE / WRITE_SIZE passes of tools/_build/wide_hp_prof 1024 (configuration 3's ReID pass) -> c3_kernel_stats.txt, c3_pmc_traffic.txt
+#   c5trace    kernel trace of tools/clip_bench.py --crops 512 (configuration 5's ReID pass) -> clip_kernel_stats.txt
 #   c3 / c5    tools/config_bench.py for configurations 3 / 5                 -> config_bench.jsonl
 #   soak       tools/parity_soak.py (all trackers, short)                     -> soak.log
 #   groups     tools/config_bench.py for configurations 3 and 5 with 1 and 2 stream groups (no id gate)     -> config_groups.jsonl
@@ -70,6 +72,19 @@ for step in "$@"; do
                python profiles/summarize_sq.py $(db sq$i) >> $O/hp_sq_counters_m$MODE.txt 2>&1; rm -rf $O/sq$i
              done
              grep -c SQ_ $O/hp_sq_counters_m$MODE.txt ;;
+    c3trace) # configuration 3's ReID pass (fp32-grade osnet_x1_0 family): per-kernel table + HBM traffic, on tools/_build/wide_hp_prof (built from this tree)
+             (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/c3kt -o p -- $R/tools/_build/wide_hp_prof 1024 4 > $O/c3_wide_hp_prof.txt 2>&1)
+             stamp > $O/c3_kernel_stats.txt; grep -E "forward|checksum" $O/c3_wide_hp_prof.txt | sed 's/^/# /' >> $O/c3_kernel_stats.txt
+             python profiles/summarize_rocpd.py $(db c3kt) >> $O/c3_kernel_stats.txt 2>&1; rm -rf $O/c3kt
+             (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE -d $O/c3f -o p -- $R/tools/_build/wide_hp_prof 1024 2 > $O/c3f.log 2>&1
+              timeout 300 rocprofv3 --pmc WRITE_SIZE -d $O/c3w -o p -- $R/tools/_build/wide_hp_prof 1024 2 > $O/c3w.log 2>&1)
+             stamp > $O/c3_pmc_traffic.txt
+             python profiles/summarize_pmc.py $(db c3f) $(db c3w) 1024 >> $O/c3_pmc_traffic.txt 2>&1; rm -rf $O/c3f $O/c3w
+             head -n 12 $O/c3_kernel_stats.txt | cut -c1-150; tail -n 3 $O/c3_pmc_traffic.txt ;;
+    c5trace) # configuration 5's ReID pass (CLIP-ReID ViT-B/16, 512 crops): per-kernel table
+             (cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $O/c5kt -o p -- python $R/tools/clip_bench.py --crops 512 --iters 8 > $O/clip_bench.txt 2>&1)
+             stamp > $O/clip_kernel_stats.txt; tail -n 1 $O/clip_bench.txt | sed 's/^/# /' >> $O/clip_kernel_stats.txt
+             python profiles/summarize_rocpd.py $(db c5kt) >> $O/clip_kernel_stats.txt 2>&1; rm -rf $O/c5kt; head -n 10 $O/clip_kernel_stats.txt | cut -c1-150 ;;
     c3)      timeout 600 python tools/config_bench.py --config c3 --reid-mode ${C3_MODE:-2} >> $O/config_bench.jsonl 2> $O/c3.err; tail -n 1 $O/config_bench.jsonl | cut -c1-900 ;;
     c5)      timeout 900 python tools/config_bench.py --config c5 >> $O/config_bench.jsonl 2> $O/c5.err; tail -n 1 $O/config_bench.jsonl | cut -c1-900 ;;
     soak)    timeout 900 python tools/parity_soak.py 10 200 > $O/soak.log 2>&1; tail -n 12 $O/soak.log ;;
