@@ -381,14 +381,16 @@ inline emu_f4 emu_mfma_f32_k4(float a, float b, emu_f4 c) {
 #define BM_WAVE_LDS_SYNC() g_emu_block->wave_barrier[threadIdx.x / EMU_WAVE].wait()
 // ds_read_b64_tr_b16: the 16 lanes of a lane group name the sixteen 8-byte chunks (4 halves) of a [4 rows][16 columns] block in chunk order
 // (lane i: row i / 4, columns 4 (i % 4) ..); lane c of the group receives column c: the halves (row 0..3, column c)
-typedef _Float16 emu_h4_tr __attribute__((ext_vector_type(4)));
-inline emu_h4_tr emu_ds_read_tr16_b64(const _Float16* p) {
+// (a template over the half type: harnesses built with a compiler that has no _Float16 include this header too and never instantiate it)
+template <class H>
+inline auto emu_ds_read_tr16_b64(const H* p) {
+    typedef H h4_tr __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x % EMU_WAVE, wave = threadIdx.x / EMU_WAVE, g = lane >> 4, c = lane & 15;
     g_emu_block->xbuf[wave][lane] = (uint64_t)reinterpret_cast<uintptr_t>(p);
     g_emu_block->wave_barrier[wave].wait();
-    emu_h4_tr out;
+    h4_tr out;
     for (int j = 0; j < 4; ++j) {
-        const _Float16* src = reinterpret_cast<const _Float16*>((uintptr_t)g_emu_block->xbuf[wave][16 * g + 4 * j + (c >> 2)]);
+        const H* src = reinterpret_cast<const H*>((uintptr_t)g_emu_block->xbuf[wave][16 * g + 4 * j + (c >> 2)]);
         out[j] = src[c & 3];
     }
     g_emu_block->wave_barrier[wave].wait();
