@@ -247,9 +247,9 @@ __global__ void __launch_bounds__(256) k_clip_attention(const _Float16* __restri
 
 // ---------------------------------------------------------------------------
 // The same attention for a COMPILE-TIME token count (ViT-B/16 on 256 x 128 crops: T = 129), three wavefronts per (crop, head):
-//   * the 9 query tiles are dealt 3 per wave and a wave runs ITS THREE TILES TOGETHER: every K fragment and every V^T fragment read from
-//     LDS feeds three MFMAs (a third of the fragment reads of a tile-by-tile loop, three independent accumulator chains on the matrix pipe);
-//     k_clip_attention's four waves take 3 / 2 / 2 / 2 tiles one after the other;
+//   * the 9 query tiles are dealt 3 per wave (k_clip_attention's four waves take 3 / 2 / 2 / 2); a wave runs them QB at a time -- one by
+//     one by default: 112 registers, so three workgroups (nine waves) share a CU and one workgroup's load phase runs under the others'
+//     arithmetic; QB = 3 (every K / V^T fragment read feeds three MFMAs) needs 240 registers and measured 16 % slower;
 //   * Q never touches LDS: a lane's B fragments are two 16-byte global loads per tile;
 //   * V stays ROW-MAJOR in LDS ([key][64] halves, rows 160 bytes apart) and the V^T fragments come from ds_read_b64_tr_b16 (BM_DS_READ_TR16_B64:
 //     the 16 lanes of a lane group name the sixteen 8-byte chunks of a [4 keys][16 features] block, lane c receives column c = feature c
@@ -264,14 +264,18 @@ typedef short cs4 __attribute__((ext_vector_type(4)));
 #define BM_DS_READ_TR16_B64(lds_ptr) \
     __builtin_bit_cast(ch4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) cs4*)(lds_ptr)))
 #endif
+#ifndef BM_CLIP_ATTN_QB
+#define BM_CLIP_ATTN_QB 1          // query tiles a wave runs together: 1 = three passes at 112 registers, three workgroups per CU (0.112 ms per layer at 512 crops);
+                                   // 3 = every K / V fragment read feeds three MFMAs but 240 registers, two workgroups per CU (0.134 ms) -- profiles/r6_clip_ab.txt
+#endif
 constexpr int ATT_VLD = 80;             // halves per V row in LDS: 8 consecutive keys land on disjoint 8-bank windows (40 dwords apart)
 template <int T>
 __host__ __device__ constexpr int clip_attn_t_lds_bytes() { return (((T + 15) / 16 * 16) * ATT_LD + ((T + 31) / 32 * 32) * ATT_VLD) * 2; }
 
-template <int T>
+template <int T, int QB = BM_CLIP_ATTN_QB>
 __global__ void __launch_bounds__(192) k_clip_attention_t(const _Float16* __restrict__ qkv, _Float16* __restrict__ out, int D, int heads) {
     constexpr int TP = (T + 15) / 16 * 16, NKT = TP / 16, KP = (T + 31) / 32 * 32, NKS = KP / 32, NQ = NKT / 3;
-    static_assert(NKT % 3 == 0 && T <= ATT_MAX_T, "three waves share the query tiles evenly");
+    static_assert(NKT % 3 == 0 && T <= ATT_MAX_T && NQ % QB == 0, "three waves share the query tiles evenly, QB of them per pass");
     BM_DYNAMIC_LDS_T(unsigned char, lds);
     _Float16* sK = reinterpret_cast<_Float16*>(lds);
     _Float16* sV = sK + TP * ATT_LD;
@@ -301,24 +305,26 @@ __global__ void __launch_bounds__(192) k_clip_attention_t(const _Float16* __rest
         *reinterpret_cast<ch8*>(sV + t * ATT_VLD + c) = v;
     }
     __syncthreads();
+#pragma unroll
+    for (int a0 = 0; a0 < NQ; a0 += QB) {
     // S^T = K . Q^T for the wave's three query tiles
-    cf4 sc[NQ][NKT];
+    cf4 sc[QB][NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
         ch8 ak[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) ak[s] = *reinterpret_cast<const ch8*>(sK + (16 * kt + l16) * ATT_LD + 32 * s + 8 * g);
 #pragma unroll
-        for (int a = 0; a < NQ; ++a) {
+        for (int a = 0; a < QB; ++a) {
             cf4 acc = cf4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < 2; ++s) acc = BM_MFMA_F16_K32(ak[s], bq[a][s], acc);
+            for (int s = 0; s < 2; ++s) acc = BM_MFMA_F16_K32(ak[s], bq[a0 + a][s], acc);
             sc[a][kt] = acc;
         }
     }
-    float inv[NQ];
+    float inv[QB];
 #pragma unroll
-    for (int a = 0; a < NQ; ++a) {
+    for (int a = 0; a < QB; ++a) {
         float mx = -3.0e38f;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
@@ -345,18 +351,18 @@ __global__ void __launch_bounds__(192) k_clip_attention_t(const _Float16* __rest
         inv[a] = 1.0f / sum;
     }
     // O^T = V^T . P^T: k-slot (g, j) of step ks is key 32 ks + 4 g + j (j < 4) / 32 ks + 16 + 4 g + j - 4 (j >= 4), as in k_clip_attention
-    cf4 o[NQ][4];
+    cf4 o[QB][4];
 #pragma unroll
-    for (int a = 0; a < NQ; ++a)
+    for (int a = 0; a < QB; ++a)
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[a][dt] = cf4{0.f, 0.f, 0.f, 0.f};
     // the lane's chunk of a [4 keys][16 features] block: key l16 / 4, features 4 (l16 % 4) ..
     const _Float16* vchunk = sV + (4 * g + (l16 >> 2)) * ATT_VLD + 4 * (l16 & 3);
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
-        ch8 pb[NQ];
+        ch8 pb[QB];
 #pragma unroll
-        for (int a = 0; a < NQ; ++a)
+        for (int a = 0; a < QB; ++a)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 pb[a][j] = (_Float16)sc[a][2 * ks][j];
@@ -368,12 +374,12 @@ __global__ void __launch_bounds__(192) k_clip_attention_t(const _Float16* __rest
             const ch4 hi = BM_DS_READ_TR16_B64(vchunk + (32 * ks + 16) * ATT_VLD + 16 * dt);
             const ch8 av = ch8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
-            for (int a = 0; a < NQ; ++a) o[a][dt] = BM_MFMA_F16_K32(av, pb[a], o[a][dt]);
+            for (int a = 0; a < QB; ++a) o[a][dt] = BM_MFMA_F16_K32(av, pb[a], o[a][dt]);
         }
     }
 #pragma unroll
-    for (int a = 0; a < NQ; ++a) {
-        const int q = 16 * (wave + 3 * a) + l16;
+    for (int a = 0; a < QB; ++a) {
+        const int q = 16 * (wave + 3 * (a0 + a)) + l16;
         if (q < T) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
@@ -383,6 +389,7 @@ __global__ void __launch_bounds__(192) k_clip_attention_t(const _Float16* __rest
                 *reinterpret_cast<ch4*>(out + (crop * T + q) * D + head * ATT_DH + 16 * dt + 4 * g) = w;
             }
         }
+    }
     }
 }
 

@@ -385,6 +385,9 @@ __global__ void __launch_bounds__(256) k_gemm_f16_glds(const _Float16* __restric
 constexpr int GEMM256_EPI_LD = 136;                        // halves per row of a wave's epilogue region (128 + 8 of padding)
 constexpr int GEMM256_LDS_BYTES = 8 * 64 * GEMM256_EPI_LD * 2;       // 136 KB: the epilogue regions; the k-loop uses 2 x 4 half tiles = 128 KB of it
 
+#ifndef BM_GEMM_EPI2_DEEP
+#define BM_GEMM_EPI2_DEEP 1
+#endif
 #ifndef BM_GEMM_PHASE_SYNC
 #define BM_GEMM_PHASE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define BM_GEMM_BARRIER() asm volatile("s_barrier" ::: "memory")
@@ -560,11 +563,25 @@ __global__ void __launch_bounds__(512) k_gemm_f16_256(const _Float16* __restrict
     }
     if constexpr (EPI == 2) {
         // fp32 C += result, the same way in two halves of 64 features: 4 rows x 256 contiguous bytes per load / store instruction
-        // instead of 16-byte pieces of 16 rows (the residual stream is read and rewritten once per projection: 2 x 101 MB at 256 crops)
+        // instead of 16-byte pieces of 16 rows (the residual stream is read and rewritten once per projection: 2 x 101 MB at 256 crops).
+        // BM_GEMM_EPI2_DEEP: the sixteen loads of a half's old values are all requested BEFORE the half's accumulators go through LDS
+        // (the fragment registers are dead: 64 more fit), so a half waits for HBM once instead of twice and the wait runs under the
+        // transposition; 0: two batches of eight, each requested and waited for at its use.
         float* reg = reinterpret_cast<float*>(lds_raw) + wave * (64 * 68);
         float* c = static_cast<float*>(Cout);
+        constexpr int NB = BM_GEMM_EPI2_DEEP ? 16 : 8;          // loads in flight
 #pragma unroll
         for (int hp = 0; hp < 2; ++hp) {
+            cf4 old[NB];
+            auto request = [&](int i0) {
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    long m = m0 + wc * 64 + (i0 + i) * 4 + g;
+                    if (m >= M) m = M - 1;
+                    old[i] = *reinterpret_cast<const cf4*>(c + m * N + n0 + wr * 128 + hp * 64 + l16 * 4);
+                }
+            };
+            if constexpr (BM_GEMM_EPI2_DEEP) request(0);
 #pragma unroll
             for (int pp = 0; pp < 4; ++pp) {
                 const int p = hp * 4 + pp, n = n0 + wr * 128 + p * 16 + 4 * g;
@@ -583,16 +600,10 @@ __global__ void __launch_bounds__(512) k_gemm_f16_256(const _Float16* __restrict
             }
             BM_WAVE_LDS_SYNC();
 #pragma unroll
-            for (int i0 = 0; i0 < 16; i0 += 8) {
-                cf4 old[8];
+            for (int i0 = 0; i0 < 16; i0 += NB) {
+                if constexpr (!BM_GEMM_EPI2_DEEP) request(i0);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    long m = m0 + wc * 64 + (i0 + i) * 4 + g;
-                    if (m >= M) m = M - 1;
-                    old[i] = *reinterpret_cast<const cf4*>(c + m * N + n0 + wr * 128 + hp * 64 + l16 * 4);
-                }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
+                for (int i = 0; i < NB; ++i) {
                     const int row = (i0 + i) * 4 + g;
                     const long m = m0 + wc * 64 + row;
                     const cf4 v = *reinterpret_cast<const cf4*>(reg + row * 68 + l16 * 4);
