@@ -317,11 +317,7 @@ def m1_tracker_only(kw, dev, rank, streams=256):
 
     def run(S1):
         ms = MultiStreamBotSort(S1, max_tracks=2 * N_TRACKS, max_dets=nd, emb_dim=EMB_DIM, **kw)
-        if S1 <= S_all:
-            d_dets, d_cnt, d_embs = (torch.from_numpy(np.ascontiguousarray(x[:, :S1])).to(dev) for x in (dets_h, cnt_h, embs_h))
-        else:       # more streams than scenarios were generated: stream s runs scenario s % S_all (independent trackers, repeated inputs)
-            rep = S1 // S_all
-            d_dets, d_cnt, d_embs = (torch.from_numpy(x).to(dev).repeat(*([1, rep] + [1] * (x.ndim - 2))).contiguous() for x in (dets_h, cnt_h, embs_h))
+        d_dets, d_cnt, d_embs = (torch.from_numpy(np.ascontiguousarray(x[:, :S1])).to(dev) for x in (dets_h, cnt_h, embs_h))
         d_out = torch.zeros((S1, nd, 8), dtype=torch.float32, device=dev)
         d_out_n = torch.zeros(S1, dtype=torch.int32, device=dev)
         torch.cuda.synchronize()
@@ -342,14 +338,10 @@ def m1_tracker_only(kw, dev, rank, streams=256):
     out = {"mode": "M1 embs-supplied (tracker math only)", "frames_per_s": fps, "streams": S_all, "steps": K1, "ms_per_step": ms_full,
            "kernel": "botsort_step_kernel", "algorithmic_bytes_per_frame": 1.68e6, "hbm_GBps": gbs, "hbm_frac_of_8TBps": gbs / 8000.0,
            "at_32_streams": {"frames_per_s": 32 / (ms_32 * 1e-3), "ms_per_step": ms_32,
-                             "note": "32 of 256 CUs busy: the latency of one workgroup's phase chain, not a throughput"}}
-    if S_all == 256:        # one workgroup per stream: 256 streams are ONE workgroup per CU; with four per CU queued the phase chains of different streams overlap
-        try:
-            ms_1k = run(1024)
-            out["at_1024_streams"] = {"frames_per_s": 1024 / (ms_1k * 1e-3), "ms_per_step": ms_1k, "hbm_frac_of_8TBps": 1024 / (ms_1k * 1e-3) * 1.68e6 / 8e12,
-                                      "note": "four workgroups per CU (streams 256 .. 1023 repeat the inputs of streams 0 .. 255): the device's tracker-math throughput"}
-        except Exception as exc:
-            out["at_1024_streams"] = {"error": f"{type(exc).__name__}: {exc}"}
+                             "note": "32 of 256 CUs busy: the latency of one workgroup's phase chain, not a throughput"},
+           # (measured in round 6: 1024 streams take 4 x the 256-stream step, 665 k frames/s -- at 256 registers per lane one 512-thread
+           # workgroup fills a CU, so more streams queue behind each other instead of overlapping)
+           }
     return out
 
 
